@@ -1,0 +1,686 @@
+/*
+ * flacenc_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.  See flacenc_oracle.h.
+ *
+ * CPU restatement (plain C99) of flacenc-rs v0.5.1's quantised-LPC analysis
+ * path.  Every function cites the reference file:line it follows.  Floating
+ * point follows the reference operation-for-operation (explicit fma() where
+ * the reference calls mul_add; build with -ffp-contract=off so nothing else
+ * is fused; glibc cosf/log2/round are the libm Rust-on-Linux calls too).
+ *
+ * Parity pin: reference KATs only (tests/test_oracle_kat.py); the Rust
+ * reference cannot be built in this image (no rustc/cargo) -> coefficient-level
+ * parity on arbitrary audio is "parity unpinned".
+ */
+#define _GNU_SOURCE
+#include "flacenc_oracle.h"
+
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+/* ------------------------------------------------------------------------ */
+/* src/lpc.rs                                                               */
+/* ------------------------------------------------------------------------ */
+
+/* window_weights, src/lpc.rs:96-120.  All arithmetic in f32, expression order
+ * exactly as written there; `Tukey{alpha: 0.0}` short-circuits to all-ones. */
+void orc_window_weights(uint32_t window_type, float alpha, size_t len, float* out) {
+  if (window_type == ORC_WINDOW_RECTANGLE || alpha == 0.0f) {
+    for (size_t t = 0; t < len; ++t) out[t] = 1.0f;
+    return;
+  }
+  const float pi = 3.14159265358979323846f; /* std::f32::consts::PI */
+  float max_t = (float)len - 1.0f;
+  float alpha_len = alpha * max_t;
+  for (size_t ti = 0; ti < len; ++ti) {
+    float t = (float)ti;
+    float w;
+    if (t < alpha_len / 2.0f) {
+      float arg = 2.0f * pi * t / alpha_len;
+      w = 0.5f * (1.0f - cosf(arg));
+    } else if (t < max_t - alpha_len / 2.0f) {
+      w = 1.0f;
+    } else {
+      float arg = 2.0f * pi * (max_t - t) / alpha_len;
+      w = 0.5f * (1.0f - cosf(arg));
+    }
+    out[ti] = w;
+  }
+}
+
+/* LpcEstimator::fill_windowed_signal, src/lpc.rs:739-756: i32 -> f32 cast
+ * (round-to-nearest-even), one f32 multiply. */
+void orc_fill_windowed_signal(const int32_t* signal, const float* window, size_t n, float* out) {
+  for (size_t t = 0; t < n; ++t) out[t] = (float)signal[t] * window[t];
+}
+
+/* weighted_auto_correlation (src/lpc.rs:551-564) -> _nosimd (src/lpc.rs:533-548)
+ * with NoWeight, T = f64: for t in (order-1)..n, for tau < order:
+ * dest[tau] = mul_add(signal[t - tau] as f64, signal[t] as f64, dest[tau]). */
+void orc_auto_correlation_f64(size_t order, const float* signal, size_t n, double* dest) {
+  for (size_t tau = 0; tau < order; ++tau) dest[tau] = 0.0;
+  if (order == 0) return;
+  for (size_t t = order - 1; t < n; ++t) {
+    double wy = (double)signal[t];
+    for (size_t tau = 0; tau < order; ++tau) {
+      dest[tau] = fma((double)signal[t - tau], wy, dest[tau]);
+    }
+  }
+}
+
+/* same with T = f32 (used by the reference's tests, src/lpc.rs:998-1022) */
+void orc_auto_correlation_f32(size_t order, const float* signal, size_t n, float* dest) {
+  for (size_t tau = 0; tau < order; ++tau) dest[tau] = 0.0f;
+  if (order == 0) return;
+  for (size_t t = order - 1; t < n; ++t) {
+    float wy = signal[t];
+    for (size_t tau = 0; tau < order; ++tau) {
+      dest[tau] = fmaf(signal[t - tau], wy, dest[tau]);
+    }
+  }
+}
+
+/* The build's canonical summation order (NOT a reference function): the same
+ * sum as src/lpc.rs:533-548 (common lower bound t = order-1 for every lag),
+ * re-associated so that a GPU can evaluate it in parallel and a CPU can
+ * reproduce it bit-for-bit:
+ *   1. samples are cut into 16-sample chunks [16c, 16c+16);
+ *   2. each chunk's partial sum is a sequential fma chain in t order starting
+ *      from +0.0 (only t with order-1 <= t < n contribute);
+ *   3. chunk partials are combined by a perfectly balanced pairwise tree over
+ *      the chunk index, zero-padded to a power of two.
+ * Every f32*f32 product is exact in f64, so only the additions round. */
+static double orc_tree_sum(const double* v, size_t lo, size_t hi, size_t count) {
+  if (hi - lo == 1) return lo < count ? v[lo] : 0.0;
+  size_t mid = lo + (hi - lo) / 2;
+  return orc_tree_sum(v, lo, mid, count) + orc_tree_sum(v, mid, hi, count);
+}
+
+void orc_auto_correlation_canonical_f64(size_t order, const float* signal, size_t n,
+                                        double* dest) {
+  for (size_t tau = 0; tau < order; ++tau) dest[tau] = 0.0;
+  if (order == 0 || n == 0) return;
+  size_t nchunks = (n + 15) / 16;
+  size_t pow2 = 1;
+  while (pow2 < nchunks) pow2 <<= 1;
+  double* partial = (double*)malloc(sizeof(double) * nchunks);
+  for (size_t tau = 0; tau < order; ++tau) {
+    for (size_t c = 0; c < nchunks; ++c) {
+      double acc = 0.0;
+      for (size_t t = 16 * c; t < 16 * c + 16 && t < n; ++t) {
+        if (t + 1 < order) continue; /* t < order - 1 */
+        acc = fma((double)signal[t - tau], (double)signal[t], acc);
+      }
+      partial[c] = acc;
+    }
+    dest[tau] = orc_tree_sum(partial, 0, pow2, nchunks);
+  }
+  free(partial);
+}
+
+/* symmetric_levinson_recursion, src/lpc.rs:633-705.
+ * NOTE on `continue` (src/lpc.rs:679-682): it sits inside `for n in 1..order`
+ * nested in `loop { .. break; }`; an unlabeled `continue` continues the
+ * innermost loop, i.e. the `for`.  So a zero denominator updates
+ * `diagonal_loading` (never read again, forward[0]/dest[0] were computed
+ * before the `for`) and SKIPS the rest of iteration n -- it does not restart.
+ * This restatement follows the code as compiled, not the comment. */
+#define ORC_DEFINE_LEVINSON(NAME, T, FMA, ONE, ZERO)                                \
+  int NAME(const T* coefs, const T* ys, size_t order, T* dest) {                    \
+    T forward[ORC_MAX_LPC_ORDER + 1];                                               \
+    T forward_next[ORC_MAX_LPC_ORDER + 1];                                          \
+    for (size_t i = 0; i < order; ++i) dest[i] = ZERO;                              \
+    if (order == 0) return ORC_STATUS_OK;                                           \
+    if (!(coefs[0] >= ZERO)) return ORC_STATUS_NEG_ENERGY; /* assert, :646 */       \
+    if (coefs[0] == ZERO) {                                                         \
+      int allzero = 1;                                                              \
+      for (size_t i = 0; i < order; ++i) allzero &= (ys[i] == ZERO) & (coefs[i] == ZERO); \
+      return allzero ? ORC_STATUS_OK : ORC_STATUS_NEG_ENERGY; /* assert, :652 */    \
+    }                                                                               \
+    for (size_t i = 0; i <= ORC_MAX_LPC_ORDER; ++i) forward[i] = forward_next[i] = ZERO; \
+    T diagonal_loading = ZERO;                                                      \
+    forward[0] = ONE / (coefs[0] + diagonal_loading); /* Float::recip */            \
+    dest[0] = ys[0] / (coefs[0] + diagonal_loading);                                \
+    for (size_t n = 1; n < order; ++n) {                                            \
+      T error = ZERO;                                                               \
+      for (size_t d = 0; d < n; ++d) error = FMA(coefs[n - d], forward[d], error);  \
+      T denom = FMA(error, -error, ONE);                                            \
+      if (denom == ZERO) {                                                          \
+        T dd = diagonal_loading + diagonal_loading;                                 \
+        diagonal_loading = (ONE > dd) ? ONE : dd;                                   \
+        continue;                                                                   \
+      }                                                                             \
+      T alpha = ONE / denom;                                                        \
+      T beta = -alpha * error;                                                      \
+      for (size_t d = 0; d <= n; ++d) {                                             \
+        T bf = beta * forward[n - d];                                               \
+        forward_next[d] = FMA(alpha, forward[d], bf);                               \
+      }                                                                             \
+      for (size_t d = 0; d <= n; ++d) forward[d] = forward_next[d];                 \
+      T delta = ZERO;                                                               \
+      for (size_t d = 0; d < n; ++d) delta = FMA(coefs[n - d], dest[d], delta);     \
+      T resid = ys[n] - delta;                                                      \
+      for (size_t d = 0; d <= n; ++d) dest[d] = FMA(resid, forward[n - d], dest[d]);\
+    }                                                                               \
+    (void)diagonal_loading;                                                         \
+    return ORC_STATUS_OK;                                                           \
+  }
+
+ORC_DEFINE_LEVINSON(orc_symmetric_levinson_f64, double, fma, 1.0, 0.0)
+ORC_DEFINE_LEVINSON(orc_symmetric_levinson_f32, float, fmaf, 1.0f, 0.0f)
+
+/* find_shift, src/lpc.rs:234-254 */
+int32_t orc_find_shift(const double* coefs, size_t n, uint32_t precision) {
+  double max_abs = fabs(coefs[0]);
+  for (size_t i = 1; i < n; ++i) max_abs = fmax(max_abs, fabs(coefs[i])); /* f64::max */
+  double l = fmax(ceil(log2(max_abs)), (double)(INT16_MIN + 16));
+  /* `.as_()` float -> i16 is a saturating cast, NaN -> 0 */
+  int32_t abs_log2;
+  if (l != l) abs_log2 = 0;
+  else if (l >= 32767.0) abs_log2 = 32767;
+  else if (l <= -32768.0) abs_log2 = -32768;
+  else abs_log2 = (int32_t)l;
+  int32_t shift = ((int32_t)precision - 1) - abs_log2;
+  if (shift < ORC_QLPC_MIN_SHIFT) shift = ORC_QLPC_MIN_SHIFT;
+  if (shift > ORC_QLPC_MAX_SHIFT) shift = ORC_QLPC_MAX_SHIFT;
+  return shift;
+}
+
+/* quantize_parameter, src/lpc.rs:258-270 */
+static int16_t orc_quantize_parameter(double p, int32_t shift) {
+  double scalefac = ldexp(1.0, shift); /* powi(2, shift): exact */
+  double scaled_int = round(p * scalefac); /* Float::round: half away from zero */
+  if (scaled_int < -32768.0) scaled_int = -32768.0;
+  if (scaled_int > 32767.0) scaled_int = 32767.0;
+  if (scaled_int != scaled_int) return 0;
+  return (int16_t)scaled_int;
+}
+
+/* quantize_parameters, src/lpc.rs:273-302 */
+void orc_quantize_parameters(const double* coefs, size_t n, uint32_t precision, orc_qparams* out) {
+  memset(out, 0, sizeof(*out));
+  out->precision = precision;
+  if (n == 0) return; /* from_parts(&[], 0, 0, precision) */
+  int32_t shift = orc_find_shift(coefs, n, precision);
+  int32_t lo = -(1 << (precision - 1));
+  int32_t hi = (1 << (precision - 1)) - 1;
+  for (size_t i = 0; i < n; ++i) {
+    int32_t q = orc_quantize_parameter(coefs[i], shift);
+    if (q < lo) q = lo;
+    if (q > hi) q = hi;
+    out->coefs[i] = (int16_t)q;
+  }
+  size_t order = 1;
+  for (size_t i = 0; i < n; ++i)
+    if (out->coefs[i] != 0) order = i + 1; /* tail-zero truncation, min 1 (:295-299) */
+  for (size_t i = order; i < ORC_MAX_LPC_ORDER; ++i) out->coefs[i] = 0;
+  out->order = (uint32_t)order;
+  out->shift = shift;
+}
+
+/* compute_error_impl::<i32, _>, src/lpc.rs:306-350 (wrapping lanes) */
+static void orc_compute_error_i32(const orc_qparams* qp, const int32_t* signal, size_t n,
+                                  int32_t* errors) {
+  uint32_t* acc = (uint32_t*)errors;
+  for (size_t t = 0; t < n; ++t) acc[t] = 0;
+  for (size_t j = 0; j < qp->order; ++j) {
+    uint32_t w = (uint32_t)(int32_t)qp->coefs[j];
+    for (size_t i = 0; i + j + 1 < n; ++i) acc[i + j + 1] += w * (uint32_t)signal[i];
+  }
+  for (size_t t = 0; t < n; ++t) {
+    int32_t px = (int32_t)acc[t];
+    errors[t] = (int32_t)((uint32_t)signal[t] - (uint32_t)(px >> qp->shift));
+  }
+  for (size_t t = 0; t < qp->order && t < n; ++t) errors[t] = 0;
+}
+
+/* compute_error_impl::<i64, _> followed by `as i32`, src/lpc.rs:379-388 */
+static void orc_compute_error_i64(const orc_qparams* qp, const int32_t* signal, size_t n,
+                                  int32_t* errors) {
+  int64_t* acc = (int64_t*)calloc(n ? n : 1, sizeof(int64_t));
+  for (size_t j = 0; j < qp->order; ++j) {
+    int64_t w = qp->coefs[j];
+    for (size_t i = 0; i + j + 1 < n; ++i) acc[i + j + 1] += w * (int64_t)signal[i];
+  }
+  for (size_t t = 0; t < n; ++t) {
+    int64_t e = (int64_t)signal[t] - (acc[t] >> qp->shift);
+    errors[t] = (int32_t)(uint32_t)(uint64_t)e; /* `as i32` truncation */
+  }
+  for (size_t t = 0; t < qp->order && t < n; ++t) errors[t] = 0;
+  free(acc);
+}
+
+/* compute_error, src/lpc.rs:359-390 */
+void orc_compute_error(const orc_qparams* qp, const int32_t* signal, size_t n, int32_t* errors) {
+  uint64_t maxabs_signal = 0;
+  for (size_t t = 0; t < n; ++t) {
+    uint64_t a = signal[t] < 0 ? (uint64_t)(-(int64_t)signal[t]) : (uint64_t)signal[t];
+    if (a > maxabs_signal) maxabs_signal = a;
+  }
+  int64_t sumabs = 0;
+  for (size_t j = 0; j < ORC_MAX_LPC_ORDER; ++j) sumabs += qp->coefs[j] < 0 ? -qp->coefs[j] : qp->coefs[j];
+  uint64_t maxabs = maxabs_signal * (uint64_t)sumabs;
+  if (maxabs < (uint64_t)INT32_MAX) orc_compute_error_i32(qp, signal, n, errors);
+  else orc_compute_error_i64(qp, signal, n, errors);
+}
+
+/* LpcEstimator::weighted_lpc_from_auto_corr with NoWeight, src/lpc.rs:760-801,
+ * reached through lpc_from_autocorr (src/lpc.rs:920-930, LpcEstimator<f64>). */
+int orc_lpc_from_autocorr(const int32_t* signal, size_t n, const orc_qlpc_config* cfg,
+                          double* autocorr_out, double* coefs_out) {
+  size_t lpc_order = cfg->lpc_order;
+  for (size_t i = 0; i < lpc_order; ++i) coefs_out[i] = 0.0;
+  if (lpc_order == 0) return ORC_STATUS_OK;
+  float* window = (float*)malloc(sizeof(float) * (n ? n : 1));
+  float* xw = (float*)malloc(sizeof(float) * (n ? n : 1));
+  orc_window_weights(cfg->window_type, cfg->tukey_alpha, n, window);
+  orc_fill_windowed_signal(signal, window, n, xw);
+  double corr[ORC_MAX_LPC_ORDER + 1];
+  if (cfg->acorr_order == ORC_ACORR_CANONICAL)
+    orc_auto_correlation_canonical_f64(lpc_order + 1, xw, n, corr);
+  else
+    orc_auto_correlation_f64(lpc_order + 1, xw, n, corr);
+  free(window);
+  free(xw);
+  int status = ORC_STATUS_OK;
+  for (size_t i = 0; i <= lpc_order; ++i) {
+    if (autocorr_out) autocorr_out[i] = corr[i];
+    if (isnan(corr[i]) || isinf(corr[i])) status = ORC_STATUS_NONFINITE; /* assert :786-791 */
+  }
+  if (status != ORC_STATUS_OK) return status;
+  status = orc_symmetric_levinson_f64(corr, corr + 1, lpc_order, coefs_out);
+  if (status != ORC_STATUS_OK) return status;
+  for (size_t i = 0; i < lpc_order; ++i)
+    if (isnan(coefs_out[i]) || isinf(coefs_out[i])) return ORC_STATUS_NONFINITE; /* :797-799 */
+  return ORC_STATUS_OK;
+}
+
+/* ------------------------------------------------------------------------ */
+/* src/rice.rs                                                              */
+/* ------------------------------------------------------------------------ */
+
+/* encode_signbit, src/rice.rs:169-171 */
+uint32_t orc_encode_signbit(int32_t v) {
+  uint32_t a = v < 0 ? (uint32_t)0 - (uint32_t)v : (uint32_t)v; /* unsigned_abs */
+  return (a << 1) - (uint32_t)(v < 0);
+}
+
+/* decode_signbit, src/rice.rs:180-187 */
+int32_t orc_decode_signbit(uint32_t v) {
+  if (v & 1u) return -(int32_t)((v >> 1) + 1u);
+  return (int32_t)(v >> 1);
+}
+
+/* PrcBitTable::from_errors, src/rice.rs:65-103: u32 lanes with wrapping adds,
+ * clamp to MAX_P_TO_BITS after every 16-sample chunk and after the offset. */
+void orc_prc_bit_table_from_errors(const uint32_t* errors, size_t len, uint32_t offset,
+                                   uint32_t table[32]) {
+  uint32_t acc[32];
+  for (int p = 0; p < 32; ++p) acc[p] = 0;
+  for (size_t base = 0; base < len; base += 16) {
+    size_t end = base + 16 < len ? base + 16 : len;
+    for (size_t i = base; i < end; ++i) {
+      uint32_t v = errors[i];
+      for (int p = 0; p < 32; ++p) acc[p] += v >> p;
+    }
+    for (int p = 0; p < 32; ++p)
+      if (acc[p] > ORC_MAX_P_TO_BITS) acc[p] = ORC_MAX_P_TO_BITS;
+  }
+  for (int p = 0; p < 32; ++p) {
+    uint32_t off = offset + (uint32_t)len * (uint32_t)(p + 1);
+    uint32_t v = acc[p] + off;
+    table[p] = v > ORC_MAX_P_TO_BITS ? ORC_MAX_P_TO_BITS : v;
+  }
+}
+
+/* PrcBitTable::minimizer, src/rice.rs:115-141: min over (bits << 5) | p */
+void orc_prc_minimizer(const uint32_t table[32], uint32_t max_p, uint32_t* p_out,
+                       uint32_t* bits_out) {
+  uint32_t lo_max = max_p < 15 ? max_p : 15;
+  uint32_t minim = 0xFFFFFFFFu;
+  for (uint32_t p = 0; p < 16; ++p) {
+    uint32_t v = p <= lo_max ? table[p] : 0xFFFFFFFFu;
+    uint32_t packed = (v << 5) | p;
+    if (packed < minim) minim = packed;
+  }
+  if (max_p > 15) {
+    for (uint32_t p = 16; p < 32; ++p) {
+      uint32_t v = p <= max_p ? table[p] : 0xFFFFFFFFu;
+      uint32_t packed = (v << 5) | p;
+      if (packed < minim) minim = packed;
+    }
+  }
+  *bits_out = minim >> 5;
+  *p_out = minim & 0x1Fu;
+}
+
+/* PrcBitTable::merge, src/rice.rs:144-152 */
+void orc_prc_merge(const uint32_t a[32], const uint32_t b[32], uint32_t offset, uint32_t out[32]) {
+  for (int p = 0; p < 32; ++p) {
+    uint32_t v = a[p] + b[p] - offset;
+    out[p] = v > ORC_MAX_P_TO_BITS ? ORC_MAX_P_TO_BITS : v;
+  }
+}
+
+/* finest_partition_order, src/rice.rs:157-165 */
+uint32_t orc_finest_partition_order(size_t size, size_t min_part_size) {
+  uint32_t max_splits = (uint32_t)(size / min_part_size);
+  if (max_splits == 0) return 0; /* unreachable on the path: blocks < 64 never arrive (coding.rs:396) */
+  uint32_t max_order_for_min_part = 31u - (uint32_t)__builtin_clz(max_splits);
+  uint32_t tz = size ? (uint32_t)__builtin_ctzl(size) : 64u;
+  uint32_t m = max_order_for_min_part < tz ? max_order_for_min_part : tz;
+  return m < ORC_MAX_RICE_PARTITION_ORDER ? m : ORC_MAX_RICE_PARTITION_ORDER;
+}
+
+/* PrcParameterFinder::find, src/rice.rs:246-298 (eval_partitions :193-202,
+ * merge_partitions :208-216). */
+void orc_find_partitioned_rice_parameter(const int32_t* signal, size_t n, size_t warmup_length,
+                                         uint32_t max_p, orc_prc_parameter* out) {
+  size_t min_part = warmup_length > ORC_MIN_RICE_PARTITION_SIZE ? warmup_length
+                                                                : ORC_MIN_RICE_PARTITION_SIZE;
+  uint32_t partition_order = orc_finest_partition_order(n, min_part);
+  size_t nparts = (size_t)1 << partition_order;
+  uint32_t* errors = (uint32_t*)malloc(sizeof(uint32_t) * (n ? n : 1));
+  uint32_t(*tables)[32] = (uint32_t(*)[32])malloc(sizeof(uint32_t[32]) * nparts);
+  uint8_t* ps = (uint8_t*)malloc(nparts);
+  uint8_t* min_ps = (uint8_t*)malloc(nparts);
+  for (size_t t = 0; t < n; ++t) errors[t] = orc_encode_signbit(signal[t]);
+  size_t part_size = n / nparts;
+  for (size_t p = 0; p < nparts; ++p) {
+    size_t start = p * part_size > warmup_length ? p * part_size : warmup_length;
+    size_t end = (p + 1) * part_size;
+    orc_prc_bit_table_from_errors(errors + start, end - start, 4, tables[p]);
+  }
+  uint64_t min_bits = 0;
+  for (size_t p = 0; p < nparts; ++p) {
+    uint32_t pp, bits;
+    orc_prc_minimizer(tables[p], max_p, &pp, &bits);
+    min_bits += bits;
+    min_ps[p] = (uint8_t)pp;
+  }
+  uint32_t min_order = partition_order;
+  while (nparts > 1) {
+    size_t merged = nparts / 2;
+    for (size_t q = 0; q < merged; ++q) {
+      uint32_t tmp[32];
+      orc_prc_merge(tables[2 * q], tables[2 * q + 1], 4, tmp);
+      memcpy(tables[q], tmp, sizeof(tmp));
+    }
+    nparts = merged;
+    partition_order -= 1;
+    uint64_t next_bits = 0;
+    for (size_t q = 0; q < nparts; ++q) {
+      uint32_t pp, bits;
+      orc_prc_minimizer(tables[q], max_p, &pp, &bits);
+      next_bits += bits;
+      ps[q] = (uint8_t)pp;
+    }
+    if (next_bits < min_bits) { /* strict: ties keep the finer order (:285) */
+      min_bits = next_bits;
+      memcpy(min_ps, ps, nparts);
+      min_order = partition_order;
+    }
+  }
+  out->order = min_order;
+  out->code_bits = min_bits;
+  memcpy(out->ps, min_ps, (size_t)1 << min_order);
+  free(errors);
+  free(tables);
+  free(ps);
+  free(min_ps);
+}
+
+/* ------------------------------------------------------------------------ */
+/* src/coding.rs, src/component/bitrepr.rs, src/component/decode.rs         */
+/* ------------------------------------------------------------------------ */
+
+/* encode_residual_with_prc_parameter (src/coding.rs:140-170) with
+ * quotients_and_remainders (:58-62); sums as Residual::from_parts
+ * (src/component/datatype.rs:2325-2332). */
+void orc_encode_residual_with_prc_parameter(const int32_t* errors, size_t n, size_t warmup_length,
+                                            const orc_prc_parameter* prc, uint32_t* quotients,
+                                            uint32_t* remainders, uint64_t* sum_quotients,
+                                            uint64_t* sum_rice_params) {
+  size_t nparts = (size_t)1 << prc->order;
+  size_t part_size = n >> prc->order;
+  if (quotients) memset(quotients, 0, sizeof(uint32_t) * n);
+  if (remainders) memset(remainders, 0, sizeof(uint32_t) * n);
+  uint64_t sq = 0, sp = 0;
+  size_t offset = 0;
+  for (size_t q = 0; q < nparts; ++q) {
+    uint32_t rice_p = prc->ps[q];
+    size_t start = offset > warmup_length ? offset : warmup_length;
+    offset += part_size;
+    size_t end = offset;
+    uint32_t mask = (1u << rice_p) - 1u;
+    for (size_t t = start; t < end; ++t) {
+      uint32_t u = orc_encode_signbit(errors[t]);
+      if (quotients) quotients[t] = u >> rice_p;
+      if (remainders) remainders[t] = u & mask;
+      sq += u >> rice_p;
+    }
+    sp += rice_p;
+  }
+  *sum_quotients = sq;
+  *sum_rice_params = sp;
+}
+
+/* BitRepr for Residual::count_bits, src/component/bitrepr.rs:533-544 */
+uint64_t orc_residual_count_bits(size_t block_size, size_t warmup_length, uint32_t partition_order,
+                                 const uint8_t* rice_params, uint64_t sum_quotients,
+                                 uint64_t sum_rice_params) {
+  uint64_t nparts = (uint64_t)1 << partition_order;
+  uint64_t quotient_bits = sum_quotients + block_size - warmup_length;
+  uint64_t remainder_bits = sum_rice_params * (uint64_t)(block_size >> partition_order);
+  remainder_bits -= (uint64_t)warmup_length * rice_params[0];
+  int use_rice2 = 0;
+  for (uint64_t q = 0; q < nparts; ++q) use_rice2 |= rice_params[q] > 14;
+  uint64_t param_bits = use_rice2 ? 5 : 4;
+  return 2 + 4 + nparts * param_bits + quotient_bits + remainder_bits;
+}
+
+/* BitRepr for Lpc::count_bits, src/component/bitrepr.rs:492-499 */
+uint64_t orc_lpc_count_bits(uint32_t bits_per_sample, uint32_t order, uint32_t precision,
+                            uint64_t residual_bits) {
+  uint64_t warm_up_bits = (uint64_t)bits_per_sample * order;
+  return 8 + warm_up_bits + 4 + 5 + (uint64_t)precision * order + residual_bits;
+}
+
+/* Verbatim::count_bits_from_metadata, src/component/datatype.rs:1944-1949 */
+uint64_t orc_verbatim_count_bits(size_t n, uint32_t bits_per_sample) {
+  return 8 + (uint64_t)n * bits_per_sample;
+}
+
+/* Decode for Residual::copy_signal, src/component/decode.rs:226-237 */
+void orc_decode_residual(size_t block_size, uint32_t partition_order, const uint8_t* rice_params,
+                         const uint32_t* quotients, const uint32_t* remainders, int32_t* dest) {
+  size_t part_len = block_size >> partition_order;
+  for (size_t t = 0; t < block_size; ++t)
+    dest[t] = orc_decode_signbit((quotients[t] << rice_params[t / part_len]) + remainders[t]);
+}
+
+/* decode_lpc, src/component/decode.rs:159-177 (i64 prediction, wrapping i32 add) */
+void orc_decode_lpc(const int32_t* warm_up, size_t order, const int16_t* coefs, uint32_t shift,
+                    const int32_t* residual, size_t n, int32_t* dest) {
+  for (size_t t = 0; t < n; ++t) dest[t] = residual[t];
+  for (size_t t = 0; t < order && t < n; ++t) dest[t] = warm_up[t];
+  for (size_t t = order; t < n; ++t) {
+    int64_t pred = 0;
+    for (size_t tau = 0; tau < order; ++tau) pred += (int64_t)coefs[tau] * (int64_t)dest[t - 1 - tau];
+    dest[t] = (int32_t)((uint32_t)dest[t] + (uint32_t)(int32_t)(pred >> shift));
+  }
+}
+
+/* estimated_qlpc, src/coding.rs:360-381 (perform_qlpc :333-351 without the
+ * experimental branches; encode_residual :173-176). */
+void orc_estimated_qlpc(const int32_t* signal, size_t n, uint32_t bits_per_sample,
+                        const orc_qlpc_config* cfg, orc_qlpc_result* res, uint8_t* rice_params,
+                        int32_t* errors, uint32_t* quotients, uint32_t* remainders) {
+  memset(res, 0, sizeof(*res));
+  res->status = orc_lpc_from_autocorr(signal, n, cfg, res->autocorr, res->lpc_coefs);
+  if (res->status != ORC_STATUS_OK) {
+    res->qp.precision = cfg->quant_precision;
+    for (size_t t = 0; t < n; ++t) errors[t] = 0;
+    return;
+  }
+  orc_quantize_parameters(res->lpc_coefs, cfg->lpc_order, cfg->quant_precision, &res->qp);
+  orc_compute_error(&res->qp, signal, n, errors);
+  orc_prc_parameter* prc = (orc_prc_parameter*)malloc(sizeof(orc_prc_parameter));
+  orc_find_partitioned_rice_parameter(errors, n, res->qp.order, cfg->max_rice_parameter, prc);
+  res->rice_order = prc->order;
+  res->code_bits = prc->code_bits;
+  memcpy(rice_params, prc->ps, (size_t)1 << prc->order);
+  orc_encode_residual_with_prc_parameter(errors, n, res->qp.order, prc, quotients, remainders,
+                                         &res->sum_quotients, &res->sum_rice_params);
+  res->residual_bits = orc_residual_count_bits(n, res->qp.order, prc->order, prc->ps,
+                                               res->sum_quotients, res->sum_rice_params);
+  res->subframe_bits =
+      orc_lpc_count_bits(bits_per_sample, res->qp.order, res->qp.precision, res->residual_bits);
+  free(prc);
+}
+
+/* src/coding.rs:476-484: mid = (l + r) >> 1, side = l - r */
+void orc_stereo_to_midside(const int32_t* l, const int32_t* r, size_t n, int32_t* m, int32_t* s) {
+  for (size_t t = 0; t < n; ++t) {
+    m[t] = (int32_t)((uint32_t)l[t] + (uint32_t)r[t]) >> 1;
+    s[t] = (int32_t)((uint32_t)l[t] - (uint32_t)r[t]);
+  }
+}
+
+/* src/component/decode.rs:91-103 */
+void orc_midside_to_stereo(const int32_t* m, const int32_t* s, size_t n, int32_t* l, int32_t* r) {
+  for (size_t t = 0; t < n; ++t) {
+    int32_t sv = s[t];
+    int32_t mv = (int32_t)((uint32_t)m[t] << 1) + (sv & 1);
+    l[t] = (mv + sv) >> 1;
+    r[t] = (mv - sv) >> 1;
+  }
+}
+
+/* arrayutils::is_constant, src/arrayutils.rs:382 */
+int orc_is_constant(const int32_t* samples, size_t n) {
+  for (size_t t = 1; t < n; ++t)
+    if (samples[t] != samples[0]) return 0;
+  return 1;
+}
+
+/* ------------------------------------------------------------------------ */
+/* batch driver (threads = frame-parallel pool like src/par.rs:355-449)      */
+/* ------------------------------------------------------------------------ */
+
+typedef struct {
+  const int32_t* samples;
+  size_t begin, end, n, stride;
+  const uint8_t* bps;
+  uint32_t bps_const;
+  const orc_qlpc_config* cfg;
+  orc_subframe_record* recs;
+  int32_t* residual;
+  size_t residual_stride;
+  double* autocorr;
+  double* lpc_coefs;
+} orc_batch_job;
+
+static void* orc_batch_worker(void* arg) {
+  orc_batch_job* job = (orc_batch_job*)arg;
+  size_t n = job->n;
+  int32_t* errors = (int32_t*)malloc(sizeof(int32_t) * (n ? n : 1));
+  uint8_t* rp = (uint8_t*)malloc(ORC_MAX_RICE_PARTITIONS);
+  orc_qlpc_result res;
+  for (size_t k = job->begin; k < job->end; ++k) {
+    const int32_t* sig = job->samples + k * job->stride;
+    uint32_t bps = job->bps ? job->bps[k] : job->bps_const;
+    orc_estimated_qlpc(sig, n, bps, job->cfg, &res, rp, errors, NULL, NULL);
+    if (job->recs) {
+      orc_subframe_record* r = &job->recs[k];
+      memset(r, 0, sizeof(*r));
+      for (int i = 0; i < 32; ++i) r->coefs[i] = res.qp.coefs[i];
+      r->order = (uint8_t)res.qp.order;
+      r->shift = (int8_t)res.qp.shift;
+      r->precision = (uint8_t)res.qp.precision;
+      r->rice_order = (uint8_t)res.rice_order;
+      r->status = res.status;
+      r->code_bits = res.code_bits;
+      r->subframe_bits = res.subframe_bits;
+      r->sum_quotients = res.sum_quotients;
+      size_t np = (size_t)1 << res.rice_order;
+      memcpy(r->rice_params, rp, np < 256 ? np : 256);
+    }
+    if (job->residual) memcpy(job->residual + k * job->residual_stride, errors, sizeof(int32_t) * n);
+    if (job->autocorr) memcpy(job->autocorr + k * 33, res.autocorr, sizeof(double) * 33);
+    if (job->lpc_coefs) memcpy(job->lpc_coefs + k * 32, res.lpc_coefs, sizeof(double) * 32);
+  }
+  free(errors);
+  free(rp);
+  return NULL;
+}
+
+static void orc_run_batch(orc_batch_job* proto, size_t n_subframes, int nthreads) {
+  if (nthreads < 1) nthreads = 1;
+  if ((size_t)nthreads > n_subframes) nthreads = n_subframes ? (int)n_subframes : 1;
+  pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)nthreads);
+  orc_batch_job* jobs = (orc_batch_job*)malloc(sizeof(orc_batch_job) * (size_t)nthreads);
+  for (int i = 0; i < nthreads; ++i) {
+    jobs[i] = *proto;
+    jobs[i].begin = n_subframes * (size_t)i / (size_t)nthreads;
+    jobs[i].end = n_subframes * (size_t)(i + 1) / (size_t)nthreads;
+    if (nthreads == 1) orc_batch_worker(&jobs[i]);
+    else pthread_create(&th[i], NULL, orc_batch_worker, &jobs[i]);
+  }
+  if (nthreads > 1)
+    for (int i = 0; i < nthreads; ++i) pthread_join(th[i], NULL);
+  free(th);
+  free(jobs);
+}
+
+void orc_qlpc_batch(const int32_t* samples, size_t n_subframes, size_t n, size_t stride,
+                    const uint8_t* bps, const orc_qlpc_config* cfg, orc_subframe_record* recs,
+                    int32_t* residual, size_t residual_stride, double* autocorr, double* lpc_coefs,
+                    int nthreads) {
+  orc_batch_job job;
+  memset(&job, 0, sizeof(job));
+  job.samples = samples;
+  job.n = n;
+  job.stride = stride;
+  job.bps = bps;
+  job.bps_const = 16;
+  job.cfg = cfg;
+  job.recs = recs;
+  job.residual = residual;
+  job.residual_stride = residual_stride;
+  job.autocorr = autocorr;
+  job.lpc_coefs = lpc_coefs;
+  orc_run_batch(&job, n_subframes, nthreads);
+}
+
+/* cpu_baseline timing: `repeats` passes of estimated_qlpc over the batch with
+ * `nthreads` workers; returns wall seconds.  Results are discarded except for
+ * a checksum kept alive through a volatile sink. */
+double orc_bench_qlpc(const int32_t* samples, size_t n_subframes, size_t n, size_t stride,
+                      uint32_t bits_per_sample, const orc_qlpc_config* cfg, int nthreads,
+                      int repeats) {
+  orc_subframe_record* recs =
+      (orc_subframe_record*)malloc(sizeof(orc_subframe_record) * (n_subframes ? n_subframes : 1));
+  orc_batch_job job;
+  memset(&job, 0, sizeof(job));
+  job.samples = samples;
+  job.n = n;
+  job.stride = stride;
+  job.bps = NULL;
+  job.bps_const = bits_per_sample;
+  job.cfg = cfg;
+  job.recs = recs;
+  struct timespec t0, t1;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  for (int r = 0; r < repeats; ++r) orc_run_batch(&job, n_subframes, nthreads);
+  clock_gettime(CLOCK_MONOTONIC, &t1);
+  static volatile uint64_t sink;
+  uint64_t s = 0;
+  for (size_t k = 0; k < n_subframes; ++k) s += recs[k].subframe_bits;
+  sink = s;
+  (void)sink;
+  free(recs);
+  return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}

@@ -1,0 +1,429 @@
+"""ctypes front-end of the CPU oracle (TEST INFRASTRUCTURE, NOT PRODUCT CODE).
+
+Only tests/, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg
+may import this module; the product package never does.  See
+``oracle/flacenc_oracle.h`` for what the oracle is and how it is pinned.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libflacenc_oracle.so")
+
+ACORR_REFERENCE = 0
+ACORR_CANONICAL = 1
+WINDOW_RECTANGLE = 0
+WINDOW_TUKEY = 1
+MAX_P_TO_BITS = (1 << 27) - 1
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with gcc (``make -C oracle``)."""
+    src = os.path.join(_HERE, "flacenc_oracle.c")
+    hdr = os.path.join(_HERE, "flacenc_oracle.h")
+    stale = (not os.path.exists(_LIB_PATH)) or any(
+        os.path.getmtime(p) > os.path.getmtime(_LIB_PATH) for p in (src, hdr)
+    )
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libflacenc_oracle.so"],
+                              stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+class QlpcConfig(C.Structure):
+    _fields_ = [
+        ("lpc_order", C.c_uint32),
+        ("quant_precision", C.c_uint32),
+        ("window_type", C.c_uint32),
+        ("tukey_alpha", C.c_float),
+        ("max_rice_parameter", C.c_uint32),
+        ("acorr_order", C.c_uint32),
+    ]
+
+
+class QParams(C.Structure):
+    _fields_ = [
+        ("coefs", C.c_int16 * 32),
+        ("order", C.c_uint32),
+        ("shift", C.c_int32),
+        ("precision", C.c_uint32),
+    ]
+
+
+class PrcParameter(C.Structure):
+    _fields_ = [
+        ("order", C.c_uint32),
+        ("code_bits", C.c_uint64),
+        ("ps", C.c_uint8 * (256 * 128)),
+    ]
+
+
+class QlpcResult(C.Structure):
+    _fields_ = [
+        ("qp", QParams),
+        ("rice_order", C.c_uint32),
+        ("code_bits", C.c_uint64),
+        ("sum_quotients", C.c_uint64),
+        ("sum_rice_params", C.c_uint64),
+        ("residual_bits", C.c_uint64),
+        ("subframe_bits", C.c_uint64),
+        ("status", C.c_int32),
+        ("autocorr", C.c_double * 33),
+        ("lpc_coefs", C.c_double * 32),
+    ]
+
+
+# numpy view of orc_subframe_record == flacenc_hip_subframe_params (352 bytes)
+RECORD_DTYPE = np.dtype(
+    [
+        ("coefs", np.int16, (32,)),
+        ("order", np.uint8),
+        ("shift", np.int8),
+        ("precision", np.uint8),
+        ("rice_order", np.uint8),
+        ("status", np.int32),
+        ("code_bits", np.uint64),
+        ("subframe_bits", np.uint64),
+        ("sum_quotients", np.uint64),
+        ("rice_params", np.uint8, (256,)),
+    ],
+    align=True,
+)
+assert RECORD_DTYPE.itemsize == 352, RECORD_DTYPE.itemsize
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+        _declare(_lib)
+    return _lib
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def _declare(L):
+    f32p, f64p = C.POINTER(C.c_float), C.POINTER(C.c_double)
+    i32p, u32p, u8p = C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint8)
+    L.orc_window_weights.argtypes = [C.c_uint32, C.c_float, C.c_size_t, f32p]
+    L.orc_fill_windowed_signal.argtypes = [i32p, f32p, C.c_size_t, f32p]
+    L.orc_auto_correlation_f64.argtypes = [C.c_size_t, f32p, C.c_size_t, f64p]
+    L.orc_auto_correlation_f32.argtypes = [C.c_size_t, f32p, C.c_size_t, f32p]
+    L.orc_auto_correlation_canonical_f64.argtypes = [C.c_size_t, f32p, C.c_size_t, f64p]
+    L.orc_symmetric_levinson_f64.argtypes = [f64p, f64p, C.c_size_t, f64p]
+    L.orc_symmetric_levinson_f64.restype = C.c_int
+    L.orc_symmetric_levinson_f32.argtypes = [f32p, f32p, C.c_size_t, f32p]
+    L.orc_symmetric_levinson_f32.restype = C.c_int
+    L.orc_find_shift.argtypes = [f64p, C.c_size_t, C.c_uint32]
+    L.orc_find_shift.restype = C.c_int32
+    L.orc_quantize_parameters.argtypes = [f64p, C.c_size_t, C.c_uint32, C.POINTER(QParams)]
+    L.orc_compute_error.argtypes = [C.POINTER(QParams), i32p, C.c_size_t, i32p]
+    L.orc_lpc_from_autocorr.argtypes = [i32p, C.c_size_t, C.POINTER(QlpcConfig), f64p, f64p]
+    L.orc_lpc_from_autocorr.restype = C.c_int
+    L.orc_encode_signbit.argtypes = [C.c_int32]
+    L.orc_encode_signbit.restype = C.c_uint32
+    L.orc_decode_signbit.argtypes = [C.c_uint32]
+    L.orc_decode_signbit.restype = C.c_int32
+    L.orc_prc_bit_table_from_errors.argtypes = [u32p, C.c_size_t, C.c_uint32, u32p]
+    L.orc_prc_minimizer.argtypes = [u32p, C.c_uint32, u32p, u32p]
+    L.orc_prc_merge.argtypes = [u32p, u32p, C.c_uint32, u32p]
+    L.orc_finest_partition_order.argtypes = [C.c_size_t, C.c_size_t]
+    L.orc_finest_partition_order.restype = C.c_uint32
+    L.orc_find_partitioned_rice_parameter.argtypes = [
+        i32p, C.c_size_t, C.c_size_t, C.c_uint32, C.POINTER(PrcParameter)]
+    L.orc_encode_residual_with_prc_parameter.argtypes = [
+        i32p, C.c_size_t, C.c_size_t, C.POINTER(PrcParameter), u32p, u32p,
+        C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.orc_residual_count_bits.argtypes = [
+        C.c_size_t, C.c_size_t, C.c_uint32, u8p, C.c_uint64, C.c_uint64]
+    L.orc_residual_count_bits.restype = C.c_uint64
+    L.orc_lpc_count_bits.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64]
+    L.orc_lpc_count_bits.restype = C.c_uint64
+    L.orc_verbatim_count_bits.argtypes = [C.c_size_t, C.c_uint32]
+    L.orc_verbatim_count_bits.restype = C.c_uint64
+    L.orc_decode_residual.argtypes = [C.c_size_t, C.c_uint32, u8p, u32p, u32p, i32p]
+    L.orc_decode_lpc.argtypes = [i32p, C.c_size_t, C.POINTER(C.c_int16), C.c_uint32, i32p,
+                                 C.c_size_t, i32p]
+    L.orc_estimated_qlpc.argtypes = [i32p, C.c_size_t, C.c_uint32, C.POINTER(QlpcConfig),
+                                     C.POINTER(QlpcResult), u8p, i32p, u32p, u32p]
+    L.orc_qlpc_batch.argtypes = [i32p, C.c_size_t, C.c_size_t, C.c_size_t, u8p,
+                                 C.POINTER(QlpcConfig), C.c_void_p, i32p, C.c_size_t, f64p, f64p,
+                                 C.c_int]
+    L.orc_stereo_to_midside.argtypes = [i32p, i32p, C.c_size_t, i32p, i32p]
+    L.orc_midside_to_stereo.argtypes = [i32p, i32p, C.c_size_t, i32p, i32p]
+    L.orc_is_constant.argtypes = [i32p, C.c_size_t]
+    L.orc_is_constant.restype = C.c_int
+    L.orc_bench_qlpc.argtypes = [i32p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint32,
+                                 C.POINTER(QlpcConfig), C.c_int, C.c_int]
+    L.orc_bench_qlpc.restype = C.c_double
+
+
+def make_config(lpc_order=10, quant_precision=15, window=("tukey", 0.4), max_rice_parameter=30,
+                acorr=ACORR_REFERENCE) -> QlpcConfig:
+    """config::Qlpc / config::Prc defaults, src/constant.rs:109-115, src/config.rs:216-221."""
+    if window == "rectangle" or window[0] == "rectangle":
+        wt, alpha = WINDOW_RECTANGLE, 0.0
+    else:
+        wt, alpha = WINDOW_TUKEY, float(window[1])
+    return QlpcConfig(lpc_order, quant_precision, wt, alpha, max_rice_parameter, acorr)
+
+
+# ---------------------------------------------------------------- lpc.rs ----
+def window_weights(window, n: int) -> np.ndarray:
+    cfg = make_config(window=window)
+    out = np.empty(n, np.float32)
+    lib().orc_window_weights(cfg.window_type, cfg.tukey_alpha, n, _p(out, C.c_float))
+    return out
+
+
+def fill_windowed_signal(signal, window) -> np.ndarray:
+    s = np.ascontiguousarray(signal, np.int32)
+    w = np.ascontiguousarray(window, np.float32)
+    out = np.empty(len(s), np.float32)
+    lib().orc_fill_windowed_signal(_p(s, C.c_int32), _p(w, C.c_float), len(s), _p(out, C.c_float))
+    return out
+
+
+def auto_correlation(order: int, signal, dtype=np.float64, canonical=False) -> np.ndarray:
+    x = np.ascontiguousarray(signal, np.float32)
+    if dtype == np.float32:
+        out = np.zeros(order, np.float32)
+        lib().orc_auto_correlation_f32(order, _p(x, C.c_float), len(x), _p(out, C.c_float))
+        return out
+    out = np.zeros(order, np.float64)
+    fn = lib().orc_auto_correlation_canonical_f64 if canonical else lib().orc_auto_correlation_f64
+    fn(order, _p(x, C.c_float), len(x), _p(out, C.c_double))
+    return out
+
+
+def symmetric_levinson_recursion(coefs, ys, dtype=np.float64):
+    if dtype == np.float32:
+        c = np.ascontiguousarray(coefs, np.float32)
+        y = np.ascontiguousarray(ys, np.float32)
+        out = np.zeros(len(y), np.float32)
+        st = lib().orc_symmetric_levinson_f32(_p(c, C.c_float), _p(y, C.c_float), len(y),
+                                              _p(out, C.c_float))
+    else:
+        c = np.ascontiguousarray(coefs, np.float64)
+        y = np.ascontiguousarray(ys, np.float64)
+        out = np.zeros(len(y), np.float64)
+        st = lib().orc_symmetric_levinson_f64(_p(c, C.c_double), _p(y, C.c_double), len(y),
+                                              _p(out, C.c_double))
+    return out, st
+
+
+def find_shift(coefs, precision: int) -> int:
+    c = np.ascontiguousarray(coefs, np.float64)
+    return int(lib().orc_find_shift(_p(c, C.c_double), len(c), precision))
+
+
+def quantize_parameters(coefs, precision: int) -> QParams:
+    c = np.ascontiguousarray(coefs, np.float64)
+    qp = QParams()
+    lib().orc_quantize_parameters(_p(c, C.c_double), len(c), precision, C.byref(qp))
+    return qp
+
+
+def qparams(coefs, shift: int, precision: int) -> QParams:
+    qp = QParams()
+    for i, v in enumerate(coefs):
+        qp.coefs[i] = int(v)
+    qp.order, qp.shift, qp.precision = len(coefs), shift, precision
+    return qp
+
+
+def compute_error(qp: QParams, signal) -> np.ndarray:
+    s = np.ascontiguousarray(signal, np.int32)
+    out = np.zeros(len(s), np.int32)
+    lib().orc_compute_error(C.byref(qp), _p(s, C.c_int32), len(s), _p(out, C.c_int32))
+    return out
+
+
+def lpc_from_autocorr(signal, cfg: QlpcConfig):
+    s = np.ascontiguousarray(signal, np.int32)
+    corr = np.zeros(33, np.float64)
+    coefs = np.zeros(32, np.float64)
+    st = lib().orc_lpc_from_autocorr(_p(s, C.c_int32), len(s), C.byref(cfg), _p(corr, C.c_double),
+                                     _p(coefs, C.c_double))
+    return corr[: cfg.lpc_order + 1], coefs[: cfg.lpc_order], st
+
+
+# --------------------------------------------------------------- rice.rs ----
+def encode_signbit(v: int) -> int:
+    return int(lib().orc_encode_signbit(int(v)))
+
+
+def decode_signbit(v: int) -> int:
+    return int(lib().orc_decode_signbit(int(v)))
+
+
+def prc_bit_table_from_errors(errors, offset: int) -> np.ndarray:
+    e = np.ascontiguousarray(errors, np.uint32)
+    out = np.zeros(32, np.uint32)
+    lib().orc_prc_bit_table_from_errors(_p(e, C.c_uint32), len(e), offset, _p(out, C.c_uint32))
+    return out
+
+
+def prc_minimizer(table, max_p: int):
+    t = np.ascontiguousarray(table, np.uint32)
+    p, bits = C.c_uint32(), C.c_uint32()
+    lib().orc_prc_minimizer(_p(t, C.c_uint32), max_p, C.byref(p), C.byref(bits))
+    return p.value, bits.value
+
+
+def prc_merge(a, b, offset: int) -> np.ndarray:
+    a = np.ascontiguousarray(a, np.uint32)
+    b = np.ascontiguousarray(b, np.uint32)
+    out = np.zeros(32, np.uint32)
+    lib().orc_prc_merge(_p(a, C.c_uint32), _p(b, C.c_uint32), offset, _p(out, C.c_uint32))
+    return out
+
+
+def finest_partition_order(size: int, min_part_size: int) -> int:
+    return int(lib().orc_finest_partition_order(size, min_part_size))
+
+
+def find_partitioned_rice_parameter(signal, warmup_length: int, max_p: int):
+    s = np.ascontiguousarray(signal, np.int32)
+    prc = PrcParameter()
+    lib().orc_find_partitioned_rice_parameter(_p(s, C.c_int32), len(s), warmup_length, max_p,
+                                              C.byref(prc))
+    ps = np.frombuffer(prc.ps, np.uint8, 1 << prc.order).copy()
+    return prc.order, ps, int(prc.code_bits), prc
+
+
+def encode_residual(errors, warmup_length: int, max_p: int = 30):
+    """coding::encode_residual (src/coding.rs:173-176) -> dict mirroring component::Residual."""
+    e = np.ascontiguousarray(errors, np.int32)
+    order, ps, code_bits, prc = find_partitioned_rice_parameter(e, warmup_length, max_p)
+    q = np.zeros(len(e), np.uint32)
+    r = np.zeros(len(e), np.uint32)
+    sq, sp = C.c_uint64(), C.c_uint64()
+    lib().orc_encode_residual_with_prc_parameter(_p(e, C.c_int32), len(e), warmup_length,
+                                                 C.byref(prc), _p(q, C.c_uint32),
+                                                 _p(r, C.c_uint32), C.byref(sq), C.byref(sp))
+    bits = residual_count_bits(len(e), warmup_length, order, ps, sq.value, sp.value)
+    return dict(partition_order=order, rice_params=ps, quotients=q, remainders=r,
+                sum_quotients=sq.value, sum_rice_params=sp.value, code_bits=code_bits,
+                count_bits=bits, block_size=len(e), warmup_length=warmup_length)
+
+
+def residual_count_bits(block_size, warmup_length, partition_order, rice_params, sum_quotients,
+                        sum_rice_params) -> int:
+    rp = np.ascontiguousarray(rice_params, np.uint8)
+    return int(lib().orc_residual_count_bits(block_size, warmup_length, partition_order,
+                                             _p(rp, C.c_uint8), sum_quotients, sum_rice_params))
+
+
+def lpc_count_bits(bits_per_sample, order, precision, residual_bits) -> int:
+    return int(lib().orc_lpc_count_bits(bits_per_sample, order, precision, residual_bits))
+
+
+def verbatim_count_bits(n, bits_per_sample) -> int:
+    return int(lib().orc_verbatim_count_bits(n, bits_per_sample))
+
+
+def decode_residual(res: dict) -> np.ndarray:
+    out = np.zeros(res["block_size"], np.int32)
+    rp = np.ascontiguousarray(res["rice_params"], np.uint8)
+    lib().orc_decode_residual(res["block_size"], res["partition_order"], _p(rp, C.c_uint8),
+                              _p(res["quotients"], C.c_uint32), _p(res["remainders"], C.c_uint32),
+                              _p(out, C.c_int32))
+    return out
+
+
+def decode_lpc(warm_up, coefs, shift: int, residual) -> np.ndarray:
+    w = np.ascontiguousarray(warm_up, np.int32)
+    c = np.ascontiguousarray(coefs, np.int16)
+    r = np.ascontiguousarray(residual, np.int32)
+    out = np.zeros(len(r), np.int32)
+    lib().orc_decode_lpc(_p(w, C.c_int32), len(w), _p(c, C.c_int16), shift, _p(r, C.c_int32),
+                         len(r), _p(out, C.c_int32))
+    return out
+
+
+# ------------------------------------------------------------- coding.rs ----
+def estimated_qlpc(signal, bits_per_sample: int, cfg: QlpcConfig) -> dict:
+    """coding::estimated_qlpc (src/coding.rs:360-381) for one subframe."""
+    s = np.ascontiguousarray(signal, np.int32)
+    n = len(s)
+    res = QlpcResult()
+    rp = np.zeros(32768, np.uint8)
+    err = np.zeros(n, np.int32)
+    q = np.zeros(n, np.uint32)
+    r = np.zeros(n, np.uint32)
+    lib().orc_estimated_qlpc(_p(s, C.c_int32), n, bits_per_sample, C.byref(cfg), C.byref(res),
+                             _p(rp, C.c_uint8), _p(err, C.c_int32), _p(q, C.c_uint32),
+                             _p(r, C.c_uint32))
+    order = res.qp.order
+    return dict(
+        status=res.status,
+        coefs=np.array(res.qp.coefs[:order], np.int16),
+        order=order, shift=res.qp.shift, precision=res.qp.precision,
+        warm_up=s[:order].copy(), residual=err,
+        rice_order=res.rice_order, rice_params=rp[: 1 << res.rice_order].copy(),
+        quotients=q, remainders=r,
+        code_bits=int(res.code_bits), sum_quotients=int(res.sum_quotients),
+        residual_bits=int(res.residual_bits), subframe_bits=int(res.subframe_bits),
+        autocorr=np.array(res.autocorr[: cfg.lpc_order + 1]),
+        lpc_coefs=np.array(res.lpc_coefs[: cfg.lpc_order]),
+    )
+
+
+def qlpc_batch(samples, bps, cfg: QlpcConfig, nthreads: int = 1, want_fp: bool = True):
+    """estimated_qlpc over a [n_subframes, n] int32 array.  Returns (records, residual, R, a)."""
+    x = np.ascontiguousarray(samples, np.int32)
+    ns, n = x.shape
+    recs = np.zeros(ns, RECORD_DTYPE)
+    residual = np.zeros((ns, n), np.int32)
+    bps_a = np.ascontiguousarray(np.broadcast_to(np.asarray(bps, np.uint8), (ns,)))
+    R = np.zeros((ns, 33), np.float64) if want_fp else None
+    A = np.zeros((ns, 32), np.float64) if want_fp else None
+    lib().orc_qlpc_batch(_p(x, C.c_int32), ns, n, n, _p(bps_a, C.c_uint8), C.byref(cfg),
+                         recs.ctypes.data_as(C.c_void_p), _p(residual, C.c_int32), n,
+                         _p(R, C.c_double) if want_fp else None,
+                         _p(A, C.c_double) if want_fp else None, nthreads)
+    return recs, residual, R, A
+
+
+def stereo_to_midside(l, r):
+    l = np.ascontiguousarray(l, np.int32)
+    r = np.ascontiguousarray(r, np.int32)
+    m = np.zeros_like(l)
+    s = np.zeros_like(l)
+    lib().orc_stereo_to_midside(_p(l, C.c_int32), _p(r, C.c_int32), len(l), _p(m, C.c_int32),
+                                _p(s, C.c_int32))
+    return m, s
+
+
+def midside_to_stereo(m, s):
+    m = np.ascontiguousarray(m, np.int32)
+    s = np.ascontiguousarray(s, np.int32)
+    l = np.zeros_like(m)
+    r = np.zeros_like(m)
+    lib().orc_midside_to_stereo(_p(m, C.c_int32), _p(s, C.c_int32), len(m), _p(l, C.c_int32),
+                                _p(r, C.c_int32))
+    return l, r
+
+
+def is_constant(samples) -> bool:
+    s = np.ascontiguousarray(samples, np.int32)
+    return bool(lib().orc_is_constant(_p(s, C.c_int32), len(s)))
+
+
+def bench_qlpc(samples, bits_per_sample: int, cfg: QlpcConfig, nthreads: int, repeats: int = 1):
+    """Wall seconds for `repeats` passes of estimated_qlpc over the batch (cpu_baseline)."""
+    x = np.ascontiguousarray(samples, np.int32)
+    ns, n = x.shape
+    return float(lib().orc_bench_qlpc(_p(x, C.c_int32), ns, n, n, bits_per_sample, C.byref(cfg),
+                                      nthreads, repeats))

@@ -1,0 +1,422 @@
+"""Pins the CPU oracle against the reference's own in-source known-answer tests.
+
+Every test cites the reference test it restates (paths relative to
+/root/reference/).  Inputs and expected values are the reference's test data.
+Where the reference test draws from `sigen::Noise` (rand's StdRng, not
+reproducible here) the same property is asserted on counter-based noise.
+"""
+import numpy as np
+import pytest
+
+import util
+from oracle import oracle as orc
+
+
+def assert_close(actual, expected, rtol=1e-5, atol=1e-5):
+    """assert_close!, src/test_helper.rs:46-56."""
+    assert abs(actual - expected) < rtol * abs(expected) + atol, (actual, expected)
+
+
+# ---------------------------------------------------------------- lpc.rs ----
+def test_auto_correlation_computation():
+    """src/lpc.rs:997-1022 (T = f32): 128-sample sine of period 32 -> argmax 0, argmin 16."""
+    t = np.arange(128, dtype=np.float32)
+    signal = (np.sin((t / np.float32(32.0) * np.float32(2.0) * np.float32(np.pi)).astype(np.float32))
+              .astype(np.float32) * np.float32(1024.0)).astype(np.float32)
+    corr = orc.auto_correlation(32, signal, dtype=np.float32)
+    assert int(np.argmax(corr)) == 0
+    assert int(np.argmin(corr)) == 16
+
+
+KNOWN = [0.0] * 8 + [1, 1, 1, 1, -1, -1, -1, -1, 1, 1, -1, -1, 1, 1, -1, -1,
+                     1, -1, 1, -1, 1, -1, 1, -1,
+                     1, -1, 1, -1, 1, -1, 1, -1, 1, 1, -1, -1, 1, 1, -1, -1,
+                     1, 1, 1, 1, -1, -1, -1, -1] + [0.0] * 8
+
+
+@pytest.mark.parametrize("canonical", [False, True])
+def test_auto_correlation_computation_with_known_samples(canonical):
+    """src/lpc.rs:1024-1041: 64-sample +-1 pattern, order 33 -> 24, -4, 2, ..., R[32] = 0.
+    All partial sums are small integers, so the canonical order must agree exactly too."""
+    assert len(KNOWN) == 64
+    corr = orc.auto_correlation(33, np.array(KNOWN, np.float32), canonical=canonical)
+    assert corr[0] == 24.0
+    assert corr[1] == -4.0
+    assert corr[2] == 2.0
+    assert corr[32] == 0.0
+
+
+def test_symmetric_levinson_algorithm():
+    """src/lpc.rs:1043-1066."""
+    xs, st = orc.symmetric_levinson_recursion([1.0, 0.5, 0.0, 0.25], [1.0, -1.0, 1.0, -1.0],
+                                              dtype=np.float32)
+    assert st == 0
+    assert xs.tolist() == [8.0, -10.0, 10.0, -8.0]  # exact in f32
+    xs, st = orc.symmetric_levinson_recursion([1.0, -0.5, -1.0, -0.5, 0.5],
+                                              [1.0, 0.5, 0.25, 0.125, 0.0625], dtype=np.float32)
+    for x, e in zip(xs, [0.80833, -0.26458, -0.36667, -0.45208, -1.06667]):
+        assert_close(float(x), e)
+    # the f64 instantiation the path uses (lpc.rs:916) must agree to the same tolerance
+    xs64, _ = orc.symmetric_levinson_recursion([1.0, -0.5, -1.0, -0.5, 0.5],
+                                               [1.0, 0.5, 0.25, 0.125, 0.0625])
+    for x, e in zip(xs64, [0.80833, -0.26458, -0.36667, -0.45208, -1.06667]):
+        assert_close(float(x), e)
+
+
+def test_shift_finder():
+    """src/lpc.rs:1068-1074."""
+    assert orc.find_shift([0.25, 0.125, 0.000001, 0.0], 8) == 9
+
+
+def test_parameter_quantizer():
+    """src/lpc.rs:1076-1086."""
+    qp = orc.quantize_parameters([0.0, 0.5, 0.1], 4)
+    assert list(qp.coefs[: qp.order]) == [0, 7, 2]
+    qp = orc.quantize_parameters([1.0, -0.5, 0.5], 2)
+    assert list(qp.coefs[: qp.order]) == [1, -1, 1]
+    # QuantizedParameters::dequantized, src/component/datatype.rs:2174-2177, 2258-2263
+    deq = [np.float32(c) * np.float32(2.0) ** np.float32(-qp.shift) for c in qp.coefs[: qp.order]]
+    assert deq == [0.5, -0.5, 0.5]
+
+
+def test_qlpc_auto_truncation():
+    """src/lpc.rs:1088-1093."""
+    assert orc.quantize_parameters([1.0, 0.5, 0.0, 0.0], 8).order == 2
+
+
+@pytest.mark.parametrize("lpc_order", [2, 12, 24])
+def test_qlpc_recovery(lpc_order):
+    """src/lpc.rs:1095-1143: Sine(32, 0.8) + noise(0.01), 16-bit, 1024 samples, Tukey(0.1),
+    precision 15: error energy < signal energy and e[t] + (sum c*s >> shift) == s[t]."""
+    signal = util.sine_noise(1024, 16, 32, 0.8, 0.01, seed=123)
+    cfg = orc.make_config(lpc_order=lpc_order, quant_precision=15, window=("tukey", 0.1))
+    _, coefs, st = orc.lpc_from_autocorr(signal, cfg)
+    assert st == 0 and np.isfinite(coefs).all()
+    qlpc = orc.quantize_parameters(coefs, 15)
+    assert qlpc.order <= lpc_order
+    errors = orc.compute_error(qlpc, signal)
+    sig_e = float((signal[lpc_order:].astype(np.float64) ** 2).sum())
+    err_e = float((errors[lpc_order:].astype(np.float64) ** 2).sum())
+    assert err_e < sig_e
+    qc = [int(c) for c in qlpc.coefs[: qlpc.order]]
+    for t in range(lpc_order, len(signal)):
+        pred = sum(int(signal[t - tau - 1]) * c for tau, c in enumerate(qc)) >> qlpc.shift
+        assert int(errors[t]) + pred == int(signal[t]), t
+
+
+def test_lpc_with_pure_dc():
+    """src/lpc.rs:1145-1169 (f32 estimator, order 1)."""
+    signal = np.array([12345] * 7, np.int32)
+    corr = orc.auto_correlation(2, signal.astype(np.float32), dtype=np.float32)
+    coefs, _ = orc.symmetric_levinson_recursion(corr[:1], corr[1:2], dtype=np.float32)
+    assert_close(float(coefs[0]), 1.0)
+    qlpc = orc.quantize_parameters(coefs.astype(np.float64), 15)
+    errors = orc.compute_error(qlpc, signal)
+    assert (errors < 2).all()
+
+
+def test_lpc_with_known_coefs():
+    """src/lpc.rs:1171-1192: sign pattern (+, -, +) of the order-3 estimate."""
+    signal = [0, -512, 0, 512, 256, -256, -256, 128, 256, 0, -192, -64, 128, 96, -64, -96, 16,
+              80, 16, -56, -32, 32, 36, -12]
+    cfg = orc.make_config(lpc_order=3, window=("tukey", 0.25))
+    _, coefs, st = orc.lpc_from_autocorr(np.array(signal, np.int32), cfg)
+    assert st == 0
+    assert coefs[0] > 0.0 and coefs[1] < 0.0 and coefs[2] > 0.0
+
+
+def test_tukey_window():
+    """src/lpc.rs:1214-1228: Tukey(0.3, 32) against scipy.signal.windows.tukey(32, 0.3)."""
+    reference = [0., 0.1098376, 0.39109322, 0.720197, 0.95255725] + [1.] * 22 + \
+                [0.95255725, 0.720197, 0.39109322, 0.1098376, 0.]
+    win = orc.window_weights(("tukey", 0.3), 32)
+    for w, e in zip(win, reference):
+        assert_close(float(w), e)
+
+
+def test_tukey_window_range():
+    """src/lpc.rs:1230-1243: every weight is normal or zero for alpha in {0, .3, .5, .8, 1}."""
+    tiny = np.finfo(np.float32).tiny
+    for alpha in [0.0, 0.3, 0.5, 0.8, 1.0]:
+        w = orc.window_weights(("tukey", alpha), 4096)
+        assert np.isfinite(w).all()
+        assert ((np.abs(w) >= tiny) | (w == 0.0)).all()
+    assert (orc.window_weights(("tukey", 0.0), 64) == 1.0).all()  # lpc.rs:99-101
+    assert (orc.window_weights("rectangle", 64) == 1.0).all()
+    assert orc.window_weights(("tukey", 0.4), 4096)[0] == 0.0  # t == 0 -> exactly 0
+
+
+def test_qlpc_with_test_signal():
+    """src/lpc.rs:1258-1295: sus109 ch0, 4096 samples, order 8, precision 12, Tukey(0.1)."""
+    signal = util.test_signal("sus109", 0)[:4096]
+    cfg = orc.make_config(lpc_order=8, quant_precision=12, window=("tukey", 0.1))
+    _, coefs, st = orc.lpc_from_autocorr(signal, cfg)
+    assert st == 0
+    qlpc = orc.quantize_parameters(coefs, 12)
+    assert qlpc.order == 8
+    errors = orc.compute_error(qlpc, signal)
+    sig_e = float((signal[8:].astype(np.float64) ** 2).sum())
+    err_e = float((errors[8:].astype(np.float64) ** 2).sum())
+    assert err_e < sig_e
+
+
+def test_overflow_patterns():
+    """src/lpc.rs:1415-1429: must not crash on the i64 fallback; plus losslessness."""
+    signal = np.array([127] * 33 + [29] + [0] * 30, np.int32)
+    cfg = orc.make_config(lpc_order=15, quant_precision=13, window="rectangle")
+    _, coefs, st = orc.lpc_from_autocorr(signal, cfg)
+    assert st == 0
+    qlpc = orc.quantize_parameters(coefs, 13)
+    errors = orc.compute_error(qlpc, signal)
+    dec = orc.decode_lpc(signal[: qlpc.order], qlpc.coefs[: qlpc.order], qlpc.shift, errors)
+    assert (dec == signal).all()
+
+
+def test_order_zero_lpc():
+    """src/lpc.rs:1431-1446."""
+    signal = np.zeros(64, np.int32)
+    cfg = orc.make_config(lpc_order=0, quant_precision=13, window="rectangle")
+    _, coefs, st = orc.lpc_from_autocorr(signal, cfg)
+    assert st == 0 and len(coefs) == 0
+    qlpc = orc.quantize_parameters([], 13)
+    assert qlpc.order == 0
+    assert (orc.compute_error(qlpc, signal) == 0).all()
+
+
+def test_levinson_zero_denominator_skips_iteration():
+    """src/lpc.rs:678-682: `continue` targets the `for`, so iteration n is skipped.
+    R = [1, 1, ...] gives error = 1, denom = fma(1, -1, 1) = 0 at n = 1."""
+    xs, st = orc.symmetric_levinson_recursion([1.0, 1.0, 1.0], [1.0, 1.0, 1.0])
+    assert st == 0
+    assert np.isfinite(xs).all()
+    assert xs[0] == 1.0  # dest[0] = ys[0] / coefs[0]; iterations 1 and 2 both skipped
+    assert xs[1] == 0.0 and xs[2] == 0.0
+
+
+def test_compute_error_i32_and_i64_paths_agree():
+    """src/lpc.rs:373-389: both branches produce the exact value truncated to i32."""
+    sig16 = util.sine_noise(512, 16, 50, 0.3, 0.01, seed=5)
+    sig24 = util.sine_noise(512, 24, 50, 0.9, 0.05, seed=6)
+    qp = orc.qparams([12000, -9000, 4000, -1500], 13, 15)
+    for sig in (sig16, sig24):
+        e = orc.compute_error(qp, sig)
+        for t in range(4, len(sig)):
+            pred = sum(int(sig[t - 1 - j]) * int(qp.coefs[j]) for j in range(4)) >> 13
+            want = (int(sig[t]) - pred + (1 << 31)) % (1 << 32) - (1 << 31)
+            assert int(e[t]) == want
+        assert (e[:4] == 0).all()
+
+
+# --------------------------------------------------------------- rice.rs ----
+def test_bit_table_initialization():
+    """src/rice.rs:319-324."""
+    table = orc.prc_bit_table_from_errors([6, 8, 10, 12], 4)
+    assert table[0] == 3 * 2 + 4 * 2 + 5 * 2 + 6 * 2 + 8
+    assert table[1] == 3 + 4 + 5 + 6 + 8 + 4
+
+
+def test_prc_parameter_search():
+    """src/rice.rs:326-339 (property on 12-bit noise of amplitude 0.25, 64 samples)."""
+    signal = util.quantize(util.noise(11, 64, 0.25), 12)
+    errors = [orc.encode_signbit(int(v)) for v in signal]
+    p, _ = orc.prc_minimizer(orc.prc_bit_table_from_errors(errors, 4), 14)
+    assert 0 < p < 14
+
+
+def test_finest_partition_order_search():
+    """src/rice.rs:341-349."""
+    assert orc.finest_partition_order(64, 4) == 4
+    assert orc.finest_partition_order(64, 3) == 4
+    assert orc.finest_partition_order(192, 1) == 6
+    assert orc.finest_partition_order(192, 3) == 6
+    assert orc.finest_partition_order(192, 4) == 5
+    # sizes the path sees
+    assert [orc.finest_partition_order(n, 64) for n in (4096, 8192, 16384)] == [6, 7, 8]
+
+
+def test_partitioned_rice_parameter_search():
+    """src/rice.rs:351-365: loud half + quiet half, 8-bit, 128 samples, warm-up 4."""
+    signal = util.quantize(np.concatenate([util.noise(0, 64, 0.5), util.noise(1, 64, 0.05)]), 8)
+    errors = np.array([orc.encode_signbit(int(v)) for v in signal], np.uint32)
+    _, single_bits = orc.prc_minimizer(orc.prc_bit_table_from_errors(errors[4:], 4), 14)
+    order, ps, code_bits, _ = orc.find_partitioned_rice_parameter(signal, 4, 14)
+    assert code_bits <= single_bits
+    assert order == 1
+    assert ps[0] > ps[1]
+
+
+def _table(vals):
+    t = np.zeros(32, np.uint32)  # PrcBitTable::zero(), src/rice.rs:58-63
+    t[: len(vals)] = vals
+    return t
+
+
+def test_partition_evaluation():
+    """src/rice.rs:367-378 (eval_partitions)."""
+    p1, b1 = orc.prc_minimizer(_table([17, 19, 15, 11, 19]), 4)
+    p2, b2 = orc.prc_minimizer(_table([12, 14, 16, 18, 20]), 4)
+    assert b1 + b2 == 23
+    assert [p1, p2] == [3, 0]
+
+
+def test_partition_merging():
+    """src/rice.rs:380-391 (merge_partitions, offset 4)."""
+    merged = orc.prc_merge(_table([17, 19, 15, 11, 19]), _table([12, 14, 16, 18, 20]), 4)
+    assert merged[:5].tolist() == [25, 29, 27, 25, 35]
+    # lanes where both inputs are 0 wrap to 2^32 - 4 and clamp to MAX_P_TO_BITS (rice.rs:147-150)
+    assert merged[5] == orc.MAX_P_TO_BITS
+
+
+def test_minimizer_search():
+    """src/rice.rs:393-412 incl. the tie -> smallest p rule."""
+    assert orc.prc_minimizer(_table([6, 7, 4, 5, 9, 0, 0, 0]), 4) == (2, 4)
+    assert orc.prc_minimizer(_table([6, 7, 8, 5, 3, 0, 0, 0]), 4) == (4, 3)
+    assert orc.prc_minimizer(_table([1, 7, 8, 5, 3, 0, 0, 0]), 4) == (0, 1)
+    assert orc.prc_minimizer(_table([7, 1, 1, 1, 3, 0, 0, 0]), 4) == (1, 1)
+    # high half (params 16..30), rice.rs:126-135
+    t = np.full(32, 1000, np.uint32)
+    t[20] = 7
+    assert orc.prc_minimizer(t, 30) == (20, 7)
+    assert orc.prc_minimizer(t, 15) == (0, 1000)
+
+
+def test_prc_max_bits():
+    """src/rice.rs:414-419: saturation at 2^27 - 1."""
+    table = orc.prc_bit_table_from_errors([0x0FFFFFFE, 0x01000000], 0)
+    assert table[0] == orc.MAX_P_TO_BITS
+
+
+def test_signbit_coding():
+    """src/rice.rs:169-187: 0, -1, 1, -2 -> 0, 1, 2, 3 and back."""
+    assert [orc.encode_signbit(v) for v in (0, -1, 1, -2)] == [0, 1, 2, 3]
+    for v in (0, -1, 1, -2, 12345, -12345, 2**31 - 1, -(2**31) + 1):
+        assert orc.decode_signbit(orc.encode_signbit(v)) == v
+
+
+# ------------------------------------------------- coding.rs / bitrepr.rs ----
+def test_losslessness_residual_coding():
+    """src/coding.rs:771-785."""
+    signal = util.quantize(util.noise(3, 64, 0.4), 8)
+    res = orc.encode_residual(signal, 0)
+    assert (orc.decode_residual(res) == signal).all()
+    signal = util.quantize(np.concatenate([util.noise(4, 2048, 0.9), util.sine(2048, 40, 0.1)]), 8)
+    res = orc.encode_residual(signal, 0)
+    assert (orc.decode_residual(res) == signal).all()
+
+
+@pytest.mark.parametrize("case", ["noise", "sine"])
+def test_losslessness_subframe_coding(case):
+    """src/coding.rs:787-799 restricted to the LPC candidate (the path under test):
+    estimated_qlpc output must decode (decode.rs:159-177) to the input."""
+    bps = 8
+    signal = (util.quantize(util.noise(8, 64, 0.4), bps) if case == "noise"
+              else util.quantize(util.sine(64, 40, 0.9), bps))
+    out = orc.estimated_qlpc(signal, bps, orc.make_config())
+    assert out["status"] == 0
+    res = dict(block_size=64, partition_order=out["rice_order"], rice_params=out["rice_params"],
+               quotients=out["quotients"], remainders=out["remainders"])
+    resid = orc.decode_residual(res)
+    assert (resid == out["residual"]).all()
+    dec = orc.decode_lpc(out["warm_up"], out["coefs"], out["shift"], resid)
+    assert (dec == signal).all()
+
+
+@pytest.mark.parametrize("seed,n,warm,max_p", [(1, 4096, 10, 30), (2, 4096, 1, 14), (3, 1152, 8, 30),
+                                               (4, 64, 0, 30), (5, 8192, 24, 30)])
+def test_residual_count_bits_is_accurate(seed, n, warm, max_p):
+    """src/component/bitrepr.rs:706-717 ("`Residual::count_bits` should be accurate"):
+    the formula (bitrepr.rs:533-544) equals the number of bits `write` emits."""
+    errors = util.quantize(util.noise(seed, n, 0.3) * util.sine(n, 300, 1.0), 16)
+    errors[:warm] = 0
+    res = orc.encode_residual(errors, warm, max_p)
+    assert res["count_bits"] == util.residual_write_bits(res)
+    # search estimate vs written size differ only by the RICE2 parameter width
+    nparts = 1 << res["partition_order"]
+    rice2 = nparts if (res["rice_params"] > 14).any() else 0
+    assert res["count_bits"] == 6 + res["code_bits"] + rice2
+    assert (res["quotients"][:warm] == 0).all() and (res["remainders"][:warm] == 0).all()
+
+
+def test_rice2_parameter_width():
+    """bitrepr.rs:540-543: any p > 14 switches to 5-bit parameters."""
+    errors = util.quantize(util.noise(9, 4096, 0.9), 24)
+    res = orc.encode_residual(errors, 0, 30)
+    assert (res["rice_params"] > 14).any()
+    assert res["count_bits"] == util.residual_write_bits(res)
+    res14 = orc.encode_residual(errors, 0, 14)
+    assert (res14["rice_params"] <= 14).all()
+    assert res14["count_bits"] == util.residual_write_bits(res14)
+
+
+def test_lpc_count_bits_formula():
+    """bitrepr.rs:492-499 on the doctest component of datatype.rs:2077-2084:
+    Residual::new(0, 64, 1, &[8], zeros, zeros), QuantizedParameters::new(&[1], 1, 0, 7), bps 16."""
+    rbits = orc.residual_count_bits(64, 1, 0, [8], 0, 8)
+    assert rbits == 2 + 4 + 4 + 63 + (8 * 64 - 8)
+    assert orc.lpc_count_bits(16, 1, 7, rbits) == 8 + 16 + 4 + 5 + 7 + rbits
+    assert orc.verbatim_count_bits(4096, 16) == 8 + 4096 * 16  # datatype.rs:1944-1949
+
+
+def test_midside_roundtrip():
+    """coding.rs:476-484 vs decode.rs:91-103."""
+    l = util.quantize(util.noise(21, 512, 0.9), 16)
+    r = util.quantize(util.noise(22, 512, 0.9), 16)
+    m, s = orc.stereo_to_midside(l, r)
+    assert (m == ((l.astype(np.int64) + r) >> 1)).all() and (s == l - r).all()
+    l2, r2 = orc.midside_to_stereo(m, s)
+    assert (l2 == l).all() and (r2 == r).all()
+
+
+# --------------------------------------------------- whole path properties ----
+@pytest.mark.parametrize("n,bps,order,window", [
+    (4096, 16, 8, ("tukey", 0.4)), (4096, 16, 10, ("tukey", 0.4)), (4096, 17, 10, ("tukey", 0.4)),
+    (8192, 24, 24, ("tukey", 0.4)), (8192, 25, 32, ("tukey", 0.4)), (16384, 24, 24, ("tukey", 0.4)),
+    (1152, 16, 12, ("tukey", 0.5)), (576, 8, 6, "rectangle"), (1001, 16, 10, ("tukey", 0.4)),
+    (64, 16, 10, ("tukey", 0.4)), (32767, 16, 8, ("tukey", 0.1)),
+])
+def test_estimated_qlpc_is_lossless(n, bps, order, window):
+    """fuzz/fuzz_targets/frame_encode.rs:197-212 property on the path: decode == input,
+    and Residual invariants of src/component/verify.rs:274-332."""
+    signal = util.sine_noise(n, bps, 36, 0.4, 0.04, seed=n + order)
+    cfg = orc.make_config(lpc_order=order, window=window)
+    out = orc.estimated_qlpc(signal, bps, cfg)
+    assert out["status"] == 0
+    assert 1 <= out["order"] <= order
+    assert 0 <= out["shift"] <= 15
+    assert (np.abs(out["coefs"].astype(np.int32)) <= (1 << 14)).all()
+    nparts = 1 << out["rice_order"]
+    assert n % nparts == 0 and (n >> out["rice_order"]) >= out["order"]
+    assert (out["rice_params"] <= 30).all()
+    assert (out["residual"][: out["order"]] == 0).all()
+    dec = orc.decode_lpc(out["warm_up"], out["coefs"], out["shift"], out["residual"])
+    assert (dec == signal).all()
+    res = dict(block_size=n, warmup_length=out["order"], partition_order=out["rice_order"],
+               rice_params=out["rice_params"], quotients=out["quotients"])
+    assert out["residual_bits"] == util.residual_write_bits(res)
+
+
+def test_canonical_vs_reference_order_tolerance():
+    """T2 of the parity contract: the build's canonical summation order agrees with the
+    reference (nosimd) order within 1e-12 relative on R and 1e-8 relative on LPC
+    coefficients (same bound class as the reference's own simd/nosimd parity test,
+    src/lpc.rs:1392-1413, which only asserts rtol 1e-5)."""
+    worst_r, worst_a, same, total = 0.0, 0.0, 0, 0
+    for seed in range(24):
+        bps = 16 if seed % 2 == 0 else 24
+        n = [4096, 8192, 1152][seed % 3]
+        signal = util.sine_noise(n, bps, 20 + 7 * seed, 0.5, 0.02 + 0.02 * (seed % 5), seed=seed)
+        ref = orc.estimated_qlpc(signal, bps, orc.make_config(lpc_order=10))
+        can = orc.estimated_qlpc(signal, bps, orc.make_config(lpc_order=10, acorr=orc.ACORR_CANONICAL))
+        worst_r = max(worst_r, float(np.max(np.abs(ref["autocorr"] - can["autocorr"])
+                                            / np.abs(ref["autocorr"][0]))))
+        worst_a = max(worst_a, float(np.max(np.abs(ref["lpc_coefs"] - can["lpc_coefs"])
+                                            / np.max(np.abs(ref["lpc_coefs"])))))
+        total += 1
+        if (ref["coefs"].tolist(), ref["shift"]) == (can["coefs"].tolist(), can["shift"]):
+            same += 1
+            assert (ref["residual"] == can["residual"]).all()
+            assert ref["rice_params"].tolist() == can["rice_params"].tolist()
+            assert ref["subframe_bits"] == can["subframe_bits"]
+    assert worst_r < 1e-12, worst_r
+    assert worst_a < 1e-8, worst_a
+    assert same >= total - 1, (same, total)

@@ -1,0 +1,222 @@
+"""ctypes binding of the C ABI in ``include/flacenc_hip.h`` (libflacenc_hip.so).
+
+This is plumbing for the Python test/bench drivers: every compute call goes
+through the same ``extern "C"`` entry points a Rust/C host would bind.  There is
+no CPU fallback -- if the HIP library is missing or no GPU is present the calls
+raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libflacenc_hip.so")
+
+OK = 0
+ERR_BAD_CONFIG = -1
+ERR_BAD_ARGUMENT = -2
+ERR_DEVICE = -3
+ERR_UNSUPPORTED = -4
+ERR_NO_DEVICE = -5
+_ERR_NAMES = {
+    ERR_BAD_CONFIG: "BAD_CONFIG",
+    ERR_BAD_ARGUMENT: "BAD_ARGUMENT",
+    ERR_DEVICE: "DEVICE",
+    ERR_UNSUPPORTED: "UNSUPPORTED",
+    ERR_NO_DEVICE: "NO_DEVICE",
+}
+
+WINDOW_RECTANGLE = 0
+WINDOW_TUKEY = 1
+FLAG_ALLOW_ORDER_32 = 1
+MEM_HOST = 0
+MEM_DEVICE = 1
+
+# every symbol include/flacenc_hip.h declares
+EXPORTED_SYMBOLS = (
+    "flacenc_hip_abi_version",
+    "flacenc_hip_device_count",
+    "flacenc_hip_create",
+    "flacenc_hip_destroy",
+    "flacenc_hip_last_error",
+    "flacenc_hip_verify_config",
+    "flacenc_hip_window_weights",
+    "flacenc_hip_qlpc_batch",
+    "flacenc_hip_qlpc_batch_async",
+    "flacenc_hip_synchronize",
+)
+
+
+class QlpcConfig(C.Structure):
+    """flacenc_hip_qlpc_config == the path's fields of config::Qlpc / config::Prc."""
+
+    _fields_ = [
+        ("lpc_order", C.c_uint32),
+        ("quant_precision", C.c_uint32),
+        ("window_type", C.c_uint32),
+        ("tukey_alpha", C.c_float),
+        ("max_rice_parameter", C.c_uint32),
+        ("flags", C.c_uint32),
+    ]
+
+
+# flacenc_hip_subframe_params (352 bytes)
+PARAMS_DTYPE = np.dtype(
+    [
+        ("coefs", np.int16, (32,)),
+        ("order", np.uint8),
+        ("shift", np.int8),
+        ("precision", np.uint8),
+        ("rice_order", np.uint8),
+        ("status", np.int32),
+        ("code_bits", np.uint64),
+        ("subframe_bits", np.uint64),
+        ("sum_quotients", np.uint64),
+        ("rice_params", np.uint8, (256,)),
+    ],
+    align=True,
+)
+assert PARAMS_DTYPE.itemsize == 352
+
+
+class FlacencHipError(RuntimeError):
+    def __init__(self, code, message=""):
+        self.code = code
+        super().__init__(f"flacenc_hip error {_ERR_NAMES.get(code, code)}: {message}")
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libflacenc_hip.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FileNotFoundError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`"
+            " or `make -C flacenc_rs_amd/csrc`")
+    L = C.CDLL(LIB_PATH)
+    vp, i32p, u8p, f64p = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p
+    L.flacenc_hip_abi_version.restype = C.c_int
+    L.flacenc_hip_device_count.restype = C.c_int
+    L.flacenc_hip_create.argtypes = [C.POINTER(vp), C.c_int]
+    L.flacenc_hip_create.restype = C.c_int
+    L.flacenc_hip_destroy.argtypes = [vp]
+    L.flacenc_hip_destroy.restype = None
+    L.flacenc_hip_last_error.argtypes = [vp]
+    L.flacenc_hip_last_error.restype = C.c_char_p
+    L.flacenc_hip_verify_config.argtypes = [C.POINTER(QlpcConfig)]
+    L.flacenc_hip_verify_config.restype = C.c_int
+    L.flacenc_hip_window_weights.argtypes = [C.POINTER(QlpcConfig), C.c_uint32, vp]
+    L.flacenc_hip_window_weights.restype = C.c_int
+    L.flacenc_hip_synchronize.argtypes = [vp]
+    L.flacenc_hip_synchronize.restype = C.c_int
+    batch_args = [vp, C.POINTER(QlpcConfig), i32p, C.c_size_t, C.c_uint32, C.c_size_t, u8p, vp, i32p,
+                  C.c_size_t, f64p, f64p]
+    L.flacenc_hip_qlpc_batch.argtypes = batch_args + [C.c_int]
+    L.flacenc_hip_qlpc_batch.restype = C.c_int
+    L.flacenc_hip_qlpc_batch_async.argtypes = batch_args + [vp]
+    L.flacenc_hip_qlpc_batch_async.restype = C.c_int
+    _lib = L
+    return L
+
+
+def make_config(lpc_order=10, quant_precision=15, window=("tukey", 0.4), max_rice_parameter=30,
+                flags=0) -> QlpcConfig:
+    """Defaults of config::Qlpc / config::Prc (src/constant.rs:109-115, src/config.rs:216-221)."""
+    if window == "rectangle" or window[0] == "rectangle":
+        wt, alpha = WINDOW_RECTANGLE, 0.0
+    else:
+        wt, alpha = WINDOW_TUKEY, float(window[1])
+    if lpc_order > 24:
+        flags |= FLAG_ALLOW_ORDER_32
+    return QlpcConfig(lpc_order, quant_precision, wt, alpha, max_rice_parameter, flags)
+
+
+def verify_config(cfg: QlpcConfig) -> int:
+    return int(load().flacenc_hip_verify_config(C.byref(cfg)))
+
+
+def window_weights(cfg: QlpcConfig, block_size: int) -> np.ndarray:
+    out = np.empty(block_size, np.float32)
+    rc = load().flacenc_hip_window_weights(C.byref(cfg), block_size, out.ctypes.data)
+    if rc != OK:
+        raise FlacencHipError(rc)
+    return out
+
+
+class Handle:
+    """RAII wrapper of flacenc_hip_handle (one per host thread / GPU)."""
+
+    def __init__(self, device_id: int = 0):
+        self._lib = load()
+        self._h = C.c_void_p()
+        rc = self._lib.flacenc_hip_create(C.byref(self._h), device_id)
+        if rc != OK:
+            raise FlacencHipError(rc, "flacenc_hip_create failed (is a GPU visible?)")
+
+    def close(self):
+        if self._h:
+            self._lib.flacenc_hip_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc):
+        if rc != OK:
+            raise FlacencHipError(rc, self._lib.flacenc_hip_last_error(self._h).decode())
+
+    def synchronize(self):
+        self._check(self._lib.flacenc_hip_synchronize(self._h))
+
+    # -- host-memory path (what the reference's FFI would hand over) ----------
+    def qlpc_batch(self, samples, bps, cfg: QlpcConfig, want_fp: bool = False):
+        """estimated_qlpc over a [n_subframes, block_size] int32 host array.
+
+        Returns (params record array, residual [n_subframes, block_size], R, a).
+        """
+        x = np.ascontiguousarray(samples, np.int32)
+        ns, n = x.shape
+        params = np.zeros(ns, PARAMS_DTYPE)
+        residual = np.zeros((ns, n), np.int32)
+        bps_a = np.ascontiguousarray(np.broadcast_to(np.asarray(bps, np.uint8), (ns,)))
+        R = np.zeros((ns, 33), np.float64) if want_fp else None
+        A = np.zeros((ns, 32), np.float64) if want_fp else None
+        rc = self._lib.flacenc_hip_qlpc_batch(
+            self._h, C.byref(cfg), x.ctypes.data, ns, n, n, bps_a.ctypes.data, params.ctypes.data,
+            residual.ctypes.data, n, R.ctypes.data if want_fp else None,
+            A.ctypes.data if want_fp else None, MEM_HOST)
+        self._check(rc)
+        return params, residual, R, A
+
+    # -- device-memory path (raw pointers; torch tensors' data_ptr()) ---------
+    def qlpc_batch_device(self, cfg: QlpcConfig, samples_ptr: int, n_subframes: int, block_size: int,
+                          stride: int, bps_ptr: int, params_ptr: int, residual_ptr: int,
+                          residual_stride: int, autocorr_ptr: int = 0, lpc_ptr: int = 0,
+                          stream: int | None = None, sync: bool = False):
+        if stream is None and sync:
+            rc = self._lib.flacenc_hip_qlpc_batch(
+                self._h, C.byref(cfg), samples_ptr, n_subframes, block_size, stride, bps_ptr or None,
+                params_ptr, residual_ptr, residual_stride, autocorr_ptr or None, lpc_ptr or None,
+                MEM_DEVICE)
+        else:
+            rc = self._lib.flacenc_hip_qlpc_batch_async(
+                self._h, C.byref(cfg), samples_ptr, n_subframes, block_size, stride, bps_ptr or None,
+                params_ptr, residual_ptr, residual_stride, autocorr_ptr or None, lpc_ptr or None,
+                stream or None)
+        self._check(rc)

@@ -1,0 +1,364 @@
+// flacenc_hip_api.cpp -- the C ABI declared in include/flacenc_hip.h.
+//
+// Owns the per-handle state the reference keeps in thread-locals (`reusable!`,
+// src/lib.rs:92-116): the window cache (WINDOW_CACHE, src/lpc.rs:219-231) and
+// the scratch buffers, here as device memory.  No allocation happens on the
+// device-pointer path once the window for a block size is cached.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "flacenc_hip.h"
+#include "qlpc_kernel.h"
+
+namespace {
+
+struct WindowEntry {
+  uint32_t n;
+  uint32_t type;
+  uint32_t alpha_bits;
+  float* dev;  // 32 pad + rows*16 floats
+  int32_t flat_lo, flat_hi;
+};
+
+struct DeviceBuffer {
+  void* ptr = nullptr;
+  size_t cap = 0;
+};
+
+}  // namespace
+
+struct flacenc_hip_handle {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string last_error;
+  std::vector<WindowEntry> windows;
+  DeviceBuffer d_samples, d_residual, d_params, d_bps, d_autocorr, d_lpc, d_tables;
+};
+
+namespace {
+
+bool set_error(flacenc_hip_handle* h, const char* what, hipError_t err) {
+  if (h) {
+    char buf[512];
+    std::snprintf(buf, sizeof(buf), "%s: %s", what, hipGetErrorString(err));
+    h->last_error = buf;
+  }
+  return false;
+}
+
+#define HIP_TRY(h, expr)                          \
+  do {                                            \
+    hipError_t err__ = (expr);                    \
+    if (err__ != hipSuccess) {                    \
+      set_error((h), #expr, err__);               \
+      return FLACENC_HIP_ERR_DEVICE;              \
+    }                                             \
+  } while (0)
+
+int ensure(flacenc_hip_handle* h, DeviceBuffer& b, size_t bytes) {
+  if (bytes <= b.cap) return FLACENC_HIP_OK;
+  if (b.ptr) HIP_TRY(h, hipFree(b.ptr));
+  b.ptr = nullptr;
+  b.cap = 0;
+  size_t want = bytes + bytes / 4 + 256;
+  HIP_TRY(h, hipMalloc(&b.ptr, want));
+  b.cap = want;
+  return FLACENC_HIP_OK;
+}
+
+// lpc::window_weights, src/lpc.rs:96-120: f32 arithmetic in exactly this order,
+// libm cosf (what f32::cos lowers to on Linux).  Built with -ffp-contract=off.
+void window_weights(uint32_t type, float alpha, size_t len, float* out) {
+  if (type == FLACENC_HIP_WINDOW_RECTANGLE || alpha == 0.0f) {
+    for (size_t t = 0; t < len; ++t) out[t] = 1.0f;
+    return;
+  }
+  const float pi = 3.14159265358979323846f;
+  const float max_t = static_cast<float>(len) - 1.0f;
+  const float alpha_len = alpha * max_t;
+  for (size_t ti = 0; ti < len; ++ti) {
+    const float t = static_cast<float>(ti);
+    float w;
+    if (t < alpha_len / 2.0f) {
+      const float arg = 2.0f * pi * t / alpha_len;
+      w = 0.5f * (1.0f - cosf(arg));
+    } else if (t < max_t - alpha_len / 2.0f) {
+      w = 1.0f;
+    } else {
+      const float arg = 2.0f * pi * (max_t - t) / alpha_len;
+      w = 0.5f * (1.0f - cosf(arg));
+    }
+    out[ti] = w;
+  }
+}
+
+// get_window, src/lpc.rs:222-231.  The reference keys its cache by
+// (size, fingerprint) where the fingerprint quantises alpha to 16 bits
+// (src/lpc.rs:123-132), so two alphas closer than 1/65535 share the first
+// one's table; this cache keys by the exact alpha bits instead.
+int get_window(flacenc_hip_handle* h, const flacenc_hip_qlpc_config* cfg, uint32_t n,
+               const WindowEntry** out) {
+  uint32_t alpha_bits;
+  std::memcpy(&alpha_bits, &cfg->tukey_alpha, 4);
+  uint32_t type = cfg->window_type;
+  if (type == FLACENC_HIP_WINDOW_TUKEY && cfg->tukey_alpha == 0.0f) type = FLACENC_HIP_WINDOW_RECTANGLE;
+  if (type == FLACENC_HIP_WINDOW_RECTANGLE) alpha_bits = 0;
+  for (const WindowEntry& e : h->windows) {
+    if (e.n == n && e.type == type && e.alpha_bits == alpha_bits) {
+      *out = &e;
+      return FLACENC_HIP_OK;
+    }
+  }
+  WindowEntry e;
+  e.n = n;
+  e.type = type;
+  e.alpha_bits = alpha_bits;
+  e.dev = nullptr;
+  e.flat_lo = -64;
+  e.flat_hi = 0x7FFFFFFF;
+  if (type != FLACENC_HIP_WINDOW_RECTANGLE) {
+    const size_t rows = (n + 15) / 16;
+    const size_t total = 32 + rows * 16 + 16;
+    std::vector<float> host(total, 0.0f);
+    window_weights(type, cfg->tukey_alpha, n, host.data() + 32);
+    // longest run of exactly-1.0 weights: chunks inside it skip the table
+    int best_lo = 0, best_hi = 0, run_lo = -1;
+    for (int t = 0; t <= static_cast<int>(n); ++t) {
+      const bool one = t < static_cast<int>(n) && host[32 + t] == 1.0f;
+      if (one && run_lo < 0) run_lo = t;
+      if (!one && run_lo >= 0) {
+        if (t - run_lo > best_hi - best_lo) {
+          best_lo = run_lo;
+          best_hi = t;
+        }
+        run_lo = -1;
+      }
+    }
+    e.flat_lo = best_lo;
+    e.flat_hi = best_hi;
+    HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&e.dev), total * sizeof(float)));
+    HIP_TRY(h, hipMemcpy(e.dev, host.data(), total * sizeof(float), hipMemcpyHostToDevice));
+  }
+  h->windows.push_back(e);
+  *out = &h->windows.back();
+  return FLACENC_HIP_OK;
+}
+
+int check_batch_args(flacenc_hip_handle* h, const flacenc_hip_qlpc_config* cfg, const int32_t* samples,
+                     size_t n_subframes, uint32_t block_size, size_t stride,
+                     flacenc_hip_subframe_params* params, int32_t* residual, size_t residual_stride) {
+  if (!h || !cfg) return FLACENC_HIP_ERR_BAD_ARGUMENT;
+  int rc = flacenc_hip_verify_config(cfg);
+  if (rc != FLACENC_HIP_OK) {
+    h->last_error = "config::Qlpc / config::Prc verification failed";
+    return rc;
+  }
+  if (block_size < FLACENC_HIP_MIN_BLOCK_SIZE || block_size > FLACENC_HIP_MAX_BLOCK_SIZE) {
+    h->last_error = "block_size must be in 64..=32767";
+    return FLACENC_HIP_ERR_BAD_ARGUMENT;
+  }
+  if (n_subframes == 0) return FLACENC_HIP_OK;
+  if (!samples || !params || !residual || stride < block_size || residual_stride < block_size ||
+      n_subframes > 0x7FFFFFFFull) {
+    h->last_error = "null pointer, stride < block_size, or too many subframes";
+    return FLACENC_HIP_ERR_BAD_ARGUMENT;
+  }
+  return FLACENC_HIP_OK;
+}
+
+int enqueue(flacenc_hip_handle* h, const flacenc_hip_qlpc_config* cfg, const int32_t* samples,
+            size_t n_subframes, uint32_t block_size, size_t stride, const uint8_t* bps,
+            flacenc_hip_subframe_params* params, int32_t* residual, size_t residual_stride,
+            double* autocorr, double* lpc_coefs, hipStream_t stream) {
+  const WindowEntry* win = nullptr;
+  int rc = get_window(h, cfg, block_size, &win);
+  if (rc != FLACENC_HIP_OK) return rc;
+  flacenc_hip::QlpcLaunchPlan plan = flacenc_hip::plan_qlpc_launch(block_size, cfg->lpc_order);
+  if (plan.smem_bytes > 160 * 1024) {
+    h->last_error = "internal: LDS plan exceeds 160 KiB";
+    return FLACENC_HIP_ERR_UNSUPPORTED;
+  }
+  flacenc_hip::QlpcKernelArgs a;
+  a.samples = samples;
+  a.stride = stride;
+  a.block_size = block_size;
+  a.n_subframes = static_cast<uint32_t>(n_subframes);
+  a.bps = bps;
+  a.window = win->dev;
+  a.flat_lo = win->flat_lo;
+  a.flat_hi = win->flat_hi;
+  a.lpc_order = cfg->lpc_order;
+  a.precision = cfg->quant_precision;
+  a.max_rice_parameter = cfg->max_rice_parameter;
+  a.params = params;
+  a.residual = residual;
+  a.residual_stride = residual_stride;
+  a.autocorr = autocorr;
+  a.lpc_coefs = lpc_coefs;
+  a.table_scratch = nullptr;
+  if (plan.table_scratch_bytes_per_subframe) {
+    rc = ensure(h, h->d_tables, plan.table_scratch_bytes_per_subframe * n_subframes);
+    if (rc != FLACENC_HIP_OK) return rc;
+    a.table_scratch = static_cast<uint32_t*>(h->d_tables.ptr);
+  }
+  HIP_TRY(h, flacenc_hip::launch_qlpc(a, plan, stream));
+  return FLACENC_HIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int flacenc_hip_abi_version(void) { return FLACENC_HIP_ABI_VERSION; }
+
+int flacenc_hip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int flacenc_hip_create(flacenc_hip_handle** out, int device_id) {
+  if (!out) return FLACENC_HIP_ERR_BAD_ARGUMENT;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return FLACENC_HIP_ERR_NO_DEVICE;
+  if (device_id < 0 || device_id >= n) return FLACENC_HIP_ERR_BAD_ARGUMENT;
+  flacenc_hip_handle* h = new (std::nothrow) flacenc_hip_handle();
+  if (!h) return FLACENC_HIP_ERR_DEVICE;
+  h->device = device_id;
+  if (hipSetDevice(device_id) != hipSuccess ||
+      hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete h;
+    return FLACENC_HIP_ERR_DEVICE;
+  }
+  *out = h;
+  return FLACENC_HIP_OK;
+}
+
+void flacenc_hip_destroy(flacenc_hip_handle* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  for (WindowEntry& e : h->windows)
+    if (e.dev) (void)hipFree(e.dev);
+  for (DeviceBuffer* b : {&h->d_samples, &h->d_residual, &h->d_params, &h->d_bps, &h->d_autocorr,
+                          &h->d_lpc, &h->d_tables})
+    if (b->ptr) (void)hipFree(b->ptr);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+const char* flacenc_hip_last_error(const flacenc_hip_handle* h) {
+  return h ? h->last_error.c_str() : "null handle";
+}
+
+int flacenc_hip_verify_config(const flacenc_hip_qlpc_config* cfg) {
+  if (!cfg) return FLACENC_HIP_ERR_BAD_ARGUMENT;
+  const uint32_t max_order = (cfg->flags & FLACENC_HIP_FLAG_ALLOW_ORDER_32)
+                                 ? FLACENC_HIP_MAX_LPC_ORDER
+                                 : FLACENC_HIP_REF_MAX_LPC_ORDER;
+  // config::Qlpc::verify, src/config.rs:302-326
+  if (cfg->lpc_order < 1 || cfg->lpc_order > max_order) return FLACENC_HIP_ERR_BAD_CONFIG;
+  if (cfg->quant_precision < 1 || cfg->quant_precision > FLACENC_HIP_MAX_PRECISION)
+    return FLACENC_HIP_ERR_BAD_CONFIG;
+  // config::Window::verify, src/config.rs:371-387
+  if (cfg->window_type == FLACENC_HIP_WINDOW_TUKEY) {
+    if (!(cfg->tukey_alpha >= 0.0f && cfg->tukey_alpha <= 1.0f)) return FLACENC_HIP_ERR_BAD_CONFIG;
+  } else if (cfg->window_type != FLACENC_HIP_WINDOW_RECTANGLE) {
+    return FLACENC_HIP_ERR_BAD_CONFIG;
+  }
+  // config::Prc::verify, src/config.rs:224-229
+  if (cfg->max_rice_parameter > FLACENC_HIP_MAX_RICE_PARAMETER) return FLACENC_HIP_ERR_BAD_CONFIG;
+  return FLACENC_HIP_OK;
+}
+
+int flacenc_hip_window_weights(const flacenc_hip_qlpc_config* cfg, uint32_t block_size, float* out) {
+  if (!cfg || !out) return FLACENC_HIP_ERR_BAD_ARGUMENT;
+  int rc = flacenc_hip_verify_config(cfg);
+  if (rc != FLACENC_HIP_OK) return rc;
+  window_weights(cfg->window_type, cfg->tukey_alpha, block_size, out);
+  return FLACENC_HIP_OK;
+}
+
+int flacenc_hip_synchronize(flacenc_hip_handle* h) {
+  if (!h) return FLACENC_HIP_ERR_BAD_ARGUMENT;
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return FLACENC_HIP_OK;
+}
+
+int flacenc_hip_qlpc_batch_async(flacenc_hip_handle* h, const flacenc_hip_qlpc_config* cfg,
+                                 const int32_t* samples, size_t n_subframes, uint32_t block_size,
+                                 size_t stride, const uint8_t* bps,
+                                 flacenc_hip_subframe_params* params, int32_t* residual,
+                                 size_t residual_stride, double* autocorr, double* lpc_coefs,
+                                 void* stream) {
+  int rc = check_batch_args(h, cfg, samples, n_subframes, block_size, stride, params, residual,
+                            residual_stride);
+  if (rc != FLACENC_HIP_OK || n_subframes == 0) return rc;
+  HIP_TRY(h, hipSetDevice(h->device));
+  hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
+  return enqueue(h, cfg, samples, n_subframes, block_size, stride, bps, params, residual,
+                 residual_stride, autocorr, lpc_coefs, s);
+}
+
+int flacenc_hip_qlpc_batch(flacenc_hip_handle* h, const flacenc_hip_qlpc_config* cfg,
+                           const int32_t* samples, size_t n_subframes, uint32_t block_size,
+                           size_t stride, const uint8_t* bps,
+                           flacenc_hip_subframe_params* params, int32_t* residual,
+                           size_t residual_stride, double* autocorr, double* lpc_coefs,
+                           int memory_kind) {
+  int rc = check_batch_args(h, cfg, samples, n_subframes, block_size, stride, params, residual,
+                            residual_stride);
+  if (rc != FLACENC_HIP_OK || n_subframes == 0) return rc;
+  HIP_TRY(h, hipSetDevice(h->device));
+  if (memory_kind == FLACENC_HIP_MEM_DEVICE) {
+    rc = enqueue(h, cfg, samples, n_subframes, block_size, stride, bps, params, residual,
+                 residual_stride, autocorr, lpc_coefs, h->stream);
+    if (rc != FLACENC_HIP_OK) return rc;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return FLACENC_HIP_OK;
+  }
+  if (memory_kind != FLACENC_HIP_MEM_HOST) return FLACENC_HIP_ERR_BAD_ARGUMENT;
+
+  // host pointers: stage through the handle's device scratch (PCIe both ways)
+  const size_t dstride = (static_cast<size_t>(block_size) + 3) & ~static_cast<size_t>(3);
+  if ((rc = ensure(h, h->d_samples, n_subframes * dstride * 4)) != FLACENC_HIP_OK) return rc;
+  if ((rc = ensure(h, h->d_residual, n_subframes * dstride * 4)) != FLACENC_HIP_OK) return rc;
+  if ((rc = ensure(h, h->d_params, n_subframes * sizeof(flacenc_hip_subframe_params))) != FLACENC_HIP_OK)
+    return rc;
+  if (bps && (rc = ensure(h, h->d_bps, n_subframes)) != FLACENC_HIP_OK) return rc;
+  if (autocorr && (rc = ensure(h, h->d_autocorr, n_subframes * 33 * 8)) != FLACENC_HIP_OK) return rc;
+  if (lpc_coefs && (rc = ensure(h, h->d_lpc, n_subframes * 32 * 8)) != FLACENC_HIP_OK) return rc;
+  hipStream_t s = h->stream;
+  HIP_TRY(h, hipMemcpy2DAsync(h->d_samples.ptr, dstride * 4, samples, stride * 4,
+                              static_cast<size_t>(block_size) * 4, n_subframes,
+                              hipMemcpyHostToDevice, s));
+  if (bps) HIP_TRY(h, hipMemcpyAsync(h->d_bps.ptr, bps, n_subframes, hipMemcpyHostToDevice, s));
+  rc = enqueue(h, cfg, static_cast<const int32_t*>(h->d_samples.ptr), n_subframes, block_size, dstride,
+               bps ? static_cast<const uint8_t*>(h->d_bps.ptr) : nullptr,
+               static_cast<flacenc_hip_subframe_params*>(h->d_params.ptr),
+               static_cast<int32_t*>(h->d_residual.ptr), dstride,
+               autocorr ? static_cast<double*>(h->d_autocorr.ptr) : nullptr,
+               lpc_coefs ? static_cast<double*>(h->d_lpc.ptr) : nullptr, s);
+  if (rc != FLACENC_HIP_OK) return rc;
+  HIP_TRY(h, hipMemcpy2DAsync(residual, residual_stride * 4, h->d_residual.ptr, dstride * 4,
+                              static_cast<size_t>(block_size) * 4, n_subframes,
+                              hipMemcpyDeviceToHost, s));
+  HIP_TRY(h, hipMemcpyAsync(params, h->d_params.ptr, n_subframes * sizeof(flacenc_hip_subframe_params),
+                            hipMemcpyDeviceToHost, s));
+  if (autocorr)
+    HIP_TRY(h, hipMemcpyAsync(autocorr, h->d_autocorr.ptr, n_subframes * 33 * 8, hipMemcpyDeviceToHost, s));
+  if (lpc_coefs)
+    HIP_TRY(h, hipMemcpyAsync(lpc_coefs, h->d_lpc.ptr, n_subframes * 32 * 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(h, hipStreamSynchronize(s));
+  return FLACENC_HIP_OK;
+}
+
+}  // extern "C"

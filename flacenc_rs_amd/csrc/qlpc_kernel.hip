@@ -1,0 +1,714 @@
+// qlpc_kernel.hip -- the QLPC analysis hot path as one fused HIP kernel for gfx950.
+//
+// One workgroup analyses one subframe (one channel of one block), start to
+// finish, with the samples staged once in LDS:
+//
+//   phase 0  coalesced int32 loads HBM -> LDS (padded 16-sample rows), max|s|
+//   phase 1  Tukey windowing in f32 + autocorrelation R[0..=P] in f64
+//            (lpc.rs:739-756, 533-548): every thread owns 16-sample chunks, keeps
+//            the windowed samples of its chunk (+P halo) in registers and runs
+//            P+1 independent fma chains; chunk partials are combined by a
+//            balanced tree (wave butterfly, then LDS) -- the build's canonical
+//            summation order, reproduced bit-for-bit by the CPU oracle
+//   phase 2  Levinson-Durbin + coefficient quantisation (lpc.rs:633-705, 234-302),
+//            serial, one lane, registers only
+//   phase 3  integer residual (lpc.rs:306-390) from the LDS-resident samples,
+//            written back over them in LDS
+//   phase 4  partitioned-Rice parameter search (rice.rs:65-165, 246-298): per
+//            finest partition a 32-entry bit table, then log2 merges
+//   phase 5  coalesced residual store LDS -> HBM, one parameter record
+//
+// Algorithmic HBM traffic: 4 B read + 4 B written per sample.
+// All `file:line` citations are relative to the flacenc-rs v0.5.1 tree.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "flacenc_hip.h"
+#include "qlpc_kernel.h"
+
+namespace flacenc_hip {
+namespace {
+
+constexpr uint32_t kMaxPToBits = (1u << 27) - 1u;  // rice.rs:51
+constexpr int kLeadRows = 2;                       // zero rows in front of the samples (halo of chunk 0/1)
+
+// ---------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t zigzag(int32_t e) {  // rice::encode_signbit, rice.rs:169-171
+  return ((uint32_t)e << 1) ^ (uint32_t)(e >> 31);
+}
+
+__device__ __forceinline__ double wave_butterfly_sum(double v) {
+  // balanced pairwise tree over the lane index: level k adds lanes i and i^(1<<k)
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) {
+    uint32_t o = (uint32_t)__shfl_xor((int)v, m, 64);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+
+__device__ __forceinline__ uint32_t wave_or_u32(uint32_t v) {
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) v |= (uint32_t)__shfl_xor((int)v, m, 64);
+  return v;
+}
+
+// exact ceil(log2(m)) for finite m > 0 from the exponent/mantissa fields
+__device__ __forceinline__ int ceil_log2_pos(double m) {
+  uint64_t b = (uint64_t)__double_as_longlong(m);
+  int e = (int)((b >> 52) & 0x7FF);
+  uint64_t frac = b & 0xFFFFFFFFFFFFFull;
+  if (e == 0) return -32752;  // zero / subnormal: far below the clamp of lpc.rs:247-250
+  return (e - 1023) + (frac != 0 ? 1 : 0);
+}
+
+// LDS layout ------------------------------------------------------------------
+// Samples live in rows of 16 int32 with a row stride of ROWSTRIDE dwords
+// (20 = 16 + 4 pad: a thread reading its own row with ds_read_b128 then lands
+// on a distinct 4-bank group for any 16 consecutive lanes; 16 = unpadded, for
+// blocks too large for the padded image).  Two all-zero rows precede row 0.
+template <int ROWSTRIDE>
+__device__ __forceinline__ int sidx(int t) {
+  return ((t >> 4) + kLeadRows) * ROWSTRIDE + (t & 15);
+}
+
+struct SmemLayout {
+  int32_t* sbuf;
+  uint32_t* tables;
+  double* red;
+  double* racc;    // R[33]
+  int32_t* qc;     // 32 quantised coefficients as int32
+  uint32_t* misc;  // see kMisc*
+  unsigned long long* level_bits;  // [9]
+  uint8_t* ps;     // per-level rice parameters, 2*nparts bytes
+};
+
+enum {
+  kMiscMaxAbs = 0,
+  kMiscOrder,
+  kMiscShift,
+  kMiscStatus,
+  kMiscWide,
+  kMiscOrBits,
+  kMiscSat,
+  kMiscBestOrder,
+  kMiscCount = 16
+};
+
+// ---------------------------------------------------------------------------
+// phase 2: Levinson-Durbin + quantisation, one lane, fully unrolled
+// ---------------------------------------------------------------------------
+// symmetric_levinson_recursion::<f64, _>, lpc.rs:633-705, with
+// coefs = R[0..P], ys = R[1..P+1] (lpc.rs:792-796).  NOTE lpc.rs:679-682: the
+// unlabeled `continue` targets `for n in 1..order`, so a zero denominator
+// skips iteration n (it does not restart).  Operation order and every fma
+// follow the reference; forward[] is updated in place pairwise (d, n-d) which
+// reads exactly the old values forward_next[] would be computed from.
+template <int MAXP>
+__device__ int levinson_quantize(const double* __restrict__ Rl, int P, int precision,
+                                 double (&a)[MAXP], int32_t* qc_out, int* order_out,
+                                 int* shift_out) {
+  double R[MAXP + 1];
+#pragma unroll
+  for (int i = 0; i <= MAXP; ++i) R[i] = (i <= P) ? Rl[i] : 0.0;
+#pragma unroll
+  for (int i = 0; i < MAXP; ++i) a[i] = 0.0;
+
+  int status = FLACENC_HIP_SUBFRAME_OK;
+#pragma unroll
+  for (int i = 0; i <= MAXP; ++i) {
+    if (i <= P) {
+      uint64_t b = (uint64_t)__double_as_longlong(R[i]);
+      if (((b >> 52) & 0x7FF) == 0x7FF) status |= FLACENC_HIP_SUBFRAME_NONFINITE;  // lpc.rs:786-791
+    }
+  }
+  if (status == 0 && !(R[0] >= 0.0)) status |= FLACENC_HIP_SUBFRAME_NEG_ENERGY;  // lpc.rs:646
+  if (status == 0 && R[0] == 0.0) {
+    bool allzero = true;
+#pragma unroll
+    for (int i = 0; i <= MAXP; ++i)
+      if (i <= P && R[i] != 0.0) allzero = false;
+    if (!allzero) status |= FLACENC_HIP_SUBFRAME_NEG_ENERGY;  // lpc.rs:652-655
+  }
+
+  if (status == 0 && R[0] != 0.0) {
+    double fwd[MAXP];
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i) fwd[i] = 0.0;
+    fwd[0] = 1.0 / R[0];   // Float::recip(coefs[0] + diagonal_loading), loading = 0
+    a[0] = R[1] / R[0];    // ys[0] / (coefs[0] + diagonal_loading)
+#pragma unroll
+    for (int n = 1; n < MAXP; ++n) {
+      if (n < P) {
+        double err = 0.0;
+#pragma unroll
+        for (int d = 0; d < n; ++d) err = __builtin_fma(R[n - d], fwd[d], err);
+        double denom = __builtin_fma(err, -err, 1.0);
+        if (denom != 0.0) {
+          double alpha = 1.0 / denom;
+          double beta = -alpha * err;
+          // forward_next[d] = fma(alpha, forward[d], beta * forward[n - d]), d <= n
+#pragma unroll
+          for (int d = 0; 2 * d <= n; ++d) {
+            double fd = fwd[d], fe = fwd[n - d];
+            double nd = __builtin_fma(alpha, fd, beta * fe);
+            double ne = __builtin_fma(alpha, fe, beta * fd);
+            fwd[d] = nd;
+            fwd[n - d] = ne;
+          }
+          double delta = 0.0;
+#pragma unroll
+          for (int d = 0; d < n; ++d) delta = __builtin_fma(R[n - d], a[d], delta);
+          double resid = R[n + 1] - delta;  // ys[n] - delta
+#pragma unroll
+          for (int d = 0; d <= n; ++d) a[d] = __builtin_fma(resid, fwd[n - d], a[d]);
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i) {
+      if (i < P) {
+        uint64_t b = (uint64_t)__double_as_longlong(a[i]);
+        if (((b >> 52) & 0x7FF) == 0x7FF) status |= FLACENC_HIP_SUBFRAME_NONFINITE;  // lpc.rs:797-799
+      }
+    }
+  }
+
+  // quantize_parameters, lpc.rs:273-302 (find_shift :234-254, quantize_parameter :258-270)
+  int shift = 0, order = 0;
+#pragma unroll
+  for (int i = 0; i < MAXP; ++i) qc_out[i] = 0;
+  if (status == 0) {
+    double max_abs = 0.0;
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i)
+      if (i < P) max_abs = fmax(max_abs, fabs(a[i]));
+    int abs_log2 = ceil_log2_pos(max_abs);
+    if (abs_log2 < -32752) abs_log2 = -32752;
+    shift = (precision - 1) - abs_log2;
+    shift = shift < 0 ? 0 : (shift > 15 ? 15 : shift);
+    double scalefac = (double)(1 << shift);
+    int lo = -(1 << (precision - 1)), hi = (1 << (precision - 1)) - 1;
+    order = 1;
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i) {
+      if (i < P) {
+        double s = round(a[i] * scalefac);  // half away from zero
+        s = s < -32768.0 ? -32768.0 : (s > 32767.0 ? 32767.0 : s);
+        int q = (int)s;
+        q = q < lo ? lo : (q > hi ? hi : q);
+        qc_out[i] = q;
+        if (q != 0) order = i + 1;  // tail-zero truncation, min 1 (lpc.rs:295-299)
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i)
+      if (i >= order) qc_out[i] = 0;
+  }
+  *order_out = order;
+  *shift_out = shift;
+  return status;
+}
+
+// ---------------------------------------------------------------------------
+// phase 1 inner block: 16 samples x (MAXP+1) lags, registers only
+// ---------------------------------------------------------------------------
+template <int MAXP, int HP, bool MASK>
+__device__ __forceinline__ void acorr_chunk(const double (&dw)[HP + 16], double (&acc)[MAXP + 1],
+                                            int t0, int P) {
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    double cur = dw[HP + k];
+    if (MASK) cur = (t0 + k >= P) ? cur : 0.0;  // common lower bound t = P for every lag (lpc.rs:542)
+#pragma unroll
+    for (int tau = 0; tau <= MAXP; ++tau) acc[tau] = __builtin_fma(cur, dw[HP + k - tau], acc[tau]);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// the fused kernel
+// ---------------------------------------------------------------------------
+template <int MAXP, bool BIG>
+__global__ void __launch_bounds__(MAXP <= 12 ? 1024 : (MAXP <= 16 ? 512 : 256))
+qlpc_subframe_kernel(QlpcKernelArgs a) {
+  constexpr int ROWSTRIDE = BIG ? 16 : 20;
+  constexpr int HP = (MAXP + 3) & ~3;  // halo samples loaded, multiple of 4
+  constexpr int NLAG = MAXP + 1;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+
+  const int tid = threadIdx.x;
+  const int T = blockDim.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int W = T >> 6;
+  const int n = (int)a.block_size;
+  const int rows = (n + 15) >> 4;
+  const int J = (rows + T - 1) / T;
+  int Jp = 1;
+  while (Jp < J) Jp <<= 1;
+  const int P = (int)a.lpc_order;
+  const uint32_t sf = blockIdx.x;
+
+  // ---- carve LDS (every offset a multiple of 16 bytes) ----
+  SmemLayout L;
+  {
+    unsigned char* p = smem_raw;
+    L.sbuf = reinterpret_cast<int32_t*>(p);
+    p += (size_t)(rows + kLeadRows) * ROWSTRIDE * 4;
+    L.red = reinterpret_cast<double*>(p);
+    p += (size_t)Jp * W * NLAG * 8;
+    p = smem_raw + (((size_t)(p - smem_raw) + 15) & ~(size_t)15);
+    L.racc = reinterpret_cast<double*>(p);
+    p += 40 * 8;
+    L.level_bits = reinterpret_cast<unsigned long long*>(p);
+    p += 16 * 8;
+    L.qc = reinterpret_cast<int32_t*>(p);
+    p += 32 * 4;
+    L.misc = reinterpret_cast<uint32_t*>(p);
+    p += kMiscCount * 4;
+    L.ps = reinterpret_cast<uint8_t*>(p);
+    p += 2 * FLACENC_HIP_MAX_RICE_PARTITIONS;
+    L.tables = BIG ? (a.table_scratch + (size_t)sf * FLACENC_HIP_MAX_RICE_PARTITIONS * 32)
+                   : reinterpret_cast<uint32_t*>(p);
+  }
+
+  // ======================= phase 0: load ===================================
+  const int32_t* __restrict__ src = a.samples + (size_t)sf * a.stride;
+  if (tid < kMiscCount) L.misc[tid] = 0;
+  if (tid < 16) L.level_bits[tid] = 0ull;
+  for (int i = tid; i < kLeadRows * ROWSTRIDE; i += T) L.sbuf[i] = 0;
+  uint32_t my_maxabs = 0;
+  {
+    const bool vec_ok = ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
+    for (int q = tid; q < rows * 4; q += T) {
+      int t = q * 4;
+      int4 v;
+      if (vec_ok && t + 3 < n) {
+        v = *reinterpret_cast<const int4*>(src + t);
+      } else {
+        v.x = (t + 0 < n) ? src[t + 0] : 0;
+        v.y = (t + 1 < n) ? src[t + 1] : 0;
+        v.z = (t + 2 < n) ? src[t + 2] : 0;
+        v.w = (t + 3 < n) ? src[t + 3] : 0;
+      }
+      *reinterpret_cast<int4*>(&L.sbuf[sidx<ROWSTRIDE>(t)]) = v;
+      uint32_t ax = (uint32_t)(v.x < 0 ? -(int64_t)v.x : (int64_t)v.x);
+      uint32_t ay = (uint32_t)(v.y < 0 ? -(int64_t)v.y : (int64_t)v.y);
+      uint32_t az = (uint32_t)(v.z < 0 ? -(int64_t)v.z : (int64_t)v.z);
+      uint32_t aw = (uint32_t)(v.w < 0 ? -(int64_t)v.w : (int64_t)v.w);
+      ax = ax > ay ? ax : ay;
+      az = az > aw ? az : aw;
+      ax = ax > az ? ax : az;
+      my_maxabs = my_maxabs > ax ? my_maxabs : ax;
+    }
+  }
+  __syncthreads();
+  my_maxabs = wave_max_u32(my_maxabs);
+  if (lane == 0) atomicMax(&L.misc[kMiscMaxAbs], my_maxabs);
+
+  // ======================= phase 1: window + autocorrelation ==============
+  // window table has 32 floats of zero padding in front and is padded to whole rows
+  const float* __restrict__ wtab = a.window ? (a.window + 32) : nullptr;
+  for (int j = 0; j < J; ++j) {
+    const int c = tid + j * T;  // chunk index
+    const int t0 = c << 4;
+    double acc[NLAG];
+#pragma unroll
+    for (int i = 0; i < NLAG; ++i) acc[i] = 0.0;
+    if (c < rows) {
+      // samples t0-HP .. t0+15 from LDS
+      int sw[HP + 16];
+#pragma unroll
+      for (int i = 0; i < (HP + 16) / 4; ++i) {
+        int t = t0 - HP + 4 * i;
+        int4 v = *reinterpret_cast<const int4*>(&L.sbuf[sidx<ROWSTRIDE>(t)]);
+        sw[4 * i + 0] = v.x;
+        sw[4 * i + 1] = v.y;
+        sw[4 * i + 2] = v.z;
+        sw[4 * i + 3] = v.w;
+      }
+      double dw[HP + 16];
+      const bool flat = (wtab == nullptr) || (t0 - HP >= a.flat_lo && t0 + 16 <= a.flat_hi);
+      if (flat) {
+        // w == 1.0f: (f32)s * 1.0f == (f32)s exactly (lpc.rs:751-754)
+#pragma unroll
+        for (int i = 0; i < HP + 16; ++i) dw[i] = (double)(float)sw[i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < (HP + 16) / 4; ++i) {
+          float4 wv = *reinterpret_cast<const float4*>(wtab + (t0 - HP + 4 * i));
+          dw[4 * i + 0] = (double)((float)sw[4 * i + 0] * wv.x);
+          dw[4 * i + 1] = (double)((float)sw[4 * i + 1] * wv.y);
+          dw[4 * i + 2] = (double)((float)sw[4 * i + 2] * wv.z);
+          dw[4 * i + 3] = (double)((float)sw[4 * i + 3] * wv.w);
+        }
+      }
+      if (t0 < P) acorr_chunk<MAXP, HP, true>(dw, acc, t0, P);
+      else acorr_chunk<MAXP, HP, false>(dw, acc, t0, P);
+    }
+    // balanced tree over the chunk index: lanes first ...
+#pragma unroll
+    for (int tau = 0; tau < NLAG; ++tau) {
+      double v = wave_butterfly_sum(acc[tau]);
+      if (lane == 0) L.red[((size_t)j * W + wave) * NLAG + tau] = v;
+    }
+  }
+  for (int i = tid; i < (Jp - J) * W * NLAG; i += T) L.red[(size_t)J * W * NLAG + i] = 0.0;
+  __syncthreads();
+  // ... then waves and chunk rounds (entry e = j*W + w are the chunk index's high bits)
+  if (tid < NLAG) {
+    const int E = Jp * W;
+    for (int s = 1; s < E; s <<= 1)
+      for (int e = 0; e < E; e += 2 * s)
+        L.red[(size_t)e * NLAG + tid] += L.red[(size_t)(e + s) * NLAG + tid];
+    double r = L.red[tid];
+    L.racc[tid] = r;
+    if (a.autocorr) a.autocorr[(size_t)sf * 33 + tid] = (tid <= P) ? r : 0.0;
+  }
+  if (a.autocorr && tid >= NLAG && tid < 33) a.autocorr[(size_t)sf * 33 + tid] = 0.0;
+  __syncthreads();
+
+  // ======================= phase 2: Levinson + quantisation ================
+  if (tid == 0) {
+    double coef[MAXP];
+    int32_t qc[MAXP];
+    int order, shift;
+    int status = levinson_quantize<MAXP>(L.racc, P, (int)a.precision, coef, qc, &order, &shift);
+    int64_t sumabs = 0;
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i) {
+      L.qc[i] = qc[i];
+      sumabs += qc[i] < 0 ? -qc[i] : qc[i];
+    }
+    for (int i = MAXP; i < 32; ++i) L.qc[i] = 0;
+    // compute_error's path choice (lpc.rs:361-377): i32 lanes iff max|s| * sum|c| < i32::MAX.
+    // The narrow path below additionally needs |s| < 2^23 for the 24-bit multiplier.
+    uint64_t maxabs = (uint64_t)L.misc[kMiscMaxAbs];
+    bool narrow = (maxabs * (uint64_t)sumabs < 0x7FFFFFFFull) && (maxabs < (1u << 23));
+    L.misc[kMiscOrder] = (uint32_t)order;
+    L.misc[kMiscShift] = (uint32_t)shift;
+    L.misc[kMiscStatus] = (uint32_t)status;
+    L.misc[kMiscWide] = narrow ? 0u : 1u;
+    if (a.lpc_coefs) {
+#pragma unroll
+      for (int i = 0; i < MAXP; ++i) a.lpc_coefs[(size_t)sf * 32 + i] = (i < P && status == 0) ? coef[i] : 0.0;
+      for (int i = MAXP; i < 32; ++i) a.lpc_coefs[(size_t)sf * 32 + i] = 0.0;
+    }
+  }
+  __syncthreads();
+
+  const int warm = (int)L.misc[kMiscOrder];
+  const int shift = (int)L.misc[kMiscShift];
+  const int status = (int)L.misc[kMiscStatus];
+  const bool wide = L.misc[kMiscWide] != 0;
+
+  // ======================= phase 3: residual ===============================
+  // e[t] = s[t] - ((sum_j c_j * s[t-1-j]) >> shift), e[0..order') = 0 (lpc.rs:306-350).
+  // Chunk rounds run downwards so a round only overwrites rows no later round reads.
+  uint32_t my_or = 0;
+  {
+    int32_t cq[MAXP];
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i) cq[i] = L.qc[i];
+    for (int j = J - 1; j >= 0; --j) {
+      const int c = tid + j * T;
+      const int t0 = c << 4;
+      int32_t e[16];
+      if (c < rows) {
+        int sw[HP + 16];
+#pragma unroll
+        for (int i = 0; i < (HP + 16) / 4; ++i) {
+          int t = t0 - HP + 4 * i;
+          int4 v = *reinterpret_cast<const int4*>(&L.sbuf[sidx<ROWSTRIDE>(t)]);
+          sw[4 * i + 0] = v.x;
+          sw[4 * i + 1] = v.y;
+          sw[4 * i + 2] = v.z;
+          sw[4 * i + 3] = v.w;
+        }
+        if (!wide) {
+#pragma unroll
+          for (int k = 0; k < 16; ++k) {
+            int32_t pred = 0;
+#pragma unroll
+            for (int i = 0; i < MAXP; ++i) pred += __mul24(cq[i], sw[HP + k - 1 - i]);
+            e[k] = sw[HP + k] - (pred >> shift);
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < 16; ++k) {
+            int64_t pred = 0;
+#pragma unroll
+            for (int i = 0; i < MAXP; ++i) pred += (int64_t)cq[i] * (int64_t)sw[HP + k - 1 - i];
+            e[k] = (int32_t)(uint32_t)(uint64_t)((int64_t)sw[HP + k] - (pred >> shift));
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          int t = t0 + k;
+          if (t < warm || t >= n || status != 0) e[k] = 0;
+          my_or |= zigzag(e[k]);
+        }
+      }
+      __syncthreads();
+      if (c < rows) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          int4 v;
+          v.x = e[4 * i + 0];
+          v.y = e[4 * i + 1];
+          v.z = e[4 * i + 2];
+          v.w = e[4 * i + 3];
+          *reinterpret_cast<int4*>(&L.sbuf[sidx<ROWSTRIDE>(t0 + 4 * i)]) = v;
+        }
+      }
+    }
+  }
+  my_or = wave_or_u32(my_or);
+  if (lane == 0) atomicOr(&L.misc[kMiscOrBits], my_or);
+  __syncthreads();
+
+  // ======================= phase 4: partitioned-Rice search ================
+  // finest_partition_order(n, max(64, warm)), rice.rs:157-165, 247-250 (warm <= 32 < 64)
+  int fo;
+  {
+    uint32_t max_splits = (uint32_t)n / 64u;
+    int lg = 31 - __clz((int)max_splits);
+    int tz = __ffs(n) - 1;
+    fo = lg < tz ? lg : tz;
+    fo = fo < 15 ? fo : 15;
+    if (fo > 8) fo = 8;  // unreachable for n <= 32767
+  }
+  const int nparts = 1 << fo;
+  const int psize = n >> fo;
+  const int hw = tid >> 5;      // half-wave id: one bit table (32 lanes = 32 parameters) each
+  const int NHW = T >> 5;
+  const uint32_t p = (uint32_t)(tid & 31);
+  const uint32_t max_p = a.max_rice_parameter;
+
+  // PrcBitTable::from_errors(errs, 4), rice.rs:65-103, literally: u32 wrapping adds,
+  // clamp after every 16 samples of the partition's slice and after the offset.
+  for (int q = hw; q < nparts; q += NHW) {
+    int start = q * psize;
+    if (start < warm) start = warm;
+    const int end = (q + 1) * psize;
+    const int len = end - start;
+    uint32_t accb = 0;
+    for (int i = 0; i < len; ++i) {
+      uint32_t u = zigzag(L.sbuf[sidx<ROWSTRIDE>(start + i)]);
+      accb += u >> p;
+      if ((i & 15) == 15) accb = accb < kMaxPToBits ? accb : kMaxPToBits;
+    }
+    accb = accb < kMaxPToBits ? accb : kMaxPToBits;
+    uint32_t v = accb + (4u + (uint32_t)len * (p + 1u));
+    v = v < kMaxPToBits ? v : kMaxPToBits;
+    L.tables[(size_t)q * 32 + p] = v;
+  }
+  if (BIG) __threadfence_block();
+  __syncthreads();
+
+  // eval_partitions / merge_partitions over all orders fo, fo-1, ..., 0
+  // (rice.rs:193-216, 277-291).  Level k keeps its tables at indices q << k.
+  for (int k = 0; k <= fo; ++k) {
+    const int m = nparts >> k;
+    const int stride = 1 << k;
+    uint8_t* ps_k = L.ps + (2 * nparts - 2 * m);  // level k owns m bytes at this offset
+    for (int q = hw; q < m; q += NHW) {
+      const size_t idx = (size_t)q * stride;
+      uint32_t v = L.tables[idx * 32 + p];
+      if (k > 0) {
+        // PrcBitTable::merge(other, 4), rice.rs:144-152
+        uint32_t o = L.tables[(idx + (stride >> 1)) * 32 + p];
+        v = v + o - 4u;
+        v = v < kMaxPToBits ? v : kMaxPToBits;
+        L.tables[idx * 32 + p] = v;
+      }
+      // PrcBitTable::minimizer(max_p), rice.rs:115-141: min of (bits << 5) | p, ties -> smallest p
+      uint32_t packed = (((p <= max_p) ? v : 0xFFFFFFFFu) << 5) | p;
+#pragma unroll
+      for (int msk = 1; msk < 32; msk <<= 1) {
+        uint32_t o = (uint32_t)__shfl_xor((int)packed, msk, 64);
+        packed = o < packed ? o : packed;
+      }
+      if (p == 0) {
+        uint32_t bits = packed >> 5;
+        ps_k[q] = (uint8_t)(packed & 31u);
+        atomicAdd(&L.level_bits[k], (unsigned long long)bits);
+        if (bits >= kMaxPToBits) atomicOr(&L.misc[kMiscSat], 1u << k);
+      }
+    }
+    if (BIG) __threadfence_block();
+    __syncthreads();
+  }
+
+  // pick the order: start at the finest, move to a coarser one only on strictly
+  // fewer bits (rice.rs:285) -> among equal totals the finest wins.
+  if (tid == 0) {
+    int best = 0;
+    unsigned long long best_bits = L.level_bits[0];
+    for (int k = 1; k <= fo; ++k) {
+      if (L.level_bits[k] < best_bits) {
+        best_bits = L.level_bits[k];
+        best = k;
+      }
+    }
+    L.misc[kMiscBestOrder] = (uint32_t)best;
+  }
+  __syncthreads();
+  const int bestk = (int)L.misc[kMiscBestOrder];
+  const int rice_order = fo - bestk;
+  const int best_parts = nparts >> bestk;
+  const uint8_t* best_ps = L.ps + (2 * nparts - 2 * best_parts);
+  const int best_psize = n >> rice_order;
+  const unsigned long long code_bits = L.level_bits[bestk];
+
+  // ======================= phase 5: outputs ================================
+  int32_t* __restrict__ dst = a.residual + (size_t)sf * a.residual_stride;
+  {
+    const bool vec_ok = ((reinterpret_cast<uintptr_t>(dst) & 15) == 0);
+    for (int q = tid; q < rows * 4; q += T) {
+      int t = q * 4;
+      int4 v = *reinterpret_cast<const int4*>(&L.sbuf[sidx<ROWSTRIDE>(t)]);
+      if (vec_ok && t + 3 < n) {
+        *reinterpret_cast<int4*>(dst + t) = v;
+      } else {
+        if (t + 0 < n) dst[t + 0] = v.x;
+        if (t + 1 < n) dst[t + 1] = v.y;
+        if (t + 2 < n) dst[t + 2] = v.z;
+        if (t + 3 < n) dst[t + 3] = v.w;
+      }
+    }
+  }
+
+  // Residual::sum_quotients (datatype.rs:2325-2331).  When no selected table entry
+  // saturated it follows from code_bits: code_bits = sum_q + 4*parts + (n - warm)
+  // + sum_k p_k * len_k (rice.rs:69-71, 95-98).  Otherwise count it from the samples.
+  unsigned long long sum_q = 0;
+  const bool saturated = (L.misc[kMiscSat] >> bestk) & 1u;
+  if (saturated) {
+    unsigned long long mine = 0;
+    for (int t = tid; t < n; t += T) {
+      if (t >= warm) {
+        uint32_t u = zigzag(L.sbuf[sidx<ROWSTRIDE>(t)]);
+        mine += (unsigned long long)(u >> best_ps[t / best_psize]);
+      }
+    }
+    __syncthreads();
+    if (tid == 0) L.level_bits[15] = 0ull;
+    __syncthreads();
+    atomicAdd(&L.level_bits[15], mine);
+    __syncthreads();
+    sum_q = L.level_bits[15];
+  }
+
+  flacenc_hip_subframe_params* rec = a.params + sf;
+  for (int i = tid; i < FLACENC_HIP_MAX_RICE_PARTITIONS; i += T)
+    rec->rice_params[i] = (i < best_parts && status == 0) ? best_ps[i] : (uint8_t)0;
+  if (tid < 32) rec->coefs[tid] = (status == 0) ? (int16_t)L.qc[tid] : (int16_t)0;
+  if (tid == 0) {
+    unsigned long long sum_p = 0;
+    for (int i = 0; i < best_parts; ++i) sum_p += best_ps[i];
+    if (!saturated) {
+      sum_q = code_bits - 4ull * (unsigned long long)best_parts - (unsigned long long)(n - warm) -
+              (sum_p * (unsigned long long)best_psize - (unsigned long long)warm * best_ps[0]);
+    }
+    // BitRepr for Residual::count_bits, bitrepr.rs:533-544
+    bool rice2 = false;
+    for (int i = 0; i < best_parts; ++i) rice2 |= best_ps[i] > 14;
+    unsigned long long residual_bits = 2ull + 4ull + (unsigned long long)best_parts * (rice2 ? 5ull : 4ull) +
+                                       (sum_q + (unsigned long long)(n - warm)) +
+                                       (sum_p * (unsigned long long)best_psize -
+                                        (unsigned long long)warm * best_ps[0]);
+    // BitRepr for Lpc::count_bits, bitrepr.rs:492-499
+    unsigned long long bps = a.bps ? (unsigned long long)a.bps[sf] : 16ull;
+    unsigned long long sub_bits = 8ull + bps * (unsigned long long)warm + 4ull + 5ull +
+                                  (unsigned long long)a.precision * (unsigned long long)warm + residual_bits;
+    rec->order = (uint8_t)warm;
+    rec->shift = (int8_t)shift;
+    rec->precision = (uint8_t)a.precision;
+    rec->rice_order = (uint8_t)(status == 0 ? rice_order : 0);
+    rec->status = status;
+    rec->code_bits = status == 0 ? code_bits : 0ull;
+    rec->subframe_bits = status == 0 ? sub_bits : 0ull;
+    rec->sum_quotients = status == 0 ? sum_q : 0ull;
+  }
+}
+
+template <int MAXP, bool BIG>
+hipError_t launch_one(const QlpcKernelArgs& a, int threads, size_t smem, hipStream_t stream) {
+  auto kern = qlpc_subframe_kernel<MAXP, BIG>;
+  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  if (err != hipSuccess) return err;
+  hipLaunchKernelGGL(kern, dim3(a.n_subframes), dim3(threads), smem, stream, a);
+  return hipGetLastError();
+}
+
+int bucket_order(int P) {
+  if (P <= 8) return 8;
+  if (P <= 10) return 10;
+  if (P <= 12) return 12;
+  if (P <= 16) return 16;
+  if (P <= 24) return 24;
+  return 32;
+}
+
+}  // namespace
+
+QlpcLaunchPlan plan_qlpc_launch(uint32_t block_size, uint32_t lpc_order) {
+  QlpcLaunchPlan plan;
+  const int n = (int)block_size;
+  const int rows = (n + 15) / 16;
+  plan.big = n > 16384;
+  plan.maxp = bucket_order((int)lpc_order);
+  if (plan.big) plan.maxp = plan.maxp <= 12 ? 12 : 32;
+  const int max_threads = plan.maxp <= 12 ? 1024 : (plan.maxp <= 16 ? 512 : 256);
+  int threads = 64;
+  while (threads < rows && threads < max_threads) threads <<= 1;
+  plan.threads = threads;
+  const int J = (rows + threads - 1) / threads;
+  int Jp = 1;
+  while (Jp < J) Jp <<= 1;
+  const int W = threads / 64;
+  const int rowstride = plan.big ? 16 : 20;
+  size_t bytes = (size_t)(rows + kLeadRows) * rowstride * 4;
+  bytes += (size_t)Jp * W * (plan.maxp + 1) * 8;
+  bytes = (bytes + 15) & ~(size_t)15;
+  bytes += 40 * 8 + 16 * 8 + 32 * 4 + kMiscCount * 4 + 2 * FLACENC_HIP_MAX_RICE_PARTITIONS;
+  if (!plan.big) {
+    int lg = 31 - __builtin_clz((unsigned)(n / 64));
+    int tz = __builtin_ctz((unsigned)n);
+    int fo = lg < tz ? lg : tz;
+    if (fo > 8) fo = 8;
+    bytes += (size_t)(1 << fo) * 32 * 4;
+  }
+  plan.smem_bytes = bytes;
+  plan.table_scratch_bytes_per_subframe = plan.big ? (size_t)FLACENC_HIP_MAX_RICE_PARTITIONS * 32 * 4 : 0;
+  return plan;
+}
+
+hipError_t launch_qlpc(const QlpcKernelArgs& a, const QlpcLaunchPlan& plan, hipStream_t stream) {
+  if (a.n_subframes == 0) return hipSuccess;
+#define FLACENC_CASE(MP, BG) \
+  if (plan.maxp == MP && plan.big == BG) return launch_one<MP, BG>(a, plan.threads, plan.smem_bytes, stream);
+  FLACENC_CASE(8, false)
+  FLACENC_CASE(10, false)
+  FLACENC_CASE(12, false)
+  FLACENC_CASE(16, false)
+  FLACENC_CASE(24, false)
+  FLACENC_CASE(32, false)
+  FLACENC_CASE(12, true)
+  FLACENC_CASE(32, true)
+#undef FLACENC_CASE
+  return hipErrorInvalidValue;
+}
+
+}  // namespace flacenc_hip

@@ -1,0 +1,162 @@
+/*
+ * flacenc_hip.h -- C ABI of the MI355X (gfx950) implementation of flacenc-rs's
+ * per-subframe quantised-LPC analysis path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++/torch types.
+ * Each entry point names the reference interface it replaces (paths relative
+ * to the flacenc-rs v0.5.1 source tree).  The Rust-side binding a maintainer
+ * would add is shown in INTEGRATION.md and shipped as source in rust/.
+ *
+ * Threading: a handle owns one HIP stream, its device scratch and its window
+ * cache; it is NOT thread-safe -- use one handle per host thread / per GPU,
+ * like the reference's per-thread `reusable!` scratch (src/lib.rs:92-116).
+ * Errors never unwind across this boundary: every call returns an int status
+ * (0 = OK, negative = error) and per-subframe `status` fields carry the
+ * conditions on which the reference would panic.
+ */
+#ifndef FLACENC_HIP_H_
+#define FLACENC_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FLACENC_HIP_ABI_VERSION 1
+
+/* FLAC allows LPC order 32; the reference's config verifier caps it at 24
+ * (src/constant.rs:118, src/config.rs:304).  Orders 25..32 are an extension
+ * and are rejected unless FLACENC_HIP_FLAG_ALLOW_ORDER_32 is set. */
+#define FLACENC_HIP_MAX_LPC_ORDER 32
+#define FLACENC_HIP_REF_MAX_LPC_ORDER 24
+#define FLACENC_HIP_MAX_PRECISION 15      /* src/constant.rs qlpc::MAX_PRECISION */
+#define FLACENC_HIP_MAX_RICE_PARAMETER 30 /* src/constant.rs:143 */
+#define FLACENC_HIP_MIN_BLOCK_SIZE 64     /* MIN_BLOCK_SIZE_FOR_PREDICTION, src/constant.rs:51 */
+#define FLACENC_HIP_MAX_BLOCK_SIZE 32767  /* src/constant.rs:57 */
+#define FLACENC_HIP_MAX_RICE_PARTITIONS 256 /* 2^8: finest order for any block <= 32767 */
+
+/* return codes */
+#define FLACENC_HIP_OK 0
+#define FLACENC_HIP_ERR_BAD_CONFIG (-1)   /* -> EncodeError::Config(VerifyError), src/error.rs:458 */
+#define FLACENC_HIP_ERR_BAD_ARGUMENT (-2)
+#define FLACENC_HIP_ERR_DEVICE (-3)       /* HIP runtime failure; see flacenc_hip_last_error */
+#define FLACENC_HIP_ERR_UNSUPPORTED (-4)
+#define FLACENC_HIP_ERR_NO_DEVICE (-5)
+
+/* per-subframe status bits (the reference panics on these) */
+#define FLACENC_HIP_SUBFRAME_OK 0
+#define FLACENC_HIP_SUBFRAME_NONFINITE 1  /* assert at src/lpc.rs:786-799 */
+#define FLACENC_HIP_SUBFRAME_NEG_ENERGY 2 /* assert at src/lpc.rs:646-655 */
+
+/* config::Window, src/config.rs:344-359 */
+#define FLACENC_HIP_WINDOW_RECTANGLE 0
+#define FLACENC_HIP_WINDOW_TUKEY 1
+
+#define FLACENC_HIP_FLAG_ALLOW_ORDER_32 1u
+
+/* where the caller's sample / output buffers live */
+#define FLACENC_HIP_MEM_HOST 0
+#define FLACENC_HIP_MEM_DEVICE 1
+
+typedef struct flacenc_hip_handle flacenc_hip_handle;
+
+/* The fields of config::Qlpc (src/config.rs:271-288) and config::Prc
+ * (src/config.rs:211-214) that parameterise the path.  Defaults: order 10,
+ * precision 15, Tukey(0.4), max_parameter 30 (src/constant.rs:109-115,
+ * src/config.rs:216-221).  `use_direct_mse` / `mae_optimization_steps`
+ * (experimental, nalgebra) are not part of this ABI. */
+typedef struct flacenc_hip_qlpc_config {
+  uint32_t lpc_order;          /* 1..=24 (..=32 with ALLOW_ORDER_32) */
+  uint32_t quant_precision;    /* 1..=15 */
+  uint32_t window_type;        /* FLACENC_HIP_WINDOW_* */
+  float tukey_alpha;           /* 0.0..=1.0 */
+  uint32_t max_rice_parameter; /* ..=30 */
+  uint32_t flags;
+} flacenc_hip_qlpc_config;
+
+/* One record per analysed subframe: everything `estimated_qlpc`
+ * (src/coding.rs:360-381) returns inside SubFrame::Lpc except the residual
+ * samples (written separately) and the warm-up samples (= the first `order`
+ * input samples).  Fixed size (352 bytes) so that records can be all-gathered
+ * across GPUs as-is.
+ *   coefs/order/shift/precision = component::QuantizedParameters
+ *                                 (src/component/datatype.rs:2164-2170)
+ *   rice_order/rice_params      = component::Residual partition_order / rice_params
+ *                                 (src/component/datatype.rs:2269-2284)
+ *   code_bits                   = rice::PrcParameter::code_bits (src/rice.rs:220-224)
+ *   sum_quotients               = Residual::sum_quotients (datatype.rs:2325-2331)
+ *   subframe_bits               = BitRepr for Lpc::count_bits (src/component/bitrepr.rs:492-499)
+ */
+typedef struct flacenc_hip_subframe_params {
+  int16_t coefs[32];
+  uint8_t order;
+  int8_t shift;
+  uint8_t precision;
+  uint8_t rice_order;
+  int32_t status;
+  uint64_t code_bits;
+  uint64_t subframe_bits;
+  uint64_t sum_quotients;
+  uint8_t rice_params[FLACENC_HIP_MAX_RICE_PARTITIONS];
+} flacenc_hip_subframe_params;
+
+/* ---- lifetime --------------------------------------------------------- */
+int flacenc_hip_abi_version(void);
+int flacenc_hip_device_count(void);
+/* Replaces the per-thread scratch set-up of the reference (`reusable!`
+ * LPC_ESTIMATOR src/lpc.rs:916, WINDOW_CACHE :219, QLPC_ERROR_BUFFER
+ * src/coding.rs:353, PRC_FINDER src/rice.rs:301). */
+int flacenc_hip_create(flacenc_hip_handle** out, int device_id);
+void flacenc_hip_destroy(flacenc_hip_handle* h);
+const char* flacenc_hip_last_error(const flacenc_hip_handle* h);
+
+/* config::Qlpc::verify + config::Prc::verify, src/config.rs:302-326, 224-229 */
+int flacenc_hip_verify_config(const flacenc_hip_qlpc_config* cfg);
+
+/* lpc::window_weights (src/lpc.rs:96-120), evaluated on the host in f32 with
+ * libm cosf exactly as the reference does; this is the table the kernels use. */
+int flacenc_hip_window_weights(const flacenc_hip_qlpc_config* cfg, uint32_t block_size, float* out);
+
+/* ---- the hot path ----------------------------------------------------- */
+/*
+ * Batched `estimated_qlpc` (src/coding.rs:360-381): for k in 0..n_subframes the
+ * subframe is the `block_size` samples at `samples + k*stride` (the layout of
+ * FrameBuf::channel_slice, src/source.rs:251-253, batched).  Requires
+ * 64 <= block_size <= 32767 (blocks < 64 never reach the path, coding.rs:396).
+ *   bps[k]        bits per sample of subframe k (8..=25; side channels carry +1,
+ *                 src/coding.rs:444); only enters subframe_bits.
+ *   params[k]     output record (see above)
+ *   residual      output, subframe k at residual + k*residual_stride; first
+ *                 `order` slots are zero (src/lpc.rs:349)
+ *   autocorr      optional [n_subframes][33] f64: R[0..=lpc_order] (src/lpc.rs:780-785)
+ *   lpc_coefs     optional [n_subframes][32] f64: unquantised coefficients (src/lpc.rs:792-796)
+ *   memory_kind   FLACENC_HIP_MEM_HOST: all pointers are host memory, the call
+ *                 stages through the handle's device scratch and returns after
+ *                 the results are back on the host.
+ *                 FLACENC_HIP_MEM_DEVICE: all pointers are device memory on the
+ *                 handle's GPU; the call returns after the kernel completed.
+ */
+int flacenc_hip_qlpc_batch(flacenc_hip_handle* h, const flacenc_hip_qlpc_config* cfg,
+                           const int32_t* samples, size_t n_subframes, uint32_t block_size,
+                           size_t stride, const uint8_t* bps,
+                           flacenc_hip_subframe_params* params, int32_t* residual,
+                           size_t residual_stride, double* autocorr, double* lpc_coefs,
+                           int memory_kind);
+
+/* Same with device pointers only, enqueued on `stream` (a hipStream_t; NULL =
+ * the handle's own stream) without synchronising. */
+int flacenc_hip_qlpc_batch_async(flacenc_hip_handle* h, const flacenc_hip_qlpc_config* cfg,
+                                 const int32_t* samples, size_t n_subframes, uint32_t block_size,
+                                 size_t stride, const uint8_t* bps,
+                                 flacenc_hip_subframe_params* params, int32_t* residual,
+                                 size_t residual_stride, double* autocorr, double* lpc_coefs,
+                                 void* stream);
+
+int flacenc_hip_synchronize(flacenc_hip_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLACENC_HIP_H_ */

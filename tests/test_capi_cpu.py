@@ -1,0 +1,64 @@
+"""CPU-only checks of the C-ABI library: it loads, exports every symbol the header declares,
+and its host-side entry points behave (no GPU compute is called here)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import util
+from flacenc_rs_amd import _capi
+from oracle import oracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _capi.load()
+    header = open(os.path.join(ROOT, "include", "flacenc_hip.h")).read()
+    declared = set(re.findall(r"\b(flacenc_hip_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_capi.EXPORTED_SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.flacenc_hip_abi_version() == 1
+
+
+def test_params_record_layout_matches_oracle_record():
+    assert _capi.PARAMS_DTYPE == orc.RECORD_DTYPE
+    assert _capi.PARAMS_DTYPE.itemsize == 352
+
+
+def test_verify_config_mirrors_reference_ranges():
+    """config::Qlpc::verify / Prc::verify / Window::verify, src/config.rs:302-326, 224-229, 371-387."""
+    ok = _capi.make_config()
+    assert _capi.verify_config(ok) == _capi.OK
+    for bad in (dict(lpc_order=0), dict(lpc_order=25, flags=0), dict(quant_precision=0),
+                dict(quant_precision=16), dict(max_rice_parameter=31), dict(window=("tukey", 1.5)),
+                dict(window=("tukey", -0.1))):
+        cfg = _capi.make_config(**{k: v for k, v in bad.items() if k != "flags"})
+        if "flags" in bad:
+            cfg.flags = bad["flags"]
+        assert _capi.verify_config(cfg) == _capi.ERR_BAD_CONFIG, bad
+    assert _capi.verify_config(_capi.make_config(lpc_order=24)) == _capi.OK
+    assert _capi.verify_config(_capi.make_config(lpc_order=32)) == _capi.OK  # extension flag set
+    cfg = _capi.make_config()
+    cfg.window_type = 7
+    assert _capi.verify_config(cfg) == _capi.ERR_BAD_CONFIG
+
+
+@pytest.mark.parametrize("window,n", [(("tukey", 0.4), 4096), (("tukey", 0.3), 32), (("tukey", 1.0), 1001),
+                                      (("tukey", 0.0), 64), ("rectangle", 100), (("tukey", 0.1), 16384)])
+def test_window_weights_equal_oracle(window, n):
+    """lpc::window_weights (src/lpc.rs:96-120): the product's host table == the oracle's, bitwise."""
+    w = _capi.window_weights(_capi.make_config(window=window), n)
+    assert np.array_equal(w.view(np.uint32), orc.window_weights(window, n).view(np.uint32))
+
+
+def test_create_without_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(_capi.FlacencHipError) as ei:
+        _capi.Handle(0)
+    assert ei.value.code == _capi.ERR_NO_DEVICE

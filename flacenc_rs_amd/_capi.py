@@ -46,7 +46,10 @@ EXPORTED_SYMBOLS = (
     "flacenc_hip_window_weights",
     "flacenc_hip_qlpc_batch",
     "flacenc_hip_qlpc_batch_async",
+    "flacenc_hip_stereo_qlpc_batch",
+    "flacenc_hip_stereo_qlpc_batch_async",
     "flacenc_hip_synchronize",
+    "flacenc_sigen_fill_frames",
 )
 
 
@@ -122,6 +125,16 @@ def load() -> C.CDLL:
     L.flacenc_hip_qlpc_batch.restype = C.c_int
     L.flacenc_hip_qlpc_batch_async.argtypes = batch_args + [vp]
     L.flacenc_hip_qlpc_batch_async.restype = C.c_int
+    stereo_args = [vp, C.POINTER(QlpcConfig), i32p, C.c_size_t, C.c_uint32, C.c_size_t, C.c_uint32,
+                   vp, i32p, C.c_size_t]
+    L.flacenc_hip_stereo_qlpc_batch.argtypes = stereo_args + [C.c_int]
+    L.flacenc_hip_stereo_qlpc_batch.restype = C.c_int
+    L.flacenc_hip_stereo_qlpc_batch_async.argtypes = stereo_args + [vp]
+    L.flacenc_hip_stereo_qlpc_batch_async.restype = C.c_int
+    L.flacenc_sigen_fill_frames.argtypes = [vp, C.c_size_t, C.c_uint32, C.c_uint32, C.c_size_t,
+                                            C.c_uint32, C.c_float, C.c_float, C.c_float,
+                                            C.c_uint64, C.c_uint64, C.c_int]
+    L.flacenc_sigen_fill_frames.restype = C.c_int
     _lib = L
     return L
 
@@ -147,6 +160,21 @@ def window_weights(cfg: QlpcConfig, block_size: int) -> np.ndarray:
     rc = load().flacenc_hip_window_weights(C.byref(cfg), block_size, out.ctypes.data)
     if rc != OK:
         raise FlacencHipError(rc)
+    return out
+
+
+def sigen_frames(n_frames: int, channels: int, block_size: int, bits_per_sample: int,
+                 sine_period: float, sine_amplitude: float, noise_amplitude: float, seed: int,
+                 first_frame: int = 0, nthreads: int | None = None) -> np.ndarray:
+    """flacenc_sigen_fill_frames -> int32 [n_frames, channels, block_size] (FrameBuf layout)."""
+    out = np.empty((n_frames, channels, block_size), np.int32)
+    if nthreads is None:
+        nthreads = min(32, os.cpu_count() or 1)
+    rc = load().flacenc_sigen_fill_frames(out.ctypes.data, n_frames, channels, block_size,
+                                          block_size, bits_per_sample, sine_period, sine_amplitude,
+                                          noise_amplitude, seed, first_frame, nthreads)
+    if rc != 0:
+        raise FlacencHipError(rc, "flacenc_sigen_fill_frames")
     return out
 
 
@@ -203,6 +231,31 @@ class Handle:
             A.ctypes.data if want_fp else None, MEM_HOST)
         self._check(rc)
         return params, residual, R, A
+
+    def stereo_qlpc_batch(self, frames, bits_per_sample: int, cfg: QlpcConfig):
+        """The four estimated_qlpc calls of encode_frame per 2-channel frame (L, R, M, S).
+
+        `frames` is int32 [n_frames, 2, block_size]; returns (params [n_frames, 4],
+        residual [n_frames, 4, block_size]).
+        """
+        x = np.ascontiguousarray(frames, np.int32)
+        nf, ch, n = x.shape
+        assert ch == 2
+        params = np.zeros((nf, 4), PARAMS_DTYPE)
+        residual = np.zeros((nf, 4, n), np.int32)
+        rc = self._lib.flacenc_hip_stereo_qlpc_batch(
+            self._h, C.byref(cfg), x.ctypes.data, nf, n, n, bits_per_sample, params.ctypes.data,
+            residual.ctypes.data, n, MEM_HOST)
+        self._check(rc)
+        return params, residual
+
+    def stereo_qlpc_batch_device(self, cfg: QlpcConfig, frames_ptr: int, n_frames: int,
+                                 block_size: int, stride: int, bits_per_sample: int, params_ptr: int,
+                                 residual_ptr: int, residual_stride: int, stream: int | None = None):
+        rc = self._lib.flacenc_hip_stereo_qlpc_batch_async(
+            self._h, C.byref(cfg), frames_ptr, n_frames, block_size, stride, bits_per_sample,
+            params_ptr, residual_ptr, residual_stride, stream or None)
+        self._check(rc)
 
     # -- device-memory path (raw pointers; torch tensors' data_ptr()) ---------
     def qlpc_batch_device(self, cfg: QlpcConfig, samples_ptr: int, n_subframes: int, block_size: int,

@@ -175,7 +175,8 @@ int check_batch_args(flacenc_hip_handle* h, const flacenc_hip_qlpc_config* cfg, 
 int enqueue(flacenc_hip_handle* h, const flacenc_hip_qlpc_config* cfg, const int32_t* samples,
             size_t n_subframes, uint32_t block_size, size_t stride, const uint8_t* bps,
             flacenc_hip_subframe_params* params, int32_t* residual, size_t residual_stride,
-            double* autocorr, double* lpc_coefs, hipStream_t stream) {
+            double* autocorr, double* lpc_coefs, hipStream_t stream, bool stereo = false,
+            uint32_t bps_uniform = 16) {
   const WindowEntry* win = nullptr;
   int rc = get_window(h, cfg, block_size, &win);
   if (rc != FLACENC_HIP_OK) return rc;
@@ -190,6 +191,8 @@ int enqueue(flacenc_hip_handle* h, const flacenc_hip_qlpc_config* cfg, const int
   a.block_size = block_size;
   a.n_subframes = static_cast<uint32_t>(n_subframes);
   a.bps = bps;
+  a.bps_uniform = bps_uniform;
+  a.stereo = stereo ? 1u : 0u;
   a.window = win->dev;
   a.flat_lo = win->flat_lo;
   a.flat_hi = win->flat_hi;
@@ -357,6 +360,65 @@ int flacenc_hip_qlpc_batch(flacenc_hip_handle* h, const flacenc_hip_qlpc_config*
     HIP_TRY(h, hipMemcpyAsync(autocorr, h->d_autocorr.ptr, n_subframes * 33 * 8, hipMemcpyDeviceToHost, s));
   if (lpc_coefs)
     HIP_TRY(h, hipMemcpyAsync(lpc_coefs, h->d_lpc.ptr, n_subframes * 32 * 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(h, hipStreamSynchronize(s));
+  return FLACENC_HIP_OK;
+}
+
+int flacenc_hip_stereo_qlpc_batch_async(flacenc_hip_handle* h, const flacenc_hip_qlpc_config* cfg,
+                                        const int32_t* frames, size_t n_frames, uint32_t block_size,
+                                        size_t stride, uint32_t bits_per_sample,
+                                        flacenc_hip_subframe_params* params, int32_t* residual,
+                                        size_t residual_stride, void* stream) {
+  int rc = check_batch_args(h, cfg, frames, n_frames * 4, block_size, stride, params, residual,
+                            residual_stride);
+  if (rc != FLACENC_HIP_OK || n_frames == 0) return rc;
+  if (bits_per_sample < 8 || bits_per_sample > 24) {
+    h->last_error = "bits_per_sample must be in 8..=24";
+    return FLACENC_HIP_ERR_BAD_ARGUMENT;
+  }
+  HIP_TRY(h, hipSetDevice(h->device));
+  hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
+  return enqueue(h, cfg, frames, n_frames * 4, block_size, stride, nullptr, params, residual,
+                 residual_stride, nullptr, nullptr, s, true, bits_per_sample);
+}
+
+int flacenc_hip_stereo_qlpc_batch(flacenc_hip_handle* h, const flacenc_hip_qlpc_config* cfg,
+                                  const int32_t* frames, size_t n_frames, uint32_t block_size,
+                                  size_t stride, uint32_t bits_per_sample,
+                                  flacenc_hip_subframe_params* params, int32_t* residual,
+                                  size_t residual_stride, int memory_kind) {
+  if (memory_kind == FLACENC_HIP_MEM_DEVICE) {
+    int rc = flacenc_hip_stereo_qlpc_batch_async(h, cfg, frames, n_frames, block_size, stride,
+                                                 bits_per_sample, params, residual, residual_stride,
+                                                 nullptr);
+    if (rc != FLACENC_HIP_OK || n_frames == 0) return rc;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return FLACENC_HIP_OK;
+  }
+  if (memory_kind != FLACENC_HIP_MEM_HOST) return FLACENC_HIP_ERR_BAD_ARGUMENT;
+  int rc = check_batch_args(h, cfg, frames, n_frames * 4, block_size, stride, params, residual,
+                            residual_stride);
+  if (rc != FLACENC_HIP_OK || n_frames == 0) return rc;
+  HIP_TRY(h, hipSetDevice(h->device));
+  const size_t dstride = (static_cast<size_t>(block_size) + 3) & ~static_cast<size_t>(3);
+  const size_t n_sub = n_frames * 4;
+  if ((rc = ensure(h, h->d_samples, n_frames * 2 * dstride * 4)) != FLACENC_HIP_OK) return rc;
+  if ((rc = ensure(h, h->d_residual, n_sub * dstride * 4)) != FLACENC_HIP_OK) return rc;
+  if ((rc = ensure(h, h->d_params, n_sub * sizeof(flacenc_hip_subframe_params))) != FLACENC_HIP_OK)
+    return rc;
+  hipStream_t s = h->stream;
+  HIP_TRY(h, hipMemcpy2DAsync(h->d_samples.ptr, dstride * 4, frames, stride * 4,
+                              static_cast<size_t>(block_size) * 4, n_frames * 2,
+                              hipMemcpyHostToDevice, s));
+  rc = flacenc_hip_stereo_qlpc_batch_async(h, cfg, static_cast<const int32_t*>(h->d_samples.ptr),
+                                           n_frames, block_size, dstride, bits_per_sample,
+                                           static_cast<flacenc_hip_subframe_params*>(h->d_params.ptr),
+                                           static_cast<int32_t*>(h->d_residual.ptr), dstride, s);
+  if (rc != FLACENC_HIP_OK) return rc;
+  HIP_TRY(h, hipMemcpy2DAsync(residual, residual_stride * 4, h->d_residual.ptr, dstride * 4,
+                              static_cast<size_t>(block_size) * 4, n_sub, hipMemcpyDeviceToHost, s));
+  HIP_TRY(h, hipMemcpyAsync(params, h->d_params.ptr, n_sub * sizeof(flacenc_hip_subframe_params),
+                            hipMemcpyDeviceToHost, s));
   HIP_TRY(h, hipStreamSynchronize(s));
   return FLACENC_HIP_OK;
 }

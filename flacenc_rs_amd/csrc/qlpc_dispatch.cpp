@@ -1,0 +1,67 @@
+// qlpc_dispatch.cpp -- launch planning (workgroup size, LDS budget, order bucket)
+// and dispatch to the per-bucket kernel instantiations.
+#include "qlpc_kernel.h"
+
+namespace flacenc_hip {
+namespace {
+
+constexpr int kLeadRows = 2;
+constexpr int kMiscCount = 16;
+
+int bucket_order(int P) {
+  if (P <= 8) return 8;
+  if (P <= 10) return 10;
+  if (P <= 12) return 12;
+  if (P <= 16) return 16;
+  if (P <= 24) return 24;
+  return 32;
+}
+
+}  // namespace
+
+QlpcLaunchPlan plan_qlpc_launch(uint32_t block_size, uint32_t lpc_order) {
+  QlpcLaunchPlan plan;
+  const int n = static_cast<int>(block_size);
+  const int rows = (n + 15) / 16;
+  plan.big = n > 16384;
+  plan.maxp = bucket_order(static_cast<int>(lpc_order));
+  if (plan.big) plan.maxp = plan.maxp <= 12 ? 12 : 32;
+  // must match the kernel's __launch_bounds__
+  const int max_threads = plan.maxp <= 12 ? 1024 : (plan.maxp <= 16 ? 512 : 256);
+  int threads = 64;
+  while (threads < rows && threads < max_threads) threads <<= 1;
+  plan.threads = threads;
+  const int J = (rows + threads - 1) / threads;
+  int Jp = 1;
+  while (Jp < J) Jp <<= 1;
+  const int W = threads / 64;
+  const int rowstride = plan.big ? 16 : 20;
+  size_t bytes = static_cast<size_t>(rows + kLeadRows) * rowstride * 4;
+  bytes += static_cast<size_t>(Jp) * W * (plan.maxp + 1) * 8;
+  bytes = (bytes + 15) & ~static_cast<size_t>(15);
+  bytes += 40 * 8 + 16 * 8 + 32 * 4 + kMiscCount * 4 + 2 * FLACENC_HIP_MAX_RICE_PARTITIONS;
+  if (!plan.big) {
+    // finest_partition_order, rice.rs:157-165 (warm-up <= 32 < 64)
+    int lg = 31 - __builtin_clz(static_cast<unsigned>(n / 64));
+    int tz = __builtin_ctz(static_cast<unsigned>(n));
+    int fo = lg < tz ? lg : tz;
+    if (fo > 8) fo = 8;
+    bytes += static_cast<size_t>(1 << fo) * 32 * 4;
+  }
+  plan.smem_bytes = bytes;
+  plan.table_scratch_bytes_per_subframe =
+      plan.big ? static_cast<size_t>(FLACENC_HIP_MAX_RICE_PARTITIONS) * 32 * 4 : 0;
+  return plan;
+}
+
+hipError_t launch_qlpc(const QlpcKernelArgs& a, const QlpcLaunchPlan& plan, hipStream_t stream) {
+  if (a.n_subframes == 0) return hipSuccess;
+#define FLACENC_HIP_CASE(MP, BG)                       \
+  if (plan.maxp == MP && plan.big == (BG != 0))        \
+    return launch_qlpc_##MP##_##BG(a, plan.threads, plan.smem_bytes, stream);
+  FLACENC_HIP_FOR_EACH_INSTANCE(FLACENC_HIP_CASE)
+#undef FLACENC_HIP_CASE
+  return hipErrorInvalidValue;
+}
+
+}  // namespace flacenc_hip

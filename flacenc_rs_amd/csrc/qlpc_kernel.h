@@ -19,7 +19,9 @@ struct QlpcKernelArgs {
   size_t stride;
   uint32_t block_size;
   uint32_t n_subframes;
-  const uint8_t* bps;       // device, per subframe (nullable -> 16)
+  const uint8_t* bps;       // device, per subframe (nullable -> bps_uniform)
+  uint32_t bps_uniform;
+  uint32_t stereo;          // 1: workgroups 4f..4f+3 = L, R, M, S of 2-channel frame f
   const float* window;      // device table with 32 leading pad floats, nullptr = all ones
   int32_t flat_lo;          // window[t] == 1.0f for flat_lo <= t < flat_hi
   int32_t flat_hi;
@@ -44,6 +46,13 @@ struct QlpcLaunchPlan {
 
 QlpcLaunchPlan plan_qlpc_launch(uint32_t block_size, uint32_t lpc_order);
 hipError_t launch_qlpc(const QlpcKernelArgs& args, const QlpcLaunchPlan& plan, hipStream_t stream);
+
+// one per (order bucket, big) instantiation, each defined by its own translation unit
+#define FLACENC_HIP_FOR_EACH_INSTANCE(X) \
+  X(8, 0) X(10, 0) X(12, 0) X(16, 0) X(24, 0) X(32, 0) X(12, 1) X(32, 1)
+#define FLACENC_HIP_DECLARE_INSTANCE(MP, BG) \
+  hipError_t launch_qlpc_##MP##_##BG(const QlpcKernelArgs&, int threads, size_t smem, hipStream_t);
+FLACENC_HIP_FOR_EACH_INSTANCE(FLACENC_HIP_DECLARE_INSTANCE)
 
 }  // namespace flacenc_hip
 #endif

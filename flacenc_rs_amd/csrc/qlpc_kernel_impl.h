@@ -1,4 +1,7 @@
-// qlpc_kernel.hip -- the QLPC analysis hot path as one fused HIP kernel for gfx950.
+#ifndef FLACENC_HIP_QLPC_KERNEL_IMPL_H_
+#define FLACENC_HIP_QLPC_KERNEL_IMPL_H_
+// qlpc_kernel_impl.h -- the QLPC analysis hot path as one fused HIP kernel for gfx950.
+// (template; instantiated once per (order bucket, big) pair by qlpc_inst.hip)
 //
 // One workgroup analyses one subframe (one channel of one block), start to
 // finish, with the samples staged once in LDS:
@@ -282,13 +285,20 @@ qlpc_subframe_kernel(QlpcKernelArgs a) {
   }
 
   // ======================= phase 0: load ===================================
-  const int32_t* __restrict__ src = a.samples + (size_t)sf * a.stride;
+  // Plain mode: subframe sf is the block at samples + sf*stride.  Stereo mode
+  // (try_stereo_coding, coding.rs:476-484): workgroups 4f..4f+3 analyse L, R,
+  // M = (l + r) >> 1 and S = l - r of frame f, formed here from the two channels.
+  const int role = a.stereo ? (int)(sf & 3u) : 0;
+  const int32_t* __restrict__ src =
+      a.stereo ? a.samples + (size_t)(2u * (sf >> 2) + (role == 1 ? 1u : 0u)) * a.stride
+               : a.samples + (size_t)sf * a.stride;
+  const int32_t* __restrict__ src2 = src + a.stride;  // right channel, roles 2 and 3 only
   if (tid < kMiscCount) L.misc[tid] = 0;
   if (tid < 16) L.level_bits[tid] = 0ull;
   for (int i = tid; i < kLeadRows * ROWSTRIDE; i += T) L.sbuf[i] = 0;
   uint32_t my_maxabs = 0;
   {
-    const bool vec_ok = ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
+    const bool vec_ok = ((reinterpret_cast<uintptr_t>(src) & 15) == 0) && ((a.stride & 3) == 0);
     for (int q = tid; q < rows * 4; q += T) {
       int t = q * 4;
       int4 v;
@@ -299,6 +309,28 @@ qlpc_subframe_kernel(QlpcKernelArgs a) {
         v.y = (t + 1 < n) ? src[t + 1] : 0;
         v.z = (t + 2 < n) ? src[t + 2] : 0;
         v.w = (t + 3 < n) ? src[t + 3] : 0;
+      }
+      if (role >= 2) {
+        int4 r;
+        if (vec_ok && t + 3 < n) {
+          r = *reinterpret_cast<const int4*>(src2 + t);
+        } else {
+          r.x = (t + 0 < n) ? src2[t + 0] : 0;
+          r.y = (t + 1 < n) ? src2[t + 1] : 0;
+          r.z = (t + 2 < n) ? src2[t + 2] : 0;
+          r.w = (t + 3 < n) ? src2[t + 3] : 0;
+        }
+        if (role == 2) {
+          v.x = (v.x + r.x) >> 1;
+          v.y = (v.y + r.y) >> 1;
+          v.z = (v.z + r.z) >> 1;
+          v.w = (v.w + r.w) >> 1;
+        } else {
+          v.x -= r.x;
+          v.y -= r.y;
+          v.z -= r.z;
+          v.w -= r.w;
+        }
       }
       *reinterpret_cast<int4*>(&L.sbuf[sidx<ROWSTRIDE>(t)]) = v;
       uint32_t ax = (uint32_t)(v.x < 0 ? -(int64_t)v.x : (int64_t)v.x);
@@ -573,7 +605,7 @@ qlpc_subframe_kernel(QlpcKernelArgs a) {
   // ======================= phase 5: outputs ================================
   int32_t* __restrict__ dst = a.residual + (size_t)sf * a.residual_stride;
   {
-    const bool vec_ok = ((reinterpret_cast<uintptr_t>(dst) & 15) == 0);
+    const bool vec_ok = ((reinterpret_cast<uintptr_t>(dst) & 15) == 0) && ((a.residual_stride & 3) == 0);
     for (int q = tid; q < rows * 4; q += T) {
       int t = q * 4;
       int4 v = *reinterpret_cast<const int4*>(&L.sbuf[sidx<ROWSTRIDE>(t)]);
@@ -628,7 +660,9 @@ qlpc_subframe_kernel(QlpcKernelArgs a) {
                                        (sum_p * (unsigned long long)best_psize -
                                         (unsigned long long)warm * best_ps[0]);
     // BitRepr for Lpc::count_bits, bitrepr.rs:492-499
-    unsigned long long bps = a.bps ? (unsigned long long)a.bps[sf] : 16ull;
+    // side channel carries one extra bit (ChannelAssignment::bits_per_sample_offset, coding.rs:444)
+    unsigned long long bps = a.bps ? (unsigned long long)a.bps[sf]
+                                   : (unsigned long long)(a.bps_uniform + (role == 3 ? 1u : 0u));
     unsigned long long sub_bits = 8ull + bps * (unsigned long long)warm + 4ull + 5ull +
                                   (unsigned long long)a.precision * (unsigned long long)warm + residual_bits;
     rec->order = (uint8_t)warm;
@@ -645,70 +679,17 @@ qlpc_subframe_kernel(QlpcKernelArgs a) {
 template <int MAXP, bool BIG>
 hipError_t launch_one(const QlpcKernelArgs& a, int threads, size_t smem, hipStream_t stream) {
   auto kern = qlpc_subframe_kernel<MAXP, BIG>;
-  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  if (err != hipSuccess) return err;
+  static size_t configured_smem = 0;  // per instantiation; the attribute only ever needs to grow
+  if (smem > configured_smem) {
+    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (err != hipSuccess) return err;
+    configured_smem = smem;
+  }
   hipLaunchKernelGGL(kern, dim3(a.n_subframes), dim3(threads), smem, stream, a);
   return hipGetLastError();
 }
 
-int bucket_order(int P) {
-  if (P <= 8) return 8;
-  if (P <= 10) return 10;
-  if (P <= 12) return 12;
-  if (P <= 16) return 16;
-  if (P <= 24) return 24;
-  return 32;
-}
-
 }  // namespace
-
-QlpcLaunchPlan plan_qlpc_launch(uint32_t block_size, uint32_t lpc_order) {
-  QlpcLaunchPlan plan;
-  const int n = (int)block_size;
-  const int rows = (n + 15) / 16;
-  plan.big = n > 16384;
-  plan.maxp = bucket_order((int)lpc_order);
-  if (plan.big) plan.maxp = plan.maxp <= 12 ? 12 : 32;
-  const int max_threads = plan.maxp <= 12 ? 1024 : (plan.maxp <= 16 ? 512 : 256);
-  int threads = 64;
-  while (threads < rows && threads < max_threads) threads <<= 1;
-  plan.threads = threads;
-  const int J = (rows + threads - 1) / threads;
-  int Jp = 1;
-  while (Jp < J) Jp <<= 1;
-  const int W = threads / 64;
-  const int rowstride = plan.big ? 16 : 20;
-  size_t bytes = (size_t)(rows + kLeadRows) * rowstride * 4;
-  bytes += (size_t)Jp * W * (plan.maxp + 1) * 8;
-  bytes = (bytes + 15) & ~(size_t)15;
-  bytes += 40 * 8 + 16 * 8 + 32 * 4 + kMiscCount * 4 + 2 * FLACENC_HIP_MAX_RICE_PARTITIONS;
-  if (!plan.big) {
-    int lg = 31 - __builtin_clz((unsigned)(n / 64));
-    int tz = __builtin_ctz((unsigned)n);
-    int fo = lg < tz ? lg : tz;
-    if (fo > 8) fo = 8;
-    bytes += (size_t)(1 << fo) * 32 * 4;
-  }
-  plan.smem_bytes = bytes;
-  plan.table_scratch_bytes_per_subframe = plan.big ? (size_t)FLACENC_HIP_MAX_RICE_PARTITIONS * 32 * 4 : 0;
-  return plan;
-}
-
-hipError_t launch_qlpc(const QlpcKernelArgs& a, const QlpcLaunchPlan& plan, hipStream_t stream) {
-  if (a.n_subframes == 0) return hipSuccess;
-#define FLACENC_CASE(MP, BG) \
-  if (plan.maxp == MP && plan.big == BG) return launch_one<MP, BG>(a, plan.threads, plan.smem_bytes, stream);
-  FLACENC_CASE(8, false)
-  FLACENC_CASE(10, false)
-  FLACENC_CASE(12, false)
-  FLACENC_CASE(16, false)
-  FLACENC_CASE(24, false)
-  FLACENC_CASE(32, false)
-  FLACENC_CASE(12, true)
-  FLACENC_CASE(32, true)
-#undef FLACENC_CASE
-  return hipErrorInvalidValue;
-}
-
 }  // namespace flacenc_hip
+#endif

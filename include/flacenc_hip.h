@@ -154,6 +154,28 @@ int flacenc_hip_qlpc_batch_async(flacenc_hip_handle* h, const flacenc_hip_qlpc_c
                                  size_t residual_stride, double* autocorr, double* lpc_coefs,
                                  void* stream);
 
+/*
+ * The four `estimated_qlpc` calls `encode_frame` makes for a 2-channel frame
+ * (src/coding.rs:530-544): encode_frame_impl(Independent(2)) on L and R, then
+ * try_stereo_coding's MidSide frame on M = (l + r) >> 1 and S = l - r
+ * (src/coding.rs:476-491).  `frames` is batched FrameBuf layout
+ * (src/source.rs:115-127): channel c of frame f at frames + (2f + c)*stride.
+ * M and S are formed on the GPU.  Outputs are indexed 4f + {0:L, 1:R, 2:M, 3:S};
+ * the S record's subframe_bits uses bits_per_sample + 1 (src/coding.rs:444).
+ * The choice between L+R / L+S / R+S / M+S stays with the caller
+ * (src/coding.rs:493-522) until the fixed-LPC candidate is on the GPU too.
+ */
+int flacenc_hip_stereo_qlpc_batch(flacenc_hip_handle* h, const flacenc_hip_qlpc_config* cfg,
+                                  const int32_t* frames, size_t n_frames, uint32_t block_size,
+                                  size_t stride, uint32_t bits_per_sample,
+                                  flacenc_hip_subframe_params* params, int32_t* residual,
+                                  size_t residual_stride, int memory_kind);
+int flacenc_hip_stereo_qlpc_batch_async(flacenc_hip_handle* h, const flacenc_hip_qlpc_config* cfg,
+                                        const int32_t* frames, size_t n_frames, uint32_t block_size,
+                                        size_t stride, uint32_t bits_per_sample,
+                                        flacenc_hip_subframe_params* params, int32_t* residual,
+                                        size_t residual_stride, void* stream);
+
 int flacenc_hip_synchronize(flacenc_hip_handle* h);
 
 #ifdef __cplusplus

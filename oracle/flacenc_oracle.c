@@ -684,3 +684,79 @@ double orc_bench_qlpc(const int32_t* samples, size_t n_subframes, size_t n, size
   free(recs);
   return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
 }
+
+/* cpu_baseline for the stereo workload: per 2-channel frame the reference's
+ * encode_frame runs the path four times -- L, R (encode_frame_impl, coding.rs:538)
+ * and M, S formed by try_stereo_coding (coding.rs:476-491).  `frames` is batched
+ * FrameBuf layout: channel c of frame f at frames + (2f + c)*stride. */
+typedef struct {
+  const int32_t* frames;
+  size_t begin, end, n, stride;
+  uint32_t bps;
+  const orc_qlpc_config* cfg;
+  uint64_t checksum;
+} orc_stereo_job;
+
+static void* orc_stereo_worker(void* arg) {
+  orc_stereo_job* job = (orc_stereo_job*)arg;
+  size_t n = job->n;
+  int32_t* errors = (int32_t*)malloc(sizeof(int32_t) * n);
+  int32_t* m = (int32_t*)malloc(sizeof(int32_t) * n);
+  int32_t* s = (int32_t*)malloc(sizeof(int32_t) * n);
+  uint8_t* rp = (uint8_t*)malloc(ORC_MAX_RICE_PARTITIONS);
+  orc_qlpc_result res;
+  uint64_t sum = 0;
+  for (size_t f = job->begin; f < job->end; ++f) {
+    const int32_t* l = job->frames + (2 * f) * job->stride;
+    const int32_t* r = l + job->stride;
+    orc_stereo_to_midside(l, r, n, m, s);
+    orc_estimated_qlpc(l, n, job->bps, job->cfg, &res, rp, errors, NULL, NULL);
+    sum += res.subframe_bits;
+    orc_estimated_qlpc(r, n, job->bps, job->cfg, &res, rp, errors, NULL, NULL);
+    sum += res.subframe_bits;
+    orc_estimated_qlpc(m, n, job->bps, job->cfg, &res, rp, errors, NULL, NULL);
+    sum += res.subframe_bits;
+    orc_estimated_qlpc(s, n, job->bps + 1, job->cfg, &res, rp, errors, NULL, NULL);
+    sum += res.subframe_bits;
+  }
+  job->checksum = sum;
+  free(errors);
+  free(m);
+  free(s);
+  free(rp);
+  return NULL;
+}
+
+double orc_bench_stereo_qlpc(const int32_t* frames, size_t n_frames, size_t n, size_t stride,
+                             uint32_t bits_per_sample, const orc_qlpc_config* cfg, int nthreads,
+                             int repeats, uint64_t* checksum_out) {
+  if (nthreads < 1) nthreads = 1;
+  if ((size_t)nthreads > n_frames) nthreads = n_frames ? (int)n_frames : 1;
+  pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)nthreads);
+  orc_stereo_job* jobs = (orc_stereo_job*)malloc(sizeof(orc_stereo_job) * (size_t)nthreads);
+  struct timespec t0, t1;
+  uint64_t total = 0;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  for (int r = 0; r < repeats; ++r) {
+    for (int i = 0; i < nthreads; ++i) {
+      jobs[i].frames = frames;
+      jobs[i].n = n;
+      jobs[i].stride = stride;
+      jobs[i].bps = bits_per_sample;
+      jobs[i].cfg = cfg;
+      jobs[i].begin = n_frames * (size_t)i / (size_t)nthreads;
+      jobs[i].end = n_frames * (size_t)(i + 1) / (size_t)nthreads;
+      jobs[i].checksum = 0;
+      pthread_create(&th[i], NULL, orc_stereo_worker, &jobs[i]);
+    }
+    for (int i = 0; i < nthreads; ++i) {
+      pthread_join(th[i], NULL);
+      total += jobs[i].checksum;
+    }
+  }
+  clock_gettime(CLOCK_MONOTONIC, &t1);
+  if (checksum_out) *checksum_out = total;
+  free(th);
+  free(jobs);
+  return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}

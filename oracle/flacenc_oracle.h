@@ -167,6 +167,10 @@ double orc_bench_qlpc(const int32_t* samples, size_t n_subframes, size_t n, size
                       uint32_t bits_per_sample, const orc_qlpc_config* cfg, int nthreads,
                       int repeats);
 
+double orc_bench_stereo_qlpc(const int32_t* frames, size_t n_frames, size_t n, size_t stride,
+                             uint32_t bits_per_sample, const orc_qlpc_config* cfg, int nthreads,
+                             int repeats, uint64_t* checksum_out);
+
 #ifdef __cplusplus
 }
 #endif

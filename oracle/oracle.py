@@ -166,6 +166,10 @@ def _declare(L):
     L.orc_bench_qlpc.argtypes = [i32p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint32,
                                  C.POINTER(QlpcConfig), C.c_int, C.c_int]
     L.orc_bench_qlpc.restype = C.c_double
+    L.orc_bench_stereo_qlpc.argtypes = [i32p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint32,
+                                        C.POINTER(QlpcConfig), C.c_int, C.c_int,
+                                        C.POINTER(C.c_uint64)]
+    L.orc_bench_stereo_qlpc.restype = C.c_double
 
 
 def make_config(lpc_order=10, quant_precision=15, window=("tukey", 0.4), max_rice_parameter=30,
@@ -427,3 +431,15 @@ def bench_qlpc(samples, bits_per_sample: int, cfg: QlpcConfig, nthreads: int, re
     ns, n = x.shape
     return float(lib().orc_bench_qlpc(_p(x, C.c_int32), ns, n, n, bits_per_sample, C.byref(cfg),
                                       nthreads, repeats))
+
+
+def bench_stereo_qlpc(frames, bits_per_sample: int, cfg: QlpcConfig, nthreads: int, repeats: int = 1):
+    """Wall seconds for `repeats` passes of the stereo workload (L, R, M, S through the path per
+    frame) over int32 [n_frames, 2, n]; also returns the sum of subframe_bits as a checksum."""
+    x = np.ascontiguousarray(frames, np.int32)
+    nf, ch, n = x.shape
+    assert ch == 2
+    chk = C.c_uint64()
+    secs = float(lib().orc_bench_stereo_qlpc(_p(x, C.c_int32), nf, n, n, bits_per_sample,
+                                             C.byref(cfg), nthreads, repeats, C.byref(chk)))
+    return secs, int(chk.value)

@@ -16,8 +16,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_library_exports_every_declared_symbol():
     lib = _capi.load()
-    header = open(os.path.join(ROOT, "include", "flacenc_hip.h")).read()
-    declared = set(re.findall(r"\b(flacenc_hip_[a-z0-9_]+)\s*\(", header))
+    header = "".join(open(os.path.join(ROOT, "include", f)).read()
+                     for f in sorted(os.listdir(os.path.join(ROOT, "include"))) if f.endswith(".h"))
+    declared = set(re.findall(r"\b(flacenc_(?:hip|sigen)_[a-z0-9_]+)\s*\(", header))
     assert declared == set(_capi.EXPORTED_SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name
@@ -62,3 +63,24 @@ def test_create_without_gpu_fails_loudly():
     with pytest.raises(_capi.FlacencHipError) as ei:
         _capi.Handle(0)
     assert ei.value.code == _capi.ERR_NO_DEVICE
+
+
+def test_sigen_matches_numpy_model():
+    """flacenc_sigen_fill_frames == Sine + Noise + to_vec_quantized (src/sigen.rs:35-53, 159-168,
+    227-232) re-stated in numpy with the same counter-based noise (tests/util.py)."""
+    n, bps = 4096, 16
+    x = _capi.sigen_frames(3, 2, n, bps, 200.0, 0.4, 0.4, seed=7, first_frame=5)
+    assert x.shape == (3, 2, n) and x.dtype == np.int32
+    lo, hi = -(1 << (bps - 1)), (1 << (bps - 1)) - 1
+    assert x.min() >= lo and x.max() <= hi
+    for f in range(3):
+        for c in range(2):
+            off = (5 + f) * n
+            ref = util.quantize(util.sine(n, 200.0 + 7.0 * c, 0.4, phase=0.5 * c, offset=off)
+                                + util.noise(7 + c, n, 0.4, offset=off), bps)
+            # libm sinf vs numpy's sin may differ in the last ulp -> allow +-1 LSB on a few samples
+            d = np.abs(x[f, c] - ref)
+            assert d.max() <= 1 and (d != 0).mean() < 0.01
+    # determinism and thread-count independence
+    y = _capi.sigen_frames(3, 2, n, bps, 200.0, 0.4, 0.4, seed=7, first_frame=5, nthreads=1)
+    assert np.array_equal(x, y)

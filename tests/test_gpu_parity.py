@@ -307,3 +307,36 @@ def test_large_batch_statistics(handle):
     assert_records_equal(gp, cp)
     assert np.array_equal(gres, cres)
     check_lossless(x[::64], gp[::64], gres[::64])
+
+
+# ------------------------------------------------------------------ stereo entry point ----
+@pytest.mark.parametrize("n,bps,order", [(4096, 16, 8), (4096, 16, 10), (8192, 24, 24), (1152, 16, 12)])
+def test_stereo_batch_equals_four_subframe_analyses(handle, n, bps, order):
+    """flacenc_hip_stereo_qlpc_batch == estimated_qlpc on L, R, M = (l+r)>>1, S = l-r
+    (coding.rs:476-491), S with bps + 1 (coding.rs:444); and M/S decode back to L/R
+    (decode.rs:91-103)."""
+    nf = 6
+    frames = _capi.sigen_frames(nf, 2, n, bps, 200.0, 0.4, 0.1, seed=n + order)
+    frames[:, 1] = (frames[:, 1] * 3) // 4 + frames[:, 0] // 8  # correlated channels
+    params, residual = handle.stereo_qlpc_batch(frames, bps, gpu_cfg(order))
+    ocfg = orc_cfg(order, acorr=orc.ACORR_CANONICAL)
+    for f in range(nf):
+        l, r = frames[f, 0], frames[f, 1]
+        m, s = orc.stereo_to_midside(l, r)
+        decoded = []
+        for role, (sig, b) in enumerate(((l, bps), (r, bps), (m, bps), (s, bps + 1))):
+            want = orc.estimated_qlpc(sig, b, ocfg)
+            got = params[f, role]
+            k = want["order"]
+            assert int(got["status"]) == 0
+            assert (int(got["order"]), int(got["shift"])) == (k, want["shift"])
+            assert got["coefs"][:k].tolist() == want["coefs"].tolist()
+            assert np.array_equal(residual[f, role], want["residual"])
+            assert int(got["rice_order"]) == want["rice_order"]
+            assert got["rice_params"][: 1 << want["rice_order"]].tolist() == want["rice_params"].tolist()
+            assert int(got["code_bits"]) == want["code_bits"]
+            assert int(got["subframe_bits"]) == want["subframe_bits"]
+            decoded.append(orc.decode_lpc(sig[:k], got["coefs"][:k], int(got["shift"]), residual[f, role]))
+        assert np.array_equal(decoded[0], l) and np.array_equal(decoded[1], r)
+        l2, r2 = orc.midside_to_stereo(decoded[2], decoded[3])
+        assert np.array_equal(l2, l) and np.array_equal(r2, r)

@@ -169,14 +169,26 @@ def _measured_traffic():
         return None
 
 
+def usable_cores():
+    """Host threads this process may really use: affinity mask capped by the cgroup CPU quota."""
+    cores = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return cores
+
+
 def cpu_baseline(host, bps, args, n):
     """The oracle (a port of the reference's path in reference summation order) timed on this
     box's host cores over a bounded sample of the same frames."""
     from oracle import oracle as orc
 
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     ocfg = orc.make_config(lpc_order=args.lpc_order)
-    sample_frames = min(host.shape[0], 64 * cores)
+    sample_frames = min(host.shape[0], 16 * cores)
     sample = np.ascontiguousarray(host[:sample_frames])
     secs, _ = orc.bench_stereo_qlpc(sample, bps, ocfg, cores, 1)  # calibration pass
     repeats = max(1, int(args.cpu_seconds / max(secs, 1e-3)))

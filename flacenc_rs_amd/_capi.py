@@ -49,6 +49,7 @@ EXPORTED_SYMBOLS = (
     "flacenc_hip_stereo_qlpc_batch",
     "flacenc_hip_stereo_qlpc_batch_async",
     "flacenc_hip_synchronize",
+    "flacenc_hip_debug_set_stamps",
     "flacenc_sigen_fill_frames",
 )
 
@@ -119,6 +120,8 @@ def load() -> C.CDLL:
     L.flacenc_hip_window_weights.restype = C.c_int
     L.flacenc_hip_synchronize.argtypes = [vp]
     L.flacenc_hip_synchronize.restype = C.c_int
+    L.flacenc_hip_debug_set_stamps.argtypes = [vp, vp]
+    L.flacenc_hip_debug_set_stamps.restype = C.c_int
     batch_args = [vp, C.POINTER(QlpcConfig), i32p, C.c_size_t, C.c_uint32, C.c_size_t, u8p, vp, i32p,
                   C.c_size_t, f64p, f64p]
     L.flacenc_hip_qlpc_batch.argtypes = batch_args + [C.c_int]
@@ -208,6 +211,9 @@ class Handle:
     def _check(self, rc):
         if rc != OK:
             raise FlacencHipError(rc, self._lib.flacenc_hip_last_error(self._h).decode())
+
+    def debug_set_stamps(self, device_ptr: int):
+        self._check(self._lib.flacenc_hip_debug_set_stamps(self._h, device_ptr or None))
 
     def synchronize(self):
         self._check(self._lib.flacenc_hip_synchronize(self._h))

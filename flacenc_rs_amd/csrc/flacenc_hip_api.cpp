@@ -39,6 +39,7 @@ struct flacenc_hip_handle {
   std::string last_error;
   std::vector<WindowEntry> windows;
   DeviceBuffer d_samples, d_residual, d_params, d_bps, d_autocorr, d_lpc, d_tables;
+  unsigned long long* stamps = nullptr;  // profiling hook, see flacenc_hip_debug_set_stamps
 };
 
 namespace {
@@ -205,6 +206,7 @@ int enqueue(flacenc_hip_handle* h, const flacenc_hip_qlpc_config* cfg, const int
   a.autocorr = autocorr;
   a.lpc_coefs = lpc_coefs;
   a.table_scratch = nullptr;
+  a.stamps = h->stamps;
   if (plan.table_scratch_bytes_per_subframe) {
     rc = ensure(h, h->d_tables, plan.table_scratch_bytes_per_subframe * n_subframes);
     if (rc != FLACENC_HIP_OK) return rc;
@@ -289,6 +291,12 @@ int flacenc_hip_window_weights(const flacenc_hip_qlpc_config* cfg, uint32_t bloc
   return FLACENC_HIP_OK;
 }
 
+int flacenc_hip_debug_set_stamps(flacenc_hip_handle* h, unsigned long long* device_stamps) {
+  if (!h) return FLACENC_HIP_ERR_BAD_ARGUMENT;
+  h->stamps = device_stamps;
+  return FLACENC_HIP_OK;
+}
+
 int flacenc_hip_synchronize(flacenc_hip_handle* h) {
   if (!h) return FLACENC_HIP_ERR_BAD_ARGUMENT;
   HIP_TRY(h, hipSetDevice(h->device));
@@ -306,7 +314,7 @@ int flacenc_hip_qlpc_batch_async(flacenc_hip_handle* h, const flacenc_hip_qlpc_c
                             residual_stride);
   if (rc != FLACENC_HIP_OK || n_subframes == 0) return rc;
   HIP_TRY(h, hipSetDevice(h->device));
-  hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
+  hipStream_t s = static_cast<hipStream_t>(stream);  // NULL = HIP's default (null) stream
   return enqueue(h, cfg, samples, n_subframes, block_size, stride, bps, params, residual,
                  residual_stride, autocorr, lpc_coefs, s);
 }
@@ -377,7 +385,7 @@ int flacenc_hip_stereo_qlpc_batch_async(flacenc_hip_handle* h, const flacenc_hip
     return FLACENC_HIP_ERR_BAD_ARGUMENT;
   }
   HIP_TRY(h, hipSetDevice(h->device));
-  hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
+  hipStream_t s = static_cast<hipStream_t>(stream);  // NULL = HIP's default (null) stream
   return enqueue(h, cfg, frames, n_frames * 4, block_size, stride, nullptr, params, residual,
                  residual_stride, nullptr, nullptr, s, true, bits_per_sample);
 }
@@ -388,9 +396,10 @@ int flacenc_hip_stereo_qlpc_batch(flacenc_hip_handle* h, const flacenc_hip_qlpc_
                                   flacenc_hip_subframe_params* params, int32_t* residual,
                                   size_t residual_stride, int memory_kind) {
   if (memory_kind == FLACENC_HIP_MEM_DEVICE) {
+    if (!h) return FLACENC_HIP_ERR_BAD_ARGUMENT;
     int rc = flacenc_hip_stereo_qlpc_batch_async(h, cfg, frames, n_frames, block_size, stride,
                                                  bits_per_sample, params, residual, residual_stride,
-                                                 nullptr);
+                                                 h->stream);
     if (rc != FLACENC_HIP_OK || n_frames == 0) return rc;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return FLACENC_HIP_OK;

@@ -34,6 +34,7 @@ struct QlpcKernelArgs {
   double* autocorr;                     // device, nullable, [n][33]
   double* lpc_coefs;                    // device, nullable, [n][32]
   uint32_t* table_scratch;              // device, only for blocks > 16384 samples
+  unsigned long long* stamps;           // device, nullable: [n][8] phase timestamps (profiling)
 };
 
 struct QlpcLaunchPlan {

@@ -73,6 +73,13 @@ __device__ __forceinline__ int ceil_log2_pos(double m) {
   return (e - 1023) + (frac != 0 ? 1 : 0);
 }
 
+// Optional per-phase timestamps (s_memtime, shader clock) for the profiling build of
+// tools/phase_profile.py: workgroup leader only, never read by the kernel itself.
+#define FLACENC_STAMP(slot)                                                             \
+  do {                                                                                  \
+    if (a.stamps && tid == 0) a.stamps[(size_t)sf * 8 + (slot)] = (unsigned long long)clock64(); \
+  } while (0)
+
 // LDS layout ------------------------------------------------------------------
 // Samples live in rows of 16 int32 with a row stride of ROWSTRIDE dwords
 // (20 = 16 + 4 pad: a thread reading its own row with ds_read_b128 then lands
@@ -259,7 +266,15 @@ qlpc_subframe_kernel(QlpcKernelArgs a) {
   int Jp = 1;
   while (Jp < J) Jp <<= 1;
   const int P = (int)a.lpc_order;
-  const uint32_t sf = blockIdx.x;
+  // Stereo mode: the four workgroups of a frame should share an XCD (and its L2) so that the
+  // left/right channels are fetched from HBM once: workgroups are dealt round-robin over the
+  // 8 XCDs, so block b and b+8 share one.  Blocks are grouped by 32: block 32g + 8r + x
+  // analyses role r of frame 8g + x.  (Placement is a speed matter only.)
+  uint32_t sf = blockIdx.x;
+  if (a.stereo && (a.n_subframes & 31u) == 0) {
+    const uint32_t g = sf >> 5, r = (sf >> 3) & 3u, x = sf & 7u;
+    sf = ((g << 3) + x) * 4u + r;
+  }
 
   // ---- carve LDS (every offset a multiple of 16 bytes) ----
   SmemLayout L;
@@ -284,6 +299,7 @@ qlpc_subframe_kernel(QlpcKernelArgs a) {
                    : reinterpret_cast<uint32_t*>(p);
   }
 
+  FLACENC_STAMP(0);
   // ======================= phase 0: load ===================================
   // Plain mode: subframe sf is the block at samples + sf*stride.  Stereo mode
   // (try_stereo_coding, coding.rs:476-484): workgroups 4f..4f+3 analyse L, R,
@@ -347,6 +363,7 @@ qlpc_subframe_kernel(QlpcKernelArgs a) {
   my_maxabs = wave_max_u32(my_maxabs);
   if (lane == 0) atomicMax(&L.misc[kMiscMaxAbs], my_maxabs);
 
+  FLACENC_STAMP(1);
   // ======================= phase 1: window + autocorrelation ==============
   // window table has 32 floats of zero padding in front and is padded to whole rows
   const float* __restrict__ wtab = a.window ? (a.window + 32) : nullptr;
@@ -409,6 +426,7 @@ qlpc_subframe_kernel(QlpcKernelArgs a) {
   if (a.autocorr && tid >= NLAG && tid < 33) a.autocorr[(size_t)sf * 33 + tid] = 0.0;
   __syncthreads();
 
+  FLACENC_STAMP(2);
   // ======================= phase 2: Levinson + quantisation ================
   if (tid == 0) {
     double coef[MAXP];
@@ -438,6 +456,7 @@ qlpc_subframe_kernel(QlpcKernelArgs a) {
   }
   __syncthreads();
 
+  FLACENC_STAMP(3);
   const int warm = (int)L.misc[kMiscOrder];
   const int shift = (int)L.misc[kMiscShift];
   const int status = (int)L.misc[kMiscStatus];
@@ -508,6 +527,7 @@ qlpc_subframe_kernel(QlpcKernelArgs a) {
   if (lane == 0) atomicOr(&L.misc[kMiscOrBits], my_or);
   __syncthreads();
 
+  FLACENC_STAMP(4);
   // ======================= phase 4: partitioned-Rice search ================
   // finest_partition_order(n, max(64, warm)), rice.rs:157-165, 247-250 (warm <= 32 < 64)
   int fo;
@@ -524,32 +544,186 @@ qlpc_subframe_kernel(QlpcKernelArgs a) {
   const int hw = tid >> 5;      // half-wave id: one bit table (32 lanes = 32 parameters) each
   const int NHW = T >> 5;
   const uint32_t p = (uint32_t)(tid & 31);
-  const uint32_t max_p = a.max_rice_parameter;
 
-  // PrcBitTable::from_errors(errs, 4), rice.rs:65-103, literally: u32 wrapping adds,
-  // clamp after every 16 samples of the partition's slice and after the offset.
-  for (int q = hw; q < nparts; q += NHW) {
-    int start = q * psize;
-    if (start < warm) start = warm;
-    const int end = (q + 1) * psize;
-    const int len = end - start;
-    uint32_t accb = 0;
-    for (int i = 0; i < len; ++i) {
-      uint32_t u = zigzag(L.sbuf[sidx<ROWSTRIDE>(start + i)]);
-      accb += u >> p;
-      if ((i & 15) == 15) accb = accb < kMaxPToBits ? accb : kMaxPToBits;
+  // Parameters beyond the residual's bit length can never win: for p >= bitlen every
+  // u >> p is 0, so a table entry is 4 + len*(p+1), strictly increasing in p, in every
+  // partition and therefore in every merged table.  Capping the search at
+  // min(max_p, bitlen) returns the same minimiser and the same bits as rice.rs:115-141.
+  const uint32_t maxu = L.misc[kMiscOrBits];
+  const uint32_t bitlen = maxu ? (uint32_t)(32 - __clz((int)maxu)) : 0u;
+  const uint32_t max_p = a.max_rice_parameter < bitlen ? a.max_rice_parameter : bitlen;
+
+  // Fast path: finest partitions of exactly 64 samples (every power-of-two block) are the
+  // 4 x 16 samples of 4 adjacent lanes.  Sum_i (u_i >> p) = Sum_b C_b 2^(b-p) with C_b the
+  // number of samples whose bit b is set; C_b is counted for all 32 b at once, bit-sliced:
+  // a carry-save adder tree over the thread's 16 words gives 5 bit-planes, two cross-lane
+  // adds (DPP quad permutes) give the 7 planes of the partition's counts, and then
+  // Sum_i (u_i >> p) = Sum_k (plane_k >> p) << k.  Exact totals equal the reference's
+  // chunk-clamped u32 sums (rice.rs:75-98) as long as no 16-sample chunk can wrap or
+  // exceed the clamp before the final min, i.e. u < 2^26; otherwise the literal path runs.
+  int first_generic_level = 0;
+  const bool fast = (psize == 64) && (maxu < (1u << 26));
+  if (fast) {
+    int kw = fo < 4 ? fo : 4;  // merge levels that stay inside one wave (16 partitions)
+    for (int j = 0; j < J; ++j) {
+      const int c = tid + j * T;
+      uint32_t u[16];
+      if (c < rows) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          int4 v = *reinterpret_cast<const int4*>(&L.sbuf[sidx<ROWSTRIDE>((c << 4) + 4 * i)]);
+          u[4 * i + 0] = zigzag(v.x);
+          u[4 * i + 1] = zigzag(v.y);
+          u[4 * i + 2] = zigzag(v.z);
+          u[4 * i + 3] = zigzag(v.w);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) u[i] = 0;
+      }
+      // Harley-Seal carry-save adder tree: 16 words -> planes {1, 2, 4, 8, 16}
+      uint32_t pl[7];
+      {
+        uint32_t ones = 0, twos = 0, fours = 0, eights = 0, sixteens;
+        uint32_t twosA, twosB, foursA, foursB, eightsA, eightsB;
+#define FLACENC_CSA(h, l, a_, b_, c_)                  \
+  {                                                    \
+    uint32_t t_ = (a_) ^ (b_);                         \
+    uint32_t h_ = (t_ & (c_)) | (~t_ & (a_));          \
+    l = t_ ^ (c_);                                     \
+    h = h_;                                            \
+  }
+        FLACENC_CSA(twosA, ones, ones, u[0], u[1])
+        FLACENC_CSA(twosB, ones, ones, u[2], u[3])
+        FLACENC_CSA(foursA, twos, twos, twosA, twosB)
+        FLACENC_CSA(twosA, ones, ones, u[4], u[5])
+        FLACENC_CSA(twosB, ones, ones, u[6], u[7])
+        FLACENC_CSA(foursB, twos, twos, twosA, twosB)
+        FLACENC_CSA(eightsA, fours, fours, foursA, foursB)
+        FLACENC_CSA(twosA, ones, ones, u[8], u[9])
+        FLACENC_CSA(twosB, ones, ones, u[10], u[11])
+        FLACENC_CSA(foursA, twos, twos, twosA, twosB)
+        FLACENC_CSA(twosA, ones, ones, u[12], u[13])
+        FLACENC_CSA(twosB, ones, ones, u[14], u[15])
+        FLACENC_CSA(foursB, twos, twos, twosA, twosB)
+        FLACENC_CSA(eightsB, fours, fours, foursA, foursB)
+        FLACENC_CSA(sixteens, eights, eights, eightsA, eightsB)
+#undef FLACENC_CSA
+        pl[0] = ones;
+        pl[1] = twos;
+        pl[2] = fours;
+        pl[3] = eights;
+        pl[4] = sixteens;
+      }
+      // bit-sliced ripple adds with lane^1 (quad_perm 1,0,3,2) then lane^2 (quad_perm 2,3,0,1)
+      {
+        uint32_t carry = 0;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+          uint32_t b = (uint32_t)__builtin_amdgcn_mov_dpp((int)pl[k], 0xB1, 0xF, 0xF, false);
+          uint32_t t_ = pl[k] ^ b;
+          uint32_t s_ = t_ ^ carry;
+          carry = (t_ & carry) | (~t_ & pl[k]);
+          pl[k] = s_;
+        }
+        pl[5] = carry;
+        carry = 0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          uint32_t b = (uint32_t)__builtin_amdgcn_mov_dpp((int)pl[k], 0x4E, 0xF, 0xF, false);
+          uint32_t t_ = pl[k] ^ b;
+          uint32_t s_ = t_ ^ carry;
+          carry = (t_ & carry) | (~t_ & pl[k]);
+          pl[k] = s_;
+        }
+        pl[6] = carry;
+      }
+      // this lane's share of the partition's table: parameters p = (lane & 3) + 4 i
+      const int q0 = c >> 2;  // finest partition index
+      const uint32_t len = 64u - (q0 == 0 ? (uint32_t)warm : 0u);
+      const uint32_t pq = (uint32_t)(tid & 3);
+      uint32_t tv[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const uint32_t pp = pq + 4u * (uint32_t)i;
+        uint32_t sum = 0;
+        if (4u * (uint32_t)i <= max_p) {  // block-uniform trip count
+#pragma unroll
+          for (int k = 0; k < 7; ++k) sum += (pl[k] >> pp) << k;
+        }
+        sum = sum < kMaxPToBits ? sum : kMaxPToBits;
+        uint32_t v = sum + (4u + len * (pp + 1u));  // rice.rs:69-71, 95-98
+        tv[i] = v < kMaxPToBits ? v : kMaxPToBits;
+      }
+      // orders fo .. fo-kw inside the wave: minimiser per partition (quad, then wider groups),
+      // merge with the neighbouring group by a lane butterfly (rice.rs:144-152, 193-216)
+      for (int k = 0; k <= kw; ++k) {
+        if (k > 0) {
+          const int xm = 2 << k;  // lane xor 4, 8, 16, 32
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            uint32_t o = (uint32_t)__shfl_xor((int)tv[i], xm, 64);
+            uint32_t v = tv[i] + o - 4u;
+            tv[i] = v < kMaxPToBits ? v : kMaxPToBits;
+          }
+        }
+        uint32_t packed = 0xFFFFFFFFu;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const uint32_t pp = pq + 4u * (uint32_t)i;
+          uint32_t cand = (((pp <= max_p) ? tv[i] : 0xFFFFFFFFu) << 5) | pp;
+          packed = cand < packed ? cand : packed;
+        }
+        {
+          uint32_t o = (uint32_t)__builtin_amdgcn_mov_dpp((int)packed, 0xB1, 0xF, 0xF, false);
+          packed = o < packed ? o : packed;
+          o = (uint32_t)__builtin_amdgcn_mov_dpp((int)packed, 0x4E, 0xF, 0xF, false);
+          packed = o < packed ? o : packed;
+        }
+        const int qk = q0 >> k;
+        const int m = nparts >> k;
+        if ((lane & ((4 << k) - 1)) == 0 && qk < m) {
+          uint32_t bits = packed >> 5;
+          uint8_t* ps_k = L.ps + (2 * nparts - 2 * m);
+          ps_k[qk] = (uint8_t)(packed & 31u);
+          atomicAdd(&L.level_bits[k], (unsigned long long)bits);
+          if (bits >= kMaxPToBits) atomicOr(&L.misc[kMiscSat], 1u << k);
+        }
+      }
+      // hand the wave's order-(fo-kw) table to the cross-wave levels
+      if (kw < fo && lane < 4 && c < rows) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) L.tables[(size_t)q0 * 32 + pq + 4u * (uint32_t)i] = tv[i];
+      }
     }
-    accb = accb < kMaxPToBits ? accb : kMaxPToBits;
-    uint32_t v = accb + (4u + (uint32_t)len * (p + 1u));
-    v = v < kMaxPToBits ? v : kMaxPToBits;
-    L.tables[(size_t)q * 32 + p] = v;
+    first_generic_level = kw + 1;
+  } else {
+    // PrcBitTable::from_errors(errs, 4), rice.rs:65-103, literally: u32 wrapping adds,
+    // clamp after every 16 samples of the partition's slice and after the offset.
+    for (int q = hw; q < nparts; q += NHW) {
+      int start = q * psize;
+      if (start < warm) start = warm;
+      const int end = (q + 1) * psize;
+      const int len = end - start;
+      uint32_t accb = 0;
+      for (int i = 0; i < len; ++i) {
+        uint32_t u = zigzag(L.sbuf[sidx<ROWSTRIDE>(start + i)]);
+        accb += u >> p;
+        if ((i & 15) == 15) accb = accb < kMaxPToBits ? accb : kMaxPToBits;
+      }
+      accb = accb < kMaxPToBits ? accb : kMaxPToBits;
+      uint32_t v = accb + (4u + (uint32_t)len * (p + 1u));
+      v = v < kMaxPToBits ? v : kMaxPToBits;
+      L.tables[(size_t)q * 32 + p] = v;
+    }
   }
   if (BIG) __threadfence_block();
   __syncthreads();
 
-  // eval_partitions / merge_partitions over all orders fo, fo-1, ..., 0
-  // (rice.rs:193-216, 277-291).  Level k keeps its tables at indices q << k.
-  for (int k = 0; k <= fo; ++k) {
+  FLACENC_STAMP(5);
+  // eval_partitions / merge_partitions over the remaining orders (rice.rs:193-216, 277-291).
+  // Level k keeps its tables at indices q << k.
+  for (int k = first_generic_level; k <= fo; ++k) {
     const int m = nparts >> k;
     const int stride = 1 << k;
     uint8_t* ps_k = L.ps + (2 * nparts - 2 * m);  // level k owns m bytes at this offset
@@ -602,6 +776,7 @@ qlpc_subframe_kernel(QlpcKernelArgs a) {
   const int best_psize = n >> rice_order;
   const unsigned long long code_bits = L.level_bits[bestk];
 
+  FLACENC_STAMP(6);
   // ======================= phase 5: outputs ================================
   int32_t* __restrict__ dst = a.residual + (size_t)sf * a.residual_stride;
   {
@@ -674,6 +849,7 @@ qlpc_subframe_kernel(QlpcKernelArgs a) {
     rec->subframe_bits = status == 0 ? sub_bits : 0ull;
     rec->sum_quotients = status == 0 ? sum_q : 0ull;
   }
+  FLACENC_STAMP(7);
 }
 
 template <int MAXP, bool BIG>

@@ -146,7 +146,7 @@ int flacenc_hip_qlpc_batch(flacenc_hip_handle* h, const flacenc_hip_qlpc_config*
                            int memory_kind);
 
 /* Same with device pointers only, enqueued on `stream` (a hipStream_t; NULL =
- * the handle's own stream) without synchronising. */
+ * HIP's default stream) without synchronising. */
 int flacenc_hip_qlpc_batch_async(flacenc_hip_handle* h, const flacenc_hip_qlpc_config* cfg,
                                  const int32_t* samples, size_t n_subframes, uint32_t block_size,
                                  size_t stride, const uint8_t* bps,
@@ -177,6 +177,12 @@ int flacenc_hip_stereo_qlpc_batch_async(flacenc_hip_handle* h, const flacenc_hip
                                         size_t residual_stride, void* stream);
 
 int flacenc_hip_synchronize(flacenc_hip_handle* h);
+
+/* Profiling hook (no reference counterpart): when `device_stamps` is non-NULL every
+ * following launch makes each workgroup leader store 8 shader-clock timestamps
+ * (phase boundaries of the fused kernel) at device_stamps[subframe*8 + phase].
+ * Pass NULL to switch it off again.  See tools/phase_profile.py. */
+int flacenc_hip_debug_set_stamps(flacenc_hip_handle* h, unsigned long long* device_stamps);
 
 #ifdef __cplusplus
 }

@@ -21,6 +21,42 @@
 #include <time.h>
 
 /* ------------------------------------------------------------------------ */
+/* per-thread scratch (the role of the reference's `reusable!` thread-locals, */
+/* src/lib.rs:92-116: WINDOW_CACHE lpc.rs:219, LPC_ESTIMATOR :916,           */
+/* QLPC_ERROR_BUFFER coding.rs:353, PRC_FINDER rice.rs:301)                  */
+/* ------------------------------------------------------------------------ */
+typedef struct {
+  float* window;  /* cached window_weights(type, alpha, n) */
+  size_t window_n;
+  uint32_t window_type;
+  float window_alpha;
+  float* xw;
+  size_t xw_cap;
+  uint32_t* uerr;
+  size_t uerr_cap;
+  uint32_t (*tables)[32];
+  size_t tables_cap;
+  uint8_t* ps;
+  uint8_t* min_ps;
+  size_t ps_cap;
+  int64_t* acc64;
+  size_t acc64_cap;
+  double* partial;
+  size_t partial_cap;
+} orc_scratch;
+
+static __thread orc_scratch orc_tls;
+
+#define ORC_GROW(ptr, cap, need, type)                          \
+  do {                                                          \
+    if ((cap) < (size_t)(need)) {                               \
+      free(ptr);                                                \
+      (cap) = (size_t)(need) + 64;                              \
+      (ptr) = (type*)malloc(sizeof(type) * (cap));              \
+    }                                                           \
+  } while (0)
+
+/* ------------------------------------------------------------------------ */
 /* src/lpc.rs                                                               */
 /* ------------------------------------------------------------------------ */
 
@@ -105,7 +141,8 @@ void orc_auto_correlation_canonical_f64(size_t order, const float* signal, size_
   size_t nchunks = (n + 15) / 16;
   size_t pow2 = 1;
   while (pow2 < nchunks) pow2 <<= 1;
-  double* partial = (double*)malloc(sizeof(double) * nchunks);
+  ORC_GROW(orc_tls.partial, orc_tls.partial_cap, nchunks, double);
+  double* partial = orc_tls.partial;
   for (size_t tau = 0; tau < order; ++tau) {
     for (size_t c = 0; c < nchunks; ++c) {
       double acc = 0.0;
@@ -117,7 +154,6 @@ void orc_auto_correlation_canonical_f64(size_t order, const float* signal, size_
     }
     dest[tau] = orc_tree_sum(partial, 0, pow2, nchunks);
   }
-  free(partial);
 }
 
 /* symmetric_levinson_recursion, src/lpc.rs:633-705.
@@ -239,7 +275,9 @@ static void orc_compute_error_i32(const orc_qparams* qp, const int32_t* signal, 
 /* compute_error_impl::<i64, _> followed by `as i32`, src/lpc.rs:379-388 */
 static void orc_compute_error_i64(const orc_qparams* qp, const int32_t* signal, size_t n,
                                   int32_t* errors) {
-  int64_t* acc = (int64_t*)calloc(n ? n : 1, sizeof(int64_t));
+  ORC_GROW(orc_tls.acc64, orc_tls.acc64_cap, n + 1, int64_t);
+  int64_t* acc = orc_tls.acc64;
+  for (size_t t = 0; t < n; ++t) acc[t] = 0;
   for (size_t j = 0; j < qp->order; ++j) {
     int64_t w = qp->coefs[j];
     for (size_t i = 0; i + j + 1 < n; ++i) acc[i + j + 1] += w * (int64_t)signal[i];
@@ -249,7 +287,6 @@ static void orc_compute_error_i64(const orc_qparams* qp, const int32_t* signal, 
     errors[t] = (int32_t)(uint32_t)(uint64_t)e; /* `as i32` truncation */
   }
   for (size_t t = 0; t < qp->order && t < n; ++t) errors[t] = 0;
-  free(acc);
 }
 
 /* compute_error, src/lpc.rs:359-390 */
@@ -273,17 +310,25 @@ int orc_lpc_from_autocorr(const int32_t* signal, size_t n, const orc_qlpc_config
   size_t lpc_order = cfg->lpc_order;
   for (size_t i = 0; i < lpc_order; ++i) coefs_out[i] = 0.0;
   if (lpc_order == 0) return ORC_STATUS_OK;
-  float* window = (float*)malloc(sizeof(float) * (n ? n : 1));
-  float* xw = (float*)malloc(sizeof(float) * (n ? n : 1));
-  orc_window_weights(cfg->window_type, cfg->tukey_alpha, n, window);
+  /* get_window, src/lpc.rs:222-231: the table is computed once per (size, window) per thread */
+  if (orc_tls.window == NULL || orc_tls.window_n != n || orc_tls.window_type != cfg->window_type ||
+      orc_tls.window_alpha != cfg->tukey_alpha) {
+    free(orc_tls.window);
+    orc_tls.window = (float*)malloc(sizeof(float) * (n ? n : 1));
+    orc_window_weights(cfg->window_type, cfg->tukey_alpha, n, orc_tls.window);
+    orc_tls.window_n = n;
+    orc_tls.window_type = cfg->window_type;
+    orc_tls.window_alpha = cfg->tukey_alpha;
+  }
+  ORC_GROW(orc_tls.xw, orc_tls.xw_cap, n + 1, float);
+  float* window = orc_tls.window;
+  float* xw = orc_tls.xw;
   orc_fill_windowed_signal(signal, window, n, xw);
   double corr[ORC_MAX_LPC_ORDER + 1];
   if (cfg->acorr_order == ORC_ACORR_CANONICAL)
     orc_auto_correlation_canonical_f64(lpc_order + 1, xw, n, corr);
   else
     orc_auto_correlation_f64(lpc_order + 1, xw, n, corr);
-  free(window);
-  free(xw);
   int status = ORC_STATUS_OK;
   for (size_t i = 0; i <= lpc_order; ++i) {
     if (autocorr_out) autocorr_out[i] = corr[i];
@@ -382,10 +427,23 @@ void orc_find_partitioned_rice_parameter(const int32_t* signal, size_t n, size_t
                                                                 : ORC_MIN_RICE_PARTITION_SIZE;
   uint32_t partition_order = orc_finest_partition_order(n, min_part);
   size_t nparts = (size_t)1 << partition_order;
-  uint32_t* errors = (uint32_t*)malloc(sizeof(uint32_t) * (n ? n : 1));
-  uint32_t(*tables)[32] = (uint32_t(*)[32])malloc(sizeof(uint32_t[32]) * nparts);
-  uint8_t* ps = (uint8_t*)malloc(nparts);
-  uint8_t* min_ps = (uint8_t*)malloc(nparts);
+  ORC_GROW(orc_tls.uerr, orc_tls.uerr_cap, n + 1, uint32_t);
+  if (orc_tls.tables_cap < nparts) {
+    free(orc_tls.tables);
+    orc_tls.tables_cap = nparts;
+    orc_tls.tables = (uint32_t(*)[32])malloc(sizeof(uint32_t[32]) * nparts);
+  }
+  if (orc_tls.ps_cap < nparts) {
+    free(orc_tls.ps);
+    free(orc_tls.min_ps);
+    orc_tls.ps_cap = nparts;
+    orc_tls.ps = (uint8_t*)malloc(nparts);
+    orc_tls.min_ps = (uint8_t*)malloc(nparts);
+  }
+  uint32_t* errors = orc_tls.uerr;
+  uint32_t(*tables)[32] = orc_tls.tables;
+  uint8_t* ps = orc_tls.ps;
+  uint8_t* min_ps = orc_tls.min_ps;
   for (size_t t = 0; t < n; ++t) errors[t] = orc_encode_signbit(signal[t]);
   size_t part_size = n / nparts;
   for (size_t p = 0; p < nparts; ++p) {
@@ -426,10 +484,6 @@ void orc_find_partitioned_rice_parameter(const int32_t* signal, size_t n, size_t
   out->order = min_order;
   out->code_bits = min_bits;
   memcpy(out->ps, min_ps, (size_t)1 << min_order);
-  free(errors);
-  free(tables);
-  free(ps);
-  free(min_ps);
 }
 
 /* ------------------------------------------------------------------------ */
@@ -527,7 +581,8 @@ void orc_estimated_qlpc(const int32_t* signal, size_t n, uint32_t bits_per_sampl
   }
   orc_quantize_parameters(res->lpc_coefs, cfg->lpc_order, cfg->quant_precision, &res->qp);
   orc_compute_error(&res->qp, signal, n, errors);
-  orc_prc_parameter* prc = (orc_prc_parameter*)malloc(sizeof(orc_prc_parameter));
+  static __thread orc_prc_parameter prc_storage;
+  orc_prc_parameter* prc = &prc_storage;
   orc_find_partitioned_rice_parameter(errors, n, res->qp.order, cfg->max_rice_parameter, prc);
   res->rice_order = prc->order;
   res->code_bits = prc->code_bits;
@@ -538,7 +593,6 @@ void orc_estimated_qlpc(const int32_t* signal, size_t n, uint32_t bits_per_sampl
                                                res->sum_quotients, res->sum_rice_params);
   res->subframe_bits =
       orc_lpc_count_bits(bits_per_sample, res->qp.order, res->qp.precision, res->residual_bits);
-  free(prc);
 }
 
 /* src/coding.rs:476-484: mid = (l + r) >> 1, side = l - r */
@@ -693,6 +747,7 @@ typedef struct {
   const int32_t* frames;
   size_t begin, end, n, stride;
   uint32_t bps;
+  int repeats;
   const orc_qlpc_config* cfg;
   uint64_t checksum;
 } orc_stereo_job;
@@ -706,6 +761,7 @@ static void* orc_stereo_worker(void* arg) {
   uint8_t* rp = (uint8_t*)malloc(ORC_MAX_RICE_PARTITIONS);
   orc_qlpc_result res;
   uint64_t sum = 0;
+  for (int rep = 0; rep < job->repeats; ++rep)
   for (size_t f = job->begin; f < job->end; ++f) {
     const int32_t* l = job->frames + (2 * f) * job->stride;
     const int32_t* r = l + job->stride;
@@ -737,9 +793,10 @@ double orc_bench_stereo_qlpc(const int32_t* frames, size_t n_frames, size_t n, s
   struct timespec t0, t1;
   uint64_t total = 0;
   clock_gettime(CLOCK_MONOTONIC, &t0);
-  for (int r = 0; r < repeats; ++r) {
+  { /* threads are spawned once; each makes `repeats` passes over its own frames */
     for (int i = 0; i < nthreads; ++i) {
       jobs[i].frames = frames;
+      jobs[i].repeats = repeats;
       jobs[i].n = n;
       jobs[i].stride = stride;
       jobs[i].bps = bits_per_sample;

@@ -1,0 +1,18 @@
+#!/bin/bash
+# rocprofv3 PMC passes for bench.py (one counter group per pass; --kernel-trace only).
+# usage: tools/pmc_profile.sh <outdir-under-gpurun_out> [bench args...]
+set -u
+OUT=$GRAFT_REPO_ROOT/gpurun_out/$1; shift
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+run() { # name counters...
+  local name=$1; shift
+  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline "${BENCH_ARGS[@]}" > $OUT/$name.log 2>&1
+}
+BENCH_ARGS=("$@")
+run fetch FETCH_SIZE
+run write WRITE_SIZE
+run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS
+run sq2 SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS
+run sq3 SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_LDS_UNALIGNED_STALL GRBM_GUI_ACTIVE
+python3 $GRAFT_REPO_ROOT/tools/pmc_summarize.py $OUT

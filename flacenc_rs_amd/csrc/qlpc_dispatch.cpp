@@ -2,6 +2,8 @@
 // and dispatch to the per-bucket kernel instantiations.
 #include "qlpc_kernel.h"
 
+#include <cstdlib>
+
 namespace flacenc_hip {
 namespace {
 
@@ -19,8 +21,18 @@ int bucket_order(int P) {
 
 }  // namespace
 
+bool wave_kernel_eligible(const QlpcKernelArgs& a) {
+  if (a.block_size != 4096 || a.lpc_order > 12) return false;
+  if (getenv("FLACENC_HIP_FORCE_GENERIC")) return false;
+  if ((reinterpret_cast<uintptr_t>(a.samples) & 15) || (a.stride & 3)) return false;
+  if ((reinterpret_cast<uintptr_t>(a.residual) & 15) || (a.residual_stride & 3)) return false;
+  if (a.stereo && (a.n_subframes & 3)) return false;
+  return true;
+}
+
 QlpcLaunchPlan plan_qlpc_launch(uint32_t block_size, uint32_t lpc_order) {
   QlpcLaunchPlan plan;
+  plan.wave = false;
   const int n = static_cast<int>(block_size);
   const int rows = (n + 15) / 16;
   plan.big = n > 16384;
@@ -56,6 +68,13 @@ QlpcLaunchPlan plan_qlpc_launch(uint32_t block_size, uint32_t lpc_order) {
 
 hipError_t launch_qlpc(const QlpcKernelArgs& a, const QlpcLaunchPlan& plan, hipStream_t stream) {
   if (a.n_subframes == 0) return hipSuccess;
+  if (wave_kernel_eligible(a)) {
+    const int mp = a.lpc_order <= 8 ? 8 : (a.lpc_order <= 10 ? 10 : 12);
+#define FLACENC_HIP_WCASE(MP, ST) \
+  if (mp == MP && (a.stereo != 0) == (ST != 0)) return launch_qlpc_wave_##MP##_##ST(a, stream);
+    FLACENC_HIP_FOR_EACH_WAVE_INSTANCE(FLACENC_HIP_WCASE)
+#undef FLACENC_HIP_WCASE
+  }
 #define FLACENC_HIP_CASE(MP, BG)                       \
   if (plan.maxp == MP && plan.big == (BG != 0))        \
     return launch_qlpc_##MP##_##BG(a, plan.threads, plan.smem_bytes, stream);

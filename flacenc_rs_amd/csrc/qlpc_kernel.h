@@ -38,6 +38,7 @@ struct QlpcKernelArgs {
 };
 
 struct QlpcLaunchPlan {
+  bool wave;       // wave-per-subframe kernel (block_size 4096, order <= 12, aligned buffers)
   int maxp;        // template bucket for the LPC order
   bool big;        // block_size > 16384: unpadded LDS image, bit tables in HBM scratch
   int threads;     // workgroup size (power of two, 64..1024)
@@ -46,6 +47,8 @@ struct QlpcLaunchPlan {
 };
 
 QlpcLaunchPlan plan_qlpc_launch(uint32_t block_size, uint32_t lpc_order);
+// true if the wave-per-subframe kernel can take this launch (decided per call: alignment)
+bool wave_kernel_eligible(const QlpcKernelArgs& args);
 hipError_t launch_qlpc(const QlpcKernelArgs& args, const QlpcLaunchPlan& plan, hipStream_t stream);
 
 // one per (order bucket, big) instantiation, each defined by its own translation unit
@@ -54,6 +57,11 @@ hipError_t launch_qlpc(const QlpcKernelArgs& args, const QlpcLaunchPlan& plan, h
 #define FLACENC_HIP_DECLARE_INSTANCE(MP, BG) \
   hipError_t launch_qlpc_##MP##_##BG(const QlpcKernelArgs&, int threads, size_t smem, hipStream_t);
 FLACENC_HIP_FOR_EACH_INSTANCE(FLACENC_HIP_DECLARE_INSTANCE)
+
+#define FLACENC_HIP_FOR_EACH_WAVE_INSTANCE(X) X(8, 0) X(8, 1) X(10, 0) X(10, 1) X(12, 0) X(12, 1)
+#define FLACENC_HIP_DECLARE_WAVE_INSTANCE(MP, ST) \
+  hipError_t launch_qlpc_wave_##MP##_##ST(const QlpcKernelArgs&, hipStream_t);
+FLACENC_HIP_FOR_EACH_WAVE_INSTANCE(FLACENC_HIP_DECLARE_WAVE_INSTANCE)
 
 }  // namespace flacenc_hip
 #endif

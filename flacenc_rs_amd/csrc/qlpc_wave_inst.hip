@@ -1,0 +1,12 @@
+// qlpc_wave_inst.hip -- one instantiation of the wave-per-subframe kernel per translation
+// unit (compiled with -DFLACENC_MAXP=<8|10|12> -DFLACENC_STEREO=<0|1>).
+#include "qlpc_wave_kernel_impl.h"
+
+#define FLACENC_CAT2(a, b, c) launch_qlpc_wave_##a##_##b
+#define FLACENC_CAT(a, b) FLACENC_CAT2(a, b, )
+
+namespace flacenc_hip {
+hipError_t FLACENC_CAT(FLACENC_MAXP, FLACENC_STEREO)(const QlpcKernelArgs& a, hipStream_t stream) {
+  return launch_wave4096<FLACENC_MAXP, (FLACENC_STEREO != 0)>(a, stream);
+}
+}  // namespace flacenc_hip

@@ -1,0 +1,639 @@
+// qlpc_wave_kernel_impl.h -- wave-per-subframe variant of the fused QLPC kernel for
+// 4096-sample blocks (the default block size and every 44.1 kHz BASELINE config).
+//
+// The generic kernel (qlpc_kernel_impl.h) spreads one subframe over a whole
+// workgroup and therefore stalls all of it on every serial step (Levinson, the
+// cross-wave reductions).  Here ONE WAVE owns one subframe from the first LDS
+// read to the parameter record: lane l holds the 64 samples [64 l, 64 l + 64)
+// = four 16-sample chunks = exactly one finest Rice partition, so
+//   * the autocorrelation tree is 2 in-lane levels + one 6-level lane butterfly
+//     (identical balanced tree over the chunk index -> same canonical sums),
+//   * Levinson + quantisation run redundantly on all lanes (no broadcast, no barrier),
+//   * the residual, its bit-sliced population counts and the partition's 32-entry
+//     bit table never leave the lane's registers,
+//   * orders 6..0 of the Rice search are a lane butterfly.
+// A workgroup is 4 waves: in stereo mode the four roles L, R, M, S of one frame
+// sharing the two channel images in LDS (HBM reads: each channel once); in plain
+// mode four independent subframes.
+//
+// All `file:line` citations are relative to the flacenc-rs v0.5.1 tree.
+#ifndef FLACENC_HIP_QLPC_WAVE_KERNEL_IMPL_H_
+#define FLACENC_HIP_QLPC_WAVE_KERNEL_IMPL_H_
+
+#include "qlpc_kernel_impl.h"
+
+namespace flacenc_hip {
+namespace {
+
+constexpr int kWaveN = 4096;        // block size handled by this kernel
+constexpr int kSeg = 68;            // dwords per lane segment: 64 samples + 4 pad (conflict-free b128)
+constexpr int kBufDwords = 65 * kSeg;  // one leading all-zero segment (halo of lane 0)
+
+__device__ __forceinline__ int widx(int t) { return ((t >> 6) + 1) * kSeg + (t & 63); }
+// |v| with i32::MIN -> 2^31 - 1 + 1 handled by the caller's unsigned compare; inputs are <= 25 bits
+__device__ __forceinline__ int abs_sat(int v) { return v < 0 ? -v : v; }
+
+// ---- cross-lane helpers (DPP: no LDS traffic) --------------------------------
+#define FLACENC_DPP(v, ctrl, rowmask) \
+  ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), (ctrl), (rowmask), 0xF, false))
+
+// value of lane + s for s in {1, 2, 4, 8} (row_shl), 16 (swizzle xor 16), 32 (readlane);
+// only meaningful on lanes that are multiples of 2 s -- the group leaders that use it
+template <int S>
+__device__ __forceinline__ uint32_t from_upper_half(uint32_t v) {
+  if (S == 1) return FLACENC_DPP(v, 0x101, 0xF);
+  if (S == 2) return FLACENC_DPP(v, 0x102, 0xF);
+  if (S == 4) return FLACENC_DPP(v, 0x104, 0xF);
+  if (S == 8) return FLACENC_DPP(v, 0x108, 0xF);
+  if (S == 16) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x401F);  // lane ^ 16
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 32);
+}
+
+// wave-wide sum (< 2^32), result uniform: row scan (row_shr 1,2,4,8), row_bcast15, row_bcast31
+__device__ __forceinline__ uint32_t wave_sum_dpp(uint32_t v) {
+  v += FLACENC_DPP(v, 0x111, 0xF);
+  v += FLACENC_DPP(v, 0x112, 0xF);
+  v += FLACENC_DPP(v, 0x114, 0xF);
+  v += FLACENC_DPP(v, 0x118, 0xF);
+  v += FLACENC_DPP(v, 0x142, 0xA);
+  v += FLACENC_DPP(v, 0x143, 0xC);
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+__device__ __forceinline__ uint32_t wave_or_dpp(uint32_t v) {
+  v |= FLACENC_DPP(v, 0x111, 0xF);
+  v |= FLACENC_DPP(v, 0x112, 0xF);
+  v |= FLACENC_DPP(v, 0x114, 0xF);
+  v |= FLACENC_DPP(v, 0x118, 0xF);
+  v |= FLACENC_DPP(v, 0x142, 0xA);
+  v |= FLACENC_DPP(v, 0x143, 0xC);
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+__device__ __forceinline__ uint32_t wave_max_dpp(uint32_t v) {
+  uint32_t o;
+  o = FLACENC_DPP(v, 0x111, 0xF); v = o > v ? o : v;
+  o = FLACENC_DPP(v, 0x112, 0xF); v = o > v ? o : v;
+  o = FLACENC_DPP(v, 0x114, 0xF); v = o > v ? o : v;
+  o = FLACENC_DPP(v, 0x118, 0xF); v = o > v ? o : v;
+  o = FLACENC_DPP(v, 0x142, 0xA); v = o > v ? o : v;
+  o = FLACENC_DPP(v, 0x143, 0xC); v = o > v ? o : v;
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// carry-save adder on bit-planes: (h, l) = a + b + c per bit position
+#define FLACENC_CSA(h, l, a_, b_, c_)             \
+  {                                               \
+    uint32_t t_ = (a_) ^ (b_);                    \
+    uint32_t h_ = (t_ & (c_)) | (~t_ & (a_));     \
+    l = t_ ^ (c_);                                \
+    h = h_;                                       \
+  }
+
+// 16 words -> bit-planes {1, 2, 4, 8, 16} of the per-bit population counts (Harley-Seal)
+__device__ __forceinline__ void popcount_planes16(const uint32_t* u, uint32_t (&pl)[5]) {
+  uint32_t ones = 0, twos = 0, fours = 0, eights = 0, sixteens;
+  uint32_t twosA, twosB, foursA, foursB, eightsA, eightsB;
+  FLACENC_CSA(twosA, ones, ones, u[0], u[1])
+  FLACENC_CSA(twosB, ones, ones, u[2], u[3])
+  FLACENC_CSA(foursA, twos, twos, twosA, twosB)
+  FLACENC_CSA(twosA, ones, ones, u[4], u[5])
+  FLACENC_CSA(twosB, ones, ones, u[6], u[7])
+  FLACENC_CSA(foursB, twos, twos, twosA, twosB)
+  FLACENC_CSA(eightsA, fours, fours, foursA, foursB)
+  FLACENC_CSA(twosA, ones, ones, u[8], u[9])
+  FLACENC_CSA(twosB, ones, ones, u[10], u[11])
+  FLACENC_CSA(foursA, twos, twos, twosA, twosB)
+  FLACENC_CSA(twosA, ones, ones, u[12], u[13])
+  FLACENC_CSA(twosB, ones, ones, u[14], u[15])
+  FLACENC_CSA(foursB, twos, twos, twosA, twosB)
+  FLACENC_CSA(eightsB, fours, fours, foursA, foursB)
+  FLACENC_CSA(sixteens, eights, eights, eightsA, eightsB)
+  pl[0] = ones;
+  pl[1] = twos;
+  pl[2] = fours;
+  pl[3] = eights;
+  pl[4] = sixteens;
+}
+
+// bit-sliced add: a (NA planes) += b (NA planes) -> NA + 1 planes
+template <int NA>
+__device__ __forceinline__ void planes_add(uint32_t* a, const uint32_t* b) {
+  uint32_t carry = 0;
+#pragma unroll
+  for (int k = 0; k < NA; ++k) {
+    uint32_t t_ = a[k] ^ b[k];
+    uint32_t s_ = t_ ^ carry;
+    carry = (t_ & carry) | (~t_ & a[k]);
+    a[k] = s_;
+  }
+  a[NA] = carry;
+}
+
+struct RiceResult {
+  int bestk;                     // chosen order = 6 - bestk (uniform)
+  unsigned long long best_bits;  // PrcParameter::code_bits (uniform)
+  uint32_t my_p;                 // parameter of the chosen-order partition this lane leads
+  bool saturated;
+};
+
+// Orders 6..0 of PrcParameterFinder::find (rice.rs:246-298) for a 4096 block with one finest
+// partition per lane.  Table entries are kept as  Wp[p] = table[p] - 4  so that
+//   merge   (rice.rs:144-152): min(a + b - 4, MAX) on tables == min(Wa + Wb, MAX - 4)
+//   minimiser (rice.rs:115-141): min over p of (Wp[p] << 5 | p), bits = (min >> 5) + 4, p = min & 31.
+// Level k's tables are valid on the lanes that are multiples of 2^k (group leaders), which
+// fetch their partner's entries from lane + 2^(k-1).  NP = number of parameters evaluated
+// (a multiple of 8 above max_p; entries above max_p are masked in the minimiser).
+// EXACT = false: literal chunk-clamped sums of rice.rs:75-98 for residuals >= 2^26.
+template <int NP, bool EXACT>
+__device__ __forceinline__ RiceResult rice_search(const uint32_t (&pl)[7], const uint32_t* u, uint32_t len0,
+                                                  uint32_t max_p, bool small_bits, int lane, int warm) {
+  constexpr uint32_t kWMax = kMaxPToBits - 4u;
+  uint32_t Wp[NP];
+  if (EXACT) {
+#pragma unroll
+    for (int pp = 0; pp < NP; ++pp) {
+      uint32_t sum = 0;
+#pragma unroll
+      for (int k = 0; k < 7; ++k) sum += (pl[k] >> pp) << k;  // sum_i (u_i >> pp)
+      sum = sum < kMaxPToBits ? sum : kMaxPToBits;
+      uint32_t v = sum + len0 * (uint32_t)(pp + 1);  // rice.rs:69-71, 95-98 (minus the 4)
+      v = v < kWMax ? v : kWMax;
+      Wp[pp] = v;
+    }
+  } else {
+    // the reference's slice of partition 0 starts at `warm`; its clamp cadence follows.
+    // (rare path: runtime loop over p, registers selected by compare chains -- no scratch)
+    const int off = (lane == 0) ? warm : 0;
+#pragma unroll
+    for (int q = 0; q < NP; ++q) Wp[q] = 0;
+#pragma unroll 1
+    for (int pp = 0; pp < NP; ++pp) {
+      uint32_t accb = 0;
+#pragma unroll
+      for (int k = 0; k < 64; ++k) {
+        if (k >= off) {
+          accb += u[k] >> pp;
+          if (((k - off) & 15) == 15) accb = accb < kMaxPToBits ? accb : kMaxPToBits;
+        }
+      }
+      accb = accb < kMaxPToBits ? accb : kMaxPToBits;
+      uint32_t v = accb + len0 * (uint32_t)(pp + 1);
+      v = v < kWMax ? v : kWMax;
+#pragma unroll
+      for (int q = 0; q < NP; ++q) Wp[q] = (q == pp) ? v : Wp[q];
+    }
+  }
+
+  RiceResult r;
+  r.bestk = 0;
+  r.best_bits = 0;
+  r.my_p = 0;
+  r.saturated = false;
+  uint32_t sat_any = 0;
+#define FLACENC_RICE_LEVEL(K, S)                                                              \
+  {                                                                                           \
+    if (K > 0) {                                                                              \
+      _Pragma("unroll") for (int pp = 0; pp < NP; ++pp) {                                     \
+        uint32_t v = Wp[pp] + from_upper_half<S>(Wp[pp]);                                     \
+        Wp[pp] = v < kWMax ? v : kWMax;                                                       \
+      }                                                                                       \
+    }                                                                                         \
+    uint32_t packed = 0xFFFFFFFFu;                                                            \
+    _Pragma("unroll") for (int pp = 0; pp < NP; ++pp) {                                       \
+      uint32_t cand = ((uint32_t)pp <= max_p) ? ((Wp[pp] << 5) | (uint32_t)pp) : 0xFFFFFFFFu; \
+      packed = cand < packed ? cand : packed;                                                 \
+    }                                                                                         \
+    const uint32_t bits = (packed >> 5) + 4u;                                                 \
+    const bool lead = (lane & ((1 << K) - 1)) == 0;                                           \
+    const uint32_t lb = lead ? bits : 0u;                                                     \
+    sat_any |= (lead && bits >= kMaxPToBits) ? (1u << K) : 0u;                                \
+    unsigned long long tot;                                                                   \
+    if (small_bits) tot = wave_sum_dpp(lb);                                                   \
+    else tot = ((unsigned long long)wave_sum_dpp(lb >> 16) << 16) + wave_sum_dpp(lb & 0xFFFFu); \
+    if (K == 0 || tot < r.best_bits) { /* strict: ties keep the finer order (rice.rs:285) */  \
+      r.best_bits = tot;                                                                      \
+      r.bestk = K;                                                                            \
+      r.my_p = packed & 31u;                                                                  \
+    }                                                                                         \
+  }
+  FLACENC_RICE_LEVEL(0, 1)
+  FLACENC_RICE_LEVEL(1, 1)
+  FLACENC_RICE_LEVEL(2, 2)
+  FLACENC_RICE_LEVEL(3, 4)
+  FLACENC_RICE_LEVEL(4, 8)
+  FLACENC_RICE_LEVEL(5, 16)
+  FLACENC_RICE_LEVEL(6, 32)
+#undef FLACENC_RICE_LEVEL
+  sat_any = wave_or_dpp(sat_any);
+  r.saturated = (sat_any >> r.bestk) & 1u;
+  return r;
+}
+
+template <int MAXP, bool STEREO>
+__global__ void __launch_bounds__(256) qlpc_wave4096_kernel(QlpcKernelArgs a) {
+  constexpr int HP = (MAXP + 3) & ~3;
+  constexpr int NLAG = MAXP + 1;
+  constexpr int NBUF = STEREO ? 2 : 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  int32_t* const sm = reinterpret_cast<int32_t*>(smem_raw);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = uni(tid >> 6);  // wave-uniform by construction; tell the compiler
+  const int P = (int)a.lpc_order;
+  const int n = kWaveN;
+
+  // ---- which subframe does this wave own ----
+  uint32_t blk = blockIdx.x;
+  uint32_t sf;
+  int role = 0;
+  bool active = true;
+  if (STEREO) {
+    role = wave;
+    sf = blk * 4u + (uint32_t)wave;
+  } else {
+    sf = blk * 4u + (uint32_t)wave;
+    active = sf < a.n_subframes;
+  }
+  if (a.stamps && lane == 0 && active) a.stamps[(size_t)sf * 8 + 0] = (unsigned long long)clock64();
+
+  // ======================= phase 0: HBM -> LDS ==============================
+  // Segment layout: sample t of a channel image lives at widx(t); segment 0 is zero.
+  for (int i = tid; i < NBUF * kSeg; i += 256) sm[(i / kSeg) * kBufDwords + (i % kSeg)] = 0;
+  if (STEREO) {
+    const int32_t* __restrict__ src = a.samples + (size_t)(2u * blk) * a.stride;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int q = tid + it * 256;  // 0..2047
+      const int ch = q >> 10;
+      const int t = (q & 1023) << 2;
+      const int4 v = *reinterpret_cast<const int4*>(src + (size_t)ch * a.stride + t);
+      *reinterpret_cast<int4*>(&sm[ch * kBufDwords + widx(t)]) = v;
+    }
+    __syncthreads();
+  } else {
+    if (active) {
+      const int32_t* __restrict__ src = a.samples + (size_t)sf * a.stride;
+#pragma unroll
+      for (int it = 0; it < 16; ++it) {
+        const int t = (lane + it * 64) << 2;
+        const int4 v = *reinterpret_cast<const int4*>(src + t);
+        *reinterpret_cast<int4*>(&sm[wave * kBufDwords + widx(t)]) = v;
+      }
+    }
+    __syncthreads();  // (also orders the zero segment written by other waves)
+  }
+  if (!active) return;
+  if (a.stamps && lane == 0) a.stamps[(size_t)sf * 8 + 1] = (unsigned long long)clock64();
+
+  const int32_t* const bufA = sm + (STEREO ? (role == 1 ? 1 : 0) : wave) * kBufDwords;
+  const int32_t* const bufB = sm + kBufDwords;  // right channel (stereo roles 2, 3)
+  // four samples of this wave's role starting at t (multiple of 4, >= -64)
+  auto ld4 = [&](int t) -> int4 {
+    int4 v = *reinterpret_cast<const int4*>(&bufA[widx(t)]);
+    if (STEREO && role >= 2) {
+      const int4 r = *reinterpret_cast<const int4*>(&bufB[widx(t)]);
+      if (role == 2) {  // mid = (l + r) >> 1, coding.rs:483
+        v.x = (v.x + r.x) >> 1;
+        v.y = (v.y + r.y) >> 1;
+        v.z = (v.z + r.z) >> 1;
+        v.w = (v.w + r.w) >> 1;
+      } else {  // side = l - r
+        v.x -= r.x;
+        v.y -= r.y;
+        v.z -= r.z;
+        v.w -= r.w;
+      }
+    }
+    return v;
+  };
+
+  // ======================= phase 1: window + autocorrelation ==============
+  const float* __restrict__ wtab = a.window ? (a.window + 32) : nullptr;
+  const int tl = lane << 6;  // first sample of this lane
+  double R[NLAG];
+  uint32_t my_maxabs = 0;
+  {
+    double dw[HP + 16];
+    double s01[NLAG], tot[NLAG];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int t0 = tl + 16 * i;
+      // slide the window: the last HP values of the previous chunk are this chunk's halo
+      if (i > 0) {
+#pragma unroll
+        for (int k = 0; k < HP; ++k) dw[k] = dw[k + 16];
+      }
+      const int first = (i == 0) ? 0 : HP;  // dw[first..HP+16) are new
+      const int tfirst = (i == 0) ? t0 - HP : t0;
+      // taper weights come from the table; inside the flat part (and for a rectangular
+      // window) the weight is exactly 1.0f and (f32)s * 1.0f == (f32)s (lpc.rs:751-754)
+      const bool flat = (wtab == nullptr) || (tfirst >= a.flat_lo && t0 + 16 <= a.flat_hi);
+#pragma unroll
+      for (int k = first; k < HP + 16; k += 4) {
+        const int t = t0 - HP + k;
+        const int4 v = ld4(t);
+        if (k >= HP) {
+          int mx = max(max(abs_sat(v.x), abs_sat(v.y)), max(abs_sat(v.z), abs_sat(v.w)));
+          my_maxabs = my_maxabs > (uint32_t)mx ? my_maxabs : (uint32_t)mx;
+        }
+        float4 wv = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+        if (!flat) wv = *reinterpret_cast<const float4*>(wtab + t);
+        dw[k + 0] = (double)((float)v.x * wv.x);  // one f32 rounding, then widen
+        dw[k + 1] = (double)((float)v.y * wv.y);
+        dw[k + 2] = (double)((float)v.z * wv.z);
+        dw[k + 3] = (double)((float)v.w * wv.w);
+      }
+      double acc[NLAG];
+#pragma unroll
+      for (int k = 0; k < NLAG; ++k) acc[k] = 0.0;
+      // only the very first chunk of the block can contain t < P (P <= 12 < 16)
+      if (i == 0) acorr_chunk<MAXP, HP, true>(dw, acc, t0, P);  // (selects only; i is compile-time)
+      else acorr_chunk<MAXP, HP, false>(dw, acc, t0, P);
+      // balanced tree over the chunk index c = 4 lane + i: (c0 + c1) + (c2 + c3) in-lane
+      if (i == 0) {
+#pragma unroll
+        for (int k = 0; k < NLAG; ++k) s01[k] = acc[k];
+      } else if (i == 1) {
+#pragma unroll
+        for (int k = 0; k < NLAG; ++k) s01[k] = s01[k] + acc[k];
+      } else if (i == 2) {
+#pragma unroll
+        for (int k = 0; k < NLAG; ++k) tot[k] = acc[k];
+      } else {
+#pragma unroll
+        for (int k = 0; k < NLAG; ++k) tot[k] = s01[k] + (tot[k] + acc[k]);
+      }
+    }
+    // ... then the 6 lane levels
+#pragma unroll
+    for (int k = 0; k < NLAG; ++k) R[k] = wave_butterfly_sum(tot[k]);
+  }
+  my_maxabs = wave_max_dpp(my_maxabs);
+  if (a.autocorr && lane < 33) {
+    double rv = 0.0;
+#pragma unroll
+    for (int k = 0; k < NLAG; ++k)
+      if (k == lane && k <= P) rv = R[k];
+    a.autocorr[(size_t)sf * 33 + lane] = rv;
+  }
+  if (a.stamps && lane == 0) a.stamps[(size_t)sf * 8 + 2] = (unsigned long long)clock64();
+
+  // ======================= phase 2: Levinson + quantisation (every lane) ====
+  // All lanes hold the same R[], so all compute the same coefficients; the results are
+  // then moved to scalar registers (they are wave-uniform).
+  int32_t cq[MAXP];
+  int warm, shift, status;
+  {
+    double coef[MAXP];
+    int32_t cqv[MAXP];
+    int warm_v, shift_v;
+    const int st = levinson_quantize<MAXP>(R, P, (int)a.precision, coef, cqv, &warm_v, &shift_v);
+    status = uni(st);
+    warm = uni(warm_v);
+    shift = uni(shift_v);
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i) cq[i] = uni(cqv[i]);
+    if (a.lpc_coefs && lane == 0) {
+#pragma unroll
+      for (int i = 0; i < MAXP; ++i) a.lpc_coefs[(size_t)sf * 32 + i] = (i < P && status == 0) ? coef[i] : 0.0;
+      for (int i = MAXP; i < 32; ++i) a.lpc_coefs[(size_t)sf * 32 + i] = 0.0;
+    }
+  }
+  int sumabs = 0;
+#pragma unroll
+  for (int i = 0; i < MAXP; ++i) sumabs += cq[i] < 0 ? -cq[i] : cq[i];
+  // compute_error's path choice, lpc.rs:361-377 (+ |s| < 2^23 for the 24-bit multiplier)
+  const bool wide = !(((uint64_t)my_maxabs * (uint64_t)sumabs < 0x7FFFFFFFull) && (my_maxabs < (1u << 23)));
+  if (a.stamps && lane == 0) a.stamps[(size_t)sf * 8 + 3] = (unsigned long long)clock64();
+
+  // ======================= phase 3: residual -> registers ==================
+  int32_t e[64];
+  {
+    int sw[HP + 16];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int t0 = tl + 16 * i;
+      if (i > 0) {
+#pragma unroll
+        for (int k = 0; k < HP; ++k) sw[k] = sw[k + 16];
+      }
+      const int first = (i == 0) ? 0 : HP;
+#pragma unroll
+      for (int k = first; k < HP + 16; k += 4) {
+        const int4 v = ld4(t0 - HP + k);
+        sw[k + 0] = v.x;
+        sw[k + 1] = v.y;
+        sw[k + 2] = v.z;
+        sw[k + 3] = v.w;
+      }
+      if (!wide) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          int32_t pred = 0;
+#pragma unroll
+          for (int j = 0; j < MAXP; ++j) pred += __mul24(cq[j], sw[HP + k - 1 - j]);
+          e[16 * i + k] = sw[HP + k] - (pred >> shift);
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          int64_t pred = 0;
+#pragma unroll
+          for (int j = 0; j < MAXP; ++j) pred += (int64_t)cq[j] * (int64_t)sw[HP + k - 1 - j];
+          e[16 * i + k] = (int32_t)(uint32_t)(uint64_t)((int64_t)sw[HP + k] - (pred >> shift));
+        }
+      }
+    }
+    // e[0 .. order') = 0 (lpc.rs:349): only lane 0, only its first 16 slots (order' <= 12)
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+      if ((lane == 0 && k < warm) || status != 0) e[k] = 0;
+    if (status != 0) {
+#pragma unroll
+      for (int k = 16; k < 64; ++k) e[k] = 0;
+    }
+  }
+  if (a.stamps && lane == 0) a.stamps[(size_t)sf * 8 + 4] = (unsigned long long)clock64();
+
+  // ======================= residual store: registers -> LDS -> HBM ==========
+  // (before the Rice search so the stores drain underneath it)
+  {
+    auto put_own = [&](int32_t* buf) {
+#pragma unroll
+      for (int k = 0; k < 64; k += 4) {
+        int4 v;
+        v.x = e[k + 0];
+        v.y = e[k + 1];
+        v.z = e[k + 2];
+        v.w = e[k + 3];
+        *reinterpret_cast<int4*>(&buf[widx(tl + k)]) = v;
+      }
+    };
+    if (STEREO) {
+      int32_t* __restrict__ dst0 = a.residual + (size_t)(blk * 4u) * a.residual_stride;
+      __syncthreads();  // every wave is done reading the channel images
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        if ((wave >> 1) == half) put_own(sm + (wave & 1) * kBufDwords);
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          const int q = tid + it * 256;
+          const int ch = q >> 10;
+          const int t = (q & 1023) << 2;
+          const int4 v = *reinterpret_cast<const int4*>(&sm[ch * kBufDwords + widx(t)]);
+          *reinterpret_cast<int4*>(dst0 + (size_t)(2 * half + ch) * a.residual_stride + t) = v;
+        }
+        if (half == 0) __syncthreads();
+      }
+    } else {
+      int32_t* __restrict__ dst = a.residual + (size_t)sf * a.residual_stride;
+      int32_t* own = sm + wave * kBufDwords;
+      put_own(own);
+#pragma unroll
+      for (int it = 0; it < 16; ++it) {
+        const int t = (lane + it * 64) << 2;
+        const int4 v = *reinterpret_cast<const int4*>(&own[widx(t)]);
+        *reinterpret_cast<int4*>(dst + t) = v;
+      }
+    }
+  }
+  if (a.stamps && lane == 0) a.stamps[(size_t)sf * 8 + 5] = (unsigned long long)clock64();
+
+  // ======================= phase 4: partitioned-Rice search ================
+  // n = 4096: finest order 6, 64 partitions of 64 samples = one per lane (rice.rs:157-165).
+  uint32_t* u = reinterpret_cast<uint32_t*>(e);
+  uint32_t maxu = 0;
+#pragma unroll
+  for (int k = 0; k < 64; ++k) {
+    u[k] = zigzag(e[k]);
+    maxu |= u[k];
+  }
+  maxu = wave_or_dpp(maxu);
+  // Parameters beyond the residual's bit length can never win (see the generic kernel).
+  const uint32_t bitlen = maxu ? (uint32_t)(32 - __builtin_clz(maxu)) : 0u;
+  const uint32_t max_p = a.max_rice_parameter < bitlen ? a.max_rice_parameter : bitlen;
+  // with the search not cut short by the configuration, every minimum is <= 4 + len*(bitlen+1)
+  // and level totals fit 32 bits; otherwise sum in two 16-bit halves
+  const bool small_bits = a.max_rice_parameter >= bitlen;
+  const uint32_t len0 = 64u - (lane == 0 ? (uint32_t)warm : 0u);
+
+  RiceResult rr;
+  if (maxu < (1u << 26)) {
+    // bit-sliced population counts of the lane's 64 words -> 7 planes
+    uint32_t pl[7], pb[5];
+    popcount_planes16(u, pb);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) pl[k] = pb[k];
+    popcount_planes16(u + 16, pb);
+    planes_add<5>(pl, pb);
+    {
+      uint32_t pc[6], pd[5];
+      popcount_planes16(u + 32, pd);
+#pragma unroll
+      for (int k = 0; k < 5; ++k) pc[k] = pd[k];
+      popcount_planes16(u + 48, pd);
+      planes_add<5>(pc, pd);
+      planes_add<6>(pl, pc);
+    }
+    if (max_p < 8) rr = rice_search<8, true>(pl, u, len0, max_p, small_bits, lane, warm);
+    else if (max_p < 16) rr = rice_search<16, true>(pl, u, len0, max_p, small_bits, lane, warm);
+    else if (max_p < 24) rr = rice_search<24, true>(pl, u, len0, max_p, small_bits, lane, warm);
+    else rr = rice_search<32, true>(pl, u, len0, max_p, small_bits, lane, warm);
+  } else {
+    uint32_t pl[7] = {0, 0, 0, 0, 0, 0, 0};
+    rr = rice_search<32, false>(pl, u, len0, max_p, small_bits, lane, warm);
+  }
+  const int bestk = rr.bestk;
+  const unsigned long long best_bits = rr.best_bits;
+  const uint32_t my_p = rr.my_p;
+  const int rice_order = 6 - bestk;
+  const int best_parts = 1 << rice_order;
+
+  // Residual::sum_quotients / count_bits (datatype.rs:2325-2331, bitrepr.rs:533-544)
+  const bool leader = (lane & ((1 << bestk) - 1)) == 0;
+  const uint32_t sum_p = wave_sum_dpp(leader ? my_p : 0u);
+  const uint32_t p0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)my_p);
+  const uint32_t rice2 = wave_or_dpp(my_p > 14 ? 1u : 0u);
+  unsigned long long sum_q;
+  const unsigned long long rem_bits = (unsigned long long)sum_p * (unsigned long long)(n >> rice_order) -
+                                      (unsigned long long)warm * p0;
+  if (!rr.saturated) {
+    sum_q = best_bits - 4ull * (unsigned long long)best_parts - (unsigned long long)(n - warm) - rem_bits;
+  } else {
+    // partition of sample k on this lane at the chosen order: the lane's group leader's parameter
+    const uint32_t gp = (uint32_t)__shfl((int)my_p, lane & ~((1 << bestk) - 1), 64);
+    uint32_t lo = 0, hi = 0;
+#pragma unroll
+    for (int k = 0; k < 64; ++k) {
+      uint32_t qv = u[k] >> gp;  // warm-up slots hold 0
+      lo += qv & 0xFFFFu;
+      hi += qv >> 16;
+    }
+    // per lane 64 x 16 bits = 22 bits; x 64 lanes = 28 bits
+    sum_q = ((unsigned long long)wave_sum_dpp(hi) << 16) + (unsigned long long)wave_sum_dpp(lo);
+  }
+
+  flacenc_hip_subframe_params* rec = a.params + sf;
+  {
+    // partition j of the chosen order lives on lane j << bestk
+    const int srcl = (lane << bestk) & 63;
+    const uint32_t pv = (uint32_t)__shfl((int)my_p, srcl, 64);
+    uint32_t w0 = (lane < best_parts && status == 0) ? pv : 0u;
+    rec->rice_params[lane] = (uint8_t)w0;
+    rec->rice_params[lane + 64] = 0;
+    rec->rice_params[lane + 128] = 0;
+    rec->rice_params[lane + 192] = 0;
+  }
+  if (lane < 32) {
+    int32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i)
+      if (i == lane) c = cq[i];
+    rec->coefs[lane] = (status == 0) ? (int16_t)c : (int16_t)0;
+  }
+  if (lane == 0) {
+    const unsigned long long residual_bits = 2ull + 4ull + (unsigned long long)best_parts * (rice2 ? 5ull : 4ull) +
+                                             (sum_q + (unsigned long long)(n - warm)) + rem_bits;
+    const unsigned long long bps = a.bps ? (unsigned long long)a.bps[sf]
+                                         : (unsigned long long)(a.bps_uniform + ((STEREO && role == 3) ? 1u : 0u));
+    const unsigned long long sub_bits = 8ull + bps * (unsigned long long)warm + 4ull + 5ull +
+                                        (unsigned long long)a.precision * (unsigned long long)warm + residual_bits;
+    rec->order = (uint8_t)warm;
+    rec->shift = (int8_t)shift;
+    rec->precision = (uint8_t)a.precision;
+    rec->rice_order = (uint8_t)(status == 0 ? rice_order : 0);
+    rec->status = status;
+    rec->code_bits = status == 0 ? best_bits : 0ull;
+    rec->subframe_bits = status == 0 ? sub_bits : 0ull;
+    rec->sum_quotients = status == 0 ? sum_q : 0ull;
+  }
+  if (a.stamps && lane == 0) {
+    a.stamps[(size_t)sf * 8 + 6] = (unsigned long long)clock64();
+    a.stamps[(size_t)sf * 8 + 7] = (unsigned long long)clock64();
+  }
+}
+
+template <int MAXP, bool STEREO>
+hipError_t launch_wave4096(const QlpcKernelArgs& a, hipStream_t stream) {
+  auto kern = qlpc_wave4096_kernel<MAXP, STEREO>;
+  constexpr size_t smem = (size_t)(STEREO ? 2 : 4) * kBufDwords * 4;
+  static bool configured = false;
+  if (!configured) {
+    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (err != hipSuccess) return err;
+    configured = true;
+  }
+  const uint32_t blocks = STEREO ? a.n_subframes / 4u : (a.n_subframes + 3u) / 4u;
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), smem, stream, a);
+  return hipGetLastError();
+}
+
+}  // namespace
+}  // namespace flacenc_hip
+#endif

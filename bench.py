@@ -46,7 +46,7 @@ def main():
     import torch
     import torch.distributed as dist
 
-    from flacenc_rs_amd import _capi
+    from flacenc_rs_amd import _capi, shard
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -63,13 +63,13 @@ def main():
     cfg = _capi.make_config(lpc_order=args.lpc_order)  # precision 15, Tukey(0.4), max_p 30
     # synthetic "sigen" audio: Sine(200, 0.4) + Noise(0.4) like the reference's
     # stereo_frame_encoder_noisy_sine_lpc bench (src/coding.rs:1152), one continuous stream,
-    # rank r takes frames [r*F, (r+1)*F)
-    host = _capi.sigen_frames(F, 2, n, bps, 200.0, 0.4, 0.4, seed=0xF1AC0001, first_frame=rank * F)
+    # dealt round-robin: stream frame f belongs to rank f mod G (flacenc_rs_amd/shard.py)
+    host = _capi.sigen_frames(F, 2, n, bps, 200.0, 0.4, 0.4, seed=0xF1AC0001, first_frame=rank,
+                              frame_step=world)
     x = torch.from_numpy(host).to(dev)
     params = torch.empty((F * 4, _capi.PARAMS_DTYPE.itemsize), dtype=torch.uint8, device=dev)
     residual = torch.empty((F * 4, n), dtype=torch.int32, device=dev)
-    gathered = torch.empty((world * F * 4, _capi.PARAMS_DTYPE.itemsize), dtype=torch.uint8,
-                           device=dev) if world > 1 else None
+    params_by_frame = params.view(F, 4 * _capi.PARAMS_DTYPE.itemsize)
     handle = _capi.Handle(local_rank)
     stream = torch.cuda.current_stream()
 
@@ -77,7 +77,7 @@ def main():
         handle.stereo_qlpc_batch_device(cfg, x.data_ptr(), F, n, n, bps, params.data_ptr(),
                                         residual.data_ptr(), n, stream=stream.cuda_stream)
         if world > 1:
-            dist.all_gather_into_tensor(gathered, params)
+            shard.all_gather_records(params_by_frame, world * F)
 
     def fence():
         if world > 1:
@@ -97,7 +97,7 @@ def main():
                                         residual.data_ptr(), n, stream=stream.cuda_stream)
         ev[k][1].record(stream)
         if world > 1:
-            dist.all_gather_into_tensor(gathered, params)
+            shard.all_gather_records(params_by_frame, world * F)
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -144,7 +144,7 @@ def main():
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": _measured_traffic(),
-            "kernel": "qlpc_subframe_kernel<8,false>",
+            "kernel": "qlpc_wave4096_kernel<8,true>",
             "kernel_ms": round(kernel_ms, 4),
             "algorithmic_bytes_per_launch": ALGO_BYTES_PER_SAMPLE * samples_per_step,
         },

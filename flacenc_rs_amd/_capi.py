@@ -51,6 +51,7 @@ EXPORTED_SYMBOLS = (
     "flacenc_hip_synchronize",
     "flacenc_hip_debug_set_stamps",
     "flacenc_sigen_fill_frames",
+    "flacenc_sigen_fill_frames_strided",
 )
 
 
@@ -138,6 +139,10 @@ def load() -> C.CDLL:
                                             C.c_uint32, C.c_float, C.c_float, C.c_float,
                                             C.c_uint64, C.c_uint64, C.c_int]
     L.flacenc_sigen_fill_frames.restype = C.c_int
+    L.flacenc_sigen_fill_frames_strided.argtypes = [vp, C.c_size_t, C.c_uint32, C.c_uint32, C.c_size_t,
+                                                    C.c_uint32, C.c_float, C.c_float, C.c_float,
+                                                    C.c_uint64, C.c_uint64, C.c_uint64, C.c_int]
+    L.flacenc_sigen_fill_frames_strided.restype = C.c_int
     _lib = L
     return L
 
@@ -168,14 +173,17 @@ def window_weights(cfg: QlpcConfig, block_size: int) -> np.ndarray:
 
 def sigen_frames(n_frames: int, channels: int, block_size: int, bits_per_sample: int,
                  sine_period: float, sine_amplitude: float, noise_amplitude: float, seed: int,
-                 first_frame: int = 0, nthreads: int | None = None) -> np.ndarray:
-    """flacenc_sigen_fill_frames -> int32 [n_frames, channels, block_size] (FrameBuf layout)."""
+                 first_frame: int = 0, nthreads: int | None = None, frame_step: int = 1) -> np.ndarray:
+    """flacenc_sigen_fill_frames[_strided] -> int32 [n_frames, channels, block_size] (FrameBuf layout).
+
+    Local frame f is stream frame first_frame + f*frame_step."""
     out = np.empty((n_frames, channels, block_size), np.int32)
     if nthreads is None:
-        nthreads = min(32, os.cpu_count() or 1)
-    rc = load().flacenc_sigen_fill_frames(out.ctypes.data, n_frames, channels, block_size,
-                                          block_size, bits_per_sample, sine_period, sine_amplitude,
-                                          noise_amplitude, seed, first_frame, nthreads)
+        nthreads = min(16, os.cpu_count() or 1)
+    rc = load().flacenc_sigen_fill_frames_strided(out.ctypes.data, n_frames, channels, block_size,
+                                                  block_size, bits_per_sample, sine_period,
+                                                  sine_amplitude, noise_amplitude, seed, first_frame,
+                                                  frame_step, nthreads)
     if rc != 0:
         raise FlacencHipError(rc, "flacenc_sigen_fill_frames")
     return out

@@ -25,6 +25,9 @@
 namespace flacenc_hip {
 namespace {
 
+#ifndef FLACENC_WAVE_OCC
+#define FLACENC_WAVE_OCC 1
+#endif
 constexpr int kWaveN = 4096;        // block size handled by this kernel
 constexpr int kSeg = 68;            // dwords per lane segment: 64 samples + 4 pad (conflict-free b128)
 constexpr int kBufDwords = 65 * kSeg;  // one leading all-zero segment (halo of lane 0)
@@ -233,7 +236,7 @@ __device__ __forceinline__ RiceResult rice_search(const uint32_t (&pl)[7], const
 }
 
 template <int MAXP, bool STEREO>
-__global__ void __launch_bounds__(256) qlpc_wave4096_kernel(QlpcKernelArgs a) {
+__global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(QlpcKernelArgs a) {
   constexpr int HP = (MAXP + 3) & ~3;
   constexpr int NLAG = MAXP + 1;
   constexpr int NBUF = STEREO ? 2 : 4;

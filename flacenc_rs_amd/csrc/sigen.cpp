@@ -22,7 +22,7 @@ inline float open01(uint64_t seed, uint64_t t) {
 
 void fill_range(int32_t* dst, size_t f_begin, size_t f_end, uint32_t channels, uint32_t block_size,
                 size_t stride, uint32_t bps, float period, float amp, float namp, uint64_t seed,
-                uint64_t first_frame) {
+                uint64_t first_frame, uint64_t frame_step) {
   const float pi = 3.14159265358979323846f;
   const float scale = static_cast<float>(1u << (bps - 1));
   const float lo = -scale, hi = scale - 1.0f;
@@ -31,7 +31,7 @@ void fill_range(int32_t* dst, size_t f_begin, size_t f_end, uint32_t channels, u
       int32_t* out = dst + (f * channels + c) * stride;
       const float period_c = period + 7.0f * static_cast<float>(c);
       const float phase_c = 0.5f * static_cast<float>(c);
-      const uint64_t t0 = (first_frame + f) * block_size;
+      const uint64_t t0 = (first_frame + f * frame_step) * block_size;
       for (uint32_t i = 0; i < block_size; ++i) {
         const uint64_t ti = t0 + i;
         const float t = static_cast<float>(ti);
@@ -54,6 +54,17 @@ extern "C" int flacenc_sigen_fill_frames(int32_t* dst, size_t n_frames, uint32_t
                                          uint32_t block_size, size_t stride, uint32_t bits_per_sample,
                                          float sine_period, float sine_amplitude, float noise_amplitude,
                                          uint64_t seed, uint64_t first_frame, int nthreads) {
+  return flacenc_sigen_fill_frames_strided(dst, n_frames, channels, block_size, stride, bits_per_sample,
+                                           sine_period, sine_amplitude, noise_amplitude, seed,
+                                           first_frame, 1, nthreads);
+}
+
+extern "C" int flacenc_sigen_fill_frames_strided(int32_t* dst, size_t n_frames, uint32_t channels,
+                                                 uint32_t block_size, size_t stride,
+                                                 uint32_t bits_per_sample, float sine_period,
+                                                 float sine_amplitude, float noise_amplitude,
+                                                 uint64_t seed, uint64_t first_frame,
+                                                 uint64_t frame_step, int nthreads) {
   if (!dst || channels == 0 || block_size == 0 || stride < block_size || bits_per_sample < 5 ||
       bits_per_sample > 25 || !(sine_period > 0.0f))
     return -2;
@@ -63,7 +74,7 @@ extern "C" int flacenc_sigen_fill_frames(int32_t* dst, size_t n_frames, uint32_t
   for (int i = 0; i < nthreads; ++i) {
     const size_t b = n_frames * i / nthreads, e = n_frames * (i + 1) / nthreads;
     th.emplace_back(fill_range, dst, b, e, channels, block_size, stride, bits_per_sample, sine_period,
-                    sine_amplitude, noise_amplitude, seed, first_frame);
+                    sine_amplitude, noise_amplitude, seed, first_frame, frame_step);
   }
   for (auto& t : th) t.join();
   return 0;

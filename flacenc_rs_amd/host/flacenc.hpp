@@ -1,0 +1,602 @@
+// flacenc.hpp -- C++ host-side mirror of the flacenc-rs API surface around the GPU path.
+//
+// The reference is a Rust crate; this image has no Rust toolchain, so the host side above the
+// C ABI (include/flacenc_hip.h) is written in C++ with the reference's names, argument meaning
+// and error behaviour:
+//
+//   flacenc::config::{Encoder, StereoCoding, SubFrameCoding, Qlpc, Prc, Fixed, OrderSel, Window}
+//                                                        src/config.rs:80-432
+//   flacenc::error::{VerifyError, EncodeError}           src/error.rs:178, 458
+//   flacenc::source::{Source, FrameBuf, MemSource}       src/source.rs:445, 115, 543
+//   flacenc::component::{QuantizedParameters, Residual, Lpc, Constant, Verbatim, SubFrame,
+//                        ChannelAssignment, Frame, Stream, StreamInfo}   src/component/datatype.rs
+//   flacenc::encode_with_fixed_block_size                src/coding.rs:645 (pub, lib.rs:162)
+//   Decode (feature "decode")                            src/component/decode.rs
+//
+// The controller logic (`encode_subframe` src/coding.rs:384-418, `try_stereo_coding`
+// :469-527) runs on the host exactly as in the reference; every `estimated_qlpc` call is served
+// by the GPU through flacenc_hip_*_qlpc_batch.  There is no CPU implementation of the path here.
+// Not mirrored (out of scope): bit writer, container metadata, MD5, serde.
+// Fixed-LPC candidate (`fixed_lpc`, src/coding.rs:298) is not on the GPU yet: a config with
+// `use_fixed = true` is rejected with EncodeError::Config (the reference default has it on).
+#ifndef FLACENC_HOST_FLACENC_HPP_
+#define FLACENC_HOST_FLACENC_HPP_
+
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <variant>
+#include <vector>
+
+#include "flacenc_hip.h"
+
+namespace flacenc {
+
+// ---------------------------------------------------------------- constant.rs ----
+namespace constant {
+constexpr size_t DEFAULT_BLOCK_SIZE = 4096;            // src/constant.rs:32
+constexpr size_t MIN_BLOCK_SIZE = 32;                  // :45
+constexpr size_t MAX_BLOCK_SIZE = 32767;               // :57
+constexpr size_t MIN_BLOCK_SIZE_FOR_PREDICTION = 64;   // :51
+constexpr size_t MIN_BITS_PER_SAMPLE = 8;              // :38
+constexpr size_t MAX_BITS_PER_SAMPLE = 24;             // :54
+constexpr size_t MAX_CHANNELS = 8;                     // :60
+namespace qlpc {
+constexpr size_t DEFAULT_ORDER = 10;       // :109
+constexpr size_t DEFAULT_PRECISION = 15;   // :112
+constexpr float DEFAULT_TUKEY_ALPHA = 0.4f;  // :115
+constexpr size_t MAX_ORDER = 24;           // :118
+constexpr size_t MAX_PRECISION = 15;
+}  // namespace qlpc
+namespace rice {
+constexpr size_t MAX_RICE_PARAMETER = 30;  // :143
+}
+}  // namespace constant
+
+// ------------------------------------------------------------------- error.rs ----
+namespace error {
+// VerifyError, src/error.rs:178: component path + reason
+struct VerifyError : std::runtime_error {
+  std::string component;
+  VerifyError(std::string comp, const std::string& reason)
+      : std::runtime_error("verification error: `" + comp + "` is not valid. reason: " + reason),
+        component(std::move(comp)) {}
+  VerifyError within(const std::string& outer) const {  // src/error.rs:216
+    const std::string what_s = what();
+    const size_t pos = what_s.find("reason: ");
+    return VerifyError(outer + "." + component, pos == std::string::npos ? what_s : what_s.substr(pos + 8));
+  }
+};
+// EncodeError, src/error.rs:458: Source | Config
+struct EncodeError : std::runtime_error {
+  enum Kind { Source, Config, Device } kind;
+  EncodeError(Kind k, const std::string& msg) : std::runtime_error(msg), kind(k) {}
+};
+}  // namespace error
+
+// ------------------------------------------------------------------ config.rs ----
+namespace config {
+struct Window {  // src/config.rs:344-359
+  enum Type { Rectangle, Tukey } type = Tukey;
+  float alpha = constant::qlpc::DEFAULT_TUKEY_ALPHA;
+  void verify() const {  // :371-387
+    if (type == Tukey && !(alpha >= 0.0f && alpha <= 1.0f))
+      throw error::VerifyError("tukey.alpha", "alpha must be in range between 0 and 1");
+  }
+};
+struct OrderSel {  // :400-409
+  enum Type { BitCount, ApproxEnt } type = ApproxEnt;
+  size_t partitions = 16;
+};
+struct Prc {  // :211-214
+  size_t max_parameter = constant::rice::MAX_RICE_PARAMETER;
+  void verify() const {
+    if (max_parameter > constant::rice::MAX_RICE_PARAMETER)
+      throw error::VerifyError("max_parameter", "must be in range ..=30");
+  }
+};
+struct Fixed {  // :236-244
+  size_t max_order = 4;
+  OrderSel order_sel;
+};
+struct Qlpc {  // :271-288
+  size_t lpc_order = constant::qlpc::DEFAULT_ORDER;
+  size_t quant_precision = constant::qlpc::DEFAULT_PRECISION;
+  bool use_direct_mse = false;
+  size_t mae_optimization_steps = 0;
+  Window window;
+  void verify() const {  // :302-326
+    if (lpc_order < 1 || lpc_order > constant::qlpc::MAX_ORDER)
+      throw error::VerifyError("lpc_order", "must be in range 1..=24");
+    if (quant_precision < 1 || quant_precision > constant::qlpc::MAX_PRECISION)
+      throw error::VerifyError("quant_precision", "must be in range 1..=15");
+    if (use_direct_mse)
+      throw error::VerifyError("use_direct_mse", "this feature is only available in `experimental` build.");
+    if (mae_optimization_steps != 0)
+      throw error::VerifyError("mae_optimization_steps",
+                               "this feature is only available in `experimental` build.");
+    try {
+      window.verify();
+    } catch (const error::VerifyError& e) {
+      throw e.within("window");
+    }
+  }
+};
+struct SubFrameCoding {  // :167-183
+  bool use_constant = true;
+  bool use_fixed = true;
+  bool use_lpc = true;
+  Fixed fixed;
+  Qlpc qlpc;
+  Prc prc;
+  void verify() const {  // :198-204
+    try {
+      qlpc.verify();
+    } catch (const error::VerifyError& e) {
+      throw e.within("qlpc");
+    }
+    try {
+      prc.verify();
+    } catch (const error::VerifyError& e) {
+      throw e.within("prc");
+    }
+  }
+};
+struct StereoCoding {  // :137-144
+  bool use_leftside = true;
+  bool use_rightside = true;
+  bool use_midside = true;
+};
+struct Encoder {  // :85-99
+  size_t block_size = constant::DEFAULT_BLOCK_SIZE;
+  bool multithread = true;
+  StereoCoding stereo_coding;
+  SubFrameCoding subframe_coding;
+  void verify() const {  // :114-130
+    if (block_size < constant::MIN_BLOCK_SIZE || block_size > constant::MAX_BLOCK_SIZE)
+      throw error::VerifyError("block_size", "must be in range 32..=32767");
+    try {
+      subframe_coding.verify();
+    } catch (const error::VerifyError& e) {
+      throw e.within("subframe_coding");
+    }
+  }
+};
+}  // namespace config
+
+// ------------------------------------------------------------------ source.rs ----
+namespace source {
+// FrameBuf, src/source.rs:115-127: channel-major i32, channel c at [c*size, c*size + filled)
+class FrameBuf {
+ public:
+  FrameBuf(size_t channels, size_t size) : samples_(channels * size, 0), channels_(channels), size_(size) {}
+  size_t size() const { return size_; }
+  size_t channels() const { return channels_; }
+  size_t filled_size() const { return filled_; }
+  const int32_t* channel_slice(size_t ch) const { return samples_.data() + ch * size_; }  // :251-253
+  int32_t* channel_slice_mut(size_t ch) { return samples_.data() + ch * size_; }
+  const int32_t* raw() const { return samples_.data(); }
+  // Fill::fill_interleaved, src/source.rs:42-70
+  void fill_interleaved(const int32_t* interleaved, size_t n_samples_total) {
+    const size_t per_ch = n_samples_total / channels_;
+    for (size_t c = 0; c < channels_; ++c) {
+      int32_t* dst = channel_slice_mut(c);
+      for (size_t t = 0; t < per_ch; ++t) dst[t] = interleaved[t * channels_ + c];
+      for (size_t t = per_ch; t < size_; ++t) dst[t] = 0;
+    }
+    filled_ = per_ch;
+  }
+  // verify_samples, src/source.rs:262-275
+  void verify_samples(size_t bits_per_sample) const {
+    const int32_t lo = -(1 << (bits_per_sample - 1)), hi = (1 << (bits_per_sample - 1)) - 1;
+    for (size_t c = 0; c < channels_; ++c)
+      for (size_t t = 0; t < filled_; ++t) {
+        const int32_t v = channel_slice(c)[t];
+        if (v < lo || v > hi) throw error::VerifyError("samples", "sample out of range for bits_per_sample");
+      }
+  }
+
+ private:
+  std::vector<int32_t> samples_;
+  size_t channels_, size_, filled_ = 0;
+};
+
+// Source, src/source.rs:445-480
+class Source {
+ public:
+  virtual ~Source() = default;
+  virtual size_t channels() const = 0;
+  virtual size_t bits_per_sample() const = 0;
+  virtual size_t sample_rate() const = 0;
+  // reads up to block_size inter-channel samples into dest; returns the count read (0 = end)
+  virtual size_t read_samples(size_t block_size, FrameBuf& dest) = 0;
+};
+
+// MemSource, src/source.rs:543-600
+class MemSource : public Source {
+ public:
+  static MemSource from_samples(const std::vector<int32_t>& interleaved, size_t channels,
+                                size_t bits_per_sample, size_t sample_rate) {
+    MemSource s;
+    s.samples_ = interleaved;
+    s.channels_ = channels;
+    s.bps_ = bits_per_sample;
+    s.rate_ = sample_rate;
+    return s;
+  }
+  size_t channels() const override { return channels_; }
+  size_t bits_per_sample() const override { return bps_; }
+  size_t sample_rate() const override { return rate_; }
+  size_t read_samples(size_t block_size, FrameBuf& dest) override {
+    const size_t begin = pos_ * channels_;
+    const size_t end = std::min(samples_.size(), begin + block_size * channels_);
+    if (end <= begin) return 0;
+    dest.fill_interleaved(samples_.data() + begin, end - begin);
+    const size_t n = (end - begin) / channels_;
+    pos_ += n;
+    return n;
+  }
+  size_t len_hint() const { return samples_.size() / channels_; }
+
+ private:
+  std::vector<int32_t> samples_;
+  size_t channels_ = 1, bps_ = 16, rate_ = 44100, pos_ = 0;
+};
+}  // namespace source
+
+// ------------------------------------------------------------------ component ----
+namespace component {
+// rice::encode_signbit / decode_signbit, src/rice.rs:169-187
+inline uint32_t encode_signbit(int32_t v) { return (static_cast<uint32_t>(v) << 1) ^ static_cast<uint32_t>(v >> 31); }
+inline int32_t decode_signbit(uint32_t v) { return static_cast<int32_t>(v >> 1) ^ -static_cast<int32_t>(v & 1u); }
+
+// QuantizedParameters, src/component/datatype.rs:2164-2170
+struct QuantizedParameters {
+  int16_t coefs[32] = {0};
+  size_t order = 0;
+  int8_t shift = 0;
+  size_t precision = 0;
+};
+
+// Residual, src/component/datatype.rs:2269-2284 (quotients/remainders derived on demand,
+// src/coding.rs:58-62, 140-170)
+struct Residual {
+  uint8_t partition_order = 0;
+  size_t block_size = 0;
+  size_t warmup_length = 0;
+  std::vector<uint8_t> rice_params;
+  std::vector<int32_t> errors;  // first warmup_length slots are zero
+  uint64_t sum_quotients = 0;
+  uint64_t sum_rice_params = 0;
+  std::pair<uint32_t, uint32_t> quotient_and_remainder(size_t t) const {
+    if (t < warmup_length) return {0u, 0u};
+    const uint8_t p = rice_params[t / (block_size >> partition_order)];
+    const uint32_t u = encode_signbit(errors[t]);
+    return {u >> p, u & ((1u << p) - 1u)};
+  }
+  // BitRepr::count_bits, src/component/bitrepr.rs:533-544
+  size_t count_bits() const {
+    const size_t nparts = size_t(1) << partition_order;
+    bool rice2 = false;
+    for (size_t i = 0; i < nparts; ++i) rice2 |= rice_params[i] > 14;
+    return 2 + 4 + nparts * (rice2 ? 5 : 4) + (sum_quotients + block_size - warmup_length) +
+           (sum_rice_params * (block_size >> partition_order) - warmup_length * rice_params[0]);
+  }
+  // Decode::copy_signal, src/component/decode.rs:226-237
+  void copy_signal(int32_t* dest) const {
+    for (size_t t = 0; t < block_size; ++t) {
+      auto qr = quotient_and_remainder(t);
+      const uint8_t p = rice_params[t / (block_size >> partition_order)];
+      dest[t] = decode_signbit((qr.first << p) + qr.second);
+    }
+  }
+};
+
+struct Constant {  // datatype.rs:1820
+  size_t block_size;
+  int32_t dc_offset;
+  uint8_t bits_per_sample;
+  size_t count_bits() const { return 8 + bits_per_sample; }  // bitrepr.rs:445
+};
+struct Verbatim {  // datatype.rs:1896
+  std::vector<int32_t> samples;
+  uint8_t bits_per_sample;
+  static size_t count_bits_from_metadata(size_t n, size_t bps) { return 8 + n * bps; }  // datatype.rs:1944
+  size_t count_bits() const { return count_bits_from_metadata(samples.size(), bits_per_sample); }
+};
+struct Lpc {  // datatype.rs:2057-2062
+  QuantizedParameters parameters;
+  std::vector<int32_t> warm_up;
+  Residual residual;
+  uint8_t bits_per_sample;
+  size_t order() const { return parameters.order; }
+  size_t count_bits() const {  // bitrepr.rs:492-499
+    return 8 + size_t(bits_per_sample) * order() + 4 + 5 + parameters.precision * order() + residual.count_bits();
+  }
+};
+using SubFrame = std::variant<Constant, Verbatim, Lpc>;  // datatype.rs:1782 (FixedLpc: see header note)
+inline size_t count_bits(const SubFrame& sf) {
+  return std::visit([](const auto& c) { return c.count_bits(); }, sf);
+}
+
+// Decode for SubFrame, src/component/decode.rs:116-218
+inline std::vector<int32_t> decode(const SubFrame& sf) {
+  if (const auto* c = std::get_if<Constant>(&sf)) return std::vector<int32_t>(c->block_size, c->dc_offset);
+  if (const auto* v = std::get_if<Verbatim>(&sf)) return v->samples;
+  const Lpc& l = std::get<Lpc>(sf);
+  std::vector<int32_t> dest(l.residual.block_size);
+  l.residual.copy_signal(dest.data());
+  for (size_t t = 0; t < l.warm_up.size(); ++t) dest[t] = l.warm_up[t];
+  for (size_t t = l.warm_up.size(); t < dest.size(); ++t) {  // decode_lpc, decode.rs:159-177
+    int64_t pred = 0;
+    for (size_t tau = 0; tau < l.order(); ++tau) pred += int64_t(l.parameters.coefs[tau]) * int64_t(dest[t - 1 - tau]);
+    dest[t] = int32_t(uint32_t(dest[t]) + uint32_t(int32_t(pred >> l.parameters.shift)));
+  }
+  return dest;
+}
+
+enum class ChannelAssignment { Independent, LeftSide, RightSide, MidSide };  // datatype.rs:1083
+
+struct Frame {  // datatype.rs:820
+  uint32_t frame_number = 0;
+  size_t block_size = 0;
+  ChannelAssignment channel_assignment = ChannelAssignment::Independent;
+  std::vector<SubFrame> subframes;
+  size_t count_subframe_bits() const {
+    size_t b = 0;
+    for (const auto& s : subframes) b += count_bits(s);
+    return b;
+  }
+  // Decode for Frame, src/component/decode.rs:61-113: returns channel-major samples
+  std::vector<std::vector<int32_t>> decode_channels() const {
+    std::vector<std::vector<int32_t>> ch;
+    for (const auto& s : subframes) ch.push_back(decode(s));
+    if (channel_assignment == ChannelAssignment::LeftSide) {
+      for (size_t t = 0; t < block_size; ++t) ch[1][t] = ch[0][t] - ch[1][t];
+    } else if (channel_assignment == ChannelAssignment::RightSide) {
+      for (size_t t = 0; t < block_size; ++t) ch[0][t] += ch[1][t];
+    } else if (channel_assignment == ChannelAssignment::MidSide) {
+      for (size_t t = 0; t < block_size; ++t) {
+        const int32_t s = ch[1][t];
+        const int32_t m = int32_t(uint32_t(ch[0][t]) << 1) + (s & 1);
+        ch[0][t] = (m + s) >> 1;
+        ch[1][t] = (m - s) >> 1;
+      }
+    }
+    return ch;
+  }
+};
+
+struct StreamInfo {  // datatype.rs:435
+  size_t sample_rate = 0, channels = 0, bits_per_sample = 0;
+  size_t min_block_size = 0, max_block_size = 0;
+  uint64_t total_samples = 0;
+};
+struct Stream {  // datatype.rs:65
+  StreamInfo stream_info;
+  std::vector<Frame> frames;
+  void add_frame(Frame f) { frames.push_back(std::move(f)); }
+};
+}  // namespace component
+
+// ----------------------------------------------------------------- the GPU side ----
+// RAII owner of a flacenc_hip_handle (the role of the reference's per-thread scratch)
+class HipContext {
+ public:
+  explicit HipContext(int device_id = 0) {
+    const int rc = flacenc_hip_create(&h_, device_id);
+    if (rc != FLACENC_HIP_OK)
+      throw error::EncodeError(error::EncodeError::Device, "flacenc_hip_create failed (no usable GPU)");
+  }
+  ~HipContext() { flacenc_hip_destroy(h_); }
+  HipContext(const HipContext&) = delete;
+  HipContext& operator=(const HipContext&) = delete;
+  flacenc_hip_handle* get() const { return h_; }
+
+ private:
+  flacenc_hip_handle* h_ = nullptr;
+};
+
+namespace detail {
+inline flacenc_hip_qlpc_config to_abi(const config::SubFrameCoding& c) {
+  flacenc_hip_qlpc_config o{};
+  o.lpc_order = static_cast<uint32_t>(c.qlpc.lpc_order);
+  o.quant_precision = static_cast<uint32_t>(c.qlpc.quant_precision);
+  o.window_type = c.qlpc.window.type == config::Window::Rectangle ? FLACENC_HIP_WINDOW_RECTANGLE
+                                                                  : FLACENC_HIP_WINDOW_TUKEY;
+  o.tukey_alpha = c.qlpc.window.alpha;
+  o.max_rice_parameter = static_cast<uint32_t>(c.prc.max_parameter);
+  o.flags = 0;
+  return o;
+}
+
+inline bool is_constant(const int32_t* s, size_t n) {  // arrayutils::is_constant, arrayutils.rs:382
+  for (size_t t = 1; t < n; ++t)
+    if (s[t] != s[0]) return false;
+  return true;
+}
+
+// SubFrame::Lpc from one GPU record + residual row (Lpc::from_parts, coding.rs:373-380)
+inline component::Lpc make_lpc(const flacenc_hip_subframe_params& p, const int32_t* residual,
+                               const int32_t* signal, size_t n, uint8_t bps) {
+  component::Lpc l;
+  std::memcpy(l.parameters.coefs, p.coefs, sizeof(p.coefs));
+  l.parameters.order = p.order;
+  l.parameters.shift = p.shift;
+  l.parameters.precision = p.precision;
+  l.warm_up.assign(signal, signal + p.order);
+  l.residual.partition_order = p.rice_order;
+  l.residual.block_size = n;
+  l.residual.warmup_length = p.order;
+  l.residual.rice_params.assign(p.rice_params, p.rice_params + (size_t(1) << p.rice_order));
+  l.residual.errors.assign(residual, residual + n);
+  l.residual.sum_quotients = p.sum_quotients;
+  l.residual.sum_rice_params = 0;
+  for (uint8_t v : l.residual.rice_params) l.residual.sum_rice_params += v;
+  l.bits_per_sample = bps;
+  return l;
+}
+
+// encode_subframe, src/coding.rs:384-418, with the LPC candidate supplied by the GPU
+inline component::SubFrame encode_subframe(const config::SubFrameCoding& cfg, const int32_t* samples, size_t n,
+                                           uint8_t bps, const flacenc_hip_subframe_params* lpc_rec,
+                                           const int32_t* lpc_residual) {
+  if (cfg.use_constant && is_constant(samples, n)) return component::Constant{n, samples[0], bps};
+  const size_t verbatim_bits = component::Verbatim::count_bits_from_metadata(n, bps);
+  const bool too_short = n < constant::MIN_BLOCK_SIZE_FOR_PREDICTION;
+  const size_t baseline_bits = verbatim_bits;  // no fixed-LPC candidate (see header note)
+  if (!too_short && cfg.use_lpc && lpc_rec != nullptr) {
+    if (lpc_rec->status != FLACENC_HIP_SUBFRAME_OK)
+      throw std::runtime_error("LPC analysis reported a non-finite result (the reference panics here, lpc.rs:786)");
+    component::Lpc cand = make_lpc(*lpc_rec, lpc_residual, samples, n, bps);
+    if (cand.count_bits() < baseline_bits) return cand;
+  }
+  return component::Verbatim{std::vector<int32_t>(samples, samples + n), bps};
+}
+}  // namespace detail
+
+// encode_with_fixed_block_size, src/coding.rs:645-700: reads the whole source, analyses all
+// full-size frames in ONE GPU batch (the tail frame, if shorter, in a second one), then runs the
+// reference's per-frame controller on the host.
+template <class SourceT>
+component::Stream encode_with_fixed_block_size(const config::Encoder& config, SourceT src, size_t block_size,
+                                               HipContext& gpu) {
+  try {
+    config.verify();
+  } catch (const error::VerifyError& e) {
+    throw error::EncodeError(error::EncodeError::Config, e.what());
+  }
+  const config::SubFrameCoding& sc = config.subframe_coding;
+  if (sc.use_fixed)
+    throw error::EncodeError(error::EncodeError::Config,
+                             "subframe_coding.use_fixed: the fixed-LPC candidate is not available on the GPU "
+                             "path yet; set use_fixed = false");
+  const size_t nch = src.channels();
+  const size_t bps = src.bits_per_sample();
+  if (nch < 1 || nch > constant::MAX_CHANNELS || bps < constant::MIN_BITS_PER_SAMPLE ||
+      bps > constant::MAX_BITS_PER_SAMPLE)
+    throw error::EncodeError(error::EncodeError::Config, "stream_info: channels / bits_per_sample out of range");
+
+  component::Stream stream;
+  stream.stream_info.sample_rate = src.sample_rate();
+  stream.stream_info.channels = nch;
+  stream.stream_info.bits_per_sample = bps;
+
+  // 1. drain the source into FrameBufs (src/coding.rs:662-674)
+  std::vector<source::FrameBuf> bufs;
+  for (;;) {
+    source::FrameBuf fb(nch, block_size);
+    const size_t got = src.read_samples(block_size, fb);
+    if (got == 0) break;
+    fb.verify_samples(bps);
+    stream.stream_info.total_samples += got;
+    bufs.push_back(std::move(fb));
+  }
+  const flacenc_hip_qlpc_config abi_cfg = detail::to_abi(sc);
+  const bool stereo = (nch == 2);
+  const size_t per_frame = stereo ? 4 : nch;  // analyses per frame (coding.rs:530-544)
+
+  // 2. group frames by filled size (all but the last are block_size) and batch each group
+  size_t f0 = 0;
+  while (f0 < bufs.size()) {
+    const size_t n = bufs[f0].filled_size();
+    size_t f1 = f0;
+    while (f1 < bufs.size() && bufs[f1].filled_size() == n) ++f1;
+    const size_t nf = f1 - f0;
+    std::vector<flacenc_hip_subframe_params> recs(nf * per_frame);
+    std::vector<int32_t> resid(nf * per_frame * n);
+    const bool use_gpu = sc.use_lpc && n >= constant::MIN_BLOCK_SIZE_FOR_PREDICTION;
+    if (use_gpu) {
+      std::vector<int32_t> staged(nf * nch * n);
+      for (size_t f = 0; f < nf; ++f)
+        for (size_t c = 0; c < nch; ++c)
+          std::memcpy(&staged[(f * nch + c) * n], bufs[f0 + f].channel_slice(c), n * sizeof(int32_t));
+      int rc;
+      if (stereo) {
+        rc = flacenc_hip_stereo_qlpc_batch(gpu.get(), &abi_cfg, staged.data(), nf, static_cast<uint32_t>(n), n,
+                                           static_cast<uint32_t>(bps), recs.data(), resid.data(), n,
+                                           FLACENC_HIP_MEM_HOST);
+      } else {
+        std::vector<uint8_t> bpsv(nf * nch, static_cast<uint8_t>(bps));
+        rc = flacenc_hip_qlpc_batch(gpu.get(), &abi_cfg, staged.data(), nf * nch, static_cast<uint32_t>(n), n,
+                                    bpsv.data(), recs.data(), resid.data(), n, nullptr, nullptr,
+                                    FLACENC_HIP_MEM_HOST);
+      }
+      if (rc == FLACENC_HIP_ERR_BAD_CONFIG)
+        throw error::EncodeError(error::EncodeError::Config, flacenc_hip_last_error(gpu.get()));
+      if (rc != FLACENC_HIP_OK) throw error::EncodeError(error::EncodeError::Device, flacenc_hip_last_error(gpu.get()));
+    }
+    // 3. the reference's controller per frame (encode_frame, coding.rs:530-544)
+    for (size_t f = 0; f < nf; ++f) {
+      const source::FrameBuf& fb = bufs[f0 + f];
+      component::Frame frame;
+      frame.frame_number = static_cast<uint32_t>(f0 + f);
+      frame.block_size = n;
+      auto rec = [&](size_t k) { return use_gpu ? &recs[f * per_frame + k] : nullptr; };
+      auto res = [&](size_t k) { return use_gpu ? &resid[(f * per_frame + k) * n] : nullptr; };
+      if (!stereo) {
+        for (size_t c = 0; c < nch; ++c)
+          frame.subframes.push_back(detail::encode_subframe(sc, fb.channel_slice(c), n, static_cast<uint8_t>(bps),
+                                                            rec(c), res(c)));
+      } else {
+        // try_stereo_coding, coding.rs:469-527
+        const int32_t* l = fb.channel_slice(0);
+        const int32_t* r = fb.channel_slice(1);
+        std::vector<int32_t> m(n), s(n);
+        for (size_t t = 0; t < n; ++t) {
+          m[t] = (l[t] + r[t]) >> 1;
+          s[t] = l[t] - r[t];
+        }
+        component::SubFrame sl = detail::encode_subframe(sc, l, n, static_cast<uint8_t>(bps), rec(0), res(0));
+        component::SubFrame sr = detail::encode_subframe(sc, r, n, static_cast<uint8_t>(bps), rec(1), res(1));
+        component::SubFrame sm = detail::encode_subframe(sc, m.data(), n, static_cast<uint8_t>(bps), rec(2), res(2));
+        component::SubFrame ss = detail::encode_subframe(sc, s.data(), n, static_cast<uint8_t>(bps + 1), rec(3), res(3));
+        const size_t bl = component::count_bits(sl), br = component::count_bits(sr);
+        const size_t bm = component::count_bits(sm), bs = component::count_bits(ss);
+        size_t min_bits = bl + br;
+        component::ChannelAssignment best = component::ChannelAssignment::Independent;
+        if (config.stereo_coding.use_leftside && bl + bs < min_bits) {
+          min_bits = bl + bs;
+          best = component::ChannelAssignment::LeftSide;
+        }
+        if (config.stereo_coding.use_rightside && br + bs < min_bits) {
+          min_bits = br + bs;
+          best = component::ChannelAssignment::RightSide;
+        }
+        if (config.stereo_coding.use_midside && bm + bs < min_bits) {
+          min_bits = bm + bs;
+          best = component::ChannelAssignment::MidSide;
+        }
+        frame.channel_assignment = best;
+        // ChannelAssignment::select_channels, datatype.rs:1145-1171
+        switch (best) {
+          case component::ChannelAssignment::Independent:
+            frame.subframes = {std::move(sl), std::move(sr)};
+            break;
+          case component::ChannelAssignment::LeftSide:
+            frame.subframes = {std::move(sl), std::move(ss)};
+            break;
+          case component::ChannelAssignment::RightSide:
+            frame.subframes = {std::move(ss), std::move(sr)};
+            break;
+          case component::ChannelAssignment::MidSide:
+            frame.subframes = {std::move(sm), std::move(ss)};
+            break;
+        }
+      }
+      stream.add_frame(std::move(frame));
+    }
+    f0 = f1;
+  }
+  // fixed-block mode exposes one block size in STREAMINFO (coding.rs:676-690)
+  stream.stream_info.min_block_size = block_size;
+  stream.stream_info.max_block_size = block_size;
+  return stream;
+}
+
+}  // namespace flacenc
+#endif  // FLACENC_HOST_FLACENC_HPP_

@@ -31,6 +31,14 @@ int flacenc_sigen_fill_frames(int32_t* dst, size_t n_frames, uint32_t channels, 
                               float sine_amplitude, float noise_amplitude, uint64_t seed,
                               uint64_t first_frame, int nthreads);
 
+/* Same, but local frame f is stream frame first_frame + f*frame_step: the frames a rank owns
+ * when a stream is dealt round-robin over `frame_step` GPUs (frame f -> GPU f mod G). */
+int flacenc_sigen_fill_frames_strided(int32_t* dst, size_t n_frames, uint32_t channels,
+                                      uint32_t block_size, size_t stride, uint32_t bits_per_sample,
+                                      float sine_period, float sine_amplitude, float noise_amplitude,
+                                      uint64_t seed, uint64_t first_frame, uint64_t frame_step,
+                                      int nthreads);
+
 #ifdef __cplusplus
 }
 #endif

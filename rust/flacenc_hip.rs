@@ -1,0 +1,174 @@
+//! flacenc_hip.rs -- Rust side of the drop-in boundary (SOURCE ONLY: there is no rustc in the
+//! build image, so this file has never been compiled; the executable host mirror is the C++
+//! header `flacenc_rs_amd/host/flacenc.hpp`, which follows the same structure).
+//!
+//! A maintainer adds this module to the crate (`mod gpu;` behind a `hip` cargo feature), links
+//! `libflacenc_hip.so` (`build.rs`: `println!("cargo:rustc-link-lib=dylib=flacenc_hip")`), and
+//! branches to it where `encode_with_fixed_block_size` already branches on `config.multithread`
+//! (`src/coding.rs:650-655`).  Nothing else in the crate changes: the controller
+//! (`encode_subframe` `src/coding.rs:384`, `try_stereo_coding` `:469`) keeps running on the
+//! host and receives its `estimated_qlpc` candidates from the GPU.
+
+use std::os::raw::{c_char, c_int, c_void};
+
+use crate::component::{Lpc, QuantizedParameters, Residual, SubFrame};
+use crate::config;
+use crate::error::{EncodeError, Verified, VerifyError};
+
+pub const OK: c_int = 0;
+pub const ERR_BAD_CONFIG: c_int = -1;
+pub const MEM_HOST: c_int = 0;
+
+/// `flacenc_hip_qlpc_config` (include/flacenc_hip.h): the path's fields of `config::Qlpc` /
+/// `config::Prc` (`src/config.rs:271-288`, `211-214`).
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct QlpcConfig {
+    pub lpc_order: u32,
+    pub quant_precision: u32,
+    pub window_type: u32, // 0 = Rectangle, 1 = Tukey
+    pub tukey_alpha: f32,
+    pub max_rice_parameter: u32,
+    pub flags: u32,
+}
+
+/// `flacenc_hip_subframe_params`: 352 bytes, one per analysed subframe.
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct SubframeParams {
+    pub coefs: [i16; 32],
+    pub order: u8,
+    pub shift: i8,
+    pub precision: u8,
+    pub rice_order: u8,
+    pub status: i32,
+    pub code_bits: u64,
+    pub subframe_bits: u64,
+    pub sum_quotients: u64,
+    pub rice_params: [u8; 256],
+}
+
+#[repr(C)]
+pub struct Handle {
+    _private: [u8; 0],
+}
+
+extern "C" {
+    pub fn flacenc_hip_create(out: *mut *mut Handle, device_id: c_int) -> c_int;
+    pub fn flacenc_hip_destroy(h: *mut Handle);
+    pub fn flacenc_hip_last_error(h: *const Handle) -> *const c_char;
+    pub fn flacenc_hip_verify_config(cfg: *const QlpcConfig) -> c_int;
+    pub fn flacenc_hip_qlpc_batch(
+        h: *mut Handle, cfg: *const QlpcConfig, samples: *const i32, n_subframes: usize,
+        block_size: u32, stride: usize, bps: *const u8, params: *mut SubframeParams,
+        residual: *mut i32, residual_stride: usize, autocorr: *mut f64, lpc_coefs: *mut f64,
+        memory_kind: c_int,
+    ) -> c_int;
+    pub fn flacenc_hip_stereo_qlpc_batch(
+        h: *mut Handle, cfg: *const QlpcConfig, frames: *const i32, n_frames: usize,
+        block_size: u32, stride: usize, bits_per_sample: u32, params: *mut SubframeParams,
+        residual: *mut i32, residual_stride: usize, memory_kind: c_int,
+    ) -> c_int;
+    pub fn flacenc_hip_qlpc_batch_async(
+        h: *mut Handle, cfg: *const QlpcConfig, samples: *const i32, n_subframes: usize,
+        block_size: u32, stride: usize, bps: *const u8, params: *mut SubframeParams,
+        residual: *mut i32, residual_stride: usize, autocorr: *mut f64, lpc_coefs: *mut f64,
+        stream: *mut c_void,
+    ) -> c_int;
+}
+
+/// One handle per host thread, like the crate's `reusable!` thread-locals (`src/lib.rs:92-116`).
+pub struct Gpu(*mut Handle);
+
+impl Gpu {
+    pub fn new(device_id: i32) -> Result<Self, EncodeError> {
+        let mut h = std::ptr::null_mut();
+        match unsafe { flacenc_hip_create(&mut h, device_id) } {
+            OK => Ok(Self(h)),
+            _ => Err(EncodeError::Config(VerifyError::new("gpu", "no usable HIP device"))),
+        }
+    }
+}
+
+impl Drop for Gpu {
+    fn drop(&mut self) {
+        unsafe { flacenc_hip_destroy(self.0) }
+    }
+}
+
+fn abi_config(c: &config::SubFrameCoding) -> QlpcConfig {
+    let (window_type, tukey_alpha) = match c.qlpc.window {
+        config::Window::Rectangle => (0, 0.0),
+        config::Window::Tukey { alpha } => (1, alpha),
+    };
+    QlpcConfig {
+        lpc_order: c.qlpc.lpc_order as u32,
+        quant_precision: c.qlpc.quant_precision as u32,
+        window_type,
+        tukey_alpha,
+        max_rice_parameter: c.prc.max_parameter as u32,
+        flags: 0,
+    }
+}
+
+/// Rebuilds the `SubFrame::Lpc` that `estimated_qlpc` (`src/coding.rs:360-381`) would have
+/// returned from one GPU record + residual row, through the crate's own constructors
+/// (`QuantizedParameters::from_parts` `datatype.rs:2214`, `Residual::from_parts` `:2315`,
+/// `Lpc::from_parts` `:2115`).
+pub fn lpc_from_record(p: &SubframeParams, residual: &[i32], signal: &[i32], bps: u8) -> SubFrame {
+    assert_eq!(p.status, 0, "the reference panics on non-finite LPC statistics (lpc.rs:786)");
+    let order = p.order as usize;
+    let qlpc = QuantizedParameters::from_parts(&p.coefs[..order], order, p.shift, p.precision as usize);
+    let nparts = 1usize << p.rice_order;
+    let part_size = signal.len() >> p.rice_order;
+    let mut quotients = vec![0u32; signal.len()];
+    let mut remainders = vec![0u32; signal.len()];
+    for t in order..signal.len() {
+        let rice_p = p.rice_params[t / part_size];
+        // quotients_and_remainders, src/coding.rs:58-62
+        let err = crate::rice::encode_signbit(residual[t]);
+        quotients[t] = err >> rice_p;
+        remainders[t] = err & ((1u32 << rice_p) - 1);
+    }
+    let residual = Residual::from_parts(
+        p.rice_order, signal.len(), order, p.rice_params[..nparts].to_vec(), quotients, remainders,
+    );
+    Lpc::from_parts(
+        heapless::Vec::from_slice(&signal[..order]).expect("LPC order exceeded the maximum"),
+        qlpc, residual, bps,
+    )
+    .into()
+}
+
+/// Batched replacement of the `estimated_qlpc` calls of a run of frames.  `framebufs` are the
+/// crate's `FrameBuf`s (channel-major, `src/source.rs:115-127`); returns, per frame, the LPC
+/// candidates in the order `encode_frame` asks for them (L, R, M, S for stereo).
+pub fn estimated_qlpc_batch(
+    gpu: &Gpu, config: &Verified<config::Encoder>, staged: &[i32], n_frames: usize,
+    channels: usize, block_size: usize, bits_per_sample: u8,
+) -> Result<(Vec<SubframeParams>, Vec<i32>), EncodeError> {
+    let cfg = abi_config(&config.subframe_coding);
+    let per_frame = if channels == 2 { 4 } else { channels };
+    let mut params = vec![unsafe { std::mem::zeroed::<SubframeParams>() }; n_frames * per_frame];
+    let mut residual = vec![0i32; n_frames * per_frame * block_size];
+    let rc = unsafe {
+        if channels == 2 {
+            flacenc_hip_stereo_qlpc_batch(
+                gpu.0, &cfg, staged.as_ptr(), n_frames, block_size as u32, block_size,
+                bits_per_sample as u32, params.as_mut_ptr(), residual.as_mut_ptr(), block_size, MEM_HOST,
+            )
+        } else {
+            let bps = vec![bits_per_sample; n_frames * channels];
+            flacenc_hip_qlpc_batch(
+                gpu.0, &cfg, staged.as_ptr(), n_frames * channels, block_size as u32, block_size,
+                bps.as_ptr(), params.as_mut_ptr(), residual.as_mut_ptr(), block_size,
+                std::ptr::null_mut(), std::ptr::null_mut(), MEM_HOST,
+            )
+        }
+    };
+    match rc {
+        OK => Ok((params, residual)),
+        ERR_BAD_CONFIG => Err(EncodeError::Config(VerifyError::new("subframe_coding", "rejected by the GPU path"))),
+        _ => panic!("flacenc_hip device error"), // the reference panics on internal errors too
+    }
+}

@@ -1,0 +1,77 @@
+"""world_size-2 gloo test of the multi-GPU path on CPU: round-robin frame sharding + ordered
+all-gather of the parameter records must reproduce the single-process result in frame order
+(the role of ParSink, src/par.rs:67-95, tested there by `par_sink_finalization`, par.rs:457-556).
+No GPU here: each rank fills its records with the CPU oracle (allowed in tests/)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_frames, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from flacenc_rs_amd import _capi, shard
+    from oracle import oracle as orc
+
+    n, bps, order = 256, 16, 8
+    mine = shard.frames_of_rank(n_frames, rank, world)
+    frames = _capi.sigen_frames(len(mine), 2, n, bps, 50.0, 0.4, 0.1, seed=3, first_frame=rank,
+                                frame_step=world, nthreads=1)
+    recs = np.zeros((len(mine), 2), _capi.PARAMS_DTYPE)
+    cfg = orc.make_config(lpc_order=order)
+    for j in range(len(mine)):
+        r, _, _, _ = orc.qlpc_batch(frames[j], bps, cfg, want_fp=False)
+        recs[j] = r
+    local = torch.from_numpy(recs.view(np.uint8).reshape(len(mine), 2, 352).copy())
+    ordered = shard.all_gather_records(local, n_frames)
+    assert ordered.shape == (n_frames, 2, 352)
+    np.save(os.path.join(out_dir, f"rank{rank}.npy"), ordered.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_frames", [8, 7])
+def test_round_robin_shard_and_ordered_gather(tmp_path, n_frames):
+    world = 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, n_frames, str(tmp_path)), nprocs=world, join=True)
+    sys.path.insert(0, ROOT)
+    from flacenc_rs_amd import _capi
+    from oracle import oracle as orc
+
+    # single-process reference: the whole stream in frame order
+    frames = _capi.sigen_frames(n_frames, 2, 256, 16, 50.0, 0.4, 0.1, seed=3, nthreads=1)
+    want = np.zeros((n_frames, 2), _capi.PARAMS_DTYPE)
+    for f in range(n_frames):
+        want[f], _, _, _ = orc.qlpc_batch(frames[f], 16, orc.make_config(lpc_order=8), want_fp=False)
+    want_bytes = want.view(np.uint8).reshape(n_frames, 2, 352)
+    for rank in range(world):
+        got = np.load(os.path.join(str(tmp_path), f"rank{rank}.npy"))
+        assert np.array_equal(got, want_bytes), rank
+
+
+def test_frames_of_rank_partition():
+    from flacenc_rs_amd import shard
+    for total in (0, 1, 7, 8, 9, 64):
+        for world in (1, 2, 4, 8):
+            seen = sorted(f for r in range(world) for f in shard.frames_of_rank(total, r, world))
+            assert seen == list(range(total))
+            assert all(f % world == r for r in range(world) for f in shard.frames_of_rank(total, r, world))

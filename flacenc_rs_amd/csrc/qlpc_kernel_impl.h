@@ -238,8 +238,14 @@ __device__ __forceinline__ void acorr_chunk(const double (&dw)[HP + 16], double 
   for (int k = 0; k < 16; ++k) {
     double cur = dw[HP + k];
     if (MASK) cur = (t0 + k >= P) ? cur : 0.0;  // common lower bound t = P for every lag (lpc.rs:542)
+    if (k == 0) {
+      // chain start: fma(x, y, +0.0) -- written with the literal so no zero-filled accumulators
 #pragma unroll
-    for (int tau = 0; tau <= MAXP; ++tau) acc[tau] = __builtin_fma(cur, dw[HP + k - tau], acc[tau]);
+      for (int tau = 0; tau <= MAXP; ++tau) acc[tau] = __builtin_fma(cur, dw[HP + k - tau], 0.0);
+    } else {
+#pragma unroll
+      for (int tau = 0; tau <= MAXP; ++tau) acc[tau] = __builtin_fma(cur, dw[HP + k - tau], acc[tau]);
+    }
   }
 }
 

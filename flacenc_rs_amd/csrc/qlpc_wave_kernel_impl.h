@@ -86,6 +86,23 @@ __device__ __forceinline__ uint32_t wave_max_dpp(uint32_t v) {
 
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+__device__ __forceinline__ uint32_t umin3(uint32_t a, uint32_t b, uint32_t c) {
+  uint32_t r;
+  asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
+__device__ __forceinline__ uint32_t wave_min_dpp(uint32_t v) {
+  uint32_t o;
+  o = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFF, (int)v, 0x111, 0xF, 0xF, false); v = o < v ? o : v;
+  o = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFF, (int)v, 0x112, 0xF, 0xF, false); v = o < v ? o : v;
+  o = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFF, (int)v, 0x114, 0xF, 0xF, false); v = o < v ? o : v;
+  o = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFF, (int)v, 0x118, 0xF, 0xF, false); v = o < v ? o : v;
+  o = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFF, (int)v, 0x142, 0xA, 0xF, false); v = o < v ? o : v;
+  o = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFF, (int)v, 0x143, 0xC, 0xF, false); v = o < v ? o : v;
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 // carry-save adder on bit-planes: (h, l) = a + b + c per bit position
 #define FLACENC_CSA(h, l, a_, b_, c_)             \
   {                                               \
@@ -139,54 +156,63 @@ struct RiceResult {
   int bestk;                     // chosen order = 6 - bestk (uniform)
   unsigned long long best_bits;  // PrcParameter::code_bits (uniform)
   uint32_t my_p;                 // parameter of the chosen-order partition this lane leads
-  bool saturated;
+  bool saturated;                // the chosen order has a saturated table minimum
+  uint32_t sat_levels;           // bit k: some group minimum at level k hit MAX_P_TO_BITS
 };
 
 // Orders 6..0 of PrcParameterFinder::find (rice.rs:246-298) for a 4096 block with one finest
-// partition per lane.  Table entries are kept as  Wp[p] = table[p] - 4  so that
+// partition per lane.  Table entries are kept as  Wp[j] = table[p_lo + j] - 4  so that
 //   merge   (rice.rs:144-152): min(a + b - 4, MAX) on tables == min(Wa + Wb, MAX - 4)
-//   minimiser (rice.rs:115-141): min over p of (Wp[p] << 5 | p), bits = (min >> 5) + 4, p = min & 31.
+//   minimiser (rice.rs:115-141): min over p of (Wp << 5 | p), bits = (min >> 5) + 4, p = min & 31.
 // Level k's tables are valid on the lanes that are multiples of 2^k (group leaders), which
-// fetch their partner's entries from lane + 2^(k-1).  NP = number of parameters evaluated
-// (a multiple of 8 above max_p; entries above max_p are masked in the minimiser).
+// fetch their partner's entries from lane + 2^(k-1).
+//
+// Only the parameters p_lo .. p_lo + NP - 1 are evaluated; [p_lo, max_p] is a window that
+// provably contains every minimiser of every partition at every order (see rice_window), so
+// the result is identical to searching 0..=max_p.  Entries above max_p are set to the
+// saturation value once: they can then never beat (or tie ahead of) a legal parameter.
 // EXACT = false: literal chunk-clamped sums of rice.rs:75-98 for residuals >= 2^26.
 template <int NP, bool EXACT>
 __device__ __forceinline__ RiceResult rice_search(const uint32_t (&pl)[7], const uint32_t* u, uint32_t len0,
-                                                  uint32_t max_p, bool small_bits, int lane, int warm) {
+                                                  uint32_t p_lo, uint32_t max_p, bool small_bits, int lane,
+                                                  int warm) {
   constexpr uint32_t kWMax = kMaxPToBits - 4u;
   uint32_t Wp[NP];
   if (EXACT) {
 #pragma unroll
-    for (int pp = 0; pp < NP; ++pp) {
+    for (int j = 0; j < NP; ++j) {
+      const uint32_t pp = p_lo + (uint32_t)j;  // wave-uniform
       uint32_t sum = 0;
 #pragma unroll
-      for (int k = 0; k < 7; ++k) sum += (pl[k] >> pp) << k;  // sum_i (u_i >> pp)
+      for (int k = 0; k < 7; ++k) sum += (pl[k] >> (pp & 31u)) << k;  // sum_i (u_i >> pp)
       sum = sum < kMaxPToBits ? sum : kMaxPToBits;
-      uint32_t v = sum + len0 * (uint32_t)(pp + 1);  // rice.rs:69-71, 95-98 (minus the 4)
+      uint32_t v = sum + len0 * (pp + 1u);  // rice.rs:69-71, 95-98 (minus the 4)
       v = v < kWMax ? v : kWMax;
-      Wp[pp] = v;
+      Wp[j] = (pp <= max_p) ? v : kWMax;
     }
   } else {
     // the reference's slice of partition 0 starts at `warm`; its clamp cadence follows.
     // (rare path: runtime loop over p, registers selected by compare chains -- no scratch)
     const int off = (lane == 0) ? warm : 0;
 #pragma unroll
-    for (int q = 0; q < NP; ++q) Wp[q] = 0;
+    for (int q = 0; q < NP; ++q) Wp[q] = kWMax;
 #pragma unroll 1
-    for (int pp = 0; pp < NP; ++pp) {
+    for (int j = 0; j < NP; ++j) {
+      const uint32_t pp = p_lo + (uint32_t)j;
       uint32_t accb = 0;
 #pragma unroll
       for (int k = 0; k < 64; ++k) {
         if (k >= off) {
-          accb += u[k] >> pp;
+          accb += u[k] >> (pp & 31u);
           if (((k - off) & 15) == 15) accb = accb < kMaxPToBits ? accb : kMaxPToBits;
         }
       }
       accb = accb < kMaxPToBits ? accb : kMaxPToBits;
-      uint32_t v = accb + len0 * (uint32_t)(pp + 1);
+      uint32_t v = accb + len0 * (pp + 1u);
       v = v < kWMax ? v : kWMax;
+      if (pp > max_p) v = kWMax;
 #pragma unroll
-      for (int q = 0; q < NP; ++q) Wp[q] = (q == pp) ? v : Wp[q];
+      for (int q = 0; q < NP; ++q) Wp[q] = (q == j) ? v : Wp[q];
     }
   }
 
@@ -199,15 +225,18 @@ __device__ __forceinline__ RiceResult rice_search(const uint32_t (&pl)[7], const
 #define FLACENC_RICE_LEVEL(K, S)                                                              \
   {                                                                                           \
     if (K > 0) {                                                                              \
-      _Pragma("unroll") for (int pp = 0; pp < NP; ++pp) {                                     \
-        uint32_t v = Wp[pp] + from_upper_half<S>(Wp[pp]);                                     \
-        Wp[pp] = v < kWMax ? v : kWMax;                                                       \
+      uint32_t part[NP];                                                                      \
+      _Pragma("unroll") for (int j = 0; j < NP; ++j) part[j] = from_upper_half<S>(Wp[j]);     \
+      _Pragma("unroll") for (int j = 0; j < NP; ++j) {                                        \
+        uint32_t v = Wp[j] + part[j];                                                         \
+        Wp[j] = v < kWMax ? v : kWMax;                                                        \
       }                                                                                       \
     }                                                                                         \
     uint32_t packed = 0xFFFFFFFFu;                                                            \
-    _Pragma("unroll") for (int pp = 0; pp < NP; ++pp) {                                       \
-      uint32_t cand = ((uint32_t)pp <= max_p) ? ((Wp[pp] << 5) | (uint32_t)pp) : 0xFFFFFFFFu; \
-      packed = cand < packed ? cand : packed;                                                 \
+    _Pragma("unroll") for (int j = 0; j + 1 < NP; j += 2) {                                   \
+      const uint32_t c0 = (Wp[j] << 5) | (p_lo + (uint32_t)j);                                \
+      const uint32_t c1 = (Wp[j + 1] << 5) | (p_lo + (uint32_t)j + 1u);                       \
+      packed = umin3(packed, c0, c1);                                                         \
     }                                                                                         \
     const uint32_t bits = (packed >> 5) + 4u;                                                 \
     const bool lead = (lane & ((1 << K) - 1)) == 0;                                           \
@@ -232,6 +261,7 @@ __device__ __forceinline__ RiceResult rice_search(const uint32_t (&pl)[7], const
 #undef FLACENC_RICE_LEVEL
   sat_any = wave_or_dpp(sat_any);
   r.saturated = (sat_any >> r.bestk) & 1u;
+  r.sat_levels = sat_any;
   return r;
 }
 
@@ -543,13 +573,33 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
       planes_add<5>(pc, pd);
       planes_add<6>(pl, pc);
     }
-    if (max_p < 8) rr = rice_search<8, true>(pl, u, len0, max_p, small_bits, lane, warm);
-    else if (max_p < 16) rr = rice_search<16, true>(pl, u, len0, max_p, small_bits, lane, warm);
-    else if (max_p < 24) rr = rice_search<24, true>(pl, u, len0, max_p, small_bits, lane, warm);
-    else rr = rice_search<32, true>(pl, u, len0, max_p, small_bits, lane, warm);
+    // rice_window: a lower end for the parameter search.  For a partition (or merged group)
+    // with sum S over len samples and mean m = S / len let p0 = floor(log2(m + 1)).  From
+    // S/2^p - len < sum_i (u_i >> p) <= S/2^p:  table[p0] - 4 < len (p0 + 3)  and, for
+    // p <= p0 - 3,  table[p] - 4 > len (m / 2^p + p) >= len (p0 + 4).  So no p <= p0 - 3 can
+    // win or tie.  A group's mean is at least the smallest 64-sample partition mean, so the
+    // wave-minimum of the (conservatively rounded) per-lane p0 bounds every order.  If the
+    // configured max_p lies below that, the same inequalities leave max_p as the only candidate.
+    uint32_t s0 = 0;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) s0 += pl[k] << k;  // sum of the lane's 64 words (< 2^32: u < 2^26)
+    const uint32_t q0 = (s0 >> 6) + 1u;
+    const uint32_t p0min = wave_min_dpp(31u - (uint32_t)__builtin_clz(q0));
+    uint32_t p_lo = p0min > 2u ? p0min - 2u : 0u;
+    p_lo = p_lo < max_p ? p_lo : max_p;
+    const uint32_t span = max_p - p_lo + 1u;
+    if (span <= 8) rr = rice_search<8, true>(pl, u, len0, p_lo, max_p, small_bits, lane, warm);
+    else if (span <= 16) rr = rice_search<16, true>(pl, u, len0, p_lo, max_p, small_bits, lane, warm);
+    else if (span <= 24) rr = rice_search<24, true>(pl, u, len0, p_lo, max_p, small_bits, lane, warm);
+    else rr = rice_search<32, true>(pl, u, len0, 0u, max_p, small_bits, lane, warm);
+    // The window argument compares unclamped table values.  If any group minimum saturated at
+    // MAX_P_TO_BITS, clamped entries outside the window could tie with it (ties go to the
+    // smallest p, rice.rs:123-124), so search the whole range then.
+    if (rr.sat_levels != 0 && p_lo != 0 && span <= 24)
+      rr = rice_search<32, true>(pl, u, len0, 0u, max_p, small_bits, lane, warm);
   } else {
     uint32_t pl[7] = {0, 0, 0, 0, 0, 0, 0};
-    rr = rice_search<32, false>(pl, u, len0, max_p, small_bits, lane, warm);
+    rr = rice_search<32, false>(pl, u, len0, 0u, max_p, small_bits, lane, warm);
   }
   const int bestk = rr.bestk;
   const unsigned long long best_bits = rr.best_bits;

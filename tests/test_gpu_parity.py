@@ -340,3 +340,48 @@ def test_stereo_batch_equals_four_subframe_analyses(handle, n, bps, order):
         assert np.array_equal(decoded[0], l) and np.array_equal(decoded[1], r)
         l2, r2 = orc.midside_to_stereo(decoded[2], decoded[3])
         assert np.array_equal(l2, l) and np.array_equal(r2, r)
+
+
+# ------------------------------------------------------------------ Rice search stress ----
+@pytest.mark.parametrize("max_p", [30, 14, 6, 1])
+def test_rice_search_window_stress(handle, max_p):
+    """The 4096-block kernel searches only a provably sufficient window of Rice parameters
+    (DESIGN.md 4.1).  Stress it with residual statistics that vary wildly inside a block:
+    bursts, silence next to full scale, slow amplitude ramps, single outliers, per-partition
+    alternation -- results must stay bit-identical to the exhaustive reference search."""
+    n, rng = 4096, np.random.default_rng(20260 + max_p)
+    sigs = []
+    for k in range(96):
+        kind = k % 8
+        base = util.noise(5000 + k, n, 1.0)
+        env = np.ones(n, np.float32)
+        if kind == 0:    # burst in one 64-sample partition
+            env[:] = 0.001
+            q = int(rng.integers(0, 64)) * 64
+            env[q:q + 64] = 0.9
+        elif kind == 1:  # silence then loud
+            env[: n // 2] = 0.0
+            env[n // 2:] = 0.8
+        elif kind == 2:  # exponential ramp over 5 orders of magnitude
+            env = np.exp(np.linspace(np.log(1e-5), np.log(0.9), n)).astype(np.float32)
+        elif kind == 3:  # alternating partitions quiet / loud
+            env = np.where((np.arange(n) // 64) % 2 == 0, 0.002, 0.7).astype(np.float32)
+        elif kind == 4:  # single outlier sample
+            env[:] = 0.003
+            env[int(rng.integers(100, n))] = 1.0
+        elif kind == 5:  # tiny noise: residual of a few LSBs
+            env[:] = 3.0 / 32768
+        elif kind == 6:  # tone + modulated noise
+            base = base * 0.2 + util.sine(n, 23.0 + k, 0.7)
+            env = (0.05 + 0.9 * np.abs(util.sine(n, 700.0, 1.0))).astype(np.float32)
+        else:            # random per-partition gains
+            env = np.repeat(rng.choice([1e-4, 1e-3, 1e-2, 0.1, 0.9], size=64), 64).astype(np.float32)
+        bps = 24 if k % 3 == 0 else 16
+        sigs.append((util.quantize(base * env, bps), bps))
+    x = np.stack([s for s, _ in sigs])
+    bps = np.array([b for _, b in sigs], np.uint8)
+    gp, gres, _, _ = handle.qlpc_batch(x, bps, gpu_cfg(8, max_p=max_p))
+    cp, cres, _, _ = orc.qlpc_batch(x, bps, orc_cfg(8, max_p=max_p, acorr=orc.ACORR_CANONICAL), want_fp=False)
+    assert_records_equal(gp, cp, f"max_p={max_p}")
+    assert np.array_equal(gres, cres)
+    check_lossless(x, gp, gres)

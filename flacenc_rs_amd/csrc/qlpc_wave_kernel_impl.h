@@ -20,17 +20,25 @@
 #ifndef FLACENC_HIP_QLPC_WAVE_KERNEL_IMPL_H_
 #define FLACENC_HIP_QLPC_WAVE_KERNEL_IMPL_H_
 
+#include <type_traits>
+
 #include "qlpc_kernel_impl.h"
 
 namespace flacenc_hip {
 namespace {
 
+// waves per SIMD the register allocator must leave room for: 3 workgroups per CU is what the
+// stereo LDS footprint (2 images + window) allows; plain mode (4 images) is LDS-bound earlier
 #ifndef FLACENC_WAVE_OCC
-#define FLACENC_WAVE_OCC 1
+#if defined(FLACENC_STEREO) && FLACENC_STEREO && defined(FLACENC_MAXP) && FLACENC_MAXP <= 10
+#define FLACENC_WAVE_OCC 3
+#else
+#define FLACENC_WAVE_OCC 2
+#endif
 #endif
 constexpr int kWaveN = 4096;        // block size handled by this kernel
 constexpr int kSeg = 68;            // dwords per lane segment: 64 samples + 4 pad (conflict-free b128)
-constexpr int kBufDwords = 65 * kSeg;  // one leading all-zero segment (halo of lane 0)
+constexpr int kBufDwords = 65 * kSeg + 8;  // one leading all-zero segment (halo of lane 0) + look-ahead slack
 
 __device__ __forceinline__ int widx(int t) { return ((t >> 6) + 1) * kSeg + (t & 63); }
 // |v| with i32::MIN -> 2^31 - 1 + 1 handled by the caller's unsigned compare; inputs are <= 25 bits
@@ -290,12 +298,28 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
   } else {
     sf = blk * 4u + (uint32_t)wave;
     active = sf < a.n_subframes;
+    // tail waves of the last workgroup redo the last subframe (identical bytes to the same
+    // addresses) so that every wave reaches the workgroup barriers with valid data
+    if (!active) sf = a.n_subframes - 1u;
   }
   if (a.stamps && lane == 0 && active) a.stamps[(size_t)sf * 8 + 0] = (unsigned long long)clock64();
 
   // ======================= phase 0: HBM -> LDS ==============================
   // Segment layout: sample t of a channel image lives at widx(t); segment 0 is zero.
   for (int i = tid; i < NBUF * kSeg; i += 256) sm[(i / kSeg) * kBufDwords + (i % kSeg)] = 0;
+  // The window table (lpc.rs:96-120, computed on the host) is staged once per workgroup in the
+  // same segment layout and shared by the four waves (3 workgroups x 53 KB fit one CU's LDS).
+  float* const wlds = reinterpret_cast<float*>(sm + NBUF * kBufDwords);
+  const bool has_window = a.window != nullptr;  // nullptr = all ones (rectangle / Tukey(0))
+  if (has_window) {
+    const float* __restrict__ wsrc = a.window + 32;
+    if (tid < kSeg) wlds[tid] = 0.0f;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int t = (tid + it * 256) << 2;
+      *reinterpret_cast<float4*>(&wlds[widx(t)]) = *reinterpret_cast<const float4*>(wsrc + t);
+    }
+  }
   if (STEREO) {
     const int32_t* __restrict__ src = a.samples + (size_t)(2u * blk) * a.stride;
 #pragma unroll
@@ -308,7 +332,7 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
     }
     __syncthreads();
   } else {
-    if (active) {
+    {
       const int32_t* __restrict__ src = a.samples + (size_t)sf * a.stride;
 #pragma unroll
       for (int it = 0; it < 16; ++it) {
@@ -319,17 +343,22 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
     }
     __syncthreads();  // (also orders the zero segment written by other waves)
   }
-  if (!active) return;
+  // (inactive tail waves of plain mode stay for the workgroup barriers and write nothing)
   if (a.stamps && lane == 0) a.stamps[(size_t)sf * 8 + 1] = (unsigned long long)clock64();
 
+#if defined(FLACENC_CUT) && FLACENC_CUT == 1
+  if (lane == 0) a.residual[sf] = sm[tid]; return;
+#endif
   const int32_t* const bufA = sm + (STEREO ? (role == 1 ? 1 : 0) : wave) * kBufDwords;
   const int32_t* const bufB = sm + kBufDwords;  // right channel (stereo roles 2, 3)
-  // four samples of this wave's role starting at t (multiple of 4, >= -64)
-  auto ld4 = [&](int t) -> int4 {
+  // four samples of this wave's role starting at t (multiple of 4, >= -64).  The role is
+  // wave-uniform; phases are instantiated per role kind so that no branch sits in their loops.
+  auto ld4k = [&](auto kind_tag, int t) -> int4 {
+    constexpr int KIND = decltype(kind_tag)::value;  // 0 = own image, 2 = mid, 3 = side
     int4 v = *reinterpret_cast<const int4*>(&bufA[widx(t)]);
-    if (STEREO && role >= 2) {
+    if (KIND >= 2) {
       const int4 r = *reinterpret_cast<const int4*>(&bufB[widx(t)]);
-      if (role == 2) {  // mid = (l + r) >> 1, coding.rs:483
+      if (KIND == 2) {  // mid = (l + r) >> 1, coding.rs:483
         v.x = (v.x + r.x) >> 1;
         v.y = (v.y + r.y) >> 1;
         v.z = (v.z + r.z) >> 1;
@@ -343,50 +372,92 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
     }
     return v;
   };
+  // run `f(kind_tag)` with the wave's role kind as a compile-time constant
+  auto with_role = [&](auto&& f) {
+    if (STEREO && role == 2) f(std::integral_constant<int, 2>{});
+    else if (STEREO && role == 3) f(std::integral_constant<int, 3>{});
+    else f(std::integral_constant<int, 0>{});
+  };
 
   // ======================= phase 1: window + autocorrelation ==============
-  const float* __restrict__ wtab = a.window ? (a.window + 32) : nullptr;
   const int tl = lane << 6;  // first sample of this lane
   double R[NLAG];
   uint32_t my_maxabs = 0;
-  {
-    double dw[HP + 16];
-    double s01[NLAG], tot[NLAG];
+  int vmax = 0, vmin = 0;
+  with_role([&](auto kind) {
+    auto ld4 = [&](int t) { return ld4k(kind, t); };
+    // The lane walks its 64 samples as 4 chunks x 2 steps of 8 with a sliding f64 window of
+    // HP halo + 8 new values.  A 16-sample chunk is one fma chain per lag, started with the
+    // literal +0.0; chunk partials are combined (c0 + c1) + (c2 + c3): the in-lane levels of
+    // the balanced tree over the chunk index c = 4 lane + i.  The chunk loop is deliberately
+    // NOT unrolled: unrolled, the compiler hoists every chunk's loads and conversions to the
+    // top and needs > 250 VGPRs; rolled it stays under 128 and four waves fit a SIMD.
+    constexpr int WN = HP + 8;
+    double dw[WN];
+    double acc[NLAG], s01[NLAG], p2[NLAG];
+    // raw samples and weights of one 8-sample step, fetched one step ahead of their use
+    int4 rv[2];
+    float4 rw[2];
+    auto fetch = [&](int t0) {
 #pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        rv[q] = ld4(t0 + 4 * q);
+        rw[q] = has_window ? *reinterpret_cast<const float4*>(&wlds[widx(t0 + 4 * q)])
+                           : make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+      }
+    };
+    // x_w[t] = (f32)s[t] * w[t]: one f32 rounding, then widen (lpc.rs:751-754)
+    auto convert = [&](int base) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        dw[base + 4 * q + 0] = (double)((float)rv[q].x * rw[q].x);
+        dw[base + 4 * q + 1] = (double)((float)rv[q].y * rw[q].y);
+        dw[base + 4 * q + 2] = (double)((float)rv[q].z * rw[q].z);
+        dw[base + 4 * q + 3] = (double)((float)rv[q].w * rw[q].w);
+      }
+    };
+    // halo of the lane's first chunk (HP = 8 or 12 samples in front of it)
+    fetch(tl - 8);
+    convert(HP);  // lands in dw[HP .. HP+8), slid to dw[HP-8 .. HP) by the first step
+    if (HP > 8) {
+      const int4 v = ld4(tl - 12);
+      const float4 wv = has_window ? *reinterpret_cast<const float4*>(&wlds[widx(tl - 12)])
+                                   : make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+      dw[HP - 4 + 0] = (double)((float)v.x * wv.x);
+      dw[HP - 4 + 1] = (double)((float)v.y * wv.y);
+      dw[HP - 4 + 2] = (double)((float)v.z * wv.z);
+      dw[HP - 4 + 3] = (double)((float)v.w * wv.w);
+    }
+    fetch(tl);
+#pragma unroll 1
     for (int i = 0; i < 4; ++i) {
-      const int t0 = tl + 16 * i;
-      // slide the window: the last HP values of the previous chunk are this chunk's halo
-      if (i > 0) {
 #pragma unroll
-        for (int k = 0; k < HP; ++k) dw[k] = dw[k + 16];
-      }
-      const int first = (i == 0) ? 0 : HP;  // dw[first..HP+16) are new
-      const int tfirst = (i == 0) ? t0 - HP : t0;
-      // taper weights come from the table; inside the flat part (and for a rectangular
-      // window) the weight is exactly 1.0f and (f32)s * 1.0f == (f32)s (lpc.rs:751-754)
-      const bool flat = (wtab == nullptr) || (tfirst >= a.flat_lo && t0 + 16 <= a.flat_hi);
+      for (int h = 0; h < 2; ++h) {
+        const int t0 = tl + 16 * i + 8 * h;
 #pragma unroll
-      for (int k = first; k < HP + 16; k += 4) {
-        const int t = t0 - HP + k;
-        const int4 v = ld4(t);
-        if (k >= HP) {
-          int mx = max(max(abs_sat(v.x), abs_sat(v.y)), max(abs_sat(v.z), abs_sat(v.w)));
-          my_maxabs = my_maxabs > (uint32_t)mx ? my_maxabs : (uint32_t)mx;
+        for (int k = 0; k < HP; ++k) dw[k] = dw[k + 8];  // slide: last HP values become the halo
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          vmax = max(max(vmax, rv[q].x), max(rv[q].y, max(rv[q].z, rv[q].w)));
+          vmin = min(min(vmin, rv[q].x), min(rv[q].y, min(rv[q].z, rv[q].w)));
         }
-        float4 wv = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
-        if (!flat) wv = *reinterpret_cast<const float4*>(wtab + t);
-        dw[k + 0] = (double)((float)v.x * wv.x);  // one f32 rounding, then widen
-        dw[k + 1] = (double)((float)v.y * wv.y);
-        dw[k + 2] = (double)((float)v.z * wv.z);
-        dw[k + 3] = (double)((float)v.w * wv.w);
-      }
-      double acc[NLAG];
+        convert(HP);
+        fetch(t0 + 8);  // next step (one segment of slack exists behind the last lane)
 #pragma unroll
-      for (int k = 0; k < NLAG; ++k) acc[k] = 0.0;
-      // only the very first chunk of the block can contain t < P (P <= 12 < 16)
-      if (i == 0) acorr_chunk<MAXP, HP, true>(dw, acc, t0, P);  // (selects only; i is compile-time)
-      else acorr_chunk<MAXP, HP, false>(dw, acc, t0, P);
-      // balanced tree over the chunk index c = 4 lane + i: (c0 + c1) + (c2 + c3) in-lane
+        for (int k = 0; k < 8; ++k) {
+          double cur = dw[HP + k];
+          // only the first chunk of the block contains t < P (P <= 12 < 16): common lower
+          // bound t = P for every lag (lpc.rs:542); the select is wave-uniform on i
+          if (i == 0) cur = (t0 + k >= P) ? cur : 0.0;
+          if (h == 0 && k == 0) {
+#pragma unroll
+            for (int tau = 0; tau <= MAXP; ++tau) acc[tau] = __builtin_fma(cur, dw[HP + k - tau], 0.0);
+          } else {
+#pragma unroll
+            for (int tau = 0; tau <= MAXP; ++tau) acc[tau] = __builtin_fma(cur, dw[HP + k - tau], acc[tau]);
+          }
+        }
+      }
       if (i == 0) {
 #pragma unroll
         for (int k = 0; k < NLAG; ++k) s01[k] = acc[k];
@@ -395,17 +466,18 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
         for (int k = 0; k < NLAG; ++k) s01[k] = s01[k] + acc[k];
       } else if (i == 2) {
 #pragma unroll
-        for (int k = 0; k < NLAG; ++k) tot[k] = acc[k];
+        for (int k = 0; k < NLAG; ++k) p2[k] = acc[k];
       } else {
 #pragma unroll
-        for (int k = 0; k < NLAG; ++k) tot[k] = s01[k] + (tot[k] + acc[k]);
+        for (int k = 0; k < NLAG; ++k) p2[k] = s01[k] + (p2[k] + acc[k]);
       }
     }
     // ... then the 6 lane levels
 #pragma unroll
-    for (int k = 0; k < NLAG; ++k) R[k] = wave_butterfly_sum(tot[k]);
-  }
-  my_maxabs = wave_max_dpp(my_maxabs);
+    for (int k = 0; k < NLAG; ++k) R[k] = wave_butterfly_sum(p2[k]);
+  });
+  // max |s| (find_max_abs, arrayutils.rs:509) from the running max / min
+  my_maxabs = wave_max_dpp((uint32_t)max(vmax, -vmin) | (vmin == INT32_MIN ? 0x80000000u : 0u));
   if (a.autocorr && lane < 33) {
     double rv = 0.0;
 #pragma unroll
@@ -413,74 +485,117 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
       if (k == lane && k <= P) rv = R[k];
     a.autocorr[(size_t)sf * 33 + lane] = rv;
   }
+#if defined(FLACENC_CUT) && FLACENC_CUT == 2
+  if (lane == 0) a.autocorr[sf] = R[0] + R[MAXP]; return;
+#endif
+  __builtin_amdgcn_sched_barrier(0);
   if (a.stamps && lane == 0) a.stamps[(size_t)sf * 8 + 2] = (unsigned long long)clock64();
 
-  // ======================= phase 2: Levinson + quantisation (every lane) ====
-  // All lanes hold the same R[], so all compute the same coefficients; the results are
-  // then moved to scalar registers (they are wave-uniform).
+  // ======================= phase 2: Levinson + quantisation ================
+  // Serial, ~650 VALU instructions, and a wave instruction costs the same with 1 or 64 active
+  // lanes -- so the four waves of the workgroup hand their R[] to wave 0, whose lanes 0..3
+  // run the recursion for the four subframes side by side (one instruction stream instead of
+  // four), and pick their quantised coefficients up again from LDS.
   int32_t cq[MAXP];
   int warm, shift, status;
   {
-    double coef[MAXP];
-    int32_t cqv[MAXP];
-    int warm_v, shift_v;
-    const int st = levinson_quantize<MAXP>(R, P, (int)a.precision, coef, cqv, &warm_v, &shift_v);
-    status = uni(st);
-    warm = uni(warm_v);
-    shift = uni(shift_v);
+    // exchange area: kept small -- LDS is allocated in 1280-byte granules and three workgroups
+    // must fit one CU (3 x 42 granules = 157.5 KB)
+    constexpr int XR = (NLAG + 1) & ~1;
+    double* const xr = reinterpret_cast<double*>(sm + (NBUF + 1) * kBufDwords);  // [4][XR]
+    int32_t* const xq = reinterpret_cast<int32_t*>(xr + 4 * XR);                   // [4][16]
+    if (lane == 0) {
 #pragma unroll
-    for (int i = 0; i < MAXP; ++i) cq[i] = uni(cqv[i]);
-    if (a.lpc_coefs && lane == 0) {
-#pragma unroll
-      for (int i = 0; i < MAXP; ++i) a.lpc_coefs[(size_t)sf * 32 + i] = (i < P && status == 0) ? coef[i] : 0.0;
-      for (int i = MAXP; i < 32; ++i) a.lpc_coefs[(size_t)sf * 32 + i] = 0.0;
+      for (int k = 0; k < NLAG; ++k) xr[wave * XR + k] = R[k];
     }
+    __syncthreads();
+    if (wave == 0 && lane < 4) {
+      double Rl[NLAG];
+#pragma unroll
+      for (int k = 0; k < NLAG; ++k) Rl[k] = xr[lane * XR + k];
+      double coef[MAXP];
+      int32_t cqv[MAXP];
+      int warm_v, shift_v;
+      const int st = levinson_quantize<MAXP>(Rl, P, (int)a.precision, coef, cqv, &warm_v, &shift_v);
+#pragma unroll
+      for (int i = 0; i < MAXP; ++i) xq[lane * 16 + i] = cqv[i];
+      xq[lane * 16 + 12] = warm_v;
+      xq[lane * 16 + 13] = shift_v;
+      xq[lane * 16 + 14] = st;
+      uint32_t sfl = blk * 4u + (uint32_t)lane;
+      if (sfl >= a.n_subframes) sfl = a.n_subframes - 1u;
+      if (a.lpc_coefs) {
+#pragma unroll
+        for (int i = 0; i < MAXP; ++i) a.lpc_coefs[(size_t)sfl * 32 + i] = (i < P && st == 0) ? coef[i] : 0.0;
+        for (int i = MAXP; i < 32; ++i) a.lpc_coefs[(size_t)sfl * 32 + i] = 0.0;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i) cq[i] = uni(xq[wave * 16 + i]);
+    warm = uni(xq[wave * 16 + 12]);
+    shift = uni(xq[wave * 16 + 13]);
+    status = uni(xq[wave * 16 + 14]);
   }
   int sumabs = 0;
 #pragma unroll
   for (int i = 0; i < MAXP; ++i) sumabs += cq[i] < 0 ? -cq[i] : cq[i];
   // compute_error's path choice, lpc.rs:361-377 (+ |s| < 2^23 for the 24-bit multiplier)
   const bool wide = !(((uint64_t)my_maxabs * (uint64_t)sumabs < 0x7FFFFFFFull) && (my_maxabs < (1u << 23)));
+#if defined(FLACENC_CUT) && FLACENC_CUT == 3
+  if (lane == 0) a.residual[sf] = cq[0] + cq[MAXP-1] + warm + shift; return;
+#endif
+  __builtin_amdgcn_sched_barrier(0);
   if (a.stamps && lane == 0) a.stamps[(size_t)sf * 8 + 3] = (unsigned long long)clock64();
 
   // ======================= phase 3: residual -> registers ==================
   int32_t e[64];
   {
-    int sw[HP + 16];
+    // e[t] = s[t] - ((sum_j c_j s[t-1-j]) >> shift) (lpc.rs:306-350); the i32 / i64 choice of
+    // lpc.rs:373-389 is wave-uniform, so it selects one of two straight-line bodies
+    auto residual_pass = [&](auto wide_tag, auto kind) {
+      constexpr bool WIDE = decltype(wide_tag)::value;
+      auto ld4 = [&](int t) { return ld4k(kind, t); };
+      int sw[HP + 16];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int t0 = tl + 16 * i;
-      if (i > 0) {
+      for (int i = 0; i < 4; ++i) {
+        const int t0 = tl + 16 * i;
+        // compiler-level memory barrier: keeps the next chunk's LDS reads from being hoisted
+        // above this chunk's arithmetic (which would cost VGPRs and an occupancy step)
+        asm volatile("" ::: "memory");
+        if (i > 0) {
 #pragma unroll
-        for (int k = 0; k < HP; ++k) sw[k] = sw[k + 16];
-      }
-      const int first = (i == 0) ? 0 : HP;
+          for (int k = 0; k < HP; ++k) sw[k] = sw[k + 16];
+        }
+        const int first = (i == 0) ? 0 : HP;
 #pragma unroll
-      for (int k = first; k < HP + 16; k += 4) {
-        const int4 v = ld4(t0 - HP + k);
-        sw[k + 0] = v.x;
-        sw[k + 1] = v.y;
-        sw[k + 2] = v.z;
-        sw[k + 3] = v.w;
-      }
-      if (!wide) {
+        for (int k = first; k < HP + 16; k += 4) {
+          const int4 v = ld4(t0 - HP + k);
+          sw[k + 0] = v.x;
+          sw[k + 1] = v.y;
+          sw[k + 2] = v.z;
+          sw[k + 3] = v.w;
+        }
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
-          int32_t pred = 0;
+          if (!WIDE) {
+            int32_t pred = 0;
 #pragma unroll
-          for (int j = 0; j < MAXP; ++j) pred += __mul24(cq[j], sw[HP + k - 1 - j]);
-          e[16 * i + k] = sw[HP + k] - (pred >> shift);
-        }
-      } else {
+            for (int j = 0; j < MAXP; ++j) pred += __mul24(cq[j], sw[HP + k - 1 - j]);
+            e[16 * i + k] = sw[HP + k] - (pred >> shift);
+          } else {
+            int64_t pred = 0;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-          int64_t pred = 0;
-#pragma unroll
-          for (int j = 0; j < MAXP; ++j) pred += (int64_t)cq[j] * (int64_t)sw[HP + k - 1 - j];
-          e[16 * i + k] = (int32_t)(uint32_t)(uint64_t)((int64_t)sw[HP + k] - (pred >> shift));
+            for (int j = 0; j < MAXP; ++j) pred += (int64_t)cq[j] * (int64_t)sw[HP + k - 1 - j];
+            e[16 * i + k] = (int32_t)(uint32_t)(uint64_t)((int64_t)sw[HP + k] - (pred >> shift));
+          }
         }
       }
-    }
+    };
+    with_role([&](auto kind) {
+      if (!wide) residual_pass(std::false_type{}, kind);
+      else residual_pass(std::true_type{}, kind);
+    });
     // e[0 .. order') = 0 (lpc.rs:349): only lane 0, only its first 16 slots (order' <= 12)
 #pragma unroll
     for (int k = 0; k < 16; ++k)
@@ -490,6 +605,10 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
       for (int k = 16; k < 64; ++k) e[k] = 0;
     }
   }
+#if defined(FLACENC_CUT) && FLACENC_CUT == 4
+  { int z = 0; for (int k = 0; k < 64; ++k) z ^= e[k]; a.residual[sf * 64 + lane] = z; return; }
+#endif
+  __builtin_amdgcn_sched_barrier(0);
   if (a.stamps && lane == 0) a.stamps[(size_t)sf * 8 + 4] = (unsigned long long)clock64();
 
   // ======================= residual store: registers -> LDS -> HBM ==========
@@ -535,6 +654,10 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
       }
     }
   }
+#if defined(FLACENC_CUT) && FLACENC_CUT == 5
+  return;
+#endif
+  __builtin_amdgcn_sched_barrier(0);
   if (a.stamps && lane == 0) a.stamps[(size_t)sf * 8 + 5] = (unsigned long long)clock64();
 
   // ======================= phase 4: partitioned-Rice search ================
@@ -556,8 +679,9 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
   const uint32_t len0 = 64u - (lane == 0 ? (uint32_t)warm : 0u);
 
   RiceResult rr;
+  unsigned long long sat_sum_q = 0;  // exact sum of quotients, only evaluated if a minimum saturated
   if (maxu < (1u << 26)) {
-    // bit-sliced population counts of the lane's 64 words -> 7 planes
+    // bit-sliced population counts of the lane's 64 words -> 7 planes; the words die here
     uint32_t pl[7], pb[5];
     popcount_planes16(u, pb);
 #pragma unroll
@@ -588,18 +712,39 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
     uint32_t p_lo = p0min > 2u ? p0min - 2u : 0u;
     p_lo = p_lo < max_p ? p_lo : max_p;
     const uint32_t span = max_p - p_lo + 1u;
-    if (span <= 8) rr = rice_search<8, true>(pl, u, len0, p_lo, max_p, small_bits, lane, warm);
-    else if (span <= 16) rr = rice_search<16, true>(pl, u, len0, p_lo, max_p, small_bits, lane, warm);
-    else if (span <= 24) rr = rice_search<24, true>(pl, u, len0, p_lo, max_p, small_bits, lane, warm);
-    else rr = rice_search<32, true>(pl, u, len0, 0u, max_p, small_bits, lane, warm);
+    if (span <= 8) rr = rice_search<8, true>(pl, nullptr, len0, p_lo, max_p, small_bits, lane, warm);
+    else if (span <= 16) rr = rice_search<16, true>(pl, nullptr, len0, p_lo, max_p, small_bits, lane, warm);
+    else if (span <= 24) rr = rice_search<24, true>(pl, nullptr, len0, p_lo, max_p, small_bits, lane, warm);
+    else rr = rice_search<32, true>(pl, nullptr, len0, 0u, max_p, small_bits, lane, warm);
     // The window argument compares unclamped table values.  If any group minimum saturated at
     // MAX_P_TO_BITS, clamped entries outside the window could tie with it (ties go to the
     // smallest p, rice.rs:123-124), so search the whole range then.
     if (rr.sat_levels != 0 && p_lo != 0 && span <= 24)
-      rr = rice_search<32, true>(pl, u, len0, 0u, max_p, small_bits, lane, warm);
+      rr = rice_search<32, true>(pl, nullptr, len0, 0u, max_p, small_bits, lane, warm);
+    if (rr.saturated) {
+      // sum_i (u_i >> p) of this lane's partition under its group's parameter, from the planes
+      const uint32_t gp = (uint32_t)__shfl((int)rr.my_p, lane & ~((1 << rr.bestk) - 1), 64);
+      unsigned long long mine = 0;
+#pragma unroll
+      for (int k = 0; k < 7; ++k) mine += (unsigned long long)(pl[k] >> gp) << k;
+      sat_sum_q = ((unsigned long long)wave_sum_dpp((uint32_t)(mine >> 16)) << 16) +
+                  (unsigned long long)wave_sum_dpp((uint32_t)(mine & 0xFFFFu));
+    }
   } else {
     uint32_t pl[7] = {0, 0, 0, 0, 0, 0, 0};
     rr = rice_search<32, false>(pl, u, len0, 0u, max_p, small_bits, lane, warm);
+    if (rr.saturated) {
+      const uint32_t gp = (uint32_t)__shfl((int)rr.my_p, lane & ~((1 << rr.bestk) - 1), 64);
+      uint32_t lo = 0, hi = 0;
+#pragma unroll
+      for (int k = 0; k < 64; ++k) {
+        uint32_t qv = u[k] >> gp;  // warm-up slots hold 0
+        lo += qv & 0xFFFFu;
+        hi += qv >> 16;
+      }
+      // per lane 64 x 16 bits = 22 bits; x 64 lanes = 28 bits
+      sat_sum_q = ((unsigned long long)wave_sum_dpp(hi) << 16) + (unsigned long long)wave_sum_dpp(lo);
+    }
   }
   const int bestk = rr.bestk;
   const unsigned long long best_bits = rr.best_bits;
@@ -612,24 +757,11 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
   const uint32_t sum_p = wave_sum_dpp(leader ? my_p : 0u);
   const uint32_t p0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)my_p);
   const uint32_t rice2 = wave_or_dpp(my_p > 14 ? 1u : 0u);
-  unsigned long long sum_q;
   const unsigned long long rem_bits = (unsigned long long)sum_p * (unsigned long long)(n >> rice_order) -
                                       (unsigned long long)warm * p0;
-  if (!rr.saturated) {
-    sum_q = best_bits - 4ull * (unsigned long long)best_parts - (unsigned long long)(n - warm) - rem_bits;
-  } else {
-    // partition of sample k on this lane at the chosen order: the lane's group leader's parameter
-    const uint32_t gp = (uint32_t)__shfl((int)my_p, lane & ~((1 << bestk) - 1), 64);
-    uint32_t lo = 0, hi = 0;
-#pragma unroll
-    for (int k = 0; k < 64; ++k) {
-      uint32_t qv = u[k] >> gp;  // warm-up slots hold 0
-      lo += qv & 0xFFFFu;
-      hi += qv >> 16;
-    }
-    // per lane 64 x 16 bits = 22 bits; x 64 lanes = 28 bits
-    sum_q = ((unsigned long long)wave_sum_dpp(hi) << 16) + (unsigned long long)wave_sum_dpp(lo);
-  }
+  const unsigned long long sum_q =
+      rr.saturated ? sat_sum_q
+                   : best_bits - 4ull * (unsigned long long)best_parts - (unsigned long long)(n - warm) - rem_bits;
 
   flacenc_hip_subframe_params* rec = a.params + sf;
   {
@@ -674,7 +806,7 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
 template <int MAXP, bool STEREO>
 hipError_t launch_wave4096(const QlpcKernelArgs& a, hipStream_t stream) {
   auto kern = qlpc_wave4096_kernel<MAXP, STEREO>;
-  constexpr size_t smem = (size_t)(STEREO ? 2 : 4) * kBufDwords * 4;
+  constexpr size_t smem = ((size_t)(STEREO ? 2 : 4) + 1) * kBufDwords * 4 + 4 * (((MAXP + 2) & ~1) * 8 + 64);  // images + window + exchange
   static bool configured = false;
   if (!configured) {
     hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),

@@ -60,24 +60,26 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     n, F, bps = args.block_size, args.frames, args.bps
-    cfg = _capi.make_config(lpc_order=args.lpc_order)  # precision 15, Tukey(0.4), max_p 30
+    # precision 15, Tukey(0.4), max_p 30; candidates Constant / Verbatim / LPC (use_fixed off: the
+    # fixed-LPC candidate is not on the GPU path yet), all stereo assignments allowed
+    cfg = _capi.make_frame_config(_capi.make_config(lpc_order=args.lpc_order))
     # synthetic "sigen" audio: Sine(200, 0.4) + Noise(0.4) like the reference's
     # stereo_frame_encoder_noisy_sine_lpc bench (src/coding.rs:1152), one continuous stream,
     # dealt round-robin: stream frame f belongs to rank f mod G (flacenc_rs_amd/shard.py)
     host = _capi.sigen_frames(F, 2, n, bps, 200.0, 0.4, 0.4, seed=0xF1AC0001, first_frame=rank,
                               frame_step=world)
     x = torch.from_numpy(host).to(dev)
-    params = torch.empty((F * 4, _capi.PARAMS_DTYPE.itemsize), dtype=torch.uint8, device=dev)
-    residual = torch.empty((F * 4, n), dtype=torch.int32, device=dev)
-    params_by_frame = params.view(F, 4 * _capi.PARAMS_DTYPE.itemsize)
+    rec_bytes = _capi.FRAME_RESULT_DTYPE.itemsize
+    results = torch.empty((F, rec_bytes), dtype=torch.uint8, device=dev)  # one record per frame
+    residual = torch.empty((F * 2, n), dtype=torch.int32, device=dev)     # the two chosen channels
     handle = _capi.Handle(local_rank)
     stream = torch.cuda.current_stream()
 
     def step():
-        handle.stereo_qlpc_batch_device(cfg, x.data_ptr(), F, n, n, bps, params.data_ptr(),
-                                        residual.data_ptr(), n, stream=stream.cuda_stream)
+        handle.encode_stereo_frames_device(cfg, x.data_ptr(), F, n, n, bps, results.data_ptr(),
+                                           residual.data_ptr(), n, stream=stream.cuda_stream)
         if world > 1:
-            shard.all_gather_records(params_by_frame, world * F)
+            shard.all_gather_records(results, world * F)
 
     def fence():
         if world > 1:
@@ -93,11 +95,11 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         ev[k][0].record(stream)
-        handle.stereo_qlpc_batch_device(cfg, x.data_ptr(), F, n, n, bps, params.data_ptr(),
-                                        residual.data_ptr(), n, stream=stream.cuda_stream)
+        handle.encode_stereo_frames_device(cfg, x.data_ptr(), F, n, n, bps, results.data_ptr(),
+                                           residual.data_ptr(), n, stream=stream.cuda_stream)
         ev[k][1].record(stream)
         if world > 1:
-            shard.all_gather_records(params_by_frame, world * F)
+            shard.all_gather_records(results, world * F)
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -107,9 +109,11 @@ def main():
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if args.steps else float("nan")
 
     # sanity: nothing in the timed region may have failed
-    p = np.frombuffer(params.cpu().numpy().tobytes(), dtype=_capi.PARAMS_DTYPE)
-    assert (p["status"] == 0).all(), "subframe status != 0"
-    bits = int(p["subframe_bits"].sum())
+    p = np.frombuffer(results.cpu().numpy().tobytes(), dtype=_capi.FRAME_RESULT_DTYPE)
+    lpc_kind = p["kind"] == 3
+    assert (p["lpc"]["status"][lpc_kind] == 0).all(), "subframe status != 0"
+    chosen_bits = int(sum(int(p["bits"][f, r]) for f in range(F) for r in p["role"][f]))
+    assign_hist = np.bincount(p["channel_assignment"], minlength=4).tolist()
 
     samples_per_step = F * 2 * n  # input channel-samples per rank per step
     value = world * samples_per_step * args.steps / elapsed / 1e6
@@ -131,11 +135,14 @@ def main():
         "config": {
             "workload": "configs[1]: sigen Sine(200,0.4)+Noise(0.4), 44.1kHz/16-bit stereo, "
                         f"block_size={n}, LPC order {args.lpc_order}, precision 15, Tukey(0.4), "
-                        "full partitioned-Rice search (max_p 30); L,R,M,S analysed per frame",
+                        "full partitioned-Rice search (max_p 30); L,R,M,S analysed per frame, encode_frame decision",
             "frames_per_step_per_gpu": F,
             "subframes_analysed_per_step_per_gpu": 4 * F,
-            "gather": "all_gather of 352-B parameter records (RCCL)" if world > 1 else "none",
-            "compressed_bits_per_sample_sum_LRMS": round(bits / (4 * F * n), 4),
+            "decision": "encode_subframe {Constant, Verbatim, LPC} + try_stereo_coding on the GPU; "
+                        "the two chosen residuals written",
+            "gather": "all_gather of 752-B frame records (RCCL)" if world > 1 else "none",
+            "subframe_bits_per_sample": round(chosen_bits / (2 * F * n), 4),
+            "assignments_indep_left_right_mid": assign_hist,
         },
         "roofline": {
             "bound": "hbm",
@@ -144,7 +151,7 @@ def main():
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": _measured_traffic(),
-            "kernel": "qlpc_wave4096_kernel<8,true>",
+            "kernel": "qlpc_wave4096_kernel<8,true,true>",
             "kernel_ms": round(kernel_ms, 4),
             "algorithmic_bytes_per_launch": ALGO_BYTES_PER_SAMPLE * samples_per_step,
         },

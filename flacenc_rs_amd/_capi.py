@@ -48,6 +48,8 @@ EXPORTED_SYMBOLS = (
     "flacenc_hip_qlpc_batch_async",
     "flacenc_hip_stereo_qlpc_batch",
     "flacenc_hip_stereo_qlpc_batch_async",
+    "flacenc_hip_encode_stereo_frames",
+    "flacenc_hip_encode_stereo_frames_async",
     "flacenc_hip_synchronize",
     "flacenc_hip_debug_set_stamps",
     "flacenc_sigen_fill_frames",
@@ -85,6 +87,42 @@ PARAMS_DTYPE = np.dtype(
     align=True,
 )
 assert PARAMS_DTYPE.itemsize == 352
+
+
+class FrameConfig(C.Structure):
+    """flacenc_hip_frame_config: the config::Encoder fields that steer encode_frame."""
+
+    _fields_ = [
+        ("qlpc", QlpcConfig),
+        ("use_constant", C.c_uint32),
+        ("use_fixed", C.c_uint32),
+        ("use_lpc", C.c_uint32),
+        ("use_leftside", C.c_uint32),
+        ("use_rightside", C.c_uint32),
+        ("use_midside", C.c_uint32),
+    ]
+
+
+def make_frame_config(qlpc: QlpcConfig | None = None, use_constant=True, use_fixed=False, use_lpc=True,
+                      use_leftside=True, use_rightside=True, use_midside=True) -> FrameConfig:
+    return FrameConfig(qlpc or make_config(), int(use_constant), int(use_fixed), int(use_lpc),
+                       int(use_leftside), int(use_rightside), int(use_midside))
+
+
+# flacenc_hip_stereo_frame_result (752 bytes)
+FRAME_RESULT_DTYPE = np.dtype(
+    [
+        ("channel_assignment", np.uint8),
+        ("kind", np.uint8, (2,)),
+        ("role", np.uint8, (2,)),
+        ("pad", np.uint8, (3,)),
+        ("dc_offset", np.int32, (2,)),
+        ("bits", np.uint64, (4,)),
+        ("lpc", PARAMS_DTYPE, (2,)),
+    ],
+    align=True,
+)
+assert FRAME_RESULT_DTYPE.itemsize == 752
 
 
 class FlacencHipError(RuntimeError):
@@ -135,6 +173,12 @@ def load() -> C.CDLL:
     L.flacenc_hip_stereo_qlpc_batch.restype = C.c_int
     L.flacenc_hip_stereo_qlpc_batch_async.argtypes = stereo_args + [vp]
     L.flacenc_hip_stereo_qlpc_batch_async.restype = C.c_int
+    frame_args = [vp, C.POINTER(FrameConfig), i32p, C.c_size_t, C.c_uint32, C.c_size_t, C.c_uint32,
+                  vp, i32p, C.c_size_t]
+    L.flacenc_hip_encode_stereo_frames.argtypes = frame_args + [C.c_int]
+    L.flacenc_hip_encode_stereo_frames.restype = C.c_int
+    L.flacenc_hip_encode_stereo_frames_async.argtypes = frame_args + [vp]
+    L.flacenc_hip_encode_stereo_frames_async.restype = C.c_int
     L.flacenc_sigen_fill_frames.argtypes = [vp, C.c_size_t, C.c_uint32, C.c_uint32, C.c_size_t,
                                             C.c_uint32, C.c_float, C.c_float, C.c_float,
                                             C.c_uint64, C.c_uint64, C.c_int]
@@ -269,6 +313,29 @@ class Handle:
         rc = self._lib.flacenc_hip_stereo_qlpc_batch_async(
             self._h, C.byref(cfg), frames_ptr, n_frames, block_size, stride, bits_per_sample,
             params_ptr, residual_ptr, residual_stride, stream or None)
+        self._check(rc)
+
+    def encode_stereo_frames(self, frames, bits_per_sample: int, cfg: FrameConfig):
+        """encode_frame with the decision on the GPU: `frames` int32 [n_frames, 2, block_size] ->
+        (results FRAME_RESULT_DTYPE [n_frames], residual [n_frames, 2, block_size])."""
+        x = np.ascontiguousarray(frames, np.int32)
+        nf, ch, n = x.shape
+        assert ch == 2
+        results = np.zeros(nf, FRAME_RESULT_DTYPE)
+        residual = np.zeros((nf, 2, n), np.int32)
+        rc = self._lib.flacenc_hip_encode_stereo_frames(
+            self._h, C.byref(cfg), x.ctypes.data, nf, n, n, bits_per_sample, results.ctypes.data,
+            residual.ctypes.data, n, MEM_HOST)
+        self._check(rc)
+        return results, residual
+
+    def encode_stereo_frames_device(self, cfg: FrameConfig, frames_ptr: int, n_frames: int,
+                                    block_size: int, stride: int, bits_per_sample: int,
+                                    results_ptr: int, residual_ptr: int, residual_stride: int,
+                                    stream: int | None = None):
+        rc = self._lib.flacenc_hip_encode_stereo_frames_async(
+            self._h, C.byref(cfg), frames_ptr, n_frames, block_size, stride, bits_per_sample,
+            results_ptr, residual_ptr, residual_stride, stream or None)
         self._check(rc)
 
     # -- device-memory path (raw pointers; torch tensors' data_ptr()) ---------

@@ -207,6 +207,8 @@ int enqueue(flacenc_hip_handle* h, const flacenc_hip_qlpc_config* cfg, const int
   a.lpc_coefs = lpc_coefs;
   a.table_scratch = nullptr;
   a.stamps = h->stamps;
+  a.frame_results = nullptr;
+  a.use_constant = a.use_lpc = a.use_leftside = a.use_rightside = a.use_midside = 1;
   if (plan.table_scratch_bytes_per_subframe) {
     rc = ensure(h, h->d_tables, plan.table_scratch_bytes_per_subframe * n_subframes);
     if (rc != FLACENC_HIP_OK) return rc;
@@ -427,6 +429,103 @@ int flacenc_hip_stereo_qlpc_batch(flacenc_hip_handle* h, const flacenc_hip_qlpc_
   HIP_TRY(h, hipMemcpy2DAsync(residual, residual_stride * 4, h->d_residual.ptr, dstride * 4,
                               static_cast<size_t>(block_size) * 4, n_sub, hipMemcpyDeviceToHost, s));
   HIP_TRY(h, hipMemcpyAsync(params, h->d_params.ptr, n_sub * sizeof(flacenc_hip_subframe_params),
+                            hipMemcpyDeviceToHost, s));
+  HIP_TRY(h, hipStreamSynchronize(s));
+  return FLACENC_HIP_OK;
+}
+
+int flacenc_hip_encode_stereo_frames_async(flacenc_hip_handle* h, const flacenc_hip_frame_config* cfg,
+                                           const int32_t* frames, size_t n_frames, uint32_t block_size,
+                                           size_t stride, uint32_t bits_per_sample,
+                                           flacenc_hip_stereo_frame_result* results, int32_t* residual,
+                                           size_t residual_stride, void* stream) {
+  if (!h || !cfg || (!results && n_frames)) return FLACENC_HIP_ERR_BAD_ARGUMENT;
+  int rc = check_batch_args(h, &cfg->qlpc, frames, n_frames * 4, block_size, stride,
+                            reinterpret_cast<flacenc_hip_subframe_params*>(results), residual, residual_stride);
+  if (rc != FLACENC_HIP_OK || n_frames == 0) return rc;
+  if (bits_per_sample < 8 || bits_per_sample > 24) {
+    h->last_error = "bits_per_sample must be in 8..=24";
+    return FLACENC_HIP_ERR_BAD_ARGUMENT;
+  }
+  if (cfg->use_fixed) {
+    h->last_error = "use_fixed: the fixed-LPC candidate is not available on the GPU path yet";
+    return FLACENC_HIP_ERR_UNSUPPORTED;
+  }
+  HIP_TRY(h, hipSetDevice(h->device));
+  const WindowEntry* win = nullptr;
+  rc = get_window(h, &cfg->qlpc, block_size, &win);
+  if (rc != FLACENC_HIP_OK) return rc;
+  flacenc_hip::QlpcKernelArgs a;
+  a.samples = frames;
+  a.stride = stride;
+  a.block_size = block_size;
+  a.n_subframes = static_cast<uint32_t>(n_frames * 4);
+  a.bps = nullptr;
+  a.bps_uniform = bits_per_sample;
+  a.stereo = 1;
+  a.window = win->dev;
+  a.flat_lo = win->flat_lo;
+  a.flat_hi = win->flat_hi;
+  a.lpc_order = cfg->qlpc.lpc_order;
+  a.precision = cfg->qlpc.quant_precision;
+  a.max_rice_parameter = cfg->qlpc.max_rice_parameter;
+  a.params = nullptr;
+  a.residual = residual;
+  a.residual_stride = residual_stride;
+  a.autocorr = nullptr;
+  a.lpc_coefs = nullptr;
+  a.table_scratch = nullptr;
+  a.stamps = h->stamps;
+  a.frame_results = results;
+  a.use_constant = cfg->use_constant;
+  a.use_lpc = cfg->use_lpc;
+  a.use_leftside = cfg->use_leftside;
+  a.use_rightside = cfg->use_rightside;
+  a.use_midside = cfg->use_midside;
+  if (!flacenc_hip::wave_kernel_eligible(a)) {
+    h->last_error = "encode_stereo_frames: needs block_size 4096, lpc_order <= 12 and 16-byte aligned rows";
+    return FLACENC_HIP_ERR_UNSUPPORTED;
+  }
+  flacenc_hip::QlpcLaunchPlan plan = flacenc_hip::plan_qlpc_launch(block_size, cfg->qlpc.lpc_order);
+  HIP_TRY(h, flacenc_hip::launch_qlpc(a, plan, static_cast<hipStream_t>(stream)));
+  return FLACENC_HIP_OK;
+}
+
+int flacenc_hip_encode_stereo_frames(flacenc_hip_handle* h, const flacenc_hip_frame_config* cfg,
+                                     const int32_t* frames, size_t n_frames, uint32_t block_size,
+                                     size_t stride, uint32_t bits_per_sample,
+                                     flacenc_hip_stereo_frame_result* results, int32_t* residual,
+                                     size_t residual_stride, int memory_kind) {
+  if (!h) return FLACENC_HIP_ERR_BAD_ARGUMENT;
+  if (memory_kind == FLACENC_HIP_MEM_DEVICE) {
+    int rc = flacenc_hip_encode_stereo_frames_async(h, cfg, frames, n_frames, block_size, stride,
+                                                    bits_per_sample, results, residual, residual_stride,
+                                                    h->stream);
+    if (rc != FLACENC_HIP_OK || n_frames == 0) return rc;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return FLACENC_HIP_OK;
+  }
+  if (memory_kind != FLACENC_HIP_MEM_HOST || !cfg) return FLACENC_HIP_ERR_BAD_ARGUMENT;
+  if (n_frames == 0) return flacenc_hip_verify_config(&cfg->qlpc);
+  if (!frames || !results || !residual) return FLACENC_HIP_ERR_BAD_ARGUMENT;
+  HIP_TRY(h, hipSetDevice(h->device));
+  const size_t dstride = (static_cast<size_t>(block_size) + 3) & ~static_cast<size_t>(3);
+  int rc;
+  if ((rc = ensure(h, h->d_samples, n_frames * 2 * dstride * 4)) != FLACENC_HIP_OK) return rc;
+  if ((rc = ensure(h, h->d_residual, n_frames * 2 * dstride * 4)) != FLACENC_HIP_OK) return rc;
+  if ((rc = ensure(h, h->d_params, n_frames * sizeof(flacenc_hip_stereo_frame_result))) != FLACENC_HIP_OK)
+    return rc;
+  hipStream_t s = h->stream;
+  HIP_TRY(h, hipMemcpy2DAsync(h->d_samples.ptr, dstride * 4, frames, stride * 4,
+                              static_cast<size_t>(block_size) * 4, n_frames * 2, hipMemcpyHostToDevice, s));
+  rc = flacenc_hip_encode_stereo_frames_async(h, cfg, static_cast<const int32_t*>(h->d_samples.ptr), n_frames,
+                                              block_size, dstride, bits_per_sample,
+                                              static_cast<flacenc_hip_stereo_frame_result*>(h->d_params.ptr),
+                                              static_cast<int32_t*>(h->d_residual.ptr), dstride, s);
+  if (rc != FLACENC_HIP_OK) return rc;
+  HIP_TRY(h, hipMemcpy2DAsync(residual, residual_stride * 4, h->d_residual.ptr, dstride * 4,
+                              static_cast<size_t>(block_size) * 4, n_frames * 2, hipMemcpyDeviceToHost, s));
+  HIP_TRY(h, hipMemcpyAsync(results, h->d_params.ptr, n_frames * sizeof(flacenc_hip_stereo_frame_result),
                             hipMemcpyDeviceToHost, s));
   HIP_TRY(h, hipStreamSynchronize(s));
   return FLACENC_HIP_OK;

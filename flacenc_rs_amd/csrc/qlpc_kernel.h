@@ -35,6 +35,9 @@ struct QlpcKernelArgs {
   double* lpc_coefs;                    // device, nullable, [n][32]
   uint32_t* table_scratch;              // device, only for blocks > 16384 samples
   unsigned long long* stamps;           // device, nullable: [n][8] phase timestamps (profiling)
+  // on-device encode_frame decision (stereo, wave kernel only)
+  flacenc_hip_stereo_frame_result* frame_results;  // device, [n_frames]; non-null selects DECIDE
+  uint32_t use_constant, use_lpc, use_leftside, use_rightside, use_midside;
 };
 
 struct QlpcLaunchPlan {
@@ -58,7 +61,8 @@ hipError_t launch_qlpc(const QlpcKernelArgs& args, const QlpcLaunchPlan& plan, h
   hipError_t launch_qlpc_##MP##_##BG(const QlpcKernelArgs&, int threads, size_t smem, hipStream_t);
 FLACENC_HIP_FOR_EACH_INSTANCE(FLACENC_HIP_DECLARE_INSTANCE)
 
-#define FLACENC_HIP_FOR_EACH_WAVE_INSTANCE(X) X(8, 0) X(8, 1) X(10, 0) X(10, 1) X(12, 0) X(12, 1)
+#define FLACENC_HIP_FOR_EACH_WAVE_INSTANCE(X) \
+  X(8, 0) X(8, 1) X(8, 2) X(10, 0) X(10, 1) X(10, 2) X(12, 0) X(12, 1) X(12, 2)
 #define FLACENC_HIP_DECLARE_WAVE_INSTANCE(MP, ST) \
   hipError_t launch_qlpc_wave_##MP##_##ST(const QlpcKernelArgs&, hipStream_t);
 FLACENC_HIP_FOR_EACH_WAVE_INSTANCE(FLACENC_HIP_DECLARE_WAVE_INSTANCE)

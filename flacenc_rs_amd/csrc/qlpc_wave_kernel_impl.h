@@ -121,7 +121,10 @@ __device__ __forceinline__ uint32_t wave_min_dpp(uint32_t v) {
   }
 
 // 16 words -> bit-planes {1, 2, 4, 8, 16} of the per-bit population counts (Harley-Seal)
-__device__ __forceinline__ void popcount_planes16(const uint32_t* u, uint32_t (&pl)[5]) {
+__device__ __forceinline__ void popcount_planes16(const int32_t* e, uint32_t (&pl)[5]) {
+  uint32_t u[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) u[k] = zigzag(e[k]);  // rice::encode_signbit
   uint32_t ones = 0, twos = 0, fours = 0, eights = 0, sixteens;
   uint32_t twosA, twosB, foursA, foursB, eightsA, eightsB;
   FLACENC_CSA(twosA, ones, ones, u[0], u[1])
@@ -181,7 +184,7 @@ struct RiceResult {
 // saturation value once: they can then never beat (or tie ahead of) a legal parameter.
 // EXACT = false: literal chunk-clamped sums of rice.rs:75-98 for residuals >= 2^26.
 template <int NP, bool EXACT>
-__device__ __forceinline__ RiceResult rice_search(const uint32_t (&pl)[7], const uint32_t* u, uint32_t len0,
+__device__ __forceinline__ RiceResult rice_search(const uint32_t (&pl)[7], const int32_t* e, uint32_t len0,
                                                   uint32_t p_lo, uint32_t max_p, bool small_bits, int lane,
                                                   int warm) {
   constexpr uint32_t kWMax = kMaxPToBits - 4u;
@@ -211,7 +214,7 @@ __device__ __forceinline__ RiceResult rice_search(const uint32_t (&pl)[7], const
 #pragma unroll
       for (int k = 0; k < 64; ++k) {
         if (k >= off) {
-          accb += u[k] >> (pp & 31u);
+          accb += zigzag(e[k]) >> (pp & 31u);
           if (((k - off) & 15) == 15) accb = accb < kMaxPToBits ? accb : kMaxPToBits;
         }
       }
@@ -273,8 +276,12 @@ __device__ __forceinline__ RiceResult rice_search(const uint32_t (&pl)[7], const
   return r;
 }
 
-template <int MAXP, bool STEREO>
+// DECIDE (stereo only): run encode_subframe's candidate choice and try_stereo_coding's channel
+// assignment (coding.rs:384-418 without the fixed-LPC candidate, :493-522) on the device and
+// write one flacenc_hip_stereo_frame_result + the TWO chosen residual rows per frame.
+template <int MAXP, bool STEREO, bool DECIDE>
 __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(QlpcKernelArgs a) {
+  static_assert(!DECIDE || STEREO, "the decision needs the four roles of a stereo frame");
   constexpr int HP = (MAXP + 3) & ~3;
   constexpr int NLAG = MAXP + 1;
   constexpr int NBUF = STEREO ? 2 : 4;
@@ -383,7 +390,7 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
   const int tl = lane << 6;  // first sample of this lane
   double R[NLAG];
   uint32_t my_maxabs = 0;
-  int vmax = 0, vmin = 0;
+  int vmax = INT32_MIN, vmin = INT32_MAX;
   with_role([&](auto kind) {
     auto ld4 = [&](int t) { return ld4k(kind, t); };
     // The lane walks its 64 samples as 4 chunks x 2 steps of 8 with a sliding f64 window of
@@ -476,8 +483,11 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
 #pragma unroll
     for (int k = 0; k < NLAG; ++k) R[k] = wave_butterfly_sum(p2[k]);
   });
+  // is_constant (arrayutils.rs:382): all samples of the role equal <=> max == min
+  const int role_max = (int)(wave_max_dpp((uint32_t)vmax ^ 0x80000000u) ^ 0x80000000u);
+  const int role_min = (int)(wave_min_dpp((uint32_t)vmin ^ 0x80000000u) ^ 0x80000000u);
   // max |s| (find_max_abs, arrayutils.rs:509) from the running max / min
-  my_maxabs = wave_max_dpp((uint32_t)max(vmax, -vmin) | (vmin == INT32_MIN ? 0x80000000u : 0u));
+  my_maxabs = (uint32_t)max(role_max, -role_min) | (role_min == INT32_MIN ? 0x80000000u : 0u);
   if (a.autocorr && lane < 33) {
     double rv = 0.0;
 #pragma unroll
@@ -612,8 +622,20 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
   if (a.stamps && lane == 0) a.stamps[(size_t)sf * 8 + 4] = (unsigned long long)clock64();
 
   // ======================= residual store: registers -> LDS -> HBM ==========
-  // (before the Rice search so the stores drain underneath it)
-  {
+  // (before the Rice search so the stores drain underneath it; with DECIDE only the two chosen
+  // roles are stored, after the decision)
+  auto put_own_e = [&](int32_t* buf) {
+#pragma unroll
+    for (int k = 0; k < 64; k += 4) {
+      int4 v;
+      v.x = e[k + 0];
+      v.y = e[k + 1];
+      v.z = e[k + 2];
+      v.w = e[k + 3];
+      *reinterpret_cast<int4*>(&buf[widx(tl + k)]) = v;
+    }
+  };
+  if (!DECIDE) {
     auto put_own = [&](int32_t* buf) {
 #pragma unroll
       for (int k = 0; k < 64; k += 4) {
@@ -662,14 +684,26 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
 
   // ======================= phase 4: partitioned-Rice search ================
   // n = 4096: finest order 6, 64 partitions of 64 samples = one per lane (rice.rs:157-165).
-  uint32_t* u = reinterpret_cast<uint32_t*>(e);
-  uint32_t maxu = 0;
+  // bit-sliced population counts of the lane's 64 zig-zag coded residuals -> 7 planes
+  // (exact for any magnitude); e[] itself stays intact for the store
+  uint32_t pl[7];
+  {
+    uint32_t pb[5];
+    popcount_planes16(e, pb);
 #pragma unroll
-  for (int k = 0; k < 64; ++k) {
-    u[k] = zigzag(e[k]);
-    maxu |= u[k];
+    for (int k = 0; k < 5; ++k) pl[k] = pb[k];
+    popcount_planes16(e + 16, pb);
+    planes_add<5>(pl, pb);
+    uint32_t pc[6], pd[5];
+    popcount_planes16(e + 32, pd);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) pc[k] = pd[k];
+    popcount_planes16(e + 48, pd);
+    planes_add<5>(pc, pd);
+    planes_add<6>(pl, pc);
   }
-  maxu = wave_or_dpp(maxu);
+  // a bit is set in some residual <=> its count is non-zero <=> it is set in some plane
+  const uint32_t maxu = wave_or_dpp(pl[0] | pl[1] | pl[2] | pl[3] | pl[4] | pl[5] | pl[6]);
   // Parameters beyond the residual's bit length can never win (see the generic kernel).
   const uint32_t bitlen = maxu ? (uint32_t)(32 - __builtin_clz(maxu)) : 0u;
   const uint32_t max_p = a.max_rice_parameter < bitlen ? a.max_rice_parameter : bitlen;
@@ -681,22 +715,6 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
   RiceResult rr;
   unsigned long long sat_sum_q = 0;  // exact sum of quotients, only evaluated if a minimum saturated
   if (maxu < (1u << 26)) {
-    // bit-sliced population counts of the lane's 64 words -> 7 planes; the words die here
-    uint32_t pl[7], pb[5];
-    popcount_planes16(u, pb);
-#pragma unroll
-    for (int k = 0; k < 5; ++k) pl[k] = pb[k];
-    popcount_planes16(u + 16, pb);
-    planes_add<5>(pl, pb);
-    {
-      uint32_t pc[6], pd[5];
-      popcount_planes16(u + 32, pd);
-#pragma unroll
-      for (int k = 0; k < 5; ++k) pc[k] = pd[k];
-      popcount_planes16(u + 48, pd);
-      planes_add<5>(pc, pd);
-      planes_add<6>(pl, pc);
-    }
     // rice_window: a lower end for the parameter search.  For a partition (or merged group)
     // with sum S over len samples and mean m = S / len let p0 = floor(log2(m + 1)).  From
     // S/2^p - len < sum_i (u_i >> p) <= S/2^p:  table[p0] - 4 < len (p0 + 3)  and, for
@@ -731,14 +749,13 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
                   (unsigned long long)wave_sum_dpp((uint32_t)(mine & 0xFFFFu));
     }
   } else {
-    uint32_t pl[7] = {0, 0, 0, 0, 0, 0, 0};
-    rr = rice_search<32, false>(pl, u, len0, 0u, max_p, small_bits, lane, warm);
+    rr = rice_search<32, false>(pl, e, len0, 0u, max_p, small_bits, lane, warm);
     if (rr.saturated) {
       const uint32_t gp = (uint32_t)__shfl((int)rr.my_p, lane & ~((1 << rr.bestk) - 1), 64);
       uint32_t lo = 0, hi = 0;
 #pragma unroll
       for (int k = 0; k < 64; ++k) {
-        uint32_t qv = u[k] >> gp;  // warm-up slots hold 0
+        uint32_t qv = zigzag(e[k]) >> gp;  // warm-up slots hold 0
         lo += qv & 0xFFFFu;
         hi += qv >> 16;
       }
@@ -763,39 +780,132 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
       rr.saturated ? sat_sum_q
                    : best_bits - 4ull * (unsigned long long)best_parts - (unsigned long long)(n - warm) - rem_bits;
 
-  flacenc_hip_subframe_params* rec = a.params + sf;
-  {
-    // partition j of the chosen order lives on lane j << bestk
-    const int srcl = (lane << bestk) & 63;
-    const uint32_t pv = (uint32_t)__shfl((int)my_p, srcl, 64);
-    uint32_t w0 = (lane < best_parts && status == 0) ? pv : 0u;
-    rec->rice_params[lane] = (uint8_t)w0;
-    rec->rice_params[lane + 64] = 0;
-    rec->rice_params[lane + 128] = 0;
-    rec->rice_params[lane + 192] = 0;
-  }
-  if (lane < 32) {
-    int32_t c = 0;
+  // BitRepr for Residual / Lpc::count_bits, bitrepr.rs:533-544, 492-499 (all wave-uniform)
+  const unsigned long long residual_bits = 2ull + 4ull + (unsigned long long)best_parts * (rice2 ? 5ull : 4ull) +
+                                           (sum_q + (unsigned long long)(n - warm)) + rem_bits;
+  const unsigned long long bps_role = a.bps ? (unsigned long long)a.bps[sf]
+                                            : (unsigned long long)(a.bps_uniform + ((STEREO && role == 3) ? 1u : 0u));
+  const unsigned long long sub_bits = 8ull + bps_role * (unsigned long long)warm + 4ull + 5ull +
+                                      (unsigned long long)a.precision * (unsigned long long)warm + residual_bits;
+
+  flacenc_hip_subframe_params* rec = a.params ? a.params + sf : nullptr;
+  if (DECIDE) {
+    // ---- encode_subframe for this role (coding.rs:384-418, use_fixed = false) ----
+    const bool is_const = a.use_constant && (role_max == role_min);
+    const unsigned long long verbatim_bits = 8ull + (unsigned long long)n * bps_role;  // datatype.rs:1944
+    uint32_t kind;
+    unsigned long long bits;
+    if (is_const) {
+      kind = 0u;  // Constant
+      bits = 8ull + bps_role;  // bitrepr.rs:445
+    } else if (a.use_lpc && status == 0 && sub_bits < verbatim_bits) {
+      kind = 3u;  // Lpc
+      bits = sub_bits;
+    } else {
+      kind = 1u;  // Verbatim
+      bits = verbatim_bits;
+    }
+    // ---- try_stereo_coding (coding.rs:493-522): exchange the four candidates' sizes ----
+    // (reuses the R[] exchange area, which nobody reads after the Levinson barriers)
+    unsigned long long* const xb = reinterpret_cast<unsigned long long*>(sm + (NBUF + 1) * kBufDwords);
+    if (lane == 0) {
+      xb[wave] = bits;
+      xb[4 + wave] = ((unsigned long long)kind << 32) | (unsigned long long)(uint32_t)role_max;
+    }
+    __syncthreads();  // also: every wave is done reading the channel images
+    const unsigned long long bl = xb[0], br = xb[1], bm = xb[2], bs = xb[3];
+    unsigned long long min_bits = bl + br;
+    int assignment = 0;  // Independent(2)
+    if (a.use_leftside && bl + bs < min_bits) {
+      min_bits = bl + bs;
+      assignment = 1;
+    }
+    if (a.use_rightside && br + bs < min_bits) {
+      min_bits = br + bs;
+      assignment = 2;
+    }
+    if (a.use_midside && bm + bs < min_bits) {
+      min_bits = bm + bs;
+      assignment = 3;
+    }
+    assignment = uni(assignment);
+    // ChannelAssignment::select_channels (datatype.rs:1173-1185): which role fills output channel 0 / 1
+    const int role0 = assignment == 2 ? 3 : (assignment == 3 ? 2 : 0);
+    const int role1 = (assignment == 0 || assignment == 2) ? 1 : 3;
+    const int slot = (role == role0) ? 0 : ((role == role1) ? 1 : -1);
+    flacenc_hip_stereo_frame_result* fr = a.frame_results + blk;
+    if (wave == 0 && lane == 0) {
+      fr->channel_assignment = (uint8_t)assignment;
+      fr->role[0] = (uint8_t)role0;
+      fr->role[1] = (uint8_t)role1;
+      fr->pad[0] = fr->pad[1] = fr->pad[2] = 0;
+      const unsigned long long k0 = xb[4 + role0], k1 = xb[4 + role1];
+      fr->kind[0] = (uint8_t)(k0 >> 32);
+      fr->kind[1] = (uint8_t)(k1 >> 32);
+      fr->dc_offset[0] = (k0 >> 32) == 0 ? (int32_t)(uint32_t)k0 : 0;
+      fr->dc_offset[1] = (k1 >> 32) == 0 ? (int32_t)(uint32_t)k1 : 0;
+      fr->bits[0] = bl;
+      fr->bits[1] = br;
+      fr->bits[2] = bm;
+      fr->bits[3] = bs;
+    }
+    // the two chosen roles hand their residual (zeros unless the LPC candidate was kept) to the
+    // channel images, then the whole workgroup streams both rows out
+    if (slot >= 0) {
+      if (kind != 3u) {
 #pragma unroll
-    for (int i = 0; i < MAXP; ++i)
-      if (i == lane) c = cq[i];
-    rec->coefs[lane] = (status == 0) ? (int16_t)c : (int16_t)0;
+        for (int k = 0; k < 64; ++k) e[k] = 0;
+      }
+      put_own_e(sm + slot * kBufDwords);
+    }
+    __syncthreads();
+    {
+      int32_t* __restrict__ dst0 = a.residual + (size_t)(blk * 2u) * a.residual_stride;
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int q = tid + it * 256;
+        const int ch = q >> 10;
+        const int t = (q & 1023) << 2;
+        const int4 v = *reinterpret_cast<const int4*>(&sm[ch * kBufDwords + widx(t)]);
+        *reinterpret_cast<int4*>(dst0 + (size_t)ch * a.residual_stride + t) = v;
+      }
+    }
+    rec = (slot >= 0) ? &fr->lpc[slot] : nullptr;
+    if (rec != nullptr && kind != 3u) {
+      // not an LPC subframe: blank record
+      for (int i = lane; i < (int)(sizeof(flacenc_hip_subframe_params) / 4); i += 64)
+        reinterpret_cast<uint32_t*>(rec)[i] = 0u;
+      rec = nullptr;
+    }
   }
-  if (lane == 0) {
-    const unsigned long long residual_bits = 2ull + 4ull + (unsigned long long)best_parts * (rice2 ? 5ull : 4ull) +
-                                             (sum_q + (unsigned long long)(n - warm)) + rem_bits;
-    const unsigned long long bps = a.bps ? (unsigned long long)a.bps[sf]
-                                         : (unsigned long long)(a.bps_uniform + ((STEREO && role == 3) ? 1u : 0u));
-    const unsigned long long sub_bits = 8ull + bps * (unsigned long long)warm + 4ull + 5ull +
-                                        (unsigned long long)a.precision * (unsigned long long)warm + residual_bits;
-    rec->order = (uint8_t)warm;
-    rec->shift = (int8_t)shift;
-    rec->precision = (uint8_t)a.precision;
-    rec->rice_order = (uint8_t)(status == 0 ? rice_order : 0);
-    rec->status = status;
-    rec->code_bits = status == 0 ? best_bits : 0ull;
-    rec->subframe_bits = status == 0 ? sub_bits : 0ull;
-    rec->sum_quotients = status == 0 ? sum_q : 0ull;
+  if (rec != nullptr) {
+    {
+      // partition j of the chosen order lives on lane j << bestk
+      const int srcl = (lane << bestk) & 63;
+      const uint32_t pv = (uint32_t)__shfl((int)my_p, srcl, 64);
+      uint32_t w0 = (lane < best_parts && status == 0) ? pv : 0u;
+      rec->rice_params[lane] = (uint8_t)w0;
+      rec->rice_params[lane + 64] = 0;
+      rec->rice_params[lane + 128] = 0;
+      rec->rice_params[lane + 192] = 0;
+    }
+    if (lane < 32) {
+      int32_t c = 0;
+#pragma unroll
+      for (int i = 0; i < MAXP; ++i)
+        if (i == lane) c = cq[i];
+      rec->coefs[lane] = (status == 0) ? (int16_t)c : (int16_t)0;
+    }
+    if (lane == 0) {
+      rec->order = (uint8_t)warm;
+      rec->shift = (int8_t)shift;
+      rec->precision = (uint8_t)a.precision;
+      rec->rice_order = (uint8_t)(status == 0 ? rice_order : 0);
+      rec->status = status;
+      rec->code_bits = status == 0 ? best_bits : 0ull;
+      rec->subframe_bits = status == 0 ? sub_bits : 0ull;
+      rec->sum_quotients = status == 0 ? sum_q : 0ull;
+    }
   }
   if (a.stamps && lane == 0) {
     a.stamps[(size_t)sf * 8 + 6] = (unsigned long long)clock64();
@@ -803,9 +913,9 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
   }
 }
 
-template <int MAXP, bool STEREO>
+template <int MAXP, bool STEREO, bool DECIDE>
 hipError_t launch_wave4096(const QlpcKernelArgs& a, hipStream_t stream) {
-  auto kern = qlpc_wave4096_kernel<MAXP, STEREO>;
+  auto kern = qlpc_wave4096_kernel<MAXP, STEREO, DECIDE>;
   constexpr size_t smem = ((size_t)(STEREO ? 2 : 4) + 1) * kBufDwords * 4 + 4 * (((MAXP + 2) & ~1) * 8 + 64);  // images + window + exchange
   static bool configured = false;
   if (!configured) {

@@ -176,6 +176,61 @@ int flacenc_hip_stereo_qlpc_batch_async(flacenc_hip_handle* h, const flacenc_hip
                                         flacenc_hip_subframe_params* params, int32_t* residual,
                                         size_t residual_stride, void* stream);
 
+/* ---- encode_frame for 2-channel frames, decision on the device ------------------------ */
+/*
+ * config::Encoder fields that steer `encode_frame` (src/coding.rs:530-544): SubFrameCoding's
+ * candidate switches (src/config.rs:167-183) and StereoCoding (src/config.rs:137-144).
+ * `use_fixed` must be 0: the fixed-LPC candidate is not on the GPU yet (ERR_UNSUPPORTED).
+ */
+typedef struct flacenc_hip_frame_config {
+  flacenc_hip_qlpc_config qlpc;
+  uint32_t use_constant;
+  uint32_t use_fixed;
+  uint32_t use_lpc;
+  uint32_t use_leftside;
+  uint32_t use_rightside;
+  uint32_t use_midside;
+} flacenc_hip_frame_config;
+
+#define FLACENC_HIP_KIND_CONSTANT 0 /* SubFrame::Constant */
+#define FLACENC_HIP_KIND_VERBATIM 1 /* SubFrame::Verbatim */
+#define FLACENC_HIP_KIND_LPC 3      /* SubFrame::Lpc */
+
+/* What `encode_frame` decides for one stereo frame: `try_stereo_coding`'s channel assignment
+ * (src/coding.rs:493-522; 0 Independent(2), 1 LeftSide, 2 RightSide, 3 MidSide), and for each of
+ * the two output channels (ChannelAssignment::select_channels, datatype.rs:1173-1185) which of
+ * L, R, M, S it is (`role` 0..3), which SubFrame variant `encode_subframe` picked (`kind`), the
+ * Constant's value, and the LPC record when kind == LPC.  `bits` are SubFrame::count_bits of the
+ * four candidates L, R, M, S after encode_subframe. */
+typedef struct flacenc_hip_stereo_frame_result {
+  uint8_t channel_assignment;
+  uint8_t kind[2];
+  uint8_t role[2];
+  uint8_t pad[3];
+  int32_t dc_offset[2];
+  uint64_t bits[4];
+  flacenc_hip_subframe_params lpc[2];
+} flacenc_hip_stereo_frame_result;
+
+/*
+ * `encode_frame` (src/coding.rs:530-544) for a batch of 2-channel frames with the whole decision
+ * on the GPU: L, R, M, S analysed, `encode_subframe` (coding.rs:384-418) applied to each,
+ * `try_stereo_coding` picks the assignment, and only the two chosen residual rows are written:
+ * residual + (2f + c)*residual_stride for output channel c of frame f (zeros unless kind == LPC).
+ * Currently available for block_size 4096, lpc_order <= 12 and 16-byte aligned rows
+ * (FLACENC_HIP_ERR_UNSUPPORTED otherwise: use flacenc_hip_stereo_qlpc_batch and decide on the host).
+ */
+int flacenc_hip_encode_stereo_frames(flacenc_hip_handle* h, const flacenc_hip_frame_config* cfg,
+                                     const int32_t* frames, size_t n_frames, uint32_t block_size,
+                                     size_t stride, uint32_t bits_per_sample,
+                                     flacenc_hip_stereo_frame_result* results, int32_t* residual,
+                                     size_t residual_stride, int memory_kind);
+int flacenc_hip_encode_stereo_frames_async(flacenc_hip_handle* h, const flacenc_hip_frame_config* cfg,
+                                           const int32_t* frames, size_t n_frames, uint32_t block_size,
+                                           size_t stride, uint32_t bits_per_sample,
+                                           flacenc_hip_stereo_frame_result* results, int32_t* residual,
+                                           size_t residual_stride, void* stream);
+
 int flacenc_hip_synchronize(flacenc_hip_handle* h);
 
 /* Profiling hook (no reference counterpart): when `device_stamps` is non-NULL every

@@ -817,3 +817,97 @@ double orc_bench_stereo_qlpc(const int32_t* frames, size_t n_frames, size_t n, s
   free(jobs);
   return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
 }
+
+/* ------------------------------------------------------------------------ */
+/* encode_subframe / try_stereo_coding restricted to the candidates the GPU  */
+/* path produces (use_fixed = false)                                         */
+/* ------------------------------------------------------------------------ */
+
+/* encode_subframe, src/coding.rs:384-418 with config.use_fixed == false:
+ * Constant if use_constant && is_constant; else the LPC candidate iff
+ * use_lpc && !too_short && count_bits < verbatim_bits; else Verbatim.
+ * kind: 0 Constant, 1 Verbatim, 3 Lpc.  `lpc` receives estimated_qlpc's result when
+ * it was evaluated (errors = its residual). */
+int orc_encode_subframe_nofixed(const int32_t* samples, size_t n, uint32_t bps, int use_constant,
+                                int use_lpc, const orc_qlpc_config* cfg, uint64_t* bits_out,
+                                orc_qlpc_result* lpc, uint8_t* rice_params, int32_t* errors) {
+  if (use_constant && orc_is_constant(samples, n)) {
+    *bits_out = 8 + bps; /* Constant::count_bits, bitrepr.rs:445 */
+    return 0;
+  }
+  uint64_t verbatim_bits = orc_verbatim_count_bits(n, bps);
+  int too_short = n < 64; /* MIN_BLOCK_SIZE_FOR_PREDICTION, constant.rs:51 */
+  if (!too_short && use_lpc) {
+    orc_estimated_qlpc(samples, n, bps, cfg, lpc, rice_params, errors, NULL, NULL);
+    if (lpc->status == ORC_STATUS_OK && lpc->subframe_bits < verbatim_bits) {
+      *bits_out = lpc->subframe_bits;
+      return 3;
+    }
+  }
+  *bits_out = verbatim_bits;
+  return 1;
+}
+
+/* encode_frame for 2 channels (src/coding.rs:530-544) = encode_frame_impl(Independent(2)) +
+ * try_stereo_coding (:469-527).  Outputs mirror flacenc_hip_stereo_frame_result. */
+void orc_encode_stereo_frame(const int32_t* l, const int32_t* r, size_t n, uint32_t bps,
+                             const orc_qlpc_config* cfg, int use_constant, int use_lpc,
+                             int use_leftside, int use_rightside, int use_midside,
+                             orc_stereo_frame_result* out, int32_t* residual0, int32_t* residual1) {
+  int32_t* m = (int32_t*)malloc(sizeof(int32_t) * n);
+  int32_t* s = (int32_t*)malloc(sizeof(int32_t) * n);
+  int32_t* err[4];
+  uint8_t* rp[4];
+  orc_qlpc_result res[4];
+  int kind[4];
+  uint64_t bits[4];
+  const int32_t* sig[4];
+  orc_stereo_to_midside(l, r, n, m, s);
+  sig[0] = l; sig[1] = r; sig[2] = m; sig[3] = s;
+  for (int k = 0; k < 4; ++k) {
+    err[k] = (int32_t*)calloc(n, sizeof(int32_t));
+    rp[k] = (uint8_t*)calloc(ORC_MAX_RICE_PARTITIONS, 1);
+    memset(&res[k], 0, sizeof(res[k]));
+    kind[k] = orc_encode_subframe_nofixed(sig[k], n, bps + (k == 3 ? 1 : 0), use_constant, use_lpc, cfg,
+                                          &bits[k], &res[k], rp[k], err[k]);
+  }
+  /* src/coding.rs:493-522 */
+  uint64_t min_bits = bits[0] + bits[1];
+  int assignment = 0; /* Independent(2) */
+  if (use_leftside && bits[0] + bits[3] < min_bits) { min_bits = bits[0] + bits[3]; assignment = 1; }
+  if (use_rightside && bits[1] + bits[3] < min_bits) { min_bits = bits[1] + bits[3]; assignment = 2; }
+  if (use_midside && bits[2] + bits[3] < min_bits) { min_bits = bits[2] + bits[3]; assignment = 3; }
+  /* ChannelAssignment::select_channels, datatype.rs:1173-1185 */
+  int role0 = assignment == 2 ? 3 : (assignment == 3 ? 2 : 0);
+  int role1 = assignment == 0 ? 1 : (assignment == 2 ? 1 : 3);
+  memset(out, 0, sizeof(*out));
+  out->channel_assignment = (uint8_t)assignment;
+  int roles[2] = {role0, role1};
+  int32_t* resid_out[2] = {residual0, residual1};
+  for (int c = 0; c < 2; ++c) {
+    int k = roles[c];
+    out->role[c] = (uint8_t)k;
+    out->kind[c] = (uint8_t)kind[k];
+    out->dc_offset[c] = kind[k] == 0 ? sig[k][0] : 0;
+    if (kind[k] == 3) {
+      orc_subframe_record* rec = &out->lpc[c];
+      for (int i = 0; i < 32; ++i) rec->coefs[i] = res[k].qp.coefs[i];
+      rec->order = (uint8_t)res[k].qp.order;
+      rec->shift = (int8_t)res[k].qp.shift;
+      rec->precision = (uint8_t)res[k].qp.precision;
+      rec->rice_order = (uint8_t)res[k].rice_order;
+      rec->status = res[k].status;
+      rec->code_bits = res[k].code_bits;
+      rec->subframe_bits = res[k].subframe_bits;
+      rec->sum_quotients = res[k].sum_quotients;
+      memcpy(rec->rice_params, rp[k], (size_t)1 << res[k].rice_order);
+      if (resid_out[c]) memcpy(resid_out[c], err[k], sizeof(int32_t) * n);
+    } else if (resid_out[c]) {
+      memset(resid_out[c], 0, sizeof(int32_t) * n);
+    }
+  }
+  for (int k = 0; k < 4; ++k) out->bits[k] = bits[k];
+  for (int k = 0; k < 4; ++k) { free(err[k]); free(rp[k]); }
+  free(m);
+  free(s);
+}

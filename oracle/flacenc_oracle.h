@@ -167,6 +167,25 @@ double orc_bench_qlpc(const int32_t* samples, size_t n_subframes, size_t n, size
                       uint32_t bits_per_sample, const orc_qlpc_config* cfg, int nthreads,
                       int repeats);
 
+/* mirrors flacenc_hip_stereo_frame_result (include/flacenc_hip.h) */
+typedef struct {
+  uint8_t channel_assignment; /* 0 Independent(2), 1 LeftSide, 2 RightSide, 3 MidSide */
+  uint8_t kind[2];            /* 0 Constant, 1 Verbatim, 3 Lpc */
+  uint8_t role[2];            /* 0 L, 1 R, 2 M, 3 S */
+  uint8_t pad[3];
+  int32_t dc_offset[2];
+  uint64_t bits[4];
+  orc_subframe_record lpc[2];
+} orc_stereo_frame_result;
+
+int orc_encode_subframe_nofixed(const int32_t* samples, size_t n, uint32_t bps, int use_constant,
+                                int use_lpc, const orc_qlpc_config* cfg, uint64_t* bits_out,
+                                orc_qlpc_result* lpc, uint8_t* rice_params, int32_t* errors);
+void orc_encode_stereo_frame(const int32_t* l, const int32_t* r, size_t n, uint32_t bps,
+                             const orc_qlpc_config* cfg, int use_constant, int use_lpc,
+                             int use_leftside, int use_rightside, int use_midside,
+                             orc_stereo_frame_result* out, int32_t* residual0, int32_t* residual1);
+
 double orc_bench_stereo_qlpc(const int32_t* frames, size_t n_frames, size_t n, size_t stride,
                              uint32_t bits_per_sample, const orc_qlpc_config* cfg, int nthreads,
                              int repeats, uint64_t* checksum_out);

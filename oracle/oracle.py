@@ -96,6 +96,20 @@ RECORD_DTYPE = np.dtype(
 )
 assert RECORD_DTYPE.itemsize == 352, RECORD_DTYPE.itemsize
 
+FRAME_RESULT_DTYPE = np.dtype(
+    [
+        ("channel_assignment", np.uint8),
+        ("kind", np.uint8, (2,)),
+        ("role", np.uint8, (2,)),
+        ("pad", np.uint8, (3,)),
+        ("dc_offset", np.int32, (2,)),
+        ("bits", np.uint64, (4,)),
+        ("lpc", RECORD_DTYPE, (2,)),
+    ],
+    align=True,
+)
+assert FRAME_RESULT_DTYPE.itemsize == 8 + 8 + 32 + 704, FRAME_RESULT_DTYPE.itemsize
+
 _lib = None
 
 
@@ -170,6 +184,9 @@ def _declare(L):
                                         C.POINTER(QlpcConfig), C.c_int, C.c_int,
                                         C.POINTER(C.c_uint64)]
     L.orc_bench_stereo_qlpc.restype = C.c_double
+    L.orc_encode_stereo_frame.argtypes = [i32p, i32p, C.c_size_t, C.c_uint32, C.POINTER(QlpcConfig),
+                                          C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                          i32p, i32p]
 
 
 def make_config(lpc_order=10, quant_precision=15, window=("tukey", 0.4), max_rice_parameter=30,
@@ -443,3 +460,22 @@ def bench_stereo_qlpc(frames, bits_per_sample: int, cfg: QlpcConfig, nthreads: i
     secs = float(lib().orc_bench_stereo_qlpc(_p(x, C.c_int32), nf, n, n, bits_per_sample,
                                              C.byref(cfg), nthreads, repeats, C.byref(chk)))
     return secs, int(chk.value)
+
+
+def encode_stereo_frames(frames, bps: int, cfg: QlpcConfig, use_constant=True, use_lpc=True,
+                         use_leftside=True, use_rightside=True, use_midside=True):
+    """encode_frame for 2-channel frames (src/coding.rs:530-544, 469-527) with use_fixed = false.
+
+    `frames` int32 [n_frames, 2, n] -> (results FRAME_RESULT_DTYPE [n_frames], residual [n_frames, 2, n])."""
+    x = np.ascontiguousarray(frames, np.int32)
+    nf, ch, n = x.shape
+    assert ch == 2
+    out = np.zeros(nf, FRAME_RESULT_DTYPE)
+    resid = np.zeros((nf, 2, n), np.int32)
+    for f in range(nf):
+        lib().orc_encode_stereo_frame(_p(x[f, 0], C.c_int32), _p(x[f, 1], C.c_int32), n, bps, C.byref(cfg),
+                                      int(use_constant), int(use_lpc), int(use_leftside),
+                                      int(use_rightside), int(use_midside),
+                                      out[f:f + 1].ctypes.data_as(C.c_void_p),
+                                      _p(resid[f, 0], C.c_int32), _p(resid[f, 1], C.c_int32))
+    return out, resid

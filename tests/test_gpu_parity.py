@@ -385,3 +385,101 @@ def test_rice_search_window_stress(handle, max_p):
     assert_records_equal(gp, cp, f"max_p={max_p}")
     assert np.array_equal(gres, cres)
     check_lossless(x, gp, gres)
+
+
+# ------------------------------------------------------------------ encode_frame on device ----
+def _stereo_corpus(n=4096, bps=16):
+    """Frames that exercise every channel assignment and every SubFrame kind."""
+    fr = []
+    base = _capi.sigen_frames(24, 2, n, bps, 200.0, 0.4, 0.05, seed=42)
+    for f in range(24):
+        l, r = base[f, 0].copy(), base[f, 1].copy()
+        k = f % 8
+        if k == 0:
+            r = l.copy()                       # identical channels -> side is digital silence (Constant)
+        elif k == 1:
+            r = (l * 7) // 8                   # strongly correlated -> left/side or mid/side
+        elif k == 2:
+            l = (r * 3) // 4 + 5               # right/side territory
+        elif k == 3:
+            l[:] = 1234                        # constant left
+        elif k == 4:
+            l = util.quantize(util.noise(900 + f, n, 0.999), bps)  # white noise -> Verbatim
+            r = util.quantize(util.noise(950 + f, n, 0.999), bps)
+        elif k == 5:
+            r = -l                             # anti-phase: mid ~ 0
+        elif k == 6:
+            l[:] = 0
+            r[:] = 0                           # digital silence everywhere
+        fr.append(np.stack([l, r]))
+    return np.stack(fr).astype(np.int32)
+
+
+@pytest.mark.parametrize("order,flags", [
+    (8, dict()), (10, dict()), (12, dict(use_midside=False)),
+    (8, dict(use_leftside=False, use_rightside=False)), (8, dict(use_constant=False)),
+    (8, dict(use_lpc=False)), (8, dict(use_leftside=False, use_rightside=False, use_midside=False)),
+])
+def test_encode_stereo_frames_decision_equals_reference_controller(handle, order, flags):
+    """flacenc_hip_encode_stereo_frames == encode_frame (coding.rs:530-544): encode_subframe's choice
+    per candidate (coding.rs:384-418, use_fixed = false) and try_stereo_coding's assignment
+    (coding.rs:493-522, strict '<' in the order LeftSide, RightSide, MidSide), restated by the oracle."""
+    bps = 16
+    x = _stereo_corpus()
+    cfg = _capi.make_frame_config(gpu_cfg(order), **flags)
+    got, gres = handle.encode_stereo_frames(x, bps, cfg)
+    want, wres = orc.encode_stereo_frames(x, bps, orc_cfg(order, acorr=orc.ACORR_CANONICAL), **flags)
+    for f in range(x.shape[0]):
+        g, w = got[f], want[f]
+        assert int(g["channel_assignment"]) == int(w["channel_assignment"]), f
+        assert g["role"].tolist() == w["role"].tolist(), f
+        assert g["kind"].tolist() == w["kind"].tolist(), f
+        assert g["dc_offset"].tolist() == w["dc_offset"].tolist(), f
+        assert g["bits"].tolist() == w["bits"].tolist(), f
+        for c in range(2):
+            if int(g["kind"][c]) == 3:
+                gl, wl = g["lpc"][c], w["lpc"][c]
+                for fld in ("order", "shift", "precision", "rice_order", "status", "code_bits",
+                            "subframe_bits", "sum_quotients"):
+                    assert int(gl[fld]) == int(wl[fld]), (f, c, fld)
+                assert gl["coefs"].tolist() == wl["coefs"].tolist()
+                assert gl["rice_params"].tolist() == wl["rice_params"].tolist()
+            assert np.array_equal(gres[f, c], wres[f, c]), (f, c)
+    kinds = set(got["kind"].ravel().tolist())
+    assigns = set(got["channel_assignment"].tolist())
+    if not flags:
+        assert kinds == {0, 1, 3} and len(assigns) >= 3, (kinds, assigns)
+    # losslessness of the chosen representation (decode.rs:61-113)
+    for f in range(x.shape[0]):
+        g = got[f]
+        ch = []
+        for c in range(2):
+            role = int(g["role"][c])
+            l, r = x[f, 0], x[f, 1]
+            sig = [l, r, *orc.stereo_to_midside(l, r)][role]
+            if int(g["kind"][c]) == 0:
+                ch.append(np.full(4096, int(g["dc_offset"][c]), np.int32))
+            elif int(g["kind"][c]) == 1:
+                ch.append(sig.copy())
+            else:
+                p = g["lpc"][c]
+                k = int(p["order"])
+                ch.append(orc.decode_lpc(sig[:k], p["coefs"][:k], int(p["shift"]), gres[f, c]))
+        a = int(g["channel_assignment"])
+        if a == 1:
+            ch[1] = ch[0] - ch[1]
+        elif a == 2:
+            ch[0] = ch[0] + ch[1]
+        elif a == 3:
+            ch[0], ch[1] = orc.midside_to_stereo(ch[0], ch[1])
+        assert np.array_equal(ch[0], x[f, 0]) and np.array_equal(ch[1], x[f, 1]), f
+
+
+def test_encode_stereo_frames_rejects_unsupported(handle):
+    x = np.zeros((2, 2, 4096), np.int32)
+    with pytest.raises(_capi.FlacencHipError) as ei:
+        handle.encode_stereo_frames(x, 16, _capi.make_frame_config(gpu_cfg(8), use_fixed=True))
+    assert ei.value.code == _capi.ERR_UNSUPPORTED
+    with pytest.raises(_capi.FlacencHipError) as ei:
+        handle.encode_stereo_frames(np.zeros((2, 2, 1152), np.int32), 16, _capi.make_frame_config(gpu_cfg(8)))
+    assert ei.value.code == _capi.ERR_UNSUPPORTED

@@ -23,18 +23,18 @@ n, F = args.block_size, args.frames
 dev = torch.device("cuda", 0)
 host = _capi.sigen_frames(F, 2, n, args.bps, 200.0, 0.4, 0.4, seed=0xF1AC0001)
 x = torch.from_numpy(host).to(dev)
-params = torch.empty((F * 4, 352), dtype=torch.uint8, device=dev)
-residual = torch.empty((F * 4, n), dtype=torch.int32, device=dev)
+results = torch.empty((F, 752), dtype=torch.uint8, device=dev)
+residual = torch.empty((F * 2, n), dtype=torch.int32, device=dev)
 stamps = torch.zeros((F * 4, 8), dtype=torch.int64, device=dev)
-cfg = _capi.make_config(lpc_order=args.lpc_order)
+cfg = _capi.make_frame_config(_capi.make_config(lpc_order=args.lpc_order))
 h = _capi.Handle(0)
 for it in range(3):
     h.debug_set_stamps(stamps.data_ptr() if it == 2 else 0)
-    h.stereo_qlpc_batch_device(cfg, x.data_ptr(), F, n, n, args.bps, params.data_ptr(), residual.data_ptr(), n, stream=0)
+    h.encode_stereo_frames_device(cfg, x.data_ptr(), F, n, n, args.bps, results.data_ptr(), residual.data_ptr(), n, stream=0)
     torch.cuda.synchronize()
 s = stamps.cpu().numpy().astype(np.float64)
 d = np.diff(s, axis=1)
-names = ["load", "acorr", "levinson+quant", "residual", "rice tables", "rice levels", "store+record"]
+names = ["load", "acorr", "levinson+quant", "residual", "(store, 4-candidate mode)", "rice+decide+store", "record"]
 tot = s[:, 7] - s[:, 0]
 print(f"workgroups {len(s)}; median total {np.median(tot):.0f} cycles; span {s.max() - s.min():.0f} cycles")
 for i, nm in enumerate(names):

@@ -30,7 +30,9 @@ namespace {
 // waves per SIMD the register allocator must leave room for: 3 workgroups per CU is what the
 // stereo LDS footprint (2 images + window) allows; plain mode (4 images) is LDS-bound earlier
 #ifndef FLACENC_WAVE_OCC
-#if defined(FLACENC_STEREO) && FLACENC_STEREO && defined(FLACENC_MAXP) && FLACENC_MAXP <= 10
+// (the deciding variant keeps 64 residuals live through the Rice search: at 3 waves/SIMD it
+// spills ~260 B/lane, which shows up as HBM traffic, for a 3 % gain -- so it stays at 2)
+#if defined(FLACENC_STEREO) && FLACENC_STEREO == 1 && defined(FLACENC_MAXP) && FLACENC_MAXP <= 10
 #define FLACENC_WAVE_OCC 3
 #else
 #define FLACENC_WAVE_OCC 2
@@ -688,20 +690,29 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
   // (exact for any magnitude); e[] itself stays intact for the store
   uint32_t pl[7];
   {
+    // (scheduling barriers keep the four 16-word groups apart: interleaved, their zig-zag
+    // temporaries alone cost ~50 VGPRs on top of the 64 live residuals)
     uint32_t pb[5];
     popcount_planes16(e, pb);
 #pragma unroll
     for (int k = 0; k < 5; ++k) pl[k] = pb[k];
+    __builtin_amdgcn_sched_barrier(0);
     popcount_planes16(e + 16, pb);
     planes_add<5>(pl, pb);
+    __builtin_amdgcn_sched_barrier(0);
     uint32_t pc[6], pd[5];
     popcount_planes16(e + 32, pd);
 #pragma unroll
     for (int k = 0; k < 5; ++k) pc[k] = pd[k];
+    __builtin_amdgcn_sched_barrier(0);
     popcount_planes16(e + 48, pd);
     planes_add<5>(pc, pd);
     planes_add<6>(pl, pc);
+    __builtin_amdgcn_sched_barrier(0);
   }
+#if defined(FLACENC_CUT) && FLACENC_CUT == 6
+  { int z = 0; for (int k = 0; k < 64; ++k) z ^= e[k]; for (int k = 0; k < 7; ++k) z ^= (int)pl[k]; a.residual[sf * 64 + lane] = z; return; }
+#endif
   // a bit is set in some residual <=> its count is non-zero <=> it is set in some plane
   const uint32_t maxu = wave_or_dpp(pl[0] | pl[1] | pl[2] | pl[3] | pl[4] | pl[5] | pl[6]);
   // Parameters beyond the residual's bit length can never win (see the generic kernel).
@@ -763,6 +774,9 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
       sat_sum_q = ((unsigned long long)wave_sum_dpp(hi) << 16) + (unsigned long long)wave_sum_dpp(lo);
     }
   }
+#if defined(FLACENC_CUT) && FLACENC_CUT == 7
+  { int z = rr.bestk + (int)rr.best_bits + (int)rr.my_p; for (int k = 0; k < 64; ++k) z ^= e[k]; a.residual[sf * 64 + lane] = z; return; }
+#endif
   const int bestk = rr.bestk;
   const unsigned long long best_bits = rr.best_bits;
   const uint32_t my_p = rr.my_p;

@@ -326,9 +326,22 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
   for (int i = tid; i < NBUF * kSeg; i += 256) sm[(i / kSeg) * kBufDwords + (i % kSeg)] = 0;
   // The window table (lpc.rs:96-120, computed on the host) is staged once per workgroup in the
   // same segment layout and shared by the four waves (3 workgroups x 53 KB fit one CU's LDS).
+  // Plain mode keeps four sample images (71 KB) and reads the taper weights from the
+  // L2-resident table instead, so that two workgroups still fit a CU.
+  constexpr bool WINDOW_IN_LDS = STEREO;
+  constexpr int NIMG = NBUF + (WINDOW_IN_LDS ? 1 : 0);
   float* const wlds = reinterpret_cast<float*>(sm + NBUF * kBufDwords);
   const bool has_window = a.window != nullptr;  // nullptr = all ones (rectangle / Tukey(0))
-  if (has_window) {
+  const float* __restrict__ wtab = a.window + 32;
+  const int flat_lo = a.flat_lo, flat_hi = a.flat_hi;
+  auto window4 = [&](int t) -> float4 {
+    if (!has_window) return make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+    if (WINDOW_IN_LDS) return *reinterpret_cast<const float4*>(&wlds[widx(t)]);
+    float4 wv = make_float4(1.0f, 1.0f, 1.0f, 1.0f);  // exactly 1.0f inside the flat part
+    if (!(t >= flat_lo && t + 4 <= flat_hi)) wv = *reinterpret_cast<const float4*>(wtab + t);
+    return wv;
+  };
+  if (has_window && WINDOW_IN_LDS) {
     const float* __restrict__ wsrc = a.window + 32;
     if (tid < kSeg) wlds[tid] = 0.0f;
 #pragma unroll
@@ -419,8 +432,7 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         rv[q] = ld4(t0 + 4 * q);
-        rw[q] = has_window ? *reinterpret_cast<const float4*>(&wlds[widx(t0 + 4 * q)])
-                           : make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+        rw[q] = window4(t0 + 4 * q);
       }
     };
     // x_w[t] = (f32)s[t] * w[t]: one f32 rounding, then widen (lpc.rs:751-754)
@@ -438,8 +450,7 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
     convert(HP);  // lands in dw[HP .. HP+8), slid to dw[HP-8 .. HP) by the first step
     if (HP > 8) {
       const int4 v = ld4(tl - 12);
-      const float4 wv = has_window ? *reinterpret_cast<const float4*>(&wlds[widx(tl - 12)])
-                                   : make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+      const float4 wv = window4(tl - 12);
       dw[HP - 4 + 0] = (double)((float)v.x * wv.x);
       dw[HP - 4 + 1] = (double)((float)v.y * wv.y);
       dw[HP - 4 + 2] = (double)((float)v.z * wv.z);
@@ -527,7 +538,7 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
     // exchange area: kept small -- LDS is allocated in 1280-byte granules and three workgroups
     // must fit one CU (3 x 42 granules = 157.5 KB)
     constexpr int XR = (NLAG + 1) & ~1;
-    double* const xr = reinterpret_cast<double*>(sm + (NBUF + 1) * kBufDwords);  // [4][XR]
+    double* const xr = reinterpret_cast<double*>(sm + NIMG * kBufDwords);  // [4][XR]
     int32_t* const xq = reinterpret_cast<int32_t*>(xr + 4 * XR);                   // [4][16]
     if (lane == 0) {
 #pragma unroll
@@ -834,7 +845,7 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
     }
     // ---- try_stereo_coding (coding.rs:493-522): exchange the four candidates' sizes ----
     // (reuses the R[] exchange area, which nobody reads after the Levinson barriers)
-    unsigned long long* const xb = reinterpret_cast<unsigned long long*>(sm + (NBUF + 1) * kBufDwords);
+    unsigned long long* const xb = reinterpret_cast<unsigned long long*>(sm + NIMG * kBufDwords);
     if (lane == 0) {
       xb[wave] = bits;
       xb[4 + wave] = ((unsigned long long)kind << 32) | (unsigned long long)(uint32_t)role_max;
@@ -943,7 +954,7 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
 template <int MAXP, bool STEREO, bool DECIDE>
 hipError_t launch_wave4096(const QlpcKernelArgs& a, hipStream_t stream) {
   auto kern = qlpc_wave4096_kernel<MAXP, STEREO, DECIDE>;
-  constexpr size_t smem = ((size_t)(STEREO ? 2 : 4) + 1) * kBufDwords * 4 + 4 * (((MAXP + 2) & ~1) * 8 + 64);  // images + window + exchange
+  constexpr size_t smem = (size_t)(STEREO ? 3 : 4) * kBufDwords * 4 + 4 * (((MAXP + 2) & ~1) * 8 + 64);  // images (+ window) + exchange
   static bool configured = false;
   if (!configured) {
     hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),

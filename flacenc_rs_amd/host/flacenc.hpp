@@ -510,6 +510,64 @@ component::Stream encode_with_fixed_block_size(const config::Encoder& config, So
     std::vector<flacenc_hip_subframe_params> recs(nf * per_frame);
     std::vector<int32_t> resid(nf * per_frame * n);
     const bool use_gpu = sc.use_lpc && n >= constant::MIN_BLOCK_SIZE_FOR_PREDICTION;
+    // 2a. stereo: try the entry point that also runs the controller on the GPU
+    //     (flacenc_hip_encode_stereo_frames: block 4096, order <= 12); its records are turned
+    //     into Frames directly.  Anything else falls through to the 4-candidate path below and the
+    //     host-side controller -- same result either way (tests/test_gpu_parity.py).
+    if (use_gpu && stereo) {
+      std::vector<int32_t> staged(nf * 2 * n);
+      for (size_t f = 0; f < nf; ++f)
+        for (size_t c = 0; c < 2; ++c)
+          std::memcpy(&staged[(f * 2 + c) * n], bufs[f0 + f].channel_slice(c), n * sizeof(int32_t));
+      flacenc_hip_frame_config fc{};
+      fc.qlpc = abi_cfg;
+      fc.use_constant = sc.use_constant;
+      fc.use_fixed = 0;
+      fc.use_lpc = sc.use_lpc;
+      fc.use_leftside = config.stereo_coding.use_leftside;
+      fc.use_rightside = config.stereo_coding.use_rightside;
+      fc.use_midside = config.stereo_coding.use_midside;
+      std::vector<flacenc_hip_stereo_frame_result> fr(nf);
+      std::vector<int32_t> resid2(nf * 2 * n);
+      const int rc = flacenc_hip_encode_stereo_frames(gpu.get(), &fc, staged.data(), nf, static_cast<uint32_t>(n), n,
+                                                      static_cast<uint32_t>(bps), fr.data(), resid2.data(), n,
+                                                      FLACENC_HIP_MEM_HOST);
+      if (rc == FLACENC_HIP_OK) {
+        for (size_t f = 0; f < nf; ++f) {
+          const source::FrameBuf& fb = bufs[f0 + f];
+          const int32_t* l = fb.channel_slice(0);
+          const int32_t* r = fb.channel_slice(1);
+          component::Frame frame;
+          frame.frame_number = static_cast<uint32_t>(f0 + f);
+          frame.block_size = n;
+          frame.channel_assignment = static_cast<component::ChannelAssignment>(fr[f].channel_assignment);
+          for (int c = 0; c < 2; ++c) {
+            const int role = fr[f].role[c];
+            std::vector<int32_t> sig(n);
+            for (size_t t = 0; t < n; ++t)
+              sig[t] = role == 0 ? l[t] : role == 1 ? r[t] : role == 2 ? ((l[t] + r[t]) >> 1) : (l[t] - r[t]);
+            const uint8_t b = static_cast<uint8_t>(bps + (role == 3 ? 1 : 0));
+            if (fr[f].kind[c] == FLACENC_HIP_KIND_CONSTANT) {
+              frame.subframes.push_back(component::Constant{n, fr[f].dc_offset[c], b});
+            } else if (fr[f].kind[c] == FLACENC_HIP_KIND_VERBATIM) {
+              frame.subframes.push_back(component::Verbatim{std::move(sig), b});
+            } else {
+              if (fr[f].lpc[c].status != FLACENC_HIP_SUBFRAME_OK)
+                throw std::runtime_error("LPC analysis reported a non-finite result (lpc.rs:786)");
+              frame.subframes.push_back(detail::make_lpc(fr[f].lpc[c], &resid2[(f * 2 + c) * n], sig.data(), n, b));
+            }
+          }
+          stream.add_frame(std::move(frame));
+        }
+        f0 = f1;
+        continue;
+      }
+      if (rc == FLACENC_HIP_ERR_BAD_CONFIG)
+        throw error::EncodeError(error::EncodeError::Config, flacenc_hip_last_error(gpu.get()));
+      if (rc != FLACENC_HIP_ERR_UNSUPPORTED)
+        throw error::EncodeError(error::EncodeError::Device, flacenc_hip_last_error(gpu.get()));
+    }
+    // 2b. the LPC candidates of every channel (stereo: L, R, M, S) in one batch
     if (use_gpu) {
       std::vector<int32_t> staged(nf * nch * n);
       for (size_t f = 0; f < nf; ++f)

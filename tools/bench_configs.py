@@ -1,0 +1,56 @@
+"""Throughput of the other BASELINE.json configs (parity-test shapes, not the bench line):
+device-resident subframes through flacenc_hip_qlpc_batch_async / stereo entry points."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch  # noqa: E402
+
+from flacenc_rs_amd import _capi  # noqa: E402
+
+dev = torch.device("cuda", 0)
+h = _capi.Handle(0)
+
+
+def run(name, frames, ch, n, bps, order, stereo):
+    host = _capi.sigen_frames(frames, ch, n, bps, 200.0, 0.4, 0.1, seed=7)
+    x = torch.from_numpy(host).to(dev)
+    nsub = frames * (4 if stereo else ch)
+    params = torch.empty((nsub, 352), dtype=torch.uint8, device=dev)
+    resid = torch.empty((nsub, n), dtype=torch.int32, device=dev)
+    bpsv = torch.full((nsub,), bps, dtype=torch.uint8, device=dev)
+    cfg = _capi.make_config(lpc_order=order)
+
+    def go():
+        if stereo:
+            h.stereo_qlpc_batch_device(cfg, x.data_ptr(), frames, n, n, bps, params.data_ptr(), resid.data_ptr(), n, stream=0)
+        else:
+            h.qlpc_batch_device(cfg, x.data_ptr(), frames * ch, n, n, bpsv.data_ptr(), params.data_ptr(),
+                                resid.data_ptr(), n, stream=0)
+
+    for _ in range(2):
+        go()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    reps = 5
+    for _ in range(reps):
+        go()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    inp = frames * ch * n
+    print(f"{name:52s} {ms:8.3f} ms  {inp / ms / 1e3:9.1f} Msamples/s input  ({nsub * n / ms / 1e3:9.1f} analysed)"
+          f"  {8 * inp / ms / 1e6 / 8000:6.3f} of 8 TB/s")
+
+
+run("config1: 4096 x 16b stereo, order 10 (4 candidates)", 8192, 2, 4096, 16, 10, True)
+run("config2: 4096 x 16b stereo, order 8 (4 candidates)", 8192, 2, 4096, 16, 8, True)
+run("config3: 8192 x 24b stereo, order 24 (generic kernel)", 2048, 2, 8192, 24, 24, True)
+run("config3: 8192 x 24b stereo, order 32 (generic kernel)", 2048, 2, 8192, 24, 32, True)
+run("config4: 4096 x 16b 8-channel, order 10 (plain)", 2048, 8, 4096, 16, 10, False)
+run("config5: 16384 x 24b stereo, order 24 (generic kernel)", 1024, 2, 16384, 24, 24, True)
+run("config5: 16384 x 24b stereo, order 32 (generic kernel)", 1024, 2, 16384, 24, 32, True)
+run("ragged: 4608 x 16b stereo, order 10 (generic kernel)", 4096, 2, 4608, 16, 10, True)

@@ -121,20 +121,26 @@ __device__ __forceinline__ uint32_t wave_min_dpp(uint32_t v) {
   return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
-// carry-save adder on bit-planes: (h, l) = a + b + c per bit position
-#define FLACENC_CSA(h, l, a_, b_, c_)             \
-  {                                               \
-    uint32_t t_ = (a_) ^ (b_);                    \
-    uint32_t h_ = (t_ & (c_)) | (~t_ & (a_));     \
-    l = t_ ^ (c_);                                \
-    h = h_;                                       \
+// carry-save adder on bit-planes: (h, l) = a + b + c per bit position, two v_bitop3_b32
+// (truth tables 0x96 = a ^ b ^ c, 0xE8 = majority)
+#define FLACENC_CSA(h, l, a_, b_, c_)                                          \
+  {                                                                            \
+    const uint32_t x_ = (a_), y_ = (b_), z_ = (c_);                            \
+    h = __builtin_amdgcn_bitop3_b32(x_, y_, z_, 0xE8);                         \
+    l = __builtin_amdgcn_bitop3_b32(x_, y_, z_, 0x96);                         \
   }
 
 // 16 words -> bit-planes {1, 2, 4, 8, 16} of the per-bit population counts (Harley-Seal)
+// The counted words are NOT the zig-zag codes u = 2 m + neg (rice::encode_signbit, rice.rs:169)
+// but w = m | neg << 31 with m = e ^ (e >> 31): one shift + one bitop per sample instead of
+// three ops, and u >> p == m >> (p - 1) for p >= 1, sum u == 2 sum m + #neg (see plane_sum).
 __device__ __forceinline__ void popcount_planes16(const int32_t* e, uint32_t (&pl)[5]) {
   uint32_t u[16];
 #pragma unroll
-  for (int k = 0; k < 16; ++k) u[k] = zigzag(e[k]);  // rice::encode_signbit
+  for (int k = 0; k < 16; ++k) {
+    const uint32_t x = (uint32_t)e[k], t = (uint32_t)(e[k] >> 31);
+    u[k] = (x & 0x80000000u) | ((x ^ t) & 0x7FFFFFFFu);
+  }
   uint32_t ones = 0, twos = 0, fours = 0, eights = 0, sixteens;
   uint32_t twosA, twosB, foursA, foursB, eightsA, eightsB;
   FLACENC_CSA(twosA, ones, ones, u[0], u[1])
@@ -162,13 +168,13 @@ __device__ __forceinline__ void popcount_planes16(const int32_t* e, uint32_t (&p
 // bit-sliced add: a (NA planes) += b (NA planes) -> NA + 1 planes
 template <int NA>
 __device__ __forceinline__ void planes_add(uint32_t* a, const uint32_t* b) {
-  uint32_t carry = 0;
+  uint32_t carry = a[0] & b[0];
+  a[0] ^= b[0];
 #pragma unroll
-  for (int k = 0; k < NA; ++k) {
-    uint32_t t_ = a[k] ^ b[k];
-    uint32_t s_ = t_ ^ carry;
-    carry = (t_ & carry) | (~t_ & a[k]);
-    a[k] = s_;
+  for (int k = 1; k < NA; ++k) {
+    const uint32_t x_ = a[k], y_ = b[k];
+    a[k] = __builtin_amdgcn_bitop3_b32(x_, y_, carry, 0x96);
+    carry = __builtin_amdgcn_bitop3_b32(x_, y_, carry, 0xE8);
   }
   a[NA] = carry;
 }
@@ -193,8 +199,42 @@ struct RiceResult {
 // the result is identical to searching 0..=max_p.  Entries above max_p are set to the
 // saturation value once: they can then never beat (or tie ahead of) a legal parameter.
 // EXACT = false: literal chunk-clamped sums of rice.rs:75-98 for residuals >= 2^26.
+// sum over the lane's 64 samples of (u_i >> p), u = zig-zag code, from the bit-planes of the
+// w words (magnitude planes q[k] = pl[k] & 0x7FFFFFFF, sign counts in bit 31):
+//   p >= 1: u >> p = m >> (p - 1);   p == 0: sum u = 2 sum m + #negative
+struct PlaneSums {
+  uint32_t q[7];     // magnitude planes
+  uint32_t sum_m;    // sum of m over the lane's samples
+  uint32_t negs;     // number of negative samples
+};
+__device__ __forceinline__ PlaneSums make_plane_sums(const uint32_t (&pl)[7]) {
+  PlaneSums ps;
+  ps.sum_m = 0;
+  ps.negs = 0;
+#pragma unroll
+  for (int k = 0; k < 7; ++k) {
+    ps.q[k] = pl[k] & 0x7FFFFFFFu;
+    ps.sum_m += ps.q[k] << k;
+    ps.negs += (pl[k] >> 31) << k;
+  }
+  return ps;
+}
+__device__ __forceinline__ uint32_t plane_sum_ge1(const PlaneSums& ps, uint32_t p) {  // p >= 1
+  uint32_t sum = 0;
+#pragma unroll
+  for (int k = 0; k < 7; ++k) sum += (ps.q[k] >> ((p - 1u) & 31u)) << k;
+  return sum;
+}
+__device__ __forceinline__ unsigned long long plane_sum_any64(const PlaneSums& ps, uint32_t p) {
+  if (p == 0) return 2ull * ps.sum_m + ps.negs;
+  unsigned long long sum = 0;
+#pragma unroll
+  for (int k = 0; k < 7; ++k) sum += (unsigned long long)(ps.q[k] >> ((p - 1u) & 31u)) << k;
+  return sum;
+}
+
 template <int NP, bool EXACT>
-__device__ __forceinline__ RiceResult rice_search(const uint32_t (&pl)[7], const int32_t* e, uint32_t len0,
+__device__ __forceinline__ RiceResult rice_search(const PlaneSums& ps, const int32_t* e, uint32_t len0,
                                                   uint32_t p_lo, uint32_t max_p, bool small_bits, int lane,
                                                   int warm) {
   constexpr uint32_t kWMax = kMaxPToBits - 4u;
@@ -203,9 +243,9 @@ __device__ __forceinline__ RiceResult rice_search(const uint32_t (&pl)[7], const
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
       const uint32_t pp = p_lo + (uint32_t)j;  // wave-uniform
-      uint32_t sum = 0;
-#pragma unroll
-      for (int k = 0; k < 7; ++k) sum += (pl[k] >> (pp & 31u)) << k;  // sum_i (u_i >> pp)
+      uint32_t sum;  // sum_i (u_i >> pp); pp == 0 is only possible for j == 0
+      if (j == 0) sum = (pp == 0) ? 2u * ps.sum_m + ps.negs : plane_sum_ge1(ps, pp);
+      else sum = plane_sum_ge1(ps, pp);
       sum = sum < kMaxPToBits ? sum : kMaxPToBits;
       uint32_t v = sum + len0 * (pp + 1u);  // rice.rs:69-71, 95-98 (minus the 4)
       v = v < kWMax ? v : kWMax;
@@ -737,8 +777,11 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
 #if defined(FLACENC_CUT) && FLACENC_CUT == 6
   { int z = 0; for (int k = 0; k < 64; ++k) z ^= e[k]; for (int k = 0; k < 7; ++k) z ^= (int)pl[k]; a.residual[sf * 64 + lane] = z; return; }
 #endif
-  // a bit is set in some residual <=> its count is non-zero <=> it is set in some plane
-  const uint32_t maxu = wave_or_dpp(pl[0] | pl[1] | pl[2] | pl[3] | pl[4] | pl[5] | pl[6]);
+  // a bit is set in some word <=> its count is non-zero <=> it is set in some plane; and the
+  // OR of the zig-zag codes u = 2 m + neg is (OR m) << 1 | (any neg)
+  const uint32_t orw = wave_or_dpp(pl[0] | pl[1] | pl[2] | pl[3] | pl[4] | pl[5] | pl[6]);
+  const uint32_t maxu = (orw << 1) | (orw >> 31);  // (m < 2^31, so nothing is lost by the shift)
+  const PlaneSums ps = make_plane_sums(pl);
   // Parameters beyond the residual's bit length can never win (see the generic kernel).
   const uint32_t bitlen = maxu ? (uint32_t)(32 - __builtin_clz(maxu)) : 0u;
   const uint32_t max_p = a.max_rice_parameter < bitlen ? a.max_rice_parameter : bitlen;
@@ -757,34 +800,30 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
     // win or tie.  A group's mean is at least the smallest 64-sample partition mean, so the
     // wave-minimum of the (conservatively rounded) per-lane p0 bounds every order.  If the
     // configured max_p lies below that, the same inequalities leave max_p as the only candidate.
-    uint32_t s0 = 0;
-#pragma unroll
-    for (int k = 0; k < 7; ++k) s0 += pl[k] << k;  // sum of the lane's 64 words (< 2^32: u < 2^26)
+    const uint32_t s0 = 2u * ps.sum_m + ps.negs;  // sum of the lane's 64 codes (< 2^32: u < 2^26)
     const uint32_t q0 = (s0 >> 6) + 1u;
     const uint32_t p0min = wave_min_dpp(31u - (uint32_t)__builtin_clz(q0));
     uint32_t p_lo = p0min > 2u ? p0min - 2u : 0u;
     p_lo = p_lo < max_p ? p_lo : max_p;
     const uint32_t span = max_p - p_lo + 1u;
-    if (span <= 8) rr = rice_search<8, true>(pl, nullptr, len0, p_lo, max_p, small_bits, lane, warm);
-    else if (span <= 16) rr = rice_search<16, true>(pl, nullptr, len0, p_lo, max_p, small_bits, lane, warm);
-    else if (span <= 24) rr = rice_search<24, true>(pl, nullptr, len0, p_lo, max_p, small_bits, lane, warm);
-    else rr = rice_search<32, true>(pl, nullptr, len0, 0u, max_p, small_bits, lane, warm);
+    if (span <= 8) rr = rice_search<8, true>(ps, nullptr, len0, p_lo, max_p, small_bits, lane, warm);
+    else if (span <= 16) rr = rice_search<16, true>(ps, nullptr, len0, p_lo, max_p, small_bits, lane, warm);
+    else if (span <= 24) rr = rice_search<24, true>(ps, nullptr, len0, p_lo, max_p, small_bits, lane, warm);
+    else rr = rice_search<32, true>(ps, nullptr, len0, 0u, max_p, small_bits, lane, warm);
     // The window argument compares unclamped table values.  If any group minimum saturated at
     // MAX_P_TO_BITS, clamped entries outside the window could tie with it (ties go to the
     // smallest p, rice.rs:123-124), so search the whole range then.
     if (rr.sat_levels != 0 && p_lo != 0 && span <= 24)
-      rr = rice_search<32, true>(pl, nullptr, len0, 0u, max_p, small_bits, lane, warm);
+      rr = rice_search<32, true>(ps, nullptr, len0, 0u, max_p, small_bits, lane, warm);
     if (rr.saturated) {
       // sum_i (u_i >> p) of this lane's partition under its group's parameter, from the planes
       const uint32_t gp = (uint32_t)__shfl((int)rr.my_p, lane & ~((1 << rr.bestk) - 1), 64);
-      unsigned long long mine = 0;
-#pragma unroll
-      for (int k = 0; k < 7; ++k) mine += (unsigned long long)(pl[k] >> gp) << k;
+      const unsigned long long mine = plane_sum_any64(ps, gp);
       sat_sum_q = ((unsigned long long)wave_sum_dpp((uint32_t)(mine >> 16)) << 16) +
                   (unsigned long long)wave_sum_dpp((uint32_t)(mine & 0xFFFFu));
     }
   } else {
-    rr = rice_search<32, false>(pl, e, len0, 0u, max_p, small_bits, lane, warm);
+    rr = rice_search<32, false>(ps, e, len0, 0u, max_p, small_bits, lane, warm);
     if (rr.saturated) {
       const uint32_t gp = (uint32_t)__shfl((int)rr.my_p, lane & ~((1 << rr.bestk) - 1), 64);
       uint32_t lo = 0, hi = 0;

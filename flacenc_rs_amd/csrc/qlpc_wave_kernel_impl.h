@@ -416,9 +416,6 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
   // (inactive tail waves of plain mode stay for the workgroup barriers and write nothing)
   if (a.stamps && lane == 0) a.stamps[(size_t)sf * 8 + 1] = (unsigned long long)clock64();
 
-#if defined(FLACENC_CUT) && FLACENC_CUT == 1
-  if (lane == 0) a.residual[sf] = sm[tid]; return;
-#endif
   const int32_t* const bufA = sm + (STEREO ? (role == 1 ? 1 : 0) : wave) * kBufDwords;
   const int32_t* const bufB = sm + kBufDwords;  // right channel (stereo roles 2, 3)
   // four samples of this wave's role starting at t (multiple of 4, >= -64).  The role is
@@ -561,9 +558,6 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
       if (k == lane && k <= P) rv = R[k];
     a.autocorr[(size_t)sf * 33 + lane] = rv;
   }
-#if defined(FLACENC_CUT) && FLACENC_CUT == 2
-  if (lane == 0) a.autocorr[sf] = R[0] + R[MAXP]; return;
-#endif
   __builtin_amdgcn_sched_barrier(0);
   if (a.stamps && lane == 0) a.stamps[(size_t)sf * 8 + 2] = (unsigned long long)clock64();
 
@@ -618,9 +612,6 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
   for (int i = 0; i < MAXP; ++i) sumabs += cq[i] < 0 ? -cq[i] : cq[i];
   // compute_error's path choice, lpc.rs:361-377 (+ |s| < 2^23 for the 24-bit multiplier)
   const bool wide = !(((uint64_t)my_maxabs * (uint64_t)sumabs < 0x7FFFFFFFull) && (my_maxabs < (1u << 23)));
-#if defined(FLACENC_CUT) && FLACENC_CUT == 3
-  if (lane == 0) a.residual[sf] = cq[0] + cq[MAXP-1] + warm + shift; return;
-#endif
   __builtin_amdgcn_sched_barrier(0);
   if (a.stamps && lane == 0) a.stamps[(size_t)sf * 8 + 3] = (unsigned long long)clock64();
 
@@ -681,9 +672,6 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
       for (int k = 16; k < 64; ++k) e[k] = 0;
     }
   }
-#if defined(FLACENC_CUT) && FLACENC_CUT == 4
-  { int z = 0; for (int k = 0; k < 64; ++k) z ^= e[k]; a.residual[sf * 64 + lane] = z; return; }
-#endif
   __builtin_amdgcn_sched_barrier(0);
   if (a.stamps && lane == 0) a.stamps[(size_t)sf * 8 + 4] = (unsigned long long)clock64();
 
@@ -742,9 +730,6 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
       }
     }
   }
-#if defined(FLACENC_CUT) && FLACENC_CUT == 5
-  return;
-#endif
   __builtin_amdgcn_sched_barrier(0);
   if (a.stamps && lane == 0) a.stamps[(size_t)sf * 8 + 5] = (unsigned long long)clock64();
 
@@ -774,9 +759,6 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
     planes_add<6>(pl, pc);
     __builtin_amdgcn_sched_barrier(0);
   }
-#if defined(FLACENC_CUT) && FLACENC_CUT == 6
-  { int z = 0; for (int k = 0; k < 64; ++k) z ^= e[k]; for (int k = 0; k < 7; ++k) z ^= (int)pl[k]; a.residual[sf * 64 + lane] = z; return; }
-#endif
   // a bit is set in some word <=> its count is non-zero <=> it is set in some plane; and the
   // OR of the zig-zag codes u = 2 m + neg is (OR m) << 1 | (any neg)
   const uint32_t orw = wave_or_dpp(pl[0] | pl[1] | pl[2] | pl[3] | pl[4] | pl[5] | pl[6]);
@@ -837,9 +819,6 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
       sat_sum_q = ((unsigned long long)wave_sum_dpp(hi) << 16) + (unsigned long long)wave_sum_dpp(lo);
     }
   }
-#if defined(FLACENC_CUT) && FLACENC_CUT == 7
-  { int z = rr.bestk + (int)rr.best_bits + (int)rr.my_p; for (int k = 0; k < 64; ++k) z ^= e[k]; a.residual[sf * 64 + lane] = z; return; }
-#endif
   const int bestk = rr.bestk;
   const unsigned long long best_bits = rr.best_bits;
   const uint32_t my_p = rr.my_p;

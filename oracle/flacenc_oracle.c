@@ -156,6 +156,54 @@ void orc_auto_correlation_canonical_f64(size_t order, const float* signal, size_
   }
 }
 
+/* weighted_auto_correlation_simd (src/lpc.rs:510-531) -> weighted_delay_prod_sum_impl
+ * (src/lpc.rs:439-500), the `simd-nightly` build's summation order, with NoWeight, T = f64.
+ * Per lag DELAY: LANES = next_power_of_two((DELAY | 7) - 1) = 8 / 16 / 32 / 32 / 64 f64 lanes;
+ * signal[warm_up..] is split by `as_simd` into an unaligned scalar head, LANES-wide body
+ * vectors and a scalar foot; head and foot are sequential mul_add chains from 0, each body
+ * lane is its own mul_add chain, and the lanes are added left to right (reduce_sum is
+ * simd_reduce_add_ordered) before  acc(head) + acc(foot) + lanes.
+ * The head length depends on the address of signal[warm_up] modulo the vector alignment:
+ * `base_mod` is the element offset of signal[0] from a LANES*4-byte boundary (0 for the
+ * 64-byte aligned SimdVec when LANES <= 16; allocator-dependent beyond that -- which is why the
+ * reference's own simd/nosimd parity test only asserts rtol 1e-5, src/lpc.rs:1392-1413). */
+void orc_auto_correlation_nightly_f64(size_t order, const float* signal, size_t n, double* dest,
+                                      size_t base_mod) {
+  for (size_t tau = 0; tau < order; ++tau) dest[tau] = 0.0;
+  if (order == 0 || n + 1 <= order) return;
+  size_t warm_up = order - 1;
+  for (size_t delay = 0; delay < order; ++delay) {
+    size_t x = (delay | 7) - 1, lanes = 1;
+    while (lanes < x) lanes <<= 1;
+    if (lanes > 64) lanes = 64;
+    size_t len = n - warm_up;
+    size_t mis = (base_mod + warm_up) % lanes;
+    size_t head = mis ? lanes - mis : 0;
+    if (head > len) head = len;
+    size_t nbody = (len - head) / lanes;
+    size_t t = warm_up;
+    double acc = 0.0;
+    { /* head */
+      double a = 0.0;
+      for (size_t i = 0; i < head; ++i, ++t) a = fma((double)signal[t - delay], (double)signal[t], a);
+      acc += a;
+    }
+    double acc_v[64];
+    for (size_t l = 0; l < lanes; ++l) acc_v[l] = 0.0;
+    for (size_t b = 0; b < nbody; ++b, t += lanes)
+      for (size_t l = 0; l < lanes; ++l)
+        acc_v[l] = fma((double)signal[t + l], (double)signal[t + l - delay], acc_v[l]);
+    { /* foot */
+      double a = 0.0;
+      for (; t < n; ++t) a = fma((double)signal[t - delay], (double)signal[t], a);
+      acc += a;
+    }
+    double lanesum = 0.0;
+    for (size_t l = 0; l < lanes; ++l) lanesum += acc_v[l];
+    dest[delay] = acc + lanesum;
+  }
+}
+
 /* symmetric_levinson_recursion, src/lpc.rs:633-705.
  * NOTE on `continue` (src/lpc.rs:679-682): it sits inside `for n in 1..order`
  * nested in `loop { .. break; }`; an unlabeled `continue` continues the
@@ -327,6 +375,8 @@ int orc_lpc_from_autocorr(const int32_t* signal, size_t n, const orc_qlpc_config
   double corr[ORC_MAX_LPC_ORDER + 1];
   if (cfg->acorr_order == ORC_ACORR_CANONICAL)
     orc_auto_correlation_canonical_f64(lpc_order + 1, xw, n, corr);
+  else if (cfg->acorr_order == ORC_ACORR_NIGHTLY)
+    orc_auto_correlation_nightly_f64(lpc_order + 1, xw, n, corr, 0);
   else
     orc_auto_correlation_f64(lpc_order + 1, xw, n, corr);
   int status = ORC_STATUS_OK;

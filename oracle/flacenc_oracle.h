@@ -43,6 +43,7 @@ extern "C" {
 /* autocorrelation summation orders */
 #define ORC_ACORR_REFERENCE 0 /* weighted_auto_correlation_nosimd, src/lpc.rs:533-548 */
 #define ORC_ACORR_CANONICAL 1 /* the build's canonical order: 16-sample chunk chains + balanced tree */
+#define ORC_ACORR_NIGHTLY 2   /* weighted_auto_correlation_simd, src/lpc.rs:510-531 (aligned buffer) */
 
 #define ORC_STATUS_OK 0
 #define ORC_STATUS_NONFINITE 1   /* the reference would panic (src/lpc.rs:786-799) */
@@ -92,6 +93,8 @@ void orc_fill_windowed_signal(const int32_t* signal, const float* window, size_t
 void orc_auto_correlation_f64(size_t order, const float* signal, size_t n, double* dest);
 void orc_auto_correlation_f32(size_t order, const float* signal, size_t n, float* dest);
 void orc_auto_correlation_canonical_f64(size_t order, const float* signal, size_t n, double* dest);
+void orc_auto_correlation_nightly_f64(size_t order, const float* signal, size_t n, double* dest,
+                                      size_t base_mod);
 int orc_symmetric_levinson_f64(const double* coefs, const double* ys, size_t order, double* dest);
 int orc_symmetric_levinson_f32(const float* coefs, const float* ys, size_t order, float* dest);
 int32_t orc_find_shift(const double* coefs, size_t n, uint32_t precision);

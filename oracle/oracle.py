@@ -17,6 +17,7 @@ _LIB_PATH = os.path.join(_HERE, "libflacenc_oracle.so")
 
 ACORR_REFERENCE = 0
 ACORR_CANONICAL = 1
+ACORR_NIGHTLY = 2
 WINDOW_RECTANGLE = 0
 WINDOW_TUKEY = 1
 MAX_P_TO_BITS = (1 << 27) - 1
@@ -134,6 +135,7 @@ def _declare(L):
     L.orc_auto_correlation_f64.argtypes = [C.c_size_t, f32p, C.c_size_t, f64p]
     L.orc_auto_correlation_f32.argtypes = [C.c_size_t, f32p, C.c_size_t, f32p]
     L.orc_auto_correlation_canonical_f64.argtypes = [C.c_size_t, f32p, C.c_size_t, f64p]
+    L.orc_auto_correlation_nightly_f64.argtypes = [C.c_size_t, f32p, C.c_size_t, f64p, C.c_size_t]
     L.orc_symmetric_levinson_f64.argtypes = [f64p, f64p, C.c_size_t, f64p]
     L.orc_symmetric_levinson_f64.restype = C.c_int
     L.orc_symmetric_levinson_f32.argtypes = [f32p, f32p, C.c_size_t, f32p]
@@ -212,6 +214,14 @@ def fill_windowed_signal(signal, window) -> np.ndarray:
     w = np.ascontiguousarray(window, np.float32)
     out = np.empty(len(s), np.float32)
     lib().orc_fill_windowed_signal(_p(s, C.c_int32), _p(w, C.c_float), len(s), _p(out, C.c_float))
+    return out
+
+
+def auto_correlation_nightly(order: int, signal, base_mod: int = 0) -> np.ndarray:
+    """simd-nightly summation order (src/lpc.rs:510-531, 439-500)."""
+    x = np.ascontiguousarray(signal, np.float32)
+    out = np.zeros(order, np.float64)
+    lib().orc_auto_correlation_nightly_f64(order, _p(x, C.c_float), len(x), _p(out, C.c_double), base_mod)
     return out
 
 

@@ -39,6 +39,9 @@ def main():
     ap.add_argument("--block-size", type=int, default=4096)
     ap.add_argument("--lpc-order", type=int, default=8)
     ap.add_argument("--bps", type=int, default=16)
+    ap.add_argument("--use-fixed", action="store_true",
+                    help="also run the fixed-LPC candidate (the reference's default SubFrameCoding); "
+                         "not the north-star workload, reported in DESIGN.md")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU work for cpu_baseline")
     args = ap.parse_args()
@@ -62,7 +65,7 @@ def main():
     n, F, bps = args.block_size, args.frames, args.bps
     # precision 15, Tukey(0.4), max_p 30; candidates Constant / Verbatim / LPC (use_fixed off: the
     # fixed-LPC candidate is not on the GPU path yet), all stereo assignments allowed
-    cfg = _capi.make_frame_config(_capi.make_config(lpc_order=args.lpc_order))
+    cfg = _capi.make_frame_config(_capi.make_config(lpc_order=args.lpc_order), use_fixed=args.use_fixed)
     # synthetic "sigen" audio: Sine(200, 0.4) + Noise(0.4) like the reference's
     # stereo_frame_encoder_noisy_sine_lpc bench (src/coding.rs:1152), one continuous stream,
     # dealt round-robin: stream frame f belongs to rank f mod G (flacenc_rs_amd/shard.py)
@@ -110,7 +113,7 @@ def main():
 
     # sanity: nothing in the timed region may have failed
     p = np.frombuffer(results.cpu().numpy().tobytes(), dtype=_capi.FRAME_RESULT_DTYPE)
-    lpc_kind = p["kind"] == 3
+    lpc_kind = p["kind"] >= 2
     assert (p["lpc"]["status"][lpc_kind] == 0).all(), "subframe status != 0"
     chosen_bits = int(sum(int(p["bits"][f, r]) for f in range(F) for r in p["role"][f]))
     assign_hist = np.bincount(p["channel_assignment"], minlength=4).tolist()
@@ -138,8 +141,9 @@ def main():
                         "full partitioned-Rice search (max_p 30); L,R,M,S analysed per frame, encode_frame decision",
             "frames_per_step_per_gpu": F,
             "subframes_analysed_per_step_per_gpu": 4 * F,
-            "decision": "encode_subframe {Constant, Verbatim, LPC} + try_stereo_coding on the GPU; "
-                        "the two chosen residuals written",
+            "decision": ("encode_subframe {Constant, Verbatim, FixedLpc(ApproxEnt 16), LPC}" if args.use_fixed
+                         else "encode_subframe {Constant, Verbatim, LPC}") +
+                        " + try_stereo_coding on the GPU; the two chosen residuals written",
             "gather": "all_gather of 752-B frame records (RCCL)" if world > 1 else "none",
             "subframe_bits_per_sample": round(chosen_bits / (2 * F * n), 4),
             "assignments_indep_left_right_mid": assign_hist,
@@ -151,7 +155,7 @@ def main():
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": _measured_traffic(),
-            "kernel": "qlpc_wave4096_kernel<8,true,true>",
+            "kernel": "qlpc_wave4096_kernel<8,true,true,%s>" % ("true" if args.use_fixed else "false"),
             "kernel_ms": round(kernel_ms, 4),
             "algorithmic_bytes_per_launch": ALGO_BYTES_PER_SAMPLE * samples_per_step,
         },

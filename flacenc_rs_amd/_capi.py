@@ -52,6 +52,7 @@ EXPORTED_SYMBOLS = (
     "flacenc_hip_encode_stereo_frames_async",
     "flacenc_hip_synchronize",
     "flacenc_hip_debug_set_stamps",
+    "flacenc_hip_debug_set_fixed_keys",
     "flacenc_sigen_fill_frames",
     "flacenc_sigen_fill_frames_strided",
 )
@@ -100,13 +101,27 @@ class FrameConfig(C.Structure):
         ("use_leftside", C.c_uint32),
         ("use_rightside", C.c_uint32),
         ("use_midside", C.c_uint32),
+        ("fixed_max_order", C.c_uint32),
+        ("fixed_order_sel", C.c_uint32),
+        ("fixed_partitions", C.c_uint32),
+        ("reserved", C.c_uint32),
     ]
 
 
+ORDERSEL_BITCOUNT = 0
+ORDERSEL_APPROXENT = 1
+KIND_CONSTANT, KIND_VERBATIM, KIND_FIXED, KIND_LPC = 0, 1, 2, 3
+
+
 def make_frame_config(qlpc: QlpcConfig | None = None, use_constant=True, use_fixed=False, use_lpc=True,
-                      use_leftside=True, use_rightside=True, use_midside=True) -> FrameConfig:
+                      use_leftside=True, use_rightside=True, use_midside=True, fixed_max_order=4,
+                      fixed_order_sel=ORDERSEL_APPROXENT, fixed_partitions=16) -> FrameConfig:
+    """config::SubFrameCoding / config::Fixed / StereoCoding (src/config.rs:167-183, 236-244, 137-144).
+    The reference's default has use_fixed = True; here it is opt-in so that the QLPC-only analysis
+    the north-star metric is quoted on stays the default of the bench."""
     return FrameConfig(qlpc or make_config(), int(use_constant), int(use_fixed), int(use_lpc),
-                       int(use_leftside), int(use_rightside), int(use_midside))
+                       int(use_leftside), int(use_rightside), int(use_midside), int(fixed_max_order),
+                       int(fixed_order_sel), int(fixed_partitions), 0)
 
 
 # flacenc_hip_stereo_frame_result (752 bytes)
@@ -161,6 +176,8 @@ def load() -> C.CDLL:
     L.flacenc_hip_synchronize.restype = C.c_int
     L.flacenc_hip_debug_set_stamps.argtypes = [vp, vp]
     L.flacenc_hip_debug_set_stamps.restype = C.c_int
+    L.flacenc_hip_debug_set_fixed_keys.argtypes = [vp, vp]
+    L.flacenc_hip_debug_set_fixed_keys.restype = C.c_int
     batch_args = [vp, C.POINTER(QlpcConfig), i32p, C.c_size_t, C.c_uint32, C.c_size_t, u8p, vp, i32p,
                   C.c_size_t, f64p, f64p]
     L.flacenc_hip_qlpc_batch.argtypes = batch_args + [C.c_int]
@@ -263,6 +280,9 @@ class Handle:
     def _check(self, rc):
         if rc != OK:
             raise FlacencHipError(rc, self._lib.flacenc_hip_last_error(self._h).decode())
+
+    def debug_set_fixed_keys(self, device_ptr: int):
+        self._check(self._lib.flacenc_hip_debug_set_fixed_keys(self._h, device_ptr or None))
 
     def debug_set_stamps(self, device_ptr: int):
         self._check(self._lib.flacenc_hip_debug_set_stamps(self._h, device_ptr or None))

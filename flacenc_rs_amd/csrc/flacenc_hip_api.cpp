@@ -40,6 +40,7 @@ struct flacenc_hip_handle {
   std::vector<WindowEntry> windows;
   DeviceBuffer d_samples, d_residual, d_params, d_bps, d_autocorr, d_lpc, d_tables;
   unsigned long long* stamps = nullptr;  // profiling hook, see flacenc_hip_debug_set_stamps
+  unsigned long long* fixed_keys = nullptr;  // test hook, see flacenc_hip_debug_set_fixed_keys
 };
 
 namespace {
@@ -209,6 +210,8 @@ int enqueue(flacenc_hip_handle* h, const flacenc_hip_qlpc_config* cfg, const int
   a.stamps = h->stamps;
   a.frame_results = nullptr;
   a.use_constant = a.use_lpc = a.use_leftside = a.use_rightside = a.use_midside = 1;
+  a.use_fixed = a.fixed_max_order = a.fixed_order_sel = a.fixed_group_log2 = 0;
+  a.fixed_keys = nullptr;
   if (plan.table_scratch_bytes_per_subframe) {
     rc = ensure(h, h->d_tables, plan.table_scratch_bytes_per_subframe * n_subframes);
     if (rc != FLACENC_HIP_OK) return rc;
@@ -290,6 +293,12 @@ int flacenc_hip_window_weights(const flacenc_hip_qlpc_config* cfg, uint32_t bloc
   int rc = flacenc_hip_verify_config(cfg);
   if (rc != FLACENC_HIP_OK) return rc;
   window_weights(cfg->window_type, cfg->tukey_alpha, block_size, out);
+  return FLACENC_HIP_OK;
+}
+
+int flacenc_hip_debug_set_fixed_keys(flacenc_hip_handle* h, unsigned long long* device_keys) {
+  if (!h) return FLACENC_HIP_ERR_BAD_ARGUMENT;
+  h->fixed_keys = device_keys;
   return FLACENC_HIP_OK;
 }
 
@@ -447,9 +456,30 @@ int flacenc_hip_encode_stereo_frames_async(flacenc_hip_handle* h, const flacenc_
     h->last_error = "bits_per_sample must be in 8..=24";
     return FLACENC_HIP_ERR_BAD_ARGUMENT;
   }
+  uint32_t fixed_group_log2 = 0;
   if (cfg->use_fixed) {
-    h->last_error = "use_fixed: the fixed-LPC candidate is not available on the GPU path yet";
-    return FLACENC_HIP_ERR_UNSUPPORTED;
+    // config::Fixed::verify (config.rs:246-255) + OrderSel::verify (:419-431)
+    if (cfg->fixed_max_order > FLACENC_HIP_MAX_FIXED_LPC_ORDER ||
+        (cfg->fixed_order_sel != FLACENC_HIP_ORDERSEL_BITCOUNT &&
+         cfg->fixed_order_sel != FLACENC_HIP_ORDERSEL_APPROXENT) ||
+        (cfg->fixed_order_sel == FLACENC_HIP_ORDERSEL_APPROXENT &&
+         (cfg->fixed_partitions < 1 || cfg->fixed_partitions > 64))) {
+      h->last_error = "fixed: max_order must be ..=4, order_sel BitCount / ApproxEnt, ApproxEnt.partitions 1..=64";
+      return FLACENC_HIP_ERR_BAD_CONFIG;
+    }
+    if (cfg->fixed_order_sel == FLACENC_HIP_ORDERSEL_APPROXENT) {
+      // the estimator's partitions must be whole groups of 64-sample lanes
+      const uint32_t p = cfg->fixed_partitions;
+      if ((p & (p - 1)) != 0) {
+        h->last_error = "fixed: ApproxEnt.partitions must be a power of two on the GPU path";
+        return FLACENC_HIP_ERR_UNSUPPORTED;
+      }
+      uint32_t lanes = 64u / p;
+      while (lanes > 1) {
+        ++fixed_group_log2;
+        lanes >>= 1;
+      }
+    }
   }
   HIP_TRY(h, hipSetDevice(h->device));
   const WindowEntry* win = nullptr;
@@ -482,6 +512,11 @@ int flacenc_hip_encode_stereo_frames_async(flacenc_hip_handle* h, const flacenc_
   a.use_leftside = cfg->use_leftside;
   a.use_rightside = cfg->use_rightside;
   a.use_midside = cfg->use_midside;
+  a.use_fixed = cfg->use_fixed;
+  a.fixed_max_order = cfg->fixed_max_order;
+  a.fixed_order_sel = cfg->fixed_order_sel;
+  a.fixed_group_log2 = fixed_group_log2;
+  a.fixed_keys = h->fixed_keys;
   if (!flacenc_hip::wave_kernel_eligible(a)) {
     h->last_error = "encode_stereo_frames: needs block_size 4096, lpc_order <= 12 and 16-byte aligned rows";
     return FLACENC_HIP_ERR_UNSUPPORTED;

@@ -179,6 +179,75 @@ __device__ __forceinline__ void planes_add(uint32_t* a, const uint32_t* b) {
   a[NA] = carry;
 }
 
+// |x - y| + acc on unsigned operands (v_sad_u32)
+__device__ __forceinline__ uint32_t sad_u32(uint32_t x, uint32_t y, uint32_t acc) {
+  uint32_t r;
+  asm("v_sad_u32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(acc));
+  return r;
+}
+
+// f32::log2 = libm log2f.  glibc's algorithm (sysdeps/ieee754/flt-32/e_log2f.c, 2.27+): 16-entry
+// {1/c, log2 c} table around OFF = 0x3f330000, degree-4 polynomial in double, one rounding to
+// float.  Same restatement as oracle/flacenc_oracle.c orc_log2f (checked there against the
+// host libm over every positive float).
+__device__ const double kLog2fTab[32] = {
+    0x1.661ec79f8f3bep+0, -0x1.efec65b963019p-2, 0x1.571ed4aaf883dp+0, -0x1.b0b6832d4fca4p-2,
+    0x1.49539f0f010bp+0,  -0x1.7418b0a1fb77bp-2, 0x1.3c995b0b80385p+0, -0x1.39de91a6dcf7bp-2,
+    0x1.30d190c8864a5p+0, -0x1.01d9bf3f2b631p-2, 0x1.25e227b0b8eap+0,  -0x1.97c1d1b3b7afp-3,
+    0x1.1bb4a4a1a343fp+0, -0x1.2f9e393af3c9fp-3, 0x1.12358f08ae5bap+0, -0x1.960cbbf788d5cp-4,
+    0x1.0953f419900a7p+0, -0x1.a6f9db6475fcep-5, 0x1p+0,               0x0p+0,
+    0x1.e608cfd9a47acp-1, 0x1.338ca9f24f53dp-4,  0x1.ca4b31f026aap-1,  0x1.476a9543891bap-3,
+    0x1.b2036576afce6p-1, 0x1.e840b4ac4e4d2p-3,  0x1.9c2d163a1aa2dp-1, 0x1.40645f0c6651cp-2,
+    0x1.886e6037841edp-1, 0x1.88e9c2c1b9ff8p-2,  0x1.767dcf5534862p-1, 0x1.ce0a44eb17bccp-2,
+};
+
+__device__ __forceinline__ float dev_log2f(float x) {
+  uint32_t ix = __float_as_uint(x);
+  if (ix == 0x3f800000u) return 0.0f;
+  if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u) {
+    if (ix * 2u == 0u) return -__builtin_inff();
+    if (ix == 0x7f800000u) return x;
+    if ((ix & 0x80000000u) || ix * 2u >= 0xff000000u) return __builtin_nanf("");
+    ix = __float_as_uint(x * 0x1p23f) - (23u << 23);
+  }
+  const uint32_t tmp = ix - 0x3f330000u;
+  const int i = (int)((tmp >> 19) & 15u);
+  const uint32_t top = tmp & 0xff800000u;
+  const int k = (int)tmp >> 23;
+  const double z = (double)__uint_as_float(ix - top);
+  const double r = z * kLog2fTab[2 * i] - 1.0;
+  const double y0 = kLog2fTab[2 * i + 1] + (double)k;
+  const double r2 = r * r;
+  double y = 0x1.ecabf496832ep-2 * r + -0x1.715479ffae3dep-1;
+  y = -0x1.712b6f70a7e4dp-2 * r2 + y;
+  const double p = 0x1.715475f35c8b8p0 * r + y0;
+  y = y * r2 + p;
+  return (float)y;
+}
+
+// one partition of estimate_entropy (coding.rs:215-222): `sum` is the exact integer sum of
+// |e| over the partition (rounded to f32 once -- the canonical definition of DESIGN.md; equal to
+// find_sum_abs_f32 in either reference build while the sum stays below 2^24)
+__device__ __forceinline__ uint32_t approx_ent_bits(double sum, uint32_t count) {
+  const float sum_errors = (float)sum;
+  const float cnt = (float)count;
+  const float avg_errors = sum_errors * 2.0f / (cnt + 0.00001f);
+  const float geom_p = 1.0f / (avg_errors + 1.0f);
+  const float xent = __builtin_fmaf(avg_errors, -dev_log2f(1.0f - geom_p), -dev_log2f(geom_p));
+  const float v = xent * cnt;
+  return v > 0.0f ? (uint32_t)v : 0u;  // `as usize`: NaN and negatives -> 0
+}
+
+// what fixed_lpc (coding.rs:298-331) settled on for one subframe
+struct FixedChoice {
+  bool have;
+  int order;                     // uniform
+  unsigned long long key;        // the selector's key of `order` (estimate or real bits)
+  int bestk;                     // Rice result of the order's error signal
+  uint32_t my_p;
+  unsigned long long code_bits, sum_q, sub_bits;
+};
+
 struct RiceResult {
   int bestk;                     // chosen order = 6 - bestk (uniform)
   unsigned long long best_bits;  // PrcParameter::code_bits (uniform)
@@ -329,9 +398,10 @@ __device__ __forceinline__ RiceResult rice_search(const PlaneSums& ps, const int
 // DECIDE (stereo only): run encode_subframe's candidate choice and try_stereo_coding's channel
 // assignment (coding.rs:384-418 without the fixed-LPC candidate, :493-522) on the device and
 // write one flacenc_hip_stereo_frame_result + the TWO chosen residual rows per frame.
-template <int MAXP, bool STEREO, bool DECIDE>
+template <int MAXP, bool STEREO, bool DECIDE, bool FIXED>
 __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(QlpcKernelArgs a) {
   static_assert(!DECIDE || STEREO, "the decision needs the four roles of a stereo frame");
+  static_assert(!FIXED || DECIDE, "the fixed-LPC candidate only exists inside encode_subframe's decision");
   constexpr int HP = (MAXP + 3) & ~3;
   constexpr int NLAG = MAXP + 1;
   constexpr int NBUF = STEREO ? 2 : 4;
@@ -446,8 +516,142 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
     else f(std::integral_constant<int, 0>{});
   };
 
-  // ======================= phase 1: window + autocorrelation ==============
   const int tl = lane << 6;  // first sample of this lane
+  const unsigned long long bps_role = a.bps ? (unsigned long long)a.bps[sf]
+                                            : (unsigned long long)(a.bps_uniform + ((STEREO && role == 3) ? 1u : 0u));
+
+  // ======================= fixed-LPC candidate: order selection ============
+  // fixed_lpc (coding.rs:298-331).  `cand` walks the candidates that go through the Rice search:
+  // 0..4 = the fixed-LPC error signal of that order, 5 = the QLPC candidate (always last, so e[]
+  // ends up holding its residual).  ApproxEnt (coding.rs:265-287) codes only its argmin order;
+  // BitCount (:243-264) codes every order up to max_order and keeps the first minimum.
+  int cand = 5;
+  FixedChoice fx;
+  fx.have = false;
+  fx.order = 0;
+  fx.key = ~0ull;
+  fx.bestk = 0;
+  fx.my_p = 0;
+  fx.code_bits = fx.sum_q = fx.sub_bits = 0;
+  // the lane's 64 samples + 4 in front of them (zeros in front of the block: the reference's
+  // carry starts at 0, coding.rs:188), differenced `ord` times in place; valid from index ord on
+  auto fixed_load = [&](uint32_t (&v)[68]) {
+    with_role([&](auto kind) {
+#pragma unroll
+      for (int k = 0; k < 17; ++k) {
+        const int4 q = ld4k(kind, tl - 4 + 4 * k);
+        v[4 * k + 0] = (uint32_t)q.x;
+        v[4 * k + 1] = (uint32_t)q.y;
+        v[4 * k + 2] = (uint32_t)q.z;
+        v[4 * k + 3] = (uint32_t)q.w;
+      }
+    });
+  };
+  if (FIXED && a.use_fixed) {
+    if (a.fixed_order_sel == 1u) {
+      // ---- estimate_entropy (coding.rs:200-227) for orders 0..max_order ----
+      // per-lane sums of |e_k| as exact integers: v_sad_u32 on values biased by 2^31 gives
+      // |x - y| of the signed values, i.e. the NEXT order's magnitude, straight from this order's
+      // values; 16-sample sub-sums stay below 2^32 for inputs up to 25 bits, then go to f64
+      double ls[5];
+      {
+        uint32_t b[68];
+        fixed_load(b);
+#pragma unroll
+        for (int i = 0; i < 68; ++i) b[i] ^= 0x80000000u;
+#pragma unroll
+        for (int ord = 0; ord < 5; ++ord) {
+          uint32_t c[4] = {0u, 0u, 0u, 0u};
+          if (ord == 0) {
+#pragma unroll
+            for (int j = 0; j < 64; ++j) c[j >> 4] = sad_u32(b[4 + j], 0x80000000u, c[j >> 4]);
+          } else {
+#pragma unroll
+            for (int j = 0; j < 64; ++j) c[j >> 4] = sad_u32(b[4 + j], b[3 + j], c[j >> 4]);
+            if (ord < 4) {
+#pragma unroll
+              for (int i = 67; i >= ord; --i) b[i] = (b[i] - b[i - 1]) ^ 0x80000000u;
+            }
+          }
+          ls[ord] = ((double)c[0] + (double)c[1]) + ((double)c[2] + (double)c[3]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      // partition sums: partitions of 4096 / P samples = groups of 2^g lanes (P a power of two)
+      const int g = (int)a.fixed_group_log2;
+#pragma unroll 1
+      for (int lvl = 0; lvl < g; ++lvl) {
+#pragma unroll
+        for (int ord = 0; ord < 5; ++ord) ls[ord] += __shfl_xor(ls[ord], 1 << lvl, 64);
+      }
+      const bool gleader = (lane & ((1 << g) - 1)) == 0;
+      const uint32_t psize = 64u << g;
+      unsigned long long best_key = ~0ull;
+      int best_ord = 0;
+#pragma unroll 1
+      for (int ord = 0; ord <= (int)a.fixed_max_order; ++ord) {
+        double sv = ls[0];
+#pragma unroll
+        for (int q = 1; q < 5; ++q) sv = (q == ord) ? ls[q] : sv;
+        // sample_count = min(end - warmup, partition_len): only partition 0 loses the warm-up
+        const uint32_t cnt = psize - ((lane >> g) == 0 ? (uint32_t)ord : 0u);
+        const uint32_t pb = approx_ent_bits(sv, cnt);
+        const unsigned long long key = (unsigned long long)wave_sum_dpp(gleader ? pb : 0u) +
+                                       bps_role * (unsigned long long)ord;
+        if (a.fixed_keys && lane == 0) a.fixed_keys[(size_t)sf * 8 + ord] = key;
+        if (key < best_key) {  // min_by_key keeps the first minimum
+          best_key = key;
+          best_ord = ord;
+        }
+      }
+      fx.key = best_key;
+      fx.order = uni(best_ord);
+      cand = fx.order;
+    } else {
+      cand = 0;
+    }
+  }
+
+  // hoisted: produced by the candidate pass(es) below, consumed by the decision and the records
+  int32_t e[64];
+  int32_t cq[MAXP];
+  int warm = 0, shift = 0, status = 0;
+  int role_max = 0, role_min = 0;
+  int bestk = 0, rice_order = 0, best_parts = 1;
+  unsigned long long best_bits = 0, sum_q = 0, sub_bits = 0;
+  uint32_t my_p = 0;
+  auto put_own_e = [&](int32_t* buf) {
+#pragma unroll
+    for (int k = 0; k < 64; k += 4) {
+      int4 v;
+      v.x = e[k + 0];
+      v.y = e[k + 1];
+      v.z = e[k + 2];
+      v.w = e[k + 3];
+      *reinterpret_cast<int4*>(&buf[widx(tl + k)]) = v;
+    }
+  };
+#pragma unroll 1
+  for (;;) {
+  if (FIXED && cand != 5) {
+    // ---- the order-`cand` fixed-LPC error signal (coding.rs:182-197) -> e[] ----
+    uint32_t v[68];
+    fixed_load(v);
+#pragma unroll 1
+    for (int lvl = 1; lvl <= cand; ++lvl) {
+#pragma unroll
+      for (int i = 67; i >= 1; --i) v[i] -= v[i - 1];
+    }
+#pragma unroll
+    for (int k = 0; k < 64; ++k) e[k] = (int32_t)v[4 + k];
+    // the first `order` errors are never coded (Residual keeps zeros there, coding.rs:151-160)
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (lane == 0 && k < cand) e[k] = 0;
+    warm = cand;
+    status = 0;
+  } else {
+  // ======================= phase 1: window + autocorrelation ==============
   double R[NLAG];
   uint32_t my_maxabs = 0;
   int vmax = INT32_MIN, vmin = INT32_MAX;
@@ -547,8 +751,8 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
     for (int k = 0; k < NLAG; ++k) R[k] = wave_butterfly_sum(p2[k]);
   });
   // is_constant (arrayutils.rs:382): all samples of the role equal <=> max == min
-  const int role_max = (int)(wave_max_dpp((uint32_t)vmax ^ 0x80000000u) ^ 0x80000000u);
-  const int role_min = (int)(wave_min_dpp((uint32_t)vmin ^ 0x80000000u) ^ 0x80000000u);
+  role_max = (int)(wave_max_dpp((uint32_t)vmax ^ 0x80000000u) ^ 0x80000000u);
+  role_min = (int)(wave_min_dpp((uint32_t)vmin ^ 0x80000000u) ^ 0x80000000u);
   // max |s| (find_max_abs, arrayutils.rs:509) from the running max / min
   my_maxabs = (uint32_t)max(role_max, -role_min) | (role_min == INT32_MIN ? 0x80000000u : 0u);
   if (a.autocorr && lane < 33) {
@@ -566,8 +770,6 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
   // lanes -- so the four waves of the workgroup hand their R[] to wave 0, whose lanes 0..3
   // run the recursion for the four subframes side by side (one instruction stream instead of
   // four), and pick their quantised coefficients up again from LDS.
-  int32_t cq[MAXP];
-  int warm, shift, status;
   {
     // exchange area: kept small -- LDS is allocated in 1280-byte granules and three workgroups
     // must fit one CU (3 x 42 granules = 157.5 KB)
@@ -616,7 +818,6 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
   if (a.stamps && lane == 0) a.stamps[(size_t)sf * 8 + 3] = (unsigned long long)clock64();
 
   // ======================= phase 3: residual -> registers ==================
-  int32_t e[64];
   {
     // e[t] = s[t] - ((sum_j c_j s[t-1-j]) >> shift) (lpc.rs:306-350); the i32 / i64 choice of
     // lpc.rs:373-389 is wave-uniform, so it selects one of two straight-line bodies
@@ -674,21 +875,11 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
   }
   __builtin_amdgcn_sched_barrier(0);
   if (a.stamps && lane == 0) a.stamps[(size_t)sf * 8 + 4] = (unsigned long long)clock64();
+  }  // QLPC candidate
 
   // ======================= residual store: registers -> LDS -> HBM ==========
   // (before the Rice search so the stores drain underneath it; with DECIDE only the two chosen
   // roles are stored, after the decision)
-  auto put_own_e = [&](int32_t* buf) {
-#pragma unroll
-    for (int k = 0; k < 64; k += 4) {
-      int4 v;
-      v.x = e[k + 0];
-      v.y = e[k + 1];
-      v.z = e[k + 2];
-      v.w = e[k + 3];
-      *reinterpret_cast<int4*>(&buf[widx(tl + k)]) = v;
-    }
-  };
   if (!DECIDE) {
     auto put_own = [&](int32_t* buf) {
 #pragma unroll
@@ -819,11 +1010,11 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
       sat_sum_q = ((unsigned long long)wave_sum_dpp(hi) << 16) + (unsigned long long)wave_sum_dpp(lo);
     }
   }
-  const int bestk = rr.bestk;
-  const unsigned long long best_bits = rr.best_bits;
-  const uint32_t my_p = rr.my_p;
-  const int rice_order = 6 - bestk;
-  const int best_parts = 1 << rice_order;
+  bestk = rr.bestk;
+  best_bits = rr.best_bits;
+  my_p = rr.my_p;
+  rice_order = 6 - bestk;
+  best_parts = 1 << rice_order;
 
   // Residual::sum_quotients / count_bits (datatype.rs:2325-2331, bitrepr.rs:533-544)
   const bool leader = (lane & ((1 << bestk) - 1)) == 0;
@@ -832,31 +1023,56 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
   const uint32_t rice2 = wave_or_dpp(my_p > 14 ? 1u : 0u);
   const unsigned long long rem_bits = (unsigned long long)sum_p * (unsigned long long)(n >> rice_order) -
                                       (unsigned long long)warm * p0;
-  const unsigned long long sum_q =
-      rr.saturated ? sat_sum_q
-                   : best_bits - 4ull * (unsigned long long)best_parts - (unsigned long long)(n - warm) - rem_bits;
+  sum_q = rr.saturated ? sat_sum_q
+                       : best_bits - 4ull * (unsigned long long)best_parts - (unsigned long long)(n - warm) - rem_bits;
 
   // BitRepr for Residual / Lpc::count_bits, bitrepr.rs:533-544, 492-499 (all wave-uniform)
   const unsigned long long residual_bits = 2ull + 4ull + (unsigned long long)best_parts * (rice2 ? 5ull : 4ull) +
                                            (sum_q + (unsigned long long)(n - warm)) + rem_bits;
-  const unsigned long long bps_role = a.bps ? (unsigned long long)a.bps[sf]
-                                            : (unsigned long long)(a.bps_uniform + ((STEREO && role == 3) ? 1u : 0u));
-  const unsigned long long sub_bits = 8ull + bps_role * (unsigned long long)warm + 4ull + 5ull +
-                                      (unsigned long long)a.precision * (unsigned long long)warm + residual_bits;
+  if (FIXED && cand != 5) {
+    // BitRepr for FixedLpc::count_bits, bitrepr.rs:473-477; the selector's key for BitCount is
+    // bits_per_sample * order + code_bits (coding.rs:249)
+    const unsigned long long key =
+        a.fixed_order_sel == 1u ? fx.key : bps_role * (unsigned long long)cand + best_bits;
+    if (a.fixed_order_sel != 1u && a.fixed_keys && lane == 0) a.fixed_keys[(size_t)sf * 8 + cand] = key;
+    if (a.fixed_order_sel == 1u || key < fx.key) {  // first minimum
+      fx.key = key;
+      fx.order = cand;
+      fx.bestk = bestk;
+      fx.my_p = my_p;
+      fx.code_bits = best_bits;
+      fx.sum_q = sum_q;
+      fx.sub_bits = 8ull + bps_role * (unsigned long long)cand + residual_bits;
+    }
+    cand = (a.fixed_order_sel != 1u && cand < (int)a.fixed_max_order) ? cand + 1 : 5;
+    continue;
+  }
+  sub_bits = 8ull + bps_role * (unsigned long long)warm + 4ull + 5ull +
+             (unsigned long long)a.precision * (unsigned long long)warm + residual_bits;
+  break;
+  }  // candidate loop
 
   flacenc_hip_subframe_params* rec = a.params ? a.params + sf : nullptr;
+  bool fixed_record = false;
   if (DECIDE) {
-    // ---- encode_subframe for this role (coding.rs:384-418, use_fixed = false) ----
+    // ---- encode_subframe for this role (coding.rs:384-418) ----
     const bool is_const = a.use_constant && (role_max == role_min);
     const unsigned long long verbatim_bits = 8ull + (unsigned long long)n * bps_role;  // datatype.rs:1944
+    // fixed_lpc returns Some iff the selector's key beats verbatim_bits (coding.rs:262, :284)
+    const bool have_fixed = FIXED && a.use_fixed && fx.key < verbatim_bits;
+    const unsigned long long baseline_bits =
+        (have_fixed && fx.sub_bits < verbatim_bits) ? fx.sub_bits : verbatim_bits;  // coding.rs:403-405
     uint32_t kind;
     unsigned long long bits;
     if (is_const) {
       kind = 0u;  // Constant
       bits = 8ull + bps_role;  // bitrepr.rs:445
-    } else if (a.use_lpc && status == 0 && sub_bits < verbatim_bits) {
+    } else if (a.use_lpc && status == 0 && sub_bits < baseline_bits) {
       kind = 3u;  // Lpc
       bits = sub_bits;
+    } else if (have_fixed && fx.sub_bits < verbatim_bits) {
+      kind = 2u;  // FixedLpc
+      bits = fx.sub_bits;
     } else {
       kind = 1u;  // Verbatim
       bits = verbatim_bits;
@@ -907,8 +1123,27 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
     }
     // the two chosen roles hand their residual (zeros unless the LPC candidate was kept) to the
     // channel images, then the whole workgroup streams both rows out
+    if (FIXED) {
+      // a chosen FixedLpc subframe: its error signal is rebuilt from the channel images, which
+      // must therefore stay intact until every wave is past this point
+      if (slot >= 0 && kind == 2u) {
+        uint32_t v[68];
+        fixed_load(v);
+#pragma unroll 1
+        for (int lvl = 1; lvl <= fx.order; ++lvl) {
+#pragma unroll
+          for (int i = 67; i >= 1; --i) v[i] -= v[i - 1];
+        }
+#pragma unroll
+        for (int k = 0; k < 64; ++k) e[k] = (int32_t)v[4 + k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (lane == 0 && k < fx.order) e[k] = 0;
+      }
+      __syncthreads();
+    }
     if (slot >= 0) {
-      if (kind != 3u) {
+      if (kind < 2u) {
 #pragma unroll
         for (int k = 0; k < 64; ++k) e[k] = 0;
       }
@@ -927,11 +1162,32 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
       }
     }
     rec = (slot >= 0) ? &fr->lpc[slot] : nullptr;
-    if (rec != nullptr && kind != 3u) {
-      // not an LPC subframe: blank record
+    if (rec != nullptr && kind < 2u) {
+      // neither an LPC nor a FixedLpc subframe: blank record
       for (int i = lane; i < (int)(sizeof(flacenc_hip_subframe_params) / 4); i += 64)
         reinterpret_cast<uint32_t*>(rec)[i] = 0u;
       rec = nullptr;
+    }
+    if (FIXED && rec != nullptr && kind == 2u) {
+      // the record of a FixedLpc subframe: FIXED_LPC_COEFS[order] with shift 0 (decode.rs:179-201)
+      bestk = fx.bestk;
+      rice_order = 6 - bestk;
+      best_parts = 1 << rice_order;
+      my_p = fx.my_p;
+      best_bits = fx.code_bits;
+      sum_q = fx.sum_q;
+      sub_bits = fx.sub_bits;
+      warm = fx.order;
+      shift = 0;
+      status = 0;
+      fixed_record = true;
+#pragma unroll
+      for (int i = 0; i < MAXP; ++i) cq[i] = 0;
+      const int o = fx.order;
+      cq[0] = o;                                        // 0, 1, 2, 3, 4
+      cq[1] = o == 2 ? -1 : (o == 3 ? -3 : (o == 4 ? -6 : 0));
+      cq[2] = o == 3 ? 1 : (o == 4 ? 4 : 0);
+      cq[3] = o == 4 ? -1 : 0;
     }
   }
   if (rec != nullptr) {
@@ -955,7 +1211,7 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
     if (lane == 0) {
       rec->order = (uint8_t)warm;
       rec->shift = (int8_t)shift;
-      rec->precision = (uint8_t)a.precision;
+      rec->precision = (uint8_t)(fixed_record ? 0u : a.precision);
       rec->rice_order = (uint8_t)(status == 0 ? rice_order : 0);
       rec->status = status;
       rec->code_bits = status == 0 ? best_bits : 0ull;
@@ -969,9 +1225,9 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
   }
 }
 
-template <int MAXP, bool STEREO, bool DECIDE>
+template <int MAXP, bool STEREO, bool DECIDE, bool FIXED>
 hipError_t launch_wave4096(const QlpcKernelArgs& a, hipStream_t stream) {
-  auto kern = qlpc_wave4096_kernel<MAXP, STEREO, DECIDE>;
+  auto kern = qlpc_wave4096_kernel<MAXP, STEREO, DECIDE, FIXED>;
   constexpr size_t smem = (size_t)(STEREO ? 3 : 4) * kBufDwords * 4 + 4 * (((MAXP + 2) & ~1) * 8 + 64);  // images (+ window) + exchange
   static bool configured = false;
   if (!configured) {

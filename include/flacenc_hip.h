@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define FLACENC_HIP_ABI_VERSION 1
+#define FLACENC_HIP_ABI_VERSION 2
 
 /* FLAC allows LPC order 32; the reference's config verifier caps it at 24
  * (src/constant.rs:118, src/config.rs:304).  Orders 25..32 are an extension
@@ -36,6 +36,7 @@ extern "C" {
 #define FLACENC_HIP_MIN_BLOCK_SIZE 64     /* MIN_BLOCK_SIZE_FOR_PREDICTION, src/constant.rs:51 */
 #define FLACENC_HIP_MAX_BLOCK_SIZE 32767  /* src/constant.rs:57 */
 #define FLACENC_HIP_MAX_RICE_PARTITIONS 256 /* 2^8: finest order for any block <= 32767 */
+#define FLACENC_HIP_MAX_FIXED_LPC_ORDER 4   /* src/constant.rs:95 */
 
 /* return codes */
 #define FLACENC_HIP_OK 0
@@ -179,9 +180,14 @@ int flacenc_hip_stereo_qlpc_batch_async(flacenc_hip_handle* h, const flacenc_hip
 /* ---- encode_frame for 2-channel frames, decision on the device ------------------------ */
 /*
  * config::Encoder fields that steer `encode_frame` (src/coding.rs:530-544): SubFrameCoding's
- * candidate switches (src/config.rs:167-183) and StereoCoding (src/config.rs:137-144).
- * `use_fixed` must be 0: the fixed-LPC candidate is not on the GPU yet (ERR_UNSUPPORTED).
+ * candidate switches (src/config.rs:167-183), its config::Fixed (src/config.rs:236-244: max_order
+ * and OrderSel, :400-409) and StereoCoding (src/config.rs:137-144).  Reference defaults: every
+ * switch on, fixed_max_order 4, ApproxEnt with 16 partitions (src/constant.rs:35, :95).
+ * On the GPU path ApproxEnt.partitions must be a power of two (1..64).
  */
+#define FLACENC_HIP_ORDERSEL_BITCOUNT 0  /* OrderSel::BitCount: code every order, count the bits */
+#define FLACENC_HIP_ORDERSEL_APPROXENT 1 /* OrderSel::ApproxEnt { partitions } (the default) */
+
 typedef struct flacenc_hip_frame_config {
   flacenc_hip_qlpc_config qlpc;
   uint32_t use_constant;
@@ -190,17 +196,25 @@ typedef struct flacenc_hip_frame_config {
   uint32_t use_leftside;
   uint32_t use_rightside;
   uint32_t use_midside;
+  uint32_t fixed_max_order;  /* 0..=4 */
+  uint32_t fixed_order_sel;  /* FLACENC_HIP_ORDERSEL_* */
+  uint32_t fixed_partitions; /* ApproxEnt.partitions */
+  uint32_t reserved;
 } flacenc_hip_frame_config;
 
 #define FLACENC_HIP_KIND_CONSTANT 0 /* SubFrame::Constant */
 #define FLACENC_HIP_KIND_VERBATIM 1 /* SubFrame::Verbatim */
+#define FLACENC_HIP_KIND_FIXED 2    /* SubFrame::FixedLpc */
 #define FLACENC_HIP_KIND_LPC 3      /* SubFrame::Lpc */
 
 /* What `encode_frame` decides for one stereo frame: `try_stereo_coding`'s channel assignment
  * (src/coding.rs:493-522; 0 Independent(2), 1 LeftSide, 2 RightSide, 3 MidSide), and for each of
  * the two output channels (ChannelAssignment::select_channels, datatype.rs:1173-1185) which of
  * L, R, M, S it is (`role` 0..3), which SubFrame variant `encode_subframe` picked (`kind`), the
- * Constant's value, and the LPC record when kind == LPC.  `bits` are SubFrame::count_bits of the
+ * Constant's value, and the predictor record when kind == LPC or FIXED.  A FixedLpc subframe's
+ * record holds FIXED_LPC_COEFS[order] (src/component/decode.rs:179-185) with shift 0 and
+ * precision 0, the Rice partition of its error signal, and FixedLpc::count_bits
+ * (src/component/bitrepr.rs:473-477) in subframe_bits.  `bits` are SubFrame::count_bits of the
  * four candidates L, R, M, S after encode_subframe. */
 typedef struct flacenc_hip_stereo_frame_result {
   uint8_t channel_assignment;
@@ -216,7 +230,11 @@ typedef struct flacenc_hip_stereo_frame_result {
  * `encode_frame` (src/coding.rs:530-544) for a batch of 2-channel frames with the whole decision
  * on the GPU: L, R, M, S analysed, `encode_subframe` (coding.rs:384-418) applied to each,
  * `try_stereo_coding` picks the assignment, and only the two chosen residual rows are written:
- * residual + (2f + c)*residual_stride for output channel c of frame f (zeros unless kind == LPC).
+ * residual + (2f + c)*residual_stride for output channel c of frame f (the LPC residual or the
+ * fixed-LPC error signal, warm-up slots zero; all zeros for Constant / Verbatim).
+ * With use_fixed the other input of encode_subframe, `fixed_lpc` (src/coding.rs:298-331:
+ * reset_fixed_lpc_errors :182-197, estimate_entropy :200-227, select_order_and_encode_residual
+ * :230-288), runs on the GPU too, so the whole default-configuration decision is on the device.
  * Currently available for block_size 4096, lpc_order <= 12 and 16-byte aligned rows
  * (FLACENC_HIP_ERR_UNSUPPORTED otherwise: use flacenc_hip_stereo_qlpc_batch and decide on the host).
  */
@@ -232,6 +250,11 @@ int flacenc_hip_encode_stereo_frames_async(flacenc_hip_handle* h, const flacenc_
                                            size_t residual_stride, void* stream);
 
 int flacenc_hip_synchronize(flacenc_hip_handle* h);
+
+/* Test hook (no reference counterpart): when `device_keys` is non-NULL, launches with use_fixed
+ * store the order selector's key for each tried fixed order (estimate_entropy + bps*order, or
+ * the BitCount bits; src/coding.rs:249, :271) at device_keys[subframe*8 + order]. */
+int flacenc_hip_debug_set_fixed_keys(flacenc_hip_handle* h, unsigned long long* device_keys);
 
 /* Profiling hook (no reference counterpart): when `device_stamps` is non-NULL every
  * following launch makes each workgroup leader store 8 shader-clock timestamps

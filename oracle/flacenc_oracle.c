@@ -869,6 +869,211 @@ double orc_bench_stereo_qlpc(const int32_t* frames, size_t n_frames, size_t n, s
 }
 
 /* ------------------------------------------------------------------------ */
+/* fixed-LPC candidate, src/coding.rs:178-331                                 */
+/* ------------------------------------------------------------------------ */
+
+/* f32::log2 lowers to libm's log2f.  On the reference's Linux targets that is glibc
+ * (>= 2.27: sysdeps/ieee754/flt-32/e_log2f.c + e_log2f_data.c, S. Nagy's table method; the
+ * image has 2.35): 16-entry {1/c, log2 c} table, centre OFF = 0x3f330000, degree-4 polynomial
+ * in double, one rounding to float at the end.  Restated here so that oracle and kernel share
+ * one definition; tests/test_oracle_kat.py checks it against the host's log2f (exhaustively over
+ * all 2^31 positive floats with --full-log2f: 0 mismatches with and without fma contraction). */
+static const double orc_log2f_tab[16][2] = {
+    {0x1.661ec79f8f3bep+0, -0x1.efec65b963019p-2}, {0x1.571ed4aaf883dp+0, -0x1.b0b6832d4fca4p-2},
+    {0x1.49539f0f010bp+0, -0x1.7418b0a1fb77bp-2},  {0x1.3c995b0b80385p+0, -0x1.39de91a6dcf7bp-2},
+    {0x1.30d190c8864a5p+0, -0x1.01d9bf3f2b631p-2}, {0x1.25e227b0b8eap+0, -0x1.97c1d1b3b7afp-3},
+    {0x1.1bb4a4a1a343fp+0, -0x1.2f9e393af3c9fp-3}, {0x1.12358f08ae5bap+0, -0x1.960cbbf788d5cp-4},
+    {0x1.0953f419900a7p+0, -0x1.a6f9db6475fcep-5}, {0x1p+0, 0x0p+0},
+    {0x1.e608cfd9a47acp-1, 0x1.338ca9f24f53dp-4},  {0x1.ca4b31f026aap-1, 0x1.476a9543891bap-3},
+    {0x1.b2036576afce6p-1, 0x1.e840b4ac4e4d2p-3},  {0x1.9c2d163a1aa2dp-1, 0x1.40645f0c6651cp-2},
+    {0x1.886e6037841edp-1, 0x1.88e9c2c1b9ff8p-2},  {0x1.767dcf5534862p-1, 0x1.ce0a44eb17bccp-2},
+};
+static const double orc_log2f_poly[4] = {-0x1.712b6f70a7e4dp-2, 0x1.ecabf496832ep-2,
+                                         -0x1.715479ffae3dep-1, 0x1.715475f35c8b8p0};
+
+float orc_log2f(float x) {
+  uint32_t ix;
+  memcpy(&ix, &x, 4);
+  if (ix == 0x3f800000u) return 0.0f;
+  if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u) {
+    if (ix * 2u == 0) return -INFINITY;           /* log2(+-0) */
+    if (ix == 0x7f800000u) return x;              /* log2(inf) */
+    if ((ix & 0x80000000u) || ix * 2u >= 0xff000000u) return NAN; /* x < 0 or NaN */
+    float xs = x * 0x1p23f;                       /* subnormal: normalise */
+    memcpy(&ix, &xs, 4);
+    ix -= 23u << 23;
+  }
+  uint32_t tmp = ix - 0x3f330000u;
+  int i = (int)((tmp >> 19) & 15u);
+  uint32_t top = tmp & 0xff800000u;
+  uint32_t iz = ix - top;
+  int k = (int32_t)tmp >> 23;
+  float zf;
+  memcpy(&zf, &iz, 4);
+  double z = (double)zf;
+  double r = z * orc_log2f_tab[i][0] - 1.0;
+  double y0 = orc_log2f_tab[i][1] + (double)k;
+  double r2 = r * r;
+  double y = orc_log2f_poly[1] * r + orc_log2f_poly[2];
+  y = orc_log2f_poly[0] * r2 + y;
+  double p = orc_log2f_poly[3] * r + y0;
+  y = y * r2 + p;
+  return (float)y;
+}
+
+/* reset_fixed_lpc_errors, src/coding.rs:182-197: errors[0] = signal, errors[k+1][t] =
+ * errors[k][t] - errors[k][t-1] with errors[k][-1] = 0 (carry starts at 0), wrapping i32 lanes.
+ * The first k entries of errors[k] are therefore partial differences, not zeros. */
+void orc_reset_fixed_lpc_errors(const int32_t* signal, size_t n, int32_t* errors) {
+  memcpy(errors, signal, sizeof(int32_t) * n);
+  for (int order = 0; order < 4; ++order) {
+    const int32_t* cur = errors + (size_t)order * n;
+    int32_t* next = errors + (size_t)(order + 1) * n;
+    int32_t carry = 0;
+    for (size_t t = 0; t < n; ++t) {
+      next[t] = (int32_t)((uint32_t)cur[t] - (uint32_t)carry);
+      carry = cur[t];
+    }
+  }
+}
+
+static inline float orc_abs_as_f32(int32_t x) {
+  int32_t a = (int32_t)(x < 0 ? 0u - (uint32_t)x : (uint32_t)x); /* i32::abs, wrapping in release */
+  return (float)a;
+}
+
+/* arrayutils::find_sum_abs_f32::<16>, src/arrayutils.rs:496-506 via simd_map_and_reduce
+ * (:459-493).  ORC_SUMABS_STABLE: slice_as_simd = (data, [], []) (:435-438), one sequential f32
+ * chain.  ORC_SUMABS_NIGHTLY: `as_simd` splits at 64-byte boundaries (`base_mod` = element
+ * offset of data[0] from one; SimdVec storage is 64-byte aligned), 16 f32 lane sums + head/foot
+ * scalar chain, acc + ordered lane sum.  ORC_SUMABS_CANONICAL (the build's definition): the
+ * exact integer sum rounded to f32 once -- equal to both reference orders whenever every
+ * partial sum is < 2^24 (all 16-bit material at the default 16 partitions for orders 0-1,
+ * and any quiet signal), and inside their mutual spread otherwise. */
+float orc_find_sum_abs_f32(const int32_t* data, size_t len, int mode, size_t base_mod) {
+  if (mode == ORC_SUMABS_CANONICAL) {
+    uint64_t acc = 0;
+    for (size_t t = 0; t < len; ++t) acc += data[t] < 0 ? (uint64_t)(-(int64_t)data[t]) : (uint64_t)data[t];
+    return (float)acc; /* round to nearest even, once */
+  }
+  if (mode == ORC_SUMABS_STABLE) {
+    float acc = 0.0f;
+    for (size_t t = 0; t < len; ++t) acc = orc_abs_as_f32(data[t]) + acc;
+    return acc + 0.0f;
+  }
+  size_t mis = base_mod % 16;
+  size_t head = mis ? 16 - mis : 0;
+  if (head > len) head = len;
+  size_t nbody = (len - head) / 16;
+  float acc = 0.0f, acc_v[16];
+  for (int l = 0; l < 16; ++l) acc_v[l] = 0.0f;
+  size_t t = 0;
+  for (; t < head; ++t) acc = orc_abs_as_f32(data[t]) + acc;
+  for (size_t b = 0; b < nbody; ++b, t += 16)
+    for (int l = 0; l < 16; ++l) acc_v[l] = orc_abs_as_f32(data[t + l]) + acc_v[l];
+  for (; t < len; ++t) acc = orc_abs_as_f32(data[t]) + acc;
+  float lanes = 0.0f;
+  for (int l = 0; l < 16; ++l) lanes += acc_v[l];
+  return acc + lanes;
+}
+
+/* Rust `f32 as usize`: saturating, NaN -> 0 */
+static inline uint64_t orc_f32_as_usize(float v) {
+  if (!(v > 0.0f)) return 0;
+  if (v >= 18446744073709551616.0f) return UINT64_MAX;
+  return (uint64_t)v;
+}
+
+/* estimate_entropy, src/coding.rs:200-227 */
+uint64_t orc_estimate_entropy(const int32_t* errors, size_t n, size_t warmup_len, size_t partitions,
+                              int mode) {
+  size_t partition_size = (n + partitions - 1) / partitions;
+  size_t offset = 0;
+  uint64_t acc = 0;
+  for (size_t p = 0; p < partitions; ++p) {
+    size_t end = offset + partition_size < n ? offset + partition_size : n;
+    size_t partition_len = end - offset;
+    if (end >= warmup_len) {
+      size_t sample_count = end - warmup_len < partition_len ? end - warmup_len : partition_len;
+      float sum_errors = orc_find_sum_abs_f32(errors + offset, partition_len, mode, offset);
+      float avg_errors = sum_errors * 2.0f / ((float)sample_count + 0.00001f);
+      float geom_p = 1.0f / (avg_errors + 1.0f);
+      float xent = fmaf(avg_errors, -orc_log2f(1.0f - geom_p), -orc_log2f(geom_p));
+      acc += orc_f32_as_usize(xent * (float)sample_count);
+    }
+    offset = end;
+  }
+  return acc;
+}
+
+/* FIXED_LPC_COEFS, src/component/decode.rs:179-185 */
+const int16_t orc_fixed_lpc_coefs[5][4] = {
+    {0, 0, 0, 0}, {1, 0, 0, 0}, {2, -1, 0, 0}, {3, -3, 1, 0}, {4, -6, 4, -1}};
+
+/* fixed_lpc (src/coding.rs:298-331) = reset_fixed_lpc_errors + select_order_and_encode_residual
+ * (:230-288).  Returns 1 and fills `res` / `rice_params` / `errors_out` (the chosen order's error
+ * signal with the warm-up slots zeroed, as Residual stores them: coding.rs:151-160) when a
+ * candidate is produced (selector key < baseline_bits), 0 otherwise.  `res->estimate[k]` is the
+ * selector's key for order k either way.  min_by_key keeps the FIRST minimum. */
+int orc_fixed_lpc(const int32_t* signal, size_t n, uint32_t bps, uint64_t baseline_bits,
+                  const orc_fixed_config* fc, uint32_t max_rice_p, orc_fixed_result* res,
+                  uint8_t* rice_params, int32_t* errors_out) {
+  memset(res, 0, sizeof(*res));
+  int32_t* errors = (int32_t*)malloc(sizeof(int32_t) * n * 5);
+  orc_reset_fixed_lpc_errors(signal, n, errors);
+  static __thread orc_prc_parameter prc_storage, best_prc_storage;
+  orc_prc_parameter* prc = &prc_storage;
+  orc_prc_parameter* best_prc = &best_prc_storage;
+  uint32_t best_order = 0;
+  uint64_t best_bits = UINT64_MAX;
+  int have = 0;
+  for (uint32_t order = 0; order <= fc->max_order && order <= 4; ++order) {
+    const int32_t* err = errors + (size_t)order * n;
+    uint64_t bits;
+    if (fc->order_sel == ORC_ORDERSEL_BITCOUNT) {
+      orc_find_partitioned_rice_parameter(err, n, order, max_rice_p, prc);
+      bits = (uint64_t)bps * order + prc->code_bits;
+    } else {
+      bits = orc_estimate_entropy(err, n, order, fc->partitions, (int)fc->sum_mode) + (uint64_t)bps * order;
+    }
+    res->estimate[order] = bits;
+    if (!have || bits < best_bits) {
+      have = 1;
+      best_bits = bits;
+      best_order = order;
+      if (fc->order_sel == ORC_ORDERSEL_BITCOUNT) {
+        best_prc->order = prc->order;
+        best_prc->code_bits = prc->code_bits;
+        memcpy(best_prc->ps, prc->ps, (size_t)1 << prc->order);
+      }
+    }
+  }
+  res->order = best_order;
+  int selected = have && best_bits < baseline_bits;
+  if (selected) {
+    const int32_t* err = errors + (size_t)best_order * n;
+    if (fc->order_sel != ORC_ORDERSEL_BITCOUNT)
+      orc_find_partitioned_rice_parameter(err, n, best_order, max_rice_p, best_prc);
+    res->rice_order = best_prc->order;
+    res->code_bits = best_prc->code_bits;
+    memcpy(rice_params, best_prc->ps, (size_t)1 << best_prc->order);
+    orc_encode_residual_with_prc_parameter(err, n, best_order, best_prc, NULL, NULL,
+                                           &res->sum_quotients, &res->sum_rice_params);
+    res->residual_bits = orc_residual_count_bits(n, best_order, best_prc->order, best_prc->ps,
+                                                 res->sum_quotients, res->sum_rice_params);
+    /* BitRepr for FixedLpc::count_bits, src/component/bitrepr.rs:473-477 */
+    res->subframe_bits = 8 + (uint64_t)bps * best_order + res->residual_bits;
+    if (errors_out) {
+      memcpy(errors_out, err, sizeof(int32_t) * n);
+      for (size_t t = 0; t < best_order && t < n; ++t) errors_out[t] = 0;
+    }
+  }
+  res->selected = selected;
+  free(errors);
+  return selected;
+}
+
+/* ------------------------------------------------------------------------ */
 /* encode_subframe / try_stereo_coding restricted to the candidates the GPU  */
 /* path produces (use_fixed = false)                                         */
 /* ------------------------------------------------------------------------ */
@@ -881,21 +1086,61 @@ double orc_bench_stereo_qlpc(const int32_t* frames, size_t n_frames, size_t n, s
 int orc_encode_subframe_nofixed(const int32_t* samples, size_t n, uint32_t bps, int use_constant,
                                 int use_lpc, const orc_qlpc_config* cfg, uint64_t* bits_out,
                                 orc_qlpc_result* lpc, uint8_t* rice_params, int32_t* errors) {
-  if (use_constant && orc_is_constant(samples, n)) {
+  orc_frame_config fc;
+  memset(&fc, 0, sizeof(fc));
+  fc.qlpc = *cfg;
+  fc.use_constant = (uint32_t)use_constant;
+  fc.use_lpc = (uint32_t)use_lpc;
+  orc_fixed_result fixed;
+  return orc_encode_subframe(samples, n, bps, &fc, bits_out, lpc, &fixed, rice_params, errors);
+}
+
+/* encode_subframe, src/coding.rs:384-418, all candidates.  kind: 0 Constant, 1 Verbatim,
+ * 2 FixedLpc, 3 Lpc.  `rice_params` / `errors` receive the chosen candidate's Rice parameters and
+ * error signal (kind 2 or 3). */
+int orc_encode_subframe(const int32_t* samples, size_t n, uint32_t bps, const orc_frame_config* fc,
+                        uint64_t* bits_out, orc_qlpc_result* lpc, orc_fixed_result* fixed,
+                        uint8_t* rice_params, int32_t* errors) {
+  memset(fixed, 0, sizeof(*fixed));
+  if (fc->use_constant && orc_is_constant(samples, n)) {
     *bits_out = 8 + bps; /* Constant::count_bits, bitrepr.rs:445 */
     return 0;
   }
   uint64_t verbatim_bits = orc_verbatim_count_bits(n, bps);
   int too_short = n < 64; /* MIN_BLOCK_SIZE_FOR_PREDICTION, constant.rs:51 */
-  if (!too_short && use_lpc) {
-    orc_estimated_qlpc(samples, n, bps, cfg, lpc, rice_params, errors, NULL, NULL);
-    if (lpc->status == ORC_STATUS_OK && lpc->subframe_bits < verbatim_bits) {
-      *bits_out = lpc->subframe_bits;
-      return 3;
+  int have_fixed = 0;
+  uint8_t* fixed_rp = NULL;
+  int32_t* fixed_err = NULL;
+  if (!too_short && fc->use_fixed) {
+    fixed_rp = (uint8_t*)calloc(ORC_MAX_RICE_PARTITIONS, 1);
+    fixed_err = (int32_t*)calloc(n, sizeof(int32_t));
+    have_fixed = orc_fixed_lpc(samples, n, bps, verbatim_bits, &fc->fixed, fc->qlpc.max_rice_parameter,
+                               fixed, fixed_rp, fixed_err);
+  }
+  uint64_t baseline_bits = verbatim_bits;
+  if (have_fixed && fixed->subframe_bits < baseline_bits) baseline_bits = fixed->subframe_bits;
+  int kind = 1;
+  uint64_t bits = verbatim_bits;
+  int have_lpc = 0;
+  if (!too_short && fc->use_lpc) {
+    orc_estimated_qlpc(samples, n, bps, &fc->qlpc, lpc, rice_params, errors, NULL, NULL);
+    have_lpc = lpc->status == ORC_STATUS_OK && lpc->subframe_bits < baseline_bits;
+  }
+  /* est_lpc.or(fixed).filter(|sf| sf.count_bits() < verbatim_bits) */
+  if (have_lpc) {
+    if (lpc->subframe_bits < verbatim_bits) { kind = 3; bits = lpc->subframe_bits; }
+  } else if (have_fixed) {
+    if (fixed->subframe_bits < verbatim_bits) {
+      kind = 2;
+      bits = fixed->subframe_bits;
+      memcpy(rice_params, fixed_rp, (size_t)1 << fixed->rice_order);
+      memcpy(errors, fixed_err, sizeof(int32_t) * n);
     }
   }
-  *bits_out = verbatim_bits;
-  return 1;
+  free(fixed_rp);
+  free(fixed_err);
+  *bits_out = bits;
+  return kind;
 }
 
 /* encode_frame for 2 channels (src/coding.rs:530-544) = encode_frame_impl(Independent(2)) +
@@ -904,11 +1149,26 @@ void orc_encode_stereo_frame(const int32_t* l, const int32_t* r, size_t n, uint3
                              const orc_qlpc_config* cfg, int use_constant, int use_lpc,
                              int use_leftside, int use_rightside, int use_midside,
                              orc_stereo_frame_result* out, int32_t* residual0, int32_t* residual1) {
+  orc_frame_config fc;
+  memset(&fc, 0, sizeof(fc));
+  fc.qlpc = *cfg;
+  fc.use_constant = (uint32_t)use_constant;
+  fc.use_lpc = (uint32_t)use_lpc;
+  fc.use_leftside = (uint32_t)use_leftside;
+  fc.use_rightside = (uint32_t)use_rightside;
+  fc.use_midside = (uint32_t)use_midside;
+  orc_encode_stereo_frame_cfg(l, r, n, bps, &fc, out, residual0, residual1);
+}
+
+void orc_encode_stereo_frame_cfg(const int32_t* l, const int32_t* r, size_t n, uint32_t bps,
+                                 const orc_frame_config* fc, orc_stereo_frame_result* out,
+                                 int32_t* residual0, int32_t* residual1) {
   int32_t* m = (int32_t*)malloc(sizeof(int32_t) * n);
   int32_t* s = (int32_t*)malloc(sizeof(int32_t) * n);
   int32_t* err[4];
   uint8_t* rp[4];
   orc_qlpc_result res[4];
+  orc_fixed_result fres[4];
   int kind[4];
   uint64_t bits[4];
   const int32_t* sig[4];
@@ -918,15 +1178,15 @@ void orc_encode_stereo_frame(const int32_t* l, const int32_t* r, size_t n, uint3
     err[k] = (int32_t*)calloc(n, sizeof(int32_t));
     rp[k] = (uint8_t*)calloc(ORC_MAX_RICE_PARTITIONS, 1);
     memset(&res[k], 0, sizeof(res[k]));
-    kind[k] = orc_encode_subframe_nofixed(sig[k], n, bps + (k == 3 ? 1 : 0), use_constant, use_lpc, cfg,
-                                          &bits[k], &res[k], rp[k], err[k]);
+    kind[k] = orc_encode_subframe(sig[k], n, bps + (k == 3 ? 1 : 0), fc, &bits[k], &res[k], &fres[k],
+                                  rp[k], err[k]);
   }
   /* src/coding.rs:493-522 */
   uint64_t min_bits = bits[0] + bits[1];
   int assignment = 0; /* Independent(2) */
-  if (use_leftside && bits[0] + bits[3] < min_bits) { min_bits = bits[0] + bits[3]; assignment = 1; }
-  if (use_rightside && bits[1] + bits[3] < min_bits) { min_bits = bits[1] + bits[3]; assignment = 2; }
-  if (use_midside && bits[2] + bits[3] < min_bits) { min_bits = bits[2] + bits[3]; assignment = 3; }
+  if (fc->use_leftside && bits[0] + bits[3] < min_bits) { min_bits = bits[0] + bits[3]; assignment = 1; }
+  if (fc->use_rightside && bits[1] + bits[3] < min_bits) { min_bits = bits[1] + bits[3]; assignment = 2; }
+  if (fc->use_midside && bits[2] + bits[3] < min_bits) { min_bits = bits[2] + bits[3]; assignment = 3; }
   /* ChannelAssignment::select_channels, datatype.rs:1173-1185 */
   int role0 = assignment == 2 ? 3 : (assignment == 3 ? 2 : 0);
   int role1 = assignment == 0 ? 1 : (assignment == 2 ? 1 : 3);
@@ -939,8 +1199,8 @@ void orc_encode_stereo_frame(const int32_t* l, const int32_t* r, size_t n, uint3
     out->role[c] = (uint8_t)k;
     out->kind[c] = (uint8_t)kind[k];
     out->dc_offset[c] = kind[k] == 0 ? sig[k][0] : 0;
+    orc_subframe_record* rec = &out->lpc[c];
     if (kind[k] == 3) {
-      orc_subframe_record* rec = &out->lpc[c];
       for (int i = 0; i < 32; ++i) rec->coefs[i] = res[k].qp.coefs[i];
       rec->order = (uint8_t)res[k].qp.order;
       rec->shift = (int8_t)res[k].qp.shift;
@@ -951,6 +1211,19 @@ void orc_encode_stereo_frame(const int32_t* l, const int32_t* r, size_t n, uint3
       rec->subframe_bits = res[k].subframe_bits;
       rec->sum_quotients = res[k].sum_quotients;
       memcpy(rec->rice_params, rp[k], (size_t)1 << res[k].rice_order);
+      if (resid_out[c]) memcpy(resid_out[c], err[k], sizeof(int32_t) * n);
+    } else if (kind[k] == 2) {
+      /* FixedLpc: the record carries FIXED_LPC_COEFS[order] with shift 0 (decode.rs:187-201) */
+      for (int i = 0; i < 4; ++i) rec->coefs[i] = orc_fixed_lpc_coefs[fres[k].order][i];
+      rec->order = (uint8_t)fres[k].order;
+      rec->shift = 0;
+      rec->precision = 0;
+      rec->rice_order = (uint8_t)fres[k].rice_order;
+      rec->status = 0;
+      rec->code_bits = fres[k].code_bits;
+      rec->subframe_bits = fres[k].subframe_bits;
+      rec->sum_quotients = fres[k].sum_quotients;
+      memcpy(rec->rice_params, rp[k], (size_t)1 << fres[k].rice_order);
       if (resid_out[c]) memcpy(resid_out[c], err[k], sizeof(int32_t) * n);
     } else if (resid_out[c]) {
       memset(resid_out[c], 0, sizeof(int32_t) * n);

@@ -45,6 +45,15 @@ extern "C" {
 #define ORC_ACORR_CANONICAL 1 /* the build's canonical order: 16-sample chunk chains + balanced tree */
 #define ORC_ACORR_NIGHTLY 2   /* weighted_auto_correlation_simd, src/lpc.rs:510-531 (aligned buffer) */
 
+/* find_sum_abs_f32 summation orders (src/arrayutils.rs:496-506) */
+#define ORC_SUMABS_STABLE 0    /* stable build: one sequential f32 chain */
+#define ORC_SUMABS_NIGHTLY 1   /* simd-nightly: 16 f32 lanes + head/foot */
+#define ORC_SUMABS_CANONICAL 2 /* the build's definition: exact integer sum, rounded to f32 once */
+
+/* config::OrderSel, src/config.rs:400-409 */
+#define ORC_ORDERSEL_BITCOUNT 0
+#define ORC_ORDERSEL_APPROXENT 1
+
 #define ORC_STATUS_OK 0
 #define ORC_STATUS_NONFINITE 1   /* the reference would panic (src/lpc.rs:786-799) */
 #define ORC_STATUS_NEG_ENERGY 2  /* the reference would panic (src/lpc.rs:646) */
@@ -86,6 +95,32 @@ typedef struct {
   double autocorr[ORC_MAX_LPC_ORDER + 1];
   double lpc_coefs[ORC_MAX_LPC_ORDER];
 } orc_qlpc_result;
+
+/* config::Fixed (src/config.rs:236-244) */
+typedef struct {
+  uint32_t max_order;  /* ..=4, src/constant.rs:95 */
+  uint32_t order_sel;  /* ORC_ORDERSEL_* (default ApproxEnt) */
+  uint32_t partitions; /* ApproxEnt.partitions, 1..=64, default 16 (src/constant.rs:35, :63) */
+  uint32_t sum_mode;   /* ORC_SUMABS_* */
+} orc_fixed_config;
+
+/* config::SubFrameCoding (src/config.rs:167-183) + config::StereoCoding (:137-144) */
+typedef struct {
+  orc_qlpc_config qlpc;
+  uint32_t use_constant, use_fixed, use_lpc;
+  uint32_t use_leftside, use_rightside, use_midside;
+  orc_fixed_config fixed;
+} orc_frame_config;
+
+/* what fixed_lpc (src/coding.rs:298-331) produced */
+typedef struct {
+  int32_t selected;     /* Some(..) / None */
+  uint32_t order;       /* the selector's argmin (first minimum) */
+  uint64_t estimate[5]; /* selector key per order: ApproxEnt estimate or BitCount bits, + bps*order */
+  uint32_t rice_order;
+  uint64_t code_bits, sum_quotients, sum_rice_params, residual_bits;
+  uint64_t subframe_bits; /* FixedLpc::count_bits, bitrepr.rs:473-477 */
+} orc_fixed_result;
 
 /* ---- lpc.rs ---- */
 void orc_window_weights(uint32_t window_type, float alpha, size_t len, float* out);
@@ -173,13 +208,29 @@ double orc_bench_qlpc(const int32_t* samples, size_t n_subframes, size_t n, size
 /* mirrors flacenc_hip_stereo_frame_result (include/flacenc_hip.h) */
 typedef struct {
   uint8_t channel_assignment; /* 0 Independent(2), 1 LeftSide, 2 RightSide, 3 MidSide */
-  uint8_t kind[2];            /* 0 Constant, 1 Verbatim, 3 Lpc */
+  uint8_t kind[2];            /* 0 Constant, 1 Verbatim, 2 FixedLpc, 3 Lpc */
   uint8_t role[2];            /* 0 L, 1 R, 2 M, 3 S */
   uint8_t pad[3];
   int32_t dc_offset[2];
   uint64_t bits[4];
   orc_subframe_record lpc[2];
 } orc_stereo_frame_result;
+
+float orc_log2f(float x);
+void orc_reset_fixed_lpc_errors(const int32_t* signal, size_t n, int32_t* errors /* [5][n] */);
+float orc_find_sum_abs_f32(const int32_t* data, size_t len, int mode, size_t base_mod);
+uint64_t orc_estimate_entropy(const int32_t* errors, size_t n, size_t warmup_len, size_t partitions,
+                              int mode);
+extern const int16_t orc_fixed_lpc_coefs[5][4];
+int orc_fixed_lpc(const int32_t* signal, size_t n, uint32_t bps, uint64_t baseline_bits,
+                  const orc_fixed_config* fc, uint32_t max_rice_p, orc_fixed_result* res,
+                  uint8_t* rice_params, int32_t* errors_out);
+int orc_encode_subframe(const int32_t* samples, size_t n, uint32_t bps, const orc_frame_config* fc,
+                        uint64_t* bits_out, orc_qlpc_result* lpc, orc_fixed_result* fixed,
+                        uint8_t* rice_params, int32_t* errors);
+void orc_encode_stereo_frame_cfg(const int32_t* l, const int32_t* r, size_t n, uint32_t bps,
+                                 const orc_frame_config* fc, orc_stereo_frame_result* out,
+                                 int32_t* residual0, int32_t* residual1);
 
 int orc_encode_subframe_nofixed(const int32_t* samples, size_t n, uint32_t bps, int use_constant,
                                 int use_lpc, const orc_qlpc_config* cfg, uint64_t* bits_out,

@@ -18,6 +18,13 @@ _LIB_PATH = os.path.join(_HERE, "libflacenc_oracle.so")
 ACORR_REFERENCE = 0
 ACORR_CANONICAL = 1
 ACORR_NIGHTLY = 2
+SUMABS_STABLE = 0
+SUMABS_NIGHTLY = 1
+SUMABS_CANONICAL = 2
+ORDERSEL_BITCOUNT = 0
+ORDERSEL_APPROXENT = 1
+KIND_CONSTANT, KIND_VERBATIM, KIND_FIXED, KIND_LPC = 0, 1, 2, 3
+FIXED_LPC_COEFS = [[0, 0, 0, 0], [1, 0, 0, 0], [2, -1, 0, 0], [3, -3, 1, 0], [4, -6, 4, -1]]
 WINDOW_RECTANGLE = 0
 WINDOW_TUKEY = 1
 MAX_P_TO_BITS = (1 << 27) - 1
@@ -45,6 +52,26 @@ class QlpcConfig(C.Structure):
         ("max_rice_parameter", C.c_uint32),
         ("acorr_order", C.c_uint32),
     ]
+
+
+class FixedConfig(C.Structure):
+    """config::Fixed, src/config.rs:236-244."""
+    _fields_ = [("max_order", C.c_uint32), ("order_sel", C.c_uint32), ("partitions", C.c_uint32),
+                ("sum_mode", C.c_uint32)]
+
+
+class FrameConfig(C.Structure):
+    """config::SubFrameCoding + config::StereoCoding, src/config.rs:167-183, 137-144."""
+    _fields_ = [("qlpc", QlpcConfig), ("use_constant", C.c_uint32), ("use_fixed", C.c_uint32),
+                ("use_lpc", C.c_uint32), ("use_leftside", C.c_uint32), ("use_rightside", C.c_uint32),
+                ("use_midside", C.c_uint32), ("fixed", FixedConfig)]
+
+
+class FixedResult(C.Structure):
+    _fields_ = [("selected", C.c_int32), ("order", C.c_uint32), ("estimate", C.c_uint64 * 5),
+                ("rice_order", C.c_uint32), ("code_bits", C.c_uint64), ("sum_quotients", C.c_uint64),
+                ("sum_rice_params", C.c_uint64), ("residual_bits", C.c_uint64),
+                ("subframe_bits", C.c_uint64)]
 
 
 class QParams(C.Structure):
@@ -189,6 +216,38 @@ def _declare(L):
     L.orc_encode_stereo_frame.argtypes = [i32p, i32p, C.c_size_t, C.c_uint32, C.POINTER(QlpcConfig),
                                           C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                           i32p, i32p]
+
+
+    L.orc_log2f.argtypes = [C.c_float]
+    L.orc_log2f.restype = C.c_float
+    L.orc_reset_fixed_lpc_errors.argtypes = [i32p, C.c_size_t, i32p]
+    L.orc_find_sum_abs_f32.argtypes = [i32p, C.c_size_t, C.c_int, C.c_size_t]
+    L.orc_find_sum_abs_f32.restype = C.c_float
+    L.orc_estimate_entropy.argtypes = [i32p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int]
+    L.orc_estimate_entropy.restype = C.c_uint64
+    L.orc_fixed_lpc.argtypes = [i32p, C.c_size_t, C.c_uint32, C.c_uint64, C.POINTER(FixedConfig),
+                                C.c_uint32, C.POINTER(FixedResult), u8p, i32p]
+    L.orc_fixed_lpc.restype = C.c_int
+    L.orc_encode_subframe.argtypes = [i32p, C.c_size_t, C.c_uint32, C.POINTER(FrameConfig),
+                                      C.POINTER(C.c_uint64), C.POINTER(QlpcResult),
+                                      C.POINTER(FixedResult), u8p, i32p]
+    L.orc_encode_subframe.restype = C.c_int
+    L.orc_encode_stereo_frame_cfg.argtypes = [i32p, i32p, C.c_size_t, C.c_uint32,
+                                              C.POINTER(FrameConfig), C.c_void_p, i32p, i32p]
+
+
+def make_fixed_config(max_order=4, order_sel=ORDERSEL_APPROXENT, partitions=16,
+                      sum_mode=SUMABS_STABLE) -> FixedConfig:
+    """config::Fixed defaults: max_order 4 (constant.rs:95), ApproxEnt{16} (config.rs:411-417)."""
+    return FixedConfig(max_order, order_sel, partitions, sum_mode)
+
+
+def make_frame_config(qlpc=None, use_constant=True, use_fixed=True, use_lpc=True, use_leftside=True,
+                      use_rightside=True, use_midside=True, fixed=None) -> FrameConfig:
+    """config::SubFrameCoding / StereoCoding defaults: everything on (config.rs:185-196, 146-154)."""
+    return FrameConfig(qlpc or make_config(), int(use_constant), int(use_fixed), int(use_lpc),
+                       int(use_leftside), int(use_rightside), int(use_midside),
+                       fixed or make_fixed_config())
 
 
 def make_config(lpc_order=10, quant_precision=15, window=("tukey", 0.4), max_rice_parameter=30,
@@ -450,6 +509,85 @@ def midside_to_stereo(m, s):
 def is_constant(samples) -> bool:
     s = np.ascontiguousarray(samples, np.int32)
     return bool(lib().orc_is_constant(_p(s, C.c_int32), len(s)))
+
+
+# ------------------------------------------------------ fixed LPC ----
+def log2f(x: float) -> float:
+    return float(lib().orc_log2f(float(np.float32(x))))
+
+
+def reset_fixed_lpc_errors(signal) -> np.ndarray:
+    """reset_fixed_lpc_errors, src/coding.rs:182-197 -> int32 [5, n]."""
+    x = np.ascontiguousarray(signal, np.int32)
+    out = np.zeros((5, len(x)), np.int32)
+    lib().orc_reset_fixed_lpc_errors(_p(x, C.c_int32), len(x), _p(out, C.c_int32))
+    return out
+
+
+def find_sum_abs_f32(data, mode=SUMABS_STABLE, base_mod=0) -> float:
+    x = np.ascontiguousarray(data, np.int32)
+    return float(lib().orc_find_sum_abs_f32(_p(x, C.c_int32), len(x), mode, base_mod))
+
+
+def estimate_entropy(errors, warmup_len: int, partitions: int, mode=SUMABS_STABLE) -> int:
+    x = np.ascontiguousarray(errors, np.int32)
+    return int(lib().orc_estimate_entropy(_p(x, C.c_int32), len(x), warmup_len, partitions, mode))
+
+
+def fixed_lpc(signal, bits_per_sample: int, baseline_bits: int, fixed: FixedConfig = None,
+              max_p: int = 30):
+    """fixed_lpc, src/coding.rs:298-331 -> dict or None (the Option)."""
+    x = np.ascontiguousarray(signal, np.int32)
+    n = len(x)
+    fc = fixed or make_fixed_config()
+    res = FixedResult()
+    rp = np.zeros(32768, np.uint8)
+    err = np.zeros(n, np.int32)
+    sel = lib().orc_fixed_lpc(_p(x, C.c_int32), n, bits_per_sample, min(baseline_bits, 2 ** 64 - 1),
+                              C.byref(fc), max_p, C.byref(res), _p(rp, C.c_uint8), _p(err, C.c_int32))
+    out = {"selected": bool(sel), "order": int(res.order), "estimate": list(res.estimate)}
+    if sel:
+        out.update(rice_order=int(res.rice_order), code_bits=int(res.code_bits),
+                   sum_quotients=int(res.sum_quotients), residual_bits=int(res.residual_bits),
+                   subframe_bits=int(res.subframe_bits), rice_params=rp[:1 << res.rice_order].copy(),
+                   residual=err, warm_up=x[:res.order].copy())
+    return out
+
+
+def decode_fixed(warm_up, residual) -> np.ndarray:
+    """Decode for FixedLpc, src/component/decode.rs:187-201."""
+    order = len(warm_up)
+    return decode_lpc(warm_up, np.array(FIXED_LPC_COEFS[order][:order], np.int16), 0, residual)
+
+
+def encode_subframe(samples, bits_per_sample: int, fc: FrameConfig) -> dict:
+    """encode_subframe, src/coding.rs:384-418."""
+    x = np.ascontiguousarray(samples, np.int32)
+    n = len(x)
+    bits = C.c_uint64()
+    lpc, fixed = QlpcResult(), FixedResult()
+    rp = np.zeros(32768, np.uint8)
+    err = np.zeros(n, np.int32)
+    kind = lib().orc_encode_subframe(_p(x, C.c_int32), n, bits_per_sample, C.byref(fc), C.byref(bits),
+                                     C.byref(lpc), C.byref(fixed), _p(rp, C.c_uint8), _p(err, C.c_int32))
+    return {"kind": kind, "bits": int(bits.value), "lpc": lpc, "fixed": fixed, "rice_params": rp,
+            "residual": err}
+
+
+def encode_stereo_frames_cfg(frames, bps: int, fc: FrameConfig):
+    """encode_frame for 2-channel frames (src/coding.rs:530-544, 469-527), every candidate.
+
+    `frames` int32 [n_frames, 2, n] -> (results FRAME_RESULT_DTYPE [n_frames], residual [n_frames, 2, n])."""
+    x = np.ascontiguousarray(frames, np.int32)
+    nf, ch, n = x.shape
+    assert ch == 2
+    out = np.zeros(nf, FRAME_RESULT_DTYPE)
+    resid = np.zeros((nf, 2, n), np.int32)
+    for f in range(nf):
+        lib().orc_encode_stereo_frame_cfg(_p(x[f, 0], C.c_int32), _p(x[f, 1], C.c_int32), n, bps,
+                                          C.byref(fc), out[f:f + 1].ctypes.data_as(C.c_void_p),
+                                          _p(resid[f, 0], C.c_int32), _p(resid[f, 1], C.c_int32))
+    return out, resid
 
 
 def bench_qlpc(samples, bits_per_sample: int, cfg: QlpcConfig, nthreads: int, repeats: int = 1):

@@ -475,11 +475,165 @@ def test_encode_stereo_frames_decision_equals_reference_controller(handle, order
         assert np.array_equal(ch[0], x[f, 0]) and np.array_equal(ch[1], x[f, 1]), f
 
 
+def _fixed_corpus(n=4096, bps=16):
+    """_stereo_corpus plus frames on which the fixed-LPC candidate beats the QLPC one (smooth
+    ramps / parabolas / steps / square waves / quiet 8-bit-like tones) and loud material on
+    which the estimator's sums exceed 2^24."""
+    t = np.arange(n)
+    extra = [
+        np.stack([(t // 7), (t // 5) + 3]),
+        np.stack([(t - 2048) ** 2 // 400, (t - 1000) ** 2 // 300 - 2000]),
+        np.stack([np.repeat(np.arange(64) * 10, 64), np.repeat(np.arange(32) * 25, 128)]),
+        np.stack([(t // 50 % 2) * 200 - 100, (t // 80 % 2) * 300 - 150]),
+        np.stack([np.abs((t % 200) - 100) * 50, np.abs((t % 300) - 150) * 40]),
+        np.stack([util.quantize(util.sine(n, 100, 0.6), 8), util.quantize(util.sine(n, 70, 0.5, phase=1.0), 8)]),
+        np.stack([util.quantize(util.noise(7, n, 0.999), bps), util.quantize(util.sine(n, 3.1, 0.99), bps)]),
+        np.stack([util.sine_noise(n, bps, 2.3, 0.9, 0.09, seed=8), util.sine_noise(n, bps, 2.7, 0.9, 0.09, seed=9)]),
+    ]
+    return np.concatenate([_stereo_corpus(n, bps), np.stack(extra).astype(np.int32)])
+
+
+def _check_frames_against_oracle(x, bps, got, gres, want, wres):
+    for f in range(x.shape[0]):
+        g, w = got[f], want[f]
+        assert int(g["channel_assignment"]) == int(w["channel_assignment"]), f
+        assert g["role"].tolist() == w["role"].tolist(), f
+        assert g["kind"].tolist() == w["kind"].tolist(), f
+        assert g["dc_offset"].tolist() == w["dc_offset"].tolist(), f
+        assert g["bits"].tolist() == w["bits"].tolist(), f
+        for c in range(2):
+            if int(g["kind"][c]) >= 2:
+                gl, wl = g["lpc"][c], w["lpc"][c]
+                for fld in ("order", "shift", "precision", "rice_order", "status", "code_bits",
+                            "subframe_bits", "sum_quotients"):
+                    assert int(gl[fld]) == int(wl[fld]), (f, c, fld)
+                assert gl["coefs"].tolist() == wl["coefs"].tolist()
+                assert gl["rice_params"].tolist() == wl["rice_params"].tolist()
+            assert np.array_equal(gres[f, c], wres[f, c]), (f, c)
+
+
+def _decode_frames(x, got, gres):
+    """Decode for Frame / SubFrame (decode.rs:61-113, 159-217): Constant, Verbatim, FixedLpc, Lpc."""
+    n = x.shape[2]
+    for f in range(x.shape[0]):
+        g = got[f]
+        ch = []
+        for c in range(2):
+            role = int(g["role"][c])
+            l, r = x[f, 0], x[f, 1]
+            sig = [l, r, *orc.stereo_to_midside(l, r)][role]
+            kind = int(g["kind"][c])
+            if kind == 0:
+                ch.append(np.full(n, int(g["dc_offset"][c]), np.int32))
+            elif kind == 1:
+                ch.append(sig.copy())
+            else:
+                p = g["lpc"][c]
+                k = int(p["order"])
+                if kind == 2:
+                    assert p["coefs"][:4].tolist() == orc.FIXED_LPC_COEFS[k] and int(p["shift"]) == 0
+                ch.append(orc.decode_lpc(sig[:k], p["coefs"][:k], int(p["shift"]), gres[f, c]))
+        a = int(g["channel_assignment"])
+        if a == 1:
+            ch[1] = ch[0] - ch[1]
+        elif a == 2:
+            ch[0] = ch[0] + ch[1]
+        elif a == 3:
+            ch[0], ch[1] = orc.midside_to_stereo(ch[0], ch[1])
+        assert np.array_equal(ch[0], x[f, 0]) and np.array_equal(ch[1], x[f, 1]), f
+
+
+@pytest.mark.parametrize("order,fixed", [
+    (8, dict()), (10, dict(fixed_max_order=2)), (12, dict(fixed_partitions=64)),
+    (8, dict(fixed_partitions=1)), (8, dict(fixed_partitions=4, fixed_max_order=3)),
+    (8, dict(fixed_order_sel=0)), (10, dict(fixed_order_sel=0, fixed_max_order=1)),
+    (8, dict(fixed_max_order=0)),
+])
+def test_encode_stereo_frames_with_fixed_lpc_candidate(handle, order, fixed):
+    """The reference's default SubFrameCoding (use_fixed = true): fixed_lpc (coding.rs:298-331) with
+    either order selector, encode_subframe's three-way choice (coding.rs:384-418) and
+    try_stereo_coding, all on the GPU == the oracle with the canonical summation definitions."""
+    bps = 16
+    x = _fixed_corpus()
+    cfg = _capi.make_frame_config(gpu_cfg(order), use_fixed=True, **fixed)
+    got, gres = handle.encode_stereo_frames(x, bps, cfg)
+    ofixed = orc.make_fixed_config(max_order=fixed.get("fixed_max_order", 4),
+                                   order_sel=fixed.get("fixed_order_sel", 1),
+                                   partitions=fixed.get("fixed_partitions", 16),
+                                   sum_mode=orc.SUMABS_CANONICAL)
+    ocfg = orc.make_frame_config(orc_cfg(order, acorr=orc.ACORR_CANONICAL), use_fixed=True, fixed=ofixed)
+    want, wres = orc.encode_stereo_frames_cfg(x, bps, ocfg)
+    _check_frames_against_oracle(x, bps, got, gres, want, wres)
+    if not fixed:
+        assert set(got["kind"].ravel().tolist()) == {0, 1, 2, 3}
+    _decode_frames(x, got, gres)
+
+
+def test_fixed_lpc_selector_keys_equal_oracle(handle):
+    """The selector's per-order keys (estimate_entropy + bps*order, coding.rs:271; BitCount bits,
+    coding.rs:249) for L, R, M, S of every frame, bit for bit; and against the reference's own two
+    summation orders wherever every partition sum stays below 2^24."""
+    import torch
+    bps = 16
+    x = _fixed_corpus()
+    F = x.shape[0]
+    for sel in (1, 0):
+        keys = torch.zeros((F * 4, 8), dtype=torch.int64, device="cuda")
+        handle.debug_set_fixed_keys(keys.data_ptr())
+        try:
+            handle.encode_stereo_frames(x, bps, _capi.make_frame_config(gpu_cfg(8), use_fixed=True,
+                                                                         fixed_order_sel=sel))
+        finally:
+            handle.debug_set_fixed_keys(0)
+        k = keys.cpu().numpy().astype(np.uint64).reshape(F, 4, 8)
+        exact_everywhere = 0
+        for f in range(F):
+            l, r = x[f, 0], x[f, 1]
+            for role, sig in enumerate([l, r, *orc.stereo_to_midside(l, r)]):
+                b = bps + (1 if role == 3 else 0)
+                fc = orc.make_fixed_config(order_sel=sel, sum_mode=orc.SUMABS_CANONICAL)
+                want = orc.fixed_lpc(sig, b, 2 ** 63, fc)["estimate"]
+                assert k[f, role, :5].tolist() == want, (sel, f, role)
+                if sel == 1:
+                    errs = orc.reset_fixed_lpc_errors(sig)
+                    small = all(np.abs(errs[o].astype(np.int64)).reshape(16, -1).sum(axis=1).max() < 2 ** 24
+                                for o in range(5))
+                    if small:
+                        exact_everywhere += 1
+                        for mode in (orc.SUMABS_STABLE, orc.SUMABS_NIGHTLY):
+                            ref = orc.fixed_lpc(sig, b, 2 ** 63, orc.make_fixed_config(sum_mode=mode))
+                            assert ref["estimate"] == want, (f, role, mode)
+        if sel == 1:
+            assert exact_everywhere >= 2 * F  # most of the corpus is in the exactly-pinned regime
+
+
+def test_encode_stereo_frames_fixed_24bit(handle):
+    """24-bit material: the side channel has 25 bits, order-4 differences reach 2^28 and the
+    estimator's partition sums 2^36 -- the exact-integer sums must still agree."""
+    bps = 24
+    x = _capi.sigen_frames(6, 2, 4096, bps, 37.0, 0.7, 0.2, seed=77)
+    x[1] = x[1] // 4096
+    x[2, 1] = -x[2, 0]
+    x[3] = (np.arange(4096)[None, :] * np.array([[1000], [-900]])).astype(np.int32)
+    x[4, 0] = np.where(np.arange(4096) % 2 == 0, 2 ** 23 - 1, -2 ** 23)   # worst-case alternation
+    x[4, 1] = -x[4, 0] - 1
+    cfg = _capi.make_frame_config(gpu_cfg(8), use_fixed=True)
+    got, gres = handle.encode_stereo_frames(x, bps, cfg)
+    ocfg = orc.make_frame_config(orc_cfg(8, acorr=orc.ACORR_CANONICAL), use_fixed=True,
+                                 fixed=orc.make_fixed_config(sum_mode=orc.SUMABS_CANONICAL))
+    want, wres = orc.encode_stereo_frames_cfg(x, bps, ocfg)
+    _check_frames_against_oracle(x, bps, got, gres, want, wres)
+    _decode_frames(x, got, gres)
+
+
 def test_encode_stereo_frames_rejects_unsupported(handle):
     x = np.zeros((2, 2, 4096), np.int32)
     with pytest.raises(_capi.FlacencHipError) as ei:
-        handle.encode_stereo_frames(x, 16, _capi.make_frame_config(gpu_cfg(8), use_fixed=True))
+        handle.encode_stereo_frames(x, 16, _capi.make_frame_config(gpu_cfg(8), use_fixed=True, fixed_partitions=12))
     assert ei.value.code == _capi.ERR_UNSUPPORTED
+    with pytest.raises(_capi.FlacencHipError) as ei:
+        handle.encode_stereo_frames(x, 16, _capi.make_frame_config(gpu_cfg(8), use_fixed=True, fixed_max_order=5))
+    assert ei.value.code == _capi.ERR_BAD_CONFIG
     with pytest.raises(_capi.FlacencHipError) as ei:
         handle.encode_stereo_frames(np.zeros((2, 2, 1152), np.int32), 16, _capi.make_frame_config(gpu_cfg(8)))
     assert ei.value.code == _capi.ERR_UNSUPPORTED

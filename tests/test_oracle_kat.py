@@ -472,3 +472,112 @@ def test_three_summation_orders_agree_equally_well():
     assert max(worst.values()) < 1e-12
     assert worst["stable-canonical"] < 10 * max(worst["stable-nightly"], 1e-16) + 1e-15
     assert min(same.values()) >= total - 2
+
+
+# ------------------------------------------------- fixed LPC (coding.rs) ----
+def test_fixed_lpc_error_computation():
+    """src/coding.rs:707-723: Sine(32, 0.3) + noise(0.1), 16-bit, 64 samples."""
+    signal = util.sine_noise(64, 16, 32, 0.3, 0.1, seed=9)
+    errors = orc.reset_fixed_lpc_errors(signal)
+    s = signal.astype(np.int64)
+    assert np.array_equal(errors[0], signal)
+    assert np.array_equal(errors[1][1:], (s[1:] - s[:-1]).astype(np.int32))
+    assert np.array_equal(errors[2][2:], (s[2:] - 2 * s[1:-1] + s[:-2]).astype(np.int32))
+    # carry starts at 0 (coding.rs:188): the first k entries are partial differences
+    assert errors[1][0] == signal[0] and errors[2][0] == signal[0]
+    assert errors[2][1] == signal[1] - 2 * signal[0]
+
+
+def test_fixed_lpc_of_sine():
+    """src/coding.rs:725-737: Sine(100, 0.6), 8-bit, 1024 samples; max_order 0..4 all decode."""
+    signal = util.quantize(util.sine(1024, 100, 0.6), 8)
+    for max_order in range(5):
+        sub = orc.fixed_lpc(signal, 8, 2 ** 64 - 1, orc.make_fixed_config(max_order=max_order))
+        assert sub["selected"] and sub["order"] <= max_order
+        assert np.array_equal(orc.decode_fixed(sub["warm_up"], sub["residual"]), signal)
+        # FixedLpc::count_bits, bitrepr.rs:473-477, against the bits Residual::write emits
+        assert sub["subframe_bits"] == 8 + 8 * sub["order"] + sub["residual_bits"]
+
+
+def test_order_selector_bitcount():
+    """src/coding.rs:944-980: errors 255 / 256 / 128 (orders 0, 1, 2), 256 samples, 16-bit ->
+    order 0, and no order has fewer real bits."""
+    errs = [np.full(256, v, np.int32) for v in (255, 256, 128)]
+    keys = [16 * k + orc.find_partitioned_rice_parameter(e, k, 30)[2] for k, e in enumerate(errs)]
+    assert int(np.argmin(keys)) == 0
+    counts = []
+    for k, e in enumerate(errs):
+        res = orc.encode_residual(e, k)
+        counts.append(orc.residual_count_bits(256, k, res["partition_order"], res["rice_params"],
+                                              res["sum_quotients"], res["sum_rice_params"]) + 16 * k)
+    assert all(c >= counts[0] for c in counts)
+
+
+def test_order_selector_approxent():
+    """src/coding.rs:982-1004: errors 255 / 256 / 128 / 127, ApproxEnt{partitions: 32} -> order 2."""
+    errs = [np.full(256, v, np.int32) for v in (255, 256, 128, 127)]
+    for mode in (orc.SUMABS_STABLE, orc.SUMABS_NIGHTLY, orc.SUMABS_CANONICAL):
+        keys = [orc.estimate_entropy(e, k, 32, mode) + 16 * k for k, e in enumerate(errs)]
+        assert int(np.argmin(keys)) == 2  # min_by_key: first minimum
+
+
+def test_log2f_restatement_matches_host_libm():
+    """f32::log2 -> libm log2f (glibc 2.35 here).  The restatement shared by oracle and kernel
+    must equal it bit for bit; a strided sweep over every binade of the positive floats plus the
+    arguments the estimator really uses (1/(avg+1) and 1 - 1/(avg+1))."""
+    import ctypes
+    libm = ctypes.CDLL("libm.so.6")
+    libm.log2f.argtypes = [ctypes.c_float]
+    libm.log2f.restype = ctypes.c_float
+    bits = np.arange(0x00000001, 0x7f800000, 104729, dtype=np.uint32)
+    avg = np.float32(2.0) * np.arange(1, 200000, 37, dtype=np.float32) / np.float32(256.00001)
+    gp = (np.float32(1.0) / (avg + np.float32(1.0))).astype(np.float32)
+    xs = np.concatenate([bits.view(np.float32), gp, (np.float32(1.0) - gp).astype(np.float32),
+                         np.array([1.0, 0.5, 2.0, 0.0, np.inf], np.float32)])
+    for x in xs:
+        a, b = orc.log2f(float(x)), libm.log2f(float(x))
+        assert a == b or (np.isnan(a) and np.isnan(b)), (float(x).hex(), a, b)
+    assert np.isnan(orc.log2f(-1.0)) and orc.log2f(0.0) == -np.inf
+
+
+def test_sum_abs_orders_agree_below_2_24():
+    """find_sum_abs_f32 (arrayutils.rs:496-506): while every partial sum stays below 2^24 the
+    stable chain, the simd-nightly lanes and the exact-integer canonical definition are the same
+    number; beyond it they differ by f32 rounding only, and the canonical one is the correctly
+    rounded sum."""
+    rng = np.random.default_rng(5)
+    small = rng.integers(-2 ** 14, 2 ** 14, 256).astype(np.int32)  # sum <= 2^22
+    vals = {orc.find_sum_abs_f32(small, m, off) for m in range(3) for off in (0, 5, 16)}
+    assert len(vals) == 1 and vals.pop() == float(np.abs(small.astype(np.int64)).sum())
+    big = rng.integers(-2 ** 22, 2 ** 22, 1024).astype(np.int32)   # sum ~ 2^31: rounding shows
+    exact = int(np.abs(big.astype(np.int64)).sum())
+    can = orc.find_sum_abs_f32(big, orc.SUMABS_CANONICAL)
+    assert can == float(np.float32(exact))
+    for m in (orc.SUMABS_STABLE, orc.SUMABS_NIGHTLY):
+        assert abs(orc.find_sum_abs_f32(big, m) - exact) <= 1e-5 * exact
+
+
+def test_encode_subframe_with_fixed_candidate():
+    """encode_subframe, src/coding.rs:384-418: LPC must beat min(verbatim, fixed) strictly;
+    otherwise fixed if it beats verbatim; the result always decodes."""
+    fc = orc.make_frame_config(orc.make_config(lpc_order=8))
+    kinds = set()
+    for seed, (amp, namp, period) in enumerate([(0.4, 0.4, 200), (0.6, 0.0, 100), (0.3, 0.001, 37),
+                                                (0.0, 0.9, 50), (0.2, 0.02, 16)]):
+        x = util.sine_noise(4096, 16, period, amp, namp, seed=40 + seed)
+        r = orc.encode_subframe(x, 16, fc)
+        kinds.add(r["kind"])
+        verbatim = orc.verbatim_count_bits(4096, 16)
+        assert r["bits"] <= verbatim
+        fx = orc.fixed_lpc(x, 16, verbatim)
+        lp = orc.estimated_qlpc(x, 16, fc.qlpc)
+        if r["kind"] == orc.KIND_LPC:
+            assert lp["subframe_bits"] < min(verbatim, fx["subframe_bits"] if fx["selected"] else verbatim)
+            dec = orc.decode_lpc(lp["warm_up"], lp["coefs"], lp["shift"], r["residual"])
+        elif r["kind"] == orc.KIND_FIXED:
+            assert fx["selected"] and fx["subframe_bits"] < verbatim and lp["subframe_bits"] >= fx["subframe_bits"]
+            dec = orc.decode_fixed(x[:fx["order"]], r["residual"])
+        else:
+            continue
+        assert np.array_equal(dec, x)
+    assert orc.KIND_LPC in kinds

@@ -50,6 +50,8 @@ EXPORTED_SYMBOLS = (
     "flacenc_hip_stereo_qlpc_batch_async",
     "flacenc_hip_encode_stereo_frames",
     "flacenc_hip_encode_stereo_frames_async",
+    "flacenc_hip_fixed_lpc_batch",
+    "flacenc_hip_fixed_lpc_batch_async",
     "flacenc_hip_synchronize",
     "flacenc_hip_debug_set_stamps",
     "flacenc_hip_debug_set_fixed_keys",
@@ -108,6 +110,8 @@ class FrameConfig(C.Structure):
     ]
 
 
+LAYOUT_SUBFRAMES = 0
+LAYOUT_STEREO_FRAMES = 1
 ORDERSEL_BITCOUNT = 0
 ORDERSEL_APPROXENT = 1
 KIND_CONSTANT, KIND_VERBATIM, KIND_FIXED, KIND_LPC = 0, 1, 2, 3
@@ -190,6 +194,12 @@ def load() -> C.CDLL:
     L.flacenc_hip_stereo_qlpc_batch.restype = C.c_int
     L.flacenc_hip_stereo_qlpc_batch_async.argtypes = stereo_args + [vp]
     L.flacenc_hip_stereo_qlpc_batch_async.restype = C.c_int
+    fixed_args = [vp, C.POINTER(FrameConfig), i32p, C.c_size_t, C.c_uint32, C.c_size_t, vp, C.c_uint32,
+                  C.c_int, vp, i32p, C.c_size_t, vp]
+    L.flacenc_hip_fixed_lpc_batch.argtypes = fixed_args + [C.c_int]
+    L.flacenc_hip_fixed_lpc_batch.restype = C.c_int
+    L.flacenc_hip_fixed_lpc_batch_async.argtypes = fixed_args + [vp]
+    L.flacenc_hip_fixed_lpc_batch_async.restype = C.c_int
     frame_args = [vp, C.POINTER(FrameConfig), i32p, C.c_size_t, C.c_uint32, C.c_size_t, C.c_uint32,
                   vp, i32p, C.c_size_t]
     L.flacenc_hip_encode_stereo_frames.argtypes = frame_args + [C.c_int]
@@ -334,6 +344,36 @@ class Handle:
             self._h, C.byref(cfg), frames_ptr, n_frames, block_size, stride, bits_per_sample,
             params_ptr, residual_ptr, residual_stride, stream or None)
         self._check(rc)
+
+    def fixed_lpc_batch(self, samples, bps, cfg: FrameConfig, stereo: bool = False):
+        """fixed_lpc (src/coding.rs:298-331) for a batch of any block size.
+
+        plain:  `samples` int32 [n_subframes, n], `bps` array or int -> params [n_subframes], residual
+                [n_subframes, n], selector keys [n_subframes];
+        stereo: `samples` int32 [n_frames, 2, n], `bps` int -> the same for L, R, M, S: [n_frames, 4, ...]."""
+        x = np.ascontiguousarray(samples, np.int32)
+        if stereo:
+            nf, ch, n = x.shape
+            assert ch == 2
+            n_units, n_sub, shape = nf, nf * 4, (nf, 4)
+            bps_arr, bps_uni = None, int(bps)
+        else:
+            n_units, n = x.shape
+            n_sub, shape = n_units, (n_units,)
+            if np.ndim(bps) == 0:
+                bps_arr, bps_uni = None, int(bps)
+            else:
+                bps_arr, bps_uni = np.ascontiguousarray(bps, np.uint8), 16
+        params = np.zeros(shape, PARAMS_DTYPE)
+        residual = np.zeros(shape + (n,), np.int32)
+        keys = np.zeros(shape, np.uint64)
+        rc = self._lib.flacenc_hip_fixed_lpc_batch(
+            self._h, C.byref(cfg), x.ctypes.data, n_units, n, n,
+            bps_arr.ctypes.data if bps_arr is not None else None, bps_uni,
+            LAYOUT_STEREO_FRAMES if stereo else LAYOUT_SUBFRAMES, params.ctypes.data, residual.ctypes.data, n,
+            keys.ctypes.data, MEM_HOST)
+        self._check(rc)
+        return params, residual, keys
 
     def encode_stereo_frames(self, frames, bits_per_sample: int, cfg: FrameConfig):
         """encode_frame with the decision on the GPU: `frames` int32 [n_frames, 2, block_size] ->

@@ -38,7 +38,7 @@ struct flacenc_hip_handle {
   hipStream_t stream = nullptr;
   std::string last_error;
   std::vector<WindowEntry> windows;
-  DeviceBuffer d_samples, d_residual, d_params, d_bps, d_autocorr, d_lpc, d_tables;
+  DeviceBuffer d_samples, d_residual, d_params, d_bps, d_autocorr, d_lpc, d_tables, d_keys, d_sel;
   unsigned long long* stamps = nullptr;  // profiling hook, see flacenc_hip_debug_set_stamps
   unsigned long long* fixed_keys = nullptr;  // test hook, see flacenc_hip_debug_set_fixed_keys
 };
@@ -212,11 +212,125 @@ int enqueue(flacenc_hip_handle* h, const flacenc_hip_qlpc_config* cfg, const int
   a.use_constant = a.use_lpc = a.use_leftside = a.use_rightside = a.use_midside = 1;
   a.use_fixed = a.fixed_max_order = a.fixed_order_sel = a.fixed_group_log2 = 0;
   a.fixed_keys = nullptr;
+  a.fixed_mode = a.fixed_partitions = a.forced_uniform = 0;
+  a.forced_orders = nullptr;
+  a.selector_keys = nullptr;
   if (plan.table_scratch_bytes_per_subframe) {
     rc = ensure(h, h->d_tables, plan.table_scratch_bytes_per_subframe * n_subframes);
     if (rc != FLACENC_HIP_OK) return rc;
     a.table_scratch = static_cast<uint32_t*>(h->d_tables.ptr);
   }
+  HIP_TRY(h, flacenc_hip::launch_qlpc(a, plan, stream));
+  return FLACENC_HIP_OK;
+}
+
+// config::Fixed::verify (config.rs:246-255) + OrderSel::verify (:419-431)
+int verify_fixed(flacenc_hip_handle* h, const flacenc_hip_frame_config* cfg) {
+  if (cfg->fixed_max_order > FLACENC_HIP_MAX_FIXED_LPC_ORDER ||
+      (cfg->fixed_order_sel != FLACENC_HIP_ORDERSEL_BITCOUNT &&
+       cfg->fixed_order_sel != FLACENC_HIP_ORDERSEL_APPROXENT) ||
+      (cfg->fixed_order_sel == FLACENC_HIP_ORDERSEL_APPROXENT &&
+       (cfg->fixed_partitions < 1 || cfg->fixed_partitions > 64))) {
+    h->last_error = "fixed: max_order must be ..=4, order_sel BitCount / ApproxEnt, ApproxEnt.partitions 1..=64";
+    return FLACENC_HIP_ERR_BAD_CONFIG;
+  }
+  return FLACENC_HIP_OK;
+}
+
+// OrderSel::BitCount (coding.rs:243-264): first minimum of the per-order keys
+__global__ void bitcount_pick_kernel(const unsigned long long* keys, uint32_t n, uint32_t n_orders,
+                                     uint8_t* orders, unsigned long long* best_keys) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  unsigned long long best = keys[i];
+  uint32_t bk = 0;
+  for (uint32_t k = 1; k < n_orders; ++k) {
+    const unsigned long long v = keys[(size_t)k * n + i];
+    if (v < best) {
+      best = v;
+      bk = k;
+    }
+  }
+  orders[i] = (uint8_t)bk;
+  if (best_keys) best_keys[i] = best;
+}
+
+// `fixed_lpc` (coding.rs:298-331) for a batch, device pointers, on `stream`
+int enqueue_fixed(flacenc_hip_handle* h, const flacenc_hip_frame_config* cfg, const int32_t* samples,
+                  size_t n_subframes, uint32_t block_size, size_t stride, const uint8_t* bps,
+                  uint32_t bps_uniform, bool stereo, flacenc_hip_subframe_params* params, int32_t* residual,
+                  size_t residual_stride, unsigned long long* selector_keys, hipStream_t stream) {
+  int rc = verify_fixed(h, cfg);
+  if (rc != FLACENC_HIP_OK) return rc;
+  flacenc_hip::QlpcLaunchPlan plan = flacenc_hip::plan_qlpc_launch(block_size, 4);
+  if (plan.smem_bytes > 160 * 1024) {
+    h->last_error = "internal: LDS plan exceeds 160 KiB";
+    return FLACENC_HIP_ERR_UNSUPPORTED;
+  }
+  flacenc_hip::QlpcKernelArgs a;
+  a.samples = samples;
+  a.stride = stride;
+  a.block_size = block_size;
+  a.n_subframes = static_cast<uint32_t>(n_subframes);
+  a.bps = bps;
+  a.bps_uniform = bps_uniform;
+  a.stereo = stereo ? 1u : 0u;
+  a.window = nullptr;
+  a.flat_lo = 0;
+  a.flat_hi = 0;
+  a.lpc_order = 4;
+  a.precision = 0;
+  a.max_rice_parameter = cfg->qlpc.max_rice_parameter;
+  a.params = params;
+  a.residual = residual;
+  a.residual_stride = residual_stride;
+  a.autocorr = nullptr;
+  a.lpc_coefs = nullptr;
+  a.table_scratch = nullptr;
+  a.stamps = nullptr;
+  a.frame_results = nullptr;
+  a.use_constant = a.use_lpc = a.use_leftside = a.use_rightside = a.use_midside = 1;
+  a.use_fixed = 1;
+  a.fixed_max_order = cfg->fixed_max_order;
+  a.fixed_order_sel = cfg->fixed_order_sel;
+  a.fixed_group_log2 = 0;
+  a.fixed_keys = h->fixed_keys;
+  a.fixed_partitions = cfg->fixed_partitions;
+  a.forced_uniform = 0;
+  a.forced_orders = nullptr;
+  a.selector_keys = selector_keys;
+  if (plan.table_scratch_bytes_per_subframe) {
+    rc = ensure(h, h->d_tables, plan.table_scratch_bytes_per_subframe * n_subframes);
+    if (rc != FLACENC_HIP_OK) return rc;
+    a.table_scratch = static_cast<uint32_t*>(h->d_tables.ptr);
+  }
+  if (cfg->fixed_order_sel == FLACENC_HIP_ORDERSEL_APPROXENT) {
+    a.fixed_mode = 1;
+    HIP_TRY(h, flacenc_hip::launch_qlpc(a, plan, stream));
+    return FLACENC_HIP_OK;
+  }
+  // BitCount: code every order, keep the first minimum of bps*order + code_bits, code it again
+  const uint32_t n_orders = cfg->fixed_max_order + 1;
+  if ((rc = ensure(h, h->d_keys, n_subframes * n_orders * 8)) != FLACENC_HIP_OK) return rc;
+  if ((rc = ensure(h, h->d_sel, n_subframes)) != FLACENC_HIP_OK) return rc;
+  unsigned long long* keys = static_cast<unsigned long long*>(h->d_keys.ptr);
+  for (uint32_t k = 0; k < n_orders; ++k) {
+    a.fixed_mode = 2;
+    a.forced_uniform = k;
+    a.selector_keys = keys + static_cast<size_t>(k) * n_subframes;
+    HIP_TRY(h, flacenc_hip::launch_qlpc(a, plan, stream));
+    if (h->fixed_keys) {  // test hook: keys[sf*8 + k]
+      HIP_TRY(h, hipMemcpy2DAsync(h->fixed_keys + k, 8 * 8, a.selector_keys, 8, 8, n_subframes,
+                                  hipMemcpyDeviceToDevice, stream));
+    }
+  }
+  const uint32_t n32 = static_cast<uint32_t>(n_subframes);
+  hipLaunchKernelGGL(bitcount_pick_kernel, dim3((n32 + 255) / 256), dim3(256), 0, stream, keys, n32, n_orders,
+                     static_cast<uint8_t*>(h->d_sel.ptr), selector_keys);
+  HIP_TRY(h, hipGetLastError());
+  a.fixed_mode = 3;
+  a.forced_orders = static_cast<const uint8_t*>(h->d_sel.ptr);
+  a.selector_keys = nullptr;
   HIP_TRY(h, flacenc_hip::launch_qlpc(a, plan, stream));
   return FLACENC_HIP_OK;
 }
@@ -258,7 +372,7 @@ void flacenc_hip_destroy(flacenc_hip_handle* h) {
   for (WindowEntry& e : h->windows)
     if (e.dev) (void)hipFree(e.dev);
   for (DeviceBuffer* b : {&h->d_samples, &h->d_residual, &h->d_params, &h->d_bps, &h->d_autocorr,
-                          &h->d_lpc, &h->d_tables})
+                          &h->d_lpc, &h->d_tables, &h->d_keys, &h->d_sel})
     if (b->ptr) (void)hipFree(b->ptr);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -305,6 +419,75 @@ int flacenc_hip_debug_set_fixed_keys(flacenc_hip_handle* h, unsigned long long* 
 int flacenc_hip_debug_set_stamps(flacenc_hip_handle* h, unsigned long long* device_stamps) {
   if (!h) return FLACENC_HIP_ERR_BAD_ARGUMENT;
   h->stamps = device_stamps;
+  return FLACENC_HIP_OK;
+}
+
+int flacenc_hip_fixed_lpc_batch_async(flacenc_hip_handle* h, const flacenc_hip_frame_config* cfg,
+                                      const int32_t* samples, size_t n_units, uint32_t block_size,
+                                      size_t stride, const uint8_t* bps, uint32_t bits_per_sample, int layout,
+                                      flacenc_hip_subframe_params* params, int32_t* residual,
+                                      size_t residual_stride, uint64_t* selector_keys, void* stream) {
+  if (!h || !cfg) return FLACENC_HIP_ERR_BAD_ARGUMENT;
+  const bool stereo = layout == FLACENC_HIP_LAYOUT_STEREO_FRAMES;
+  if (!stereo && layout != FLACENC_HIP_LAYOUT_SUBFRAMES) return FLACENC_HIP_ERR_BAD_ARGUMENT;
+  const size_t n_sub = stereo ? n_units * 4 : n_units;
+  int rc = check_batch_args(h, &cfg->qlpc, samples, n_sub, block_size, stride, params, residual, residual_stride);
+  if (rc != FLACENC_HIP_OK || n_units == 0) return rc;
+  if (!bps && (bits_per_sample < 8 || bits_per_sample > 25)) {
+    h->last_error = "bits_per_sample must be in 8..=25 when no per-subframe bps array is given";
+    return FLACENC_HIP_ERR_BAD_ARGUMENT;
+  }
+  HIP_TRY(h, hipSetDevice(h->device));
+  return enqueue_fixed(h, cfg, samples, n_sub, block_size, stride, stereo ? nullptr : bps, bits_per_sample, stereo,
+                       params, residual, residual_stride, reinterpret_cast<unsigned long long*>(selector_keys),
+                       static_cast<hipStream_t>(stream));
+}
+
+int flacenc_hip_fixed_lpc_batch(flacenc_hip_handle* h, const flacenc_hip_frame_config* cfg,
+                                const int32_t* samples, size_t n_units, uint32_t block_size, size_t stride,
+                                const uint8_t* bps, uint32_t bits_per_sample, int layout,
+                                flacenc_hip_subframe_params* params, int32_t* residual, size_t residual_stride,
+                                uint64_t* selector_keys, int memory_kind) {
+  if (!h || !cfg) return FLACENC_HIP_ERR_BAD_ARGUMENT;
+  if (memory_kind == FLACENC_HIP_MEM_DEVICE) {
+    int rc = flacenc_hip_fixed_lpc_batch_async(h, cfg, samples, n_units, block_size, stride, bps, bits_per_sample,
+                                               layout, params, residual, residual_stride, selector_keys, h->stream);
+    if (rc != FLACENC_HIP_OK || n_units == 0) return rc;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return FLACENC_HIP_OK;
+  }
+  if (memory_kind != FLACENC_HIP_MEM_HOST) return FLACENC_HIP_ERR_BAD_ARGUMENT;
+  const bool stereo = layout == FLACENC_HIP_LAYOUT_STEREO_FRAMES;
+  if (!stereo && layout != FLACENC_HIP_LAYOUT_SUBFRAMES) return FLACENC_HIP_ERR_BAD_ARGUMENT;
+  const size_t n_sub = stereo ? n_units * 4 : n_units;
+  const size_t n_rows = stereo ? n_units * 2 : n_units;
+  int rc = check_batch_args(h, &cfg->qlpc, samples, n_sub, block_size, stride, params, residual, residual_stride);
+  if (rc != FLACENC_HIP_OK || n_units == 0) return rc;
+  HIP_TRY(h, hipSetDevice(h->device));
+  const size_t dstride = (static_cast<size_t>(block_size) + 3) & ~static_cast<size_t>(3);
+  if ((rc = ensure(h, h->d_samples, n_rows * dstride * 4)) != FLACENC_HIP_OK) return rc;
+  if ((rc = ensure(h, h->d_residual, n_sub * dstride * 4)) != FLACENC_HIP_OK) return rc;
+  if ((rc = ensure(h, h->d_params, n_sub * sizeof(flacenc_hip_subframe_params))) != FLACENC_HIP_OK) return rc;
+  if ((rc = ensure(h, h->d_autocorr, n_sub * 8)) != FLACENC_HIP_OK) return rc;  // selector keys
+  if (bps && !stereo && (rc = ensure(h, h->d_bps, n_sub)) != FLACENC_HIP_OK) return rc;
+  hipStream_t s = h->stream;
+  HIP_TRY(h, hipMemcpy2DAsync(h->d_samples.ptr, dstride * 4, samples, stride * 4,
+                              static_cast<size_t>(block_size) * 4, n_rows, hipMemcpyHostToDevice, s));
+  if (bps && !stereo) HIP_TRY(h, hipMemcpyAsync(h->d_bps.ptr, bps, n_sub, hipMemcpyHostToDevice, s));
+  rc = flacenc_hip_fixed_lpc_batch_async(h, cfg, static_cast<const int32_t*>(h->d_samples.ptr), n_units, block_size,
+                                         dstride, (bps && !stereo) ? static_cast<const uint8_t*>(h->d_bps.ptr) : nullptr,
+                                         bits_per_sample, layout,
+                                         static_cast<flacenc_hip_subframe_params*>(h->d_params.ptr),
+                                         static_cast<int32_t*>(h->d_residual.ptr), dstride,
+                                         static_cast<uint64_t*>(h->d_autocorr.ptr), s);
+  if (rc != FLACENC_HIP_OK) return rc;
+  HIP_TRY(h, hipMemcpy2DAsync(residual, residual_stride * 4, h->d_residual.ptr, dstride * 4,
+                              static_cast<size_t>(block_size) * 4, n_sub, hipMemcpyDeviceToHost, s));
+  HIP_TRY(h, hipMemcpyAsync(params, h->d_params.ptr, n_sub * sizeof(flacenc_hip_subframe_params),
+                            hipMemcpyDeviceToHost, s));
+  if (selector_keys)
+    HIP_TRY(h, hipMemcpyAsync(selector_keys, h->d_autocorr.ptr, n_sub * 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(h, hipStreamSynchronize(s));
   return FLACENC_HIP_OK;
 }
 
@@ -458,15 +641,7 @@ int flacenc_hip_encode_stereo_frames_async(flacenc_hip_handle* h, const flacenc_
   }
   uint32_t fixed_group_log2 = 0;
   if (cfg->use_fixed) {
-    // config::Fixed::verify (config.rs:246-255) + OrderSel::verify (:419-431)
-    if (cfg->fixed_max_order > FLACENC_HIP_MAX_FIXED_LPC_ORDER ||
-        (cfg->fixed_order_sel != FLACENC_HIP_ORDERSEL_BITCOUNT &&
-         cfg->fixed_order_sel != FLACENC_HIP_ORDERSEL_APPROXENT) ||
-        (cfg->fixed_order_sel == FLACENC_HIP_ORDERSEL_APPROXENT &&
-         (cfg->fixed_partitions < 1 || cfg->fixed_partitions > 64))) {
-      h->last_error = "fixed: max_order must be ..=4, order_sel BitCount / ApproxEnt, ApproxEnt.partitions 1..=64";
-      return FLACENC_HIP_ERR_BAD_CONFIG;
-    }
+    if ((rc = verify_fixed(h, cfg)) != FLACENC_HIP_OK) return rc;
     if (cfg->fixed_order_sel == FLACENC_HIP_ORDERSEL_APPROXENT) {
       // the estimator's partitions must be whole groups of 64-sample lanes
       const uint32_t p = cfg->fixed_partitions;
@@ -517,6 +692,9 @@ int flacenc_hip_encode_stereo_frames_async(flacenc_hip_handle* h, const flacenc_
   a.fixed_order_sel = cfg->fixed_order_sel;
   a.fixed_group_log2 = fixed_group_log2;
   a.fixed_keys = h->fixed_keys;
+  a.fixed_mode = a.fixed_partitions = a.forced_uniform = 0;
+  a.forced_orders = nullptr;
+  a.selector_keys = nullptr;
   if (!flacenc_hip::wave_kernel_eligible(a)) {
     h->last_error = "encode_stereo_frames: needs block_size 4096, lpc_order <= 12 and 16-byte aligned rows";
     return FLACENC_HIP_ERR_UNSUPPORTED;

@@ -23,6 +23,7 @@ int bucket_order(int P) {
 
 bool wave_kernel_eligible(const QlpcKernelArgs& a) {
   if (a.block_size != 4096 || a.lpc_order > 12) return false;
+  if (a.fixed_mode != 0) return false;  // fixed_lpc as a stand-alone batch: generic kernel
   if (getenv("FLACENC_HIP_FORCE_GENERIC")) return false;
   if ((reinterpret_cast<uintptr_t>(a.samples) & 15) || (a.stride & 3)) return false;
   if ((reinterpret_cast<uintptr_t>(a.residual) & 15) || (a.residual_stride & 3)) return false;
@@ -52,6 +53,7 @@ QlpcLaunchPlan plan_qlpc_launch(uint32_t block_size, uint32_t lpc_order) {
   bytes += static_cast<size_t>(Jp) * W * (plan.maxp + 1) * 8;
   bytes = (bytes + 15) & ~static_cast<size_t>(15);
   bytes += 40 * 8 + 16 * 8 + 32 * 4 + kMiscCount * 4 + 2 * FLACENC_HIP_MAX_RICE_PARTITIONS;
+  bytes += (5 * 64 + 16) * 8;  // kFixedSumWords (qlpc_kernel_impl.h): fixed-LPC order selection
   if (!plan.big) {
     // finest_partition_order, rice.rs:157-165 (warm-up <= 32 < 64)
     int lg = 31 - __builtin_clz(static_cast<unsigned>(n / 64));

@@ -44,6 +44,13 @@ struct QlpcKernelArgs {
   uint32_t fixed_order_sel;    // 0 BitCount, 1 ApproxEnt
   uint32_t fixed_group_log2;   // ApproxEnt: lanes per estimator partition = 2^g (4096 / partitions / 64)
   unsigned long long* fixed_keys;  // device, nullable: [n][8] the selector's key per order (tests)
+  // generic kernel as `fixed_lpc` (src/coding.rs:298-331): 0 = QLPC analysis (default),
+  // 1 = ApproxEnt order selection + coding, 2 = code order forced_uniform, 3 = code forced_orders[sf]
+  uint32_t fixed_mode;
+  uint32_t fixed_partitions;       // mode 1: OrderSel::ApproxEnt.partitions (1..64)
+  uint32_t forced_uniform;         // mode 2
+  const uint8_t* forced_orders;    // mode 3, device, [n]
+  unsigned long long* selector_keys;  // device, nullable, [n]: the chosen order's selector key
 };
 
 struct QlpcLaunchPlan {

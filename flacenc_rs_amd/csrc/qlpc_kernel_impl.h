@@ -73,6 +73,58 @@ __device__ __forceinline__ int ceil_log2_pos(double m) {
   return (e - 1023) + (frac != 0 ? 1 : 0);
 }
 
+// f32::log2 = libm log2f.  glibc's algorithm (sysdeps/ieee754/flt-32/e_log2f.c, 2.27+): 16-entry
+// {1/c, log2 c} table around OFF = 0x3f330000, degree-4 polynomial in double, one rounding to
+// float.  Same restatement as oracle/flacenc_oracle.c orc_log2f (checked there against the
+// host libm over every positive float).
+__device__ const double kLog2fTab[32] = {
+    0x1.661ec79f8f3bep+0, -0x1.efec65b963019p-2, 0x1.571ed4aaf883dp+0, -0x1.b0b6832d4fca4p-2,
+    0x1.49539f0f010bp+0,  -0x1.7418b0a1fb77bp-2, 0x1.3c995b0b80385p+0, -0x1.39de91a6dcf7bp-2,
+    0x1.30d190c8864a5p+0, -0x1.01d9bf3f2b631p-2, 0x1.25e227b0b8eap+0,  -0x1.97c1d1b3b7afp-3,
+    0x1.1bb4a4a1a343fp+0, -0x1.2f9e393af3c9fp-3, 0x1.12358f08ae5bap+0, -0x1.960cbbf788d5cp-4,
+    0x1.0953f419900a7p+0, -0x1.a6f9db6475fcep-5, 0x1p+0,               0x0p+0,
+    0x1.e608cfd9a47acp-1, 0x1.338ca9f24f53dp-4,  0x1.ca4b31f026aap-1,  0x1.476a9543891bap-3,
+    0x1.b2036576afce6p-1, 0x1.e840b4ac4e4d2p-3,  0x1.9c2d163a1aa2dp-1, 0x1.40645f0c6651cp-2,
+    0x1.886e6037841edp-1, 0x1.88e9c2c1b9ff8p-2,  0x1.767dcf5534862p-1, 0x1.ce0a44eb17bccp-2,
+};
+
+__device__ __forceinline__ float dev_log2f(float x) {
+  uint32_t ix = __float_as_uint(x);
+  if (ix == 0x3f800000u) return 0.0f;
+  if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u) {
+    if (ix * 2u == 0u) return -__builtin_inff();
+    if (ix == 0x7f800000u) return x;
+    if ((ix & 0x80000000u) || ix * 2u >= 0xff000000u) return __builtin_nanf("");
+    ix = __float_as_uint(x * 0x1p23f) - (23u << 23);
+  }
+  const uint32_t tmp = ix - 0x3f330000u;
+  const int i = (int)((tmp >> 19) & 15u);
+  const uint32_t top = tmp & 0xff800000u;
+  const int k = (int)tmp >> 23;
+  const double z = (double)__uint_as_float(ix - top);
+  const double r = z * kLog2fTab[2 * i] - 1.0;
+  const double y0 = kLog2fTab[2 * i + 1] + (double)k;
+  const double r2 = r * r;
+  double y = 0x1.ecabf496832ep-2 * r + -0x1.715479ffae3dep-1;
+  y = -0x1.712b6f70a7e4dp-2 * r2 + y;
+  const double p = 0x1.715475f35c8b8p0 * r + y0;
+  y = y * r2 + p;
+  return (float)y;
+}
+
+// one partition of estimate_entropy (coding.rs:215-222): `sum` is the exact integer sum of
+// |e| over the partition (rounded to f32 once -- the canonical definition of DESIGN.md; equal to
+// find_sum_abs_f32 in either reference build while the sum stays below 2^24)
+__device__ __forceinline__ uint32_t approx_ent_bits(double sum, uint32_t count) {
+  const float sum_errors = (float)sum;
+  const float cnt = (float)count;
+  const float avg_errors = sum_errors * 2.0f / (cnt + 0.00001f);
+  const float geom_p = 1.0f / (avg_errors + 1.0f);
+  const float xent = __builtin_fmaf(avg_errors, -dev_log2f(1.0f - geom_p), -dev_log2f(geom_p));
+  const float v = xent * cnt;
+  return v > 0.0f ? (uint32_t)v : 0u;  // `as usize`: NaN and negatives -> 0
+}
+
 // Optional per-phase timestamps (s_memtime, shader clock) for the profiling build of
 // tools/phase_profile.py: workgroup leader only, never read by the kernel itself.
 #define FLACENC_STAMP(slot)                                                             \
@@ -99,7 +151,9 @@ struct SmemLayout {
   uint32_t* misc;  // see kMisc*
   unsigned long long* level_bits;  // [9]
   uint8_t* ps;     // per-level rice parameters, 2*nparts bytes
+  unsigned long long* fsum;  // fixed-LPC order selection: [5][64] partition sums + [8] totals
 };
+constexpr int kFixedSumWords = 5 * 64 + 16;
 
 enum {
   kMiscMaxAbs = 0,
@@ -301,6 +355,8 @@ qlpc_subframe_kernel(QlpcKernelArgs a) {
     p += kMiscCount * 4;
     L.ps = reinterpret_cast<uint8_t*>(p);
     p += 2 * FLACENC_HIP_MAX_RICE_PARTITIONS;
+    L.fsum = reinterpret_cast<unsigned long long*>(p);
+    p += kFixedSumWords * 8;
     L.tables = BIG ? (a.table_scratch + (size_t)sf * FLACENC_HIP_MAX_RICE_PARTITIONS * 32)
                    : reinterpret_cast<uint32_t*>(p);
   }
@@ -370,6 +426,123 @@ qlpc_subframe_kernel(QlpcKernelArgs a) {
   if (lane == 0) atomicMax(&L.misc[kMiscMaxAbs], my_maxabs);
 
   FLACENC_STAMP(1);
+  if (a.fixed_mode != 0) {
+    // ======================= fixed-LPC candidate (coding.rs:298-331) =========
+    // The predictor is one of FIXED_LPC_COEFS (decode.rs:179-185) with shift 0 instead of the
+    // Levinson solution; everything downstream (error signal, Rice search, bit counts) is the
+    // QLPC machinery.  fixed_mode 1: pick the order with estimate_entropy (OrderSel::ApproxEnt,
+    // coding.rs:265-287) first; 2: order = forced_uniform (one pass of OrderSel::BitCount,
+    // coding.rs:243-264); 3: order = forced_orders[sf] (BitCount's final pass).
+    const unsigned long long bps_sf = a.bps ? (unsigned long long)a.bps[sf]
+                                            : (unsigned long long)(a.bps_uniform + (role == 3 ? 1u : 0u));
+    if (a.fixed_mode == 1u) {
+      unsigned long long* const fsum = L.fsum;
+      unsigned long long* const ftot = L.fsum + 5 * 64;
+      for (int i = tid; i < kFixedSumWords; i += T) fsum[i] = 0ull;
+      __syncthreads();
+      const int parts = (int)a.fixed_partitions;
+      const int psz = (n + parts - 1) / parts;  // block_size.div_ceil(partitions), coding.rs:209
+      // exact integer sums of |e_k[t]| per (order, partition); e_k by the binomial form of k
+      // wrapping differences with zero history (reset_fixed_lpc_errors, coding.rs:182-197)
+      for (int j = 0; j < J; ++j) {
+        const int c = tid + j * T;
+        const int t0 = c << 4;
+        if (c < rows) {
+          uint32_t x[20];
+#pragma unroll
+          for (int i = 0; i < 5; ++i) {
+            const int4 v = *reinterpret_cast<const int4*>(&L.sbuf[sidx<ROWSTRIDE>(t0 - 4 + 4 * i)]);
+            x[4 * i + 0] = (uint32_t)v.x;
+            x[4 * i + 1] = (uint32_t)v.y;
+            x[4 * i + 2] = (uint32_t)v.z;
+            x[4 * i + 3] = (uint32_t)v.w;
+          }
+          int cur = t0 / psz;
+          unsigned long long acc[5] = {0ull, 0ull, 0ull, 0ull, 0ull};
+#pragma unroll
+          for (int k = 0; k < 16; ++k) {
+            const int t = t0 + k;
+            if (t < n) {
+              const int pidx = t / psz;
+              if (pidx != cur) {
+#pragma unroll
+                for (int o = 0; o < 5; ++o) {
+                  if (acc[o]) atomicAdd(&fsum[o * 64 + cur], acc[o]);
+                  acc[o] = 0ull;
+                }
+                cur = pidx;
+              }
+              const uint32_t x0 = x[4 + k], x1 = x[3 + k], x2 = x[2 + k], x3 = x[1 + k], x4 = x[k];
+              const int32_t e0 = (int32_t)x0;
+              const int32_t e1 = (int32_t)(x0 - x1);
+              const int32_t e2 = (int32_t)(x0 - 2u * x1 + x2);
+              const int32_t e3 = (int32_t)(x0 - 3u * x1 + 3u * x2 - x3);
+              const int32_t e4 = (int32_t)(x0 - 4u * x1 + 6u * x2 - 4u * x3 + x4);
+              acc[0] += (unsigned long long)(e0 < 0 ? -(int64_t)e0 : (int64_t)e0);
+              acc[1] += (unsigned long long)(e1 < 0 ? -(int64_t)e1 : (int64_t)e1);
+              acc[2] += (unsigned long long)(e2 < 0 ? -(int64_t)e2 : (int64_t)e2);
+              acc[3] += (unsigned long long)(e3 < 0 ? -(int64_t)e3 : (int64_t)e3);
+              acc[4] += (unsigned long long)(e4 < 0 ? -(int64_t)e4 : (int64_t)e4);
+            }
+          }
+#pragma unroll
+          for (int o = 0; o < 5; ++o)
+            if (acc[o]) atomicAdd(&fsum[o * 64 + cur], acc[o]);
+        }
+      }
+      __syncthreads();
+      // estimate_entropy, coding.rs:200-227: one (order, partition) pair per thread
+      for (int i = tid; i < 5 * parts; i += T) {
+        const int ord = i / parts, pidx = i - ord * parts;
+        if (ord <= (int)a.fixed_max_order) {
+          const long long off0 = (long long)pidx * psz;
+          const int offset = off0 < n ? (int)off0 : n;
+          const int end = offset + psz < n ? offset + psz : n;
+          const int plen = end - offset;
+          if (end >= ord) {
+            const int cnt = end - ord < plen ? end - ord : plen;
+            const uint32_t pb = approx_ent_bits((double)fsum[ord * 64 + pidx], (uint32_t)cnt);
+            atomicAdd(&ftot[ord], (unsigned long long)pb);
+          }
+        }
+      }
+      __syncthreads();
+    }
+    if (tid == 0) {
+      int k;
+      unsigned long long key = 0ull;
+      if (a.fixed_mode == 1u) {
+        k = 0;
+        key = ~0ull;
+        for (int ord = 0; ord <= (int)a.fixed_max_order; ++ord) {
+          const unsigned long long kk = L.fsum[5 * 64 + ord] + bps_sf * (unsigned long long)ord;
+          if (a.fixed_keys) a.fixed_keys[(size_t)sf * 8 + ord] = kk;
+          if (kk < key) {  // min_by_key keeps the first minimum
+            key = kk;
+            k = ord;
+          }
+        }
+        if (a.selector_keys) a.selector_keys[sf] = key;
+      } else if (a.fixed_mode == 2u) {
+        k = (int)a.forced_uniform;
+      } else {
+        k = (int)a.forced_orders[sf];
+      }
+      for (int i = 0; i < 32; ++i) L.qc[i] = 0;
+      L.qc[0] = k;  // FIXED_LPC_COEFS[k]: 0 / 1 / 2,-1 / 3,-3,1 / 4,-6,4,-1
+      L.qc[1] = k == 2 ? -1 : (k == 3 ? -3 : (k == 4 ? -6 : 0));
+      L.qc[2] = k == 3 ? 1 : (k == 4 ? 4 : 0);
+      L.qc[3] = k == 4 ? -1 : 0;
+      const uint64_t maxabs = (uint64_t)L.misc[kMiscMaxAbs];
+      const uint64_t sumabs = k == 0 ? 0 : (k == 1 ? 1 : (k == 2 ? 3 : (k == 3 ? 7 : 15)));
+      const bool narrow = (maxabs * sumabs < 0x7FFFFFFFull) && (maxabs < (1u << 23));
+      L.misc[kMiscOrder] = (uint32_t)k;
+      L.misc[kMiscShift] = 0u;
+      L.misc[kMiscStatus] = 0u;
+      L.misc[kMiscWide] = narrow ? 0u : 1u;
+    }
+    __syncthreads();
+  } else {
   // ======================= phase 1: window + autocorrelation ==============
   // window table has 32 floats of zero padding in front and is padded to whole rows
   const float* __restrict__ wtab = a.window ? (a.window + 32) : nullptr;
@@ -461,6 +634,7 @@ qlpc_subframe_kernel(QlpcKernelArgs a) {
     }
   }
   __syncthreads();
+  }  // QLPC predictor
 
   FLACENC_STAMP(3);
   const int warm = (int)L.misc[kMiscOrder];
@@ -846,9 +1020,13 @@ qlpc_subframe_kernel(QlpcKernelArgs a) {
                                    : (unsigned long long)(a.bps_uniform + (role == 3 ? 1u : 0u));
     unsigned long long sub_bits = 8ull + bps * (unsigned long long)warm + 4ull + 5ull +
                                   (unsigned long long)a.precision * (unsigned long long)warm + residual_bits;
+    // BitRepr for FixedLpc::count_bits, bitrepr.rs:473-477
+    if (a.fixed_mode != 0) sub_bits = 8ull + bps * (unsigned long long)warm + residual_bits;
+    // OrderSel::BitCount's key: bits_per_sample * order + code_bits (coding.rs:249)
+    if (a.fixed_mode >= 2u && a.selector_keys) a.selector_keys[sf] = bps * (unsigned long long)warm + code_bits;
     rec->order = (uint8_t)warm;
     rec->shift = (int8_t)shift;
-    rec->precision = (uint8_t)a.precision;
+    rec->precision = (uint8_t)(a.fixed_mode != 0 ? 0u : a.precision);
     rec->rice_order = (uint8_t)(status == 0 ? rice_order : 0);
     rec->status = status;
     rec->code_bits = status == 0 ? code_bits : 0ull;

@@ -186,58 +186,6 @@ __device__ __forceinline__ uint32_t sad_u32(uint32_t x, uint32_t y, uint32_t acc
   return r;
 }
 
-// f32::log2 = libm log2f.  glibc's algorithm (sysdeps/ieee754/flt-32/e_log2f.c, 2.27+): 16-entry
-// {1/c, log2 c} table around OFF = 0x3f330000, degree-4 polynomial in double, one rounding to
-// float.  Same restatement as oracle/flacenc_oracle.c orc_log2f (checked there against the
-// host libm over every positive float).
-__device__ const double kLog2fTab[32] = {
-    0x1.661ec79f8f3bep+0, -0x1.efec65b963019p-2, 0x1.571ed4aaf883dp+0, -0x1.b0b6832d4fca4p-2,
-    0x1.49539f0f010bp+0,  -0x1.7418b0a1fb77bp-2, 0x1.3c995b0b80385p+0, -0x1.39de91a6dcf7bp-2,
-    0x1.30d190c8864a5p+0, -0x1.01d9bf3f2b631p-2, 0x1.25e227b0b8eap+0,  -0x1.97c1d1b3b7afp-3,
-    0x1.1bb4a4a1a343fp+0, -0x1.2f9e393af3c9fp-3, 0x1.12358f08ae5bap+0, -0x1.960cbbf788d5cp-4,
-    0x1.0953f419900a7p+0, -0x1.a6f9db6475fcep-5, 0x1p+0,               0x0p+0,
-    0x1.e608cfd9a47acp-1, 0x1.338ca9f24f53dp-4,  0x1.ca4b31f026aap-1,  0x1.476a9543891bap-3,
-    0x1.b2036576afce6p-1, 0x1.e840b4ac4e4d2p-3,  0x1.9c2d163a1aa2dp-1, 0x1.40645f0c6651cp-2,
-    0x1.886e6037841edp-1, 0x1.88e9c2c1b9ff8p-2,  0x1.767dcf5534862p-1, 0x1.ce0a44eb17bccp-2,
-};
-
-__device__ __forceinline__ float dev_log2f(float x) {
-  uint32_t ix = __float_as_uint(x);
-  if (ix == 0x3f800000u) return 0.0f;
-  if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u) {
-    if (ix * 2u == 0u) return -__builtin_inff();
-    if (ix == 0x7f800000u) return x;
-    if ((ix & 0x80000000u) || ix * 2u >= 0xff000000u) return __builtin_nanf("");
-    ix = __float_as_uint(x * 0x1p23f) - (23u << 23);
-  }
-  const uint32_t tmp = ix - 0x3f330000u;
-  const int i = (int)((tmp >> 19) & 15u);
-  const uint32_t top = tmp & 0xff800000u;
-  const int k = (int)tmp >> 23;
-  const double z = (double)__uint_as_float(ix - top);
-  const double r = z * kLog2fTab[2 * i] - 1.0;
-  const double y0 = kLog2fTab[2 * i + 1] + (double)k;
-  const double r2 = r * r;
-  double y = 0x1.ecabf496832ep-2 * r + -0x1.715479ffae3dep-1;
-  y = -0x1.712b6f70a7e4dp-2 * r2 + y;
-  const double p = 0x1.715475f35c8b8p0 * r + y0;
-  y = y * r2 + p;
-  return (float)y;
-}
-
-// one partition of estimate_entropy (coding.rs:215-222): `sum` is the exact integer sum of
-// |e| over the partition (rounded to f32 once -- the canonical definition of DESIGN.md; equal to
-// find_sum_abs_f32 in either reference build while the sum stays below 2^24)
-__device__ __forceinline__ uint32_t approx_ent_bits(double sum, uint32_t count) {
-  const float sum_errors = (float)sum;
-  const float cnt = (float)count;
-  const float avg_errors = sum_errors * 2.0f / (cnt + 0.00001f);
-  const float geom_p = 1.0f / (avg_errors + 1.0f);
-  const float xent = __builtin_fmaf(avg_errors, -dev_log2f(1.0f - geom_p), -dev_log2f(geom_p));
-  const float v = xent * cnt;
-  return v > 0.0f ? (uint32_t)v : 0u;  // `as usize`: NaN and negatives -> 0
-}
-
 // what fixed_lpc (coding.rs:298-331) settled on for one subframe
 struct FixedChoice {
   bool have;

@@ -17,8 +17,9 @@
 // :469-527) runs on the host exactly as in the reference; every `estimated_qlpc` call is served
 // by the GPU through flacenc_hip_*_qlpc_batch.  There is no CPU implementation of the path here.
 // Not mirrored (out of scope): bit writer, container metadata, MD5, serde.
-// Fixed-LPC candidate (`fixed_lpc`, src/coding.rs:298) is not on the GPU yet: a config with
-// `use_fixed = true` is rejected with EncodeError::Config (the reference default has it on).
+// Fixed-LPC candidate (`fixed_lpc`, src/coding.rs:298): fused into the on-GPU controller where that
+// exists (flacenc_hip_encode_stereo_frames: 2 channels, block 4096, lpc_order <= 12,
+// ApproxEnt.partitions a power of two), served by flacenc_hip_fixed_lpc_batch everywhere else.
 #ifndef FLACENC_HOST_FLACENC_HPP_
 #define FLACENC_HOST_FLACENC_HPP_
 
@@ -102,6 +103,11 @@ struct Prc {  // :211-214
 struct Fixed {  // :236-244
   size_t max_order = 4;
   OrderSel order_sel;
+  void verify() const {  // :246-255, :419-431
+    if (max_order > 4) throw error::VerifyError("max_order", "must be in range ..=4");
+    if (order_sel.type == OrderSel::ApproxEnt && (order_sel.partitions < 1 || order_sel.partitions > 64))
+      throw error::VerifyError("order_sel.ApproxEnt.partitions", "must be in range 1..=64");
+  }
 };
 struct Qlpc {  // :271-288
   size_t lpc_order = constant::qlpc::DEFAULT_ORDER;
@@ -134,6 +140,11 @@ struct SubFrameCoding {  // :167-183
   Qlpc qlpc;
   Prc prc;
   void verify() const {  // :198-204
+    try {
+      fixed.verify();
+    } catch (const error::VerifyError& e) {
+      throw e.within("fixed");
+    }
     try {
       qlpc.verify();
     } catch (const error::VerifyError& e) {
@@ -318,7 +329,16 @@ struct Lpc {  // datatype.rs:2057-2062
     return 8 + size_t(bits_per_sample) * order() + 4 + 5 + parameters.precision * order() + residual.count_bits();
   }
 };
-using SubFrame = std::variant<Constant, Verbatim, Lpc>;  // datatype.rs:1782 (FixedLpc: see header note)
+struct FixedLpc {  // datatype.rs:1960-1964
+  std::vector<int32_t> warm_up;
+  Residual residual;
+  uint8_t bits_per_sample;
+  size_t order() const { return warm_up.size(); }
+  size_t count_bits() const {  // bitrepr.rs:473-477
+    return 8 + size_t(bits_per_sample) * order() + residual.count_bits();
+  }
+};
+using SubFrame = std::variant<Constant, Verbatim, FixedLpc, Lpc>;  // datatype.rs:1782
 inline size_t count_bits(const SubFrame& sf) {
   return std::visit([](const auto& c) { return c.count_bits(); }, sf);
 }
@@ -327,6 +347,19 @@ inline size_t count_bits(const SubFrame& sf) {
 inline std::vector<int32_t> decode(const SubFrame& sf) {
   if (const auto* c = std::get_if<Constant>(&sf)) return std::vector<int32_t>(c->block_size, c->dc_offset);
   if (const auto* v = std::get_if<Verbatim>(&sf)) return v->samples;
+  if (const auto* fx = std::get_if<FixedLpc>(&sf)) {  // decode.rs:179-201
+    static const int32_t kFixedCoefs[5][4] = {{0, 0, 0, 0}, {1, 0, 0, 0}, {2, -1, 0, 0}, {3, -3, 1, 0}, {4, -6, 4, -1}};
+    std::vector<int32_t> dest(fx->residual.block_size);
+    fx->residual.copy_signal(dest.data());
+    const size_t order = fx->order();
+    for (size_t t = 0; t < order; ++t) dest[t] = fx->warm_up[t];
+    for (size_t t = order; t < dest.size(); ++t) {
+      int64_t pred = 0;
+      for (size_t tau = 0; tau < order; ++tau) pred += int64_t(kFixedCoefs[order][tau]) * int64_t(dest[t - 1 - tau]);
+      dest[t] = int32_t(uint32_t(dest[t]) + uint32_t(int32_t(pred)));
+    }
+    return dest;
+  }
   const Lpc& l = std::get<Lpc>(sf);
   std::vector<int32_t> dest(l.residual.block_size);
   l.residual.copy_signal(dest.data());
@@ -441,19 +474,46 @@ inline component::Lpc make_lpc(const flacenc_hip_subframe_params& p, const int32
   return l;
 }
 
-// encode_subframe, src/coding.rs:384-418, with the LPC candidate supplied by the GPU
+// SubFrame::FixedLpc from one GPU record + error-signal row (FixedLpc::from_parts, coding.rs:321-328)
+inline component::FixedLpc make_fixed_lpc(const flacenc_hip_subframe_params& p, const int32_t* residual,
+                                          const int32_t* signal, size_t n, uint8_t bps) {
+  component::FixedLpc fx;
+  fx.warm_up.assign(signal, signal + p.order);
+  fx.residual.partition_order = p.rice_order;
+  fx.residual.block_size = n;
+  fx.residual.warmup_length = p.order;
+  fx.residual.rice_params.assign(p.rice_params, p.rice_params + (size_t(1) << p.rice_order));
+  fx.residual.errors.assign(residual, residual + n);
+  fx.residual.sum_quotients = p.sum_quotients;
+  fx.residual.sum_rice_params = 0;
+  for (uint8_t v : fx.residual.rice_params) fx.residual.sum_rice_params += v;
+  fx.bits_per_sample = bps;
+  return fx;
+}
+
+// encode_subframe, src/coding.rs:384-418, with the LPC and fixed-LPC candidates supplied by the GPU
+// (`fixed_key` = the order selector's key of the fixed candidate: fixed_lpc returned Some iff it is
+// below verbatim_bits, coding.rs:262, :284)
 inline component::SubFrame encode_subframe(const config::SubFrameCoding& cfg, const int32_t* samples, size_t n,
                                            uint8_t bps, const flacenc_hip_subframe_params* lpc_rec,
-                                           const int32_t* lpc_residual) {
+                                           const int32_t* lpc_residual,
+                                           const flacenc_hip_subframe_params* fixed_rec = nullptr,
+                                           const int32_t* fixed_residual = nullptr, uint64_t fixed_key = 0) {
   if (cfg.use_constant && is_constant(samples, n)) return component::Constant{n, samples[0], bps};
   const size_t verbatim_bits = component::Verbatim::count_bits_from_metadata(n, bps);
   const bool too_short = n < constant::MIN_BLOCK_SIZE_FOR_PREDICTION;
-  const size_t baseline_bits = verbatim_bits;  // no fixed-LPC candidate (see header note)
+  const bool have_fixed = !too_short && cfg.use_fixed && fixed_rec != nullptr && fixed_key < verbatim_bits;
+  size_t baseline_bits = verbatim_bits;
+  if (have_fixed) baseline_bits = std::min<size_t>(verbatim_bits, fixed_rec->subframe_bits);
   if (!too_short && cfg.use_lpc && lpc_rec != nullptr) {
     if (lpc_rec->status != FLACENC_HIP_SUBFRAME_OK)
       throw std::runtime_error("LPC analysis reported a non-finite result (the reference panics here, lpc.rs:786)");
     component::Lpc cand = make_lpc(*lpc_rec, lpc_residual, samples, n, bps);
-    if (cand.count_bits() < baseline_bits) return cand;
+    if (cand.count_bits() < baseline_bits) return cand;  // then also < verbatim_bits
+  }
+  if (have_fixed) {
+    component::FixedLpc cand = make_fixed_lpc(*fixed_rec, fixed_residual, samples, n, bps);
+    if (cand.count_bits() < verbatim_bits) return cand;
   }
   return component::Verbatim{std::vector<int32_t>(samples, samples + n), bps};
 }
@@ -471,10 +531,6 @@ component::Stream encode_with_fixed_block_size(const config::Encoder& config, So
     throw error::EncodeError(error::EncodeError::Config, e.what());
   }
   const config::SubFrameCoding& sc = config.subframe_coding;
-  if (sc.use_fixed)
-    throw error::EncodeError(error::EncodeError::Config,
-                             "subframe_coding.use_fixed: the fixed-LPC candidate is not available on the GPU "
-                             "path yet; set use_fixed = false");
   const size_t nch = src.channels();
   const size_t bps = src.bits_per_sample();
   if (nch < 1 || nch > constant::MAX_CHANNELS || bps < constant::MIN_BITS_PER_SAMPLE ||
@@ -514,7 +570,8 @@ component::Stream encode_with_fixed_block_size(const config::Encoder& config, So
     //     (flacenc_hip_encode_stereo_frames: block 4096, order <= 12); its records are turned
     //     into Frames directly.  Anything else falls through to the 4-candidate path below and the
     //     host-side controller -- same result either way (tests/test_gpu_parity.py).
-    if (use_gpu && stereo) {
+    const bool fused_ok = (sc.use_lpc || sc.use_fixed) && n >= constant::MIN_BLOCK_SIZE_FOR_PREDICTION;
+    if (fused_ok && stereo) {
       std::vector<int32_t> staged(nf * 2 * n);
       for (size_t f = 0; f < nf; ++f)
         for (size_t c = 0; c < 2; ++c)
@@ -522,7 +579,11 @@ component::Stream encode_with_fixed_block_size(const config::Encoder& config, So
       flacenc_hip_frame_config fc{};
       fc.qlpc = abi_cfg;
       fc.use_constant = sc.use_constant;
-      fc.use_fixed = 0;
+      fc.use_fixed = sc.use_fixed;
+      fc.fixed_max_order = static_cast<uint32_t>(sc.fixed.max_order);
+      fc.fixed_order_sel = sc.fixed.order_sel.type == config::OrderSel::BitCount ? FLACENC_HIP_ORDERSEL_BITCOUNT
+                                                                                 : FLACENC_HIP_ORDERSEL_APPROXENT;
+      fc.fixed_partitions = static_cast<uint32_t>(sc.fixed.order_sel.partitions);
       fc.use_lpc = sc.use_lpc;
       fc.use_leftside = config.stereo_coding.use_leftside;
       fc.use_rightside = config.stereo_coding.use_rightside;
@@ -551,6 +612,9 @@ component::Stream encode_with_fixed_block_size(const config::Encoder& config, So
               frame.subframes.push_back(component::Constant{n, fr[f].dc_offset[c], b});
             } else if (fr[f].kind[c] == FLACENC_HIP_KIND_VERBATIM) {
               frame.subframes.push_back(component::Verbatim{std::move(sig), b});
+            } else if (fr[f].kind[c] == FLACENC_HIP_KIND_FIXED) {
+              frame.subframes.push_back(
+                  detail::make_fixed_lpc(fr[f].lpc[c], &resid2[(f * 2 + c) * n], sig.data(), n, b));
             } else {
               if (fr[f].lpc[c].status != FLACENC_HIP_SUBFRAME_OK)
                 throw std::runtime_error("LPC analysis reported a non-finite result (lpc.rs:786)");
@@ -588,6 +652,34 @@ component::Stream encode_with_fixed_block_size(const config::Encoder& config, So
         throw error::EncodeError(error::EncodeError::Config, flacenc_hip_last_error(gpu.get()));
       if (rc != FLACENC_HIP_OK) throw error::EncodeError(error::EncodeError::Device, flacenc_hip_last_error(gpu.get()));
     }
+    // 2c. the fixed-LPC candidates of the same subframes (fixed_lpc, coding.rs:298-331)
+    const bool use_fixed_gpu = sc.use_fixed && n >= constant::MIN_BLOCK_SIZE_FOR_PREDICTION;
+    std::vector<flacenc_hip_subframe_params> frecs;
+    std::vector<int32_t> fresid;
+    std::vector<uint64_t> fkeys;
+    if (use_fixed_gpu) {
+      frecs.resize(nf * per_frame);
+      fresid.resize(nf * per_frame * n);
+      fkeys.resize(nf * per_frame);
+      std::vector<int32_t> staged(nf * nch * n);
+      for (size_t f = 0; f < nf; ++f)
+        for (size_t c = 0; c < nch; ++c)
+          std::memcpy(&staged[(f * nch + c) * n], bufs[f0 + f].channel_slice(c), n * sizeof(int32_t));
+      flacenc_hip_frame_config fc{};
+      fc.qlpc = abi_cfg;
+      fc.use_fixed = 1;
+      fc.fixed_max_order = static_cast<uint32_t>(sc.fixed.max_order);
+      fc.fixed_order_sel = sc.fixed.order_sel.type == config::OrderSel::BitCount ? FLACENC_HIP_ORDERSEL_BITCOUNT
+                                                                                 : FLACENC_HIP_ORDERSEL_APPROXENT;
+      fc.fixed_partitions = static_cast<uint32_t>(sc.fixed.order_sel.partitions);
+      const int rc = flacenc_hip_fixed_lpc_batch(
+          gpu.get(), &fc, staged.data(), stereo ? nf : nf * nch, static_cast<uint32_t>(n), n, nullptr,
+          static_cast<uint32_t>(bps), stereo ? FLACENC_HIP_LAYOUT_STEREO_FRAMES : FLACENC_HIP_LAYOUT_SUBFRAMES,
+          frecs.data(), fresid.data(), n, fkeys.data(), FLACENC_HIP_MEM_HOST);
+      if (rc == FLACENC_HIP_ERR_BAD_CONFIG)
+        throw error::EncodeError(error::EncodeError::Config, flacenc_hip_last_error(gpu.get()));
+      if (rc != FLACENC_HIP_OK) throw error::EncodeError(error::EncodeError::Device, flacenc_hip_last_error(gpu.get()));
+    }
     // 3. the reference's controller per frame (encode_frame, coding.rs:530-544)
     for (size_t f = 0; f < nf; ++f) {
       const source::FrameBuf& fb = bufs[f0 + f];
@@ -596,10 +688,13 @@ component::Stream encode_with_fixed_block_size(const config::Encoder& config, So
       frame.block_size = n;
       auto rec = [&](size_t k) { return use_gpu ? &recs[f * per_frame + k] : nullptr; };
       auto res = [&](size_t k) { return use_gpu ? &resid[(f * per_frame + k) * n] : nullptr; };
+      auto frec = [&](size_t k) { return use_fixed_gpu ? &frecs[f * per_frame + k] : nullptr; };
+      auto fres = [&](size_t k) { return use_fixed_gpu ? &fresid[(f * per_frame + k) * n] : nullptr; };
+      auto fkey = [&](size_t k) { return use_fixed_gpu ? fkeys[f * per_frame + k] : uint64_t(0); };
       if (!stereo) {
         for (size_t c = 0; c < nch; ++c)
           frame.subframes.push_back(detail::encode_subframe(sc, fb.channel_slice(c), n, static_cast<uint8_t>(bps),
-                                                            rec(c), res(c)));
+                                                            rec(c), res(c), frec(c), fres(c), fkey(c)));
       } else {
         // try_stereo_coding, coding.rs:469-527
         const int32_t* l = fb.channel_slice(0);
@@ -609,10 +704,10 @@ component::Stream encode_with_fixed_block_size(const config::Encoder& config, So
           m[t] = (l[t] + r[t]) >> 1;
           s[t] = l[t] - r[t];
         }
-        component::SubFrame sl = detail::encode_subframe(sc, l, n, static_cast<uint8_t>(bps), rec(0), res(0));
-        component::SubFrame sr = detail::encode_subframe(sc, r, n, static_cast<uint8_t>(bps), rec(1), res(1));
-        component::SubFrame sm = detail::encode_subframe(sc, m.data(), n, static_cast<uint8_t>(bps), rec(2), res(2));
-        component::SubFrame ss = detail::encode_subframe(sc, s.data(), n, static_cast<uint8_t>(bps + 1), rec(3), res(3));
+        component::SubFrame sl = detail::encode_subframe(sc, l, n, static_cast<uint8_t>(bps), rec(0), res(0), frec(0), fres(0), fkey(0));
+        component::SubFrame sr = detail::encode_subframe(sc, r, n, static_cast<uint8_t>(bps), rec(1), res(1), frec(1), fres(1), fkey(1));
+        component::SubFrame sm = detail::encode_subframe(sc, m.data(), n, static_cast<uint8_t>(bps), rec(2), res(2), frec(2), fres(2), fkey(2));
+        component::SubFrame ss = detail::encode_subframe(sc, s.data(), n, static_cast<uint8_t>(bps + 1), rec(3), res(3), frec(3), fres(3), fkey(3));
         const size_t bl = component::count_bits(sl), br = component::count_bits(sr);
         const size_t bm = component::count_bits(sm), bs = component::count_bits(ss);
         size_t min_bits = bl + br;

@@ -249,6 +249,38 @@ int flacenc_hip_encode_stereo_frames_async(flacenc_hip_handle* h, const flacenc_
                                            flacenc_hip_stereo_frame_result* results, int32_t* residual,
                                            size_t residual_stride, void* stream);
 
+/* ---- fixed_lpc as a stand-alone batch (any block size, any channel count) ---------------- */
+#define FLACENC_HIP_LAYOUT_SUBFRAMES 0     /* unit = one subframe at samples + k*stride */
+#define FLACENC_HIP_LAYOUT_STEREO_FRAMES 1 /* unit = one 2-channel frame; outputs 4f + {L, R, M, S} */
+/*
+ * `fixed_lpc` (src/coding.rs:298-331) for a batch: reset_fixed_lpc_errors (:182-197), the order
+ * selector of cfg->fixed_* (select_order_and_encode_residual :230-288; ApproxEnt partitions may
+ * be any 1..=64 here) and the Rice-coded error signal of the selected order.  Only the fixed_* and
+ * qlpc.max_rice_parameter fields of `cfg` are used.  Per subframe:
+ *   params[k]        order = selected fixed order, coefs = FIXED_LPC_COEFS[order]
+ *                    (src/component/decode.rs:179-185), shift 0, precision 0, the Rice partition,
+ *                    code_bits, sum_quotients, subframe_bits = FixedLpc::count_bits (bitrepr.rs:473-477)
+ *   residual         the order's error signal, first `order` slots zero
+ *   selector_keys[k] optional: the selector's key of the selected order (estimate_entropy +
+ *                    bps*order, or bps*order + code_bits for BitCount).  `fixed_lpc` returns Some(..)
+ *                    iff this key is < baseline_bits (coding.rs:262, :284): that comparison, and
+ *                    encode_subframe's choice (coding.rs:384-418), stay with the caller.
+ *   bps              per-subframe bits per sample (SUBFRAMES layout; NULL -> bits_per_sample);
+ *                    STEREO_FRAMES uses bits_per_sample (+1 for the side channel, coding.rs:444).
+ * This is the general-shape companion of flacenc_hip_encode_stereo_frames, which fuses the same
+ * computation into the frame decision for block_size 4096.
+ */
+int flacenc_hip_fixed_lpc_batch(flacenc_hip_handle* h, const flacenc_hip_frame_config* cfg,
+                                const int32_t* samples, size_t n_units, uint32_t block_size, size_t stride,
+                                const uint8_t* bps, uint32_t bits_per_sample, int layout,
+                                flacenc_hip_subframe_params* params, int32_t* residual, size_t residual_stride,
+                                uint64_t* selector_keys, int memory_kind);
+int flacenc_hip_fixed_lpc_batch_async(flacenc_hip_handle* h, const flacenc_hip_frame_config* cfg,
+                                      const int32_t* samples, size_t n_units, uint32_t block_size,
+                                      size_t stride, const uint8_t* bps, uint32_t bits_per_sample, int layout,
+                                      flacenc_hip_subframe_params* params, int32_t* residual,
+                                      size_t residual_stride, uint64_t* selector_keys, void* stream);
+
 int flacenc_hip_synchronize(flacenc_hip_handle* h);
 
 /* Test hook (no reference counterpart): when `device_keys` is non-NULL, launches with use_fixed

@@ -108,15 +108,48 @@ int main() {
       std::printf("  expected config error: %s\n", e.what());
     }
     CHECK(thrown);
-    config::Encoder fixed_on;  // reference default has use_fixed = true: not on the GPU path yet
+    config::Encoder bad_fixed;
+    bad_fixed.subframe_coding.fixed.max_order = 5;  // config.rs:246-255
     thrown = false;
     try {
       auto src = source::MemSource::from_samples(std::vector<int32_t>(8192, 1), 1, 16, 44100);
-      encode_with_fixed_block_size(fixed_on, src, 4096, gpu);
+      encode_with_fixed_block_size(bad_fixed, src, 4096, gpu);
     } catch (const error::EncodeError& e) {
       thrown = e.kind == error::EncodeError::Config;
     }
     CHECK(thrown);
+  }
+  // the reference's default configuration (use_fixed = true): fused path for stereo 4096 blocks,
+  // flacenc_hip_fixed_lpc_batch for the short tail block and every other shape
+  {
+    config::Encoder def;
+    for (size_t channels : {1, 2, 3}) integrity_test(gpu, def, channels, 16123, 16, 4096);
+    integrity_test(gpu, def, 2, 16123, 16, 1152);
+    integrity_test(gpu, def, 2, 40000, 24, 8192);
+    config::Encoder bc = def;
+    bc.subframe_coding.fixed.order_sel.type = config::OrderSel::BitCount;
+    integrity_test(gpu, bc, 2, 16123, 16, 4096);
+    integrity_test(gpu, bc, 1, 9000, 16, 2304);
+    // a slow ramp: FixedLpc must win over both Verbatim and the QLPC candidate (fixed_lpc_of_sine-like)
+    for (size_t block : {size_t(4096), size_t(1152)}) {
+      std::vector<int32_t> ramp(2 * 12000);
+      for (size_t t = 0; t < 12000; ++t) {
+        ramp[2 * t] = int32_t(t / 7);
+        ramp[2 * t + 1] = int32_t((t * t) / 40000) - 1000;
+      }
+      auto src = source::MemSource::from_samples(ramp, 2, 16, 44100);
+      auto st = encode_with_fixed_block_size(def, src, block, gpu);
+      size_t fixed = 0, pos = 0;
+      for (const auto& f : st.frames) {
+        const auto ch = f.decode_channels();
+        for (size_t c = 0; c < 2; ++c)
+          for (size_t t = 0; t < f.block_size; ++t) CHECK(ch[c][t] == ramp[(pos + t) * 2 + c]);
+        for (const auto& sf : f.subframes) fixed += std::holds_alternative<component::FixedLpc>(sf);
+        pos += f.block_size;
+      }
+      std::printf("  ramp, block %zu: %zu FixedLpc subframes of %zu\n", block, fixed, st.frames.size() * 2);
+      CHECK(fixed > 0);
+    }
   }
   if (failures) {
     std::printf("FAILED: %d\n", failures);

@@ -626,6 +626,64 @@ def test_encode_stereo_frames_fixed_24bit(handle):
     _decode_frames(x, got, gres)
 
 
+@pytest.mark.parametrize("n,bps,sel,parts,max_order", [
+    (4096, 16, 1, 16, 4), (4608, 16, 1, 16, 4), (1152, 16, 1, 7, 4), (8192, 24, 1, 64, 4),
+    (576, 16, 1, 1, 2), (100, 8, 1, 64, 4), (16384, 24, 1, 16, 4), (20000, 16, 1, 33, 3),
+    (4096, 16, 0, 16, 4), (4608, 16, 0, 16, 2), (192, 16, 0, 16, 4), (8192, 24, 0, 16, 4),
+])
+def test_fixed_lpc_batch_any_shape(handle, n, bps, sel, parts, max_order):
+    """flacenc_hip_fixed_lpc_batch == fixed_lpc (coding.rs:298-331) on ragged / large / tiny blocks,
+    any ApproxEnt partition count (incl. partitions shorter than the warm-up and empty ones) and
+    BitCount: selector keys, chosen order, Rice partition, bit counts and the error signal."""
+    sigs = [util.sine_noise(n, bps, 200, 0.4, 0.05, seed=1), util.sine_noise(n, bps, 31, 0.7, 0.3, seed=2),
+            util.quantize(util.sine(n, 100, 0.6), bps), (np.arange(n) // 7).astype(np.int32),
+            ((np.arange(n) - n // 2) ** 2 // 400 % (1 << (bps - 2))).astype(np.int32),
+            np.full(n, 77, np.int32), np.zeros(n, np.int32),
+            util.quantize(util.noise(5, n, 0.999), bps),
+            np.where(np.arange(n) % 2 == 0, 2 ** (bps - 1) - 1, -2 ** (bps - 1)).astype(np.int32)]
+    x = np.stack(sigs).astype(np.int32)
+    bpsv = np.full(len(sigs), bps, np.uint8)
+    bpsv[1] = bps + 1 if bps < 25 else bps
+    cfg = _capi.make_frame_config(gpu_cfg(8), use_fixed=True, fixed_order_sel=sel, fixed_partitions=parts,
+                                  fixed_max_order=max_order)
+    params, resid, keys = handle.fixed_lpc_batch(x, bpsv, cfg)
+    fc = orc.make_fixed_config(max_order=max_order, order_sel=sel, partitions=parts,
+                               sum_mode=orc.SUMABS_CANONICAL)
+    for k in range(len(sigs)):
+        w = orc.fixed_lpc(x[k], int(bpsv[k]), 2 ** 63, fc)
+        p = params[k]
+        assert int(p["order"]) == w["order"], k
+        assert int(keys[k]) == w["estimate"][w["order"]], k
+        for fld in ("rice_order", "code_bits", "subframe_bits", "sum_quotients"):
+            assert int(p[fld]) == int(w[fld]), (k, fld)
+        assert int(p["shift"]) == 0 and int(p["precision"]) == 0 and int(p["status"]) == 0
+        assert p["coefs"][:4].tolist() == orc.FIXED_LPC_COEFS[w["order"]]
+        assert p["rice_params"][: 1 << w["rice_order"]].tolist() == w["rice_params"].tolist()
+        assert np.array_equal(resid[k], w["residual"]), k
+        assert np.array_equal(orc.decode_fixed(x[k][: w["order"]], resid[k]), x[k]), k
+
+
+@pytest.mark.parametrize("n,sel", [(4608, 1), (4096, 1), (2048, 0)])
+def test_fixed_lpc_batch_stereo_roles(handle, n, sel):
+    """STEREO_FRAMES layout: L, R and the M = (l+r)>>1, S = l-r formed on the GPU (coding.rs:476-484),
+    side channel with one more bit per sample (coding.rs:444)."""
+    bps = 16
+    x = _capi.sigen_frames(5, 2, n, bps, 90.0, 0.5, 0.02, seed=31)
+    x[1, 1] = x[1, 0] // 2 + 3
+    x[2] = (np.arange(n)[None, :] * np.array([[3], [-2]]) // 5).astype(np.int32)
+    cfg = _capi.make_frame_config(gpu_cfg(8), use_fixed=True, fixed_order_sel=sel)
+    params, resid, keys = handle.fixed_lpc_batch(x, bps, cfg, stereo=True)
+    fc = orc.make_fixed_config(order_sel=sel, sum_mode=orc.SUMABS_CANONICAL)
+    for f in range(x.shape[0]):
+        l, r = x[f, 0], x[f, 1]
+        for role, sig in enumerate([l, r, *orc.stereo_to_midside(l, r)]):
+            w = orc.fixed_lpc(sig, bps + (1 if role == 3 else 0), 2 ** 63, fc)
+            p = params[f, role]
+            assert int(p["order"]) == w["order"] and int(keys[f, role]) == w["estimate"][w["order"]], (f, role)
+            assert int(p["subframe_bits"]) == w["subframe_bits"] and int(p["code_bits"]) == w["code_bits"]
+            assert np.array_equal(resid[f, role], w["residual"]), (f, role)
+
+
 def test_encode_stereo_frames_rejects_unsupported(handle):
     x = np.zeros((2, 2, 4096), np.int32)
     with pytest.raises(_capi.FlacencHipError) as ei:

@@ -48,6 +48,60 @@ pub struct SubframeParams {
     pub rice_params: [u8; 256],
 }
 
+/// `flacenc_hip_frame_config`: `config::SubFrameCoding` switches, `config::Fixed`
+/// (`src/config.rs:236-244`) and `config::StereoCoding` (`:137-144`).
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct FrameConfig {
+    pub qlpc: QlpcConfig,
+    pub use_constant: u32,
+    pub use_fixed: u32,
+    pub use_lpc: u32,
+    pub use_leftside: u32,
+    pub use_rightside: u32,
+    pub use_midside: u32,
+    pub fixed_max_order: u32,
+    pub fixed_order_sel: u32, // 0 = OrderSel::BitCount, 1 = OrderSel::ApproxEnt
+    pub fixed_partitions: u32,
+    pub reserved: u32,
+}
+
+impl FrameConfig {
+    pub fn from_encoder(config: &config::Encoder) -> Self {
+        let sc = &config.subframe_coding;
+        let (sel, partitions) = match sc.fixed.order_sel {
+            config::OrderSel::BitCount => (0, 0),
+            config::OrderSel::ApproxEnt { partitions } => (1, partitions as u32),
+        };
+        Self {
+            qlpc: abi_config(sc),
+            use_constant: sc.use_constant as u32,
+            use_fixed: sc.use_fixed as u32,
+            use_lpc: sc.use_lpc as u32,
+            use_leftside: config.stereo_coding.use_leftside as u32,
+            use_rightside: config.stereo_coding.use_rightside as u32,
+            use_midside: config.stereo_coding.use_midside as u32,
+            fixed_max_order: sc.fixed.max_order as u32,
+            fixed_order_sel: sel,
+            fixed_partitions: partitions,
+            reserved: 0,
+        }
+    }
+}
+
+/// `flacenc_hip_stereo_frame_result`: 752 bytes, what `encode_frame` decided for one frame.
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct StereoFrameResult {
+    pub channel_assignment: u8, // 0 Independent(2), 1 LeftSide, 2 RightSide, 3 MidSide
+    pub kind: [u8; 2],          // 0 Constant, 1 Verbatim, 2 FixedLpc, 3 Lpc
+    pub role: [u8; 2],          // 0 L, 1 R, 2 M, 3 S
+    pub pad: [u8; 3],
+    pub dc_offset: [i32; 2],
+    pub bits: [u64; 4],
+    pub lpc: [SubframeParams; 2],
+}
+
 #[repr(C)]
 pub struct Handle {
     _private: [u8; 0],
@@ -67,6 +121,19 @@ extern "C" {
     pub fn flacenc_hip_stereo_qlpc_batch(
         h: *mut Handle, cfg: *const QlpcConfig, frames: *const i32, n_frames: usize,
         block_size: u32, stride: usize, bits_per_sample: u32, params: *mut SubframeParams,
+        residual: *mut i32, residual_stride: usize, memory_kind: c_int,
+    ) -> c_int;
+    /// `fixed_lpc` (`src/coding.rs:298-331`) for a batch; `layout` 0 = subframes, 1 = stereo frames.
+    pub fn flacenc_hip_fixed_lpc_batch(
+        h: *mut Handle, cfg: *const FrameConfig, samples: *const i32, n_units: usize,
+        block_size: u32, stride: usize, bps: *const u8, bits_per_sample: u32, layout: c_int,
+        params: *mut SubframeParams, residual: *mut i32, residual_stride: usize,
+        selector_keys: *mut u64, memory_kind: c_int,
+    ) -> c_int;
+    /// `encode_frame` (`src/coding.rs:530-544`) for 2-channel frames, decision on the GPU.
+    pub fn flacenc_hip_encode_stereo_frames(
+        h: *mut Handle, cfg: *const FrameConfig, frames: *const i32, n_frames: usize,
+        block_size: u32, stride: usize, bits_per_sample: u32, results: *mut StereoFrameResult,
         residual: *mut i32, residual_stride: usize, memory_kind: c_int,
     ) -> c_int;
     pub fn flacenc_hip_qlpc_batch_async(
@@ -136,6 +203,33 @@ pub fn lpc_from_record(p: &SubframeParams, residual: &[i32], signal: &[i32], bps
     Lpc::from_parts(
         heapless::Vec::from_slice(&signal[..order]).expect("LPC order exceeded the maximum"),
         qlpc, residual, bps,
+    )
+    .into()
+}
+
+/// Rebuilds the `SubFrame::FixedLpc` that `fixed_lpc` (`src/coding.rs:298-331`) would have returned
+/// from one record of `flacenc_hip_fixed_lpc_batch` (or a `kind == 2` slot of a
+/// `StereoFrameResult`) + its error-signal row (`FixedLpc::from_parts`, `src/coding.rs:321-328`).
+/// For the stand-alone batch the caller first checks `selector_key < baseline_bits`
+/// (`src/coding.rs:262, 284`): otherwise `fixed_lpc` returned `None`.
+pub fn fixed_lpc_from_record(p: &SubframeParams, residual: &[i32], signal: &[i32], bps: u8) -> SubFrame {
+    let order = p.order as usize;
+    let nparts = 1usize << p.rice_order;
+    let part_size = signal.len() >> p.rice_order;
+    let mut quotients = vec![0u32; signal.len()];
+    let mut remainders = vec![0u32; signal.len()];
+    for t in order..signal.len() {
+        let rice_p = p.rice_params[t / part_size];
+        let err = crate::rice::encode_signbit(residual[t]);
+        quotients[t] = err >> rice_p;
+        remainders[t] = err & ((1u32 << rice_p) - 1);
+    }
+    let residual = Residual::from_parts(
+        p.rice_order, signal.len(), order, p.rice_params[..nparts].to_vec(), quotients, remainders,
+    );
+    crate::component::FixedLpc::from_parts(
+        heapless::Vec::from_slice(&signal[..order]).expect("Exceeded maximum order for FixedLpc component."),
+        residual, bps,
     )
     .into()
 }

@@ -1234,3 +1234,245 @@ void orc_encode_stereo_frame_cfg(const int32_t* l, const int32_t* r, size_t n, u
   free(m);
   free(s);
 }
+
+/* ------------------------------------------------------------------------ */
+/* bit writer: src/component/bitrepr.rs (Frame, FrameHeader, SubFrame,        */
+/* Residual), MSB-first like bitsink::MemSink                                 */
+/* ------------------------------------------------------------------------ */
+
+typedef struct {
+  uint8_t* buf;
+  size_t cap;    /* bytes */
+  size_t bitpos; /* bits written; bits beyond are zero */
+} orc_bitsink;
+
+static void orc_sink_put(orc_bitsink* s, uint64_t val, unsigned nbits) {
+  for (unsigned i = 0; i < nbits; ++i) {
+    size_t b = s->bitpos++;
+    if ((b >> 3) >= s->cap) continue; /* counted, not stored */
+    if ((val >> (nbits - 1 - i)) & 1u) s->buf[b >> 3] |= (uint8_t)(0x80u >> (b & 7));
+  }
+}
+static void orc_sink_zeros(orc_bitsink* s, size_t n) { s->bitpos += n; }
+/* BitSink::write_twoc: the low `bits` bits of the two's complement value */
+static void orc_sink_twoc(orc_bitsink* s, int32_t v, unsigned bits) {
+  orc_sink_put(s, (uint64_t)(uint32_t)v & ((bits >= 32) ? 0xFFFFFFFFull : ((1ull << bits) - 1)), bits);
+}
+
+/* crc::CRC_8_SMBUS (poly 0x07, init 0, no reflection, xorout 0), bitrepr.rs:39 */
+uint8_t orc_crc8(const uint8_t* data, size_t len) {
+  uint8_t crc = 0;
+  for (size_t i = 0; i < len; ++i) {
+    crc ^= data[i];
+    for (int b = 0; b < 8; ++b) crc = (uint8_t)((crc & 0x80) ? (crc << 1) ^ 0x07 : (crc << 1));
+  }
+  return crc;
+}
+/* crc::CRC_16_UMTS (poly 0x8005, init 0, no reflection, xorout 0), bitrepr.rs:40 */
+uint16_t orc_crc16(const uint8_t* data, size_t len) {
+  uint16_t crc = 0;
+  for (size_t i = 0; i < len; ++i) {
+    crc ^= (uint16_t)((uint16_t)data[i] << 8);
+    for (int b = 0; b < 8; ++b) crc = (uint16_t)((crc & 0x8000) ? (crc << 1) ^ 0x8005 : (crc << 1));
+  }
+  return crc;
+}
+
+/* encode_to_utf8like, bitrepr.rs:108-154; returns the byte count (0 if val needs > 36 bits) */
+size_t orc_encode_to_utf8like(uint64_t val, uint8_t out[7]) {
+  static const uint8_t heads[7] = {0x80, 0xC0, 0xE0, 0xF0, 0xF8, 0xFC, 0xFE};
+  unsigned code_bits = 0;
+  while (code_bits < 64 && (val >> code_bits) != 0) ++code_bits;
+  if (code_bits <= 7) {
+    out[0] = (uint8_t)val;
+    return 1;
+  }
+  if (code_bits > 36) return 0;
+  unsigned trailing = (code_bits - 2) / 5;
+  unsigned capacity = trailing * 6 + 6 - trailing;
+  unsigned first_bits = 6 - trailing;
+  uint64_t v = val << (64 - capacity);
+  out[0] = trailing == 6 ? 0xFE : (uint8_t)(heads[trailing] | (first_bits ? ((v >> (64 - first_bits)) & 0xFF) : 0));
+  v = first_bits ? (v << first_bits) : v;
+  for (unsigned i = 0; i < trailing; ++i) {
+    out[1 + i] = (uint8_t)(0x80u | (uint8_t)(v >> 58));
+    v <<= 6;
+  }
+  return 1 + trailing;
+}
+
+/* BlockSizeSpec::from_size + tag + extra bits, datatype.rs:1239-1294 */
+static void orc_block_size_spec(uint32_t size, uint32_t* tag, uint32_t* extra_bits, uint32_t* extra) {
+  *extra_bits = 0;
+  *extra = 0;
+  if (size == 192) { *tag = 1; return; }
+  for (uint32_t x = 0; x < 4; ++x)
+    if (size == (576u << x)) { *tag = 2 + x; return; }
+  for (uint32_t x = 0; x < 8; ++x)
+    if (size == (256u << x)) { *tag = 8 + x; return; }
+  if (size <= 256) { *tag = 6; *extra_bits = 8; *extra = (size - 1) & 0xFF; return; }
+  *tag = 7;
+  *extra_bits = 16;
+  *extra = (size - 1) & 0xFFFF;
+}
+
+/* SampleRateSpec::from_freq + tag + extra bits, datatype.rs:1427-1453, 1503-1543;
+ * encode_frame_impl falls back to Unspecified (coding.rs:434-435) */
+static void orc_sample_rate_spec(uint32_t freq, uint32_t* tag, uint32_t* extra_bits, uint32_t* extra) {
+  static const uint32_t known[12] = {0, 88200, 176400, 192000, 8000, 16000, 22050, 24000, 32000, 44100, 48000, 96000};
+  *extra_bits = 0;
+  *extra = 0;
+  for (uint32_t t = 1; t < 12; ++t)
+    if (freq == known[t]) { *tag = t; return; }
+  if (freq % 1000 == 0 && freq / 1000 <= 255) { *tag = 12; *extra_bits = 8; *extra = freq / 1000; return; }
+  if (freq % 10 == 0 && freq / 10 <= 65535) { *tag = 14; *extra_bits = 16; *extra = freq / 10; return; }
+  if (freq <= 65535) { *tag = 13; *extra_bits = 16; *extra = freq; return; }
+  *tag = 0;
+}
+
+/* SampleSizeSpec::from_bits / into_tag, datatype.rs:1304-1360 */
+static uint32_t orc_sample_size_tag(uint32_t bits) {
+  switch (bits) {
+    case 8: return 1;
+    case 12: return 2;
+    case 16: return 4;
+    case 20: return 5;
+    case 24: return 6;
+    case 32: return 7;
+    default: return 0;
+  }
+}
+
+/* BitRepr for FrameHeader::write, bitrepr.rs:373-419.  `variable` selects the blocking strategy
+ * and what `offset` means (FrameOffset::StartSample / ::Frame); `sample_rate` = 0 and
+ * `bits_per_sample` = 0 give the Unspecified specs.  Returns the header length in bytes. */
+size_t orc_write_frame_header(uint32_t block_size, uint32_t channel_tag, uint32_t bits_per_sample,
+                              uint32_t sample_rate, int variable, uint64_t offset, uint8_t* out) {
+  uint8_t hdr[24];
+  size_t n = 0;
+  uint32_t bs_tag, bs_bits, bs_extra, sr_tag, sr_bits, sr_extra;
+  orc_block_size_spec(block_size, &bs_tag, &bs_bits, &bs_extra);
+  if (sample_rate) orc_sample_rate_spec(sample_rate, &sr_tag, &sr_bits, &sr_extra);
+  else { sr_tag = 0; sr_bits = 0; sr_extra = 0; }
+  uint32_t header_word = 0xFFF8u + (variable ? 1u : 0u);
+  hdr[n++] = (uint8_t)(header_word >> 8);
+  hdr[n++] = (uint8_t)header_word;
+  hdr[n++] = (uint8_t)((bs_tag << 4) | sr_tag);
+  hdr[n++] = (uint8_t)((channel_tag << 4) | (orc_sample_size_tag(bits_per_sample) << 1));
+  n += orc_encode_to_utf8like(offset, hdr + n);
+  if (bs_bits == 8) hdr[n++] = (uint8_t)bs_extra;
+  if (bs_bits == 16) { hdr[n++] = (uint8_t)(bs_extra >> 8); hdr[n++] = (uint8_t)bs_extra; }
+  if (sr_bits == 8) hdr[n++] = (uint8_t)sr_extra;
+  if (sr_bits == 16) { hdr[n++] = (uint8_t)(sr_extra >> 8); hdr[n++] = (uint8_t)sr_extra; }
+  hdr[n] = orc_crc8(hdr, n);
+  ++n;
+  memcpy(out, hdr, n);
+  return n;
+}
+
+/* BitRepr for Residual::write, bitrepr.rs:550-597 */
+static void orc_write_residual(orc_bitsink* s, const int32_t* errors, size_t n, size_t warmup,
+                               uint32_t partition_order, const uint8_t* rice_params) {
+  size_t nparts = (size_t)1 << partition_order;
+  int rice2 = 0;
+  for (size_t q = 0; q < nparts; ++q) rice2 |= rice_params[q] > 14;
+  orc_sink_put(s, ((uint64_t)(rice2 ? 1 : 0) << 4) | partition_order, 6);
+  size_t part_len = n >> partition_order, offset = 0;
+  for (size_t q = 0; q < nparts; ++q) {
+    uint32_t p = rice_params[q];
+    orc_sink_put(s, p, rice2 ? 5 : 4);
+    size_t start = warmup > offset ? warmup : offset;
+    offset += part_len;
+    for (size_t t = start; t < offset; ++t) {
+      uint32_t u = orc_encode_signbit(errors[t]);
+      orc_sink_zeros(s, u >> p);                                              /* unary quotient */
+      orc_sink_put(s, (uint64_t)((u & ((1u << p) - 1u)) | (1u << p)), p + 1); /* stop bit + remainder */
+    }
+  }
+}
+
+/* BitRepr for SubFrame::write: Constant bitrepr.rs:449-454, Verbatim :463-470, FixedLpc :479-487,
+ * Lpc :501-527.  Returns the bits written. */
+static size_t orc_write_subframe_sink(orc_bitsink* s, const orc_subframe_desc* d, size_t n) {
+  size_t start = s->bitpos;
+  if (d->kind == 0) {
+    orc_sink_put(s, 0x00, 8);
+    orc_sink_twoc(s, d->dc_offset, d->bps);
+  } else if (d->kind == 1) {
+    orc_sink_put(s, 0x02, 8);
+    for (size_t t = 0; t < n; ++t) orc_sink_twoc(s, d->samples[t], d->bps);
+  } else if (d->kind == 2) {
+    orc_sink_put(s, 0x10u | (d->order << 1), 8);
+    for (uint32_t t = 0; t < d->order; ++t) orc_sink_twoc(s, d->samples[t], d->bps);
+    orc_write_residual(s, d->residual, n, d->order, d->rice_order, d->rice_params);
+  } else {
+    orc_sink_put(s, 0x40u | ((d->order - 1) << 1), 8);
+    for (uint32_t t = 0; t < d->order; ++t) orc_sink_twoc(s, d->samples[t], d->bps);
+    orc_sink_put(s, d->precision - 1, 4);
+    orc_sink_twoc(s, d->shift, 5);
+    for (uint32_t t = 0; t < d->order; ++t) orc_sink_twoc(s, d->coefs[t], d->precision);
+    orc_write_residual(s, d->residual, n, d->order, d->rice_order, d->rice_params);
+  }
+  return s->bitpos - start;
+}
+
+size_t orc_write_subframe(const orc_subframe_desc* d, size_t n, uint8_t* out, size_t cap) {
+  memset(out, 0, cap);
+  orc_bitsink s = {out, cap, 0};
+  return orc_write_subframe_sink(&s, d, n);
+}
+
+/* BitRepr for Frame::write, bitrepr.rs:289-319, for a frame made by encode_fixed_size_frame
+ * (coding.rs:581-606: fixed blocking, FrameOffset::Frame).  channel_assignment: 0 Independent
+ * (nch), 1 LeftSide, 2 RightSide, 3 MidSide (ChannelAssignment::write, bitrepr.rs:329-356).
+ * Returns the frame length in bytes (the bytes beyond `cap` are counted but not stored). */
+size_t orc_write_frame(uint32_t block_size, uint32_t channel_assignment, uint32_t nch,
+                       uint32_t bits_per_sample, uint32_t sample_rate, uint32_t frame_number,
+                       const orc_subframe_desc* subframes, uint8_t* out, size_t cap) {
+  memset(out, 0, cap);
+  uint32_t channel_tag = channel_assignment == 0 ? nch - 1 : 7 + channel_assignment;
+  uint8_t hdr[24];
+  size_t hn = orc_write_frame_header(block_size, channel_tag, bits_per_sample, sample_rate ? sample_rate : 0, 0,
+                                     frame_number, hdr);
+  memcpy(out, hdr, hn < cap ? hn : cap);
+  orc_bitsink s = {out, cap, hn * 8};
+  for (uint32_t c = 0; c < nch; ++c) orc_write_subframe_sink(&s, &subframes[c], block_size);
+  size_t nbytes = (s.bitpos + 7) >> 3; /* align_to_byte */
+  if (nbytes + 2 <= cap) {
+    uint16_t crc = orc_crc16(out, nbytes);
+    out[nbytes] = (uint8_t)(crc >> 8);
+    out[nbytes + 1] = (uint8_t)crc;
+  }
+  return nbytes + 2;
+}
+
+/* the frame encode_frame would write for one orc_stereo_frame_result (2 channels) */
+size_t orc_write_stereo_frame(const orc_stereo_frame_result* fr, const int32_t* l, const int32_t* r, size_t n,
+                              uint32_t bits_per_sample, uint32_t sample_rate, uint32_t frame_number,
+                              const int32_t* residual0, const int32_t* residual1, uint8_t* out, size_t cap) {
+  int32_t* m = (int32_t*)malloc(sizeof(int32_t) * n);
+  int32_t* sd = (int32_t*)malloc(sizeof(int32_t) * n);
+  orc_stereo_to_midside(l, r, n, m, sd);
+  const int32_t* sig[4] = {l, r, m, sd};
+  const int32_t* resid[2] = {residual0, residual1};
+  orc_subframe_desc d[2];
+  for (int c = 0; c < 2; ++c) {
+    const orc_subframe_record* rec = &fr->lpc[c];
+    d[c].kind = fr->kind[c];
+    d[c].bps = bits_per_sample + (fr->role[c] == 3 ? 1u : 0u);
+    d[c].dc_offset = fr->dc_offset[c];
+    d[c].samples = sig[fr->role[c]];
+    d[c].order = rec->order;
+    d[c].shift = rec->shift;
+    d[c].precision = rec->precision;
+    d[c].coefs = rec->coefs;
+    d[c].rice_order = rec->rice_order;
+    d[c].rice_params = rec->rice_params;
+    d[c].residual = resid[c];
+  }
+  size_t len = orc_write_frame((uint32_t)n, fr->channel_assignment, 2, bits_per_sample, sample_rate, frame_number,
+                               d, out, cap);
+  free(m);
+  free(sd);
+  return len;
+}

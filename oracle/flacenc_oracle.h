@@ -240,6 +240,34 @@ void orc_encode_stereo_frame(const int32_t* l, const int32_t* r, size_t n, uint3
                              int use_leftside, int use_rightside, int use_midside,
                              orc_stereo_frame_result* out, int32_t* residual0, int32_t* residual1);
 
+/* ---- bit writer, src/component/bitrepr.rs ---- */
+typedef struct {
+  uint32_t kind; /* 0 Constant, 1 Verbatim, 2 FixedLpc, 3 Lpc */
+  uint32_t bps;  /* bits per sample of this subframe (side channel: +1) */
+  int32_t dc_offset;
+  const int32_t* samples; /* the subframe's input: Verbatim body / warm-up source */
+  uint32_t order;
+  int32_t shift;
+  uint32_t precision;
+  const int16_t* coefs;
+  uint32_t rice_order;
+  const uint8_t* rice_params;
+  const int32_t* residual; /* error signal, warm-up slots ignored */
+} orc_subframe_desc;
+
+uint8_t orc_crc8(const uint8_t* data, size_t len);
+uint16_t orc_crc16(const uint8_t* data, size_t len);
+size_t orc_encode_to_utf8like(uint64_t val, uint8_t out[7]);
+size_t orc_write_frame_header(uint32_t block_size, uint32_t channel_tag, uint32_t bits_per_sample,
+                              uint32_t sample_rate, int variable, uint64_t offset, uint8_t* out);
+size_t orc_write_subframe(const orc_subframe_desc* d, size_t n, uint8_t* out, size_t cap);
+size_t orc_write_frame(uint32_t block_size, uint32_t channel_assignment, uint32_t nch,
+                       uint32_t bits_per_sample, uint32_t sample_rate, uint32_t frame_number,
+                       const orc_subframe_desc* subframes, uint8_t* out, size_t cap);
+size_t orc_write_stereo_frame(const orc_stereo_frame_result* fr, const int32_t* l, const int32_t* r, size_t n,
+                              uint32_t bits_per_sample, uint32_t sample_rate, uint32_t frame_number,
+                              const int32_t* residual0, const int32_t* residual1, uint8_t* out, size_t cap);
+
 double orc_bench_stereo_qlpc(const int32_t* frames, size_t n_frames, size_t n, size_t stride,
                              uint32_t bits_per_sample, const orc_qlpc_config* cfg, int nthreads,
                              int repeats, uint64_t* checksum_out);

@@ -74,6 +74,13 @@ class FixedResult(C.Structure):
                 ("subframe_bits", C.c_uint64)]
 
 
+class SubframeDesc(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("bps", C.c_uint32), ("dc_offset", C.c_int32),
+                ("samples", C.POINTER(C.c_int32)), ("order", C.c_uint32), ("shift", C.c_int32),
+                ("precision", C.c_uint32), ("coefs", C.POINTER(C.c_int16)), ("rice_order", C.c_uint32),
+                ("rice_params", C.POINTER(C.c_uint8)), ("residual", C.POINTER(C.c_int32))]
+
+
 class QParams(C.Structure):
     _fields_ = [
         ("coefs", C.c_int16 * 32),
@@ -234,6 +241,24 @@ def _declare(L):
     L.orc_encode_subframe.restype = C.c_int
     L.orc_encode_stereo_frame_cfg.argtypes = [i32p, i32p, C.c_size_t, C.c_uint32,
                                               C.POINTER(FrameConfig), C.c_void_p, i32p, i32p]
+
+
+    L.orc_crc8.argtypes = [u8p, C.c_size_t]
+    L.orc_crc8.restype = C.c_uint8
+    L.orc_crc16.argtypes = [u8p, C.c_size_t]
+    L.orc_crc16.restype = C.c_uint16
+    L.orc_encode_to_utf8like.argtypes = [C.c_uint64, u8p]
+    L.orc_encode_to_utf8like.restype = C.c_size_t
+    L.orc_write_frame_header.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_uint64, u8p]
+    L.orc_write_frame_header.restype = C.c_size_t
+    L.orc_write_subframe.argtypes = [C.POINTER(SubframeDesc), C.c_size_t, u8p, C.c_size_t]
+    L.orc_write_subframe.restype = C.c_size_t
+    L.orc_write_frame.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                  C.POINTER(SubframeDesc), u8p, C.c_size_t]
+    L.orc_write_frame.restype = C.c_size_t
+    L.orc_write_stereo_frame.argtypes = [C.c_void_p, i32p, i32p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32,
+                                         i32p, i32p, u8p, C.c_size_t]
+    L.orc_write_stereo_frame.restype = C.c_size_t
 
 
 def make_fixed_config(max_order=4, order_sel=ORDERSEL_APPROXENT, partitions=16,
@@ -588,6 +613,67 @@ def encode_stereo_frames_cfg(frames, bps: int, fc: FrameConfig):
                                           C.byref(fc), out[f:f + 1].ctypes.data_as(C.c_void_p),
                                           _p(resid[f, 0], C.c_int32), _p(resid[f, 1], C.c_int32))
     return out, resid
+
+
+# ------------------------------------------------------ bit writer ----
+def crc8(data: bytes) -> int:
+    b = np.frombuffer(bytes(data), np.uint8).copy()
+    return int(lib().orc_crc8(_p(b, C.c_uint8), len(b)))
+
+
+def crc16(data: bytes) -> int:
+    b = np.frombuffer(bytes(data), np.uint8).copy()
+    return int(lib().orc_crc16(_p(b, C.c_uint8), len(b)))
+
+
+def encode_to_utf8like(val: int):
+    out = np.zeros(7, np.uint8)
+    n = lib().orc_encode_to_utf8like(val, _p(out, C.c_uint8))
+    return bytes(out[:n]) if n else None
+
+
+def write_frame_header(block_size, channel_tag, bits_per_sample, sample_rate, variable, offset) -> bytes:
+    out = np.zeros(24, np.uint8)
+    n = lib().orc_write_frame_header(block_size, channel_tag, bits_per_sample, sample_rate, int(variable), offset,
+                                     _p(out, C.c_uint8))
+    return bytes(out[:n])
+
+
+def _desc(kind, bps, n, samples=None, dc_offset=0, order=0, shift=0, precision=0, coefs=None, rice_order=0,
+          rice_params=None, residual=None):
+    keep = [np.ascontiguousarray(samples if samples is not None else np.zeros(n), np.int32),
+            np.ascontiguousarray(coefs if coefs is not None else np.zeros(32), np.int16),
+            np.ascontiguousarray(rice_params if rice_params is not None else np.zeros(1), np.uint8),
+            np.ascontiguousarray(residual if residual is not None else np.zeros(n), np.int32)]
+    d = SubframeDesc(kind, bps, dc_offset, _p(keep[0], C.c_int32), order, shift, precision, _p(keep[1], C.c_int16),
+                     rice_order, _p(keep[2], C.c_uint8), _p(keep[3], C.c_int32))
+    return d, keep
+
+
+def write_subframe(kind, bps, n, **kw):
+    """BitRepr for SubFrame::write (bitrepr.rs:449-527) -> (bytes, bit count)."""
+    d, keep = _desc(kind, bps, n, **kw)
+    cap = n * 5 + 64
+    out = np.zeros(cap, np.uint8)
+    bits = lib().orc_write_subframe(C.byref(d), n, _p(out, C.c_uint8), cap)
+    return bytes(out[:(bits + 7) // 8]), int(bits)
+
+
+def write_stereo_frame(result, l, r, bps, sample_rate, frame_number, residual0, residual1) -> bytes:
+    """Frame::write (bitrepr.rs:289-319) of the frame one FRAME_RESULT_DTYPE record describes."""
+    rec = np.ascontiguousarray(result.reshape(1) if hasattr(result, "reshape") else np.array([result]))
+    l = np.ascontiguousarray(l, np.int32)
+    r = np.ascontiguousarray(r, np.int32)
+    r0 = np.ascontiguousarray(residual0, np.int32)
+    r1 = np.ascontiguousarray(residual1, np.int32)
+    n = len(l)
+    cap = n * 8 + 64
+    out = np.zeros(cap, np.uint8)
+    ln = lib().orc_write_stereo_frame(rec.ctypes.data_as(C.c_void_p), _p(l, C.c_int32), _p(r, C.c_int32), n, bps,
+                                      sample_rate, frame_number, _p(r0, C.c_int32), _p(r1, C.c_int32),
+                                      _p(out, C.c_uint8), cap)
+    assert ln <= cap
+    return bytes(out[:ln])
 
 
 def bench_qlpc(samples, bits_per_sample: int, cfg: QlpcConfig, nthreads: int, repeats: int = 1):

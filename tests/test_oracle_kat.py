@@ -581,3 +581,79 @@ def test_encode_subframe_with_fixed_candidate():
             continue
         assert np.array_equal(dec, x)
     assert orc.KIND_LPC in kinds
+
+
+# ------------------------------------------------- bit writer (bitrepr.rs) ----
+def test_utf8_encoding():
+    """src/component.rs:59-77."""
+    assert orc.encode_to_utf8like(0x56) == bytes([0x56])
+    assert orc.encode_to_utf8like(0x1024) == bytes([0xE1, 0x80, 0xA4])
+    assert orc.encode_to_utf8like(0xFFFFFFFFF) == bytes([0xFE, 0xBF, 0xBF, 0xBF, 0xBF, 0xBF, 0xBF])
+    assert orc.encode_to_utf8like(0x1000000000) is None  # out of domain
+
+
+def test_crc_catalogue_check_values():
+    """crc::CRC_8_SMBUS / crc::CRC_16_UMTS (bitrepr.rs:39-40): the catalogue's check values for
+    b"123456789"."""
+    assert orc.crc8(b"123456789") == 0xF4
+    assert orc.crc16(b"123456789") == 0xFEE8
+
+
+def test_write_frame_header():
+    """src/component/bitrepr.rs:635-667: block 192, Independent(2), Unspecified specs, variable
+    blocking, start sample 0 -> the bit string incl. CRC-8 0x69; and the doctest of FrameHeader::new
+    (datatype.rs:1588-1599): 192 / mono / 8-bit / 44.1 kHz / StartSample(123456)."""
+    h = orc.write_frame_header(192, 1, 0, 0, True, 0)
+    assert h == bytes([0b11111111, 0b11111001, 0b00010000, 0b00010000, 0b00000000, 0b01101001])
+    h = orc.write_frame_header(192, 0, 8, 44100, True, 123456)
+    assert h[:8] == bytes([0xFF, 0xF9, 0x19, 0x02, 0xF0, 0x9E, 0x89, 0x80])
+    # FrameHeader::count_bits (bitrepr.rs:361-371): 40 + utf8 + extra block-size / rate bits
+    assert len(orc.write_frame_header(2304, 1, 16, 44100, False, 0)) == 6
+    assert len(orc.write_frame_header(1000, 1, 16, 12345, False, 0x1024)) == 5 + 3 + 2 + 2
+
+
+def test_subframe_byte_layouts():
+    """Doctests of Constant / Verbatim / FixedLpc / Lpc::new, src/component/datatype.rs:1839-1845,
+    1914-1923, 1986-1991, 2077-2084, and verify_bit_counter (count_bits == bits written)."""
+    b, bits = orc.write_subframe(0, 16, 1024, dc_offset=3)
+    assert b == bytes([0x00, 0x00, 0x03]) and bits == 8 + 16
+    b, bits = orc.write_subframe(1, 16, 64, samples=np.full(64, 0xAB))
+    assert b[0] == 0x02 and all(b[1 + 2 * t:3 + 2 * t] == bytes([0x00, 0xAB]) for t in range(64))
+    assert bits == orc.verbatim_count_bits(64, 16)
+    zeros = dict(rice_order=0, rice_params=[8], residual=np.zeros(64))
+    b, bits = orc.write_subframe(2, 16, 64, samples=[0xCD] + [0] * 63, order=1, **zeros)
+    assert b[0] == 0x12 and b[1:3] == bytes([0x00, 0xCD])
+    b, bits = orc.write_subframe(3, 16, 64, samples=[0xEF] + [0] * 63, order=1, shift=0, precision=7,
+                                 coefs=[1] + [0] * 31, **zeros)
+    assert b[0] == 0x40 and b[1:3] == bytes([0x00, 0xEF]) and b[3:5] == bytes([0x60, 0x01])
+    res_bits = orc.residual_count_bits(64, 1, 0, np.array([8], np.uint8), 0, 8)
+    assert bits == orc.lpc_count_bits(16, 1, 7, res_bits)
+
+
+def test_written_frames_parse_back_to_the_input():
+    """Frame::write (bitrepr.rs:289-319) for every SubFrame kind and channel assignment: the bytes
+    decode to the input with an independent FLAC parser (tests/flac_parse.py), both CRCs match, and
+    the length equals Frame::count_bits (bitrepr.rs:275-287)."""
+    import flac_parse
+    n, bps = 4096, 16
+    t = np.arange(n)
+    frames = [np.stack([util.sine_noise(n, bps, 200, 0.4, 0.05, seed=1), util.sine_noise(n, bps, 170, 0.3, 0.05, seed=2)]),
+              np.stack([t // 7, t // 5 + 3]),
+              np.stack([np.full(n, 1234), util.quantize(util.noise(3, n, 0.999), bps)]),
+              np.stack([util.sine_noise(n, bps, 90, 0.5, 0.01, seed=4)] * 2)]
+    frames[3][1] = frames[3][0] * 7 // 8
+    x = np.stack(frames).astype(np.int32)
+    fc = orc.make_frame_config(orc.make_config(lpc_order=8))
+    res, resid = orc.encode_stereo_frames_cfg(x, bps, fc)
+    seen = set()
+    for f in range(len(x)):
+        data = orc.write_stereo_frame(res[f], x[f, 0], x[f, 1], bps, 44100, 1000 + f, resid[f, 0], resid[f, 1])
+        got = flac_parse.parse_frame(data)
+        assert got["length"] == len(data) and got["number"] == 1000 + f and not got["variable"]
+        assert got["block_size"] == n and got["sample_rate"] == 44100 and got["bps"] == bps
+        assert np.array_equal(got["channels"], x[f])
+        roles = res[f]["role"]
+        sub_bits = sum(int(res[f]["bits"][r]) for r in roles)
+        assert len(data) * 8 == (8 * 7 + sub_bits + 7) // 8 * 8 + 16   # header here is 7 bytes
+        seen.update(got["kinds"])
+    assert seen == {"constant", "verbatim", "fixed", "lpc"}

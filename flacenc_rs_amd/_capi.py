@@ -52,6 +52,9 @@ EXPORTED_SYMBOLS = (
     "flacenc_hip_encode_stereo_frames_async",
     "flacenc_hip_fixed_lpc_batch",
     "flacenc_hip_fixed_lpc_batch_async",
+    "flacenc_hip_stereo_frame_bytes_bound",
+    "flacenc_hip_pack_stereo_frames",
+    "flacenc_hip_pack_stereo_frames_async",
     "flacenc_hip_synchronize",
     "flacenc_hip_debug_set_stamps",
     "flacenc_hip_debug_set_fixed_keys",
@@ -200,6 +203,14 @@ def load() -> C.CDLL:
     L.flacenc_hip_fixed_lpc_batch.restype = C.c_int
     L.flacenc_hip_fixed_lpc_batch_async.argtypes = fixed_args + [vp]
     L.flacenc_hip_fixed_lpc_batch_async.restype = C.c_int
+    pack_args = [vp, i32p, C.c_size_t, C.c_uint32, C.c_size_t, vp, i32p, C.c_size_t, C.c_uint32, C.c_uint32,
+                 C.c_uint32, C.c_uint32, vp, C.c_size_t, vp]
+    L.flacenc_hip_pack_stereo_frames.argtypes = pack_args + [C.c_int]
+    L.flacenc_hip_pack_stereo_frames.restype = C.c_int
+    L.flacenc_hip_pack_stereo_frames_async.argtypes = pack_args + [vp]
+    L.flacenc_hip_pack_stereo_frames_async.restype = C.c_int
+    L.flacenc_hip_stereo_frame_bytes_bound.argtypes = [C.c_uint32, C.c_uint32]
+    L.flacenc_hip_stereo_frame_bytes_bound.restype = C.c_size_t
     frame_args = [vp, C.POINTER(FrameConfig), i32p, C.c_size_t, C.c_uint32, C.c_size_t, C.c_uint32,
                   vp, i32p, C.c_size_t]
     L.flacenc_hip_encode_stereo_frames.argtypes = frame_args + [C.c_int]
@@ -374,6 +385,36 @@ class Handle:
             keys.ctypes.data, MEM_HOST)
         self._check(rc)
         return params, residual, keys
+
+    def pack_stereo_frames(self, frames, results, residual, bits_per_sample: int, sample_rate: int,
+                           first_frame_number: int = 0, frame_number_step: int = 1):
+        """Frame::write (src/component/bitrepr.rs:289-319) for the frames encode_stereo_frames decided:
+        -> list of `bytes`, one FLAC frame each."""
+        x = np.ascontiguousarray(frames, np.int32)
+        nf, ch, n = x.shape
+        res = np.ascontiguousarray(results)
+        rs = np.ascontiguousarray(residual, np.int32)
+        stride = int(self._lib.flacenc_hip_stereo_frame_bytes_bound(n, bits_per_sample))
+        out = np.zeros((nf, stride), np.uint8)
+        lens = np.zeros(nf, np.uint32)
+        rc = self._lib.flacenc_hip_pack_stereo_frames(
+            self._h, x.ctypes.data, nf, n, n, res.ctypes.data, rs.ctypes.data, n, bits_per_sample, sample_rate,
+            first_frame_number, frame_number_step, out.ctypes.data, stride, lens.ctypes.data, MEM_HOST)
+        self._check(rc)
+        return [bytes(out[f, :lens[f]]) for f in range(nf)]
+
+    def pack_stereo_frames_device(self, frames_ptr: int, n_frames: int, block_size: int, stride: int,
+                                  results_ptr: int, residual_ptr: int, residual_stride: int, bits_per_sample: int,
+                                  sample_rate: int, first_frame_number: int, frame_number_step: int, out_ptr: int,
+                                  out_stride: int, out_len_ptr: int, stream: int | None = None):
+        rc = self._lib.flacenc_hip_pack_stereo_frames_async(
+            self._h, frames_ptr, n_frames, block_size, stride, results_ptr, residual_ptr, residual_stride,
+            bits_per_sample, sample_rate, first_frame_number, frame_number_step, out_ptr, out_stride, out_len_ptr,
+            stream or None)
+        self._check(rc)
+
+    def frame_bytes_bound(self, block_size: int, bits_per_sample: int) -> int:
+        return int(self._lib.flacenc_hip_stereo_frame_bytes_bound(block_size, bits_per_sample))
 
     def encode_stereo_frames(self, frames, bits_per_sample: int, cfg: FrameConfig):
         """encode_frame with the decision on the GPU: `frames` int32 [n_frames, 2, block_size] ->

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "flacenc_hip.h"
+#include "frame_pack.h"
 #include "qlpc_kernel.h"
 
 namespace {
@@ -38,7 +39,7 @@ struct flacenc_hip_handle {
   hipStream_t stream = nullptr;
   std::string last_error;
   std::vector<WindowEntry> windows;
-  DeviceBuffer d_samples, d_residual, d_params, d_bps, d_autocorr, d_lpc, d_tables, d_keys, d_sel;
+  DeviceBuffer d_samples, d_residual, d_params, d_bps, d_autocorr, d_lpc, d_tables, d_keys, d_sel, d_results, d_out, d_outlen;
   unsigned long long* stamps = nullptr;  // profiling hook, see flacenc_hip_debug_set_stamps
   unsigned long long* fixed_keys = nullptr;  // test hook, see flacenc_hip_debug_set_fixed_keys
 };
@@ -372,7 +373,7 @@ void flacenc_hip_destroy(flacenc_hip_handle* h) {
   for (WindowEntry& e : h->windows)
     if (e.dev) (void)hipFree(e.dev);
   for (DeviceBuffer* b : {&h->d_samples, &h->d_residual, &h->d_params, &h->d_bps, &h->d_autocorr,
-                          &h->d_lpc, &h->d_tables, &h->d_keys, &h->d_sel})
+                          &h->d_lpc, &h->d_tables, &h->d_keys, &h->d_sel, &h->d_results, &h->d_out, &h->d_outlen})
     if (b->ptr) (void)hipFree(b->ptr);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -487,6 +488,159 @@ int flacenc_hip_fixed_lpc_batch(flacenc_hip_handle* h, const flacenc_hip_frame_c
                             hipMemcpyDeviceToHost, s));
   if (selector_keys)
     HIP_TRY(h, hipMemcpyAsync(selector_keys, h->d_autocorr.ptr, n_sub * 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(h, hipStreamSynchronize(s));
+  return FLACENC_HIP_OK;
+}
+
+size_t flacenc_hip_stereo_frame_bytes_bound(uint32_t block_size, uint32_t bits_per_sample) {
+  return (flacenc_hip::stereo_frame_bytes_bound(block_size, bits_per_sample) + 3) & ~static_cast<size_t>(3);
+}
+
+int flacenc_hip_pack_stereo_frames_async(flacenc_hip_handle* h, const int32_t* frames, size_t n_frames,
+                                         uint32_t block_size, size_t stride,
+                                         const flacenc_hip_stereo_frame_result* results, const int32_t* residual,
+                                         size_t residual_stride, uint32_t bits_per_sample, uint32_t sample_rate,
+                                         uint32_t first_frame_number, uint32_t frame_number_step, uint8_t* out,
+                                         size_t out_stride, uint32_t* out_len, void* stream) {
+  if (!h) return FLACENC_HIP_ERR_BAD_ARGUMENT;
+  if (n_frames == 0) return FLACENC_HIP_OK;
+  if (!frames || !results || !residual || !out || !out_len || stride < block_size || residual_stride < block_size ||
+      block_size < FLACENC_HIP_MIN_BLOCK_SIZE || block_size > FLACENC_HIP_MAX_BLOCK_SIZE ||
+      bits_per_sample < 8 || bits_per_sample > 24 || n_frames > 0x7FFFFFFFull ||
+      (reinterpret_cast<uintptr_t>(out) & 3) || (out_stride & 3) ||
+      out_stride < flacenc_hip_stereo_frame_bytes_bound(block_size, bits_per_sample)) {
+    h->last_error = "pack_stereo_frames: null pointer, bad size, or out_stride below flacenc_hip_stereo_frame_bytes_bound";
+    return FLACENC_HIP_ERR_BAD_ARGUMENT;
+  }
+  // frame numbers must stay below 2^31 (encode_fixed_size_frame, coding.rs:587-591)
+  const unsigned long long last = static_cast<unsigned long long>(first_frame_number) +
+                                  static_cast<unsigned long long>(n_frames - 1) * frame_number_step;
+  if (last >= (1ull << 31)) {
+    h->last_error = "pack_stereo_frames: frame_number must be below 2^31";
+    return FLACENC_HIP_ERR_BAD_ARGUMENT;
+  }
+  flacenc_hip::FramePackArgs a;
+  a.frames = frames;
+  a.stride = stride;
+  a.block_size = block_size;
+  a.n_frames = static_cast<uint32_t>(n_frames);
+  a.results = results;
+  a.residual = residual;
+  a.residual_stride = residual_stride;
+  a.bits_per_sample = bits_per_sample;
+  a.first_frame_number = first_frame_number;
+  a.frame_number_step = frame_number_step;
+  a.out = out;
+  a.out_stride = out_stride;
+  a.out_len = out_len;
+  // BlockSizeSpec::from_size / tag / extra bits, datatype.rs:1239-1294
+  uint32_t bs_tag = 0, extra_len = 0;
+  a.extra[0] = a.extra[1] = a.extra[2] = a.extra[3] = 0;
+  if (block_size == 192) bs_tag = 1;
+  for (uint32_t x = 0; x < 4 && !bs_tag; ++x)
+    if (block_size == (576u << x)) bs_tag = 2 + x;
+  for (uint32_t x = 0; x < 8 && !bs_tag; ++x)
+    if (block_size == (256u << x)) bs_tag = 8 + x;
+  if (!bs_tag) {
+    if (block_size <= 256) {
+      bs_tag = 6;
+      a.extra[extra_len++] = static_cast<uint8_t>(block_size - 1);
+    } else {
+      bs_tag = 7;
+      a.extra[extra_len++] = static_cast<uint8_t>((block_size - 1) >> 8);
+      a.extra[extra_len++] = static_cast<uint8_t>(block_size - 1);
+    }
+  }
+  // SampleRateSpec::from_freq / tag / extra bits, datatype.rs:1427-1453, 1503-1543 (Unspecified if
+  // not representable, coding.rs:434-435)
+  static const uint32_t known[12] = {0, 88200, 176400, 192000, 8000, 16000, 22050, 24000, 32000, 44100, 48000, 96000};
+  uint32_t sr_tag = 0;
+  for (uint32_t t = 1; t < 12; ++t)
+    if (sample_rate == known[t]) sr_tag = t;
+  if (!sr_tag && sample_rate) {
+    if (sample_rate % 1000 == 0 && sample_rate / 1000 <= 255) {
+      sr_tag = 12;
+      a.extra[extra_len++] = static_cast<uint8_t>(sample_rate / 1000);
+    } else if (sample_rate % 10 == 0 && sample_rate / 10 <= 65535) {
+      sr_tag = 14;
+      a.extra[extra_len++] = static_cast<uint8_t>((sample_rate / 10) >> 8);
+      a.extra[extra_len++] = static_cast<uint8_t>(sample_rate / 10);
+    } else if (sample_rate <= 65535) {
+      sr_tag = 13;
+      a.extra[extra_len++] = static_cast<uint8_t>(sample_rate >> 8);
+      a.extra[extra_len++] = static_cast<uint8_t>(sample_rate);
+    }
+  }
+  // SampleSizeSpec::from_bits, datatype.rs:1350-1360
+  uint32_t ss_tag = 0;
+  switch (bits_per_sample) {
+    case 8: ss_tag = 1; break;
+    case 12: ss_tag = 2; break;
+    case 16: ss_tag = 4; break;
+    case 20: ss_tag = 5; break;
+    case 24: ss_tag = 6; break;
+    default: ss_tag = 0; break;
+  }
+  a.header_mid = (bs_tag << 12) | (sr_tag << 8) | (ss_tag << 1);
+  a.extra_len = extra_len;
+  a.lds_words = static_cast<uint32_t>(flacenc_hip_stereo_frame_bytes_bound(block_size, bits_per_sample) / 4 + 4);
+  if (static_cast<size_t>(a.lds_words) * 4 > 150 * 1024) {
+    h->last_error = "pack_stereo_frames: frame too large for the LDS bit buffer (block_size x bits_per_sample)";
+    return FLACENC_HIP_ERR_UNSUPPORTED;
+  }
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, flacenc_hip::launch_frame_pack(a, static_cast<hipStream_t>(stream)));
+  return FLACENC_HIP_OK;
+}
+
+int flacenc_hip_pack_stereo_frames(flacenc_hip_handle* h, const int32_t* frames, size_t n_frames,
+                                   uint32_t block_size, size_t stride,
+                                   const flacenc_hip_stereo_frame_result* results, const int32_t* residual,
+                                   size_t residual_stride, uint32_t bits_per_sample, uint32_t sample_rate,
+                                   uint32_t first_frame_number, uint32_t frame_number_step, uint8_t* out,
+                                   size_t out_stride, uint32_t* out_len, int memory_kind) {
+  if (!h) return FLACENC_HIP_ERR_BAD_ARGUMENT;
+  if (memory_kind == FLACENC_HIP_MEM_DEVICE) {
+    int rc = flacenc_hip_pack_stereo_frames_async(h, frames, n_frames, block_size, stride, results, residual,
+                                                  residual_stride, bits_per_sample, sample_rate, first_frame_number,
+                                                  frame_number_step, out, out_stride, out_len, h->stream);
+    if (rc != FLACENC_HIP_OK || n_frames == 0) return rc;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return FLACENC_HIP_OK;
+  }
+  if (memory_kind != FLACENC_HIP_MEM_HOST) return FLACENC_HIP_ERR_BAD_ARGUMENT;
+  if (n_frames == 0) return FLACENC_HIP_OK;
+  if (!frames || !results || !residual || !out || !out_len || stride < block_size || residual_stride < block_size)
+    return FLACENC_HIP_ERR_BAD_ARGUMENT;
+  HIP_TRY(h, hipSetDevice(h->device));
+  int rc;
+  const size_t dstride = (static_cast<size_t>(block_size) + 3) & ~static_cast<size_t>(3);
+  const size_t ostride = flacenc_hip_stereo_frame_bytes_bound(block_size, bits_per_sample);
+  if (out_stride < ostride) {
+    h->last_error = "pack_stereo_frames: out_stride below flacenc_hip_stereo_frame_bytes_bound";
+    return FLACENC_HIP_ERR_BAD_ARGUMENT;
+  }
+  if ((rc = ensure(h, h->d_samples, n_frames * 2 * dstride * 4)) != FLACENC_HIP_OK) return rc;
+  if ((rc = ensure(h, h->d_residual, n_frames * 2 * dstride * 4)) != FLACENC_HIP_OK) return rc;
+  if ((rc = ensure(h, h->d_results, n_frames * sizeof(flacenc_hip_stereo_frame_result))) != FLACENC_HIP_OK) return rc;
+  if ((rc = ensure(h, h->d_out, n_frames * ostride)) != FLACENC_HIP_OK) return rc;
+  if ((rc = ensure(h, h->d_outlen, n_frames * 4)) != FLACENC_HIP_OK) return rc;
+  hipStream_t s = h->stream;
+  HIP_TRY(h, hipMemcpy2DAsync(h->d_samples.ptr, dstride * 4, frames, stride * 4, static_cast<size_t>(block_size) * 4,
+                              n_frames * 2, hipMemcpyHostToDevice, s));
+  HIP_TRY(h, hipMemcpy2DAsync(h->d_residual.ptr, dstride * 4, residual, residual_stride * 4,
+                              static_cast<size_t>(block_size) * 4, n_frames * 2, hipMemcpyHostToDevice, s));
+  HIP_TRY(h, hipMemcpyAsync(h->d_results.ptr, results, n_frames * sizeof(flacenc_hip_stereo_frame_result),
+                            hipMemcpyHostToDevice, s));
+  rc = flacenc_hip_pack_stereo_frames_async(h, static_cast<const int32_t*>(h->d_samples.ptr), n_frames, block_size,
+                                            dstride, static_cast<const flacenc_hip_stereo_frame_result*>(h->d_results.ptr),
+                                            static_cast<const int32_t*>(h->d_residual.ptr), dstride, bits_per_sample,
+                                            sample_rate, first_frame_number, frame_number_step,
+                                            static_cast<uint8_t*>(h->d_out.ptr), ostride,
+                                            static_cast<uint32_t*>(h->d_outlen.ptr), s);
+  if (rc != FLACENC_HIP_OK) return rc;
+  HIP_TRY(h, hipMemcpy2DAsync(out, out_stride, h->d_out.ptr, ostride, ostride, n_frames, hipMemcpyDeviceToHost, s));
+  HIP_TRY(h, hipMemcpyAsync(out_len, h->d_outlen.ptr, n_frames * 4, hipMemcpyDeviceToHost, s));
   HIP_TRY(h, hipStreamSynchronize(s));
   return FLACENC_HIP_OK;
 }

@@ -1,0 +1,273 @@
+// frame_pack.cpp -- BitRepr::write for Frame / FrameHeader / SubFrame / Residual
+// (src/component/bitrepr.rs:289-319, 373-419, 449-597 of flacenc-rs v0.5.1) on the GPU.
+//
+// One workgroup assembles one 2-channel frame in LDS from what flacenc_hip_encode_stereo_frames
+// left on the device: the frame record (channel assignment, subframe kinds, predictor parameters,
+// Rice partition) and the two residual rows.  The frame's bits are built in a zero-initialised LDS
+// bit buffer; every field is OR-ed in at its final position, so nothing is written sequentially:
+//   * the sizes of both subframes are already known exactly (SubFrame::count_bits in the record),
+//   * inside a Rice-coded residual a block-wide prefix sum over per-thread bit counts gives each
+//     thread the position of its first sample; a sample is `q` skipped (zero) bits followed by
+//     (1 << p | r) in p + 1 bits (bitrepr.rs:581-586), i.e. one OR of at most two words,
+//   * CRC-16 (CRC_16_UMTS, init 0, no xor-out: a plain polynomial remainder, hence linear) is
+//     computed per thread over a slice of the bytes and combined with x^(8 * bytes after the slice).
+#include "frame_pack.h"
+
+namespace flacenc_hip {
+namespace {
+
+constexpr int kPackThreads = 256;
+
+// bit position b of the frame = bit (31 - b % 32) of word b / 32 (words are stored big-endian)
+__device__ __forceinline__ void put_bits(uint32_t* w, uint32_t bitpos, uint32_t value, uint32_t nbits) {
+  if (nbits == 0) return;
+  const uint32_t word = bitpos >> 5, off = bitpos & 31u;
+  const unsigned long long v = (unsigned long long)value << (64u - off - nbits);
+  const uint32_t hi = (uint32_t)(v >> 32), lo = (uint32_t)v;
+  if (hi) atomicOr(&w[word], hi);
+  if (lo) atomicOr(&w[word + 1], lo);
+}
+
+__device__ __forceinline__ uint32_t zigzag32(int32_t v) {  // rice::encode_signbit, rice.rs:169-171
+  return ((uint32_t)v << 1) ^ (uint32_t)(v >> 31);
+}
+
+// a * b mod (x^16 + x^15 + x^2 + 1) over GF(2)
+__device__ __forceinline__ uint32_t gf_mulmod16(uint32_t a, uint32_t b) {
+  uint32_t r = 0;
+  for (int i = 15; i >= 0; --i) {
+    r <<= 1;
+    if (r & 0x10000u) r ^= 0x18005u;
+    if ((b >> i) & 1u) r ^= a;
+  }
+  return r & 0xFFFFu;
+}
+
+__device__ __forceinline__ uint32_t crc16_byte(uint32_t crc, uint32_t byte) {
+  crc ^= byte << 8;
+#pragma unroll
+  for (int b = 0; b < 8; ++b) crc = (crc & 0x8000u) ? ((crc << 1) ^ 0x8005u) & 0xFFFFu : (crc << 1) & 0xFFFFu;
+  return crc;
+}
+
+__device__ __forceinline__ uint32_t crc8_byte(uint32_t crc, uint32_t byte) {
+  crc ^= byte;
+#pragma unroll
+  for (int b = 0; b < 8; ++b) crc = (crc & 0x80u) ? ((crc << 1) ^ 0x07u) & 0xFFu : (crc << 1) & 0xFFu;
+  return crc;
+}
+
+// block-wide exclusive prefix sum of one value per thread (256 threads); `total` gets the sum
+__device__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* scratch, int tid, uint32_t* total) {
+  const int lane = tid & 63, wave = tid >> 6;
+  uint32_t incl = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64);
+    if (lane >= d) incl += o;
+  }
+  if (lane == 63) scratch[wave] = incl;
+  __syncthreads();
+  uint32_t base = 0;
+  for (int w = 0; w < wave; ++w) base += scratch[w];
+  *total = scratch[0] + scratch[1] + scratch[2] + scratch[3];
+  __syncthreads();
+  return base + incl - v;
+}
+
+__global__ void __launch_bounds__(kPackThreads) frame_pack_kernel(FramePackArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t words[];
+  __shared__ uint32_t scan_scratch[4];
+  __shared__ uint32_t crc_part[kPackThreads / 64];
+  __shared__ uint8_t rice_p[2][FLACENC_HIP_MAX_RICE_PARTITIONS];
+  const int tid = threadIdx.x;
+  const uint32_t f = blockIdx.x;
+  const int n = (int)a.block_size;
+  const flacenc_hip_stereo_frame_result* fr = a.results + f;
+
+  for (uint32_t i = tid; i < a.lds_words; i += kPackThreads) words[i] = 0u;
+  for (int i = tid; i < 2 * FLACENC_HIP_MAX_RICE_PARTITIONS; i += kPackThreads)
+    rice_p[i >> 8][i & 255] = fr->lpc[i >> 8].rice_params[i & 255];
+  __syncthreads();
+
+  // ---- FrameHeader::write, bitrepr.rs:373-419 (fixed blocking, FrameOffset::Frame) ----
+  const uint32_t assignment = fr->channel_assignment;
+  const uint32_t frame_number = a.first_frame_number + f * a.frame_number_step;
+  uint32_t utf8_len;
+  {
+    const uint32_t code_bits = frame_number ? 32u - (uint32_t)__builtin_clz(frame_number) : 0u;
+    utf8_len = code_bits <= 7 ? 1u : 1u + (code_bits - 2u) / 5u;  // utf8like_bytesize, bitrepr.rs:157-166
+  }
+  const uint32_t header_bytes = 4u + utf8_len + a.extra_len + 1u;
+  if (tid == 0) {
+    uint8_t hdr[16];
+    uint32_t hn = 0;
+    const uint32_t channel_tag = assignment == 0 ? 1u : 7u + assignment;  // Independent(2) -> 1
+    hdr[hn++] = 0xFF;
+    hdr[hn++] = 0xF8;
+    hdr[hn++] = (uint8_t)(a.header_mid >> 8);
+    hdr[hn++] = (uint8_t)((channel_tag << 4) | (a.header_mid & 0x0Fu));
+    if (utf8_len == 1) {
+      hdr[hn++] = (uint8_t)frame_number;
+    } else {  // encode_to_utf8like, bitrepr.rs:108-154
+      const uint32_t trailing = utf8_len - 1u;
+      const uint32_t first_bits = 6u - trailing;
+      const uint32_t head = (0xFFu << (8u - trailing - 1u)) & 0xFFu;  // 0xC0, 0xE0, 0xF0, 0xF8, 0xFC
+      hdr[hn++] = (uint8_t)(head | ((frame_number >> (6u * trailing)) & ((1u << first_bits) - 1u)));
+      for (uint32_t i = 0; i < trailing; ++i)
+        hdr[hn++] = (uint8_t)(0x80u | ((frame_number >> (6u * (trailing - 1u - i))) & 0x3Fu));
+    }
+    for (uint32_t i = 0; i < a.extra_len; ++i) hdr[hn++] = a.extra[i];
+    uint32_t crc = 0;
+    for (uint32_t i = 0; i < hn; ++i) crc = crc8_byte(crc, hdr[i]);
+    hdr[hn++] = (uint8_t)crc;
+    for (uint32_t i = 0; i < hn; ++i) put_bits(words, 8u * i, hdr[i], 8u);
+  }
+
+  // ---- the two subframes ----
+  const int32_t* __restrict__ lsrc = a.frames + (size_t)(2u * f) * a.stride;
+  const int32_t* __restrict__ rsrc = lsrc + a.stride;
+  uint32_t sub_base = header_bytes * 8u;
+  for (int c = 0; c < 2; ++c) {
+    const uint32_t kind = fr->kind[c];
+    const uint32_t role = fr->role[c];
+    const uint32_t bps = a.bits_per_sample + (role == 3u ? 1u : 0u);
+    const uint32_t sub_bits = (uint32_t)fr->bits[role];
+    const uint32_t bps_mask = bps >= 32u ? 0xFFFFFFFFu : ((1u << bps) - 1u);
+    auto sample = [&](int t) -> int32_t {  // the role's input sample (coding.rs:476-484 for M / S)
+      const int32_t l = lsrc[t];
+      if (role == 0u) return l;
+      const int32_t r = rsrc[t];
+      if (role == 1u) return r;
+      return role == 2u ? ((l + r) >> 1) : (l - r);
+    };
+    if (kind == FLACENC_HIP_KIND_CONSTANT) {  // bitrepr.rs:449-454
+      if (tid == 0) put_bits(words, sub_base + 8u, (uint32_t)fr->dc_offset[c] & bps_mask, bps);
+    } else if (kind == FLACENC_HIP_KIND_VERBATIM) {  // bitrepr.rs:463-470
+      if (tid == 0) put_bits(words, sub_base, 0x02u, 8u);
+      for (int t = tid; t < n; t += kPackThreads)
+        put_bits(words, sub_base + 8u + (uint32_t)t * bps, (uint32_t)sample(t) & bps_mask, bps);
+    } else {
+      const flacenc_hip_subframe_params* rec = &fr->lpc[c];
+      const uint32_t order = rec->order;
+      const uint32_t precision = rec->precision;
+      // FixedLpc::write bitrepr.rs:479-487 / Lpc::write :501-527 up to the residual
+      const uint32_t head_bits = 8u + order * bps + (kind == FLACENC_HIP_KIND_LPC ? 9u + order * precision : 0u);
+      if (tid == 0) {
+        uint32_t pos = sub_base;
+        put_bits(words, pos, kind == FLACENC_HIP_KIND_LPC ? (0x40u | ((order - 1u) << 1)) : (0x10u | (order << 1)), 8u);
+        pos += 8u;
+        for (uint32_t t = 0; t < order; ++t, pos += bps) put_bits(words, pos, (uint32_t)sample((int)t) & bps_mask, bps);
+        if (kind == FLACENC_HIP_KIND_LPC) {
+          put_bits(words, pos, precision - 1u, 4u);
+          put_bits(words, pos + 4u, (uint32_t)rec->shift & 31u, 5u);
+          pos += 9u;
+          for (uint32_t t = 0; t < order; ++t, pos += precision)
+            put_bits(words, pos, (uint32_t)(int32_t)rec->coefs[t] & ((1u << precision) - 1u), precision);
+        }
+      }
+      // Residual::write, bitrepr.rs:550-597
+      const uint32_t porder = rec->rice_order;
+      const uint32_t nparts = 1u << porder;
+      const uint32_t part_len = (uint32_t)n >> porder;
+      uint32_t rice2 = 0;
+      for (uint32_t q = tid; q < nparts; q += kPackThreads) rice2 |= rice_p[c][q] > 14 ? 1u : 0u;
+      rice2 = __syncthreads_or((int)rice2) ? 1u : 0u;
+      const uint32_t pbits = rice2 ? 5u : 4u;
+      if (tid == 0) put_bits(words, sub_base + head_bits, (rice2 << 4) | porder, 6u);
+      const int32_t* __restrict__ e = a.residual + (size_t)(2u * f + (uint32_t)c) * a.residual_stride;
+      // contiguous slice of samples per thread; pass 1 counts its bits, pass 2 writes them
+      const int per = (n + kPackThreads - 1) / kPackThreads;
+      const int t_lo = tid * per < n ? tid * per : n;
+      const int t_hi = t_lo + per < n ? t_lo + per : n;
+      uint32_t my_bits = 0;
+      for (int t = t_lo; t < t_hi; ++t) {
+        const uint32_t q = (uint32_t)t / part_len;
+        const uint32_t start = q * part_len > order ? q * part_len : order;  // max(warmup, offset)
+        if ((uint32_t)t < order) continue;
+        const uint32_t p = rice_p[c][q];
+        if ((uint32_t)t == start) my_bits += pbits;
+        my_bits += (zigzag32(e[t]) >> p) + 1u + p;
+      }
+      uint32_t total;
+      uint32_t pos = sub_base + head_bits + 6u + block_exclusive_scan(my_bits, scan_scratch, tid, &total);
+      for (int t = t_lo; t < t_hi; ++t) {
+        if ((uint32_t)t < order) continue;
+        const uint32_t q = (uint32_t)t / part_len;
+        const uint32_t start = q * part_len > order ? q * part_len : order;
+        const uint32_t p = rice_p[c][q];
+        if ((uint32_t)t == start) {
+          put_bits(words, pos, p, pbits);
+          pos += pbits;
+        }
+        const uint32_t u = zigzag32(e[t]);
+        pos += u >> p;  // unary quotient: zeros
+        put_bits(words, pos, (u & ((1u << p) - 1u)) | (1u << p), p + 1u);
+        pos += p + 1u;
+      }
+      (void)total;
+    }
+    sub_base += sub_bits;
+  }
+  __syncthreads();
+
+  // ---- align_to_byte + CRC-16 over everything before it (bitrepr.rs:306-316) ----
+  const uint32_t body_bytes = (sub_base + 7u) >> 3;
+  {
+    // slices of `per` bytes counted from the END so that every slice but the first has full length
+    const uint32_t per = (body_bytes + kPackThreads - 1u) / kPackThreads;
+    const uint32_t after = (uint32_t)(kPackThreads - 1 - tid) * per;  // bytes behind this slice
+    uint32_t crc = 0;
+    if (after < body_bytes) {
+      const uint32_t hi = body_bytes - after;
+      const uint32_t lo = hi > per ? hi - per : 0u;
+      for (uint32_t i = lo; i < hi; ++i) crc = crc16_byte(crc, (words[i >> 2] >> (24u - 8u * (i & 3u))) & 0xFFu);
+      // times x^(8 * after) mod P, by square-and-multiply on x^8
+      uint32_t base = 0x0100u, ex = after;  // x^8
+      while (ex) {
+        if (ex & 1u) crc = gf_mulmod16(crc, base);
+        base = gf_mulmod16(base, base);
+        ex >>= 1;
+      }
+    }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) crc ^= (uint32_t)__shfl_xor((int)crc, d, 64);
+    if ((tid & 63) == 0) crc_part[tid >> 6] = crc;
+  }
+  __syncthreads();
+  const uint32_t frame_bytes = body_bytes + 2u;
+  if (tid == 0) {
+    const uint32_t crc = crc_part[0] ^ crc_part[1] ^ crc_part[2] ^ crc_part[3];
+    put_bits(words, body_bytes * 8u, crc, 16u);
+    a.out_len[f] = frame_bytes;
+  }
+  __syncthreads();
+  uint32_t* __restrict__ dst = reinterpret_cast<uint32_t*>(a.out + (size_t)f * a.out_stride);
+  const uint32_t nwords = (frame_bytes + 3u) >> 2;
+  for (uint32_t i = tid; i < nwords; i += kPackThreads) dst[i] = __builtin_bswap32(words[i]);
+}
+
+}  // namespace
+
+size_t stereo_frame_bytes_bound(uint32_t block_size, uint32_t bits_per_sample) {
+  // header <= 4 + 6 (frame number < 2^31) + 2 + 2 + 1, two subframes of at most Verbatim size
+  // (encode_subframe never keeps anything larger, coding.rs:413-416), CRC-16
+  const size_t bits = 2 * 8 + static_cast<size_t>(block_size) * (2 * bits_per_sample + 1);
+  return 15 + (bits + 7) / 8 + 2;
+}
+
+hipError_t launch_frame_pack(const FramePackArgs& a, hipStream_t stream) {
+  if (a.n_frames == 0) return hipSuccess;
+  const size_t smem = static_cast<size_t>(a.lds_words) * 4;
+  static size_t configured = 0;
+  if (smem > configured) {
+    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(frame_pack_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(smem));
+    if (err != hipSuccess) return err;
+    configured = smem;
+  }
+  hipLaunchKernelGGL(frame_pack_kernel, dim3(a.n_frames), dim3(kPackThreads), smem, stream, a);
+  return hipGetLastError();
+}
+
+}  // namespace flacenc_hip

@@ -1,0 +1,40 @@
+// frame_pack.h -- launch interface of the frame bit-packing kernel (Frame::write on the GPU).
+#ifndef FLACENC_HIP_FRAME_PACK_H_
+#define FLACENC_HIP_FRAME_PACK_H_
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "flacenc_hip.h"
+
+namespace flacenc_hip {
+
+struct FramePackArgs {
+  const int32_t* frames;  // device; channel c of frame f at frames + (2f + c)*stride
+  size_t stride;
+  uint32_t block_size;
+  uint32_t n_frames;
+  const flacenc_hip_stereo_frame_result* results;  // device, [n_frames]
+  const int32_t* residual;                         // device; output channel c of frame f at (2f + c)*residual_stride
+  size_t residual_stride;
+  uint32_t bits_per_sample;
+  // FrameHeader bytes 2..3 without the channel assignment (block-size tag << 12 | rate tag << 8 |
+  // sample-size tag << 1) and the extra block-size / sample-rate bytes that follow the frame number
+  uint32_t header_mid;
+  uint32_t extra_len;
+  uint8_t extra[4];
+  uint32_t first_frame_number;
+  uint32_t frame_number_step;
+  uint8_t* out;  // device; frame f at out + f*out_stride (multiple of 4)
+  size_t out_stride;
+  uint32_t* out_len;  // device, [n_frames]
+  uint32_t lds_words;  // bit buffer size
+};
+
+// worst-case frame length in bytes for a 2-channel frame (both subframes Verbatim, one a side channel)
+size_t stereo_frame_bytes_bound(uint32_t block_size, uint32_t bits_per_sample);
+hipError_t launch_frame_pack(const FramePackArgs& args, hipStream_t stream);
+
+}  // namespace flacenc_hip
+#endif

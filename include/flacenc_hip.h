@@ -281,6 +281,35 @@ int flacenc_hip_fixed_lpc_batch_async(flacenc_hip_handle* h, const flacenc_hip_f
                                       flacenc_hip_subframe_params* params, int32_t* residual,
                                       size_t residual_stride, uint64_t* selector_keys, void* stream);
 
+/* ---- Frame::write on the GPU ---------------------------------------- */
+/*
+ * BitRepr::write for the frames flacenc_hip_encode_stereo_frames decided (src/component/bitrepr.rs:
+ * Frame :289-319, FrameHeader :373-419 with fixed blocking and FrameOffset::Frame as
+ * encode_fixed_size_frame sets it (src/coding.rs:581-606), Constant :449-454, Verbatim :463-470,
+ * FixedLpc :479-487, Lpc :501-527, Residual :550-597; CRC_8_SMBUS over the header, CRC_16_UMTS over
+ * the byte-aligned frame, :39-40).  Inputs are the outputs of flacenc_hip_encode_stereo_frames plus
+ * its input samples (warm-up and Verbatim bodies); frame f gets frame number
+ * first_frame_number + f*frame_number_step (step > 1 when frames were dealt round-robin over GPUs).
+ *   out       frame f's bytes at out + f*out_stride; out_stride >= flacenc_hip_stereo_frame_bytes_bound
+ *             (a multiple of 4; out 4-byte aligned); bytes beyond out_len[f] are unspecified
+ *   out_len   [n_frames] byte length of each frame = Frame::count_bits / 8 (bitrepr.rs:275-287)
+ * sample_rate / bits_per_sample go into the header specs exactly as encode_frame_impl chooses them
+ * (src/coding.rs:431-436); a rate or size without a code becomes "Unspecified".
+ */
+size_t flacenc_hip_stereo_frame_bytes_bound(uint32_t block_size, uint32_t bits_per_sample);
+int flacenc_hip_pack_stereo_frames(flacenc_hip_handle* h, const int32_t* frames, size_t n_frames,
+                                   uint32_t block_size, size_t stride,
+                                   const flacenc_hip_stereo_frame_result* results, const int32_t* residual,
+                                   size_t residual_stride, uint32_t bits_per_sample, uint32_t sample_rate,
+                                   uint32_t first_frame_number, uint32_t frame_number_step, uint8_t* out,
+                                   size_t out_stride, uint32_t* out_len, int memory_kind);
+int flacenc_hip_pack_stereo_frames_async(flacenc_hip_handle* h, const int32_t* frames, size_t n_frames,
+                                         uint32_t block_size, size_t stride,
+                                         const flacenc_hip_stereo_frame_result* results, const int32_t* residual,
+                                         size_t residual_stride, uint32_t bits_per_sample, uint32_t sample_rate,
+                                         uint32_t first_frame_number, uint32_t frame_number_step, uint8_t* out,
+                                         size_t out_stride, uint32_t* out_len, void* stream);
+
 int flacenc_hip_synchronize(flacenc_hip_handle* h);
 
 /* Test hook (no reference counterpart): when `device_keys` is non-NULL, launches with use_fixed

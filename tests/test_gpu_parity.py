@@ -684,6 +684,74 @@ def test_fixed_lpc_batch_stereo_roles(handle, n, sel):
             assert np.array_equal(resid[f, role], w["residual"]), (f, role)
 
 
+@pytest.mark.parametrize("bps,rate,first,step,use_fixed", [
+    (16, 44100, 0, 1, True), (16, 48000, 120, 1, False), (16, 12345, 2 ** 20 + 5, 8, True),
+    (24, 96000, 2 ** 26, 3, True), (16, 17000, 2 ** 30, 1, True), (16, 1234567, 2047, 1, True),
+])
+def test_pack_stereo_frames_bytes_equal_reference_writer(handle, bps, rate, first, step, use_fixed):
+    """flacenc_hip_pack_stereo_frames == Frame::write (bitrepr.rs:289-319) restated by the oracle,
+    byte for byte, for every SubFrame kind / channel assignment / header variant (frame-number
+    UTF-8 lengths 1..6, coded and explicit sample rates); and the bytes decode to the input with
+    the independent parser of tests/flac_parse.py (sync code, CRC-8, CRC-16, Rice coding)."""
+    import flac_parse
+    x = _fixed_corpus()
+    if bps == 24:
+        x = (x.astype(np.int64) * 181).astype(np.int32)   # 24-bit range, same structure
+        x[4] = np.stack([util.quantize(util.noise(21, 4096, 0.999), 24), util.quantize(util.noise(22, 4096, 0.999), 24)])
+    cfg = _capi.make_frame_config(gpu_cfg(8), use_fixed=use_fixed)
+    res, resid = handle.encode_stereo_frames(x, bps, cfg)
+    frames = handle.pack_stereo_frames(x, res, resid, bps, rate, first, step)
+    kinds = set()
+    for f in range(x.shape[0]):
+        want = orc.write_stereo_frame(res[f], x[f, 0], x[f, 1], bps, rate, first + f * step, resid[f, 0], resid[f, 1])
+        assert frames[f] == want, (f, len(frames[f]), len(want))
+        sub_bits = sum(int(res[f]["bits"][r]) for r in res[f]["role"])
+        hdr = orc.write_frame_header(4096, 1, bps, rate, False, first + f * step)
+        assert len(frames[f]) * 8 == (8 * len(hdr) + sub_bits + 7) // 8 * 8 + 16   # Frame::count_bits
+        if f % 3 == 0 or f == 4 or f >= 24:
+            got = flac_parse.parse_frame(frames[f], stream_bps=bps, stream_rate=rate)
+            assert got["number"] == first + f * step and got["length"] == len(frames[f])
+            assert np.array_equal(got["channels"], x[f]), f
+            kinds.update(got["kinds"])
+    assert kinds >= ({"constant", "verbatim", "fixed", "lpc"} if use_fixed else {"constant", "verbatim", "lpc"})
+
+
+def test_pack_stereo_frames_device_pipeline_checksum(handle):
+    """encode + pack entirely on the device for a large batch: every frame's CRC-16 (computed by the
+    independent parser's CRC over the bytes) matches its footer, lengths equal Frame::count_bits,
+    and a sample of frames decodes back to the input."""
+    import torch
+    import flac_parse
+    F, n, bps = 512, 4096, 16
+    host = _capi.sigen_frames(F, 2, n, bps, 200.0, 0.4, 0.4, seed=99)
+    host[7] = host[7] // 64
+    x = torch.from_numpy(host).cuda()
+    res = torch.empty((F, 752), dtype=torch.uint8, device="cuda")
+    resid = torch.empty((F * 2, n), dtype=torch.int32, device="cuda")
+    stride = handle.frame_bytes_bound(n, bps)
+    out = torch.zeros((F, stride), dtype=torch.uint8, device="cuda")
+    lens = torch.zeros(F, dtype=torch.int32, device="cuda")
+    cfg = _capi.make_frame_config(gpu_cfg(8), use_fixed=True)
+    s = torch.cuda.current_stream().cuda_stream
+    handle.encode_stereo_frames_device(cfg, x.data_ptr(), F, n, n, bps, res.data_ptr(), resid.data_ptr(), n, stream=s)
+    handle.pack_stereo_frames_device(x.data_ptr(), F, n, n, res.data_ptr(), resid.data_ptr(), n, bps, 44100, 0, 1,
+                                     out.data_ptr(), stride, lens.data_ptr(), stream=s)
+    torch.cuda.synchronize()
+    o, ln = out.cpu().numpy(), lens.cpu().numpy()
+    r = np.frombuffer(res.cpu().numpy().tobytes(), dtype=_capi.FRAME_RESULT_DTYPE)
+    for f in range(F):
+        b = bytes(o[f, :ln[f]])
+        assert b[:2] == bytes([0xFF, 0xF8])
+        assert flac_parse.crc16(b[:-2]) == (b[-2] << 8 | b[-1]), f
+        hdr_len = 6 if f < 128 else 7
+        assert flac_parse.crc8(b[:hdr_len - 1]) == b[hdr_len - 1], f
+        sub_bits = sum(int(r[f]["bits"][k]) for k in r[f]["role"])
+        assert ln[f] * 8 == (8 * hdr_len + sub_bits + 7) // 8 * 8 + 16
+    for f in (0, 7, 127, 128, 511):
+        got = flac_parse.parse_frame(bytes(o[f, :ln[f]]))
+        assert got["number"] == f and np.array_equal(got["channels"], host[f])
+
+
 def test_encode_stereo_frames_rejects_unsupported(handle):
     x = np.zeros((2, 2, 4096), np.int32)
     with pytest.raises(_capi.FlacencHipError) as ei:

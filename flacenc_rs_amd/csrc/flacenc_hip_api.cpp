@@ -493,7 +493,7 @@ int flacenc_hip_fixed_lpc_batch(flacenc_hip_handle* h, const flacenc_hip_frame_c
 }
 
 size_t flacenc_hip_stereo_frame_bytes_bound(uint32_t block_size, uint32_t bits_per_sample) {
-  return (flacenc_hip::stereo_frame_bytes_bound(block_size, bits_per_sample) + 3) & ~static_cast<size_t>(3);
+  return (flacenc_hip::stereo_frame_bytes_bound(block_size, bits_per_sample) + 15) & ~static_cast<size_t>(15);
 }
 
 int flacenc_hip_pack_stereo_frames_async(flacenc_hip_handle* h, const int32_t* frames, size_t n_frames,
@@ -507,7 +507,7 @@ int flacenc_hip_pack_stereo_frames_async(flacenc_hip_handle* h, const int32_t* f
   if (!frames || !results || !residual || !out || !out_len || stride < block_size || residual_stride < block_size ||
       block_size < FLACENC_HIP_MIN_BLOCK_SIZE || block_size > FLACENC_HIP_MAX_BLOCK_SIZE ||
       bits_per_sample < 8 || bits_per_sample > 24 || n_frames > 0x7FFFFFFFull ||
-      (reinterpret_cast<uintptr_t>(out) & 3) || (out_stride & 3) ||
+      (reinterpret_cast<uintptr_t>(out) & 15) || (out_stride & 15) ||
       out_stride < flacenc_hip_stereo_frame_bytes_bound(block_size, bits_per_sample)) {
     h->last_error = "pack_stereo_frames: null pointer, bad size, or out_stride below flacenc_hip_stereo_frame_bytes_bound";
     return FLACENC_HIP_ERR_BAD_ARGUMENT;
@@ -584,6 +584,32 @@ int flacenc_hip_pack_stereo_frames_async(flacenc_hip_handle* h, const int32_t* f
   a.header_mid = (bs_tag << 12) | (sr_tag << 8) | (ss_tag << 1);
   a.extra_len = extra_len;
   a.lds_words = static_cast<uint32_t>(flacenc_hip_stereo_frame_bytes_bound(block_size, bits_per_sample) / 4 + 4);
+  {
+    // y = x^(8 per) mod P and its powers (see frame_pack.h)
+    auto mulmod = [](uint32_t x, uint32_t y) {
+      uint32_t r = 0;
+      for (int i = 15; i >= 0; --i) {
+        r <<= 1;
+        if (r & 0x10000u) r ^= 0x18005u;
+        if ((y >> i) & 1u) r ^= x;
+      }
+      return r & 0xFFFFu;
+    };
+    a.crc_per = (static_cast<uint32_t>(a.lds_words) * 4 + 255) / 256;
+    uint32_t y = 1;
+    for (uint32_t i = 0; i < 8 * a.crc_per; ++i) y = mulmod(y, 2);  // times x
+    uint32_t acc = 1;
+    for (int i = 0; i < 16; ++i) {
+      a.crc_pow[i] = static_cast<uint16_t>(acc);
+      acc = mulmod(acc, y);
+    }
+    const uint32_t y16 = acc;  // y^16
+    acc = 1;
+    for (int i = 0; i < 16; ++i) {
+      a.crc_pow[16 + i] = static_cast<uint16_t>(acc);
+      acc = mulmod(acc, y16);
+    }
+  }
   if (static_cast<size_t>(a.lds_words) * 4 > 150 * 1024) {
     h->last_error = "pack_stereo_frames: frame too large for the LDS bit buffer (block_size x bits_per_sample)";
     return FLACENC_HIP_ERR_UNSUPPORTED;

@@ -80,12 +80,15 @@ __global__ void __launch_bounds__(kPackThreads) frame_pack_kernel(FramePackArgs 
   __shared__ uint32_t scan_scratch[4];
   __shared__ uint32_t crc_part[kPackThreads / 64];
   __shared__ uint8_t rice_p[2][FLACENC_HIP_MAX_RICE_PARTITIONS];
+  __shared__ uint16_t crc_tab[256];  // CRC-16 of the single byte i
   const int tid = threadIdx.x;
+  crc_tab[tid] = (uint16_t)crc16_byte(0u, (uint32_t)tid);
   const uint32_t f = blockIdx.x;
   const int n = (int)a.block_size;
   const flacenc_hip_stereo_frame_result* fr = a.results + f;
 
-  for (uint32_t i = tid; i < a.lds_words; i += kPackThreads) words[i] = 0u;
+  for (uint32_t i = tid; i < a.lds_words / 4u; i += kPackThreads)
+    reinterpret_cast<int4*>(words)[i] = make_int4(0, 0, 0, 0);  // lds_words is a multiple of 4
   for (int i = tid; i < 2 * FLACENC_HIP_MAX_RICE_PARTITIONS; i += kPackThreads)
     rice_p[i >> 8][i & 255] = fr->lpc[i >> 8].rice_params[i & 255];
   __syncthreads();
@@ -153,17 +156,16 @@ __global__ void __launch_bounds__(kPackThreads) frame_pack_kernel(FramePackArgs 
       const uint32_t precision = rec->precision;
       // FixedLpc::write bitrepr.rs:479-487 / Lpc::write :501-527 up to the residual
       const uint32_t head_bits = 8u + order * bps + (kind == FLACENC_HIP_KIND_LPC ? 9u + order * precision : 0u);
-      if (tid == 0) {
-        uint32_t pos = sub_base;
-        put_bits(words, pos, kind == FLACENC_HIP_KIND_LPC ? (0x40u | ((order - 1u) << 1)) : (0x10u | (order << 1)), 8u);
-        pos += 8u;
-        for (uint32_t t = 0; t < order; ++t, pos += bps) put_bits(words, pos, (uint32_t)sample((int)t) & bps_mask, bps);
+      if ((uint32_t)tid < order)  // warm-up samples
+        put_bits(words, sub_base + 8u + (uint32_t)tid * bps, (uint32_t)sample(tid) & bps_mask, bps);
+      if (kind == FLACENC_HIP_KIND_LPC && tid >= 64 && (uint32_t)(tid - 64) < order)  // quantised coefficients
+        put_bits(words, sub_base + 8u + order * bps + 9u + (uint32_t)(tid - 64) * precision,
+                 (uint32_t)(int32_t)rec->coefs[tid - 64] & ((1u << precision) - 1u), precision);
+      if (tid == 128) {
+        put_bits(words, sub_base, kind == FLACENC_HIP_KIND_LPC ? (0x40u | ((order - 1u) << 1)) : (0x10u | (order << 1)), 8u);
         if (kind == FLACENC_HIP_KIND_LPC) {
-          put_bits(words, pos, precision - 1u, 4u);
-          put_bits(words, pos + 4u, (uint32_t)rec->shift & 31u, 5u);
-          pos += 9u;
-          for (uint32_t t = 0; t < order; ++t, pos += precision)
-            put_bits(words, pos, (uint32_t)(int32_t)rec->coefs[t] & ((1u << precision) - 1u), precision);
+          put_bits(words, sub_base + 8u + order * bps, precision - 1u, 4u);
+          put_bits(words, sub_base + 8u + order * bps + 4u, (uint32_t)rec->shift & 31u, 5u);
         }
       }
       // Residual::write, bitrepr.rs:550-597
@@ -174,37 +176,64 @@ __global__ void __launch_bounds__(kPackThreads) frame_pack_kernel(FramePackArgs 
       for (uint32_t q = tid; q < nparts; q += kPackThreads) rice2 |= rice_p[c][q] > 14 ? 1u : 0u;
       rice2 = __syncthreads_or((int)rice2) ? 1u : 0u;
       const uint32_t pbits = rice2 ? 5u : 4u;
-      if (tid == 0) put_bits(words, sub_base + head_bits, (rice2 << 4) | porder, 6u);
+      if (tid == 192) put_bits(words, sub_base + head_bits, (rice2 << 4) | porder, 6u);
       const int32_t* __restrict__ e = a.residual + (size_t)(2u * f + (uint32_t)c) * a.residual_stride;
-      // contiguous slice of samples per thread; pass 1 counts its bits, pass 2 writes them
+      // contiguous slice of samples per thread; pass 1 counts its bits, pass 2 writes them.
+      // Up to 16 samples per thread (blocks <= 4096) are held in registers as zig-zag codes.
       const int per = (n + kPackThreads - 1) / kPackThreads;
       const int t_lo = tid * per < n ? tid * per : n;
       const int t_hi = t_lo + per < n ? t_lo + per : n;
-      uint32_t my_bits = 0;
-      for (int t = t_lo; t < t_hi; ++t) {
-        const uint32_t q = (uint32_t)t / part_len;
-        const uint32_t start = q * part_len > order ? q * part_len : order;  // max(warmup, offset)
-        if ((uint32_t)t < order) continue;
-        const uint32_t p = rice_p[c][q];
-        if ((uint32_t)t == start) my_bits += pbits;
-        my_bits += (zigzag32(e[t]) >> p) + 1u + p;
+      const bool cached = per <= 16;
+      uint32_t uc[16];
+      if (cached) {
+        const bool vec = per == 16 && t_hi - t_lo == 16 && ((reinterpret_cast<uintptr_t>(e + t_lo) & 15) == 0);
+        if (vec) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int4 v = *reinterpret_cast<const int4*>(e + t_lo + 4 * k);
+            uc[4 * k + 0] = zigzag32(v.x);
+            uc[4 * k + 1] = zigzag32(v.y);
+            uc[4 * k + 2] = zigzag32(v.z);
+            uc[4 * k + 3] = zigzag32(v.w);
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < 16; ++k) uc[k] = (t_lo + k < t_hi) ? zigzag32(e[t_lo + k]) : 0u;
+        }
       }
+      const uint32_t q_lo = (uint32_t)t_lo / part_len;
+      // walks the slice once; `emit(t, u, p, starts)` sees every coded sample in order
+      auto walk = [&](auto&& emit) {
+        uint32_t q = q_lo, next = (q_lo + 1u) * part_len, p = rice_p[c][q_lo & 255u];
+        auto step = [&](uint32_t t, uint32_t u) {
+          if (t == next) {
+            ++q;
+            next += part_len;
+            p = rice_p[c][q & 255u];
+          }
+          if (t >= order) emit(u, p, q == 0u ? t == order : t == next - part_len);  // max(warmup, offset)
+        };
+        if (cached) {
+#pragma unroll
+          for (int k = 0; k < 16; ++k)
+            if (t_lo + k < t_hi) step((uint32_t)(t_lo + k), uc[k]);
+        } else {
+          for (int t = t_lo; t < t_hi; ++t) step((uint32_t)t, zigzag32(e[t]));
+        }
+      };
+      uint32_t my_bits = 0;
+      walk([&](uint32_t u, uint32_t p, bool starts) { my_bits += (starts ? pbits : 0u) + (u >> p) + 1u + p; });
       uint32_t total;
       uint32_t pos = sub_base + head_bits + 6u + block_exclusive_scan(my_bits, scan_scratch, tid, &total);
-      for (int t = t_lo; t < t_hi; ++t) {
-        if ((uint32_t)t < order) continue;
-        const uint32_t q = (uint32_t)t / part_len;
-        const uint32_t start = q * part_len > order ? q * part_len : order;
-        const uint32_t p = rice_p[c][q];
-        if ((uint32_t)t == start) {
+      walk([&](uint32_t u, uint32_t p, bool starts) {
+        if (starts) {
           put_bits(words, pos, p, pbits);
           pos += pbits;
         }
-        const uint32_t u = zigzag32(e[t]);
         pos += u >> p;  // unary quotient: zeros
         put_bits(words, pos, (u & ((1u << p) - 1u)) | (1u << p), p + 1u);
         pos += p + 1u;
-      }
+      });
       (void)total;
     }
     sub_base += sub_bits;
@@ -214,21 +243,22 @@ __global__ void __launch_bounds__(kPackThreads) frame_pack_kernel(FramePackArgs 
   // ---- align_to_byte + CRC-16 over everything before it (bitrepr.rs:306-316) ----
   const uint32_t body_bytes = (sub_base + 7u) >> 3;
   {
-    // slices of `per` bytes counted from the END so that every slice but the first has full length
-    const uint32_t per = (body_bytes + kPackThreads - 1u) / kPackThreads;
-    const uint32_t after = (uint32_t)(kPackThreads - 1 - tid) * per;  // bytes behind this slice
+    // slices of a.crc_per bytes counted from the END (so every slice but the first is full); the
+    // slice of thread t is followed by k = 255 - t slices, and x^(8 * crc_per * k) mod P comes from
+    // the host-made tables crc_pow[i] = y^i, crc_pow[16 + i] = y^(16 i) with y = x^(8 * crc_per)
+    const uint32_t per = a.crc_per;
+    const uint32_t k_after = (uint32_t)(kPackThreads - 1 - tid);
+    const uint32_t after = k_after * per;
     uint32_t crc = 0;
     if (after < body_bytes) {
       const uint32_t hi = body_bytes - after;
       const uint32_t lo = hi > per ? hi - per : 0u;
-      for (uint32_t i = lo; i < hi; ++i) crc = crc16_byte(crc, (words[i >> 2] >> (24u - 8u * (i & 3u))) & 0xFFu);
-      // times x^(8 * after) mod P, by square-and-multiply on x^8
-      uint32_t base = 0x0100u, ex = after;  // x^8
-      while (ex) {
-        if (ex & 1u) crc = gf_mulmod16(crc, base);
-        base = gf_mulmod16(base, base);
-        ex >>= 1;
+      for (uint32_t i = lo; i < hi; ++i) {
+        const uint32_t byte = (words[i >> 2] >> (24u - 8u * (i & 3u))) & 0xFFu;
+        crc = ((crc << 8) & 0xFFFFu) ^ crc_tab[(crc >> 8) ^ byte];
       }
+      crc = gf_mulmod16(crc, a.crc_pow[k_after & 15u]);
+      crc = gf_mulmod16(crc, a.crc_pow[16u + (k_after >> 4)]);
     }
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) crc ^= (uint32_t)__shfl_xor((int)crc, d, 64);
@@ -242,9 +272,17 @@ __global__ void __launch_bounds__(kPackThreads) frame_pack_kernel(FramePackArgs 
     a.out_len[f] = frame_bytes;
   }
   __syncthreads();
-  uint32_t* __restrict__ dst = reinterpret_cast<uint32_t*>(a.out + (size_t)f * a.out_stride);
-  const uint32_t nwords = (frame_bytes + 3u) >> 2;
-  for (uint32_t i = tid; i < nwords; i += kPackThreads) dst[i] = __builtin_bswap32(words[i]);
+  // out rows are 16-byte aligned (out 16-byte aligned, stride a multiple of 16): whole int4 stores
+  int4* __restrict__ dst = reinterpret_cast<int4*>(a.out + (size_t)f * a.out_stride);
+  const uint32_t nquads = (frame_bytes + 15u) >> 4;
+  for (uint32_t i = tid; i < nquads; i += kPackThreads) {
+    int4 v = reinterpret_cast<const int4*>(words)[i];
+    v.x = (int)__builtin_bswap32((uint32_t)v.x);
+    v.y = (int)__builtin_bswap32((uint32_t)v.y);
+    v.z = (int)__builtin_bswap32((uint32_t)v.z);
+    v.w = (int)__builtin_bswap32((uint32_t)v.w);
+    dst[i] = v;
+  }
 }
 
 }  // namespace

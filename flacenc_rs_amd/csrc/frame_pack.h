@@ -26,10 +26,14 @@ struct FramePackArgs {
   uint8_t extra[4];
   uint32_t first_frame_number;
   uint32_t frame_number_step;
-  uint8_t* out;  // device; frame f at out + f*out_stride (multiple of 4)
+  uint8_t* out;  // device, 16-byte aligned; frame f at out + f*out_stride (multiple of 16)
   size_t out_stride;
   uint32_t* out_len;  // device, [n_frames]
-  uint32_t lds_words;  // bit buffer size
+  uint32_t lds_words;  // bit buffer size, a multiple of 4
+  // CRC-16 combination: slices of crc_per bytes; crc_pow[i] = y^i, crc_pow[16 + i] = y^(16 i)
+  // (i < 16) with y = x^(8 crc_per) mod (x^16 + x^15 + x^2 + 1)
+  uint32_t crc_per;
+  uint16_t crc_pow[32];
 };
 
 // worst-case frame length in bytes for a 2-channel frame (both subframes Verbatim, one a side channel)

@@ -291,7 +291,7 @@ int flacenc_hip_fixed_lpc_batch_async(flacenc_hip_handle* h, const flacenc_hip_f
  * its input samples (warm-up and Verbatim bodies); frame f gets frame number
  * first_frame_number + f*frame_number_step (step > 1 when frames were dealt round-robin over GPUs).
  *   out       frame f's bytes at out + f*out_stride; out_stride >= flacenc_hip_stereo_frame_bytes_bound
- *             (a multiple of 4; out 4-byte aligned); bytes beyond out_len[f] are unspecified
+ *             (a multiple of 16; out 16-byte aligned); bytes beyond out_len[f] are unspecified
  *   out_len   [n_frames] byte length of each frame = Frame::count_bits / 8 (bitrepr.rs:275-287)
  * sample_rate / bits_per_sample go into the header specs exactly as encode_frame_impl chooses them
  * (src/coding.rs:431-436); a rate or size without a code becomes "Unspecified".

@@ -32,6 +32,7 @@ def crc16(data):
 class Bits:
     def __init__(self, data, pos=0):
         self.bits = np.unpackbits(np.frombuffer(bytes(data), np.uint8))
+        self.ones = np.flatnonzero(self.bits)
         self.pos = pos
 
     def u(self, n):
@@ -47,9 +48,9 @@ class Bits:
         return v - (1 << n) if n and v >> (n - 1) else v
 
     def unary(self):
-        nz = np.flatnonzero(self.bits[self.pos:])
-        assert len(nz), "unterminated unary code"
-        q = int(nz[0])
+        i = int(np.searchsorted(self.ones, self.pos))
+        assert i < len(self.ones), "unterminated unary code"
+        q = int(self.ones[i]) - self.pos
         self.pos += q + 1
         return q
 
@@ -122,8 +123,7 @@ def parse_frame(data, stream_bps=None, stream_rate=None):
     if first < 0x80:
         number = first
     else:
-        nbytes = 8 - len(bin(first ^ 0xFF)) + 2 if first != 0xFF else 8   # leading ones
-        nbytes = len(bin(first)[2:].split("0")[0])
+        nbytes = len(bin(first)[2:].split("0")[0])   # number of leading one bits
         number = first & ((1 << (7 - nbytes)) - 1)
         for _ in range(nbytes - 1):
             b = br.u(8)

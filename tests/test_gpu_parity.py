@@ -752,6 +752,38 @@ def test_pack_stereo_frames_device_pipeline_checksum(handle):
         assert got["number"] == f and np.array_equal(got["channels"], host[f])
 
 
+def test_flac_stream_end_to_end(handle):
+    """tools/encode_flac.py: "fLaC" + STREAMINFO + GPU-packed frames.  Every frame parses with the
+    independent parser, frame numbers run 0..F-1, STREAMINFO carries the right geometry and the MD5
+    of the interleaved input (src/source.rs:406-428), and the decoded audio is the input."""
+    import hashlib
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import encode_flac
+    import flac_parse
+    bps, rate, n = 16, 44100, 4096
+    frames = _capi.sigen_frames(9, 2, n, bps, rate / 440.0, 0.8, 0.2, seed=1)   # flacenc-bin's test tone
+    frames[3, 1] = frames[3, 0]
+    frames[5] //= 300
+    data, res = encode_flac.encode(frames, bps, rate, handle)
+    assert data[:4] == b"fLaC" and data[4] == 0x80 and int.from_bytes(data[5:8], "big") == 34
+    si = data[8:42]
+    assert int.from_bytes(si[0:2], "big") == n and int.from_bytes(si[2:4], "big") == n
+    packed = int.from_bytes(si[10:18], "big")
+    assert packed >> 44 == rate and (packed >> 41) & 7 == 1 and (packed >> 36) & 31 == bps - 1
+    assert packed & ((1 << 36) - 1) == 9 * n
+    inter = np.ascontiguousarray(frames.transpose(0, 2, 1)).reshape(-1).astype("<i2")
+    assert si[18:34] == hashlib.md5(inter.tobytes()).digest()
+    pos, sizes = 42, []
+    for f in range(9):
+        got = flac_parse.parse_frame(data[pos:])
+        assert got["number"] == f and np.array_equal(got["channels"], frames[f]), f
+        sizes.append(got["length"])
+        pos += got["length"]
+    assert pos == len(data)
+    assert int.from_bytes(si[4:7], "big") == min(sizes) and int.from_bytes(si[7:10], "big") == max(sizes)
+
+
 def test_encode_stereo_frames_rejects_unsupported(handle):
     x = np.zeros((2, 2, 4096), np.int32)
     with pytest.raises(_capi.FlacencHipError) as ei:

@@ -8,9 +8,10 @@ makes (L, R, M, S; src/coding.rs:530-544, 476-491), each = window -> f64 autocor
 Workload = BASELINE.json configs[1]: 44.1 kHz / 16-bit stereo, block 4096, LPC order 8
 (the reference has no "fixed Rice partition order" mode, so the reference-faithful full
 search is what runs).  value = input channel-samples (frames x 2 x 4096) per second over
-all ranks.  Multi-GPU: frames are sharded over ranks (weak scaling) and the fixed-size
-parameter records are all-gathered over RCCL each step (ParSink's ordered gather,
-src/par.rs:67-95); residuals stay on the producing GPU.
+all ranks.  Multi-GPU: frames are sharded over ranks (weak scaling); each step every rank derives
+its frames' byte lengths from the decision records and the ranks all-gather those 4 bytes per
+frame over RCCL and prefix-sum them into stream offsets (ParSink's ordered gather, src/par.rs:67-95,
+reduced to what ordering needs); records and residuals stay on the producing GPU.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
@@ -42,6 +43,9 @@ def main():
     ap.add_argument("--use-fixed", action="store_true",
                     help="also run the fixed-LPC candidate (the reference's default SubFrameCoding); "
                          "not the north-star workload, reported in DESIGN.md")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="run the multi-GPU exchange step (frame lengths -> offsets) even with one rank; "
+                         "for measuring its cost, not a reported configuration")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU work for cpu_baseline")
     args = ap.parse_args()
@@ -75,14 +79,22 @@ def main():
     rec_bytes = _capi.FRAME_RESULT_DTYPE.itemsize
     results = torch.empty((F, rec_bytes), dtype=torch.uint8, device=dev)  # one record per frame
     residual = torch.empty((F * 2, n), dtype=torch.int32, device=dev)     # the two chosen channels
+    frame_len = torch.zeros(F, dtype=torch.int32, device=dev)             # byte length of each frame
     handle = _capi.Handle(local_rank)
     stream = torch.cuda.current_stream()
+
+    def exchange():
+        # the multi-GPU exchange step: frame byte lengths -> stream order -> stream offsets
+        handle.stereo_frame_lengths_device(results.data_ptr(), F, n, bps, 44100, rank, world,
+                                           frame_len.data_ptr(), stream=stream.cuda_stream)
+        lengths_all = shard.all_gather_frame_lengths(frame_len, world * F)
+        return shard.stream_offsets(lengths_all)[0]
 
     def step():
         handle.encode_stereo_frames_device(cfg, x.data_ptr(), F, n, n, bps, results.data_ptr(),
                                            residual.data_ptr(), n, stream=stream.cuda_stream)
-        if world > 1:
-            shard.all_gather_records(results, world * F)
+        if world > 1 or args.force_exchange:
+            exchange()
 
     def fence():
         if world > 1:
@@ -101,8 +113,8 @@ def main():
         handle.encode_stereo_frames_device(cfg, x.data_ptr(), F, n, n, bps, results.data_ptr(),
                                            residual.data_ptr(), n, stream=stream.cuda_stream)
         ev[k][1].record(stream)
-        if world > 1:
-            shard.all_gather_records(results, world * F)
+        if world > 1 or args.force_exchange:
+            exchange()
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -144,7 +156,8 @@ def main():
             "decision": ("encode_subframe {Constant, Verbatim, FixedLpc(ApproxEnt 16), LPC}" if args.use_fixed
                          else "encode_subframe {Constant, Verbatim, LPC}") +
                         " + try_stereo_coding on the GPU; the two chosen residuals written",
-            "gather": "all_gather of 752-B frame records (RCCL)" if world > 1 else "none",
+            "gather": "all_gather of per-frame byte lengths (4 B/frame, RCCL) + prefix sum to stream offsets"
+                      if world > 1 else "none",
             "subframe_bits_per_sample": round(chosen_bits / (2 * F * n), 4),
             "assignments_indep_left_right_mid": assign_hist,
         },

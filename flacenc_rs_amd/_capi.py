@@ -55,6 +55,7 @@ EXPORTED_SYMBOLS = (
     "flacenc_hip_stereo_frame_bytes_bound",
     "flacenc_hip_pack_stereo_frames",
     "flacenc_hip_pack_stereo_frames_async",
+    "flacenc_hip_stereo_frame_lengths_async",
     "flacenc_hip_synchronize",
     "flacenc_hip_debug_set_stamps",
     "flacenc_hip_debug_set_fixed_keys",
@@ -209,6 +210,9 @@ def load() -> C.CDLL:
     L.flacenc_hip_pack_stereo_frames.restype = C.c_int
     L.flacenc_hip_pack_stereo_frames_async.argtypes = pack_args + [vp]
     L.flacenc_hip_pack_stereo_frames_async.restype = C.c_int
+    L.flacenc_hip_stereo_frame_lengths_async.argtypes = [vp, vp, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32,
+                                                          C.c_uint32, C.c_uint32, vp, vp]
+    L.flacenc_hip_stereo_frame_lengths_async.restype = C.c_int
     L.flacenc_hip_stereo_frame_bytes_bound.argtypes = [C.c_uint32, C.c_uint32]
     L.flacenc_hip_stereo_frame_bytes_bound.restype = C.c_size_t
     frame_args = [vp, C.POINTER(FrameConfig), i32p, C.c_size_t, C.c_uint32, C.c_size_t, C.c_uint32,
@@ -411,6 +415,14 @@ class Handle:
             self._h, frames_ptr, n_frames, block_size, stride, results_ptr, residual_ptr, residual_stride,
             bits_per_sample, sample_rate, first_frame_number, frame_number_step, out_ptr, out_stride, out_len_ptr,
             stream or None)
+        self._check(rc)
+
+    def stereo_frame_lengths_device(self, results_ptr: int, n_frames: int, block_size: int, bits_per_sample: int,
+                                    sample_rate: int, first_frame_number: int, frame_number_step: int,
+                                    out_len_ptr: int, stream: int | None = None):
+        rc = self._lib.flacenc_hip_stereo_frame_lengths_async(
+            self._h, results_ptr, n_frames, block_size, bits_per_sample, sample_rate, first_frame_number,
+            frame_number_step, out_len_ptr, stream or None)
         self._check(rc)
 
     def frame_bytes_bound(self, block_size: int, bits_per_sample: int) -> int:

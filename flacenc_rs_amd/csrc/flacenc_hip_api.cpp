@@ -225,6 +225,62 @@ int enqueue(flacenc_hip_handle* h, const flacenc_hip_qlpc_config* cfg, const int
   return FLACENC_HIP_OK;
 }
 
+// FrameHeader's constant part for a launch (bitrepr.rs:373-419 as encode_frame_impl fills it,
+// coding.rs:431-436): spec tags and the extra bytes that follow the frame number
+void fill_header_specs(flacenc_hip::FramePackArgs& a, uint32_t block_size, uint32_t sample_rate,
+                       uint32_t bits_per_sample) {
+  // BlockSizeSpec::from_size / tag / extra bits, datatype.rs:1239-1294
+  uint32_t bs_tag = 0, extra_len = 0;
+  a.extra[0] = a.extra[1] = a.extra[2] = a.extra[3] = 0;
+  if (block_size == 192) bs_tag = 1;
+  for (uint32_t x = 0; x < 4 && !bs_tag; ++x)
+    if (block_size == (576u << x)) bs_tag = 2 + x;
+  for (uint32_t x = 0; x < 8 && !bs_tag; ++x)
+    if (block_size == (256u << x)) bs_tag = 8 + x;
+  if (!bs_tag) {
+    if (block_size <= 256) {
+      bs_tag = 6;
+      a.extra[extra_len++] = static_cast<uint8_t>(block_size - 1);
+    } else {
+      bs_tag = 7;
+      a.extra[extra_len++] = static_cast<uint8_t>((block_size - 1) >> 8);
+      a.extra[extra_len++] = static_cast<uint8_t>(block_size - 1);
+    }
+  }
+  // SampleRateSpec::from_freq / tag / extra bits, datatype.rs:1427-1453, 1503-1543 (Unspecified if
+  // not representable, coding.rs:434-435)
+  static const uint32_t known[12] = {0, 88200, 176400, 192000, 8000, 16000, 22050, 24000, 32000, 44100, 48000, 96000};
+  uint32_t sr_tag = 0;
+  for (uint32_t t = 1; t < 12; ++t)
+    if (sample_rate == known[t]) sr_tag = t;
+  if (!sr_tag && sample_rate) {
+    if (sample_rate % 1000 == 0 && sample_rate / 1000 <= 255) {
+      sr_tag = 12;
+      a.extra[extra_len++] = static_cast<uint8_t>(sample_rate / 1000);
+    } else if (sample_rate % 10 == 0 && sample_rate / 10 <= 65535) {
+      sr_tag = 14;
+      a.extra[extra_len++] = static_cast<uint8_t>((sample_rate / 10) >> 8);
+      a.extra[extra_len++] = static_cast<uint8_t>(sample_rate / 10);
+    } else if (sample_rate <= 65535) {
+      sr_tag = 13;
+      a.extra[extra_len++] = static_cast<uint8_t>(sample_rate >> 8);
+      a.extra[extra_len++] = static_cast<uint8_t>(sample_rate);
+    }
+  }
+  // SampleSizeSpec::from_bits, datatype.rs:1350-1360
+  uint32_t ss_tag = 0;
+  switch (bits_per_sample) {
+    case 8: ss_tag = 1; break;
+    case 12: ss_tag = 2; break;
+    case 16: ss_tag = 4; break;
+    case 20: ss_tag = 5; break;
+    case 24: ss_tag = 6; break;
+    default: ss_tag = 0; break;
+  }
+  a.header_mid = (bs_tag << 12) | (sr_tag << 8) | (ss_tag << 1);
+  a.extra_len = extra_len;
+}
+
 // config::Fixed::verify (config.rs:246-255) + OrderSel::verify (:419-431)
 int verify_fixed(flacenc_hip_handle* h, const flacenc_hip_frame_config* cfg) {
   if (cfg->fixed_max_order > FLACENC_HIP_MAX_FIXED_LPC_ORDER ||
@@ -533,56 +589,7 @@ int flacenc_hip_pack_stereo_frames_async(flacenc_hip_handle* h, const int32_t* f
   a.out = out;
   a.out_stride = out_stride;
   a.out_len = out_len;
-  // BlockSizeSpec::from_size / tag / extra bits, datatype.rs:1239-1294
-  uint32_t bs_tag = 0, extra_len = 0;
-  a.extra[0] = a.extra[1] = a.extra[2] = a.extra[3] = 0;
-  if (block_size == 192) bs_tag = 1;
-  for (uint32_t x = 0; x < 4 && !bs_tag; ++x)
-    if (block_size == (576u << x)) bs_tag = 2 + x;
-  for (uint32_t x = 0; x < 8 && !bs_tag; ++x)
-    if (block_size == (256u << x)) bs_tag = 8 + x;
-  if (!bs_tag) {
-    if (block_size <= 256) {
-      bs_tag = 6;
-      a.extra[extra_len++] = static_cast<uint8_t>(block_size - 1);
-    } else {
-      bs_tag = 7;
-      a.extra[extra_len++] = static_cast<uint8_t>((block_size - 1) >> 8);
-      a.extra[extra_len++] = static_cast<uint8_t>(block_size - 1);
-    }
-  }
-  // SampleRateSpec::from_freq / tag / extra bits, datatype.rs:1427-1453, 1503-1543 (Unspecified if
-  // not representable, coding.rs:434-435)
-  static const uint32_t known[12] = {0, 88200, 176400, 192000, 8000, 16000, 22050, 24000, 32000, 44100, 48000, 96000};
-  uint32_t sr_tag = 0;
-  for (uint32_t t = 1; t < 12; ++t)
-    if (sample_rate == known[t]) sr_tag = t;
-  if (!sr_tag && sample_rate) {
-    if (sample_rate % 1000 == 0 && sample_rate / 1000 <= 255) {
-      sr_tag = 12;
-      a.extra[extra_len++] = static_cast<uint8_t>(sample_rate / 1000);
-    } else if (sample_rate % 10 == 0 && sample_rate / 10 <= 65535) {
-      sr_tag = 14;
-      a.extra[extra_len++] = static_cast<uint8_t>((sample_rate / 10) >> 8);
-      a.extra[extra_len++] = static_cast<uint8_t>(sample_rate / 10);
-    } else if (sample_rate <= 65535) {
-      sr_tag = 13;
-      a.extra[extra_len++] = static_cast<uint8_t>(sample_rate >> 8);
-      a.extra[extra_len++] = static_cast<uint8_t>(sample_rate);
-    }
-  }
-  // SampleSizeSpec::from_bits, datatype.rs:1350-1360
-  uint32_t ss_tag = 0;
-  switch (bits_per_sample) {
-    case 8: ss_tag = 1; break;
-    case 12: ss_tag = 2; break;
-    case 16: ss_tag = 4; break;
-    case 20: ss_tag = 5; break;
-    case 24: ss_tag = 6; break;
-    default: ss_tag = 0; break;
-  }
-  a.header_mid = (bs_tag << 12) | (sr_tag << 8) | (ss_tag << 1);
-  a.extra_len = extra_len;
+  fill_header_specs(a, block_size, sample_rate, bits_per_sample);
   a.lds_words = static_cast<uint32_t>(flacenc_hip_stereo_frame_bytes_bound(block_size, bits_per_sample) / 4 + 4);
   {
     // y = x^(8 per) mod P and its powers (see frame_pack.h)
@@ -616,6 +623,31 @@ int flacenc_hip_pack_stereo_frames_async(flacenc_hip_handle* h, const int32_t* f
   }
   HIP_TRY(h, hipSetDevice(h->device));
   HIP_TRY(h, flacenc_hip::launch_frame_pack(a, static_cast<hipStream_t>(stream)));
+  return FLACENC_HIP_OK;
+}
+
+int flacenc_hip_stereo_frame_lengths_async(flacenc_hip_handle* h, const flacenc_hip_stereo_frame_result* results,
+                                           size_t n_frames, uint32_t block_size, uint32_t bits_per_sample,
+                                           uint32_t sample_rate, uint32_t first_frame_number,
+                                           uint32_t frame_number_step, uint32_t* out_len, void* stream) {
+  if (!h) return FLACENC_HIP_ERR_BAD_ARGUMENT;
+  if (n_frames == 0) return FLACENC_HIP_OK;
+  if (!results || !out_len || n_frames > 0x7FFFFFFFull) return FLACENC_HIP_ERR_BAD_ARGUMENT;
+  const unsigned long long last = static_cast<unsigned long long>(first_frame_number) +
+                                  static_cast<unsigned long long>(n_frames - 1) * frame_number_step;
+  if (last >= (1ull << 31)) {
+    h->last_error = "stereo_frame_lengths: frame_number must be below 2^31";
+    return FLACENC_HIP_ERR_BAD_ARGUMENT;
+  }
+  flacenc_hip::FramePackArgs a{};
+  a.results = results;
+  a.n_frames = static_cast<uint32_t>(n_frames);
+  a.first_frame_number = first_frame_number;
+  a.frame_number_step = frame_number_step;
+  a.out_len = out_len;
+  fill_header_specs(a, block_size, sample_rate, bits_per_sample);
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, flacenc_hip::launch_frame_lengths(a, static_cast<hipStream_t>(stream)));
   return FLACENC_HIP_OK;
 }
 

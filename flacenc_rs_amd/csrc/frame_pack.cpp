@@ -285,7 +285,25 @@ __global__ void __launch_bounds__(kPackThreads) frame_pack_kernel(FramePackArgs 
   }
 }
 
+// Frame::count_bits / 8 (bitrepr.rs:275-287) from the decision records alone
+__global__ void frame_lengths_kernel(FramePackArgs a) {
+  const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= a.n_frames) return;
+  const flacenc_hip_stereo_frame_result* fr = a.results + f;
+  const uint32_t frame_number = a.first_frame_number + f * a.frame_number_step;
+  const uint32_t code_bits = frame_number ? 32u - (uint32_t)__builtin_clz(frame_number) : 0u;
+  const uint32_t utf8_len = code_bits <= 7 ? 1u : 1u + (code_bits - 2u) / 5u;
+  const unsigned long long bits = 8ull * (4u + utf8_len + a.extra_len + 1u) + fr->bits[fr->role[0]] + fr->bits[fr->role[1]];
+  a.out_len[f] = (uint32_t)((bits + 7ull) >> 3) + 2u;
+}
+
 }  // namespace
+
+hipError_t launch_frame_lengths(const FramePackArgs& a, hipStream_t stream) {
+  if (a.n_frames == 0) return hipSuccess;
+  hipLaunchKernelGGL(frame_lengths_kernel, dim3((a.n_frames + 255) / 256), dim3(256), 0, stream, a);
+  return hipGetLastError();
+}
 
 size_t stereo_frame_bytes_bound(uint32_t block_size, uint32_t bits_per_sample) {
   // header <= 4 + 6 (frame number < 2^31) + 2 + 2 + 1, two subframes of at most Verbatim size

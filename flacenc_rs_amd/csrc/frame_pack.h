@@ -39,6 +39,8 @@ struct FramePackArgs {
 // worst-case frame length in bytes for a 2-channel frame (both subframes Verbatim, one a side channel)
 size_t stereo_frame_bytes_bound(uint32_t block_size, uint32_t bits_per_sample);
 hipError_t launch_frame_pack(const FramePackArgs& args, hipStream_t stream);
+// only results, n_frames, extra_len, first_frame_number, frame_number_step, out_len are read
+hipError_t launch_frame_lengths(const FramePackArgs& args, hipStream_t stream);
 
 }  // namespace flacenc_hip
 #endif

@@ -4,10 +4,12 @@ The reference's only parallelism is a frame-level worker pool (src/par.rs): fram
 whichever worker is free and `ParSink` (src/par.rs:67-95) re-orders finished frames by
 frame number.  Here the pool is the node's GPUs, one process per GPU: frame f belongs to
 rank f mod G (round-robin, BASELINE config 4), every rank analyses its frames with no
-communication, and the ordered gather is ONE all-gather of the fixed-size parameter
-records (352 B per analysed subframe, include/flacenc_hip.h) over RCCL/xGMI.  Residuals
-stay on the GPU that produced them (they are 47x larger than the records and the next
-stage, Rice bit-packing, is local to a frame).
+communication.  What the ordered gather has to exchange is only what places a frame in the
+output stream: its byte length (4 B per frame, flacenc_hip_stereo_frame_lengths) -- one small
+all-gather over RCCL/xGMI followed by a prefix sum gives every rank the stream offset of each
+of its frames; residuals, parameter records and packed frame bytes stay on the GPU that
+produced them and leave it by D2H at those offsets.  (`all_gather_records` moves whole
+fixed-size records instead, for callers that want every decision on every rank.)
 """
 from __future__ import annotations
 
@@ -52,3 +54,19 @@ def all_gather_records(local: torch.Tensor, n_frames_total: int, group=None) -> 
     g = gathered.view((world, per_rank) + tuple(local.shape[1:]))
     ordered = g.transpose(0, 1).reshape((world * per_rank,) + tuple(local.shape[1:]))
     return ordered[:n_frames_total]
+
+
+def all_gather_frame_lengths(local_lengths: torch.Tensor, n_frames_total: int, group=None) -> torch.Tensor:
+    """Byte lengths of all frames in stream order, on every rank (ParSink's ordering, src/par.rs:67-95,
+    reduced to what it needs).  `local_lengths` is this rank's [n_local_frames] integer tensor."""
+    return all_gather_records(local_lengths, n_frames_total, group=group)
+
+
+def stream_offsets(lengths_all: torch.Tensor, header_bytes: int = 0):
+    """Exclusive prefix sum: byte offset of every frame in the output stream (after `header_bytes` of
+    container metadata) and the total stream size (a 0-d tensor: no host synchronisation here)."""
+    wide = lengths_all.to(torch.int64)
+    csum = torch.cumsum(wide, dim=0)
+    offsets = csum - wide + header_bytes
+    total = csum[-1] + header_bytes if csum.numel() else torch.zeros((), dtype=torch.int64) + header_bytes
+    return offsets, total

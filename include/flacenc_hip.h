@@ -310,6 +310,15 @@ int flacenc_hip_pack_stereo_frames_async(flacenc_hip_handle* h, const int32_t* f
                                          uint32_t first_frame_number, uint32_t frame_number_step, uint8_t* out,
                                          size_t out_stride, uint32_t* out_len, void* stream);
 
+/* Frame::count_bits / 8 (src/component/bitrepr.rs:275-287) of every frame from the decision records
+ * alone: exactly the out_len flacenc_hip_pack_stereo_frames will produce.  Device pointers.  These
+ * 4 bytes per frame are all an ordered multi-GPU gather has to exchange to place every frame in
+ * the output stream (the role of ParSink, src/par.rs:67-95); the bytes themselves stay local. */
+int flacenc_hip_stereo_frame_lengths_async(flacenc_hip_handle* h, const flacenc_hip_stereo_frame_result* results,
+                                           size_t n_frames, uint32_t block_size, uint32_t bits_per_sample,
+                                           uint32_t sample_rate, uint32_t first_frame_number,
+                                           uint32_t frame_number_step, uint32_t* out_len, void* stream);
+
 int flacenc_hip_synchronize(flacenc_hip_handle* h);
 
 /* Test hook (no reference counterpart): when `device_keys` is non-NULL, launches with use_fixed

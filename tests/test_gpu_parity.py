@@ -736,7 +736,10 @@ def test_pack_stereo_frames_device_pipeline_checksum(handle):
     handle.encode_stereo_frames_device(cfg, x.data_ptr(), F, n, n, bps, res.data_ptr(), resid.data_ptr(), n, stream=s)
     handle.pack_stereo_frames_device(x.data_ptr(), F, n, n, res.data_ptr(), resid.data_ptr(), n, bps, 44100, 0, 1,
                                      out.data_ptr(), stride, lens.data_ptr(), stream=s)
+    lens2 = torch.zeros(F, dtype=torch.int32, device="cuda")
+    handle.stereo_frame_lengths_device(res.data_ptr(), F, n, bps, 44100, 0, 1, lens2.data_ptr(), stream=s)
     torch.cuda.synchronize()
+    assert torch.equal(lens, lens2)   # Frame::count_bits from the records alone == bytes really packed
     o, ln = out.cpu().numpy(), lens.cpu().numpy()
     r = np.frombuffer(res.cpu().numpy().tobytes(), dtype=_capi.FRAME_RESULT_DTYPE)
     for f in range(F):

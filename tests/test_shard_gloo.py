@@ -44,6 +44,14 @@ def _worker(rank, world, port, n_frames, out_dir):
     ordered = shard.all_gather_records(local, n_frames)
     assert ordered.shape == (n_frames, 2, 352)
     np.save(os.path.join(out_dir, f"rank{rank}.npy"), ordered.numpy())
+    # the light-weight exchange bench.py uses: frame byte lengths -> stream offsets
+    lens = torch.tensor([1000 + 7 * f for f in mine], dtype=torch.int32)
+    lengths_all = shard.all_gather_frame_lengths(lens, n_frames)
+    offsets, total = shard.stream_offsets(lengths_all, header_bytes=42)
+    want = np.array([1000 + 7 * f for f in range(n_frames)], np.int64)
+    assert lengths_all.tolist() == want.tolist()
+    assert offsets.tolist() == (42 + np.concatenate([[0], np.cumsum(want)[:-1]])).tolist()
+    assert int(total) == 42 + int(want.sum())
     dist.barrier()
     dist.destroy_process_group()
 

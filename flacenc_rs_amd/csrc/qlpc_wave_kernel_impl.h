@@ -554,7 +554,9 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
       }
       fx.key = best_key;
       fx.order = uni(best_ord);
-      cand = fx.order;
+      // fixed_lpc returns None when the estimate does not beat verbatim_bits (coding.rs:284):
+      // then no residual is ever coded for it
+      cand = best_key < 8ull + (unsigned long long)n * bps_role ? fx.order : 5;
     } else {
       cand = 0;
     }

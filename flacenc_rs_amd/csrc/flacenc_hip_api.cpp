@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "flacenc_hip.h"
+#include "frame_decide.h"
 #include "frame_pack.h"
 #include "qlpc_kernel.h"
 
@@ -39,7 +40,7 @@ struct flacenc_hip_handle {
   hipStream_t stream = nullptr;
   std::string last_error;
   std::vector<WindowEntry> windows;
-  DeviceBuffer d_samples, d_residual, d_params, d_bps, d_autocorr, d_lpc, d_tables, d_keys, d_sel, d_results, d_out, d_outlen;
+  DeviceBuffer d_samples, d_residual, d_params, d_bps, d_autocorr, d_lpc, d_tables, d_keys, d_sel, d_results, d_out, d_outlen, d_cparams, d_cresid, d_fparams, d_fresid, d_fkeys;
   unsigned long long* stamps = nullptr;  // profiling hook, see flacenc_hip_debug_set_stamps
   unsigned long long* fixed_keys = nullptr;  // test hook, see flacenc_hip_debug_set_fixed_keys
 };
@@ -429,7 +430,8 @@ void flacenc_hip_destroy(flacenc_hip_handle* h) {
   for (WindowEntry& e : h->windows)
     if (e.dev) (void)hipFree(e.dev);
   for (DeviceBuffer* b : {&h->d_samples, &h->d_residual, &h->d_params, &h->d_bps, &h->d_autocorr,
-                          &h->d_lpc, &h->d_tables, &h->d_keys, &h->d_sel, &h->d_results, &h->d_out, &h->d_outlen})
+                          &h->d_lpc, &h->d_tables, &h->d_keys, &h->d_sel, &h->d_results, &h->d_out, &h->d_outlen, &h->d_cparams, &h->d_cresid,
+                          &h->d_fparams, &h->d_fresid, &h->d_fkeys})
     if (b->ptr) (void)hipFree(b->ptr);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -852,16 +854,14 @@ int flacenc_hip_encode_stereo_frames_async(flacenc_hip_handle* h, const flacenc_
     return FLACENC_HIP_ERR_BAD_ARGUMENT;
   }
   uint32_t fixed_group_log2 = 0;
+  bool fixed_composite = false;
   if (cfg->use_fixed) {
     if ((rc = verify_fixed(h, cfg)) != FLACENC_HIP_OK) return rc;
     if (cfg->fixed_order_sel == FLACENC_HIP_ORDERSEL_APPROXENT) {
       // the estimator's partitions must be whole groups of 64-sample lanes
       const uint32_t p = cfg->fixed_partitions;
-      if ((p & (p - 1)) != 0) {
-        h->last_error = "fixed: ApproxEnt.partitions must be a power of two on the GPU path";
-        return FLACENC_HIP_ERR_UNSUPPORTED;
-      }
-      uint32_t lanes = 64u / p;
+      if ((p & (p - 1)) != 0) fixed_composite = true;  // partitions not whole lane groups: general path
+      uint32_t lanes = fixed_composite ? 1u : 64u / p;
       while (lanes > 1) {
         ++fixed_group_log2;
         lanes >>= 1;
@@ -907,9 +907,53 @@ int flacenc_hip_encode_stereo_frames_async(flacenc_hip_handle* h, const flacenc_
   a.fixed_mode = a.fixed_partitions = a.forced_uniform = 0;
   a.forced_orders = nullptr;
   a.selector_keys = nullptr;
-  if (!flacenc_hip::wave_kernel_eligible(a)) {
-    h->last_error = "encode_stereo_frames: needs block_size 4096, lpc_order <= 12 and 16-byte aligned rows";
-    return FLACENC_HIP_ERR_UNSUPPORTED;
+  if (!flacenc_hip::wave_kernel_eligible(a) || fixed_composite) {
+    // General shapes: the same result from candidate batches (4 QLPC + 4 fixed-LPC candidates per
+    // frame in handle scratch) and the stand-alone controller kernel (frame_decide.cpp).
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t n_sub = n_frames * 4;
+    const size_t cstride = (static_cast<size_t>(block_size) + 3) & ~static_cast<size_t>(3);
+    flacenc_hip::FrameDecideArgs d{};
+    d.frames = frames;
+    d.stride = stride;
+    d.block_size = block_size;
+    d.n_frames = static_cast<uint32_t>(n_frames);
+    d.bits_per_sample = bits_per_sample;
+    d.use_constant = cfg->use_constant;
+    d.use_fixed = cfg->use_fixed;
+    d.use_lpc = cfg->use_lpc;
+    d.use_leftside = cfg->use_leftside;
+    d.use_rightside = cfg->use_rightside;
+    d.use_midside = cfg->use_midside;
+    d.cand_stride = cstride;
+    d.results = results;
+    d.residual = residual;
+    d.residual_stride = residual_stride;
+    if (cfg->use_lpc) {
+      if ((rc = ensure(h, h->d_cparams, n_sub * sizeof(flacenc_hip_subframe_params))) != FLACENC_HIP_OK) return rc;
+      if ((rc = ensure(h, h->d_cresid, n_sub * cstride * 4)) != FLACENC_HIP_OK) return rc;
+      rc = enqueue(h, &cfg->qlpc, frames, n_sub, block_size, stride, nullptr,
+                   static_cast<flacenc_hip_subframe_params*>(h->d_cparams.ptr),
+                   static_cast<int32_t*>(h->d_cresid.ptr), cstride, nullptr, nullptr, s, true, bits_per_sample);
+      if (rc != FLACENC_HIP_OK) return rc;
+      d.lpc_params = static_cast<const flacenc_hip_subframe_params*>(h->d_cparams.ptr);
+      d.lpc_residual = static_cast<const int32_t*>(h->d_cresid.ptr);
+    }
+    if (cfg->use_fixed) {
+      if ((rc = ensure(h, h->d_fparams, n_sub * sizeof(flacenc_hip_subframe_params))) != FLACENC_HIP_OK) return rc;
+      if ((rc = ensure(h, h->d_fresid, n_sub * cstride * 4)) != FLACENC_HIP_OK) return rc;
+      if ((rc = ensure(h, h->d_fkeys, n_sub * 8)) != FLACENC_HIP_OK) return rc;
+      rc = enqueue_fixed(h, cfg, frames, n_sub, block_size, stride, nullptr, bits_per_sample, true,
+                         static_cast<flacenc_hip_subframe_params*>(h->d_fparams.ptr),
+                         static_cast<int32_t*>(h->d_fresid.ptr), cstride,
+                         static_cast<unsigned long long*>(h->d_fkeys.ptr), s);
+      if (rc != FLACENC_HIP_OK) return rc;
+      d.fixed_params = static_cast<const flacenc_hip_subframe_params*>(h->d_fparams.ptr);
+      d.fixed_residual = static_cast<const int32_t*>(h->d_fresid.ptr);
+      d.fixed_keys = static_cast<const unsigned long long*>(h->d_fkeys.ptr);
+    }
+    HIP_TRY(h, flacenc_hip::launch_frame_decide(d, s));
+    return FLACENC_HIP_OK;
   }
   flacenc_hip::QlpcLaunchPlan plan = flacenc_hip::plan_qlpc_launch(block_size, cfg->qlpc.lpc_order);
   HIP_TRY(h, flacenc_hip::launch_qlpc(a, plan, static_cast<hipStream_t>(stream)));

@@ -1,0 +1,35 @@
+// frame_decide.h -- encode_subframe + try_stereo_coding over candidate batches (any block size).
+#ifndef FLACENC_HIP_FRAME_DECIDE_H_
+#define FLACENC_HIP_FRAME_DECIDE_H_
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "flacenc_hip.h"
+
+namespace flacenc_hip {
+
+struct FrameDecideArgs {
+  const int32_t* frames;  // device; channel c of frame f at frames + (2f + c)*stride
+  size_t stride;
+  uint32_t block_size;
+  uint32_t n_frames;
+  uint32_t bits_per_sample;
+  uint32_t use_constant, use_fixed, use_lpc, use_leftside, use_rightside, use_midside;
+  // candidates of subframe 4f + role (role = L, R, M, S); null when the candidate kind is off
+  const flacenc_hip_subframe_params* lpc_params;
+  const int32_t* lpc_residual;
+  const flacenc_hip_subframe_params* fixed_params;
+  const int32_t* fixed_residual;
+  const unsigned long long* fixed_keys;  // the order selector's key of each fixed candidate
+  size_t cand_stride;                    // row stride of both candidate residual buffers
+  flacenc_hip_stereo_frame_result* results;  // out, [n_frames]
+  int32_t* residual;                         // out; output channel c of frame f at (2f + c)*residual_stride
+  size_t residual_stride;
+};
+
+hipError_t launch_frame_decide(const FrameDecideArgs& args, hipStream_t stream);
+
+}  // namespace flacenc_hip
+#endif

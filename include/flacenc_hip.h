@@ -183,7 +183,6 @@ int flacenc_hip_stereo_qlpc_batch_async(flacenc_hip_handle* h, const flacenc_hip
  * candidate switches (src/config.rs:167-183), its config::Fixed (src/config.rs:236-244: max_order
  * and OrderSel, :400-409) and StereoCoding (src/config.rs:137-144).  Reference defaults: every
  * switch on, fixed_max_order 4, ApproxEnt with 16 partitions (src/constant.rs:35, :95).
- * On the GPU path ApproxEnt.partitions must be a power of two (1..64).
  */
 #define FLACENC_HIP_ORDERSEL_BITCOUNT 0  /* OrderSel::BitCount: code every order, count the bits */
 #define FLACENC_HIP_ORDERSEL_APPROXENT 1 /* OrderSel::ApproxEnt { partitions } (the default) */
@@ -235,8 +234,10 @@ typedef struct flacenc_hip_stereo_frame_result {
  * With use_fixed the other input of encode_subframe, `fixed_lpc` (src/coding.rs:298-331:
  * reset_fixed_lpc_errors :182-197, estimate_entropy :200-227, select_order_and_encode_residual
  * :230-288), runs on the GPU too, so the whole default-configuration decision is on the device.
- * Currently available for block_size 4096, lpc_order <= 12 and 16-byte aligned rows
- * (FLACENC_HIP_ERR_UNSUPPORTED otherwise: use flacenc_hip_stereo_qlpc_batch and decide on the host).
+ * Block size 4096 with lpc_order <= 12, 16-byte aligned rows and power-of-two ApproxEnt.partitions
+ * runs as ONE fused kernel (a wave per candidate, samples read from HBM once, losing candidates never
+ * leave the CU); every other shape (any block size 64..32767, any order, any partition count) runs
+ * the candidate batches into handle scratch followed by a controller kernel -- same outputs.
  */
 int flacenc_hip_encode_stereo_frames(flacenc_hip_handle* h, const flacenc_hip_frame_config* cfg,
                                      const int32_t* frames, size_t n_frames, uint32_t block_size,

@@ -787,14 +787,49 @@ def test_flac_stream_end_to_end(handle):
     assert int.from_bytes(si[4:7], "big") == min(sizes) and int.from_bytes(si[7:10], "big") == max(sizes)
 
 
-def test_encode_stereo_frames_rejects_unsupported(handle):
+@pytest.mark.parametrize("n,bps,order,kw", [
+    (4608, 16, 8, dict()), (1152, 16, 10, dict()), (576, 16, 12, dict(fixed_partitions=12)),
+    (8192, 24, 24, dict()), (192, 16, 8, dict(fixed_order_sel=0)), (4096, 16, 16, dict()),
+    (4096, 16, 8, dict(fixed_partitions=12)), (16384, 24, 12, dict(use_lpc=False)),
+    (2304, 16, 8, dict(use_fixed=False)), (100, 8, 4, dict()),
+])
+def test_encode_stereo_frames_any_shape(handle, n, bps, order, kw):
+    """flacenc_hip_encode_stereo_frames outside the fused kernel's shape (ragged / large / tiny
+    blocks, orders > 12, partition counts that are not lane groups): candidate batches + the
+    controller kernel == the oracle's encode_frame, and the frames pack and parse back."""
+    import flac_parse
+    base = _capi.sigen_frames(6, 2, n, bps, 120.0, 0.5, 0.03, seed=n + order)
+    t = np.arange(n)
+    base[1, 1] = base[1, 0]
+    half = 1 << (bps - 2)
+    base[2] = np.stack([(t // 7) % half, (t * t // (n // 4 + 1)) % half - half // 2]).astype(np.int32)
+    base[3, 0] = 77
+    base[4] = np.stack([util.quantize(util.noise(1, n, 0.999), bps), util.quantize(util.noise(2, n, 0.999), bps)])
+    use_fixed = kw.pop("use_fixed", True)
+    cfg = _capi.make_frame_config(gpu_cfg(order), use_fixed=use_fixed, **kw)
+    got, gres = handle.encode_stereo_frames(base, bps, cfg)
+    ofixed = orc.make_fixed_config(max_order=kw.get("fixed_max_order", 4), order_sel=kw.get("fixed_order_sel", 1),
+                                   partitions=kw.get("fixed_partitions", 16), sum_mode=orc.SUMABS_CANONICAL)
+    ocfg = orc.make_frame_config(orc_cfg(order, acorr=orc.ACORR_CANONICAL), use_fixed=use_fixed,
+                                 use_lpc=kw.get("use_lpc", True), fixed=ofixed)
+    want, wres = orc.encode_stereo_frames_cfg(base, bps, ocfg)
+    _check_frames_against_oracle(base, bps, got, gres, want, wres)
+    frames = handle.pack_stereo_frames(base, got, gres, bps, 48000, 5, 1)
+    for f in range(base.shape[0]):
+        assert frames[f] == orc.write_stereo_frame(got[f], base[f, 0], base[f, 1], bps, 48000, 5 + f, gres[f, 0], gres[f, 1])
+        if n <= 4608:
+            parsed = flac_parse.parse_frame(frames[f], stream_bps=bps)
+            assert parsed["block_size"] == n and np.array_equal(parsed["channels"], base[f]), f
+
+
+def test_encode_stereo_frames_rejects_bad_config(handle):
     x = np.zeros((2, 2, 4096), np.int32)
-    with pytest.raises(_capi.FlacencHipError) as ei:
-        handle.encode_stereo_frames(x, 16, _capi.make_frame_config(gpu_cfg(8), use_fixed=True, fixed_partitions=12))
-    assert ei.value.code == _capi.ERR_UNSUPPORTED
     with pytest.raises(_capi.FlacencHipError) as ei:
         handle.encode_stereo_frames(x, 16, _capi.make_frame_config(gpu_cfg(8), use_fixed=True, fixed_max_order=5))
     assert ei.value.code == _capi.ERR_BAD_CONFIG
     with pytest.raises(_capi.FlacencHipError) as ei:
-        handle.encode_stereo_frames(np.zeros((2, 2, 1152), np.int32), 16, _capi.make_frame_config(gpu_cfg(8)))
-    assert ei.value.code == _capi.ERR_UNSUPPORTED
+        handle.encode_stereo_frames(x, 16, _capi.make_frame_config(gpu_cfg(8), use_fixed=True, fixed_partitions=65))
+    assert ei.value.code == _capi.ERR_BAD_CONFIG
+    with pytest.raises(_capi.FlacencHipError) as ei:
+        handle.encode_stereo_frames(np.zeros((2, 2, 32), np.int32), 16, _capi.make_frame_config(gpu_cfg(8)))
+    assert ei.value.code == _capi.ERR_BAD_ARGUMENT

@@ -379,6 +379,9 @@ struct Frame {  // datatype.rs:820
   size_t block_size = 0;
   ChannelAssignment channel_assignment = ChannelAssignment::Independent;
   std::vector<SubFrame> subframes;
+  // Frame::precomputed_bitstream (datatype.rs:820-830): the frame as it goes into the stream;
+  // filled by the GPU bit writer (flacenc_hip_pack_stereo_frames) where that path is taken
+  std::vector<uint8_t> precomputed_bitstream;
   size_t count_subframe_bits() const {
     size_t b = 0;
     for (const auto& s : subframes) b += count_bits(s);
@@ -404,15 +407,54 @@ struct Frame {  // datatype.rs:820
   }
 };
 
-struct StreamInfo {  // datatype.rs:435
+struct StreamInfo {  // datatype.rs:435-445, defaults :476-479
   size_t sample_rate = 0, channels = 0, bits_per_sample = 0;
-  size_t min_block_size = 0, max_block_size = 0;
+  size_t min_block_size = 0xFFFF, max_block_size = 0;
+  size_t min_frame_size = 0xFFFFFFFFu, max_frame_size = 0;
   uint64_t total_samples = 0;
+  uint8_t md5_digest[16] = {0};  // all zero = "not computed" (MD5 is host work outside this mirror)
+  // update_frame_info, datatype.rs:514-523 (total_samples is counted by the encoder loop here)
+  void update_frame_info(const Frame& f) {
+    min_block_size = std::min(min_block_size, f.block_size);
+    max_block_size = std::max(max_block_size, f.block_size);
+    if (!f.precomputed_bitstream.empty()) {
+      min_frame_size = std::min(min_frame_size, f.precomputed_bitstream.size());
+      max_frame_size = std::max(max_frame_size, f.precomputed_bitstream.size());
+    }
+  }
 };
 struct Stream {  // datatype.rs:65
   StreamInfo stream_info;
   std::vector<Frame> frames;
-  void add_frame(Frame f) { frames.push_back(std::move(f)); }
+  void add_frame(Frame f) {  // datatype.rs:184-187
+    stream_info.update_frame_info(f);
+    frames.push_back(std::move(f));
+  }
+  // BitRepr for Stream::write (bitrepr.rs:185-196): "fLaC", the STREAMINFO block (:207-216,
+  // :246-270, last-block flag set as Stream::write does for a stream without further metadata),
+  // then every frame's precomputed bitstream (:290-293).  Frames that did not go through the GPU
+  // bit writer have none: the host-side bit writer is outside this mirror.
+  std::vector<uint8_t> to_bytes() const {
+    std::vector<uint8_t> out = {0x66, 0x4c, 0x61, 0x43, 0x80, 0x00, 0x00, 34};
+    auto be = [&](uint64_t v, int bytes) {
+      for (int i = bytes - 1; i >= 0; --i) out.push_back(uint8_t(v >> (8 * i)));
+    };
+    be(stream_info.min_block_size, 2);
+    be(stream_info.max_block_size, 2);
+    be(stream_info.min_frame_size & 0xFFFFFF, 3);
+    be(stream_info.max_frame_size & 0xFFFFFF, 3);
+    be((uint64_t(stream_info.sample_rate) << 44) | (uint64_t(stream_info.channels - 1) << 41) |
+           (uint64_t(stream_info.bits_per_sample - 1) << 36) | (stream_info.total_samples & 0xFFFFFFFFFull),
+       8);
+    out.insert(out.end(), stream_info.md5_digest, stream_info.md5_digest + 16);
+    for (const Frame& f : frames) {
+      if (f.precomputed_bitstream.empty())
+        throw std::runtime_error("Stream::to_bytes: a frame has no precomputed bitstream (only 2-channel "
+                                 "streams go through the GPU bit writer)");
+      out.insert(out.end(), f.precomputed_bitstream.begin(), f.precomputed_bitstream.end());
+    }
+    return out;
+  }
 };
 }  // namespace component
 
@@ -594,6 +636,16 @@ component::Stream encode_with_fixed_block_size(const config::Encoder& config, So
                                                       static_cast<uint32_t>(bps), fr.data(), resid2.data(), n,
                                                       FLACENC_HIP_MEM_HOST);
       if (rc == FLACENC_HIP_OK) {
+        // Frame::write on the GPU too (bitrepr.rs:289-319): the frames' final bytes
+        const size_t ostride = flacenc_hip_stereo_frame_bytes_bound(static_cast<uint32_t>(n), static_cast<uint32_t>(bps));
+        std::vector<uint8_t> packed(nf * ostride);
+        std::vector<uint32_t> packed_len(nf);
+        const int prc = flacenc_hip_pack_stereo_frames(
+            gpu.get(), staged.data(), nf, static_cast<uint32_t>(n), n, fr.data(), resid2.data(), n,
+            static_cast<uint32_t>(bps), static_cast<uint32_t>(src.sample_rate()), static_cast<uint32_t>(f0), 1,
+            packed.data(), ostride, packed_len.data(), FLACENC_HIP_MEM_HOST);
+        if (prc != FLACENC_HIP_OK && prc != FLACENC_HIP_ERR_UNSUPPORTED)
+          throw error::EncodeError(error::EncodeError::Device, flacenc_hip_last_error(gpu.get()));
         for (size_t f = 0; f < nf; ++f) {
           const source::FrameBuf& fb = bufs[f0 + f];
           const int32_t* l = fb.channel_slice(0);
@@ -621,6 +673,8 @@ component::Stream encode_with_fixed_block_size(const config::Encoder& config, So
               frame.subframes.push_back(detail::make_lpc(fr[f].lpc[c], &resid2[(f * 2 + c) * n], sig.data(), n, b));
             }
           }
+          if (prc == FLACENC_HIP_OK)
+            frame.precomputed_bitstream.assign(packed.begin() + f * ostride, packed.begin() + f * ostride + packed_len[f]);
           stream.add_frame(std::move(frame));
         }
         f0 = f1;

@@ -12,6 +12,7 @@
 // Build + run: see tests/test_host_mirror_gpu.py.
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 #include "flacenc.hpp"
@@ -71,7 +72,7 @@ static void integrity_test(HipContext& gpu, const config::Encoder& cfg, size_t c
   CHECK(lpc > 0);  // a predictable sinusoid must pick the LPC candidate
 }
 
-int main() {
+int main(int argc, char** argv) {
   HipContext gpu(0);
   config::Encoder cfg;                    // defaults: order 10, precision 15, Tukey(0.4), max_p 30
   cfg.subframe_coding.use_fixed = false;  // see flacenc.hpp header note
@@ -150,6 +151,45 @@ int main() {
       std::printf("  ramp, block %zu: %zu FixedLpc subframes of %zu\n", block, fixed, st.frames.size() * 2);
       CHECK(fixed > 0);
     }
+  }
+  // Stream::write with every frame's bytes made by the GPU bit writer: a complete .flac for a
+  // 2-channel stream incl. its short tail block; tests/test_host_mirror_gpu.py parses it back
+  {
+    config::Encoder def;
+    const size_t len = 16123;
+    const std::vector<int32_t> signal = make_signal(2, len, 16, 4242);
+    auto src = source::MemSource::from_samples(signal, 2, 16, 44100);
+    component::Stream st = encode_with_fixed_block_size(def, src, 4096, gpu);
+    std::vector<uint8_t> bytes = st.to_bytes();
+    CHECK(bytes.size() > 42 && bytes[0] == 'f' && bytes[3] == 'C');
+    size_t frame_bytes = 0;
+    for (const auto& f : st.frames) frame_bytes += f.precomputed_bitstream.size();
+    CHECK(bytes.size() == 42 + frame_bytes);
+    CHECK(st.stream_info.max_frame_size >= st.stream_info.min_frame_size && st.stream_info.min_frame_size > 0);
+    if (argc > 1) {
+      const std::string dir = argv[1];
+      FILE* fo = std::fopen((dir + "/mirror.flac").c_str(), "wb");
+      CHECK(fo != nullptr);
+      if (fo) {
+        std::fwrite(bytes.data(), 1, bytes.size(), fo);
+        std::fclose(fo);
+      }
+      fo = std::fopen((dir + "/mirror.pcm").c_str(), "wb");
+      if (fo) {
+        std::fwrite(signal.data(), sizeof(int32_t), signal.size(), fo);
+        std::fclose(fo);
+      }
+    }
+    // a mono stream is analysed on the GPU but its frames have no GPU-made bytes
+    auto mono = source::MemSource::from_samples(make_signal(1, 9000, 16, 7), 1, 16, 44100);
+    component::Stream ms = encode_with_fixed_block_size(def, mono, 4096, gpu);
+    bool thrown = false;
+    try {
+      ms.to_bytes();
+    } catch (const std::runtime_error&) {
+      thrown = true;
+    }
+    CHECK(thrown);
   }
   if (failures) {
     std::printf("FAILED: %d\n", failures);

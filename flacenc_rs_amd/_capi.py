@@ -56,6 +56,11 @@ EXPORTED_SYMBOLS = (
     "flacenc_hip_pack_stereo_frames",
     "flacenc_hip_pack_stereo_frames_async",
     "flacenc_hip_stereo_frame_lengths_async",
+    "flacenc_hip_encode_frames",
+    "flacenc_hip_encode_frames_async",
+    "flacenc_hip_frame_bytes_bound",
+    "flacenc_hip_pack_frames",
+    "flacenc_hip_pack_frames_async",
     "flacenc_hip_synchronize",
     "flacenc_hip_debug_set_stamps",
     "flacenc_hip_debug_set_fixed_keys",
@@ -131,6 +136,12 @@ def make_frame_config(qlpc: QlpcConfig | None = None, use_constant=True, use_fix
                        int(use_leftside), int(use_rightside), int(use_midside), int(fixed_max_order),
                        int(fixed_order_sel), int(fixed_partitions), 0)
 
+
+# flacenc_hip_channel_result (368 bytes): one channel of an Independent(n) frame
+CHANNEL_RESULT_DTYPE = np.dtype(
+    [("kind", np.uint8), ("pad", np.uint8, (3,)), ("dc_offset", np.int32), ("bits", np.uint64),
+     ("params", PARAMS_DTYPE)], align=False)
+assert CHANNEL_RESULT_DTYPE.itemsize == 368
 
 # flacenc_hip_stereo_frame_result (752 bytes)
 FRAME_RESULT_DTYPE = np.dtype(
@@ -215,6 +226,19 @@ def load() -> C.CDLL:
     L.flacenc_hip_stereo_frame_lengths_async.restype = C.c_int
     L.flacenc_hip_stereo_frame_bytes_bound.argtypes = [C.c_uint32, C.c_uint32]
     L.flacenc_hip_stereo_frame_bytes_bound.restype = C.c_size_t
+    L.flacenc_hip_encode_frames.argtypes = [vp, C.POINTER(FrameConfig), i32p, C.c_size_t, C.c_uint32, C.c_uint32,
+                                            C.c_size_t, C.c_uint32, vp, i32p, C.c_size_t, C.c_int]
+    L.flacenc_hip_encode_frames.restype = C.c_int
+    L.flacenc_hip_encode_frames_async.argtypes = L.flacenc_hip_encode_frames.argtypes[:-1] + [vp]
+    L.flacenc_hip_encode_frames_async.restype = C.c_int
+    L.flacenc_hip_frame_bytes_bound.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
+    L.flacenc_hip_frame_bytes_bound.restype = C.c_size_t
+    L.flacenc_hip_pack_frames.argtypes = [vp, i32p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_size_t, vp, i32p,
+                                          C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_size_t,
+                                          vp, C.c_int]
+    L.flacenc_hip_pack_frames.restype = C.c_int
+    L.flacenc_hip_pack_frames_async.argtypes = L.flacenc_hip_pack_frames.argtypes[:-1] + [vp]
+    L.flacenc_hip_pack_frames_async.restype = C.c_int
     frame_args = [vp, C.POINTER(FrameConfig), i32p, C.c_size_t, C.c_uint32, C.c_size_t, C.c_uint32,
                   vp, i32p, C.c_size_t]
     L.flacenc_hip_encode_stereo_frames.argtypes = frame_args + [C.c_int]
@@ -427,6 +451,34 @@ class Handle:
 
     def frame_bytes_bound(self, block_size: int, bits_per_sample: int) -> int:
         return int(self._lib.flacenc_hip_stereo_frame_bytes_bound(block_size, bits_per_sample))
+
+    def encode_frames(self, frames, bits_per_sample: int, cfg: FrameConfig):
+        """encode_frame for Independent(channels) frames: `frames` int32 [n_frames, channels, n] ->
+        (results CHANNEL_RESULT_DTYPE [n_frames, channels], residual [n_frames, channels, n])."""
+        x = np.ascontiguousarray(frames, np.int32)
+        nf, ch, n = x.shape
+        results = np.zeros((nf, ch), CHANNEL_RESULT_DTYPE)
+        residual = np.zeros((nf, ch, n), np.int32)
+        rc = self._lib.flacenc_hip_encode_frames(self._h, C.byref(cfg), x.ctypes.data, nf, ch, n, n, bits_per_sample,
+                                                 results.ctypes.data, residual.ctypes.data, n, MEM_HOST)
+        self._check(rc)
+        return results, residual
+
+    def pack_frames(self, frames, results, residual, bits_per_sample: int, sample_rate: int,
+                    first_frame_number: int = 0, frame_number_step: int = 1):
+        """Frame::write for the frames encode_frames decided -> list of `bytes`."""
+        x = np.ascontiguousarray(frames, np.int32)
+        nf, ch, n = x.shape
+        res = np.ascontiguousarray(results)
+        rs = np.ascontiguousarray(residual, np.int32)
+        stride = int(self._lib.flacenc_hip_frame_bytes_bound(ch, n, bits_per_sample))
+        out = np.zeros((nf, stride), np.uint8)
+        lens = np.zeros(nf, np.uint32)
+        rc = self._lib.flacenc_hip_pack_frames(self._h, x.ctypes.data, nf, ch, n, n, res.ctypes.data, rs.ctypes.data, n,
+                                               bits_per_sample, sample_rate, first_frame_number, frame_number_step,
+                                               out.ctypes.data, stride, lens.ctypes.data, MEM_HOST)
+        self._check(rc)
+        return [bytes(out[f, :lens[f]]) for f in range(nf)]
 
     def encode_stereo_frames(self, frames, bits_per_sample: int, cfg: FrameConfig):
         """encode_frame with the decision on the GPU: `frames` int32 [n_frames, 2, block_size] ->

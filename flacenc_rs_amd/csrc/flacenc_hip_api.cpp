@@ -550,23 +550,31 @@ int flacenc_hip_fixed_lpc_batch(flacenc_hip_handle* h, const flacenc_hip_frame_c
   return FLACENC_HIP_OK;
 }
 
+size_t flacenc_hip_frame_bytes_bound(uint32_t channels, uint32_t block_size, uint32_t bits_per_sample) {
+  return (flacenc_hip::frame_bytes_bound(channels, block_size, bits_per_sample) + 15) & ~static_cast<size_t>(15);
+}
+
 size_t flacenc_hip_stereo_frame_bytes_bound(uint32_t block_size, uint32_t bits_per_sample) {
   return (flacenc_hip::stereo_frame_bytes_bound(block_size, bits_per_sample) + 15) & ~static_cast<size_t>(15);
 }
 
-int flacenc_hip_pack_stereo_frames_async(flacenc_hip_handle* h, const int32_t* frames, size_t n_frames,
-                                         uint32_t block_size, size_t stride,
-                                         const flacenc_hip_stereo_frame_result* results, const int32_t* residual,
-                                         size_t residual_stride, uint32_t bits_per_sample, uint32_t sample_rate,
-                                         uint32_t first_frame_number, uint32_t frame_number_step, uint8_t* out,
-                                         size_t out_stride, uint32_t* out_len, void* stream) {
+// Frame::write for a batch: `results` (2-channel records) or `chan_results` + channels
+static int enqueue_pack(flacenc_hip_handle* h, const int32_t* frames, size_t n_frames, uint32_t channels,
+                        uint32_t block_size, size_t stride, const flacenc_hip_stereo_frame_result* results,
+                        const flacenc_hip_channel_result* chan_results, const int32_t* residual,
+                        size_t residual_stride, uint32_t bits_per_sample, uint32_t sample_rate,
+                        uint32_t first_frame_number, uint32_t frame_number_step, uint8_t* out,
+                        size_t out_stride, uint32_t* out_len, void* stream) {
   if (!h) return FLACENC_HIP_ERR_BAD_ARGUMENT;
   if (n_frames == 0) return FLACENC_HIP_OK;
-  if (!frames || !results || !residual || !out || !out_len || stride < block_size || residual_stride < block_size ||
+  const size_t bound = chan_results ? flacenc_hip_frame_bytes_bound(channels, block_size, bits_per_sample)
+                                    : flacenc_hip_stereo_frame_bytes_bound(block_size, bits_per_sample);
+  if (chan_results && (channels < 1 || channels > 8)) return FLACENC_HIP_ERR_BAD_ARGUMENT;
+  if (!frames || (!results && !chan_results) || !residual || !out || !out_len || stride < block_size || residual_stride < block_size ||
       block_size < FLACENC_HIP_MIN_BLOCK_SIZE || block_size > FLACENC_HIP_MAX_BLOCK_SIZE ||
       bits_per_sample < 8 || bits_per_sample > 24 || n_frames > 0x7FFFFFFFull ||
       (reinterpret_cast<uintptr_t>(out) & 15) || (out_stride & 15) ||
-      out_stride < flacenc_hip_stereo_frame_bytes_bound(block_size, bits_per_sample)) {
+      out_stride < bound) {
     h->last_error = "pack_stereo_frames: null pointer, bad size, or out_stride below flacenc_hip_stereo_frame_bytes_bound";
     return FLACENC_HIP_ERR_BAD_ARGUMENT;
   }
@@ -583,6 +591,8 @@ int flacenc_hip_pack_stereo_frames_async(flacenc_hip_handle* h, const int32_t* f
   a.block_size = block_size;
   a.n_frames = static_cast<uint32_t>(n_frames);
   a.results = results;
+  a.chan_results = chan_results;
+  a.channels = chan_results ? channels : 2u;
   a.residual = residual;
   a.residual_stride = residual_stride;
   a.bits_per_sample = bits_per_sample;
@@ -592,7 +602,7 @@ int flacenc_hip_pack_stereo_frames_async(flacenc_hip_handle* h, const int32_t* f
   a.out_stride = out_stride;
   a.out_len = out_len;
   fill_header_specs(a, block_size, sample_rate, bits_per_sample);
-  a.lds_words = static_cast<uint32_t>(flacenc_hip_stereo_frame_bytes_bound(block_size, bits_per_sample) / 4 + 4);
+  a.lds_words = static_cast<uint32_t>(bound / 4 + 4);
   {
     // y = x^(8 per) mod P and its powers (see frame_pack.h)
     auto mulmod = [](uint32_t x, uint32_t y) {
@@ -626,6 +636,29 @@ int flacenc_hip_pack_stereo_frames_async(flacenc_hip_handle* h, const int32_t* f
   HIP_TRY(h, hipSetDevice(h->device));
   HIP_TRY(h, flacenc_hip::launch_frame_pack(a, static_cast<hipStream_t>(stream)));
   return FLACENC_HIP_OK;
+}
+
+int flacenc_hip_pack_stereo_frames_async(flacenc_hip_handle* h, const int32_t* frames, size_t n_frames,
+                                         uint32_t block_size, size_t stride,
+                                         const flacenc_hip_stereo_frame_result* results, const int32_t* residual,
+                                         size_t residual_stride, uint32_t bits_per_sample, uint32_t sample_rate,
+                                         uint32_t first_frame_number, uint32_t frame_number_step, uint8_t* out,
+                                         size_t out_stride, uint32_t* out_len, void* stream) {
+  if (!results && n_frames) return FLACENC_HIP_ERR_BAD_ARGUMENT;
+  return enqueue_pack(h, frames, n_frames, 2, block_size, stride, results, nullptr, residual, residual_stride,
+                      bits_per_sample, sample_rate, first_frame_number, frame_number_step, out, out_stride, out_len,
+                      stream);
+}
+
+int flacenc_hip_pack_frames_async(flacenc_hip_handle* h, const int32_t* frames, size_t n_frames, uint32_t channels,
+                                  uint32_t block_size, size_t stride, const flacenc_hip_channel_result* results,
+                                  const int32_t* residual, size_t residual_stride, uint32_t bits_per_sample,
+                                  uint32_t sample_rate, uint32_t first_frame_number, uint32_t frame_number_step,
+                                  uint8_t* out, size_t out_stride, uint32_t* out_len, void* stream) {
+  if (!results && n_frames) return FLACENC_HIP_ERR_BAD_ARGUMENT;
+  return enqueue_pack(h, frames, n_frames, channels, block_size, stride, nullptr, results, residual, residual_stride,
+                      bits_per_sample, sample_rate, first_frame_number, frame_number_step, out, out_stride, out_len,
+                      stream);
 }
 
 int flacenc_hip_stereo_frame_lengths_async(flacenc_hip_handle* h, const flacenc_hip_stereo_frame_result* results,
@@ -698,6 +731,154 @@ int flacenc_hip_pack_stereo_frames(flacenc_hip_handle* h, const int32_t* frames,
                                             sample_rate, first_frame_number, frame_number_step,
                                             static_cast<uint8_t*>(h->d_out.ptr), ostride,
                                             static_cast<uint32_t*>(h->d_outlen.ptr), s);
+  if (rc != FLACENC_HIP_OK) return rc;
+  HIP_TRY(h, hipMemcpy2DAsync(out, out_stride, h->d_out.ptr, ostride, ostride, n_frames, hipMemcpyDeviceToHost, s));
+  HIP_TRY(h, hipMemcpyAsync(out_len, h->d_outlen.ptr, n_frames * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(h, hipStreamSynchronize(s));
+  return FLACENC_HIP_OK;
+}
+
+int flacenc_hip_encode_frames_async(flacenc_hip_handle* h, const flacenc_hip_frame_config* cfg,
+                                    const int32_t* frames, size_t n_frames, uint32_t channels,
+                                    uint32_t block_size, size_t stride, uint32_t bits_per_sample,
+                                    flacenc_hip_channel_result* results, int32_t* residual,
+                                    size_t residual_stride, void* stream) {
+  if (!h || !cfg || (!results && n_frames) || channels < 1 || channels > 8) return FLACENC_HIP_ERR_BAD_ARGUMENT;
+  const size_t n_sub = n_frames * channels;
+  int rc = check_batch_args(h, &cfg->qlpc, frames, n_sub, block_size, stride,
+                            reinterpret_cast<flacenc_hip_subframe_params*>(results), residual, residual_stride);
+  if (rc != FLACENC_HIP_OK || n_frames == 0) return rc;
+  if (bits_per_sample < 8 || bits_per_sample > 24) {
+    h->last_error = "bits_per_sample must be in 8..=24";
+    return FLACENC_HIP_ERR_BAD_ARGUMENT;
+  }
+  if (cfg->use_fixed && (rc = verify_fixed(h, cfg)) != FLACENC_HIP_OK) return rc;
+  HIP_TRY(h, hipSetDevice(h->device));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const size_t cstride = (static_cast<size_t>(block_size) + 3) & ~static_cast<size_t>(3);
+  flacenc_hip::ChannelDecideArgs d{};
+  d.samples = frames;
+  d.stride = stride;
+  d.block_size = block_size;
+  d.n_subframes = static_cast<uint32_t>(n_sub);
+  d.bits_per_sample = bits_per_sample;
+  d.use_constant = cfg->use_constant;
+  d.use_fixed = cfg->use_fixed;
+  d.use_lpc = cfg->use_lpc;
+  d.cand_stride = cstride;
+  d.results = results;
+  d.residual = residual;
+  d.residual_stride = residual_stride;
+  if (cfg->use_lpc) {
+    if ((rc = ensure(h, h->d_cparams, n_sub * sizeof(flacenc_hip_subframe_params))) != FLACENC_HIP_OK) return rc;
+    if ((rc = ensure(h, h->d_cresid, n_sub * cstride * 4)) != FLACENC_HIP_OK) return rc;
+    rc = enqueue(h, &cfg->qlpc, frames, n_sub, block_size, stride, nullptr,
+                 static_cast<flacenc_hip_subframe_params*>(h->d_cparams.ptr), static_cast<int32_t*>(h->d_cresid.ptr),
+                 cstride, nullptr, nullptr, s, false, bits_per_sample);
+    if (rc != FLACENC_HIP_OK) return rc;
+    d.lpc_params = static_cast<const flacenc_hip_subframe_params*>(h->d_cparams.ptr);
+    d.lpc_residual = static_cast<const int32_t*>(h->d_cresid.ptr);
+  }
+  if (cfg->use_fixed) {
+    if ((rc = ensure(h, h->d_fparams, n_sub * sizeof(flacenc_hip_subframe_params))) != FLACENC_HIP_OK) return rc;
+    if ((rc = ensure(h, h->d_fresid, n_sub * cstride * 4)) != FLACENC_HIP_OK) return rc;
+    if ((rc = ensure(h, h->d_fkeys, n_sub * 8)) != FLACENC_HIP_OK) return rc;
+    rc = enqueue_fixed(h, cfg, frames, n_sub, block_size, stride, nullptr, bits_per_sample, false,
+                       static_cast<flacenc_hip_subframe_params*>(h->d_fparams.ptr),
+                       static_cast<int32_t*>(h->d_fresid.ptr), cstride,
+                       static_cast<unsigned long long*>(h->d_fkeys.ptr), s);
+    if (rc != FLACENC_HIP_OK) return rc;
+    d.fixed_params = static_cast<const flacenc_hip_subframe_params*>(h->d_fparams.ptr);
+    d.fixed_residual = static_cast<const int32_t*>(h->d_fresid.ptr);
+    d.fixed_keys = static_cast<const unsigned long long*>(h->d_fkeys.ptr);
+  }
+  HIP_TRY(h, flacenc_hip::launch_channel_decide(d, s));
+  return FLACENC_HIP_OK;
+}
+
+int flacenc_hip_encode_frames(flacenc_hip_handle* h, const flacenc_hip_frame_config* cfg,
+                              const int32_t* frames, size_t n_frames, uint32_t channels, uint32_t block_size,
+                              size_t stride, uint32_t bits_per_sample, flacenc_hip_channel_result* results,
+                              int32_t* residual, size_t residual_stride, int memory_kind) {
+  if (!h) return FLACENC_HIP_ERR_BAD_ARGUMENT;
+  if (memory_kind == FLACENC_HIP_MEM_DEVICE) {
+    int rc = flacenc_hip_encode_frames_async(h, cfg, frames, n_frames, channels, block_size, stride, bits_per_sample,
+                                             results, residual, residual_stride, h->stream);
+    if (rc != FLACENC_HIP_OK || n_frames == 0) return rc;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return FLACENC_HIP_OK;
+  }
+  if (memory_kind != FLACENC_HIP_MEM_HOST || !cfg || channels < 1 || channels > 8) return FLACENC_HIP_ERR_BAD_ARGUMENT;
+  const size_t n_sub = n_frames * channels;
+  int rc = check_batch_args(h, &cfg->qlpc, frames, n_sub, block_size, stride,
+                            reinterpret_cast<flacenc_hip_subframe_params*>(results), residual, residual_stride);
+  if (rc != FLACENC_HIP_OK || n_frames == 0) return rc;
+  HIP_TRY(h, hipSetDevice(h->device));
+  const size_t dstride = (static_cast<size_t>(block_size) + 3) & ~static_cast<size_t>(3);
+  if ((rc = ensure(h, h->d_samples, n_sub * dstride * 4)) != FLACENC_HIP_OK) return rc;
+  if ((rc = ensure(h, h->d_residual, n_sub * dstride * 4)) != FLACENC_HIP_OK) return rc;
+  if ((rc = ensure(h, h->d_results, n_sub * sizeof(flacenc_hip_channel_result))) != FLACENC_HIP_OK) return rc;
+  hipStream_t s = h->stream;
+  HIP_TRY(h, hipMemcpy2DAsync(h->d_samples.ptr, dstride * 4, frames, stride * 4, static_cast<size_t>(block_size) * 4,
+                              n_sub, hipMemcpyHostToDevice, s));
+  rc = flacenc_hip_encode_frames_async(h, cfg, static_cast<const int32_t*>(h->d_samples.ptr), n_frames, channels,
+                                       block_size, dstride, bits_per_sample,
+                                       static_cast<flacenc_hip_channel_result*>(h->d_results.ptr),
+                                       static_cast<int32_t*>(h->d_residual.ptr), dstride, s);
+  if (rc != FLACENC_HIP_OK) return rc;
+  HIP_TRY(h, hipMemcpy2DAsync(residual, residual_stride * 4, h->d_residual.ptr, dstride * 4,
+                              static_cast<size_t>(block_size) * 4, n_sub, hipMemcpyDeviceToHost, s));
+  HIP_TRY(h, hipMemcpyAsync(results, h->d_results.ptr, n_sub * sizeof(flacenc_hip_channel_result),
+                            hipMemcpyDeviceToHost, s));
+  HIP_TRY(h, hipStreamSynchronize(s));
+  return FLACENC_HIP_OK;
+}
+
+int flacenc_hip_pack_frames(flacenc_hip_handle* h, const int32_t* frames, size_t n_frames, uint32_t channels,
+                            uint32_t block_size, size_t stride, const flacenc_hip_channel_result* results,
+                            const int32_t* residual, size_t residual_stride, uint32_t bits_per_sample,
+                            uint32_t sample_rate, uint32_t first_frame_number, uint32_t frame_number_step,
+                            uint8_t* out, size_t out_stride, uint32_t* out_len, int memory_kind) {
+  if (!h) return FLACENC_HIP_ERR_BAD_ARGUMENT;
+  if (memory_kind == FLACENC_HIP_MEM_DEVICE) {
+    int rc = flacenc_hip_pack_frames_async(h, frames, n_frames, channels, block_size, stride, results, residual,
+                                           residual_stride, bits_per_sample, sample_rate, first_frame_number,
+                                           frame_number_step, out, out_stride, out_len, h->stream);
+    if (rc != FLACENC_HIP_OK || n_frames == 0) return rc;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return FLACENC_HIP_OK;
+  }
+  if (memory_kind != FLACENC_HIP_MEM_HOST || channels < 1 || channels > 8) return FLACENC_HIP_ERR_BAD_ARGUMENT;
+  if (n_frames == 0) return FLACENC_HIP_OK;
+  if (!frames || !results || !residual || !out || !out_len || stride < block_size || residual_stride < block_size)
+    return FLACENC_HIP_ERR_BAD_ARGUMENT;
+  HIP_TRY(h, hipSetDevice(h->device));
+  int rc;
+  const size_t n_sub = n_frames * channels;
+  const size_t dstride = (static_cast<size_t>(block_size) + 3) & ~static_cast<size_t>(3);
+  const size_t ostride = flacenc_hip_frame_bytes_bound(channels, block_size, bits_per_sample);
+  if (out_stride < ostride) {
+    h->last_error = "pack_frames: out_stride below flacenc_hip_frame_bytes_bound";
+    return FLACENC_HIP_ERR_BAD_ARGUMENT;
+  }
+  if ((rc = ensure(h, h->d_samples, n_sub * dstride * 4)) != FLACENC_HIP_OK) return rc;
+  if ((rc = ensure(h, h->d_residual, n_sub * dstride * 4)) != FLACENC_HIP_OK) return rc;
+  if ((rc = ensure(h, h->d_results, n_sub * sizeof(flacenc_hip_channel_result))) != FLACENC_HIP_OK) return rc;
+  if ((rc = ensure(h, h->d_out, n_frames * ostride)) != FLACENC_HIP_OK) return rc;
+  if ((rc = ensure(h, h->d_outlen, n_frames * 4)) != FLACENC_HIP_OK) return rc;
+  hipStream_t s = h->stream;
+  HIP_TRY(h, hipMemcpy2DAsync(h->d_samples.ptr, dstride * 4, frames, stride * 4, static_cast<size_t>(block_size) * 4,
+                              n_sub, hipMemcpyHostToDevice, s));
+  HIP_TRY(h, hipMemcpy2DAsync(h->d_residual.ptr, dstride * 4, residual, residual_stride * 4,
+                              static_cast<size_t>(block_size) * 4, n_sub, hipMemcpyHostToDevice, s));
+  HIP_TRY(h, hipMemcpyAsync(h->d_results.ptr, results, n_sub * sizeof(flacenc_hip_channel_result),
+                            hipMemcpyHostToDevice, s));
+  rc = flacenc_hip_pack_frames_async(h, static_cast<const int32_t*>(h->d_samples.ptr), n_frames, channels, block_size,
+                                     dstride, static_cast<const flacenc_hip_channel_result*>(h->d_results.ptr),
+                                     static_cast<const int32_t*>(h->d_residual.ptr), dstride, bits_per_sample,
+                                     sample_rate, first_frame_number, frame_number_step,
+                                     static_cast<uint8_t*>(h->d_out.ptr), ostride,
+                                     static_cast<uint32_t*>(h->d_outlen.ptr), s);
   if (rc != FLACENC_HIP_OK) return rc;
   HIP_TRY(h, hipMemcpy2DAsync(out, out_stride, h->d_out.ptr, ostride, ostride, n_frames, hipMemcpyDeviceToHost, s));
   HIP_TRY(h, hipMemcpyAsync(out_len, h->d_outlen.ptr, n_frames * 4, hipMemcpyDeviceToHost, s));

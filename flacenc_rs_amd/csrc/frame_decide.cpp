@@ -140,7 +140,86 @@ __global__ void __launch_bounds__(kThreads) frame_decide_kernel(FrameDecideArgs 
   }
 }
 
+// encode_subframe (coding.rs:384-418) for one channel of an Independent(n) frame
+__global__ void __launch_bounds__(kThreads) channel_decide_kernel(ChannelDecideArgs a) {
+  __shared__ int smin[kThreads / 64], smax[kThreads / 64];
+  __shared__ uint32_t skind;
+  const int tid = threadIdx.x;
+  const size_t sf = blockIdx.x;
+  const int n = (int)a.block_size;
+  const int32_t* __restrict__ x = a.samples + sf * a.stride;
+  int mn = INT32_MAX, mx = INT32_MIN;
+  for (int t = tid; t < n; t += kThreads) {
+    const int v = x[t];
+    mn = v < mn ? v : mn;
+    mx = v > mx ? v : mx;
+  }
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int o1 = __shfl_xor(mn, d, 64), o2 = __shfl_xor(mx, d, 64);
+    mn = o1 < mn ? o1 : mn;
+    mx = o2 > mx ? o2 : mx;
+  }
+  if ((tid & 63) == 0) {
+    smin[tid >> 6] = mn;
+    smax[tid >> 6] = mx;
+  }
+  __syncthreads();
+  flacenc_hip_channel_result* out = a.results + sf;
+  if (tid == 0) {
+    int lo = smin[0], hi = smax[0];
+    for (int w = 1; w < kThreads / 64; ++w) {
+      lo = smin[w] < lo ? smin[w] : lo;
+      hi = smax[w] > hi ? smax[w] : hi;
+    }
+    const unsigned long long bps = a.bits_per_sample;
+    const unsigned long long verbatim_bits = 8ull + (unsigned long long)n * bps;
+    const bool have_fixed = a.use_fixed && a.fixed_params && a.fixed_keys[sf] < verbatim_bits;
+    const unsigned long long fixed_bits = have_fixed ? a.fixed_params[sf].subframe_bits : ~0ull;
+    const unsigned long long baseline = fixed_bits < verbatim_bits ? fixed_bits : verbatim_bits;
+    const bool lpc_ok = a.use_lpc && a.lpc_params && a.lpc_params[sf].status == 0;
+    uint32_t kind;
+    unsigned long long bits;
+    if (a.use_constant && lo == hi) {
+      kind = FLACENC_HIP_KIND_CONSTANT;
+      bits = 8ull + bps;
+    } else if (lpc_ok && a.lpc_params[sf].subframe_bits < baseline) {
+      kind = FLACENC_HIP_KIND_LPC;
+      bits = a.lpc_params[sf].subframe_bits;
+    } else if (have_fixed && fixed_bits < verbatim_bits) {
+      kind = FLACENC_HIP_KIND_FIXED;
+      bits = fixed_bits;
+    } else {
+      kind = FLACENC_HIP_KIND_VERBATIM;
+      bits = verbatim_bits;
+    }
+    skind = kind;
+    out->kind = (uint8_t)kind;
+    out->pad[0] = out->pad[1] = out->pad[2] = 0;
+    out->dc_offset = kind == FLACENC_HIP_KIND_CONSTANT ? lo : 0;
+    out->bits = bits;
+  }
+  __syncthreads();
+  const uint32_t kind = skind;
+  uint32_t* rec = reinterpret_cast<uint32_t*>(&out->params);
+  const uint32_t* src_rec = kind == FLACENC_HIP_KIND_LPC     ? reinterpret_cast<const uint32_t*>(a.lpc_params + sf)
+                            : kind == FLACENC_HIP_KIND_FIXED ? reinterpret_cast<const uint32_t*>(a.fixed_params + sf)
+                                                             : nullptr;
+  for (int i = tid; i < (int)(sizeof(flacenc_hip_subframe_params) / 4); i += kThreads) rec[i] = src_rec ? src_rec[i] : 0u;
+  const int32_t* src = kind == FLACENC_HIP_KIND_LPC     ? a.lpc_residual + sf * a.cand_stride
+                       : kind == FLACENC_HIP_KIND_FIXED ? a.fixed_residual + sf * a.cand_stride
+                                                        : nullptr;
+  int32_t* dst = a.residual + sf * a.residual_stride;
+  for (int t = tid; t < n; t += kThreads) dst[t] = src ? src[t] : 0;
+}
+
 }  // namespace
+
+hipError_t launch_channel_decide(const ChannelDecideArgs& a, hipStream_t stream) {
+  if (a.n_subframes == 0) return hipSuccess;
+  hipLaunchKernelGGL(channel_decide_kernel, dim3(a.n_subframes), dim3(kThreads), 0, stream, a);
+  return hipGetLastError();
+}
 
 hipError_t launch_frame_decide(const FrameDecideArgs& a, hipStream_t stream) {
   if (a.n_frames == 0) return hipSuccess;

@@ -31,5 +31,26 @@ struct FrameDecideArgs {
 
 hipError_t launch_frame_decide(const FrameDecideArgs& args, hipStream_t stream);
 
+// Independent(channels) frames (mono / multi-channel, coding.rs:537-541): one encode_subframe per
+// channel, no stereo decision.  Subframe k = f*channels + c everywhere.
+struct ChannelDecideArgs {
+  const int32_t* samples;  // device; subframe k at samples + k*stride
+  size_t stride;
+  uint32_t block_size;
+  uint32_t n_subframes;
+  uint32_t bits_per_sample;
+  uint32_t use_constant, use_fixed, use_lpc;
+  const flacenc_hip_subframe_params* lpc_params;
+  const int32_t* lpc_residual;
+  const flacenc_hip_subframe_params* fixed_params;
+  const int32_t* fixed_residual;
+  const unsigned long long* fixed_keys;
+  size_t cand_stride;
+  flacenc_hip_channel_result* results;  // out, [n_subframes]
+  int32_t* residual;                    // out; subframe k at k*residual_stride
+  size_t residual_stride;
+};
+hipError_t launch_channel_decide(const ChannelDecideArgs& args, hipStream_t stream);
+
 }  // namespace flacenc_hip
 #endif

@@ -75,26 +75,65 @@ __device__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* scratch, int tid,
   return base + incl - v;
 }
 
-__global__ void __launch_bounds__(kPackThreads) frame_pack_kernel(FramePackArgs a) {
+// What the packer needs to know about one frame, for the two kinds of decision records.
+struct StereoView {  // flacenc_hip_stereo_frame_result: 2 subframes, roles L / R / M / S
+  const flacenc_hip_stereo_frame_result* fr;
+  const int32_t* l;
+  const int32_t* r;
+  uint32_t bps0;
+  size_t row0;
+  __device__ uint32_t nsub() const { return 2u; }
+  __device__ uint32_t channel_tag() const {  // ChannelAssignment::write, bitrepr.rs:329-356
+    return fr->channel_assignment == 0 ? 1u : 7u + fr->channel_assignment;
+  }
+  __device__ uint32_t kind(int c) const { return fr->kind[c]; }
+  __device__ uint32_t bps(int c) const { return bps0 + (fr->role[c] == 3 ? 1u : 0u); }
+  __device__ unsigned long long bits(int c) const { return fr->bits[fr->role[c]]; }
+  __device__ int32_t dc(int c) const { return fr->dc_offset[c]; }
+  __device__ const flacenc_hip_subframe_params* rec(int c) const { return &fr->lpc[c]; }
+  __device__ size_t residual_row(int c) const { return row0 + (size_t)c; }
+  __device__ int32_t sample(int c, int t) const {  // the role's input sample (coding.rs:476-484 for M / S)
+    const uint32_t role = fr->role[c];
+    const int32_t lv = l[t];
+    if (role == 0u) return lv;
+    const int32_t rv = r[t];
+    if (role == 1u) return rv;
+    return role == 2u ? ((lv + rv) >> 1) : (lv - rv);
+  }
+};
+struct ChannelView {  // flacenc_hip_channel_result x channels: Independent(n)
+  const flacenc_hip_channel_result* ch;
+  const int32_t* x;
+  size_t stride;
+  uint32_t nch, bps0;
+  size_t row0;
+  __device__ uint32_t nsub() const { return nch; }
+  __device__ uint32_t channel_tag() const { return nch - 1u; }
+  __device__ uint32_t kind(int c) const { return ch[c].kind; }
+  __device__ uint32_t bps(int) const { return bps0; }
+  __device__ unsigned long long bits(int c) const { return ch[c].bits; }
+  __device__ int32_t dc(int c) const { return ch[c].dc_offset; }
+  __device__ const flacenc_hip_subframe_params* rec(int c) const { return &ch[c].params; }
+  __device__ size_t residual_row(int c) const { return row0 + (size_t)c; }
+  __device__ int32_t sample(int c, int t) const { return x[(size_t)c * stride + t]; }
+};
+
+template <class View>
+__device__ __forceinline__ void frame_pack_body(const FramePackArgs& a, const View& view, uint32_t f) {
   extern __shared__ __attribute__((aligned(16))) uint32_t words[];
   __shared__ uint32_t scan_scratch[4];
   __shared__ uint32_t crc_part[kPackThreads / 64];
-  __shared__ uint8_t rice_p[2][FLACENC_HIP_MAX_RICE_PARTITIONS];
+  __shared__ uint8_t rice_p[FLACENC_HIP_MAX_RICE_PARTITIONS];
   __shared__ uint16_t crc_tab[256];  // CRC-16 of the single byte i
   const int tid = threadIdx.x;
   crc_tab[tid] = (uint16_t)crc16_byte(0u, (uint32_t)tid);
-  const uint32_t f = blockIdx.x;
   const int n = (int)a.block_size;
-  const flacenc_hip_stereo_frame_result* fr = a.results + f;
 
   for (uint32_t i = tid; i < a.lds_words / 4u; i += kPackThreads)
     reinterpret_cast<int4*>(words)[i] = make_int4(0, 0, 0, 0);  // lds_words is a multiple of 4
-  for (int i = tid; i < 2 * FLACENC_HIP_MAX_RICE_PARTITIONS; i += kPackThreads)
-    rice_p[i >> 8][i & 255] = fr->lpc[i >> 8].rice_params[i & 255];
   __syncthreads();
 
   // ---- FrameHeader::write, bitrepr.rs:373-419 (fixed blocking, FrameOffset::Frame) ----
-  const uint32_t assignment = fr->channel_assignment;
   const uint32_t frame_number = a.first_frame_number + f * a.frame_number_step;
   uint32_t utf8_len;
   {
@@ -105,7 +144,7 @@ __global__ void __launch_bounds__(kPackThreads) frame_pack_kernel(FramePackArgs 
   if (tid == 0) {
     uint8_t hdr[16];
     uint32_t hn = 0;
-    const uint32_t channel_tag = assignment == 0 ? 1u : 7u + assignment;  // Independent(2) -> 1
+    const uint32_t channel_tag = view.channel_tag();
     hdr[hn++] = 0xFF;
     hdr[hn++] = 0xF8;
     hdr[hn++] = (uint8_t)(a.header_mid >> 8);
@@ -127,31 +166,26 @@ __global__ void __launch_bounds__(kPackThreads) frame_pack_kernel(FramePackArgs 
     for (uint32_t i = 0; i < hn; ++i) put_bits(words, 8u * i, hdr[i], 8u);
   }
 
-  // ---- the two subframes ----
-  const int32_t* __restrict__ lsrc = a.frames + (size_t)(2u * f) * a.stride;
-  const int32_t* __restrict__ rsrc = lsrc + a.stride;
+  // ---- the subframes ----
   uint32_t sub_base = header_bytes * 8u;
-  for (int c = 0; c < 2; ++c) {
-    const uint32_t kind = fr->kind[c];
-    const uint32_t role = fr->role[c];
-    const uint32_t bps = a.bits_per_sample + (role == 3u ? 1u : 0u);
-    const uint32_t sub_bits = (uint32_t)fr->bits[role];
+  const int nsub = (int)view.nsub();
+  for (int c = 0; c < nsub; ++c) {
+    const uint32_t kind = view.kind(c);
+    const uint32_t bps = view.bps(c);
+    const uint32_t sub_bits = (uint32_t)view.bits(c);
     const uint32_t bps_mask = bps >= 32u ? 0xFFFFFFFFu : ((1u << bps) - 1u);
-    auto sample = [&](int t) -> int32_t {  // the role's input sample (coding.rs:476-484 for M / S)
-      const int32_t l = lsrc[t];
-      if (role == 0u) return l;
-      const int32_t r = rsrc[t];
-      if (role == 1u) return r;
-      return role == 2u ? ((l + r) >> 1) : (l - r);
-    };
+    auto sample = [&](int t) -> int32_t { return view.sample(c, t); };
     if (kind == FLACENC_HIP_KIND_CONSTANT) {  // bitrepr.rs:449-454
-      if (tid == 0) put_bits(words, sub_base + 8u, (uint32_t)fr->dc_offset[c] & bps_mask, bps);
+      if (tid == 0) put_bits(words, sub_base + 8u, (uint32_t)view.dc(c) & bps_mask, bps);
     } else if (kind == FLACENC_HIP_KIND_VERBATIM) {  // bitrepr.rs:463-470
       if (tid == 0) put_bits(words, sub_base, 0x02u, 8u);
       for (int t = tid; t < n; t += kPackThreads)
         put_bits(words, sub_base + 8u + (uint32_t)t * bps, (uint32_t)sample(t) & bps_mask, bps);
     } else {
-      const flacenc_hip_subframe_params* rec = &fr->lpc[c];
+      const flacenc_hip_subframe_params* rec = view.rec(c);
+      __syncthreads();  // the previous subframe is done with rice_p
+      rice_p[tid] = rec->rice_params[tid];
+      __syncthreads();
       const uint32_t order = rec->order;
       const uint32_t precision = rec->precision;
       // FixedLpc::write bitrepr.rs:479-487 / Lpc::write :501-527 up to the residual
@@ -173,11 +207,11 @@ __global__ void __launch_bounds__(kPackThreads) frame_pack_kernel(FramePackArgs 
       const uint32_t nparts = 1u << porder;
       const uint32_t part_len = (uint32_t)n >> porder;
       uint32_t rice2 = 0;
-      for (uint32_t q = tid; q < nparts; q += kPackThreads) rice2 |= rice_p[c][q] > 14 ? 1u : 0u;
+      for (uint32_t q = tid; q < nparts; q += kPackThreads) rice2 |= rice_p[q] > 14 ? 1u : 0u;
       rice2 = __syncthreads_or((int)rice2) ? 1u : 0u;
       const uint32_t pbits = rice2 ? 5u : 4u;
       if (tid == 192) put_bits(words, sub_base + head_bits, (rice2 << 4) | porder, 6u);
-      const int32_t* __restrict__ e = a.residual + (size_t)(2u * f + (uint32_t)c) * a.residual_stride;
+      const int32_t* __restrict__ e = a.residual + view.residual_row(c) * a.residual_stride;
       // contiguous slice of samples per thread; pass 1 counts its bits, pass 2 writes them.
       // Up to 16 samples per thread (blocks <= 4096) are held in registers as zig-zag codes.
       const int per = (n + kPackThreads - 1) / kPackThreads;
@@ -204,12 +238,12 @@ __global__ void __launch_bounds__(kPackThreads) frame_pack_kernel(FramePackArgs 
       const uint32_t q_lo = (uint32_t)t_lo / part_len;
       // walks the slice once; `emit(t, u, p, starts)` sees every coded sample in order
       auto walk = [&](auto&& emit) {
-        uint32_t q = q_lo, next = (q_lo + 1u) * part_len, p = rice_p[c][q_lo & 255u];
+        uint32_t q = q_lo, next = (q_lo + 1u) * part_len, p = rice_p[q_lo & 255u];
         auto step = [&](uint32_t t, uint32_t u) {
           if (t == next) {
             ++q;
             next += part_len;
-            p = rice_p[c][q & 255u];
+            p = rice_p[q & 255u];
           }
           if (t >= order) emit(u, p, q == 0u ? t == order : t == next - part_len);  // max(warmup, offset)
         };
@@ -285,15 +319,43 @@ __global__ void __launch_bounds__(kPackThreads) frame_pack_kernel(FramePackArgs 
   }
 }
 
+__global__ void __launch_bounds__(kPackThreads) frame_pack_kernel(FramePackArgs a) {
+  const uint32_t f = blockIdx.x;
+  StereoView v;
+  v.fr = a.results + f;
+  v.l = a.frames + (size_t)(2u * f) * a.stride;
+  v.r = v.l + a.stride;
+  v.bps0 = a.bits_per_sample;
+  v.row0 = (size_t)(2u * f);
+  frame_pack_body(a, v, f);
+}
+
+__global__ void __launch_bounds__(kPackThreads) channel_pack_kernel(FramePackArgs a) {
+  const uint32_t f = blockIdx.x;
+  ChannelView v;
+  v.ch = a.chan_results + (size_t)f * a.channels;
+  v.x = a.frames + (size_t)f * a.channels * a.stride;
+  v.stride = a.stride;
+  v.nch = a.channels;
+  v.bps0 = a.bits_per_sample;
+  v.row0 = (size_t)f * a.channels;
+  frame_pack_body(a, v, f);
+}
+
 // Frame::count_bits / 8 (bitrepr.rs:275-287) from the decision records alone
 __global__ void frame_lengths_kernel(FramePackArgs a) {
   const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
   if (f >= a.n_frames) return;
-  const flacenc_hip_stereo_frame_result* fr = a.results + f;
   const uint32_t frame_number = a.first_frame_number + f * a.frame_number_step;
   const uint32_t code_bits = frame_number ? 32u - (uint32_t)__builtin_clz(frame_number) : 0u;
   const uint32_t utf8_len = code_bits <= 7 ? 1u : 1u + (code_bits - 2u) / 5u;
-  const unsigned long long bits = 8ull * (4u + utf8_len + a.extra_len + 1u) + fr->bits[fr->role[0]] + fr->bits[fr->role[1]];
+  unsigned long long bits = 8ull * (4u + utf8_len + a.extra_len + 1u);
+  if (a.chan_results) {
+    for (uint32_t c = 0; c < a.channels; ++c) bits += a.chan_results[(size_t)f * a.channels + c].bits;
+  } else {
+    const flacenc_hip_stereo_frame_result* fr = a.results + f;
+    bits += fr->bits[fr->role[0]] + fr->bits[fr->role[1]];
+  }
   a.out_len[f] = (uint32_t)((bits + 7ull) >> 3) + 2u;
 }
 
@@ -303,6 +365,11 @@ hipError_t launch_frame_lengths(const FramePackArgs& a, hipStream_t stream) {
   if (a.n_frames == 0) return hipSuccess;
   hipLaunchKernelGGL(frame_lengths_kernel, dim3((a.n_frames + 255) / 256), dim3(256), 0, stream, a);
   return hipGetLastError();
+}
+
+size_t frame_bytes_bound(uint32_t channels, uint32_t block_size, uint32_t bits_per_sample) {
+  const size_t bits = static_cast<size_t>(channels) * (8 + static_cast<size_t>(block_size) * bits_per_sample);
+  return 15 + (bits + 7) / 8 + 2;
 }
 
 size_t stereo_frame_bytes_bound(uint32_t block_size, uint32_t bits_per_sample) {
@@ -322,7 +389,18 @@ hipError_t launch_frame_pack(const FramePackArgs& a, hipStream_t stream) {
     if (err != hipSuccess) return err;
     configured = smem;
   }
-  hipLaunchKernelGGL(frame_pack_kernel, dim3(a.n_frames), dim3(kPackThreads), smem, stream, a);
+  if (a.chan_results) {
+    static size_t configured_ch = 0;
+    if (smem > configured_ch) {
+      hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(channel_pack_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(smem));
+      if (err != hipSuccess) return err;
+      configured_ch = smem;
+    }
+    hipLaunchKernelGGL(channel_pack_kernel, dim3(a.n_frames), dim3(kPackThreads), smem, stream, a);
+  } else {
+    hipLaunchKernelGGL(frame_pack_kernel, dim3(a.n_frames), dim3(kPackThreads), smem, stream, a);
+  }
   return hipGetLastError();
 }
 

@@ -15,7 +15,9 @@ struct FramePackArgs {
   size_t stride;
   uint32_t block_size;
   uint32_t n_frames;
-  const flacenc_hip_stereo_frame_result* results;  // device, [n_frames]
+  const flacenc_hip_stereo_frame_result* results;  // device, [n_frames] (2-channel frames), or
+  const flacenc_hip_channel_result* chan_results;  // device, [n_frames * channels] (Independent frames)
+  uint32_t channels;                               // used with chan_results
   const int32_t* residual;                         // device; output channel c of frame f at (2f + c)*residual_stride
   size_t residual_stride;
   uint32_t bits_per_sample;
@@ -38,6 +40,7 @@ struct FramePackArgs {
 
 // worst-case frame length in bytes for a 2-channel frame (both subframes Verbatim, one a side channel)
 size_t stereo_frame_bytes_bound(uint32_t block_size, uint32_t bits_per_sample);
+size_t frame_bytes_bound(uint32_t channels, uint32_t block_size, uint32_t bits_per_sample);
 hipError_t launch_frame_pack(const FramePackArgs& args, hipStream_t stream);
 // only results, n_frames, extra_len, first_frame_number, frame_number_step, out_len are read
 hipError_t launch_frame_lengths(const FramePackArgs& args, hipStream_t stream);

@@ -311,6 +311,47 @@ int flacenc_hip_pack_stereo_frames_async(flacenc_hip_handle* h, const int32_t* f
                                          uint32_t first_frame_number, uint32_t frame_number_step, uint8_t* out,
                                          size_t out_stride, uint32_t* out_len, void* stream);
 
+/* ---- encode_frame / Frame::write for Independent(channels) frames: mono and multi-channel -- */
+/* What encode_subframe (src/coding.rs:384-418) decided for one channel of an Independent(n) frame
+ * (encode_frame for channels != 2, src/coding.rs:537-541): the SubFrame variant, the Constant's
+ * value, SubFrame::count_bits and the predictor record when kind == LPC or FIXED.  368 bytes. */
+typedef struct flacenc_hip_channel_result {
+  uint8_t kind; /* FLACENC_HIP_KIND_* */
+  uint8_t pad[3];
+  int32_t dc_offset;
+  uint64_t bits;
+  flacenc_hip_subframe_params params;
+} flacenc_hip_channel_result;
+
+/*
+ * encode_frame for frames of 1..8 independent channels (no stereo decorrelation: 2-channel
+ * streams should use flacenc_hip_encode_stereo_frames).  `frames` is batched FrameBuf layout:
+ * channel c of frame f at frames + (f*channels + c)*stride; results and residual rows use the same
+ * index f*channels + c.  Candidates are computed as by flacenc_hip_qlpc_batch /
+ * flacenc_hip_fixed_lpc_batch (handle scratch), then encode_subframe's choice runs on the GPU.
+ */
+int flacenc_hip_encode_frames(flacenc_hip_handle* h, const flacenc_hip_frame_config* cfg,
+                              const int32_t* frames, size_t n_frames, uint32_t channels, uint32_t block_size,
+                              size_t stride, uint32_t bits_per_sample, flacenc_hip_channel_result* results,
+                              int32_t* residual, size_t residual_stride, int memory_kind);
+int flacenc_hip_encode_frames_async(flacenc_hip_handle* h, const flacenc_hip_frame_config* cfg,
+                                    const int32_t* frames, size_t n_frames, uint32_t channels,
+                                    uint32_t block_size, size_t stride, uint32_t bits_per_sample,
+                                    flacenc_hip_channel_result* results, int32_t* residual,
+                                    size_t residual_stride, void* stream);
+/* Frame::write for those frames; arguments as flacenc_hip_pack_stereo_frames. */
+size_t flacenc_hip_frame_bytes_bound(uint32_t channels, uint32_t block_size, uint32_t bits_per_sample);
+int flacenc_hip_pack_frames(flacenc_hip_handle* h, const int32_t* frames, size_t n_frames, uint32_t channels,
+                            uint32_t block_size, size_t stride, const flacenc_hip_channel_result* results,
+                            const int32_t* residual, size_t residual_stride, uint32_t bits_per_sample,
+                            uint32_t sample_rate, uint32_t first_frame_number, uint32_t frame_number_step,
+                            uint8_t* out, size_t out_stride, uint32_t* out_len, int memory_kind);
+int flacenc_hip_pack_frames_async(flacenc_hip_handle* h, const int32_t* frames, size_t n_frames, uint32_t channels,
+                                  uint32_t block_size, size_t stride, const flacenc_hip_channel_result* results,
+                                  const int32_t* residual, size_t residual_stride, uint32_t bits_per_sample,
+                                  uint32_t sample_rate, uint32_t first_frame_number, uint32_t frame_number_step,
+                                  uint8_t* out, size_t out_stride, uint32_t* out_len, void* stream);
+
 /* Frame::count_bits / 8 (src/component/bitrepr.rs:275-287) of every frame from the decision records
  * alone: exactly the out_len flacenc_hip_pack_stereo_frames will produce.  Device pointers.  These
  * 4 bytes per frame are all an ordered multi-GPU gather has to exchange to place every frame in

@@ -659,6 +659,22 @@ def write_subframe(kind, bps, n, **kw):
     return bytes(out[:(bits + 7) // 8]), int(bits)
 
 
+def write_frame(block_size, channel_assignment, bits_per_sample, sample_rate, frame_number, subframes) -> bytes:
+    """Frame::write (bitrepr.rs:289-319); `subframes` = list of dicts with the _desc keywords
+    (kind, bps, samples, dc_offset, order, shift, precision, coefs, rice_order, rice_params, residual)."""
+    keep, descs = [], (SubframeDesc * len(subframes))()
+    for i, sf in enumerate(subframes):
+        d, k = _desc(n=block_size, **sf)
+        descs[i] = d
+        keep.append(k)
+    cap = len(subframes) * (block_size * 4 + 16) + 64
+    out = np.zeros(cap, np.uint8)
+    ln = lib().orc_write_frame(block_size, channel_assignment, len(subframes), bits_per_sample, sample_rate,
+                               frame_number, descs, _p(out, C.c_uint8), cap)
+    assert ln <= cap
+    return bytes(out[:ln])
+
+
 def write_stereo_frame(result, l, r, bps, sample_rate, frame_number, residual0, residual1) -> bytes:
     """Frame::write (bitrepr.rs:289-319) of the frame one FRAME_RESULT_DTYPE record describes."""
     rec = np.ascontiguousarray(result.reshape(1) if hasattr(result, "reshape") else np.array([result]))

@@ -822,6 +822,55 @@ def test_encode_stereo_frames_any_shape(handle, n, bps, order, kw):
             assert parsed["block_size"] == n and np.array_equal(parsed["channels"], base[f]), f
 
 
+@pytest.mark.parametrize("channels,n,bps,order,use_fixed", [
+    (1, 4096, 16, 8, True), (8, 4096, 16, 10, True), (3, 1152, 16, 12, True), (5, 4608, 24, 8, False),
+    (1, 300, 8, 4, True),
+])
+def test_encode_and_pack_independent_channel_frames(handle, channels, n, bps, order, use_fixed):
+    """Mono / multi-channel streams (encode_frame with Independent(n), coding.rs:537-541):
+    flacenc_hip_encode_frames == encode_subframe per channel, flacenc_hip_pack_frames == Frame::write,
+    both against the oracle, and the bytes parse back to the input (BASELINE config 4 is the 8-channel case)."""
+    import flac_parse
+    x = _capi.sigen_frames(4, channels, n, bps, 150.0, 0.5, 0.04, seed=channels * 1000 + n)
+    half = 1 << (bps - 2)
+    x[1, 0] = (np.arange(n) // 9) % half          # FixedLpc territory
+    x[2, channels - 1] = -5                        # Constant
+    x[3, 0] = util.quantize(util.noise(4, n, 0.999), bps)   # Verbatim
+    cfg = _capi.make_frame_config(gpu_cfg(order), use_fixed=use_fixed)
+    res, resid = handle.encode_frames(x, bps, cfg)
+    ocfg = orc.make_frame_config(orc_cfg(order, acorr=orc.ACORR_CANONICAL), use_fixed=use_fixed,
+                                 fixed=orc.make_fixed_config(sum_mode=orc.SUMABS_CANONICAL))
+    packed = handle.pack_frames(x, res, resid, bps, 44100, 70, 1)
+    kinds = set()
+    for f in range(x.shape[0]):
+        subs = []
+        for c in range(channels):
+            w = orc.encode_subframe(x[f, c], bps, ocfg)
+            g = res[f, c]
+            assert int(g["kind"]) == w["kind"] and int(g["bits"]) == w["bits"], (f, c)
+            kinds.add(w["kind"])
+            p = g["params"]
+            if w["kind"] >= 2:
+                src = w["lpc"] if w["kind"] == 3 else w["fixed"]
+                order_w = int(src.qp.order) if w["kind"] == 3 else int(src.order)
+                assert int(p["order"]) == order_w and int(p["rice_order"]) == int(src.rice_order)
+                assert int(p["subframe_bits"]) == int(src.subframe_bits) == w["bits"]
+                assert np.array_equal(resid[f, c], w["residual"]), (f, c)
+            else:
+                assert not resid[f, c].any()
+            subs.append(dict(kind=int(g["kind"]), bps=bps, samples=x[f, c], dc_offset=int(g["dc_offset"]),
+                             order=int(p["order"]), shift=int(p["shift"]), precision=int(p["precision"]),
+                             coefs=p["coefs"], rice_order=int(p["rice_order"]), rice_params=p["rice_params"],
+                             residual=resid[f, c]))
+        want = orc.write_frame(n, 0, bps, 44100, 70 + f, subs)
+        assert packed[f] == want, (f, len(packed[f]), len(want))
+        got = flac_parse.parse_frame(packed[f], stream_bps=bps)
+        assert got["channel_tag"] == channels - 1 and got["number"] == 70 + f
+        assert np.array_equal(got["channels"], x[f]), f
+    if n >= 1152:
+        assert {0, 1, 3} <= kinds and (2 in kinds or not use_fixed)
+
+
 def test_encode_stereo_frames_rejects_bad_config(handle):
     x = np.zeros((2, 2, 4096), np.int32)
     with pytest.raises(_capi.FlacencHipError) as ei:

@@ -685,6 +685,71 @@ component::Stream encode_with_fixed_block_size(const config::Encoder& config, So
       if (rc != FLACENC_HIP_ERR_UNSUPPORTED)
         throw error::EncodeError(error::EncodeError::Device, flacenc_hip_last_error(gpu.get()));
     }
+    // 2a'. mono / multi-channel: encode_frame for Independent(n) on the GPU (flacenc_hip_encode_frames)
+    //      and the frames' bytes (flacenc_hip_pack_frames)
+    if (fused_ok && !stereo) {
+      std::vector<int32_t> staged(nf * nch * n);
+      for (size_t f = 0; f < nf; ++f)
+        for (size_t c = 0; c < nch; ++c)
+          std::memcpy(&staged[(f * nch + c) * n], bufs[f0 + f].channel_slice(c), n * sizeof(int32_t));
+      flacenc_hip_frame_config fc{};
+      fc.qlpc = abi_cfg;
+      fc.use_constant = sc.use_constant;
+      fc.use_fixed = sc.use_fixed;
+      fc.use_lpc = sc.use_lpc;
+      fc.fixed_max_order = static_cast<uint32_t>(sc.fixed.max_order);
+      fc.fixed_order_sel = sc.fixed.order_sel.type == config::OrderSel::BitCount ? FLACENC_HIP_ORDERSEL_BITCOUNT
+                                                                                 : FLACENC_HIP_ORDERSEL_APPROXENT;
+      fc.fixed_partitions = static_cast<uint32_t>(sc.fixed.order_sel.partitions);
+      std::vector<flacenc_hip_channel_result> cr(nf * nch);
+      std::vector<int32_t> resid2(nf * nch * n);
+      const int rc = flacenc_hip_encode_frames(gpu.get(), &fc, staged.data(), nf, static_cast<uint32_t>(nch),
+                                               static_cast<uint32_t>(n), n, static_cast<uint32_t>(bps), cr.data(),
+                                               resid2.data(), n, FLACENC_HIP_MEM_HOST);
+      if (rc == FLACENC_HIP_OK) {
+        const size_t ostride = flacenc_hip_frame_bytes_bound(static_cast<uint32_t>(nch), static_cast<uint32_t>(n),
+                                                             static_cast<uint32_t>(bps));
+        std::vector<uint8_t> packed(nf * ostride);
+        std::vector<uint32_t> packed_len(nf);
+        const int prc = flacenc_hip_pack_frames(gpu.get(), staged.data(), nf, static_cast<uint32_t>(nch),
+                                                static_cast<uint32_t>(n), n, cr.data(), resid2.data(), n,
+                                                static_cast<uint32_t>(bps), static_cast<uint32_t>(src.sample_rate()),
+                                                static_cast<uint32_t>(f0), 1, packed.data(), ostride,
+                                                packed_len.data(), FLACENC_HIP_MEM_HOST);
+        if (prc != FLACENC_HIP_OK && prc != FLACENC_HIP_ERR_UNSUPPORTED)
+          throw error::EncodeError(error::EncodeError::Device, flacenc_hip_last_error(gpu.get()));
+        for (size_t f = 0; f < nf; ++f) {
+          component::Frame frame;
+          frame.frame_number = static_cast<uint32_t>(f0 + f);
+          frame.block_size = n;
+          for (size_t c = 0; c < nch; ++c) {
+            const flacenc_hip_channel_result& r = cr[f * nch + c];
+            const int32_t* sig = bufs[f0 + f].channel_slice(c);
+            const uint8_t b = static_cast<uint8_t>(bps);
+            if (r.kind == FLACENC_HIP_KIND_CONSTANT) {
+              frame.subframes.push_back(component::Constant{n, r.dc_offset, b});
+            } else if (r.kind == FLACENC_HIP_KIND_VERBATIM) {
+              frame.subframes.push_back(component::Verbatim{std::vector<int32_t>(sig, sig + n), b});
+            } else if (r.kind == FLACENC_HIP_KIND_FIXED) {
+              frame.subframes.push_back(detail::make_fixed_lpc(r.params, &resid2[(f * nch + c) * n], sig, n, b));
+            } else {
+              if (r.params.status != FLACENC_HIP_SUBFRAME_OK)
+                throw std::runtime_error("LPC analysis reported a non-finite result (lpc.rs:786)");
+              frame.subframes.push_back(detail::make_lpc(r.params, &resid2[(f * nch + c) * n], sig, n, b));
+            }
+          }
+          if (prc == FLACENC_HIP_OK)
+            frame.precomputed_bitstream.assign(packed.begin() + f * ostride, packed.begin() + f * ostride + packed_len[f]);
+          stream.add_frame(std::move(frame));
+        }
+        f0 = f1;
+        continue;
+      }
+      if (rc == FLACENC_HIP_ERR_BAD_CONFIG)
+        throw error::EncodeError(error::EncodeError::Config, flacenc_hip_last_error(gpu.get()));
+      if (rc != FLACENC_HIP_ERR_UNSUPPORTED)
+        throw error::EncodeError(error::EncodeError::Device, flacenc_hip_last_error(gpu.get()));
+    }
     // 2b. the LPC candidates of every channel (stereo: L, R, M, S) in one batch
     if (use_gpu) {
       std::vector<int32_t> staged(nf * nch * n);

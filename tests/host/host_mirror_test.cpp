@@ -180,16 +180,27 @@ int main(int argc, char** argv) {
         std::fclose(fo);
       }
     }
-    // a mono stream is analysed on the GPU but its frames have no GPU-made bytes
-    auto mono = source::MemSource::from_samples(make_signal(1, 9000, 16, 7), 1, 16, 44100);
-    component::Stream ms = encode_with_fixed_block_size(def, mono, 4096, gpu);
-    bool thrown = false;
-    try {
-      ms.to_bytes();
-    } catch (const std::runtime_error&) {
-      thrown = true;
+    // mono and multi-channel streams go through flacenc_hip_encode_frames / pack_frames
+    for (size_t channels : {size_t(1), size_t(3)}) {
+      const std::vector<int32_t> sig = make_signal(channels, 9000, 16, 7 + channels);
+      auto msrc = source::MemSource::from_samples(sig, channels, 16, 48000);
+      component::Stream ms = encode_with_fixed_block_size(def, msrc, 4096, gpu);
+      std::vector<uint8_t> mb = ms.to_bytes();
+      CHECK(mb.size() > 42);
+      if (argc > 1) {
+        const std::string base = std::string(argv[1]) + "/mirror" + std::to_string(channels);
+        FILE* fo = std::fopen((base + ".flac").c_str(), "wb");
+        if (fo) {
+          std::fwrite(mb.data(), 1, mb.size(), fo);
+          std::fclose(fo);
+        }
+        fo = std::fopen((base + ".pcm").c_str(), "wb");
+        if (fo) {
+          std::fwrite(sig.data(), sizeof(int32_t), sig.size(), fo);
+          std::fclose(fo);
+        }
+      }
     }
-    CHECK(thrown);
   }
   if (failures) {
     std::printf("FAILED: %d\n", failures);

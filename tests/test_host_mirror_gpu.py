@@ -55,3 +55,14 @@ def test_host_mirror_integrity_on_gpu(tmp_path):
         assert np.array_equal(got["channels"], pcm[t:t + n].T), number
         pos, t, number = pos + got["length"], t + n, number + 1
     assert t == len(pcm) == 16123 and number == 4   # three full blocks + the 3835-sample tail
+    for channels in (1, 3):   # mono / 3-channel streams: Independent(n) frames incl. an 808-sample tail
+        data = open(os.path.join(str(tmp_path), f"mirror{channels}.flac"), "rb").read()
+        pcm = np.fromfile(os.path.join(str(tmp_path), f"mirror{channels}.pcm"), np.int32).reshape(-1, channels)
+        pos, t, number = 42, 0, 0
+        while pos < len(data):
+            got = flac_parse.parse_frame(data[pos:])
+            assert got["number"] == number and got["channel_tag"] == channels - 1 and got["sample_rate"] == 48000
+            n = got["block_size"]
+            assert np.array_equal(got["channels"], pcm[t:t + n].T), (channels, number)
+            pos, t, number = pos + got["length"], t + n, number + 1
+        assert t == len(pcm) == 9000 and number == 3

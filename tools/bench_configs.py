@@ -54,3 +54,40 @@ run("config4: 4096 x 16b 8-channel, order 10 (plain)", 2048, 8, 4096, 16, 10, Fa
 run("config5: 16384 x 24b stereo, order 24 (generic kernel)", 1024, 2, 16384, 24, 24, True)
 run("config5: 16384 x 24b stereo, order 32 (generic kernel)", 1024, 2, 16384, 24, 32, True)
 run("ragged: 4608 x 16b stereo, order 10 (generic kernel)", 4096, 2, 4608, 16, 10, True)
+
+
+def run_frames(name, frames, ch, n, bps, order):
+    """Frame-level pipeline for Independent(ch) frames: encode_frames (+ fixed-LPC) and pack_frames."""
+    host = _capi.sigen_frames(frames, ch, n, bps, 200.0, 0.4, 0.1, seed=7)
+    x = torch.from_numpy(host).to(dev)
+    res = torch.empty((frames * ch, 368), dtype=torch.uint8, device=dev)
+    resid = torch.empty((frames * ch, n), dtype=torch.int32, device=dev)
+    stride = int(h._lib.flacenc_hip_frame_bytes_bound(ch, n, bps))
+    out = torch.empty((frames, stride), dtype=torch.uint8, device=dev)
+    lens = torch.zeros(frames, dtype=torch.int32, device=dev)
+    cfg = _capi.make_frame_config(_capi.make_config(lpc_order=order), use_fixed=True)
+
+    def go():
+        h._check(h._lib.flacenc_hip_encode_frames_async(h._h, cfg, x.data_ptr(), frames, ch, n, n, bps, res.data_ptr(),
+                                                        resid.data_ptr(), n, None))
+        h._check(h._lib.flacenc_hip_pack_frames_async(h._h, x.data_ptr(), frames, ch, n, n, res.data_ptr(),
+                                                      resid.data_ptr(), n, bps, 44100, 0, 1, out.data_ptr(), stride,
+                                                      lens.data_ptr(), None))
+
+    for _ in range(2):
+        go()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        go()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 5
+    inp = frames * ch * n
+    print(f"{name:52s} {ms:8.3f} ms  {inp / ms / 1e3:9.1f} Msamples/s input, PCM -> frame bytes "
+          f"({int(lens.sum().item()) / (inp * bps / 8):.3f} of PCM size)")
+
+
+run_frames("config4: 4096 x 16b 8-channel, default config, frames", 2048, 8, 4096, 16, 10)
+run_frames("mono: 4096 x 16b, default config, frames", 8192, 1, 4096, 16, 10)

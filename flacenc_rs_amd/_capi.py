@@ -13,7 +13,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libflacenc_hip.so")
+# FLACENC_HIP_LIB: development aid for A/B timing of two builds on one GPU box; never a fallback
+LIB_PATH = os.environ.get("FLACENC_HIP_LIB") or os.path.join(_HERE, "libflacenc_hip.so")
 
 OK = 0
 ERR_BAD_CONFIG = -1

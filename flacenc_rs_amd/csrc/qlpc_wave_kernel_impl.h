@@ -1102,9 +1102,14 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
     __syncthreads();
     {
       int32_t* __restrict__ dst0 = a.residual + (size_t)(blk * 2u) * a.residual_stride;
+      // (FIXED: the thread index is laundered so that these addresses are recomputed here instead
+      // of being kept alive -- and, at 256 VGPRs, spilled -- from the identical expressions of the
+      // load phase; the variants with registers to spare are 1.4 % faster keeping them)
+      int tid_out = tid;
+      if (FIXED) asm volatile("" : "+v"(tid_out));
 #pragma unroll
       for (int it = 0; it < 8; ++it) {
-        const int q = tid + it * 256;
+        const int q = tid_out + it * 256;
         const int ch = q >> 10;
         const int t = (q & 1023) << 2;
         const int4 v = *reinterpret_cast<const int4*>(&sm[ch * kBufDwords + widx(t)]);

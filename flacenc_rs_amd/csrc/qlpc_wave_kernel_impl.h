@@ -732,6 +732,7 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
     }
     __syncthreads();
     if (wave == 0 && lane < 4) {
+      __builtin_amdgcn_s_setprio(3);  // the other three waves of the workgroup wait for this one
       double Rl[NLAG];
 #pragma unroll
       for (int k = 0; k < NLAG; ++k) Rl[k] = xr[lane * XR + k];
@@ -744,6 +745,7 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
       xq[lane * 16 + 12] = warm_v;
       xq[lane * 16 + 13] = shift_v;
       xq[lane * 16 + 14] = st;
+      __builtin_amdgcn_s_setprio(0);
       uint32_t sfl = blk * 4u + (uint32_t)lane;
       if (sfl >= a.n_subframes) sfl = a.n_subframes - 1u;
       if (a.lpc_coefs) {

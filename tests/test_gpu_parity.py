@@ -871,6 +871,40 @@ def test_encode_and_pack_independent_channel_frames(handle, channels, n, bps, or
         assert {0, 1, 3} <= kinds and (2 in kinds or not use_fixed)
 
 
+@pytest.mark.parametrize("order,bps,use_fixed", [(8, 16, True), (12, 16, False), (10, 24, True)])
+def test_frame_pipeline_soak(handle, order, bps, use_fixed):
+    """768 frames of mixed material (tones with little or much noise, near-silence, hard-panned and
+    anti-phase channels, full-scale bursts) through analysis -> decision -> packing, every record,
+    residual row and packed byte against the oracle."""
+    rng = np.random.default_rng(order * 100 + bps)
+    parts = []
+    for k in range(12):
+        period = float(rng.uniform(2.5, 900.0))
+        amp = float(rng.choice([0.001, 0.02, 0.3, 0.9]))
+        namp = float(rng.choice([0.0, 0.0005, 0.01, 0.2, 0.7])) * min(1.0, (0.99 - amp) / 0.7 + 0.3)
+        namp = min(namp, 0.99 - amp)
+        parts.append(_capi.sigen_frames(64, 2, 4096, bps, period, amp, max(namp, 0.0), seed=1000 * order + k))
+    x = np.concatenate(parts)
+    x[5::37, 1] = x[5::37, 0]
+    x[9::41, 1] = -x[9::41, 0]
+    x[11::53, 0] = 0
+    x[13::59] = x[13::59] // 1024
+    x[17::61, 1] = x[17::61, 0] // 2 + 1
+    cfg = _capi.make_frame_config(gpu_cfg(order), use_fixed=use_fixed)
+    got, gres = handle.encode_stereo_frames(x, bps, cfg)
+    ocfg = orc.make_frame_config(orc_cfg(order, acorr=orc.ACORR_CANONICAL), use_fixed=use_fixed,
+                                 fixed=orc.make_fixed_config(sum_mode=orc.SUMABS_CANONICAL))
+    want, wres = orc.encode_stereo_frames_cfg(x, bps, ocfg)
+    _check_frames_against_oracle(x, bps, got, gres, want, wres)
+    frames = handle.pack_stereo_frames(x, got, gres, bps, 44100, 0, 1)
+    for f in range(x.shape[0]):
+        assert frames[f] == orc.write_stereo_frame(got[f], x[f, 0], x[f, 1], bps, 44100, f, gres[f, 0], gres[f, 1]), f
+    hist = np.bincount(got["kind"].ravel(), minlength=4)
+    print("kinds constant/verbatim/fixed/lpc:", hist.tolist(), " assignments:",
+          np.bincount(got["channel_assignment"], minlength=4).tolist())
+    assert hist[3] > 0 and hist[0] > 0
+
+
 def test_encode_stereo_frames_rejects_bad_config(handle):
     x = np.zeros((2, 2, 4096), np.int32)
     with pytest.raises(_capi.FlacencHipError) as ei:

@@ -785,6 +785,17 @@ def test_flac_stream_end_to_end(handle):
         pos += got["length"]
     assert pos == len(data)
     assert int.from_bytes(si[4:7], "big") == min(sizes) and int.from_bytes(si[7:10], "big") == max(sizes)
+    # arbitrary length: three whole blocks and a 1234-sample tail block (a second, one-frame batch)
+    pcm = np.ascontiguousarray(frames[:4].transpose(0, 2, 1)).reshape(-1, 2)[: 3 * n + 1234]
+    data, res = encode_flac.encode_pcm(pcm, bps, rate, handle)
+    assert len(res) == 4 and int.from_bytes(data[8:42][10:18], "big") & ((1 << 36) - 1) == len(pcm)
+    pos, t = 42, 0
+    for f in range(4):
+        got = flac_parse.parse_frame(data[pos:])
+        assert got["number"] == f and got["block_size"] == (n if f < 3 else 1234)
+        assert np.array_equal(got["channels"], pcm[t:t + got["block_size"]].T), f
+        pos, t = pos + got["length"], t + got["block_size"]
+    assert pos == len(data) and t == len(pcm)
 
 
 @pytest.mark.parametrize("n,bps,order,kw", [

@@ -532,26 +532,34 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
 #pragma unroll
         for (int ord = 0; ord < 5; ++ord) ls[ord] += __shfl_xor(ls[ord], 1 << lvl, 64);
       }
-      const bool gleader = (lane & ((1 << g) - 1)) == 0;
+      // estimate_entropy for several orders at once: the 2^g lanes of a partition all hold its
+      // five sums, so lane j of a group takes order r 2^g + j in pass r.  Its partition estimates
+      // are added up over the groups (lanes with equal j) by the butterfly levels >= g, and the
+      // first minimum of the keys is the minimum of (key << 3 | order).
+      const int G = 1 << g;
+      const int jsub = lane & (G - 1);
       const uint32_t psize = 64u << g;
-      unsigned long long best_key = ~0ull;
-      int best_ord = 0;
+      uint32_t best_packed = 0xFFFFFFFFu;
 #pragma unroll 1
-      for (int ord = 0; ord <= (int)a.fixed_max_order; ++ord) {
+      for (int r = 0; r * G <= (int)a.fixed_max_order; ++r) {
+        const int ord = r * G + jsub;
+        const bool valid = ord <= (int)a.fixed_max_order;
         double sv = ls[0];
 #pragma unroll
         for (int q = 1; q < 5; ++q) sv = (q == ord) ? ls[q] : sv;
         // sample_count = min(end - warmup, partition_len): only partition 0 loses the warm-up
         const uint32_t cnt = psize - ((lane >> g) == 0 ? (uint32_t)ord : 0u);
-        const uint32_t pb = approx_ent_bits(sv, cnt);
-        const unsigned long long key = (unsigned long long)wave_sum_dpp(gleader ? pb : 0u) +
-                                       bps_role * (unsigned long long)ord;
-        if (a.fixed_keys && lane == 0) a.fixed_keys[(size_t)sf * 8 + ord] = key;
-        if (key < best_key) {  // min_by_key keeps the first minimum
-          best_key = key;
-          best_ord = ord;
-        }
+        uint32_t pb = valid ? approx_ent_bits(sv, cnt) : 0u;
+#pragma unroll 1
+        for (int lvl = g; lvl < 6; ++lvl) pb += (uint32_t)__shfl_xor((int)pb, 1 << lvl, 64);
+        const unsigned long long key = (unsigned long long)pb + bps_role * (unsigned long long)ord;
+        if (a.fixed_keys && valid && lane < G) a.fixed_keys[(size_t)sf * 8 + ord] = key;
+        const uint32_t packed = valid ? (((uint32_t)key << 3) | (uint32_t)ord) : 0xFFFFFFFFu;  // key < 2^29
+        const uint32_t m = wave_min_dpp(packed);
+        best_packed = m < best_packed ? m : best_packed;
       }
+      const unsigned long long best_key = (unsigned long long)(best_packed >> 3);
+      const int best_ord = (int)(best_packed & 7u);
       fx.key = best_key;
       fx.order = uni(best_ord);
       // fixed_lpc returns None when the estimate does not beat verbatim_bits (coding.rs:284):

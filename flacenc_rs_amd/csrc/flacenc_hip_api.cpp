@@ -40,7 +40,7 @@ struct flacenc_hip_handle {
   hipStream_t stream = nullptr;
   std::string last_error;
   std::vector<WindowEntry> windows;
-  DeviceBuffer d_samples, d_residual, d_params, d_bps, d_autocorr, d_lpc, d_tables, d_keys, d_sel, d_results, d_out, d_outlen, d_cparams, d_cresid, d_fparams, d_fresid, d_fkeys;
+  DeviceBuffer d_samples, d_residual, d_params, d_bps, d_autocorr, d_lpc, d_tables, d_keys, d_sel, d_results, d_out, d_outlen, d_cparams, d_cresid, d_fparams, d_fresid, d_fkeys, d_split;
   unsigned long long* stamps = nullptr;  // profiling hook, see flacenc_hip_debug_set_stamps
   unsigned long long* fixed_keys = nullptr;  // test hook, see flacenc_hip_debug_set_fixed_keys
 };
@@ -217,6 +217,15 @@ int enqueue(flacenc_hip_handle* h, const flacenc_hip_qlpc_config* cfg, const int
   a.fixed_mode = a.fixed_partitions = a.forced_uniform = 0;
   a.forced_orders = nullptr;
   a.selector_keys = nullptr;
+  a.lpc_stage = 0;
+  a.pred = nullptr;
+  a.pred_out = nullptr;
+  a.split_scratch = nullptr;
+  if (cfg->lpc_order >= 16) {
+    rc = ensure(h, h->d_split, n_subframes * (33 * 8 + 36 * 4));
+    if (rc != FLACENC_HIP_OK) return rc;
+    a.split_scratch = h->d_split.ptr;
+  }
   if (plan.table_scratch_bytes_per_subframe) {
     rc = ensure(h, h->d_tables, plan.table_scratch_bytes_per_subframe * n_subframes);
     if (rc != FLACENC_HIP_OK) return rc;
@@ -357,6 +366,10 @@ int enqueue_fixed(flacenc_hip_handle* h, const flacenc_hip_frame_config* cfg, co
   a.forced_uniform = 0;
   a.forced_orders = nullptr;
   a.selector_keys = selector_keys;
+  a.lpc_stage = 0;
+  a.pred = nullptr;
+  a.pred_out = nullptr;
+  a.split_scratch = nullptr;
   if (plan.table_scratch_bytes_per_subframe) {
     rc = ensure(h, h->d_tables, plan.table_scratch_bytes_per_subframe * n_subframes);
     if (rc != FLACENC_HIP_OK) return rc;
@@ -431,7 +444,7 @@ void flacenc_hip_destroy(flacenc_hip_handle* h) {
     if (e.dev) (void)hipFree(e.dev);
   for (DeviceBuffer* b : {&h->d_samples, &h->d_residual, &h->d_params, &h->d_bps, &h->d_autocorr,
                           &h->d_lpc, &h->d_tables, &h->d_keys, &h->d_sel, &h->d_results, &h->d_out, &h->d_outlen, &h->d_cparams, &h->d_cresid,
-                          &h->d_fparams, &h->d_fresid, &h->d_fkeys})
+                          &h->d_fparams, &h->d_fresid, &h->d_fkeys, &h->d_split})
     if (b->ptr) (void)hipFree(b->ptr);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -1088,6 +1101,10 @@ int flacenc_hip_encode_stereo_frames_async(flacenc_hip_handle* h, const flacenc_
   a.fixed_mode = a.fixed_partitions = a.forced_uniform = 0;
   a.forced_orders = nullptr;
   a.selector_keys = nullptr;
+  a.lpc_stage = 0;
+  a.pred = nullptr;
+  a.pred_out = nullptr;
+  a.split_scratch = nullptr;
   if (!flacenc_hip::wave_kernel_eligible(a) || fixed_composite) {
     // General shapes: the same result from candidate batches (4 QLPC + 4 fixed-LPC candidates per
     // frame in handle scratch) and the stand-alone controller kernel (frame_decide.cpp).

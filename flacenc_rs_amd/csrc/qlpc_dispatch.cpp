@@ -79,6 +79,32 @@ hipError_t launch_qlpc(const QlpcKernelArgs& a, const QlpcLaunchPlan& plan, hipS
     FLACENC_HIP_FOR_EACH_WAVE_INSTANCE(FLACENC_HIP_WCASE)
 #undef FLACENC_HIP_WCASE
   }
+  // Large orders: the recursion is ~5 P^2 / 2 serial instructions, during which a whole workgroup
+  // would idle -- run it one subframe per lane between two launches of the generic kernel instead
+  // (R[] and the quantised predictor go through `split_scratch`; the samples are read twice).
+  if (a.fixed_mode == 0 && a.lpc_stage == 0 && a.lpc_order >= 16 && a.split_scratch != nullptr) {
+    QlpcKernelArgs s1 = a, s2 = a, s3 = a;
+    double* racc = reinterpret_cast<double*>(a.split_scratch);
+    int32_t* pred = reinterpret_cast<int32_t*>(racc + static_cast<size_t>(a.n_subframes) * 33);
+    s1.lpc_stage = 1;
+    s1.autocorr = a.autocorr ? a.autocorr : racc;
+    s2.autocorr = s1.autocorr;
+    s2.pred_out = pred;
+    s3.lpc_stage = 3;
+    s3.pred = pred;
+    s3.autocorr = nullptr;  // already written by the first launch
+    s3.lpc_coefs = nullptr;  // written by the batch kernel
+#define FLACENC_HIP_SPLIT(MP, BG)                                                              \
+  if (plan.maxp == MP && plan.big == (BG != 0)) {                                              \
+    hipError_t err = launch_qlpc_##MP##_##BG(s1, plan.threads, plan.smem_bytes, stream);       \
+    if (err != hipSuccess) return err;                                                         \
+    err = launch_levinson_##MP##_##BG(s2, stream);                                             \
+    if (err != hipSuccess) return err;                                                         \
+    return launch_qlpc_##MP##_##BG(s3, plan.threads, plan.smem_bytes, stream);                 \
+  }
+    FLACENC_HIP_FOR_EACH_INSTANCE(FLACENC_HIP_SPLIT)
+#undef FLACENC_HIP_SPLIT
+  }
 #define FLACENC_HIP_CASE(MP, BG)                       \
   if (plan.maxp == MP && plan.big == (BG != 0))        \
     return launch_qlpc_##MP##_##BG(a, plan.threads, plan.smem_bytes, stream);

@@ -11,4 +11,9 @@ hipError_t FLACENC_CAT(FLACENC_MAXP, FLACENC_BIG)(const QlpcKernelArgs& a, int t
                                                    hipStream_t stream) {
   return launch_one<FLACENC_MAXP, (FLACENC_BIG != 0)>(a, threads, smem, stream);
 }
+#define FLACENC_LCAT2(a, b, c) launch_levinson_##a##_##b
+#define FLACENC_LCAT(a, b) FLACENC_LCAT2(a, b, )
+hipError_t FLACENC_LCAT(FLACENC_MAXP, FLACENC_BIG)(const QlpcKernelArgs& a, hipStream_t stream) {
+  return launch_levinson_batch<FLACENC_MAXP>(a, stream);
+}
 }  // namespace flacenc_hip

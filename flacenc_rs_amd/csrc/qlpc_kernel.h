@@ -51,6 +51,13 @@ struct QlpcKernelArgs {
   uint32_t forced_uniform;         // mode 2
   const uint8_t* forced_orders;    // mode 3, device, [n]
   unsigned long long* selector_keys;  // device, nullable, [n]: the chosen order's selector key
+  // three-launch split of the generic kernel for large orders (launch_qlpc): 0 = fused,
+  // 1 = window + autocorrelation only (R[] to `autocorr`), 3 = residual + Rice with the predictor
+  // levinson_batch_kernel left in `pred` ([n][36] int32: qc[32], order, shift, status, 0)
+  uint32_t lpc_stage;
+  const int32_t* pred;
+  int32_t* pred_out;
+  void* split_scratch;  // device, n * (33 * 8 + 36 * 4) bytes, or nullptr: no split
 };
 
 struct QlpcLaunchPlan {
@@ -71,7 +78,8 @@ hipError_t launch_qlpc(const QlpcKernelArgs& args, const QlpcLaunchPlan& plan, h
 #define FLACENC_HIP_FOR_EACH_INSTANCE(X) \
   X(8, 0) X(10, 0) X(12, 0) X(16, 0) X(24, 0) X(32, 0) X(12, 1) X(32, 1)
 #define FLACENC_HIP_DECLARE_INSTANCE(MP, BG) \
-  hipError_t launch_qlpc_##MP##_##BG(const QlpcKernelArgs&, int threads, size_t smem, hipStream_t);
+  hipError_t launch_qlpc_##MP##_##BG(const QlpcKernelArgs&, int threads, size_t smem, hipStream_t); \
+  hipError_t launch_levinson_##MP##_##BG(const QlpcKernelArgs&, hipStream_t);
 FLACENC_HIP_FOR_EACH_INSTANCE(FLACENC_HIP_DECLARE_INSTANCE)
 
 #define FLACENC_HIP_FOR_EACH_WAVE_INSTANCE(X) \

@@ -542,6 +542,25 @@ qlpc_subframe_kernel(QlpcKernelArgs a) {
       L.misc[kMiscWide] = narrow ? 0u : 1u;
     }
     __syncthreads();
+  } else if (a.lpc_stage == 3u) {
+    // ======================= predictor solved by levinson_batch_kernel ========
+    // (three-launch split for large orders: the serial recursion runs one subframe per LANE in a
+    // kernel of its own instead of one per workgroup here; see launch_qlpc)
+    if (tid == 0) {
+      const int32_t* pr = a.pred + (size_t)sf * 36;
+      int64_t sumabs = 0;
+      for (int i = 0; i < 32; ++i) {
+        L.qc[i] = pr[i];
+        sumabs += pr[i] < 0 ? -pr[i] : pr[i];
+      }
+      const uint64_t maxabs = (uint64_t)L.misc[kMiscMaxAbs];
+      const bool narrow = (maxabs * (uint64_t)sumabs < 0x7FFFFFFFull) && (maxabs < (1u << 23));
+      L.misc[kMiscOrder] = (uint32_t)pr[32];
+      L.misc[kMiscShift] = (uint32_t)pr[33];
+      L.misc[kMiscStatus] = (uint32_t)pr[34];
+      L.misc[kMiscWide] = narrow ? 0u : 1u;
+    }
+    __syncthreads();
   } else {
   // ======================= phase 1: window + autocorrelation ==============
   // window table has 32 floats of zero padding in front and is padded to whole rows
@@ -603,6 +622,7 @@ qlpc_subframe_kernel(QlpcKernelArgs a) {
     if (a.autocorr) a.autocorr[(size_t)sf * 33 + tid] = (tid <= P) ? r : 0.0;
   }
   if (a.autocorr && tid >= NLAG && tid < 33) a.autocorr[(size_t)sf * 33 + tid] = 0.0;
+  if (a.lpc_stage == 1u) return;  // first launch of the split: R[] is all this one produces
   __syncthreads();
 
   FLACENC_STAMP(2);
@@ -1034,6 +1054,38 @@ qlpc_subframe_kernel(QlpcKernelArgs a) {
     rec->sum_quotients = status == 0 ? sum_q : 0ull;
   }
   FLACENC_STAMP(7);
+}
+
+// Levinson-Durbin + quantisation for a batch, one subframe per lane (second launch of the split):
+// pred[sf] = {qc[32], order, shift, status, 0}.
+template <int MAXP>
+__global__ void __launch_bounds__(64) levinson_batch_kernel(QlpcKernelArgs a) {
+  const uint32_t sf = blockIdx.x * 64u + threadIdx.x;
+  if (sf >= a.n_subframes) return;
+  double coef[MAXP];
+  int32_t qc[MAXP];
+  int order, shift;
+  const int status = levinson_quantize<MAXP>(a.autocorr + (size_t)sf * 33, (int)a.lpc_order, (int)a.precision, coef, qc,
+                                             &order, &shift);
+  int32_t* pr = a.pred_out + (size_t)sf * 36;
+#pragma unroll
+  for (int i = 0; i < MAXP; ++i) pr[i] = qc[i];
+  for (int i = MAXP; i < 32; ++i) pr[i] = 0;
+  pr[32] = order;
+  pr[33] = shift;
+  pr[34] = status;
+  pr[35] = 0;
+  if (a.lpc_coefs) {
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i) a.lpc_coefs[(size_t)sf * 32 + i] = (i < (int)a.lpc_order && status == 0) ? coef[i] : 0.0;
+    for (int i = MAXP; i < 32; ++i) a.lpc_coefs[(size_t)sf * 32 + i] = 0.0;
+  }
+}
+
+template <int MAXP>
+hipError_t launch_levinson_batch(const QlpcKernelArgs& a, hipStream_t stream) {
+  hipLaunchKernelGGL(levinson_batch_kernel<MAXP>, dim3((a.n_subframes + 63) / 64), dim3(64), 0, stream, a);
+  return hipGetLastError();
 }
 
 template <int MAXP, bool BIG>

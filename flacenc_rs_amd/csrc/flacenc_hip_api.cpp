@@ -211,6 +211,7 @@ int enqueue(flacenc_hip_handle* h, const flacenc_hip_qlpc_config* cfg, const int
   a.table_scratch = nullptr;
   a.stamps = h->stamps;
   a.frame_results = nullptr;
+  a.chan_results = nullptr;
   a.use_constant = a.use_lpc = a.use_leftside = a.use_rightside = a.use_midside = 1;
   a.use_fixed = a.fixed_max_order = a.fixed_order_sel = a.fixed_group_log2 = 0;
   a.fixed_keys = nullptr;
@@ -356,6 +357,7 @@ int enqueue_fixed(flacenc_hip_handle* h, const flacenc_hip_frame_config* cfg, co
   a.table_scratch = nullptr;
   a.stamps = nullptr;
   a.frame_results = nullptr;
+  a.chan_results = nullptr;
   a.use_constant = a.use_lpc = a.use_leftside = a.use_rightside = a.use_midside = 1;
   a.use_fixed = 1;
   a.fixed_max_order = cfg->fixed_max_order;
@@ -768,6 +770,63 @@ int flacenc_hip_encode_frames_async(flacenc_hip_handle* h, const flacenc_hip_fra
   if (cfg->use_fixed && (rc = verify_fixed(h, cfg)) != FLACENC_HIP_OK) return rc;
   HIP_TRY(h, hipSetDevice(h->device));
   hipStream_t s = static_cast<hipStream_t>(stream);
+  {
+    // block size 4096, order <= 12: one fused kernel, a wave per channel (analysis, fixed-LPC
+    // candidate, encode_subframe's choice, only the chosen residual written)
+    uint32_t glog = 0;
+    bool pow2 = true;
+    if (cfg->use_fixed && cfg->fixed_order_sel == FLACENC_HIP_ORDERSEL_APPROXENT) {
+      const uint32_t p = cfg->fixed_partitions;
+      pow2 = (p & (p - 1)) == 0;
+      for (uint32_t lanes = pow2 ? 64u / p : 1u; lanes > 1; lanes >>= 1) ++glog;
+    }
+    const WindowEntry* win = nullptr;
+    rc = get_window(h, &cfg->qlpc, block_size, &win);
+    if (rc != FLACENC_HIP_OK) return rc;
+    flacenc_hip::QlpcKernelArgs a;
+    a.samples = frames;
+    a.stride = stride;
+    a.block_size = block_size;
+    a.n_subframes = static_cast<uint32_t>(n_sub);
+    a.bps = nullptr;
+    a.bps_uniform = bits_per_sample;
+    a.stereo = 0;
+    a.window = win->dev;
+    a.flat_lo = win->flat_lo;
+    a.flat_hi = win->flat_hi;
+    a.lpc_order = cfg->qlpc.lpc_order;
+    a.precision = cfg->qlpc.quant_precision;
+    a.max_rice_parameter = cfg->qlpc.max_rice_parameter;
+    a.params = nullptr;
+    a.residual = residual;
+    a.residual_stride = residual_stride;
+    a.autocorr = nullptr;
+    a.lpc_coefs = nullptr;
+    a.table_scratch = nullptr;
+    a.stamps = nullptr;
+    a.frame_results = nullptr;
+    a.chan_results = results;
+    a.use_constant = cfg->use_constant;
+    a.use_lpc = cfg->use_lpc;
+    a.use_leftside = a.use_rightside = a.use_midside = 0;
+    a.use_fixed = cfg->use_fixed;
+    a.fixed_max_order = cfg->fixed_max_order;
+    a.fixed_order_sel = cfg->fixed_order_sel;
+    a.fixed_group_log2 = glog;
+    a.fixed_keys = h->fixed_keys;
+    a.fixed_mode = a.fixed_partitions = a.forced_uniform = 0;
+    a.forced_orders = nullptr;
+    a.selector_keys = nullptr;
+    a.lpc_stage = 0;
+    a.pred = nullptr;
+    a.pred_out = nullptr;
+    a.split_scratch = nullptr;
+    if (pow2 && flacenc_hip::wave_kernel_eligible(a)) {
+      flacenc_hip::QlpcLaunchPlan plan = flacenc_hip::plan_qlpc_launch(block_size, cfg->qlpc.lpc_order);
+      HIP_TRY(h, flacenc_hip::launch_qlpc(a, plan, s));
+      return FLACENC_HIP_OK;
+    }
+  }
   const size_t cstride = (static_cast<size_t>(block_size) + 3) & ~static_cast<size_t>(3);
   flacenc_hip::ChannelDecideArgs d{};
   d.samples = frames;
@@ -1088,6 +1147,7 @@ int flacenc_hip_encode_stereo_frames_async(flacenc_hip_handle* h, const flacenc_
   a.table_scratch = nullptr;
   a.stamps = h->stamps;
   a.frame_results = results;
+  a.chan_results = nullptr;
   a.use_constant = cfg->use_constant;
   a.use_lpc = cfg->use_lpc;
   a.use_leftside = cfg->use_leftside;

@@ -37,6 +37,8 @@ struct QlpcKernelArgs {
   unsigned long long* stamps;           // device, nullable: [n][8] phase timestamps (profiling)
   // on-device encode_frame decision (stereo, wave kernel only)
   flacenc_hip_stereo_frame_result* frame_results;  // device, [n_frames]; non-null selects DECIDE
+  flacenc_hip_channel_result* chan_results;        // device, [n_subframes]; non-null selects the
+                                                   // independent-channel DECIDE variant (stereo = 0)
   uint32_t use_constant, use_lpc, use_leftside, use_rightside, use_midside;
   // fixed-LPC candidate (config::Fixed, src/config.rs:236-244); wave kernel variant 3 only
   uint32_t use_fixed;
@@ -83,7 +85,8 @@ hipError_t launch_qlpc(const QlpcKernelArgs& args, const QlpcLaunchPlan& plan, h
 FLACENC_HIP_FOR_EACH_INSTANCE(FLACENC_HIP_DECLARE_INSTANCE)
 
 #define FLACENC_HIP_FOR_EACH_WAVE_INSTANCE(X) \
-  X(8, 0) X(8, 1) X(8, 2) X(8, 3) X(10, 0) X(10, 1) X(10, 2) X(10, 3) X(12, 0) X(12, 1) X(12, 2) X(12, 3)
+  X(8, 0) X(8, 1) X(8, 2) X(8, 3) X(8, 4) X(10, 0) X(10, 1) X(10, 2) X(10, 3) X(10, 4) \
+  X(12, 0) X(12, 1) X(12, 2) X(12, 3) X(12, 4)
 #define FLACENC_HIP_DECLARE_WAVE_INSTANCE(MP, ST) \
   hipError_t launch_qlpc_wave_##MP##_##ST(const QlpcKernelArgs&, hipStream_t);
 FLACENC_HIP_FOR_EACH_WAVE_INSTANCE(FLACENC_HIP_DECLARE_WAVE_INSTANCE)

@@ -348,7 +348,8 @@ __device__ __forceinline__ RiceResult rice_search(const PlaneSums& ps, const int
 // write one flacenc_hip_stereo_frame_result + the TWO chosen residual rows per frame.
 template <int MAXP, bool STEREO, bool DECIDE, bool FIXED>
 __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(QlpcKernelArgs a) {
-  static_assert(!DECIDE || STEREO, "the decision needs the four roles of a stereo frame");
+  // DECIDE with STEREO: encode_frame for a 2-channel frame (four roles + try_stereo_coding);
+  // DECIDE without: encode_subframe for four independent channels (Independent(n) frames)
   static_assert(!FIXED || DECIDE, "the fixed-LPC candidate only exists inside encode_subframe's decision");
   constexpr int HP = (MAXP + 3) & ~3;
   constexpr int NLAG = MAXP + 1;
@@ -1037,6 +1038,51 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
       kind = 1u;  // Verbatim
       bits = verbatim_bits;
     }
+    if (!STEREO) {
+      // ---- Independent(n) frames: this wave's subframe is one output channel ----
+      if (FIXED && kind == 2u) {
+        uint32_t v[68];
+        fixed_load(v);
+#pragma unroll 1
+        for (int lvl = 1; lvl <= fx.order; ++lvl) {
+#pragma unroll
+          for (int i = 67; i >= 1; --i) v[i] -= v[i - 1];
+        }
+#pragma unroll
+        for (int k = 0; k < 64; ++k) e[k] = (int32_t)v[4 + k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (lane == 0 && k < fx.order) e[k] = 0;
+      } else if (kind < 2u) {
+#pragma unroll
+        for (int k = 0; k < 64; ++k) e[k] = 0;
+      }
+      {
+        // own image -> coalesced store (only this wave touches its image)
+        int32_t* own = sm + wave * kBufDwords;
+        int32_t* __restrict__ dst = a.residual + (size_t)sf * a.residual_stride;
+        put_own_e(own);
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+          const int t = (lane + it * 64) << 2;
+          const int4 v = *reinterpret_cast<const int4*>(&own[widx(t)]);
+          *reinterpret_cast<int4*>(dst + t) = v;
+        }
+      }
+      flacenc_hip_channel_result* out = a.chan_results + sf;
+      if (lane == 0) {
+        out->kind = (uint8_t)kind;
+        out->pad[0] = out->pad[1] = out->pad[2] = 0;
+        out->dc_offset = kind == 0u ? role_max : 0;
+        out->bits = bits;
+      }
+      rec = &out->params;
+      if (kind < 2u) {
+        for (int i = lane; i < (int)(sizeof(flacenc_hip_subframe_params) / 4); i += 64)
+          reinterpret_cast<uint32_t*>(rec)[i] = 0u;
+        rec = nullptr;
+      }
+    } else {
     // ---- try_stereo_coding (coding.rs:493-522): exchange the four candidates' sizes ----
     // (reuses the R[] exchange area, which nobody reads after the Levinson barriers)
     unsigned long long* const xb = reinterpret_cast<unsigned long long*>(sm + NIMG * kBufDwords);
@@ -1133,6 +1179,7 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
         reinterpret_cast<uint32_t*>(rec)[i] = 0u;
       rec = nullptr;
     }
+    }  // STEREO
     if (FIXED && rec != nullptr && kind == 2u) {
       // the record of a FixedLpc subframe: FIXED_LPC_COEFS[order] with shift 0 (decode.rs:179-201)
       bestk = fx.bestk;

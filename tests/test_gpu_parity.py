@@ -833,11 +833,13 @@ def test_encode_stereo_frames_any_shape(handle, n, bps, order, kw):
             assert parsed["block_size"] == n and np.array_equal(parsed["channels"], base[f]), f
 
 
-@pytest.mark.parametrize("channels,n,bps,order,use_fixed", [
-    (1, 4096, 16, 8, True), (8, 4096, 16, 10, True), (3, 1152, 16, 12, True), (5, 4608, 24, 8, False),
-    (1, 300, 8, 4, True),
+@pytest.mark.parametrize("channels,n,bps,order,use_fixed,kw", [
+    (1, 4096, 16, 8, True, {}), (8, 4096, 16, 10, True, {}), (3, 1152, 16, 12, True, {}),
+    (5, 4608, 24, 8, False, {}), (1, 300, 8, 4, True, {}), (2, 4096, 16, 12, False, {}),
+    (3, 4096, 24, 8, True, dict(fixed_order_sel=0)), (2, 4096, 16, 8, True, dict(fixed_partitions=12)),
+    (4, 4096, 16, 10, True, dict(fixed_partitions=64, fixed_max_order=2)),
 ])
-def test_encode_and_pack_independent_channel_frames(handle, channels, n, bps, order, use_fixed):
+def test_encode_and_pack_independent_channel_frames(handle, channels, n, bps, order, use_fixed, kw):
     """Mono / multi-channel streams (encode_frame with Independent(n), coding.rs:537-541):
     flacenc_hip_encode_frames == encode_subframe per channel, flacenc_hip_pack_frames == Frame::write,
     both against the oracle, and the bytes parse back to the input (BASELINE config 4 is the 8-channel case)."""
@@ -847,10 +849,13 @@ def test_encode_and_pack_independent_channel_frames(handle, channels, n, bps, or
     x[1, 0] = (np.arange(n) // 9) % half          # FixedLpc territory
     x[2, channels - 1] = -5                        # Constant
     x[3, 0] = util.quantize(util.noise(4, n, 0.999), bps)   # Verbatim
-    cfg = _capi.make_frame_config(gpu_cfg(order), use_fixed=use_fixed)
+    cfg = _capi.make_frame_config(gpu_cfg(order), use_fixed=use_fixed, **kw)
     res, resid = handle.encode_frames(x, bps, cfg)
     ocfg = orc.make_frame_config(orc_cfg(order, acorr=orc.ACORR_CANONICAL), use_fixed=use_fixed,
-                                 fixed=orc.make_fixed_config(sum_mode=orc.SUMABS_CANONICAL))
+                                 fixed=orc.make_fixed_config(max_order=kw.get("fixed_max_order", 4),
+                                                             order_sel=kw.get("fixed_order_sel", 1),
+                                                             partitions=kw.get("fixed_partitions", 16),
+                                                             sum_mode=orc.SUMABS_CANONICAL))
     packed = handle.pack_frames(x, res, resid, bps, 44100, 70, 1)
     kinds = set()
     for f in range(x.shape[0]):

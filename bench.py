@@ -77,24 +77,45 @@ def main():
                               frame_step=world)
     x = torch.from_numpy(host).to(dev)
     rec_bytes = _capi.FRAME_RESULT_DTYPE.itemsize
-    results = torch.empty((F, rec_bytes), dtype=torch.uint8, device=dev)  # one record per frame
+    # decision records and frame lengths are double-buffered: the exchange of step k (on its own
+    # stream) overlaps the analysis of step k + 1
+    results2 = [torch.empty((F, rec_bytes), dtype=torch.uint8, device=dev) for _ in range(2)]
+    frame_len2 = [torch.zeros(F, dtype=torch.int32, device=dev) for _ in range(2)]
+    results = results2[0]
     residual = torch.empty((F * 2, n), dtype=torch.int32, device=dev)     # the two chosen channels
-    frame_len = torch.zeros(F, dtype=torch.int32, device=dev)             # byte length of each frame
     handle = _capi.Handle(local_rank)
     stream = torch.cuda.current_stream()
+    comm = torch.cuda.Stream(device=dev)
+    exchanging = world > 1 or args.force_exchange
+    consumed = [None, None]  # event: the exchange that read buffer b has finished
+    step_no = [0]
 
-    def exchange():
+    def exchange(b):
         # the multi-GPU exchange step: frame byte lengths -> stream order -> stream offsets
-        handle.stereo_frame_lengths_device(results.data_ptr(), F, n, bps, 44100, rank, world,
-                                           frame_len.data_ptr(), stream=stream.cuda_stream)
-        lengths_all = shard.all_gather_frame_lengths(frame_len, world * F)
+        handle.stereo_frame_lengths_device(results2[b].data_ptr(), F, n, bps, 44100, rank, world,
+                                           frame_len2[b].data_ptr(), stream=comm.cuda_stream)
+        lengths_all = shard.all_gather_frame_lengths(frame_len2[b], world * F)
         return shard.stream_offsets(lengths_all)[0]
 
-    def step():
-        handle.encode_stereo_frames_device(cfg, x.data_ptr(), F, n, n, bps, results.data_ptr(),
+    def step(events=None):
+        b = step_no[0] & 1
+        step_no[0] += 1
+        if exchanging and consumed[b] is not None:
+            stream.wait_event(consumed[b])  # the records of two steps ago have been read
+        if events:
+            events[0].record(stream)
+        handle.encode_stereo_frames_device(cfg, x.data_ptr(), F, n, n, bps, results2[b].data_ptr(),
                                            residual.data_ptr(), n, stream=stream.cuda_stream)
-        if world > 1 or args.force_exchange:
-            exchange()
+        if events:
+            events[1].record(stream)
+        if exchanging:
+            ready = torch.cuda.Event()
+            ready.record(stream)
+            with torch.cuda.stream(comm):
+                comm.wait_event(ready)
+                exchange(b)
+                consumed[b] = torch.cuda.Event()
+                consumed[b].record(comm)
 
     def fence():
         if world > 1:
@@ -109,12 +130,7 @@ def main():
           for _ in range(args.steps)]
     t0 = time.perf_counter()
     for k in range(args.steps):
-        ev[k][0].record(stream)
-        handle.encode_stereo_frames_device(cfg, x.data_ptr(), F, n, n, bps, results.data_ptr(),
-                                           residual.data_ptr(), n, stream=stream.cuda_stream)
-        ev[k][1].record(stream)
-        if world > 1 or args.force_exchange:
-            exchange()
+        step(ev[k])
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -124,7 +140,7 @@ def main():
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if args.steps else float("nan")
 
     # sanity: nothing in the timed region may have failed
-    p = np.frombuffer(results.cpu().numpy().tobytes(), dtype=_capi.FRAME_RESULT_DTYPE)
+    p = np.frombuffer(results2[(step_no[0] - 1) & 1].cpu().numpy().tobytes(), dtype=_capi.FRAME_RESULT_DTYPE)
     lpc_kind = p["kind"] >= 2
     assert (p["lpc"]["status"][lpc_kind] == 0).all(), "subframe status != 0"
     chosen_bits = int(sum(int(p["bits"][f, r]) for f in range(F) for r in p["role"][f]))
@@ -156,8 +172,8 @@ def main():
             "decision": ("encode_subframe {Constant, Verbatim, FixedLpc(ApproxEnt 16), LPC}" if args.use_fixed
                          else "encode_subframe {Constant, Verbatim, LPC}") +
                         " + try_stereo_coding on the GPU; the two chosen residuals written",
-            "gather": "all_gather of per-frame byte lengths (4 B/frame, RCCL) + prefix sum to stream offsets"
-                      if world > 1 else "none",
+            "gather": "all_gather of per-frame byte lengths (4 B/frame, RCCL) + prefix sum to stream offsets, "
+                      "on its own stream, overlapping the next step's analysis" if world > 1 else "none",
             "subframe_bits_per_sample": round(chosen_bits / (2 * F * n), 4),
             "assignments_indep_left_right_mid": assign_hist,
         },

@@ -62,6 +62,8 @@ EXPORTED_SYMBOLS = (
     "flacenc_hip_frame_bytes_bound",
     "flacenc_hip_pack_frames",
     "flacenc_hip_pack_frames_async",
+    "flacenc_hip_fill_le_bytes",
+    "flacenc_hip_fill_le_bytes_async",
     "flacenc_hip_synchronize",
     "flacenc_hip_debug_set_stamps",
     "flacenc_hip_debug_set_fixed_keys",
@@ -225,6 +227,12 @@ def load() -> C.CDLL:
     L.flacenc_hip_stereo_frame_lengths_async.argtypes = [vp, vp, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32,
                                                           C.c_uint32, C.c_uint32, vp, vp]
     L.flacenc_hip_stereo_frame_lengths_async.restype = C.c_int
+    L.flacenc_hip_fill_le_bytes.argtypes = [vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_size_t, C.c_uint32, i32p,
+                                            C.c_size_t, C.c_int]
+    L.flacenc_hip_fill_le_bytes.restype = C.c_int
+    L.flacenc_hip_fill_le_bytes_async.argtypes = [vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_size_t, C.c_uint32,
+                                                  vp, C.c_size_t, vp]
+    L.flacenc_hip_fill_le_bytes_async.restype = C.c_int
     L.flacenc_hip_stereo_frame_bytes_bound.argtypes = [C.c_uint32, C.c_uint32]
     L.flacenc_hip_stereo_frame_bytes_bound.restype = C.c_size_t
     L.flacenc_hip_encode_frames.argtypes = [vp, C.POINTER(FrameConfig), i32p, C.c_size_t, C.c_uint32, C.c_uint32,
@@ -449,6 +457,17 @@ class Handle:
             self._h, results_ptr, n_frames, block_size, bits_per_sample, sample_rate, first_frame_number,
             frame_number_step, out_len_ptr, stream or None)
         self._check(rc)
+
+    def fill_le_bytes(self, data: bytes, channels: int, bytes_per_sample: int, block_size: int):
+        """FrameBuf::fill_le_bytes for a whole stream: packed interleaved PCM -> int32 [n_frames, channels, n]."""
+        b = np.frombuffer(bytes(data), np.uint8).copy()
+        total = len(b) // (channels * bytes_per_sample)
+        nf = (total + block_size - 1) // block_size
+        out = np.full((nf, channels, block_size), -1, np.int32)
+        rc = self._lib.flacenc_hip_fill_le_bytes(self._h, b.ctypes.data, total, channels, bytes_per_sample, nf,
+                                                 block_size, out.ctypes.data, block_size, MEM_HOST)
+        self._check(rc)
+        return out
 
     def frame_bytes_bound(self, block_size: int, bits_per_sample: int) -> int:
         return int(self._lib.flacenc_hip_stereo_frame_bytes_bound(block_size, bits_per_sample))

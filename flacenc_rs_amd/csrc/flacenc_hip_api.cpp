@@ -958,6 +958,58 @@ int flacenc_hip_pack_frames(flacenc_hip_handle* h, const int32_t* frames, size_t
   return FLACENC_HIP_OK;
 }
 
+int flacenc_hip_fill_le_bytes_async(flacenc_hip_handle* h, const uint8_t* bytes, uint64_t total_samples,
+                                    uint32_t channels, uint32_t bytes_per_sample, size_t n_frames,
+                                    uint32_t block_size, int32_t* frames, size_t stride, void* stream) {
+  if (!h) return FLACENC_HIP_ERR_BAD_ARGUMENT;
+  if (n_frames == 0) return FLACENC_HIP_OK;
+  if (!bytes || !frames || channels < 1 || channels > 8 || bytes_per_sample < 1 || bytes_per_sample > 4 ||
+      block_size < 1 || block_size > FLACENC_HIP_MAX_BLOCK_SIZE || stride < block_size || n_frames > 0xFFFFull) {
+    h->last_error = "fill_le_bytes: null pointer, channels not in 1..=8, bytes_per_sample not in 1..=4, or > 65535 frames";
+    return FLACENC_HIP_ERR_BAD_ARGUMENT;
+  }
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, flacenc_hip::launch_fill_le_bytes(bytes, channels, bytes_per_sample, total_samples,
+                                               static_cast<uint32_t>(n_frames), block_size, frames, stride,
+                                               static_cast<hipStream_t>(stream)));
+  return FLACENC_HIP_OK;
+}
+
+int flacenc_hip_fill_le_bytes(flacenc_hip_handle* h, const uint8_t* bytes, uint64_t total_samples,
+                              uint32_t channels, uint32_t bytes_per_sample, size_t n_frames, uint32_t block_size,
+                              int32_t* frames, size_t stride, int memory_kind) {
+  if (!h) return FLACENC_HIP_ERR_BAD_ARGUMENT;
+  if (memory_kind == FLACENC_HIP_MEM_DEVICE) {
+    int rc = flacenc_hip_fill_le_bytes_async(h, bytes, total_samples, channels, bytes_per_sample, n_frames,
+                                             block_size, frames, stride, h->stream);
+    if (rc != FLACENC_HIP_OK || n_frames == 0) return rc;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return FLACENC_HIP_OK;
+  }
+  if (memory_kind != FLACENC_HIP_MEM_HOST) return FLACENC_HIP_ERR_BAD_ARGUMENT;
+  if (n_frames == 0) return FLACENC_HIP_OK;
+  if (!bytes || !frames || channels < 1 || channels > 8 || bytes_per_sample < 1 || bytes_per_sample > 4 ||
+      stride < block_size)
+    return FLACENC_HIP_ERR_BAD_ARGUMENT;
+  HIP_TRY(h, hipSetDevice(h->device));
+  int rc;
+  const uint64_t wanted = static_cast<uint64_t>(n_frames) * block_size;
+  const uint64_t have = total_samples < wanted ? total_samples : wanted;
+  const size_t nbytes = static_cast<size_t>(have) * channels * bytes_per_sample;
+  const size_t dstride = (static_cast<size_t>(block_size) + 3) & ~static_cast<size_t>(3);
+  if ((rc = ensure(h, h->d_out, nbytes + 16)) != FLACENC_HIP_OK) return rc;
+  if ((rc = ensure(h, h->d_samples, n_frames * channels * dstride * 4)) != FLACENC_HIP_OK) return rc;
+  hipStream_t s = h->stream;
+  HIP_TRY(h, hipMemcpyAsync(h->d_out.ptr, bytes, nbytes, hipMemcpyHostToDevice, s));
+  rc = flacenc_hip_fill_le_bytes_async(h, static_cast<const uint8_t*>(h->d_out.ptr), have, channels, bytes_per_sample,
+                                       n_frames, block_size, static_cast<int32_t*>(h->d_samples.ptr), dstride, s);
+  if (rc != FLACENC_HIP_OK) return rc;
+  HIP_TRY(h, hipMemcpy2DAsync(frames, stride * 4, h->d_samples.ptr, dstride * 4, static_cast<size_t>(block_size) * 4,
+                              n_frames * channels, hipMemcpyDeviceToHost, s));
+  HIP_TRY(h, hipStreamSynchronize(s));
+  return FLACENC_HIP_OK;
+}
+
 int flacenc_hip_synchronize(flacenc_hip_handle* h) {
   if (!h) return FLACENC_HIP_ERR_BAD_ARGUMENT;
   HIP_TRY(h, hipSetDevice(h->device));

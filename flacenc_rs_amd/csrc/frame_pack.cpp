@@ -359,7 +359,41 @@ __global__ void frame_lengths_kernel(FramePackArgs a) {
   a.out_len[f] = (uint32_t)((bits + 7ull) >> 3) + 2u;
 }
 
+// FrameBuf::fill_le_bytes (src/source.rs:288-298) for a run of consecutive frames of one stream:
+// le_bytes_to_i32s (arrayutils.rs:273-290: little-endian, sign-extended) + deinterleave
+// (arrayutils.rs:248-264: channel-major rows, the unfilled rest of a row is zero)
+__global__ void __launch_bounds__(256) fill_le_bytes_kernel(const uint8_t* __restrict__ bytes, uint32_t channels,
+                                                            uint32_t bytes_per_sample, uint64_t total_samples,
+                                                            uint32_t block_size, int32_t* __restrict__ frames,
+                                                            size_t stride) {
+  const uint32_t f = blockIdx.y;
+  const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+  if (t >= block_size) return;
+  const uint64_t idx = (uint64_t)f * block_size + t;  // inter-channel sample index in the stream
+  const bool filled = idx < total_samples;
+  const uint8_t* src = bytes + idx * channels * bytes_per_sample;
+  for (uint32_t c = 0; c < channels; ++c) {
+    int32_t v = 0;
+    if (filled) {
+      uint32_t u = 0;
+      for (uint32_t b = 0; b < bytes_per_sample; ++b) u |= (uint32_t)src[c * bytes_per_sample + b] << (8u * b);
+      const uint32_t sh = 32u - 8u * bytes_per_sample;
+      v = (int32_t)(u << sh) >> sh;
+    }
+    frames[((size_t)f * channels + c) * stride + t] = v;
+  }
+}
+
 }  // namespace
+
+hipError_t launch_fill_le_bytes(const uint8_t* bytes, uint32_t channels, uint32_t bytes_per_sample,
+                                uint64_t total_samples, uint32_t n_frames, uint32_t block_size, int32_t* frames,
+                                size_t stride, hipStream_t stream) {
+  if (n_frames == 0) return hipSuccess;
+  hipLaunchKernelGGL(fill_le_bytes_kernel, dim3((block_size + 255) / 256, n_frames), dim3(256), 0, stream, bytes,
+                     channels, bytes_per_sample, total_samples, block_size, frames, stride);
+  return hipGetLastError();
+}
 
 hipError_t launch_frame_lengths(const FramePackArgs& a, hipStream_t stream) {
   if (a.n_frames == 0) return hipSuccess;

@@ -44,6 +44,10 @@ size_t frame_bytes_bound(uint32_t channels, uint32_t block_size, uint32_t bits_p
 hipError_t launch_frame_pack(const FramePackArgs& args, hipStream_t stream);
 // only results, n_frames, extra_len, first_frame_number, frame_number_step, out_len are read
 hipError_t launch_frame_lengths(const FramePackArgs& args, hipStream_t stream);
+// packed little-endian interleaved PCM -> batched FrameBuf layout (int32, channel-major rows)
+hipError_t launch_fill_le_bytes(const uint8_t* bytes, uint32_t channels, uint32_t bytes_per_sample,
+                                uint64_t total_samples, uint32_t n_frames, uint32_t block_size, int32_t* frames,
+                                size_t stride, hipStream_t stream);
 
 }  // namespace flacenc_hip
 #endif

@@ -361,6 +361,23 @@ int flacenc_hip_stereo_frame_lengths_async(flacenc_hip_handle* h, const flacenc_
                                            uint32_t sample_rate, uint32_t first_frame_number,
                                            uint32_t frame_number_step, uint32_t* out_len, void* stream);
 
+/* ---- input side ------------------------------------------------------- */
+/*
+ * FrameBuf::fill_le_bytes (src/source.rs:288-298) for a run of consecutive frames of one stream, on
+ * the GPU: le_bytes_to_i32s (src/arrayutils.rs:273-290; little-endian samples of 1..4 bytes, sign-
+ * extended) and deinterleave (src/arrayutils.rs:248-264).  `bytes` holds `total_samples` inter-channel
+ * samples of packed interleaved PCM starting at the first frame of the run; frame f, channel c goes
+ * to frames + (f*channels + c)*stride, zero-filled beyond total_samples (the short last block).
+ * Uploading packed 16- / 24-bit PCM and widening here halves (or better) the PCIe traffic of the
+ * host-pointer paths; the MD5 of the input stays with the caller (src/source.rs:406-428).
+ */
+int flacenc_hip_fill_le_bytes(flacenc_hip_handle* h, const uint8_t* bytes, uint64_t total_samples,
+                              uint32_t channels, uint32_t bytes_per_sample, size_t n_frames, uint32_t block_size,
+                              int32_t* frames, size_t stride, int memory_kind);
+int flacenc_hip_fill_le_bytes_async(flacenc_hip_handle* h, const uint8_t* bytes, uint64_t total_samples,
+                                    uint32_t channels, uint32_t bytes_per_sample, size_t n_frames,
+                                    uint32_t block_size, int32_t* frames, size_t stride, void* stream);
+
 int flacenc_hip_synchronize(flacenc_hip_handle* h);
 
 /* Test hook (no reference counterpart): when `device_keys` is non-NULL, launches with use_fixed

@@ -1476,3 +1476,27 @@ size_t orc_write_stereo_frame(const orc_stereo_frame_result* fr, const int32_t* 
   free(sd);
   return len;
 }
+
+/* ------------------------------------------------------------------------ */
+/* input side: src/arrayutils.rs                                              */
+/* ------------------------------------------------------------------------ */
+
+/* le_bytes_to_i32s_impl, src/arrayutils.rs:273-290 */
+void orc_le_bytes_to_i32s(const uint8_t* bytes, size_t nbytes, int32_t* dest, uint32_t bytes_per_sample) {
+  size_t n = 0;
+  for (size_t t = 0; t + bytes_per_sample <= nbytes; t += bytes_per_sample) {
+    uint32_t u = 0;
+    for (uint32_t i = 0; i < bytes_per_sample; ++i) u |= (uint32_t)bytes[t + i] << (8u * (i + 4u - bytes_per_sample));
+    dest[n++] = (int32_t)u >> ((4u - bytes_per_sample) * 8u);
+  }
+}
+
+/* deinterleave_gen, src/arrayutils.rs:229-245 (all channel counts agree with it, :248-264) */
+void orc_deinterleave(const int32_t* interleaved, size_t len, size_t channels, size_t channel_stride,
+                      int32_t* dest) {
+  size_t samples = len / channels;
+  for (size_t c = 0; c < channels; ++c) {
+    for (size_t t = 0; t < samples; ++t) dest[c * channel_stride + t] = interleaved[t * channels + c];
+    for (size_t t = samples; t < channel_stride; ++t) dest[c * channel_stride + t] = 0;
+  }
+}

@@ -268,6 +268,11 @@ size_t orc_write_stereo_frame(const orc_stereo_frame_result* fr, const int32_t* 
                               uint32_t bits_per_sample, uint32_t sample_rate, uint32_t frame_number,
                               const int32_t* residual0, const int32_t* residual1, uint8_t* out, size_t cap);
 
+/* ---- input side, src/arrayutils.rs ---- */
+void orc_le_bytes_to_i32s(const uint8_t* bytes, size_t nbytes, int32_t* dest, uint32_t bytes_per_sample);
+void orc_deinterleave(const int32_t* interleaved, size_t len, size_t channels, size_t channel_stride,
+                      int32_t* dest);
+
 double orc_bench_stereo_qlpc(const int32_t* frames, size_t n_frames, size_t n, size_t stride,
                              uint32_t bits_per_sample, const orc_qlpc_config* cfg, int nthreads,
                              int repeats, uint64_t* checksum_out);

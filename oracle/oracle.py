@@ -261,6 +261,10 @@ def _declare(L):
     L.orc_write_stereo_frame.restype = C.c_size_t
 
 
+    L.orc_le_bytes_to_i32s.argtypes = [u8p, C.c_size_t, i32p, C.c_uint32]
+    L.orc_deinterleave.argtypes = [i32p, C.c_size_t, C.c_size_t, C.c_size_t, i32p]
+
+
 def make_fixed_config(max_order=4, order_sel=ORDERSEL_APPROXENT, partitions=16,
                       sum_mode=SUMABS_STABLE) -> FixedConfig:
     """config::Fixed defaults: max_order 4 (constant.rs:95), ApproxEnt{16} (config.rs:411-417)."""
@@ -690,6 +694,23 @@ def write_stereo_frame(result, l, r, bps, sample_rate, frame_number, residual0, 
                                       _p(out, C.c_uint8), cap)
     assert ln <= cap
     return bytes(out[:ln])
+
+
+# ------------------------------------------------------ input side ----
+def le_bytes_to_i32s(data: bytes, bytes_per_sample: int) -> np.ndarray:
+    """le_bytes_to_i32s, src/arrayutils.rs:273-290."""
+    b = np.frombuffer(bytes(data), np.uint8).copy()
+    out = np.zeros(len(b) // bytes_per_sample, np.int32)
+    lib().orc_le_bytes_to_i32s(_p(b, C.c_uint8), len(b), _p(out, C.c_int32), bytes_per_sample)
+    return out
+
+
+def deinterleave(interleaved, channels: int, channel_stride: int, dest_len: int = None, fill: int = 0) -> np.ndarray:
+    """deinterleave, src/arrayutils.rs:248-264 -> flat dest (channels * channel_stride, or `dest_len`)."""
+    x = np.ascontiguousarray(interleaved, np.int32)
+    out = np.full(dest_len or channels * channel_stride, fill, np.int32)
+    lib().orc_deinterleave(_p(x, C.c_int32), len(x), channels, channel_stride, _p(out, C.c_int32))
+    return out
 
 
 def bench_qlpc(samples, bits_per_sample: int, cfg: QlpcConfig, nthreads: int, repeats: int = 1):

@@ -921,6 +921,23 @@ def test_frame_pipeline_soak(handle, order, bps, use_fixed):
     assert hist[3] > 0 and hist[0] > 0
 
 
+@pytest.mark.parametrize("channels,bytes_per_sample,total,block", [
+    (2, 2, 3 * 4096 + 1234, 4096), (1, 3, 5000, 1152), (8, 2, 4096, 4096), (3, 1, 777, 256), (2, 4, 9000, 4608),
+])
+def test_fill_le_bytes_equals_reference(handle, channels, bytes_per_sample, total, block):
+    """flacenc_hip_fill_le_bytes == le_bytes_to_i32s + deinterleave (arrayutils.rs:273-290, 248-264) per
+    FrameBuf (source.rs:288-298), incl. the zero-filled short last block."""
+    rng = np.random.default_rng(total)
+    data = rng.integers(0, 256, total * channels * bytes_per_sample, dtype=np.uint8).tobytes()
+    got = handle.fill_le_bytes(data, channels, bytes_per_sample, block)
+    ints = orc.le_bytes_to_i32s(data, bytes_per_sample)
+    nf = (total + block - 1) // block
+    assert got.shape == (nf, channels, block)
+    for f in range(nf):
+        chunk = ints[f * block * channels:(f + 1) * block * channels]
+        assert np.array_equal(got[f].reshape(-1), orc.deinterleave(chunk, channels, block)), f
+
+
 def test_encode_stereo_frames_rejects_bad_config(handle):
     x = np.zeros((2, 2, 4096), np.int32)
     with pytest.raises(_capi.FlacencHipError) as ei:

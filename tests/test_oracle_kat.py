@@ -657,3 +657,22 @@ def test_written_frames_parse_back_to_the_input():
         assert len(data) * 8 == (8 * 7 + sub_bits + 7) // 8 * 8 + 16   # header here is 7 bytes
         seen.update(got["kinds"])
     assert seen == {"constant", "verbatim", "fixed", "lpc"}
+
+
+# ------------------------------------------------- input side (arrayutils.rs) ----
+def test_do_deinterleave():
+    """src/arrayutils.rs:671-686."""
+    inter = [0, 0, -1, -2, 1, 2, -3, 6]
+    assert orc.deinterleave(inter, 2, 4).tolist() == [0, -1, 1, -3, 0, -2, 2, 6]
+    assert orc.deinterleave(inter, 4, 3, dest_len=12, fill=-123).tolist() == [0, 1, 0, 0, 2, 0, -1, -3, 0, -2, 6, 0]
+
+
+def test_convert_le_bytes_to_ints():
+    """src/arrayutils.rs:711-728 (3-byte and 1-byte samples)."""
+    b = bytes([0x56, 0x34, 0x12, 0x9B, 0x57, 0x13, 0xFF, 0xFF, 0xFF, 0xAC, 0x68, 0x24])
+    assert orc.le_bytes_to_i32s(b, 3).tolist() == [0x123456, 0x13579B, -1, 0x2468AC]
+    b = bytes([0x56, 0x34, 0x12, 0x9B, 0x80, 0x13, 0xFF, 0x68])
+    assert orc.le_bytes_to_i32s(b, 1).tolist() == [0x56, 0x34, 0x12, -0x65, -0x80, 0x13, -0x01, 0x68]
+    # the Fill doctest, src/source.rs:72-80
+    assert orc.deinterleave(orc.le_bytes_to_i32s(bytes([0x12, 0x34, 0x54, 0x76, 0x56, 0x78, 0x10, 0x32]), 2),
+                            2, 2).tolist() == [0x3412, 0x7856, 0x7654, 0x3210]

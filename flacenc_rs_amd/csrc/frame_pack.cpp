@@ -21,11 +21,13 @@ constexpr int kPackThreads = 256;
 // bit position b of the frame = bit (31 - b % 32) of word b / 32 (words are stored big-endian)
 __device__ __forceinline__ void put_bits(uint32_t* w, uint32_t bitpos, uint32_t value, uint32_t nbits) {
   if (nbits == 0) return;
-  const uint32_t word = bitpos >> 5, off = bitpos & 31u;
-  const unsigned long long v = (unsigned long long)value << (64u - off - nbits);
-  const uint32_t hi = (uint32_t)(v >> 32), lo = (uint32_t)v;
-  if (hi) atomicOr(&w[word], hi);
-  if (lo) atomicOr(&w[word + 1], lo);
+  const uint32_t word = bitpos >> 5, end = (bitpos & 31u) + nbits;  // 1..63: bits used from `word` on
+  if (end <= 32u) {
+    atomicOr(&w[word], value << (32u - end));
+  } else {
+    atomicOr(&w[word], value >> (end - 32u));
+    atomicOr(&w[word + 1], value << (64u - end));
+  }
 }
 
 __device__ __forceinline__ uint32_t zigzag32(int32_t v) {  // rice::encode_signbit, rice.rs:169-171

@@ -67,8 +67,9 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     n, F, bps = args.block_size, args.frames, args.bps
-    # precision 15, Tukey(0.4), max_p 30; candidates Constant / Verbatim / LPC (use_fixed off: the
-    # fixed-LPC candidate is not on the GPU path yet), all stereo assignments allowed
+    # precision 15, Tukey(0.4), max_p 30; candidates Constant / Verbatim / LPC -- the QLPC analysis path
+    # the metric names (--use-fixed adds the reference default's fixed-LPC candidate); all stereo
+    # assignments allowed
     cfg = _capi.make_frame_config(_capi.make_config(lpc_order=args.lpc_order), use_fixed=args.use_fixed)
     # synthetic "sigen" audio: Sine(200, 0.4) + Noise(0.4) like the reference's
     # stereo_frame_encoder_noisy_sine_lpc bench (src/coding.rs:1152), one continuous stream,

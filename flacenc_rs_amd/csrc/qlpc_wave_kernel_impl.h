@@ -8,13 +8,19 @@
 // = four 16-sample chunks = exactly one finest Rice partition, so
 //   * the autocorrelation tree is 2 in-lane levels + one 6-level lane butterfly
 //     (identical balanced tree over the chunk index -> same canonical sums),
-//   * Levinson + quantisation run redundantly on all lanes (no broadcast, no barrier),
-//   * the residual, its bit-sliced population counts and the partition's 32-entry
-//     bit table never leave the lane's registers,
+//   * Levinson + quantisation of the workgroup's four subframes run side by side on four
+//     lanes of one wave (a wave instruction costs the same for 1 or 64 lanes),
+//   * the residual, its bit-sliced population counts and the partition's bit table
+//     never leave the lane's registers,
 //   * orders 6..0 of the Rice search are a lane butterfly.
 // A workgroup is 4 waves: in stereo mode the four roles L, R, M, S of one frame
 // sharing the two channel images in LDS (HBM reads: each channel once); in plain
 // mode four independent subframes.
+//
+// Template switches: STEREO (roles of a 2-channel frame vs independent subframes), DECIDE
+// (encode_subframe's candidate choice, and try_stereo_coding's channel assignment when STEREO,
+// on the device: only the chosen residual rows are written), FIXED (the fixed-LPC candidate of
+// coding.rs:298-331 goes through the same Rice search in a rolled candidate loop).
 //
 // All `file:line` citations are relative to the flacenc-rs v0.5.1 tree.
 #ifndef FLACENC_HIP_QLPC_WAVE_KERNEL_IMPL_H_

@@ -938,6 +938,54 @@ def test_fill_le_bytes_equals_reference(handle, channels, bytes_per_sample, tota
         assert np.array_equal(got[f].reshape(-1), orc.deinterleave(chunk, channels, block)), f
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_frame_pipeline_config_fuzz(handle, seed):
+    """Random configurations (order, precision, window, Rice limit, candidate and stereo switches,
+    fixed-LPC selector settings, bits per sample, block size) x random material through
+    encode_stereo_frames + pack_stereo_frames, everything against the oracle.  Seeded, so a failure
+    names its configuration."""
+    rng = np.random.default_rng(9000 + seed)
+    for trial in range(5):
+        n = int(rng.choice([4096, 4096, 4096, 1152, 4608, 256, 2048]))
+        bps = int(rng.choice([8, 12, 16, 16, 20, 24]))
+        order = int(rng.choice([1, 2, 4, 6, 8, 8, 10, 12, 12, 16, 24]))
+        qcfg = dict(lpc_order=order, quant_precision=int(rng.integers(2, 16)),
+                    window=("rectangle" if rng.random() < 0.2 else ("tukey", float(np.round(rng.random(), 2)))),
+                    max_rice_parameter=int(rng.choice([0, 3, 7, 14, 15, 30, 30])))
+        flags = dict(use_constant=bool(rng.random() < 0.85), use_fixed=bool(rng.random() < 0.7),
+                     use_lpc=bool(rng.random() < 0.85), use_leftside=bool(rng.random() < 0.8),
+                     use_rightside=bool(rng.random() < 0.8), use_midside=bool(rng.random() < 0.8))
+        fixed = dict(fixed_max_order=int(rng.integers(0, 5)), fixed_order_sel=int(rng.random() < 0.75),
+                     fixed_partitions=int(rng.choice([1, 2, 4, 8, 16, 16, 32, 64, 3, 12])))
+        tag = (seed, trial, n, bps, qcfg, flags, fixed)
+        parts = []
+        for k in range(3):
+            amp = float(rng.choice([0.0, 0.002, 0.1, 0.5, 0.9]))
+            namp = float(min(0.99 - amp, rng.choice([0.0, 0.001, 0.05, 0.5])))
+            parts.append(_capi.sigen_frames(4, 2, n, bps, float(rng.uniform(2.2, 500.0)), amp, namp,
+                                            seed=int(rng.integers(1, 1 << 30))))
+        x = np.concatenate(parts)
+        x[1, 1] = x[1, 0]
+        x[5, 0] = -x[5, 1]
+        x[9] = x[9] // 256
+        cfg = _capi.make_frame_config(_capi.make_config(**qcfg), **flags, **fixed)
+        got, gres = handle.encode_stereo_frames(x, bps, cfg)
+        ocfg = orc.make_frame_config(orc.make_config(acorr=orc.ACORR_CANONICAL, **qcfg), **flags,
+                                     fixed=orc.make_fixed_config(max_order=fixed["fixed_max_order"],
+                                                                 order_sel=fixed["fixed_order_sel"],
+                                                                 partitions=fixed["fixed_partitions"],
+                                                                 sum_mode=orc.SUMABS_CANONICAL))
+        want, wres = orc.encode_stereo_frames_cfg(x, bps, ocfg)
+        try:
+            _check_frames_against_oracle(x, bps, got, gres, want, wres)
+            frames = handle.pack_stereo_frames(x, got, gres, bps, 48000, 1 << 20, 1)
+            for f in range(x.shape[0]):
+                assert frames[f] == orc.write_stereo_frame(got[f], x[f, 0], x[f, 1], bps, 48000, (1 << 20) + f,
+                                                           gres[f, 0], gres[f, 1]), f
+        except AssertionError as e:
+            raise AssertionError(f"configuration {tag}: {e}") from e
+
+
 def test_encode_stereo_frames_rejects_bad_config(handle):
     x = np.zeros((2, 2, 4096), np.int32)
     with pytest.raises(_capi.FlacencHipError) as ei:

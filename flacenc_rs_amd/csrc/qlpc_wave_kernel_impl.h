@@ -987,7 +987,9 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
   const bool leader = (lane & ((1 << bestk) - 1)) == 0;
   const uint32_t sum_p = wave_sum_dpp(leader ? my_p : 0u);
   const uint32_t p0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)my_p);
-  const uint32_t rice2 = wave_or_dpp(my_p > 14 ? 1u : 0u);
+  // (only the group leaders hold a parameter of the chosen order; the other lanes' my_p is whatever
+  // their meaningless merged tables minimised to)
+  const uint32_t rice2 = wave_or_dpp((leader && my_p > 14) ? 1u : 0u);
   const unsigned long long rem_bits = (unsigned long long)sum_p * (unsigned long long)(n >> rice_order) -
                                       (unsigned long long)warm * p0;
   sum_q = rr.saturated ? sat_sum_q

@@ -938,7 +938,10 @@ def test_fill_le_bytes_equals_reference(handle, channels, bytes_per_sample, tota
         assert np.array_equal(got[f].reshape(-1), orc.deinterleave(chunk, channels, block)), f
 
 
-@pytest.mark.parametrize("seed", range(6))
+# 1596 ..: seeds on which a sweep of 40 000 configurations (tools/fuzz_more.py) once found the RICE2
+# flag (bitrepr.rs:540-543) taken from lanes that lead no partition -- 20/24-bit material with
+# parameters around 14/15
+@pytest.mark.parametrize("seed", list(range(6)) + [1596, 3312, 4204, 4558, 4664, 5313])
 def test_frame_pipeline_config_fuzz(handle, seed):
     """Random configurations (order, precision, window, Rice limit, candidate and stereo switches,
     fixed-LPC selector settings, bits per sample, block size) x random material through

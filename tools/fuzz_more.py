@@ -1,0 +1,17 @@
+import os, sys, time
+root = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
+import test_gpu_parity as T
+from flacenc_rs_amd import _capi
+h = _capi.Handle(0)
+t0 = time.time(); bad = 0
+lo = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+hi = int(sys.argv[2]) if len(sys.argv) > 2 else 406
+for seed in range(lo, hi):
+    try:
+        T.test_frame_pipeline_config_fuzz(h, seed)
+    except AssertionError as e:
+        bad += 1
+        print("FAIL seed", seed, str(e)[:600], flush=True)
+        if bad > 5: break
+print("done", seed, "failures", bad, "in", round(time.time() - t0), "s")

@@ -989,6 +989,80 @@ def test_frame_pipeline_config_fuzz(handle, seed):
             raise AssertionError(f"configuration {tag}: {e}") from e
 
 
+@pytest.mark.parametrize("seed", range(4))
+def test_candidate_and_channel_api_fuzz(handle, seed):
+    """Random shapes and configurations through the candidate-level batches (qlpc_batch with
+    per-subframe bps, fixed_lpc_batch) and the independent-channel frame calls, against the oracle."""
+    rng = np.random.default_rng(7000 + seed)
+    for trial in range(4):
+        n = int(rng.choice([4096, 4096, 64, 100, 192, 576, 1152, 2304, 4608, 8192, 16384, 20000, 4097, 1000]))
+        bps = int(rng.choice([8, 12, 16, 16, 20, 24]))
+        order = int(rng.choice([1, 3, 8, 10, 12, 16, 24, 32]))
+        order = min(order, 32)
+        qcfg = dict(lpc_order=order, quant_precision=int(rng.integers(2, 16)),
+                    window=("rectangle" if rng.random() < 0.2 else ("tukey", float(np.round(rng.random(), 2)))),
+                    max_rice_parameter=int(rng.choice([0, 5, 14, 15, 30, 30])))
+        channels = int(rng.choice([1, 2, 3, 5, 8]))
+        nf = int(rng.integers(1, 4))
+        amp = float(rng.choice([0.0, 0.003, 0.2, 0.8]))
+        namp = float(min(0.99 - amp, rng.choice([0.0, 0.002, 0.1, 0.6])))
+        x = _capi.sigen_frames(nf, channels, n, bps, float(rng.uniform(2.2, 400.0)), amp, namp,
+                               seed=int(rng.integers(1, 1 << 30)))
+        if rng.random() < 0.3:
+            x[0, 0] = int(rng.integers(-100, 100))
+        tag = (seed, trial, n, bps, channels, nf, qcfg)
+        try:
+            # --- candidate level: every channel as an independent subframe, mixed bps ---
+            flat = x.reshape(-1, n)
+            bpsv = np.full(flat.shape[0], bps, np.uint8)
+            if bps < 24:
+                bpsv[::3] = bps + 1
+            params, resid, _, _ = handle.qlpc_batch(flat, bpsv, _capi.make_config(**qcfg))
+            ocfg = orc.make_config(acorr=orc.ACORR_CANONICAL, **qcfg)
+            for k in range(flat.shape[0]):
+                w = orc.estimated_qlpc(flat[k], int(bpsv[k]), ocfg)
+                p = params[k]
+                assert int(p["status"]) == w["status"], k
+                if w["status"] == 0:
+                    assert int(p["order"]) == w["order"] and int(p["shift"]) == w["shift"], k
+                    assert p["coefs"][: w["order"]].tolist() == w["coefs"].tolist(), k
+                    assert int(p["rice_order"]) == w["rice_order"] and int(p["code_bits"]) == w["code_bits"], k
+                    assert int(p["subframe_bits"]) == w["subframe_bits"] and int(p["sum_quotients"]) == w["sum_quotients"], k
+                    assert np.array_equal(resid[k], w["residual"]), k
+            fx = dict(fixed_max_order=int(rng.integers(0, 5)), fixed_order_sel=int(rng.random() < 0.7),
+                      fixed_partitions=int(rng.integers(1, 65)))
+            fcfg = _capi.make_frame_config(_capi.make_config(**qcfg), use_fixed=True, **fx)
+            fp, fr, fk = handle.fixed_lpc_batch(flat, bpsv, fcfg)
+            ofx = orc.make_fixed_config(max_order=fx["fixed_max_order"], order_sel=fx["fixed_order_sel"],
+                                        partitions=fx["fixed_partitions"], sum_mode=orc.SUMABS_CANONICAL)
+            for k in range(flat.shape[0]):
+                w = orc.fixed_lpc(flat[k], int(bpsv[k]), 2 ** 63, ofx, max_p=qcfg["max_rice_parameter"])
+                assert int(fp[k]["order"]) == w["order"] and int(fk[k]) == w["estimate"][w["order"]], (k, fx)
+                assert int(fp[k]["subframe_bits"]) == w["subframe_bits"] and np.array_equal(fr[k], w["residual"]), (k, fx)
+            # --- frame level, independent channels ---
+            flags = dict(use_constant=bool(rng.random() < 0.8), use_lpc=bool(rng.random() < 0.85))
+            fcfg = _capi.make_frame_config(_capi.make_config(**qcfg), use_fixed=bool(rng.random() < 0.7), **flags, **fx)
+            res, rr = handle.encode_frames(x, bps, fcfg)
+            ofc = orc.make_frame_config(ocfg, use_fixed=bool(fcfg.use_fixed), fixed=ofx, **flags)
+            packed = handle.pack_frames(x, res, rr, bps, 44100, 3, 2)
+            for f in range(nf):
+                subs = []
+                for c in range(channels):
+                    w = orc.encode_subframe(x[f, c], bps, ofc)
+                    g = res[f, c]
+                    assert int(g["kind"]) == w["kind"] and int(g["bits"]) == w["bits"], (f, c, fx, flags)
+                    if w["kind"] >= 2:
+                        assert np.array_equal(rr[f, c], w["residual"]), (f, c)
+                    pz = g["params"]
+                    subs.append(dict(kind=int(g["kind"]), bps=bps, samples=x[f, c], dc_offset=int(g["dc_offset"]),
+                                     order=int(pz["order"]), shift=int(pz["shift"]), precision=int(pz["precision"]),
+                                     coefs=pz["coefs"], rice_order=int(pz["rice_order"]), rice_params=pz["rice_params"],
+                                     residual=rr[f, c]))
+                assert packed[f] == orc.write_frame(n, 0, bps, 44100, 3 + 2 * f, subs), f
+        except AssertionError as e:
+            raise AssertionError(f"configuration {tag}: {e}") from e
+
+
 def test_encode_stereo_frames_rejects_bad_config(handle):
     x = np.zeros((2, 2, 4096), np.int32)
     with pytest.raises(_capi.FlacencHipError) as ei:

@@ -9,7 +9,10 @@ lo = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 hi = int(sys.argv[2]) if len(sys.argv) > 2 else 406
 for seed in range(lo, hi):
     try:
-        T.test_frame_pipeline_config_fuzz(h, seed)
+        if os.environ.get("FUZZ_KIND") == "channel":
+            T.test_candidate_and_channel_api_fuzz(h, seed)
+        else:
+            T.test_frame_pipeline_config_fuzz(h, seed)
     except AssertionError as e:
         bad += 1
         print("FAIL seed", seed, str(e)[:600], flush=True)

@@ -294,6 +294,8 @@ int flacenc_hip_fixed_lpc_batch_async(flacenc_hip_handle* h, const flacenc_hip_f
  *   out       frame f's bytes at out + f*out_stride; out_stride >= flacenc_hip_stereo_frame_bytes_bound
  *             (a multiple of 16; out 16-byte aligned); bytes beyond out_len[f] are unspecified
  *   out_len   [n_frames] byte length of each frame = Frame::count_bits / 8 (bitrepr.rs:275-287)
+ * The frame is assembled in LDS: frames whose worst case (flacenc_hip_*_frame_bytes_bound) exceeds
+ * 150 KiB -- e.g. 8 channels x 16384 samples x 24 bits -- are FLACENC_HIP_ERR_UNSUPPORTED.
  * sample_rate / bits_per_sample go into the header specs exactly as encode_frame_impl chooses them
  * (src/coding.rs:431-436); a rate or size without a code becomes "Unspecified".
  */

@@ -13,7 +13,7 @@ for seed in range(lo, hi):
             T.test_candidate_and_channel_api_fuzz(h, seed)
         else:
             T.test_frame_pipeline_config_fuzz(h, seed)
-    except AssertionError as e:
+    except Exception as e:
         bad += 1
         print("FAIL seed", seed, str(e)[:600], flush=True)
         if bad > 5: break

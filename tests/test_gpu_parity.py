@@ -1070,6 +1070,95 @@ def test_candidate_and_channel_api_fuzz(handle, seed):
             raise AssertionError(f"configuration {tag}: {e}") from e
 
 
+def _extreme_frames(rng, n, bps):
+    """Stereo frames built from worst-case material: full-scale alternation and square waves,
+    impulses, full-range ramps, clipped sines, one channel silent / constant / inverted."""
+    lo, hi = -(1 << (bps - 1)), (1 << (bps - 1)) - 1
+    t = np.arange(n)
+
+    def one():
+        k = int(rng.integers(0, 8))
+        if k == 0:
+            return np.where(t % 2 == 0, hi, lo)
+        if k == 1:
+            return np.where((t // int(rng.integers(1, 200))) % 2 == 0, hi, lo)
+        if k == 2:
+            x = np.zeros(n, np.int64)
+            x[rng.integers(0, n, int(rng.integers(1, 6)))] = rng.choice([lo, hi])
+            return x
+        if k == 3:
+            return np.linspace(lo, hi, n).astype(np.int64)
+        if k == 4:
+            return np.clip(np.sin(t / float(rng.uniform(1.5, 300.0))) * hi * float(rng.uniform(1.0, 4.0)), lo, hi).astype(np.int64)
+        if k == 5:
+            return np.full(n, int(rng.integers(lo, hi + 1)))
+        if k == 6:
+            return rng.integers(lo, hi + 1, n)
+        return (rng.integers(-3, 4, n)).cumsum().clip(lo, hi)
+
+    frames = []
+    for _ in range(6):
+        l, r = one(), one()
+        m = int(rng.integers(0, 5))
+        if m == 0:
+            r = l.copy()
+        elif m == 1:
+            r = np.clip(-l, lo, hi)
+        elif m == 2:
+            r = np.clip(l + rng.integers(-2, 3, n), lo, hi)
+        frames.append(np.stack([l, r]))
+    return np.stack(frames).astype(np.int32)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_extreme_signals_and_layout_fuzz(handle, seed):
+    """Worst-case material (the i64 residual path, saturating Rice tables, RICE2 parameters, constant
+    and verbatim subframes) through the device-pointer entry points with random row strides and
+    misaligned base pointers (which must push block-4096 work onto the general path), against the
+    oracle."""
+    import torch
+    rng = np.random.default_rng(5000 + seed)
+    for trial in range(4):
+        n = int(rng.choice([4096, 4096, 4096, 1152, 4608, 512]))
+        bps = int(rng.choice([8, 16, 16, 24]))
+        order = int(rng.choice([1, 4, 8, 12, 24]))
+        qcfg = dict(lpc_order=order, quant_precision=int(rng.integers(3, 16)),
+                    window=("rectangle" if rng.random() < 0.3 else ("tukey", float(np.round(rng.random(), 2)))),
+                    max_rice_parameter=int(rng.choice([0, 4, 14, 15, 30, 30])))
+        use_fixed = bool(rng.random() < 0.6)
+        fx = dict(fixed_max_order=int(rng.integers(0, 5)), fixed_order_sel=int(rng.random() < 0.7),
+                  fixed_partitions=int(rng.choice([1, 4, 16, 64, 7])))
+        x = _extreme_frames(rng, n, bps)
+        F = x.shape[0]
+        stride = n + int(rng.choice([0, 0, 4, 8, 3, 5]))
+        rstride = n + int(rng.choice([0, 0, 4, 1]))
+        off_in, off_out = int(rng.choice([0, 0, 4, 1, 2])), int(rng.choice([0, 0, 4, 3]))
+        tag = (seed, trial, n, bps, qcfg, use_fixed, fx, stride, rstride, off_in, off_out)
+        buf = torch.zeros(F * 2 * stride + 8, dtype=torch.int32, device="cuda")
+        view = buf[off_in:off_in + F * 2 * stride].view(F * 2, stride)
+        view[:, :n] = torch.from_numpy(x.reshape(F * 2, n)).cuda()
+        res = torch.zeros((F, 752), dtype=torch.uint8, device="cuda")
+        rbuf = torch.full((F * 2 * rstride + 8,), -7, dtype=torch.int32, device="cuda")
+        rview = rbuf[off_out:off_out + F * 2 * rstride].view(F * 2, rstride)
+        cfg = _capi.make_frame_config(_capi.make_config(**qcfg), use_fixed=use_fixed, **fx)
+        handle.encode_stereo_frames_device(cfg, view.data_ptr(), F, n, stride, bps, res.data_ptr(), rview.data_ptr(),
+                                           rstride, stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        got = np.frombuffer(res.cpu().numpy().tobytes(), dtype=_capi.FRAME_RESULT_DTYPE)
+        gres = rview[:, :n].cpu().numpy().reshape(F, 2, n)
+        ocfg = orc.make_frame_config(orc.make_config(acorr=orc.ACORR_CANONICAL, **qcfg), use_fixed=use_fixed,
+                                     fixed=orc.make_fixed_config(max_order=fx["fixed_max_order"], order_sel=fx["fixed_order_sel"],
+                                                                 partitions=fx["fixed_partitions"], sum_mode=orc.SUMABS_CANONICAL))
+        want, wres = orc.encode_stereo_frames_cfg(x, bps, ocfg)
+        try:
+            _check_frames_against_oracle(x, bps, got, gres, want, wres)
+            if rstride > n:
+                assert bool((rview[:, n:] == -7).all()), "wrote beyond the block"
+            _decode_frames(x, got, gres)
+        except AssertionError as e:
+            raise AssertionError(f"configuration {tag}: {e}") from e
+
+
 def test_encode_stereo_frames_rejects_bad_config(handle):
     x = np.zeros((2, 2, 4096), np.int32)
     with pytest.raises(_capi.FlacencHipError) as ei:

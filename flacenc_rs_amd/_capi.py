@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -180,6 +181,15 @@ def load() -> C.CDLL:
         raise FileNotFoundError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`"
             " or `make -C flacenc_rs_amd/csrc`")
+    # One HIP runtime per process: PyTorch ships its own libamdhip64 and the library links the
+    # system one under the same SONAME, so whichever is loaded first serves both.  PyTorch cannot
+    # work on the system copy ("No HIP GPUs are available"), the library is fine on PyTorch's --
+    # so in a process that will use both (tests, bench) PyTorch has to come first.
+    if "torch" not in sys.modules:
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     L = C.CDLL(LIB_PATH)
     vp, i32p, u8p, f64p = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p
     L.flacenc_hip_abi_version.restype = C.c_int

@@ -1,6 +1,8 @@
 import os, sys, time
 root = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
+import torch
+torch.cuda.init()  # before the library creates its own HIP context
 import test_gpu_parity as T
 from flacenc_rs_amd import _capi
 h = _capi.Handle(0)

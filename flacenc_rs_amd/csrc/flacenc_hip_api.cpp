@@ -8,6 +8,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -40,7 +41,7 @@ struct flacenc_hip_handle {
   hipStream_t stream = nullptr;
   std::string last_error;
   std::vector<WindowEntry> windows;
-  DeviceBuffer d_samples, d_residual, d_params, d_bps, d_autocorr, d_lpc, d_tables, d_keys, d_sel, d_results, d_out, d_outlen, d_cparams, d_cresid, d_fparams, d_fresid, d_fkeys, d_split;
+  DeviceBuffer d_samples, d_residual, d_params, d_bps, d_autocorr, d_lpc, d_tables, d_keys, d_sel, d_results, d_out, d_outlen, d_cparams, d_cresid, d_fparams, d_fresid, d_fkeys, d_split, d_presid;
   unsigned long long* stamps = nullptr;  // profiling hook, see flacenc_hip_debug_set_stamps
   unsigned long long* fixed_keys = nullptr;  // test hook, see flacenc_hip_debug_set_fixed_keys
 };
@@ -219,6 +220,7 @@ int enqueue(flacenc_hip_handle* h, const flacenc_hip_qlpc_config* cfg, const int
   a.forced_orders = nullptr;
   a.selector_keys = nullptr;
   a.lpc_stage = 0;
+  a.pack_out = nullptr;
   a.pred = nullptr;
   a.pred_out = nullptr;
   a.split_scratch = nullptr;
@@ -234,6 +236,33 @@ int enqueue(flacenc_hip_handle* h, const flacenc_hip_qlpc_config* cfg, const int
   }
   HIP_TRY(h, flacenc_hip::launch_qlpc(a, plan, stream));
   return FLACENC_HIP_OK;
+}
+
+// y = x^(8 per) mod P and its powers for the CRC-16 slice combination (see frame_pack.h)
+void fill_crc_powers(uint32_t lds_words, uint32_t* crc_per, uint16_t crc_pow[32]) {
+  auto mulmod = [](uint32_t x, uint32_t y) {
+    uint32_t r = 0;
+    for (int i = 15; i >= 0; --i) {
+      r <<= 1;
+      if (r & 0x10000u) r ^= 0x18005u;
+      if ((y >> i) & 1u) r ^= x;
+    }
+    return r & 0xFFFFu;
+  };
+  *crc_per = (lds_words * 4 + 255) / 256;
+  uint32_t y = 1;
+  for (uint32_t i = 0; i < 8 * *crc_per; ++i) y = mulmod(y, 2);  // times x
+  uint32_t acc = 1;
+  for (int i = 0; i < 16; ++i) {
+    crc_pow[i] = static_cast<uint16_t>(acc);
+    acc = mulmod(acc, y);
+  }
+  const uint32_t y16 = acc;  // y^16
+  acc = 1;
+  for (int i = 0; i < 16; ++i) {
+    crc_pow[16 + i] = static_cast<uint16_t>(acc);
+    acc = mulmod(acc, y16);
+  }
 }
 
 // FrameHeader's constant part for a launch (bitrepr.rs:373-419 as encode_frame_impl fills it,
@@ -369,6 +398,7 @@ int enqueue_fixed(flacenc_hip_handle* h, const flacenc_hip_frame_config* cfg, co
   a.forced_orders = nullptr;
   a.selector_keys = selector_keys;
   a.lpc_stage = 0;
+  a.pack_out = nullptr;
   a.pred = nullptr;
   a.pred_out = nullptr;
   a.split_scratch = nullptr;
@@ -410,6 +440,18 @@ int enqueue_fixed(flacenc_hip_handle* h, const flacenc_hip_frame_config* cfg, co
 
 }  // namespace
 
+struct PackTarget {  // optional: where the fused kernel puts the packed frames
+  uint8_t* out = nullptr;
+  size_t out_stride = 0;
+  uint32_t* out_len = nullptr;
+  uint32_t sample_rate = 0, first_frame_number = 0, frame_number_step = 1;
+};
+static int encode_stereo_frames_impl(flacenc_hip_handle* h, const flacenc_hip_frame_config* cfg,
+                                     const int32_t* frames, size_t n_frames, uint32_t block_size, size_t stride,
+                                     uint32_t bits_per_sample, flacenc_hip_stereo_frame_result* results,
+                                     int32_t* residual, size_t residual_stride, void* stream,
+                                     const PackTarget* pack, bool* packed);
+
 extern "C" {
 
 int flacenc_hip_abi_version(void) { return FLACENC_HIP_ABI_VERSION; }
@@ -446,7 +488,7 @@ void flacenc_hip_destroy(flacenc_hip_handle* h) {
     if (e.dev) (void)hipFree(e.dev);
   for (DeviceBuffer* b : {&h->d_samples, &h->d_residual, &h->d_params, &h->d_bps, &h->d_autocorr,
                           &h->d_lpc, &h->d_tables, &h->d_keys, &h->d_sel, &h->d_results, &h->d_out, &h->d_outlen, &h->d_cparams, &h->d_cresid,
-                          &h->d_fparams, &h->d_fresid, &h->d_fkeys, &h->d_split})
+                          &h->d_fparams, &h->d_fresid, &h->d_fkeys, &h->d_split, &h->d_presid})
     if (b->ptr) (void)hipFree(b->ptr);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -618,32 +660,7 @@ static int enqueue_pack(flacenc_hip_handle* h, const int32_t* frames, size_t n_f
   a.out_len = out_len;
   fill_header_specs(a, block_size, sample_rate, bits_per_sample);
   a.lds_words = static_cast<uint32_t>(bound / 4 + 4);
-  {
-    // y = x^(8 per) mod P and its powers (see frame_pack.h)
-    auto mulmod = [](uint32_t x, uint32_t y) {
-      uint32_t r = 0;
-      for (int i = 15; i >= 0; --i) {
-        r <<= 1;
-        if (r & 0x10000u) r ^= 0x18005u;
-        if ((y >> i) & 1u) r ^= x;
-      }
-      return r & 0xFFFFu;
-    };
-    a.crc_per = (static_cast<uint32_t>(a.lds_words) * 4 + 255) / 256;
-    uint32_t y = 1;
-    for (uint32_t i = 0; i < 8 * a.crc_per; ++i) y = mulmod(y, 2);  // times x
-    uint32_t acc = 1;
-    for (int i = 0; i < 16; ++i) {
-      a.crc_pow[i] = static_cast<uint16_t>(acc);
-      acc = mulmod(acc, y);
-    }
-    const uint32_t y16 = acc;  // y^16
-    acc = 1;
-    for (int i = 0; i < 16; ++i) {
-      a.crc_pow[16 + i] = static_cast<uint16_t>(acc);
-      acc = mulmod(acc, y16);
-    }
-  }
+  fill_crc_powers(a.lds_words, &a.crc_per, a.crc_pow);
   if (static_cast<size_t>(a.lds_words) * 4 > 150 * 1024) {
     h->last_error = "pack_stereo_frames: frame too large for the LDS bit buffer (block_size x bits_per_sample)";
     return FLACENC_HIP_ERR_UNSUPPORTED;
@@ -818,6 +835,8 @@ int flacenc_hip_encode_frames_async(flacenc_hip_handle* h, const flacenc_hip_fra
     a.forced_orders = nullptr;
     a.selector_keys = nullptr;
     a.lpc_stage = 0;
+    a.pack_out = nullptr;
+  a.pack_out = nullptr;
     a.pred = nullptr;
     a.pred_out = nullptr;
     a.split_scratch = nullptr;
@@ -1010,6 +1029,47 @@ int flacenc_hip_fill_le_bytes(flacenc_hip_handle* h, const uint8_t* bytes, uint6
   return FLACENC_HIP_OK;
 }
 
+int flacenc_hip_encode_pack_stereo_frames_async(flacenc_hip_handle* h, const flacenc_hip_frame_config* cfg,
+                                                const int32_t* frames, size_t n_frames, uint32_t block_size,
+                                                size_t stride, uint32_t bits_per_sample, uint32_t sample_rate,
+                                                uint32_t first_frame_number, uint32_t frame_number_step,
+                                                flacenc_hip_stereo_frame_result* results, uint8_t* out,
+                                                size_t out_stride, uint32_t* out_len, void* stream) {
+  if (!h || !cfg) return FLACENC_HIP_ERR_BAD_ARGUMENT;
+  if (n_frames == 0) return FLACENC_HIP_OK;
+  if (!out || !out_len || (reinterpret_cast<uintptr_t>(out) & 15) || (out_stride & 15) ||
+      out_stride < flacenc_hip_stereo_frame_bytes_bound(block_size, bits_per_sample)) {
+    h->last_error = "encode_pack_stereo_frames: out must be 16-byte aligned, out_stride a multiple of 16 and at least "
+                    "flacenc_hip_stereo_frame_bytes_bound";
+    return FLACENC_HIP_ERR_BAD_ARGUMENT;
+  }
+  const unsigned long long last = static_cast<unsigned long long>(first_frame_number) +
+                                  static_cast<unsigned long long>(n_frames - 1) * frame_number_step;
+  if (last >= (1ull << 31)) {
+    h->last_error = "encode_pack_stereo_frames: frame_number must be below 2^31";
+    return FLACENC_HIP_ERR_BAD_ARGUMENT;
+  }
+  // residual rows are only an intermediate here: handle scratch
+  int rc;
+  const size_t cstride = (static_cast<size_t>(block_size) + 3) & ~static_cast<size_t>(3);
+  if ((rc = ensure(h, h->d_presid, n_frames * 2 * cstride * 4)) != FLACENC_HIP_OK) return rc;
+  PackTarget pt;
+  pt.out = out;
+  pt.out_stride = out_stride;
+  pt.out_len = out_len;
+  pt.sample_rate = sample_rate;
+  pt.first_frame_number = first_frame_number;
+  pt.frame_number_step = frame_number_step;
+  bool packed = false;
+  rc = encode_stereo_frames_impl(h, cfg, frames, n_frames, block_size, stride, bits_per_sample, results,
+                                 static_cast<int32_t*>(h->d_presid.ptr), cstride, stream, &pt, &packed);
+  if (rc != FLACENC_HIP_OK || packed) return rc;
+  return flacenc_hip_pack_stereo_frames_async(h, frames, n_frames, block_size, stride, results,
+                                              static_cast<const int32_t*>(h->d_presid.ptr), cstride, bits_per_sample,
+                                              sample_rate, first_frame_number, frame_number_step, out, out_stride,
+                                              out_len, stream);
+}
+
 int flacenc_hip_synchronize(flacenc_hip_handle* h) {
   if (!h) return FLACENC_HIP_ERR_BAD_ARGUMENT;
   HIP_TRY(h, hipSetDevice(h->device));
@@ -1150,6 +1210,19 @@ int flacenc_hip_encode_stereo_frames_async(flacenc_hip_handle* h, const flacenc_
                                            size_t stride, uint32_t bits_per_sample,
                                            flacenc_hip_stereo_frame_result* results, int32_t* residual,
                                            size_t residual_stride, void* stream) {
+  return encode_stereo_frames_impl(h, cfg, frames, n_frames, block_size, stride, bits_per_sample, results, residual,
+                                   residual_stride, stream, nullptr, nullptr);
+}
+
+// `pack` non-null: if the launch can run as the fused kernel with the bit writer, the frames are
+// packed there (*packed = true, `residual` untouched); otherwise *packed = false and the call
+// behaves like flacenc_hip_encode_stereo_frames_async (the caller packs in a second launch).
+static int encode_stereo_frames_impl(flacenc_hip_handle* h, const flacenc_hip_frame_config* cfg,
+                                     const int32_t* frames, size_t n_frames, uint32_t block_size, size_t stride,
+                                     uint32_t bits_per_sample, flacenc_hip_stereo_frame_result* results,
+                                     int32_t* residual, size_t residual_stride, void* stream,
+                                     const PackTarget* pack, bool* packed) {
+  if (packed) *packed = false;
   if (!h || !cfg || (!results && n_frames)) return FLACENC_HIP_ERR_BAD_ARGUMENT;
   int rc = check_batch_args(h, &cfg->qlpc, frames, n_frames * 4, block_size, stride,
                             reinterpret_cast<flacenc_hip_subframe_params*>(results), residual, residual_stride);
@@ -1214,9 +1287,37 @@ int flacenc_hip_encode_stereo_frames_async(flacenc_hip_handle* h, const flacenc_
   a.forced_orders = nullptr;
   a.selector_keys = nullptr;
   a.lpc_stage = 0;
+  a.pack_out = nullptr;
   a.pred = nullptr;
   a.pred_out = nullptr;
   a.split_scratch = nullptr;
+  // The fused bit writer pays off when the fixed-LPC candidate is on (measured on MI355X, 8192 frames:
+  // 0.69 ms vs 0.53 + 0.22 ms in two launches); without it the packing tail -- two of the four waves
+  // busy, 8 waves per CU to hide the CRC's table latency -- costs more than the separate packer
+  // running at full occupancy (0.54 vs 0.30 + 0.22 ms), so that case stays two-stage.
+  // FLACENC_HIP_FUSED_PACK=0 / 1 overrides the choice (A/B timing).
+  bool want_fused = cfg->use_fixed != 0;
+  if (const char* ov = getenv("FLACENC_HIP_FUSED_PACK")) want_fused = ov[0] == '1';
+  if (pack && want_fused && !fixed_composite && flacenc_hip::wave_kernel_eligible(a)) {
+    const size_t bound = flacenc_hip_stereo_frame_bytes_bound(block_size, bits_per_sample);
+    flacenc_hip::FramePackArgs pa{};
+    fill_header_specs(pa, block_size, pack->sample_rate, bits_per_sample);
+    a.pack_out = pack->out;
+    a.pack_out_stride = pack->out_stride;
+    a.pack_out_len = pack->out_len;
+    a.pack_header_mid = pa.header_mid;
+    a.pack_extra_len = pa.extra_len;
+    for (int i = 0; i < 4; ++i) a.pack_extra[i] = pa.extra[i];
+    a.pack_first_frame = pack->first_frame_number;
+    a.pack_frame_step = pack->frame_number_step;
+    a.pack_lds_words = static_cast<uint32_t>(bound / 4 + 4);
+    fill_crc_powers(a.pack_lds_words, &a.pack_crc_per, a.pack_crc_pow);
+    if (static_cast<size_t>(a.pack_lds_words) * 4 <= 35424) {  // the bit buffer reuses the two channel images
+      if (packed) *packed = true;
+    } else {
+      a.pack_out = nullptr;
+    }
+  }
   if (!flacenc_hip::wave_kernel_eligible(a) || fixed_composite) {
     // General shapes: the same result from candidate batches (4 QLPC + 4 fixed-LPC candidates per
     // frame in handle scratch) and the stand-alone controller kernel (frame_decide.cpp).

@@ -13,51 +13,12 @@
 //     computed per thread over a slice of the bytes and combined with x^(8 * bytes after the slice).
 #include "frame_pack.h"
 
+#include "frame_bits.h"
+
 namespace flacenc_hip {
 namespace {
 
 constexpr int kPackThreads = 256;
-
-// bit position b of the frame = bit (31 - b % 32) of word b / 32 (words are stored big-endian)
-__device__ __forceinline__ void put_bits(uint32_t* w, uint32_t bitpos, uint32_t value, uint32_t nbits) {
-  if (nbits == 0) return;
-  const uint32_t word = bitpos >> 5, end = (bitpos & 31u) + nbits;  // 1..63: bits used from `word` on
-  if (end <= 32u) {
-    atomicOr(&w[word], value << (32u - end));
-  } else {
-    atomicOr(&w[word], value >> (end - 32u));
-    atomicOr(&w[word + 1], value << (64u - end));
-  }
-}
-
-__device__ __forceinline__ uint32_t zigzag32(int32_t v) {  // rice::encode_signbit, rice.rs:169-171
-  return ((uint32_t)v << 1) ^ (uint32_t)(v >> 31);
-}
-
-// a * b mod (x^16 + x^15 + x^2 + 1) over GF(2)
-__device__ __forceinline__ uint32_t gf_mulmod16(uint32_t a, uint32_t b) {
-  uint32_t r = 0;
-  for (int i = 15; i >= 0; --i) {
-    r <<= 1;
-    if (r & 0x10000u) r ^= 0x18005u;
-    if ((b >> i) & 1u) r ^= a;
-  }
-  return r & 0xFFFFu;
-}
-
-__device__ __forceinline__ uint32_t crc16_byte(uint32_t crc, uint32_t byte) {
-  crc ^= byte << 8;
-#pragma unroll
-  for (int b = 0; b < 8; ++b) crc = (crc & 0x8000u) ? ((crc << 1) ^ 0x8005u) & 0xFFFFu : (crc << 1) & 0xFFFFu;
-  return crc;
-}
-
-__device__ __forceinline__ uint32_t crc8_byte(uint32_t crc, uint32_t byte) {
-  crc ^= byte;
-#pragma unroll
-  for (int b = 0; b < 8; ++b) crc = (crc & 0x80u) ? ((crc << 1) ^ 0x07u) & 0xFFu : (crc << 1) & 0xFFu;
-  return crc;
-}
 
 // block-wide exclusive prefix sum of one value per thread (256 threads); `total` gets the sum
 __device__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* scratch, int tid, uint32_t* total) {

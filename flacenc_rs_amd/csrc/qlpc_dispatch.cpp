@@ -73,7 +73,8 @@ hipError_t launch_qlpc(const QlpcKernelArgs& a, const QlpcLaunchPlan& plan, hipS
   if ((a.frame_results || a.chan_results) && !wave_kernel_eligible(a)) return hipErrorNotSupported;
   if (wave_kernel_eligible(a)) {
     const int mp = a.lpc_order <= 8 ? 8 : (a.lpc_order <= 10 ? 10 : 12);
-    const int variant = a.stereo ? (a.frame_results ? (a.use_fixed ? 3 : 2) : 1) : (a.chan_results ? 4 : 0);
+    const int variant = a.stereo ? (a.frame_results ? (a.pack_out ? 5 : (a.use_fixed ? 3 : 2)) : 1)
+                                 : (a.chan_results ? 4 : 0);
 #define FLACENC_HIP_WCASE(MP, ST) \
   if (mp == MP && variant == ST) return launch_qlpc_wave_##MP##_##ST(a, stream);
     FLACENC_HIP_FOR_EACH_WAVE_INSTANCE(FLACENC_HIP_WCASE)

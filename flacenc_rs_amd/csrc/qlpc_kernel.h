@@ -60,6 +60,16 @@ struct QlpcKernelArgs {
   const int32_t* pred;
   int32_t* pred_out;
   void* split_scratch;  // device, n * (33 * 8 + 36 * 4) bytes, or nullptr: no split
+  // Frame::write fused into the deciding wave kernel (variant 5): non-null pack_out selects it.
+  // Header constants and CRC combination powers as in FramePackArgs (frame_pack.h).
+  uint8_t* pack_out;          // device, 16-byte aligned; frame f at pack_out + f*pack_out_stride
+  size_t pack_out_stride;     // multiple of 16
+  uint32_t* pack_out_len;     // device, [n_frames]
+  uint32_t pack_header_mid, pack_extra_len;
+  uint8_t pack_extra[4];
+  uint32_t pack_first_frame, pack_frame_step;
+  uint32_t pack_lds_words, pack_crc_per;
+  uint16_t pack_crc_pow[32];
 };
 
 struct QlpcLaunchPlan {
@@ -85,8 +95,8 @@ hipError_t launch_qlpc(const QlpcKernelArgs& args, const QlpcLaunchPlan& plan, h
 FLACENC_HIP_FOR_EACH_INSTANCE(FLACENC_HIP_DECLARE_INSTANCE)
 
 #define FLACENC_HIP_FOR_EACH_WAVE_INSTANCE(X) \
-  X(8, 0) X(8, 1) X(8, 2) X(8, 3) X(8, 4) X(10, 0) X(10, 1) X(10, 2) X(10, 3) X(10, 4) \
-  X(12, 0) X(12, 1) X(12, 2) X(12, 3) X(12, 4)
+  X(8, 0) X(8, 1) X(8, 2) X(8, 3) X(8, 4) X(8, 5) X(10, 0) X(10, 1) X(10, 2) X(10, 3) X(10, 4) X(10, 5) \
+  X(12, 0) X(12, 1) X(12, 2) X(12, 3) X(12, 4) X(12, 5)
 #define FLACENC_HIP_DECLARE_WAVE_INSTANCE(MP, ST) \
   hipError_t launch_qlpc_wave_##MP##_##ST(const QlpcKernelArgs&, hipStream_t);
 FLACENC_HIP_FOR_EACH_WAVE_INSTANCE(FLACENC_HIP_DECLARE_WAVE_INSTANCE)

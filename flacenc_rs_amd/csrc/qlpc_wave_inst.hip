@@ -1,7 +1,8 @@
 // qlpc_wave_inst.hip -- one instantiation of the wave-per-subframe kernel per translation
 // unit (compiled with -DFLACENC_MAXP=<8|10|12> -DFLACENC_STEREO=<0|1|2|3|4>; 2 = stereo with the
 // on-device candidate / channel-assignment decision, 3 = 2 + the fixed-LPC candidate, 4 = independent
-// channels with encode_subframe's decision and the fixed-LPC candidate).
+// channels with encode_subframe's decision and the fixed-LPC candidate, 5 = 3 + Frame::write in the
+// kernel: packed frame bytes instead of residual rows).
 #include "qlpc_wave_kernel_impl.h"
 
 #define FLACENC_CAT2(a, b, c) launch_qlpc_wave_##a##_##b
@@ -9,6 +10,7 @@
 
 namespace flacenc_hip {
 hipError_t FLACENC_CAT(FLACENC_MAXP, FLACENC_STEREO)(const QlpcKernelArgs& a, hipStream_t stream) {
-  return launch_wave4096<FLACENC_MAXP, (FLACENC_STEREO != 0 && FLACENC_STEREO != 4), (FLACENC_STEREO >= 2), (FLACENC_STEREO >= 3)>(a, stream);
+  return launch_wave4096<FLACENC_MAXP, (FLACENC_STEREO != 0 && FLACENC_STEREO != 4), (FLACENC_STEREO >= 2), (FLACENC_STEREO >= 3),
+                         (FLACENC_STEREO == 5)>(a, stream);
 }
 }  // namespace flacenc_hip

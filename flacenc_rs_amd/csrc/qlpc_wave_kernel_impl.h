@@ -28,6 +28,7 @@
 
 #include <type_traits>
 
+#include "frame_bits.h"
 #include "qlpc_kernel_impl.h"
 
 namespace flacenc_hip {
@@ -77,6 +78,18 @@ __device__ __forceinline__ uint32_t wave_sum_dpp(uint32_t v) {
   v += FLACENC_DPP(v, 0x142, 0xA);
   v += FLACENC_DPP(v, 0x143, 0xC);
   return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// exclusive prefix sum over the 64 lanes (same DPP row scan as wave_sum_dpp)
+__device__ __forceinline__ uint32_t wave_excl_scan_dpp(uint32_t v) {
+  uint32_t s = v;
+  s += FLACENC_DPP(s, 0x111, 0xF);
+  s += FLACENC_DPP(s, 0x112, 0xF);
+  s += FLACENC_DPP(s, 0x114, 0xF);
+  s += FLACENC_DPP(s, 0x118, 0xF);
+  s += FLACENC_DPP(s, 0x142, 0xA);
+  s += FLACENC_DPP(s, 0x143, 0xC);
+  return s - v;
 }
 
 __device__ __forceinline__ uint32_t wave_or_dpp(uint32_t v) {
@@ -352,8 +365,9 @@ __device__ __forceinline__ RiceResult rice_search(const PlaneSums& ps, const int
 // DECIDE (stereo only): run encode_subframe's candidate choice and try_stereo_coding's channel
 // assignment (coding.rs:384-418 without the fixed-LPC candidate, :493-522) on the device and
 // write one flacenc_hip_stereo_frame_result + the TWO chosen residual rows per frame.
-template <int MAXP, bool STEREO, bool DECIDE, bool FIXED>
+template <int MAXP, bool STEREO, bool DECIDE, bool FIXED, bool PACK>
 __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(QlpcKernelArgs a) {
+  static_assert(!PACK || (STEREO && DECIDE && FIXED), "the fused bit writer extends the full stereo frame kernel");
   // DECIDE with STEREO: encode_frame for a 2-channel frame (four roles + try_stereo_coding);
   // DECIDE without: encode_subframe for four independent channels (Independent(n) frames)
   static_assert(!FIXED || DECIDE, "the fixed-LPC candidate only exists inside encode_subframe's decision");
@@ -1023,6 +1037,29 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
 
   flacenc_hip_subframe_params* rec = a.params ? a.params + sf : nullptr;
   bool fixed_record = false;
+  int32_t pack_wsmp = 0;
+  // a FixedLpc subframe was chosen: from here on the predictor / Rice variables describe it --
+  // FIXED_LPC_COEFS[order] with shift 0 (decode.rs:179-201) and the Rice partition of its error signal
+  auto use_fixed_record = [&]() {
+    bestk = fx.bestk;
+    rice_order = 6 - bestk;
+    best_parts = 1 << rice_order;
+    my_p = fx.my_p;
+    best_bits = fx.code_bits;
+    sum_q = fx.sum_q;
+    sub_bits = fx.sub_bits;
+    warm = fx.order;
+    shift = 0;
+    status = 0;
+    fixed_record = true;
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i) cq[i] = 0;
+    const int o = fx.order;
+    cq[0] = o;  // 0, 1, 2, 3, 4
+    cq[1] = o == 2 ? -1 : (o == 3 ? -3 : (o == 4 ? -6 : 0));
+    cq[2] = o == 3 ? 1 : (o == 4 ? 4 : 0);
+    cq[3] = o == 4 ? -1 : 0;
+  };
   if (DECIDE) {
     // ---- encode_subframe for this role (coding.rs:384-418) ----
     const bool is_const = a.use_constant && (role_max == role_min);
@@ -1154,8 +1191,169 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
         for (int k = 0; k < 4; ++k)
           if (lane == 0 && k < fx.order) e[k] = 0;
       }
+      if (PACK && slot >= 0) {
+        // the bit buffer will reuse the image area: keep what the writer still needs from it --
+        // the warm-up samples (lane i < 16 holds sample i) and a Verbatim subframe's samples
+        with_role([&](auto kind_tag) {
+          const int4 q = ld4k(kind_tag, lane < 16 ? (lane & ~3) : 0);
+          pack_wsmp = (lane & 3) == 0 ? q.x : ((lane & 3) == 1 ? q.y : ((lane & 3) == 2 ? q.z : q.w));
+          if (kind == 1u) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+              const int4 v4 = ld4k(kind_tag, tl + 4 * k);
+              e[4 * k + 0] = v4.x;
+              e[4 * k + 1] = v4.y;
+              e[4 * k + 2] = v4.z;
+              e[4 * k + 3] = v4.w;
+            }
+          }
+        });
+      }
       __syncthreads();
     }
+    if (PACK) {
+      // ================= Frame::write (bitrepr.rs:289-319) in the workgroup =================
+      // Same construction as frame_pack.cpp: every field is OR-ed into a zeroed LDS bit buffer at its
+      // final position; here a lane's 64 residuals are still in its registers.
+      uint32_t* const words = reinterpret_cast<uint32_t*>(sm);  // over the two channel images
+      uint16_t* const crc_tab = reinterpret_cast<uint16_t*>(sm + NIMG * kBufDwords);  // exchange area
+      const unsigned long long bits0 = role0 == 0 ? bl : (role0 == 2 ? bm : bs);
+      for (uint32_t i = (uint32_t)tid; i < a.pack_lds_words / 4u; i += 256u)
+        reinterpret_cast<int4*>(words)[i] = make_int4(0, 0, 0, 0);
+      crc_tab[tid] = (uint16_t)crc16_byte(0u, (uint32_t)tid);
+      __syncthreads();
+      const uint32_t frame_number = a.pack_first_frame + blk * a.pack_frame_step;
+      const uint32_t code_bits_fn = frame_number ? 32u - (uint32_t)__builtin_clz(frame_number) : 0u;
+      const uint32_t utf8_len = code_bits_fn <= 7 ? 1u : 1u + (code_bits_fn - 2u) / 5u;
+      const uint32_t header_bytes = 4u + utf8_len + a.pack_extra_len + 1u;
+      if (wave == 0 && lane == 0) {  // FrameHeader::write, bitrepr.rs:373-419
+        uint8_t hdr[16];
+        uint32_t hn = 0;
+        const uint32_t channel_tag = assignment == 0 ? 1u : 7u + (uint32_t)assignment;
+        hdr[hn++] = 0xFF;
+        hdr[hn++] = 0xF8;
+        hdr[hn++] = (uint8_t)(a.pack_header_mid >> 8);
+        hdr[hn++] = (uint8_t)((channel_tag << 4) | (a.pack_header_mid & 0x0Fu));
+        if (utf8_len == 1) {
+          hdr[hn++] = (uint8_t)frame_number;
+        } else {
+          const uint32_t trailing = utf8_len - 1u, first_bits = 6u - trailing;
+          hdr[hn++] = (uint8_t)(((0xFFu << (8u - trailing - 1u)) & 0xFFu) |
+                                ((frame_number >> (6u * trailing)) & ((1u << first_bits) - 1u)));
+          for (uint32_t i = 0; i < trailing; ++i)
+            hdr[hn++] = (uint8_t)(0x80u | ((frame_number >> (6u * (trailing - 1u - i))) & 0x3Fu));
+        }
+        for (uint32_t i = 0; i < a.pack_extra_len; ++i) hdr[hn++] = a.pack_extra[i];
+        uint32_t crc = 0;
+        for (uint32_t i = 0; i < hn; ++i) crc = crc8_byte(crc, hdr[i]);
+        hdr[hn++] = (uint8_t)crc;
+        for (uint32_t i = 0; i < hn; ++i) put_bits(words, 8u * i, hdr[i], 8u);
+      }
+      if (slot >= 0) {
+        const uint32_t sub_base = header_bytes * 8u + (slot == 1 ? (uint32_t)bits0 : 0u);
+        const uint32_t sbps = (uint32_t)bps_role;
+        const uint32_t bps_mask = (1u << sbps) - 1u;  // sbps <= 25
+        if (kind == 0u) {  // Constant, bitrepr.rs:449-454
+          if (lane == 0) put_bits(words, sub_base + 8u, (uint32_t)role_max & bps_mask, sbps);
+        } else if (kind == 1u) {  // Verbatim, bitrepr.rs:463-470
+          if (lane == 0) put_bits(words, sub_base, 0x02u, 8u);
+#pragma unroll
+          for (int k = 0; k < 64; ++k)
+            put_bits(words, sub_base + 8u + (uint32_t)(tl + k) * sbps, (uint32_t)e[k] & bps_mask, sbps);
+        } else {
+          if (kind == 2u) use_fixed_record();
+          const uint32_t order = (uint32_t)warm;
+          const uint32_t precision = fixed_record ? 0u : a.precision;
+          const uint32_t head_bits = 8u + order * sbps + (kind == 3u ? 9u + order * precision : 0u);
+          if ((uint32_t)lane < order) put_bits(words, sub_base + 8u + (uint32_t)lane * sbps, (uint32_t)pack_wsmp & bps_mask, sbps);
+          if (kind == 3u && lane >= 16 && (uint32_t)(lane - 16) < order) {
+            int32_t c = 0;
+#pragma unroll
+            for (int i = 0; i < MAXP; ++i)
+              if (i == lane - 16) c = cq[i];
+            put_bits(words, sub_base + 8u + order * sbps + 9u + (uint32_t)(lane - 16) * precision,
+                     (uint32_t)c & ((1u << precision) - 1u), precision);
+          }
+          if (lane == 32) {  // FixedLpc::write bitrepr.rs:479-487 / Lpc::write :501-527
+            put_bits(words, sub_base, kind == 3u ? (0x40u | ((order - 1u) << 1)) : (0x10u | (order << 1)), 8u);
+            if (kind == 3u) {
+              put_bits(words, sub_base + 8u + order * sbps, precision - 1u, 4u);
+              put_bits(words, sub_base + 8u + order * sbps + 4u, (uint32_t)shift & 31u, 5u);
+            }
+          }
+          // Residual::write, bitrepr.rs:550-597: a partition of the chosen order = 2^bestk lanes
+          const bool pleader = (lane & ((1 << bestk) - 1)) == 0;
+          const uint32_t r2 = wave_or_dpp((pleader && my_p > 14) ? 1u : 0u);
+          const uint32_t pbits = r2 ? 5u : 4u;
+          if (lane == 33) put_bits(words, sub_base + head_bits, (r2 << 4) | (uint32_t)(6 - bestk), 6u);
+          const uint32_t gp = (uint32_t)__shfl((int)my_p, lane & ~((1 << bestk) - 1), 64);
+          uint32_t my_bits = pleader ? pbits : 0u;
+#pragma unroll
+          for (int k = 0; k < 64; ++k) {
+            const bool coded = k >= 16 || lane != 0 || k >= warm;  // the warm-up slots are not coded
+            my_bits += coded ? (zigzag32(e[k]) >> gp) + 1u + gp : 0u;
+          }
+          uint32_t pos = sub_base + head_bits + 6u + wave_excl_scan_dpp(my_bits);
+          if (pleader) {
+            put_bits(words, pos, gp, pbits);
+            pos += pbits;
+          }
+#pragma unroll
+          for (int k = 0; k < 64; ++k) {
+            const bool coded = k >= 16 || lane != 0 || k >= warm;
+            if (coded) {
+              const uint32_t u = zigzag32(e[k]);
+              pos += u >> gp;  // unary quotient: zeros
+              put_bits(words, pos, (u & ((1u << gp) - 1u)) | (1u << gp), gp + 1u);
+              pos += gp + 1u;
+            }
+          }
+        }
+      }
+      __syncthreads();
+      // align_to_byte + CRC-16 (bitrepr.rs:306-316), slices combined as in frame_pack.cpp
+      const uint32_t total_bits = header_bytes * 8u + (uint32_t)bits0 +
+                                  (uint32_t)(role1 == 1 ? br : bs);
+      const uint32_t body_bytes = (total_bits + 7u) >> 3;
+      {
+        const uint32_t per = a.pack_crc_per;
+        const uint32_t k_after = (uint32_t)(255 - tid);
+        const uint32_t after = k_after * per;
+        uint32_t crc = 0;
+        if (after < body_bytes) {
+          const uint32_t hi = body_bytes - after;
+          const uint32_t lo = hi > per ? hi - per : 0u;
+          for (uint32_t i = lo; i < hi; ++i) {
+            const uint32_t byte = (words[i >> 2] >> (24u - 8u * (i & 3u))) & 0xFFu;
+            crc = ((crc << 8) & 0xFFFFu) ^ crc_tab[(crc >> 8) ^ byte];
+          }
+          crc = gf_mulmod16(crc, a.pack_crc_pow[k_after & 15u]);
+          crc = gf_mulmod16(crc, a.pack_crc_pow[16u + (k_after >> 4)]);
+        }
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) crc ^= (uint32_t)__shfl_xor((int)crc, d, 64);
+        __syncthreads();  // every thread is done with crc_tab's neighbours? (crc_tab is read-only here)
+        if (lane == 0) crc_tab[256 + wave] = (uint16_t)crc;  // 576-byte exchange area: 288 uint16
+      }
+      __syncthreads();
+      const uint32_t frame_bytes = body_bytes + 2u;
+      if (tid == 0) {
+        const uint32_t crc = (uint32_t)crc_tab[256] ^ crc_tab[257] ^ crc_tab[258] ^ crc_tab[259];
+        put_bits(words, body_bytes * 8u, crc, 16u);
+        a.pack_out_len[blk] = frame_bytes;
+      }
+      __syncthreads();
+      int4* __restrict__ dstp = reinterpret_cast<int4*>(a.pack_out + (size_t)blk * a.pack_out_stride);
+      const uint32_t nquads = (frame_bytes + 15u) >> 4;
+      for (uint32_t i = (uint32_t)tid; i < nquads; i += 256u) {
+        int4 v4 = reinterpret_cast<const int4*>(words)[i];
+        v4.x = (int)__builtin_bswap32((uint32_t)v4.x);
+        v4.y = (int)__builtin_bswap32((uint32_t)v4.y);
+        v4.z = (int)__builtin_bswap32((uint32_t)v4.z);
+        v4.w = (int)__builtin_bswap32((uint32_t)v4.w);
+        dstp[i] = v4;
+      }
+    } else {
     if (slot >= 0) {
       if (kind < 2u) {
 #pragma unroll
@@ -1180,6 +1378,7 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
         *reinterpret_cast<int4*>(dst0 + (size_t)ch * a.residual_stride + t) = v;
       }
     }
+    }  // !PACK
     rec = (slot >= 0) ? &fr->lpc[slot] : nullptr;
     if (rec != nullptr && kind < 2u) {
       // neither an LPC nor a FixedLpc subframe: blank record
@@ -1188,27 +1387,7 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
       rec = nullptr;
     }
     }  // STEREO
-    if (FIXED && rec != nullptr && kind == 2u) {
-      // the record of a FixedLpc subframe: FIXED_LPC_COEFS[order] with shift 0 (decode.rs:179-201)
-      bestk = fx.bestk;
-      rice_order = 6 - bestk;
-      best_parts = 1 << rice_order;
-      my_p = fx.my_p;
-      best_bits = fx.code_bits;
-      sum_q = fx.sum_q;
-      sub_bits = fx.sub_bits;
-      warm = fx.order;
-      shift = 0;
-      status = 0;
-      fixed_record = true;
-#pragma unroll
-      for (int i = 0; i < MAXP; ++i) cq[i] = 0;
-      const int o = fx.order;
-      cq[0] = o;                                        // 0, 1, 2, 3, 4
-      cq[1] = o == 2 ? -1 : (o == 3 ? -3 : (o == 4 ? -6 : 0));
-      cq[2] = o == 3 ? 1 : (o == 4 ? 4 : 0);
-      cq[3] = o == 4 ? -1 : 0;
-    }
+    if (FIXED && rec != nullptr && kind == 2u) use_fixed_record();
   }
   if (rec != nullptr) {
     {
@@ -1245,9 +1424,9 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
   }
 }
 
-template <int MAXP, bool STEREO, bool DECIDE, bool FIXED>
+template <int MAXP, bool STEREO, bool DECIDE, bool FIXED, bool PACK>
 hipError_t launch_wave4096(const QlpcKernelArgs& a, hipStream_t stream) {
-  auto kern = qlpc_wave4096_kernel<MAXP, STEREO, DECIDE, FIXED>;
+  auto kern = qlpc_wave4096_kernel<MAXP, STEREO, DECIDE, FIXED, PACK>;
   constexpr size_t smem = (size_t)(STEREO ? 3 : 4) * kBufDwords * 4 + 4 * (((MAXP + 2) & ~1) * 8 + 64);  // images (+ window) + exchange
   static bool configured = false;
   if (!configured) {

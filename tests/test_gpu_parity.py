@@ -1159,6 +1159,48 @@ def test_extreme_signals_and_layout_fuzz(handle, seed):
             raise AssertionError(f"configuration {tag}: {e}") from e
 
 
+@pytest.mark.parametrize("n,bps,order,use_fixed,first,step", [
+    (4096, 16, 8, True, 0, 1), (4096, 16, 12, False, 1 << 21, 3), (4096, 24, 10, True, 100, 1),
+    (4096, 8, 8, True, 5, 1), (1152, 16, 8, True, 0, 1), (4096, 16, 16, True, 7, 1),
+])
+def test_fused_encode_and_pack_equals_two_stage_path(handle, monkeypatch, n, bps, order, use_fixed, first, step):
+    """flacenc_hip_encode_pack_stereo_frames_async (for 4096-sample blocks one kernel: the residual
+    never reaches HBM) == encode_stereo_frames followed by pack_stereo_frames == the oracle's
+    controller and bit writer, for every subframe kind and channel assignment."""
+    import torch
+    monkeypatch.setenv("FLACENC_HIP_FUSED_PACK", "1")   # also without the fixed-LPC candidate (default: two-stage there)
+    x = np.ascontiguousarray(_fixed_corpus()[:, :, :n])
+    if bps == 24:
+        x = (x.astype(np.int64) * 181).astype(np.int32)
+        x[4] = np.stack([util.quantize(util.noise(21, n, 0.999), 24), util.quantize(util.noise(22, n, 0.999), 24)])
+    if bps == 8:
+        x = (x // 256).astype(np.int32)
+    F = x.shape[0]
+    cfg = _capi.make_frame_config(gpu_cfg(order), use_fixed=use_fixed)
+    xs = torch.from_numpy(x).cuda()
+    res = torch.zeros((F, 752), dtype=torch.uint8, device="cuda")
+    stride = handle.frame_bytes_bound(n, bps)
+    out = torch.zeros((F, stride), dtype=torch.uint8, device="cuda")
+    lens = torch.zeros(F, dtype=torch.int32, device="cuda")
+    handle.encode_pack_stereo_frames_device(cfg, xs.data_ptr(), F, n, n, bps, 44100, first, step, res.data_ptr(),
+                                            out.data_ptr(), stride, lens.data_ptr(),
+                                            stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = np.frombuffer(res.cpu().numpy().tobytes(), dtype=_capi.FRAME_RESULT_DTYPE)
+    o, ln = out.cpu().numpy(), lens.cpu().numpy()
+    want, wres = handle.encode_stereo_frames(x, bps, cfg)
+    frames = handle.pack_stereo_frames(x, want, wres, bps, 44100, first, step)
+    kinds = set()
+    for f in range(F):
+        assert got[f].tobytes() == want[f].tobytes(), f
+        assert bytes(o[f, :ln[f]]) == frames[f], (f, int(ln[f]), len(frames[f]))
+        assert frames[f] == orc.write_stereo_frame(want[f], x[f, 0], x[f, 1], bps, 44100, first + f * step,
+                                                   wres[f, 0], wres[f, 1]), f
+        kinds.update(want[f]["kind"].tolist())
+    if n == 4096 and bps != 8:
+        assert kinds >= ({0, 1, 2, 3} if use_fixed else {0, 1, 3})
+
+
 def test_encode_stereo_frames_rejects_bad_config(handle):
     x = np.zeros((2, 2, 4096), np.int32)
     with pytest.raises(_capi.FlacencHipError) as ei:

@@ -45,10 +45,23 @@ def pack():
                                 out.data_ptr(), stride, lens.data_ptr(), stream=st.cuda_stream)
 
 
+def fused():
+    h.encode_pack_stereo_frames_device(cfg, x.data_ptr(), F, n, n, bps, 44100, 0, 1, res.data_ptr(), out.data_ptr(),
+                                       stride, lens.data_ptr(), stream=st.cuda_stream)
+
+
 for _ in range(3):
     enc()
     pack()
+    fused()
 torch.cuda.synchronize()
+evf = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+for k in range(args.steps):
+    evf[k].record(st)
+    fused()
+evf[args.steps].record(st)
+torch.cuda.synchronize()
+t_fused = evf[0].elapsed_time(evf[args.steps]) / args.steps
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(3 * args.steps)]
 for k in range(args.steps):
     ev[3 * k].record(st)
@@ -63,7 +76,8 @@ total_bytes = int(lens.sum().item())
 samples = F * 2 * n
 print(json.dumps({
     "frames": F, "use_fixed": args.use_fixed,
-    "encode_ms": round(t_enc, 4), "pack_ms": round(t_pack, 4),
+    "encode_ms": round(t_enc, 4), "pack_ms": round(t_pack, 4), "encode_pack_one_call_ms": round(t_fused, 4),
+    "encode_pack_one_call_Msamples_per_s": round(samples / (t_fused * 1e-3) / 1e6, 1),
     "pipeline_Msamples_per_s": round(samples / ((t_enc + t_pack) * 1e-3) / 1e6, 1),
     "pack_Msamples_per_s": round(samples / (t_pack * 1e-3) / 1e6, 1),
     "flac_bytes": total_bytes, "compression_ratio": round(total_bytes / (samples * bps / 8), 4),

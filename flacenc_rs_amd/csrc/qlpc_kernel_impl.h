@@ -999,7 +999,9 @@ qlpc_subframe_kernel(QlpcKernelArgs a) {
   // saturated it follows from code_bits: code_bits = sum_q + 4*parts + (n - warm)
   // + sum_k p_k * len_k (rice.rs:69-71, 95-98).  Otherwise count it from the samples.
   unsigned long long sum_q = 0;
-  const bool saturated = (L.misc[kMiscSat] >> bestk) & 1u;
+  // (the literal table sums are u32 wrapping adds, rice.rs:88-93: once a 16-sample run of quotients
+  // can wrap -- zig-zag codes of 2^26 and more -- code_bits no longer determines the true sum either)
+  const bool saturated = ((L.misc[kMiscSat] >> bestk) & 1u) != 0 || maxu >= (1u << 26);
   if (saturated) {
     unsigned long long mine = 0;
     for (int t = tid; t < n; t += T) {

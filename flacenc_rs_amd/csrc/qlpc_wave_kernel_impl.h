@@ -978,7 +978,10 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
     }
   } else {
     rr = rice_search<32, false>(ps, e, len0, 0u, max_p, small_bits, lane, warm);
-    if (rr.saturated) {
+    // the table sums of this path are the reference's wrapping u32 adds (rice.rs:88-93): code_bits
+    // does not determine the true quotient sum any more, saturated or not -- always count it
+    rr.saturated = true;
+    {
       const uint32_t gp = (uint32_t)__shfl((int)rr.my_p, lane & ~((1 << rr.bestk) - 1), 64);
       uint32_t lo = 0, hi = 0;
 #pragma unroll

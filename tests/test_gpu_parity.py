@@ -1216,6 +1216,58 @@ def test_fused_encode_and_pack_equals_two_stage_path(handle, monkeypatch, n, bps
         assert kinds >= ({0, 1, 2, 3} if use_fixed else {0, 1, 3})
 
 
+@pytest.mark.parametrize("seed", range(4))
+def test_extreme_candidates_fuzz(handle, seed):
+    """Worst-case material through the candidate-level batches for random block sizes and orders up
+    to 32: QLPC records, fixed-LPC records and the independent-channel frame decisions vs the oracle."""
+    rng = np.random.default_rng(3000 + seed)
+    for trial in range(4):
+        n = int(rng.choice([4096, 4096, 64, 97, 192, 1152, 4608, 8192, 16384, 4000, 17000]))
+        bps = int(rng.choice([8, 16, 16, 24, 24]))
+        order = int(rng.choice([1, 2, 8, 12, 16, 24, 32]))
+        qcfg = dict(lpc_order=order, quant_precision=int(rng.integers(2, 16)),
+                    window=("rectangle" if rng.random() < 0.3 else ("tukey", float(np.round(rng.random(), 2)))),
+                    max_rice_parameter=int(rng.choice([0, 4, 14, 15, 30, 30])))
+        x = _extreme_frames(rng, n, bps)          # [6, 2, n]
+        flat = x.reshape(-1, n)
+        bpsv = np.full(flat.shape[0], bps, np.uint8)
+        if bps < 24:
+            bpsv[1::2] = bps + 1
+        tag = (seed, trial, n, bps, qcfg)
+        try:
+            params, resid, _, _ = handle.qlpc_batch(flat, bpsv, _capi.make_config(**qcfg))
+            ocfg = orc.make_config(acorr=orc.ACORR_CANONICAL, **qcfg)
+            for k in range(flat.shape[0]):
+                w = orc.estimated_qlpc(flat[k], int(bpsv[k]), ocfg)
+                p = params[k]
+                assert int(p["status"]) == w["status"], (k, "status")
+                if w["status"] == 0:
+                    for fld in ("order", "shift", "rice_order", "code_bits", "subframe_bits", "sum_quotients"):
+                        assert int(p[fld]) == int(w[fld]), (k, fld, int(p[fld]), int(w[fld]))
+                    assert p["coefs"][: w["order"]].tolist() == w["coefs"].tolist(), (k, "coefs")
+                    assert np.array_equal(resid[k], w["residual"]), (k, "residual")
+            fx = dict(fixed_max_order=int(rng.integers(0, 5)), fixed_order_sel=int(rng.random() < 0.7),
+                      fixed_partitions=int(rng.integers(1, 65)))
+            fcfg = _capi.make_frame_config(_capi.make_config(**qcfg), use_fixed=True, **fx)
+            fp, fr, fk = handle.fixed_lpc_batch(flat, bpsv, fcfg)
+            ofx = orc.make_fixed_config(max_order=fx["fixed_max_order"], order_sel=fx["fixed_order_sel"],
+                                        partitions=fx["fixed_partitions"], sum_mode=orc.SUMABS_CANONICAL)
+            for k in range(flat.shape[0]):
+                w = orc.fixed_lpc(flat[k], int(bpsv[k]), 2 ** 63, ofx, max_p=qcfg["max_rice_parameter"])
+                assert int(fp[k]["order"]) == w["order"] and int(fk[k]) == w["estimate"][w["order"]], (k, fx, "fixed order/key")
+                assert int(fp[k]["subframe_bits"]) == w["subframe_bits"], (k, fx, "fixed bits", int(fp[k]["subframe_bits"]), w["subframe_bits"])
+                assert np.array_equal(fr[k], w["residual"]), (k, fx, "fixed residual")
+            res, rr = handle.encode_frames(x, bps, fcfg)
+            ofc = orc.make_frame_config(ocfg, use_fixed=True, fixed=ofx)
+            for f in range(x.shape[0]):
+                for c in range(2):
+                    w = orc.encode_subframe(x[f, c], bps, ofc)
+                    assert int(res[f, c]["kind"]) == w["kind"] and int(res[f, c]["bits"]) == w["bits"], \
+                        (f, c, fx, int(res[f, c]["kind"]), w["kind"], int(res[f, c]["bits"]), w["bits"])
+        except AssertionError as e:
+            raise AssertionError(f"configuration {tag}: {e}") from e
+
+
 def test_encode_stereo_frames_rejects_bad_config(handle):
     x = np.zeros((2, 2, 4096), np.int32)
     with pytest.raises(_capi.FlacencHipError) as ei:

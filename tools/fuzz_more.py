@@ -18,7 +18,9 @@ lo = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 hi = int(sys.argv[2]) if len(sys.argv) > 2 else 406
 for seed in range(lo, hi):
     try:
-        if os.environ.get("FUZZ_KIND") == "extreme":
+        if os.environ.get("FUZZ_KIND") == "xcand":
+            T.test_extreme_candidates_fuzz(h, seed)
+        elif os.environ.get("FUZZ_KIND") == "extreme":
             T.test_extreme_signals_and_layout_fuzz(h, _Env(), seed)
         elif os.environ.get("FUZZ_KIND") == "channel":
             T.test_candidate_and_channel_api_fuzz(h, seed)

@@ -185,7 +185,7 @@ def main():
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": _measured_traffic(),
-            "kernel": "qlpc_wave4096_kernel<8,true,true,%s>" % ("true" if args.use_fixed else "false"),
+            "kernel": "qlpc_wave4096_kernel<8,true,true,%s,false>" % ("true" if args.use_fixed else "false"),
             "kernel_ms": round(kernel_ms, 4),
             "algorithmic_bytes_per_launch": ALGO_BYTES_PER_SAMPLE * samples_per_step,
         },

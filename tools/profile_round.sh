@@ -7,7 +7,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/profile_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/trace.log 2>&1
-tail -1 $OUT/trace.log > $OUT/bench_under_rocprof.json
+grep "^{\"metric\"" $OUT/trace.log | tail -1 > $OUT/bench_under_rocprof.json
 cp $OUT/trace/*/*kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null
 bash $GRAFT_REPO_ROOT/tools/pmc_profile.sh profile_$TAG/pmc > $OUT/pmc_summary.txt 2>&1
 cat $OUT/kernel_stats.csv

@@ -906,10 +906,20 @@ qlpc_subframe_kernel(QlpcKernelArgs a) {
       const int end = (q + 1) * psize;
       const int len = end - start;
       uint32_t accb = 0;
-      for (int i = 0; i < len; ++i) {
+      // (16 at a time: the LDS reads of a run are independent of the running sum, so unrolled they
+      // overlap instead of paying the LDS latency once per sample)
+      int i = 0;
+      for (; i + 16 <= len; i += 16) {
+        uint32_t uu[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) uu[j] = zigzag(L.sbuf[sidx<ROWSTRIDE>(start + i + j)]);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) accb += uu[j] >> p;
+        accb = accb < kMaxPToBits ? accb : kMaxPToBits;  // i + 15 is the run's 16th sample
+      }
+      for (; i < len; ++i) {
         uint32_t u = zigzag(L.sbuf[sidx<ROWSTRIDE>(start + i)]);
         accb += u >> p;
-        if ((i & 15) == 15) accb = accb < kMaxPToBits ? accb : kMaxPToBits;
       }
       accb = accb < kMaxPToBits ? accb : kMaxPToBits;
       uint32_t v = accb + (4u + (uint32_t)len * (p + 1u));

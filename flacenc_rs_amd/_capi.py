@@ -66,6 +66,7 @@ EXPORTED_SYMBOLS = (
     "flacenc_hip_fill_le_bytes",
     "flacenc_hip_fill_le_bytes_async",
     "flacenc_hip_encode_pack_stereo_frames_async",
+    "flacenc_hip_encode_pack_frames_async",
     "flacenc_hip_synchronize",
     "flacenc_hip_debug_set_stamps",
     "flacenc_hip_debug_set_fixed_keys",
@@ -248,6 +249,10 @@ def load() -> C.CDLL:
                                                                C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32,
                                                                C.c_uint32, vp, vp, C.c_size_t, vp, vp]
     L.flacenc_hip_encode_pack_stereo_frames_async.restype = C.c_int
+    L.flacenc_hip_encode_pack_frames_async.argtypes = [vp, C.POINTER(FrameConfig), vp, C.c_size_t, C.c_uint32,
+                                                        C.c_uint32, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32,
+                                                        C.c_uint32, vp, vp, C.c_size_t, vp, vp]
+    L.flacenc_hip_encode_pack_frames_async.restype = C.c_int
     L.flacenc_hip_stereo_frame_bytes_bound.argtypes = [C.c_uint32, C.c_uint32]
     L.flacenc_hip_stereo_frame_bytes_bound.restype = C.c_size_t
     L.flacenc_hip_encode_frames.argtypes = [vp, C.POINTER(FrameConfig), i32p, C.c_size_t, C.c_uint32, C.c_uint32,
@@ -491,6 +496,15 @@ class Handle:
         """PCM frames -> FLAC frame bytes on the device (one fused kernel for 4096-sample blocks)."""
         rc = self._lib.flacenc_hip_encode_pack_stereo_frames_async(
             self._h, C.byref(cfg), frames_ptr, n_frames, block_size, stride, bits_per_sample, sample_rate,
+            first_frame_number, frame_number_step, results_ptr, out_ptr, out_stride, out_len_ptr, stream or None)
+        self._check(rc)
+
+    def encode_pack_frames_device(self, cfg: FrameConfig, frames_ptr: int, n_frames: int, channels: int,
+                                  block_size: int, stride: int, bits_per_sample: int, sample_rate: int,
+                                  first_frame_number: int, frame_number_step: int, results_ptr: int, out_ptr: int,
+                                  out_stride: int, out_len_ptr: int, stream: int | None = None):
+        rc = self._lib.flacenc_hip_encode_pack_frames_async(
+            self._h, C.byref(cfg), frames_ptr, n_frames, channels, block_size, stride, bits_per_sample, sample_rate,
             first_frame_number, frame_number_step, results_ptr, out_ptr, out_stride, out_len_ptr, stream or None)
         self._check(rc)
 

@@ -1070,6 +1070,28 @@ int flacenc_hip_encode_pack_stereo_frames_async(flacenc_hip_handle* h, const fla
                                               out_len, stream);
 }
 
+int flacenc_hip_encode_pack_frames_async(flacenc_hip_handle* h, const flacenc_hip_frame_config* cfg,
+                                         const int32_t* frames, size_t n_frames, uint32_t channels,
+                                         uint32_t block_size, size_t stride, uint32_t bits_per_sample,
+                                         uint32_t sample_rate, uint32_t first_frame_number,
+                                         uint32_t frame_number_step, flacenc_hip_channel_result* results,
+                                         uint8_t* out, size_t out_stride, uint32_t* out_len, void* stream) {
+  if (!h || !cfg) return FLACENC_HIP_ERR_BAD_ARGUMENT;
+  if (n_frames == 0) return FLACENC_HIP_OK;
+  if (channels < 1 || channels > 8) return FLACENC_HIP_ERR_BAD_ARGUMENT;
+  // residual rows are only an intermediate here: handle scratch
+  int rc;
+  const size_t cstride = (static_cast<size_t>(block_size) + 3) & ~static_cast<size_t>(3);
+  if ((rc = ensure(h, h->d_presid, n_frames * channels * cstride * 4)) != FLACENC_HIP_OK) return rc;
+  rc = flacenc_hip_encode_frames_async(h, cfg, frames, n_frames, channels, block_size, stride, bits_per_sample, results,
+                                       static_cast<int32_t*>(h->d_presid.ptr), cstride, stream);
+  if (rc != FLACENC_HIP_OK) return rc;
+  return flacenc_hip_pack_frames_async(h, frames, n_frames, channels, block_size, stride, results,
+                                       static_cast<const int32_t*>(h->d_presid.ptr), cstride, bits_per_sample,
+                                       sample_rate, first_frame_number, frame_number_step, out, out_stride, out_len,
+                                       stream);
+}
+
 int flacenc_hip_synchronize(flacenc_hip_handle* h) {
   if (!h) return FLACENC_HIP_ERR_BAD_ARGUMENT;
   HIP_TRY(h, hipSetDevice(h->device));

@@ -368,6 +368,15 @@ int flacenc_hip_encode_pack_stereo_frames_async(flacenc_hip_handle* h, const fla
                                                 flacenc_hip_stereo_frame_result* results, uint8_t* out,
                                                 size_t out_stride, uint32_t* out_len, void* stream);
 
+/* The same for Independent(channels) frames: flacenc_hip_encode_frames_async +
+ * flacenc_hip_pack_frames_async with the residual rows in handle scratch. */
+int flacenc_hip_encode_pack_frames_async(flacenc_hip_handle* h, const flacenc_hip_frame_config* cfg,
+                                         const int32_t* frames, size_t n_frames, uint32_t channels,
+                                         uint32_t block_size, size_t stride, uint32_t bits_per_sample,
+                                         uint32_t sample_rate, uint32_t first_frame_number,
+                                         uint32_t frame_number_step, flacenc_hip_channel_result* results,
+                                         uint8_t* out, size_t out_stride, uint32_t* out_len, void* stream);
+
 /* Frame::count_bits / 8 (src/component/bitrepr.rs:275-287) of every frame from the decision records
  * alone: exactly the out_len flacenc_hip_pack_stereo_frames will produce.  Device pointers.  These
  * 4 bytes per frame are all an ordered multi-GPU gather has to exchange to place every frame in

@@ -1268,6 +1268,30 @@ def test_extreme_candidates_fuzz(handle, seed):
             raise AssertionError(f"configuration {tag}: {e}") from e
 
 
+@pytest.mark.parametrize("channels,n", [(1, 4096), (6, 4096), (3, 1000)])
+def test_one_call_independent_channel_pipeline(handle, channels, n):
+    """flacenc_hip_encode_pack_frames_async == encode_frames + pack_frames."""
+    import torch
+    bps = 16
+    x = _capi.sigen_frames(5, channels, n, bps, 77.0, 0.4, 0.03, seed=channels + n)
+    x[2, 0] = (np.arange(n) // 5) % 3000
+    cfg = _capi.make_frame_config(gpu_cfg(8), use_fixed=True)
+    want, wres = handle.encode_frames(x, bps, cfg)
+    frames = handle.pack_frames(x, want, wres, bps, 32000, 9, 1)
+    xs = torch.from_numpy(x).cuda()
+    res = torch.zeros((5 * channels, 368), dtype=torch.uint8, device="cuda")
+    stride = int(handle._lib.flacenc_hip_frame_bytes_bound(channels, n, bps))
+    out = torch.zeros((5, stride), dtype=torch.uint8, device="cuda")
+    lens = torch.zeros(5, dtype=torch.int32, device="cuda")
+    handle.encode_pack_frames_device(cfg, xs.data_ptr(), 5, channels, n, n, bps, 32000, 9, 1, res.data_ptr(),
+                                     out.data_ptr(), stride, lens.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert res.cpu().numpy().tobytes() == want.tobytes()
+    o, ln = out.cpu().numpy(), lens.cpu().numpy()
+    for f in range(5):
+        assert bytes(o[f, :ln[f]]) == frames[f], f
+
+
 def test_encode_stereo_frames_rejects_bad_config(handle):
     x = np.zeros((2, 2, 4096), np.int32)
     with pytest.raises(_capi.FlacencHipError) as ei:

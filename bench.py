@@ -43,6 +43,10 @@ def main():
     ap.add_argument("--use-fixed", action="store_true",
                     help="also run the fixed-LPC candidate (the reference's default SubFrameCoding); "
                          "not the north-star workload, reported in DESIGN.md")
+    ap.add_argument("--gather", choices=["lengths", "records"], default="lengths",
+                    help="what the multi-GPU exchange step moves: the frames' byte lengths (4 B/frame, enough to "
+                         "place every frame in the stream; default) or the whole 752-B decision records "
+                         "(every SubFrame component on every rank)")
     ap.add_argument("--force-exchange", action="store_true",
                     help="run the multi-GPU exchange step (frame lengths -> offsets) even with one rank; "
                          "for measuring its cost, not a reported configuration")
@@ -96,6 +100,8 @@ def main():
         handle.stereo_frame_lengths_device(results2[b].data_ptr(), F, n, bps, 44100, rank, world,
                                            frame_len2[b].data_ptr(), stream=comm.cuda_stream)
         lengths_all = shard.all_gather_frame_lengths(frame_len2[b], world * F)
+        if args.gather == "records":
+            shard.all_gather_records(results2[b], world * F)
         return shard.stream_offsets(lengths_all)[0]
 
     def step(events=None):
@@ -173,8 +179,9 @@ def main():
             "decision": ("encode_subframe {Constant, Verbatim, FixedLpc(ApproxEnt 16), LPC}" if args.use_fixed
                          else "encode_subframe {Constant, Verbatim, LPC}") +
                         " + try_stereo_coding on the GPU; the two chosen residuals written",
-            "gather": "all_gather of per-frame byte lengths (4 B/frame, RCCL) + prefix sum to stream offsets, "
-                      "on its own stream, overlapping the next step's analysis" if world > 1 else "none",
+            "gather": (("all_gather of per-frame byte lengths (4 B/frame, RCCL) + prefix sum to stream offsets"
+                        + (" + all_gather of the 752-B frame records" if args.gather == "records" else "")
+                        + ", on its own stream, overlapping the next step's analysis") if world > 1 else "none"),
             "subframe_bits_per_sample": round(chosen_bits / (2 * F * n), 4),
             "assignments_indep_left_right_mid": assign_hist,
         },

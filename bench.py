@@ -43,6 +43,9 @@ def main():
     ap.add_argument("--use-fixed", action="store_true",
                     help="also run the fixed-LPC candidate (the reference's default SubFrameCoding); "
                          "not the north-star workload, reported in DESIGN.md")
+    ap.add_argument("--finest-rice-order", action="store_true",
+                    help="build extension (not a reference mode): keep the finest Rice partition order, "
+                         "BASELINE config 2's 'fixed Rice partition order'; reported in DESIGN.md, not the default")
     ap.add_argument("--gather", choices=["lengths", "records"], default="lengths",
                     help="what the multi-GPU exchange step moves: the frames' byte lengths (4 B/frame, enough to "
                          "place every frame in the stream; default) or the whole 752-B decision records "
@@ -74,7 +77,8 @@ def main():
     # precision 15, Tukey(0.4), max_p 30; candidates Constant / Verbatim / LPC -- the QLPC analysis path
     # the metric names (--use-fixed adds the reference default's fixed-LPC candidate); all stereo
     # assignments allowed
-    cfg = _capi.make_frame_config(_capi.make_config(lpc_order=args.lpc_order), use_fixed=args.use_fixed)
+    cfg = _capi.make_frame_config(_capi.make_config(lpc_order=args.lpc_order, rice_finest_only=args.finest_rice_order),
+                                  use_fixed=args.use_fixed)
     # synthetic "sigen" audio: Sine(200, 0.4) + Noise(0.4) like the reference's
     # stereo_frame_encoder_noisy_sine_lpc bench (src/coding.rs:1152), one continuous stream,
     # dealt round-robin: stream frame f belongs to rank f mod G (flacenc_rs_amd/shard.py)
@@ -173,7 +177,9 @@ def main():
         "config": {
             "workload": "configs[1]: sigen Sine(200,0.4)+Noise(0.4), 44.1kHz/16-bit stereo, "
                         f"block_size={n}, LPC order {args.lpc_order}, precision 15, Tukey(0.4), "
-                        "full partitioned-Rice search (max_p 30); L,R,M,S analysed per frame, encode_frame decision",
+                        + ("finest Rice partition order only (build extension)" if args.finest_rice_order
+                           else "full partitioned-Rice search") +
+                        " (max_p 30); L,R,M,S analysed per frame, encode_frame decision",
             "frames_per_step_per_gpu": F,
             "subframes_analysed_per_step_per_gpu": 4 * F,
             "decision": ("encode_subframe {Constant, Verbatim, FixedLpc(ApproxEnt 16), LPC}" if args.use_fixed

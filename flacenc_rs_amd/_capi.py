@@ -286,8 +286,11 @@ def load() -> C.CDLL:
     return L
 
 
+FLAG_FINEST_RICE_ORDER = 2
+
+
 def make_config(lpc_order=10, quant_precision=15, window=("tukey", 0.4), max_rice_parameter=30,
-                flags=0) -> QlpcConfig:
+                flags=0, rice_finest_only=False) -> QlpcConfig:
     """Defaults of config::Qlpc / config::Prc (src/constant.rs:109-115, src/config.rs:216-221)."""
     if window == "rectangle" or window[0] == "rectangle":
         wt, alpha = WINDOW_RECTANGLE, 0.0
@@ -295,6 +298,8 @@ def make_config(lpc_order=10, quant_precision=15, window=("tukey", 0.4), max_ric
         wt, alpha = WINDOW_TUKEY, float(window[1])
     if lpc_order > 24:
         flags |= FLAG_ALLOW_ORDER_32
+    if rice_finest_only:  # build extension: BASELINE config 2's "fixed Rice partition order"
+        flags |= FLAG_FINEST_RICE_ORDER
     return QlpcConfig(lpc_order, quant_precision, wt, alpha, max_rice_parameter, flags)
 
 

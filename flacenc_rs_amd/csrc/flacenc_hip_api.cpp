@@ -204,6 +204,7 @@ int enqueue(flacenc_hip_handle* h, const flacenc_hip_qlpc_config* cfg, const int
   a.lpc_order = cfg->lpc_order;
   a.precision = cfg->quant_precision;
   a.max_rice_parameter = cfg->max_rice_parameter;
+  a.rice_finest_only = (cfg->flags & FLACENC_HIP_FLAG_FINEST_RICE_ORDER) ? 1u : 0u;
   a.params = params;
   a.residual = residual;
   a.residual_stride = residual_stride;
@@ -378,6 +379,7 @@ int enqueue_fixed(flacenc_hip_handle* h, const flacenc_hip_frame_config* cfg, co
   a.lpc_order = 4;
   a.precision = 0;
   a.max_rice_parameter = cfg->qlpc.max_rice_parameter;
+  a.rice_finest_only = (cfg->qlpc.flags & FLACENC_HIP_FLAG_FINEST_RICE_ORDER) ? 1u : 0u;
   a.params = params;
   a.residual = residual;
   a.residual_stride = residual_stride;
@@ -814,6 +816,7 @@ int flacenc_hip_encode_frames_async(flacenc_hip_handle* h, const flacenc_hip_fra
     a.lpc_order = cfg->qlpc.lpc_order;
     a.precision = cfg->qlpc.quant_precision;
     a.max_rice_parameter = cfg->qlpc.max_rice_parameter;
+  a.rice_finest_only = (cfg->qlpc.flags & FLACENC_HIP_FLAG_FINEST_RICE_ORDER) ? 1u : 0u;
     a.params = nullptr;
     a.residual = residual;
     a.residual_stride = residual_stride;
@@ -1286,6 +1289,7 @@ static int encode_stereo_frames_impl(flacenc_hip_handle* h, const flacenc_hip_fr
   a.lpc_order = cfg->qlpc.lpc_order;
   a.precision = cfg->qlpc.quant_precision;
   a.max_rice_parameter = cfg->qlpc.max_rice_parameter;
+  a.rice_finest_only = (cfg->qlpc.flags & FLACENC_HIP_FLAG_FINEST_RICE_ORDER) ? 1u : 0u;
   a.params = nullptr;
   a.residual = residual;
   a.residual_stride = residual_stride;

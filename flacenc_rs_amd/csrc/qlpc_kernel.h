@@ -28,6 +28,7 @@ struct QlpcKernelArgs {
   uint32_t lpc_order;
   uint32_t precision;
   uint32_t max_rice_parameter;
+  uint32_t rice_finest_only;  // FLACENC_HIP_FLAG_FINEST_RICE_ORDER: no merging below the finest order
   flacenc_hip_subframe_params* params;  // device
   int32_t* residual;                    // device
   size_t residual_stride;

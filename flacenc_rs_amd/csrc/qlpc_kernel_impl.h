@@ -749,6 +749,7 @@ qlpc_subframe_kernel(QlpcKernelArgs a) {
   // u >> p is 0, so a table entry is 4 + len*(p+1), strictly increasing in p, in every
   // partition and therefore in every merged table.  Capping the search at
   // min(max_p, bitlen) returns the same minimiser and the same bits as rice.rs:115-141.
+  const bool finest_only = a.rice_finest_only != 0;  // FLACENC_HIP_FLAG_FINEST_RICE_ORDER
   const uint32_t maxu = L.misc[kMiscOrBits];
   const uint32_t bitlen = maxu ? (uint32_t)(32 - __clz((int)maxu)) : 0u;
   const uint32_t max_p = a.max_rice_parameter < bitlen ? a.max_rice_parameter : bitlen;
@@ -857,7 +858,7 @@ qlpc_subframe_kernel(QlpcKernelArgs a) {
       }
       // orders fo .. fo-kw inside the wave: minimiser per partition (quad, then wider groups),
       // merge with the neighbouring group by a lane butterfly (rice.rs:144-152, 193-216)
-      for (int k = 0; k <= kw; ++k) {
+      for (int k = 0; k <= (finest_only ? 0 : kw); ++k) {
         if (k > 0) {
           const int xm = 2 << k;  // lane xor 4, 8, 16, 32
 #pragma unroll
@@ -933,7 +934,7 @@ qlpc_subframe_kernel(QlpcKernelArgs a) {
   FLACENC_STAMP(5);
   // eval_partitions / merge_partitions over the remaining orders (rice.rs:193-216, 277-291).
   // Level k keeps its tables at indices q << k.
-  for (int k = first_generic_level; k <= fo; ++k) {
+  for (int k = first_generic_level; k <= (finest_only ? 0 : fo); ++k) {
     const int m = nparts >> k;
     const int stride = 1 << k;
     uint8_t* ps_k = L.ps + (2 * nparts - 2 * m);  // level k owns m bytes at this offset
@@ -970,7 +971,7 @@ qlpc_subframe_kernel(QlpcKernelArgs a) {
   if (tid == 0) {
     int best = 0;
     unsigned long long best_bits = L.level_bits[0];
-    for (int k = 1; k <= fo; ++k) {
+    for (int k = 1; k <= (finest_only ? 0 : fo); ++k) {
       if (L.level_bits[k] < best_bits) {
         best_bits = L.level_bits[k];
         best = k;

@@ -272,7 +272,7 @@ __device__ __forceinline__ unsigned long long plane_sum_any64(const PlaneSums& p
 template <int NP, bool EXACT>
 __device__ __forceinline__ RiceResult rice_search(const PlaneSums& ps, const int32_t* e, uint32_t len0,
                                                   uint32_t p_lo, uint32_t max_p, bool small_bits, int lane,
-                                                  int warm) {
+                                                  int warm, bool finest_only) {
   constexpr uint32_t kWMax = kMaxPToBits - 4u;
   uint32_t Wp[NP];
   if (EXACT) {
@@ -349,12 +349,14 @@ __device__ __forceinline__ RiceResult rice_search(const PlaneSums& ps, const int
     }                                                                                         \
   }
   FLACENC_RICE_LEVEL(0, 1)
-  FLACENC_RICE_LEVEL(1, 1)
-  FLACENC_RICE_LEVEL(2, 2)
-  FLACENC_RICE_LEVEL(3, 4)
-  FLACENC_RICE_LEVEL(4, 8)
-  FLACENC_RICE_LEVEL(5, 16)
-  FLACENC_RICE_LEVEL(6, 32)
+  if (!finest_only) {  // (FLACENC_HIP_FLAG_FINEST_RICE_ORDER keeps order 6)
+    FLACENC_RICE_LEVEL(1, 1)
+    FLACENC_RICE_LEVEL(2, 2)
+    FLACENC_RICE_LEVEL(3, 4)
+    FLACENC_RICE_LEVEL(4, 8)
+    FLACENC_RICE_LEVEL(5, 16)
+    FLACENC_RICE_LEVEL(6, 32)
+  }
 #undef FLACENC_RICE_LEVEL
   sat_any = wave_or_dpp(sat_any);
   r.saturated = (sat_any >> r.bestk) & 1u;
@@ -944,6 +946,7 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
   const bool small_bits = a.max_rice_parameter >= bitlen;
   const uint32_t len0 = 64u - (lane == 0 ? (uint32_t)warm : 0u);
 
+  const bool finest_only = a.rice_finest_only != 0;
   RiceResult rr;
   unsigned long long sat_sum_q = 0;  // exact sum of quotients, only evaluated if a minimum saturated
   if (maxu < (1u << 26)) {
@@ -960,15 +963,15 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
     uint32_t p_lo = p0min > 2u ? p0min - 2u : 0u;
     p_lo = p_lo < max_p ? p_lo : max_p;
     const uint32_t span = max_p - p_lo + 1u;
-    if (span <= 8) rr = rice_search<8, true>(ps, nullptr, len0, p_lo, max_p, small_bits, lane, warm);
-    else if (span <= 16) rr = rice_search<16, true>(ps, nullptr, len0, p_lo, max_p, small_bits, lane, warm);
-    else if (span <= 24) rr = rice_search<24, true>(ps, nullptr, len0, p_lo, max_p, small_bits, lane, warm);
-    else rr = rice_search<32, true>(ps, nullptr, len0, 0u, max_p, small_bits, lane, warm);
+    if (span <= 8) rr = rice_search<8, true>(ps, nullptr, len0, p_lo, max_p, small_bits, lane, warm, finest_only);
+    else if (span <= 16) rr = rice_search<16, true>(ps, nullptr, len0, p_lo, max_p, small_bits, lane, warm, finest_only);
+    else if (span <= 24) rr = rice_search<24, true>(ps, nullptr, len0, p_lo, max_p, small_bits, lane, warm, finest_only);
+    else rr = rice_search<32, true>(ps, nullptr, len0, 0u, max_p, small_bits, lane, warm, finest_only);
     // The window argument compares unclamped table values.  If any group minimum saturated at
     // MAX_P_TO_BITS, clamped entries outside the window could tie with it (ties go to the
     // smallest p, rice.rs:123-124), so search the whole range then.
     if (rr.sat_levels != 0 && p_lo != 0 && span <= 24)
-      rr = rice_search<32, true>(ps, nullptr, len0, 0u, max_p, small_bits, lane, warm);
+      rr = rice_search<32, true>(ps, nullptr, len0, 0u, max_p, small_bits, lane, warm, finest_only);
     if (rr.saturated) {
       // sum_i (u_i >> p) of this lane's partition under its group's parameter, from the planes
       const uint32_t gp = (uint32_t)__shfl((int)rr.my_p, lane & ~((1 << rr.bestk) - 1), 64);
@@ -977,7 +980,7 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
                   (unsigned long long)wave_sum_dpp((uint32_t)(mine & 0xFFFFu));
     }
   } else {
-    rr = rice_search<32, false>(ps, e, len0, 0u, max_p, small_bits, lane, warm);
+    rr = rice_search<32, false>(ps, e, len0, 0u, max_p, small_bits, lane, warm, finest_only);
     // the table sums of this path are the reference's wrapping u32 adds (rice.rs:88-93): code_bits
     // does not determine the true quotient sum any more, saturated or not -- always count it
     rr.saturated = true;

@@ -56,6 +56,11 @@ extern "C" {
 #define FLACENC_HIP_WINDOW_TUKEY 1
 
 #define FLACENC_HIP_FLAG_ALLOW_ORDER_32 1u
+/* Build extension, NOT a reference mode (the reference always runs the exhaustive search,
+ * src/rice.rs:246-298): keep the finest Rice partition order instead of merging down to order 0 --
+ * BASELINE config 2's "fixed Rice partition order".  Output stays valid, lossless FLAC; it is just
+ * not the partition the reference would pick when a coarser order is cheaper. */
+#define FLACENC_HIP_FLAG_FINEST_RICE_ORDER 2u
 
 /* where the caller's sample / output buffers live */
 #define FLACENC_HIP_MEM_HOST 0

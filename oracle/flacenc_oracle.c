@@ -473,6 +473,10 @@ uint32_t orc_finest_partition_order(size_t size, size_t min_part_size) {
  * merge_partitions :208-216). */
 void orc_find_partitioned_rice_parameter(const int32_t* signal, size_t n, size_t warmup_length,
                                          uint32_t max_p, orc_prc_parameter* out) {
+  /* ORC_RICE_FINEST_ONLY (not a reference mode; BASELINE config 2's "fixed Rice partition order"):
+   * the search stops at the finest order instead of merging down to order 0 */
+  const int finest_only = (max_p & ORC_RICE_FINEST_ONLY) != 0;
+  max_p &= 0xFFu;
   size_t min_part = warmup_length > ORC_MIN_RICE_PARTITION_SIZE ? warmup_length
                                                                 : ORC_MIN_RICE_PARTITION_SIZE;
   uint32_t partition_order = orc_finest_partition_order(n, min_part);
@@ -509,7 +513,7 @@ void orc_find_partitioned_rice_parameter(const int32_t* signal, size_t n, size_t
     min_ps[p] = (uint8_t)pp;
   }
   uint32_t min_order = partition_order;
-  while (nparts > 1) {
+  while (nparts > 1 && !finest_only) {
     size_t merged = nparts / 2;
     for (size_t q = 0; q < merged; ++q) {
       uint32_t tmp[32];

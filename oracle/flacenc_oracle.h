@@ -54,6 +54,10 @@ extern "C" {
 #define ORC_ORDERSEL_BITCOUNT 0
 #define ORC_ORDERSEL_APPROXENT 1
 
+/* OR-ed into max_rice_parameter: stop the partitioned-Rice search at the finest order (a build
+ * extension mirrored from FLACENC_HIP_FLAG_FINEST_RICE_ORDER; the reference always searches all orders) */
+#define ORC_RICE_FINEST_ONLY 0x100u
+
 #define ORC_STATUS_OK 0
 #define ORC_STATUS_NONFINITE 1   /* the reference would panic (src/lpc.rs:786-799) */
 #define ORC_STATUS_NEG_ENERGY 2  /* the reference would panic (src/lpc.rs:646) */

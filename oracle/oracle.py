@@ -279,14 +279,18 @@ def make_frame_config(qlpc=None, use_constant=True, use_fixed=True, use_lpc=True
                        fixed or make_fixed_config())
 
 
+RICE_FINEST_ONLY = 0x100
+
+
 def make_config(lpc_order=10, quant_precision=15, window=("tukey", 0.4), max_rice_parameter=30,
-                acorr=ACORR_REFERENCE) -> QlpcConfig:
+                acorr=ACORR_REFERENCE, rice_finest_only=False) -> QlpcConfig:
     """config::Qlpc / config::Prc defaults, src/constant.rs:109-115, src/config.rs:216-221."""
     if window == "rectangle" or window[0] == "rectangle":
         wt, alpha = WINDOW_RECTANGLE, 0.0
     else:
         wt, alpha = WINDOW_TUKEY, float(window[1])
-    return QlpcConfig(lpc_order, quant_precision, wt, alpha, max_rice_parameter, acorr)
+    return QlpcConfig(lpc_order, quant_precision, wt, alpha,
+                      max_rice_parameter | (RICE_FINEST_ONLY if rice_finest_only else 0), acorr)
 
 
 # ---------------------------------------------------------------- lpc.rs ----

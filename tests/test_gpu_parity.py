@@ -1292,6 +1292,36 @@ def test_one_call_independent_channel_pipeline(handle, channels, n):
         assert bytes(o[f, :ln[f]]) == frames[f], f
 
 
+@pytest.mark.parametrize("n,bps,order,use_fixed", [(4096, 16, 8, True), (4096, 16, 12, False), (4096, 24, 10, True),
+                                                   (4608, 16, 8, True), (8192, 24, 24, False), (1152, 16, 10, True)])
+def test_finest_rice_order_extension(handle, n, bps, order, use_fixed):
+    """FLACENC_HIP_FLAG_FINEST_RICE_ORDER (a build extension, BASELINE config 2's "fixed Rice partition
+    order"): the search keeps the finest partition order.  Same restriction in the oracle -> identical
+    decisions, records, residuals and packed bytes; the frames are valid FLAC (independent parser); and no
+    frame is smaller than what the exhaustive search gives."""
+    import flac_parse
+    x = np.ascontiguousarray(_fixed_corpus()[:12, :, :n]) if n <= 4096 else _capi.sigen_frames(6, 2, n, 16, 90.0, 0.4, 0.05, seed=n)
+    if bps == 24:
+        x = (x.astype(np.int64) * 181).astype(np.int32)
+    cfg = _capi.make_frame_config(_capi.make_config(lpc_order=order, rice_finest_only=True), use_fixed=use_fixed)
+    got, gres = handle.encode_stereo_frames(x, bps, cfg)
+    ocfg = orc.make_frame_config(orc.make_config(lpc_order=order, acorr=orc.ACORR_CANONICAL, rice_finest_only=True),
+                                 use_fixed=use_fixed, fixed=orc.make_fixed_config(sum_mode=orc.SUMABS_CANONICAL))
+    want, wres = orc.encode_stereo_frames_cfg(x, bps, ocfg)
+    _check_frames_against_oracle(x, bps, got, gres, want, wres)
+    full, _ = handle.encode_stereo_frames(x, bps, _capi.make_frame_config(_capi.make_config(lpc_order=order), use_fixed=use_fixed))
+    frames = handle.pack_stereo_frames(x, got, gres, bps, 44100, 0, 1)
+    fo = {4096: 6, 4608: 6, 8192: 7, 1152: 4}[n]
+    for f in range(x.shape[0]):
+        for c in range(2):
+            if int(got[f]["kind"][c]) >= 2:
+                assert int(got[f]["lpc"][c]["rice_order"]) == fo
+        assert sum(int(got[f]["bits"][r]) for r in got[f]["role"]) >= sum(int(full[f]["bits"][r]) for r in full[f]["role"])
+        assert frames[f] == orc.write_stereo_frame(got[f], x[f, 0], x[f, 1], bps, 44100, f, gres[f, 0], gres[f, 1])
+        if n <= 4608 and f < 4:
+            assert np.array_equal(flac_parse.parse_frame(frames[f], stream_bps=bps)["channels"], x[f])
+
+
 def test_encode_stereo_frames_rejects_bad_config(handle):
     x = np.zeros((2, 2, 4096), np.int32)
     with pytest.raises(_capi.FlacencHipError) as ei:

@@ -1033,7 +1033,7 @@ def test_candidate_and_channel_api_fuzz(handle, seed):
             ofx = orc.make_fixed_config(max_order=fx["fixed_max_order"], order_sel=fx["fixed_order_sel"],
                                         partitions=fx["fixed_partitions"], sum_mode=orc.SUMABS_CANONICAL)
             for k in range(flat.shape[0]):
-                w = orc.fixed_lpc(flat[k], int(bpsv[k]), 2 ** 63, ofx, max_p=qcfg["max_rice_parameter"])
+                w = orc.fixed_lpc(flat[k], int(bpsv[k]), 2 ** 63, ofx, max_p=int(ocfg.max_rice_parameter))
                 assert int(fp[k]["order"]) == w["order"] and int(fk[k]) == w["estimate"][w["order"]], (k, fx)
                 assert int(fp[k]["subframe_bits"]) == w["subframe_bits"] and np.array_equal(fr[k], w["residual"]), (k, fx)
             # --- frame level, independent channels ---
@@ -1253,7 +1253,7 @@ def test_extreme_candidates_fuzz(handle, seed):
             ofx = orc.make_fixed_config(max_order=fx["fixed_max_order"], order_sel=fx["fixed_order_sel"],
                                         partitions=fx["fixed_partitions"], sum_mode=orc.SUMABS_CANONICAL)
             for k in range(flat.shape[0]):
-                w = orc.fixed_lpc(flat[k], int(bpsv[k]), 2 ** 63, ofx, max_p=qcfg["max_rice_parameter"])
+                w = orc.fixed_lpc(flat[k], int(bpsv[k]), 2 ** 63, ofx, max_p=int(ocfg.max_rice_parameter))
                 assert int(fp[k]["order"]) == w["order"] and int(fk[k]) == w["estimate"][w["order"]], (k, fx, "fixed order/key")
                 assert int(fp[k]["subframe_bits"]) == w["subframe_bits"], (k, fx, "fixed bits", int(fp[k]["subframe_bits"]), w["subframe_bits"])
                 assert np.array_equal(fr[k], w["residual"]), (k, fx, "fixed residual")

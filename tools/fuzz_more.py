@@ -6,6 +6,11 @@ torch.cuda.init()  # before the library creates its own HIP context
 import test_gpu_parity as T
 from flacenc_rs_amd import _capi
 h = _capi.Handle(0)
+if os.environ.get("FUZZ_FINEST") == "1":  # run every fuzzer with FLACENC_HIP_FLAG_FINEST_RICE_ORDER on both sides
+    from oracle import oracle as _orc
+    _g, _o = _capi.make_config, _orc.make_config
+    _capi.make_config = lambda *a, **k: _g(*a, **{**k, "rice_finest_only": True})
+    _orc.make_config = lambda *a, **k: _o(*a, **{**k, "rice_finest_only": True})
 
 
 class _Env:  # stands in for pytest's monkeypatch

@@ -1,6 +1,15 @@
 /*
  * flacenc_hip.h -- C ABI of the MI355X (gfx950) implementation of flacenc-rs's
- * per-subframe quantised-LPC analysis path.
+ * per-subframe quantised-LPC analysis path and of the stages either side of it.
+ *
+ * Three levels, each a superset of the one before:
+ *   candidates   flacenc_hip_qlpc_batch / _stereo_qlpc_batch   (coding::estimated_qlpc)
+ *                flacenc_hip_fixed_lpc_batch                   (coding::fixed_lpc)
+ *   frames       flacenc_hip_encode_stereo_frames / _encode_frames   (coding::encode_frame: the
+ *                candidates plus encode_subframe and try_stereo_coding on the device)
+ *   bytes        flacenc_hip_pack_stereo_frames / _pack_frames (Frame::write, both CRCs),
+ *                flacenc_hip_encode_pack_*_frames_async (PCM in HBM -> frame bytes in one call),
+ *                flacenc_hip_fill_le_bytes (packed interleaved PCM -> FrameBuf layout)
  *
  * This is the drop-in boundary: plain pointers and sizes, no C++/torch types.
  * Each entry point names the reference interface it replaces (paths relative

@@ -136,6 +136,20 @@ extern "C" {
         block_size: u32, stride: usize, bits_per_sample: u32, results: *mut StereoFrameResult,
         residual: *mut i32, residual_stride: usize, memory_kind: c_int,
     ) -> c_int;
+    /// `Frame::write` (`src/component/bitrepr.rs:289-319`) for the frames of
+    /// `flacenc_hip_encode_stereo_frames`: bytes for `Frame::set_precomputed_bitstream`.
+    pub fn flacenc_hip_stereo_frame_bytes_bound(block_size: u32, bits_per_sample: u32) -> usize;
+    pub fn flacenc_hip_pack_stereo_frames(
+        h: *mut Handle, frames: *const i32, n_frames: usize, block_size: u32, stride: usize,
+        results: *const StereoFrameResult, residual: *const i32, residual_stride: usize,
+        bits_per_sample: u32, sample_rate: u32, first_frame_number: u32, frame_number_step: u32,
+        out: *mut u8, out_stride: usize, out_len: *mut u32, memory_kind: c_int,
+    ) -> c_int;
+    /// `FrameBuf::fill_le_bytes` (`src/source.rs:288-298`) for a run of frames.
+    pub fn flacenc_hip_fill_le_bytes(
+        h: *mut Handle, bytes: *const u8, total_samples: u64, channels: u32, bytes_per_sample: u32,
+        n_frames: usize, block_size: u32, frames: *mut i32, stride: usize, memory_kind: c_int,
+    ) -> c_int;
     pub fn flacenc_hip_qlpc_batch_async(
         h: *mut Handle, cfg: *const QlpcConfig, samples: *const i32, n_subframes: usize,
         block_size: u32, stride: usize, bps: *const u8, params: *mut SubframeParams,

@@ -491,108 +491,6 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
   const unsigned long long bps_role = a.bps ? (unsigned long long)a.bps[sf]
                                             : (unsigned long long)(a.bps_uniform + ((STEREO && role == 3) ? 1u : 0u));
 
-  // ======================= fixed-LPC candidate: order selection ============
-  // fixed_lpc (coding.rs:298-331).  `cand` walks the candidates that go through the Rice search:
-  // 0..4 = the fixed-LPC error signal of that order, 5 = the QLPC candidate (always last, so e[]
-  // ends up holding its residual).  ApproxEnt (coding.rs:265-287) codes only its argmin order;
-  // BitCount (:243-264) codes every order up to max_order and keeps the first minimum.
-  int cand = 5;
-  FixedChoice fx;
-  fx.have = false;
-  fx.order = 0;
-  fx.key = ~0ull;
-  fx.bestk = 0;
-  fx.my_p = 0;
-  fx.code_bits = fx.sum_q = fx.sub_bits = 0;
-  // the lane's 64 samples + 4 in front of them (zeros in front of the block: the reference's
-  // carry starts at 0, coding.rs:188), differenced `ord` times in place; valid from index ord on
-  auto fixed_load = [&](uint32_t (&v)[68]) {
-    with_role([&](auto kind) {
-#pragma unroll
-      for (int k = 0; k < 17; ++k) {
-        const int4 q = ld4k(kind, tl - 4 + 4 * k);
-        v[4 * k + 0] = (uint32_t)q.x;
-        v[4 * k + 1] = (uint32_t)q.y;
-        v[4 * k + 2] = (uint32_t)q.z;
-        v[4 * k + 3] = (uint32_t)q.w;
-      }
-    });
-  };
-  if (FIXED && a.use_fixed) {
-    if (a.fixed_order_sel == 1u) {
-      // ---- estimate_entropy (coding.rs:200-227) for orders 0..max_order ----
-      // per-lane sums of |e_k| as exact integers: v_sad_u32 on values biased by 2^31 gives
-      // |x - y| of the signed values, i.e. the NEXT order's magnitude, straight from this order's
-      // values; 16-sample sub-sums stay below 2^32 for inputs up to 25 bits, then go to f64
-      double ls[5];
-      {
-        uint32_t b[68];
-        fixed_load(b);
-#pragma unroll
-        for (int i = 0; i < 68; ++i) b[i] ^= 0x80000000u;
-#pragma unroll
-        for (int ord = 0; ord < 5; ++ord) {
-          uint32_t c[4] = {0u, 0u, 0u, 0u};
-          if (ord == 0) {
-#pragma unroll
-            for (int j = 0; j < 64; ++j) c[j >> 4] = sad_u32(b[4 + j], 0x80000000u, c[j >> 4]);
-          } else {
-#pragma unroll
-            for (int j = 0; j < 64; ++j) c[j >> 4] = sad_u32(b[4 + j], b[3 + j], c[j >> 4]);
-            if (ord < 4) {
-#pragma unroll
-              for (int i = 67; i >= ord; --i) b[i] = (b[i] - b[i - 1]) ^ 0x80000000u;
-            }
-          }
-          ls[ord] = ((double)c[0] + (double)c[1]) + ((double)c[2] + (double)c[3]);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-      // partition sums: partitions of 4096 / P samples = groups of 2^g lanes (P a power of two)
-      const int g = (int)a.fixed_group_log2;
-#pragma unroll 1
-      for (int lvl = 0; lvl < g; ++lvl) {
-#pragma unroll
-        for (int ord = 0; ord < 5; ++ord) ls[ord] += __shfl_xor(ls[ord], 1 << lvl, 64);
-      }
-      // estimate_entropy for several orders at once: the 2^g lanes of a partition all hold its
-      // five sums, so lane j of a group takes order r 2^g + j in pass r.  Its partition estimates
-      // are added up over the groups (lanes with equal j) by the butterfly levels >= g, and the
-      // first minimum of the keys is the minimum of (key << 3 | order).
-      const int G = 1 << g;
-      const int jsub = lane & (G - 1);
-      const uint32_t psize = 64u << g;
-      uint32_t best_packed = 0xFFFFFFFFu;
-#pragma unroll 1
-      for (int r = 0; r * G <= (int)a.fixed_max_order; ++r) {
-        const int ord = r * G + jsub;
-        const bool valid = ord <= (int)a.fixed_max_order;
-        double sv = ls[0];
-#pragma unroll
-        for (int q = 1; q < 5; ++q) sv = (q == ord) ? ls[q] : sv;
-        // sample_count = min(end - warmup, partition_len): only partition 0 loses the warm-up
-        const uint32_t cnt = psize - ((lane >> g) == 0 ? (uint32_t)ord : 0u);
-        uint32_t pb = valid ? approx_ent_bits(sv, cnt) : 0u;
-#pragma unroll 1
-        for (int lvl = g; lvl < 6; ++lvl) pb += (uint32_t)__shfl_xor((int)pb, 1 << lvl, 64);
-        const unsigned long long key = (unsigned long long)pb + bps_role * (unsigned long long)ord;
-        if (a.fixed_keys && valid && lane < G) a.fixed_keys[(size_t)sf * 8 + ord] = key;
-        const uint32_t packed = valid ? (((uint32_t)key << 3) | (uint32_t)ord) : 0xFFFFFFFFu;  // key < 2^29
-        const uint32_t m = wave_min_dpp(packed);
-        best_packed = m < best_packed ? m : best_packed;
-      }
-      const unsigned long long best_key = (unsigned long long)(best_packed >> 3);
-      const int best_ord = (int)(best_packed & 7u);
-      fx.key = best_key;
-      fx.order = uni(best_ord);
-      // fixed_lpc returns None when the estimate does not beat verbatim_bits (coding.rs:284):
-      // then no residual is ever coded for it
-      cand = best_key < 8ull + (unsigned long long)n * bps_role ? fx.order : 5;
-    } else {
-      cand = 0;
-    }
-  }
-
   // hoisted: produced by the candidate pass(es) below, consumed by the decision and the records
   int32_t e[64];
   int32_t cq[MAXP];
@@ -601,40 +499,15 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
   int bestk = 0, rice_order = 0, best_parts = 1;
   unsigned long long best_bits = 0, sum_q = 0, sub_bits = 0;
   uint32_t my_p = 0;
-  auto put_own_e = [&](int32_t* buf) {
-#pragma unroll
-    for (int k = 0; k < 64; k += 4) {
-      int4 v;
-      v.x = e[k + 0];
-      v.y = e[k + 1];
-      v.z = e[k + 2];
-      v.w = e[k + 3];
-      *reinterpret_cast<int4*>(&buf[widx(tl + k)]) = v;
-    }
-  };
-#pragma unroll 1
-  for (;;) {
-  if (FIXED && cand != 5) {
-    // ---- the order-`cand` fixed-LPC error signal (coding.rs:182-197) -> e[] ----
-    uint32_t v[68];
-    fixed_load(v);
-#pragma unroll 1
-    for (int lvl = 1; lvl <= cand; ++lvl) {
-#pragma unroll
-      for (int i = 67; i >= 1; --i) v[i] -= v[i - 1];
-    }
-#pragma unroll
-    for (int k = 0; k < 64; ++k) e[k] = (int32_t)v[4 + k];
-    // the first `order` errors are never coded (Residual keeps zeros there, coding.rs:151-160)
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-      if (lane == 0 && k < cand) e[k] = 0;
-    warm = cand;
-    status = 0;
-  } else {
+  // Phase 1 and the first half of phase 2 of the QLPC candidate as one unit: window +
+  // autocorrelation, R[] handed to wave 0, which solves the workgroup's four systems.  Its
+  // results are picked up after a second barrier.  With the fixed-LPC candidate in the kernel this
+  // runs BEFORE the fixed candidate's selection and coding pass, so that the other three waves
+  // do that work instead of idling while wave 0 is in the serial recursion.
+  uint32_t my_maxabs = 0;
+  auto lpc_front = [&]() {
   // ======================= phase 1: window + autocorrelation ==============
   double R[NLAG];
-  uint32_t my_maxabs = 0;
   int vmax = INT32_MIN, vmin = INT32_MAX;
   with_role([&](auto kind) {
     auto ld4 = [&](int t) { return ld4k(kind, t); };
@@ -785,6 +658,149 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
         for (int i = MAXP; i < 32; ++i) a.lpc_coefs[(size_t)sfl * 32 + i] = 0.0;
       }
     }
+  }
+  };
+  if (FIXED) lpc_front();
+
+  // ======================= fixed-LPC candidate: order selection ============
+  // fixed_lpc (coding.rs:298-331).  `cand` walks the candidates that go through the Rice search:
+  // 0..4 = the fixed-LPC error signal of that order, 5 = the QLPC candidate (always last, so e[]
+  // ends up holding its residual).  ApproxEnt (coding.rs:265-287) codes only its argmin order;
+  // BitCount (:243-264) codes every order up to max_order and keeps the first minimum.
+  int cand = 5;
+  FixedChoice fx;
+  fx.have = false;
+  fx.order = 0;
+  fx.key = ~0ull;
+  fx.bestk = 0;
+  fx.my_p = 0;
+  fx.code_bits = fx.sum_q = fx.sub_bits = 0;
+  // the lane's 64 samples + 4 in front of them (zeros in front of the block: the reference's
+  // carry starts at 0, coding.rs:188), differenced `ord` times in place; valid from index ord on
+  auto fixed_load = [&](uint32_t (&v)[68]) {
+    with_role([&](auto kind) {
+#pragma unroll
+      for (int k = 0; k < 17; ++k) {
+        const int4 q = ld4k(kind, tl - 4 + 4 * k);
+        v[4 * k + 0] = (uint32_t)q.x;
+        v[4 * k + 1] = (uint32_t)q.y;
+        v[4 * k + 2] = (uint32_t)q.z;
+        v[4 * k + 3] = (uint32_t)q.w;
+      }
+    });
+  };
+  if (FIXED && a.use_fixed) {
+    if (a.fixed_order_sel == 1u) {
+      // ---- estimate_entropy (coding.rs:200-227) for orders 0..max_order ----
+      // per-lane sums of |e_k| as exact integers: v_sad_u32 on values biased by 2^31 gives
+      // |x - y| of the signed values, i.e. the NEXT order's magnitude, straight from this order's
+      // values; 16-sample sub-sums stay below 2^32 for inputs up to 25 bits, then go to f64
+      double ls[5];
+      {
+        uint32_t b[68];
+        fixed_load(b);
+#pragma unroll
+        for (int i = 0; i < 68; ++i) b[i] ^= 0x80000000u;
+#pragma unroll
+        for (int ord = 0; ord < 5; ++ord) {
+          uint32_t c[4] = {0u, 0u, 0u, 0u};
+          if (ord == 0) {
+#pragma unroll
+            for (int j = 0; j < 64; ++j) c[j >> 4] = sad_u32(b[4 + j], 0x80000000u, c[j >> 4]);
+          } else {
+#pragma unroll
+            for (int j = 0; j < 64; ++j) c[j >> 4] = sad_u32(b[4 + j], b[3 + j], c[j >> 4]);
+            if (ord < 4) {
+#pragma unroll
+              for (int i = 67; i >= ord; --i) b[i] = (b[i] - b[i - 1]) ^ 0x80000000u;
+            }
+          }
+          ls[ord] = ((double)c[0] + (double)c[1]) + ((double)c[2] + (double)c[3]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      // partition sums: partitions of 4096 / P samples = groups of 2^g lanes (P a power of two)
+      const int g = (int)a.fixed_group_log2;
+#pragma unroll 1
+      for (int lvl = 0; lvl < g; ++lvl) {
+#pragma unroll
+        for (int ord = 0; ord < 5; ++ord) ls[ord] += __shfl_xor(ls[ord], 1 << lvl, 64);
+      }
+      // estimate_entropy for several orders at once: the 2^g lanes of a partition all hold its
+      // five sums, so lane j of a group takes order r 2^g + j in pass r.  Its partition estimates
+      // are added up over the groups (lanes with equal j) by the butterfly levels >= g, and the
+      // first minimum of the keys is the minimum of (key << 3 | order).
+      const int G = 1 << g;
+      const int jsub = lane & (G - 1);
+      const uint32_t psize = 64u << g;
+      uint32_t best_packed = 0xFFFFFFFFu;
+#pragma unroll 1
+      for (int r = 0; r * G <= (int)a.fixed_max_order; ++r) {
+        const int ord = r * G + jsub;
+        const bool valid = ord <= (int)a.fixed_max_order;
+        double sv = ls[0];
+#pragma unroll
+        for (int q = 1; q < 5; ++q) sv = (q == ord) ? ls[q] : sv;
+        // sample_count = min(end - warmup, partition_len): only partition 0 loses the warm-up
+        const uint32_t cnt = psize - ((lane >> g) == 0 ? (uint32_t)ord : 0u);
+        uint32_t pb = valid ? approx_ent_bits(sv, cnt) : 0u;
+#pragma unroll 1
+        for (int lvl = g; lvl < 6; ++lvl) pb += (uint32_t)__shfl_xor((int)pb, 1 << lvl, 64);
+        const unsigned long long key = (unsigned long long)pb + bps_role * (unsigned long long)ord;
+        if (a.fixed_keys && valid && lane < G) a.fixed_keys[(size_t)sf * 8 + ord] = key;
+        const uint32_t packed = valid ? (((uint32_t)key << 3) | (uint32_t)ord) : 0xFFFFFFFFu;  // key < 2^29
+        const uint32_t m = wave_min_dpp(packed);
+        best_packed = m < best_packed ? m : best_packed;
+      }
+      const unsigned long long best_key = (unsigned long long)(best_packed >> 3);
+      const int best_ord = (int)(best_packed & 7u);
+      fx.key = best_key;
+      fx.order = uni(best_ord);
+      // fixed_lpc returns None when the estimate does not beat verbatim_bits (coding.rs:284):
+      // then no residual is ever coded for it
+      cand = best_key < 8ull + (unsigned long long)n * bps_role ? fx.order : 5;
+    } else {
+      cand = 0;
+    }
+  }
+
+  auto put_own_e = [&](int32_t* buf) {
+#pragma unroll
+    for (int k = 0; k < 64; k += 4) {
+      int4 v;
+      v.x = e[k + 0];
+      v.y = e[k + 1];
+      v.z = e[k + 2];
+      v.w = e[k + 3];
+      *reinterpret_cast<int4*>(&buf[widx(tl + k)]) = v;
+    }
+  };
+#pragma unroll 1
+  for (;;) {
+  if (FIXED && cand != 5) {
+    // ---- the order-`cand` fixed-LPC error signal (coding.rs:182-197) -> e[] ----
+    uint32_t v[68];
+    fixed_load(v);
+#pragma unroll 1
+    for (int lvl = 1; lvl <= cand; ++lvl) {
+#pragma unroll
+      for (int i = 67; i >= 1; --i) v[i] -= v[i - 1];
+    }
+#pragma unroll
+    for (int k = 0; k < 64; ++k) e[k] = (int32_t)v[4 + k];
+    // the first `order` errors are never coded (Residual keeps zeros there, coding.rs:151-160)
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (lane == 0 && k < cand) e[k] = 0;
+    warm = cand;
+    status = 0;
+  } else {
+  if (!FIXED) lpc_front();  // (FIXED: already run before the fixed-LPC work, see there)
+  {
+    constexpr int XR = (NLAG + 1) & ~1;
+    double* const xr = reinterpret_cast<double*>(sm + NIMG * kBufDwords);  // [4][XR]
+    int32_t* const xq = reinterpret_cast<int32_t*>(xr + 4 * XR);                   // [4][16]
+    (void)xr;
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < MAXP; ++i) cq[i] = uni(xq[wave * 16 + i]);

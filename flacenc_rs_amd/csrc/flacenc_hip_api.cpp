@@ -1318,7 +1318,7 @@ static int encode_stereo_frames_impl(flacenc_hip_handle* h, const flacenc_hip_fr
   a.pred_out = nullptr;
   a.split_scratch = nullptr;
   // The fused bit writer pays off when the fixed-LPC candidate is on (measured on MI355X, 8192 frames:
-  // 0.69 ms vs 0.53 + 0.22 ms in two launches); without it the packing tail -- two of the four waves
+  // 0.64 ms vs 0.49 + 0.22 ms in two launches); without it the packing tail -- two of the four waves
   // busy, 8 waves per CU to hide the CRC's table latency -- costs more than the separate packer
   // running at full occupancy (0.54 vs 0.30 + 0.22 ms), so that case stays two-stage.
   // FLACENC_HIP_FUSED_PACK=0 / 1 overrides the choice (A/B timing).

@@ -8,30 +8,43 @@ makes (L, R, M, S; src/coding.rs:530-544, 476-491), each = window -> f64 autocor
 Workload = BASELINE.json configs[1]: 44.1 kHz / 16-bit stereo, block 4096, LPC order 8
 (the reference has no "fixed Rice partition order" mode, so the reference-faithful full
 search is what runs).  value = input channel-samples (frames x 2 x 4096) per second over
-all ranks.  Multi-GPU: frames are sharded over ranks (weak scaling); each step every rank derives
-its frames' byte lengths from the decision records and the ranks all-gather those 4 bytes per
-frame over RCCL and prefix-sum them into stream offsets (ParSink's ordered gather, src/par.rs:67-95,
-reduced to what ordering needs); records and residuals stay on the producing GPU.
+all ranks.
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+Multi-GPU: one process per GPU, stream frame f belongs to rank f mod G (weak scaling: fixed frames
+per GPU).  Each step every rank derives its frames' byte lengths from the decision records, and the
+ranks all-gather over RCCL (a) those lengths and (b) the encoded SubFrame components -- the 752-byte
+frame records: channel assignment, subframe kinds, quantised coefficients, shift, Rice partition
+order and parameters, bit counts -- and put both into stream order (ParSink's ordered gather,
+src/par.rs:67-95).  `--gather payload` moves the packed FLAC frame bytes as well, `--gather lengths`
+only what ordering needs.  The exchange of step k runs on its own HIP stream under step k + 1.
+
+    python bench.py                         # 1 GPU
+    python bench.py --gpus 8                # starts 8 ranks itself (torch.distributed.run)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N   # or let a launcher start the ranks
+    python bench.py --gpus 2 --backend gloo --dry-run   # CPU check of launch + exchange plumbing
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 ALGO_BYTES_PER_SAMPLE = 8.0  # 4 B sample read + 4 B residual written per input channel-sample
+N_SIMDS = 256 * 4  # 256 CUs x 4 SIMDs
+VALU_ISSUE_CYCLES = 4  # a wave64 VALU instruction occupies its SIMD for 4 cycles (f64 fma included)
+SHADER_CLOCK_HZ = 2.4e9
+SAMPLE_RATE = 44100
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -42,21 +55,113 @@ def main():
     ap.add_argument("--bps", type=int, default=16)
     ap.add_argument("--use-fixed", action="store_true",
                     help="also run the fixed-LPC candidate (the reference's default SubFrameCoding); "
-                         "not the north-star workload, reported in DESIGN.md")
+                         "not the north-star workload (it is reported under `secondary`)")
     ap.add_argument("--finest-rice-order", action="store_true",
                     help="build extension (not a reference mode): keep the finest Rice partition order, "
-                         "BASELINE config 2's 'fixed Rice partition order'; reported in DESIGN.md, not the default")
-    ap.add_argument("--gather", choices=["lengths", "records"], default="lengths",
-                    help="what the multi-GPU exchange step moves: the frames' byte lengths (4 B/frame, enough to "
-                         "place every frame in the stream; default) or the whole 752-B decision records "
-                         "(every SubFrame component on every rank)")
+                         "BASELINE config 2's 'fixed Rice partition order'; not the default")
+    ap.add_argument("--gather", choices=["records", "payload", "lengths"], default="records",
+                    help="what the multi-GPU exchange moves besides the frames' byte lengths: the 752-B "
+                         "decision records = the encoded SubFrame components (default), the packed frame "
+                         "bytes too (payload), or nothing (lengths)")
     ap.add_argument("--force-exchange", action="store_true",
-                    help="run the multi-GPU exchange step (frame lengths -> offsets) even with one rank; "
-                         "for measuring its cost, not a reported configuration")
+                    help="run the multi-GPU exchange step even with one rank; for measuring its cost")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="torch.distributed backend; nccl is RCCL on ROCm.  gloo only with --dry-run")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="CPU check of the launch and exchange plumbing (no GPU, no analysis, no "
+                         "measurement): stand-in records, real sharding + collectives over gloo")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU work for cpu_baseline")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(args, argv):
+    """`--gpus N` without a launcher: start N rank processes (one per GPU) and relay rank 0's JSON
+    line.  This parent never imports torch or touches the GPU, and nothing is exec'ed from a process
+    that has: the ranks are fresh children of torch.distributed.run."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.backend == "gloo" and not args.dry_run:
+        raise SystemExit("--backend gloo is only for --dry-run (the product path has no CPU fallback)")
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        sys.exit(launch_ranks(args, argv))
+    world = int(env_world or "1")
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; start one rank per GPU "
+              f"(python bench.py --gpus N does that itself)", file=sys.stderr)
+        sys.exit(2)
+    if args.dry_run:
+        dry_run(args, world)
+    else:
+        run(args, world)
+
+
+# ---------------------------------------------------------------------------------------------
+def kernel_source_sha():
+    """Fingerprint of the fused kernel's source: profile-derived figures are only attached to a run of
+    the very code they were measured on."""
+    h = hashlib.sha256()
+    for name in ("qlpc_wave_kernel_impl.h", "qlpc_wave_inst.hip", "qlpc_dispatch.cpp"):
+        with open(os.path.join(ROOT, "flacenc_rs_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def profiled_counters(args):
+    """Per-launch figures from the committed rocprofv3 PMC passes (profiles/headline_pmc.json): HBM
+    bytes and VALU instructions per wave.  None unless this run is the profiled configuration AND the
+    kernel source is the profiled one."""
+    default = parse_args([])
+    same_cfg = all(getattr(args, k) == getattr(default, k)
+                   for k in ("frames", "block_size", "lpc_order", "bps", "use_fixed", "finest_rice_order"))
+    try:
+        with open(os.path.join(ROOT, "profiles", "headline_pmc.json")) as f:
+            p = json.load(f)
+    except Exception:
+        return None
+    if not same_cfg or p.get("kernel_source_sha") != kernel_source_sha():
+        return None
+    return p
+
+
+def kernel_name(args):
+    """The kernel flacenc_hip_encode_stereo_frames dispatches to for this run (qlpc_dispatch.cpp)."""
+    if args.block_size == 4096 and args.lpc_order <= 12:
+        maxp = 8 if args.lpc_order <= 8 else 10 if args.lpc_order <= 10 else 12
+        return "qlpc_wave4096_kernel<%d,true,true,%s,false>" % (maxp, "true" if args.use_fixed else "false")
+    return "qlpc_subframe_kernel (+ fixed-LPC batch) + frame_decide_kernel"
+
+
+def stats(ms):
+    import numpy as np
+    a = np.asarray(ms, dtype=np.float64)
+    return {"min": round(float(a.min()), 4), "median": round(float(np.median(a)), 4),
+            "mean": round(float(a.mean()), 4), "max": round(float(a.max()), 4), "n": int(a.size)}
+
+
+def run(args, world):
+    import numpy as np
     import torch
     import torch.distributed as dist
 
@@ -64,21 +169,25 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the product path)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    ranks_observed = 1
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
+        one = torch.ones(1, dtype=torch.int32, device=dev)
+        dist.all_reduce(one)  # counted by RCCL itself, not read from the environment
+        ranks_observed = int(one.item())
+        assert ranks_observed == dist.get_world_size() == world
 
     n, F, bps = args.block_size, args.frames, args.bps
     # precision 15, Tukey(0.4), max_p 30; candidates Constant / Verbatim / LPC -- the QLPC analysis path
     # the metric names (--use-fixed adds the reference default's fixed-LPC candidate); all stereo
     # assignments allowed
-    cfg = _capi.make_frame_config(_capi.make_config(lpc_order=args.lpc_order, rice_finest_only=args.finest_rice_order),
-                                  use_fixed=args.use_fixed)
+    qcfg = _capi.make_config(lpc_order=args.lpc_order, rice_finest_only=args.finest_rice_order)
+    cfg = _capi.make_frame_config(qcfg, use_fixed=args.use_fixed)
     # synthetic "sigen" audio: Sine(200, 0.4) + Noise(0.4) like the reference's
     # stereo_frame_encoder_noisy_sine_lpc bench (src/coding.rs:1152), one continuous stream,
     # dealt round-robin: stream frame f belongs to rank f mod G (flacenc_rs_amd/shard.py)
@@ -90,23 +199,34 @@ def main():
     # stream) overlaps the analysis of step k + 1
     results2 = [torch.empty((F, rec_bytes), dtype=torch.uint8, device=dev) for _ in range(2)]
     frame_len2 = [torch.zeros(F, dtype=torch.int32, device=dev) for _ in range(2)]
-    results = results2[0]
     residual = torch.empty((F * 2, n), dtype=torch.int32, device=dev)     # the two chosen channels
     handle = _capi.Handle(local_rank)
     stream = torch.cuda.current_stream()
     comm = torch.cuda.Stream(device=dev)
     exchanging = world > 1 or args.force_exchange
+    payload = exchanging and args.gather == "payload"
+    if payload:
+        out_stride = handle.frame_bytes_bound(n, bps)
+        packed2 = [torch.empty((F, out_stride), dtype=torch.uint8, device=dev) for _ in range(2)]
     consumed = [None, None]  # event: the exchange that read buffer b has finished
     step_no = [0]
+    last_exchange = {}
 
     def exchange(b):
-        # the multi-GPU exchange step: frame byte lengths -> stream order -> stream offsets
-        handle.stereo_frame_lengths_device(results2[b].data_ptr(), F, n, bps, 44100, rank, world,
-                                           frame_len2[b].data_ptr(), stream=comm.cuda_stream)
+        # the multi-GPU exchange step (ParSink's ordered gather): byte lengths -> stream order ->
+        # stream offsets, then the encoded components themselves in stream order
+        if not payload:
+            handle.stereo_frame_lengths_device(results2[b].data_ptr(), F, n, bps, SAMPLE_RATE, rank, world,
+                                               frame_len2[b].data_ptr(), stream=comm.cuda_stream)
         lengths_all = shard.all_gather_frame_lengths(frame_len2[b], world * F)
-        if args.gather == "records":
-            shard.all_gather_records(results2[b], world * F)
-        return shard.stream_offsets(lengths_all)[0]
+        offsets, total = shard.stream_offsets(lengths_all)
+        last_exchange.update(lengths_all=lengths_all, offsets=offsets, total=total)
+        if args.gather in ("records", "payload"):
+            last_exchange["records_all"] = shard.all_gather_records(results2[b], world * F)
+        if payload:
+            last_exchange["stream_bytes"] = shard.all_gather_frame_bytes(
+                shard.device_place(handle, comm.cuda_stream), packed2[b], frame_len2[b], lengths_all, offsets,
+                world * F)
 
     def step(events=None):
         b = step_no[0] & 1
@@ -119,6 +239,11 @@ def main():
                                            residual.data_ptr(), n, stream=stream.cuda_stream)
         if events:
             events[1].record(stream)
+        if payload:
+            # Frame::write on the producing GPU: the payload of the exchange
+            handle.pack_stereo_frames_device(x.data_ptr(), F, n, n, results2[b].data_ptr(), residual.data_ptr(), n,
+                                             bps, SAMPLE_RATE, rank, world, packed2[b].data_ptr(), out_stride,
+                                             frame_len2[b].data_ptr(), stream=stream.cuda_stream)
         if exchanging:
             ready = torch.cuda.Event()
             ready.record(stream)
@@ -148,24 +273,47 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if args.steps else float("nan")
+    kernel_times = [a.elapsed_time(b) for a, b in ev] if args.steps else [float("nan")]
+    kernel_ms = float(np.mean(kernel_times))
 
     # sanity: nothing in the timed region may have failed
-    p = np.frombuffer(results2[(step_no[0] - 1) & 1].cpu().numpy().tobytes(), dtype=_capi.FRAME_RESULT_DTYPE)
+    last_b = (step_no[0] - 1) & 1
+    p = np.frombuffer(results2[last_b].cpu().numpy().tobytes(), dtype=_capi.FRAME_RESULT_DTYPE)
     lpc_kind = p["kind"] >= 2
     assert (p["lpc"]["status"][lpc_kind] == 0).all(), "subframe status != 0"
     chosen_bits = int(sum(int(p["bits"][f, r]) for f in range(F) for r in p["role"][f]))
     assign_hist = np.bincount(p["channel_assignment"], minlength=4).tolist()
+    exchange_check = None
+    if exchanging:
+        exchange_check = check_exchange(torch, dist, last_exchange, results2[last_b], frame_len2[last_b], rank,
+                                        world, F, packed2[last_b] if payload else None)
 
     samples_per_step = F * 2 * n  # input channel-samples per rank per step
     value = world * samples_per_step * args.steps / elapsed / 1e6
     achieved = ALGO_BYTES_PER_SAMPLE * samples_per_step / (kernel_ms * 1e-3) / 1e9
+    prof = profiled_counters(args)
+    valu_frac = None
+    if prof and prof.get("valu_insts_per_wave"):
+        # instruction counts are a property of kernel + data; the busy fraction uses the live duration
+        waves = 4 * F
+        valu_frac = round(prof["valu_insts_per_wave"] * VALU_ISSUE_CYCLES * waves / N_SIMDS / SHADER_CLOCK_HZ
+                          / (kernel_ms * 1e-3), 4)
+
+    gather_desc = "none"
+    if exchanging:
+        gather_desc = "RCCL all_gather of per-frame byte lengths (4 B/frame) + prefix sum to stream offsets"
+        if args.gather in ("records", "payload"):
+            gather_desc += " + all_gather of the 752-B frame records (the encoded SubFrame components) into stream order"
+        if payload:
+            gather_desc += " + Frame::write on the producing GPU and all_gather of the packed frame bytes, placed at their stream offsets"
+        gather_desc += "; on its own stream, overlapping the next step's analysis"
 
     out = {
         "metric": "Msamples/s encoded (44.1kHz/16b stereo, block=4096): QLPC analysis path",
         "value": round(value, 2),
         "unit": "Msamples/s",
         "n_gpus": world,
+        "ranks_observed": ranks_observed,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 4),
@@ -185,9 +333,8 @@ def main():
             "decision": ("encode_subframe {Constant, Verbatim, FixedLpc(ApproxEnt 16), LPC}" if args.use_fixed
                          else "encode_subframe {Constant, Verbatim, LPC}") +
                         " + try_stereo_coding on the GPU; the two chosen residuals written",
-            "gather": (("all_gather of per-frame byte lengths (4 B/frame, RCCL) + prefix sum to stream offsets"
-                        + (" + all_gather of the 752-B frame records" if args.gather == "records" else "")
-                        + ", on its own stream, overlapping the next step's analysis") if world > 1 else "none"),
+            "gather": gather_desc,
+            "exchange_check": exchange_check,
             "subframe_bits_per_sample": round(chosen_bits / (2 * F * n), 4),
             "assignments_indep_left_right_mid": assign_hist,
         },
@@ -197,13 +344,21 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": _measured_traffic(),
-            "kernel": "qlpc_wave4096_kernel<8,true,true,%s,false>" % ("true" if args.use_fixed else "false"),
+            "traffic": prof.get("bytes_per_launch") if prof else None,
+            "kernel": kernel_name(args),
             "kernel_ms": round(kernel_ms, 4),
+            "kernel_ms_stats": stats(kernel_times),
             "algorithmic_bytes_per_launch": ALGO_BYTES_PER_SAMPLE * samples_per_step,
+            # what the counters say binds the kernel: the HBM roof above is the roof the path is priced
+            # against, the VALU issue slots are what it actually runs out of
+            "limiter": "valu_issue",
+            "valu_issue_frac": valu_frac,
+            "counters_from": ("profiles/headline_pmc.json @ kernel source %s" % prof["kernel_source_sha"]) if prof else None,
         },
     }
 
+    if rank == 0 and world == 1 and not args.no_secondary:
+        out["secondary"] = secondary(torch, _capi, handle, args, dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(host, bps, args, n)
     if rank == 0:
@@ -213,16 +368,188 @@ def main():
         dist.destroy_process_group()
 
 
-def _measured_traffic():
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/), or None."""
-    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    try:
-        with open(path) as f:
-            return json.load(f).get("bytes_per_launch")
-    except Exception:
-        return None
+def check_exchange(torch, dist, ex, my_records, my_lengths, rank, world, F, my_packed):
+    """After the timed region: what the last exchange delivered must contain this rank's own frames at
+    stream positions rank, rank + G, ... and, summed over ranks, account for every frame once."""
+    torch.cuda.synchronize()
+    lengths_all, offsets = ex["lengths_all"], ex["offsets"]
+    ok = bool(torch.equal(lengths_all[rank::world], my_lengths))
+    ok &= int(offsets[0]) == 0 and bool((offsets[1:] - offsets[:-1] == lengths_all[:-1].to(offsets.dtype)).all())
+    if "records_all" in ex:
+        ok &= bool(torch.equal(ex["records_all"][rank::world], my_records))
+    if "stream_bytes" in ex:
+        sb = ex["stream_bytes"]
+        ok &= int(ex["total"]) == int(lengths_all.to(torch.int64).sum())
+        for j in (0, F // 2, F - 1):  # spot-check this rank's frames inside the assembled stream
+            f = j * world + rank
+            o, ln = int(offsets[f]), int(lengths_all[f])
+            ok &= bool(torch.equal(sb[o:o + ln], my_packed[j, :ln]))
+    total = lengths_all.to(torch.int64).sum().reshape(1).clone()
+    if world > 1:
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=lengths_all.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        ok = bool(flag.item())
+        # every rank must have assembled the same stream
+        lo, hi = total.clone(), total.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        ok &= int(lo.item()) == int(hi.item())
+    assert ok, "multi-GPU exchange delivered wrong data"
+    return {"ok": ok, "stream_frames": int(lengths_all.numel()), "stream_bytes": int(total.item())}
 
 
+def secondary(torch, _capi, handle, args, dev):
+    """Driver-timed side measurements at N = 1 (HIP events on the launch stream, a few launches each):
+    the reference's default candidate set (use_fixed), the one-call PCM -> FLAC-frame-bytes path, and a
+    tonal low-residual workload (Sine(36,0.4)+Noise(0.04), src/lib.rs:219-221) on the headline kernel."""
+    import numpy as np
+    n, F, bps = args.block_size, args.frames, args.bps
+    steps, warm = 6, 2
+    stream = torch.cuda.current_stream()
+    rec_bytes = _capi.FRAME_RESULT_DTYPE.itemsize
+    results = torch.empty((F, rec_bytes), dtype=torch.uint8, device=dev)
+    residual = torch.empty((F * 2, n), dtype=torch.int32, device=dev)
+    out_stride = handle.frame_bytes_bound(n, bps)
+    packed = torch.empty((F, out_stride), dtype=torch.uint8, device=dev)
+    lens = torch.zeros(F, dtype=torch.int32, device=dev)
+    qcfg = _capi.make_config(lpc_order=args.lpc_order, rice_finest_only=args.finest_rice_order)
+
+    def timed(fn):
+        for _ in range(warm):
+            fn()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        for a, b in ev:
+            a.record(stream)
+            fn()
+            b.record(stream)
+        torch.cuda.synchronize()
+        ms = [a.elapsed_time(b) for a, b in ev]
+        return ms
+
+    def entry(ms, extra=None):
+        med = float(np.median(ms))
+        e = {"ms_per_launch": stats(ms), "Msamples_per_s": round(F * 2 * n / (med * 1e-3) / 1e6, 1),
+             "hbm_frac": round(ALGO_BYTES_PER_SAMPLE * F * 2 * n / (med * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        if extra:
+            e.update(extra)
+        return e
+
+    def bits_per_sample():
+        p = np.frombuffer(results.cpu().numpy().tobytes(), dtype=_capi.FRAME_RESULT_DTYPE)
+        rows = np.arange(F)
+        return round(float(sum(int(p["bits"][rows, p["role"][:, c]].sum()) for c in range(2))) / (2 * F * n), 4)
+
+    sec = {}
+    noisy = torch.from_numpy(_capi.sigen_frames(F, 2, n, bps, 200.0, 0.4, 0.4, seed=0xF1AC0001)).to(dev)
+    for name, use_fixed in (("default_config_use_fixed", True),):
+        fcfg = _capi.make_frame_config(qcfg, use_fixed=use_fixed)
+        ms = timed(lambda: handle.encode_stereo_frames_device(fcfg, noisy.data_ptr(), F, n, n, bps, results.data_ptr(),
+                                                              residual.data_ptr(), n, stream=stream.cuda_stream))
+        sec[name] = entry(ms, {"what": "encode_frame decision with the fixed-LPC candidate (reference default "
+                                       "SubFrameCoding), same frames", "subframe_bits_per_sample": bits_per_sample()})
+    for name, use_fixed in (("pcm_to_frame_bytes", False), ("pcm_to_frame_bytes_use_fixed", True)):
+        fcfg = _capi.make_frame_config(qcfg, use_fixed=use_fixed)
+        ms = timed(lambda: handle.encode_pack_stereo_frames_device(
+            fcfg, noisy.data_ptr(), F, n, n, bps, SAMPLE_RATE, 0, 1, results.data_ptr(), packed.data_ptr(),
+            out_stride, lens.data_ptr(), stream=stream.cuda_stream))
+        sec[name] = entry(ms, {"what": "one call, PCM in HBM -> FLAC frame bytes in HBM (analysis + decision + "
+                                       "Frame::write with both CRCs)",
+                               "frame_bytes_per_step": int(lens.to(torch.int64).sum().item())})
+    del noisy
+    tonal = torch.from_numpy(_capi.sigen_frames(F, 2, n, bps, 36.0, 0.4, 0.04, seed=0xF1AC0002)).to(dev)
+    fcfg = _capi.make_frame_config(qcfg, use_fixed=False)
+    ms = timed(lambda: handle.encode_stereo_frames_device(fcfg, tonal.data_ptr(), F, n, n, bps, results.data_ptr(),
+                                                          residual.data_ptr(), n, stream=stream.cuda_stream))
+    sec["tonal_workload"] = entry(ms, {"what": "headline kernel on sigen Sine(36,0.4)+Noise(0.04) (src/lib.rs:219-221)",
+                                       "subframe_bits_per_sample": bits_per_sample()})
+    return sec
+
+
+# ---------------------------------------------------------------------------------------------
+def dry_run(args, world):
+    """CPU check of what cannot be exercised on a 1-GPU box: that `--gpus N` really yields N ranks and
+    that sharding + the ordered exchange deliver every frame once, in stream order, on every rank.
+    The analysis is replaced by stand-in records (frame number stamped into the record, a length that
+    is a function of the frame number); the collectives and shard.py are the real ones.  Measures
+    nothing: `value` is 0 and `dry_run` is true."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from flacenc_rs_amd import shard
+
+    rank = int(os.environ.get("RANK", "0"))
+    ranks_observed = 1
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(args.backend)
+        one = torch.ones(1, dtype=torch.int32)
+        dist.all_reduce(one)
+        ranks_observed = int(one.item())
+        assert ranks_observed == dist.get_world_size() == world
+    F = min(args.frames, 64)
+    total_frames = world * F
+    rec_bytes = 752
+
+    def length_of(f):
+        return 1000 + (f * 7919) % 977
+
+    mine = list(shard.frames_of_rank(total_frames, rank, world))
+    recs = np.zeros((F, rec_bytes), np.uint8)
+    for j, f in enumerate(mine):
+        recs[j, :4] = np.frombuffer(np.uint32(f).tobytes(), np.uint8)
+        recs[j, 4:] = (f * 31 + np.arange(rec_bytes - 4)) & 0xFF
+    lens = torch.tensor([length_of(f) for f in mine], dtype=torch.int32)
+    cap = 2048
+    packed = torch.zeros((F, cap), dtype=torch.uint8)
+    for j, f in enumerate(mine):
+        packed[j, :length_of(f)] = torch.arange(length_of(f), dtype=torch.int64).add(f).remainder(251).to(torch.uint8)
+
+    def host_place(src, src_offsets, lengths, dst, dst_offsets):
+        # dry-run stand-in for flacenc_hip_place_frames_async (the product passes shard.device_place)
+        s, d = src.reshape(-1), dst.reshape(-1)
+        for so, ln, do in zip(src_offsets.tolist(), lengths.tolist(), dst_offsets.tolist()):
+            d[do:do + ln] = s[so:so + ln]
+
+    ok = True
+    for _ in range(max(1, args.steps)):
+        lengths_all = shard.all_gather_frame_lengths(lens, total_frames)
+        offsets, total = shard.stream_offsets(lengths_all)
+        want = [length_of(f) for f in range(total_frames)]
+        ok &= lengths_all.tolist() == want
+        ok &= offsets.tolist() == np.concatenate([[0], np.cumsum(want)[:-1]]).tolist() and int(total) == sum(want)
+        if args.gather in ("records", "payload"):
+            ordered = shard.all_gather_records(torch.from_numpy(recs), total_frames).numpy()
+            ids = ordered[:, :4].copy().view(np.uint32).reshape(-1)
+            ok &= ids.tolist() == list(range(total_frames))
+            ok &= all(np.array_equal(ordered[f, 4:], (f * 31 + np.arange(rec_bytes - 4)) & 0xFF)
+                      for f in range(total_frames))
+        if args.gather == "payload":
+            sb = shard.all_gather_frame_bytes(host_place, packed, lens, lengths_all, offsets, total_frames)
+            ok &= sb.numel() >= sum(want)
+            for f in range(total_frames):
+                o = int(offsets[f])
+                w = torch.arange(want[f], dtype=torch.int64).add(f).remainder(251).to(torch.uint8)
+                ok &= bool(torch.equal(sb[o:o + want[f]], w))
+    if world > 1:
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        ok = bool(flag.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "Msamples/s encoded (44.1kHz/16b stereo, block=4096): QLPC analysis path",
+            "dry_run": True, "value": 0.0, "unit": "Msamples/s", "n_gpus": world,
+            "ranks_observed": ranks_observed, "backend": args.backend, "steps": args.steps, "warmup": args.warmup,
+            "config": {"workload": "dry run: stand-in records, real sharding + collectives; nothing measured",
+                       "gather": args.gather, "exchange_check": {"ok": ok, "stream_frames": total_frames}},
+        }), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    if not ok:
+        sys.exit(1)
+
+
+# ---------------------------------------------------------------------------------------------
 def usable_cores():
     """Host threads this process may really use: affinity mask capped by the cgroup CPU quota."""
     cores = len(os.sched_getaffinity(0))
@@ -238,6 +565,8 @@ def usable_cores():
 def cpu_baseline(host, bps, args, n):
     """The oracle (a port of the reference's path in reference summation order) timed on this
     box's host cores over a bounded sample of the same frames."""
+    import numpy as np
+
     from oracle import oracle as orc
 
     cores = usable_cores()

@@ -58,6 +58,7 @@ EXPORTED_SYMBOLS = (
     "flacenc_hip_pack_stereo_frames",
     "flacenc_hip_pack_stereo_frames_async",
     "flacenc_hip_stereo_frame_lengths_async",
+    "flacenc_hip_place_frames_async",
     "flacenc_hip_encode_frames",
     "flacenc_hip_encode_frames_async",
     "flacenc_hip_frame_bytes_bound",
@@ -239,6 +240,8 @@ def load() -> C.CDLL:
     L.flacenc_hip_stereo_frame_lengths_async.argtypes = [vp, vp, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32,
                                                           C.c_uint32, C.c_uint32, vp, vp]
     L.flacenc_hip_stereo_frame_lengths_async.restype = C.c_int
+    L.flacenc_hip_place_frames_async.argtypes = [vp, vp, vp, vp, C.c_size_t, vp, vp, vp]
+    L.flacenc_hip_place_frames_async.restype = C.c_int
     L.flacenc_hip_fill_le_bytes.argtypes = [vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_size_t, C.c_uint32, i32p,
                                             C.c_size_t, C.c_int]
     L.flacenc_hip_fill_le_bytes.restype = C.c_int
@@ -287,6 +290,9 @@ def load() -> C.CDLL:
 
 
 FLAG_FINEST_RICE_ORDER = 2
+FLAG_GENERIC_KERNEL = 4
+FLAG_FUSED_PACK = 8
+FLAG_TWO_STAGE_PACK = 16
 
 
 def make_config(lpc_order=10, quant_precision=15, window=("tukey", 0.4), max_rice_parameter=30,
@@ -481,6 +487,14 @@ class Handle:
         rc = self._lib.flacenc_hip_stereo_frame_lengths_async(
             self._h, results_ptr, n_frames, block_size, bits_per_sample, sample_rate, first_frame_number,
             frame_number_step, out_len_ptr, stream or None)
+        self._check(rc)
+
+    def place_frames_device(self, src_ptr: int, src_offsets_ptr: int, lengths_ptr: int, n_frames: int, dst_ptr: int,
+                            dst_offsets_ptr: int, stream: int | None = None):
+        """ParSink's reordering on the GPU: frame i = lengths[i] bytes, src + src_offsets[i] -> dst + dst_offsets[i]
+        (uint64 offsets, uint32 lengths, all device pointers)."""
+        rc = self._lib.flacenc_hip_place_frames_async(self._h, src_ptr, src_offsets_ptr, lengths_ptr, n_frames,
+                                                      dst_ptr, dst_offsets_ptr, stream or None)
         self._check(rc)
 
     def fill_le_bytes(self, data: bytes, channels: int, bytes_per_sample: int, block_size: int):

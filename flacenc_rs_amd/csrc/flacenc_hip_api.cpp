@@ -205,6 +205,7 @@ int enqueue(flacenc_hip_handle* h, const flacenc_hip_qlpc_config* cfg, const int
   a.precision = cfg->quant_precision;
   a.max_rice_parameter = cfg->max_rice_parameter;
   a.rice_finest_only = (cfg->flags & FLACENC_HIP_FLAG_FINEST_RICE_ORDER) ? 1u : 0u;
+  a.force_generic = (cfg->flags & FLACENC_HIP_FLAG_GENERIC_KERNEL) ? 1u : 0u;
   a.params = params;
   a.residual = residual;
   a.residual_stride = residual_stride;
@@ -380,6 +381,7 @@ int enqueue_fixed(flacenc_hip_handle* h, const flacenc_hip_frame_config* cfg, co
   a.precision = 0;
   a.max_rice_parameter = cfg->qlpc.max_rice_parameter;
   a.rice_finest_only = (cfg->qlpc.flags & FLACENC_HIP_FLAG_FINEST_RICE_ORDER) ? 1u : 0u;
+  a.force_generic = (cfg->qlpc.flags & FLACENC_HIP_FLAG_GENERIC_KERNEL) ? 1u : 0u;
   a.params = params;
   a.residual = residual;
   a.residual_stride = residual_stride;
@@ -720,6 +722,19 @@ int flacenc_hip_stereo_frame_lengths_async(flacenc_hip_handle* h, const flacenc_
   return FLACENC_HIP_OK;
 }
 
+int flacenc_hip_place_frames_async(flacenc_hip_handle* h, const uint8_t* src, const uint64_t* src_offsets,
+                                   const uint32_t* lengths, size_t n_frames, uint8_t* dst,
+                                   const uint64_t* dst_offsets, void* stream) {
+  if (!h) return FLACENC_HIP_ERR_BAD_ARGUMENT;
+  if (n_frames == 0) return FLACENC_HIP_OK;
+  if (!src || !src_offsets || !lengths || !dst || !dst_offsets || n_frames > 0x7FFFFFFFull)
+    return FLACENC_HIP_ERR_BAD_ARGUMENT;
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, flacenc_hip::launch_place_frames(src, src_offsets, lengths, dst, dst_offsets,
+                                              static_cast<uint32_t>(n_frames), static_cast<hipStream_t>(stream)));
+  return FLACENC_HIP_OK;
+}
+
 int flacenc_hip_pack_stereo_frames(flacenc_hip_handle* h, const int32_t* frames, size_t n_frames,
                                    uint32_t block_size, size_t stride,
                                    const flacenc_hip_stereo_frame_result* results, const int32_t* residual,
@@ -817,6 +832,7 @@ int flacenc_hip_encode_frames_async(flacenc_hip_handle* h, const flacenc_hip_fra
     a.precision = cfg->qlpc.quant_precision;
     a.max_rice_parameter = cfg->qlpc.max_rice_parameter;
   a.rice_finest_only = (cfg->qlpc.flags & FLACENC_HIP_FLAG_FINEST_RICE_ORDER) ? 1u : 0u;
+  a.force_generic = (cfg->qlpc.flags & FLACENC_HIP_FLAG_GENERIC_KERNEL) ? 1u : 0u;
     a.params = nullptr;
     a.residual = residual;
     a.residual_stride = residual_stride;
@@ -1290,6 +1306,7 @@ static int encode_stereo_frames_impl(flacenc_hip_handle* h, const flacenc_hip_fr
   a.precision = cfg->qlpc.quant_precision;
   a.max_rice_parameter = cfg->qlpc.max_rice_parameter;
   a.rice_finest_only = (cfg->qlpc.flags & FLACENC_HIP_FLAG_FINEST_RICE_ORDER) ? 1u : 0u;
+  a.force_generic = (cfg->qlpc.flags & FLACENC_HIP_FLAG_GENERIC_KERNEL) ? 1u : 0u;
   a.params = nullptr;
   a.residual = residual;
   a.residual_stride = residual_stride;
@@ -1321,9 +1338,10 @@ static int encode_stereo_frames_impl(flacenc_hip_handle* h, const flacenc_hip_fr
   // 0.64 ms vs 0.49 + 0.22 ms in two launches); without it the packing tail -- two of the four waves
   // busy, 8 waves per CU to hide the CRC's table latency -- costs more than the separate packer
   // running at full occupancy (0.54 vs 0.30 + 0.22 ms), so that case stays two-stage.
-  // FLACENC_HIP_FUSED_PACK=0 / 1 overrides the choice (A/B timing).
+  // FLACENC_HIP_FLAG_FUSED_PACK / _TWO_STAGE_PACK in cfg->qlpc.flags override the choice (A/B timing).
   bool want_fused = cfg->use_fixed != 0;
-  if (const char* ov = getenv("FLACENC_HIP_FUSED_PACK")) want_fused = ov[0] == '1';
+  if (cfg->qlpc.flags & FLACENC_HIP_FLAG_FUSED_PACK) want_fused = true;
+  if (cfg->qlpc.flags & FLACENC_HIP_FLAG_TWO_STAGE_PACK) want_fused = false;
   if (pack && want_fused && !fixed_composite && flacenc_hip::wave_kernel_eligible(a)) {
     const size_t bound = flacenc_hip_stereo_frame_bytes_bound(block_size, bits_per_sample);
     flacenc_hip::FramePackArgs pa{};

@@ -14,6 +14,7 @@
 #include "frame_pack.h"
 
 #include "frame_bits.h"
+#include "lds_opt_in.h"
 
 namespace flacenc_hip {
 namespace {
@@ -369,6 +370,47 @@ size_t frame_bytes_bound(uint32_t channels, uint32_t block_size, uint32_t bits_p
   return 15 + (bits + 7) / 8 + 2;
 }
 
+// One workgroup per frame.  Destination-aligned dword stores; the source dword that feeds each of them
+// is assembled from two aligned loads with v_alignbyte_b32, so a frame moves at dword granularity
+// whatever the two byte offsets are (frames are byte-aligned in a FLAC stream, nothing more).
+__global__ __launch_bounds__(256) void place_frames_kernel(const uint8_t* __restrict__ src,
+                                                           const uint64_t* __restrict__ src_offsets,
+                                                           const uint32_t* __restrict__ lengths,
+                                                           uint8_t* __restrict__ dst,
+                                                           const uint64_t* __restrict__ dst_offsets) {
+  const uint32_t f = blockIdx.x;
+  const uint8_t* s = src + src_offsets[f];
+  uint8_t* d = dst + dst_offsets[f];
+  uint32_t len = lengths[f];
+  uint32_t head = static_cast<uint32_t>(-reinterpret_cast<uintptr_t>(d)) & 3u;
+  if (head > len) head = len;
+  if (threadIdx.x < head) d[threadIdx.x] = s[threadIdx.x];
+  s += head;
+  d += head;
+  len -= head;
+  const uint32_t n_dwords = len >> 2;
+  const uint32_t skew = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(s)) & 3u;
+  const uint32_t* sw = reinterpret_cast<const uint32_t*>(s - skew);
+  uint32_t* dw = reinterpret_cast<uint32_t*>(d);
+  if (skew == 0) {
+    for (uint32_t k = threadIdx.x; k < n_dwords; k += blockDim.x) dw[k] = sw[k];
+  } else {
+    // bytes [4k + skew, 4k + skew + 4) of the aligned source: both dwords hold bytes of this frame
+    for (uint32_t k = threadIdx.x; k < n_dwords; k += blockDim.x)
+      dw[k] = __builtin_amdgcn_alignbyte(sw[k + 1], sw[k], skew);
+  }
+  const uint32_t tail = len & 3u;
+  if (threadIdx.x < tail) d[n_dwords * 4 + threadIdx.x] = s[n_dwords * 4 + threadIdx.x];
+}
+
+hipError_t launch_place_frames(const uint8_t* src, const uint64_t* src_offsets, const uint32_t* lengths,
+                               uint8_t* dst, const uint64_t* dst_offsets, uint32_t n_frames, hipStream_t stream) {
+  if (n_frames == 0) return hipSuccess;
+  hipLaunchKernelGGL(place_frames_kernel, dim3(n_frames), dim3(256), 0, stream, src, src_offsets, lengths, dst,
+                     dst_offsets);
+  return hipGetLastError();
+}
+
 size_t stereo_frame_bytes_bound(uint32_t block_size, uint32_t bits_per_sample) {
   // header <= 4 + 6 (frame number < 2^31) + 2 + 2 + 1, two subframes of at most Verbatim size
   // (encode_subframe never keeps anything larger, coding.rs:413-416), CRC-16
@@ -379,23 +421,16 @@ size_t stereo_frame_bytes_bound(uint32_t block_size, uint32_t bits_per_sample) {
 hipError_t launch_frame_pack(const FramePackArgs& a, hipStream_t stream) {
   if (a.n_frames == 0) return hipSuccess;
   const size_t smem = static_cast<size_t>(a.lds_words) * 4;
-  static size_t configured = 0;
-  if (smem > configured) {
-    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(frame_pack_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(smem));
-    if (err != hipSuccess) return err;
-    configured = smem;
-  }
+  static DynamicLdsOptIn opt_in_stereo, opt_in_channels;  // per kernel, per device inside
   if (a.chan_results) {
-    static size_t configured_ch = 0;
-    if (smem > configured_ch) {
-      hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(channel_pack_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(smem));
-      if (err != hipSuccess) return err;
-      configured_ch = smem;
-    }
+    if (hipError_t err = opt_in_channels.ensure(reinterpret_cast<const void*>(channel_pack_kernel), smem);
+        err != hipSuccess)
+      return err;
     hipLaunchKernelGGL(channel_pack_kernel, dim3(a.n_frames), dim3(kPackThreads), smem, stream, a);
   } else {
+    if (hipError_t err = opt_in_stereo.ensure(reinterpret_cast<const void*>(frame_pack_kernel), smem);
+        err != hipSuccess)
+      return err;
     hipLaunchKernelGGL(frame_pack_kernel, dim3(a.n_frames), dim3(kPackThreads), smem, stream, a);
   }
   return hipGetLastError();

@@ -49,5 +49,10 @@ hipError_t launch_fill_le_bytes(const uint8_t* bytes, uint32_t channels, uint32_
                                 uint64_t total_samples, uint32_t n_frames, uint32_t block_size, int32_t* frames,
                                 size_t stride, hipStream_t stream);
 
+// ParSink's reordering (src/par.rs:67-95) for packed frames in HBM: frame i = `lengths[i]` bytes at
+// src + src_offsets[i]  ->  dst + dst_offsets[i]; any alignment.
+hipError_t launch_place_frames(const uint8_t* src, const uint64_t* src_offsets, const uint32_t* lengths,
+                               uint8_t* dst, const uint64_t* dst_offsets, uint32_t n_frames, hipStream_t stream);
+
 }  // namespace flacenc_hip
 #endif

@@ -2,8 +2,6 @@
 // and dispatch to the per-bucket kernel instantiations.
 #include "qlpc_kernel.h"
 
-#include <cstdlib>
-
 namespace flacenc_hip {
 namespace {
 
@@ -24,7 +22,7 @@ int bucket_order(int P) {
 bool wave_kernel_eligible(const QlpcKernelArgs& a) {
   if (a.block_size != 4096 || a.lpc_order > 12) return false;
   if (a.fixed_mode != 0) return false;  // fixed_lpc as a stand-alone batch: generic kernel
-  if (getenv("FLACENC_HIP_FORCE_GENERIC")) return false;
+  if (a.force_generic) return false;
   if ((reinterpret_cast<uintptr_t>(a.samples) & 15) || (a.stride & 3)) return false;
   if ((reinterpret_cast<uintptr_t>(a.residual) & 15) || (a.residual_stride & 3)) return false;
   if (a.stereo && (a.n_subframes & 3)) return false;

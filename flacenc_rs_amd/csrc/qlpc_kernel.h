@@ -6,7 +6,9 @@
 #include <stddef.h>
 #include <stdint.h>
 
+
 #include "flacenc_hip.h"
+#include "lds_opt_in.h"
 
 namespace flacenc_hip {
 
@@ -29,6 +31,7 @@ struct QlpcKernelArgs {
   uint32_t precision;
   uint32_t max_rice_parameter;
   uint32_t rice_finest_only;  // FLACENC_HIP_FLAG_FINEST_RICE_ORDER: no merging below the finest order
+  uint32_t force_generic;     // FLACENC_HIP_FLAG_GENERIC_KERNEL: never the wave-per-subframe kernel
   flacenc_hip_subframe_params* params;  // device
   int32_t* residual;                    // device
   size_t residual_stride;

@@ -1104,13 +1104,8 @@ hipError_t launch_levinson_batch(const QlpcKernelArgs& a, hipStream_t stream) {
 template <int MAXP, bool BIG>
 hipError_t launch_one(const QlpcKernelArgs& a, int threads, size_t smem, hipStream_t stream) {
   auto kern = qlpc_subframe_kernel<MAXP, BIG>;
-  static size_t configured_smem = 0;  // per instantiation; the attribute only ever needs to grow
-  if (smem > configured_smem) {
-    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (err != hipSuccess) return err;
-    configured_smem = smem;
-  }
+  static DynamicLdsOptIn opt_in;  // per instantiation, per device inside; the attribute only ever grows
+  if (hipError_t err = opt_in.ensure(reinterpret_cast<const void*>(kern), smem); err != hipSuccess) return err;
   hipLaunchKernelGGL(kern, dim3(a.n_subframes), dim3(threads), smem, stream, a);
   return hipGetLastError();
 }

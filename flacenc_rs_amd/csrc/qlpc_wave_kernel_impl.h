@@ -1450,13 +1450,8 @@ template <int MAXP, bool STEREO, bool DECIDE, bool FIXED, bool PACK>
 hipError_t launch_wave4096(const QlpcKernelArgs& a, hipStream_t stream) {
   auto kern = qlpc_wave4096_kernel<MAXP, STEREO, DECIDE, FIXED, PACK>;
   constexpr size_t smem = (size_t)(STEREO ? 3 : 4) * kBufDwords * 4 + 4 * (((MAXP + 2) & ~1) * 8 + 64);  // images (+ window) + exchange
-  static bool configured = false;
-  if (!configured) {
-    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (err != hipSuccess) return err;
-    configured = true;
-  }
+  static DynamicLdsOptIn opt_in;  // per instantiation, per device inside
+  if (hipError_t err = opt_in.ensure(reinterpret_cast<const void*>(kern), smem); err != hipSuccess) return err;
   const uint32_t blocks = STEREO ? a.n_subframes / 4u : (a.n_subframes + 3u) / 4u;
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), smem, stream, a);
   return hipGetLastError();

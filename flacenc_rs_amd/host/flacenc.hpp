@@ -26,9 +26,13 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstring>
+#include <exception>
+#include <map>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <utility>
 #include <variant>
 #include <vector>
@@ -467,9 +471,20 @@ class HipContext {
     if (rc != FLACENC_HIP_OK)
       throw error::EncodeError(error::EncodeError::Device, "flacenc_hip_create failed (no usable GPU)");
   }
-  ~HipContext() { flacenc_hip_destroy(h_); }
+  ~HipContext() {
+    if (h_) flacenc_hip_destroy(h_);
+  }
   HipContext(const HipContext&) = delete;
   HipContext& operator=(const HipContext&) = delete;
+  HipContext(HipContext&& o) noexcept : h_(o.h_) { o.h_ = nullptr; }  // std::vector<HipContext>: one per GPU
+  HipContext& operator=(HipContext&& o) noexcept {
+    if (this != &o) {
+      if (h_) flacenc_hip_destroy(h_);
+      h_ = o.h_;
+      o.h_ = nullptr;
+    }
+    return *this;
+  }
   flacenc_hip_handle* get() const { return h_; }
 
  private:
@@ -561,39 +576,18 @@ inline component::SubFrame encode_subframe(const config::SubFrameCoding& cfg, co
 }
 }  // namespace detail
 
-// encode_with_fixed_block_size, src/coding.rs:645-700: reads the whole source, analyses all
-// full-size frames in ONE GPU batch (the tail frame, if shorter, in a second one), then runs the
-// reference's per-frame controller on the host.
-template <class SourceT>
-component::Stream encode_with_fixed_block_size(const config::Encoder& config, SourceT src, size_t block_size,
-                                               HipContext& gpu) {
-  try {
-    config.verify();
-  } catch (const error::VerifyError& e) {
-    throw error::EncodeError(error::EncodeError::Config, e.what());
-  }
+namespace detail {
+// encode_fixed_size_frame (src/coding.rs:581-606) for a run of frames on ONE GPU: `bufs[i]` is stream
+// frame first_number + i*number_step (number_step > 1 when frames were dealt round-robin over several
+// GPUs).  Frames of equal filled size (all but the stream's last) are analysed in one batch; the
+// reference's per-frame controller runs on the device where the ABI offers it and on the host otherwise.
+inline std::vector<component::Frame> encode_frame_run(const config::Encoder& config,
+                                                      const std::vector<const source::FrameBuf*>& bufs,
+                                                      size_t first_number, size_t number_step, size_t nch,
+                                                      size_t bps, size_t sample_rate, HipContext& gpu) {
   const config::SubFrameCoding& sc = config.subframe_coding;
-  const size_t nch = src.channels();
-  const size_t bps = src.bits_per_sample();
-  if (nch < 1 || nch > constant::MAX_CHANNELS || bps < constant::MIN_BITS_PER_SAMPLE ||
-      bps > constant::MAX_BITS_PER_SAMPLE)
-    throw error::EncodeError(error::EncodeError::Config, "stream_info: channels / bits_per_sample out of range");
-
-  component::Stream stream;
-  stream.stream_info.sample_rate = src.sample_rate();
-  stream.stream_info.channels = nch;
-  stream.stream_info.bits_per_sample = bps;
-
-  // 1. drain the source into FrameBufs (src/coding.rs:662-674)
-  std::vector<source::FrameBuf> bufs;
-  for (;;) {
-    source::FrameBuf fb(nch, block_size);
-    const size_t got = src.read_samples(block_size, fb);
-    if (got == 0) break;
-    fb.verify_samples(bps);
-    stream.stream_info.total_samples += got;
-    bufs.push_back(std::move(fb));
-  }
+  std::vector<component::Frame> out;
+  out.reserve(bufs.size());
   const flacenc_hip_qlpc_config abi_cfg = detail::to_abi(sc);
   const bool stereo = (nch == 2);
   const size_t per_frame = stereo ? 4 : nch;  // analyses per frame (coding.rs:530-544)
@@ -601,9 +595,9 @@ component::Stream encode_with_fixed_block_size(const config::Encoder& config, So
   // 2. group frames by filled size (all but the last are block_size) and batch each group
   size_t f0 = 0;
   while (f0 < bufs.size()) {
-    const size_t n = bufs[f0].filled_size();
+    const size_t n = bufs[f0]->filled_size();
     size_t f1 = f0;
-    while (f1 < bufs.size() && bufs[f1].filled_size() == n) ++f1;
+    while (f1 < bufs.size() && bufs[f1]->filled_size() == n) ++f1;
     const size_t nf = f1 - f0;
     std::vector<flacenc_hip_subframe_params> recs(nf * per_frame);
     std::vector<int32_t> resid(nf * per_frame * n);
@@ -617,7 +611,7 @@ component::Stream encode_with_fixed_block_size(const config::Encoder& config, So
       std::vector<int32_t> staged(nf * 2 * n);
       for (size_t f = 0; f < nf; ++f)
         for (size_t c = 0; c < 2; ++c)
-          std::memcpy(&staged[(f * 2 + c) * n], bufs[f0 + f].channel_slice(c), n * sizeof(int32_t));
+          std::memcpy(&staged[(f * 2 + c) * n], bufs[f0 + f]->channel_slice(c), n * sizeof(int32_t));
       flacenc_hip_frame_config fc{};
       fc.qlpc = abi_cfg;
       fc.use_constant = sc.use_constant;
@@ -642,16 +636,17 @@ component::Stream encode_with_fixed_block_size(const config::Encoder& config, So
         std::vector<uint32_t> packed_len(nf);
         const int prc = flacenc_hip_pack_stereo_frames(
             gpu.get(), staged.data(), nf, static_cast<uint32_t>(n), n, fr.data(), resid2.data(), n,
-            static_cast<uint32_t>(bps), static_cast<uint32_t>(src.sample_rate()), static_cast<uint32_t>(f0), 1,
+            static_cast<uint32_t>(bps), static_cast<uint32_t>(sample_rate), static_cast<uint32_t>(first_number + f0 * number_step),
+            static_cast<uint32_t>(number_step),
             packed.data(), ostride, packed_len.data(), FLACENC_HIP_MEM_HOST);
         if (prc != FLACENC_HIP_OK && prc != FLACENC_HIP_ERR_UNSUPPORTED)
           throw error::EncodeError(error::EncodeError::Device, flacenc_hip_last_error(gpu.get()));
         for (size_t f = 0; f < nf; ++f) {
-          const source::FrameBuf& fb = bufs[f0 + f];
+          const source::FrameBuf& fb = *bufs[f0 + f];
           const int32_t* l = fb.channel_slice(0);
           const int32_t* r = fb.channel_slice(1);
           component::Frame frame;
-          frame.frame_number = static_cast<uint32_t>(f0 + f);
+          frame.frame_number = static_cast<uint32_t>(first_number + (f0 + f) * number_step);
           frame.block_size = n;
           frame.channel_assignment = static_cast<component::ChannelAssignment>(fr[f].channel_assignment);
           for (int c = 0; c < 2; ++c) {
@@ -675,7 +670,7 @@ component::Stream encode_with_fixed_block_size(const config::Encoder& config, So
           }
           if (prc == FLACENC_HIP_OK)
             frame.precomputed_bitstream.assign(packed.begin() + f * ostride, packed.begin() + f * ostride + packed_len[f]);
-          stream.add_frame(std::move(frame));
+          out.push_back(std::move(frame));
         }
         f0 = f1;
         continue;
@@ -691,7 +686,7 @@ component::Stream encode_with_fixed_block_size(const config::Encoder& config, So
       std::vector<int32_t> staged(nf * nch * n);
       for (size_t f = 0; f < nf; ++f)
         for (size_t c = 0; c < nch; ++c)
-          std::memcpy(&staged[(f * nch + c) * n], bufs[f0 + f].channel_slice(c), n * sizeof(int32_t));
+          std::memcpy(&staged[(f * nch + c) * n], bufs[f0 + f]->channel_slice(c), n * sizeof(int32_t));
       flacenc_hip_frame_config fc{};
       fc.qlpc = abi_cfg;
       fc.use_constant = sc.use_constant;
@@ -713,18 +708,19 @@ component::Stream encode_with_fixed_block_size(const config::Encoder& config, So
         std::vector<uint32_t> packed_len(nf);
         const int prc = flacenc_hip_pack_frames(gpu.get(), staged.data(), nf, static_cast<uint32_t>(nch),
                                                 static_cast<uint32_t>(n), n, cr.data(), resid2.data(), n,
-                                                static_cast<uint32_t>(bps), static_cast<uint32_t>(src.sample_rate()),
-                                                static_cast<uint32_t>(f0), 1, packed.data(), ostride,
+                                                static_cast<uint32_t>(bps), static_cast<uint32_t>(sample_rate),
+                                                static_cast<uint32_t>(first_number + f0 * number_step),
+            static_cast<uint32_t>(number_step), packed.data(), ostride,
                                                 packed_len.data(), FLACENC_HIP_MEM_HOST);
         if (prc != FLACENC_HIP_OK && prc != FLACENC_HIP_ERR_UNSUPPORTED)
           throw error::EncodeError(error::EncodeError::Device, flacenc_hip_last_error(gpu.get()));
         for (size_t f = 0; f < nf; ++f) {
           component::Frame frame;
-          frame.frame_number = static_cast<uint32_t>(f0 + f);
+          frame.frame_number = static_cast<uint32_t>(first_number + (f0 + f) * number_step);
           frame.block_size = n;
           for (size_t c = 0; c < nch; ++c) {
             const flacenc_hip_channel_result& r = cr[f * nch + c];
-            const int32_t* sig = bufs[f0 + f].channel_slice(c);
+            const int32_t* sig = bufs[f0 + f]->channel_slice(c);
             const uint8_t b = static_cast<uint8_t>(bps);
             if (r.kind == FLACENC_HIP_KIND_CONSTANT) {
               frame.subframes.push_back(component::Constant{n, r.dc_offset, b});
@@ -740,7 +736,7 @@ component::Stream encode_with_fixed_block_size(const config::Encoder& config, So
           }
           if (prc == FLACENC_HIP_OK)
             frame.precomputed_bitstream.assign(packed.begin() + f * ostride, packed.begin() + f * ostride + packed_len[f]);
-          stream.add_frame(std::move(frame));
+          out.push_back(std::move(frame));
         }
         f0 = f1;
         continue;
@@ -755,7 +751,7 @@ component::Stream encode_with_fixed_block_size(const config::Encoder& config, So
       std::vector<int32_t> staged(nf * nch * n);
       for (size_t f = 0; f < nf; ++f)
         for (size_t c = 0; c < nch; ++c)
-          std::memcpy(&staged[(f * nch + c) * n], bufs[f0 + f].channel_slice(c), n * sizeof(int32_t));
+          std::memcpy(&staged[(f * nch + c) * n], bufs[f0 + f]->channel_slice(c), n * sizeof(int32_t));
       int rc;
       if (stereo) {
         rc = flacenc_hip_stereo_qlpc_batch(gpu.get(), &abi_cfg, staged.data(), nf, static_cast<uint32_t>(n), n,
@@ -783,7 +779,7 @@ component::Stream encode_with_fixed_block_size(const config::Encoder& config, So
       std::vector<int32_t> staged(nf * nch * n);
       for (size_t f = 0; f < nf; ++f)
         for (size_t c = 0; c < nch; ++c)
-          std::memcpy(&staged[(f * nch + c) * n], bufs[f0 + f].channel_slice(c), n * sizeof(int32_t));
+          std::memcpy(&staged[(f * nch + c) * n], bufs[f0 + f]->channel_slice(c), n * sizeof(int32_t));
       flacenc_hip_frame_config fc{};
       fc.qlpc = abi_cfg;
       fc.use_fixed = 1;
@@ -801,9 +797,9 @@ component::Stream encode_with_fixed_block_size(const config::Encoder& config, So
     }
     // 3. the reference's controller per frame (encode_frame, coding.rs:530-544)
     for (size_t f = 0; f < nf; ++f) {
-      const source::FrameBuf& fb = bufs[f0 + f];
+      const source::FrameBuf& fb = *bufs[f0 + f];
       component::Frame frame;
-      frame.frame_number = static_cast<uint32_t>(f0 + f);
+      frame.frame_number = static_cast<uint32_t>(first_number + (f0 + f) * number_step);
       frame.block_size = n;
       auto rec = [&](size_t k) { return use_gpu ? &recs[f * per_frame + k] : nullptr; };
       auto res = [&](size_t k) { return use_gpu ? &resid[(f * per_frame + k) * n] : nullptr; };
@@ -860,11 +856,130 @@ component::Stream encode_with_fixed_block_size(const config::Encoder& config, So
             break;
         }
       }
-      stream.add_frame(std::move(frame));
+      out.push_back(std::move(frame));
     }
     f0 = f1;
   }
+  return out;
+}
+
+// src/coding.rs:662-674 (serial) / the feed loop of src/par.rs:288-325
+template <class SourceT>
+std::vector<source::FrameBuf> drain_source(SourceT& src, size_t block_size, size_t nch, size_t bps,
+                                           component::Stream& stream) {
+  std::vector<source::FrameBuf> bufs;
+  for (;;) {
+    source::FrameBuf fb(nch, block_size);
+    const size_t got = src.read_samples(block_size, fb);
+    if (got == 0) break;
+    fb.verify_samples(bps);
+    stream.stream_info.total_samples += got;
+    bufs.push_back(std::move(fb));
+  }
+  return bufs;
+}
+
+template <class SourceT>
+component::Stream new_stream_for(const config::Encoder& config, const SourceT& src) {
+  try {
+    config.verify();
+  } catch (const error::VerifyError& e) {
+    throw error::EncodeError(error::EncodeError::Config, e.what());
+  }
+  const size_t nch = src.channels();
+  const size_t bps = src.bits_per_sample();
+  if (nch < 1 || nch > constant::MAX_CHANNELS || bps < constant::MIN_BITS_PER_SAMPLE ||
+      bps > constant::MAX_BITS_PER_SAMPLE)
+    throw error::EncodeError(error::EncodeError::Config, "stream_info: channels / bits_per_sample out of range");
+  component::Stream stream;
+  stream.stream_info.sample_rate = src.sample_rate();
+  stream.stream_info.channels = nch;
+  stream.stream_info.bits_per_sample = bps;
+  return stream;
+}
+}  // namespace detail
+
+// encode_with_fixed_block_size, src/coding.rs:645-700: reads the whole source, analyses all
+// full-size frames in ONE GPU batch (the tail frame, if shorter, in a second one), then runs the
+// reference's per-frame controller (on the device for the shapes the ABI covers, else on the host).
+template <class SourceT>
+component::Stream encode_with_fixed_block_size(const config::Encoder& config, SourceT src, size_t block_size,
+                                               HipContext& gpu) {
+  component::Stream stream = detail::new_stream_for(config, src);
+  const size_t nch = src.channels(), bps = src.bits_per_sample();
+  std::vector<source::FrameBuf> bufs = detail::drain_source(src, block_size, nch, bps, stream);
+  std::vector<const source::FrameBuf*> run;
+  run.reserve(bufs.size());
+  for (const source::FrameBuf& fb : bufs) run.push_back(&fb);
+  for (component::Frame& f : detail::encode_frame_run(config, run, 0, 1, nch, bps, src.sample_rate(), gpu))
+    stream.add_frame(std::move(f));
   // fixed-block mode exposes one block size in STREAMINFO (coding.rs:676-690)
+  stream.stream_info.min_block_size = block_size;
+  stream.stream_info.max_block_size = block_size;
+  return stream;
+}
+
+// Sink that stores encoding results by serial id and hands them out in id order: ParSink,
+// src/par.rs:67-95 (a BTreeMap behind a Mutex there, a std::map behind a std::mutex here).
+template <class T>
+class ParSink {
+ public:
+  void push(size_t idx, T element) {
+    std::lock_guard<std::mutex> lock(mutex_);
+    data_.emplace(idx, std::move(element));
+  }
+  template <class F>
+  void finalize(F f) {  // empties the sink, calling f in the order of the serial id
+    std::map<size_t, T> data;
+    {
+      std::lock_guard<std::mutex> lock(mutex_);
+      data.swap(data_);
+    }
+    for (auto& kv : data) f(std::move(kv.second));
+  }
+
+ private:
+  std::mutex mutex_;
+  std::map<size_t, T> data_;
+};
+
+// encode_with_fixed_block_size over several GPUs -- the shape of the reference's par-mode encoder
+// (src/par.rs:355-449) with the worker pool replaced by the node's GPUs: one host thread and one
+// handle per device (a handle is single-threaded, like the reference's thread-local scratch), stream
+// frame f goes to device f mod G (BASELINE config 4's round-robin; frames are independent),
+// every device analyses and packs its frames as one batch with the right frame numbers in the headers
+// (first = r, step = G), and a ParSink puts the finished frames back into frame-number order.
+// Errors raised on a worker thread are re-thrown here after all workers have been joined.
+template <class SourceT>
+component::Stream encode_with_fixed_block_size(const config::Encoder& config, SourceT src, size_t block_size,
+                                               std::vector<HipContext>& gpus) {
+  if (gpus.empty()) throw error::EncodeError(error::EncodeError::Device, "no GPU context given");
+  component::Stream stream = detail::new_stream_for(config, src);
+  const size_t nch = src.channels(), bps = src.bits_per_sample(), rate = src.sample_rate();
+  std::vector<source::FrameBuf> bufs = detail::drain_source(src, block_size, nch, bps, stream);
+  const size_t G = gpus.size();
+  ParSink<component::Frame> sink;
+  std::vector<std::exception_ptr> failures(G);
+  std::vector<std::thread> workers;
+  workers.reserve(G);
+  for (size_t r = 0; r < G; ++r) {
+    workers.emplace_back([&, r] {
+      try {
+        std::vector<const source::FrameBuf*> run;
+        for (size_t f = r; f < bufs.size(); f += G) run.push_back(&bufs[f]);
+        for (component::Frame& fr : detail::encode_frame_run(config, run, r, G, nch, bps, rate, gpus[r])) {
+          const size_t number = fr.frame_number;
+          sink.push(number, std::move(fr));
+        }
+      } catch (...) {
+        failures[r] = std::current_exception();
+      }
+    });
+  }
+  for (std::thread& t : workers) t.join();
+  for (const std::exception_ptr& e : failures)
+    if (e) std::rethrow_exception(e);
+  sink.finalize([&](component::Frame f) { stream.add_frame(std::move(f)); });
   stream.stream_info.min_block_size = block_size;
   stream.stream_info.max_block_size = block_size;
   return stream;

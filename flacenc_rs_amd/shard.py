@@ -62,6 +62,58 @@ def all_gather_frame_lengths(local_lengths: torch.Tensor, n_frames_total: int, g
     return all_gather_records(local_lengths, n_frames_total, group=group)
 
 
+def all_gather_frame_bytes(place, packed: torch.Tensor, local_lengths: torch.Tensor, lengths_all: torch.Tensor,
+                           offsets: torch.Tensor, n_frames_total: int, group=None) -> torch.Tensor:
+    """All-gather the packed FLAC frames themselves and return the assembled frame stream (uint8, frames
+    back to back in frame-number order) on every rank -- ParSink::finalize's output (src/par.rs:82-94).
+
+    `packed` is this rank's pack output [n_local_frames, out_stride] (frame j in row j, `local_lengths[j]`
+    bytes used); `lengths_all` / `offsets` are all_gather_frame_lengths / stream_offsets of the whole
+    stream.  Frames are variable-length, so: (1) this rank's rows are compacted into one contiguous run,
+    (2) runs are all-gathered padded to the longest rank's run, (3) every frame is copied from its place
+    in its producer's run to its stream offset.  Steps 1 and 3 are `place(src, src_offsets, lengths, dst,
+    dst_offsets)` = flacenc_hip_place_frames_async on the GPU (Handle.place_frames_device wrapped by the
+    caller); there is no host fallback here.  One host synchronisation: the padded run size."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    per_rank = (n_frames_total + world - 1) // world
+    n_local = local_frame_count(n_frames_total, rank, world)
+    assert packed.shape[0] == n_local and packed.dtype == torch.uint8 and packed.is_contiguous()
+    dev = packed.device
+    # lengths by (position in the rank's run j, rank r); absent frames of shorter ranks have length 0
+    grid = torch.zeros(per_rank * world, dtype=torch.int64, device=dev)
+    grid[:n_frames_total] = lengths_all.to(torch.int64)
+    grid = grid.view(per_rank, world)
+    run_offsets = torch.cumsum(grid, dim=0) - grid            # [j, r]: offset of frame (j, r) inside rank r's run
+    run_bytes = int(grid.sum(dim=0).max().item())             # host sync: the collective needs one size
+    cap = (run_bytes + 15) & ~15
+    run = torch.zeros(max(cap, 16), dtype=torch.uint8, device=dev)
+    row_offsets = torch.arange(n_local, dtype=torch.int64, device=dev) * packed.shape[1]
+    my_lengths = local_lengths.to(torch.int32).contiguous()
+    place(packed, row_offsets, my_lengths, run, run_offsets[:n_local, rank].contiguous())
+    if world > 1:
+        runs = torch.empty(world * run.numel(), dtype=torch.uint8, device=dev)
+        dist.all_gather_into_tensor(runs, run, group=group)
+    else:
+        runs = run
+    # frame f = j * world + r lives at r * cap' + run_offsets[j, r] in `runs`
+    src = (run_offsets + torch.arange(world, dtype=torch.int64, device=dev) * run.numel()).reshape(-1)[:n_frames_total]
+    total = int(lengths_all.to(torch.int64).sum().item())
+    stream_bytes = torch.empty(max(total, 1), dtype=torch.uint8, device=dev)
+    place(runs, src.contiguous(), lengths_all.to(torch.int32).contiguous(), stream_bytes,
+          offsets.to(torch.int64).contiguous())
+    return stream_bytes[:total]
+
+
+def device_place(handle, stream: int | None = None):
+    """`place` for all_gather_frame_bytes on the GPU: flacenc_hip_place_frames_async through the C ABI."""
+    def place(src, src_offsets, lengths, dst, dst_offsets):
+        assert src.is_cuda and dst.is_cuda, "the frame exchange runs on the GPU (no host fallback)"
+        handle.place_frames_device(src.data_ptr(), src_offsets.data_ptr(), lengths.data_ptr(), lengths.numel(),
+                                   dst.data_ptr(), dst_offsets.data_ptr(), stream=stream)
+    return place
+
+
 def stream_offsets(lengths_all: torch.Tensor, header_bytes: int = 0):
     """Exclusive prefix sum: byte offset of every frame in the output stream (after `header_bytes` of
     container metadata) and the total stream size (a 0-d tensor: no host synchronisation here)."""

@@ -70,6 +70,13 @@ extern "C" {
  * BASELINE config 2's "fixed Rice partition order".  Output stays valid, lossless FLAC; it is just
  * not the partition the reference would pick when a coarser order is cheaper. */
 #define FLACENC_HIP_FLAG_FINEST_RICE_ORDER 2u
+/* Kernel selection overrides (no reference counterpart; every choice produces identical results):
+ * GENERIC_KERNEL keeps block-4096 / order <= 12 launches off the fused wave-per-subframe kernel;
+ * FUSED_PACK / TWO_STAGE_PACK force flacenc_hip_encode_pack_stereo_frames_async's one-kernel or
+ * two-kernel form (default: fused exactly when use_fixed is set, the faster choice measured). */
+#define FLACENC_HIP_FLAG_GENERIC_KERNEL 4u
+#define FLACENC_HIP_FLAG_FUSED_PACK 8u
+#define FLACENC_HIP_FLAG_TWO_STAGE_PACK 16u
 
 /* where the caller's sample / output buffers live */
 #define FLACENC_HIP_MEM_HOST 0
@@ -399,6 +406,15 @@ int flacenc_hip_stereo_frame_lengths_async(flacenc_hip_handle* h, const flacenc_
                                            size_t n_frames, uint32_t block_size, uint32_t bits_per_sample,
                                            uint32_t sample_rate, uint32_t first_frame_number,
                                            uint32_t frame_number_step, uint32_t* out_len, void* stream);
+
+/* ParSink's reordering (src/par.rs:67-95: finished frames are put back into frame-number order for the
+ * writer) for packed frames in HBM: frame i = lengths[i] bytes at src + src_offsets[i] is copied to
+ * dst + dst_offsets[i].  Device pointers, any byte alignment.  Used twice by the multi-GPU gather of
+ * packed frames: to compact a rank's strided pack output into one contiguous run for the RCCL
+ * all-gather, and to place every rank's frames at their stream offsets afterwards. */
+int flacenc_hip_place_frames_async(flacenc_hip_handle* h, const uint8_t* src, const uint64_t* src_offsets,
+                                   const uint32_t* lengths, size_t n_frames, uint8_t* dst,
+                                   const uint64_t* dst_offsets, void* stream);
 
 /* ---- input side ------------------------------------------------------- */
 /*

@@ -202,6 +202,53 @@ int main(int argc, char** argv) {
       }
     }
   }
+  // several handles: the par-mode shape (src/par.rs:355-449; ParSink's ordering is its test
+  // par_sink_finalization, par.rs:457-556).  One host thread + handle per device, frame f -> handle
+  // f mod G; on a one-GPU box the handles share device 0, on a node each gets its own device.  The
+  // stream must be byte-identical to the single-handle one for stereo, mono and 8-channel input, with
+  // frame counts that do and do not divide by G, short tail block included.
+  {
+    const int n_dev = flacenc_hip_device_count();
+    config::Encoder def;
+    for (size_t G : {size_t(2), size_t(3)}) {
+      std::vector<HipContext> gpus;
+      for (size_t r = 0; r < G; ++r) gpus.emplace_back(n_dev > 1 ? int(r % size_t(n_dev)) : 0);
+      for (size_t channels : {size_t(2), size_t(1), size_t(8)}) {
+        const size_t len = 4096 * 7 + 1234;  // 8 frames, the last one short
+        const std::vector<int32_t> sig = make_signal(channels, len, 16, 99 + channels);
+        auto s1 = source::MemSource::from_samples(sig, channels, 16, 44100);
+        auto sg = source::MemSource::from_samples(sig, channels, 16, 44100);
+        component::Stream one = encode_with_fixed_block_size(def, s1, 4096, gpu);
+        component::Stream many = encode_with_fixed_block_size(def, sg, 4096, gpus);
+        CHECK(many.frames.size() == 8 && one.frames.size() == 8);
+        for (size_t f = 0; f < many.frames.size(); ++f) CHECK(many.frames[f].frame_number == f);
+        CHECK(many.to_bytes() == one.to_bytes());
+        CHECK(many.stream_info.total_samples == len);
+      }
+      std::printf("  %zu handles (%d device%s): streams byte-identical to the single-handle encoder\n", G, n_dev,
+                  n_dev == 1 ? "" : "s");
+    }
+    // a worker's error is re-thrown on the calling thread after the join
+    bool thrown = false;
+    try {
+      std::vector<HipContext> gpus;
+      gpus.emplace_back(0);
+      gpus.emplace_back(0);
+      config::Encoder bad;
+      bad.subframe_coding.qlpc.lpc_order = 25;
+      auto src = source::MemSource::from_samples(std::vector<int32_t>(4 * 8192, 1), 2, 16, 44100);
+      encode_with_fixed_block_size(bad, src, 4096, gpus);
+    } catch (const error::EncodeError& e) {
+      thrown = e.kind == error::EncodeError::Config;
+    }
+    CHECK(thrown);
+    // ParSink by itself: out-of-order pushes come back in id order (par.rs:457-556)
+    ParSink<int> sink;
+    for (int id : {5, 1, 4, 0, 3, 2}) sink.push(size_t(id), id * 10);
+    std::vector<int> seen;
+    sink.finalize([&](int v) { seen.push_back(v); });
+    CHECK((seen == std::vector<int>{0, 10, 20, 30, 40, 50}));
+  }
   if (failures) {
     std::printf("FAILED: %d\n", failures);
     return 1;

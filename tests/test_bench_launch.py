@@ -1,0 +1,65 @@
+"""bench.py's launch contract on CPU: `--gpus N` with no launcher in the environment must start N ranks
+itself (missing #1), the printed line must carry the rank count the collective layer saw, and
+the ordered exchange (lengths, 752-B component records, packed frame bytes) must deliver every frame once,
+in stream order, on every rank.  `--dry-run --backend gloo` replaces the GPU analysis by stand-in records;
+sharding (flacenc_rs_amd/shard.py) and the collectives are the real ones (src/par.rs:67-95 is the
+reference's ordered gather)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(argv, env_extra=None, timeout=300):
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, BENCH] + argv, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def _json_line(stdout):
+    lines = [ln for ln in stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, stdout
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("gather", ["records", "payload", "lengths"])
+def test_gpus_flag_starts_that_many_ranks(gather):
+    r = _run(["--gpus", "2", "--backend", "gloo", "--dry-run", "--steps", "2", "--gather", gather])
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = _json_line(r.stdout)
+    assert line["n_gpus"] == 2 and line["ranks_observed"] == 2 and line["dry_run"] is True
+    assert line["config"]["exchange_check"] == {"ok": True, "stream_frames": 128}
+    assert line["config"]["gather"] == gather
+
+
+def test_three_ranks_uneven_is_still_ordered():
+    r = _run(["--gpus", "3", "--backend", "gloo", "--dry-run", "--steps", "1", "--frames", "5", "--gather", "payload"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = _json_line(r.stdout)
+    assert line["n_gpus"] == 3 and line["ranks_observed"] == 3
+    assert line["config"]["exchange_check"]["ok"] is True
+
+
+def test_world_size_mismatch_is_an_error():
+    r = _run(["--gpus", "2", "--backend", "gloo", "--dry-run"], {"WORLD_SIZE": "3", "RANK": "0"})
+    assert r.returncode == 2 and "WORLD_SIZE=3" in r.stderr
+
+
+def test_gloo_needs_dry_run():
+    r = _run(["--gpus", "1", "--backend", "gloo"])
+    assert r.returncode != 0 and "dry-run" in r.stderr
+
+
+def test_no_gpu_fails_loudly():
+    """Without --dry-run there is no CPU fallback: on a box without a GPU the bench must refuse."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    r = _run(["--steps", "1", "--warmup", "0", "--frames", "4"])
+    assert r.returncode != 0 and "GPU" in (r.stderr + r.stdout)

@@ -1116,7 +1116,6 @@ def test_extreme_signals_and_layout_fuzz(handle, monkeypatch, seed):
     misaligned base pointers (which must push block-4096 work onto the general path), against the
     oracle."""
     import torch
-    monkeypatch.setenv("FLACENC_HIP_FUSED_PACK", "1")
     rng = np.random.default_rng(5000 + seed)
     for trial in range(4):
         n = int(rng.choice([4096, 4096, 4096, 1152, 4608, 512]))
@@ -1140,7 +1139,7 @@ def test_extreme_signals_and_layout_fuzz(handle, monkeypatch, seed):
         res = torch.zeros((F, 752), dtype=torch.uint8, device="cuda")
         rbuf = torch.full((F * 2 * rstride + 8,), -7, dtype=torch.int32, device="cuda")
         rview = rbuf[off_out:off_out + F * 2 * rstride].view(F * 2, rstride)
-        cfg = _capi.make_frame_config(_capi.make_config(**qcfg), use_fixed=use_fixed, **fx)
+        cfg = _capi.make_frame_config(_capi.make_config(flags=_capi.FLAG_FUSED_PACK, **qcfg), use_fixed=use_fixed, **fx)
         handle.encode_stereo_frames_device(cfg, view.data_ptr(), F, n, stride, bps, res.data_ptr(), rview.data_ptr(),
                                            rstride, stream=torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
@@ -1183,7 +1182,6 @@ def test_fused_encode_and_pack_equals_two_stage_path(handle, monkeypatch, n, bps
     never reaches HBM) == encode_stereo_frames followed by pack_stereo_frames == the oracle's
     controller and bit writer, for every subframe kind and channel assignment."""
     import torch
-    monkeypatch.setenv("FLACENC_HIP_FUSED_PACK", "1")   # also without the fixed-LPC candidate (default: two-stage there)
     x = np.ascontiguousarray(_fixed_corpus()[:, :, :n])
     if bps == 24:
         x = (x.astype(np.int64) * 181).astype(np.int32)
@@ -1191,7 +1189,8 @@ def test_fused_encode_and_pack_equals_two_stage_path(handle, monkeypatch, n, bps
     if bps == 8:
         x = (x // 256).astype(np.int32)
     F = x.shape[0]
-    cfg = _capi.make_frame_config(gpu_cfg(order), use_fixed=use_fixed)
+    # one kernel also without the fixed-LPC candidate (the default is two-stage there)
+    cfg = _capi.make_frame_config(_capi.make_config(lpc_order=order, flags=_capi.FLAG_FUSED_PACK), use_fixed=use_fixed)
     xs = torch.from_numpy(x).cuda()
     res = torch.zeros((F, 752), dtype=torch.uint8, device="cuda")
     stride = handle.frame_bytes_bound(n, bps)

@@ -16,7 +16,7 @@ def build_host_test():
            os.path.join(ROOT, "tests", "host", "host_mirror_test.cpp"),
            "-L", os.path.join(ROOT, "flacenc_rs_amd"), "-lflacenc_hip",
            "-Wl,-rpath," + os.path.join(ROOT, "flacenc_rs_amd"), "-Wl,-rpath,/opt/rocm/lib",
-           "-L/opt/rocm/lib", "-lamdhip64", "-o", out]
+           "-L/opt/rocm/lib", "-lamdhip64", "-pthread", "-o", out]
     subprocess.check_call(cmd)
     return out
 

@@ -52,6 +52,29 @@ def _worker(rank, world, port, n_frames, out_dir):
     assert lengths_all.tolist() == want.tolist()
     assert offsets.tolist() == (42 + np.concatenate([[0], np.cumsum(want)[:-1]])).tolist()
     assert int(total) == 42 + int(want.sum())
+    # the heavy exchange (`bench.py --gather payload`): the packed frame bytes themselves, assembled into
+    # the frame stream on every rank.  Frames are written by the oracle's Frame::write with their stream
+    # frame numbers; `place` here is the test's stand-in for flacenc_hip_place_frames_async.
+    fc = orc.make_frame_config(cfg, use_fixed=True)
+    res, resid = orc.encode_stereo_frames_cfg(frames, bps, fc)
+    blobs = [orc.write_stereo_frame(res[j], frames[j, 0], frames[j, 1], bps, 44100, f, resid[j, 0], resid[j, 1])
+             for j, f in enumerate(mine)]
+    cap = max(len(b) for b in blobs) + 5
+    packed = torch.zeros((len(mine), cap), dtype=torch.uint8)
+    for j, b in enumerate(blobs):
+        packed[j, :len(b)] = torch.frombuffer(bytearray(b), dtype=torch.uint8)
+    my_len = torch.tensor([len(b) for b in blobs], dtype=torch.int32)
+
+    def place(src, src_offsets, lengths, dst, dst_offsets):
+        sflat, dflat = src.reshape(-1), dst.reshape(-1)
+        for so, ln, do in zip(src_offsets.tolist(), lengths.tolist(), dst_offsets.tolist()):
+            dflat[do:do + ln] = sflat[so:so + ln]
+
+    lengths_all = shard.all_gather_frame_lengths(my_len, n_frames)
+    offsets, total = shard.stream_offsets(lengths_all)
+    stream = shard.all_gather_frame_bytes(place, packed, my_len, lengths_all, offsets, n_frames)
+    assert stream.numel() == int(total)
+    np.save(os.path.join(out_dir, f"stream{rank}.npy"), stream.numpy())
     dist.barrier()
     dist.destroy_process_group()
 
@@ -74,6 +97,17 @@ def test_round_robin_shard_and_ordered_gather(tmp_path, n_frames):
     for rank in range(world):
         got = np.load(os.path.join(str(tmp_path), f"rank{rank}.npy"))
         assert np.array_equal(got, want_bytes), rank
+    # the assembled frame stream: identical on both ranks, and an independent parser walks it frame by
+    # frame (numbers 0..n-1 in order, both CRCs) back to the input samples
+    from tests import flac_parse
+    s0 = np.load(os.path.join(str(tmp_path), "stream0.npy")).tobytes()
+    assert s0 == np.load(os.path.join(str(tmp_path), "stream1.npy")).tobytes()
+    pos = 0
+    for f in range(n_frames):
+        fr = flac_parse.parse_frame(s0[pos:], stream_bps=16, stream_rate=44100)
+        assert fr["number"] == f and np.array_equal(fr["channels"], frames[f])
+        pos += fr["length"]
+    assert pos == len(s0)
 
 
 def test_frames_of_rank_partition():

@@ -269,56 +269,61 @@ __device__ __forceinline__ unsigned long long plane_sum_any64(const PlaneSums& p
   return sum;
 }
 
-template <int NP, bool EXACT>
+// The parameter axis is walked in groups of 8 (a rolled, wave-uniform loop): different parameters never
+// interact -- a merge adds table entries of the same p, a minimiser takes the minimum over p of
+// (bits << 5 | p) -- so each group runs all seven levels on its own 8 entries and leaves its packed
+// minimum per level in pk[level]; the minimum over the groups is the minimum over the window.  One
+// instance of the level code instead of one per window width keeps the search at 8 + 8 + 7 registers
+// whatever the span (typical material: one group).
+template <bool EXACT>
 __device__ __forceinline__ RiceResult rice_search(const PlaneSums& ps, const int32_t* e, uint32_t len0,
                                                   uint32_t p_lo, uint32_t max_p, bool small_bits, int lane,
                                                   int warm, bool finest_only) {
+  constexpr int NP = 8;
   constexpr uint32_t kWMax = kMaxPToBits - 4u;
-  uint32_t Wp[NP];
-  if (EXACT) {
+  uint32_t pk[7];
 #pragma unroll
-    for (int j = 0; j < NP; ++j) {
-      const uint32_t pp = p_lo + (uint32_t)j;  // wave-uniform
-      uint32_t sum;  // sum_i (u_i >> pp); pp == 0 is only possible for j == 0
-      if (j == 0) sum = (pp == 0) ? 2u * ps.sum_m + ps.negs : plane_sum_ge1(ps, pp);
-      else sum = plane_sum_ge1(ps, pp);
-      sum = sum < kMaxPToBits ? sum : kMaxPToBits;
-      uint32_t v = sum + len0 * (pp + 1u);  // rice.rs:69-71, 95-98 (minus the 4)
-      v = v < kWMax ? v : kWMax;
-      Wp[j] = (pp <= max_p) ? v : kWMax;
-    }
-  } else {
-    // the reference's slice of partition 0 starts at `warm`; its clamp cadence follows.
-    // (rare path: runtime loop over p, registers selected by compare chains -- no scratch)
-    const int off = (lane == 0) ? warm : 0;
-#pragma unroll
-    for (int q = 0; q < NP; ++q) Wp[q] = kWMax;
+  for (int k = 0; k < 7; ++k) pk[k] = 0xFFFFFFFFu;
 #pragma unroll 1
-    for (int j = 0; j < NP; ++j) {
-      const uint32_t pp = p_lo + (uint32_t)j;
-      uint32_t accb = 0;
+  for (uint32_t p_base = p_lo; p_base <= max_p; p_base += (uint32_t)NP) {
+    uint32_t Wp[NP];
+    if (EXACT) {
 #pragma unroll
-      for (int k = 0; k < 64; ++k) {
-        if (k >= off) {
-          accb += zigzag(e[k]) >> (pp & 31u);
-          if (((k - off) & 15) == 15) accb = accb < kMaxPToBits ? accb : kMaxPToBits;
-        }
+      for (int j = 0; j < NP; ++j) {
+        const uint32_t pp = p_base + (uint32_t)j;  // wave-uniform
+        uint32_t sum;  // sum_i (u_i >> pp); pp == 0 is only possible for j == 0
+        if (j == 0) sum = (pp == 0) ? 2u * ps.sum_m + ps.negs : plane_sum_ge1(ps, pp);
+        else sum = plane_sum_ge1(ps, pp);
+        sum = sum < kMaxPToBits ? sum : kMaxPToBits;
+        uint32_t v = sum + len0 * (pp + 1u);  // rice.rs:69-71, 95-98 (minus the 4)
+        v = v < kWMax ? v : kWMax;
+        Wp[j] = (pp <= max_p) ? v : kWMax;
       }
-      accb = accb < kMaxPToBits ? accb : kMaxPToBits;
-      uint32_t v = accb + len0 * (pp + 1u);
-      v = v < kWMax ? v : kWMax;
-      if (pp > max_p) v = kWMax;
+    } else {
+      // the reference's slice of partition 0 starts at `warm`; its clamp cadence follows.
+      // (rare path: runtime loop over p, registers selected by compare chains -- no scratch)
+      const int off = (lane == 0) ? warm : 0;
 #pragma unroll
-      for (int q = 0; q < NP; ++q) Wp[q] = (q == j) ? v : Wp[q];
+      for (int q = 0; q < NP; ++q) Wp[q] = kWMax;
+#pragma unroll 1
+      for (int j = 0; j < NP; ++j) {
+        const uint32_t pp = p_base + (uint32_t)j;
+        uint32_t accb = 0;
+#pragma unroll
+        for (int k = 0; k < 64; ++k) {
+          if (k >= off) {
+            accb += zigzag(e[k]) >> (pp & 31u);
+            if (((k - off) & 15) == 15) accb = accb < kMaxPToBits ? accb : kMaxPToBits;
+          }
+        }
+        accb = accb < kMaxPToBits ? accb : kMaxPToBits;
+        uint32_t v = accb + len0 * (pp + 1u);
+        v = v < kWMax ? v : kWMax;
+        if (pp > max_p) v = kWMax;
+#pragma unroll
+        for (int q = 0; q < NP; ++q) Wp[q] = (q == j) ? v : Wp[q];
+      }
     }
-  }
-
-  RiceResult r;
-  r.bestk = 0;
-  r.best_bits = 0;
-  r.my_p = 0;
-  r.saturated = false;
-  uint32_t sat_any = 0;
 #define FLACENC_RICE_LEVEL(K, S)                                                              \
   {                                                                                           \
     if (K > 0) {                                                                              \
@@ -329,35 +334,50 @@ __device__ __forceinline__ RiceResult rice_search(const PlaneSums& ps, const int
         Wp[j] = v < kWMax ? v : kWMax;                                                        \
       }                                                                                       \
     }                                                                                         \
-    uint32_t packed = 0xFFFFFFFFu;                                                            \
+    uint32_t packed = pk[K];                                                                  \
     _Pragma("unroll") for (int j = 0; j + 1 < NP; j += 2) {                                   \
-      const uint32_t c0 = (Wp[j] << 5) | (p_lo + (uint32_t)j);                                \
-      const uint32_t c1 = (Wp[j + 1] << 5) | (p_lo + (uint32_t)j + 1u);                       \
+      const uint32_t c0 = (Wp[j] << 5) | (p_base + (uint32_t)j);                              \
+      const uint32_t c1 = (Wp[j + 1] << 5) | (p_base + (uint32_t)j + 1u);                     \
       packed = umin3(packed, c0, c1);                                                         \
     }                                                                                         \
-    const uint32_t bits = (packed >> 5) + 4u;                                                 \
-    const bool lead = (lane & ((1 << K) - 1)) == 0;                                           \
-    const uint32_t lb = lead ? bits : 0u;                                                     \
-    sat_any |= (lead && bits >= kMaxPToBits) ? (1u << K) : 0u;                                \
-    unsigned long long tot;                                                                   \
-    if (small_bits) tot = wave_sum_dpp(lb);                                                   \
-    else tot = ((unsigned long long)wave_sum_dpp(lb >> 16) << 16) + wave_sum_dpp(lb & 0xFFFFu); \
-    if (K == 0 || tot < r.best_bits) { /* strict: ties keep the finer order (rice.rs:285) */  \
-      r.best_bits = tot;                                                                      \
-      r.bestk = K;                                                                            \
-      r.my_p = packed & 31u;                                                                  \
-    }                                                                                         \
+    pk[K] = packed;                                                                           \
   }
-  FLACENC_RICE_LEVEL(0, 1)
-  if (!finest_only) {  // (FLACENC_HIP_FLAG_FINEST_RICE_ORDER keeps order 6)
-    FLACENC_RICE_LEVEL(1, 1)
-    FLACENC_RICE_LEVEL(2, 2)
-    FLACENC_RICE_LEVEL(3, 4)
-    FLACENC_RICE_LEVEL(4, 8)
-    FLACENC_RICE_LEVEL(5, 16)
-    FLACENC_RICE_LEVEL(6, 32)
-  }
+    FLACENC_RICE_LEVEL(0, 1)
+    if (!finest_only) {  // (FLACENC_HIP_FLAG_FINEST_RICE_ORDER keeps order 6)
+      FLACENC_RICE_LEVEL(1, 1)
+      FLACENC_RICE_LEVEL(2, 2)
+      FLACENC_RICE_LEVEL(3, 4)
+      FLACENC_RICE_LEVEL(4, 8)
+      FLACENC_RICE_LEVEL(5, 16)
+      FLACENC_RICE_LEVEL(6, 32)
+    }
 #undef FLACENC_RICE_LEVEL
+  }
+
+  RiceResult r;
+  r.bestk = 0;
+  r.best_bits = 0;
+  r.my_p = 0;
+  r.saturated = false;
+  uint32_t sat_any = 0;
+  // level totals: the group leaders' minima summed over the wave; strict < keeps the finer order on
+  // ties (rice.rs:285)
+#pragma unroll
+  for (int K = 0; K < 7; ++K) {
+    if (K > 0 && finest_only) break;
+    const uint32_t bits = (pk[K] >> 5) + 4u;
+    const bool lead = (lane & ((1 << K) - 1)) == 0;
+    const uint32_t lb = lead ? bits : 0u;
+    sat_any |= (lead && bits >= kMaxPToBits) ? (1u << K) : 0u;
+    unsigned long long tot;
+    if (small_bits) tot = wave_sum_dpp(lb);
+    else tot = ((unsigned long long)wave_sum_dpp(lb >> 16) << 16) + wave_sum_dpp(lb & 0xFFFFu);
+    if (K == 0 || tot < r.best_bits) {
+      r.best_bits = tot;
+      r.bestk = K;
+      r.my_p = pk[K] & 31u;
+    }
+  }
   sat_any = wave_or_dpp(sat_any);
   r.saturated = (sat_any >> r.bestk) & 1u;
   r.sat_levels = sat_any;
@@ -978,16 +998,12 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
     const uint32_t p0min = wave_min_dpp(31u - (uint32_t)__builtin_clz(q0));
     uint32_t p_lo = p0min > 2u ? p0min - 2u : 0u;
     p_lo = p_lo < max_p ? p_lo : max_p;
-    const uint32_t span = max_p - p_lo + 1u;
-    if (span <= 8) rr = rice_search<8, true>(ps, nullptr, len0, p_lo, max_p, small_bits, lane, warm, finest_only);
-    else if (span <= 16) rr = rice_search<16, true>(ps, nullptr, len0, p_lo, max_p, small_bits, lane, warm, finest_only);
-    else if (span <= 24) rr = rice_search<24, true>(ps, nullptr, len0, p_lo, max_p, small_bits, lane, warm, finest_only);
-    else rr = rice_search<32, true>(ps, nullptr, len0, 0u, max_p, small_bits, lane, warm, finest_only);
+    rr = rice_search<true>(ps, nullptr, len0, p_lo, max_p, small_bits, lane, warm, finest_only);
     // The window argument compares unclamped table values.  If any group minimum saturated at
     // MAX_P_TO_BITS, clamped entries outside the window could tie with it (ties go to the
     // smallest p, rice.rs:123-124), so search the whole range then.
-    if (rr.sat_levels != 0 && p_lo != 0 && span <= 24)
-      rr = rice_search<32, true>(ps, nullptr, len0, 0u, max_p, small_bits, lane, warm, finest_only);
+    if (rr.sat_levels != 0 && p_lo != 0)
+      rr = rice_search<true>(ps, nullptr, len0, 0u, max_p, small_bits, lane, warm, finest_only);
     if (rr.saturated) {
       // sum_i (u_i >> p) of this lane's partition under its group's parameter, from the planes
       const uint32_t gp = (uint32_t)__shfl((int)rr.my_p, lane & ~((1 << rr.bestk) - 1), 64);
@@ -996,7 +1012,7 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
                   (unsigned long long)wave_sum_dpp((uint32_t)(mine & 0xFFFFu));
     }
   } else {
-    rr = rice_search<32, false>(ps, e, len0, 0u, max_p, small_bits, lane, warm, finest_only);
+    rr = rice_search<false>(ps, e, len0, 0u, max_p, small_bits, lane, warm, finest_only);
     // the table sums of this path are the reference's wrapping u32 adds (rice.rs:88-93): code_bits
     // does not determine the true quotient sum any more, saturated or not -- always count it
     rr.saturated = true;
@@ -1386,11 +1402,11 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
     __syncthreads();
     {
       int32_t* __restrict__ dst0 = a.residual + (size_t)(blk * 2u) * a.residual_stride;
-      // (FIXED: the thread index is laundered so that these addresses are recomputed here instead
-      // of being kept alive -- and, at 256 VGPRs, spilled -- from the identical expressions of the
-      // load phase; the variants with registers to spare are 1.4 % faster keeping them)
+      // (the thread index is laundered so that these addresses are recomputed here instead of being
+      // kept alive -- and, under a tight register budget, spilled to scratch and reloaded at HBM
+      // latency -- from the identical expressions of the load phase)
       int tid_out = tid;
-      if (FIXED) asm volatile("" : "+v"(tid_out));
+      asm volatile("" : "+v"(tid_out));
 #pragma unroll
       for (int it = 0; it < 8; ++it) {
         const int q = tid_out + it * 256;

@@ -37,9 +37,13 @@ namespace {
 // waves per SIMD the register allocator must leave room for: 3 workgroups per CU is what the
 // stereo LDS footprint (2 images + window) allows; plain mode (4 images) is LDS-bound earlier
 #ifndef FLACENC_WAVE_OCC
-// (the deciding variant keeps 64 residuals live through the Rice search: at 3 waves/SIMD it
-// spills ~260 B/lane, which shows up as HBM traffic, for a 3 % gain -- so it stays at 2)
-#if defined(FLACENC_STEREO) && FLACENC_STEREO == 1 && defined(FLACENC_MAXP) && FLACENC_MAXP <= 10
+// 3 where the instance fits 168 VGPRs with nothing of its common path in scratch (checked with
+// tools/kernel_resources.py and the Spill / Reload comments of tools/asm_variant.sh's output): the
+// order-8 deciding kernel (the bench workload; 8 dwords spilled, all of them around the out-of-line call
+// of the rare literal Rice search) and the 4-candidate stereo kernel up to order 10.  Measured on the
+// bench workload, same box, alternating runs: 0.313 -> 0.275 ms median for the deciding kernel.
+#if defined(FLACENC_STEREO) && defined(FLACENC_MAXP) && \
+    ((FLACENC_STEREO == 1 && FLACENC_MAXP <= 10) || (FLACENC_STEREO == 2 && FLACENC_MAXP <= 8))
 #define FLACENC_WAVE_OCC 3
 #else
 #define FLACENC_WAVE_OCC 2
@@ -382,6 +386,41 @@ __device__ __forceinline__ RiceResult rice_search(const PlaneSums& ps, const int
   r.saturated = (sat_any >> r.bestk) & 1u;
   r.sat_levels = sat_any;
   return r;
+}
+
+// The literal chunk-clamped search (residuals >= 2^26: full-scale 24/25-bit material with a useless
+// predictor) as a real function call: it is rare, and inlined it made the register allocator park
+// values of the common path in scratch across the branch.  Out of line, the call site -- inside the rare
+// branch -- is where live registers are saved, and the residuals are handed over through private memory.
+struct RiceLiteralResult {
+  RiceResult rr;
+  unsigned long long sum_q;
+};
+__device__ __attribute__((noinline)) void rice_search_literal(const int32_t* e, uint32_t len0, uint32_t max_p,
+                                                              int small_bits, int lane, int warm, int finest_only,
+                                                              RiceLiteralResult* out) {
+  int32_t ev[64];
+#pragma unroll
+  for (int k = 0; k < 64; ++k) ev[k] = e[k];
+  PlaneSums none;
+#pragma unroll
+  for (int k = 0; k < 7; ++k) none.q[k] = 0;
+  none.sum_m = none.negs = 0;
+  RiceResult rr = rice_search<false>(none, ev, len0, 0u, max_p, small_bits != 0, lane, warm, finest_only != 0);
+  // the table sums of this path are the reference's wrapping u32 adds (rice.rs:88-93): code_bits
+  // does not determine the true quotient sum any more, saturated or not -- always count it
+  rr.saturated = true;
+  const uint32_t gp = (uint32_t)__shfl((int)rr.my_p, lane & ~((1 << rr.bestk) - 1), 64);
+  uint32_t lo = 0, hi = 0;
+#pragma unroll
+  for (int k = 0; k < 64; ++k) {
+    uint32_t qv = zigzag(ev[k]) >> gp;  // warm-up slots hold 0
+    lo += qv & 0xFFFFu;
+    hi += qv >> 16;
+  }
+  // per lane 64 x 16 bits = 22 bits; x 64 lanes = 28 bits
+  out->sum_q = ((unsigned long long)wave_sum_dpp(hi) << 16) + (unsigned long long)wave_sum_dpp(lo);
+  out->rr = rr;
 }
 
 // DECIDE (stereo only): run encode_subframe's candidate choice and try_stereo_coding's channel
@@ -1012,22 +1051,13 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
                   (unsigned long long)wave_sum_dpp((uint32_t)(mine & 0xFFFFu));
     }
   } else {
-    rr = rice_search<false>(ps, e, len0, 0u, max_p, small_bits, lane, warm, finest_only);
-    // the table sums of this path are the reference's wrapping u32 adds (rice.rs:88-93): code_bits
-    // does not determine the true quotient sum any more, saturated or not -- always count it
-    rr.saturated = true;
-    {
-      const uint32_t gp = (uint32_t)__shfl((int)rr.my_p, lane & ~((1 << rr.bestk) - 1), 64);
-      uint32_t lo = 0, hi = 0;
+    int32_t handed[64];  // private memory, written on this path only; e[] itself stays in registers
 #pragma unroll
-      for (int k = 0; k < 64; ++k) {
-        uint32_t qv = zigzag(e[k]) >> gp;  // warm-up slots hold 0
-        lo += qv & 0xFFFFu;
-        hi += qv >> 16;
-      }
-      // per lane 64 x 16 bits = 22 bits; x 64 lanes = 28 bits
-      sat_sum_q = ((unsigned long long)wave_sum_dpp(hi) << 16) + (unsigned long long)wave_sum_dpp(lo);
-    }
+    for (int k = 0; k < 64; ++k) handed[k] = e[k];
+    RiceLiteralResult lit;
+    rice_search_literal(handed, len0, max_p, small_bits ? 1 : 0, lane, warm, finest_only ? 1 : 0, &lit);
+    rr = lit.rr;
+    sat_sum_q = lit.sum_q;
   }
   bestk = rr.bestk;
   best_bits = rr.best_bits;

@@ -49,7 +49,9 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=8192, help="stereo frames per step per GPU")
+    ap.add_argument("--frames", type=int, default=24576,
+                    help="stereo frames per step per GPU (32 full rounds of the 768 workgroups an MI355X holds; "
+                         "805 MB of samples in, 805 MB of residual out per step)")
     ap.add_argument("--block-size", type=int, default=4096)
     ap.add_argument("--lpc-order", type=int, default=8)
     ap.add_argument("--bps", type=int, default=16)

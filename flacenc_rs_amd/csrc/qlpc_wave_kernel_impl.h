@@ -576,6 +576,7 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
     // the balanced tree over the chunk index c = 4 lane + i.  The chunk loop is deliberately
     // NOT unrolled: unrolled, the compiler hoists every chunk's loads and conversions to the
     // top and needs > 250 VGPRs; rolled it stays under 128 and four waves fit a SIMD.
+    constexpr bool PINGPONG = (HP == 8);  // halo == step: two 8-value blocks swap roles, nothing slides
     constexpr int WN = HP + 8;
     double dw[WN];
     double acc[NLAG], s01[NLAG], p2[NLAG];
@@ -601,7 +602,7 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
     };
     // halo of the lane's first chunk (HP = 8 or 12 samples in front of it)
     fetch(tl - 8);
-    convert(HP);  // lands in dw[HP .. HP+8), slid to dw[HP-8 .. HP) by the first step
+    convert(HP);  // lands in dw[HP .. HP+8): the "previous step" of the first step
     if (HP > 8) {
       const int4 v = ld4(tl - 12);
       const float4 wv = window4(tl - 12);
@@ -612,31 +613,39 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
     }
     fetch(tl);
     // one 16-sample chunk = two 8-sample steps; MASKED only for the block's first chunk, the
-    // only one containing t < P (P <= 12 < 16): common lower bound t = P for every lag (lpc.rs:542)
+    // only one containing t < P (P <= 12 < 16): common lower bound t = P for every lag (lpc.rs:542).
+    // PINGPONG: step h writes its 8 values into block (h ^ 1) and finds the previous step's in block h
+    // (the chunk body holds both parities, so every index is a compile-time constant); the halo
+    // convert above landed in block 1 = what step h = 0 expects.  Otherwise (HP = 12) the last HP
+    // values slide down to become the halo.
     auto chunk = [&](auto masked_tag, int i) {
       constexpr bool MASKED = decltype(masked_tag)::value;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int t0 = tl + 16 * i + 8 * h;
+        const int cur0 = PINGPONG ? 8 * h : HP;        // where this step's values go
+        const int old0 = PINGPONG ? 8 * (h ^ 1) : 0;   // PINGPONG: the previous step's block
+        if (!PINGPONG) {
 #pragma unroll
-        for (int k = 0; k < HP; ++k) dw[k] = dw[k + 8];  // slide: last HP values become the halo
+          for (int k = 0; k < HP; ++k) dw[k] = dw[k + 8];  // slide: last HP values become the halo
+        }
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
           vmax = max(max(vmax, rv[q].x), max(rv[q].y, max(rv[q].z, rv[q].w)));
           vmin = min(min(vmin, rv[q].x), min(rv[q].y, min(rv[q].z, rv[q].w)));
         }
-        convert(HP);
+        convert(cur0);
         fetch(t0 + 8);  // next step (one segment of slack exists behind the last lane)
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-          double cur = dw[HP + k];
+          double cur = dw[cur0 + k];
           if (MASKED) cur = (t0 + k >= P) ? cur : 0.0;
-          if (h == 0 && k == 0) {
 #pragma unroll
-            for (int tau = 0; tau <= MAXP; ++tau) acc[tau] = __builtin_fma(cur, dw[HP + k - tau], 0.0);
-          } else {
-#pragma unroll
-            for (int tau = 0; tau <= MAXP; ++tau) acc[tau] = __builtin_fma(cur, dw[HP + k - tau], acc[tau]);
+          for (int tau = 0; tau <= MAXP; ++tau) {
+            // x_w[t - tau]: in this step's block, or tau - k values before the end of the previous one
+            const double lagged = PINGPONG ? (tau <= k ? dw[cur0 + k - tau] : dw[old0 + 8 + k - tau])
+                                           : dw[HP + k - tau];
+            acc[tau] = (h == 0 && k == 0) ? __builtin_fma(cur, lagged, 0.0) : __builtin_fma(cur, lagged, acc[tau]);
           }
         }
       }

@@ -61,6 +61,9 @@ def parse_args(argv=None):
     ap.add_argument("--finest-rice-order", action="store_true",
                     help="build extension (not a reference mode): keep the finest Rice partition order, "
                          "BASELINE config 2's 'fixed Rice partition order'; not the default")
+    ap.add_argument("--reference-order", action="store_true",
+                    help="FLACENC_HIP_FLAG_REFERENCE_SUM_ORDER: autocorrelation in the reference's stable "
+                         "summation order (bit-identical coefficients; one extra pass over the samples)")
     ap.add_argument("--gather", choices=["records", "payload", "lengths"], default="records",
                     help="what the multi-GPU exchange moves besides the frames' byte lengths: the 752-B "
                          "decision records = the encoded SubFrame components (default), the packed frame "
@@ -136,7 +139,8 @@ def profiled_counters(args):
     kernel source is the profiled one."""
     default = parse_args([])
     same_cfg = all(getattr(args, k) == getattr(default, k)
-                   for k in ("frames", "block_size", "lpc_order", "bps", "use_fixed", "finest_rice_order"))
+                   for k in ("frames", "block_size", "lpc_order", "bps", "use_fixed", "finest_rice_order",
+                             "reference_order"))
     try:
         with open(os.path.join(ROOT, "profiles", "headline_pmc.json")) as f:
             p = json.load(f)
@@ -151,7 +155,8 @@ def kernel_name(args):
     """The kernel flacenc_hip_encode_stereo_frames dispatches to for this run (qlpc_dispatch.cpp)."""
     if args.block_size == 4096 and args.lpc_order <= 12:
         maxp = 8 if args.lpc_order <= 8 else 10 if args.lpc_order <= 10 else 12
-        return "qlpc_wave4096_kernel<%d,true,true,%s,false>" % (maxp, "true" if args.use_fixed else "false")
+        k = "qlpc_wave4096_kernel<%d,true,true,%s,false>" % (maxp, "true" if args.use_fixed else "false")
+        return ("acorr_reference_kernel + " + k) if args.reference_order else k
     return "qlpc_subframe_kernel (+ fixed-LPC batch) + frame_decide_kernel"
 
 
@@ -188,7 +193,8 @@ def run(args, world):
     # precision 15, Tukey(0.4), max_p 30; candidates Constant / Verbatim / LPC -- the QLPC analysis path
     # the metric names (--use-fixed adds the reference default's fixed-LPC candidate); all stereo
     # assignments allowed
-    qcfg = _capi.make_config(lpc_order=args.lpc_order, rice_finest_only=args.finest_rice_order)
+    qcfg = _capi.make_config(lpc_order=args.lpc_order, rice_finest_only=args.finest_rice_order,
+                             flags=_capi.FLAG_REFERENCE_SUM_ORDER if args.reference_order else 0)
     cfg = _capi.make_frame_config(qcfg, use_fixed=args.use_fixed)
     # synthetic "sigen" audio: Sine(200, 0.4) + Noise(0.4) like the reference's
     # stereo_frame_encoder_noisy_sine_lpc bench (src/coding.rs:1152), one continuous stream,
@@ -457,6 +463,14 @@ def secondary(torch, _capi, handle, args, dev):
         sec[name] = entry(ms, {"what": "one call, PCM in HBM -> FLAC frame bytes in HBM (analysis + decision + "
                                        "Frame::write with both CRCs)",
                                "frame_bytes_per_step": int(lens.to(torch.int64).sum().item())})
+    rcfg = _capi.make_frame_config(_capi.make_config(lpc_order=args.lpc_order, rice_finest_only=args.finest_rice_order,
+                                                     flags=_capi.FLAG_REFERENCE_SUM_ORDER), use_fixed=False)
+    ms = timed(lambda: handle.encode_stereo_frames_device(rcfg, noisy.data_ptr(), F, n, n, bps, results.data_ptr(),
+                                                          residual.data_ptr(), n, stream=stream.cuda_stream))
+    sec["reference_sum_order"] = entry(ms, {
+        "what": "FLACENC_HIP_FLAG_REFERENCE_SUM_ORDER: autocorrelation as one sequential chain per lag "
+                "(src/lpc.rs:533-548) by a lane-per-subframe kernel, then the fused kernel without its phase 1; "
+                "coefficients bit-identical to the reference's stable build", "subframe_bits_per_sample": bits_per_sample()})
     del noisy
     tonal = torch.from_numpy(_capi.sigen_frames(F, 2, n, bps, 36.0, 0.4, 0.04, seed=0xF1AC0002)).to(dev)
     fcfg = _capi.make_frame_config(qcfg, use_fixed=False)

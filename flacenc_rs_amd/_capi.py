@@ -293,6 +293,7 @@ FLAG_FINEST_RICE_ORDER = 2
 FLAG_GENERIC_KERNEL = 4
 FLAG_FUSED_PACK = 8
 FLAG_TWO_STAGE_PACK = 16
+FLAG_REFERENCE_SUM_ORDER = 32
 
 
 def make_config(lpc_order=10, quant_precision=15, window=("tukey", 0.4), max_rice_parameter=30,

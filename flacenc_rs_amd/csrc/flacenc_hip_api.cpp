@@ -206,6 +206,8 @@ int enqueue(flacenc_hip_handle* h, const flacenc_hip_qlpc_config* cfg, const int
   a.max_rice_parameter = cfg->max_rice_parameter;
   a.rice_finest_only = (cfg->flags & FLACENC_HIP_FLAG_FINEST_RICE_ORDER) ? 1u : 0u;
   a.force_generic = (cfg->flags & FLACENC_HIP_FLAG_GENERIC_KERNEL) ? 1u : 0u;
+  a.reference_order = (cfg->flags & FLACENC_HIP_FLAG_REFERENCE_SUM_ORDER) ? 1u : 0u;
+  a.acorr_in = nullptr;
   a.params = params;
   a.residual = residual;
   a.residual_stride = residual_stride;
@@ -226,7 +228,7 @@ int enqueue(flacenc_hip_handle* h, const flacenc_hip_qlpc_config* cfg, const int
   a.pred = nullptr;
   a.pred_out = nullptr;
   a.split_scratch = nullptr;
-  if (cfg->lpc_order >= 16) {
+  if (cfg->lpc_order >= 16 || a.reference_order) {
     rc = ensure(h, h->d_split, n_subframes * (33 * 8 + 36 * 4));
     if (rc != FLACENC_HIP_OK) return rc;
     a.split_scratch = h->d_split.ptr;
@@ -382,6 +384,8 @@ int enqueue_fixed(flacenc_hip_handle* h, const flacenc_hip_frame_config* cfg, co
   a.max_rice_parameter = cfg->qlpc.max_rice_parameter;
   a.rice_finest_only = (cfg->qlpc.flags & FLACENC_HIP_FLAG_FINEST_RICE_ORDER) ? 1u : 0u;
   a.force_generic = (cfg->qlpc.flags & FLACENC_HIP_FLAG_GENERIC_KERNEL) ? 1u : 0u;
+  a.reference_order = (cfg->qlpc.flags & FLACENC_HIP_FLAG_REFERENCE_SUM_ORDER) ? 1u : 0u;
+  a.acorr_in = nullptr;
   a.params = params;
   a.residual = residual;
   a.residual_stride = residual_stride;
@@ -833,6 +837,8 @@ int flacenc_hip_encode_frames_async(flacenc_hip_handle* h, const flacenc_hip_fra
     a.max_rice_parameter = cfg->qlpc.max_rice_parameter;
   a.rice_finest_only = (cfg->qlpc.flags & FLACENC_HIP_FLAG_FINEST_RICE_ORDER) ? 1u : 0u;
   a.force_generic = (cfg->qlpc.flags & FLACENC_HIP_FLAG_GENERIC_KERNEL) ? 1u : 0u;
+  a.reference_order = (cfg->qlpc.flags & FLACENC_HIP_FLAG_REFERENCE_SUM_ORDER) ? 1u : 0u;
+  a.acorr_in = nullptr;
     a.params = nullptr;
     a.residual = residual;
     a.residual_stride = residual_stride;
@@ -859,6 +865,10 @@ int flacenc_hip_encode_frames_async(flacenc_hip_handle* h, const flacenc_hip_fra
     a.pred = nullptr;
     a.pred_out = nullptr;
     a.split_scratch = nullptr;
+    if (a.reference_order) {  // R[] of the reference-order pass
+      if ((rc = ensure(h, h->d_split, static_cast<size_t>(a.n_subframes) * (33 * 8 + 36 * 4))) != FLACENC_HIP_OK) return rc;
+      a.split_scratch = h->d_split.ptr;
+    }
     if (pow2 && flacenc_hip::wave_kernel_eligible(a)) {
       flacenc_hip::QlpcLaunchPlan plan = flacenc_hip::plan_qlpc_launch(block_size, cfg->qlpc.lpc_order);
       HIP_TRY(h, flacenc_hip::launch_qlpc(a, plan, s));
@@ -1307,6 +1317,8 @@ static int encode_stereo_frames_impl(flacenc_hip_handle* h, const flacenc_hip_fr
   a.max_rice_parameter = cfg->qlpc.max_rice_parameter;
   a.rice_finest_only = (cfg->qlpc.flags & FLACENC_HIP_FLAG_FINEST_RICE_ORDER) ? 1u : 0u;
   a.force_generic = (cfg->qlpc.flags & FLACENC_HIP_FLAG_GENERIC_KERNEL) ? 1u : 0u;
+  a.reference_order = (cfg->qlpc.flags & FLACENC_HIP_FLAG_REFERENCE_SUM_ORDER) ? 1u : 0u;
+  a.acorr_in = nullptr;
   a.params = nullptr;
   a.residual = residual;
   a.residual_stride = residual_stride;
@@ -1334,6 +1346,11 @@ static int encode_stereo_frames_impl(flacenc_hip_handle* h, const flacenc_hip_fr
   a.pred = nullptr;
   a.pred_out = nullptr;
   a.split_scratch = nullptr;
+  if (a.reference_order) {  // R[] of the reference-order pass
+    int rc2 = ensure(h, h->d_split, static_cast<size_t>(a.n_subframes) * (33 * 8 + 36 * 4));
+    if (rc2 != FLACENC_HIP_OK) return rc2;
+    a.split_scratch = h->d_split.ptr;
+  }
   // The fused bit writer pays off when the fixed-LPC candidate is on (measured on MI355X, 8192 frames:
   // 0.64 ms vs 0.49 + 0.22 ms in two launches); without it the packing tail -- two of the four waves
   // busy, 8 waves per CU to hide the CRC's table latency -- costs more than the separate packer

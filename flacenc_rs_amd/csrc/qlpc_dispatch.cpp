@@ -2,6 +2,8 @@
 // and dispatch to the per-bucket kernel instantiations.
 #include "qlpc_kernel.h"
 
+#include "acorr_reference.h"
+
 namespace flacenc_hip {
 namespace {
 
@@ -69,6 +71,48 @@ QlpcLaunchPlan plan_qlpc_launch(uint32_t block_size, uint32_t lpc_order) {
 hipError_t launch_qlpc(const QlpcKernelArgs& a, const QlpcLaunchPlan& plan, hipStream_t stream) {
   if (a.n_subframes == 0) return hipSuccess;
   if ((a.frame_results || a.chan_results) && !wave_kernel_eligible(a)) return hipErrorNotSupported;
+  if (a.reference_order && a.fixed_mode == 0 && a.lpc_stage == 0 && a.acorr_in == nullptr) {
+    // Reference summation order: R[] by the lane-per-subframe kernel, then the usual pipeline from
+    // Levinson on -- the fused wave kernel with its phase 1 skipped, or the generic kernel's
+    // three-launch split from its second launch.
+    if (a.split_scratch == nullptr) return hipErrorInvalidValue;
+    double* racc = a.autocorr ? a.autocorr : reinterpret_cast<double*>(a.split_scratch);
+    AcorrRefArgs r{};
+    r.samples = a.samples;
+    r.stride = a.stride;
+    r.block_size = a.block_size;
+    r.n_subframes = a.n_subframes;
+    r.stereo = a.stereo;
+    r.window = a.window;
+    r.lpc_order = a.lpc_order;
+    r.out = racc;
+    hipError_t err = launch_acorr_reference(r, stream);
+    if (err != hipSuccess) return err;
+    QlpcKernelArgs b = a;
+    b.acorr_in = racc;
+    if (wave_kernel_eligible(b)) {
+      b.autocorr = nullptr;  // already written
+      return launch_qlpc(b, plan, stream);
+    }
+    QlpcKernelArgs s2 = b, s3 = b;
+    int32_t* pred = reinterpret_cast<int32_t*>(reinterpret_cast<double*>(a.split_scratch) +
+                                                static_cast<size_t>(a.n_subframes) * 33);
+    s2.autocorr = racc;
+    s2.pred_out = pred;
+    s3.lpc_stage = 3;
+    s3.pred = pred;
+    s3.autocorr = nullptr;
+    s3.lpc_coefs = nullptr;  // written by the batch kernel
+#define FLACENC_HIP_REFSPLIT(MP, BG)                                                           \
+  if (plan.maxp == MP && plan.big == (BG != 0)) {                                              \
+    err = launch_levinson_##MP##_##BG(s2, stream);                                             \
+    if (err != hipSuccess) return err;                                                         \
+    return launch_qlpc_##MP##_##BG(s3, plan.threads, plan.smem_bytes, stream);                 \
+  }
+    FLACENC_HIP_FOR_EACH_INSTANCE(FLACENC_HIP_REFSPLIT)
+#undef FLACENC_HIP_REFSPLIT
+    return hipErrorInvalidValue;
+  }
   if (wave_kernel_eligible(a)) {
     const int mp = a.lpc_order <= 8 ? 8 : (a.lpc_order <= 10 ? 10 : 12);
     const int variant = a.stereo ? (a.frame_results ? (a.pack_out ? 5 : (a.use_fixed ? 3 : 2)) : 1)

@@ -32,6 +32,11 @@ struct QlpcKernelArgs {
   uint32_t max_rice_parameter;
   uint32_t rice_finest_only;  // FLACENC_HIP_FLAG_FINEST_RICE_ORDER: no merging below the finest order
   uint32_t force_generic;     // FLACENC_HIP_FLAG_GENERIC_KERNEL: never the wave-per-subframe kernel
+  // FLACENC_HIP_FLAG_REFERENCE_SUM_ORDER: R[] comes from acorr_reference_kernel (the reference's stable
+  // summation order, one sequential chain per lag) instead of the kernels' canonical chunk tree;
+  // launch_qlpc runs it into split_scratch (or `autocorr`) and hands the result on as `acorr_in`
+  uint32_t reference_order;
+  const double* acorr_in;     // device, [n][33]: precomputed R[], skips phase 1 (wave kernel)
   flacenc_hip_subframe_params* params;  // device
   int32_t* residual;                    // device
   size_t residual_stride;

@@ -568,6 +568,21 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
   // ======================= phase 1: window + autocorrelation ==============
   double R[NLAG];
   int vmax = INT32_MIN, vmin = INT32_MAX;
+  if (a.acorr_in != nullptr) {
+    // FLACENC_HIP_FLAG_REFERENCE_SUM_ORDER: R[] was computed by acorr_reference_kernel in the
+    // reference's own summation order; what is left of this phase is the role's max / min
+    const double* __restrict__ rin = a.acorr_in + (size_t)sf * 33;
+#pragma unroll
+    for (int k = 0; k < NLAG; ++k) R[k] = rin[k];
+    with_role([&](auto kind) {
+#pragma unroll 4
+      for (int k = 0; k < 16; ++k) {
+        const int4 v = ld4k(kind, tl + 4 * k);
+        vmax = max(max(vmax, v.x), max(v.y, max(v.z, v.w)));
+        vmin = min(min(vmin, v.x), min(v.y, min(v.z, v.w)));
+      }
+    });
+  } else
   with_role([&](auto kind) {
     auto ld4 = [&](int t) { return ld4k(kind, t); };
     // The lane walks its 64 samples as 4 chunks x 2 steps of 8 with a sliding f64 window of

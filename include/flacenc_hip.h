@@ -77,6 +77,13 @@ extern "C" {
 #define FLACENC_HIP_FLAG_GENERIC_KERNEL 4u
 #define FLACENC_HIP_FLAG_FUSED_PACK 8u
 #define FLACENC_HIP_FLAG_TWO_STAGE_PACK 16u
+/* Autocorrelation in the summation order of the reference's stable build: one sequential mul_add chain
+ * per lag over t = order .. n-1 (weighted_auto_correlation_nosimd, src/lpc.rs:533-548), computed one
+ * subframe per lane by a kernel of its own, instead of the kernels' default order (16-sample chunk
+ * chains combined by a balanced tree -- same FMA count, different roundings, documented in DESIGN.md).
+ * With this flag R[], the LPC coefficients and therefore every integer output are those of the stable
+ * reference build for everything the oracle pins.  Costs one extra pass over the samples. */
+#define FLACENC_HIP_FLAG_REFERENCE_SUM_ORDER 32u
 
 /* where the caller's sample / output buffers live */
 #define FLACENC_HIP_MEM_HOST 0

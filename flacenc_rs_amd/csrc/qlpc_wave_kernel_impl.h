@@ -279,55 +279,59 @@ __device__ __forceinline__ unsigned long long plane_sum_any64(const PlaneSums& p
 // minimum per level in pk[level]; the minimum over the groups is the minimum over the window.  One
 // instance of the level code instead of one per window width keeps the search at 8 + 8 + 7 registers
 // whatever the span (typical material: one group).
+// Table entries Wp[j] = table[p_base + j] - 4 of this lane's 64-sample partition (see rice_search).
+// EXACT: from the bit-planes; otherwise the literal chunk-clamped sums of rice.rs:75-98 from e[].
 template <bool EXACT>
-__device__ __forceinline__ RiceResult rice_search(const PlaneSums& ps, const int32_t* e, uint32_t len0,
-                                                  uint32_t p_lo, uint32_t max_p, bool small_bits, int lane,
-                                                  int warm, bool finest_only) {
+__device__ __forceinline__ void rice_build_tables(const PlaneSums& ps, const int32_t* e, uint32_t len0,
+                                                  uint32_t p_base, uint32_t max_p, int lane, int warm,
+                                                  uint32_t (&Wp)[8]) {
   constexpr int NP = 8;
   constexpr uint32_t kWMax = kMaxPToBits - 4u;
-  uint32_t pk[7];
+  if (EXACT) {
 #pragma unroll
-  for (int k = 0; k < 7; ++k) pk[k] = 0xFFFFFFFFu;
-#pragma unroll 1
-  for (uint32_t p_base = p_lo; p_base <= max_p; p_base += (uint32_t)NP) {
-    uint32_t Wp[NP];
-    if (EXACT) {
-#pragma unroll
-      for (int j = 0; j < NP; ++j) {
-        const uint32_t pp = p_base + (uint32_t)j;  // wave-uniform
-        uint32_t sum;  // sum_i (u_i >> pp); pp == 0 is only possible for j == 0
-        if (j == 0) sum = (pp == 0) ? 2u * ps.sum_m + ps.negs : plane_sum_ge1(ps, pp);
-        else sum = plane_sum_ge1(ps, pp);
-        sum = sum < kMaxPToBits ? sum : kMaxPToBits;
-        uint32_t v = sum + len0 * (pp + 1u);  // rice.rs:69-71, 95-98 (minus the 4)
-        v = v < kWMax ? v : kWMax;
-        Wp[j] = (pp <= max_p) ? v : kWMax;
-      }
-    } else {
-      // the reference's slice of partition 0 starts at `warm`; its clamp cadence follows.
-      // (rare path: runtime loop over p, registers selected by compare chains -- no scratch)
-      const int off = (lane == 0) ? warm : 0;
-#pragma unroll
-      for (int q = 0; q < NP; ++q) Wp[q] = kWMax;
-#pragma unroll 1
-      for (int j = 0; j < NP; ++j) {
-        const uint32_t pp = p_base + (uint32_t)j;
-        uint32_t accb = 0;
-#pragma unroll
-        for (int k = 0; k < 64; ++k) {
-          if (k >= off) {
-            accb += zigzag(e[k]) >> (pp & 31u);
-            if (((k - off) & 15) == 15) accb = accb < kMaxPToBits ? accb : kMaxPToBits;
-          }
-        }
-        accb = accb < kMaxPToBits ? accb : kMaxPToBits;
-        uint32_t v = accb + len0 * (pp + 1u);
-        v = v < kWMax ? v : kWMax;
-        if (pp > max_p) v = kWMax;
-#pragma unroll
-        for (int q = 0; q < NP; ++q) Wp[q] = (q == j) ? v : Wp[q];
-      }
+    for (int j = 0; j < NP; ++j) {
+      const uint32_t pp = p_base + (uint32_t)j;  // wave-uniform
+      uint32_t sum;  // sum_i (u_i >> pp); pp == 0 is only possible for j == 0
+      if (j == 0) sum = (pp == 0) ? 2u * ps.sum_m + ps.negs : plane_sum_ge1(ps, pp);
+      else sum = plane_sum_ge1(ps, pp);
+      sum = sum < kMaxPToBits ? sum : kMaxPToBits;
+      uint32_t v = sum + len0 * (pp + 1u);  // rice.rs:69-71, 95-98 (minus the 4)
+      v = v < kWMax ? v : kWMax;
+      Wp[j] = (pp <= max_p) ? v : kWMax;
     }
+  } else {
+    // the reference's slice of partition 0 starts at `warm`; its clamp cadence follows.
+    // (rare path: runtime loop over p, registers selected by compare chains -- no scratch)
+    const int off = (lane == 0) ? warm : 0;
+#pragma unroll
+    for (int q = 0; q < NP; ++q) Wp[q] = kWMax;
+#pragma unroll 1
+    for (int j = 0; j < NP; ++j) {
+      const uint32_t pp = p_base + (uint32_t)j;
+      uint32_t accb = 0;
+#pragma unroll
+      for (int k = 0; k < 64; ++k) {
+        if (k >= off) {
+          accb += zigzag(e[k]) >> (pp & 31u);
+          if (((k - off) & 15) == 15) accb = accb < kMaxPToBits ? accb : kMaxPToBits;
+        }
+      }
+      accb = accb < kMaxPToBits ? accb : kMaxPToBits;
+      uint32_t v = accb + len0 * (pp + 1u);
+      v = v < kWMax ? v : kWMax;
+      if (pp > max_p) v = kWMax;
+#pragma unroll
+      for (int q = 0; q < NP; ++q) Wp[q] = (q == j) ? v : Wp[q];
+    }
+  }
+}
+
+// Levels 0..6 of one group of 8 parameters: merges in place (afterwards Wp holds, on lane 0, the table of
+// all 64 partitions merged) and lowers pk[level] to the group's packed minimum (bits << 5 | p).
+__device__ __forceinline__ void rice_group_levels(uint32_t (&Wp)[8], uint32_t (&pk)[7], uint32_t p_base,
+                                                  bool finest_only) {
+  constexpr int NP = 8;
+  constexpr uint32_t kWMax = kMaxPToBits - 4u;
 #define FLACENC_RICE_LEVEL(K, S)                                                              \
   {                                                                                           \
     if (K > 0) {                                                                              \
@@ -346,16 +350,33 @@ __device__ __forceinline__ RiceResult rice_search(const PlaneSums& ps, const int
     }                                                                                         \
     pk[K] = packed;                                                                           \
   }
-    FLACENC_RICE_LEVEL(0, 1)
-    if (!finest_only) {  // (FLACENC_HIP_FLAG_FINEST_RICE_ORDER keeps order 6)
-      FLACENC_RICE_LEVEL(1, 1)
-      FLACENC_RICE_LEVEL(2, 2)
-      FLACENC_RICE_LEVEL(3, 4)
-      FLACENC_RICE_LEVEL(4, 8)
-      FLACENC_RICE_LEVEL(5, 16)
-      FLACENC_RICE_LEVEL(6, 32)
-    }
+  FLACENC_RICE_LEVEL(0, 1)
+  if (!finest_only) {  // (FLACENC_HIP_FLAG_FINEST_RICE_ORDER keeps the finest order)
+    FLACENC_RICE_LEVEL(1, 1)
+    FLACENC_RICE_LEVEL(2, 2)
+    FLACENC_RICE_LEVEL(3, 4)
+    FLACENC_RICE_LEVEL(4, 8)
+    FLACENC_RICE_LEVEL(5, 16)
+    FLACENC_RICE_LEVEL(6, 32)
+  }
 #undef FLACENC_RICE_LEVEL
+}
+
+template <bool EXACT>
+__device__ __forceinline__ RiceResult rice_search(const PlaneSums& ps, const int32_t* e, uint32_t len0,
+                                                  uint32_t p_lo, uint32_t max_p, bool small_bits, int lane,
+                                                  int warm, bool finest_only) {
+  constexpr int NP = 8;
+  constexpr uint32_t kWMax = kMaxPToBits - 4u;
+  (void)kWMax;
+  uint32_t pk[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) pk[k] = 0xFFFFFFFFu;
+#pragma unroll 1
+  for (uint32_t p_base = p_lo; p_base <= max_p; p_base += (uint32_t)NP) {
+    uint32_t Wp[NP];
+    rice_build_tables<EXACT>(ps, e, len0, p_base, max_p, lane, warm, Wp);
+    rice_group_levels(Wp, pk, p_base, finest_only);
   }
 
   RiceResult r;

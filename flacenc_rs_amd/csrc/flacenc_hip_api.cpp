@@ -208,6 +208,7 @@ int enqueue(flacenc_hip_handle* h, const flacenc_hip_qlpc_config* cfg, const int
   a.force_generic = (cfg->flags & FLACENC_HIP_FLAG_GENERIC_KERNEL) ? 1u : 0u;
   a.reference_order = (cfg->flags & FLACENC_HIP_FLAG_REFERENCE_SUM_ORDER) ? 1u : 0u;
   a.acorr_in = nullptr;
+  a.only_marked = 0;
   a.params = params;
   a.residual = residual;
   a.residual_stride = residual_stride;
@@ -228,7 +229,7 @@ int enqueue(flacenc_hip_handle* h, const flacenc_hip_qlpc_config* cfg, const int
   a.pred = nullptr;
   a.pred_out = nullptr;
   a.split_scratch = nullptr;
-  if (cfg->lpc_order >= 16 || a.reference_order) {
+  if (cfg->lpc_order >= 13 || a.reference_order) {
     rc = ensure(h, h->d_split, n_subframes * (33 * 8 + 36 * 4));
     if (rc != FLACENC_HIP_OK) return rc;
     a.split_scratch = h->d_split.ptr;
@@ -386,6 +387,7 @@ int enqueue_fixed(flacenc_hip_handle* h, const flacenc_hip_frame_config* cfg, co
   a.force_generic = (cfg->qlpc.flags & FLACENC_HIP_FLAG_GENERIC_KERNEL) ? 1u : 0u;
   a.reference_order = (cfg->qlpc.flags & FLACENC_HIP_FLAG_REFERENCE_SUM_ORDER) ? 1u : 0u;
   a.acorr_in = nullptr;
+  a.only_marked = 0;
   a.params = params;
   a.residual = residual;
   a.residual_stride = residual_stride;
@@ -839,6 +841,7 @@ int flacenc_hip_encode_frames_async(flacenc_hip_handle* h, const flacenc_hip_fra
   a.force_generic = (cfg->qlpc.flags & FLACENC_HIP_FLAG_GENERIC_KERNEL) ? 1u : 0u;
   a.reference_order = (cfg->qlpc.flags & FLACENC_HIP_FLAG_REFERENCE_SUM_ORDER) ? 1u : 0u;
   a.acorr_in = nullptr;
+  a.only_marked = 0;
     a.params = nullptr;
     a.residual = residual;
     a.residual_stride = residual_stride;
@@ -1319,6 +1322,7 @@ static int encode_stereo_frames_impl(flacenc_hip_handle* h, const flacenc_hip_fr
   a.force_generic = (cfg->qlpc.flags & FLACENC_HIP_FLAG_GENERIC_KERNEL) ? 1u : 0u;
   a.reference_order = (cfg->qlpc.flags & FLACENC_HIP_FLAG_REFERENCE_SUM_ORDER) ? 1u : 0u;
   a.acorr_in = nullptr;
+  a.only_marked = 0;
   a.params = nullptr;
   a.residual = residual;
   a.residual_stride = residual_stride;

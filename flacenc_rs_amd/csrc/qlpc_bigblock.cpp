@@ -1,0 +1,585 @@
+// qlpc_bigblock.cpp -- blocks of 8192 / 16384 samples with LPC order 13..32 (BASELINE configs[2] and
+// configs[4]: 96 kHz / 192 kHz 24-bit material), as two kernels either side of levinson_batch_kernel:
+//
+//   bigblock_acorr_kernel      window + f64 autocorrelation -> R[]            (src/lpc.rs:739-756, 533-548)
+//   levinson_batch_kernel      one subframe per lane (qlpc_kernel_impl.h)     (src/lpc.rs:633-705, 234-302)
+//   bigblock_residual_kernel   residual + exhaustive partitioned-Rice search  (src/lpc.rs:306-390,
+//                                                                              src/rice.rs:65-298)
+//
+// Both walk a block in PASSES of 4096 samples with the layout of the fused 4096 kernel
+// (qlpc_wave_kernel_impl.h): a workgroup is 4 waves = the roles L, R, M, S of one stereo frame sharing
+// two channel images in LDS (or four plain subframes), lane l of a wave owns the 64 samples
+// [4096 k + 64 l, +64) of pass k = four 16-sample chunks = one finest Rice partition.  Only the pass's
+// 4096 samples (+ 64 of halo) are staged, so LDS stays at 35 KB per workgroup whatever the block size.
+// The autocorrelation sums are the canonical ones: 16-sample chunk chains, then a
+// balanced tree over the chunk index c = 256 k + 4 l + i -- chunk bits in the lane, lane bits by a wave
+// butterfly, pass bits last.  At order 25..32 one launch would need three 33-entry f64 accumulator sets
+// per lane; the lags are therefore split over two launches (0..16, 17..32), each with the full window.
+// The Rice search keeps the seven bit-planes of every pass in registers, runs levels 0..6 per pass with
+// the 4096 kernel's level code and adds the levels that merge whole passes (orders 7 - level, 8 - level).
+#include <type_traits>
+
+#include "qlpc_kernel.h"
+#include "qlpc_wave_kernel_impl.h"
+
+namespace flacenc_hip {
+namespace {
+
+constexpr int kPass = 4096;
+
+// cooperative load of pass k of the workgroup's rows into the LDS images: segment 0 of an image holds the
+// 64 samples in front of the pass (zeros in front of the block), the pass follows (widx layout)
+template <bool STEREO>
+__device__ __forceinline__ void bigblock_load_pass(const QlpcKernelArgs& a, int32_t* sm, uint32_t blk, int k, int tid,
+                                                   int wave, int lane, uint32_t sf) {
+  const size_t t0 = (size_t)k * kPass;
+  if (STEREO) {
+    const int32_t* __restrict__ src = a.samples + (size_t)(2u * blk) * a.stride + t0;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int q = tid + it * 256;  // 0..2047
+      const int ch = q >> 10;
+      const int t = (q & 1023) << 2;
+      const int4 v = *reinterpret_cast<const int4*>(src + (size_t)ch * a.stride + t);
+      *reinterpret_cast<int4*>(&sm[ch * kBufDwords + widx(t)]) = v;
+    }
+    if (tid < 32) {
+      const int ch = tid >> 4;
+      const int t = ((tid & 15) << 2) - 64;
+      int4 v = make_int4(0, 0, 0, 0);
+      if (k > 0) v = *reinterpret_cast<const int4*>(src + (size_t)ch * a.stride + t);
+      *reinterpret_cast<int4*>(&sm[ch * kBufDwords + widx(t)]) = v;
+    }
+  } else {
+    const int32_t* __restrict__ src = a.samples + (size_t)sf * a.stride + t0;
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int t = (lane + it * 64) << 2;
+      const int4 v = *reinterpret_cast<const int4*>(src + t);
+      *reinterpret_cast<int4*>(&sm[wave * kBufDwords + widx(t)]) = v;
+    }
+    if (lane < 16) {
+      const int t = (lane << 2) - 64;
+      int4 v = make_int4(0, 0, 0, 0);
+      if (k > 0) v = *reinterpret_cast<const int4*>(src + t);
+      *reinterpret_cast<int4*>(&sm[wave * kBufDwords + widx(t)]) = v;
+    }
+  }
+}
+
+// four samples of a role at pass-relative t (multiple of 4, >= -64): own image, mid or side
+template <int KIND>
+__device__ __forceinline__ int4 bigblock_ld4(const int32_t* bufA, const int32_t* bufB, int t) {
+  int4 v = *reinterpret_cast<const int4*>(&bufA[widx(t)]);
+  if (KIND >= 2) {
+    const int4 r = *reinterpret_cast<const int4*>(&bufB[widx(t)]);
+    if (KIND == 2) {  // mid = (l + r) >> 1, coding.rs:483
+      v.x = (v.x + r.x) >> 1;
+      v.y = (v.y + r.y) >> 1;
+      v.z = (v.z + r.z) >> 1;
+      v.w = (v.w + r.w) >> 1;
+    } else {  // side = l - r
+      v.x -= r.x;
+      v.y -= r.y;
+      v.z -= r.z;
+      v.w -= r.w;
+    }
+  }
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// lags LAG0 .. LAG0 + NL - 1 of R[]; HP = the order bucket (window depth)
+template <int HP, int LAG0, int NL, bool STEREO>
+__global__ void __launch_bounds__(256, 2) bigblock_acorr_kernel(QlpcKernelArgs a) {
+  static_assert(HP % 8 == 0 && LAG0 + NL - 1 <= HP, "window must cover the largest lag");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  int32_t* const sm = reinterpret_cast<int32_t*>(smem_raw);
+  constexpr int NBUF = STEREO ? 2 : 4;
+  double* const part = reinterpret_cast<double*>(sm + NBUF * kBufDwords);  // [4 waves][2][NL] pass partials
+  const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
+  const uint32_t blk = blockIdx.x;
+  uint32_t sf = blk * 4u + (uint32_t)wave;
+  const bool active = sf < a.n_subframes;
+  if (!active) sf = a.n_subframes - 1u;  // (plain mode tail: redo the last subframe, write nothing)
+  const int role = STEREO ? wave : 0;
+  const int P = (int)a.lpc_order;
+  const int K = (int)(a.block_size / kPass);
+  const int32_t* const bufA = sm + (STEREO ? (role == 1 ? 1 : 0) : wave) * kBufDwords;
+  const int32_t* const bufB = sm + kBufDwords;
+  const float* __restrict__ wtab = a.window ? a.window + 32 : nullptr;
+  const int tl = lane << 6;
+  constexpr int NB = HP / 8 + 1;  // ring of 8-value blocks: HP lagged values + the current 8
+
+  for (int k = 0; k < K; ++k) {
+    __syncthreads();
+    bigblock_load_pass<STEREO>(a, sm, blk, k, tid, wave, lane, sf);
+    __syncthreads();
+    double p2[NL];
+    auto run = [&](auto kind_tag) {
+      constexpr int KIND = decltype(kind_tag)::value;
+      // x_w[t] = (f32)s[t] * w[t], one f32 rounding, then widened (lpc.rs:751-754)
+      auto conv8 = [&](double (&dst)[8], int t) {  // t pass-relative, multiple of 8, >= -HP
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int4 v = bigblock_ld4<KIND>(bufA, bufB, t + 4 * q);
+          float4 w = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+          const int tg = k * kPass + t + 4 * q;  // block-relative; the table has 32 zeros in front
+          if (wtab && !(tg >= a.flat_lo && tg + 4 <= a.flat_hi)) {
+            if (tg >= 0) w = *reinterpret_cast<const float4*>(wtab + tg);
+            else w = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // in front of the block: samples are 0 anyway
+          }
+          dst[4 * q + 0] = (double)((float)v.x * w.x);
+          dst[4 * q + 1] = (double)((float)v.y * w.y);
+          dst[4 * q + 2] = (double)((float)v.z * w.z);
+          dst[4 * q + 3] = (double)((float)v.w * w.w);
+        }
+      };
+      // ring of NB blocks: step s (8 samples at tl + 8 s) lives in block s mod NB, the HP values in
+      // front of the lane in the blocks "before" block 0 -- all indices are compile-time constants
+      double ring[NB][8];
+#pragma unroll
+      for (int b = 1; b < NB; ++b) conv8(ring[b], tl - HP + 8 * (b - 1));
+      double acc[NL], s01[NL];
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        conv8(ring[s % NB], tl + 8 * s);
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+          double cur = ring[s % NB][kk];
+          // common lower bound t = P for every lag (lpc.rs:542): only the block's first 32 samples
+          if (s < 4) cur = (k == 0 && tl + 8 * s + kk < P) ? 0.0 : cur;
+#pragma unroll
+          for (int j = 0; j < NL; ++j) {
+            const int q = 8 * s + kk - (LAG0 + j);           // position of the lagged value, relative to tl
+            const int qb = q >= 0 ? q >> 3 : -((-q + 7) >> 3);  // floor(q / 8)
+            const double lagged = ring[((qb % NB) + NB) % NB][q - 8 * qb];
+            acc[j] = ((s & 1) == 0 && kk == 0) ? __builtin_fma(cur, lagged, 0.0) : __builtin_fma(cur, lagged, acc[j]);
+          }
+        }
+        // in-lane levels of the balanced tree over the chunk index: (c0 + c1) + (c2 + c3)
+        if (s == 1) {
+#pragma unroll
+          for (int j = 0; j < NL; ++j) s01[j] = acc[j];
+        } else if (s == 3) {
+#pragma unroll
+          for (int j = 0; j < NL; ++j) s01[j] = s01[j] + acc[j];
+        } else if (s == 5) {
+#pragma unroll
+          for (int j = 0; j < NL; ++j) p2[j] = acc[j];
+        } else if (s == 7) {
+#pragma unroll
+          for (int j = 0; j < NL; ++j) p2[j] = s01[j] + (p2[j] + acc[j]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    if (STEREO && role == 2) run(std::integral_constant<int, 2>{});
+    else if (STEREO && role == 3) run(std::integral_constant<int, 3>{});
+    else run(std::integral_constant<int, 0>{});
+    // lane levels, then the pass levels: K = 2: R0 + R1; K = 4: (R0 + R1) + (R2 + R3).  Partials of
+    // earlier passes wait in LDS (only lane 0's copy matters).
+    double* const mine = part + wave * 2 * NL;
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      double r = wave_butterfly_sum(p2[j]);
+      if (lane == 0) {
+        if ((k & 1) == 0) {
+          mine[(k >> 1 & 1) * NL + j] = r;                        // R0 (or R2) waits for its partner
+        } else {
+          r = mine[(k >> 1 & 1) * NL + j] + r;                    // R0 + R1 (or R2 + R3)
+          if (K == 4 && k == 1) mine[j] = r;                      // keeps waiting for (R2 + R3)
+          if (K == 4 && k == 3) r = mine[j] + r;
+          if (k == K - 1 && active)
+            a.autocorr[(size_t)sf * 33 + LAG0 + j] = (LAG0 + j <= P) ? r : 0.0;
+        }
+      }
+    }
+  }
+  if (lane == 0 && active && LAG0 == 0)
+    for (int j = HP + 1; j < 33; ++j) a.autocorr[(size_t)sf * 33 + j] = 0.0;
+}
+
+// ---------------------------------------------------------------------------------------------
+template <int MAXP, bool STEREO, int K>
+__global__ void __launch_bounds__(256, 2) bigblock_residual_kernel(QlpcKernelArgs a) {
+  constexpr int HP = MAXP;  // multiple of 8
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  int32_t* const sm = reinterpret_cast<int32_t*>(smem_raw);
+  const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
+  const uint32_t blk = blockIdx.x;
+  uint32_t sf = blk * 4u + (uint32_t)wave;
+  const bool active = sf < a.n_subframes;
+  if (!active) sf = a.n_subframes - 1u;
+  const int role = STEREO ? wave : 0;
+  const int n = (int)a.block_size;
+  const int32_t* const bufA = sm + (STEREO ? (role == 1 ? 1 : 0) : wave) * kBufDwords;
+  const int32_t* const bufB = sm + kBufDwords;
+  const int tl = lane << 6;
+  const unsigned long long bps_role = a.bps ? (unsigned long long)a.bps[sf]
+                                            : (unsigned long long)(a.bps_uniform + ((STEREO && role == 3) ? 1u : 0u));
+  // the quantised predictor levinson_batch_kernel left: qc[32], order, shift, status
+  const int32_t* __restrict__ pr = a.pred + (size_t)sf * 36;
+  int32_t cq[MAXP];
+#pragma unroll
+  for (int i = 0; i < MAXP; ++i) cq[i] = uni(pr[i]);
+  const int warm = uni(pr[32]);
+  const int shift = uni(pr[33]);
+  const int status = uni(pr[34]);
+  int32_t* __restrict__ rrow = a.residual + (size_t)sf * a.residual_stride;
+
+  uint32_t pl[K][7];
+  for (int k = 0; k < K; ++k) {
+    __syncthreads();
+    bigblock_load_pass<STEREO>(a, sm, blk, k, tid, wave, lane, sf);
+    __syncthreads();
+    auto run = [&](auto kind_tag, uint32_t (&planes)[7]) {
+      constexpr int KIND = decltype(kind_tag)::value;
+      // e[t] = s[t] - ((sum_j c_j s[t-1-j]) >> shift), exact in 64 bits, truncated to i32
+      // (lpc.rs:306-350, the i64 branch of :379-388 -- both branches give the same value)
+      int sw[HP + 16];
+      uint32_t pc[6];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int t0 = tl + 16 * i;
+        asm volatile("" ::: "memory");  // keeps the next chunk's LDS reads behind this chunk's arithmetic
+        if (i > 0) {
+#pragma unroll
+          for (int q = 0; q < HP; ++q) sw[q] = sw[q + 16];
+        }
+#pragma unroll
+        for (int q = (i == 0 ? 0 : HP); q < HP + 16; q += 4) {
+          const int4 v = bigblock_ld4<KIND>(bufA, bufB, t0 - HP + q);
+          sw[q + 0] = v.x;
+          sw[q + 1] = v.y;
+          sw[q + 2] = v.z;
+          sw[q + 3] = v.w;
+        }
+        int32_t e[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          int64_t pred = 0;
+#pragma unroll
+          for (int j = 0; j < MAXP; ++j) pred += (int64_t)cq[j] * (int64_t)sw[HP + q - 1 - j];
+          e[q] = (int32_t)(uint32_t)(uint64_t)((int64_t)sw[HP + q] - (pred >> shift));
+          // e[0 .. order') = 0 (lpc.rs:349): the block's first samples, i.e. pass 0, lane 0
+          if ((k == 0 && tl + 16 * i + q < warm) || status != 0) e[q] = 0;
+        }
+        if (active) {
+#pragma unroll
+          for (int q = 0; q < 16; q += 4)
+            *reinterpret_cast<int4*>(rrow + (size_t)k * kPass + t0 + q) = make_int4(e[q], e[q + 1], e[q + 2], e[q + 3]);
+        }
+        // bit-sliced population counts of the chunk, accumulated into the lane's 7 planes for this pass
+        uint32_t pb[5];
+        popcount_planes16(e, pb);
+        if (i == 0) {
+#pragma unroll
+          for (int q = 0; q < 5; ++q) planes[q] = pb[q];
+        } else if (i == 1) {
+          planes_add<5>(planes, pb);
+        } else if (i == 2) {
+#pragma unroll
+          for (int q = 0; q < 5; ++q) pc[q] = pb[q];
+        } else {
+          planes_add<5>(pc, pb);
+          planes_add<6>(planes, pc);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    // (the pass loop is rolled; pl[k] is selected by a compare chain so that the planes stay in registers)
+    uint32_t now[7];
+    if (STEREO && role == 2) run(std::integral_constant<int, 2>{}, now);
+    else if (STEREO && role == 3) run(std::integral_constant<int, 3>{}, now);
+    else run(std::integral_constant<int, 0>{}, now);
+#pragma unroll
+    for (int kk = 0; kk < K; ++kk)
+      if (kk == k) {
+#pragma unroll
+        for (int q = 0; q < 7; ++q) pl[kk][q] = now[q];
+      }
+  }
+
+  // ======================= partitioned-Rice search over 64 K partitions =======================
+  // finest order FO = 6 + log2 K (rice.rs:157-165); level L = order FO - L
+  constexpr int LK = K == 2 ? 1 : 2;
+  constexpr int NLEV = 7 + LK;
+  constexpr uint32_t kWMax = kMaxPToBits - 4u;
+  uint32_t orp = 0;
+#pragma unroll
+  for (int k = 0; k < K; ++k)
+#pragma unroll
+    for (int q = 0; q < 7; ++q) orp |= pl[k][q];
+  const uint32_t orw = wave_or_dpp(orp);
+  const uint32_t maxu = (orw << 1) | (orw >> 31);
+  const uint32_t bitlen = maxu ? (uint32_t)(32 - __builtin_clz(maxu)) : 0u;
+  const uint32_t max_p = a.max_rice_parameter < bitlen ? a.max_rice_parameter : bitlen;
+  const bool finest_only = a.rice_finest_only != 0;
+  PlaneSums ps[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) ps[k] = make_plane_sums(pl[k]);
+  uint32_t len0[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) len0[k] = 64u - ((k == 0 && lane == 0) ? (uint32_t)warm : 0u);
+  // residuals of 2^26 and more (the reference's wrapping chunk sums, rice.rs:88-93, then differ from the
+  // exact ones) are left to the generic kernel: this launch reports it and the dispatcher reruns it
+  const bool literal = !(maxu < (1u << 26));
+
+  uint32_t pk[K][7], pk7[K / 2], pk8 = 0xFFFFFFFFu;
+  uint32_t sat_top = 0;
+  auto search = [&](uint32_t p_lo) {
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+      for (int q = 0; q < 7; ++q) pk[k][q] = 0xFFFFFFFFu;
+#pragma unroll
+    for (int j = 0; j < K / 2; ++j) pk7[j] = 0xFFFFFFFFu;
+    pk8 = 0xFFFFFFFFu;
+#pragma unroll 1
+    for (uint32_t p_base = p_lo; p_base <= max_p; p_base += 8u) {
+      uint32_t top[K][8];
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        rice_build_tables<true>(ps[k], nullptr, len0[k], p_base, max_p, (k == 0) ? lane : 1, warm, top[k]);
+        rice_group_levels(top[k], pk[k], p_base, finest_only);
+      }
+      if (!finest_only) {
+        // levels that merge whole passes: lane 0 of the wave holds every pass's merged table
+#pragma unroll
+        for (int j = 0; j < K / 2; ++j) {
+          uint32_t packed = pk7[j];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            uint32_t v = top[2 * j][q] + top[2 * j + 1][q];
+            v = v < kWMax ? v : kWMax;
+            top[2 * j][q] = v;
+            const uint32_t c = (v << 5) | (p_base + (uint32_t)q);
+            packed = c < packed ? c : packed;
+          }
+          pk7[j] = packed;
+        }
+        if (K == 4) {
+          uint32_t packed = pk8;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            uint32_t v = top[0][q] + top[2][q];
+            v = v < kWMax ? v : kWMax;
+            const uint32_t c = (v << 5) | (p_base + (uint32_t)q);
+            packed = c < packed ? c : packed;
+          }
+          pk8 = packed;
+        }
+      }
+    }
+  };
+  // rice_window (see the 4096 kernel): the wave-minimum of floor(log2(mean + 1)) over all partitions
+  uint32_t p0l = 31u;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const uint32_t s0 = 2u * ps[k].sum_m + ps[k].negs;
+    const uint32_t c = 31u - (uint32_t)__builtin_clz((s0 >> 6) + 1u);
+    p0l = c < p0l ? c : p0l;
+  }
+  const uint32_t p0min = wave_min_dpp(p0l);
+  uint32_t p_lo = p0min > 2u ? p0min - 2u : 0u;
+  p_lo = p_lo < max_p ? p_lo : max_p;
+  if (literal) p_lo = 0u;
+
+  // level totals; strict < keeps the finer order on ties (rice.rs:285)
+  int bestl = 0;
+  unsigned long long best_bits = 0;
+  uint32_t sat_levels = 0;
+  auto totals = [&]() {
+    sat_levels = 0;
+#pragma unroll
+    for (int L = 0; L < NLEV; ++L) {
+      if (L > 0 && finest_only) break;
+      unsigned long long tot = 0;
+      uint32_t sat = 0;
+      if (L < 7) {
+        const bool lead = (lane & ((1 << L) - 1)) == 0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          const uint32_t bits = (pk[k][L] >> 5) + 4u;
+          const uint32_t lb = lead ? bits : 0u;
+          sat |= (lead && bits >= kMaxPToBits) ? 1u : 0u;
+          tot += ((unsigned long long)wave_sum_dpp(lb >> 16) << 16) + wave_sum_dpp(lb & 0xFFFFu);
+        }
+        sat = wave_or_dpp(sat);
+      } else if (L == 7) {
+#pragma unroll
+        for (int j = 0; j < K / 2; ++j) {
+          const uint32_t bits = (uint32_t)uni((int)((pk7[j] >> 5) + 4u));
+          sat |= bits >= kMaxPToBits ? 1u : 0u;
+          tot += bits;
+        }
+      } else {
+        const uint32_t bits = (uint32_t)uni((int)((pk8 >> 5) + 4u));
+        sat |= bits >= kMaxPToBits ? 1u : 0u;
+        tot = bits;
+      }
+      sat_levels |= sat << L;
+      if (L == 0 || tot < best_bits) {
+        best_bits = tot;
+        bestl = L;
+      }
+    }
+  };
+  if (!literal) {
+    search(p_lo);
+    totals();
+    // a saturated minimum could tie with clamped entries outside the window: search the whole range
+    if (sat_levels != 0 && p_lo != 0) {
+      search(0u);
+      totals();
+    }
+  }
+  (void)sat_top;
+  const bool saturated = (sat_levels >> bestl) & 1u;
+  const int rice_order = (6 + LK) - bestl;
+  const uint32_t best_parts = 1u << rice_order;
+
+  // the parameter of the chosen-order partition each (pass, lane) leads
+  uint32_t myp[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    uint32_t v = 0;
+#pragma unroll
+    for (int L = 0; L < 7; ++L) v = (L == bestl) ? (pk[k][L] & 31u) : v;
+    if (bestl == 7) v = (uint32_t)uni((int)(pk7[k >> 1] & 31u));
+    if (bestl == 8) v = (uint32_t)uni((int)(pk8 & 31u));
+    myp[k] = v;
+  }
+  // Residual::sum_quotients / count_bits (datatype.rs:2325-2331, bitrepr.rs:533-544)
+  const int lanebits = bestl < 6 ? bestl : 6;
+  const bool lane_leader = (lane & ((1 << lanebits) - 1)) == 0;
+  uint32_t sum_p = 0, rice2 = 0;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const bool pass_leader = bestl <= 6 || (bestl == 7 && (k & 1) == 0) || (bestl == 8 && k == 0);
+    const bool leader = lane_leader && pass_leader;
+    sum_p += wave_sum_dpp(leader ? myp[k] : 0u);
+    rice2 |= wave_or_dpp((leader && myp[k] > 14) ? 1u : 0u);
+  }
+  const uint32_t p_first = (uint32_t)uni((int)myp[0]);
+  const unsigned long long rem_bits = (unsigned long long)sum_p * (unsigned long long)(n >> rice_order) -
+                                      (unsigned long long)warm * p_first;
+  unsigned long long sum_q;
+  if (saturated) {
+    // exact quotient sum from the planes under each partition's parameter
+    unsigned long long acc = 0;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      uint32_t gp = (uint32_t)__shfl((int)myp[k], lane & ~((1 << lanebits) - 1), 64);
+      if (bestl == 7) gp = (uint32_t)uni((int)(pk7[k >> 1] & 31u));
+      if (bestl == 8) gp = (uint32_t)uni((int)(pk8 & 31u));
+      const unsigned long long mine = plane_sum_any64(ps[k], gp);
+      acc += ((unsigned long long)wave_sum_dpp((uint32_t)(mine >> 16)) << 16) +
+             (unsigned long long)wave_sum_dpp((uint32_t)(mine & 0xFFFFu));
+    }
+    sum_q = acc;
+  } else {
+    sum_q = best_bits - 4ull * best_parts - (unsigned long long)(n - warm) - rem_bits;
+  }
+  const unsigned long long residual_bits = 2ull + 4ull + (unsigned long long)best_parts * (rice2 ? 5ull : 4ull) +
+                                           (sum_q + (unsigned long long)(n - warm)) + rem_bits;
+  const unsigned long long sub_bits = 8ull + bps_role * (unsigned long long)warm + 4ull + 5ull +
+                                      (unsigned long long)a.precision * (unsigned long long)warm + residual_bits;
+
+  if (!active) return;
+  flacenc_hip_subframe_params* rec = a.params + sf;
+  if (literal) {
+    // marker for the dispatcher: this subframe has to go through the generic kernel's literal tables
+    if (lane == 0) rec->status = -1;
+    return;
+  }
+  // partition j of the chosen order: pass (j << bestl) >> 6, lane (j << bestl) & 63
+  {
+    const uint32_t ok = status == 0 ? 1u : 0u;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const uint32_t j = (uint32_t)(lane + 64 * r);
+      const uint32_t first = (j << bestl) & (uint32_t)(64 * K - 1);  // finest-partition index of the first member
+      const uint32_t src_lane = first & 63u, src_pass = first >> 6;
+      uint32_t v = 0;
+#pragma unroll
+      for (int k = 0; k < K; ++k) {  // (every lane takes part in every shuffle)
+        const uint32_t got = (uint32_t)__shfl((int)myp[k], (int)src_lane, 64);
+        v = (src_pass == (uint32_t)k) ? got : v;
+      }
+      if (j >= best_parts) v = 0;
+      rec->rice_params[j] = (uint8_t)(ok ? v : 0u);
+    }
+  }
+  if (lane < 32) {
+    int32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i)
+      if (i == lane) c = cq[i];
+    rec->coefs[lane] = (status == 0) ? (int16_t)c : (int16_t)0;
+  }
+  if (lane == 0) {
+    rec->order = (uint8_t)warm;
+    rec->shift = (int8_t)shift;
+    rec->precision = (uint8_t)a.precision;
+    rec->rice_order = (uint8_t)(status == 0 ? rice_order : 0);
+    rec->status = status;
+    rec->code_bits = status == 0 ? best_bits : 0ull;
+    rec->subframe_bits = status == 0 ? sub_bits : 0ull;
+    rec->sum_quotients = status == 0 ? sum_q : 0ull;
+  }
+}
+
+template <typename KernelT>
+hipError_t launch_big(KernelT kern, DynamicLdsOptIn& opt_in, const QlpcKernelArgs& a, size_t smem, hipStream_t stream) {
+  if (hipError_t err = opt_in.ensure(reinterpret_cast<const void*>(kern), smem); err != hipSuccess) return err;
+  const uint32_t blocks = a.stereo ? a.n_subframes / 4u : (a.n_subframes + 3u) / 4u;
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), smem, stream, a);
+  return hipGetLastError();
+}
+
+template <int HP, int LAG0, int NL>
+hipError_t launch_acorr(const QlpcKernelArgs& a, hipStream_t stream) {
+  static DynamicLdsOptIn opt_s, opt_p;
+  const size_t part = 4 * 2 * NL * sizeof(double);
+  if (a.stereo) return launch_big(bigblock_acorr_kernel<HP, LAG0, NL, true>, opt_s, a, 2 * kBufDwords * 4 + part, stream);
+  return launch_big(bigblock_acorr_kernel<HP, LAG0, NL, false>, opt_p, a, 4 * kBufDwords * 4 + part, stream);
+}
+
+template <int MAXP, int K>
+hipError_t launch_residual(const QlpcKernelArgs& a, hipStream_t stream) {
+  static DynamicLdsOptIn opt_s, opt_p;
+  if (a.stereo) return launch_big(bigblock_residual_kernel<MAXP, true, K>, opt_s, a, 2 * kBufDwords * 4, stream);
+  return launch_big(bigblock_residual_kernel<MAXP, false, K>, opt_p, a, 4 * kBufDwords * 4, stream);
+}
+
+}  // namespace
+
+bool bigblock_eligible(const QlpcKernelArgs& a) {
+  if (a.block_size != 8192 && a.block_size != 16384) return false;
+  if (a.lpc_order < 13 || a.lpc_order > 32) return false;
+  if (a.fixed_mode != 0 || a.lpc_stage != 0 || a.force_generic) return false;
+  if (a.frame_results || a.chan_results || a.pack_out) return false;
+  if ((reinterpret_cast<uintptr_t>(a.samples) & 15) || (a.stride & 3)) return false;
+  if ((reinterpret_cast<uintptr_t>(a.residual) & 15) || (a.residual_stride & 3)) return false;
+  if (a.stereo && (a.n_subframes & 3)) return false;
+  if (a.split_scratch == nullptr) return false;
+  return true;
+}
+
+// R[] (unless `have_r`: already in `racc`, e.g. from the reference-order kernel) into racc
+hipError_t launch_bigblock_acorr(const QlpcKernelArgs& a, hipStream_t stream) {
+  if (a.lpc_order <= 24) return launch_acorr<24, 0, 25>(a, stream);
+  hipError_t err = launch_acorr<32, 0, 17>(a, stream);
+  if (err != hipSuccess) return err;
+  return launch_acorr<32, 17, 16>(a, stream);
+}
+
+hipError_t launch_bigblock_residual(const QlpcKernelArgs& a, hipStream_t stream) {
+  const bool k2 = a.block_size == 8192;
+  if (a.lpc_order <= 24) return k2 ? launch_residual<24, 2>(a, stream) : launch_residual<24, 4>(a, stream);
+  return k2 ? launch_residual<32, 2>(a, stream) : launch_residual<32, 4>(a, stream);
+}
+
+}  // namespace flacenc_hip

@@ -73,8 +73,8 @@ hipError_t launch_qlpc(const QlpcKernelArgs& a, const QlpcLaunchPlan& plan, hipS
   if ((a.frame_results || a.chan_results) && !wave_kernel_eligible(a)) return hipErrorNotSupported;
   if (a.reference_order && a.fixed_mode == 0 && a.lpc_stage == 0 && a.acorr_in == nullptr) {
     // Reference summation order: R[] by the lane-per-subframe kernel, then the usual pipeline from
-    // Levinson on -- the fused wave kernel with its phase 1 skipped, or the generic kernel's
-    // three-launch split from its second launch.
+    // Levinson on (below: the fused wave kernel with its phase 1 skipped, the big-block kernels from
+    // their second launch, or the generic kernel's three-launch split from its second launch).
     if (a.split_scratch == nullptr) return hipErrorInvalidValue;
     double* racc = a.autocorr ? a.autocorr : reinterpret_cast<double*>(a.split_scratch);
     AcorrRefArgs r{};
@@ -90,27 +90,49 @@ hipError_t launch_qlpc(const QlpcKernelArgs& a, const QlpcLaunchPlan& plan, hipS
     if (err != hipSuccess) return err;
     QlpcKernelArgs b = a;
     b.acorr_in = racc;
-    if (wave_kernel_eligible(b)) {
-      b.autocorr = nullptr;  // already written
-      return launch_qlpc(b, plan, stream);
+    b.autocorr = nullptr;  // already written
+    return launch_qlpc(b, plan, stream);
+  }
+  if (bigblock_eligible(a) || (a.acorr_in != nullptr && !wave_kernel_eligible(a) && a.lpc_stage == 0)) {
+    // R[] -> levinson_batch_kernel (one subframe per lane) -> residual + Rice search
+    if (a.split_scratch == nullptr) return hipErrorInvalidValue;
+    const bool big = bigblock_eligible(a);
+    const double* racc = a.acorr_in;
+    hipError_t err;
+    if (racc == nullptr) {
+      QlpcKernelArgs s1 = a;
+      s1.autocorr = a.autocorr ? a.autocorr : reinterpret_cast<double*>(a.split_scratch);
+      racc = s1.autocorr;
+      err = launch_bigblock_acorr(s1, stream);
+      if (err != hipSuccess) return err;
     }
-    QlpcKernelArgs s2 = b, s3 = b;
     int32_t* pred = reinterpret_cast<int32_t*>(reinterpret_cast<double*>(a.split_scratch) +
                                                 static_cast<size_t>(a.n_subframes) * 33);
-    s2.autocorr = racc;
+    QlpcKernelArgs s2 = a, s3 = a;
+    s2.autocorr = const_cast<double*>(racc);
     s2.pred_out = pred;
     s3.lpc_stage = 3;
     s3.pred = pred;
     s3.autocorr = nullptr;
     s3.lpc_coefs = nullptr;  // written by the batch kernel
-#define FLACENC_HIP_REFSPLIT(MP, BG)                                                           \
-  if (plan.maxp == MP && plan.big == (BG != 0)) {                                              \
-    err = launch_levinson_##MP##_##BG(s2, stream);                                             \
-    if (err != hipSuccess) return err;                                                         \
-    return launch_qlpc_##MP##_##BG(s3, plan.threads, plan.smem_bytes, stream);                 \
-  }
-    FLACENC_HIP_FOR_EACH_INSTANCE(FLACENC_HIP_REFSPLIT)
-#undef FLACENC_HIP_REFSPLIT
+    s3.acorr_in = nullptr;
+    err = hipErrorInvalidValue;
+#define FLACENC_HIP_LEV(MP, BG) \
+  if (plan.maxp == MP && plan.big == (BG != 0)) err = launch_levinson_##MP##_##BG(s2, stream);
+    FLACENC_HIP_FOR_EACH_INSTANCE(FLACENC_HIP_LEV)
+#undef FLACENC_HIP_LEV
+    if (err != hipSuccess) return err;
+    if (big) {
+      err = launch_bigblock_residual(s3, stream);
+      if (err != hipSuccess) return err;
+      // clean-up launch: the generic kernel redoes the subframes the big-block kernel marked (residuals
+      // of 2^26 and more need the literal chunk-clamped bit tables); every other workgroup exits at once
+      s3.only_marked = 1;
+    }
+#define FLACENC_HIP_STAGE3(MP, BG) \
+  if (plan.maxp == MP && plan.big == (BG != 0)) return launch_qlpc_##MP##_##BG(s3, plan.threads, plan.smem_bytes, stream);
+    FLACENC_HIP_FOR_EACH_INSTANCE(FLACENC_HIP_STAGE3)
+#undef FLACENC_HIP_STAGE3
     return hipErrorInvalidValue;
   }
   if (wave_kernel_eligible(a)) {

@@ -37,6 +37,7 @@ struct QlpcKernelArgs {
   // launch_qlpc runs it into split_scratch (or `autocorr`) and hands the result on as `acorr_in`
   uint32_t reference_order;
   const double* acorr_in;     // device, [n][33]: precomputed R[], skips phase 1 (wave kernel)
+  uint32_t only_marked;       // generic kernel: redo only subframes whose record says status == -1
   flacenc_hip_subframe_params* params;  // device
   int32_t* residual;                    // device
   size_t residual_stride;
@@ -94,6 +95,11 @@ QlpcLaunchPlan plan_qlpc_launch(uint32_t block_size, uint32_t lpc_order);
 // true if the wave-per-subframe kernel can take this launch (decided per call: alignment)
 bool wave_kernel_eligible(const QlpcKernelArgs& args);
 hipError_t launch_qlpc(const QlpcKernelArgs& args, const QlpcLaunchPlan& plan, hipStream_t stream);
+// blocks of 8192 / 16384 samples at order 13..32 (qlpc_bigblock.cpp): autocorrelation and residual + Rice
+// search as two pass-structured kernels either side of levinson_batch_kernel
+bool bigblock_eligible(const QlpcKernelArgs& args);
+hipError_t launch_bigblock_acorr(const QlpcKernelArgs& args, hipStream_t stream);     // R[] -> args.autocorr
+hipError_t launch_bigblock_residual(const QlpcKernelArgs& args, hipStream_t stream);  // args.pred -> records
 
 // one per (order bucket, big) instantiation, each defined by its own translation unit
 #define FLACENC_HIP_FOR_EACH_INSTANCE(X) \

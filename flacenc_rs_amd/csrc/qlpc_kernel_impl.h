@@ -335,6 +335,9 @@ qlpc_subframe_kernel(QlpcKernelArgs a) {
     const uint32_t g = sf >> 5, r = (sf >> 3) & 3u, x = sf & 7u;
     sf = ((g << 3) + x) * 4u + r;
   }
+  // clean-up launch behind the big-block kernels: only the subframes they marked (residuals of 2^26
+  // and more, whose bit tables need the literal chunk-clamped sums) are redone here
+  if (a.only_marked && a.params[sf].status != -1) return;
 
   // ---- carve LDS (every offset a multiple of 16 bytes) ----
   SmemLayout L;

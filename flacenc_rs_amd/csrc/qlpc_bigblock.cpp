@@ -13,8 +13,9 @@
 // 4096 samples (+ 64 of halo) are staged, so LDS stays at 35 KB per workgroup whatever the block size.
 // The autocorrelation sums are the canonical ones: 16-sample chunk chains, then a
 // balanced tree over the chunk index c = 256 k + 4 l + i -- chunk bits in the lane, lane bits by a wave
-// butterfly, pass bits last.  At order 25..32 one launch would need three 33-entry f64 accumulator sets
-// per lane; the lags are therefore split over two launches (0..16, 17..32), each with the full window.
+// butterfly, pass bits last.  One launch for all lags would need three 25- or 33-entry f64 accumulator
+// sets per lane next to the window; the lags are therefore worked off in groups of at most 13 (two groups
+// at order <= 24, three above), each group re-reading the lane's samples from LDS.
 // The Rice search keeps the seven bit-planes of every pass in registers, runs levels 0..6 per pass with
 // the 4096 kernel's level code and adds the levels that merge whole passes (orders 7 - level, 8 - level).
 #include <type_traits>
@@ -89,14 +90,21 @@ __device__ __forceinline__ int4 bigblock_ld4(const int32_t* bufA, const int32_t*
 }
 
 // ---------------------------------------------------------------------------------------------
-// lags LAG0 .. LAG0 + NL - 1 of R[]; HP = the order bucket (window depth)
-template <int HP, int LAG0, int NL, bool STEREO>
+// lags 0 .. NG * NL - 1 of R[] in NG groups of NL: one group's three accumulator sets (chunk chain, two
+// tree partials) and the window of 32 lagged values + 16 current ones are what a lane holds at a time;
+// the groups re-read and re-convert the lane's samples from LDS (the pass is loaded and its window
+// weights staged once)
+template <int NG, int NL, bool STEREO>
 __global__ void __launch_bounds__(256, 2) bigblock_acorr_kernel(QlpcKernelArgs a) {
-  static_assert(HP % 8 == 0 && LAG0 + NL - 1 <= HP, "window must cover the largest lag");
+  constexpr int HP = 32;
+  constexpr int NLAG = NG * NL;
+  static_assert(NLAG - 1 <= 33 && NLAG >= 25, "lag groups must cover the order bucket");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   int32_t* const sm = reinterpret_cast<int32_t*>(smem_raw);
   constexpr int NBUF = STEREO ? 2 : 4;
-  double* const part = reinterpret_cast<double*>(sm + NBUF * kBufDwords);  // [4 waves][2][NL] pass partials
+  // after the images: the window weights of the pass in the same segment layout, then the pass partials
+  float* const wlds = reinterpret_cast<float*>(sm + NBUF * kBufDwords);
+  double* const part = reinterpret_cast<double*>(sm + (NBUF + 1) * kBufDwords);  // [4 waves][2][NLAG]
   const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
   const uint32_t blk = blockIdx.x;
   uint32_t sf = blk * 4u + (uint32_t)wave;
@@ -109,100 +117,125 @@ __global__ void __launch_bounds__(256, 2) bigblock_acorr_kernel(QlpcKernelArgs a
   const int32_t* const bufB = sm + kBufDwords;
   const float* __restrict__ wtab = a.window ? a.window + 32 : nullptr;
   const int tl = lane << 6;
-  constexpr int NB = HP / 8 + 1;  // ring of 8-value blocks: HP lagged values + the current 8
 
+  auto stamp = [&](int slot) {
+    if (a.stamps && lane == 0) a.stamps[(size_t)sf * 8 + slot] = (unsigned long long)clock64();
+  };
+  stamp(0);
   for (int k = 0; k < K; ++k) {
     __syncthreads();
+    if (k == 0) stamp(1);
     bigblock_load_pass<STEREO>(a, sm, blk, k, tid, wave, lane, sf);
+    // a pass (and the 64 samples in front of it) that lies inside the window's run of exact ones needs no
+    // table: (f32)s * 1.0f == (f32)s.  Otherwise its 64 + 4096 weights are staged once for the four waves.
+    const int g0 = k * kPass - 64;
+    const bool tapered = wtab != nullptr && !(g0 >= a.flat_lo && g0 + 64 + kPass <= a.flat_hi);
+    if (tapered) {
+      for (int i = tid; i < (kPass + 64) / 4; i += 256) {
+        const int t = (i << 2) - 64;  // pass-relative
+        float4 w = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // in front of the block: the samples are 0
+        if (g0 + 64 + t >= 0) w = *reinterpret_cast<const float4*>(wtab + (g0 + 64 + t));
+        *reinterpret_cast<float4*>(&wlds[widx(t)]) = w;
+      }
+    }
+    if (k == 0) stamp(2);
     __syncthreads();
-    double p2[NL];
-    auto run = [&](auto kind_tag) {
+    if (k == 0) stamp(3);
+    double* const mine = part + wave * 2 * NLAG;
+    auto run = [&](auto kind_tag, auto tapered_tag) {
       constexpr int KIND = decltype(kind_tag)::value;
+      constexpr bool TAPERED = decltype(tapered_tag)::value;
       // x_w[t] = (f32)s[t] * w[t], one f32 rounding, then widened (lpc.rs:751-754)
-      auto conv8 = [&](double (&dst)[8], int t) {  // t pass-relative, multiple of 8, >= -HP
+      auto conv8 = [&](double* dst, int t) {  // t pass-relative, multiple of 8, >= -HP
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
           const int4 v = bigblock_ld4<KIND>(bufA, bufB, t + 4 * q);
           float4 w = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
-          const int tg = k * kPass + t + 4 * q;  // block-relative; the table has 32 zeros in front
-          if (wtab && !(tg >= a.flat_lo && tg + 4 <= a.flat_hi)) {
-            if (tg >= 0) w = *reinterpret_cast<const float4*>(wtab + tg);
-            else w = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // in front of the block: samples are 0 anyway
-          }
+          if (TAPERED) w = *reinterpret_cast<const float4*>(&wlds[widx(t + 4 * q)]);
           dst[4 * q + 0] = (double)((float)v.x * w.x);
           dst[4 * q + 1] = (double)((float)v.y * w.y);
           dst[4 * q + 2] = (double)((float)v.z * w.z);
           dst[4 * q + 3] = (double)((float)v.w * w.w);
         }
       };
-      // ring of NB blocks: step s (8 samples at tl + 8 s) lives in block s mod NB, the HP values in
-      // front of the lane in the blocks "before" block 0 -- all indices are compile-time constants
-      double ring[NB][8];
 #pragma unroll
-      for (int b = 1; b < NB; ++b) conv8(ring[b], tl - HP + 8 * (b - 1));
-      double acc[NL], s01[NL];
+      for (int g = 0; g < NG; ++g) {  // unrolled: every window index below is a compile-time constant
+        const int lag0 = g * NL;
+        // window of HP lagged values + one 16-sample chunk, slid by 16 at the end of a ROLLED chunk loop
+        // (the loop body, 16 x NL fma, stays resident in the instruction cache)
+        double dw[HP + 16];
 #pragma unroll
-      for (int s = 0; s < 8; ++s) {
-        conv8(ring[s % NB], tl + 8 * s);
+        for (int b = 0; b < HP / 8; ++b) conv8(&dw[8 * b], tl - HP + 8 * b);
+        double acc[NL], s01[NL], p2[NL];
+#pragma unroll 1
+        for (int i = 0; i < 4; ++i) {
+          conv8(&dw[HP], tl + 16 * i);
+          conv8(&dw[HP + 8], tl + 16 * i + 8);
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-          double cur = ring[s % NB][kk];
-          // common lower bound t = P for every lag (lpc.rs:542): only the block's first 32 samples
-          if (s < 4) cur = (k == 0 && tl + 8 * s + kk < P) ? 0.0 : cur;
+          for (int kk = 0; kk < 16; ++kk) {
+            double cur = dw[HP + kk];
+            // common lower bound t = P for every lag (lpc.rs:542): only the block's first 32 samples
+            cur = (k == 0 && tl + 16 * i + kk < P) ? 0.0 : cur;
 #pragma unroll
-          for (int j = 0; j < NL; ++j) {
-            const int q = 8 * s + kk - (LAG0 + j);           // position of the lagged value, relative to tl
-            const int qb = q >= 0 ? q >> 3 : -((-q + 7) >> 3);  // floor(q / 8)
-            const double lagged = ring[((qb % NB) + NB) % NB][q - 8 * qb];
-            acc[j] = ((s & 1) == 0 && kk == 0) ? __builtin_fma(cur, lagged, 0.0) : __builtin_fma(cur, lagged, acc[j]);
+            for (int j = 0; j < NL; ++j) {
+              const int idx = HP + kk - (lag0 + j);  // (lag 33 of the 3 x 11 split does not exist: idx < 0 never read)
+              const double lagged = idx >= 0 ? dw[idx >= 0 ? idx : 0] : 0.0;
+              acc[j] = kk == 0 ? __builtin_fma(cur, lagged, 0.0) : __builtin_fma(cur, lagged, acc[j]);
+            }
+          }
+          // in-lane levels of the balanced tree over the chunk index: (c0 + c1) + (c2 + c3)
+          if (i == 0) {
+#pragma unroll
+            for (int j = 0; j < NL; ++j) s01[j] = acc[j];
+          } else if (i == 1) {
+#pragma unroll
+            for (int j = 0; j < NL; ++j) s01[j] = s01[j] + acc[j];
+          } else if (i == 2) {
+#pragma unroll
+            for (int j = 0; j < NL; ++j) p2[j] = acc[j];
+          } else {
+#pragma unroll
+            for (int j = 0; j < NL; ++j) p2[j] = s01[j] + (p2[j] + acc[j]);
+          }
+#pragma unroll
+          for (int q = 0; q < HP; ++q) dw[q] = dw[q + 16];
+        }
+        // lane levels, then the pass levels: K = 2: R0 + R1; K = 4: (R0 + R1) + (R2 + R3).  Partials of
+        // earlier passes wait in LDS (only lane 0's copy matters).
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+          double r = wave_tree_sum_dpp(p2[j]);
+          const int lag = lag0 + j;
+          if (lane == 0) {
+            if ((k & 1) == 0) {
+              mine[(k >> 1 & 1) * NLAG + lag] = r;                  // R0 (or R2) waits for its partner
+            } else {
+              r = mine[(k >> 1 & 1) * NLAG + lag] + r;              // R0 + R1 (or R2 + R3)
+              if (K == 4 && k == 1) mine[lag] = r;                  // keeps waiting for (R2 + R3)
+              if (K == 4 && k == 3) r = mine[lag] + r;
+              if (k == K - 1 && active && lag < 33) a.autocorr[(size_t)sf * 33 + lag] = (lag <= P) ? r : 0.0;
+            }
           }
         }
-        // in-lane levels of the balanced tree over the chunk index: (c0 + c1) + (c2 + c3)
-        if (s == 1) {
-#pragma unroll
-          for (int j = 0; j < NL; ++j) s01[j] = acc[j];
-        } else if (s == 3) {
-#pragma unroll
-          for (int j = 0; j < NL; ++j) s01[j] = s01[j] + acc[j];
-        } else if (s == 5) {
-#pragma unroll
-          for (int j = 0; j < NL; ++j) p2[j] = acc[j];
-        } else if (s == 7) {
-#pragma unroll
-          for (int j = 0; j < NL; ++j) p2[j] = s01[j] + (p2[j] + acc[j]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
       }
     };
-    if (STEREO && role == 2) run(std::integral_constant<int, 2>{});
-    else if (STEREO && role == 3) run(std::integral_constant<int, 3>{});
-    else run(std::integral_constant<int, 0>{});
-    // lane levels, then the pass levels: K = 2: R0 + R1; K = 4: (R0 + R1) + (R2 + R3).  Partials of
-    // earlier passes wait in LDS (only lane 0's copy matters).
-    double* const mine = part + wave * 2 * NL;
-#pragma unroll
-    for (int j = 0; j < NL; ++j) {
-      double r = wave_butterfly_sum(p2[j]);
-      if (lane == 0) {
-        if ((k & 1) == 0) {
-          mine[(k >> 1 & 1) * NL + j] = r;                        // R0 (or R2) waits for its partner
-        } else {
-          r = mine[(k >> 1 & 1) * NL + j] + r;                    // R0 + R1 (or R2 + R3)
-          if (K == 4 && k == 1) mine[j] = r;                      // keeps waiting for (R2 + R3)
-          if (K == 4 && k == 3) r = mine[j] + r;
-          if (k == K - 1 && active)
-            a.autocorr[(size_t)sf * 33 + LAG0 + j] = (LAG0 + j <= P) ? r : 0.0;
-        }
-      }
-    }
+    auto run_role = [&](auto tapered_tag) {
+      if (STEREO && role == 2) run(std::integral_constant<int, 2>{}, tapered_tag);
+      else if (STEREO && role == 3) run(std::integral_constant<int, 3>{}, tapered_tag);
+      else run(std::integral_constant<int, 0>{}, tapered_tag);
+    };
+    if (tapered) run_role(std::true_type{});
+    else run_role(std::false_type{});
+    if (k == 0) stamp(4);
+    if (k == K - 1) stamp(5);
   }
-  if (lane == 0 && active && LAG0 == 0)
-    for (int j = HP + 1; j < 33; ++j) a.autocorr[(size_t)sf * 33 + j] = 0.0;
+  if (lane == 0 && active)
+    for (int j = NLAG; j < 33; ++j) a.autocorr[(size_t)sf * 33 + j] = 0.0;
 }
 
 // ---------------------------------------------------------------------------------------------
 template <int MAXP, bool STEREO, int K>
-__global__ void __launch_bounds__(256, 2) bigblock_residual_kernel(QlpcKernelArgs a) {
+__global__ void __launch_bounds__(256, 3) bigblock_residual_kernel(QlpcKernelArgs a) {
   constexpr int HP = MAXP;  // multiple of 8
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   int32_t* const sm = reinterpret_cast<int32_t*>(smem_raw);
@@ -239,21 +272,26 @@ __global__ void __launch_bounds__(256, 2) bigblock_residual_kernel(QlpcKernelArg
       // (lpc.rs:306-350, the i64 branch of :379-388 -- both branches give the same value)
       int sw[HP + 16];
       uint32_t pc[6];
+      // the HP samples in front of the lane, then a rolled loop over its four 16-sample chunks (every
+      // register array index below is a compile-time constant; the window slides at the loop's end)
 #pragma unroll
+      for (int q = 0; q < HP; q += 4) {
+        const int4 v = bigblock_ld4<KIND>(bufA, bufB, tl - HP + q);
+        sw[q + 0] = v.x;
+        sw[q + 1] = v.y;
+        sw[q + 2] = v.z;
+        sw[q + 3] = v.w;
+      }
+#pragma unroll 1
       for (int i = 0; i < 4; ++i) {
         const int t0 = tl + 16 * i;
-        asm volatile("" ::: "memory");  // keeps the next chunk's LDS reads behind this chunk's arithmetic
-        if (i > 0) {
 #pragma unroll
-          for (int q = 0; q < HP; ++q) sw[q] = sw[q + 16];
-        }
-#pragma unroll
-        for (int q = (i == 0 ? 0 : HP); q < HP + 16; q += 4) {
-          const int4 v = bigblock_ld4<KIND>(bufA, bufB, t0 - HP + q);
-          sw[q + 0] = v.x;
-          sw[q + 1] = v.y;
-          sw[q + 2] = v.z;
-          sw[q + 3] = v.w;
+        for (int q = 0; q < 16; q += 4) {
+          const int4 v = bigblock_ld4<KIND>(bufA, bufB, t0 + q);
+          sw[HP + q + 0] = v.x;
+          sw[HP + q + 1] = v.y;
+          sw[HP + q + 2] = v.z;
+          sw[HP + q + 3] = v.w;
         }
         int32_t e[16];
 #pragma unroll
@@ -263,7 +301,7 @@ __global__ void __launch_bounds__(256, 2) bigblock_residual_kernel(QlpcKernelArg
           for (int j = 0; j < MAXP; ++j) pred += (int64_t)cq[j] * (int64_t)sw[HP + q - 1 - j];
           e[q] = (int32_t)(uint32_t)(uint64_t)((int64_t)sw[HP + q] - (pred >> shift));
           // e[0 .. order') = 0 (lpc.rs:349): the block's first samples, i.e. pass 0, lane 0
-          if ((k == 0 && tl + 16 * i + q < warm) || status != 0) e[q] = 0;
+          if ((k == 0 && t0 + q < warm) || status != 0) e[q] = 0;
         }
         if (active) {
 #pragma unroll
@@ -285,7 +323,8 @@ __global__ void __launch_bounds__(256, 2) bigblock_residual_kernel(QlpcKernelArg
           planes_add<5>(pc, pb);
           planes_add<6>(planes, pc);
         }
-        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < HP; ++q) sw[q] = sw[q + 16];
       }
     };
     // (the pass loop is rolled; pl[k] is selected by a compare chain so that the planes stay in registers)
@@ -539,12 +578,12 @@ hipError_t launch_big(KernelT kern, DynamicLdsOptIn& opt_in, const QlpcKernelArg
   return hipGetLastError();
 }
 
-template <int HP, int LAG0, int NL>
+template <int NG, int NL>
 hipError_t launch_acorr(const QlpcKernelArgs& a, hipStream_t stream) {
   static DynamicLdsOptIn opt_s, opt_p;
-  const size_t part = 4 * 2 * NL * sizeof(double);
-  if (a.stereo) return launch_big(bigblock_acorr_kernel<HP, LAG0, NL, true>, opt_s, a, 2 * kBufDwords * 4 + part, stream);
-  return launch_big(bigblock_acorr_kernel<HP, LAG0, NL, false>, opt_p, a, 4 * kBufDwords * 4 + part, stream);
+  const size_t part = 4 * 2 * NG * NL * sizeof(double);
+  if (a.stereo) return launch_big(bigblock_acorr_kernel<NG, NL, true>, opt_s, a, 3 * kBufDwords * 4 + part, stream);
+  return launch_big(bigblock_acorr_kernel<NG, NL, false>, opt_p, a, 5 * kBufDwords * 4 + part, stream);
 }
 
 template <int MAXP, int K>
@@ -570,10 +609,9 @@ bool bigblock_eligible(const QlpcKernelArgs& a) {
 
 // R[] (unless `have_r`: already in `racc`, e.g. from the reference-order kernel) into racc
 hipError_t launch_bigblock_acorr(const QlpcKernelArgs& a, hipStream_t stream) {
-  if (a.lpc_order <= 24) return launch_acorr<24, 0, 25>(a, stream);
-  hipError_t err = launch_acorr<32, 0, 17>(a, stream);
-  if (err != hipSuccess) return err;
-  return launch_acorr<32, 17, 16>(a, stream);
+  // lag groups of at most 13: window (48 doubles) + three accumulator sets must fit 256 VGPRs
+  if (a.lpc_order <= 24) return launch_acorr<2, 13>(a, stream);   // lags 0..25
+  return launch_acorr<3, 11>(a, stream);                          // lags 0..32
 }
 
 hipError_t launch_bigblock_residual(const QlpcKernelArgs& a, hipStream_t stream) {

@@ -733,7 +733,7 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
     }
     // ... then the 6 lane levels
 #pragma unroll
-    for (int k = 0; k < NLAG; ++k) R[k] = wave_butterfly_sum(p2[k]);
+    for (int k = 0; k < NLAG; ++k) R[k] = wave_tree_sum_dpp(p2[k]);
   });
   // is_constant (arrayutils.rs:382): all samples of the role equal <=> max == min
   role_max = (int)(wave_max_dpp((uint32_t)vmax ^ 0x80000000u) ^ 0x80000000u);

@@ -471,6 +471,31 @@ def secondary(torch, _capi, handle, args, dev):
         "what": "FLACENC_HIP_FLAG_REFERENCE_SUM_ORDER: autocorrelation as one sequential chain per lag "
                 "(src/lpc.rs:533-548) by a lane-per-subframe kernel, then the fused kernel without its phase 1; "
                 "coefficients bit-identical to the reference's stable build", "subframe_bits_per_sample": bits_per_sample()})
+    # what the host-pointer boundary delivers end to end: packed 16-bit interleaved PCM in host memory ->
+    # FLAC frame bytes in host memory (flacenc_hip_encode_pcm_stereo: chunked, pinned staging, upload /
+    # analysis / download of neighbouring chunks overlapped).  Wall clock, PCIe both ways included.
+    host16 = np.ascontiguousarray(noisy.cpu().numpy().transpose(0, 2, 1)).astype("<i2").view(np.uint8).reshape(-1)
+    fcfg = _capi.make_frame_config(qcfg, use_fixed=False)
+    pcie = {}
+    for label, pinned in (("pageable_caller_buffers", False), ("pinned_caller_buffers", True)):
+        src = host16
+        dst = np.empty(F * (out_stride + 16), np.uint8)
+        if pinned:
+            src = _capi.pinned_array(host16.size)
+            src[:] = host16
+            dst = _capi.pinned_array(F * (out_stride + 16))
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            out_bytes, _lens = handle.encode_pcm_stereo(src, fcfg, 2, bps, n, SAMPLE_RATE, out=dst)
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        pcie[label] = {"ms": round(best * 1e3, 3), "Msamples_per_s": round(F * 2 * n / best / 1e6, 1),
+                       "host_bytes_in": int(host16.size), "host_bytes_out": int(out_bytes.size)}
+        del src, dst
+    sec["pcie_inclusive_pcm_to_frame_bytes"] = dict(
+        pcie, what="flacenc_hip_encode_pcm_stereo: host PCM (2 B/sample) -> host frame bytes, best of 3 wall-clock "
+                   "runs; never the headline value")
     del noisy
     tonal = torch.from_numpy(_capi.sigen_frames(F, 2, n, bps, 36.0, 0.4, 0.04, seed=0xF1AC0002)).to(dev)
     fcfg = _capi.make_frame_config(qcfg, use_fixed=False)

@@ -59,6 +59,9 @@ EXPORTED_SYMBOLS = (
     "flacenc_hip_pack_stereo_frames_async",
     "flacenc_hip_stereo_frame_lengths_async",
     "flacenc_hip_place_frames_async",
+    "flacenc_hip_encode_pcm_stereo",
+    "flacenc_hip_host_alloc",
+    "flacenc_hip_host_free",
     "flacenc_hip_encode_frames",
     "flacenc_hip_encode_frames_async",
     "flacenc_hip_frame_bytes_bound",
@@ -242,6 +245,14 @@ def load() -> C.CDLL:
     L.flacenc_hip_stereo_frame_lengths_async.restype = C.c_int
     L.flacenc_hip_place_frames_async.argtypes = [vp, vp, vp, vp, C.c_size_t, vp, vp, vp]
     L.flacenc_hip_place_frames_async.restype = C.c_int
+    L.flacenc_hip_encode_pcm_stereo.argtypes = [vp, C.POINTER(FrameConfig), vp, C.c_uint64, C.c_uint32, C.c_uint32,
+                                                C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_size_t, vp,
+                                                C.POINTER(C.c_uint64)]
+    L.flacenc_hip_encode_pcm_stereo.restype = C.c_int
+    L.flacenc_hip_host_alloc.argtypes = [C.c_size_t]
+    L.flacenc_hip_host_alloc.restype = C.c_void_p
+    L.flacenc_hip_host_free.argtypes = [C.c_void_p]
+    L.flacenc_hip_host_free.restype = None
     L.flacenc_hip_fill_le_bytes.argtypes = [vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_size_t, C.c_uint32, i32p,
                                             C.c_size_t, C.c_int]
     L.flacenc_hip_fill_le_bytes.restype = C.c_int
@@ -338,6 +349,34 @@ def sigen_frames(n_frames: int, channels: int, block_size: int, bits_per_sample:
     if rc != 0:
         raise FlacencHipError(rc, "flacenc_sigen_fill_frames")
     return out
+
+
+def pinned_array(nbytes: int) -> np.ndarray:
+    """uint8 array in page-locked host memory (flacenc_hip_host_alloc); keeps the allocation alive and frees it
+    with the array."""
+    lib = load()
+    p = lib.flacenc_hip_host_alloc(nbytes)
+    if not p:
+        raise MemoryError("flacenc_hip_host_alloc")
+
+    class _Owner:
+        def __init__(self, ptr):
+            self.ptr = ptr
+
+        def __del__(self):
+            try:
+                lib.flacenc_hip_host_free(self.ptr)
+            except Exception:
+                pass
+
+    buf = (C.c_uint8 * nbytes).from_address(p)
+    arr = np.frombuffer(buf, dtype=np.uint8)
+    arr.flags.writeable = True
+    _PINNED_OWNERS[arr.ctypes.data] = _Owner(p)
+    return arr
+
+
+_PINNED_OWNERS: dict = {}
 
 
 class Handle:
@@ -497,6 +536,25 @@ class Handle:
         rc = self._lib.flacenc_hip_place_frames_async(self._h, src_ptr, src_offsets_ptr, lengths_ptr, n_frames,
                                                       dst_ptr, dst_offsets_ptr, stream or None)
         self._check(rc)
+
+    def encode_pcm_stereo(self, pcm: np.ndarray, cfg: FrameConfig, bytes_per_sample: int, bits_per_sample: int,
+                          block_size: int, sample_rate: int, out: np.ndarray | None = None,
+                          first_frame_number: int = 0, frame_number_step: int = 1):
+        """Packed interleaved LE stereo PCM (uint8 array) -> (frame bytes uint8 [total], lengths uint32 [n_frames]),
+        the streaming host path (flacenc_hip_encode_pcm_stereo).  `pcm` / `out` may be pinned_array()s."""
+        assert pcm.dtype == np.uint8 and pcm.flags["C_CONTIGUOUS"]
+        total = pcm.size // (2 * bytes_per_sample)
+        n_frames = (total + block_size - 1) // block_size
+        if out is None:
+            out = np.empty(n_frames * (self.frame_bytes_bound(block_size, bits_per_sample) + 16), np.uint8)
+        lens = np.zeros(n_frames, np.uint32)
+        written = C.c_uint64(0)
+        rc = self._lib.flacenc_hip_encode_pcm_stereo(self._h, C.byref(cfg), pcm.ctypes.data, total, bytes_per_sample,
+                                                     bits_per_sample, block_size, sample_rate, first_frame_number,
+                                                     frame_number_step, out.ctypes.data, out.size, lens.ctypes.data,
+                                                     C.byref(written))
+        self._check(rc)
+        return out[: written.value], lens
 
     def fill_le_bytes(self, data: bytes, channels: int, bytes_per_sample: int, block_size: int):
         """FrameBuf::fill_le_bytes for a whole stream: packed interleaved PCM -> int32 [n_frames, channels, n]."""

@@ -42,6 +42,16 @@ struct flacenc_hip_handle {
   std::string last_error;
   std::vector<WindowEntry> windows;
   DeviceBuffer d_samples, d_residual, d_params, d_bps, d_autocorr, d_lpc, d_tables, d_keys, d_sel, d_results, d_out, d_outlen, d_cparams, d_cresid, d_fparams, d_fresid, d_fkeys, d_split, d_presid;
+  // streaming host path (flacenc_hip_encode_pcm_stereo): copy-in / copy-out streams, two slots of pinned
+  // staging and device buffers, the events that order them
+  hipStream_t s_in = nullptr, s_out = nullptr;
+  hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_fill[2] = {nullptr, nullptr}, ev_pack[2] = {nullptr, nullptr},
+             ev_d2h[2] = {nullptr, nullptr};
+  DeviceBuffer d_pcm[2], d_pack[2], d_plen[2], d_poff[2], d_cont[2];
+  void* pin_in[2] = {nullptr, nullptr};
+  void* pin_out[2] = {nullptr, nullptr};
+  void* pin_meta[2] = {nullptr, nullptr};
+  size_t pin_in_cap = 0, pin_out_cap = 0, pin_meta_cap = 0;
   unsigned long long* stamps = nullptr;  // profiling hook, see flacenc_hip_debug_set_stamps
   unsigned long long* fixed_keys = nullptr;  // test hook, see flacenc_hip_debug_set_fixed_keys
 };
@@ -500,6 +510,16 @@ void flacenc_hip_destroy(flacenc_hip_handle* h) {
                           &h->d_lpc, &h->d_tables, &h->d_keys, &h->d_sel, &h->d_results, &h->d_out, &h->d_outlen, &h->d_cparams, &h->d_cresid,
                           &h->d_fparams, &h->d_fresid, &h->d_fkeys, &h->d_split, &h->d_presid})
     if (b->ptr) (void)hipFree(b->ptr);
+  for (int i = 0; i < 2; ++i) {
+    for (DeviceBuffer* b : {&h->d_pcm[i], &h->d_pack[i], &h->d_plen[i], &h->d_poff[i], &h->d_cont[i]})
+      if (b->ptr) (void)hipFree(b->ptr);
+    for (void* p : {h->pin_in[i], h->pin_out[i], h->pin_meta[i]})
+      if (p) (void)hipHostFree(p);
+    for (hipEvent_t e : {h->ev_h2d[i], h->ev_fill[i], h->ev_pack[i], h->ev_d2h[i]})
+      if (e) (void)hipEventDestroy(e);
+  }
+  if (h->s_in) (void)hipStreamDestroy(h->s_in);
+  if (h->s_out) (void)hipStreamDestroy(h->s_out);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -1122,6 +1142,183 @@ int flacenc_hip_encode_pack_frames_async(flacenc_hip_handle* h, const flacenc_hi
                                        static_cast<const int32_t*>(h->d_presid.ptr), cstride, bits_per_sample,
                                        sample_rate, first_frame_number, frame_number_step, out, out_stride, out_len,
                                        stream);
+}
+
+void* flacenc_hip_host_alloc(size_t bytes) {
+  void* p = nullptr;
+  if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+  return p;
+}
+
+void flacenc_hip_host_free(void* p) {
+  if (p) (void)hipHostFree(p);
+}
+
+namespace {
+bool is_pinned(const void* p) {
+  hipPointerAttribute_t attr{};
+  if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+    (void)hipGetLastError();  // plain malloc memory: not an error for the caller
+    return false;
+  }
+  return attr.type == hipMemoryTypeHost;
+}
+
+int ensure_pinned(flacenc_hip_handle* h, void** slot, size_t* cap_field, size_t bytes, bool both) {
+  (void)both;
+  if (bytes <= *cap_field && slot[0] && slot[1]) return FLACENC_HIP_OK;
+  for (int i = 0; i < 2; ++i) {
+    if (slot[i]) HIP_TRY(h, hipHostFree(slot[i]));
+    slot[i] = nullptr;
+  }
+  *cap_field = 0;
+  const size_t want = bytes + bytes / 8 + 4096;
+  for (int i = 0; i < 2; ++i) HIP_TRY(h, hipHostMalloc(&slot[i], want, hipHostMallocDefault));
+  *cap_field = want;
+  return FLACENC_HIP_OK;
+}
+}  // namespace
+
+int flacenc_hip_encode_pcm_stereo(flacenc_hip_handle* h, const flacenc_hip_frame_config* cfg, const uint8_t* pcm,
+                                  uint64_t total_samples, uint32_t bytes_per_sample, uint32_t bits_per_sample,
+                                  uint32_t block_size, uint32_t sample_rate, uint32_t first_frame_number,
+                                  uint32_t frame_number_step, uint8_t* out, size_t out_capacity, uint32_t* out_len,
+                                  uint64_t* out_total) {
+  if (!h || !cfg || !out_total) return FLACENC_HIP_ERR_BAD_ARGUMENT;
+  *out_total = 0;
+  if (total_samples == 0) return FLACENC_HIP_OK;
+  if (!pcm || !out || !out_len || bytes_per_sample < 1 || bytes_per_sample > 4 ||
+      block_size < FLACENC_HIP_MIN_BLOCK_SIZE || block_size > FLACENC_HIP_MAX_BLOCK_SIZE) {
+    h->last_error = "encode_pcm_stereo: null pointer, bytes_per_sample not in 1..=4 or block_size not in 64..=32767";
+    return FLACENC_HIP_ERR_BAD_ARGUMENT;
+  }
+  const uint64_t n_full = total_samples / block_size;
+  const uint32_t tail = static_cast<uint32_t>(total_samples % block_size);
+  if (tail != 0 && tail < FLACENC_HIP_MIN_BLOCK_SIZE) {
+    h->last_error = "encode_pcm_stereo: a last block shorter than 64 samples never reaches the analysis "
+                    "(src/coding.rs:396); write it as a Verbatim frame on the host";
+    return FLACENC_HIP_ERR_UNSUPPORTED;
+  }
+  HIP_TRY(h, hipSetDevice(h->device));
+  if (!h->s_in) {
+    HIP_TRY(h, hipStreamCreateWithFlags(&h->s_in, hipStreamNonBlocking));
+    HIP_TRY(h, hipStreamCreateWithFlags(&h->s_out, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+      HIP_TRY(h, hipEventCreateWithFlags(&h->ev_h2d[i], hipEventDisableTiming));
+      HIP_TRY(h, hipEventCreateWithFlags(&h->ev_fill[i], hipEventDisableTiming));
+      HIP_TRY(h, hipEventCreateWithFlags(&h->ev_pack[i], hipEventDisableTiming));
+      HIP_TRY(h, hipEventCreateWithFlags(&h->ev_d2h[i], hipEventDisableTiming));
+    }
+  }
+  // chunks of whole frames: big enough to run the kernels at full occupancy (>= 768 workgroups),
+  // small enough that two slots of staging stay modest and the pipeline has several stages in flight
+  const size_t frame_in_bytes = static_cast<size_t>(block_size) * 2u * bytes_per_sample;
+  size_t chunk = (48u << 20) / frame_in_bytes;
+  chunk = chunk < 768 ? 768 : (chunk > 8192 ? 8192 : chunk);
+  const size_t bound = flacenc_hip_stereo_frame_bytes_bound(block_size, bits_per_sample);
+  const size_t ostride = (bound + 15) & ~static_cast<size_t>(15);
+  const bool in_pinned = is_pinned(pcm), out_pinned = is_pinned(out);
+  int rc;
+  const size_t dstride = (static_cast<size_t>(block_size) + 3) & ~static_cast<size_t>(3);
+  if (!in_pinned && (rc = ensure_pinned(h, h->pin_in, &h->pin_in_cap, chunk * frame_in_bytes, true)) != FLACENC_HIP_OK) return rc;
+  if (!out_pinned && (rc = ensure_pinned(h, h->pin_out, &h->pin_out_cap, chunk * ostride, true)) != FLACENC_HIP_OK) return rc;
+  if ((rc = ensure_pinned(h, h->pin_meta, &h->pin_meta_cap, chunk * 4 + 16, true)) != FLACENC_HIP_OK) return rc;
+  if ((rc = ensure(h, h->d_samples, chunk * 2 * dstride * 4)) != FLACENC_HIP_OK) return rc;
+  if ((rc = ensure(h, h->d_results, chunk * sizeof(flacenc_hip_stereo_frame_result))) != FLACENC_HIP_OK) return rc;
+  for (int i = 0; i < 2; ++i) {
+    if ((rc = ensure(h, h->d_pcm[i], chunk * frame_in_bytes + 16)) != FLACENC_HIP_OK) return rc;
+    if ((rc = ensure(h, h->d_pack[i], chunk * ostride)) != FLACENC_HIP_OK) return rc;
+    if ((rc = ensure(h, h->d_plen[i], chunk * 4 + 16)) != FLACENC_HIP_OK) return rc;   // lengths, then the total
+    if ((rc = ensure(h, h->d_poff[i], chunk * 16 + 16)) != FLACENC_HIP_OK) return rc;  // src + dst offsets
+    if ((rc = ensure(h, h->d_cont[i], chunk * ostride)) != FLACENC_HIP_OK) return rc;
+  }
+
+  struct Chunk {
+    uint64_t first_frame;  // index within this call
+    size_t frames;
+    uint32_t n;            // block size of its frames
+  };
+  std::vector<Chunk> chunks;
+  for (uint64_t f = 0; f < n_full; f += chunk)
+    chunks.push_back({f, static_cast<size_t>(n_full - f < chunk ? n_full - f : chunk), block_size});
+  if (tail) chunks.push_back({n_full, 1, tail});
+
+  uint64_t written = 0;
+  // drain: wait for a chunk's lengths, then copy exactly its bytes out (contiguous on the device already)
+  auto drain = [&](size_t ci) -> int {
+    const Chunk& c = chunks[ci];
+    const int s = static_cast<int>(ci & 1);
+    HIP_TRY(h, hipEventSynchronize(h->ev_pack[s]));  // lengths + total are in pin_meta[s]
+    const uint32_t* lens = static_cast<const uint32_t*>(h->pin_meta[s]);
+    uint64_t bytes = 0;
+    for (size_t f = 0; f < c.frames; ++f) bytes += lens[f];
+    if (written + bytes > out_capacity) {
+      h->last_error = "encode_pcm_stereo: out_capacity too small";
+      return FLACENC_HIP_ERR_BAD_ARGUMENT;
+    }
+    std::memcpy(out_len + c.first_frame, lens, c.frames * 4);
+    if (out_pinned) {
+      HIP_TRY(h, hipMemcpyAsync(out + written, h->d_cont[s].ptr, bytes, hipMemcpyDeviceToHost, h->s_out));
+      HIP_TRY(h, hipEventRecord(h->ev_d2h[s], h->s_out));
+    } else {
+      HIP_TRY(h, hipMemcpyAsync(h->pin_out[s], h->d_cont[s].ptr, bytes, hipMemcpyDeviceToHost, h->s_out));
+      HIP_TRY(h, hipEventRecord(h->ev_d2h[s], h->s_out));
+      HIP_TRY(h, hipEventSynchronize(h->ev_d2h[s]));
+      std::memcpy(out + written, h->pin_out[s], bytes);
+    }
+    written += bytes;
+    return FLACENC_HIP_OK;
+  };
+
+  for (size_t ci = 0; ci < chunks.size(); ++ci) {
+    const Chunk& c = chunks[ci];
+    const int s = static_cast<int>(ci & 1);
+    const size_t in_bytes = c.frames * static_cast<size_t>(c.n) * 2u * bytes_per_sample;
+    const uint8_t* src = pcm + c.first_frame * frame_in_bytes;
+    // 1. host -> device: packed PCM (2..3 bytes per sample instead of 4)
+    if (ci >= 2) HIP_TRY(h, hipStreamWaitEvent(h->s_in, h->ev_fill[s], 0));  // d_pcm[s] has been consumed
+    if (in_pinned) {
+      HIP_TRY(h, hipMemcpyAsync(h->d_pcm[s].ptr, src, in_bytes, hipMemcpyHostToDevice, h->s_in));
+    } else {
+      if (ci >= 2) HIP_TRY(h, hipEventSynchronize(h->ev_h2d[s]));  // pin_in[s] has been sent
+      std::memcpy(h->pin_in[s], src, in_bytes);
+      HIP_TRY(h, hipMemcpyAsync(h->d_pcm[s].ptr, h->pin_in[s], in_bytes, hipMemcpyHostToDevice, h->s_in));
+    }
+    HIP_TRY(h, hipEventRecord(h->ev_h2d[s], h->s_in));
+    // 2. compute stream: widen + de-interleave, analyse + decide + Frame::write, compact
+    HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_h2d[s], 0));
+    const size_t cstride = (static_cast<size_t>(c.n) + 3) & ~static_cast<size_t>(3);
+    rc = flacenc_hip_fill_le_bytes_async(h, static_cast<const uint8_t*>(h->d_pcm[s].ptr),
+                                         static_cast<uint64_t>(c.frames) * c.n, 2, bytes_per_sample, c.frames, c.n,
+                                         static_cast<int32_t*>(h->d_samples.ptr), cstride, h->stream);
+    if (rc != FLACENC_HIP_OK) return rc;
+    HIP_TRY(h, hipEventRecord(h->ev_fill[s], h->stream));
+    if (ci >= 2) HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_d2h[s], 0));  // d_cont[s] has been copied out
+    const size_t cbound = (flacenc_hip_stereo_frame_bytes_bound(c.n, bits_per_sample) + 15) & ~static_cast<size_t>(15);
+    uint32_t* dlen = static_cast<uint32_t*>(h->d_plen[s].ptr);
+    rc = flacenc_hip_encode_pack_stereo_frames_async(
+        h, cfg, static_cast<const int32_t*>(h->d_samples.ptr), c.frames, c.n, cstride, bits_per_sample, sample_rate,
+        first_frame_number + static_cast<uint32_t>(c.first_frame) * frame_number_step, frame_number_step,
+        static_cast<flacenc_hip_stereo_frame_result*>(h->d_results.ptr), static_cast<uint8_t*>(h->d_pack[s].ptr), cbound,
+        dlen, h->stream);
+    if (rc != FLACENC_HIP_OK) return rc;
+    uint64_t* soff = static_cast<uint64_t*>(h->d_poff[s].ptr);
+    uint64_t* doff = soff + c.frames;
+    uint64_t* dtotal = reinterpret_cast<uint64_t*>(dlen + ((c.frames + 1) & ~static_cast<size_t>(1)));
+    HIP_TRY(h, flacenc_hip::launch_frame_offsets(dlen, static_cast<uint32_t>(c.frames), cbound, soff, doff, dtotal, h->stream));
+    HIP_TRY(h, flacenc_hip::launch_place_frames(static_cast<const uint8_t*>(h->d_pack[s].ptr), soff, dlen,
+                                                static_cast<uint8_t*>(h->d_cont[s].ptr), doff,
+                                                static_cast<uint32_t>(c.frames), h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->pin_meta[s], dlen, c.frames * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipEventRecord(h->ev_pack[s], h->stream));
+    // 3. while this chunk runs, hand the previous one to the caller
+    if (ci >= 1 && (rc = drain(ci - 1)) != FLACENC_HIP_OK) return rc;
+  }
+  if ((rc = drain(chunks.size() - 1)) != FLACENC_HIP_OK) return rc;
+  HIP_TRY(h, hipStreamSynchronize(h->s_out));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  *out_total = written;
+  return FLACENC_HIP_OK;
 }
 
 int flacenc_hip_synchronize(flacenc_hip_handle* h) {

@@ -411,6 +411,47 @@ hipError_t launch_place_frames(const uint8_t* src, const uint64_t* src_offsets, 
   return hipGetLastError();
 }
 
+__global__ __launch_bounds__(1024) void frame_offsets_kernel(const uint32_t* __restrict__ lengths, uint32_t n,
+                                                             unsigned long long src_stride,
+                                                             uint64_t* __restrict__ src_offsets,
+                                                             uint64_t* __restrict__ dst_offsets,
+                                                             uint64_t* __restrict__ total) {
+  __shared__ unsigned long long wave_sums[16];
+  __shared__ unsigned long long carry;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < n; base += 1024u) {
+    const uint32_t f = base + tid;
+    const unsigned long long v = f < n ? lengths[f] : 0ull;
+    unsigned long long s = v;  // inclusive scan inside the wave
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const unsigned long long o = __shfl_up(s, d, 64);
+      if ((int)lane >= d) s += o;
+    }
+    if (lane == 63) wave_sums[wave] = s;
+    __syncthreads();
+    unsigned long long before = carry;
+    for (uint32_t w = 0; w < wave; ++w) before += wave_sums[w];
+    if (f < n) {
+      src_offsets[f] = (unsigned long long)f * src_stride;
+      dst_offsets[f] = before + s - v;
+    }
+    __syncthreads();
+    if (tid == 1023) carry = before + s;
+    __syncthreads();
+  }
+  if (tid == 0) total[0] = carry;
+}
+
+hipError_t launch_frame_offsets(const uint32_t* lengths, uint32_t n_frames, size_t src_stride, uint64_t* src_offsets,
+                                uint64_t* dst_offsets, uint64_t* total, hipStream_t stream) {
+  hipLaunchKernelGGL(frame_offsets_kernel, dim3(1), dim3(1024), 0, stream, lengths, n_frames,
+                     static_cast<unsigned long long>(src_stride), src_offsets, dst_offsets, total);
+  return hipGetLastError();
+}
+
 size_t stereo_frame_bytes_bound(uint32_t block_size, uint32_t bits_per_sample) {
   // header <= 4 + 6 (frame number < 2^31) + 2 + 2 + 1, two subframes of at most Verbatim size
   // (encode_subframe never keeps anything larger, coding.rs:413-416), CRC-16

@@ -54,5 +54,10 @@ hipError_t launch_fill_le_bytes(const uint8_t* bytes, uint32_t channels, uint32_
 hipError_t launch_place_frames(const uint8_t* src, const uint64_t* src_offsets, const uint32_t* lengths,
                                uint8_t* dst, const uint64_t* dst_offsets, uint32_t n_frames, hipStream_t stream);
 
+// compaction plan of one chunk of packed frames: src_offsets[f] = f * src_stride, dst_offsets[f] = exclusive
+// prefix sum of lengths (+ base), total[0] = sum of lengths.  One workgroup; n_frames <= 65535.
+hipError_t launch_frame_offsets(const uint32_t* lengths, uint32_t n_frames, size_t src_stride, uint64_t* src_offsets,
+                                uint64_t* dst_offsets, uint64_t* total, hipStream_t stream);
+
 }  // namespace flacenc_hip
 #endif

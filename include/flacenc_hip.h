@@ -440,6 +440,34 @@ int flacenc_hip_fill_le_bytes_async(flacenc_hip_handle* h, const uint8_t* bytes,
                                     uint32_t channels, uint32_t bytes_per_sample, size_t n_frames,
                                     uint32_t block_size, int32_t* frames, size_t stride, void* stream);
 
+/* ---- host-memory streaming path: what a drop-in under encode_with_fixed_block_size experiences ---- */
+/*
+ * Packed interleaved little-endian 2-channel PCM in host memory -> FLAC frame bytes in host memory, for a
+ * whole stream (or a long run of it) in one call: the feed loop of the reference's par-mode encoder
+ * (src/par.rs:288-325: fill a FrameBuf, hand it to a worker, collect the frame) with the GPU as the
+ * worker pool.  The run is cut into chunks of whole frames; per chunk the packed PCM (2..3 bytes per sample
+ * instead of 4) goes host -> device through pinned staging on a copy stream, flacenc_hip_fill_le_bytes +
+ * flacenc_hip_encode_pack_stereo_frames run on the compute stream, the frames are compacted on the device
+ * (flacenc_hip_place_frames) and exactly their bytes come back on a second copy stream -- two slots, so the
+ * upload of chunk k + 1, the analysis of chunk k and the download of chunk k - 1 overlap.
+ *   pcm            total_samples inter-channel samples, bytes_per_sample each, L R L R ...
+ *   block_size     every frame has block_size samples except the last (total_samples % block_size, which
+ *                  must be 0 or >= 64: shorter blocks never reach the analysis, src/coding.rs:396)
+ *   out/out_len    frames back to back in frame order (what the stream writer appends after the
+ *                  metadata blocks) and each frame's byte length; out_total = bytes written
+ * `pcm` / `out` may be ordinary (pageable) memory -- then they are staged through the handle's pinned
+ * buffers with a host memcpy -- or memory from flacenc_hip_host_alloc, which is transferred directly.
+ * The MD5 of the input and STREAMINFO stay with the caller (src/source.rs:406-428).
+ */
+int flacenc_hip_encode_pcm_stereo(flacenc_hip_handle* h, const flacenc_hip_frame_config* cfg, const uint8_t* pcm,
+                                  uint64_t total_samples, uint32_t bytes_per_sample, uint32_t bits_per_sample,
+                                  uint32_t block_size, uint32_t sample_rate, uint32_t first_frame_number,
+                                  uint32_t frame_number_step, uint8_t* out, size_t out_capacity, uint32_t* out_len,
+                                  uint64_t* out_total);
+/* page-locked host memory for the call above (NULL on failure) */
+void* flacenc_hip_host_alloc(size_t bytes);
+void flacenc_hip_host_free(void* p);
+
 int flacenc_hip_synchronize(flacenc_hip_handle* h);
 
 /* Test hook (no reference counterpart): when `device_keys` is non-NULL, launches with use_fixed

@@ -1,0 +1,88 @@
+"""flacenc_hip_encode_pcm_stereo: packed interleaved PCM in host memory -> FLAC frame bytes in host memory,
+chunked and double-buffered over two copy streams.  The bytes must be exactly what the one-call device path
+(and therefore the oracle's controller + bit writer, see test_gpu_parity.py) produces for the same frames,
+whatever the chunking, for pageable and for page-locked caller buffers, with a short last block, with 16-
+and 24-bit samples, and with frame numbers dealt round-robin (first / step)."""
+import numpy as np
+import pytest
+
+import flac_parse
+from flacenc_rs_amd import _capi
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def handle():
+    h = _capi.Handle(0)
+    yield h
+    h.close()
+
+
+def pack_pcm(frames_i32, bytes_per_sample):
+    """int32 [F, 2, n] (+ optional tail [2, m]) -> interleaved little-endian bytes"""
+    inter = np.ascontiguousarray(frames_i32.transpose(0, 2, 1)).reshape(-1, 2)  # [F*n, 2]
+    raw = inter.astype("<i4").view(np.uint8).reshape(-1, 2, 4)[:, :, :bytes_per_sample]
+    return np.ascontiguousarray(raw).reshape(-1)
+
+
+def reference_bytes(handle, frames, bps, cfg, rate, first=0, step=1):
+    res, resid = handle.encode_stereo_frames(frames, bps, cfg)
+    return handle.pack_stereo_frames(frames, res, resid, bps, rate, first, step)
+
+
+@pytest.mark.parametrize("bps,bytes_ps,n,F,use_fixed", [(16, 2, 4096, 9, True), (16, 2, 4096, 1700, False),
+                                                        (24, 3, 4096, 5, True), (16, 2, 1152, 40, True),
+                                                        (24, 3, 8192, 6, False)])
+def test_stream_bytes_equal_the_one_call_path(handle, bps, bytes_ps, n, F, use_fixed):
+    frames = _capi.sigen_frames(F, 2, n, bps, 50.0, 0.3, 0.05, seed=1234 + n + F, nthreads=4)
+    cfg = _capi.make_frame_config(_capi.make_config(lpc_order=8 if n == 4096 else 12), use_fixed=use_fixed)
+    pcm = pack_pcm(frames, bytes_ps)
+    out, lens = handle.encode_pcm_stereo(pcm, cfg, bytes_ps, bps, n, 44100)
+    want = reference_bytes(handle, frames[: min(F, 64)], bps, cfg, 44100)
+    assert lens[: len(want)].tolist() == [len(b) for b in want]
+    pos = 0
+    for f, b in enumerate(want):
+        assert out[pos:pos + len(b)].tobytes() == b, f
+        pos += len(b)
+    assert int(lens.astype(np.int64).sum()) == out.size
+    # every frame of the stream parses (sync, both CRCs) with its number, and decodes to the input
+    pos = 0
+    for f in list(range(min(F, 3))) + ([F - 1] if F > 3 else []):
+        start = int(lens[:f].astype(np.int64).sum())
+        fr = flac_parse.parse_frame(out[start:start + int(lens[f])].tobytes(), stream_bps=bps, stream_rate=44100)
+        assert fr["number"] == f and np.array_equal(fr["channels"], frames[f])
+
+
+def test_short_last_block_and_round_robin_numbers(handle):
+    n, bps = 4096, 16
+    frames = _capi.sigen_frames(5, 2, n, bps, 36.0, 0.4, 0.04, seed=77, nthreads=2)
+    tail = frames[4][:, :1000]
+    cfg = _capi.make_frame_config(_capi.make_config(lpc_order=10), use_fixed=True)
+    pcm = np.concatenate([pack_pcm(frames[:4], 2), pack_pcm(tail[None], 2)])
+    out, lens = handle.encode_pcm_stereo(pcm, cfg, 2, bps, n, 48000, first_frame_number=3, frame_number_step=8)
+    assert lens.size == 5
+    want = reference_bytes(handle, frames[:4], bps, cfg, 48000, 3, 8) + reference_bytes(handle, np.ascontiguousarray(tail[None]), bps, cfg, 48000, 3 + 4 * 8, 8)
+    assert out.tobytes() == b"".join(want)
+    last = flac_parse.parse_frame(want[-1], stream_bps=bps, stream_rate=48000)
+    assert last["number"] == 35 and last["block_size"] == 1000 and np.array_equal(last["channels"], tail)
+    # a tail shorter than 64 samples is the caller's (Verbatim on the host, coding.rs:396)
+    with pytest.raises(_capi.FlacencHipError) as ei:
+        handle.encode_pcm_stereo(pcm[: (4096 * 4 + 10) * 4], cfg, 2, bps, n, 48000)
+    assert ei.value.code == _capi.ERR_UNSUPPORTED
+
+
+def test_pinned_buffers_give_identical_bytes(handle):
+    n, bps, F = 4096, 16, 1100   # more than one chunk
+    frames = _capi.sigen_frames(F, 2, n, bps, 200.0, 0.4, 0.4, seed=5, nthreads=4)
+    cfg = _capi.make_frame_config(_capi.make_config(lpc_order=8), use_fixed=False)
+    pcm = pack_pcm(frames, 2)
+    out_a, lens_a = handle.encode_pcm_stereo(pcm, cfg, 2, bps, n, 44100)
+    pin_in = _capi.pinned_array(pcm.size)
+    pin_in[:] = pcm
+    pin_out = _capi.pinned_array(F * (handle.frame_bytes_bound(n, bps) + 16))
+    out_b, lens_b = handle.encode_pcm_stereo(pin_in, cfg, 2, bps, n, 44100, out=pin_out)
+    assert np.array_equal(lens_a, lens_b) and out_a.tobytes() == out_b.tobytes()
+    # twice through the same handle (staging buffers reused)
+    out_c, lens_c = handle.encode_pcm_stereo(pcm, cfg, 2, bps, n, 44100)
+    assert out_c.tobytes() == out_a.tobytes()

@@ -149,7 +149,7 @@ def make_frame_config(qlpc: QlpcConfig | None = None, use_constant=True, use_fix
 
 # flacenc_hip_channel_result (368 bytes): one channel of an Independent(n) frame
 CHANNEL_RESULT_DTYPE = np.dtype(
-    [("kind", np.uint8), ("pad", np.uint8, (3,)), ("dc_offset", np.int32), ("bits", np.uint64),
+    [("kind", np.uint8), ("analysis_status", np.uint8), ("pad", np.uint8, (2,)), ("dc_offset", np.int32), ("bits", np.uint64),
      ("params", PARAMS_DTYPE)], align=False)
 assert CHANNEL_RESULT_DTYPE.itemsize == 368
 
@@ -159,7 +159,8 @@ FRAME_RESULT_DTYPE = np.dtype(
         ("channel_assignment", np.uint8),
         ("kind", np.uint8, (2,)),
         ("role", np.uint8, (2,)),
-        ("pad", np.uint8, (3,)),
+        ("analysis_status", np.uint8),
+        ("pad", np.uint8, (2,)),
         ("dc_offset", np.int32, (2,)),
         ("bits", np.uint64, (4,)),
         ("lpc", PARAMS_DTYPE, (2,)),

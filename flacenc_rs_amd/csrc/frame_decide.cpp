@@ -16,7 +16,7 @@ constexpr int kThreads = 256;
 __global__ void __launch_bounds__(kThreads) frame_decide_kernel(FrameDecideArgs a) {
   __shared__ int smin[4][kThreads / 64], smax[4][kThreads / 64];
   __shared__ unsigned long long sbits[4];
-  __shared__ uint32_t skind[4];
+  __shared__ uint32_t skind[4], sstatus[4];
   __shared__ int sdc[4];
   __shared__ uint32_t schoice[3];  // assignment, role0, role1
   const int tid = threadIdx.x;
@@ -85,6 +85,7 @@ __global__ void __launch_bounds__(kThreads) frame_decide_kernel(FrameDecideArgs 
     skind[role] = kind;
     sbits[role] = bits;
     sdc[role] = lo;
+    sstatus[role] = (a.use_lpc && a.lpc_params) ? (uint32_t)a.lpc_params[sf].status : 0u;
   }
   __syncthreads();
   if (tid == 0) {
@@ -108,7 +109,9 @@ __global__ void __launch_bounds__(kThreads) frame_decide_kernel(FrameDecideArgs 
     schoice[2] = (assignment == 0 || assignment == 2) ? 1u : 3u;
     flacenc_hip_stereo_frame_result* fr = a.results + f;
     fr->channel_assignment = (uint8_t)assignment;
-    fr->pad[0] = fr->pad[1] = fr->pad[2] = 0;
+    // analysis status of the four LPC candidates (the reference panics on these, lpc.rs:646 / :786-799)
+    fr->analysis_status = (uint8_t)(sstatus[0] | sstatus[1] | sstatus[2] | sstatus[3]);
+    fr->pad[0] = fr->pad[1] = 0;
     for (int c = 0; c < 2; ++c) {
       const uint32_t role = schoice[1 + c];
       fr->role[c] = (uint8_t)role;
@@ -195,7 +198,8 @@ __global__ void __launch_bounds__(kThreads) channel_decide_kernel(ChannelDecideA
     }
     skind = kind;
     out->kind = (uint8_t)kind;
-    out->pad[0] = out->pad[1] = out->pad[2] = 0;
+    out->analysis_status = (uint8_t)((a.use_lpc && a.lpc_params) ? a.lpc_params[sf].status : 0);
+    out->pad[0] = out->pad[1] = 0;
     out->dc_offset = kind == FLACENC_HIP_KIND_CONSTANT ? lo : 0;
     out->bits = bits;
   }

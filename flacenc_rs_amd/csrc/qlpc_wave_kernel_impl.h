@@ -1257,7 +1257,8 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
       flacenc_hip_channel_result* out = a.chan_results + sf;
       if (lane == 0) {
         out->kind = (uint8_t)kind;
-        out->pad[0] = out->pad[1] = out->pad[2] = 0;
+        out->analysis_status = (uint8_t)status;
+        out->pad[0] = out->pad[1] = 0;
         out->dc_offset = kind == 0u ? role_max : 0;
         out->bits = bits;
       }
@@ -1273,7 +1274,7 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
     unsigned long long* const xb = reinterpret_cast<unsigned long long*>(sm + NIMG * kBufDwords);
     if (lane == 0) {
       xb[wave] = bits;
-      xb[4 + wave] = ((unsigned long long)kind << 32) | (unsigned long long)(uint32_t)role_max;
+      xb[4 + wave] = ((unsigned long long)(kind | ((uint32_t)status << 8)) << 32) | (unsigned long long)(uint32_t)role_max;
     }
     __syncthreads();  // also: every wave is done reading the channel images
     const unsigned long long bl = xb[0], br = xb[1], bm = xb[2], bs = xb[3];
@@ -1301,12 +1302,14 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
       fr->channel_assignment = (uint8_t)assignment;
       fr->role[0] = (uint8_t)role0;
       fr->role[1] = (uint8_t)role1;
-      fr->pad[0] = fr->pad[1] = fr->pad[2] = 0;
+      // the four analyses' status bits (non-zero where the reference panics, lpc.rs:646 / :786-799)
+      fr->analysis_status = (uint8_t)(((xb[4] | xb[5] | xb[6] | xb[7]) >> 40) & 0xFFu);
+      fr->pad[0] = fr->pad[1] = 0;
       const unsigned long long k0 = xb[4 + role0], k1 = xb[4 + role1];
-      fr->kind[0] = (uint8_t)(k0 >> 32);
-      fr->kind[1] = (uint8_t)(k1 >> 32);
-      fr->dc_offset[0] = (k0 >> 32) == 0 ? (int32_t)(uint32_t)k0 : 0;
-      fr->dc_offset[1] = (k1 >> 32) == 0 ? (int32_t)(uint32_t)k1 : 0;
+      fr->kind[0] = (uint8_t)((k0 >> 32) & 0xFFu);
+      fr->kind[1] = (uint8_t)((k1 >> 32) & 0xFFu);
+      fr->dc_offset[0] = ((k0 >> 32) & 0xFFu) == 0 ? (int32_t)(uint32_t)k0 : 0;
+      fr->dc_offset[1] = ((k1 >> 32) & 0xFFu) == 0 ? (int32_t)(uint32_t)k1 : 0;
       fr->bits[0] = bl;
       fr->bits[1] = br;
       fr->bits[2] = bm;

@@ -642,6 +642,10 @@ inline std::vector<component::Frame> encode_frame_run(const config::Encoder& con
         if (prc != FLACENC_HIP_OK && prc != FLACENC_HIP_ERR_UNSUPPORTED)
           throw error::EncodeError(error::EncodeError::Device, flacenc_hip_last_error(gpu.get()));
         for (size_t f = 0; f < nf; ++f) {
+          // the reference panics where an analysis saw a non-finite or negative-energy autocorrelation
+          // (lpc.rs:646, :786-799); the GPU reports it per frame instead
+          if (fr[f].analysis_status != FLACENC_HIP_SUBFRAME_OK)
+            throw std::runtime_error("LPC analysis reported a non-finite result (lpc.rs:786)");
           const source::FrameBuf& fb = *bufs[f0 + f];
           const int32_t* l = fb.channel_slice(0);
           const int32_t* r = fb.channel_slice(1);
@@ -720,6 +724,8 @@ inline std::vector<component::Frame> encode_frame_run(const config::Encoder& con
           frame.block_size = n;
           for (size_t c = 0; c < nch; ++c) {
             const flacenc_hip_channel_result& r = cr[f * nch + c];
+            if (r.analysis_status != FLACENC_HIP_SUBFRAME_OK)
+              throw std::runtime_error("LPC analysis reported a non-finite result (lpc.rs:786)");
             const int32_t* sig = bufs[f0 + f]->channel_slice(c);
             const uint8_t b = static_cast<uint8_t>(bps);
             if (r.kind == FLACENC_HIP_KIND_CONSTANT) {

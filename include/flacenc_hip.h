@@ -247,7 +247,10 @@ typedef struct flacenc_hip_stereo_frame_result {
   uint8_t channel_assignment;
   uint8_t kind[2];
   uint8_t role[2];
-  uint8_t pad[3];
+  uint8_t analysis_status; /* OR of the FLACENC_HIP_SUBFRAME_* bits of the four LPC analyses (L, R, M, S): non-zero
+                              where the reference panics (lpc.rs:646, :786-799); the frame is still valid FLAC --
+                              the affected candidate was dropped -- but a drop-in should raise */
+  uint8_t pad[2];
   int32_t dc_offset[2];
   uint64_t bits[4];
   flacenc_hip_subframe_params lpc[2];
@@ -267,6 +270,10 @@ typedef struct flacenc_hip_stereo_frame_result {
  * leave the CU); every other shape (any block size 64..32767, any order, any partition count) runs
  * the candidate batches into handle scratch followed by a controller kernel -- same outputs.
  */
+/* Precondition (the reference checks it in FrameBuf::verify_samples, src/source.rs:262-275, before the path
+ * is reached): every sample lies in [-2^(bits_per_sample-1), 2^(bits_per_sample-1)).  The frame entry points
+ * do not re-check it; out-of-range samples give frames whose warm-up / Verbatim fields are truncated to
+ * bits_per_sample bits. */
 int flacenc_hip_encode_stereo_frames(flacenc_hip_handle* h, const flacenc_hip_frame_config* cfg,
                                      const int32_t* frames, size_t n_frames, uint32_t block_size,
                                      size_t stride, uint32_t bits_per_sample,
@@ -347,7 +354,8 @@ int flacenc_hip_pack_stereo_frames_async(flacenc_hip_handle* h, const int32_t* f
  * value, SubFrame::count_bits and the predictor record when kind == LPC or FIXED.  368 bytes. */
 typedef struct flacenc_hip_channel_result {
   uint8_t kind; /* FLACENC_HIP_KIND_* */
-  uint8_t pad[3];
+  uint8_t analysis_status; /* FLACENC_HIP_SUBFRAME_* bits of this channel's LPC analysis (see above) */
+  uint8_t pad[2];
   int32_t dc_offset;
   uint64_t bits;
   flacenc_hip_subframe_params params;

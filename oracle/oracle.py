@@ -136,7 +136,8 @@ FRAME_RESULT_DTYPE = np.dtype(
         ("channel_assignment", np.uint8),
         ("kind", np.uint8, (2,)),
         ("role", np.uint8, (2,)),
-        ("pad", np.uint8, (3,)),
+        ("analysis_status", np.uint8),
+        ("pad", np.uint8, (2,)),
         ("dc_offset", np.int32, (2,)),
         ("bits", np.uint64, (4,)),
         ("lpc", RECORD_DTYPE, (2,)),

@@ -96,7 +96,8 @@ pub struct StereoFrameResult {
     pub channel_assignment: u8, // 0 Independent(2), 1 LeftSide, 2 RightSide, 3 MidSide
     pub kind: [u8; 2],          // 0 Constant, 1 Verbatim, 2 FixedLpc, 3 Lpc
     pub role: [u8; 2],          // 0 L, 1 R, 2 M, 3 S
-    pub pad: [u8; 3],
+    pub analysis_status: u8,    // OR of the four analyses' status bits: non-zero where the crate panics (lpc.rs:646, :786)
+    pub pad: [u8; 2],
     pub dc_offset: [i32; 2],
     pub bits: [u64; 4],
     pub lpc: [SubframeParams; 2],
@@ -118,6 +119,15 @@ extern "C" {
         residual: *mut i32, residual_stride: usize, autocorr: *mut f64, lpc_coefs: *mut f64,
         memory_kind: c_int,
     ) -> c_int;
+    /// Packed interleaved LE stereo PCM in host memory -> FLAC frame bytes in host memory (chunked, pinned
+    /// staging, copies overlapped with the analysis): the call `encode_with_fixed_block_size` makes per run.
+    pub fn flacenc_hip_encode_pcm_stereo(
+        h: *mut Handle, cfg: *const FrameConfig, pcm: *const u8, total_samples: u64, bytes_per_sample: u32,
+        bits_per_sample: u32, block_size: u32, sample_rate: u32, first_frame_number: u32, frame_number_step: u32,
+        out: *mut u8, out_capacity: usize, out_len: *mut u32, out_total: *mut u64,
+    ) -> c_int;
+    pub fn flacenc_hip_host_alloc(bytes: usize) -> *mut core::ffi::c_void;
+    pub fn flacenc_hip_host_free(p: *mut core::ffi::c_void);
     pub fn flacenc_hip_stereo_qlpc_batch(
         h: *mut Handle, cfg: *const QlpcConfig, frames: *const i32, n_frames: usize,
         block_size: u32, stride: usize, bits_per_sample: u32, params: *mut SubframeParams,

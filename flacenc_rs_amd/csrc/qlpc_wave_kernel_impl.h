@@ -37,13 +37,15 @@ namespace {
 // waves per SIMD the register allocator must leave room for: 3 workgroups per CU is what the
 // stereo LDS footprint (2 images + window) allows; plain mode (4 images) is LDS-bound earlier
 #ifndef FLACENC_WAVE_OCC
-// 3 where the instance fits 168 VGPRs with nothing of its common path in scratch (checked with
-// tools/kernel_resources.py and the Spill / Reload comments of tools/asm_variant.sh's output): the
-// order-8 deciding kernel (the bench workload; 8 dwords spilled, all of them around the out-of-line call
-// of the rare literal Rice search) and the 4-candidate stereo kernel up to order 10.  Measured on the
-// bench workload, same box, alternating runs: 0.313 -> 0.275 ms median for the deciding kernel.
-#if defined(FLACENC_STEREO) && defined(FLACENC_MAXP) && \
-    ((FLACENC_STEREO == 1 && FLACENC_MAXP <= 10) || (FLACENC_STEREO == 2 && FLACENC_MAXP <= 8))
+// 3 where the instance fits 168 VGPRs with (next to) nothing of its common path in scratch -- checked with
+// tools/kernel_resources.py and the Spill / Reload comments of tools/asm_variant.sh's output, then measured
+// (same box, alternating runs, 24576 frames): the stereo kernels up to order 10, with and without the
+// on-device decision and the fixed-LPC candidate.  What is still spilled there sits around the out-of-line
+// call of the rare literal Rice search and in the decision tail.  Order 8: deciding kernel 0.313 -> 0.275 ms
+// per 8192 frames, with the fixed-LPC candidate 0.446 -> 0.380 ms.  The fused bit writer (PACK), the
+// independent-channel kernel and order 12 spill in their inner loops at 168 registers and stay at 2.
+#if defined(FLACENC_STEREO) && defined(FLACENC_MAXP) && FLACENC_MAXP <= 10 && \
+    (FLACENC_STEREO == 1 || FLACENC_STEREO == 2 || FLACENC_STEREO == 3)
 #define FLACENC_WAVE_OCC 3
 #else
 #define FLACENC_WAVE_OCC 2
@@ -563,6 +565,9 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
   }
   // (inactive tail waves of plain mode stay for the workgroup barriers and write nothing)
   if (a.stamps && lane == 0) a.stamps[(size_t)sf * 8 + 1] = (unsigned long long)clock64();
+#if defined(FLACENC_EXIT_AFTER) && FLACENC_EXIT_AFTER == 0
+  return;  // diagnostic build: dynamic instruction count of the load phase alone (tools/phase_insts.sh)
+#endif
 
   const int32_t* const bufA = sm + (STEREO ? (role == 1 ? 1 : 0) : wave) * kBufDwords;
   const int32_t* const bufB = sm + kBufDwords;  // right channel (stereo roles 2, 3)
@@ -594,12 +599,15 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
     else f(std::integral_constant<int, 0>{});
   };
 
-  const int tl = lane << 6;  // first sample of this lane
+  int tl = lane << 6;  // first sample of this lane (made opaque again at the top of the candidate loop)
   const unsigned long long bps_role = a.bps ? (unsigned long long)a.bps[sf]
                                             : (unsigned long long)(a.bps_uniform + ((STEREO && role == 3) ? 1u : 0u));
 
   // hoisted: produced by the candidate pass(es) below, consumed by the decision and the records
-  int32_t e[64];
+  // e[] sits behind four extra slots: the fixed-LPC error signal is differenced in place from the lane's
+  // 64 samples + the 4 in front of them, so that no second 68-register array is alive next to e[]
+  int32_t ebuf[68];
+  int32_t* const e = ebuf + 4;
   int32_t cq[MAXP];
   int warm = 0, shift = 0, status = 0;
   int role_max = 0, role_min = 0;
@@ -646,17 +654,23 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
     // raw samples and weights of one 8-sample step, fetched one step ahead of their use
     int4 rv[2];
     float4 rw[2];
+    // (orders above 8 carry a 12-value halo and three 11- or 13-entry accumulator sets: there the weights
+    // are read where they are used instead of one step ahead, which keeps the loop inside 168 registers)
+    constexpr bool PREFETCH_W = (HP == 8);
+    int t_conv = 0;
     auto fetch = [&](int t0) {
+      t_conv = t0;
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         rv[q] = ld4(t0 + 4 * q);
-        rw[q] = window4(t0 + 4 * q);
+        if (PREFETCH_W) rw[q] = window4(t0 + 4 * q);
       }
     };
     // x_w[t] = (f32)s[t] * w[t]: one f32 rounding, then widen (lpc.rs:751-754)
     auto convert = [&](int base) {
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
+        if (!PREFETCH_W) rw[q] = window4(t_conv + 4 * q);
         dw[base + 4 * q + 0] = (double)((float)rv[q].x * rw[q].x);
         dw[base + 4 * q + 1] = (double)((float)rv[q].y * rw[q].y);
         dw[base + 4 * q + 2] = (double)((float)rv[q].z * rw[q].z);
@@ -749,6 +763,9 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
   }
   __builtin_amdgcn_sched_barrier(0);
   if (a.stamps && lane == 0) a.stamps[(size_t)sf * 8 + 2] = (unsigned long long)clock64();
+#if defined(FLACENC_EXIT_AFTER) && FLACENC_EXIT_AFTER == 1
+  asm volatile("s_endpgm");
+#endif
 
   // ======================= phase 2: Levinson + quantisation ================
   // Serial, ~650 VALU instructions, and a wave instruction costs the same with 1 or 64 active
@@ -758,7 +775,7 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
   {
     // exchange area: kept small -- LDS is allocated in 1280-byte granules and three workgroups
     // must fit one CU (3 x 42 granules = 157.5 KB)
-    constexpr int XR = (NLAG + 1) & ~1;
+    constexpr int XR = NLAG;  // (not rounded up: at order 10 the 32 bytes decide whether three workgroups fit a CU)
     double* const xr = reinterpret_cast<double*>(sm + NIMG * kBufDwords);  // [4][XR]
     int32_t* const xq = reinterpret_cast<int32_t*>(xr + 4 * XR);                   // [4][16]
     if (lane == 0) {
@@ -817,6 +834,18 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
         v[4 * k + 1] = (uint32_t)q.y;
         v[4 * k + 2] = (uint32_t)q.z;
         v[4 * k + 3] = (uint32_t)q.w;
+      }
+    });
+  };
+  auto fixed_load_into = [&](int32_t (&v)[68]) {
+    with_role([&](auto kind) {
+#pragma unroll
+      for (int k = 0; k < 17; ++k) {
+        const int4 q = ld4k(kind, tl - 4 + 4 * k);
+        v[4 * k + 0] = q.x;
+        v[4 * k + 1] = q.y;
+        v[4 * k + 2] = q.z;
+        v[4 * k + 3] = q.w;
       }
     });
   };
@@ -908,17 +937,17 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
   };
 #pragma unroll 1
   for (;;) {
+  // (the LDS addresses below are functions of tl alone: opaque here, they are recomputed per pass instead
+  // of being hoisted out of the loop as two dozen registers that then live -- or spill -- across it)
+  if (FIXED) asm volatile("" : "+v"(tl));
   if (FIXED && cand != 5) {
     // ---- the order-`cand` fixed-LPC error signal (coding.rs:182-197) -> e[] ----
-    uint32_t v[68];
-    fixed_load(v);
+    fixed_load_into(ebuf);
 #pragma unroll 1
     for (int lvl = 1; lvl <= cand; ++lvl) {
 #pragma unroll
-      for (int i = 67; i >= 1; --i) v[i] -= v[i - 1];
+      for (int i = 67; i >= 1; --i) ebuf[i] = (int32_t)((uint32_t)ebuf[i] - (uint32_t)ebuf[i - 1]);
     }
-#pragma unroll
-    for (int k = 0; k < 64; ++k) e[k] = (int32_t)v[4 + k];
     // the first `order` errors are never coded (Residual keeps zeros there, coding.rs:151-160)
 #pragma unroll
     for (int k = 0; k < 4; ++k)
@@ -928,7 +957,7 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
   } else {
   if (!FIXED) lpc_front();  // (FIXED: already run before the fixed-LPC work, see there)
   {
-    constexpr int XR = (NLAG + 1) & ~1;
+    constexpr int XR = NLAG;  // (not rounded up: at order 10 the 32 bytes decide whether three workgroups fit a CU)
     double* const xr = reinterpret_cast<double*>(sm + NIMG * kBufDwords);  // [4][XR]
     int32_t* const xq = reinterpret_cast<int32_t*>(xr + 4 * XR);                   // [4][16]
     (void)xr;
@@ -946,6 +975,9 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
   const bool wide = !(((uint64_t)my_maxabs * (uint64_t)sumabs < 0x7FFFFFFFull) && (my_maxabs < (1u << 23)));
   __builtin_amdgcn_sched_barrier(0);
   if (a.stamps && lane == 0) a.stamps[(size_t)sf * 8 + 3] = (unsigned long long)clock64();
+#if defined(FLACENC_EXIT_AFTER) && FLACENC_EXIT_AFTER == 2
+  asm volatile("s_endpgm");
+#endif
 
   // ======================= phase 3: residual -> registers ==================
   {
@@ -1005,6 +1037,9 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
   }
   __builtin_amdgcn_sched_barrier(0);
   if (a.stamps && lane == 0) a.stamps[(size_t)sf * 8 + 4] = (unsigned long long)clock64();
+#if defined(FLACENC_EXIT_AFTER) && FLACENC_EXIT_AFTER == 3
+  asm volatile("s_endpgm");
+#endif
   }  // QLPC candidate
 
   // ======================= residual store: registers -> LDS -> HBM ==========
@@ -1226,15 +1261,12 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
     if (!STEREO) {
       // ---- Independent(n) frames: this wave's subframe is one output channel ----
       if (FIXED && kind == 2u) {
-        uint32_t v[68];
-        fixed_load(v);
+        fixed_load_into(ebuf);
 #pragma unroll 1
         for (int lvl = 1; lvl <= fx.order; ++lvl) {
 #pragma unroll
-          for (int i = 67; i >= 1; --i) v[i] -= v[i - 1];
+          for (int i = 67; i >= 1; --i) ebuf[i] = (int32_t)((uint32_t)ebuf[i] - (uint32_t)ebuf[i - 1]);
         }
-#pragma unroll
-        for (int k = 0; k < 64; ++k) e[k] = (int32_t)v[4 + k];
 #pragma unroll
         for (int k = 0; k < 4; ++k)
           if (lane == 0 && k < fx.order) e[k] = 0;
@@ -1321,15 +1353,12 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
       // a chosen FixedLpc subframe: its error signal is rebuilt from the channel images, which
       // must therefore stay intact until every wave is past this point
       if (slot >= 0 && kind == 2u) {
-        uint32_t v[68];
-        fixed_load(v);
+        fixed_load_into(ebuf);
 #pragma unroll 1
         for (int lvl = 1; lvl <= fx.order; ++lvl) {
 #pragma unroll
-          for (int i = 67; i >= 1; --i) v[i] -= v[i - 1];
+          for (int i = 67; i >= 1; --i) ebuf[i] = (int32_t)((uint32_t)ebuf[i] - (uint32_t)ebuf[i - 1]);
         }
-#pragma unroll
-        for (int k = 0; k < 64; ++k) e[k] = (int32_t)v[4 + k];
 #pragma unroll
         for (int k = 0; k < 4; ++k)
           if (lane == 0 && k < fx.order) e[k] = 0;
@@ -1476,7 +1505,7 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) crc ^= (uint32_t)__shfl_xor((int)crc, d, 64);
         __syncthreads();  // every thread is done with crc_tab's neighbours? (crc_tab is read-only here)
-        if (lane == 0) crc_tab[256 + wave] = (uint16_t)crc;  // 576-byte exchange area: 288 uint16
+        if (lane == 0) crc_tab[256 + wave] = (uint16_t)crc;  // (the exchange area holds at least 4 x (9 x 8 + 64) = 544 bytes = 272 uint16)
       }
       __syncthreads();
       const uint32_t frame_bytes = body_bytes + 2u;
@@ -1570,7 +1599,7 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
 template <int MAXP, bool STEREO, bool DECIDE, bool FIXED, bool PACK>
 hipError_t launch_wave4096(const QlpcKernelArgs& a, hipStream_t stream) {
   auto kern = qlpc_wave4096_kernel<MAXP, STEREO, DECIDE, FIXED, PACK>;
-  constexpr size_t smem = (size_t)(STEREO ? 3 : 4) * kBufDwords * 4 + 4 * (((MAXP + 2) & ~1) * 8 + 64);  // images (+ window) + exchange
+  constexpr size_t smem = (size_t)(STEREO ? 3 : 4) * kBufDwords * 4 + 4 * ((MAXP + 1) * 8 + 64);  // images (+ window) + exchange: [4][MAXP + 1] f64 + [4][16] i32
   static DynamicLdsOptIn opt_in;  // per instantiation, per device inside
   if (hipError_t err = opt_in.ensure(reinterpret_cast<const void*>(kern), smem); err != hipSuccess) return err;
   const uint32_t blocks = STEREO ? a.n_subframes / 4u : (a.n_subframes + 3u) / 4u;

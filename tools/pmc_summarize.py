@@ -12,7 +12,7 @@ for path in glob.glob(os.path.join(out, "*", "*", "*counter_collection.csv")):
     with open(path) as f:
         for row in csv.DictReader(f):
             k = row["Kernel_Name"]
-            if "qlpc" not in k and "flacenc" not in k:
+            if "qlpc_wave4096" not in k:
                 continue
             agg[k.split("(")[0][-60:]][row["Counter_Name"]].append(float(row["Counter_Value"]))
 summary = {}

@@ -1552,12 +1552,12 @@ static int encode_stereo_frames_impl(flacenc_hip_handle* h, const flacenc_hip_fr
     if (rc2 != FLACENC_HIP_OK) return rc2;
     a.split_scratch = h->d_split.ptr;
   }
-  // The fused bit writer pays off when the fixed-LPC candidate is on (measured on MI355X, 8192 frames:
-  // 0.64 ms vs 0.49 + 0.22 ms in two launches); without it the packing tail -- two of the four waves
-  // busy, 8 waves per CU to hide the CRC's table latency -- costs more than the separate packer
-  // running at full occupancy (0.54 vs 0.30 + 0.22 ms), so that case stays two-stage.
-  // FLACENC_HIP_FLAG_FUSED_PACK / _TWO_STAGE_PACK in cfg->qlpc.flags override the choice (A/B timing).
-  bool want_fused = cfg->use_fixed != 0;
+  // One kernel or two?  Measured on MI355X (24576 frames, order 8): with the fixed-LPC candidate the fused
+  // bit writer takes 1.80 ms against 1.13 + 0.63 ms for the deciding kernel followed by the stand-alone
+  // packer; without it 1.62 against 0.72 + 0.63 ms.  The deciding kernels run at three workgroups per CU,
+  // the fused one -- whose packing tail keeps two of four waves busy -- fits only two, so the two-launch
+  // form is the default; FLACENC_HIP_FLAG_FUSED_PACK / _TWO_STAGE_PACK in cfg->qlpc.flags override it.
+  bool want_fused = false;
   if (cfg->qlpc.flags & FLACENC_HIP_FLAG_FUSED_PACK) want_fused = true;
   if (cfg->qlpc.flags & FLACENC_HIP_FLAG_TWO_STAGE_PACK) want_fused = false;
   if (pack && want_fused && !fixed_composite && flacenc_hip::wave_kernel_eligible(a)) {

@@ -73,7 +73,8 @@ extern "C" {
 /* Kernel selection overrides (no reference counterpart; every choice produces identical results):
  * GENERIC_KERNEL keeps block-4096 / order <= 12 launches off the fused wave-per-subframe kernel;
  * FUSED_PACK / TWO_STAGE_PACK force flacenc_hip_encode_pack_stereo_frames_async's one-kernel or
- * two-kernel form (default: fused exactly when use_fixed is set, the faster choice measured). */
+ * two-kernel form (default: two kernels, the faster choice measured since the deciding kernels run at
+ * three workgroups per CU). */
 #define FLACENC_HIP_FLAG_GENERIC_KERNEL 4u
 #define FLACENC_HIP_FLAG_FUSED_PACK 8u
 #define FLACENC_HIP_FLAG_TWO_STAGE_PACK 16u
@@ -393,9 +394,10 @@ int flacenc_hip_pack_frames_async(flacenc_hip_handle* h, const int32_t* frames, 
 /*
  * encode_frame + Frame::write in one call, device pointers: PCM frames in, FLAC frame bytes out
  * (= flacenc_hip_encode_stereo_frames_async followed by flacenc_hip_pack_stereo_frames_async, same
- * arguments and outputs, no residual rows).  For block size 4096 with LPC order <= 12 this is ONE
- * kernel: the chosen residuals go from the deciding wave's registers straight into the frame's bit
- * buffer in LDS and never touch HBM; other shapes run the two-stage path through handle scratch.
+ * arguments and outputs, no residual rows): the residual rows live in handle scratch between the two
+ * kernels.  With FLACENC_HIP_FLAG_FUSED_PACK, block size 4096 and LPC order <= 12 it is ONE kernel: the
+ * chosen residuals go from the deciding wave's registers straight into the frame's bit buffer in LDS and
+ * never touch HBM (6 instead of 14 bytes of traffic per input sample, but fewer resident waves: slower).
  */
 int flacenc_hip_encode_pack_stereo_frames_async(flacenc_hip_handle* h, const flacenc_hip_frame_config* cfg,
                                                 const int32_t* frames, size_t n_frames, uint32_t block_size,

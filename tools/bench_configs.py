@@ -10,8 +10,11 @@ import torch  # noqa: E402
 
 from flacenc_rs_amd import _capi  # noqa: E402
 
+import json  # noqa: E402
+
 dev = torch.device("cuda", 0)
 h = _capi.Handle(0)
+ROWS = []
 
 
 def run(name, frames, ch, n, bps, order, stereo):
@@ -43,16 +46,22 @@ def run(name, frames, ch, n, bps, order, stereo):
     ms = e0.elapsed_time(e1) / reps
     inp = frames * ch * n
     print(f"{name:52s} {ms:8.3f} ms  {inp / ms / 1e3:9.1f} Msamples/s input  ({nsub * n / ms / 1e3:9.1f} analysed)"
-          f"  {8 * inp / ms / 1e6 / 8000:6.3f} of 8 TB/s")
+          f"  {8 * inp / ms / 1e6 / 8000:6.3f} of 8 TB/s", file=sys.stderr)
+    # f64 fma alone: (order + 1) per analysed sample against the FP64 vector peak (78.6 TFLOP/s = 39.3 T fma/s)
+    ROWS.append({"shape": name, "frames": frames, "channels": ch, "block_size": n, "bps": bps, "lpc_order": order,
+                 "ms_per_call": round(ms, 4), "Msamples_per_s_input": round(inp / ms / 1e3, 1),
+                 "Msamples_per_s_analysed": round(nsub * n / ms / 1e3, 1),
+                 "hbm_frac_at_8B_per_input_sample": round(8 * inp / ms / 1e6 / 8000, 4),
+                 "fp64_fma_frac": round((order + 1) * nsub * n / (ms * 1e-3) / 39.3e12, 4)})
 
 
 run("config1: 4096 x 16b stereo, order 10 (4 candidates)", 8192, 2, 4096, 16, 10, True)
 run("config2: 4096 x 16b stereo, order 8 (4 candidates)", 8192, 2, 4096, 16, 8, True)
-run("config3: 8192 x 24b stereo, order 24 (generic kernel)", 2048, 2, 8192, 24, 24, True)
-run("config3: 8192 x 24b stereo, order 32 (generic kernel)", 2048, 2, 8192, 24, 32, True)
+run("config3: 8192 x 24b stereo, order 24 (big-block kernels)", 2048, 2, 8192, 24, 24, True)
+run("config3: 8192 x 24b stereo, order 32 (big-block kernels)", 2048, 2, 8192, 24, 32, True)
 run("config4: 4096 x 16b 8-channel, order 10 (plain)", 2048, 8, 4096, 16, 10, False)
-run("config5: 16384 x 24b stereo, order 24 (generic kernel)", 1024, 2, 16384, 24, 24, True)
-run("config5: 16384 x 24b stereo, order 32 (generic kernel)", 1024, 2, 16384, 24, 32, True)
+run("config5: 16384 x 24b stereo, order 24 (big-block kernels)", 1024, 2, 16384, 24, 24, True)
+run("config5: 16384 x 24b stereo, order 32 (big-block kernels)", 1024, 2, 16384, 24, 32, True)
 run("ragged: 4608 x 16b stereo, order 10 (generic kernel)", 4096, 2, 4608, 16, 10, True)
 
 
@@ -86,8 +95,14 @@ def run_frames(name, frames, ch, n, bps, order):
     ms = e0.elapsed_time(e1) / 5
     inp = frames * ch * n
     print(f"{name:52s} {ms:8.3f} ms  {inp / ms / 1e3:9.1f} Msamples/s input, PCM -> frame bytes "
-          f"({int(lens.sum().item()) / (inp * bps / 8):.3f} of PCM size)")
+          f"({int(lens.sum().item()) / (inp * bps / 8):.3f} of PCM size)", file=sys.stderr)
+    ROWS.append({"shape": name, "frames": frames, "channels": ch, "block_size": n, "bps": bps, "lpc_order": order,
+                 "ms_per_call": round(ms, 4), "Msamples_per_s_input": round(inp / ms / 1e3, 1),
+                 "what": "encode_frames (default config: fixed-LPC candidate on) + pack_frames, PCM in HBM -> frame bytes in HBM"})
 
 
 run_frames("config4: 4096 x 16b 8-channel, default config, frames", 2048, 8, 4096, 16, 10)
 run_frames("mono: 4096 x 16b, default config, frames", 8192, 1, 4096, 16, 10)
+
+print(json.dumps({"tool": "tools/bench_configs.py", "timing": "HIP events around 5 calls after 2 warm-up calls, device-resident data",
+                  "rows": ROWS}, indent=1))

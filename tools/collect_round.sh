@@ -1,0 +1,13 @@
+#!/bin/bash
+# Everything profiles/ holds for a round, in one gpurun call: tools/collect_round.sh r02
+set -u
+TAG=$1
+export GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$PWD}
+O=$GRAFT_REPO_ROOT/gpurun_out/collect_$TAG; mkdir -p $O
+cd $GRAFT_REPO_ROOT
+python3 bench.py > $O/bench.json 2> $O/bench.err
+bash tools/profile_round.sh $TAG > $O/profile_round.log 2>&1
+bash tools/profile_stages.sh $TAG > $O/profile_stages.log 2>&1
+python3 tools/bench_configs.py > $O/configs.json 2> $O/configs.txt
+tools/prof_bigblock.sh collect_$TAG/bigblock > $O/bigblock.txt 2>&1
+tail -c 1500 $O/bench.json; cat $O/configs.txt; cat $O/bigblock.txt | tail -30

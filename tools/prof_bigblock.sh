@@ -11,6 +11,6 @@ print('== n=%s order=%s'%(sys.argv[2],sys.argv[3]))
 for r in csv.DictReader(open(f)):
     nm=r['Name'].split('::')[-1].split('(')[0][:44]
     print('   %-46s calls %s avg %.1f us'%(nm, r['Calls'], float(r['AverageNs'])/1e3)); tot+=float(r['TotalDurationNs'])/6
-print('   total per call %.1f us -> %.1f G input samples/s'%(tot/1e3, 16777216/(tot/1e9)/1e9))
+print('   total per call %.1f us -> %.1f G input samples/s'%(tot/1e3, 2*16777216/(tot/1e9)/1e9))
 PY
 done

@@ -215,6 +215,13 @@ int flacenc_hip_stereo_qlpc_batch_async(flacenc_hip_handle* h, const flacenc_hip
  */
 #define FLACENC_HIP_ORDERSEL_BITCOUNT 0  /* OrderSel::BitCount: code every order, count the bits */
 #define FLACENC_HIP_ORDERSEL_APPROXENT 1 /* OrderSel::ApproxEnt { partitions } (the default) */
+/* ApproxEnt feeds estimate_entropy (src/coding.rs:200-227) the partition's sum of |e| as an f32.  Here that
+ * is the exact integer sum rounded to f32 once; the reference accumulates in f32 (find_sum_abs_f32,
+ * src/arrayutils.rs:496: one sequential chain in the stable build, 16 lanes in simd-nightly).  All three
+ * coincide while the sum stays below 2^24 and differ by f32 rounding above it (24-bit material, loud 16-bit
+ * material at higher fixed orders): the selected fixed order -- and hence the frame bytes -- are then not
+ * guaranteed identical to a CPU build's, also under FLACENC_HIP_FLAG_REFERENCE_SUM_ORDER.  BitCount has no
+ * such dependence. */
 
 typedef struct flacenc_hip_frame_config {
   flacenc_hip_qlpc_config qlpc;

@@ -310,13 +310,25 @@ __device__ __forceinline__ unsigned long long plane_sum_any64(const PlaneSums& p
 // whatever the span (typical material: one group).
 // Table entries Wp[j] = table[p_base + j] - 4 of this lane's 64-sample partition (see rice_search).
 // EXACT: from the bit-planes; otherwise the literal chunk-clamped sums of rice.rs:75-98 from e[].
-template <bool EXACT>
+// NOSAT (only with EXACT; chosen per subframe, see rice_nosat_ok): no entry of any level can reach the
+// saturation value and every parameter of the window is legal or provably losing, so the clamps and the
+// validity selects are dropped and the entries are kept pre-shifted (W << 5) for the packed minimiser.
+template <bool EXACT, bool NOSAT = false>
 __device__ __forceinline__ void rice_build_tables(const PlaneSums& ps, const int32_t* e, uint32_t len0,
                                                   uint32_t p_base, uint32_t max_p, int lane, int warm,
                                                   uint32_t (&Wp)[8]) {
   constexpr int NP = 8;
   constexpr uint32_t kWMax = kMaxPToBits - 4u;
-  if (EXACT) {
+  if (EXACT && NOSAT) {
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const uint32_t pp = p_base + (uint32_t)j;  // wave-uniform, <= 31
+      uint32_t sum;
+      if (j == 0) sum = (pp == 0) ? 2u * ps.sum_m + ps.negs : plane_sum_ge1(ps, pp);
+      else sum = plane_sum_ge1(ps, pp);
+      Wp[j] = (sum + len0 * (pp + 1u)) << 5;
+    }
+  } else if (EXACT) {
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
       const uint32_t pp = p_base + (uint32_t)j;  // wave-uniform
@@ -357,6 +369,7 @@ __device__ __forceinline__ void rice_build_tables(const PlaneSums& ps, const int
 
 // Levels 0..6 of one group of 8 parameters: merges in place (afterwards Wp holds, on lane 0, the table of
 // all 64 partitions merged) and lowers pk[level] to the group's packed minimum (bits << 5 | p).
+template <bool NOSAT = false>
 __device__ __forceinline__ void rice_group_levels(uint32_t (&Wp)[8], uint32_t (&pk)[7], uint32_t p_base,
                                                   bool finest_only) {
   constexpr int NP = 8;
@@ -368,13 +381,13 @@ __device__ __forceinline__ void rice_group_levels(uint32_t (&Wp)[8], uint32_t (&
       _Pragma("unroll") for (int j = 0; j < NP; ++j) part[j] = from_upper_half<S>(Wp[j]);     \
       _Pragma("unroll") for (int j = 0; j < NP; ++j) {                                        \
         uint32_t v = Wp[j] + part[j];                                                         \
-        Wp[j] = v < kWMax ? v : kWMax;                                                        \
+        Wp[j] = NOSAT ? v : (v < kWMax ? v : kWMax);                                          \
       }                                                                                       \
     }                                                                                         \
     uint32_t packed = pk[K];                                                                  \
     _Pragma("unroll") for (int j = 0; j + 1 < NP; j += 2) {                                   \
-      const uint32_t c0 = (Wp[j] << 5) | (p_base + (uint32_t)j);                              \
-      const uint32_t c1 = (Wp[j + 1] << 5) | (p_base + (uint32_t)j + 1u);                     \
+      const uint32_t c0 = (NOSAT ? Wp[j] : (Wp[j] << 5)) | (p_base + (uint32_t)j);            \
+      const uint32_t c1 = (NOSAT ? Wp[j + 1] : (Wp[j + 1] << 5)) | (p_base + (uint32_t)j + 1u); \
       packed = umin3(packed, c0, c1);                                                         \
     }                                                                                         \
     pk[K] = packed;                                                                           \
@@ -391,7 +404,7 @@ __device__ __forceinline__ void rice_group_levels(uint32_t (&Wp)[8], uint32_t (&
 #undef FLACENC_RICE_LEVEL
 }
 
-template <bool EXACT>
+template <bool EXACT, bool NOSAT = false>
 __device__ __forceinline__ RiceResult rice_search(const PlaneSums& ps, const int32_t* e, uint32_t len0,
                                                   uint32_t p_lo, uint32_t max_p, bool small_bits, int lane,
                                                   int warm, bool finest_only) {
@@ -404,8 +417,8 @@ __device__ __forceinline__ RiceResult rice_search(const PlaneSums& ps, const int
 #pragma unroll 1
   for (uint32_t p_base = p_lo; p_base <= max_p; p_base += (uint32_t)NP) {
     uint32_t Wp[NP];
-    rice_build_tables<EXACT>(ps, e, len0, p_base, max_p, lane, warm, Wp);
-    rice_group_levels(Wp, pk, p_base, finest_only);
+    rice_build_tables<EXACT, NOSAT>(ps, e, len0, p_base, max_p, lane, warm, Wp);
+    rice_group_levels<NOSAT>(Wp, pk, p_base, finest_only);
   }
 
   RiceResult r;
@@ -1144,7 +1157,21 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
     const uint32_t p0min = wave_min_dpp(31u - (uint32_t)__builtin_clz(q0));
     uint32_t p_lo = p0min > 2u ? p0min - 2u : 0u;
     p_lo = p_lo < max_p ? p_lo : max_p;
-    rr = rice_search<true>(ps, nullptr, len0, p_lo, max_p, small_bits, lane, warm, finest_only);
+    // NOSAT: (1) the configured limit does not cut the search (max_p == bitlen), so a parameter above
+    // max_p inside the last group of 8 is legal-but-losing -- for p > bitlen every table entry is
+    // len (p + 1), strictly above the entry at p = bitlen -- and needs no masking; (2) bitlen <= 24 keeps
+    // every shift amount below 32; (3) no entry of any level reaches the saturation value: an entry of the
+    // fully merged table is at most sum u + 4096 * 32, and the sum of the lanes' code sums is bounded from
+    // their 64-sample means.  Then clamps never bind and the search equals the clamped one.
+    // (Not in the fixed-LPC variants: a second instance of the search inside their candidate loop costs
+    // them 35 more spilled dwords at 168 registers.)
+    bool nosat = false;
+    if (!FIXED) {
+      const uint32_t tot_hi = wave_sum_dpp(s0 >> 6);  // sum over lanes of floor(s0 / 64): < 2^32
+      nosat = small_bits && bitlen <= 24u && tot_hi < ((kMaxPToBits - 4u - 131072u) >> 6) - 64u;
+    }
+    if (!FIXED && nosat) rr = rice_search<true, true>(ps, nullptr, len0, p_lo, max_p, small_bits, lane, warm, finest_only);
+    else rr = rice_search<true>(ps, nullptr, len0, p_lo, max_p, small_bits, lane, warm, finest_only);
     // The window argument compares unclamped table values.  If any group minimum saturated at
     // MAX_P_TO_BITS, clamped entries outside the window could tie with it (ties go to the
     // smallest p, rice.rs:123-124), so search the whole range then.

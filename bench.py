@@ -230,7 +230,7 @@ def run(args, world):
         offsets, total = shard.stream_offsets(lengths_all)
         last_exchange.update(lengths_all=lengths_all, offsets=offsets, total=total)
         if args.gather in ("records", "payload"):
-            last_exchange["records_all"] = shard.all_gather_records(results2[b], world * F)
+            last_exchange["records_all"] = shard.all_gather_frame_records(results2[b], world * F, n)
         if payload:
             last_exchange["stream_bytes"] = shard.all_gather_frame_bytes(
                 shard.device_place(handle, comm.cuda_stream), packed2[b], frame_len2[b], lengths_all, offsets,
@@ -311,7 +311,9 @@ def run(args, world):
     if exchanging:
         gather_desc = "RCCL all_gather of per-frame byte lengths (4 B/frame) + prefix sum to stream offsets"
         if args.gather in ("records", "payload"):
-            gather_desc += " + all_gather of the 752-B frame records (the encoded SubFrame components) into stream order"
+            gather_desc += (" + all_gather of the frame records (the encoded SubFrame components; %d of their 752 "
+                            "bytes on the wire: Rice-parameter slots beyond the block's finest partition count are "
+                            "always zero) into stream order" % shard.wire_record_bytes(n))
         if payload:
             gather_desc += " + Frame::write on the producing GPU and all_gather of the packed frame bytes, placed at their stream offsets"
         gather_desc += "; on its own stream, overlapping the next step's analysis"
@@ -560,7 +562,15 @@ def dry_run(args, world):
         ok &= lengths_all.tolist() == want
         ok &= offsets.tolist() == np.concatenate([[0], np.cumsum(want)[:-1]]).tolist() and int(total) == sum(want)
         if args.gather in ("records", "payload"):
+            # (stand-in records are dense, so they go as they are; the wire format of real records is
+            # exercised separately below)
             ordered = shard.all_gather_records(torch.from_numpy(recs), total_frames).numpy()
+            sparse = torch.from_numpy(recs.copy())
+            sparse[:, 48 + 96 + 64:48 + 352] = 0
+            sparse[:, 48 + 352 + 96 + 64:] = 0
+            back = shard.all_gather_frame_records(sparse, total_frames, 4096)
+            mine_back = back[rank::world][:F]
+            ok &= bool(torch.equal(mine_back, sparse)) and back.shape == (total_frames, 752)
             ids = ordered[:, :4].copy().view(np.uint32).reshape(-1)
             ok &= ids.tolist() == list(range(total_frames))
             ok &= all(np.array_equal(ordered[f, 4:], (f * 31 + np.arange(rec_bytes - 4)) & 0xFF)

@@ -56,6 +56,52 @@ def all_gather_records(local: torch.Tensor, n_frames_total: int, group=None) -> 
     return ordered[:n_frames_total]
 
 
+# ---- wire format of the 752-byte stereo frame records -----------------------------------------------
+# flacenc_hip_stereo_frame_result = 48 bytes of frame fields + two 352-byte subframe records, each ending in
+# rice_params[256].  A block of n samples has at most 2^finest_order(n) partitions (64 for n = 4096), the
+# rest of that array is always zero: the exchange moves the records without those tails and restores them.
+_FRAME_HEAD = 48
+_SUB_BYTES = 352
+_SUB_FIXED = 96  # coefs[32] i16 + order/shift/precision/rice_order + status + code_bits/subframe_bits/sum_quotients
+
+
+def finest_partitions(block_size: int) -> int:
+    """2^finest_partition_order (src/rice.rs:157-165) for a warm-up of at most 64 samples."""
+    order, n = 0, block_size
+    while order < 8 and n % 2 == 0 and n // 2 >= 64:
+        n //= 2
+        order += 1
+    return 1 << order
+
+
+def wire_record_bytes(block_size: int) -> int:
+    return _FRAME_HEAD + 2 * (_SUB_FIXED + finest_partitions(block_size))
+
+
+def records_to_wire(records: torch.Tensor, block_size: int) -> torch.Tensor:
+    """[F, 752] uint8 -> [F, wire_record_bytes] uint8 (drops the always-zero tails of rice_params)."""
+    parts = finest_partitions(block_size)
+    a = _FRAME_HEAD
+    b = a + _SUB_BYTES
+    return torch.cat([records[:, :a + _SUB_FIXED + parts], records[:, b:b + _SUB_FIXED + parts]], dim=1).contiguous()
+
+
+def records_from_wire(wire: torch.Tensor, block_size: int) -> torch.Tensor:
+    parts = finest_partitions(block_size)
+    keep = _SUB_FIXED + parts
+    out = torch.zeros((wire.shape[0], _FRAME_HEAD + 2 * _SUB_BYTES), dtype=torch.uint8, device=wire.device)
+    out[:, :_FRAME_HEAD + keep] = wire[:, :_FRAME_HEAD + keep]
+    out[:, _FRAME_HEAD + _SUB_BYTES:_FRAME_HEAD + _SUB_BYTES + keep] = wire[:, _FRAME_HEAD + keep:]
+    return out
+
+
+def all_gather_frame_records(records: torch.Tensor, n_frames_total: int, block_size: int, group=None) -> torch.Tensor:
+    """All-gather the stereo frame records (the encoded SubFrame components) in wire format and return them
+    full-size, in stream order, on every rank."""
+    wire = all_gather_records(records_to_wire(records, block_size), n_frames_total, group=group)
+    return records_from_wire(wire, block_size)
+
+
 def all_gather_frame_lengths(local_lengths: torch.Tensor, n_frames_total: int, group=None) -> torch.Tensor:
     """Byte lengths of all frames in stream order, on every rank (ParSink's ordering, src/par.rs:67-95,
     reduced to what it needs).  `local_lengths` is this rank's [n_local_frames] integer tensor."""

@@ -86,3 +86,18 @@ def test_pinned_buffers_give_identical_bytes(handle):
     # twice through the same handle (staging buffers reused)
     out_c, lens_c = handle.encode_pcm_stereo(pcm, cfg, 2, bps, n, 44100)
     assert out_c.tobytes() == out_a.tobytes()
+
+
+@pytest.mark.parametrize("n,order", [(4096, 8), (4608, 10), (8192, 24), (1152, 8)])
+def test_record_wire_format_is_lossless(handle, n, order):
+    """The multi-GPU exchange moves frame records without the always-zero tails of their Rice-parameter
+    arrays (flacenc_rs_amd/shard.py): real records of every partition-count class must survive the round trip."""
+    import torch
+    from flacenc_rs_amd import shard
+    frames = _capi.sigen_frames(7, 2, n, 16, 36.0, 0.4, 0.2, seed=n + order, nthreads=2)
+    res, _ = handle.encode_stereo_frames(frames, 16, _capi.make_frame_config(_capi.make_config(lpc_order=order), use_fixed=True))
+    rec = torch.from_numpy(np.frombuffer(res.tobytes(), np.uint8).reshape(7, 752).copy())
+    wire = shard.records_to_wire(rec, n)
+    assert wire.shape == (7, shard.wire_record_bytes(n)) and wire.shape[1] < 752
+    assert torch.equal(shard.records_from_wire(wire, n), rec)
+    assert int(res["lpc"]["rice_order"].max()) <= int(np.log2(shard.finest_partitions(n)))

@@ -72,6 +72,10 @@ def parse_args(argv=None):
                     help="run the multi-GPU exchange step even with one rank; for measuring its cost")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="torch.distributed backend; nccl is RCCL on ROCm.  gloo only with --dry-run")
+    ap.add_argument("--shared-gpu-test", action="store_true",
+                    help="functional test of the real multi-rank path on a box with fewer GPUs than ranks: ranks "
+                         "share devices (rank mod device count) and the collectives run over gloo.  Not a "
+                         "measurement: the line is marked and `value` is 0")
     ap.add_argument("--dry-run", action="store_true",
                     help="CPU check of the launch and exchange plumbing (no GPU, no analysis, no "
                          "measurement): stand-in records, real sharding + collectives over gloo")
@@ -106,8 +110,10 @@ def main():
     args = parse_args(argv)
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
-    if args.backend == "gloo" and not args.dry_run:
-        raise SystemExit("--backend gloo is only for --dry-run (the product path has no CPU fallback)")
+    if args.backend == "gloo" and not (args.dry_run or args.shared_gpu_test):
+        raise SystemExit("--backend gloo is only for --dry-run / --shared-gpu-test (the product path has no CPU fallback)")
+    if args.shared_gpu_test and args.backend != "gloo":
+        raise SystemExit("--shared-gpu-test needs --backend gloo (RCCL wants one device per rank)")
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None and args.gpus > 1:
         sys.exit(launch_ranks(args, argv))
@@ -178,12 +184,18 @@ def run(args, world):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the product path)")
+    if args.shared_gpu_test:
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     ranks_observed = 1
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this driver
+        if args.shared_gpu_test:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
         one = torch.ones(1, dtype=torch.int32, device=dev)
         dist.all_reduce(one)  # counted by RCCL itself, not read from the environment
         ranks_observed = int(one.item())
@@ -298,6 +310,8 @@ def run(args, world):
 
     samples_per_step = F * 2 * n  # input channel-samples per rank per step
     value = world * samples_per_step * args.steps / elapsed / 1e6
+    if args.shared_gpu_test:
+        value = 0.0  # ranks shared a GPU and the collectives went through the host: not a measurement
     achieved = ALGO_BYTES_PER_SAMPLE * samples_per_step / (kernel_ms * 1e-3) / 1e9
     prof = profiled_counters(args)
     valu_frac = None
@@ -309,7 +323,8 @@ def run(args, world):
 
     gather_desc = "none"
     if exchanging:
-        gather_desc = "RCCL all_gather of per-frame byte lengths (4 B/frame) + prefix sum to stream offsets"
+        gather_desc = ("%s all_gather of per-frame byte lengths (4 B/frame) + prefix sum to stream offsets"
+                       % ("gloo (shared-GPU functional test)" if args.shared_gpu_test else "RCCL"))
         if args.gather in ("records", "payload"):
             gather_desc += (" + all_gather of the frame records (the encoded SubFrame components; %d of their 752 "
                             "bytes on the wire: Rice-parameter slots beyond the block's finest partition count are "
@@ -324,6 +339,7 @@ def run(args, world):
         "unit": "Msamples/s",
         "n_gpus": world,
         "ranks_observed": ranks_observed,
+        **({"shared_gpu_test": True} if args.shared_gpu_test else {}),
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 4),

@@ -63,3 +63,19 @@ def test_no_gpu_fails_loudly():
         pytest.skip("a GPU is visible")
     r = _run(["--steps", "1", "--warmup", "0", "--frames", "4"])
     assert r.returncode != 0 and "GPU" in (r.stderr + r.stdout)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gather", ["records", "payload"])
+def test_two_real_ranks_on_the_visible_gpus(gather):
+    """The real multi-rank path of bench.py (sharded sigen stream, GPU analysis, exchange on its own stream,
+    stream-order checks across ranks) with two ranks.  On a one-GPU box the ranks share the device and the
+    collectives run over gloo (`--shared-gpu-test`; marked in the JSON, value 0): everything but RCCL itself."""
+    r = _run(["--gpus", "2", "--backend", "gloo", "--shared-gpu-test", "--frames", "1536", "--steps", "3",
+              "--warmup", "1", "--gather", gather], timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = _json_line(r.stdout)
+    assert line["n_gpus"] == 2 and line["ranks_observed"] == 2 and line["shared_gpu_test"] is True
+    chk = line["config"]["exchange_check"]
+    assert chk["ok"] is True and chk["stream_frames"] == 2 * 1536 and chk["stream_bytes"] > 0
+    assert line["value"] == 0.0

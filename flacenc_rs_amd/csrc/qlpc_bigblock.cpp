@@ -27,6 +27,13 @@ namespace flacenc_hip {
 namespace {
 
 constexpr int kPass = 4096;
+#ifndef FLACENC_BIG_ACORR_OCC
+#define FLACENC_BIG_ACORR_OCC 2
+#endif
+#ifndef FLACENC_BIG_NG24
+#define FLACENC_BIG_NG24 2
+#define FLACENC_BIG_NL24 13
+#endif
 
 // cooperative load of pass k of the workgroup's rows into the LDS images: segment 0 of an image holds the
 // 64 samples in front of the pass (zeros in front of the block), the pass follows (widx layout)
@@ -94,11 +101,12 @@ __device__ __forceinline__ int4 bigblock_ld4(const int32_t* bufA, const int32_t*
 // tree partials) and the window of 32 lagged values + 16 current ones are what a lane holds at a time;
 // the groups re-read and re-convert the lane's samples from LDS (the pass is loaded and its window
 // weights staged once)
-template <int NG, int NL, bool STEREO>
-__global__ void __launch_bounds__(256, 2) bigblock_acorr_kernel(QlpcKernelArgs a) {
-  constexpr int HP = 32;
+template <int HP, int NG, int NL, bool STEREO>
+__global__ void __launch_bounds__(256, FLACENC_BIG_ACORR_OCC) bigblock_acorr_kernel(QlpcKernelArgs a) {
+  // HP = window depth = the order bucket (24 or 32); lags beyond HP that a group's last slots may name
+  // (25, 26 with 3 x 9 at HP 24; 33 with 3 x 11 at HP 32) read as zero and are not stored
   constexpr int NLAG = NG * NL;
-  static_assert(NLAG - 1 <= 33 && NLAG >= 25, "lag groups must cover the order bucket");
+  static_assert(NLAG >= HP + 1 && NLAG <= HP + 3, "lag groups must cover the order bucket");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   int32_t* const sm = reinterpret_cast<int32_t*>(smem_raw);
   constexpr int NBUF = STEREO ? 2 : 4;
@@ -213,7 +221,7 @@ __global__ void __launch_bounds__(256, 2) bigblock_acorr_kernel(QlpcKernelArgs a
               r = mine[(k >> 1 & 1) * NLAG + lag] + r;              // R0 + R1 (or R2 + R3)
               if (K == 4 && k == 1) mine[lag] = r;                  // keeps waiting for (R2 + R3)
               if (K == 4 && k == 3) r = mine[lag] + r;
-              if (k == K - 1 && active && lag < 33) a.autocorr[(size_t)sf * 33 + lag] = (lag <= P) ? r : 0.0;
+              if (k == K - 1 && active && lag <= HP) a.autocorr[(size_t)sf * 33 + lag] = (lag <= P) ? r : 0.0;
             }
           }
         }
@@ -230,7 +238,7 @@ __global__ void __launch_bounds__(256, 2) bigblock_acorr_kernel(QlpcKernelArgs a
     if (k == K - 1) stamp(5);
   }
   if (lane == 0 && active)
-    for (int j = NLAG; j < 33; ++j) a.autocorr[(size_t)sf * 33 + j] = 0.0;
+    for (int j = HP + 1; j < 33; ++j) a.autocorr[(size_t)sf * 33 + j] = 0.0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -578,12 +586,12 @@ hipError_t launch_big(KernelT kern, DynamicLdsOptIn& opt_in, const QlpcKernelArg
   return hipGetLastError();
 }
 
-template <int NG, int NL>
+template <int HP, int NG, int NL>
 hipError_t launch_acorr(const QlpcKernelArgs& a, hipStream_t stream) {
   static DynamicLdsOptIn opt_s, opt_p;
   const size_t part = 4 * 2 * NG * NL * sizeof(double);
-  if (a.stereo) return launch_big(bigblock_acorr_kernel<NG, NL, true>, opt_s, a, 3 * kBufDwords * 4 + part, stream);
-  return launch_big(bigblock_acorr_kernel<NG, NL, false>, opt_p, a, 5 * kBufDwords * 4 + part, stream);
+  if (a.stereo) return launch_big(bigblock_acorr_kernel<HP, NG, NL, true>, opt_s, a, 3 * kBufDwords * 4 + part, stream);
+  return launch_big(bigblock_acorr_kernel<HP, NG, NL, false>, opt_p, a, 5 * kBufDwords * 4 + part, stream);
 }
 
 template <int MAXP, int K>
@@ -610,8 +618,8 @@ bool bigblock_eligible(const QlpcKernelArgs& a) {
 // R[] (unless `have_r`: already in `racc`, e.g. from the reference-order kernel) into racc
 hipError_t launch_bigblock_acorr(const QlpcKernelArgs& a, hipStream_t stream) {
   // lag groups of at most 13: window (48 doubles) + three accumulator sets must fit 256 VGPRs
-  if (a.lpc_order <= 24) return launch_acorr<2, 13>(a, stream);   // lags 0..25
-  return launch_acorr<3, 11>(a, stream);                          // lags 0..32
+  if (a.lpc_order <= 24) return launch_acorr<24, FLACENC_BIG_NG24, FLACENC_BIG_NL24>(a, stream);
+  return launch_acorr<32, 3, 11>(a, stream);  // lags 0..32
 }
 
 hipError_t launch_bigblock_residual(const QlpcKernelArgs& a, hipStream_t stream) {

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define FLACENC_HIP_ABI_VERSION 2
+#define FLACENC_HIP_ABI_VERSION 3 /* 3: analysis_status in the frame / channel results, streaming host path, flag bits 4..32 */
 
 /* FLAC allows LPC order 32; the reference's config verifier caps it at 24
  * (src/constant.rs:118, src/config.rs:304).  Orders 25..32 are an extension

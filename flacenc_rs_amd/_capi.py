@@ -60,6 +60,7 @@ EXPORTED_SYMBOLS = (
     "flacenc_hip_stereo_frame_lengths_async",
     "flacenc_hip_place_frames_async",
     "flacenc_hip_encode_pcm_stereo",
+    "flacenc_hip_encode_pcm",
     "flacenc_hip_host_alloc",
     "flacenc_hip_host_free",
     "flacenc_hip_encode_frames",
@@ -250,6 +251,10 @@ def load() -> C.CDLL:
                                                 C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_size_t, vp,
                                                 C.POINTER(C.c_uint64)]
     L.flacenc_hip_encode_pcm_stereo.restype = C.c_int
+    L.flacenc_hip_encode_pcm.argtypes = [vp, C.POINTER(FrameConfig), vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
+                                         C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_size_t, vp,
+                                         C.POINTER(C.c_uint64)]
+    L.flacenc_hip_encode_pcm.restype = C.c_int
     L.flacenc_hip_host_alloc.argtypes = [C.c_size_t]
     L.flacenc_hip_host_alloc.restype = C.c_void_p
     L.flacenc_hip_host_free.argtypes = [C.c_void_p]
@@ -537,6 +542,23 @@ class Handle:
         rc = self._lib.flacenc_hip_place_frames_async(self._h, src_ptr, src_offsets_ptr, lengths_ptr, n_frames,
                                                       dst_ptr, dst_offsets_ptr, stream or None)
         self._check(rc)
+
+    def encode_pcm(self, pcm: np.ndarray, channels: int, cfg: FrameConfig, bytes_per_sample: int, bits_per_sample: int,
+                   block_size: int, sample_rate: int, first_frame_number: int = 0, frame_number_step: int = 1):
+        """flacenc_hip_encode_pcm: interleaved LE PCM of 1..8 channels -> (frame bytes, lengths)."""
+        assert pcm.dtype == np.uint8 and pcm.flags["C_CONTIGUOUS"]
+        total = pcm.size // (channels * bytes_per_sample)
+        n_frames = (total + block_size - 1) // block_size
+        bound = int(self._lib.flacenc_hip_frame_bytes_bound(channels, block_size, bits_per_sample))
+        out = np.empty(n_frames * (bound + 16), np.uint8)
+        lens = np.zeros(n_frames, np.uint32)
+        written = C.c_uint64(0)
+        rc = self._lib.flacenc_hip_encode_pcm(self._h, C.byref(cfg), pcm.ctypes.data, total, channels, bytes_per_sample,
+                                              bits_per_sample, block_size, sample_rate, first_frame_number,
+                                              frame_number_step, out.ctypes.data, out.size, lens.ctypes.data,
+                                              C.byref(written))
+        self._check(rc)
+        return out[: written.value], lens
 
     def encode_pcm_stereo(self, pcm: np.ndarray, cfg: FrameConfig, bytes_per_sample: int, bits_per_sample: int,
                           block_size: int, sample_rate: int, out: np.ndarray | None = None,

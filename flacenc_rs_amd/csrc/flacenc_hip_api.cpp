@@ -1184,18 +1184,29 @@ int flacenc_hip_encode_pcm_stereo(flacenc_hip_handle* h, const flacenc_hip_frame
                                   uint32_t block_size, uint32_t sample_rate, uint32_t first_frame_number,
                                   uint32_t frame_number_step, uint8_t* out, size_t out_capacity, uint32_t* out_len,
                                   uint64_t* out_total) {
+  return flacenc_hip_encode_pcm(h, cfg, pcm, total_samples, 2, bytes_per_sample, bits_per_sample, block_size,
+                                sample_rate, first_frame_number, frame_number_step, out, out_capacity, out_len, out_total);
+}
+
+int flacenc_hip_encode_pcm(flacenc_hip_handle* h, const flacenc_hip_frame_config* cfg, const uint8_t* pcm,
+                           uint64_t total_samples, uint32_t channels, uint32_t bytes_per_sample,
+                           uint32_t bits_per_sample, uint32_t block_size, uint32_t sample_rate,
+                           uint32_t first_frame_number, uint32_t frame_number_step, uint8_t* out, size_t out_capacity,
+                           uint32_t* out_len, uint64_t* out_total) {
   if (!h || !cfg || !out_total) return FLACENC_HIP_ERR_BAD_ARGUMENT;
   *out_total = 0;
   if (total_samples == 0) return FLACENC_HIP_OK;
-  if (!pcm || !out || !out_len || bytes_per_sample < 1 || bytes_per_sample > 4 ||
+  if (!pcm || !out || !out_len || channels < 1 || channels > 8 || bytes_per_sample < 1 || bytes_per_sample > 4 ||
       block_size < FLACENC_HIP_MIN_BLOCK_SIZE || block_size > FLACENC_HIP_MAX_BLOCK_SIZE) {
-    h->last_error = "encode_pcm_stereo: null pointer, bytes_per_sample not in 1..=4 or block_size not in 64..=32767";
+    h->last_error = "encode_pcm: null pointer, channels not in 1..=8, bytes_per_sample not in 1..=4 or block_size "
+                    "not in 64..=32767";
     return FLACENC_HIP_ERR_BAD_ARGUMENT;
   }
+  const bool stereo = channels == 2;
   const uint64_t n_full = total_samples / block_size;
   const uint32_t tail = static_cast<uint32_t>(total_samples % block_size);
   if (tail != 0 && tail < FLACENC_HIP_MIN_BLOCK_SIZE) {
-    h->last_error = "encode_pcm_stereo: a last block shorter than 64 samples never reaches the analysis "
+    h->last_error = "encode_pcm: a last block shorter than 64 samples never reaches the analysis "
                     "(src/coding.rs:396); write it as a Verbatim frame on the host";
     return FLACENC_HIP_ERR_UNSUPPORTED;
   }
@@ -1212,10 +1223,11 @@ int flacenc_hip_encode_pcm_stereo(flacenc_hip_handle* h, const flacenc_hip_frame
   }
   // chunks of whole frames: big enough to run the kernels at full occupancy (>= 768 workgroups),
   // small enough that two slots of staging stay modest and the pipeline has several stages in flight
-  const size_t frame_in_bytes = static_cast<size_t>(block_size) * 2u * bytes_per_sample;
+  const size_t frame_in_bytes = static_cast<size_t>(block_size) * channels * bytes_per_sample;
   size_t chunk = (48u << 20) / frame_in_bytes;
   chunk = chunk < 768 ? 768 : (chunk > 8192 ? 8192 : chunk);
-  const size_t bound = flacenc_hip_stereo_frame_bytes_bound(block_size, bits_per_sample);
+  const size_t bound = stereo ? flacenc_hip_stereo_frame_bytes_bound(block_size, bits_per_sample)
+                              : flacenc_hip_frame_bytes_bound(channels, block_size, bits_per_sample);
   const size_t ostride = (bound + 15) & ~static_cast<size_t>(15);
   const bool in_pinned = is_pinned(pcm), out_pinned = is_pinned(out);
   int rc;
@@ -1223,8 +1235,10 @@ int flacenc_hip_encode_pcm_stereo(flacenc_hip_handle* h, const flacenc_hip_frame
   if (!in_pinned && (rc = ensure_pinned(h, h->pin_in, &h->pin_in_cap, chunk * frame_in_bytes, true)) != FLACENC_HIP_OK) return rc;
   if (!out_pinned && (rc = ensure_pinned(h, h->pin_out, &h->pin_out_cap, chunk * ostride, true)) != FLACENC_HIP_OK) return rc;
   if ((rc = ensure_pinned(h, h->pin_meta, &h->pin_meta_cap, chunk * 4 + 16, true)) != FLACENC_HIP_OK) return rc;
-  if ((rc = ensure(h, h->d_samples, chunk * 2 * dstride * 4)) != FLACENC_HIP_OK) return rc;
-  if ((rc = ensure(h, h->d_results, chunk * sizeof(flacenc_hip_stereo_frame_result))) != FLACENC_HIP_OK) return rc;
+  if ((rc = ensure(h, h->d_samples, chunk * channels * dstride * 4)) != FLACENC_HIP_OK) return rc;
+  if ((rc = ensure(h, h->d_results, chunk * (stereo ? sizeof(flacenc_hip_stereo_frame_result)
+                                                     : channels * sizeof(flacenc_hip_channel_result)))) != FLACENC_HIP_OK)
+    return rc;
   for (int i = 0; i < 2; ++i) {
     if ((rc = ensure(h, h->d_pcm[i], chunk * frame_in_bytes + 16)) != FLACENC_HIP_OK) return rc;
     if ((rc = ensure(h, h->d_pack[i], chunk * ostride)) != FLACENC_HIP_OK) return rc;
@@ -1253,7 +1267,7 @@ int flacenc_hip_encode_pcm_stereo(flacenc_hip_handle* h, const flacenc_hip_frame
     uint64_t bytes = 0;
     for (size_t f = 0; f < c.frames; ++f) bytes += lens[f];
     if (written + bytes > out_capacity) {
-      h->last_error = "encode_pcm_stereo: out_capacity too small";
+      h->last_error = "encode_pcm: out_capacity too small";
       return FLACENC_HIP_ERR_BAD_ARGUMENT;
     }
     std::memcpy(out_len + c.first_frame, lens, c.frames * 4);
@@ -1273,7 +1287,7 @@ int flacenc_hip_encode_pcm_stereo(flacenc_hip_handle* h, const flacenc_hip_frame
   for (size_t ci = 0; ci < chunks.size(); ++ci) {
     const Chunk& c = chunks[ci];
     const int s = static_cast<int>(ci & 1);
-    const size_t in_bytes = c.frames * static_cast<size_t>(c.n) * 2u * bytes_per_sample;
+    const size_t in_bytes = c.frames * static_cast<size_t>(c.n) * channels * bytes_per_sample;
     const uint8_t* src = pcm + c.first_frame * frame_in_bytes;
     // 1. host -> device: packed PCM (2..3 bytes per sample instead of 4)
     if (ci >= 2) HIP_TRY(h, hipStreamWaitEvent(h->s_in, h->ev_fill[s], 0));  // d_pcm[s] has been consumed
@@ -1289,18 +1303,26 @@ int flacenc_hip_encode_pcm_stereo(flacenc_hip_handle* h, const flacenc_hip_frame
     HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_h2d[s], 0));
     const size_t cstride = (static_cast<size_t>(c.n) + 3) & ~static_cast<size_t>(3);
     rc = flacenc_hip_fill_le_bytes_async(h, static_cast<const uint8_t*>(h->d_pcm[s].ptr),
-                                         static_cast<uint64_t>(c.frames) * c.n, 2, bytes_per_sample, c.frames, c.n,
+                                         static_cast<uint64_t>(c.frames) * c.n, channels, bytes_per_sample, c.frames, c.n,
                                          static_cast<int32_t*>(h->d_samples.ptr), cstride, h->stream);
     if (rc != FLACENC_HIP_OK) return rc;
     HIP_TRY(h, hipEventRecord(h->ev_fill[s], h->stream));
     if (ci >= 2) HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_d2h[s], 0));  // d_cont[s] has been copied out
-    const size_t cbound = (flacenc_hip_stereo_frame_bytes_bound(c.n, bits_per_sample) + 15) & ~static_cast<size_t>(15);
+    const size_t cbound = ((stereo ? flacenc_hip_stereo_frame_bytes_bound(c.n, bits_per_sample)
+                                   : flacenc_hip_frame_bytes_bound(channels, c.n, bits_per_sample)) + 15) & ~static_cast<size_t>(15);
     uint32_t* dlen = static_cast<uint32_t*>(h->d_plen[s].ptr);
-    rc = flacenc_hip_encode_pack_stereo_frames_async(
-        h, cfg, static_cast<const int32_t*>(h->d_samples.ptr), c.frames, c.n, cstride, bits_per_sample, sample_rate,
-        first_frame_number + static_cast<uint32_t>(c.first_frame) * frame_number_step, frame_number_step,
-        static_cast<flacenc_hip_stereo_frame_result*>(h->d_results.ptr), static_cast<uint8_t*>(h->d_pack[s].ptr), cbound,
-        dlen, h->stream);
+    const uint32_t number = first_frame_number + static_cast<uint32_t>(c.first_frame) * frame_number_step;
+    if (stereo) {
+      rc = flacenc_hip_encode_pack_stereo_frames_async(
+          h, cfg, static_cast<const int32_t*>(h->d_samples.ptr), c.frames, c.n, cstride, bits_per_sample, sample_rate,
+          number, frame_number_step, static_cast<flacenc_hip_stereo_frame_result*>(h->d_results.ptr),
+          static_cast<uint8_t*>(h->d_pack[s].ptr), cbound, dlen, h->stream);
+    } else {  // Independent(channels) frames, src/coding.rs:537-541
+      rc = flacenc_hip_encode_pack_frames_async(
+          h, cfg, static_cast<const int32_t*>(h->d_samples.ptr), c.frames, channels, c.n, cstride, bits_per_sample,
+          sample_rate, number, frame_number_step, static_cast<flacenc_hip_channel_result*>(h->d_results.ptr),
+          static_cast<uint8_t*>(h->d_pack[s].ptr), cbound, dlen, h->stream);
+    }
     if (rc != FLACENC_HIP_OK) return rc;
     uint64_t* soff = static_cast<uint64_t*>(h->d_poff[s].ptr);
     uint64_t* doff = soff + c.frames;

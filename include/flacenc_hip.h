@@ -481,7 +481,14 @@ int flacenc_hip_encode_pcm_stereo(flacenc_hip_handle* h, const flacenc_hip_frame
                                   uint32_t block_size, uint32_t sample_rate, uint32_t first_frame_number,
                                   uint32_t frame_number_step, uint8_t* out, size_t out_capacity, uint32_t* out_len,
                                   uint64_t* out_total);
-/* page-locked host memory for the call above (NULL on failure) */
+/* The same for any channel count 1..=8 (samples interleaved c0 c1 .. c0 c1 ..): 2 channels as above, other
+ * counts as Independent(channels) frames (src/coding.rs:537-541: flacenc_hip_encode_pack_frames_async). */
+int flacenc_hip_encode_pcm(flacenc_hip_handle* h, const flacenc_hip_frame_config* cfg, const uint8_t* pcm,
+                           uint64_t total_samples, uint32_t channels, uint32_t bytes_per_sample,
+                           uint32_t bits_per_sample, uint32_t block_size, uint32_t sample_rate,
+                           uint32_t first_frame_number, uint32_t frame_number_step, uint8_t* out, size_t out_capacity,
+                           uint32_t* out_len, uint64_t* out_total);
+/* page-locked host memory for the calls above (NULL on failure) */
 void* flacenc_hip_host_alloc(size_t bytes);
 void flacenc_hip_host_free(void* p);
 

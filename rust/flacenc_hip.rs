@@ -126,6 +126,12 @@ extern "C" {
         bits_per_sample: u32, block_size: u32, sample_rate: u32, first_frame_number: u32, frame_number_step: u32,
         out: *mut u8, out_capacity: usize, out_len: *mut u32, out_total: *mut u64,
     ) -> c_int;
+    /// The same for 1..=8 interleaved channels (2: stereo decision; others: Independent(n) frames).
+    pub fn flacenc_hip_encode_pcm(
+        h: *mut Handle, cfg: *const FrameConfig, pcm: *const u8, total_samples: u64, channels: u32,
+        bytes_per_sample: u32, bits_per_sample: u32, block_size: u32, sample_rate: u32, first_frame_number: u32,
+        frame_number_step: u32, out: *mut u8, out_capacity: usize, out_len: *mut u32, out_total: *mut u64,
+    ) -> c_int;
     pub fn flacenc_hip_host_alloc(bytes: usize) -> *mut core::ffi::c_void;
     pub fn flacenc_hip_host_free(p: *mut core::ffi::c_void);
     pub fn flacenc_hip_stereo_qlpc_batch(

@@ -101,3 +101,27 @@ def test_record_wire_format_is_lossless(handle, n, order):
     assert wire.shape == (7, shard.wire_record_bytes(n)) and wire.shape[1] < 752
     assert torch.equal(shard.records_from_wire(wire, n), rec)
     assert int(res["lpc"]["rice_order"].max()) <= int(np.log2(shard.finest_partitions(n)))
+
+
+@pytest.mark.parametrize("channels,F", [(1, 5), (3, 4), (8, 1100)])
+def test_stream_path_for_independent_channel_frames(handle, channels, F):
+    """flacenc_hip_encode_pcm for mono / multi-channel streams (BASELINE configs[3] is the 8-channel case):
+    bytes equal to encode_frames + pack_frames of the same frames, short tail block included."""
+    n, bps = 4096, 16
+    frames = _capi.sigen_frames(F, channels, n, bps, 50.0, 0.3, 0.05, seed=900 + channels, nthreads=4)
+    tail = frames[-1][:, :777]
+    cfg = _capi.make_frame_config(_capi.make_config(lpc_order=10), use_fixed=True)
+    inter = np.concatenate([np.ascontiguousarray(frames[:-1].transpose(0, 2, 1)).reshape(-1, channels), tail.T])
+    pcm = np.ascontiguousarray(inter.astype("<i4").view(np.uint8).reshape(-1, channels, 4)[:, :, :2]).reshape(-1)
+    out, lens = handle.encode_pcm(pcm, channels, cfg, 2, bps, n, 48000)
+    assert lens.size == F
+    k = min(F - 1, 40)
+    res, resid = handle.encode_frames(frames[:k], bps, cfg)
+    want = handle.pack_frames(frames[:k], res, resid, bps, 48000)
+    assert lens[:k].tolist() == [len(b) for b in want]
+    assert out[: int(lens[:k].astype(np.int64).sum())].tobytes() == b"".join(want)
+    tres, tresid = handle.encode_frames(np.ascontiguousarray(tail[None]), bps, cfg)
+    twant = handle.pack_frames(np.ascontiguousarray(tail[None]), tres, tresid, bps, 48000, first_frame_number=F - 1)
+    assert out[out.size - int(lens[-1]):].tobytes() == twant[0]
+    fr = flac_parse.parse_frame(twant[0], stream_bps=bps, stream_rate=48000)
+    assert fr["number"] == F - 1 and fr["block_size"] == 777 and np.array_equal(fr["channels"], tail)

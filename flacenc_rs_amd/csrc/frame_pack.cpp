@@ -88,9 +88,18 @@ __device__ __forceinline__ void frame_pack_body(const FramePackArgs& a, const Vi
   __shared__ uint32_t scan_scratch[4];
   __shared__ uint32_t crc_part[kPackThreads / 64];
   __shared__ uint8_t rice_p[FLACENC_HIP_MAX_RICE_PARTITIONS];
-  __shared__ uint16_t crc_tab[256];  // CRC-16 of the single byte i
+  // slicing-by-4 tables: crc_tab[k][b] = CRC-16 of byte b followed by k zero bytes
+  __shared__ uint16_t crc_tab[4][256];
   const int tid = threadIdx.x;
-  crc_tab[tid] = (uint16_t)crc16_byte(0u, (uint32_t)tid);
+  {
+    uint32_t c = crc16_byte(0u, (uint32_t)tid);
+    crc_tab[0][tid] = (uint16_t)c;
+#pragma unroll
+    for (int k = 1; k < 4; ++k) {
+      c = crc16_byte(c, 0u);
+      crc_tab[k][tid] = (uint16_t)c;
+    }
+  }
   const int n = (int)a.block_size;
 
   for (uint32_t i = tid; i < a.lds_words / 4u; i += kPackThreads)
@@ -251,9 +260,27 @@ __device__ __forceinline__ void frame_pack_body(const FramePackArgs& a, const Vi
     if (after < body_bytes) {
       const uint32_t hi = body_bytes - after;
       const uint32_t lo = hi > per ? hi - per : 0u;
-      for (uint32_t i = lo; i < hi; ++i) {
-        const uint32_t byte = (words[i >> 2] >> (24u - 8u * (i & 3u))) & 0xFFu;
-        crc = ((crc << 8) & 0xFFFFu) ^ crc_tab[(crc >> 8) ^ byte];
+      // Four bytes per step (slicing-by-4: one level of dependent table look-ups per word instead of
+      // four).  The slice ends at byte hi; it is walked in 4-byte chunks [hi - 4m, hi) from the front,
+      // and bytes in front of lo are masked to zero -- with the register still 0 there, leading zero
+      // bytes leave a CRC with init 0 unchanged.  A chunk is assembled from two big-endian buffer words.
+      const uint32_t nchunks = (hi - lo + 3u) >> 2;
+      const uint32_t sh = (hi & 3u) * 8u;  // chunk start = hi - 4 (m - j) has the byte phase of hi
+      const uint32_t w_end = hi >> 2;      // word holding byte hi (its first `hi & 3` bytes are the chunk's tail)
+      uint32_t prev = (w_end >= nchunks) ? words[w_end - nchunks] : 0u;
+      for (uint32_t j = 0; j < nchunks; ++j) {
+        const uint32_t cur = words[w_end - nchunks + j + 1u];  // (one word past body_bytes at most: inside the buffer)
+        // bytes [pos, pos + 4) with pos = 4 (w_end - nchunks + j) + (hi & 3)
+        uint32_t x = sh ? ((prev << sh) | (cur >> (32u - sh))) : prev;
+        if (j == 0) {
+          const uint32_t pos = hi - 4u * nchunks;      // may be < lo (or wrap below 0): mask those bytes
+          const uint32_t skip = lo - pos;              // 0..3 leading bytes that are not part of the slice
+          x = skip ? (x & (0xFFFFFFFFu >> (8u * skip))) : x;
+        }
+        x ^= crc << 16;
+        crc = (uint32_t)crc_tab[3][x >> 24] ^ crc_tab[2][(x >> 16) & 0xFFu] ^ crc_tab[1][(x >> 8) & 0xFFu] ^
+              crc_tab[0][x & 0xFFu];
+        prev = cur;
       }
       crc = gf_mulmod16(crc, a.crc_pow[k_after & 15u]);
       crc = gf_mulmod16(crc, a.crc_pow[16u + (k_after >> 4)]);

@@ -18,12 +18,14 @@ ap.add_argument("--frames", type=int, default=8192)
 ap.add_argument("--lpc-order", type=int, default=8)
 ap.add_argument("--block-size", type=int, default=4096)
 ap.add_argument("--bps", type=int, default=16)
+ap.add_argument("--signal", default="200,0.4,0.4", help="sine period, sine amplitude, noise amplitude")
 ap.add_argument("--use-fixed", action="store_true", help="fixed-LPC candidate on: its selection and "
                 "coding pass land in the 'acorr' slot (stamps are rewritten by the last candidate pass)")
 args = ap.parse_args()
 n, F = args.block_size, args.frames
 dev = torch.device("cuda", 0)
-host = _capi.sigen_frames(F, 2, n, args.bps, 200.0, 0.4, 0.4, seed=0xF1AC0001)
+sp, sa, na = (float(v) for v in args.signal.split(","))
+host = _capi.sigen_frames(F, 2, n, args.bps, sp, sa, na, seed=0xF1AC0001)
 x = torch.from_numpy(host).to(dev)
 results = torch.empty((F, 752), dtype=torch.uint8, device=dev)
 residual = torch.empty((F * 2, n), dtype=torch.int32, device=dev)

@@ -1284,6 +1284,17 @@ int flacenc_hip_encode_pcm(flacenc_hip_handle* h, const flacenc_hip_frame_config
     return FLACENC_HIP_OK;
   };
 
+  // an error half way leaves work in flight on three streams: drain them before handing the handle back
+  struct Drain {
+    flacenc_hip_handle* h;
+    bool armed = true;
+    ~Drain() {
+      if (!armed) return;
+      (void)hipStreamSynchronize(h->s_in);
+      (void)hipStreamSynchronize(h->stream);
+      (void)hipStreamSynchronize(h->s_out);
+    }
+  } drain_on_error{h};
   for (size_t ci = 0; ci < chunks.size(); ++ci) {
     const Chunk& c = chunks[ci];
     const int s = static_cast<int>(ci & 1);
@@ -1339,6 +1350,7 @@ int flacenc_hip_encode_pcm(flacenc_hip_handle* h, const flacenc_hip_frame_config
   if ((rc = drain(chunks.size() - 1)) != FLACENC_HIP_OK) return rc;
   HIP_TRY(h, hipStreamSynchronize(h->s_out));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
+  drain_on_error.armed = false;
   *out_total = written;
   return FLACENC_HIP_OK;
 }

@@ -125,3 +125,15 @@ def test_stream_path_for_independent_channel_frames(handle, channels, F):
     assert out[out.size - int(lens[-1]):].tobytes() == twant[0]
     fr = flac_parse.parse_frame(twant[0], stream_bps=bps, stream_rate=48000)
     assert fr["number"] == F - 1 and fr["block_size"] == 777 and np.array_equal(fr["channels"], tail)
+
+
+def test_small_output_buffer_is_an_error_and_the_handle_survives(handle):
+    n, bps, F = 4096, 16, 900
+    frames = _capi.sigen_frames(F, 2, n, bps, 200.0, 0.4, 0.4, seed=11, nthreads=4)
+    cfg = _capi.make_frame_config(_capi.make_config(lpc_order=8), use_fixed=False)
+    pcm = pack_pcm(frames, 2)
+    with pytest.raises(_capi.FlacencHipError) as ei:
+        handle.encode_pcm_stereo(pcm, cfg, 2, bps, n, 44100, out=np.empty(100000, np.uint8))
+    assert ei.value.code == _capi.ERR_BAD_ARGUMENT
+    out, lens = handle.encode_pcm_stereo(pcm, cfg, 2, bps, n, 44100)   # same handle, right away
+    assert lens.size == F and int(lens.astype(np.int64).sum()) == out.size

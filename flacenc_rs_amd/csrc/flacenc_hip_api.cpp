@@ -1164,8 +1164,7 @@ bool is_pinned(const void* p) {
   return attr.type == hipMemoryTypeHost;
 }
 
-int ensure_pinned(flacenc_hip_handle* h, void** slot, size_t* cap_field, size_t bytes, bool both) {
-  (void)both;
+int ensure_pinned(flacenc_hip_handle* h, void** slot, size_t* cap_field, size_t bytes) {
   if (bytes <= *cap_field && slot[0] && slot[1]) return FLACENC_HIP_OK;
   for (int i = 0; i < 2; ++i) {
     if (slot[i]) HIP_TRY(h, hipHostFree(slot[i]));
@@ -1232,9 +1231,9 @@ int flacenc_hip_encode_pcm(flacenc_hip_handle* h, const flacenc_hip_frame_config
   const bool in_pinned = is_pinned(pcm), out_pinned = is_pinned(out);
   int rc;
   const size_t dstride = (static_cast<size_t>(block_size) + 3) & ~static_cast<size_t>(3);
-  if (!in_pinned && (rc = ensure_pinned(h, h->pin_in, &h->pin_in_cap, chunk * frame_in_bytes, true)) != FLACENC_HIP_OK) return rc;
-  if (!out_pinned && (rc = ensure_pinned(h, h->pin_out, &h->pin_out_cap, chunk * ostride, true)) != FLACENC_HIP_OK) return rc;
-  if ((rc = ensure_pinned(h, h->pin_meta, &h->pin_meta_cap, chunk * 4 + 16, true)) != FLACENC_HIP_OK) return rc;
+  if (!in_pinned && (rc = ensure_pinned(h, h->pin_in, &h->pin_in_cap, chunk * frame_in_bytes)) != FLACENC_HIP_OK) return rc;
+  if (!out_pinned && (rc = ensure_pinned(h, h->pin_out, &h->pin_out_cap, chunk * ostride)) != FLACENC_HIP_OK) return rc;
+  if ((rc = ensure_pinned(h, h->pin_meta, &h->pin_meta_cap, chunk * 4 + 16)) != FLACENC_HIP_OK) return rc;
   if ((rc = ensure(h, h->d_samples, chunk * channels * dstride * 4)) != FLACENC_HIP_OK) return rc;
   if ((rc = ensure(h, h->d_results, chunk * (stereo ? sizeof(flacenc_hip_stereo_frame_result)
                                                      : channels * sizeof(flacenc_hip_channel_result)))) != FLACENC_HIP_OK)

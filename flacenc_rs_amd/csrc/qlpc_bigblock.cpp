@@ -374,7 +374,6 @@ __global__ void __launch_bounds__(256, 3) bigblock_residual_kernel(QlpcKernelArg
   const bool literal = !(maxu < (1u << 26));
 
   uint32_t pk[K][7], pk7[K / 2], pk8 = 0xFFFFFFFFu;
-  uint32_t sat_top = 0;
   auto search = [&](uint32_t p_lo) {
 #pragma unroll
     for (int k = 0; k < K; ++k)
@@ -482,7 +481,6 @@ __global__ void __launch_bounds__(256, 3) bigblock_residual_kernel(QlpcKernelArg
       totals();
     }
   }
-  (void)sat_top;
   const bool saturated = (sat_levels >> bestl) & 1u;
   const int rice_order = (6 + LK) - bestl;
   const uint32_t best_parts = 1u << rice_order;

@@ -491,6 +491,39 @@ class HipContext {
   flacenc_hip_handle* h_ = nullptr;
 };
 
+// Staging memory for the host-pointer entry points: page-locked (flacenc_hip_host_alloc), so that the
+// library's copies are plain DMA transfers instead of going through the driver's bounce buffers -- the
+// role of the reference's reused FrameBuf pool (src/par.rs:364-368).  Falls back to ordinary memory if
+// page-locked memory cannot be had.
+template <class T>
+class PinnedBuffer {
+ public:
+  explicit PinnedBuffer(size_t count) : count_(count) {
+    if (count == 0) return;
+    ptr_ = static_cast<T*>(flacenc_hip_host_alloc(count * sizeof(T)));
+    if (ptr_ == nullptr) {
+      fallback_.resize(count);
+      ptr_ = fallback_.data();
+    }
+  }
+  ~PinnedBuffer() {
+    if (ptr_ != nullptr && fallback_.empty()) flacenc_hip_host_free(ptr_);
+  }
+  PinnedBuffer(const PinnedBuffer&) = delete;
+  PinnedBuffer& operator=(const PinnedBuffer&) = delete;
+  T* data() { return ptr_; }
+  const T* data() const { return ptr_; }
+  T& operator[](size_t i) { return ptr_[i]; }
+  const T& operator[](size_t i) const { return ptr_[i]; }
+  T* begin() { return ptr_; }
+  size_t size() const { return count_; }
+
+ private:
+  T* ptr_ = nullptr;
+  size_t count_ = 0;
+  std::vector<T> fallback_;
+};
+
 namespace detail {
 inline flacenc_hip_qlpc_config to_abi(const config::SubFrameCoding& c) {
   flacenc_hip_qlpc_config o{};
@@ -599,8 +632,6 @@ inline std::vector<component::Frame> encode_frame_run(const config::Encoder& con
     size_t f1 = f0;
     while (f1 < bufs.size() && bufs[f1]->filled_size() == n) ++f1;
     const size_t nf = f1 - f0;
-    std::vector<flacenc_hip_subframe_params> recs(nf * per_frame);
-    std::vector<int32_t> resid(nf * per_frame * n);
     const bool use_gpu = sc.use_lpc && n >= constant::MIN_BLOCK_SIZE_FOR_PREDICTION;
     // 2a. stereo: try the entry point that also runs the controller on the GPU
     //     (flacenc_hip_encode_stereo_frames: block 4096, order <= 12); its records are turned
@@ -608,7 +639,7 @@ inline std::vector<component::Frame> encode_frame_run(const config::Encoder& con
     //     host-side controller -- same result either way (tests/test_gpu_parity.py).
     const bool fused_ok = (sc.use_lpc || sc.use_fixed) && n >= constant::MIN_BLOCK_SIZE_FOR_PREDICTION;
     if (fused_ok && stereo) {
-      std::vector<int32_t> staged(nf * 2 * n);
+      PinnedBuffer<int32_t> staged(nf * 2 * n);
       for (size_t f = 0; f < nf; ++f)
         for (size_t c = 0; c < 2; ++c)
           std::memcpy(&staged[(f * 2 + c) * n], bufs[f0 + f]->channel_slice(c), n * sizeof(int32_t));
@@ -625,14 +656,14 @@ inline std::vector<component::Frame> encode_frame_run(const config::Encoder& con
       fc.use_rightside = config.stereo_coding.use_rightside;
       fc.use_midside = config.stereo_coding.use_midside;
       std::vector<flacenc_hip_stereo_frame_result> fr(nf);
-      std::vector<int32_t> resid2(nf * 2 * n);
+      PinnedBuffer<int32_t> resid2(nf * 2 * n);
       const int rc = flacenc_hip_encode_stereo_frames(gpu.get(), &fc, staged.data(), nf, static_cast<uint32_t>(n), n,
                                                       static_cast<uint32_t>(bps), fr.data(), resid2.data(), n,
                                                       FLACENC_HIP_MEM_HOST);
       if (rc == FLACENC_HIP_OK) {
         // Frame::write on the GPU too (bitrepr.rs:289-319): the frames' final bytes
         const size_t ostride = flacenc_hip_stereo_frame_bytes_bound(static_cast<uint32_t>(n), static_cast<uint32_t>(bps));
-        std::vector<uint8_t> packed(nf * ostride);
+        PinnedBuffer<uint8_t> packed(nf * ostride);
         std::vector<uint32_t> packed_len(nf);
         const int prc = flacenc_hip_pack_stereo_frames(
             gpu.get(), staged.data(), nf, static_cast<uint32_t>(n), n, fr.data(), resid2.data(), n,
@@ -687,7 +718,7 @@ inline std::vector<component::Frame> encode_frame_run(const config::Encoder& con
     // 2a'. mono / multi-channel: encode_frame for Independent(n) on the GPU (flacenc_hip_encode_frames)
     //      and the frames' bytes (flacenc_hip_pack_frames)
     if (fused_ok && !stereo) {
-      std::vector<int32_t> staged(nf * nch * n);
+      PinnedBuffer<int32_t> staged(nf * nch * n);
       for (size_t f = 0; f < nf; ++f)
         for (size_t c = 0; c < nch; ++c)
           std::memcpy(&staged[(f * nch + c) * n], bufs[f0 + f]->channel_slice(c), n * sizeof(int32_t));
@@ -701,14 +732,14 @@ inline std::vector<component::Frame> encode_frame_run(const config::Encoder& con
                                                                                  : FLACENC_HIP_ORDERSEL_APPROXENT;
       fc.fixed_partitions = static_cast<uint32_t>(sc.fixed.order_sel.partitions);
       std::vector<flacenc_hip_channel_result> cr(nf * nch);
-      std::vector<int32_t> resid2(nf * nch * n);
+      PinnedBuffer<int32_t> resid2(nf * nch * n);
       const int rc = flacenc_hip_encode_frames(gpu.get(), &fc, staged.data(), nf, static_cast<uint32_t>(nch),
                                                static_cast<uint32_t>(n), n, static_cast<uint32_t>(bps), cr.data(),
                                                resid2.data(), n, FLACENC_HIP_MEM_HOST);
       if (rc == FLACENC_HIP_OK) {
         const size_t ostride = flacenc_hip_frame_bytes_bound(static_cast<uint32_t>(nch), static_cast<uint32_t>(n),
                                                              static_cast<uint32_t>(bps));
-        std::vector<uint8_t> packed(nf * ostride);
+        PinnedBuffer<uint8_t> packed(nf * ostride);
         std::vector<uint32_t> packed_len(nf);
         const int prc = flacenc_hip_pack_frames(gpu.get(), staged.data(), nf, static_cast<uint32_t>(nch),
                                                 static_cast<uint32_t>(n), n, cr.data(), resid2.data(), n,
@@ -753,8 +784,10 @@ inline std::vector<component::Frame> encode_frame_run(const config::Encoder& con
         throw error::EncodeError(error::EncodeError::Device, flacenc_hip_last_error(gpu.get()));
     }
     // 2b. the LPC candidates of every channel (stereo: L, R, M, S) in one batch
+    std::vector<flacenc_hip_subframe_params> recs(use_gpu ? nf * per_frame : 0);
+    PinnedBuffer<int32_t> resid(use_gpu ? nf * per_frame * n : 0);
     if (use_gpu) {
-      std::vector<int32_t> staged(nf * nch * n);
+      PinnedBuffer<int32_t> staged(nf * nch * n);
       for (size_t f = 0; f < nf; ++f)
         for (size_t c = 0; c < nch; ++c)
           std::memcpy(&staged[(f * nch + c) * n], bufs[f0 + f]->channel_slice(c), n * sizeof(int32_t));
@@ -782,7 +815,7 @@ inline std::vector<component::Frame> encode_frame_run(const config::Encoder& con
       frecs.resize(nf * per_frame);
       fresid.resize(nf * per_frame * n);
       fkeys.resize(nf * per_frame);
-      std::vector<int32_t> staged(nf * nch * n);
+      PinnedBuffer<int32_t> staged(nf * nch * n);
       for (size_t f = 0; f < nf; ++f)
         for (size_t c = 0; c < nch; ++c)
           std::memcpy(&staged[(f * nch + c) * n], bufs[f0 + f]->channel_slice(c), n * sizeof(int32_t));

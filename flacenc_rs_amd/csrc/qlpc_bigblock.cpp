@@ -179,18 +179,24 @@ __global__ void __launch_bounds__(256, FLACENC_BIG_ACORR_OCC) bigblock_acorr_ker
         for (int i = 0; i < 4; ++i) {
           conv8(&dw[HP], tl + 16 * i);
           conv8(&dw[HP + 8], tl + 16 * i + 8);
+          // common lower bound t = P for every lag (lpc.rs:542): only the block's first 32 samples -- chunks
+          // 0 and 1 of pass 0 -- can lie below it; every other chunk runs the body without the selects
+          auto body = [&](auto masked_tag) {
+            constexpr bool MASKED = decltype(masked_tag)::value;
 #pragma unroll
-          for (int kk = 0; kk < 16; ++kk) {
-            double cur = dw[HP + kk];
-            // common lower bound t = P for every lag (lpc.rs:542): only the block's first 32 samples
-            cur = (k == 0 && tl + 16 * i + kk < P) ? 0.0 : cur;
+            for (int kk = 0; kk < 16; ++kk) {
+              double cur = dw[HP + kk];
+              if (MASKED) cur = (tl + 16 * i + kk < P) ? 0.0 : cur;
 #pragma unroll
-            for (int j = 0; j < NL; ++j) {
-              const int idx = HP + kk - (lag0 + j);  // (lag 33 of the 3 x 11 split does not exist: idx < 0 never read)
-              const double lagged = idx >= 0 ? dw[idx >= 0 ? idx : 0] : 0.0;
-              acc[j] = kk == 0 ? __builtin_fma(cur, lagged, 0.0) : __builtin_fma(cur, lagged, acc[j]);
+              for (int j = 0; j < NL; ++j) {
+                const int idx = HP + kk - (lag0 + j);  // (lags beyond HP do not exist: idx < 0 is never read)
+                const double lagged = idx >= 0 ? dw[idx >= 0 ? idx : 0] : 0.0;
+                acc[j] = kk == 0 ? __builtin_fma(cur, lagged, 0.0) : __builtin_fma(cur, lagged, acc[j]);
+              }
             }
-          }
+          };
+          if (k == 0 && i < 2) body(std::true_type{});
+          else body(std::false_type{});
           // in-lane levels of the balanced tree over the chunk index: (c0 + c1) + (c2 + c3)
           if (i == 0) {
 #pragma unroll

@@ -16,10 +16,18 @@
 #include "frame_bits.h"
 #include "lds_opt_in.h"
 
+#ifndef FLACENC_DPP
+#define FLACENC_DPP(v, ctrl, rowmask) \
+  ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), (ctrl), (rowmask), 0xF, false))
+#endif
+
 namespace flacenc_hip {
 namespace {
 
 constexpr int kPackThreads = 256;
+#ifndef FLACENC_PACK_OCC
+#define FLACENC_PACK_OCC 8  // waves per SIMD asked of the register allocator (<= 64 VGPRs)
+#endif
 
 // block-wide exclusive prefix sum of one value per thread (256 threads); `total` gets the sum
 __device__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* scratch, int tid, uint32_t* total) {
@@ -37,6 +45,156 @@ __device__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* scratch, int tid,
   *total = scratch[0] + scratch[1] + scratch[2] + scratch[3];
   __syncthreads();
   return base + incl - v;
+}
+
+// slicing-by-4 tables of CRC_16_UMTS, made at compile time: t[b][k] = CRC-16 of byte b followed by k zero
+// bytes (one 8-byte load per thread brings them into LDS)
+struct Crc16Tables {
+  uint16_t t[256][4];
+};
+constexpr uint32_t crc16_step(uint32_t crc, uint32_t byte) {
+  crc ^= byte << 8;
+  for (int b = 0; b < 8; ++b) crc = (crc & 0x8000u) ? ((crc << 1) ^ 0x8005u) & 0xFFFFu : (crc << 1) & 0xFFFFu;
+  return crc;
+}
+constexpr Crc16Tables make_crc16_tables() {
+  Crc16Tables r{};
+  for (uint32_t b = 0; b < 256; ++b) {
+    uint32_t c = crc16_step(0u, b);
+    r.t[b][0] = (uint16_t)c;
+    for (int k = 1; k < 4; ++k) {
+      c = crc16_step(c, 0u);
+      r.t[b][k] = (uint16_t)c;
+    }
+  }
+  return r;
+}
+__device__ const Crc16Tables kCrc16Tables = make_crc16_tables();
+
+// OR `c` (len <= 31 bits, K = 64 - len) into the bit buffer so that it starts at bit s: the 64-bit window
+// over words s / 32 and s / 32 + 1 takes it whole (the second OR adds zero when it does not straddle)
+__device__ __forceinline__ void or_code(uint32_t* words, uint32_t s, uint32_t c, uint32_t K) {
+  const unsigned long long v = (unsigned long long)c << ((K - (s & 31u)) & 63u);
+  uint32_t* const w = words + (s >> 5);
+  atomicOr(w, (uint32_t)(v >> 32));
+  atomicOr(w + 1, (uint32_t)v);
+}
+
+// Residual::write (bitrepr.rs:550-597) for blocks whose partitions are multiples of 16 samples: rounds of
+// 4096 samples, 16 per thread.  MASKED: some lane of the wave holds warm-up samples (t < order), which
+// emit nothing (their slots were zeroed on load: quotient 0).
+template <bool MASKED>
+__device__ __forceinline__ void rice_emit16(uint32_t* words, const uint32_t (&uc)[16], uint32_t p, uint32_t pos,
+                                            int nskip) {
+  const uint32_t bit = 1u << p, mask = bit - 1u, L = p + 1u, K = 64u - L;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const uint32_t u = uc[k];
+    uint32_t code = (u & mask) | bit;
+    uint32_t len = L;
+    if (MASKED) {
+      code = k >= nskip ? code : 0u;
+      len = k >= nskip ? L : 0u;
+    }
+    const uint32_t s = pos + (u >> p);  // unary quotient: zeros
+    or_code(words, s, code, K);
+    pos = s + len;
+  }
+}
+
+// Scratch of the one-barrier block scans: two alternating buffers of (wave total, wave flag) pairs, so a
+// scan's writes cannot overtake the reads of the scan before the previous barrier.
+struct ScanScratch {
+  uint32_t total[2][4];
+  uint32_t flag[2][4];
+};
+
+// One thread = one run of 16 samples inside one partition; `params` is the subframe's Rice parameter
+// list in global memory (each thread needs exactly one entry per round).  Writes the 6-bit residual header
+// too (it needs RICE2 = any parameter > 14, which rides on the first round's scan barrier).
+__device__ __forceinline__ void rice_runs16(uint32_t* words, const int32_t* __restrict__ e, int n, uint32_t order,
+                                            uint32_t porder, const uint8_t* __restrict__ params, uint32_t hdr_pos,
+                                            ScanScratch* ss, uint32_t* scan_id, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+  const uint32_t part_len = (uint32_t)n >> porder;
+  const float inv_pl16 = 1.0f / (float)(part_len >> 4);
+  // any parameter above 14 switches the whole residual to 5-bit parameters (bitrepr.rs:540-543, 556-562)
+  uint32_t big = (uint32_t)tid < (1u << porder) ? (params[tid] > 14 ? 1u : 0u) : 0u;
+  big = __any((int)big) ? 1u : 0u;
+  uint32_t pbits = 4u;
+  uint32_t round_base = hdr_pos + 6u;
+  for (int r0 = 0; r0 < n; r0 += 16 * kPackThreads) {
+    const int t_lo = r0 + 16 * tid;
+    const bool live = t_lo < n;
+    uint32_t uc[16];
+    uint32_t p = 0, nstarts = 0;
+    bool starts = false;
+    int nskip = 0;
+    if (live) {
+      if ((reinterpret_cast<uintptr_t>(e + t_lo) & 15) == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int4 v = *reinterpret_cast<const int4*>(e + t_lo + 4 * k);
+          uc[4 * k + 0] = zigzag32(v.x);
+          uc[4 * k + 1] = zigzag32(v.y);
+          uc[4 * k + 2] = zigzag32(v.z);
+          uc[4 * k + 3] = zigzag32(v.w);
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) uc[k] = zigzag32(e[t_lo + k]);
+      }
+      // t_lo / part_len: both are multiples of 16 below 2^16, so the quotient of the sixteenths is exact in
+      // f32 with half a step of margin
+      const uint32_t qi = (uint32_t)(((float)(t_lo >> 4) + 0.5f) * inv_pl16);
+      p = params[qi & 255u];
+      starts = qi * part_len == (uint32_t)t_lo;  // the partition's parameter goes first
+      nstarts = qi + (starts ? 0u : 1u);          // partitions that began in front of this run
+      nskip = (int)order - t_lo;
+      nskip = nskip < 0 ? 0 : (nskip > 16 ? 16 : nskip);
+      if (nskip > 0) {  // (whatever the producer left in the warm-up slots: they carry no quotient)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) uc[k] = k >= nskip ? uc[k] : 0u;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) uc[k] = 0u;
+    }
+    uint32_t qsum = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) qsum += uc[k] >> p;
+    const uint32_t my_bits = live ? qsum + (uint32_t)(16 - nskip) * (p + 1u) : 0u;
+    // block scan with one barrier: DPP scan inside the wave, wave totals through LDS
+    uint32_t incl = my_bits;
+    incl += FLACENC_DPP(incl, 0x111, 0xF);
+    incl += FLACENC_DPP(incl, 0x112, 0xF);
+    incl += FLACENC_DPP(incl, 0x114, 0xF);
+    incl += FLACENC_DPP(incl, 0x118, 0xF);
+    incl += FLACENC_DPP(incl, 0x142, 0xA);
+    incl += FLACENC_DPP(incl, 0x143, 0xC);
+    const uint32_t buf = (*scan_id)++ & 1u;
+    if (lane == 63) {
+      ss->total[buf][wave] = incl;
+      ss->flag[buf][wave] = big;
+    }
+    __syncthreads();
+    const uint32_t t0 = ss->total[buf][0], t1 = ss->total[buf][1], t2 = ss->total[buf][2], t3 = ss->total[buf][3];
+    if (r0 == 0) {
+      const uint32_t rice2 = ss->flag[buf][0] | ss->flag[buf][1] | ss->flag[buf][2] | ss->flag[buf][3];
+      pbits = rice2 ? 5u : 4u;
+      if (tid == 192) put_bits(words, hdr_pos, (rice2 << 4) | porder, 6u);
+    }
+    const uint32_t wave_base = (wave > 0 ? t0 : 0u) + (wave > 1 ? t1 : 0u) + (wave > 2 ? t2 : 0u);
+    uint32_t pos = round_base + wave_base + (incl - my_bits) + pbits * nstarts;
+    round_base += t0 + t1 + t2 + t3;
+    if (live) {
+      const uint32_t lead = starts ? pbits : 0u;
+      or_code(words, pos, starts ? p : 0u, 64u - lead);
+      pos += lead;
+      if (__any(nskip > 0)) rice_emit16<true>(words, uc, p, pos, nskip);
+      else rice_emit16<false>(words, uc, p, pos, nskip);
+    }
+  }
 }
 
 // What the packer needs to know about one frame, for the two kinds of decision records.
@@ -82,24 +240,26 @@ struct ChannelView {  // flacenc_hip_channel_result x channels: Independent(n)
   __device__ int32_t sample(int c, int t) const { return x[(size_t)c * stride + t]; }
 };
 
-template <class View>
+// ALIGNED: the block size is a multiple of 4096, so every partition order up to 8 gives partitions that are
+// multiples of 16 samples and the walk over arbitrary partition boundaries is not compiled in.
+template <bool ALIGNED, class View>
 __device__ __forceinline__ void frame_pack_body(const FramePackArgs& a, const View& view, uint32_t f) {
   extern __shared__ __attribute__((aligned(16))) uint32_t words[];
   __shared__ uint32_t scan_scratch[4];
+  __shared__ ScanScratch scan_pairs;
   __shared__ uint32_t crc_part[kPackThreads / 64];
   __shared__ uint8_t rice_p[FLACENC_HIP_MAX_RICE_PARTITIONS];
   // slicing-by-4 tables: crc_tab[k][b] = CRC-16 of byte b followed by k zero bytes
   __shared__ uint16_t crc_tab[4][256];
   const int tid = threadIdx.x;
   {
-    uint32_t c = crc16_byte(0u, (uint32_t)tid);
-    crc_tab[0][tid] = (uint16_t)c;
-#pragma unroll
-    for (int k = 1; k < 4; ++k) {
-      c = crc16_byte(c, 0u);
-      crc_tab[k][tid] = (uint16_t)c;
-    }
+    const uint2 row = *reinterpret_cast<const uint2*>(&kCrc16Tables.t[tid][0]);
+    crc_tab[0][tid] = (uint16_t)row.x;
+    crc_tab[1][tid] = (uint16_t)(row.x >> 16);
+    crc_tab[2][tid] = (uint16_t)row.y;
+    crc_tab[3][tid] = (uint16_t)(row.y >> 16);
   }
+  uint32_t scan_id = 0;
   const int n = (int)a.block_size;
 
   for (uint32_t i = tid; i < a.lds_words / 4u; i += kPackThreads)
@@ -156,9 +316,6 @@ __device__ __forceinline__ void frame_pack_body(const FramePackArgs& a, const Vi
         put_bits(words, sub_base + 8u + (uint32_t)t * bps, (uint32_t)sample(t) & bps_mask, bps);
     } else {
       const flacenc_hip_subframe_params* rec = view.rec(c);
-      __syncthreads();  // the previous subframe is done with rice_p
-      rice_p[tid] = rec->rice_params[tid];
-      __syncthreads();
       const uint32_t order = rec->order;
       const uint32_t precision = rec->precision;
       // FixedLpc::write bitrepr.rs:479-487 / Lpc::write :501-527 up to the residual
@@ -179,69 +336,81 @@ __device__ __forceinline__ void frame_pack_body(const FramePackArgs& a, const Vi
       const uint32_t porder = rec->rice_order;
       const uint32_t nparts = 1u << porder;
       const uint32_t part_len = (uint32_t)n >> porder;
-      uint32_t rice2 = 0;
-      for (uint32_t q = tid; q < nparts; q += kPackThreads) rice2 |= rice_p[q] > 14 ? 1u : 0u;
-      rice2 = __syncthreads_or((int)rice2) ? 1u : 0u;
-      const uint32_t pbits = rice2 ? 5u : 4u;
-      if (tid == 192) put_bits(words, sub_base + head_bits, (rice2 << 4) | porder, 6u);
       const int32_t* __restrict__ e = a.residual + view.residual_row(c) * a.residual_stride;
-      // contiguous slice of samples per thread; pass 1 counts its bits, pass 2 writes them.
-      // Up to 16 samples per thread (blocks <= 4096) are held in registers as zig-zag codes.
-      const int per = (n + kPackThreads - 1) / kPackThreads;
-      const int t_lo = tid * per < n ? tid * per : n;
-      const int t_hi = t_lo + per < n ? t_lo + per : n;
-      const bool cached = per <= 16;
-      uint32_t uc[16];
-      if (cached) {
-        const bool vec = per == 16 && t_hi - t_lo == 16 && ((reinterpret_cast<uintptr_t>(e + t_lo) & 15) == 0);
-        if (vec) {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const int4 v = *reinterpret_cast<const int4*>(e + t_lo + 4 * k);
-            uc[4 * k + 0] = zigzag32(v.x);
-            uc[4 * k + 1] = zigzag32(v.y);
-            uc[4 * k + 2] = zigzag32(v.z);
-            uc[4 * k + 3] = zigzag32(v.w);
-          }
-        } else {
-#pragma unroll
-          for (int k = 0; k < 16; ++k) uc[k] = (t_lo + k < t_hi) ? zigzag32(e[t_lo + k]) : 0u;
-        }
-      }
-      const uint32_t q_lo = (uint32_t)t_lo / part_len;
-      // walks the slice once; `emit(t, u, p, starts)` sees every coded sample in order
-      auto walk = [&](auto&& emit) {
-        uint32_t q = q_lo, next = (q_lo + 1u) * part_len, p = rice_p[q_lo & 255u];
-        auto step = [&](uint32_t t, uint32_t u) {
-          if (t == next) {
-            ++q;
-            next += part_len;
-            p = rice_p[q & 255u];
-          }
-          if (t >= order) emit(u, p, q == 0u ? t == order : t == next - part_len);  // max(warmup, offset)
-        };
+      if (ALIGNED || ((n & 15) == 0 && (part_len & 15u) == 0u)) {
+        // Aligned runs: a thread owns 16 consecutive samples of a round of 4096, which lie inside one
+        // partition (its length is a multiple of 16) -- one Rice parameter per thread, no per-sample
+        // partition walk.  A code of p + 1 <= 31 bits at bit offset <= 31 fits a 64-bit window over two
+        // buffer words: one shift and two ORs per sample, no branch.
+        rice_runs16(words, e, n, order, porder, rec->rice_params, sub_base + head_bits, &scan_pairs, &scan_id, tid);
+      } else if (!ALIGNED) {
+        __syncthreads();  // the previous subframe is done with rice_p
+        rice_p[tid] = rec->rice_params[tid];
+        __syncthreads();
+        uint32_t rice2 = 0;
+        for (uint32_t q = tid; q < nparts; q += kPackThreads) rice2 |= rice_p[q] > 14 ? 1u : 0u;
+        rice2 = __syncthreads_or((int)rice2) ? 1u : 0u;
+        const uint32_t pbits = rice2 ? 5u : 4u;
+        if (tid == 192) put_bits(words, sub_base + head_bits, (rice2 << 4) | porder, 6u);
+        const uint32_t res_base = sub_base + head_bits + 6u;
+        // contiguous slice of samples per thread; pass 1 counts its bits, pass 2 writes them.
+        // Up to 16 samples per thread (blocks <= 4096) are held in registers as zig-zag codes.
+        const int per = (n + kPackThreads - 1) / kPackThreads;
+        const int t_lo = tid * per < n ? tid * per : n;
+        const int t_hi = t_lo + per < n ? t_lo + per : n;
+        const bool cached = per <= 16;
+        uint32_t uc[16];
         if (cached) {
-#pragma unroll
-          for (int k = 0; k < 16; ++k)
-            if (t_lo + k < t_hi) step((uint32_t)(t_lo + k), uc[k]);
-        } else {
-          for (int t = t_lo; t < t_hi; ++t) step((uint32_t)t, zigzag32(e[t]));
+          const bool vec = per == 16 && t_hi - t_lo == 16 && ((reinterpret_cast<uintptr_t>(e + t_lo) & 15) == 0);
+          if (vec) {
+  #pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const int4 v = *reinterpret_cast<const int4*>(e + t_lo + 4 * k);
+              uc[4 * k + 0] = zigzag32(v.x);
+              uc[4 * k + 1] = zigzag32(v.y);
+              uc[4 * k + 2] = zigzag32(v.z);
+              uc[4 * k + 3] = zigzag32(v.w);
+            }
+          } else {
+  #pragma unroll
+            for (int k = 0; k < 16; ++k) uc[k] = (t_lo + k < t_hi) ? zigzag32(e[t_lo + k]) : 0u;
+          }
         }
-      };
-      uint32_t my_bits = 0;
-      walk([&](uint32_t u, uint32_t p, bool starts) { my_bits += (starts ? pbits : 0u) + (u >> p) + 1u + p; });
-      uint32_t total;
-      uint32_t pos = sub_base + head_bits + 6u + block_exclusive_scan(my_bits, scan_scratch, tid, &total);
-      walk([&](uint32_t u, uint32_t p, bool starts) {
-        if (starts) {
-          put_bits(words, pos, p, pbits);
-          pos += pbits;
-        }
-        pos += u >> p;  // unary quotient: zeros
-        put_bits(words, pos, (u & ((1u << p) - 1u)) | (1u << p), p + 1u);
-        pos += p + 1u;
-      });
-      (void)total;
+        const uint32_t q_lo = (uint32_t)t_lo / part_len;
+        // walks the slice once; `emit(t, u, p, starts)` sees every coded sample in order
+        auto walk = [&](auto&& emit) {
+          uint32_t q = q_lo, next = (q_lo + 1u) * part_len, p = rice_p[q_lo & 255u];
+          auto step = [&](uint32_t t, uint32_t u) {
+            if (t == next) {
+              ++q;
+              next += part_len;
+              p = rice_p[q & 255u];
+            }
+            if (t >= order) emit(u, p, q == 0u ? t == order : t == next - part_len);  // max(warmup, offset)
+          };
+          if (cached) {
+  #pragma unroll
+            for (int k = 0; k < 16; ++k)
+              if (t_lo + k < t_hi) step((uint32_t)(t_lo + k), uc[k]);
+          } else {
+            for (int t = t_lo; t < t_hi; ++t) step((uint32_t)t, zigzag32(e[t]));
+          }
+        };
+        uint32_t my_bits = 0;
+        walk([&](uint32_t u, uint32_t p, bool starts) { my_bits += (starts ? pbits : 0u) + (u >> p) + 1u + p; });
+        uint32_t total;
+        uint32_t pos = res_base + block_exclusive_scan(my_bits, scan_scratch, tid, &total);
+        walk([&](uint32_t u, uint32_t p, bool starts) {
+          if (starts) {
+            put_bits(words, pos, p, pbits);
+            pos += pbits;
+          }
+          pos += u >> p;  // unary quotient: zeros
+          put_bits(words, pos, (u & ((1u << p) - 1u)) | (1u << p), p + 1u);
+          pos += p + 1u;
+        });
+        (void)total;
+      }
     }
     sub_base += sub_bits;
   }
@@ -310,7 +479,8 @@ __device__ __forceinline__ void frame_pack_body(const FramePackArgs& a, const Vi
   }
 }
 
-__global__ void __launch_bounds__(kPackThreads) frame_pack_kernel(FramePackArgs a) {
+template <bool ALIGNED>
+__global__ void __launch_bounds__(kPackThreads, ALIGNED ? FLACENC_PACK_OCC : 4) frame_pack_kernel(FramePackArgs a) {
   const uint32_t f = blockIdx.x;
   StereoView v;
   v.fr = a.results + f;
@@ -318,10 +488,11 @@ __global__ void __launch_bounds__(kPackThreads) frame_pack_kernel(FramePackArgs 
   v.r = v.l + a.stride;
   v.bps0 = a.bits_per_sample;
   v.row0 = (size_t)(2u * f);
-  frame_pack_body(a, v, f);
+  frame_pack_body<ALIGNED>(a, v, f);
 }
 
-__global__ void __launch_bounds__(kPackThreads) channel_pack_kernel(FramePackArgs a) {
+template <bool ALIGNED>
+__global__ void __launch_bounds__(kPackThreads, ALIGNED ? FLACENC_PACK_OCC : 4) channel_pack_kernel(FramePackArgs a) {
   const uint32_t f = blockIdx.x;
   ChannelView v;
   v.ch = a.chan_results + (size_t)f * a.channels;
@@ -330,7 +501,7 @@ __global__ void __launch_bounds__(kPackThreads) channel_pack_kernel(FramePackArg
   v.nch = a.channels;
   v.bps0 = a.bits_per_sample;
   v.row0 = (size_t)f * a.channels;
-  frame_pack_body(a, v, f);
+  frame_pack_body<ALIGNED>(a, v, f);
 }
 
 // Frame::count_bits / 8 (bitrepr.rs:275-287) from the decision records alone
@@ -489,18 +660,17 @@ size_t stereo_frame_bytes_bound(uint32_t block_size, uint32_t bits_per_sample) {
 hipError_t launch_frame_pack(const FramePackArgs& a, hipStream_t stream) {
   if (a.n_frames == 0) return hipSuccess;
   const size_t smem = static_cast<size_t>(a.lds_words) * 4;
-  static DynamicLdsOptIn opt_in_stereo, opt_in_channels;  // per kernel, per device inside
-  if (a.chan_results) {
-    if (hipError_t err = opt_in_channels.ensure(reinterpret_cast<const void*>(channel_pack_kernel), smem);
-        err != hipSuccess)
-      return err;
-    hipLaunchKernelGGL(channel_pack_kernel, dim3(a.n_frames), dim3(kPackThreads), smem, stream, a);
-  } else {
-    if (hipError_t err = opt_in_stereo.ensure(reinterpret_cast<const void*>(frame_pack_kernel), smem);
-        err != hipSuccess)
-      return err;
-    hipLaunchKernelGGL(frame_pack_kernel, dim3(a.n_frames), dim3(kPackThreads), smem, stream, a);
-  }
+  static DynamicLdsOptIn opt_in[4];  // per kernel, per device inside
+  const bool aligned = a.block_size % 4096u == 0u;
+  auto go = [&](auto kernel, DynamicLdsOptIn& opt) -> hipError_t {
+    if (hipError_t err = opt.ensure(reinterpret_cast<const void*>(kernel), smem); err != hipSuccess) return err;
+    hipLaunchKernelGGL(kernel, dim3(a.n_frames), dim3(kPackThreads), smem, stream, a);
+    return hipSuccess;
+  };
+  hipError_t err;
+  if (a.chan_results) err = aligned ? go(channel_pack_kernel<true>, opt_in[0]) : go(channel_pack_kernel<false>, opt_in[1]);
+  else err = aligned ? go(frame_pack_kernel<true>, opt_in[2]) : go(frame_pack_kernel<false>, opt_in[3]);
+  if (err != hipSuccess) return err;
   return hipGetLastError();
 }
 

@@ -506,7 +506,9 @@ def secondary(torch, _capi, handle, args, dev):
     host16 = np.ascontiguousarray(noisy.cpu().numpy().transpose(0, 2, 1)).astype("<i2").view(np.uint8).reshape(-1)
     fcfg = _capi.make_frame_config(qcfg, use_fixed=False)
     pcie = {}
-    for label, pinned in (("pageable_caller_buffers", False), ("pinned_caller_buffers", True)):
+    for label, pinned, threads in (("pageable_caller_buffers_1_thread", False, 1), ("pageable_caller_buffers", False, 4),
+                                   ("pinned_caller_buffers", True, 4)):
+        handle.set_host_threads(threads)
         src = host16
         dst = np.empty(F * (out_stride + 16), np.uint8)
         if pinned:
@@ -520,7 +522,8 @@ def secondary(torch, _capi, handle, args, dev):
             dt = time.perf_counter() - t0
             best = dt if best is None else min(best, dt)
         pcie[label] = {"ms": round(best * 1e3, 3), "Msamples_per_s": round(F * 2 * n / best / 1e6, 1),
-                       "host_bytes_in": int(host16.size), "host_bytes_out": int(out_bytes.size)}
+                       "host_bytes_in": int(host16.size), "host_bytes_out": int(out_bytes.size),
+                       "staging_threads": 0 if pinned else threads}
         del src, dst
     sec["pcie_inclusive_pcm_to_frame_bytes"] = dict(
         pcie, what="flacenc_hip_encode_pcm_stereo: host PCM (2 B/sample) -> host frame bytes, best of 3 wall-clock "

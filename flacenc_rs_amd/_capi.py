@@ -63,6 +63,7 @@ EXPORTED_SYMBOLS = (
     "flacenc_hip_encode_pcm",
     "flacenc_hip_host_alloc",
     "flacenc_hip_host_free",
+    "flacenc_hip_set_host_threads",
     "flacenc_hip_encode_frames",
     "flacenc_hip_encode_frames_async",
     "flacenc_hip_frame_bytes_bound",
@@ -259,6 +260,8 @@ def load() -> C.CDLL:
     L.flacenc_hip_host_alloc.restype = C.c_void_p
     L.flacenc_hip_host_free.argtypes = [C.c_void_p]
     L.flacenc_hip_host_free.restype = None
+    L.flacenc_hip_set_host_threads.argtypes = [C.c_void_p, C.c_int]
+    L.flacenc_hip_set_host_threads.restype = C.c_int
     L.flacenc_hip_fill_le_bytes.argtypes = [vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_size_t, C.c_uint32, i32p,
                                             C.c_size_t, C.c_int]
     L.flacenc_hip_fill_le_bytes.restype = C.c_int
@@ -424,6 +427,10 @@ class Handle:
 
     def synchronize(self):
         self._check(self._lib.flacenc_hip_synchronize(self._h))
+
+    def set_host_threads(self, threads: int):
+        """Host threads sharing the staging copies of encode_pcm* for pageable buffers (default 4)."""
+        self._check(self._lib.flacenc_hip_set_host_threads(self._h, threads))
 
     # -- host-memory path (what the reference's FFI would hand over) ----------
     def qlpc_batch(self, samples, bps, cfg: QlpcConfig, want_fp: bool = False):

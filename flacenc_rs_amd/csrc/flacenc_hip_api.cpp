@@ -10,8 +10,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "flacenc_hip.h"
@@ -34,6 +38,82 @@ struct DeviceBuffer {
   size_t cap = 0;
 };
 
+// Staging copies between ordinary (pageable) caller memory and the pinned slots of the streaming path: one
+// memcpy stream moves ~20 GB/s on the host, well under what PCIe takes in both directions at once, so a
+// copy is cut into slices for a few helper threads (the caller's thread takes one slice itself).
+class CopyPool {
+ public:
+  explicit CopyPool(unsigned workers) : tasks_(workers) {
+    for (unsigned i = 0; i < workers; ++i) threads_.emplace_back([this, i] { run(i); });
+  }
+  ~CopyPool() {
+    {
+      std::lock_guard<std::mutex> g(m_);
+      stop_ = true;
+    }
+    cv_.notify_all();
+    for (std::thread& t : threads_) t.join();
+  }
+  unsigned workers() const { return static_cast<unsigned>(threads_.size()); }
+  void copy(void* dst, const void* src, size_t n) {
+    const size_t parts = threads_.size() + 1;
+    if (threads_.empty() || n < (size_t(1) << 20)) {
+      std::memcpy(dst, src, n);
+      return;
+    }
+    const size_t slice = ((n + parts - 1) / parts + 4095) & ~size_t(4095);
+    char* d = static_cast<char*>(dst);
+    const char* sp = static_cast<const char*>(src);
+    {
+      std::lock_guard<std::mutex> g(m_);
+      for (size_t i = 0; i < threads_.size(); ++i) {
+        const size_t lo = (i + 1) * slice;
+        const size_t len = lo >= n ? 0 : (n - lo < slice ? n - lo : slice);
+        tasks_[i] = Task{d + lo, sp + lo, len};
+      }
+      pending_ = static_cast<unsigned>(threads_.size());
+      ++generation_;
+    }
+    cv_.notify_all();
+    std::memcpy(d, sp, slice < n ? slice : n);
+    std::unique_lock<std::mutex> g(m_);
+    done_cv_.wait(g, [this] { return pending_ == 0; });
+  }
+
+ private:
+  struct Task {
+    char* d = nullptr;
+    const char* s = nullptr;
+    size_t n = 0;
+  };
+  void run(unsigned idx) {
+    unsigned long long seen = 0;
+    for (;;) {
+      Task t;
+      {
+        std::unique_lock<std::mutex> g(m_);
+        cv_.wait(g, [&] { return stop_ || generation_ != seen; });
+        if (stop_) return;
+        seen = generation_;
+        t = tasks_[idx];
+      }
+      if (t.n) std::memcpy(t.d, t.s, t.n);
+      {
+        std::lock_guard<std::mutex> g(m_);
+        --pending_;
+      }
+      done_cv_.notify_one();
+    }
+  }
+  std::vector<std::thread> threads_;
+  std::vector<Task> tasks_;
+  std::mutex m_;
+  std::condition_variable cv_, done_cv_;
+  unsigned long long generation_ = 0;
+  unsigned pending_ = 0;
+  bool stop_ = false;
+};
+
 }  // namespace
 
 struct flacenc_hip_handle {
@@ -52,6 +132,8 @@ struct flacenc_hip_handle {
   void* pin_out[2] = {nullptr, nullptr};
   void* pin_meta[2] = {nullptr, nullptr};
   size_t pin_in_cap = 0, pin_out_cap = 0, pin_meta_cap = 0;
+  int host_threads = -1;  // staging-copy threads of the streaming path: -1 = default, see flacenc_hip_set_host_threads
+  std::unique_ptr<CopyPool> copy_pool;
   unsigned long long* stamps = nullptr;  // profiling hook, see flacenc_hip_debug_set_stamps
   unsigned long long* fixed_keys = nullptr;  // test hook, see flacenc_hip_debug_set_fixed_keys
 };
@@ -1154,6 +1236,13 @@ void flacenc_hip_host_free(void* p) {
   if (p) (void)hipHostFree(p);
 }
 
+int flacenc_hip_set_host_threads(flacenc_hip_handle* h, int threads) {
+  if (!h || threads < 0 || threads > 64) return FLACENC_HIP_ERR_BAD_ARGUMENT;
+  h->host_threads = threads;
+  h->copy_pool.reset();  // rebuilt with the new size at the next pageable call
+  return FLACENC_HIP_OK;
+}
+
 namespace {
 bool is_pinned(const void* p) {
   hipPointerAttribute_t attr{};
@@ -1256,9 +1345,24 @@ int flacenc_hip_encode_pcm(flacenc_hip_handle* h, const flacenc_hip_frame_config
     chunks.push_back({f, static_cast<size_t>(n_full - f < chunk ? n_full - f : chunk), block_size});
   if (tail) chunks.push_back({n_full, 1, tail});
 
+  // staging copies for pageable caller memory run on the caller's thread + the handle's helper threads
+  if ((!in_pinned || !out_pinned) && !h->copy_pool) {
+    const int want = h->host_threads < 0 ? 4 : h->host_threads;  // total, the caller's thread included
+    h->copy_pool.reset(new (std::nothrow) CopyPool(want > 1 ? static_cast<unsigned>(want - 1) : 0u));
+    if (!h->copy_pool) {
+      h->last_error = "encode_pcm: out of host memory";
+      return FLACENC_HIP_ERR_DEVICE;
+    }
+  }
   uint64_t written = 0;
-  // drain: wait for a chunk's lengths, then copy exactly its bytes out (contiguous on the device already)
-  auto drain = [&](size_t ci) -> int {
+  // A chunk's way out has two steps so that the host never idles on a transfer: start_out waits for the
+  // chunk's lengths and starts the device -> host copy of exactly its bytes (contiguous on the device
+  // already); finish_out -- one chunk later, after the next chunk's staging copy in -- waits for that
+  // transfer and hands the bytes to the caller.
+  struct Pending {
+    uint64_t at = 0, bytes = 0;
+  } pending[2];
+  auto start_out = [&](size_t ci) -> int {
     const Chunk& c = chunks[ci];
     const int s = static_cast<int>(ci & 1);
     HIP_TRY(h, hipEventSynchronize(h->ev_pack[s]));  // lengths + total are in pin_meta[s]
@@ -1270,16 +1374,19 @@ int flacenc_hip_encode_pcm(flacenc_hip_handle* h, const flacenc_hip_frame_config
       return FLACENC_HIP_ERR_BAD_ARGUMENT;
     }
     std::memcpy(out_len + c.first_frame, lens, c.frames * 4);
-    if (out_pinned) {
-      HIP_TRY(h, hipMemcpyAsync(out + written, h->d_cont[s].ptr, bytes, hipMemcpyDeviceToHost, h->s_out));
-      HIP_TRY(h, hipEventRecord(h->ev_d2h[s], h->s_out));
-    } else {
-      HIP_TRY(h, hipMemcpyAsync(h->pin_out[s], h->d_cont[s].ptr, bytes, hipMemcpyDeviceToHost, h->s_out));
-      HIP_TRY(h, hipEventRecord(h->ev_d2h[s], h->s_out));
-      HIP_TRY(h, hipEventSynchronize(h->ev_d2h[s]));
-      std::memcpy(out + written, h->pin_out[s], bytes);
-    }
+    HIP_TRY(h, hipMemcpyAsync(out_pinned ? static_cast<void*>(out + written) : h->pin_out[s], h->d_cont[s].ptr, bytes,
+                              hipMemcpyDeviceToHost, h->s_out));
+    HIP_TRY(h, hipEventRecord(h->ev_d2h[s], h->s_out));
+    pending[s].at = written;
+    pending[s].bytes = bytes;
     written += bytes;
+    return FLACENC_HIP_OK;
+  };
+  auto finish_out = [&](size_t ci) -> int {
+    if (out_pinned) return FLACENC_HIP_OK;
+    const int s = static_cast<int>(ci & 1);
+    HIP_TRY(h, hipEventSynchronize(h->ev_d2h[s]));
+    h->copy_pool->copy(out + pending[s].at, h->pin_out[s], pending[s].bytes);
     return FLACENC_HIP_OK;
   };
 
@@ -1305,7 +1412,7 @@ int flacenc_hip_encode_pcm(flacenc_hip_handle* h, const flacenc_hip_frame_config
       HIP_TRY(h, hipMemcpyAsync(h->d_pcm[s].ptr, src, in_bytes, hipMemcpyHostToDevice, h->s_in));
     } else {
       if (ci >= 2) HIP_TRY(h, hipEventSynchronize(h->ev_h2d[s]));  // pin_in[s] has been sent
-      std::memcpy(h->pin_in[s], src, in_bytes);
+      h->copy_pool->copy(h->pin_in[s], src, in_bytes);
       HIP_TRY(h, hipMemcpyAsync(h->d_pcm[s].ptr, h->pin_in[s], in_bytes, hipMemcpyHostToDevice, h->s_in));
     }
     HIP_TRY(h, hipEventRecord(h->ev_h2d[s], h->s_in));
@@ -1343,10 +1450,15 @@ int flacenc_hip_encode_pcm(flacenc_hip_handle* h, const flacenc_hip_frame_config
                                                 static_cast<uint32_t>(c.frames), h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->pin_meta[s], dlen, c.frames * 4, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipEventRecord(h->ev_pack[s], h->stream));
-    // 3. while this chunk runs, hand the previous one to the caller
-    if (ci >= 1 && (rc = drain(ci - 1)) != FLACENC_HIP_OK) return rc;
+    // 3. while this chunk runs: the chunk before the previous one reaches the caller (its transfer ran
+    // during this chunk's staging copy), then the previous one's transfer starts
+    if (ci >= 2 && (rc = finish_out(ci - 2)) != FLACENC_HIP_OK) return rc;
+    if (ci >= 1 && (rc = start_out(ci - 1)) != FLACENC_HIP_OK) return rc;
   }
-  if ((rc = drain(chunks.size() - 1)) != FLACENC_HIP_OK) return rc;
+  const size_t nc = chunks.size();
+  if (nc >= 2 && (rc = finish_out(nc - 2)) != FLACENC_HIP_OK) return rc;
+  if ((rc = start_out(nc - 1)) != FLACENC_HIP_OK) return rc;
+  if ((rc = finish_out(nc - 1)) != FLACENC_HIP_OK) return rc;
   HIP_TRY(h, hipStreamSynchronize(h->s_out));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   drain_on_error.armed = false;

@@ -491,6 +491,11 @@ int flacenc_hip_encode_pcm(flacenc_hip_handle* h, const flacenc_hip_frame_config
 /* page-locked host memory for the calls above (NULL on failure) */
 void* flacenc_hip_host_alloc(size_t bytes);
 void flacenc_hip_host_free(void* p);
+/* Host threads (the caller's included) that share the staging copies of flacenc_hip_encode_pcm* when `pcm` or
+ * `out` is pageable memory; 0 or 1 = the caller's thread alone, default 4.  The helper threads belong to the
+ * handle, sleep between calls and end with flacenc_hip_destroy -- the counterpart of the reference's worker
+ * threads feeding and draining FrameBufs (src/par.rs:288-325), which only move bytes here. */
+int flacenc_hip_set_host_threads(flacenc_hip_handle* h, int threads);
 
 int flacenc_hip_synchronize(flacenc_hip_handle* h);
 

@@ -134,6 +134,7 @@ extern "C" {
     ) -> c_int;
     pub fn flacenc_hip_host_alloc(bytes: usize) -> *mut core::ffi::c_void;
     pub fn flacenc_hip_host_free(p: *mut core::ffi::c_void);
+    pub fn flacenc_hip_set_host_threads(h: *mut Handle, threads: i32) -> i32;
     pub fn flacenc_hip_stereo_qlpc_batch(
         h: *mut Handle, cfg: *const QlpcConfig, frames: *const i32, n_frames: usize,
         block_size: u32, stride: usize, bits_per_sample: u32, params: *mut SubframeParams,

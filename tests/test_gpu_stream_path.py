@@ -88,6 +88,31 @@ def test_pinned_buffers_give_identical_bytes(handle):
     assert out_c.tobytes() == out_a.tobytes()
 
 
+@pytest.mark.parametrize("threads", [0, 1, 3, 8])
+def test_staging_thread_counts_give_identical_bytes(handle, threads):
+    """flacenc_hip_set_host_threads: the staging copies of pageable buffers are cut into slices for helper
+    threads; three chunks in flight (the two-step way out: a chunk's transfer runs during the next chunk's
+    staging copy in), a last chunk that is not full."""
+    n, bps, F = 4096, 16, 8192 * 2 + 300
+    frames = _capi.sigen_frames(F, 2, n, bps, 90.0, 0.3, 0.2, seed=99, nthreads=4)
+    cfg = _capi.make_frame_config(_capi.make_config(lpc_order=8), use_fixed=False)
+    pcm = pack_pcm(frames, 2)
+    handle.set_host_threads(4)
+    want, want_lens = handle.encode_pcm_stereo(pcm, cfg, 2, bps, n, 44100)
+    try:
+        handle.set_host_threads(threads)
+        out, lens = handle.encode_pcm_stereo(pcm, cfg, 2, bps, n, 44100)
+    finally:
+        handle.set_host_threads(4)
+    assert np.array_equal(lens, want_lens) and out.tobytes() == want.tobytes()
+    first = reference_bytes(handle, frames[:8], bps, cfg, 44100)
+    assert out[: sum(len(b) for b in first)].tobytes() == b"".join(first)
+    last = reference_bytes(handle, frames[F - 4:], bps, cfg, 44100, F - 4, 1)
+    assert out[out.size - sum(len(b) for b in last):].tobytes() == b"".join(last)
+    with pytest.raises(_capi.FlacencHipError):
+        handle.set_host_threads(-1)
+
+
 @pytest.mark.parametrize("n,order", [(4096, 8), (4608, 10), (8192, 24), (1152, 8)])
 def test_record_wire_format_is_lossless(handle, n, order):
     """The multi-GPU exchange moves frame records without the always-zero tails of their Rice-parameter

@@ -113,6 +113,7 @@ __global__ void __launch_bounds__(256, FLACENC_BIG_ACORR_OCC) bigblock_acorr_ker
   // after the images: the window weights of the pass in the same segment layout, then the pass partials
   float* const wlds = reinterpret_cast<float*>(sm + NBUF * kBufDwords);
   double* const part = reinterpret_cast<double*>(sm + (NBUF + 1) * kBufDwords);  // [4 waves][2][NLAG]
+  double* const cross = part + 4 * 2 * NLAG;                                       // [4 waves][NL][64]
   const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
   const uint32_t blk = blockIdx.x;
   uint32_t sf = blk * 4u + (uint32_t)wave;
@@ -214,13 +215,12 @@ __global__ void __launch_bounds__(256, FLACENC_BIG_ACORR_OCC) bigblock_acorr_ker
 #pragma unroll
           for (int q = 0; q < HP; ++q) dw[q] = dw[q + 16];
         }
-        // lane levels, then the pass levels: K = 2: R0 + R1; K = 4: (R0 + R1) + (R2 + R3).  Partials of
-        // earlier passes wait in LDS (only lane 0's copy matters).
-#pragma unroll
-        for (int j = 0; j < NL; ++j) {
-          double r = wave_tree_sum_dpp(p2[j]);
-          const int lag = lag0 + j;
-          if (lane == 0) {
+        // lane levels (all NL lags at once through LDS, the total of lag j lands in lane 4 j + 3), then the
+        // pass levels: K = 2: R0 + R1; K = 4: (R0 + R1) + (R2 + R3).  Partials of earlier passes wait in LDS.
+        {
+          double r = wave_tree_sums_lds<NL>(p2, cross + wave * NL * 64, lane);
+          const int lag = lag0 + (lane >> 2);
+          if ((lane & 3) == 3 && (lane >> 2) < NL) {
             if ((k & 1) == 0) {
               mine[(k >> 1 & 1) * NLAG + lag] = r;                  // R0 (or R2) waits for its partner
             } else {
@@ -594,8 +594,9 @@ template <int HP, int NG, int NL>
 hipError_t launch_acorr(const QlpcKernelArgs& a, hipStream_t stream) {
   static DynamicLdsOptIn opt_s, opt_p;
   const size_t part = 4 * 2 * NG * NL * sizeof(double);
-  if (a.stereo) return launch_big(bigblock_acorr_kernel<HP, NG, NL, true>, opt_s, a, 3 * kBufDwords * 4 + part, stream);
-  return launch_big(bigblock_acorr_kernel<HP, NG, NL, false>, opt_p, a, 5 * kBufDwords * 4 + part, stream);
+  const size_t cross = 4 * NL * 64 * sizeof(double);  // wave_tree_sums_lds
+  if (a.stereo) return launch_big(bigblock_acorr_kernel<HP, NG, NL, true>, opt_s, a, 3 * kBufDwords * 4 + part + cross, stream);
+  return launch_big(bigblock_acorr_kernel<HP, NG, NL, false>, opt_p, a, 5 * kBufDwords * 4 + part + cross, stream);
 }
 
 template <int MAXP, int K>

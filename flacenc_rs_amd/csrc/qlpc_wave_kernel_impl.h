@@ -125,6 +125,46 @@ __device__ __forceinline__ double wave_tree_sum_dpp(double v) {
   return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
+// The same canonical sums for NV values per lane at once, through a per-wave LDS area of NV x 64 doubles
+// instead of NV dependent DPP trees (35 VALU instructions each): every lane parks its NV values, lane
+// 4 j + s fetches value j of lanes [16 s, 16 s + 16) and adds them exactly as the tree pairs them --
+// ((v0 + v1) + (v2 + v3)) + ... -- and two row shifts fold the four sixteenths, (s0 + s1) + (s2 + s3).
+// The total of value j arrives in lane 4 j + 3 (other lanes, and lanes >= 4 NV, return garbage).
+template <int NV>
+__device__ __forceinline__ double wave_tree_sums_lds(const double (&v)[NV], double* buf, int lane) {
+  static_assert(4 * NV <= 64, "one quad of lanes per value");
+#pragma unroll
+  for (int j = 0; j < NV; ++j) buf[j * 64 + lane] = v[j];
+  __builtin_amdgcn_wave_barrier();  // (LDS operations of one wave complete in order)
+  const int j = (lane >> 2) < NV ? (lane >> 2) : NV - 1;
+  const double2* src = reinterpret_cast<const double2*>(buf + j * 64 + (lane & 3) * 16);
+  double x[16];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const double2 q = src[i];
+    x[2 * i] = q.x;
+    x[2 * i + 1] = q.y;
+  }
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int d = 1; d < 16; d <<= 1) {
+#pragma unroll
+    for (int i = 0; i < 16; i += 2 * d) x[i] = x[i] + x[i + d];
+  }
+  double t = x[0];
+#define FLACENC_F64_DPP_STEP(CTRL, ROWMASK)                                                              \
+  {                                                                                                      \
+    const unsigned long long b_ = (unsigned long long)__double_as_longlong(t);                          \
+    const uint32_t lo_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)b_, CTRL, ROWMASK, 0xF, false);        \
+    const uint32_t hi_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b_ >> 32), CTRL, ROWMASK, 0xF, false); \
+    t = t + __longlong_as_double((long long)(((unsigned long long)hi_ << 32) | lo_));                    \
+  }
+  FLACENC_F64_DPP_STEP(0x111, 0xF)
+  FLACENC_F64_DPP_STEP(0x112, 0xF)
+#undef FLACENC_F64_DPP_STEP
+  return t;
+}
+
 __device__ __forceinline__ uint32_t wave_or_dpp(uint32_t v) {
   v |= FLACENC_DPP(v, 0x111, 0xF);
   v |= FLACENC_DPP(v, 0x112, 0xF);

@@ -31,8 +31,10 @@ constexpr int kPass = 4096;
 #define FLACENC_BIG_ACORR_OCC 2
 #endif
 #ifndef FLACENC_BIG_NG24
-#define FLACENC_BIG_NG24 2
-#define FLACENC_BIG_NL24 13
+#define FLACENC_BIG_NG24 1
+#endif
+#ifndef FLACENC_BIG_NG32
+#define FLACENC_BIG_NG32 2
 #endif
 
 // cooperative load of pass k of the workgroup's rows into the LDS images: segment 0 of an image holds the
@@ -97,23 +99,92 @@ __device__ __forceinline__ int4 bigblock_ld4(const int32_t* bufA, const int32_t*
 }
 
 // ---------------------------------------------------------------------------------------------
-// lags 0 .. NG * NL - 1 of R[] in NG groups of NL: one group's three accumulator sets (chunk chain, two
-// tree partials) and the window of 32 lagged values + 16 current ones are what a lane holds at a time;
-// the groups re-read and re-convert the lane's samples from LDS (the pass is loaded and its window
-// weights staged once)
-template <int HP, int NG, int NL, bool STEREO>
+// Autocorrelation in HALF passes of 2048 samples: a lane owns 32 samples = two 16-sample chunks of a half
+// pass, so the in-lane part of the tree is one level (c0 + c1) and a lane carries two accumulator sets
+// instead of three -- all 25 lags of an order-24 analysis (or 17 + 16 of an order-32 one) next to the
+// window of HP lagged values + one chunk, in 256 registers, with every sample converted once per group.
+constexpr int kHalf = 2048;
+constexpr int kHSeg = 36;                    // dwords per lane segment: 32 samples + 4 pad (conflict-free b128)
+constexpr int kHBufDwords = 65 * kHSeg + 4;  // one leading segment: the 32 samples in front of the half pass
+__device__ __forceinline__ int hidx(int t) { return ((t >> 5) + 1) * kHSeg + (t & 31); }  // t >= -32
+
+// A half pass travels global -> registers -> LDS in two steps so that the loads of half pass k + 1 are in
+// flight while half pass k is being summed: fetch issues them (4 int4 per thread, plain variables -- a
+// struct or array here stays in scratch memory and the loads are waited for at once), store parks them in
+// the images once every wave is done with the previous contents.  Plain (non-stereo) mode: a wave loads its
+// own row, 8 int4 per lane; the second four are loaded and stored in the store step.  The 32 samples in front
+// of a half pass are the tail of the previous one: copied inside LDS (read before the barrier, while the old
+// contents are intact).
+#define FLACENC_HALF_FETCH(K_)                                                                                        \
+  {                                                                                                                    \
+    const size_t t0_ = (size_t)(K_) * kHalf;                                                                           \
+    if (STEREO) {                                                                                                      \
+      const int32_t* __restrict__ src_ = a.samples + (size_t)(2u * blk) * a.stride + t0_;                              \
+      pf0 = *reinterpret_cast<const int4*>(src_ + (size_t)((tid + 0) >> 9) * a.stride + (((tid + 0) & 511) << 2));     \
+      pf1 = *reinterpret_cast<const int4*>(src_ + (size_t)((tid + 256) >> 9) * a.stride + (((tid + 256) & 511) << 2)); \
+      pf2 = *reinterpret_cast<const int4*>(src_ + (size_t)((tid + 512) >> 9) * a.stride + (((tid + 512) & 511) << 2)); \
+      pf3 = *reinterpret_cast<const int4*>(src_ + (size_t)((tid + 768) >> 9) * a.stride + (((tid + 768) & 511) << 2)); \
+    } else {                                                                                                           \
+      const int32_t* __restrict__ src_ = a.samples + (size_t)sf * a.stride + t0_;                                      \
+      pf0 = *reinterpret_cast<const int4*>(src_ + ((lane + 0) << 2));                                                  \
+      pf1 = *reinterpret_cast<const int4*>(src_ + ((lane + 64) << 2));                                                 \
+      pf2 = *reinterpret_cast<const int4*>(src_ + ((lane + 128) << 2));                                                \
+      pf3 = *reinterpret_cast<const int4*>(src_ + ((lane + 192) << 2));                                                \
+    }                                                                                                                  \
+  }
+#define FLACENC_HALF_STORE(K_)                                                                                         \
+  {                                                                                                                    \
+    if (STEREO) {                                                                                                      \
+      *reinterpret_cast<int4*>(&sm[((tid + 0) >> 9) * kHBufDwords + hidx(((tid + 0) & 511) << 2)]) = pf0;              \
+      *reinterpret_cast<int4*>(&sm[((tid + 256) >> 9) * kHBufDwords + hidx(((tid + 256) & 511) << 2)]) = pf1;          \
+      *reinterpret_cast<int4*>(&sm[((tid + 512) >> 9) * kHBufDwords + hidx(((tid + 512) & 511) << 2)]) = pf2;          \
+      *reinterpret_cast<int4*>(&sm[((tid + 768) >> 9) * kHBufDwords + hidx(((tid + 768) & 511) << 2)]) = pf3;          \
+      if (tid < 16) *reinterpret_cast<int4*>(&sm[(tid >> 3) * kHBufDwords + hidx(((tid & 7) << 2) - 32)]) = pfh;       \
+    } else {                                                                                                           \
+      const int32_t* __restrict__ src_ = a.samples + (size_t)sf * a.stride + (size_t)(K_) * kHalf;                     \
+      *reinterpret_cast<int4*>(&sm[wave * kHBufDwords + hidx((lane + 0) << 2)]) = pf0;                                 \
+      *reinterpret_cast<int4*>(&sm[wave * kHBufDwords + hidx((lane + 64) << 2)]) = pf1;                                \
+      *reinterpret_cast<int4*>(&sm[wave * kHBufDwords + hidx((lane + 128) << 2)]) = pf2;                               \
+      *reinterpret_cast<int4*>(&sm[wave * kHBufDwords + hidx((lane + 192) << 2)]) = pf3;                               \
+      _Pragma("unroll") for (int it_ = 4; it_ < 8; ++it_)                                                              \
+        *reinterpret_cast<int4*>(&sm[wave * kHBufDwords + hidx((lane + it_ * 64) << 2)]) =                             \
+            *reinterpret_cast<const int4*>(src_ + ((lane + it_ * 64) << 2));                                           \
+      if (lane < 8) *reinterpret_cast<int4*>(&sm[wave * kHBufDwords + hidx((lane << 2) - 32)]) = pfh;                  \
+    }                                                                                                                  \
+  }
+
+template <int KIND>
+__device__ __forceinline__ int4 bigblock_hld4(const int32_t* bufA, const int32_t* bufB, int t) {
+  int4 v = *reinterpret_cast<const int4*>(&bufA[hidx(t)]);
+  if (KIND >= 2) {
+    const int4 r = *reinterpret_cast<const int4*>(&bufB[hidx(t)]);
+    if (KIND == 2) {  // mid = (l + r) >> 1, coding.rs:483
+      v.x = (v.x + r.x) >> 1;
+      v.y = (v.y + r.y) >> 1;
+      v.z = (v.z + r.z) >> 1;
+      v.w = (v.w + r.w) >> 1;
+    } else {  // side = l - r
+      v.x -= r.x;
+      v.y -= r.y;
+      v.z -= r.z;
+      v.w -= r.w;
+    }
+  }
+  return v;
+}
+
+template <int HP, int NG, bool STEREO>
 __global__ void __launch_bounds__(256, FLACENC_BIG_ACORR_OCC) bigblock_acorr_kernel(QlpcKernelArgs a) {
-  // HP = window depth = the order bucket (24 or 32); lags beyond HP that a group's last slots may name
-  // (25, 26 with 3 x 9 at HP 24; 33 with 3 x 11 at HP 32) read as zero and are not stored
-  constexpr int NLAG = NG * NL;
-  static_assert(NLAG >= HP + 1 && NLAG <= HP + 3, "lag groups must cover the order bucket");
+  // HP = window depth = the order bucket (24 or 32); lags 0..HP in NG groups of at most NL
+  constexpr int NLAG = HP + 1;
+  constexpr int NL = (NLAG + NG - 1) / NG;
+  constexpr int NBATCH = 13;  // lags per LDS tree round (4 lanes per lag, <= 16)
+  constexpr int LVMAX = 3;    // half passes per block <= 8
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   int32_t* const sm = reinterpret_cast<int32_t*>(smem_raw);
   constexpr int NBUF = STEREO ? 2 : 4;
-  // after the images: the window weights of the pass in the same segment layout, then the pass partials
-  float* const wlds = reinterpret_cast<float*>(sm + NBUF * kBufDwords);
-  double* const part = reinterpret_cast<double*>(sm + (NBUF + 1) * kBufDwords);  // [4 waves][2][NLAG]
-  double* const cross = part + 4 * 2 * NLAG;                                       // [4 waves][NL][64]
+  double* const part = reinterpret_cast<double*>(sm + NBUF * kHBufDwords);    // [4 waves][LVMAX][NLAG]
+  double* const cross = part + 4 * LVMAX * NLAG;                               // [4 waves][NBATCH][64]
   const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
   const uint32_t blk = blockIdx.x;
   uint32_t sf = blk * 4u + (uint32_t)wave;
@@ -121,67 +192,75 @@ __global__ void __launch_bounds__(256, FLACENC_BIG_ACORR_OCC) bigblock_acorr_ker
   if (!active) sf = a.n_subframes - 1u;  // (plain mode tail: redo the last subframe, write nothing)
   const int role = STEREO ? wave : 0;
   const int P = (int)a.lpc_order;
-  const int K = (int)(a.block_size / kPass);
-  const int32_t* const bufA = sm + (STEREO ? (role == 1 ? 1 : 0) : wave) * kBufDwords;
-  const int32_t* const bufB = sm + kBufDwords;
+  const int K2 = (int)(a.block_size / kHalf);
+  const int32_t* const bufA = sm + (STEREO ? (role == 1 ? 1 : 0) : wave) * kHBufDwords;
+  const int32_t* const bufB = sm + kHBufDwords;
   const float* __restrict__ wtab = a.window ? a.window + 32 : nullptr;
-  const int tl = lane << 6;
+  const int tl = lane << 5;
+  double* const mine = part + wave * LVMAX * NLAG;
+  double* const mycross = cross + wave * NBATCH * 64;
 
   auto stamp = [&](int slot) {
     if (a.stamps && lane == 0) a.stamps[(size_t)sf * 8 + slot] = (unsigned long long)clock64();
   };
   stamp(0);
-  for (int k = 0; k < K; ++k) {
-    __syncthreads();
-    if (k == 0) stamp(1);
-    bigblock_load_pass<STEREO>(a, sm, blk, k, tid, wave, lane, sf);
-    // a pass (and the 64 samples in front of it) that lies inside the window's run of exact ones needs no
-    // table: (f32)s * 1.0f == (f32)s.  Otherwise its 64 + 4096 weights are staged once for the four waves.
-    const int g0 = k * kPass - 64;
-    const bool tapered = wtab != nullptr && !(g0 >= a.flat_lo && g0 + 64 + kPass <= a.flat_hi);
-    if (tapered) {
-      for (int i = tid; i < (kPass + 64) / 4; i += 256) {
-        const int t = (i << 2) - 64;  // pass-relative
-        float4 w = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // in front of the block: the samples are 0
-        if (g0 + 64 + t >= 0) w = *reinterpret_cast<const float4*>(wtab + (g0 + 64 + t));
-        *reinterpret_cast<float4*>(&wlds[widx(t)]) = w;
+  int4 pf0, pf1, pf2, pf3;
+  FLACENC_HALF_FETCH(0)
+  for (int k = 0; k < K2; ++k) {
+    int4 pfh = make_int4(0, 0, 0, 0);
+    if (k > 0) {
+      if (STEREO) {
+        if (tid < 16) pfh = *reinterpret_cast<const int4*>(&sm[(tid >> 3) * kHBufDwords + hidx(kHalf - 32 + ((tid & 7) << 2))]);
+      } else {
+        if (lane < 8) pfh = *reinterpret_cast<const int4*>(&sm[wave * kHBufDwords + hidx(kHalf - 32 + (lane << 2))]);
       }
     }
+    __syncthreads();  // every wave is done with the previous half pass
+    if (k == 0) stamp(1);
+    FLACENC_HALF_STORE(k)
+    if (k + 1 < K2) FLACENC_HALF_FETCH(k + 1)  // lands during the sums below
+    // a half pass (and the 32 samples in front of it) inside the window's run of exact ones needs no
+    // weights: (f32)s * 1.0f == (f32)s.  Otherwise they are read where they are used, from the table every
+    // workgroup shares (L1 / L2 hits; the samples in front of the block are 0, whatever their weight).
+    const int g0 = k * kHalf;
+    const bool tapered = wtab != nullptr && !(g0 - 32 >= a.flat_lo && g0 + kHalf <= a.flat_hi);
     if (k == 0) stamp(2);
     __syncthreads();
     if (k == 0) stamp(3);
-    double* const mine = part + wave * 2 * NLAG;
     auto run = [&](auto kind_tag, auto tapered_tag) {
       constexpr int KIND = decltype(kind_tag)::value;
       constexpr bool TAPERED = decltype(tapered_tag)::value;
       // x_w[t] = (f32)s[t] * w[t], one f32 rounding, then widened (lpc.rs:751-754)
-      auto conv8 = [&](double* dst, int t) {  // t pass-relative, multiple of 8, >= -HP
+      auto conv8 = [&](double* dst, int t) {  // t relative to the half pass, multiple of 8, >= -HP
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-          const int4 v = bigblock_ld4<KIND>(bufA, bufB, t + 4 * q);
+          const int4 v = bigblock_hld4<KIND>(bufA, bufB, t + 4 * q);
           float4 w = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
-          if (TAPERED) w = *reinterpret_cast<const float4*>(&wlds[widx(t + 4 * q)]);
+          if (TAPERED) {
+            const int g = g0 + t + 4 * q;  // position in the block; negative only in front of the block (samples 0)
+            w = *reinterpret_cast<const float4*>(wtab + (g < 0 ? 0 : g));
+          }
           dst[4 * q + 0] = (double)((float)v.x * w.x);
           dst[4 * q + 1] = (double)((float)v.y * w.y);
           dst[4 * q + 2] = (double)((float)v.z * w.z);
           dst[4 * q + 3] = (double)((float)v.w * w.w);
         }
       };
-#pragma unroll
-      for (int g = 0; g < NG; ++g) {  // unrolled: every window index below is a compile-time constant
-        const int lag0 = g * NL;
-        // window of HP lagged values + one 16-sample chunk, slid by 16 at the end of a ROLLED chunk loop
-        // (the loop body, 16 x NL fma, stays resident in the instruction cache)
+      auto group = [&](auto g_tag) {
+        constexpr int G = decltype(g_tag)::value;
+        constexpr int lag0 = G * NL;
+        constexpr int NLG = (lag0 + NL <= NLAG) ? NL : NLAG - lag0;
+        // window of HP lagged values + one 16-sample chunk, slid by 16 between the lane's two chunks
         double dw[HP + 16];
 #pragma unroll
         for (int b = 0; b < HP / 8; ++b) conv8(&dw[8 * b], tl - HP + 8 * b);
-        double acc[NL], s01[NL], p2[NL];
+        double acc[NLG], s0[NLG];
 #pragma unroll 1
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 2; ++i) {
           conv8(&dw[HP], tl + 16 * i);
           conv8(&dw[HP + 8], tl + 16 * i + 8);
-          // common lower bound t = P for every lag (lpc.rs:542): only the block's first 32 samples -- chunks
-          // 0 and 1 of pass 0 -- can lie below it; every other chunk runs the body without the selects
+          // common lower bound t = P for every lag (lpc.rs:542): only the block's first 32 samples -- lane 0
+          // of half pass 0 -- can lie below it; every other half pass runs the body without the selects
           auto body = [&](auto masked_tag) {
             constexpr bool MASKED = decltype(masked_tag)::value;
 #pragma unroll
@@ -189,49 +268,46 @@ __global__ void __launch_bounds__(256, FLACENC_BIG_ACORR_OCC) bigblock_acorr_ker
               double cur = dw[HP + kk];
               if (MASKED) cur = (tl + 16 * i + kk < P) ? 0.0 : cur;
 #pragma unroll
-              for (int j = 0; j < NL; ++j) {
-                const int idx = HP + kk - (lag0 + j);  // (lags beyond HP do not exist: idx < 0 is never read)
-                const double lagged = idx >= 0 ? dw[idx >= 0 ? idx : 0] : 0.0;
+              for (int j = 0; j < NLG; ++j) {
+                const double lagged = dw[HP + kk - (lag0 + j)];  // lag <= HP: index >= 0
                 acc[j] = kk == 0 ? __builtin_fma(cur, lagged, 0.0) : __builtin_fma(cur, lagged, acc[j]);
               }
             }
           };
-          if (k == 0 && i < 2) body(std::true_type{});
+          if (k == 0) body(std::true_type{});
           else body(std::false_type{});
-          // in-lane levels of the balanced tree over the chunk index: (c0 + c1) + (c2 + c3)
+          // in-lane level of the balanced tree over the chunk index: c0 + c1
           if (i == 0) {
 #pragma unroll
-            for (int j = 0; j < NL; ++j) s01[j] = acc[j];
-          } else if (i == 1) {
+            for (int j = 0; j < NLG; ++j) s0[j] = acc[j];
 #pragma unroll
-            for (int j = 0; j < NL; ++j) s01[j] = s01[j] + acc[j];
-          } else if (i == 2) {
-#pragma unroll
-            for (int j = 0; j < NL; ++j) p2[j] = acc[j];
+            for (int q = 0; q < HP; ++q) dw[q] = dw[q + 16];
           } else {
 #pragma unroll
-            for (int j = 0; j < NL; ++j) p2[j] = s01[j] + (p2[j] + acc[j]);
-          }
-#pragma unroll
-          for (int q = 0; q < HP; ++q) dw[q] = dw[q + 16];
-        }
-        // lane levels (all NL lags at once through LDS, the total of lag j lands in lane 4 j + 3), then the
-        // pass levels: K = 2: R0 + R1; K = 4: (R0 + R1) + (R2 + R3).  Partials of earlier passes wait in LDS.
-        {
-          double r = wave_tree_sums_lds<NL>(p2, cross + wave * NL * 64, lane);
-          const int lag = lag0 + (lane >> 2);
-          if ((lane & 3) == 3 && (lane >> 2) < NL) {
-            if ((k & 1) == 0) {
-              mine[(k >> 1 & 1) * NLAG + lag] = r;                  // R0 (or R2) waits for its partner
-            } else {
-              r = mine[(k >> 1 & 1) * NLAG + lag] + r;              // R0 + R1 (or R2 + R3)
-              if (K == 4 && k == 1) mine[lag] = r;                  // keeps waiting for (R2 + R3)
-              if (K == 4 && k == 3) r = mine[lag] + r;
-              if (k == K - 1 && active && lag <= HP) a.autocorr[(size_t)sf * 33 + lag] = (lag <= P) ? r : 0.0;
-            }
+            for (int j = 0; j < NLG; ++j) s0[j] = s0[j] + acc[j];
           }
         }
-      }
+        // lane levels (up to NBATCH lags at once through LDS, the total of lag j lands in lane 4 j + 3), then
+        // the half-pass levels as a binary counter: a finished half pass absorbs the waiting partial of every
+        // level whose bit is set in k (earlier + later, as the tree pairs them) and parks at the first clear one
+        auto batch = [&](auto b_tag) {
+          constexpr int B0 = decltype(b_tag)::value;
+          constexpr int CNT = (NLG - B0 < NBATCH) ? NLG - B0 : NBATCH;
+          double r = wave_tree_sums_lds_n<CNT>(&s0[B0], mycross, lane);
+          const int lag = lag0 + B0 + (lane >> 2);
+          if ((lane & 3) == 3 && (lane >> 2) < CNT) {
+            int lv = 0;
+            for (; lv < LVMAX && ((k >> lv) & 1); ++lv) r = mine[lv * NLAG + lag] + r;
+            if (k != K2 - 1) mine[lv * NLAG + lag] = r;
+            else if (active) a.autocorr[(size_t)sf * 33 + lag] = (lag <= P) ? r : 0.0;
+          }
+        };
+        batch(std::integral_constant<int, 0>{});
+        if (NLG > NBATCH) batch(std::integral_constant<int, (NLG > NBATCH ? NBATCH : 0)>{});
+      };
+      group(std::integral_constant<int, 0>{});
+      if (NG > 1) group(std::integral_constant<int, (NG > 1 ? 1 : 0)>{});
+      if (NG > 2) group(std::integral_constant<int, (NG > 2 ? 2 : 0)>{});
     };
     auto run_role = [&](auto tapered_tag) {
       if (STEREO && role == 2) run(std::integral_constant<int, 2>{}, tapered_tag);
@@ -241,7 +317,7 @@ __global__ void __launch_bounds__(256, FLACENC_BIG_ACORR_OCC) bigblock_acorr_ker
     if (tapered) run_role(std::true_type{});
     else run_role(std::false_type{});
     if (k == 0) stamp(4);
-    if (k == K - 1) stamp(5);
+    if (k == K2 - 1) stamp(5);
   }
   if (lane == 0 && active)
     for (int j = HP + 1; j < 33; ++j) a.autocorr[(size_t)sf * 33 + j] = 0.0;
@@ -590,13 +666,13 @@ hipError_t launch_big(KernelT kern, DynamicLdsOptIn& opt_in, const QlpcKernelArg
   return hipGetLastError();
 }
 
-template <int HP, int NG, int NL>
+template <int HP, int NG>
 hipError_t launch_acorr(const QlpcKernelArgs& a, hipStream_t stream) {
   static DynamicLdsOptIn opt_s, opt_p;
-  const size_t part = 4 * 2 * NG * NL * sizeof(double);
-  const size_t cross = 4 * NL * 64 * sizeof(double);  // wave_tree_sums_lds
-  if (a.stereo) return launch_big(bigblock_acorr_kernel<HP, NG, NL, true>, opt_s, a, 3 * kBufDwords * 4 + part + cross, stream);
-  return launch_big(bigblock_acorr_kernel<HP, NG, NL, false>, opt_p, a, 5 * kBufDwords * 4 + part + cross, stream);
+  const size_t part = 4 * 3 * (HP + 1) * sizeof(double);
+  const size_t cross = 4 * 13 * 64 * sizeof(double);  // wave_tree_sums_lds_n
+  if (a.stereo) return launch_big(bigblock_acorr_kernel<HP, NG, true>, opt_s, a, 2 * kHBufDwords * 4 + part + cross, stream);
+  return launch_big(bigblock_acorr_kernel<HP, NG, false>, opt_p, a, 4 * kHBufDwords * 4 + part + cross, stream);
 }
 
 template <int MAXP, int K>
@@ -622,9 +698,10 @@ bool bigblock_eligible(const QlpcKernelArgs& a) {
 
 // R[] (unless `have_r`: already in `racc`, e.g. from the reference-order kernel) into racc
 hipError_t launch_bigblock_acorr(const QlpcKernelArgs& a, hipStream_t stream) {
-  // lag groups of at most 13: window (48 doubles) + three accumulator sets must fit 256 VGPRs
-  if (a.lpc_order <= 24) return launch_acorr<24, FLACENC_BIG_NG24, FLACENC_BIG_NL24>(a, stream);
-  return launch_acorr<32, 3, 11>(a, stream);  // lags 0..32
+  // order <= 24: all 25 lags in one group; up to 32: 17 + 16 (window of 48 doubles + two accumulator sets
+  // must fit 256 VGPRs)
+  if (a.lpc_order <= 24) return launch_acorr<24, FLACENC_BIG_NG24>(a, stream);
+  return launch_acorr<32, FLACENC_BIG_NG32>(a, stream);
 }
 
 hipError_t launch_bigblock_residual(const QlpcKernelArgs& a, hipStream_t stream) {

@@ -131,7 +131,7 @@ __device__ __forceinline__ double wave_tree_sum_dpp(double v) {
 // ((v0 + v1) + (v2 + v3)) + ... -- and two row shifts fold the four sixteenths, (s0 + s1) + (s2 + s3).
 // The total of value j arrives in lane 4 j + 3 (other lanes, and lanes >= 4 NV, return garbage).
 template <int NV>
-__device__ __forceinline__ double wave_tree_sums_lds(const double (&v)[NV], double* buf, int lane) {
+__device__ __forceinline__ double wave_tree_sums_lds_n(const double* v, double* buf, int lane) {
   static_assert(4 * NV <= 64, "one quad of lanes per value");
 #pragma unroll
   for (int j = 0; j < NV; ++j) buf[j * 64 + lane] = v[j];
@@ -163,6 +163,11 @@ __device__ __forceinline__ double wave_tree_sums_lds(const double (&v)[NV], doub
   FLACENC_F64_DPP_STEP(0x112, 0xF)
 #undef FLACENC_F64_DPP_STEP
   return t;
+}
+
+template <int NV>
+__device__ __forceinline__ double wave_tree_sums_lds(const double (&v)[NV], double* buf, int lane) {
+  return wave_tree_sums_lds_n<NV>(v, buf, lane);
 }
 
 __device__ __forceinline__ uint32_t wave_or_dpp(uint32_t v) {

@@ -33,9 +33,11 @@ def run(name, frames, ch, n, bps, order, stereo):
             h.qlpc_batch_device(cfg, x.data_ptr(), frames * ch, n, n, bpsv.data_ptr(), params.data_ptr(),
                                 resid.data_ptr(), n, stream=0)
 
-    for _ in range(2):
+    import time
+    t_spin = time.perf_counter()
+    while time.perf_counter() - t_spin < 0.05:  # untimed: the chip needs milliseconds of load to hold its clock
         go()
-    torch.cuda.synchronize()
+        torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     reps = 5
@@ -63,6 +65,12 @@ run("config4: 4096 x 16b 8-channel, order 10 (plain)", 2048, 8, 4096, 16, 10, Fa
 run("config5: 16384 x 24b stereo, order 24 (big-block kernels)", 1024, 2, 16384, 24, 24, True)
 run("config5: 16384 x 24b stereo, order 32 (big-block kernels)", 1024, 2, 16384, 24, 32, True)
 run("ragged: 4608 x 16b stereo, order 10 (generic kernel)", 4096, 2, 4608, 16, 10, True)
+# the big-block shapes at 3 x the batch: whole rounds of workgroups for every kernel (512 and 768 resident
+# workgroups), launch costs amortised
+run("config3, 6144 frames per launch: 8192 x 24b stereo, order 24", 6144, 2, 8192, 24, 24, True)
+run("config3, 6144 frames per launch: 8192 x 24b stereo, order 32", 6144, 2, 8192, 24, 32, True)
+run("config5, 3072 frames per launch: 16384 x 24b stereo, order 24", 3072, 2, 16384, 24, 24, True)
+run("config5, 3072 frames per launch: 16384 x 24b stereo, order 32", 3072, 2, 16384, 24, 32, True)
 
 
 def run_frames(name, frames, ch, n, bps, order):

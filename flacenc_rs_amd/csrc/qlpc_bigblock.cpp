@@ -36,6 +36,9 @@ constexpr int kPass = 4096;
 #ifndef FLACENC_BIG_NG32
 #define FLACENC_BIG_NG32 2
 #endif
+#ifndef FLACENC_BIG_RESID_PREFETCH
+#define FLACENC_BIG_RESID_PREFETCH 1
+#endif
 
 // cooperative load of pass k of the workgroup's rows into the LDS images: segment 0 of an image holds the
 // 64 samples in front of the pass (zeros in front of the block), the pass follows (widx layout)
@@ -352,9 +355,40 @@ __global__ void __launch_bounds__(256, 3) bigblock_residual_kernel(QlpcKernelArg
   int32_t* __restrict__ rrow = a.residual + (size_t)sf * a.residual_stride;
 
   uint32_t pl[K][7];
+  // Stereo blocks of two passes: the second pass's loads are issued before the first pass is worked off and
+  // parked in the images afterwards (8 int4 per thread in plain variables, see FLACENC_HALF_FETCH); the 64
+  // samples in front of a pass are the tail of the previous one, copied inside LDS.
+  // (order bucket 24 only: at 32 the eight extra registers per int4 spill, and a spilled load is waited for at once)
+  constexpr bool PREFETCH = STEREO && K == 2 && MAXP <= 24 && FLACENC_BIG_RESID_PREFETCH;
+  int4 pq0, pq1, pq2, pq3, pq4, pq5, pq6, pq7;
+#define FLACENC_PASS_FETCH(K_)                                                                                \
+  {                                                                                                            \
+    const int32_t* __restrict__ src_ = a.samples + (size_t)(2u * blk) * a.stride + (size_t)(K_) * kPass;       \
+    pq0 = *reinterpret_cast<const int4*>(src_ + (size_t)((tid + 0) >> 10) * a.stride + (((tid + 0) & 1023) << 2));       \
+    pq1 = *reinterpret_cast<const int4*>(src_ + (size_t)((tid + 256) >> 10) * a.stride + (((tid + 256) & 1023) << 2));   \
+    pq2 = *reinterpret_cast<const int4*>(src_ + (size_t)((tid + 512) >> 10) * a.stride + (((tid + 512) & 1023) << 2));   \
+    pq3 = *reinterpret_cast<const int4*>(src_ + (size_t)((tid + 768) >> 10) * a.stride + (((tid + 768) & 1023) << 2));   \
+    pq4 = *reinterpret_cast<const int4*>(src_ + (size_t)((tid + 1024) >> 10) * a.stride + (((tid + 1024) & 1023) << 2)); \
+    pq5 = *reinterpret_cast<const int4*>(src_ + (size_t)((tid + 1280) >> 10) * a.stride + (((tid + 1280) & 1023) << 2)); \
+    pq6 = *reinterpret_cast<const int4*>(src_ + (size_t)((tid + 1536) >> 10) * a.stride + (((tid + 1536) & 1023) << 2)); \
+    pq7 = *reinterpret_cast<const int4*>(src_ + (size_t)((tid + 1792) >> 10) * a.stride + (((tid + 1792) & 1023) << 2)); \
+  }
+#define FLACENC_PASS_PUT(I_, V_) \
+  *reinterpret_cast<int4*>(&sm[((tid + 256 * (I_)) >> 10) * kBufDwords + widx(((tid + 256 * (I_)) & 1023) << 2)]) = V_;
+  if (PREFETCH) FLACENC_PASS_FETCH(0)
   for (int k = 0; k < K; ++k) {
-    __syncthreads();
-    bigblock_load_pass<STEREO>(a, sm, blk, k, tid, wave, lane, sf);
+    if (PREFETCH) {
+      int4 halo = make_int4(0, 0, 0, 0);
+      if (k > 0 && tid < 32) halo = *reinterpret_cast<const int4*>(&sm[(tid >> 4) * kBufDwords + widx(kPass - 64 + ((tid & 15) << 2))]);
+      __syncthreads();
+      FLACENC_PASS_PUT(0, pq0) FLACENC_PASS_PUT(1, pq1) FLACENC_PASS_PUT(2, pq2) FLACENC_PASS_PUT(3, pq3)
+      FLACENC_PASS_PUT(4, pq4) FLACENC_PASS_PUT(5, pq5) FLACENC_PASS_PUT(6, pq6) FLACENC_PASS_PUT(7, pq7)
+      if (tid < 32) *reinterpret_cast<int4*>(&sm[(tid >> 4) * kBufDwords + widx(((tid & 15) << 2) - 64)]) = halo;
+      if (k + 1 < K) FLACENC_PASS_FETCH(k + 1)
+    } else {
+      __syncthreads();
+      bigblock_load_pass<STEREO>(a, sm, blk, k, tid, wave, lane, sf);
+    }
     __syncthreads();
     auto run = [&](auto kind_tag, uint32_t (&planes)[7]) {
       constexpr int KIND = decltype(kind_tag)::value;

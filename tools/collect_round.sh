@@ -10,4 +10,6 @@ bash tools/profile_round.sh $TAG > $O/profile_round.log 2>&1
 bash tools/profile_stages.sh $TAG > $O/profile_stages.log 2>&1
 python3 tools/bench_configs.py > $O/configs.json 2> $O/configs.txt
 tools/prof_bigblock.sh collect_$TAG/bigblock > $O/bigblock.txt 2>&1
+tools/pmc_insts_bigblock.sh collect_$TAG/bigblock_pmc24 8192 24 > $O/bigblock_pmc_n8192_p24.txt 2>&1
+tools/pmc_insts_bigblock.sh collect_$TAG/bigblock_pmc32 8192 32 > $O/bigblock_pmc_n8192_p32.txt 2>&1
 tail -c 1500 $O/bench.json; cat $O/configs.txt; cat $O/bigblock.txt | tail -30

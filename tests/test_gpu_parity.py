@@ -752,6 +752,55 @@ def test_pack_stereo_frames_device_pipeline_checksum(handle):
         assert got["number"] == f and np.array_equal(got["channels"], host[f])
 
 
+@pytest.mark.parametrize("n,bps,order,odd_stride", [
+    (4096, 24, 8, False), (8192, 24, 24, False), (12288, 24, 12, True), (16384, 24, 32, False),
+    (20480, 16, 16, False), (8192, 16, 10, True), (4096, 16, 8, True),
+])
+def test_packer_aligned_runs_all_rounds(handle, n, bps, order, odd_stride):
+    """The packer's run-of-16 path (block sizes that are multiples of 4096: one to five rounds of 4096
+    samples per subframe, partitions of 16 k samples) against the oracle's Frame::write: warm-up runs of 8,
+    24 and 32 samples (the first two threads emit nothing or a part), RICE2 (loud 24-bit noise: parameters
+    above 14), small residuals next to huge ones, constant and verbatim subframes, and residual rows that
+    are not 16-byte aligned (device entry point with an odd row stride: scalar loads)."""
+    import torch
+    F = 5
+    x = _capi.sigen_frames(F, 2, n, bps, 90.0, 0.45, 0.02, seed=31 * n + order, nthreads=2)
+    x[1] = np.stack([util.quantize(util.noise(5, n, 0.999), bps), util.quantize(util.noise(6, n, 0.999), bps)])
+    x[2, 0] = -3
+    x[3, :, n // 2:] //= 4096  # quiet second half: parameters differ wildly between partitions
+    x[4] = np.stack([util.quantize(util.noise(7, n, 0.999), bps), x[0, 1]])
+    cfg = _capi.make_frame_config(gpu_cfg(order), use_fixed=True)
+    res, resid = handle.encode_stereo_frames(x, bps, cfg)
+    want = [orc.write_stereo_frame(res[f], x[f, 0], x[f, 1], bps, 96000, 1000 + f, resid[f, 0], resid[f, 1])
+            for f in range(F)]
+    if not odd_stride:
+        got = handle.pack_stereo_frames(x, res, resid, bps, 96000, 1000, 1)
+    else:
+        rs = n + 1
+        dres = torch.zeros((F * 2, rs), dtype=torch.int32, device="cuda")
+        dres[:, :n] = torch.from_numpy(np.ascontiguousarray(resid.reshape(F * 2, n))).cuda()
+        dx = torch.from_numpy(x).cuda()
+        drec = torch.from_numpy(np.frombuffer(res.tobytes(), np.uint8).copy()).cuda()
+        stride = (handle.frame_bytes_bound(n, bps) + 15) // 16 * 16
+        out = torch.zeros((F, stride), dtype=torch.uint8, device="cuda")
+        lens = torch.zeros(F, dtype=torch.int32, device="cuda")
+        handle.pack_stereo_frames_device(dx.data_ptr(), F, n, n, drec.data_ptr(), dres.data_ptr(), rs, bps, 96000, 1000, 1,
+                                         out.data_ptr(), stride, lens.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        o, ln = out.cpu().numpy(), lens.cpu().numpy()
+        got = [bytes(o[f, :ln[f]]) for f in range(F)]
+    for f in range(F):
+        assert got[f] == want[f], (f, len(got[f]), len(want[f]))
+    rice2 = 0
+    for f in range(F):
+        for c in range(2):
+            if int(res[f]["kind"][c]) >= 2:
+                k = 1 << int(res[f]["lpc"][c]["rice_order"])
+                rice2 += int((res[f]["lpc"][c]["rice_params"][:k] > 14).any())
+    if bps == 24:
+        assert rice2 > 0
+
+
 def test_flac_stream_end_to_end(handle):
     """tools/encode_flac.py: "fLaC" + STREAMINFO + GPU-packed frames.  Every frame parses with the
     independent parser, frame numbers run 0..F-1, STREAMINFO carries the right geometry and the MD5

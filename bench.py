@@ -338,7 +338,8 @@ def run(args, world):
         if args.gather in ("records", "payload"):
             gather_desc += (" + all_gather of the frame records (the encoded SubFrame components; %d of their 752 "
                             "bytes on the wire: Rice-parameter slots beyond the block's finest partition count are "
-                            "always zero) into stream order" % shard.wire_record_bytes(n))
+                            "always zero); every rank holds the whole stream's records, addressed in stream order through a strided view "
+                            "of the collective's output" % shard.wire_record_bytes(n))
         if payload:
             gather_desc += " + Frame::write on the producing GPU and all_gather of the packed frame bytes, placed at their stream offsets"
         gather_desc += "; on its own stream, overlapping the next step's analysis"
@@ -412,7 +413,7 @@ def check_exchange(torch, dist, ex, my_records, my_lengths, rank, world, F, my_p
     ok = bool(torch.equal(lengths_all[rank::world], my_lengths))
     ok &= int(offsets[0]) == 0 and bool((offsets[1:] - offsets[:-1] == lengths_all[:-1].to(offsets.dtype)).all())
     if "records_all" in ex:
-        ok &= bool(torch.equal(ex["records_all"][rank::world], my_records))
+        ok &= bool(torch.equal(ex["records_all"].records()[rank::world], my_records))
     if "stream_bytes" in ex:
         sb = ex["stream_bytes"]
         ok &= int(ex["total"]) == int(lengths_all.to(torch.int64).sum())
@@ -619,7 +620,10 @@ def dry_run(args, world):
             sparse = torch.from_numpy(recs.copy())
             sparse[:, 48 + 96 + 64:48 + 352] = 0
             sparse[:, 48 + 352 + 96 + 64:] = 0
-            back = shard.all_gather_frame_records(sparse, total_frames, 4096)
+            gathered = shard.all_gather_frame_records(sparse, total_frames, 4096)
+            back = gathered.records()
+            ok &= all(bool(torch.equal(gathered.frame_wire(f), shard.records_to_wire(back[f:f + 1], 4096)[0]))
+                      for f in (0, total_frames // 2, total_frames - 1))
             mine_back = back[rank::world][:F]
             ok &= bool(torch.equal(mine_back, sparse)) and back.shape == (total_frames, 752)
             ids = ordered[:, :4].copy().view(np.uint32).reshape(-1)

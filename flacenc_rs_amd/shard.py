@@ -26,8 +26,10 @@ def local_frame_count(n_frames_total: int, rank: int, world: int) -> int:
     return len(frames_of_rank(n_frames_total, rank, world))
 
 
-def all_gather_records(local: torch.Tensor, n_frames_total: int, group=None) -> torch.Tensor:
+def all_gather_records(local: torch.Tensor, n_frames_total: int, group=None, materialize: bool = True) -> torch.Tensor:
     """All-gather per-frame records and return them in stream (frame-number) order.
+    `materialize=False` returns the stream order as a strided view [ceil(F / G), G, ...] of the collective's
+    output (frame f at [f // G, f % G]) instead of a re-ordered copy -- nothing but the collective runs.
 
     `local` is [n_local_frames, ...] (any trailing shape / dtype) holding this rank's frames in
     the order of `frames_of_rank`.  Ranks may own different frame counts (n_frames_total not a
@@ -36,7 +38,7 @@ def all_gather_records(local: torch.Tensor, n_frames_total: int, group=None) -> 
     """
     if not dist.is_available() or not dist.is_initialized():
         assert local.shape[0] == n_frames_total
-        return local
+        return local if materialize else local.unsqueeze(1)
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     per_rank = (n_frames_total + world - 1) // world
@@ -52,6 +54,8 @@ def all_gather_records(local: torch.Tensor, n_frames_total: int, group=None) -> 
     dist.all_gather_into_tensor(gathered, local, group=group)
     # gathered[r * per_rank + j] is stream frame j * world + r  ->  transpose (r, j) -> (j, r)
     g = gathered.view((world, per_rank) + tuple(local.shape[1:]))
+    if not materialize:
+        return g.transpose(0, 1)  # [per_rank, world, ...]: frame f at [f // world, f % world], no copy
     ordered = g.transpose(0, 1).reshape((world * per_rank,) + tuple(local.shape[1:]))
     return ordered[:n_frames_total]
 
@@ -95,11 +99,27 @@ def records_from_wire(wire: torch.Tensor, block_size: int) -> torch.Tensor:
     return out
 
 
-def all_gather_frame_records(records: torch.Tensor, n_frames_total: int, block_size: int, group=None) -> torch.Tensor:
-    """All-gather the stereo frame records (the encoded SubFrame components) in wire format and return them
-    full-size, in stream order, on every rank."""
-    wire = all_gather_records(records_to_wire(records, block_size), n_frames_total, group=group)
-    return records_from_wire(wire, block_size)
+class GatheredRecords:
+    """What all_gather_frame_records delivers on every rank: the whole stream's frame records in wire format,
+    in stream order, as a strided view of the collective's output (no re-ordering or expansion pass: a stream
+    writer reads frame f at wire[f // G, f % G]).  records() materialises the full-size 752-byte records."""
+
+    def __init__(self, wire: torch.Tensor, n_frames_total: int, block_size: int):
+        self.wire, self.n_frames_total, self.block_size = wire, n_frames_total, block_size
+
+    def frame_wire(self, f: int) -> torch.Tensor:
+        return self.wire[f // self.wire.shape[1], f % self.wire.shape[1]]
+
+    def records(self) -> torch.Tensor:
+        flat = self.wire.reshape(-1, self.wire.shape[-1])[: self.n_frames_total]
+        return records_from_wire(flat, self.block_size)
+
+
+def all_gather_frame_records(records: torch.Tensor, n_frames_total: int, block_size: int, group=None) -> GatheredRecords:
+    """All-gather the stereo frame records (the encoded SubFrame components) in wire format; every rank ends
+    up with all of them, addressable in stream order (GatheredRecords)."""
+    wire = all_gather_records(records_to_wire(records, block_size), n_frames_total, group=group, materialize=False)
+    return GatheredRecords(wire, n_frames_total, block_size)
 
 
 def all_gather_frame_lengths(local_lengths: torch.Tensor, n_frames_total: int, group=None) -> torch.Tensor:

@@ -253,6 +253,7 @@ __global__ void __launch_bounds__(256, FLACENC_BIG_ACORR_OCC) bigblock_acorr_ker
         constexpr int G = decltype(g_tag)::value;
         constexpr int lag0 = G * NL;
         constexpr int NLG = (lag0 + NL <= NLAG) ? NL : NLAG - lag0;
+        static_assert(NLG <= 2 * NBATCH, "a lag group is reduced in at most two tree rounds");
         // window of HP lagged values + one 16-sample chunk, slid by 16 between the lane's two chunks
         double dw[HP + 16];
 #pragma unroll
@@ -733,7 +734,7 @@ bool bigblock_eligible(const QlpcKernelArgs& a) {
 // R[] (unless `have_r`: already in `racc`, e.g. from the reference-order kernel) into racc
 hipError_t launch_bigblock_acorr(const QlpcKernelArgs& a, hipStream_t stream) {
   // order <= 24: all 25 lags in one group; up to 32: 17 + 16 (window of 48 doubles + two accumulator sets
-  // must fit 256 VGPRs)
+  // must fit 256 VGPRs: all 33 in one group compile to 256 registers + 5 spilled, and run 2.4 x slower)
   if (a.lpc_order <= 24) return launch_acorr<24, FLACENC_BIG_NG24>(a, stream);
   return launch_acorr<32, FLACENC_BIG_NG32>(a, stream);
 }

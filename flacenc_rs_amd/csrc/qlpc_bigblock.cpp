@@ -238,15 +238,21 @@ __global__ void __launch_bounds__(256, FLACENC_BIG_ACORR_OCC) bigblock_acorr_ker
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
           const int4 v = bigblock_hld4<KIND>(bufA, bufB, t + 4 * q);
-          float4 w = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
           if (TAPERED) {
             const int g = g0 + t + 4 * q;  // position in the block; negative only in front of the block (samples 0)
-            w = *reinterpret_cast<const float4*>(wtab + (g < 0 ? 0 : g));
+            const float4 w = *reinterpret_cast<const float4*>(wtab + (g < 0 ? 0 : g));
+            dst[4 * q + 0] = (double)((float)v.x * w.x);
+            dst[4 * q + 1] = (double)((float)v.y * w.y);
+            dst[4 * q + 2] = (double)((float)v.z * w.z);
+            dst[4 * q + 3] = (double)((float)v.w * w.w);
+          } else {
+            // weight exactly 1: (f64)((f32)s * 1.0f) == (f64)s, because samples of at most 25 bits (|s| <= 2^24,
+            // include/flacenc_hip.h) are exact in f32 -- one conversion instead of two
+            dst[4 * q + 0] = (double)v.x;
+            dst[4 * q + 1] = (double)v.y;
+            dst[4 * q + 2] = (double)v.z;
+            dst[4 * q + 3] = (double)v.w;
           }
-          dst[4 * q + 0] = (double)((float)v.x * w.x);
-          dst[4 * q + 1] = (double)((float)v.y * w.y);
-          dst[4 * q + 2] = (double)((float)v.z * w.z);
-          dst[4 * q + 3] = (double)((float)v.w * w.w);
         }
       };
       auto group = [&](auto g_tag) {

@@ -309,767 +309,35 @@ __device__ __forceinline__ void acorr_chunk(const double (&dw)[HP + 16], double 
 template <int MAXP, bool BIG>
 __global__ void __launch_bounds__(MAXP <= 12 ? 1024 : (MAXP <= 16 ? 512 : 256))
 qlpc_subframe_kernel(QlpcKernelArgs a) {
-  constexpr int ROWSTRIDE = BIG ? 16 : 20;
-  constexpr int HP = (MAXP + 3) & ~3;  // halo samples loaded, multiple of 4
-  constexpr int NLAG = MAXP + 1;
+#define FLACENC_BODY_BLOCK blockIdx.x
+#define FLACENC_BODY_DIRECT false
+#include "qlpc_kernel_body.inc"
+#undef FLACENC_BODY_BLOCK
+#undef FLACENC_BODY_DIRECT
+}
 
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-
-  const int tid = threadIdx.x;
-  const int T = blockDim.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int W = T >> 6;
-  const int n = (int)a.block_size;
-  const int rows = (n + 15) >> 4;
-  const int J = (rows + T - 1) / T;
-  int Jp = 1;
-  while (Jp < J) Jp <<= 1;
-  const int P = (int)a.lpc_order;
-  // Stereo mode: the four workgroups of a frame should share an XCD (and its L2) so that the
-  // left/right channels are fetched from HBM once: workgroups are dealt round-robin over the
-  // 8 XCDs, so block b and b+8 share one.  Blocks are grouped by 32: block 32g + 8r + x
-  // analyses role r of frame 8g + x.  (Placement is a speed matter only.)
-  uint32_t sf = blockIdx.x;
-  if (a.stereo && (a.n_subframes & 31u) == 0) {
-    const uint32_t g = sf >> 5, r = (sf >> 3) & 3u, x = sf & 7u;
-    sf = ((g << 3) + x) * 4u + r;
-  }
-  // clean-up launch behind the big-block kernels: only the subframes they marked (residuals of 2^26
-  // and more, whose bit tables need the literal chunk-clamped sums) are redone here
-  if (a.only_marked && a.params[sf].status != -1) return;
-
-  // ---- carve LDS (every offset a multiple of 16 bytes) ----
-  SmemLayout L;
-  {
-    unsigned char* p = smem_raw;
-    L.sbuf = reinterpret_cast<int32_t*>(p);
-    p += (size_t)(rows + kLeadRows) * ROWSTRIDE * 4;
-    L.red = reinterpret_cast<double*>(p);
-    p += (size_t)Jp * W * NLAG * 8;
-    p = smem_raw + (((size_t)(p - smem_raw) + 15) & ~(size_t)15);
-    L.racc = reinterpret_cast<double*>(p);
-    p += 40 * 8;
-    L.level_bits = reinterpret_cast<unsigned long long*>(p);
-    p += 16 * 8;
-    L.qc = reinterpret_cast<int32_t*>(p);
-    p += 32 * 4;
-    L.misc = reinterpret_cast<uint32_t*>(p);
-    p += kMiscCount * 4;
-    L.ps = reinterpret_cast<uint8_t*>(p);
-    p += 2 * FLACENC_HIP_MAX_RICE_PARTITIONS;
-    L.fsum = reinterpret_cast<unsigned long long*>(p);
-    p += kFixedSumWords * 8;
-    L.tables = BIG ? (a.table_scratch + (size_t)sf * FLACENC_HIP_MAX_RICE_PARTITIONS * 32)
-                   : reinterpret_cast<uint32_t*>(p);
-  }
-
-  FLACENC_STAMP(0);
-  // ======================= phase 0: load ===================================
-  // Plain mode: subframe sf is the block at samples + sf*stride.  Stereo mode
-  // (try_stereo_coding, coding.rs:476-484): workgroups 4f..4f+3 analyse L, R,
-  // M = (l + r) >> 1 and S = l - r of frame f, formed here from the two channels.
-  const int role = a.stereo ? (int)(sf & 3u) : 0;
-  const int32_t* __restrict__ src =
-      a.stereo ? a.samples + (size_t)(2u * (sf >> 2) + (role == 1 ? 1u : 0u)) * a.stride
-               : a.samples + (size_t)sf * a.stride;
-  const int32_t* __restrict__ src2 = src + a.stride;  // right channel, roles 2 and 3 only
-  if (tid < kMiscCount) L.misc[tid] = 0;
-  if (tid < 16) L.level_bits[tid] = 0ull;
-  for (int i = tid; i < kLeadRows * ROWSTRIDE; i += T) L.sbuf[i] = 0;
-  uint32_t my_maxabs = 0;
-  {
-    const bool vec_ok = ((reinterpret_cast<uintptr_t>(src) & 15) == 0) && ((a.stride & 3) == 0);
-    for (int q = tid; q < rows * 4; q += T) {
-      int t = q * 4;
-      int4 v;
-      if (vec_ok && t + 3 < n) {
-        v = *reinterpret_cast<const int4*>(src + t);
-      } else {
-        v.x = (t + 0 < n) ? src[t + 0] : 0;
-        v.y = (t + 1 < n) ? src[t + 1] : 0;
-        v.z = (t + 2 < n) ? src[t + 2] : 0;
-        v.w = (t + 3 < n) ? src[t + 3] : 0;
-      }
-      if (role >= 2) {
-        int4 r;
-        if (vec_ok && t + 3 < n) {
-          r = *reinterpret_cast<const int4*>(src2 + t);
-        } else {
-          r.x = (t + 0 < n) ? src2[t + 0] : 0;
-          r.y = (t + 1 < n) ? src2[t + 1] : 0;
-          r.z = (t + 2 < n) ? src2[t + 2] : 0;
-          r.w = (t + 3 < n) ? src2[t + 3] : 0;
-        }
-        if (role == 2) {
-          v.x = (v.x + r.x) >> 1;
-          v.y = (v.y + r.y) >> 1;
-          v.z = (v.z + r.z) >> 1;
-          v.w = (v.w + r.w) >> 1;
-        } else {
-          v.x -= r.x;
-          v.y -= r.y;
-          v.z -= r.z;
-          v.w -= r.w;
-        }
-      }
-      *reinterpret_cast<int4*>(&L.sbuf[sidx<ROWSTRIDE>(t)]) = v;
-      uint32_t ax = (uint32_t)(v.x < 0 ? -(int64_t)v.x : (int64_t)v.x);
-      uint32_t ay = (uint32_t)(v.y < 0 ? -(int64_t)v.y : (int64_t)v.y);
-      uint32_t az = (uint32_t)(v.z < 0 ? -(int64_t)v.z : (int64_t)v.z);
-      uint32_t aw = (uint32_t)(v.w < 0 ? -(int64_t)v.w : (int64_t)v.w);
-      ax = ax > ay ? ax : ay;
-      az = az > aw ? az : aw;
-      ax = ax > az ? ax : az;
-      my_maxabs = my_maxabs > ax ? my_maxabs : ax;
-    }
-  }
-  __syncthreads();
-  my_maxabs = wave_max_u32(my_maxabs);
-  if (lane == 0) atomicMax(&L.misc[kMiscMaxAbs], my_maxabs);
-
-  FLACENC_STAMP(1);
-  if (a.fixed_mode != 0) {
-    // ======================= fixed-LPC candidate (coding.rs:298-331) =========
-    // The predictor is one of FIXED_LPC_COEFS (decode.rs:179-185) with shift 0 instead of the
-    // Levinson solution; everything downstream (error signal, Rice search, bit counts) is the
-    // QLPC machinery.  fixed_mode 1: pick the order with estimate_entropy (OrderSel::ApproxEnt,
-    // coding.rs:265-287) first; 2: order = forced_uniform (one pass of OrderSel::BitCount,
-    // coding.rs:243-264); 3: order = forced_orders[sf] (BitCount's final pass).
-    const unsigned long long bps_sf = a.bps ? (unsigned long long)a.bps[sf]
-                                            : (unsigned long long)(a.bps_uniform + (role == 3 ? 1u : 0u));
-    if (a.fixed_mode == 1u) {
-      unsigned long long* const fsum = L.fsum;
-      unsigned long long* const ftot = L.fsum + 5 * 64;
-      for (int i = tid; i < kFixedSumWords; i += T) fsum[i] = 0ull;
-      __syncthreads();
-      const int parts = (int)a.fixed_partitions;
-      const int psz = (n + parts - 1) / parts;  // block_size.div_ceil(partitions), coding.rs:209
-      // exact integer sums of |e_k[t]| per (order, partition); e_k by the binomial form of k
-      // wrapping differences with zero history (reset_fixed_lpc_errors, coding.rs:182-197)
-      for (int j = 0; j < J; ++j) {
-        const int c = tid + j * T;
-        const int t0 = c << 4;
-        if (c < rows) {
-          uint32_t x[20];
-#pragma unroll
-          for (int i = 0; i < 5; ++i) {
-            const int4 v = *reinterpret_cast<const int4*>(&L.sbuf[sidx<ROWSTRIDE>(t0 - 4 + 4 * i)]);
-            x[4 * i + 0] = (uint32_t)v.x;
-            x[4 * i + 1] = (uint32_t)v.y;
-            x[4 * i + 2] = (uint32_t)v.z;
-            x[4 * i + 3] = (uint32_t)v.w;
-          }
-          int cur = t0 / psz;
-          unsigned long long acc[5] = {0ull, 0ull, 0ull, 0ull, 0ull};
-#pragma unroll
-          for (int k = 0; k < 16; ++k) {
-            const int t = t0 + k;
-            if (t < n) {
-              const int pidx = t / psz;
-              if (pidx != cur) {
-#pragma unroll
-                for (int o = 0; o < 5; ++o) {
-                  if (acc[o]) atomicAdd(&fsum[o * 64 + cur], acc[o]);
-                  acc[o] = 0ull;
-                }
-                cur = pidx;
-              }
-              const uint32_t x0 = x[4 + k], x1 = x[3 + k], x2 = x[2 + k], x3 = x[1 + k], x4 = x[k];
-              const int32_t e0 = (int32_t)x0;
-              const int32_t e1 = (int32_t)(x0 - x1);
-              const int32_t e2 = (int32_t)(x0 - 2u * x1 + x2);
-              const int32_t e3 = (int32_t)(x0 - 3u * x1 + 3u * x2 - x3);
-              const int32_t e4 = (int32_t)(x0 - 4u * x1 + 6u * x2 - 4u * x3 + x4);
-              acc[0] += (unsigned long long)(e0 < 0 ? -(int64_t)e0 : (int64_t)e0);
-              acc[1] += (unsigned long long)(e1 < 0 ? -(int64_t)e1 : (int64_t)e1);
-              acc[2] += (unsigned long long)(e2 < 0 ? -(int64_t)e2 : (int64_t)e2);
-              acc[3] += (unsigned long long)(e3 < 0 ? -(int64_t)e3 : (int64_t)e3);
-              acc[4] += (unsigned long long)(e4 < 0 ? -(int64_t)e4 : (int64_t)e4);
-            }
-          }
-#pragma unroll
-          for (int o = 0; o < 5; ++o)
-            if (acc[o]) atomicAdd(&fsum[o * 64 + cur], acc[o]);
-        }
-      }
-      __syncthreads();
-      // estimate_entropy, coding.rs:200-227: one (order, partition) pair per thread
-      for (int i = tid; i < 5 * parts; i += T) {
-        const int ord = i / parts, pidx = i - ord * parts;
-        if (ord <= (int)a.fixed_max_order) {
-          const long long off0 = (long long)pidx * psz;
-          const int offset = off0 < n ? (int)off0 : n;
-          const int end = offset + psz < n ? offset + psz : n;
-          const int plen = end - offset;
-          if (end >= ord) {
-            const int cnt = end - ord < plen ? end - ord : plen;
-            const uint32_t pb = approx_ent_bits((double)fsum[ord * 64 + pidx], (uint32_t)cnt);
-            atomicAdd(&ftot[ord], (unsigned long long)pb);
-          }
-        }
-      }
-      __syncthreads();
-    }
-    if (tid == 0) {
-      int k;
-      unsigned long long key = 0ull;
-      if (a.fixed_mode == 1u) {
-        k = 0;
-        key = ~0ull;
-        for (int ord = 0; ord <= (int)a.fixed_max_order; ++ord) {
-          const unsigned long long kk = L.fsum[5 * 64 + ord] + bps_sf * (unsigned long long)ord;
-          if (a.fixed_keys) a.fixed_keys[(size_t)sf * 8 + ord] = kk;
-          if (kk < key) {  // min_by_key keeps the first minimum
-            key = kk;
-            k = ord;
-          }
-        }
-        if (a.selector_keys) a.selector_keys[sf] = key;
-      } else if (a.fixed_mode == 2u) {
-        k = (int)a.forced_uniform;
-      } else {
-        k = (int)a.forced_orders[sf];
-      }
-      for (int i = 0; i < 32; ++i) L.qc[i] = 0;
-      L.qc[0] = k;  // FIXED_LPC_COEFS[k]: 0 / 1 / 2,-1 / 3,-3,1 / 4,-6,4,-1
-      L.qc[1] = k == 2 ? -1 : (k == 3 ? -3 : (k == 4 ? -6 : 0));
-      L.qc[2] = k == 3 ? 1 : (k == 4 ? 4 : 0);
-      L.qc[3] = k == 4 ? -1 : 0;
-      const uint64_t maxabs = (uint64_t)L.misc[kMiscMaxAbs];
-      const uint64_t sumabs = k == 0 ? 0 : (k == 1 ? 1 : (k == 2 ? 3 : (k == 3 ? 7 : 15)));
-      const bool narrow = (maxabs * sumabs < 0x7FFFFFFFull) && (maxabs < (1u << 23));
-      L.misc[kMiscOrder] = (uint32_t)k;
-      L.misc[kMiscShift] = 0u;
-      L.misc[kMiscStatus] = 0u;
-      L.misc[kMiscWide] = narrow ? 0u : 1u;
-    }
-    __syncthreads();
-  } else if (a.lpc_stage == 3u) {
-    // ======================= predictor solved by levinson_batch_kernel ========
-    // (three-launch split for large orders: the serial recursion runs one subframe per LANE in a
-    // kernel of its own instead of one per workgroup here; see launch_qlpc)
-    if (tid == 0) {
-      const int32_t* pr = a.pred + (size_t)sf * 36;
-      int64_t sumabs = 0;
-      for (int i = 0; i < 32; ++i) {
-        L.qc[i] = pr[i];
-        sumabs += pr[i] < 0 ? -pr[i] : pr[i];
-      }
-      const uint64_t maxabs = (uint64_t)L.misc[kMiscMaxAbs];
-      const bool narrow = (maxabs * (uint64_t)sumabs < 0x7FFFFFFFull) && (maxabs < (1u << 23));
-      L.misc[kMiscOrder] = (uint32_t)pr[32];
-      L.misc[kMiscShift] = (uint32_t)pr[33];
-      L.misc[kMiscStatus] = (uint32_t)pr[34];
-      L.misc[kMiscWide] = narrow ? 0u : 1u;
-    }
-    __syncthreads();
-  } else {
-  // ======================= phase 1: window + autocorrelation ==============
-  // window table has 32 floats of zero padding in front and is padded to whole rows
-  const float* __restrict__ wtab = a.window ? (a.window + 32) : nullptr;
-  for (int j = 0; j < J; ++j) {
-    const int c = tid + j * T;  // chunk index
-    const int t0 = c << 4;
-    double acc[NLAG];
-#pragma unroll
-    for (int i = 0; i < NLAG; ++i) acc[i] = 0.0;
-    if (c < rows) {
-      // samples t0-HP .. t0+15 from LDS
-      int sw[HP + 16];
-#pragma unroll
-      for (int i = 0; i < (HP + 16) / 4; ++i) {
-        int t = t0 - HP + 4 * i;
-        int4 v = *reinterpret_cast<const int4*>(&L.sbuf[sidx<ROWSTRIDE>(t)]);
-        sw[4 * i + 0] = v.x;
-        sw[4 * i + 1] = v.y;
-        sw[4 * i + 2] = v.z;
-        sw[4 * i + 3] = v.w;
-      }
-      double dw[HP + 16];
-      const bool flat = (wtab == nullptr) || (t0 - HP >= a.flat_lo && t0 + 16 <= a.flat_hi);
-      if (flat) {
-        // w == 1.0f: (f32)s * 1.0f == (f32)s exactly (lpc.rs:751-754)
-#pragma unroll
-        for (int i = 0; i < HP + 16; ++i) dw[i] = (double)(float)sw[i];
-      } else {
-#pragma unroll
-        for (int i = 0; i < (HP + 16) / 4; ++i) {
-          float4 wv = *reinterpret_cast<const float4*>(wtab + (t0 - HP + 4 * i));
-          dw[4 * i + 0] = (double)((float)sw[4 * i + 0] * wv.x);
-          dw[4 * i + 1] = (double)((float)sw[4 * i + 1] * wv.y);
-          dw[4 * i + 2] = (double)((float)sw[4 * i + 2] * wv.z);
-          dw[4 * i + 3] = (double)((float)sw[4 * i + 3] * wv.w);
-        }
-      }
-      if (t0 < P) acorr_chunk<MAXP, HP, true>(dw, acc, t0, P);
-      else acorr_chunk<MAXP, HP, false>(dw, acc, t0, P);
-    }
-    // balanced tree over the chunk index: lanes first ...
-#pragma unroll
-    for (int tau = 0; tau < NLAG; ++tau) {
-      double v = wave_butterfly_sum(acc[tau]);
-      if (lane == 0) L.red[((size_t)j * W + wave) * NLAG + tau] = v;
-    }
-  }
-  for (int i = tid; i < (Jp - J) * W * NLAG; i += T) L.red[(size_t)J * W * NLAG + i] = 0.0;
-  __syncthreads();
-  // ... then waves and chunk rounds (entry e = j*W + w are the chunk index's high bits)
-  if (tid < NLAG) {
-    const int E = Jp * W;
-    for (int s = 1; s < E; s <<= 1)
-      for (int e = 0; e < E; e += 2 * s)
-        L.red[(size_t)e * NLAG + tid] += L.red[(size_t)(e + s) * NLAG + tid];
-    double r = L.red[tid];
-    L.racc[tid] = r;
-    if (a.autocorr) a.autocorr[(size_t)sf * 33 + tid] = (tid <= P) ? r : 0.0;
-  }
-  if (a.autocorr && tid >= NLAG && tid < 33) a.autocorr[(size_t)sf * 33 + tid] = 0.0;
-  if (a.lpc_stage == 1u) return;  // first launch of the split: R[] is all this one produces
-  __syncthreads();
-
-  FLACENC_STAMP(2);
-  // ======================= phase 2: Levinson + quantisation ================
-  if (tid == 0) {
-    double coef[MAXP];
-    int32_t qc[MAXP];
-    int order, shift;
-    int status = levinson_quantize<MAXP>(L.racc, P, (int)a.precision, coef, qc, &order, &shift);
-    int64_t sumabs = 0;
-#pragma unroll
-    for (int i = 0; i < MAXP; ++i) {
-      L.qc[i] = qc[i];
-      sumabs += qc[i] < 0 ? -qc[i] : qc[i];
-    }
-    for (int i = MAXP; i < 32; ++i) L.qc[i] = 0;
-    // compute_error's path choice (lpc.rs:361-377): i32 lanes iff max|s| * sum|c| < i32::MAX.
-    // The narrow path below additionally needs |s| < 2^23 for the 24-bit multiplier.
-    uint64_t maxabs = (uint64_t)L.misc[kMiscMaxAbs];
-    bool narrow = (maxabs * (uint64_t)sumabs < 0x7FFFFFFFull) && (maxabs < (1u << 23));
-    L.misc[kMiscOrder] = (uint32_t)order;
-    L.misc[kMiscShift] = (uint32_t)shift;
-    L.misc[kMiscStatus] = (uint32_t)status;
-    L.misc[kMiscWide] = narrow ? 0u : 1u;
-    if (a.lpc_coefs) {
-#pragma unroll
-      for (int i = 0; i < MAXP; ++i) a.lpc_coefs[(size_t)sf * 32 + i] = (i < P && status == 0) ? coef[i] : 0.0;
-      for (int i = MAXP; i < 32; ++i) a.lpc_coefs[(size_t)sf * 32 + i] = 0.0;
-    }
-  }
-  __syncthreads();
-  }  // QLPC predictor
-
-  FLACENC_STAMP(3);
-  const int warm = (int)L.misc[kMiscOrder];
-  const int shift = (int)L.misc[kMiscShift];
-  const int status = (int)L.misc[kMiscStatus];
-  const bool wide = L.misc[kMiscWide] != 0;
-
-  // ======================= phase 3: residual ===============================
-  // e[t] = s[t] - ((sum_j c_j * s[t-1-j]) >> shift), e[0..order') = 0 (lpc.rs:306-350).
-  // Chunk rounds run downwards so a round only overwrites rows no later round reads.
-  uint32_t my_or = 0;
-  {
-    int32_t cq[MAXP];
-#pragma unroll
-    for (int i = 0; i < MAXP; ++i) cq[i] = L.qc[i];
-    for (int j = J - 1; j >= 0; --j) {
-      const int c = tid + j * T;
-      const int t0 = c << 4;
-      int32_t e[16];
-      if (c < rows) {
-        int sw[HP + 16];
-#pragma unroll
-        for (int i = 0; i < (HP + 16) / 4; ++i) {
-          int t = t0 - HP + 4 * i;
-          int4 v = *reinterpret_cast<const int4*>(&L.sbuf[sidx<ROWSTRIDE>(t)]);
-          sw[4 * i + 0] = v.x;
-          sw[4 * i + 1] = v.y;
-          sw[4 * i + 2] = v.z;
-          sw[4 * i + 3] = v.w;
-        }
-        if (!wide) {
-#pragma unroll
-          for (int k = 0; k < 16; ++k) {
-            int32_t pred = 0;
-#pragma unroll
-            for (int i = 0; i < MAXP; ++i) pred += __mul24(cq[i], sw[HP + k - 1 - i]);
-            e[k] = sw[HP + k] - (pred >> shift);
-          }
-        } else {
-#pragma unroll
-          for (int k = 0; k < 16; ++k) {
-            int64_t pred = 0;
-#pragma unroll
-            for (int i = 0; i < MAXP; ++i) pred += (int64_t)cq[i] * (int64_t)sw[HP + k - 1 - i];
-            e[k] = (int32_t)(uint32_t)(uint64_t)((int64_t)sw[HP + k] - (pred >> shift));
-          }
-        }
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-          int t = t0 + k;
-          if (t < warm || t >= n || status != 0) e[k] = 0;
-          my_or |= zigzag(e[k]);
-        }
-      }
-      __syncthreads();
-      if (c < rows) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          int4 v;
-          v.x = e[4 * i + 0];
-          v.y = e[4 * i + 1];
-          v.z = e[4 * i + 2];
-          v.w = e[4 * i + 3];
-          *reinterpret_cast<int4*>(&L.sbuf[sidx<ROWSTRIDE>(t0 + 4 * i)]) = v;
-        }
-      }
-    }
-  }
-  my_or = wave_or_u32(my_or);
-  if (lane == 0) atomicOr(&L.misc[kMiscOrBits], my_or);
-  __syncthreads();
-
-  FLACENC_STAMP(4);
-  // ======================= phase 4: partitioned-Rice search ================
-  // finest_partition_order(n, max(64, warm)), rice.rs:157-165, 247-250 (warm <= 32 < 64)
-  int fo;
-  {
-    uint32_t max_splits = (uint32_t)n / 64u;
-    int lg = 31 - __clz((int)max_splits);
-    int tz = __ffs(n) - 1;
-    fo = lg < tz ? lg : tz;
-    fo = fo < 15 ? fo : 15;
-    if (fo > 8) fo = 8;  // unreachable for n <= 32767
-  }
-  const int nparts = 1 << fo;
-  const int psize = n >> fo;
-  const int hw = tid >> 5;      // half-wave id: one bit table (32 lanes = 32 parameters) each
-  const int NHW = T >> 5;
-  const uint32_t p = (uint32_t)(tid & 31);
-
-  // Parameters beyond the residual's bit length can never win: for p >= bitlen every
-  // u >> p is 0, so a table entry is 4 + len*(p+1), strictly increasing in p, in every
-  // partition and therefore in every merged table.  Capping the search at
-  // min(max_p, bitlen) returns the same minimiser and the same bits as rice.rs:115-141.
-  const bool finest_only = a.rice_finest_only != 0;  // FLACENC_HIP_FLAG_FINEST_RICE_ORDER
-  const uint32_t maxu = L.misc[kMiscOrBits];
-  const uint32_t bitlen = maxu ? (uint32_t)(32 - __clz((int)maxu)) : 0u;
-  const uint32_t max_p = a.max_rice_parameter < bitlen ? a.max_rice_parameter : bitlen;
-
-  // Fast path: finest partitions of exactly 64 samples (every power-of-two block) are the
-  // 4 x 16 samples of 4 adjacent lanes.  Sum_i (u_i >> p) = Sum_b C_b 2^(b-p) with C_b the
-  // number of samples whose bit b is set; C_b is counted for all 32 b at once, bit-sliced:
-  // a carry-save adder tree over the thread's 16 words gives 5 bit-planes, two cross-lane
-  // adds (DPP quad permutes) give the 7 planes of the partition's counts, and then
-  // Sum_i (u_i >> p) = Sum_k (plane_k >> p) << k.  Exact totals equal the reference's
-  // chunk-clamped u32 sums (rice.rs:75-98) as long as no 16-sample chunk can wrap or
-  // exceed the clamp before the final min, i.e. u < 2^26; otherwise the literal path runs.
-  int first_generic_level = 0;
-  const bool fast = (psize == 64) && (maxu < (1u << 26));
-  if (fast) {
-    int kw = fo < 4 ? fo : 4;  // merge levels that stay inside one wave (16 partitions)
-    for (int j = 0; j < J; ++j) {
-      const int c = tid + j * T;
-      uint32_t u[16];
-      if (c < rows) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          int4 v = *reinterpret_cast<const int4*>(&L.sbuf[sidx<ROWSTRIDE>((c << 4) + 4 * i)]);
-          u[4 * i + 0] = zigzag(v.x);
-          u[4 * i + 1] = zigzag(v.y);
-          u[4 * i + 2] = zigzag(v.z);
-          u[4 * i + 3] = zigzag(v.w);
-        }
-      } else {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) u[i] = 0;
-      }
-      // Harley-Seal carry-save adder tree: 16 words -> planes {1, 2, 4, 8, 16}
-      uint32_t pl[7];
-      {
-        uint32_t ones = 0, twos = 0, fours = 0, eights = 0, sixteens;
-        uint32_t twosA, twosB, foursA, foursB, eightsA, eightsB;
-#define FLACENC_CSA(h, l, a_, b_, c_)                  \
-  {                                                    \
-    uint32_t t_ = (a_) ^ (b_);                         \
-    uint32_t h_ = (t_ & (c_)) | (~t_ & (a_));          \
-    l = t_ ^ (c_);                                     \
-    h = h_;                                            \
-  }
-        FLACENC_CSA(twosA, ones, ones, u[0], u[1])
-        FLACENC_CSA(twosB, ones, ones, u[2], u[3])
-        FLACENC_CSA(foursA, twos, twos, twosA, twosB)
-        FLACENC_CSA(twosA, ones, ones, u[4], u[5])
-        FLACENC_CSA(twosB, ones, ones, u[6], u[7])
-        FLACENC_CSA(foursB, twos, twos, twosA, twosB)
-        FLACENC_CSA(eightsA, fours, fours, foursA, foursB)
-        FLACENC_CSA(twosA, ones, ones, u[8], u[9])
-        FLACENC_CSA(twosB, ones, ones, u[10], u[11])
-        FLACENC_CSA(foursA, twos, twos, twosA, twosB)
-        FLACENC_CSA(twosA, ones, ones, u[12], u[13])
-        FLACENC_CSA(twosB, ones, ones, u[14], u[15])
-        FLACENC_CSA(foursB, twos, twos, twosA, twosB)
-        FLACENC_CSA(eightsB, fours, fours, foursA, foursB)
-        FLACENC_CSA(sixteens, eights, eights, eightsA, eightsB)
-#undef FLACENC_CSA
-        pl[0] = ones;
-        pl[1] = twos;
-        pl[2] = fours;
-        pl[3] = eights;
-        pl[4] = sixteens;
-      }
-      // bit-sliced ripple adds with lane^1 (quad_perm 1,0,3,2) then lane^2 (quad_perm 2,3,0,1)
-      {
-        uint32_t carry = 0;
-#pragma unroll
-        for (int k = 0; k < 5; ++k) {
-          uint32_t b = (uint32_t)__builtin_amdgcn_mov_dpp((int)pl[k], 0xB1, 0xF, 0xF, false);
-          uint32_t t_ = pl[k] ^ b;
-          uint32_t s_ = t_ ^ carry;
-          carry = (t_ & carry) | (~t_ & pl[k]);
-          pl[k] = s_;
-        }
-        pl[5] = carry;
-        carry = 0;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-          uint32_t b = (uint32_t)__builtin_amdgcn_mov_dpp((int)pl[k], 0x4E, 0xF, 0xF, false);
-          uint32_t t_ = pl[k] ^ b;
-          uint32_t s_ = t_ ^ carry;
-          carry = (t_ & carry) | (~t_ & pl[k]);
-          pl[k] = s_;
-        }
-        pl[6] = carry;
-      }
-      // this lane's share of the partition's table: parameters p = (lane & 3) + 4 i
-      const int q0 = c >> 2;  // finest partition index
-      const uint32_t len = 64u - (q0 == 0 ? (uint32_t)warm : 0u);
-      const uint32_t pq = (uint32_t)(tid & 3);
-      uint32_t tv[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const uint32_t pp = pq + 4u * (uint32_t)i;
-        uint32_t sum = 0;
-        if (4u * (uint32_t)i <= max_p) {  // block-uniform trip count
-#pragma unroll
-          for (int k = 0; k < 7; ++k) sum += (pl[k] >> pp) << k;
-        }
-        sum = sum < kMaxPToBits ? sum : kMaxPToBits;
-        uint32_t v = sum + (4u + len * (pp + 1u));  // rice.rs:69-71, 95-98
-        tv[i] = v < kMaxPToBits ? v : kMaxPToBits;
-      }
-      // orders fo .. fo-kw inside the wave: minimiser per partition (quad, then wider groups),
-      // merge with the neighbouring group by a lane butterfly (rice.rs:144-152, 193-216)
-      for (int k = 0; k <= (finest_only ? 0 : kw); ++k) {
-        if (k > 0) {
-          const int xm = 2 << k;  // lane xor 4, 8, 16, 32
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            uint32_t o = (uint32_t)__shfl_xor((int)tv[i], xm, 64);
-            uint32_t v = tv[i] + o - 4u;
-            tv[i] = v < kMaxPToBits ? v : kMaxPToBits;
-          }
-        }
-        uint32_t packed = 0xFFFFFFFFu;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const uint32_t pp = pq + 4u * (uint32_t)i;
-          uint32_t cand = (((pp <= max_p) ? tv[i] : 0xFFFFFFFFu) << 5) | pp;
-          packed = cand < packed ? cand : packed;
-        }
-        {
-          uint32_t o = (uint32_t)__builtin_amdgcn_mov_dpp((int)packed, 0xB1, 0xF, 0xF, false);
-          packed = o < packed ? o : packed;
-          o = (uint32_t)__builtin_amdgcn_mov_dpp((int)packed, 0x4E, 0xF, 0xF, false);
-          packed = o < packed ? o : packed;
-        }
-        const int qk = q0 >> k;
-        const int m = nparts >> k;
-        if ((lane & ((4 << k) - 1)) == 0 && qk < m) {
-          uint32_t bits = packed >> 5;
-          uint8_t* ps_k = L.ps + (2 * nparts - 2 * m);
-          ps_k[qk] = (uint8_t)(packed & 31u);
-          atomicAdd(&L.level_bits[k], (unsigned long long)bits);
-          if (bits >= kMaxPToBits) atomicOr(&L.misc[kMiscSat], 1u << k);
-        }
-      }
-      // hand the wave's order-(fo-kw) table to the cross-wave levels
-      if (kw < fo && lane < 4 && c < rows) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) L.tables[(size_t)q0 * 32 + pq + 4u * (uint32_t)i] = tv[i];
-      }
-    }
-    first_generic_level = kw + 1;
-  } else {
-    // PrcBitTable::from_errors(errs, 4), rice.rs:65-103, literally: u32 wrapping adds,
-    // clamp after every 16 samples of the partition's slice and after the offset.
-    for (int q = hw; q < nparts; q += NHW) {
-      int start = q * psize;
-      if (start < warm) start = warm;
-      const int end = (q + 1) * psize;
-      const int len = end - start;
-      uint32_t accb = 0;
-      // (16 at a time: the LDS reads of a run are independent of the running sum, so unrolled they
-      // overlap instead of paying the LDS latency once per sample)
-      int i = 0;
-      for (; i + 16 <= len; i += 16) {
-        uint32_t uu[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) uu[j] = zigzag(L.sbuf[sidx<ROWSTRIDE>(start + i + j)]);
-#pragma unroll
-        for (int j = 0; j < 16; ++j) accb += uu[j] >> p;
-        accb = accb < kMaxPToBits ? accb : kMaxPToBits;  // i + 15 is the run's 16th sample
-      }
-      for (; i < len; ++i) {
-        uint32_t u = zigzag(L.sbuf[sidx<ROWSTRIDE>(start + i)]);
-        accb += u >> p;
-      }
-      accb = accb < kMaxPToBits ? accb : kMaxPToBits;
-      uint32_t v = accb + (4u + (uint32_t)len * (p + 1u));
-      v = v < kMaxPToBits ? v : kMaxPToBits;
-      L.tables[(size_t)q * 32 + p] = v;
-    }
-  }
-  if (BIG) __threadfence_block();
-  __syncthreads();
-
-  FLACENC_STAMP(5);
-  // eval_partitions / merge_partitions over the remaining orders (rice.rs:193-216, 277-291).
-  // Level k keeps its tables at indices q << k.
-  for (int k = first_generic_level; k <= (finest_only ? 0 : fo); ++k) {
-    const int m = nparts >> k;
-    const int stride = 1 << k;
-    uint8_t* ps_k = L.ps + (2 * nparts - 2 * m);  // level k owns m bytes at this offset
-    for (int q = hw; q < m; q += NHW) {
-      const size_t idx = (size_t)q * stride;
-      uint32_t v = L.tables[idx * 32 + p];
-      if (k > 0) {
-        // PrcBitTable::merge(other, 4), rice.rs:144-152
-        uint32_t o = L.tables[(idx + (stride >> 1)) * 32 + p];
-        v = v + o - 4u;
-        v = v < kMaxPToBits ? v : kMaxPToBits;
-        L.tables[idx * 32 + p] = v;
-      }
-      // PrcBitTable::minimizer(max_p), rice.rs:115-141: min of (bits << 5) | p, ties -> smallest p
-      uint32_t packed = (((p <= max_p) ? v : 0xFFFFFFFFu) << 5) | p;
-#pragma unroll
-      for (int msk = 1; msk < 32; msk <<= 1) {
-        uint32_t o = (uint32_t)__shfl_xor((int)packed, msk, 64);
-        packed = o < packed ? o : packed;
-      }
-      if (p == 0) {
-        uint32_t bits = packed >> 5;
-        ps_k[q] = (uint8_t)(packed & 31u);
-        atomicAdd(&L.level_bits[k], (unsigned long long)bits);
-        if (bits >= kMaxPToBits) atomicOr(&L.misc[kMiscSat], 1u << k);
-      }
-    }
-    if (BIG) __threadfence_block();
+// Clean-up launch behind the big-block kernels: only the subframes they marked (status -1: residuals of 2^26
+// and more, whose bit tables need the literal chunk-clamped sums) are redone.  A handful of workgroups, each
+// looking at blockDim.x consecutive records at once -- normally none is marked and the launch costs what an
+// empty kernel costs instead of one workgroup, with its LDS allocation, per subframe.  The body is a real
+// call here (inlined into a loop it does not finish compiling).
+template <int MAXP, bool BIG>
+__device__ __attribute__((noinline)) void qlpc_subframe_call(const QlpcKernelArgs& a, const uint32_t sf_direct) {
+#define FLACENC_BODY_BLOCK sf_direct
+#define FLACENC_BODY_DIRECT true
+#include "qlpc_kernel_body.inc"
+#undef FLACENC_BODY_BLOCK
+#undef FLACENC_BODY_DIRECT
+}
+template <int MAXP, bool BIG>
+__global__ void __launch_bounds__(256) qlpc_marked_kernel(QlpcKernelArgs a) {
+  const uint32_t base = blockIdx.x * blockDim.x;
+  const uint32_t mine = base + threadIdx.x;
+  if (!__syncthreads_or(mine < a.n_subframes && a.params[mine].status == -1 ? 1 : 0)) return;
+  for (uint32_t i = 0; i < blockDim.x && base + i < a.n_subframes; ++i) {
+    if (a.params[base + i].status == -1) qlpc_subframe_call<MAXP, BIG>(a, base + i);
     __syncthreads();
   }
-
-  // pick the order: start at the finest, move to a coarser one only on strictly
-  // fewer bits (rice.rs:285) -> among equal totals the finest wins.
-  if (tid == 0) {
-    int best = 0;
-    unsigned long long best_bits = L.level_bits[0];
-    for (int k = 1; k <= (finest_only ? 0 : fo); ++k) {
-      if (L.level_bits[k] < best_bits) {
-        best_bits = L.level_bits[k];
-        best = k;
-      }
-    }
-    L.misc[kMiscBestOrder] = (uint32_t)best;
-  }
-  __syncthreads();
-  const int bestk = (int)L.misc[kMiscBestOrder];
-  const int rice_order = fo - bestk;
-  const int best_parts = nparts >> bestk;
-  const uint8_t* best_ps = L.ps + (2 * nparts - 2 * best_parts);
-  const int best_psize = n >> rice_order;
-  const unsigned long long code_bits = L.level_bits[bestk];
-
-  FLACENC_STAMP(6);
-  // ======================= phase 5: outputs ================================
-  int32_t* __restrict__ dst = a.residual + (size_t)sf * a.residual_stride;
-  {
-    const bool vec_ok = ((reinterpret_cast<uintptr_t>(dst) & 15) == 0) && ((a.residual_stride & 3) == 0);
-    for (int q = tid; q < rows * 4; q += T) {
-      int t = q * 4;
-      int4 v = *reinterpret_cast<const int4*>(&L.sbuf[sidx<ROWSTRIDE>(t)]);
-      if (vec_ok && t + 3 < n) {
-        *reinterpret_cast<int4*>(dst + t) = v;
-      } else {
-        if (t + 0 < n) dst[t + 0] = v.x;
-        if (t + 1 < n) dst[t + 1] = v.y;
-        if (t + 2 < n) dst[t + 2] = v.z;
-        if (t + 3 < n) dst[t + 3] = v.w;
-      }
-    }
-  }
-
-  // Residual::sum_quotients (datatype.rs:2325-2331).  When no selected table entry
-  // saturated it follows from code_bits: code_bits = sum_q + 4*parts + (n - warm)
-  // + sum_k p_k * len_k (rice.rs:69-71, 95-98).  Otherwise count it from the samples.
-  unsigned long long sum_q = 0;
-  // (the literal table sums are u32 wrapping adds, rice.rs:88-93: once a 16-sample run of quotients
-  // can wrap -- zig-zag codes of 2^26 and more -- code_bits no longer determines the true sum either)
-  const bool saturated = ((L.misc[kMiscSat] >> bestk) & 1u) != 0 || maxu >= (1u << 26);
-  if (saturated) {
-    unsigned long long mine = 0;
-    for (int t = tid; t < n; t += T) {
-      if (t >= warm) {
-        uint32_t u = zigzag(L.sbuf[sidx<ROWSTRIDE>(t)]);
-        mine += (unsigned long long)(u >> best_ps[t / best_psize]);
-      }
-    }
-    __syncthreads();
-    if (tid == 0) L.level_bits[15] = 0ull;
-    __syncthreads();
-    atomicAdd(&L.level_bits[15], mine);
-    __syncthreads();
-    sum_q = L.level_bits[15];
-  }
-
-  flacenc_hip_subframe_params* rec = a.params + sf;
-  for (int i = tid; i < FLACENC_HIP_MAX_RICE_PARTITIONS; i += T)
-    rec->rice_params[i] = (i < best_parts && status == 0) ? best_ps[i] : (uint8_t)0;
-  if (tid < 32) rec->coefs[tid] = (status == 0) ? (int16_t)L.qc[tid] : (int16_t)0;
-  if (tid == 0) {
-    unsigned long long sum_p = 0;
-    for (int i = 0; i < best_parts; ++i) sum_p += best_ps[i];
-    if (!saturated) {
-      sum_q = code_bits - 4ull * (unsigned long long)best_parts - (unsigned long long)(n - warm) -
-              (sum_p * (unsigned long long)best_psize - (unsigned long long)warm * best_ps[0]);
-    }
-    // BitRepr for Residual::count_bits, bitrepr.rs:533-544
-    bool rice2 = false;
-    for (int i = 0; i < best_parts; ++i) rice2 |= best_ps[i] > 14;
-    unsigned long long residual_bits = 2ull + 4ull + (unsigned long long)best_parts * (rice2 ? 5ull : 4ull) +
-                                       (sum_q + (unsigned long long)(n - warm)) +
-                                       (sum_p * (unsigned long long)best_psize -
-                                        (unsigned long long)warm * best_ps[0]);
-    // BitRepr for Lpc::count_bits, bitrepr.rs:492-499
-    // side channel carries one extra bit (ChannelAssignment::bits_per_sample_offset, coding.rs:444)
-    unsigned long long bps = a.bps ? (unsigned long long)a.bps[sf]
-                                   : (unsigned long long)(a.bps_uniform + (role == 3 ? 1u : 0u));
-    unsigned long long sub_bits = 8ull + bps * (unsigned long long)warm + 4ull + 5ull +
-                                  (unsigned long long)a.precision * (unsigned long long)warm + residual_bits;
-    // BitRepr for FixedLpc::count_bits, bitrepr.rs:473-477
-    if (a.fixed_mode != 0) sub_bits = 8ull + bps * (unsigned long long)warm + residual_bits;
-    // OrderSel::BitCount's key: bits_per_sample * order + code_bits (coding.rs:249)
-    if (a.fixed_mode >= 2u && a.selector_keys) a.selector_keys[sf] = bps * (unsigned long long)warm + code_bits;
-    rec->order = (uint8_t)warm;
-    rec->shift = (int8_t)shift;
-    rec->precision = (uint8_t)(a.fixed_mode != 0 ? 0u : a.precision);
-    rec->rice_order = (uint8_t)(status == 0 ? rice_order : 0);
-    rec->status = status;
-    rec->code_bits = status == 0 ? code_bits : 0ull;
-    rec->subframe_bits = status == 0 ? sub_bits : 0ull;
-    rec->sum_quotients = status == 0 ? sum_q : 0ull;
-  }
-  FLACENC_STAMP(7);
 }
 
 // Levinson-Durbin + quantisation for a batch, one subframe per lane (second launch of the split):
@@ -1106,6 +374,16 @@ hipError_t launch_levinson_batch(const QlpcKernelArgs& a, hipStream_t stream) {
 
 template <int MAXP, bool BIG>
 hipError_t launch_one(const QlpcKernelArgs& a, int threads, size_t smem, hipStream_t stream) {
+  if constexpr (MAXP >= 24) {  // (orders 17..32; the order-16 bucket's body does not finish compiling out of line:
+                               // there the marked subframes are found by one workgroup per subframe, below)
+    if (a.only_marked) {
+      auto mk = qlpc_marked_kernel<MAXP, BIG>;
+      static DynamicLdsOptIn opt_in_marked;
+      if (hipError_t err = opt_in_marked.ensure(reinterpret_cast<const void*>(mk), smem); err != hipSuccess) return err;
+      hipLaunchKernelGGL(mk, dim3((a.n_subframes + (uint32_t)threads - 1u) / (uint32_t)threads), dim3(threads), smem, stream, a);
+      return hipGetLastError();
+    }
+  }
   auto kern = qlpc_subframe_kernel<MAXP, BIG>;
   static DynamicLdsOptIn opt_in;  // per instantiation, per device inside; the attribute only ever grows
   if (hipError_t err = opt_in.ensure(reinterpret_cast<const void*>(kern), smem); err != hipSuccess) return err;

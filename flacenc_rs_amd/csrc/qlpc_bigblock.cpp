@@ -1,5 +1,6 @@
-// qlpc_bigblock.cpp -- blocks of 8192 / 16384 samples with LPC order 13..32 (BASELINE configs[2] and
-// configs[4]: 96 kHz / 192 kHz 24-bit material), as two kernels either side of levinson_batch_kernel:
+// qlpc_bigblock.cpp -- blocks of 4096 / 8192 / 16384 samples with LPC order 13..32 (BASELINE configs[2] and
+// configs[4]: 96 kHz / 192 kHz 24-bit material; 4096-sample blocks at the orders the fused 4096 kernel does
+// not carry), as two kernels either side of levinson_batch_kernel:
 //
 //   bigblock_acorr_kernel      window + f64 autocorrelation -> R[]            (src/lpc.rs:739-756, 533-548)
 //   levinson_batch_kernel      one subframe per lane (qlpc_kernel_impl.h)     (src/lpc.rs:633-705, 234-302)
@@ -473,7 +474,7 @@ __global__ void __launch_bounds__(256, 3) bigblock_residual_kernel(QlpcKernelArg
 
   // ======================= partitioned-Rice search over 64 K partitions =======================
   // finest order FO = 6 + log2 K (rice.rs:157-165); level L = order FO - L
-  constexpr int LK = K == 2 ? 1 : 2;
+  constexpr int LK = K == 1 ? 0 : (K == 2 ? 1 : 2);
   constexpr int NLEV = 7 + LK;
   constexpr uint32_t kWMax = kMaxPToBits - 4u;
   uint32_t orp = 0;
@@ -496,7 +497,7 @@ __global__ void __launch_bounds__(256, 3) bigblock_residual_kernel(QlpcKernelArg
   // exact ones) are left to the generic kernel: this launch reports it and the dispatcher reruns it
   const bool literal = !(maxu < (1u << 26));
 
-  uint32_t pk[K][7], pk7[K / 2], pk8 = 0xFFFFFFFFu;
+  uint32_t pk[K][7], pk7[K >= 2 ? K / 2 : 1], pk8 = 0xFFFFFFFFu;
   auto search = [&](uint32_t p_lo) {
 #pragma unroll
     for (int k = 0; k < K; ++k)
@@ -726,7 +727,8 @@ hipError_t launch_residual(const QlpcKernelArgs& a, hipStream_t stream) {
 }  // namespace
 
 bool bigblock_eligible(const QlpcKernelArgs& a) {
-  if (a.block_size != 8192 && a.block_size != 16384) return false;
+  // (4096 at these orders too: below 13 the fused 4096 kernel has it, above it would fall to the generic one)
+  if (a.block_size != 4096 && a.block_size != 8192 && a.block_size != 16384) return false;
   if (a.lpc_order < 13 || a.lpc_order > 32) return false;
   if (a.fixed_mode != 0 || a.lpc_stage != 0 || a.force_generic) return false;
   if (a.frame_results || a.chan_results || a.pack_out) return false;
@@ -746,9 +748,10 @@ hipError_t launch_bigblock_acorr(const QlpcKernelArgs& a, hipStream_t stream) {
 }
 
 hipError_t launch_bigblock_residual(const QlpcKernelArgs& a, hipStream_t stream) {
-  const bool k2 = a.block_size == 8192;
-  if (a.lpc_order <= 24) return k2 ? launch_residual<24, 2>(a, stream) : launch_residual<24, 4>(a, stream);
-  return k2 ? launch_residual<32, 2>(a, stream) : launch_residual<32, 4>(a, stream);
+  const int k = (int)(a.block_size / 4096u);
+  if (a.lpc_order <= 24)
+    return k == 1 ? launch_residual<24, 1>(a, stream) : (k == 2 ? launch_residual<24, 2>(a, stream) : launch_residual<24, 4>(a, stream));
+  return k == 1 ? launch_residual<32, 1>(a, stream) : (k == 2 ? launch_residual<32, 2>(a, stream) : launch_residual<32, 4>(a, stream));
 }
 
 }  // namespace flacenc_hip

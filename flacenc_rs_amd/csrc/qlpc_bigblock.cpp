@@ -179,7 +179,7 @@ __device__ __forceinline__ int4 bigblock_hld4(const int32_t* bufA, const int32_t
 
 template <int HP, int NG, bool STEREO>
 __global__ void __launch_bounds__(256, FLACENC_BIG_ACORR_OCC) bigblock_acorr_kernel(QlpcKernelArgs a) {
-  // HP = window depth = the order bucket (24 or 32); lags 0..HP in NG groups of at most NL
+  // HP = window depth = the order bucket (16, 24 or 32); lags 0..HP in NG groups of at most NL
   constexpr int NLAG = HP + 1;
   constexpr int NL = (NLAG + NG - 1) / NG;
   constexpr int NBATCH = 13;  // lags per LDS tree round (4 lanes per lag, <= 16)
@@ -743,12 +743,15 @@ bool bigblock_eligible(const QlpcKernelArgs& a) {
 hipError_t launch_bigblock_acorr(const QlpcKernelArgs& a, hipStream_t stream) {
   // order <= 24: all 25 lags in one group; up to 32: 17 + 16 (window of 48 doubles + two accumulator sets
   // must fit 256 VGPRs: all 33 in one group compile to 256 registers + 5 spilled, and run 2.4 x slower)
+  if (a.lpc_order <= 16) return launch_acorr<16, 1>(a, stream);  // 17 lags, window of 16
   if (a.lpc_order <= 24) return launch_acorr<24, FLACENC_BIG_NG24>(a, stream);
   return launch_acorr<32, FLACENC_BIG_NG32>(a, stream);
 }
 
 hipError_t launch_bigblock_residual(const QlpcKernelArgs& a, hipStream_t stream) {
   const int k = (int)(a.block_size / 4096u);
+  if (a.lpc_order <= 16)
+    return k == 1 ? launch_residual<16, 1>(a, stream) : (k == 2 ? launch_residual<16, 2>(a, stream) : launch_residual<16, 4>(a, stream));
   if (a.lpc_order <= 24)
     return k == 1 ? launch_residual<24, 1>(a, stream) : (k == 2 ? launch_residual<24, 2>(a, stream) : launch_residual<24, 4>(a, stream));
   return k == 1 ? launch_residual<32, 1>(a, stream) : (k == 2 ? launch_residual<32, 2>(a, stream) : launch_residual<32, 4>(a, stream));

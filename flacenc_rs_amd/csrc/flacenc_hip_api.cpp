@@ -511,6 +511,11 @@ int enqueue_fixed(flacenc_hip_handle* h, const flacenc_hip_frame_config* cfg, co
   }
   if (cfg->fixed_order_sel == FLACENC_HIP_ORDERSEL_APPROXENT) {
     a.fixed_mode = 1;
+    if (block_size == 4096 || block_size == 8192 || block_size == 16384) {  // the big-block kernels' predictor records
+      rc = ensure(h, h->d_split, n_subframes * (33 * 8 + 36 * 4));
+      if (rc != FLACENC_HIP_OK) return rc;
+      a.split_scratch = h->d_split.ptr;
+    }
     HIP_TRY(h, flacenc_hip::launch_qlpc(a, plan, stream));
     return FLACENC_HIP_OK;
   }

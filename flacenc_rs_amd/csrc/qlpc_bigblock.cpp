@@ -653,8 +653,12 @@ __global__ void __launch_bounds__(256, 3) bigblock_residual_kernel(QlpcKernelArg
   }
   const unsigned long long residual_bits = 2ull + 4ull + (unsigned long long)best_parts * (rice2 ? 5ull : 4ull) +
                                            (sum_q + (unsigned long long)(n - warm)) + rem_bits;
-  const unsigned long long sub_bits = 8ull + bps_role * (unsigned long long)warm + 4ull + 5ull +
-                                      (unsigned long long)a.precision * (unsigned long long)warm + residual_bits;
+  // Lpc::count_bits (bitrepr.rs:492-499); as fixed_lpc's coder: FixedLpc::count_bits (no precision / shift /
+  // coefficient fields)
+  const unsigned long long sub_bits = a.fixed_mode != 0
+      ? 8ull + bps_role * (unsigned long long)warm + residual_bits
+      : 8ull + bps_role * (unsigned long long)warm + 4ull + 5ull +
+            (unsigned long long)a.precision * (unsigned long long)warm + residual_bits;
 
   if (!active) return;
   flacenc_hip_subframe_params* rec = a.params + sf;
@@ -691,13 +695,127 @@ __global__ void __launch_bounds__(256, 3) bigblock_residual_kernel(QlpcKernelArg
   if (lane == 0) {
     rec->order = (uint8_t)warm;
     rec->shift = (int8_t)shift;
-    rec->precision = (uint8_t)a.precision;
+    rec->precision = (uint8_t)(a.fixed_mode != 0 ? 0u : a.precision);
     rec->rice_order = (uint8_t)(status == 0 ? rice_order : 0);
     rec->status = status;
     rec->code_bits = status == 0 ? best_bits : 0ull;
     rec->subframe_bits = status == 0 ? sub_bits : 0ull;
     rec->sum_quotients = status == 0 ? sum_q : 0ull;
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// fixed_lpc's order selection (OrderSel::ApproxEnt, coding.rs:265-287) for the big-block shapes: per pass
+// the exact sums of |e_k| over every estimator partition (v_sad_u32 on biased values, as in the fused
+// 4096 kernel), estimate_entropy per partition, the estimates added up over partitions and passes, the
+// first minimum of estimate + bps * order.  Writes the chosen order as a predictor record -- FIXED_LPC_COEFS
+// (decode.rs:179-185), shift 0 -- that bigblock_residual_kernel<8, ..> turns into residual, Rice partition and
+// bit counts exactly as the generic kernel's fixed mode does with its QLPC machinery.
+template <bool STEREO>
+__global__ void __launch_bounds__(256, 2) bigblock_fixed_select_kernel(QlpcKernelArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  int32_t* const sm = reinterpret_cast<int32_t*>(smem_raw);
+  const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
+  const uint32_t blk = blockIdx.x;
+  uint32_t sf = blk * 4u + (uint32_t)wave;
+  const bool active = sf < a.n_subframes;
+  if (!active) sf = a.n_subframes - 1u;
+  const int role = STEREO ? wave : 0;
+  const int n = (int)a.block_size;
+  const int K = n / kPass;
+  const int32_t* const bufA = sm + (STEREO ? (role == 1 ? 1 : 0) : wave) * kBufDwords;
+  const int32_t* const bufB = sm + kBufDwords;
+  const int tl = lane << 6;
+  const unsigned long long bps_role = a.bps ? (unsigned long long)a.bps[sf]
+                                            : (unsigned long long)(a.bps_uniform + ((STEREO && role == 3) ? 1u : 0u));
+  // estimator partitions of n / parts samples = groups of 2^g lanes of a pass (host: a power of two, 64..4096)
+  const int psize = n / (int)a.fixed_partitions;
+  const int g = 31 - __builtin_clz((unsigned)(psize >> 6));
+  const int G = 1 << g;
+  const int jsub = lane & (G - 1);
+  const int max_order = (int)a.fixed_max_order;
+  uint32_t acc_pb[5] = {0u, 0u, 0u, 0u, 0u};  // lane j of a group takes order r G + j in round r
+  for (int k = 0; k < K; ++k) {
+    __syncthreads();
+    bigblock_load_pass<STEREO>(a, sm, blk, k, tid, wave, lane, sf);
+    __syncthreads();
+    double ls[5];
+    auto sums = [&](auto kind_tag) {
+      constexpr int KIND = decltype(kind_tag)::value;
+      uint32_t b[68];  // the lane's 64 samples + 4 in front of them (zeros in front of the block), biased by 2^31
+#pragma unroll
+      for (int q = 0; q < 17; ++q) {
+        const int4 v = bigblock_ld4<KIND>(bufA, bufB, tl - 4 + 4 * q);
+        b[4 * q + 0] = (uint32_t)v.x ^ 0x80000000u;
+        b[4 * q + 1] = (uint32_t)v.y ^ 0x80000000u;
+        b[4 * q + 2] = (uint32_t)v.z ^ 0x80000000u;
+        b[4 * q + 3] = (uint32_t)v.w ^ 0x80000000u;
+      }
+#pragma unroll
+      for (int ord = 0; ord < 5; ++ord) {
+        uint32_t c[4] = {0u, 0u, 0u, 0u};
+        if (ord == 0) {
+#pragma unroll
+          for (int j = 0; j < 64; ++j) c[j >> 4] = sad_u32(b[4 + j], 0x80000000u, c[j >> 4]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 64; ++j) c[j >> 4] = sad_u32(b[4 + j], b[3 + j], c[j >> 4]);
+          if (ord < 4) {
+#pragma unroll
+            for (int i = 67; i >= ord; --i) b[i] = (b[i] - b[i - 1]) ^ 0x80000000u;
+          }
+        }
+        ls[ord] = ((double)c[0] + (double)c[1]) + ((double)c[2] + (double)c[3]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    if (STEREO && role == 2) sums(std::integral_constant<int, 2>{});
+    else if (STEREO && role == 3) sums(std::integral_constant<int, 3>{});
+    else sums(std::integral_constant<int, 0>{});
+#pragma unroll 1
+    for (int lvl = 0; lvl < g; ++lvl) {
+#pragma unroll
+      for (int ord = 0; ord < 5; ++ord) ls[ord] += __shfl_xor(ls[ord], 1 << lvl, 64);
+    }
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+      if (r * G <= max_order) {
+        const int ord = r * G + jsub;
+        double sv = ls[0];
+#pragma unroll
+        for (int q = 1; q < 5; ++q) sv = (q == ord) ? ls[q] : sv;
+        // sample_count = min(end - warmup, partition_len): only the block's first partition loses the warm-up
+        const uint32_t cnt = (uint32_t)psize - ((k == 0 && (lane >> g) == 0) ? (uint32_t)ord : 0u);
+        acc_pb[r] += ord <= max_order ? approx_ent_bits(sv, cnt) : 0u;
+      }
+    }
+  }
+  uint32_t best_packed = 0xFFFFFFFFu;
+#pragma unroll
+  for (int r = 0; r < 5; ++r) {
+    if (r * G <= max_order) {
+      const int ord = r * G + jsub;
+      const bool valid = ord <= max_order;
+      uint32_t pb = acc_pb[r];  // every lane of a group holds its partitions' estimates: one copy per group
+#pragma unroll 1
+      for (int lvl = g; lvl < 6; ++lvl) pb += (uint32_t)__shfl_xor((int)pb, 1 << lvl, 64);
+      const unsigned long long key = (unsigned long long)pb + bps_role * (unsigned long long)ord;
+      if (a.fixed_keys && active && valid && lane < G) a.fixed_keys[(size_t)sf * 8 + ord] = key;
+      const uint32_t packed = valid ? (((uint32_t)key << 3) | (uint32_t)ord) : 0xFFFFFFFFu;  // key < 2^29
+      const uint32_t m = wave_min_dpp(packed);
+      best_packed = m < best_packed ? m : best_packed;
+    }
+  }
+  if (!active || lane != 0) return;
+  const int kord = (int)(best_packed & 7u);
+  if (a.selector_keys) a.selector_keys[sf] = (unsigned long long)(best_packed >> 3);
+  int32_t* pr = a.pred_out + (size_t)sf * 36;
+  for (int i = 0; i < 36; ++i) pr[i] = 0;
+  pr[0] = kord;  // FIXED_LPC_COEFS[k]: 0 / 1 / 2,-1 / 3,-3,1 / 4,-6,4,-1
+  pr[1] = kord == 2 ? -1 : (kord == 3 ? -3 : (kord == 4 ? -6 : 0));
+  pr[2] = kord == 3 ? 1 : (kord == 4 ? 4 : 0);
+  pr[3] = kord == 4 ? -1 : 0;
+  pr[32] = kord;
 }
 
 template <typename KernelT>
@@ -725,6 +843,34 @@ hipError_t launch_residual(const QlpcKernelArgs& a, hipStream_t stream) {
 }
 
 }  // namespace
+
+// fixed_lpc with OrderSel::ApproxEnt on the same shapes: estimator partitions that are whole groups of lanes
+bool bigblock_fixed_eligible(const QlpcKernelArgs& a) {
+  if (a.fixed_mode != 1u || a.lpc_stage != 0 || a.force_generic) return false;
+  if (a.block_size != 4096 && a.block_size != 8192 && a.block_size != 16384) return false;
+  const uint32_t parts = a.fixed_partitions;
+  if (parts == 0 || (parts & (parts - 1)) != 0) return false;
+  const uint32_t psize = a.block_size / parts;
+  if (psize < 64 || psize > 4096) return false;
+  if (a.fixed_max_order > 4) return false;
+  if (a.frame_results || a.chan_results || a.pack_out) return false;
+  if ((reinterpret_cast<uintptr_t>(a.samples) & 15) || (a.stride & 3)) return false;
+  if ((reinterpret_cast<uintptr_t>(a.residual) & 15) || (a.residual_stride & 3)) return false;
+  if (a.stereo && (a.n_subframes & 3)) return false;
+  if (a.split_scratch == nullptr) return false;
+  return true;
+}
+
+hipError_t launch_bigblock_fixed_select(const QlpcKernelArgs& a, hipStream_t stream) {
+  static DynamicLdsOptIn opt_s, opt_p;
+  if (a.stereo) return launch_big(bigblock_fixed_select_kernel<true>, opt_s, a, 2 * kBufDwords * 4, stream);
+  return launch_big(bigblock_fixed_select_kernel<false>, opt_p, a, 4 * kBufDwords * 4, stream);
+}
+
+hipError_t launch_bigblock_fixed_residual(const QlpcKernelArgs& a, hipStream_t stream) {
+  const int k = (int)(a.block_size / 4096u);
+  return k == 1 ? launch_residual<8, 1>(a, stream) : (k == 2 ? launch_residual<8, 2>(a, stream) : launch_residual<8, 4>(a, stream));
+}
 
 bool bigblock_eligible(const QlpcKernelArgs& a) {
   // (4096 at these orders too: below 13 the fused 4096 kernel has it, above it would fall to the generic one)

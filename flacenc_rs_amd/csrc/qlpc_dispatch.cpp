@@ -93,6 +93,29 @@ hipError_t launch_qlpc(const QlpcKernelArgs& a, const QlpcLaunchPlan& plan, hipS
     b.autocorr = nullptr;  // already written
     return launch_qlpc(b, plan, stream);
   }
+  if (bigblock_fixed_eligible(a)) {
+    // fixed_lpc on the big-block shapes: order selection -> predictor record -> the residual + Rice kernel with
+    // FixedLpc's bit count; subframes with residuals of 2^26 and more are redone by the generic kernel
+    int32_t* pred = reinterpret_cast<int32_t*>(reinterpret_cast<double*>(a.split_scratch) +
+                                                static_cast<size_t>(a.n_subframes) * 33);
+    QlpcKernelArgs s1 = a, s3 = a;
+    s1.pred_out = pred;
+    hipError_t err = launch_bigblock_fixed_select(s1, stream);
+    if (err != hipSuccess) return err;
+    s3.pred = pred;
+    s3.selector_keys = nullptr;  // written by the selection
+    s3.fixed_keys = nullptr;
+    err = launch_bigblock_fixed_residual(s3, stream);
+    if (err != hipSuccess) return err;
+    QlpcKernelArgs s4 = a;
+    s4.only_marked = 1;
+    s4.split_scratch = nullptr;
+#define FLACENC_HIP_FIXCLEAN(MP, BG) \
+  if (plan.maxp == MP && plan.big == (BG != 0)) return launch_qlpc_##MP##_##BG(s4, plan.threads, plan.smem_bytes, stream);
+    FLACENC_HIP_FOR_EACH_INSTANCE(FLACENC_HIP_FIXCLEAN)
+#undef FLACENC_HIP_FIXCLEAN
+    return hipErrorInvalidValue;
+  }
   if (bigblock_eligible(a) || (a.acorr_in != nullptr && !wave_kernel_eligible(a) && a.lpc_stage == 0)) {
     // R[] -> levinson_batch_kernel (one subframe per lane) -> residual + Rice search
     if (a.split_scratch == nullptr) return hipErrorInvalidValue;

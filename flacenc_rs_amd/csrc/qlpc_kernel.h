@@ -100,6 +100,10 @@ hipError_t launch_qlpc(const QlpcKernelArgs& args, const QlpcLaunchPlan& plan, h
 bool bigblock_eligible(const QlpcKernelArgs& args);
 hipError_t launch_bigblock_acorr(const QlpcKernelArgs& args, hipStream_t stream);     // R[] -> args.autocorr
 hipError_t launch_bigblock_residual(const QlpcKernelArgs& args, hipStream_t stream);  // args.pred -> records
+// fixed_lpc with OrderSel::ApproxEnt on those shapes: order selection -> args.pred_out, then the residual kernel
+bool bigblock_fixed_eligible(const QlpcKernelArgs& args);
+hipError_t launch_bigblock_fixed_select(const QlpcKernelArgs& args, hipStream_t stream);
+hipError_t launch_bigblock_fixed_residual(const QlpcKernelArgs& args, hipStream_t stream);
 
 // one per (order bucket, big) instantiation, each defined by its own translation unit
 #define FLACENC_HIP_FOR_EACH_INSTANCE(X) \

@@ -556,6 +556,29 @@ def secondary(torch, _capi, handle, args, dev):
                       "fp64_fma_frac": round(25 * bf * 4 * bn / (med * 1e-3) / 39.3e12, 4),
                       "what": "flacenc_hip_stereo_qlpc_batch: 4 candidates per frame, 25 f64 fma + 24 64-bit MACs per "
                               "analysed sample; fp64_fma_frac = the fma alone against the 78.6 TFLOP/s FP64 vector peak"}
+        if bn == 8192:
+            # the same shape through the frame-level call with the reference's default candidate set (fixed-LPC
+            # on): QLPC + fixed candidates for L, R, M, S, the frame decision, then Frame::write
+            bfr = torch.empty((bf, rec_bytes), dtype=torch.uint8, device=dev)
+            bch = torch.empty((bf * 2, bn), dtype=torch.int32, device=dev)
+            bstride = (handle.frame_bytes_bound(bn, 24) + 15) // 16 * 16
+            bout = torch.empty((bf, bstride), dtype=torch.uint8, device=dev)
+            blen = torch.zeros(bf, dtype=torch.int32, device=dev)
+            dcfg = _capi.make_frame_config(bcfg, use_fixed=True)
+
+            def frames_default():
+                handle.encode_stereo_frames_device(dcfg, big.data_ptr(), bf, bn, bn, 24, bfr.data_ptr(), bch.data_ptr(), bn,
+                                                   stream=stream.cuda_stream)
+                handle.pack_stereo_frames_device(big.data_ptr(), bf, bn, bn, bfr.data_ptr(), bch.data_ptr(), bn, 24, 96000, 0, 1,
+                                                 bout.data_ptr(), bstride, blen.data_ptr(), stream=stream.cuda_stream)
+            ms = timed(frames_default)
+            med = float(np.median(ms))
+            sec["config3_frames_default_config"] = {
+                "frames": bf, "block_size": bn, "ms_per_launch": stats(ms),
+                "Msamples_per_s": round(bf * 2 * bn / (med * 1e-3) / 1e6, 1),
+                "what": "flacenc_hip_encode_stereo_frames (order 24, fixed-LPC candidate on: 8 candidate analyses per frame, "
+                        "decision) + flacenc_hip_pack_stereo_frames: PCM in HBM -> FLAC frame bytes in HBM"}
+            del bfr, bch, bout, blen
         del big, bparams, bres
     return sec
 

@@ -627,6 +627,9 @@ def test_encode_stereo_frames_fixed_24bit(handle):
     (4096, 16, 1, 16, 4), (4608, 16, 1, 16, 4), (1152, 16, 1, 7, 4), (8192, 24, 1, 64, 4),
     (576, 16, 1, 1, 2), (100, 8, 1, 64, 4), (16384, 24, 1, 16, 4), (20000, 16, 1, 33, 3),
     (4096, 16, 0, 16, 4), (4608, 16, 0, 16, 2), (192, 16, 0, 16, 4), (8192, 24, 0, 16, 4),
+    # the big-block selection kernel's group sizes: one lane, all 64 lanes of a pass, a partition per pass;
+    # and a partition longer than a pass (generic kernel)
+    (4096, 16, 1, 64, 3), (16384, 24, 1, 4, 4), (8192, 16, 1, 2, 1), (8192, 24, 1, 1, 4), (4096, 24, 1, 8, 0),
 ])
 def test_fixed_lpc_batch_any_shape(handle, n, bps, sel, parts, max_order):
     """flacenc_hip_fixed_lpc_batch == fixed_lpc (coding.rs:298-331) on ragged / large / tiny blocks,

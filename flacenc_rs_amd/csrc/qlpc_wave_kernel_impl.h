@@ -36,16 +36,22 @@ namespace {
 
 // waves per SIMD the register allocator must leave room for: 3 workgroups per CU is what the
 // stereo LDS footprint (2 images + window) allows; plain mode (4 images) is LDS-bound earlier
+#ifndef FLACENC_ORDER12_OCC3
+#define FLACENC_ORDER12_OCC3 14  // bit v: variant v (FLACENC_STEREO) of the order-12 bucket at three workgroups per CU
+#endif
 #ifndef FLACENC_WAVE_OCC
 // 3 where the instance fits 168 VGPRs with (next to) nothing of its common path in scratch -- checked with
 // tools/kernel_resources.py and the Spill / Reload comments of tools/asm_variant.sh's output, then measured
 // (same box, alternating runs, 24576 frames): the stereo kernels up to order 10, with and without the
 // on-device decision and the fixed-LPC candidate.  What is still spilled there sits around the out-of-line
 // call of the rare literal Rice search and in the decision tail.  Order 8: deciding kernel 0.313 -> 0.275 ms
-// per 8192 frames, with the fixed-LPC candidate 0.446 -> 0.380 ms.  The fused bit writer (PACK), the
-// independent-channel kernel and order 12 spill in their inner loops at 168 registers and stay at 2.
-#if defined(FLACENC_STEREO) && defined(FLACENC_MAXP) && FLACENC_MAXP <= 10 && \
-    (FLACENC_STEREO == 1 || FLACENC_STEREO == 2 || FLACENC_STEREO == 3)
+// per 8192 frames, with the fixed-LPC candidate 0.446 -> 0.380 ms.  Order 12 (17 / 35 / 44 spilled dwords in the
+// deciding / candidate / fixed-LPC variants, and an exchange area 256 bytes smaller, see kXqOverlay) gains too:
+// 1.005 -> 0.815 ms, 1.12 -> 1.02 ms and 1.54 -> 1.29 ms per 24576 frames.  The fused bit writer (PACK) and the
+// independent-channel kernel spill in their inner loops at 168 registers and stay at 2.
+#if defined(FLACENC_STEREO) && defined(FLACENC_MAXP) && \
+    ((FLACENC_MAXP <= 10 && (FLACENC_STEREO == 1 || FLACENC_STEREO == 2 || FLACENC_STEREO == 3)) || \
+     (FLACENC_MAXP == 12 && ((FLACENC_ORDER12_OCC3 >> FLACENC_STEREO) & 1)))
 #define FLACENC_WAVE_OCC 3
 #else
 #define FLACENC_WAVE_OCC 2
@@ -580,6 +586,11 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
   // L2-resident table instead, so that two workgroups still fit a CU.
   constexpr bool WINDOW_IN_LDS = STEREO;
   constexpr int NIMG = NBUF + (WINDOW_IN_LDS ? 1 : 0);
+  // Order 12 at three workgroups per CU: the quantised coefficients wave 0 hands back overlay the R[] rows it was
+  // handed (its four lanes have read them, in lockstep, before any of them writes; nobody else reads R[] after
+  // the barrier) -- 256 bytes less, which is what 3 x 42 LDS granules leave room for.  The fused bit writer
+  // reuses the area for larger things and keeps both.
+  constexpr bool kXqOverlay = MAXP > 10 && !PACK;
   float* const wlds = reinterpret_cast<float*>(sm + NBUF * kBufDwords);
   const bool has_window = a.window != nullptr;  // nullptr = all ones (rectangle / Tukey(0))
   const float* __restrict__ wtab = a.window + 32;
@@ -837,7 +848,7 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
     // must fit one CU (3 x 42 granules = 157.5 KB)
     constexpr int XR = NLAG;  // (not rounded up: at order 10 the 32 bytes decide whether three workgroups fit a CU)
     double* const xr = reinterpret_cast<double*>(sm + NIMG * kBufDwords);  // [4][XR]
-    int32_t* const xq = reinterpret_cast<int32_t*>(xr + 4 * XR);                   // [4][16]
+    int32_t* const xq = reinterpret_cast<int32_t*>(xr + (kXqOverlay ? 0 : 4 * XR));  // [4][16]
     if (lane == 0) {
 #pragma unroll
       for (int k = 0; k < NLAG; ++k) xr[wave * XR + k] = R[k];
@@ -1019,7 +1030,7 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
   {
     constexpr int XR = NLAG;  // (not rounded up: at order 10 the 32 bytes decide whether three workgroups fit a CU)
     double* const xr = reinterpret_cast<double*>(sm + NIMG * kBufDwords);  // [4][XR]
-    int32_t* const xq = reinterpret_cast<int32_t*>(xr + 4 * XR);                   // [4][16]
+    int32_t* const xq = reinterpret_cast<int32_t*>(xr + (kXqOverlay ? 0 : 4 * XR));  // [4][16]
     (void)xr;
     __syncthreads();
 #pragma unroll
@@ -1673,7 +1684,8 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
 template <int MAXP, bool STEREO, bool DECIDE, bool FIXED, bool PACK>
 hipError_t launch_wave4096(const QlpcKernelArgs& a, hipStream_t stream) {
   auto kern = qlpc_wave4096_kernel<MAXP, STEREO, DECIDE, FIXED, PACK>;
-  constexpr size_t smem = (size_t)(STEREO ? 3 : 4) * kBufDwords * 4 + 4 * ((MAXP + 1) * 8 + 64);  // images (+ window) + exchange: [4][MAXP + 1] f64 + [4][16] i32
+  // images (+ window) + exchange: [4][MAXP + 1] f64 (+ [4][16] i32 unless overlaid, see kXqOverlay)
+  constexpr size_t smem = (size_t)(STEREO ? 3 : 4) * kBufDwords * 4 + ((MAXP > 10 && !PACK) ? 4 * (MAXP + 1) * 8 : 4 * ((MAXP + 1) * 8 + 64));
   static DynamicLdsOptIn opt_in;  // per instantiation, per device inside
   if (hipError_t err = opt_in.ensure(reinterpret_cast<const void*>(kern), smem); err != hipSuccess) return err;
   const uint32_t blocks = STEREO ? a.n_subframes / 4u : (a.n_subframes + 3u) / 4u;

@@ -40,6 +40,9 @@ constexpr int kPass = 4096;
 #ifndef FLACENC_BIG_RESID_PREFETCH
 #define FLACENC_BIG_RESID_PREFETCH 1
 #endif
+#ifndef FLACENC_BIG_RESID_OCC
+#define FLACENC_BIG_RESID_OCC 3
+#endif
 
 // cooperative load of pass k of the workgroup's rows into the LDS images: segment 0 of an image holds the
 // 64 samples in front of the pass (zeros in front of the block), the pass follows (widx layout)
@@ -336,7 +339,7 @@ __global__ void __launch_bounds__(256, FLACENC_BIG_ACORR_OCC) bigblock_acorr_ker
 
 // ---------------------------------------------------------------------------------------------
 template <int MAXP, bool STEREO, int K>
-__global__ void __launch_bounds__(256, 3) bigblock_residual_kernel(QlpcKernelArgs a) {
+__global__ void __launch_bounds__(256, FLACENC_BIG_RESID_OCC) bigblock_residual_kernel(QlpcKernelArgs a) {
   constexpr int HP = MAXP;  // multiple of 8
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   int32_t* const sm = reinterpret_cast<int32_t*>(smem_raw);

@@ -121,7 +121,7 @@ struct flacenc_hip_handle {
   hipStream_t stream = nullptr;
   std::string last_error;
   std::vector<WindowEntry> windows;
-  DeviceBuffer d_samples, d_residual, d_params, d_bps, d_autocorr, d_lpc, d_tables, d_keys, d_sel, d_results, d_out, d_outlen, d_cparams, d_cresid, d_fparams, d_fresid, d_fkeys, d_split, d_presid;
+  DeviceBuffer d_samples, d_residual, d_params, d_bps, d_autocorr, d_lpc, d_tables, d_keys, d_sel, d_results, d_out, d_outlen, d_cparams, d_cresid, d_fparams, d_fresid, d_fkeys, d_split, d_presid, d_sumabs;
   // streaming host path (flacenc_hip_encode_pcm_stereo): copy-in / copy-out streams, two slots of pinned
   // staging and device buffers, the events that order them
   hipStream_t s_in = nullptr, s_out = nullptr;
@@ -266,6 +266,16 @@ int check_batch_args(flacenc_hip_handle* h, const flacenc_hip_qlpc_config* cfg, 
     h->last_error = "null pointer, stride < block_size, or too many subframes";
     return FLACENC_HIP_ERR_BAD_ARGUMENT;
   }
+  return FLACENC_HIP_OK;
+}
+
+// FLACENC_HIP_FLAG_REFERENCE_SUM_ORDER with the ApproxEnt selector: room for sumabs_reference_kernel's
+// per-partition f32 sums (launch_qlpc runs it when `sumabs_scratch` is set)
+int attach_sumabs_scratch(flacenc_hip_handle* h, flacenc_hip::QlpcKernelArgs& a, bool approx_ent) {
+  if (!a.reference_order || !approx_ent) return FLACENC_HIP_OK;
+  int rc = ensure(h, h->d_sumabs, static_cast<size_t>(a.n_subframes) * 5 * 64 * sizeof(float));
+  if (rc != FLACENC_HIP_OK) return rc;
+  a.sumabs_scratch = static_cast<float*>(h->d_sumabs.ptr);
   return FLACENC_HIP_OK;
 }
 
@@ -511,6 +521,7 @@ int enqueue_fixed(flacenc_hip_handle* h, const flacenc_hip_frame_config* cfg, co
   }
   if (cfg->fixed_order_sel == FLACENC_HIP_ORDERSEL_APPROXENT) {
     a.fixed_mode = 1;
+    if ((rc = attach_sumabs_scratch(h, a, true)) != FLACENC_HIP_OK) return rc;
     if (block_size == 4096 || block_size == 8192 || block_size == 16384) {  // the big-block kernels' predictor records
       rc = ensure(h, h->d_split, n_subframes * (33 * 8 + 36 * 4));
       if (rc != FLACENC_HIP_OK) return rc;
@@ -595,7 +606,7 @@ void flacenc_hip_destroy(flacenc_hip_handle* h) {
     if (e.dev) (void)hipFree(e.dev);
   for (DeviceBuffer* b : {&h->d_samples, &h->d_residual, &h->d_params, &h->d_bps, &h->d_autocorr,
                           &h->d_lpc, &h->d_tables, &h->d_keys, &h->d_sel, &h->d_results, &h->d_out, &h->d_outlen, &h->d_cparams, &h->d_cresid,
-                          &h->d_fparams, &h->d_fresid, &h->d_fkeys, &h->d_split, &h->d_presid})
+                          &h->d_fparams, &h->d_fresid, &h->d_fkeys, &h->d_split, &h->d_presid, &h->d_sumabs})
     if (b->ptr) (void)hipFree(b->ptr);
   for (int i = 0; i < 2; ++i) {
     for (DeviceBuffer* b : {&h->d_pcm[i], &h->d_pack[i], &h->d_plen[i], &h->d_poff[i], &h->d_cont[i]})
@@ -979,6 +990,9 @@ int flacenc_hip_encode_frames_async(flacenc_hip_handle* h, const flacenc_hip_fra
       if ((rc = ensure(h, h->d_split, static_cast<size_t>(a.n_subframes) * (33 * 8 + 36 * 4))) != FLACENC_HIP_OK) return rc;
       a.split_scratch = h->d_split.ptr;
     }
+    if ((rc = attach_sumabs_scratch(h, a, cfg->use_fixed && cfg->fixed_order_sel == FLACENC_HIP_ORDERSEL_APPROXENT)) !=
+        FLACENC_HIP_OK)
+      return rc;
     if (pow2 && flacenc_hip::wave_kernel_eligible(a)) {
       flacenc_hip::QlpcLaunchPlan plan = flacenc_hip::plan_qlpc_launch(block_size, cfg->qlpc.lpc_order);
       HIP_TRY(h, flacenc_hip::launch_qlpc(a, plan, s));
@@ -1701,6 +1715,8 @@ static int encode_stereo_frames_impl(flacenc_hip_handle* h, const flacenc_hip_fr
     int rc2 = ensure(h, h->d_split, static_cast<size_t>(a.n_subframes) * (33 * 8 + 36 * 4));
     if (rc2 != FLACENC_HIP_OK) return rc2;
     a.split_scratch = h->d_split.ptr;
+    rc2 = attach_sumabs_scratch(h, a, a.use_fixed && a.fixed_order_sel == FLACENC_HIP_ORDERSEL_APPROXENT);
+    if (rc2 != FLACENC_HIP_OK) return rc2;
   }
   // One kernel or two?  Measured on MI355X (24576 frames, order 8): with the fixed-LPC candidate the fused
   // bit writer takes 1.80 ms against 1.13 + 0.63 ms for the deciding kernel followed by the stand-alone

@@ -738,11 +738,17 @@ __global__ void __launch_bounds__(256, 2) bigblock_fixed_select_kernel(QlpcKerne
   const int jsub = lane & (G - 1);
   const int max_order = (int)a.fixed_max_order;
   uint32_t acc_pb[5] = {0u, 0u, 0u, 0u, 0u};  // lane j of a group takes order r G + j in round r
+  const bool ref_sums = a.sumabs_in != nullptr;  // FLACENC_HIP_FLAG_REFERENCE_SUM_ORDER: sumabs_reference_kernel's chains
   for (int k = 0; k < K; ++k) {
+    double ls[5];
+    if (ref_sums) {
+      const float* __restrict__ sref = a.sumabs_in + (size_t)sf * (5 * 64) + (k * (64 >> g) + (lane >> g));
+#pragma unroll
+      for (int ord = 0; ord < 5; ++ord) ls[ord] = (double)sref[ord * 64];
+    } else {
     __syncthreads();
     bigblock_load_pass<STEREO>(a, sm, blk, k, tid, wave, lane, sf);
     __syncthreads();
-    double ls[5];
     auto sums = [&](auto kind_tag) {
       constexpr int KIND = decltype(kind_tag)::value;
       uint32_t b[68];  // the lane's 64 samples + 4 in front of them (zeros in front of the block), biased by 2^31
@@ -779,6 +785,7 @@ __global__ void __launch_bounds__(256, 2) bigblock_fixed_select_kernel(QlpcKerne
     for (int lvl = 0; lvl < g; ++lvl) {
 #pragma unroll
       for (int ord = 0; ord < 5; ++ord) ls[ord] += __shfl_xor(ls[ord], 1 << lvl, 64);
+    }
     }
 #pragma unroll
     for (int r = 0; r < 5; ++r) {

@@ -3,6 +3,7 @@
 #include "qlpc_kernel.h"
 
 #include "acorr_reference.h"
+#include "sumabs_reference.h"
 
 namespace flacenc_hip {
 namespace {
@@ -71,6 +72,26 @@ QlpcLaunchPlan plan_qlpc_launch(uint32_t block_size, uint32_t lpc_order) {
 hipError_t launch_qlpc(const QlpcKernelArgs& a, const QlpcLaunchPlan& plan, hipStream_t stream) {
   if (a.n_subframes == 0) return hipSuccess;
   if ((a.frame_results || a.chan_results) && !wave_kernel_eligible(a)) return hipErrorNotSupported;
+  if (a.reference_order && a.sumabs_in == nullptr && a.sumabs_scratch != nullptr && a.lpc_stage == 0 &&
+      (a.fixed_mode == 1u || (a.fixed_mode == 0 && a.use_fixed && a.fixed_order_sel == 1u && (a.frame_results || a.chan_results)))) {
+    // Reference summation order for fixed_lpc's ApproxEnt selector: every estimator partition's sum of |e|
+    // as find_sum_abs_f32's own f32 chain, one (subframe, partition) per lane; the selecting kernels then
+    // read the sums instead of adding them up themselves.
+    SumAbsRefArgs r{};
+    r.samples = a.samples;
+    r.stride = a.stride;
+    r.block_size = a.block_size;
+    r.n_subframes = a.n_subframes;
+    r.stereo = a.stereo;
+    r.partitions = a.fixed_mode == 1u ? a.fixed_partitions : (64u >> a.fixed_group_log2);
+    r.nightly = 0;
+    r.out = a.sumabs_scratch;
+    hipError_t err = launch_sumabs_reference(r, stream);
+    if (err != hipSuccess) return err;
+    QlpcKernelArgs b = a;
+    b.sumabs_in = a.sumabs_scratch;
+    return launch_qlpc(b, plan, stream);
+  }
   if (a.reference_order && a.fixed_mode == 0 && a.lpc_stage == 0 && a.acorr_in == nullptr) {
     // Reference summation order: R[] by the lane-per-subframe kernel, then the usual pipeline from
     // Levinson on (below: the fused wave kernel with its phase 1 skipped, the big-block kernels from

@@ -37,6 +37,11 @@ struct QlpcKernelArgs {
   // launch_qlpc runs it into split_scratch (or `autocorr`) and hands the result on as `acorr_in`
   uint32_t reference_order;
   const double* acorr_in;     // device, [n][33]: precomputed R[], skips phase 1 (wave kernel)
+  // ... and, with the ApproxEnt order selector of fixed_lpc, every estimator partition's sum of |e| comes
+  // from sumabs_reference_kernel (find_sum_abs_f32's sequential f32 chain, arrayutils.rs:496-506) instead of
+  // the kernels' exact integer sums: launch_qlpc runs it into `sumabs_scratch` and hands it on as `sumabs_in`
+  const float* sumabs_in = nullptr;  // device, [n][5][64]: order k, partition p at [(sf * 5 + k) * 64 + p]
+  float* sumabs_scratch = nullptr;   // device, n * 5 * 64 floats, or nullptr
   uint32_t only_marked;       // generic kernel: redo only subframes whose record says status == -1
   flacenc_hip_subframe_params* params;  // device
   int32_t* residual;                    // device

@@ -927,6 +927,13 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
       // |x - y| of the signed values, i.e. the NEXT order's magnitude, straight from this order's
       // values; 16-sample sub-sums stay below 2^32 for inputs up to 25 bits, then go to f64
       double ls[5];
+      const int g = (int)a.fixed_group_log2;
+      if (a.sumabs_in != nullptr) {
+        // FLACENC_HIP_FLAG_REFERENCE_SUM_ORDER: find_sum_abs_f32's own f32 chains (sumabs_reference_kernel)
+        const float* __restrict__ sref = a.sumabs_in + (size_t)sf * (5 * 64) + (lane >> g);
+#pragma unroll
+        for (int ord = 0; ord < 5; ++ord) ls[ord] = (double)sref[ord * 64];
+      } else {
       {
         uint32_t b[68];
         fixed_load(b);
@@ -951,11 +958,11 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
         }
       }
       // partition sums: partitions of 4096 / P samples = groups of 2^g lanes (P a power of two)
-      const int g = (int)a.fixed_group_log2;
 #pragma unroll 1
       for (int lvl = 0; lvl < g; ++lvl) {
 #pragma unroll
         for (int ord = 0; ord < 5; ++ord) ls[ord] += __shfl_xor(ls[ord], 1 << lvl, 64);
+      }
       }
       // estimate_entropy for several orders at once: the 2^g lanes of a partition all hold its
       // five sums, so lane j of a group takes order r 2^g + j in pass r.  Its partition estimates

@@ -1,0 +1,233 @@
+// sumabs_reference.cpp -- the fixed-LPC order selector's sums of |e| in the summation orders of the reference.
+//
+// estimate_entropy (src/coding.rs:200-227) feeds every estimator partition's errors to
+// find_sum_abs_f32::<16> (src/arrayutils.rs:496-506), an f32 reduction whose order depends on the build:
+//
+//   stable (slice_as_simd = (data, [], []), arrayutils.rs:435-438; simd_map_and_reduce :459-493):
+//     ONE sequential chain  acc = |e[t]| as f32 + acc  over the partition, then acc + 0.0;
+//   simd-nightly (`as_simd`: 64-byte aligned body of 16-lane vectors, scalar head and foot):
+//     head and foot elements on the scalar chain, body element i on lane chain (i mod 16), result
+//     acc + (ordered sum of the 16 lane accumulators).
+//
+// The kernels' own definition (exact integer sum, rounded once) coincides with both while a partition's
+// sum stays below 2^24 and differs by f32 roundings above -- 24-bit material at the default 16 partitions.
+// A chain of dependent f32 adds cannot be split over lanes without changing the roundings, so here a LANE
+// owns one (subframe, partition) pair and walks it serially, carrying the five orders' chains side by side:
+// the order-k error signal is the k-th wrapping difference of the zero-extended signal
+// (reset_fixed_lpc_errors, coding.rs:182-197; the first k entries are partial differences, not zeros, and
+// ARE summed), so one pass over the samples with four values of state produces all five.
+// With the default 16 partitions a wave covers 4 subframes = the roles L, R, M, S of one stereo frame
+// (M = (l + r) >> 1 and S = l - r formed on the fly, coding.rs:483).
+//
+// |e| as f32: v_cvt_f32_i32 rounds to nearest even symmetrically, so |cvt(e)| == cvt(|e|) for every e but
+// i32::MIN, which 25-bit inputs cannot produce at order <= 4 (|e_4| <= 16 * 2^24).
+#include "sumabs_reference.h"
+
+namespace flacenc_hip {
+namespace {
+
+struct Chains {
+  float acc[5];
+};
+
+template <bool STEREO, bool NIGHTLY>
+__global__ void __launch_bounds__(256) sumabs_reference_kernel(SumAbsRefArgs a) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6);
+  const int n = (int)a.block_size;
+  const int parts = (int)a.partitions;
+  const int psz = (n + parts - 1) / parts;  // block_size.div_ceil(partitions), coding.rs:209
+  const int rpw = 64 / parts;               // subframes per wave
+  const int used = rpw * parts;
+  // lanes beyond the last whole subframe of the wave, and waves' lanes beyond the batch, shadow a valid
+  // lane (same loads, nothing stored) so that the wave-uniform "every lane is inside its partition" test
+  // below is not spoiled by idle lanes
+  const int el = lane < used ? lane : lane % used;
+  const int r = el / parts, p = el - r * parts;
+  uint32_t sf = wave * (uint32_t)rpw + (uint32_t)r;
+  const bool store = lane < used && sf < a.n_subframes;
+  if (wave * (uint32_t)rpw >= a.n_subframes) return;  // whole wave idle (uniform)
+  if (sf >= a.n_subframes) sf = a.n_subframes - 1u;
+
+  int kind = 0;
+  const int32_t* rowA;
+  const int32_t* rowB;
+  if (STEREO) {
+    const uint32_t frame = sf >> 2;
+    kind = (int)(sf & 3u);
+    rowA = a.samples + (size_t)(2u * frame + (kind == 1 ? 1u : 0u)) * a.stride;
+    rowB = kind >= 2 ? a.samples + (size_t)(2u * frame + 1u) * a.stride : rowA;
+  } else {
+    rowA = a.samples + (size_t)sf * a.stride;
+    rowB = rowA;
+  }
+  const bool vec_ok = ((reinterpret_cast<uintptr_t>(a.samples) & 15) == 0) && ((a.stride & 3) == 0);
+  auto ld = [&](const int32_t* row, int t) -> int4 {  // samples [t, t + 4), zero outside [0, n); t % 4 == 0
+    if (vec_ok && t >= 0 && t + 4 <= n) return *reinterpret_cast<const int4*>(row + t);
+    int4 v;
+    v.x = (t + 0 >= 0 && t + 0 < n) ? row[t + 0] : 0;
+    v.y = (t + 1 >= 0 && t + 1 < n) ? row[t + 1] : 0;
+    v.z = (t + 2 >= 0 && t + 2 < n) ? row[t + 2] : 0;
+    v.w = (t + 3 >= 0 && t + 3 < n) ? row[t + 3] : 0;
+    return v;
+  };
+  auto role_quad = [&](int t) -> int4 {
+    int4 v = ld(rowA, t);
+    if (STEREO) {
+      const int4 q = ld(rowB, t);
+      const int4 m = make_int4((v.x + q.x) >> 1, (v.y + q.y) >> 1, (v.z + q.z) >> 1, (v.w + q.w) >> 1);
+      const int4 s = make_int4(v.x - q.x, v.y - q.y, v.z - q.z, v.w - q.w);
+      v = kind == 2 ? m : (kind == 3 ? s : v);
+    }
+    return v;
+  };
+
+  const long long b0 = (long long)p * psz;
+  const int begin = b0 < n ? (int)b0 : n;
+  const int end = begin + psz < n ? begin + psz : n;
+  const int b4 = begin & ~3;
+
+  // state of the differencing at t = b4 - 1 (zero-extended signal in front of the block)
+  uint32_t sp, e1p, e2p, e3p;
+  {
+    const int4 h = role_quad(b4 - 4);
+    const uint32_t h0 = (uint32_t)h.x, h1 = (uint32_t)h.y, h2 = (uint32_t)h.z, h3 = (uint32_t)h.w;
+    sp = h3;
+    e1p = h3 - h2;
+    e2p = h3 - 2u * h2 + h1;
+    e3p = h3 - 3u * h2 + 3u * h1 - h0;
+  }
+
+  // stable: acc[k] is the one chain of order k.  nightly: lanes[k][j] are the 16 vector-lane chains of the
+  // aligned body and acc[k] the scalar chain of head and foot (SimdVec storage is 64-byte aligned, so the
+  // body starts at the first multiple of 16 elements at or after `begin`, arrayutils.rs:459-493)
+  float acc[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+  float vl[NIGHTLY ? 5 : 1][NIGHTLY ? 16 : 1];
+  if (NIGHTLY) {
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) vl[k][j] = 0.0f;
+  }
+  int body_lo = 0, body_hi = 0;
+  if (NIGHTLY) {
+    body_lo = (begin + 15) & ~15;
+    if (body_lo > end) body_lo = end;
+    body_hi = body_lo + ((end - body_lo) & ~15);
+  }
+
+  auto step = [&](auto masked_tag, uint32_t x, int t, int j16) {
+    constexpr bool MASKED = decltype(masked_tag)::value;
+    const uint32_t e1 = x - sp, e2 = e1 - e1p, e3 = e2 - e2p, e4 = e3 - e3p;
+    sp = x;
+    e1p = e1;
+    e2p = e2;
+    e3p = e3;
+    float f[5];
+    f[0] = __builtin_fabsf((float)(int32_t)x);
+    f[1] = __builtin_fabsf((float)(int32_t)e1);
+    f[2] = __builtin_fabsf((float)(int32_t)e2);
+    f[3] = __builtin_fabsf((float)(int32_t)e3);
+    f[4] = __builtin_fabsf((float)(int32_t)e4);
+    if (!NIGHTLY) {
+      const bool in = !MASKED || (t >= begin && t < end);
+#pragma unroll
+      for (int k = 0; k < 5; ++k) acc[k] = (in ? f[k] : 0.0f) + acc[k];  // acc >= +0: adding +0 changes nothing
+    } else {
+      // (t - body_lo) mod 16 == j16 by construction of the walk: quads start at multiples of 4 and body_lo
+      // is a multiple of 16 unless the body is empty
+      const bool in = !MASKED || (t >= begin && t < end);
+      const bool body = t >= body_lo && t < body_hi;
+#pragma unroll
+      for (int k = 0; k < 5; ++k) {
+        const float fk = in ? f[k] : 0.0f;
+        acc[k] = (body ? 0.0f : fk) + acc[k];
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+          if (j == j16) vl[k][j] = (body ? fk : 0.0f) + vl[k][j];
+      }
+    }
+  };
+
+  // the walk: 16 samples per iteration from b4 (a multiple of 4; for NIGHTLY the iteration grid is aligned
+  // to 16 so that the vector lane index is a compile-time constant)
+  const int w0 = NIGHTLY ? (begin & ~15) : b4;
+  if (NIGHTLY && w0 != b4) {
+    // state at w0 - 1 instead of b4 - 1
+    const int4 h = role_quad(w0 - 4);
+    const uint32_t h0 = (uint32_t)h.x, h1 = (uint32_t)h.y, h2 = (uint32_t)h.z, h3 = (uint32_t)h.w;
+    sp = h3;
+    e1p = h3 - h2;
+    e2p = h3 - 2u * h2 + h1;
+    e3p = h3 - 3u * h2 + 3u * h1 - h0;
+  }
+  int my_iters = (end - w0 + 15) >> 4;
+  if (my_iters < 0) my_iters = 0;
+  int iters = my_iters;
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) {
+    const int o = __shfl_xor(iters, m, 64);
+    iters = o > iters ? o : iters;
+  }
+  int4 cur[4], nxt[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) cur[q] = role_quad(w0 + 4 * q);
+#pragma unroll 1
+  for (int it = 0; it < iters; ++it) {
+    const int t0 = w0 + 16 * it;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) nxt[q] = role_quad(t0 + 16 + 4 * q);
+    const bool full = t0 >= begin && t0 + 16 <= end;
+    auto run = [&](auto masked_tag) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        step(masked_tag, (uint32_t)cur[q].x, t0 + 4 * q + 0, 4 * q + 0);
+        step(masked_tag, (uint32_t)cur[q].y, t0 + 4 * q + 1, 4 * q + 1);
+        step(masked_tag, (uint32_t)cur[q].z, t0 + 4 * q + 2, 4 * q + 2);
+        step(masked_tag, (uint32_t)cur[q].w, t0 + 4 * q + 3, 4 * q + 3);
+      }
+    };
+    if (__builtin_amdgcn_ballot_w64(!full) == 0) run(std::false_type{});
+    else run(std::true_type{});
+#pragma unroll
+    for (int q = 0; q < 4; ++q) cur[q] = nxt[q];
+  }
+
+  if (store) {
+    float* __restrict__ o = a.out + (size_t)sf * (5 * 64) + p;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      float v;
+      if (!NIGHTLY) {
+        v = acc[k] + 0.0f;  // scalar_reduce_fn(acc, reduce_sum(zero vector)), arrayutils.rs:492
+      } else {
+        float lanes = 0.0f;  // SimdFloat::reduce_sum: ordered sum of the lanes (as the oracle restates it)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) lanes += vl[k][j];
+        v = acc[k] + lanes;
+      }
+      o[k * 64] = v;
+    }
+  }
+}
+
+}  // namespace
+
+hipError_t launch_sumabs_reference(const SumAbsRefArgs& a, hipStream_t stream) {
+  if (a.n_subframes == 0) return hipSuccess;
+  if (a.partitions == 0 || a.partitions > 64) return hipErrorInvalidValue;
+  if (a.stereo && (a.n_subframes & 3u)) return hipErrorInvalidValue;
+  const uint32_t rpw = 64u / a.partitions;
+  const uint32_t waves = (a.n_subframes + rpw - 1u) / rpw;
+  const uint32_t blocks = (waves + 3u) / 4u;
+  if (a.nightly) {
+    if (a.stereo) hipLaunchKernelGGL((sumabs_reference_kernel<true, true>), dim3(blocks), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((sumabs_reference_kernel<false, true>), dim3(blocks), dim3(256), 0, stream, a);
+  } else {
+    if (a.stereo) hipLaunchKernelGGL((sumabs_reference_kernel<true, false>), dim3(blocks), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((sumabs_reference_kernel<false, false>), dim3(blocks), dim3(256), 0, stream, a);
+  }
+  return hipGetLastError();
+}
+
+}  // namespace flacenc_hip

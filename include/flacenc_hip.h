@@ -83,7 +83,13 @@ extern "C" {
  * subframe per lane by a kernel of its own, instead of the kernels' default order (16-sample chunk
  * chains combined by a balanced tree -- same FMA count, different roundings, documented in DESIGN.md).
  * With this flag R[], the LPC coefficients and therefore every integer output are those of the stable
- * reference build for everything the oracle pins.  Costs one extra pass over the samples. */
+ * reference build for everything the oracle pins.  Costs one extra pass over the samples.
+ * The flag also reaches the path's other order-sensitive sum: with OrderSel::ApproxEnt, fixed_lpc's
+ * estimator takes every partition's sum of |e| from find_sum_abs_f32 (src/arrayutils.rs:496-506), which in
+ * the stable build is one sequential f32 chain per partition; a kernel that gives a lane one (subframe,
+ * partition) pair reproduces those chains for the five orders, so the selector's keys -- and with them the
+ * chosen candidate and the frame bytes of the reference's default configuration -- are the stable
+ * build's, 24-bit material included (tests/test_gpu_reference_order.py). */
 #define FLACENC_HIP_FLAG_REFERENCE_SUM_ORDER 32u
 
 /* where the caller's sample / output buffers live */
@@ -219,9 +225,9 @@ int flacenc_hip_stereo_qlpc_batch_async(flacenc_hip_handle* h, const flacenc_hip
  * is the exact integer sum rounded to f32 once; the reference accumulates in f32 (find_sum_abs_f32,
  * src/arrayutils.rs:496: one sequential chain in the stable build, 16 lanes in simd-nightly).  All three
  * coincide while the sum stays below 2^24 and differ by f32 rounding above it (24-bit material, loud 16-bit
- * material at higher fixed orders): the selected fixed order -- and hence the frame bytes -- are then not
- * guaranteed identical to a CPU build's, also under FLACENC_HIP_FLAG_REFERENCE_SUM_ORDER.  BitCount has no
- * such dependence. */
+ * material at higher fixed orders): without FLACENC_HIP_FLAG_REFERENCE_SUM_ORDER the selected fixed order --
+ * and hence the frame bytes -- are then not guaranteed identical to a CPU build's; with it the sums are the
+ * stable build's sequential chains, bit for bit.  BitCount has no such dependence. */
 
 typedef struct flacenc_hip_frame_config {
   flacenc_hip_qlpc_config qlpc;

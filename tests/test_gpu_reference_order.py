@@ -4,7 +4,9 @@ its REFERENCE mode bit for bit -- R[], unquantised and quantised coefficients, s
 Rice partition, every bit count -- not merely within the tolerance the default (canonical-order) mode is
 held to.  Covered: the five BASELINE shapes, the reference's real-audio fixtures (src/resource/*.bin),
 the committed golden vectors (oracle output in reference order), ragged block sizes, unaligned rows, and
-the stereo / frame-level entry points (fused wave kernel with its phase 1 skipped)."""
+the stereo / frame-level entry points (fused wave kernel with its phase 1 skipped).  The flag also covers
+the other order-sensitive sum of the path: find_sum_abs_f32 (src/arrayutils.rs:496-506) inside the ApproxEnt
+order selector of fixed_lpc, one sequential f32 chain per estimator partition in the stable build."""
 import os
 
 import numpy as np
@@ -151,18 +153,26 @@ def test_stereo_candidates(handle, order):
         assert np.array_equal(gres[f], rres)
 
 
-@pytest.mark.parametrize("n,order,use_fixed", [(4096, 8, False), (4096, 8, True), (4096, 10, True), (1152, 8, True),
-                                                (8192, 24, False)])
-def test_frame_pipeline_and_bytes(handle, n, order, use_fixed):
+@pytest.mark.parametrize("n,bps,order,use_fixed", [
+    (4096, 16, 8, False), (4096, 16, 8, True), (4096, 16, 10, True), (1152, 16, 8, True), (8192, 16, 24, False),
+    # 24-bit material: the estimator's partition sums pass 2^24, where find_sum_abs_f32's sequential f32 chain
+    # (arrayutils.rs:496-506) and an exactly rounded sum part ways -- fused kernel, big-block and generic paths
+    (4096, 24, 8, True), (4096, 24, 12, True), (8192, 24, 24, True), (16384, 24, 24, True), (8192, 24, 8, True),
+    (4608, 24, 10, True),
+])
+def test_frame_pipeline_and_bytes(handle, n, bps, order, use_fixed):
     """encode_stereo_frames + pack_stereo_frames in reference order == the oracle's encode_frame controller
-    and bit writer run on reference-order coefficients: decisions, records, residual rows, frame bytes."""
-    bps = 16
+    and bit writer in the reference's stable-build orders (autocorrelation: one chain per lag; ApproxEnt
+    selector: one f32 chain per estimator partition): decisions, records, residual rows, frame bytes."""
     F = 6
     frames = _capi.sigen_frames(F, 2, n, bps, 36.0, 0.4, 0.04, seed=77 + order, nthreads=1)
+    if bps == 24:
+        frames[1] = _capi.sigen_frames(1, 2, n, bps, 300.0, 0.8, 0.001, seed=5, nthreads=1)[0]   # FixedLpc territory
+        frames[2, 1] = frames[2, 0] // 3
     cfg = _capi.make_frame_config(gcfg(order), use_fixed=use_fixed)
     res, resid = handle.encode_stereo_frames(frames, bps, cfg)
     ofc = orc.make_frame_config(ocfg(order), use_fixed=use_fixed,
-                                fixed=orc.make_fixed_config(sum_mode=orc.SUMABS_CANONICAL))
+                                fixed=orc.make_fixed_config(sum_mode=orc.SUMABS_STABLE))
     want, wres = orc.encode_stereo_frames_cfg(frames, bps, ofc)
     assert res["channel_assignment"].tolist() == want["channel_assignment"].tolist()
     assert res["kind"].tolist() == want["kind"].tolist() and res["bits"].tolist() == want["bits"].tolist()
@@ -172,6 +182,105 @@ def test_frame_pipeline_and_bytes(handle, n, order, use_fixed):
     for f in range(F):
         assert packed[f] == orc.write_stereo_frame(res[f], frames[f, 0], frames[f, 1], bps, 44100, f,
                                                    resid[f, 0], resid[f, 1])
+
+
+def _selector_corpus(n, bps):
+    sigs = [util.sine_noise(n, bps, 200, 0.4, 0.05, seed=1), util.sine_noise(n, bps, 31, 0.7, 0.3, seed=2),
+            util.quantize(util.sine(n, 100, 0.6), bps), (np.arange(n) // 7).astype(np.int32),
+            ((np.arange(n) - n // 2) ** 2 // 400 % (1 << (bps - 2))).astype(np.int32),
+            np.full(n, 77, np.int32), np.zeros(n, np.int32),
+            util.quantize(util.noise(5, n, 0.999), bps),
+            np.where(np.arange(n) % 2 == 0, 2 ** (bps - 1) - 1, -2 ** (bps - 1)).astype(np.int32),
+            util.sine_noise(n, bps, 57, 0.9, 0.01, seed=3), util.sine_noise(n, bps, 1000, 0.5, 0.1, seed=4)]
+    return np.stack(sigs).astype(np.int32)
+
+
+@pytest.mark.parametrize("n,bps,parts,max_order", [
+    (4096, 24, 16, 4), (8192, 24, 16, 4), (16384, 24, 16, 4), (16384, 25, 4, 4), (8192, 24, 64, 4),
+    (8192, 24, 1, 4), (4096, 24, 8, 0), (4096, 16, 16, 4), (4096, 16, 2, 4),
+    # generic kernel: ragged partitions (div_ceil sizes, a short or empty last partition, partitions shorter
+    # than the warm-up), block sizes with no alignment at all
+    (4608, 24, 16, 4), (1152, 24, 7, 4), (20000, 24, 33, 3), (100, 8, 64, 4), (8191, 24, 5, 4), (577, 24, 3, 2),
+])
+def test_fixed_selector_in_stable_sum_order(handle, n, bps, parts, max_order):
+    """fixed_lpc with OrderSel::ApproxEnt in reference order: the selector's key of every order equals the
+    oracle's with find_sum_abs_f32 as the stable build's sequential chain, and so do the chosen order, the Rice
+    partition, the bit counts and the error signal.  The corpus is checked to be discriminating: at 24 bits
+    some keys differ between the sequential chain and the exactly rounded sum."""
+    import torch
+    x = _selector_corpus(n, bps)
+    separating = bps == 24 and n in (8192, 16384) and parts == 16
+    if separating:  # (the oracle's two modes differ on about one in ten of these)
+        x = np.concatenate([x, batch(40, n, bps, 4000)])
+    ns = x.shape[0]
+    bpsv = np.full(ns, bps, np.uint8)
+    cfg = _capi.make_frame_config(gcfg(8), use_fixed=True, fixed_order_sel=1, fixed_partitions=parts,
+                                  fixed_max_order=max_order)
+    keys_all = torch.zeros((ns, 8), dtype=torch.int64, device="cuda")
+    handle.debug_set_fixed_keys(keys_all.data_ptr())
+    try:
+        params, resid, keys = handle.fixed_lpc_batch(x, bpsv, cfg)
+    finally:
+        handle.debug_set_fixed_keys(0)
+    ka = keys_all.cpu().numpy().astype(np.uint64)
+    fc = orc.make_fixed_config(max_order=max_order, partitions=parts, sum_mode=orc.SUMABS_STABLE)
+    fc_canon = orc.make_fixed_config(max_order=max_order, partitions=parts, sum_mode=orc.SUMABS_CANONICAL)
+    differ = 0
+    for k in range(ns):
+        w = orc.fixed_lpc(x[k], bps, 2 ** 63, fc)
+        assert ka[k, : max_order + 1].tolist() == w["estimate"][: max_order + 1], (k, "selector keys")
+        differ += w["estimate"] != orc.fixed_lpc(x[k], bps, 2 ** 63, fc_canon)["estimate"]
+        p = params[k]
+        assert int(p["order"]) == w["order"] and int(keys[k]) == w["estimate"][w["order"]], k
+        for fld in ("rice_order", "code_bits", "subframe_bits", "sum_quotients"):
+            assert int(p[fld]) == int(w[fld]), (k, fld)
+        assert p["rice_params"][: 1 << w["rice_order"]].tolist() == w["rice_params"].tolist()
+        assert np.array_equal(resid[k], w["residual"]), k
+    if separating:
+        assert differ > 0, "corpus does not separate the two summation orders"
+
+
+@pytest.mark.parametrize("n,parts", [(4096, 16), (8192, 16), (4608, 16), (4096, 32), (16384, 8)])
+def test_fixed_selector_stereo_roles_in_stable_sum_order(handle, n, parts):
+    """The same for the L, R, M, S roles of stereo frames (M and S formed inside the summing kernel)."""
+    bps = 24
+    x = _capi.sigen_frames(5, 2, n, bps, 90.0, 0.5, 0.02, seed=31, nthreads=1)
+    x[1, 1] = x[1, 0] // 2 + 3
+    x[2] = _capi.sigen_frames(1, 2, n, bps, 400.0, 0.9, 0.0005, seed=32, nthreads=1)[0]
+    cfg = _capi.make_frame_config(gcfg(8), use_fixed=True, fixed_order_sel=1, fixed_partitions=parts)
+    params, resid, keys = handle.fixed_lpc_batch(x, bps, cfg, stereo=True)
+    fc = orc.make_fixed_config(partitions=parts, sum_mode=orc.SUMABS_STABLE)
+    for f in range(x.shape[0]):
+        l, r = x[f, 0], x[f, 1]
+        for role, sig in enumerate([l, r, *orc.stereo_to_midside(l, r)]):
+            w = orc.fixed_lpc(sig, bps + (1 if role == 3 else 0), 2 ** 63, fc)
+            p = params[f, role]
+            assert int(p["order"]) == w["order"] and int(keys[f, role]) == w["estimate"][w["order"]], (f, role)
+            assert int(p["subframe_bits"]) == w["subframe_bits"] and int(p["code_bits"]) == w["code_bits"]
+            assert np.array_equal(resid[f, role], w["residual"]), (f, role)
+
+
+@pytest.mark.parametrize("channels,n,order", [(8, 4096, 10), (3, 4096, 8), (2, 8192, 12), (1, 1152, 8)])
+def test_independent_channels_default_candidates_in_stable_sum_order(handle, channels, n, order):
+    """flacenc_hip_encode_frames with the reference's default candidate set (use_fixed) on 24-bit material in
+    reference order: kind, bits, record and residual of every channel == encode_subframe (coding.rs:384-418) with
+    both reference summation orders."""
+    bps = 24
+    x = _capi.sigen_frames(4, channels, n, bps, 150.0, 0.5, 0.04, seed=channels * 1000 + n, nthreads=1)
+    x[1, 0] = _capi.sigen_frames(1, 1, n, bps, 500.0, 0.9, 0.0003, seed=9, nthreads=1)[0, 0]
+    x[2, channels - 1] = -5
+    cfg = _capi.make_frame_config(gcfg(order), use_fixed=True)
+    res, resid = handle.encode_frames(x, bps, cfg)
+    ofc = orc.make_frame_config(ocfg(order), use_fixed=True, fixed=orc.make_fixed_config(sum_mode=orc.SUMABS_STABLE))
+    for f in range(x.shape[0]):
+        for c in range(channels):
+            w = orc.encode_subframe(x[f, c], bps, ofc)
+            g = res[f, c]
+            assert int(g["kind"]) == w["kind"] and int(g["bits"]) == w["bits"], (f, c)
+            if w["kind"] >= 2:
+                assert np.array_equal(resid[f, c], w["residual"]), (f, c)
+                src = w["lpc"] if w["kind"] == 3 else w["fixed"]
+                assert int(g["params"]["subframe_bits"]) == int(src.subframe_bits)
 
 
 def test_independent_channels(handle):

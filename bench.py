@@ -39,8 +39,6 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 ALGO_BYTES_PER_SAMPLE = 8.0  # 4 B sample read + 4 B residual written per input channel-sample
 N_SIMDS = 256 * 4  # 256 CUs x 4 SIMDs
-VALU_ISSUE_CYCLES = 4  # a wave64 VALU instruction occupies its SIMD for 4 cycles (f64 fma included)
-SHADER_CLOCK_HZ = 2.4e9
 SAMPLE_RATE = 44100
 
 
@@ -191,9 +189,15 @@ def run(args, world):
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     ranks_observed = 1
-    if world > 1:
+    if world > 1 or args.force_exchange:
+        # (--force-exchange with one rank: a real 1-rank RCCL communicator, so that the exchange step of a
+        # single-GPU box goes through the same all_gather_into_tensor calls as an 8-GPU run)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this driver
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", str(free_port()))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if args.shared_gpu_test:
             dist.init_process_group("gloo")
         else:
@@ -246,9 +250,10 @@ def run(args, world):
         if args.gather in ("records", "payload"):
             last_exchange["records_all"] = shard.all_gather_frame_records(results2[b], world * F, n)
         if payload:
+            # (run capacity = the packer's bound: no host synchronisation on the exchange stream)
             last_exchange["stream_bytes"] = shard.all_gather_frame_bytes(
                 shard.device_place(handle, comm.cuda_stream), packed2[b], frame_len2[b], lengths_all, offsets,
-                world * F)
+                world * F, run_capacity=F * out_stride)
 
     def step(events=None):
         b = step_no[0] & 1
@@ -276,7 +281,7 @@ def run(args, world):
                 consumed[b].record(comm)
 
     def fence():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -299,7 +304,7 @@ def run(args, world):
         step(ev[k])
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist.is_initialized():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -324,12 +329,9 @@ def run(args, world):
         value = 0.0  # ranks shared a GPU and the collectives went through the host: not a measurement
     achieved = ALGO_BYTES_PER_SAMPLE * samples_per_step / (kernel_ms * 1e-3) / 1e9
     prof = profiled_counters(args)
-    valu_frac = None
-    if prof and prof.get("valu_insts_per_wave"):
-        # instruction counts are a property of kernel + data; the busy fraction uses the live duration
-        waves = 4 * F
-        valu_frac = round(prof["valu_insts_per_wave"] * VALU_ISSUE_CYCLES * waves / N_SIMDS / SHADER_CLOCK_HZ
-                          / (kernel_ms * 1e-3), 4)
+    # share of SIMD cycles with the VALU pipe executing: a ratio of two counters of the profiled runs of this
+    # very kernel source (no clock assumed), see tools/make_headline_pmc.py
+    valu_frac = round(prof["valu_busy_frac"], 4) if prof and prof.get("valu_busy_frac") else None
 
     gather_desc = "none"
     if exchanging:
@@ -350,6 +352,7 @@ def run(args, world):
         "unit": "Msamples/s",
         "n_gpus": world,
         "ranks_observed": ranks_observed,
+        "collective_backend": (dist.get_backend() if dist.is_initialized() else None),
         **({"shared_gpu_test": True} if args.shared_gpu_test else {}),
         "steps": args.steps,
         "warmup": args.warmup,
@@ -376,7 +379,11 @@ def run(args, world):
             "assignments_indep_left_right_mid": assign_hist,
         },
         "roofline": {
-            "bound": "hbm",
+            # what binds the dominant kernel is VALU issue (counters: the pipe executes in `valu_issue_frac` of
+            # all SIMD cycles; HBM traffic is 1.04 x the algorithmic bytes at a third of the HBM roof).  achieved /
+            # peak / frac stay priced against the HBM roof, the currency SURVEY 8(d) names for this path.
+            "bound": "valu_issue",
+            "priced_against": "hbm",
             "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
@@ -386,10 +393,8 @@ def run(args, world):
             "kernel_ms": round(kernel_ms, 4),
             "kernel_ms_stats": stats(kernel_times),
             "algorithmic_bytes_per_launch": ALGO_BYTES_PER_SAMPLE * samples_per_step,
-            # what the counters say binds the kernel: the HBM roof above is the roof the path is priced
-            # against, the VALU issue slots are what it actually runs out of
-            "limiter": "valu_issue",
             "valu_issue_frac": valu_frac,
+            "valu_insts_per_wave": prof.get("valu_insts_per_wave") if prof else None,
             "counters_from": ("profiles/headline_pmc.json @ kernel source %s" % prof["kernel_source_sha"]) if prof else None,
         },
     }
@@ -401,7 +406,7 @@ def run(args, world):
     if rank == 0:
         print(json.dumps(out), flush=True)
     handle.close()
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
@@ -422,7 +427,7 @@ def check_exchange(torch, dist, ex, my_records, my_lengths, rank, world, F, my_p
             o, ln = int(offsets[f]), int(lengths_all[f])
             ok &= bool(torch.equal(sb[o:o + ln], my_packed[j, :ln]))
     total = lengths_all.to(torch.int64).sum().reshape(1).clone()
-    if world > 1:
+    if dist.is_initialized():
         flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=lengths_all.device)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         ok = bool(flag.item())

@@ -129,7 +129,8 @@ def all_gather_frame_lengths(local_lengths: torch.Tensor, n_frames_total: int, g
 
 
 def all_gather_frame_bytes(place, packed: torch.Tensor, local_lengths: torch.Tensor, lengths_all: torch.Tensor,
-                           offsets: torch.Tensor, n_frames_total: int, group=None) -> torch.Tensor:
+                           offsets: torch.Tensor, n_frames_total: int, group=None,
+                           run_capacity: int | None = None) -> torch.Tensor:
     """All-gather the packed FLAC frames themselves and return the assembled frame stream (uint8, frames
     back to back in frame-number order) on every rank -- ParSink::finalize's output (src/par.rs:82-94).
 
@@ -139,7 +140,11 @@ def all_gather_frame_bytes(place, packed: torch.Tensor, local_lengths: torch.Ten
     (2) runs are all-gathered padded to the longest rank's run, (3) every frame is copied from its place
     in its producer's run to its stream offset.  Steps 1 and 3 are `place(src, src_offsets, lengths, dst,
     dst_offsets)` = flacenc_hip_place_frames_async on the GPU (Handle.place_frames_device wrapped by the
-    caller); there is no host fallback here.  One host synchronisation: the padded run size."""
+    caller); there is no host fallback here.  By default the runs are padded to the longest run actually
+    produced, which costs two host synchronisations (that size, and the stream's total); with `run_capacity`
+    -- an upper bound on any rank's run, e.g. n_local * out_stride -- nothing is read back: runs travel
+    padded to that bound and the result is the capacity-sized buffer whose first `stream_offsets(...)[1]`
+    bytes are the stream."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     per_rank = (n_frames_total + world - 1) // world
@@ -151,20 +156,23 @@ def all_gather_frame_bytes(place, packed: torch.Tensor, local_lengths: torch.Ten
     grid[:n_frames_total] = lengths_all.to(torch.int64)
     grid = grid.view(per_rank, world)
     run_offsets = torch.cumsum(grid, dim=0) - grid            # [j, r]: offset of frame (j, r) inside rank r's run
-    run_bytes = int(grid.sum(dim=0).max().item())             # host sync: the collective needs one size
+    if run_capacity is None:
+        run_bytes = int(grid.sum(dim=0).max().item())         # host sync: the collective needs one size
+    else:
+        run_bytes = int(run_capacity)
     cap = (run_bytes + 15) & ~15
     run = torch.zeros(max(cap, 16), dtype=torch.uint8, device=dev)
     row_offsets = torch.arange(n_local, dtype=torch.int64, device=dev) * packed.shape[1]
     my_lengths = local_lengths.to(torch.int32).contiguous()
     place(packed, row_offsets, my_lengths, run, run_offsets[:n_local, rank].contiguous())
-    if world > 1:
+    if dist.is_initialized():  # (also a 1-rank group: the same collective call as with 8 ranks)
         runs = torch.empty(world * run.numel(), dtype=torch.uint8, device=dev)
         dist.all_gather_into_tensor(runs, run, group=group)
     else:
         runs = run
     # frame f = j * world + r lives at r * cap' + run_offsets[j, r] in `runs`
     src = (run_offsets + torch.arange(world, dtype=torch.int64, device=dev) * run.numel()).reshape(-1)[:n_frames_total]
-    total = int(lengths_all.to(torch.int64).sum().item())
+    total = int(lengths_all.to(torch.int64).sum().item()) if run_capacity is None else world * cap
     stream_bytes = torch.empty(max(total, 1), dtype=torch.uint8, device=dev)
     place(runs, src.contiguous(), lengths_all.to(torch.int32).contiguous(), stream_bytes,
           offsets.to(torch.int64).contiguous())

@@ -79,3 +79,21 @@ def test_two_real_ranks_on_the_visible_gpus(gather):
     chk = line["config"]["exchange_check"]
     assert chk["ok"] is True and chk["stream_frames"] == 2 * 1536 and chk["stream_bytes"] > 0
     assert line["value"] == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gather", ["records", "payload"])
+def test_one_rank_rccl_exchange(gather):
+    """RCCL itself, on the one GPU of a test box: `--force-exchange` initialises a 1-rank `nccl` process group
+    and the exchange step runs the real collectives -- all_reduce for the rank count, all_gather_into_tensor
+    on the int32 lengths, the uint8 wire records and (payload) the packed frame runs -- exactly the calls an
+    8-GPU run makes (ParSink::finalize, src/par.rs:82-94)."""
+    r = _run(["--force-exchange", "--frames", "1536", "--steps", "3", "--warmup", "1", "--gather", gather,
+              "--no-secondary", "--no-cpu-baseline"], timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = _json_line(r.stdout)
+    assert line["n_gpus"] == 1 and line["ranks_observed"] == 1 and line["collective_backend"] == "nccl"
+    chk = line["config"]["exchange_check"]
+    assert chk["ok"] is True and chk["stream_frames"] == 1536 and chk["stream_bytes"] > 0
+    assert "RCCL all_gather" in line["config"]["gather"]
+    assert line["value"] > 0

@@ -112,5 +112,5 @@ def run_frames(name, frames, ch, n, bps, order):
 run_frames("config4: 4096 x 16b 8-channel, default config, frames", 2048, 8, 4096, 16, 10)
 run_frames("mono: 4096 x 16b, default config, frames", 8192, 1, 4096, 16, 10)
 
-print(json.dumps({"tool": "tools/bench_configs.py", "timing": "HIP events around 5 calls after 2 warm-up calls, device-resident data",
+print(json.dumps({"tool": "tools/bench_configs.py", "timing": "HIP events around 5 calls after 2 warm-up calls and 50 ms of untimed clock spin-up, device-resident data",
                   "rows": ROWS}, indent=1))

@@ -36,6 +36,12 @@ out = {
     "wave_cycles_per_wave": 4 * g("SQ_WAVE_CYCLES") / g("SQ_WAVES") if g("SQ_WAVE_CYCLES") and g("SQ_WAVES") else None,
     "wait_any_frac": g("SQ_WAIT_ANY") / g("SQ_WAVE_CYCLES") if g("SQ_WAIT_ANY") and g("SQ_WAVE_CYCLES") else None,
     "lds_bank_conflict_frac": g("SQ_LDS_BANK_CONFLICT") / g("SQ_LDS_IDX_ACTIVE") if g("SQ_LDS_BANK_CONFLICT") and g("SQ_LDS_IDX_ACTIVE") else None,
+    # share of the SIMDs' cycles in which the VALU pipe is executing, from counters alone (no assumed clock):
+    # SQ_ACTIVE_INST_VALU counts 4-cycle quanta over all SIMDs, GRBM_GUI_ACTIVE the kernel's cycles summed over
+    # the 8 XCDs
+    "valu_busy_frac": (4.0 * g("SQ_ACTIVE_INST_VALU") / (bench.N_SIMDS * g("GRBM_GUI_ACTIVE") / 8.0))
+                      if g("SQ_ACTIVE_INST_VALU") and g("GRBM_GUI_ACTIVE") else None,
+    "valu_busy_frac_formula": "4 * SQ_ACTIVE_INST_VALU / (1024 SIMDs * GRBM_GUI_ACTIVE / 8 XCDs)",
 }
 if out["bytes_per_launch"]:
     out["ratio_to_algorithmic"] = out["bytes_per_launch"] / algo

@@ -314,6 +314,7 @@ FLAG_GENERIC_KERNEL = 4
 FLAG_FUSED_PACK = 8
 FLAG_TWO_STAGE_PACK = 16
 FLAG_REFERENCE_SUM_ORDER = 32
+FLAG_NIGHTLY_SUM_ORDER = 64
 
 
 def make_config(lpc_order=10, quant_precision=15, window=("tukey", 0.4), max_rice_parameter=30,

@@ -19,6 +19,8 @@
 
 #include <type_traits>
 
+#include "lds_opt_in.h"
+
 namespace flacenc_hip {
 namespace {
 
@@ -169,6 +171,122 @@ __global__ void __launch_bounds__(64) acorr_reference_kernel(AcorrRefArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The simd-nightly build's order (weighted_auto_correlation_simd, src/lpc.rs:510-531, over
+// weighted_delay_prod_sum_impl :439-500).  Per lag d the windowed signal from t = P on is split by
+// `as_simd::<LANES>()` with LANES = 8 for d < 8 and 16 for d = 8..15 into a scalar head (up to the next
+// LANES-aligned element; the buffer is a SimdVec<f32, 16>, 64-byte aligned, lpc.rs:710), a body of whole
+// vectors and a scalar foot:
+//   acc = 0 + chain(head);  acc_v[l] = fma(x[t + l], x[t + l - d], acc_v[l]) over the body's vectors;
+//   acc += chain(foot);  R[d] = acc + reduce_sum(acc_v)   (ordered: ((0 + v0) + v1) + ...).
+// For d >= 16 LANES is 32 or 64 and the split depends on where the allocator put the buffer, so the mode
+// stops at order 15.  A vector lane's chain takes every LANES-th sample, so here a GPU LANE is a vector lane:
+// threads 0..63 are the 8 x 8 lane chains of lags 0..7, threads 64..191 the 8 x 16 of lags 8..15; one
+// workgroup per subframe, the windowed block staged once in LDS as f32.
+template <bool STEREO>
+__global__ void __launch_bounds__(256) acorr_nightly_kernel(AcorrRefArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float xw[];
+  const int tid = threadIdx.x;
+  const int n = (int)a.block_size;
+  const int P = (int)a.lpc_order;
+  const uint32_t sf = blockIdx.x;
+  const float* __restrict__ wtab = a.window ? a.window + 32 : nullptr;
+  {
+    // x_w = (f32)s * w, one f32 rounding (lpc.rs:751-754); M = (l + r) >> 1, S = l - r (coding.rs:483)
+    const int32_t* rowA;
+    const int32_t* rowB = nullptr;
+    int kind = 0;
+    if (STEREO) {
+      const uint32_t frame = sf >> 2;
+      kind = (int)(sf & 3u);
+      rowA = a.samples + (size_t)(2u * frame + (kind == 1 ? 1u : 0u)) * a.stride;
+      rowB = a.samples + (size_t)(2u * frame + 1u) * a.stride;
+    } else {
+      rowA = a.samples + (size_t)sf * a.stride;
+    }
+    for (int t = tid; t < n; t += 256) {
+      int32_t s = rowA[t];
+      if (STEREO && kind >= 2) {
+        const int32_t r = rowB[t];
+        s = kind == 2 ? (s + r) >> 1 : s - r;
+      }
+      xw[t] = (float)s * (wtab ? wtab[t] : 1.0f);
+    }
+  }
+  __syncthreads();
+  int d, l, L;
+  if (tid < 64) {
+    d = tid >> 3;
+    l = tid & 7;
+    L = 8;
+  } else {
+    d = 8 + ((tid - 64) >> 4);
+    l = (tid - 64) & 15;
+    L = 16;
+  }
+  // the split of signal[P..]: element i of the buffer is aligned iff i % L == 0
+  const int len = n - P;  // >= 1: blocks are at least 64 samples, P <= 15
+  const int mis = P % L;
+  int head = mis ? L - mis : 0;
+  if (head > len) head = len;
+  const int nbody = (len - head) / L;
+  const int t0 = P + head;
+  const bool lag_used = d <= P && d <= 15;
+  double acc_v = 0.0;
+  if (lag_used) {
+    const float* __restrict__ cur = xw + t0 + l;
+    int b = 0;
+    for (; b + 4 <= nbody; b += 4) {
+      const float c0 = cur[0], c1 = cur[L], c2 = cur[2 * L], c3 = cur[3 * L];
+      const float g0 = cur[0 - d], g1 = cur[L - d], g2 = cur[2 * L - d], g3 = cur[3 * L - d];
+      acc_v = __builtin_fma((double)c0, (double)g0, acc_v);
+      acc_v = __builtin_fma((double)c1, (double)g1, acc_v);
+      acc_v = __builtin_fma((double)c2, (double)g2, acc_v);
+      acc_v = __builtin_fma((double)c3, (double)g3, acc_v);
+      cur += 4 * L;
+    }
+    for (; b < nbody; ++b) {
+      acc_v = __builtin_fma((double)cur[0], (double)cur[0 - d], acc_v);
+      cur += L;
+    }
+  }
+  // ordered lane sum, gathered by the group's first lane (groups are aligned runs of L lanes of one wave)
+  double lanesum = 0.0;
+  const int base = (tid & 63) & ~(L - 1);
+  for (int j = 0; j < L; ++j) {
+    const double v = __shfl(acc_v, base + j, 64);
+    lanesum += v;
+  }
+  if (l == 0 && d <= 32) {
+    double r = 0.0;
+    if (lag_used) {
+      double acc = 0.0, h = 0.0, f = 0.0;
+      for (int t = P; t < t0; ++t) h = __builtin_fma((double)xw[t - d], (double)xw[t], h);
+      acc += h;
+      for (int t = t0 + nbody * L; t < n; ++t) f = __builtin_fma((double)xw[t - d], (double)xw[t], f);
+      acc += f;
+      r = acc + lanesum;
+    }
+    a.out[(size_t)sf * 33 + d] = r;
+  }
+  // lags 16..32 are not produced in this mode: written as 0 like every lag above P
+  if (tid >= 192 && tid < 192 + 17) a.out[(size_t)sf * 33 + 16 + (tid - 192)] = 0.0;
+}
+
+hipError_t launch_nightly(const AcorrRefArgs& a, hipStream_t stream) {
+  if (a.lpc_order > 15) return hipErrorNotSupported;
+  const size_t smem = (((size_t)a.block_size + 3) & ~(size_t)3) * sizeof(float);
+  static DynamicLdsOptIn opt_s, opt_p;
+  if (a.stereo) {
+    if (hipError_t e = opt_s.ensure(reinterpret_cast<const void*>(acorr_nightly_kernel<true>), smem); e != hipSuccess) return e;
+    hipLaunchKernelGGL((acorr_nightly_kernel<true>), dim3(a.n_subframes), dim3(256), smem, stream, a);
+  } else {
+    if (hipError_t e = opt_p.ensure(reinterpret_cast<const void*>(acorr_nightly_kernel<false>), smem); e != hipSuccess) return e;
+    hipLaunchKernelGGL((acorr_nightly_kernel<false>), dim3(a.n_subframes), dim3(256), smem, stream, a);
+  }
+  return hipGetLastError();
+}
+
 template <int MAXP>
 hipError_t launch_bucket(const AcorrRefArgs& a, hipStream_t stream) {
   const uint32_t blocks = (a.n_subframes + 63u) / 64u;
@@ -182,6 +300,7 @@ hipError_t launch_bucket(const AcorrRefArgs& a, hipStream_t stream) {
 hipError_t launch_acorr_reference(const AcorrRefArgs& a, hipStream_t stream) {
   if (a.n_subframes == 0) return hipSuccess;
   if (a.stereo && (a.n_subframes & 3u)) return hipErrorInvalidValue;
+  if (a.nightly) return launch_nightly(a, stream);
   const uint32_t P = a.lpc_order;
   if (P <= 8) return launch_bucket<8>(a, stream);
   if (P <= 12) return launch_bucket<12>(a, stream);

@@ -17,11 +17,14 @@ struct AcorrRefArgs {
   uint32_t stereo;
   const float* window;     // device table with 32 leading pad floats, nullptr = all ones
   uint32_t lpc_order;      // P: lags 0..P are produced
+  uint32_t nightly;        // 0: the stable build's single chain per lag; 1: simd-nightly's lane chains (P <= 15)
   double* out;             // device, [n_subframes][33]; lags above P are written as 0
 };
 
 // R[tau] = the single sequential fma chain of weighted_auto_correlation_nosimd (src/lpc.rs:533-548):
 // for t in P..n { R[tau] = fma(x_w[t - tau], x_w[t], R[tau]) }, one subframe per lane.
+// nightly: weighted_auto_correlation_simd (src/lpc.rs:510-531): 8 / 16 strided lane chains per lag + scalar head
+// and foot + ordered lane sum; hipErrorNotSupported above order 15 (alignment-dependent there).
 hipError_t launch_acorr_reference(const AcorrRefArgs& args, hipStream_t stream);
 
 }  // namespace flacenc_hip

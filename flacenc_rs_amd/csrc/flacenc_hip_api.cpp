@@ -269,6 +269,13 @@ int check_batch_args(flacenc_hip_handle* h, const flacenc_hip_qlpc_config* cfg, 
   return FLACENC_HIP_OK;
 }
 
+// QlpcKernelArgs::reference_order: 0 = the kernels' canonical sums, 1 = the stable build's orders
+// (FLACENC_HIP_FLAG_REFERENCE_SUM_ORDER), 2 = the simd-nightly build's (FLACENC_HIP_FLAG_NIGHTLY_SUM_ORDER)
+uint32_t sum_order_mode(uint32_t flags) {
+  if (flags & FLACENC_HIP_FLAG_NIGHTLY_SUM_ORDER) return 2u;
+  return (flags & FLACENC_HIP_FLAG_REFERENCE_SUM_ORDER) ? 1u : 0u;
+}
+
 // FLACENC_HIP_FLAG_REFERENCE_SUM_ORDER with the ApproxEnt selector: room for sumabs_reference_kernel's
 // per-partition f32 sums (launch_qlpc runs it when `sumabs_scratch` is set)
 int attach_sumabs_scratch(flacenc_hip_handle* h, flacenc_hip::QlpcKernelArgs& a, bool approx_ent) {
@@ -308,7 +315,7 @@ int enqueue(flacenc_hip_handle* h, const flacenc_hip_qlpc_config* cfg, const int
   a.max_rice_parameter = cfg->max_rice_parameter;
   a.rice_finest_only = (cfg->flags & FLACENC_HIP_FLAG_FINEST_RICE_ORDER) ? 1u : 0u;
   a.force_generic = (cfg->flags & FLACENC_HIP_FLAG_GENERIC_KERNEL) ? 1u : 0u;
-  a.reference_order = (cfg->flags & FLACENC_HIP_FLAG_REFERENCE_SUM_ORDER) ? 1u : 0u;
+  a.reference_order = sum_order_mode(cfg->flags);
   a.acorr_in = nullptr;
   a.only_marked = 0;
   a.params = params;
@@ -487,7 +494,7 @@ int enqueue_fixed(flacenc_hip_handle* h, const flacenc_hip_frame_config* cfg, co
   a.max_rice_parameter = cfg->qlpc.max_rice_parameter;
   a.rice_finest_only = (cfg->qlpc.flags & FLACENC_HIP_FLAG_FINEST_RICE_ORDER) ? 1u : 0u;
   a.force_generic = (cfg->qlpc.flags & FLACENC_HIP_FLAG_GENERIC_KERNEL) ? 1u : 0u;
-  a.reference_order = (cfg->qlpc.flags & FLACENC_HIP_FLAG_REFERENCE_SUM_ORDER) ? 1u : 0u;
+  a.reference_order = sum_order_mode(cfg->qlpc.flags);
   a.acorr_in = nullptr;
   a.only_marked = 0;
   a.params = params;
@@ -643,6 +650,11 @@ int flacenc_hip_verify_config(const flacenc_hip_qlpc_config* cfg) {
   }
   // config::Prc::verify, src/config.rs:224-229
   if (cfg->max_rice_parameter > FLACENC_HIP_MAX_RICE_PARAMETER) return FLACENC_HIP_ERR_BAD_CONFIG;
+  // one summation order at a time; the simd-nightly order is only defined up to lag 15 (beyond, `as_simd`
+  // splits 128- and 256-byte vectors at addresses the allocator picks, src/lpc.rs:459, :519-523)
+  if ((cfg->flags & FLACENC_HIP_FLAG_NIGHTLY_SUM_ORDER) && (cfg->flags & FLACENC_HIP_FLAG_REFERENCE_SUM_ORDER))
+    return FLACENC_HIP_ERR_BAD_CONFIG;
+  if ((cfg->flags & FLACENC_HIP_FLAG_NIGHTLY_SUM_ORDER) && cfg->lpc_order > 15) return FLACENC_HIP_ERR_UNSUPPORTED;
   return FLACENC_HIP_OK;
 }
 
@@ -957,7 +969,7 @@ int flacenc_hip_encode_frames_async(flacenc_hip_handle* h, const flacenc_hip_fra
     a.max_rice_parameter = cfg->qlpc.max_rice_parameter;
   a.rice_finest_only = (cfg->qlpc.flags & FLACENC_HIP_FLAG_FINEST_RICE_ORDER) ? 1u : 0u;
   a.force_generic = (cfg->qlpc.flags & FLACENC_HIP_FLAG_GENERIC_KERNEL) ? 1u : 0u;
-  a.reference_order = (cfg->qlpc.flags & FLACENC_HIP_FLAG_REFERENCE_SUM_ORDER) ? 1u : 0u;
+  a.reference_order = sum_order_mode(cfg->qlpc.flags);
   a.acorr_in = nullptr;
   a.only_marked = 0;
     a.params = nullptr;
@@ -1681,7 +1693,7 @@ static int encode_stereo_frames_impl(flacenc_hip_handle* h, const flacenc_hip_fr
   a.max_rice_parameter = cfg->qlpc.max_rice_parameter;
   a.rice_finest_only = (cfg->qlpc.flags & FLACENC_HIP_FLAG_FINEST_RICE_ORDER) ? 1u : 0u;
   a.force_generic = (cfg->qlpc.flags & FLACENC_HIP_FLAG_GENERIC_KERNEL) ? 1u : 0u;
-  a.reference_order = (cfg->qlpc.flags & FLACENC_HIP_FLAG_REFERENCE_SUM_ORDER) ? 1u : 0u;
+  a.reference_order = sum_order_mode(cfg->qlpc.flags);
   a.acorr_in = nullptr;
   a.only_marked = 0;
   a.params = nullptr;

@@ -84,7 +84,7 @@ hipError_t launch_qlpc(const QlpcKernelArgs& a, const QlpcLaunchPlan& plan, hipS
     r.n_subframes = a.n_subframes;
     r.stereo = a.stereo;
     r.partitions = a.fixed_mode == 1u ? a.fixed_partitions : (64u >> a.fixed_group_log2);
-    r.nightly = 0;
+    r.nightly = a.reference_order == 2u ? 1u : 0u;
     r.out = a.sumabs_scratch;
     hipError_t err = launch_sumabs_reference(r, stream);
     if (err != hipSuccess) return err;
@@ -106,6 +106,7 @@ hipError_t launch_qlpc(const QlpcKernelArgs& a, const QlpcLaunchPlan& plan, hipS
     r.stereo = a.stereo;
     r.window = a.window;
     r.lpc_order = a.lpc_order;
+    r.nightly = a.reference_order == 2u ? 1u : 0u;
     r.out = racc;
     hipError_t err = launch_acorr_reference(r, stream);
     if (err != hipSuccess) return err;

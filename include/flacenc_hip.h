@@ -91,6 +91,15 @@ extern "C" {
  * chosen candidate and the frame bytes of the reference's default configuration -- are the stable
  * build's, 24-bit material included (tests/test_gpu_reference_order.py). */
 #define FLACENC_HIP_FLAG_REFERENCE_SUM_ORDER 32u
+/* The same two sums in the order of the reference's `simd-nightly` build -- the build its published numbers and
+ * compression ratios come from (report/report.nightly.md).  Autocorrelation (weighted_auto_correlation_simd,
+ * src/lpc.rs:510-531 over weighted_delay_prod_sum_impl :439-500): per lag 8 (lags 0..7) or 16 (lags 8..15)
+ * strided f64 lane chains over the 64-byte-aligned body of the windowed buffer, a scalar chain over head and
+ * foot, an ordered lane sum.  find_sum_abs_f32 (src/arrayutils.rs:459-506): 16 f32 lane chains + head / foot.
+ * Defined up to lpc_order 15 only: from lag 16 on the vectors are 128 / 256 bytes wide and where `as_simd`
+ * splits the buffer depends on the allocator; flacenc_hip_verify_config answers ERR_UNSUPPORTED there, and
+ * BAD_CONFIG if both order flags are set. */
+#define FLACENC_HIP_FLAG_NIGHTLY_SUM_ORDER 64u
 
 /* where the caller's sample / output buffers live */
 #define FLACENC_HIP_MEM_HOST 0

@@ -366,11 +366,10 @@ __device__ __forceinline__ unsigned long long plane_sum_any64(const PlaneSums& p
 // NOSAT (only with EXACT; chosen per subframe, see rice_nosat_ok): no entry of any level can reach the
 // saturation value and every parameter of the window is legal or provably losing, so the clamps and the
 // validity selects are dropped and the entries are kept pre-shifted (W << 5) for the packed minimiser.
-template <bool EXACT, bool NOSAT = false>
+template <bool EXACT, bool NOSAT = false, int NP = 8>
 __device__ __forceinline__ void rice_build_tables(const PlaneSums& ps, const int32_t* e, uint32_t len0,
                                                   uint32_t p_base, uint32_t max_p, int lane, int warm,
-                                                  uint32_t (&Wp)[8]) {
-  constexpr int NP = 8;
+                                                  uint32_t (&Wp)[NP]) {
   constexpr uint32_t kWMax = kMaxPToBits - 4u;
   if (EXACT && NOSAT) {
 #pragma unroll
@@ -422,10 +421,10 @@ __device__ __forceinline__ void rice_build_tables(const PlaneSums& ps, const int
 
 // Levels 0..6 of one group of 8 parameters: merges in place (afterwards Wp holds, on lane 0, the table of
 // all 64 partitions merged) and lowers pk[level] to the group's packed minimum (bits << 5 | p).
-template <bool NOSAT = false>
-__device__ __forceinline__ void rice_group_levels(uint32_t (&Wp)[8], uint32_t (&pk)[7], uint32_t p_base,
+template <bool NOSAT = false, int NP = 8>
+__device__ __forceinline__ void rice_group_levels(uint32_t (&Wp)[NP], uint32_t (&pk)[7], uint32_t p_base,
                                                   bool finest_only) {
-  constexpr int NP = 8;
+  static_assert(NP % 2 == 0, "the packed minimiser takes the entries in pairs");
   constexpr uint32_t kWMax = kMaxPToBits - 4u;
 #define FLACENC_RICE_LEVEL(K, S)                                                              \
   {                                                                                           \
@@ -457,18 +456,21 @@ __device__ __forceinline__ void rice_group_levels(uint32_t (&Wp)[8], uint32_t (&
 #undef FLACENC_RICE_LEVEL
 }
 
+// [p_lo, p_hi] is the parameter window (rice_window below); groups of 4: typical material -- partitions whose
+// means lie within a factor of two of each other -- needs exactly one, and a wider window just takes more turns
+// of the rolled loop (a group of 8 evaluated twice the entries for the common case).
 template <bool EXACT, bool NOSAT = false>
 __device__ __forceinline__ RiceResult rice_search(const PlaneSums& ps, const int32_t* e, uint32_t len0,
-                                                  uint32_t p_lo, uint32_t max_p, bool small_bits, int lane,
-                                                  int warm, bool finest_only) {
-  constexpr int NP = 8;
+                                                  uint32_t p_lo, uint32_t p_hi, uint32_t max_p, bool small_bits,
+                                                  int lane, int warm, bool finest_only) {
+  constexpr int NP = EXACT ? 4 : 8;
   constexpr uint32_t kWMax = kMaxPToBits - 4u;
   (void)kWMax;
   uint32_t pk[7];
 #pragma unroll
   for (int k = 0; k < 7; ++k) pk[k] = 0xFFFFFFFFu;
 #pragma unroll 1
-  for (uint32_t p_base = p_lo; p_base <= max_p; p_base += (uint32_t)NP) {
+  for (uint32_t p_base = p_lo; p_base <= p_hi; p_base += (uint32_t)NP) {
     uint32_t Wp[NP];
     rice_build_tables<EXACT, NOSAT>(ps, e, len0, p_base, max_p, lane, warm, Wp);
     rice_group_levels<NOSAT>(Wp, pk, p_base, finest_only);
@@ -522,7 +524,7 @@ __device__ __attribute__((noinline)) void rice_search_literal(const int32_t* e, 
 #pragma unroll
   for (int k = 0; k < 7; ++k) none.q[k] = 0;
   none.sum_m = none.negs = 0;
-  RiceResult rr = rice_search<false>(none, ev, len0, 0u, max_p, small_bits != 0, lane, warm, finest_only != 0);
+  RiceResult rr = rice_search<false>(none, ev, len0, 0u, max_p, max_p, small_bits != 0, lane, warm, finest_only != 0);
   // the table sums of this path are the reference's wrapping u32 adds (rice.rs:88-93): code_bits
   // does not determine the true quotient sum any more, saturated or not -- always count it
   rr.saturated = true;
@@ -1100,8 +1102,81 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
         }
       }
     };
+    // Samples and coefficients of at most 16 bits (L, R and M of <= 16-bit material; |c| < 2^14 for any precision
+    // <= 15) with the reference's i32 criterion met: two taps per v_dot2_i32_i16 on packed sample pairs
+    // P[u] = (lo: s[u], hi: s[u - 1]) -- pred = sum_m dot2((c_2m, c_2m+1), P[t - 1 - 2m]); every partial sum fits
+    // i32 because max|s| * sum|c| does (lpc.rs:373-377).  One pack per sample replaces half the multiply-adds.
+    auto residual_dot2 = [&](auto kind) {
+      auto ld4 = [&](int t) { return ld4k(kind, t); };
+      typedef short s16x2 __attribute__((ext_vector_type(2)));
+      auto pack = [](int lo, int hi) -> int {  // (hi & 0xFFFF) << 16 | (lo & 0xFFFF): one v_perm_b32
+        return (int)__builtin_amdgcn_perm((uint32_t)hi, (uint32_t)lo, 0x05040100u);
+      };
+      auto dot2 = [](int c, int p, int acc) -> int {
+        return __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, c), __builtin_bit_cast(s16x2, p), acc, false);
+      };
+      // first pair of a chain: the three-operand form with the literal 0 (left to the compiler, every chain
+      // starts with a v_mov 0 in front of the accumulate-in-place v_dot2c form)
+      auto dot2_first = [](int c, int p) -> int {
+        int r;
+        asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(r) : "s"(c), "v"(p));
+        return r;
+      };
+      int cp[MAXP / 2];
+#pragma unroll
+      for (int m = 0; m < MAXP / 2; ++m) cp[m] = uni((cq[2 * m] & 0xFFFF) | (cq[2 * m + 1] << 16));
+      int P[HP + 16];  // P[j] pairs window positions j and j - 1 (position HP = the chunk's first sample)
+      int prev;
+      {
+        int hw[HP];
+#pragma unroll
+        for (int k = 0; k < HP; k += 4) {
+          const int4 v = ld4(tl - HP + k);
+          hw[k + 0] = v.x;
+          hw[k + 1] = v.y;
+          hw[k + 2] = v.z;
+          hw[k + 3] = v.w;
+        }
+#pragma unroll
+        for (int j = 1; j < HP; ++j) P[j] = pack(hw[j], hw[j - 1]);
+        prev = hw[HP - 1];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int t0 = tl + 16 * i;
+        asm volatile("" ::: "memory");
+        if (i > 0) {
+#pragma unroll
+          for (int j = 1; j < HP; ++j) P[j] = P[j + 16];
+        }
+        int cw[16];
+#pragma unroll
+        for (int k = 0; k < 16; k += 4) {
+          const int4 v = ld4(t0 + k);
+          cw[k + 0] = v.x;
+          cw[k + 1] = v.y;
+          cw[k + 2] = v.z;
+          cw[k + 3] = v.w;
+        }
+        P[HP] = pack(cw[0], prev);
+#pragma unroll
+        for (int k = 1; k < 16; ++k) P[HP + k] = pack(cw[k], cw[k - 1]);
+        prev = cw[15];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          int32_t pred = dot2_first(cp[0], P[HP + k - 1]);
+#pragma unroll
+          for (int m = 1; m < MAXP / 2; ++m) pred = dot2(cp[m], P[HP + k - 1 - 2 * m], pred);
+          e[16 * i + k] = cw[k] - (pred >> shift);
+        }
+      }
+    };
+    const bool dot_ok = !wide && role_min >= -32768 && role_max <= 32767;
     with_role([&](auto kind) {
-      if (!wide) residual_pass(std::false_type{}, kind);
+      constexpr int KIND = decltype(kind)::value;
+      // (no v_mad_i32_i24 variant any more: it issued as many instructions as the 64-bit one -- both cost one
+      // multiply-add per tap -- and was a third copy of the pass per role in the instruction cache)
+      if (KIND != 3 && dot_ok) residual_dot2(kind);
       else residual_pass(std::true_type{}, kind);
     });
     // e[0 .. order') = 0 (lpc.rs:349): only lane 0, only its first 16 slots (order' <= 12)
@@ -1222,6 +1297,16 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
     const uint32_t p0min = wave_min_dpp(31u - (uint32_t)__builtin_clz(q0));
     uint32_t p_lo = p0min > 2u ? p0min - 2u : 0u;
     p_lo = p_lo < max_p ? p_lo : max_p;
+    // Upper end: table[p + 1] - table[p] = len - sum_i ceil((u_i >> p) / 2) >= len - S / 2^p, which is positive
+    // as soon as 2^p > m; 2^(p0 + 1) > m + 1, so from p0 + 1 on the entries grow strictly and no p > p0 + 1 can
+    // win or tie (clamped entries can only tie among themselves, and ties go to the smaller p).  A merged
+    // group's mean is at most the largest 64-sample partition mean: the wave-maximum of p0 bounds every order.
+    // (q bounds the partition's mean from above: floor(S / 64) + 1 > S / 64, and lane 0, whose partition has
+    // only 64 - warm >= 52 coded samples, adds S / 256 + 1: S / 64 + S / 256 >= S / 52)
+    const uint32_t q0hi = q0 + (lane == 0 ? (s0 >> 8) + 1u : 0u);
+    const uint32_t p0max = wave_max_dpp(31u - (uint32_t)__builtin_clz(q0hi));
+    uint32_t p_hi = p0max + 1u;
+    p_hi = p_hi < max_p ? p_hi : max_p;
     // NOSAT: (1) the configured limit does not cut the search (max_p == bitlen), so a parameter above
     // max_p inside the last group of 8 is legal-but-losing -- for p > bitlen every table entry is
     // len (p + 1), strictly above the entry at p = bitlen -- and needs no masking; (2) bitlen <= 24 keeps
@@ -1235,13 +1320,13 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
       const uint32_t tot_hi = wave_sum_dpp(s0 >> 6);  // sum over lanes of floor(s0 / 64): < 2^32
       nosat = small_bits && bitlen <= 24u && tot_hi < ((kMaxPToBits - 4u - 131072u) >> 6) - 64u;
     }
-    if (!FIXED && nosat) rr = rice_search<true, true>(ps, nullptr, len0, p_lo, max_p, small_bits, lane, warm, finest_only);
-    else rr = rice_search<true>(ps, nullptr, len0, p_lo, max_p, small_bits, lane, warm, finest_only);
+    if (!FIXED && nosat) rr = rice_search<true, true>(ps, nullptr, len0, p_lo, p_hi, max_p, small_bits, lane, warm, finest_only);
+    else rr = rice_search<true>(ps, nullptr, len0, p_lo, p_hi, max_p, small_bits, lane, warm, finest_only);
     // The window argument compares unclamped table values.  If any group minimum saturated at
     // MAX_P_TO_BITS, clamped entries outside the window could tie with it (ties go to the
     // smallest p, rice.rs:123-124), so search the whole range then.
     if (rr.sat_levels != 0 && p_lo != 0)
-      rr = rice_search<true>(ps, nullptr, len0, 0u, max_p, small_bits, lane, warm, finest_only);
+      rr = rice_search<true>(ps, nullptr, len0, 0u, max_p, max_p, small_bits, lane, warm, finest_only);
     if (rr.saturated) {
       // sum_i (u_i >> p) of this lane's partition under its group's parameter, from the planes
       const uint32_t gp = (uint32_t)__shfl((int)rr.my_p, lane & ~((1 << rr.bestk) - 1), 64);
@@ -1631,15 +1716,22 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
       // (the thread index is laundered so that these addresses are recomputed here instead of being
       // kept alive -- and, under a tight register budget, spilled to scratch and reloaded at HBM
       // latency -- from the identical expressions of the load phase)
-      int tid_out = tid;
+      // Written out per (channel, quarter) with everything but one 32-bit lane offset uniform: the stores then
+      // address as scalar base + VGPR offset and the LDS reads as one base + immediates (left as a loop over
+      // q = tid + 256 it with ch = q >> 10, each store cost 19 VALU instructions of 64-bit address arithmetic).
+      uint32_t tid_out = (uint32_t)tid;
       asm volatile("" : "+v"(tid_out));
+      const uint32_t lds0 = ((tid_out >> 4) + 1u) * (uint32_t)kSeg + ((tid_out & 15u) << 2);  // widx(4 tid)
+      const uint32_t goff = tid_out << 2;                                                      // dwords
 #pragma unroll
-      for (int it = 0; it < 8; ++it) {
-        const int q = tid_out + it * 256;
-        const int ch = q >> 10;
-        const int t = (q & 1023) << 2;
-        const int4 v = *reinterpret_cast<const int4*>(&sm[ch * kBufDwords + widx(t)]);
-        *reinterpret_cast<int4*>(dst0 + (size_t)ch * a.residual_stride + t) = v;
+      for (int ch = 0; ch < 2; ++ch) {
+        const int32_t* const simg = sm + ch * kBufDwords;
+        int32_t* __restrict__ const drow = dst0 + (size_t)ch * a.residual_stride;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int4 v = *reinterpret_cast<const int4*>(&simg[lds0 + (uint32_t)(it * 16 * kSeg)]);
+          *reinterpret_cast<int4*>(drow + it * 1024 + goff) = v;
+        }
       }
     }
     }  // !PACK

@@ -362,31 +362,19 @@ def sigen_frames(n_frames: int, channels: int, block_size: int, bits_per_sample:
 
 
 def pinned_array(nbytes: int) -> np.ndarray:
-    """uint8 array in page-locked host memory (flacenc_hip_host_alloc); keeps the allocation alive and frees it
-    with the array."""
+    """uint8 array in page-locked host memory (flacenc_hip_host_alloc).  The allocation lives exactly as long
+    as the array and its views: the ctypes buffer the array is built on is their common base object, and a
+    finalizer on that buffer hands the memory back (flacenc_hip_host_free)."""
+    import weakref
     lib = load()
     p = lib.flacenc_hip_host_alloc(nbytes)
     if not p:
         raise MemoryError("flacenc_hip_host_alloc")
-
-    class _Owner:
-        def __init__(self, ptr):
-            self.ptr = ptr
-
-        def __del__(self):
-            try:
-                lib.flacenc_hip_host_free(self.ptr)
-            except Exception:
-                pass
-
     buf = (C.c_uint8 * nbytes).from_address(p)
+    weakref.finalize(buf, lib.flacenc_hip_host_free, p)
     arr = np.frombuffer(buf, dtype=np.uint8)
     arr.flags.writeable = True
-    _PINNED_OWNERS[arr.ctypes.data] = _Owner(p)
     return arr
-
-
-_PINNED_OWNERS: dict = {}
 
 
 class Handle:

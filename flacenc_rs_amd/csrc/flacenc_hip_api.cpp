@@ -44,7 +44,18 @@ struct DeviceBuffer {
 class CopyPool {
  public:
   explicit CopyPool(unsigned workers) : tasks_(workers) {
-    for (unsigned i = 0; i < workers; ++i) threads_.emplace_back([this, i] { run(i); });
+    try {
+      threads_.reserve(workers);
+      for (unsigned i = 0; i < workers; ++i) threads_.emplace_back([this, i] { run(i); });
+    } catch (...) {  // a thread that did start must be joined before its std::thread is destroyed
+      {
+        std::lock_guard<std::mutex> g(m_);
+        stop_ = true;
+      }
+      cv_.notify_all();
+      for (std::thread& t : threads_) t.join();
+      throw;
+    }
   }
   ~CopyPool() {
     {
@@ -249,15 +260,18 @@ int get_window(flacenc_hip_handle* h, const flacenc_hip_qlpc_config* cfg, uint32
 
 int check_batch_args(flacenc_hip_handle* h, const flacenc_hip_qlpc_config* cfg, const int32_t* samples,
                      size_t n_subframes, uint32_t block_size, size_t stride,
-                     flacenc_hip_subframe_params* params, int32_t* residual, size_t residual_stride) {
+                     flacenc_hip_subframe_params* params, int32_t* residual, size_t residual_stride,
+                     uint32_t min_block = FLACENC_HIP_MIN_BLOCK_SIZE) {
   if (!h || !cfg) return FLACENC_HIP_ERR_BAD_ARGUMENT;
   int rc = flacenc_hip_verify_config(cfg);
   if (rc != FLACENC_HIP_OK) {
     h->last_error = "config::Qlpc / config::Prc verification failed";
     return rc;
   }
-  if (block_size < FLACENC_HIP_MIN_BLOCK_SIZE || block_size > FLACENC_HIP_MAX_BLOCK_SIZE) {
-    h->last_error = "block_size must be in 64..=32767";
+  // (the frame-level calls pass min_block = 1: a stream's last block may be shorter than
+  // MIN_BLOCK_SIZE_FOR_PREDICTION; encode_subframe then skips both predictors, coding.rs:396)
+  if (block_size < min_block || block_size > FLACENC_HIP_MAX_BLOCK_SIZE) {
+    h->last_error = "block_size must be in 64..=32767 (1..=32767 for the frame-level calls)";
     return FLACENC_HIP_ERR_BAD_ARGUMENT;
   }
   if (n_subframes == 0) return FLACENC_HIP_OK;
@@ -768,7 +782,7 @@ static int enqueue_pack(flacenc_hip_handle* h, const int32_t* frames, size_t n_f
                                     : flacenc_hip_stereo_frame_bytes_bound(block_size, bits_per_sample);
   if (chan_results && (channels < 1 || channels > 8)) return FLACENC_HIP_ERR_BAD_ARGUMENT;
   if (!frames || (!results && !chan_results) || !residual || !out || !out_len || stride < block_size || residual_stride < block_size ||
-      block_size < FLACENC_HIP_MIN_BLOCK_SIZE || block_size > FLACENC_HIP_MAX_BLOCK_SIZE ||
+      block_size < 1 || block_size > FLACENC_HIP_MAX_BLOCK_SIZE ||
       bits_per_sample < 8 || bits_per_sample > 24 || n_frames > 0x7FFFFFFFull ||
       (reinterpret_cast<uintptr_t>(out) & 15) || (out_stride & 15) ||
       out_stride < bound) {
@@ -931,13 +945,20 @@ int flacenc_hip_encode_frames_async(flacenc_hip_handle* h, const flacenc_hip_fra
   if (!h || !cfg || (!results && n_frames) || channels < 1 || channels > 8) return FLACENC_HIP_ERR_BAD_ARGUMENT;
   const size_t n_sub = n_frames * channels;
   int rc = check_batch_args(h, &cfg->qlpc, frames, n_sub, block_size, stride,
-                            reinterpret_cast<flacenc_hip_subframe_params*>(results), residual, residual_stride);
+                            reinterpret_cast<flacenc_hip_subframe_params*>(results), residual, residual_stride, 1);
   if (rc != FLACENC_HIP_OK || n_frames == 0) return rc;
   if (bits_per_sample < 8 || bits_per_sample > 24) {
     h->last_error = "bits_per_sample must be in 8..=24";
     return FLACENC_HIP_ERR_BAD_ARGUMENT;
   }
   if (cfg->use_fixed && (rc = verify_fixed(h, cfg)) != FLACENC_HIP_OK) return rc;
+  // too_short (coding.rs:396): neither fixed_lpc nor estimated_qlpc is tried; Constant or Verbatim
+  flacenc_hip_frame_config short_cfg;
+  if (block_size < FLACENC_HIP_MIN_BLOCK_SIZE) {
+    short_cfg = *cfg;
+    short_cfg.use_fixed = short_cfg.use_lpc = 0;
+    cfg = &short_cfg;
+  }
   HIP_TRY(h, hipSetDevice(h->device));
   hipStream_t s = static_cast<hipStream_t>(stream);
   {
@@ -951,8 +972,13 @@ int flacenc_hip_encode_frames_async(flacenc_hip_handle* h, const flacenc_hip_fra
       for (uint32_t lanes = pow2 ? 64u / p : 1u; lanes > 1; lanes >>= 1) ++glog;
     }
     const WindowEntry* win = nullptr;
-    rc = get_window(h, &cfg->qlpc, block_size, &win);
-    if (rc != FLACENC_HIP_OK) return rc;
+    static const WindowEntry no_window{};
+    if (block_size >= FLACENC_HIP_MIN_BLOCK_SIZE) {
+      rc = get_window(h, &cfg->qlpc, block_size, &win);
+      if (rc != FLACENC_HIP_OK) return rc;
+    } else {
+      win = &no_window;  // (never read: short blocks take the candidate-free general path below)
+    }
     flacenc_hip::QlpcKernelArgs a;
     a.samples = frames;
     a.stride = stride;
@@ -1067,7 +1093,7 @@ int flacenc_hip_encode_frames(flacenc_hip_handle* h, const flacenc_hip_frame_con
   if (memory_kind != FLACENC_HIP_MEM_HOST || !cfg || channels < 1 || channels > 8) return FLACENC_HIP_ERR_BAD_ARGUMENT;
   const size_t n_sub = n_frames * channels;
   int rc = check_batch_args(h, &cfg->qlpc, frames, n_sub, block_size, stride,
-                            reinterpret_cast<flacenc_hip_subframe_params*>(results), residual, residual_stride);
+                            reinterpret_cast<flacenc_hip_subframe_params*>(results), residual, residual_stride, 1);
   if (rc != FLACENC_HIP_OK || n_frames == 0) return rc;
   HIP_TRY(h, hipSetDevice(h->device));
   const size_t dstride = (static_cast<size_t>(block_size) + 3) & ~static_cast<size_t>(3);
@@ -1324,11 +1350,8 @@ int flacenc_hip_encode_pcm(flacenc_hip_handle* h, const flacenc_hip_frame_config
   const bool stereo = channels == 2;
   const uint64_t n_full = total_samples / block_size;
   const uint32_t tail = static_cast<uint32_t>(total_samples % block_size);
-  if (tail != 0 && tail < FLACENC_HIP_MIN_BLOCK_SIZE) {
-    h->last_error = "encode_pcm: a last block shorter than 64 samples never reaches the analysis "
-                    "(src/coding.rs:396); write it as a Verbatim frame on the host";
-    return FLACENC_HIP_ERR_UNSUPPORTED;
-  }
+  // (a last block shorter than MIN_BLOCK_SIZE_FOR_PREDICTION is a frame like any other: encode_subframe skips
+  // its predictors, coding.rs:396, and the frame-level calls below do the same)
   HIP_TRY(h, hipSetDevice(h->device));
   if (!h->s_in) {
     HIP_TRY(h, hipStreamCreateWithFlags(&h->s_in, hipStreamNonBlocking));
@@ -1345,6 +1368,9 @@ int flacenc_hip_encode_pcm(flacenc_hip_handle* h, const flacenc_hip_frame_config
   const size_t frame_in_bytes = static_cast<size_t>(block_size) * channels * bytes_per_sample;
   size_t chunk = (48u << 20) / frame_in_bytes;
   chunk = chunk < 768 ? 768 : (chunk > 8192 ? 8192 : chunk);
+  // never more than the call has: staging, device buffers and the candidates' scratch are all sized from it
+  // (a one-frame call of 8 channels x 32767 samples would otherwise pin gigabytes)
+  if (chunk > n_full) chunk = n_full ? static_cast<size_t>(n_full) : 1;
   const size_t bound = stereo ? flacenc_hip_stereo_frame_bytes_bound(block_size, bits_per_sample)
                               : flacenc_hip_frame_bytes_bound(channels, block_size, bits_per_sample);
   const size_t ostride = (bound + 15) & ~static_cast<size_t>(15);
@@ -1379,10 +1405,19 @@ int flacenc_hip_encode_pcm(flacenc_hip_handle* h, const flacenc_hip_frame_config
   // staging copies for pageable caller memory run on the caller's thread + the handle's helper threads
   if ((!in_pinned || !out_pinned) && !h->copy_pool) {
     const int want = h->host_threads < 0 ? 4 : h->host_threads;  // total, the caller's thread included
-    h->copy_pool.reset(new (std::nothrow) CopyPool(want > 1 ? static_cast<unsigned>(want - 1) : 0u));
+    // (thread creation can throw std::system_error, vector growth std::bad_alloc: nothing unwinds across the ABI)
+    try {
+      h->copy_pool.reset(new CopyPool(want > 1 ? static_cast<unsigned>(want - 1) : 0u));
+    } catch (...) {
+      h->copy_pool.reset();
+    }
     if (!h->copy_pool) {
-      h->last_error = "encode_pcm: out of host memory";
-      return FLACENC_HIP_ERR_DEVICE;
+      try {
+        h->copy_pool.reset(new CopyPool(0u));  // no helper threads: plain memcpy on the caller's thread
+      } catch (...) {
+        h->last_error = "encode_pcm: out of host memory";
+        return FLACENC_HIP_ERR_DEVICE;
+      }
     }
   }
   uint64_t written = 0;
@@ -1652,11 +1687,18 @@ static int encode_stereo_frames_impl(flacenc_hip_handle* h, const flacenc_hip_fr
   if (packed) *packed = false;
   if (!h || !cfg || (!results && n_frames)) return FLACENC_HIP_ERR_BAD_ARGUMENT;
   int rc = check_batch_args(h, &cfg->qlpc, frames, n_frames * 4, block_size, stride,
-                            reinterpret_cast<flacenc_hip_subframe_params*>(results), residual, residual_stride);
+                            reinterpret_cast<flacenc_hip_subframe_params*>(results), residual, residual_stride, 1);
   if (rc != FLACENC_HIP_OK || n_frames == 0) return rc;
   if (bits_per_sample < 8 || bits_per_sample > 24) {
     h->last_error = "bits_per_sample must be in 8..=24";
     return FLACENC_HIP_ERR_BAD_ARGUMENT;
+  }
+  // too_short (coding.rs:396): neither fixed_lpc nor estimated_qlpc is tried; Constant or Verbatim
+  flacenc_hip_frame_config short_cfg;
+  if (block_size < FLACENC_HIP_MIN_BLOCK_SIZE) {
+    short_cfg = *cfg;
+    short_cfg.use_fixed = short_cfg.use_lpc = 0;
+    cfg = &short_cfg;
   }
   uint32_t fixed_group_log2 = 0;
   bool fixed_composite = false;
@@ -1675,8 +1717,13 @@ static int encode_stereo_frames_impl(flacenc_hip_handle* h, const flacenc_hip_fr
   }
   HIP_TRY(h, hipSetDevice(h->device));
   const WindowEntry* win = nullptr;
-  rc = get_window(h, &cfg->qlpc, block_size, &win);
-  if (rc != FLACENC_HIP_OK) return rc;
+  static const WindowEntry no_window{};
+  if (block_size >= FLACENC_HIP_MIN_BLOCK_SIZE) {
+    rc = get_window(h, &cfg->qlpc, block_size, &win);
+    if (rc != FLACENC_HIP_OK) return rc;
+  } else {
+    win = &no_window;  // (never read: short blocks take the candidate-free general path below)
+  }
   flacenc_hip::QlpcKernelArgs a;
   a.samples = frames;
   a.stride = stride;

@@ -169,7 +169,9 @@ int flacenc_hip_window_weights(const flacenc_hip_qlpc_config* cfg, uint32_t bloc
  * Batched `estimated_qlpc` (src/coding.rs:360-381): for k in 0..n_subframes the
  * subframe is the `block_size` samples at `samples + k*stride` (the layout of
  * FrameBuf::channel_slice, src/source.rs:251-253, batched).  Requires
- * 64 <= block_size <= 32767 (blocks < 64 never reach the path, coding.rs:396).
+ * 64 <= block_size <= 32767 (blocks < 64 never reach the path, coding.rs:396; the frame-level calls
+ * flacenc_hip_encode_[stereo_]frames / pack_* take them -- 1 <= block_size -- and run encode_subframe's
+ * `too_short` branch: Constant or Verbatim only).
  *   bps[k]        bits per sample of subframe k (8..=25; side channels carry +1,
  *                 src/coding.rs:444); only enters subframe_bits.
  *   params[k]     output record (see above)
@@ -483,8 +485,9 @@ int flacenc_hip_fill_le_bytes_async(flacenc_hip_handle* h, const uint8_t* bytes,
  * (flacenc_hip_place_frames) and exactly their bytes come back on a second copy stream -- two slots, so the
  * upload of chunk k + 1, the analysis of chunk k and the download of chunk k - 1 overlap.
  *   pcm            total_samples inter-channel samples, bytes_per_sample each, L R L R ...
- *   block_size     every frame has block_size samples except the last (total_samples % block_size, which
- *                  must be 0 or >= 64: shorter blocks never reach the analysis, src/coding.rs:396)
+ *   block_size     every frame has block_size samples except the last (total_samples % block_size; a last
+ *                  block of fewer than 64 samples is coded as the reference codes it: encode_subframe skips
+ *                  both predictors, `too_short` src/coding.rs:389-418, and emits Constant or Verbatim)
  *   out/out_len    frames back to back in frame order (what the stream writer appends after the
  *                  metadata blocks) and each frame's byte length; out_total = bytes written
  * `pcm` / `out` may be ordinary (pageable) memory -- then they are staged through the handle's pinned

@@ -1381,6 +1381,51 @@ def test_encode_stereo_frames_rejects_bad_config(handle):
     with pytest.raises(_capi.FlacencHipError) as ei:
         handle.encode_stereo_frames(x, 16, _capi.make_frame_config(gpu_cfg(8), use_fixed=True, fixed_partitions=65))
     assert ei.value.code == _capi.ERR_BAD_CONFIG
+    # (blocks below 64 samples are taken by the frame-level calls since round 3 -- test_blocks_shorter_than_the_
+    # prediction_minimum; the candidate-level batch still refuses them, as does any call above 32767)
     with pytest.raises(_capi.FlacencHipError) as ei:
-        handle.encode_stereo_frames(np.zeros((2, 2, 32), np.int32), 16, _capi.make_frame_config(gpu_cfg(8)))
+        handle.stereo_qlpc_batch(np.zeros((2, 2, 32), np.int32), 16, gpu_cfg(8))
     assert ei.value.code == _capi.ERR_BAD_ARGUMENT
+    with pytest.raises(_capi.FlacencHipError) as ei:
+        handle.encode_stereo_frames(np.zeros((1, 2, 32768), np.int32), 16, _capi.make_frame_config(gpu_cfg(8)))
+    assert ei.value.code == _capi.ERR_BAD_ARGUMENT
+
+
+@pytest.mark.parametrize("n", [1, 2, 15, 16, 33, 63])
+@pytest.mark.parametrize("channels", [1, 2, 5])
+def test_blocks_shorter_than_the_prediction_minimum(handle, n, channels):
+    """Blocks of 1..63 samples (a stream's last block): too_short in encode_subframe (src/coding.rs:389-418) -- no
+    fixed_lpc, no estimated_qlpc, Constant or Verbatim -- through the frame-level calls; decisions and frame bytes
+    == the oracle's controller and writer, and the bytes parse back to the input."""
+    import flac_parse
+    bps = 16
+    x = _capi.sigen_frames(4, channels, n, bps, 40.0, 0.5, 0.1, seed=100 * n + channels)
+    x[1, 0] = -3                      # Constant
+    if channels >= 2:
+        x[2, 1] = x[2, 0]             # side channel constant 0
+    cfg = _capi.make_frame_config(gpu_cfg(8), use_fixed=True)
+    ocfg = orc.make_frame_config(orc_cfg(8, acorr=orc.ACORR_CANONICAL), use_fixed=True,
+                                 fixed=orc.make_fixed_config(sum_mode=orc.SUMABS_CANONICAL))
+    if channels == 2:
+        res, resid = handle.encode_stereo_frames(x, bps, cfg)
+        want, wres = orc.encode_stereo_frames_cfg(x, bps, ocfg)
+        assert res["channel_assignment"].tolist() == want["channel_assignment"].tolist()
+        assert res["kind"].tolist() == want["kind"].tolist() and res["bits"].tolist() == want["bits"].tolist()
+        assert set(res["kind"].ravel().tolist()) <= {0, 1} and not resid.any()
+        packed = handle.pack_stereo_frames(x, res, resid, bps, 44100, 9, 1)
+        for f in range(x.shape[0]):
+            assert packed[f] == orc.write_stereo_frame(res[f], x[f, 0], x[f, 1], bps, 44100, 9 + f,
+                                                       resid[f, 0], resid[f, 1]), f
+    else:
+        res, resid = handle.encode_frames(x, bps, cfg)
+        packed = handle.pack_frames(x, res, resid, bps, 44100, 9, 1)
+        for f in range(x.shape[0]):
+            subs = []
+            for c in range(channels):
+                w = orc.encode_subframe(x[f, c], bps, ocfg)
+                assert int(res[f, c]["kind"]) == w["kind"] and int(res[f, c]["bits"]) == w["bits"] and w["kind"] <= 1
+                subs.append(dict(kind=w["kind"], bps=bps, samples=x[f, c], dc_offset=int(res[f, c]["dc_offset"])))
+            assert packed[f] == orc.write_frame(n, 0, bps, 44100, 9 + f, subs), f
+    for f in range(x.shape[0]):
+        got = flac_parse.parse_frame(packed[f], stream_bps=bps, stream_rate=44100)
+        assert got["block_size"] == n and got["number"] == 9 + f and np.array_equal(got["channels"], x[f]), f

@@ -66,10 +66,25 @@ def test_short_last_block_and_round_robin_numbers(handle):
     assert out.tobytes() == b"".join(want)
     last = flac_parse.parse_frame(want[-1], stream_bps=bps, stream_rate=48000)
     assert last["number"] == 35 and last["block_size"] == 1000 and np.array_equal(last["channels"], tail)
-    # a tail shorter than 64 samples is the caller's (Verbatim on the host, coding.rs:396)
-    with pytest.raises(_capi.FlacencHipError) as ei:
-        handle.encode_pcm_stereo(pcm[: (4096 * 4 + 10) * 4], cfg, 2, bps, n, 48000)
-    assert ei.value.code == _capi.ERR_UNSUPPORTED
+
+
+@pytest.mark.parametrize("tail_len", [1, 10, 63])
+def test_last_block_shorter_than_64_samples(handle, tail_len):
+    """A last block below MIN_BLOCK_SIZE_FOR_PREDICTION is a frame like any other: encode_subframe skips its
+    predictors (too_short, src/coding.rs:389-418) and emits Constant or Verbatim, the stereo decision still runs."""
+    n, bps = 4096, 16
+    frames = _capi.sigen_frames(3, 2, n, bps, 36.0, 0.4, 0.04, seed=78, nthreads=2)
+    tail = np.ascontiguousarray(frames[2][:, :tail_len])
+    if tail_len == 10:
+        tail[1] = 7  # a Constant subframe
+    cfg = _capi.make_frame_config(_capi.make_config(lpc_order=10), use_fixed=True)
+    pcm = np.concatenate([pack_pcm(frames[:2], 2), pack_pcm(tail[None], 2)])
+    out, lens = handle.encode_pcm_stereo(pcm, cfg, 2, bps, n, 44100)
+    assert lens.size == 3
+    want = reference_bytes(handle, frames[:2], bps, cfg, 44100) + reference_bytes(handle, tail[None], bps, cfg, 44100, 2, 1)
+    assert out.tobytes() == b"".join(want)
+    last = flac_parse.parse_frame(want[-1], stream_bps=bps, stream_rate=44100)
+    assert last["number"] == 2 and last["block_size"] == tail_len and np.array_equal(last["channels"], tail)
 
 
 def test_pinned_buffers_give_identical_bytes(handle):

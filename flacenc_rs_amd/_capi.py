@@ -91,6 +91,8 @@ class QlpcConfig(C.Structure):
         ("tukey_alpha", C.c_float),
         ("max_rice_parameter", C.c_uint32),
         ("flags", C.c_uint32),
+        ("use_direct_mse", C.c_uint32),
+        ("mae_optimization_steps", C.c_uint32),
     ]
 
 
@@ -318,7 +320,7 @@ FLAG_NIGHTLY_SUM_ORDER = 64
 
 
 def make_config(lpc_order=10, quant_precision=15, window=("tukey", 0.4), max_rice_parameter=30,
-                flags=0, rice_finest_only=False) -> QlpcConfig:
+                flags=0, rice_finest_only=False, use_direct_mse=False, mae_optimization_steps=0) -> QlpcConfig:
     """Defaults of config::Qlpc / config::Prc (src/constant.rs:109-115, src/config.rs:216-221)."""
     if window == "rectangle" or window[0] == "rectangle":
         wt, alpha = WINDOW_RECTANGLE, 0.0
@@ -328,7 +330,8 @@ def make_config(lpc_order=10, quant_precision=15, window=("tukey", 0.4), max_ric
         flags |= FLAG_ALLOW_ORDER_32
     if rice_finest_only:  # build extension: BASELINE config 2's "fixed Rice partition order"
         flags |= FLAG_FINEST_RICE_ORDER
-    return QlpcConfig(lpc_order, quant_precision, wt, alpha, max_rice_parameter, flags)
+    return QlpcConfig(lpc_order, quant_precision, wt, alpha, max_rice_parameter, flags, 1 if use_direct_mse else 0,
+                      int(mae_optimization_steps))
 
 
 def verify_config(cfg: QlpcConfig) -> int:

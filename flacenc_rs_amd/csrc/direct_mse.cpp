@@ -1,0 +1,444 @@
+// direct_mse.cpp -- the reference's EXPERIMENTAL estimators of perform_qlpc (src/coding.rs:333-351):
+//
+//   LpcEstimator::weighted_lpc_with_direct_mse  src/lpc.rs:853-903  covariance-method LPC
+//     weighted_auto_correlation_nosimd          src/lpc.rs:533-548  right-hand side R[1..=P]
+//     weighted_lagged_outer_prod_sum            src/lpc.rs:573-600  P x P Gram matrix of lagged vectors
+//     LpcFloat::solve_sym_mut                   src/lpc.rs:79-87    Cholesky (nalgebra) + regulariser doubling
+//   LpcEstimator::lpc_with_irls_mae             src/lpc.rs:814-850  IRLS towards the mean absolute error
+//     compute_raw_errors                        src/lpc.rs:602-618
+//
+// One workgroup per subframe.  The windowed block is staged in LDS as f32; every entry the solve needs is one
+// SEQUENTIAL fma chain over time in the reference -- R[tau] over t = P..n-1, G[i][j] (i <= j) over t = P-1..n-2
+// of the block without its last sample -- and with y_a(t') = x_w[t' + 1 - a] both are entries of one
+// (P+1) x (P+1) matrix H[a][b] = sum_{t' = P-1}^{n-2} fma(y_a, f32(w[t' + 1] * y_b), .): R[tau] = H[tau][0],
+// G[i][j] = H[i + 1][j + 1].  A chain cannot be split without changing its roundings, so a THREAD owns a chain:
+// P + 1 + P (P + 1) / 2 of them (66 at order 10, 325 at 24, 561 at 32), all walking the same LDS array.
+// The factorisation then runs on wave 0 with a lane per matrix row (the column updates of nalgebra's
+// left-looking Cholesky are independent across rows, so lanes change nothing in any element's operation
+// sequence), the triangular solves follow nalgebra's loops, including dotx's eight partial accumulators.
+// Quantisation (lpc.rs:234-302) is done here as well: the kernel's output is the predictor record the
+// residual kernels of the split pipeline take (`pred`), as levinson_batch_kernel's is.
+//
+// f32::powf in the IRLS weight (lpc.rs:828) is libm's powf: glibc's algorithm (sysdeps/ieee754/flt-32/e_powf.c:
+// log2 by a 16-entry table + degree-5 polynomial and exp2 by a 32-entry table + cubic, both in double, one
+// rounding to float) restated; checked against the host libm for y = -1.2 over every float in [0.0099, 1e6]
+// (223 M arguments, no mismatch, with and without fma contraction).
+//
+// PARITY: bit-equal to the oracle's restatement of the same algorithms (tests/test_gpu_direct_mse.py).  The
+// solver is a third-party crate outside the reference tree, the reference's tests of this path are qualitative:
+// beyond those tests (restated in tests/test_oracle_kat.py) this row is "parity unpinned".
+#include "direct_mse.h"
+
+#include "flacenc_hip.h"
+#include "lds_opt_in.h"
+
+namespace flacenc_hip {
+namespace {
+
+// exact ceil(log2(m)) for finite m > 0 from the exponent/mantissa fields (as in qlpc_kernel_impl.h)
+__device__ __forceinline__ int dm_ceil_log2_pos(double m) {
+  const uint64_t b = (uint64_t)__double_as_longlong(m);
+  const int e = (int)((b >> 52) & 0x7FF);
+  const uint64_t frac = b & 0xFFFFFFFFFFFFFull;
+  if (e == 0) return -32752;
+  return (e - 1023) + (frac != 0 ? 1 : 0);
+}
+
+__device__ const double kPowLog2Tab[32] = {
+    0x1.661ec79f8f3bep+0, -0x1.efec65b963019p-2, 0x1.571ed4aaf883dp+0, -0x1.b0b6832d4fca4p-2,
+    0x1.49539f0f010bp+0,  -0x1.7418b0a1fb77bp-2, 0x1.3c995b0b80385p+0, -0x1.39de91a6dcf7bp-2,
+    0x1.30d190c8864a5p+0, -0x1.01d9bf3f2b631p-2, 0x1.25e227b0b8eap+0,  -0x1.97c1d1b3b7afp-3,
+    0x1.1bb4a4a1a343fp+0, -0x1.2f9e393af3c9fp-3, 0x1.12358f08ae5bap+0, -0x1.960cbbf788d5cp-4,
+    0x1.0953f419900a7p+0, -0x1.a6f9db6475fcep-5, 0x1p+0,               0x0p+0,
+    0x1.e608cfd9a47acp-1, 0x1.338ca9f24f53dp-4,  0x1.ca4b31f026aap-1,  0x1.476a9543891bap-3,
+    0x1.b2036576afce6p-1, 0x1.e840b4ac4e4d2p-3,  0x1.9c2d163a1aa2dp-1, 0x1.40645f0c6651cp-2,
+    0x1.886e6037841edp-1, 0x1.88e9c2c1b9ff8p-2,  0x1.767dcf5534862p-1, 0x1.ce0a44eb17bccp-2,
+};
+__device__ const unsigned long long kExp2Tab[32] = {
+    0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull,
+    0x3fef72b83c7d517bull, 0x3fef54873168b9aaull, 0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull,
+    0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull, 0x3feedea64c123422ull, 0x3feece086061892dull,
+    0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull, 0x3feea47eb03a5585ull,
+    0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull, 0x3feea11473eb0187ull, 0x3feea589994cce13ull,
+    0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull,
+    0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull,
+    0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full, 0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull,
+};
+
+// powf(x, y) for finite normal x > 0 and moderate y (|y log2 x| < 126); +inf -> 0 for y < 0 (the weight of a
+// block whose samples are all zero: normalizer 0, lpc.rs:827-828)
+__device__ __forceinline__ float dev_powf_pos(float x, float y) {
+  uint32_t ix = __float_as_uint(x);
+  if (ix >= 0x7f800000u) return y < 0.0f ? 0.0f : x;
+  const uint32_t tmp = ix - 0x3f330000u;
+  const int i = (int)((tmp >> 19) & 15u);
+  const uint32_t top = tmp & 0xff800000u;
+  const int k = (int)top >> 23;
+  const double z = (double)__uint_as_float(ix - top);
+  const double r = z * kPowLog2Tab[2 * i] - 1.0;
+  const double y0 = kPowLog2Tab[2 * i + 1] + (double)k;
+  const double r2 = r * r;
+  double yy = 0x1.27616c9496e0bp-2 * r + -0x1.71969a075c67ap-2;
+  const double p = 0x1.ec70a6ca7baddp-2 * r + -0x1.7154748bef6c8p-1;
+  const double r4 = r2 * r2;
+  double q = 0x1.71547652ab82bp0 * r + y0;
+  q = p * r2 + q;
+  yy = yy * r4 + q;
+  const double ylogx = (double)y * yy;
+  const double kShift = 0x1.8p+47;
+  double kd = ylogx + kShift;
+  const unsigned long long ki = (unsigned long long)__double_as_longlong(kd);
+  kd -= kShift;
+  const double rr = ylogx - kd;
+  unsigned long long t = kExp2Tab[ki & 31ull];
+  t += ki << 47;
+  const double s = __longlong_as_double((long long)t);
+  const double zz = 0x1.c6af84b912394p-5 * rr + 0x1.ebfce50fac4f3p-3;
+  const double rr2 = rr * rr;
+  double o = 0x1.62e42ff0c52d6p-1 * rr + 1.0;
+  o = zz * rr2 + o;
+  o = o * s;
+  return (float)o;
+}
+
+constexpr int kErrChunk = 1024;
+
+// LDS: xw[n4] f32 | w[n4] f32 (IRLS only) | echunk[kErrChunk] f32 (IRLS only) | gram[32*32] f64 | m[32*32] f64 |
+//      corr[33] f64 | v[32] f64 | coefs[32] f64 | best[32] f64 | misc
+template <bool STEREO, bool IRLS>
+__global__ void __launch_bounds__(576) direct_mse_kernel(DirectMseArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63;
+  const int n = (int)a.block_size;
+  const int P = (int)a.lpc_order;
+  const uint32_t sf = blockIdx.x;
+  const int n4 = (n + 3) & ~3;
+  float* const xw = reinterpret_cast<float*>(smem_raw);
+  float* const wgt = xw + n4;
+  float* const echunk = wgt + (IRLS ? n4 : 0);
+  double* const gram = reinterpret_cast<double*>(echunk + (IRLS ? kErrChunk : 0));  // column-major P x P
+  double* const gram_ = gram;
+  double* const m_ = gram + 32 * 32;
+  double* const corr = m_ + 32 * 32;
+  double* const v_ = corr + 33;
+  double* const coefs = v_ + 32;
+  double* const best = coefs + 32;
+  int* const misc = reinterpret_cast<int*>(best + 32);  // [0] solve ok, [1] status
+  float* const fmisc = reinterpret_cast<float*>(misc + 4);  // [0] sum_abs_err, [1] best_error
+
+  const float* __restrict__ wtab = a.window ? a.window + 32 : nullptr;
+  const int32_t* rowA;
+  const int32_t* rowB = nullptr;
+  int kind = 0;
+  if (STEREO) {
+    const uint32_t frame = sf >> 2;
+    kind = (int)(sf & 3u);
+    rowA = a.samples + (size_t)(2u * frame + (kind == 1 ? 1u : 0u)) * a.stride;
+    rowB = a.samples + (size_t)(2u * frame + 1u) * a.stride;
+  } else {
+    rowA = a.samples + (size_t)sf * a.stride;
+  }
+  auto sample = [&](int t) -> int32_t {
+    int32_t s = rowA[t];
+    if (STEREO && kind >= 2) {
+      const int32_t r = rowB[t];
+      s = kind == 2 ? (s + r) >> 1 : s - r;  // coding.rs:483
+    }
+    return s;
+  };
+  // x_w = (f32)s * w, one f32 rounding (lpc.rs:751-754); IRLS: weights start at 1 (lpc.rs:821-822)
+  int32_t my_maxabs = 0;
+  for (int t = tid; t < n; t += nthr) {
+    const int32_t s = sample(t);
+    xw[t] = (float)s * (wtab ? wtab[t] : 1.0f);
+    if (IRLS) {
+      wgt[t] = 1.0f;
+      const int32_t ab = s < 0 ? (int32_t)(0u - (uint32_t)s) : s;  // i32::abs (wrapping)
+      my_maxabs = ab > my_maxabs ? ab : my_maxabs;
+    }
+  }
+  float normalizer = 0.0f;
+  if (IRLS) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_xor(my_maxabs, d, 64);
+      my_maxabs = o > my_maxabs ? o : my_maxabs;
+    }
+    if (tid == 0) misc[2] = 0;
+    __syncthreads();
+    if (lane == 0) atomicMax(&misc[2], my_maxabs);
+    __syncthreads();
+    normalizer = (float)misc[2];
+    if (tid == 0) {
+      fmisc[1] = 3.40282347e+38f;  // f32::MAX
+      misc[3] = 0;                 // have a best
+    }
+  }
+  if (tid == 0) misc[1] = 0;
+  __syncthreads();
+
+  // this thread's chain: c < P + 1 -> (a, b) = (c, 0) = R[c]; then the upper triangle i <= j of G as (i+1, j+1)
+  const int NC = (P + 1) + P * (P + 1) / 2;
+  int ca = 0, cb = 0;
+  if (tid < P + 1) {
+    ca = tid;
+  } else if (tid < NC) {
+    int idx = tid - (P + 1), i = 0;
+    while (idx >= P - i) {
+      idx -= P - i;
+      ++i;
+    }
+    ca = i + 1;
+    cb = i + idx + 1;
+  }
+  const int steps = IRLS ? (int)a.mae_steps : 0;
+  for (int it = 0; it <= steps; ++it) {
+    // ---- chains ----
+    if (tid < NC && n >= P + 1) {
+      double acc = 0.0;
+      const float* __restrict__ pa = xw + (P - ca);  // y_a(t') = xw[t' + 1 - a], t' = P - 1 ..
+      const float* __restrict__ pb = xw + (P - cb);
+      const float* __restrict__ pw = wgt + P;        // w[t' + 1]
+      const int len = n - P;                         // t' = P - 1 .. n - 2
+      int k = 0;
+      for (; k + 4 <= len; k += 4) {
+        const float a0 = pa[k], a1 = pa[k + 1], a2 = pa[k + 2], a3 = pa[k + 3];
+        float b0 = pb[k], b1 = pb[k + 1], b2 = pb[k + 2], b3 = pb[k + 3];
+        if (IRLS) {
+          b0 = pw[k] * b0;
+          b1 = pw[k + 1] * b1;
+          b2 = pw[k + 2] * b2;
+          b3 = pw[k + 3] * b3;
+        }
+        acc = __builtin_fma((double)a0, (double)b0, acc);
+        acc = __builtin_fma((double)a1, (double)b1, acc);
+        acc = __builtin_fma((double)a2, (double)b2, acc);
+        acc = __builtin_fma((double)a3, (double)b3, acc);
+      }
+      for (; k < len; ++k) {
+        float b0 = pb[k];
+        if (IRLS) b0 = pw[k] * b0;
+        acc = __builtin_fma((double)pa[k], (double)b0, acc);
+      }
+      if (tid < P + 1) {
+        corr[tid] = acc;
+      } else {
+        gram[(ca - 1) + (cb - 1) * P] = acc;
+        gram[(cb - 1) + (ca - 1) * P] = acc;
+      }
+    } else if (tid < NC) {
+      if (tid < P + 1) corr[tid] = 0.0;
+      else gram[(ca - 1) + (cb - 1) * P] = gram[(cb - 1) + (ca - 1) * P] = 0.0;
+    }
+    __syncthreads();
+    if (it == steps && a.autocorr && tid <= 32 && !IRLS) a.autocorr[(size_t)sf * 33 + tid] = tid <= P ? corr[tid] : 0.0;
+
+    // ---- solve_sym_mut with the regulariser loop (lpc.rs:887-896), wave 0, lane = matrix row ----
+    if (tid < 64) {
+      // (volatile: other lanes of the wave write what this lane reads next; LDS operations of one wave complete
+      // in order, the compiler just must not keep any of it in registers)
+      volatile double* const m = m_;
+      volatile double* const v = v_;
+      volatile double* const gram = gram_;
+      const int r = lane;
+      double regularizer = 0.0;
+      int tries = 0;
+      for (;;) {
+        // mat.clone(); xy = corr[1..]
+        if (r < P) {
+          for (int c = 0; c < P; ++c) m[r + c * P] = gram[r + c * P];
+          v[r] = corr[r + 1];
+        }
+        __builtin_amdgcn_wave_barrier();
+        bool ok = true;
+        for (int j = 0; j < P && ok; ++j) {
+          for (int k = 0; k < j; ++k) {
+            const double factor = -m[j + k * P];
+            if (r >= j && r < P) {
+              const double ax = factor * m[r + k * P];
+              m[r + j * P] = ax + m[r + j * P];  // array_axcpy: (a * x) * 1 + 1 * y, no fma
+            }
+            __builtin_amdgcn_wave_barrier();
+          }
+          const double diag = m[j + j * P];
+          if (diag == 0.0 || !(diag >= 0.0)) {  // is_zero() / try_sqrt() == None
+            ok = false;
+            break;
+          }
+          const double denom = __builtin_sqrt(diag);
+          __builtin_amdgcn_wave_barrier();
+          if (r == j) m[j + j * P] = denom;
+          if (r > j && r < P) m[r + j * P] = m[r + j * P] / denom;
+          __builtin_amdgcn_wave_barrier();
+        }
+        if (ok) {
+          // solve_lower_triangular_vector_unchecked_mut
+          for (int i = 0; i < P; ++i) {
+            const double coeff = v[i] / m[i + i * P];
+            __builtin_amdgcn_wave_barrier();
+            if (r == i) v[i] = coeff;
+            if (r > i && r < P) v[r] = ((-coeff) * m[r + i * P]) + v[r];
+            __builtin_amdgcn_wave_barrier();
+          }
+          // ad_solve_lower_triangular: b[i] = (b[i] - dot(L[i+1.., i], b[i+1..])) / L[i][i], dotx's accumulators
+          if (r == 0) {
+            for (int i = P - 1; i >= 0; --i) {
+              const int rows = P - (i + 1);
+              double acc8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+              double res = 0.0;
+              int q = 0;
+              while (rows - q >= 8) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc8[u] += m[(i + 1 + q + u) + i * P] * v[i + 1 + q + u];
+                q += 8;
+              }
+              res += acc8[0] + acc8[4];
+              res += acc8[1] + acc8[5];
+              res += acc8[2] + acc8[6];
+              res += acc8[3] + acc8[7];
+              for (int k = q; k < rows; ++k) res += m[(i + 1 + k) + i * P] * v[i + 1 + k];
+              v[i] = (v[i] - res) / m[i + i * P];
+            }
+          }
+          __builtin_amdgcn_wave_barrier();
+          break;
+        }
+        // regularizer = max(1, 2 regularizer); diag += regularizer - old (lpc.rs:889-895)
+        const double old = regularizer;
+        const double twice = regularizer + regularizer;
+        regularizer = 1.0 > twice ? 1.0 : twice;
+        if (r < P) gram[r + r * P] += regularizer - old;
+        __builtin_amdgcn_wave_barrier();
+        if (++tries > 2000) {  // (NaN input: the reference would not terminate)
+          if (r == 0) misc[1] = FLACENC_HIP_SUBFRAME_NONFINITE;
+          if (r < P) v[r] = 0.0;
+          break;
+        }
+      }
+      if (r < P) coefs[r] = v[r];
+    }
+    __syncthreads();
+    if (!IRLS) break;
+
+    // ---- compute_raw_errors (f32 fma chain over the taps), sum of |err| as ONE sequential f32 chain
+    //      (Iterator::sum, lpc.rs:839), new weights (lpc.rs:845-847) ----
+    if (tid == 0) fmisc[0] = 0.0f;
+    for (int base = 0; base < n; base += kErrChunk) {
+      __syncthreads();
+      for (int o = tid; o < kErrChunk && base + o < n; o += nthr) {
+        const int t = base + o;
+        float e = 0.0f;  // raw_errors[t] for t < order: never written, 0
+        if (t >= P) {
+          e = (float)(int32_t)(0u - (uint32_t)sample(t));
+          for (int j = 0; j < P; ++j) e = __builtin_fmaf((float)coefs[j], (float)sample(t - 1 - j), e);
+          float x = __builtin_fabsf(e);
+          x = x > 1.0f ? x : 1.0f;
+          x = x / normalizer;
+          x = x > 0.01f ? x : 0.01f;
+          wgt[t] = dev_powf_pos(x, -1.2f);
+        }
+        echunk[o] = __builtin_fabsf(e);
+      }
+      __syncthreads();
+      if (tid == 0) {
+        float sacc = fmisc[0];
+        const int cnt = n - base < kErrChunk ? n - base : kErrChunk;
+        for (int o = 0; o < cnt; ++o) sacc += echunk[o];
+        fmisc[0] = sacc;
+      }
+    }
+    __syncthreads();
+    if (fmisc[0] < fmisc[1]) {  // uniform: same LDS value for every thread
+      __syncthreads();
+      if (tid < P) best[tid] = coefs[tid];
+      if (tid <= 32 && a.autocorr) a.autocorr[(size_t)sf * 33 + tid] = tid <= P ? corr[tid] : 0.0;
+      if (tid == 0) {
+        fmisc[1] = fmisc[0];
+        misc[3] = 1;
+      }
+    }
+    __syncthreads();
+  }
+  if (IRLS) {
+    __syncthreads();
+    if (tid < P) coefs[tid] = misc[3] ? best[tid] : 0.0;
+    if (tid == 0 && !misc[3]) misc[1] = FLACENC_HIP_SUBFRAME_NONFINITE;  // best_coefs.unwrap() would panic
+    __syncthreads();
+  }
+
+  // ---- quantize_parameters, lpc.rs:273-302 (find_shift :234-254, quantize_parameter :258-270) ----
+  if (tid == 0) {
+    int status = misc[1];
+    for (int i = 0; i < P; ++i) {
+      const uint64_t b = (uint64_t)__double_as_longlong(coefs[i]);
+      if (((b >> 52) & 0x7FF) == 0x7FF) status |= FLACENC_HIP_SUBFRAME_NONFINITE;
+    }
+    int32_t* pr = a.pred_out + (size_t)sf * 36;
+    for (int i = 0; i < 36; ++i) pr[i] = 0;
+    int shift = 0, order = 0;
+    if (status == 0) {
+      double max_abs = 0.0;
+      for (int i = 0; i < P; ++i) max_abs = fmax(max_abs, fabs(coefs[i]));
+      int abs_log2 = dm_ceil_log2_pos(max_abs);
+      if (abs_log2 < -32752) abs_log2 = -32752;
+      const int precision = (int)a.precision;
+      shift = (precision - 1) - abs_log2;
+      shift = shift < 0 ? 0 : (shift > 15 ? 15 : shift);
+      const double scalefac = (double)(1 << shift);
+      const int lo = -(1 << (precision - 1)), hi = (1 << (precision - 1)) - 1;
+      order = 1;
+      for (int i = 0; i < P; ++i) {
+        double s = round(coefs[i] * scalefac);  // half away from zero
+        s = s < -32768.0 ? -32768.0 : (s > 32767.0 ? 32767.0 : s);
+        int q = (int)s;
+        q = q < lo ? lo : (q > hi ? hi : q);
+        pr[i] = q;
+        if (q != 0) order = i + 1;  // tail-zero truncation, min 1
+      }
+      for (int i = order; i < P; ++i) pr[i] = 0;
+    }
+    pr[32] = order;
+    pr[33] = shift;
+    pr[34] = status;
+    if (a.lpc_coefs)
+      for (int i = 0; i < 32; ++i) a.lpc_coefs[(size_t)sf * 32 + i] = (i < P && status == 0) ? coefs[i] : 0.0;
+  }
+}
+
+}  // namespace
+
+size_t direct_mse_lds_bytes(uint32_t block_size, bool irls) {
+  const size_t n4 = ((size_t)block_size + 3) & ~(size_t)3;
+  size_t b = n4 * 4;
+  if (irls) b += n4 * 4 + kErrChunk * 4;
+  b += (32 * 32 * 2 + 33 + 32 * 3) * 8 + 64;
+  return (b + 15) & ~(size_t)15;
+}
+
+hipError_t launch_direct_mse(const DirectMseArgs& a, hipStream_t stream) {
+  if (a.n_subframes == 0) return hipSuccess;
+  if (a.lpc_order < 1 || a.lpc_order > 32) return hipErrorInvalidValue;
+  if (a.stereo && (a.n_subframes & 3u)) return hipErrorInvalidValue;
+  const bool irls = a.mae_steps > 0;
+  const size_t smem = direct_mse_lds_bytes(a.block_size, irls);
+  if (smem > 160 * 1024) return hipErrorNotSupported;
+  const uint32_t P = a.lpc_order;
+  const uint32_t nc = (P + 1) + P * (P + 1) / 2;
+  const uint32_t threads = ((nc < 64 ? 64 : nc) + 63u) & ~63u;  // <= 576
+  static DynamicLdsOptIn opt[4];
+#define FLACENC_DM_LAUNCH(ST, IR, SLOT)                                                                       \
+  {                                                                                                           \
+    auto kern = direct_mse_kernel<ST, IR>;                                                                    \
+    if (hipError_t e = opt[SLOT].ensure(reinterpret_cast<const void*>(kern), smem); e != hipSuccess) return e; \
+    hipLaunchKernelGGL(kern, dim3(a.n_subframes), dim3(threads), smem, stream, a);                            \
+  }
+  if (a.stereo) {
+    if (irls) FLACENC_DM_LAUNCH(true, true, 0) else FLACENC_DM_LAUNCH(true, false, 1)
+  } else {
+    if (irls) FLACENC_DM_LAUNCH(false, true, 2) else FLACENC_DM_LAUNCH(false, false, 3)
+  }
+#undef FLACENC_DM_LAUNCH
+  return hipGetLastError();
+}
+
+}  // namespace flacenc_hip

@@ -1,0 +1,33 @@
+// direct_mse.h -- launch interface of the covariance-method ("direct MSE") / IRLS estimator kernel
+// (config::Qlpc::use_direct_mse / mae_optimization_steps, src/config.rs:280-285; experimental in the reference).
+#ifndef FLACENC_HIP_DIRECT_MSE_H_
+#define FLACENC_HIP_DIRECT_MSE_H_
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace flacenc_hip {
+
+struct DirectMseArgs {
+  const int32_t* samples;  // device; subframe k at samples + k*stride (stereo: channel c of frame f at (2f + c)*stride)
+  size_t stride;
+  uint32_t block_size;
+  uint32_t n_subframes;    // stereo: 4 per frame (L, R, M, S), a multiple of 4
+  uint32_t stereo;
+  const float* window;     // device table with 32 leading pad floats, nullptr = all ones
+  uint32_t lpc_order;      // 1..32
+  uint32_t precision;      // quant_precision
+  uint32_t mae_steps;      // 0: lpc_with_direct_mse; > 0: lpc_with_irls_mae with that many re-weighting steps
+  int32_t* pred_out;       // device, [n][36]: qc[32], order, shift, status, 0 (as levinson_batch_kernel writes it)
+  double* autocorr;        // device, nullable, [n][33]: R[0..=P] (of the chosen IRLS step)
+  double* lpc_coefs;       // device, nullable, [n][32]: the unquantised solution
+};
+
+size_t direct_mse_lds_bytes(uint32_t block_size, bool irls);
+// perform_qlpc's experimental branches (src/coding.rs:337-347) for a batch, one workgroup per subframe;
+// hipErrorNotSupported when the block does not fit the LDS (IRLS: two f32 arrays of the block).
+hipError_t launch_direct_mse(const DirectMseArgs& args, hipStream_t stream);
+
+}  // namespace flacenc_hip
+#endif

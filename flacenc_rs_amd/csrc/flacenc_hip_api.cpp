@@ -18,6 +18,7 @@
 #include <thread>
 #include <vector>
 
+#include "direct_mse.h"
 #include "flacenc_hip.h"
 #include "frame_decide.h"
 #include "frame_pack.h"
@@ -352,7 +353,14 @@ int enqueue(flacenc_hip_handle* h, const flacenc_hip_qlpc_config* cfg, const int
   a.pred = nullptr;
   a.pred_out = nullptr;
   a.split_scratch = nullptr;
-  if (cfg->lpc_order >= 13 || a.reference_order) {
+  a.direct_mse = cfg->use_direct_mse ? 1u : 0u;
+  a.mae_steps = cfg->use_direct_mse ? cfg->mae_optimization_steps : 0u;  // (ignored without it, coding.rs:337-347)
+  if (a.direct_mse && flacenc_hip::direct_mse_lds_bytes(block_size, a.mae_steps > 0) > 160 * 1024) {
+    h->last_error = "use_direct_mse: the block does not fit the LDS (IRLS keeps the windowed block and its weights there: "
+                    "block_size <= 16384)";
+    return FLACENC_HIP_ERR_UNSUPPORTED;
+  }
+  if (cfg->lpc_order >= 13 || a.reference_order || a.direct_mse) {
     rc = ensure(h, h->d_split, n_subframes * (33 * 8 + 36 * 4));
     if (rc != FLACENC_HIP_OK) return rc;
     a.split_scratch = h->d_split.ptr;
@@ -509,6 +517,7 @@ int enqueue_fixed(flacenc_hip_handle* h, const flacenc_hip_frame_config* cfg, co
   a.rice_finest_only = (cfg->qlpc.flags & FLACENC_HIP_FLAG_FINEST_RICE_ORDER) ? 1u : 0u;
   a.force_generic = (cfg->qlpc.flags & FLACENC_HIP_FLAG_GENERIC_KERNEL) ? 1u : 0u;
   a.reference_order = sum_order_mode(cfg->qlpc.flags);
+  a.direct_mse = cfg->qlpc.use_direct_mse ? 1u : 0u;  // (keeps the launch off the fused wave kernel)
   a.acorr_in = nullptr;
   a.only_marked = 0;
   a.params = params;
@@ -664,6 +673,9 @@ int flacenc_hip_verify_config(const flacenc_hip_qlpc_config* cfg) {
   }
   // config::Prc::verify, src/config.rs:224-229
   if (cfg->max_rice_parameter > FLACENC_HIP_MAX_RICE_PARAMETER) return FLACENC_HIP_ERR_BAD_CONFIG;
+  // config::Qlpc::use_direct_mse / mae_optimization_steps (src/config.rs:280-285): accepted as in the
+  // reference's `experimental` build
+  if (cfg->use_direct_mse > 1 || cfg->mae_optimization_steps > FLACENC_HIP_MAX_MAE_STEPS) return FLACENC_HIP_ERR_BAD_CONFIG;
   // one summation order at a time; the simd-nightly order is only defined up to lag 15 (beyond, `as_simd`
   // splits 128- and 256-byte vectors at addresses the allocator picks, src/lpc.rs:459, :519-523)
   if ((cfg->flags & FLACENC_HIP_FLAG_NIGHTLY_SUM_ORDER) && (cfg->flags & FLACENC_HIP_FLAG_REFERENCE_SUM_ORDER))
@@ -996,6 +1008,7 @@ int flacenc_hip_encode_frames_async(flacenc_hip_handle* h, const flacenc_hip_fra
   a.rice_finest_only = (cfg->qlpc.flags & FLACENC_HIP_FLAG_FINEST_RICE_ORDER) ? 1u : 0u;
   a.force_generic = (cfg->qlpc.flags & FLACENC_HIP_FLAG_GENERIC_KERNEL) ? 1u : 0u;
   a.reference_order = sum_order_mode(cfg->qlpc.flags);
+  a.direct_mse = cfg->qlpc.use_direct_mse ? 1u : 0u;  // (keeps the launch off the fused wave kernel)
   a.acorr_in = nullptr;
   a.only_marked = 0;
     a.params = nullptr;
@@ -1741,6 +1754,7 @@ static int encode_stereo_frames_impl(flacenc_hip_handle* h, const flacenc_hip_fr
   a.rice_finest_only = (cfg->qlpc.flags & FLACENC_HIP_FLAG_FINEST_RICE_ORDER) ? 1u : 0u;
   a.force_generic = (cfg->qlpc.flags & FLACENC_HIP_FLAG_GENERIC_KERNEL) ? 1u : 0u;
   a.reference_order = sum_order_mode(cfg->qlpc.flags);
+  a.direct_mse = cfg->qlpc.use_direct_mse ? 1u : 0u;  // (keeps the launch off the fused wave kernel)
   a.acorr_in = nullptr;
   a.only_marked = 0;
   a.params = nullptr;

@@ -884,8 +884,13 @@ hipError_t launch_bigblock_fixed_residual(const QlpcKernelArgs& a, hipStream_t s
 
 bool bigblock_eligible(const QlpcKernelArgs& a) {
   // (4096 at these orders too: below 13 the fused 4096 kernel has it, above it would fall to the generic one)
-  if (a.block_size != 4096 && a.block_size != 8192 && a.block_size != 16384) return false;
   if (a.lpc_order < 13 || a.lpc_order > 32) return false;
+  return bigblock_shape_eligible(a);
+}
+
+bool bigblock_shape_eligible(const QlpcKernelArgs& a) {
+  if (a.block_size != 4096 && a.block_size != 8192 && a.block_size != 16384) return false;
+  if (a.lpc_order < 1 || a.lpc_order > 32) return false;
   if (a.fixed_mode != 0 || a.lpc_stage != 0 || a.force_generic) return false;
   if (a.frame_results || a.chan_results || a.pack_out) return false;
   if ((reinterpret_cast<uintptr_t>(a.samples) & 15) || (a.stride & 3)) return false;
@@ -906,6 +911,8 @@ hipError_t launch_bigblock_acorr(const QlpcKernelArgs& a, hipStream_t stream) {
 
 hipError_t launch_bigblock_residual(const QlpcKernelArgs& a, hipStream_t stream) {
   const int k = (int)(a.block_size / 4096u);
+  if (a.lpc_order <= 8)  // (only reached behind direct_mse_kernel: the autocorrelation pipeline starts at order 13)
+    return k == 1 ? launch_residual<8, 1>(a, stream) : (k == 2 ? launch_residual<8, 2>(a, stream) : launch_residual<8, 4>(a, stream));
   if (a.lpc_order <= 16)
     return k == 1 ? launch_residual<16, 1>(a, stream) : (k == 2 ? launch_residual<16, 2>(a, stream) : launch_residual<16, 4>(a, stream));
   if (a.lpc_order <= 24)

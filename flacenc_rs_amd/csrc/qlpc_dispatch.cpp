@@ -3,6 +3,7 @@
 #include "qlpc_kernel.h"
 
 #include "acorr_reference.h"
+#include "direct_mse.h"
 #include "sumabs_reference.h"
 
 namespace flacenc_hip {
@@ -25,6 +26,7 @@ int bucket_order(int P) {
 bool wave_kernel_eligible(const QlpcKernelArgs& a) {
   if (a.block_size != 4096 || a.lpc_order > 12) return false;
   if (a.fixed_mode != 0) return false;  // fixed_lpc as a stand-alone batch: generic kernel
+  if (a.direct_mse) return false;       // experimental estimators: direct_mse_kernel + the split pipeline
   if (a.force_generic) return false;
   if ((reinterpret_cast<uintptr_t>(a.samples) & 15) || (a.stride & 3)) return false;
   if ((reinterpret_cast<uintptr_t>(a.residual) & 15) || (a.residual_stride & 3)) return false;
@@ -91,6 +93,46 @@ hipError_t launch_qlpc(const QlpcKernelArgs& a, const QlpcLaunchPlan& plan, hipS
     QlpcKernelArgs b = a;
     b.sumabs_in = a.sumabs_scratch;
     return launch_qlpc(b, plan, stream);
+  }
+  if (a.direct_mse && a.fixed_mode == 0 && a.lpc_stage == 0) {
+    // perform_qlpc's experimental branches (src/coding.rs:337-347): the predictor record comes from
+    // direct_mse_kernel, then the residual + Rice kernels of the split pipeline take over
+    if (a.split_scratch == nullptr) return hipErrorInvalidValue;
+    double* racc = reinterpret_cast<double*>(a.split_scratch);
+    int32_t* pred = reinterpret_cast<int32_t*>(racc + static_cast<size_t>(a.n_subframes) * 33);
+    DirectMseArgs d{};
+    d.samples = a.samples;
+    d.stride = a.stride;
+    d.block_size = a.block_size;
+    d.n_subframes = a.n_subframes;
+    d.stereo = a.stereo;
+    d.window = a.window;
+    d.lpc_order = a.lpc_order;
+    d.precision = a.precision;
+    d.mae_steps = a.mae_steps;
+    d.pred_out = pred;
+    d.autocorr = a.autocorr;
+    d.lpc_coefs = a.lpc_coefs;
+    hipError_t err = launch_direct_mse(d, stream);
+    if (err != hipSuccess) return err;
+    QlpcKernelArgs s3 = a;
+    s3.direct_mse = 0;
+    s3.reference_order = 0;  // (the estimator has one summation order; nothing left for the order flags here)
+    s3.lpc_stage = 3;
+    s3.pred = pred;
+    s3.autocorr = nullptr;
+    s3.lpc_coefs = nullptr;
+    s3.acorr_in = nullptr;
+    if (bigblock_shape_eligible(a)) {
+      err = launch_bigblock_residual(s3, stream);
+      if (err != hipSuccess) return err;
+      s3.only_marked = 1;  // residuals of 2^26 and more: redone by the generic kernel (see below)
+    }
+#define FLACENC_HIP_DM3(MP, BG) \
+  if (plan.maxp == MP && plan.big == (BG != 0)) return launch_qlpc_##MP##_##BG(s3, plan.threads, plan.smem_bytes, stream);
+    FLACENC_HIP_FOR_EACH_INSTANCE(FLACENC_HIP_DM3)
+#undef FLACENC_HIP_DM3
+    return hipErrorInvalidValue;
   }
   if (a.reference_order && a.fixed_mode == 0 && a.lpc_stage == 0 && a.acorr_in == nullptr) {
     // Reference summation order: R[] by the lane-per-subframe kernel, then the usual pipeline from

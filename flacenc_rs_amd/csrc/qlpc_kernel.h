@@ -42,6 +42,11 @@ struct QlpcKernelArgs {
   // the kernels' exact integer sums: launch_qlpc runs it into `sumabs_scratch` and hands it on as `sumabs_in`
   const float* sumabs_in = nullptr;  // device, [n][5][64]: order k, partition p at [(sf * 5 + k) * 64 + p]
   float* sumabs_scratch = nullptr;   // device, n * 5 * 64 floats, or nullptr
+  // config::Qlpc::use_direct_mse / mae_optimization_steps (experimental in the reference, src/coding.rs:337-347):
+  // the predictor comes from direct_mse_kernel (covariance-method LPC, optionally IRLS) instead of
+  // autocorrelation + Levinson; launch_qlpc runs it into split_scratch and continues with the residual kernels
+  uint32_t direct_mse = 0;
+  uint32_t mae_steps = 0;
   uint32_t only_marked;       // generic kernel: redo only subframes whose record says status == -1
   flacenc_hip_subframe_params* params;  // device
   int32_t* residual;                    // device
@@ -103,6 +108,8 @@ hipError_t launch_qlpc(const QlpcKernelArgs& args, const QlpcLaunchPlan& plan, h
 // blocks of 8192 / 16384 samples at order 13..32 (qlpc_bigblock.cpp): autocorrelation and residual + Rice
 // search as two pass-structured kernels either side of levinson_batch_kernel
 bool bigblock_eligible(const QlpcKernelArgs& args);
+// the same without the order bounds (any order 1..32: the residual kernel alone, behind a predictor record)
+bool bigblock_shape_eligible(const QlpcKernelArgs& args);
 hipError_t launch_bigblock_acorr(const QlpcKernelArgs& args, hipStream_t stream);     // R[] -> args.autocorr
 hipError_t launch_bigblock_residual(const QlpcKernelArgs& args, hipStream_t stream);  // args.pred -> records
 // fixed_lpc with OrderSel::ApproxEnt on those shapes: order selection -> args.pred_out, then the residual kernel

@@ -124,11 +124,10 @@ struct Qlpc {  // :271-288
       throw error::VerifyError("lpc_order", "must be in range 1..=24");
     if (quant_precision < 1 || quant_precision > constant::qlpc::MAX_PRECISION)
       throw error::VerifyError("quant_precision", "must be in range 1..=15");
-    if (use_direct_mse)
-      throw error::VerifyError("use_direct_mse", "this feature is only available in `experimental` build.");
-    if (mae_optimization_steps != 0)
-      throw error::VerifyError("mae_optimization_steps",
-                               "this feature is only available in `experimental` build.");
+    // (the reference rejects these two outside its `experimental` cargo feature, :310-320; this mirror follows
+    // the experimental build -- the GPU library implements both estimators, include/flacenc_hip.h)
+    if (mae_optimization_steps > FLACENC_HIP_MAX_MAE_STEPS)
+      throw error::VerifyError("mae_optimization_steps", "must be at most 64 here");
     try {
       window.verify();
     } catch (const error::VerifyError& e) {
@@ -534,6 +533,8 @@ inline flacenc_hip_qlpc_config to_abi(const config::SubFrameCoding& c) {
   o.tukey_alpha = c.qlpc.window.alpha;
   o.max_rice_parameter = static_cast<uint32_t>(c.prc.max_parameter);
   o.flags = 0;
+  o.use_direct_mse = c.qlpc.use_direct_mse ? 1u : 0u;
+  o.mae_optimization_steps = static_cast<uint32_t>(c.qlpc.mae_optimization_steps);
   return o;
 }
 

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define FLACENC_HIP_ABI_VERSION 3 /* 3: analysis_status in the frame / channel results, streaming host path, flag bits 4..32 */
+#define FLACENC_HIP_ABI_VERSION 4 /* 4: use_direct_mse / mae_optimization_steps in flacenc_hip_qlpc_config, NIGHTLY_SUM_ORDER, frame-level calls take blocks below 64 samples */
 
 /* FLAC allows LPC order 32; the reference's config verifier caps it at 24
  * (src/constant.rs:118, src/config.rs:304).  Orders 25..32 are an extension
@@ -42,6 +42,7 @@ extern "C" {
 #define FLACENC_HIP_REF_MAX_LPC_ORDER 24
 #define FLACENC_HIP_MAX_PRECISION 15      /* src/constant.rs qlpc::MAX_PRECISION */
 #define FLACENC_HIP_MAX_RICE_PARAMETER 30 /* src/constant.rs:143 */
+#define FLACENC_HIP_MAX_MAE_STEPS 64    /* (the reference has no bound; its experimental preset uses 20, src/config.rs:535) */
 #define FLACENC_HIP_MIN_BLOCK_SIZE 64     /* MIN_BLOCK_SIZE_FOR_PREDICTION, src/constant.rs:51 */
 #define FLACENC_HIP_MAX_BLOCK_SIZE 32767  /* src/constant.rs:57 */
 #define FLACENC_HIP_MAX_RICE_PARTITIONS 256 /* 2^8: finest order for any block <= 32767 */
@@ -110,8 +111,16 @@ typedef struct flacenc_hip_handle flacenc_hip_handle;
 /* The fields of config::Qlpc (src/config.rs:271-288) and config::Prc
  * (src/config.rs:211-214) that parameterise the path.  Defaults: order 10,
  * precision 15, Tukey(0.4), max_parameter 30 (src/constant.rs:109-115,
- * src/config.rs:216-221).  `use_direct_mse` / `mae_optimization_steps`
- * (experimental, nalgebra) are not part of this ABI. */
+ * src/config.rs:216-221).
+ * `use_direct_mse` / `mae_optimization_steps` (src/config.rs:280, :285; both off by default) select the
+ * reference's EXPERIMENTAL estimators in perform_qlpc (src/coding.rs:333-351): the covariance-method LPC of
+ * LpcEstimator::weighted_lpc_with_direct_mse (src/lpc.rs:853-903: weighted_lagged_outer_prod_sum :573-600, a
+ * Cholesky solve with a doubling diagonal regulariser) and, with steps > 0, its IRLS re-weighting towards the
+ * mean absolute error (lpc_with_irls_mae, :814-850; steps is ignored unless use_direct_mse is set, as there).
+ * The reference's stable `Verify` rejects both switches outside its `experimental` feature (config.rs:302-326);
+ * this ABI follows the experimental build.  Its linear solver is nalgebra's (not part of the reference tree):
+ * results equal the oracle's restatement of nalgebra 0.32's published algorithm bit for bit, which is as far
+ * as this estimator can be pinned.  IRLS needs block_size <= 16384. */
 typedef struct flacenc_hip_qlpc_config {
   uint32_t lpc_order;          /* 1..=24 (..=32 with ALLOW_ORDER_32) */
   uint32_t quant_precision;    /* 1..=15 */
@@ -119,6 +128,8 @@ typedef struct flacenc_hip_qlpc_config {
   float tukey_alpha;           /* 0.0..=1.0 */
   uint32_t max_rice_parameter; /* ..=30 */
   uint32_t flags;
+  uint32_t use_direct_mse;         /* 0 / 1 */
+  uint32_t mae_optimization_steps; /* 0..=FLACENC_HIP_MAX_MAE_STEPS */
 } flacenc_hip_qlpc_config;
 
 /* One record per analysed subframe: everything `estimated_qlpc`

@@ -14,6 +14,7 @@
 #define _GNU_SOURCE
 #include "flacenc_oracle.h"
 
+#include <float.h>
 #include <math.h>
 #include <pthread.h>
 #include <stdlib.h>
@@ -393,6 +394,216 @@ int orc_lpc_from_autocorr(const int32_t* signal, size_t n, const orc_qlpc_config
 }
 
 /* ------------------------------------------------------------------------ */
+/* experimental: covariance-method LPC ("direct MSE") and IRLS  */
+/*                                                                            */
+/* PARITY UNPINNED beyond the reference's own (mostly qualitative) tests: the */
+/* linear solver is nalgebra 0.32 (Cargo.toml:45, optional dependency, not    */
+/* under /root/reference).  Its published algorithm is restated below from    */
+/* nalgebra 0.32.x src/linalg/cholesky.rs (Cholesky::new_internal, solve_mut),*/
+/* src/linalg/solve.rs (solve_lower_triangular_vector_unchecked_mut,          */
+/* xx_solve_lower_triangular_vector_unchecked_mut) and src/base/blas.rs       */
+/* (axcpy / array_axcpy, dotx's 8-accumulator loop).                          */
+/* ------------------------------------------------------------------------ */
+
+/* weighted_auto_correlation_nosimd, src/lpc.rs:533-548, with an optional VecWeight (:194-198):
+ * wy = weight[t] * signal[t] in f32, then widened. */
+void orc_weighted_auto_correlation_nosimd_f64(size_t order, const float* signal, size_t n, const float* weight,
+                                              double* dest) {
+  for (size_t tau = 0; tau < order; ++tau) dest[tau] = 0.0;
+  if (order == 0) return;
+  for (size_t t = order - 1; t < n; ++t) {
+    float wyf = weight ? weight[t] * signal[t] : signal[t];
+    double wy = (double)wyf;
+    for (size_t tau = 0; tau < order; ++tau) dest[tau] = fma((double)signal[t - tau], wy, dest[tau]);
+  }
+}
+
+/* weighted_lagged_outer_prod_sum, src/lpc.rs:573-600: dest is order x order, column-major
+ * (nalgebra::DMatrix); `weight` is indexed t + wshift (ShiftedWeight<M>, src/lpc.rs:205-215). */
+void orc_weighted_lagged_outer_prod_sum_f64(size_t order, const float* signal, size_t len, const float* weight,
+                                            size_t wshift, double* dest) {
+  for (size_t k = 0; k < order * order; ++k) dest[k] = 0.0;
+  if (order == 0) return;
+  for (size_t t = order - 1; t < len; ++t) {
+    for (size_t i = 0; i < order; ++i) {
+      for (size_t j = i; j < order; ++j) {
+        float wxf = weight ? weight[t + wshift] * signal[t - j] : signal[t - j];
+        dest[i + j * order] = fma((double)signal[t - i], (double)wxf, dest[i + j * order]);
+      }
+    }
+  }
+  for (size_t i = 0; i < order; ++i)
+    for (size_t j = i + 1; j < order; ++j) dest[j + i * order] = dest[i + j * order];
+}
+
+/* LpcFloat::solve_sym_mut, src/lpc.rs:79-87: mat.clone().cholesky() then decompose.solve_mut(v).
+ * Returns 1 and overwrites v with the solution, or 0 (v untouched) when the factorisation fails.
+ * nalgebra: column j -= L[j][k] * column k for k < j as  y = (a * x) * 1 + 1 * y  (two roundings, no fma:
+ * array_axcpy); pivot must be non-zero with a real square root (v >= 0); column /= pivot.  Forward solve:
+ * b[i] /= L[i][i]; b[i+1..] += (-b[i]) * L[i+1.., i].  Backward (adjoint) solve: b[i] = (b[i] - dot(L[i+1.., i],
+ * b[i+1..])) / L[i][i] with dotx's eight partial accumulators. */
+int orc_cholesky_solve(const double* mat, size_t n, double* v) {
+  double m[ORC_MAX_LPC_ORDER * ORC_MAX_LPC_ORDER];
+  for (size_t k = 0; k < n * n; ++k) m[k] = mat[k];
+#define M(r, c) m[(r) + (c) * n]
+  for (size_t j = 0; j < n; ++j) {
+    for (size_t k = 0; k < j; ++k) {
+      double factor = -M(j, k);
+      for (size_t r = j; r < n; ++r) {
+        double ax = factor * M(r, k);
+        M(r, j) = (ax * 1.0) + (1.0 * M(r, j));
+      }
+    }
+    double diag = M(j, j);
+    if (diag == 0.0 || !(diag >= 0.0)) return 0; /* is_zero() / try_sqrt() == None (NaN too) */
+    double denom = sqrt(diag);
+    M(j, j) = denom;
+    for (size_t r = j + 1; r < n; ++r) M(r, j) = M(r, j) / denom;
+  }
+  /* solve_lower_triangular_unchecked_mut */
+  for (size_t i = 0; i < n; ++i) {
+    double coeff = v[i] / M(i, i);
+    v[i] = coeff;
+    double a = -coeff;
+    for (size_t r = i + 1; r < n; ++r) v[r] = ((a * M(r, i)) * 1.0) + (1.0 * v[r]);
+  }
+  /* ad_solve_lower_triangular_unchecked_mut */
+  for (size_t ii = n; ii-- > 0;) {
+    size_t rows = n - (ii + 1);
+    double acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    double res = 0.0;
+    size_t i = 0;
+    while (rows - i >= 8) {
+      for (int q = 0; q < 8; ++q) acc[q] += M(ii + 1 + i + q, ii) * v[ii + 1 + i + q];
+      i += 8;
+    }
+    res += acc[0] + acc[4];
+    res += acc[1] + acc[5];
+    res += acc[2] + acc[6];
+    res += acc[3] + acc[7];
+    for (size_t k = i; k < rows; ++k) res += M(ii + 1 + k, ii) * v[ii + 1 + k];
+    v[ii] = (v[ii] - res) / M(ii, ii);
+  }
+#undef M
+  return 1;
+}
+
+static float* orc_windowed(const int32_t* signal, size_t n, const orc_qlpc_config* cfg) {
+  if (orc_tls.window == NULL || orc_tls.window_n != n || orc_tls.window_type != cfg->window_type ||
+      orc_tls.window_alpha != cfg->tukey_alpha) {
+    free(orc_tls.window);
+    orc_tls.window = (float*)malloc(sizeof(float) * (n ? n : 1));
+    orc_window_weights(cfg->window_type, cfg->tukey_alpha, n, orc_tls.window);
+    orc_tls.window_n = n;
+    orc_tls.window_type = cfg->window_type;
+    orc_tls.window_alpha = cfg->tukey_alpha;
+  }
+  ORC_GROW(orc_tls.xw, orc_tls.xw_cap, n + 1, float);
+  orc_fill_windowed_signal(signal, orc_tls.window, n, orc_tls.xw);
+  return orc_tls.xw;
+}
+
+/* LpcEstimator::weighted_lpc_with_direct_mse, src/lpc.rs:853-903.  `weight` NULL = NoWeight.
+ * gram_out (optional) receives the order x order matrix before regularisation, column-major. */
+int orc_weighted_lpc_with_direct_mse(const int32_t* signal, size_t n, const orc_qlpc_config* cfg, const float* weight,
+                                     double* autocorr_out, double* gram_out, double* coefs_out) {
+  size_t order = cfg->lpc_order;
+  for (size_t i = 0; i < order; ++i) coefs_out[i] = 0.0;
+  if (order == 0 || n < order + 1) return ORC_STATUS_OK;
+  const float* xw = orc_windowed(signal, n, cfg);
+  double corr[ORC_MAX_LPC_ORDER + 1];
+  double gram[ORC_MAX_LPC_ORDER * ORC_MAX_LPC_ORDER];
+  orc_weighted_auto_correlation_nosimd_f64(order + 1, xw, n, weight, corr);
+  /* the signal without its last sample, the weight shifted by one (ShiftedWeight::<1, _>) */
+  orc_weighted_lagged_outer_prod_sum_f64(order, xw, n - 1, weight, 1, gram);
+  if (autocorr_out)
+    for (size_t i = 0; i <= order; ++i) autocorr_out[i] = corr[i];
+  if (gram_out)
+    for (size_t k = 0; k < order * order; ++k) gram_out[k] = gram[k];
+  double xy[ORC_MAX_LPC_ORDER];
+  for (size_t i = 0; i < order; ++i) xy[i] = corr[i + 1];
+  double regularizer = 0.0;
+  int tries = 0;
+  while (!orc_cholesky_solve(gram, order, xy)) {
+    double old = regularizer;
+    double twice = regularizer + regularizer;
+    regularizer = 1.0 > twice ? 1.0 : twice; /* T::one().max(regularizer + regularizer) */
+    for (size_t i = 0; i < order; ++i) gram[i + i * order] += regularizer - old;
+    if (++tries > 2000) return ORC_STATUS_NONFINITE; /* (the reference would loop forever on NaN input) */
+  }
+  for (size_t i = 0; i < order; ++i) coefs_out[i] = xy[i];
+  return ORC_STATUS_OK;
+}
+
+/* compute_raw_errors, src/lpc.rs:602-618 (f32, mul_add) */
+void orc_compute_raw_errors(const int32_t* signal, size_t n, const double* coefs, size_t order, float* errors) {
+  for (size_t t = order; t < n; ++t) {
+    float e = (float)(int32_t)(0u - (uint32_t)signal[t]);
+    for (size_t j = 0; j < order; ++j) e = fmaf((float)coefs[j], (float)signal[t - 1 - j], e);
+    errors[t] = e;
+  }
+}
+
+/* LpcEstimator::lpc_with_irls_mae, src/lpc.rs:814-850.  f32::powf is libm's powf. */
+int orc_lpc_with_irls_mae(const int32_t* signal, size_t n, const orc_qlpc_config* cfg, size_t steps,
+                          double* autocorr_out, double* coefs_out) {
+  size_t order = cfg->lpc_order;
+  float* weights = (float*)malloc(sizeof(float) * (n ? n : 1));
+  float* raw = (float*)calloc(n ? n : 1, sizeof(float));
+  for (size_t t = 0; t < n; ++t) weights[t] = 1.0f;
+  double best[ORC_MAX_LPC_ORDER], coefs[ORC_MAX_LPC_ORDER], corr[ORC_MAX_LPC_ORDER + 1];
+  float best_error = FLT_MAX;
+  int have = 0, status = ORC_STATUS_OK;
+  int32_t maxabs = 0;
+  for (size_t t = 0; t < n; ++t) {
+    int32_t a = signal[t] < 0 ? (int32_t)(0u - (uint32_t)signal[t]) : signal[t];
+    if (a > maxabs) maxabs = a;
+  }
+  float normalizer = (float)maxabs;
+  for (size_t it = 0; it <= steps; ++it) {
+    status = orc_weighted_lpc_with_direct_mse(signal, n, cfg, weights, corr, NULL, coefs);
+    if (status != ORC_STATUS_OK) break;
+    orc_compute_raw_errors(signal, n, coefs, order, raw);
+    float sum_abs_err = 0.0f;
+    for (size_t t = 0; t < n; ++t) sum_abs_err += fabsf(raw[t]);
+    if (sum_abs_err < best_error) {
+      best_error = sum_abs_err;
+      for (size_t i = 0; i < order; ++i) best[i] = coefs[i];
+      if (autocorr_out)
+        for (size_t i = 0; i <= order; ++i) autocorr_out[i] = corr[i];
+      have = 1;
+    }
+    for (size_t t = order; t < n; ++t) {
+      float a = fabsf(raw[t]);
+      a = a > 1.0f ? a : 1.0f;   /* f32::max(1.0) */
+      float x = a / normalizer;
+      x = x > 0.01f ? x : 0.01f; /* .max(0.01) */
+      weights[t] = powf(x, -1.2f);
+    }
+  }
+  for (size_t i = 0; i < order; ++i) coefs_out[i] = have ? best[i] : 0.0;
+  free(weights);
+  free(raw);
+  return status; /* (best_coefs.unwrap() panics if no step improved on f32::MAX: NaN errors) */
+}
+
+/* perform_qlpc, src/coding.rs:333-351: acorr_order's low byte ORC_ACORR_DIRECT_MSE selects
+ * config.qlpc.use_direct_mse, bits 8.. = mae_optimization_steps */
+int orc_perform_qlpc(const int32_t* signal, size_t n, const orc_qlpc_config* cfg, double* autocorr_out,
+                     double* coefs_out) {
+  if ((cfg->acorr_order & 0xFFu) == ORC_ACORR_DIRECT_MSE) {
+    size_t steps = cfg->acorr_order >> 8;
+    int st = steps > 0 ? orc_lpc_with_irls_mae(signal, n, cfg, steps, autocorr_out, coefs_out)
+                       : orc_weighted_lpc_with_direct_mse(signal, n, cfg, NULL, autocorr_out, NULL, coefs_out);
+    if (st != ORC_STATUS_OK) return st;
+    for (size_t i = 0; i < cfg->lpc_order; ++i)
+      if (isnan(coefs_out[i]) || isinf(coefs_out[i])) return ORC_STATUS_NONFINITE;
+    return ORC_STATUS_OK;
+  }
+  return orc_lpc_from_autocorr(signal, n, cfg, autocorr_out, coefs_out);
+}
+
+/* ------------------------------------------------------------------------ */
 /* src/rice.rs                                                              */
 /* ------------------------------------------------------------------------ */
 
@@ -627,7 +838,7 @@ void orc_estimated_qlpc(const int32_t* signal, size_t n, uint32_t bits_per_sampl
                         const orc_qlpc_config* cfg, orc_qlpc_result* res, uint8_t* rice_params,
                         int32_t* errors, uint32_t* quotients, uint32_t* remainders) {
   memset(res, 0, sizeof(*res));
-  res->status = orc_lpc_from_autocorr(signal, n, cfg, res->autocorr, res->lpc_coefs);
+  res->status = orc_perform_qlpc(signal, n, cfg, res->autocorr, res->lpc_coefs);
   if (res->status != ORC_STATUS_OK) {
     res->qp.precision = cfg->quant_precision;
     for (size_t t = 0; t < n; ++t) errors[t] = 0;

@@ -44,6 +44,10 @@ extern "C" {
 #define ORC_ACORR_REFERENCE 0 /* weighted_auto_correlation_nosimd, src/lpc.rs:533-548 */
 #define ORC_ACORR_CANONICAL 1 /* the build's canonical order: 16-sample chunk chains + balanced tree */
 #define ORC_ACORR_NIGHTLY 2   /* weighted_auto_correlation_simd, src/lpc.rs:510-531 (aligned buffer) */
+/* config::Qlpc::use_direct_mse (src/config.rs:280): covariance-method LPC, src/lpc.rs:853-903; bits 8.. of
+ * acorr_order carry config::Qlpc::mae_optimization_steps (src/config.rs:285; IRLS, src/lpc.rs:814-850).
+ * Experimental in the reference, solver from nalgebra: parity unpinned (see flacenc_oracle.c). */
+#define ORC_ACORR_DIRECT_MSE 3
 
 /* find_sum_abs_f32 summation orders (src/arrayutils.rs:496-506) */
 #define ORC_SUMABS_STABLE 0    /* stable build: one sequential f32 chain */
@@ -139,6 +143,18 @@ int orc_symmetric_levinson_f32(const float* coefs, const float* ys, size_t order
 int32_t orc_find_shift(const double* coefs, size_t n, uint32_t precision);
 void orc_quantize_parameters(const double* coefs, size_t n, uint32_t precision, orc_qparams* out);
 void orc_compute_error(const orc_qparams* qp, const int32_t* signal, size_t n, int32_t* errors);
+void orc_weighted_auto_correlation_nosimd_f64(size_t order, const float* signal, size_t n, const float* weight,
+                                              double* dest);
+void orc_weighted_lagged_outer_prod_sum_f64(size_t order, const float* signal, size_t len, const float* weight,
+                                            size_t wshift, double* dest);
+int orc_cholesky_solve(const double* mat, size_t n, double* v);
+int orc_weighted_lpc_with_direct_mse(const int32_t* signal, size_t n, const orc_qlpc_config* cfg, const float* weight,
+                                     double* autocorr_out, double* gram_out, double* coefs_out);
+void orc_compute_raw_errors(const int32_t* signal, size_t n, const double* coefs, size_t order, float* errors);
+int orc_lpc_with_irls_mae(const int32_t* signal, size_t n, const orc_qlpc_config* cfg, size_t steps,
+                          double* autocorr_out, double* coefs_out);
+int orc_perform_qlpc(const int32_t* signal, size_t n, const orc_qlpc_config* cfg, double* autocorr_out,
+                     double* coefs_out);
 int orc_lpc_from_autocorr(const int32_t* signal, size_t n, const orc_qlpc_config* cfg,
                           double* autocorr_out, double* coefs_out);
 

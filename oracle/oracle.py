@@ -18,6 +18,7 @@ _LIB_PATH = os.path.join(_HERE, "libflacenc_oracle.so")
 ACORR_REFERENCE = 0
 ACORR_CANONICAL = 1
 ACORR_NIGHTLY = 2
+ACORR_DIRECT_MSE = 3  # config::Qlpc::use_direct_mse; mae_optimization_steps in bits 8.. (experimental, X1)
 SUMABS_STABLE = 0
 SUMABS_NIGHTLY = 1
 SUMABS_CANONICAL = 2
@@ -181,6 +182,16 @@ def _declare(L):
     L.orc_compute_error.argtypes = [C.POINTER(QParams), i32p, C.c_size_t, i32p]
     L.orc_lpc_from_autocorr.argtypes = [i32p, C.c_size_t, C.POINTER(QlpcConfig), f64p, f64p]
     L.orc_lpc_from_autocorr.restype = C.c_int
+    L.orc_weighted_lagged_outer_prod_sum_f64.argtypes = [C.c_size_t, f32p, C.c_size_t, f32p, C.c_size_t, f64p]
+    L.orc_weighted_lagged_outer_prod_sum_f64.restype = None
+    L.orc_cholesky_solve.argtypes = [f64p, C.c_size_t, f64p]
+    L.orc_cholesky_solve.restype = C.c_int
+    L.orc_weighted_lpc_with_direct_mse.argtypes = [i32p, C.c_size_t, C.POINTER(QlpcConfig), f32p, f64p, f64p, f64p]
+    L.orc_weighted_lpc_with_direct_mse.restype = C.c_int
+    L.orc_lpc_with_irls_mae.argtypes = [i32p, C.c_size_t, C.POINTER(QlpcConfig), C.c_size_t, f64p, f64p]
+    L.orc_lpc_with_irls_mae.restype = C.c_int
+    L.orc_compute_raw_errors.argtypes = [i32p, C.c_size_t, f64p, C.c_size_t, f32p]
+    L.orc_compute_raw_errors.restype = None
     L.orc_encode_signbit.argtypes = [C.c_int32]
     L.orc_encode_signbit.restype = C.c_uint32
     L.orc_decode_signbit.argtypes = [C.c_uint32]
@@ -284,12 +295,16 @@ RICE_FINEST_ONLY = 0x100
 
 
 def make_config(lpc_order=10, quant_precision=15, window=("tukey", 0.4), max_rice_parameter=30,
-                acorr=ACORR_REFERENCE, rice_finest_only=False) -> QlpcConfig:
-    """config::Qlpc / config::Prc defaults, src/constant.rs:109-115, src/config.rs:216-221."""
+                acorr=ACORR_REFERENCE, rice_finest_only=False, use_direct_mse=False,
+                mae_optimization_steps=0) -> QlpcConfig:
+    """config::Qlpc / config::Prc defaults, src/constant.rs:109-115, src/config.rs:216-221.
+    use_direct_mse / mae_optimization_steps: the experimental estimators of src/coding.rs:337-347."""
     if window == "rectangle" or window[0] == "rectangle":
         wt, alpha = WINDOW_RECTANGLE, 0.0
     else:
         wt, alpha = WINDOW_TUKEY, float(window[1])
+    if use_direct_mse:
+        acorr = ACORR_DIRECT_MSE | (int(mae_optimization_steps) << 8)
     return QlpcConfig(lpc_order, quant_precision, wt, alpha,
                       max_rice_parameter | (RICE_FINEST_ONLY if rice_finest_only else 0), acorr)
 
@@ -380,6 +395,57 @@ def lpc_from_autocorr(signal, cfg: QlpcConfig):
     st = lib().orc_lpc_from_autocorr(_p(s, C.c_int32), len(s), C.byref(cfg), _p(corr, C.c_double),
                                      _p(coefs, C.c_double))
     return corr[: cfg.lpc_order + 1], coefs[: cfg.lpc_order], st
+
+
+# ---- experimental: covariance-method LPC and IRLS (src/lpc.rs:573-618, 814-903; parity unpinned) ----
+def lagged_outer_prod_sum(order: int, signal, weight=None, wshift: int = 0) -> np.ndarray:
+    """weighted_lagged_outer_prod_sum (src/lpc.rs:573-600) -> [order, order] f64"""
+    x = np.ascontiguousarray(signal, np.float32)
+    out = np.zeros(order * order, np.float64)
+    w = None if weight is None else np.ascontiguousarray(weight, np.float32)
+    lib().orc_weighted_lagged_outer_prod_sum_f64(order, _p(x, C.c_float), len(x),
+                                                 None if w is None else _p(w, C.c_float), wshift, _p(out, C.c_double))
+    return out.reshape(order, order).T.copy()  # column-major -> [row, col]
+
+
+def cholesky_solve(mat, v):
+    """LpcFloat::solve_sym_mut (src/lpc.rs:79-87; nalgebra's Cholesky): (ok, solution)"""
+    m = np.asfortranarray(np.asarray(mat, np.float64))
+    n = m.shape[0]
+    flat = np.ascontiguousarray(m.T).reshape(-1)  # column-major buffer
+    x = np.ascontiguousarray(v, np.float64).copy()
+    ok = lib().orc_cholesky_solve(_p(flat, C.c_double), n, _p(x, C.c_double))
+    return bool(ok), x
+
+
+def lpc_with_direct_mse(signal, cfg: QlpcConfig, weight=None):
+    """LpcEstimator::weighted_lpc_with_direct_mse (src/lpc.rs:853-903) -> (autocorr, gram, coefs, status)"""
+    s = np.ascontiguousarray(signal, np.int32)
+    P = cfg.lpc_order
+    corr, gram, coefs = np.zeros(33, np.float64), np.zeros(32 * 32, np.float64), np.zeros(32, np.float64)
+    w = None if weight is None else np.ascontiguousarray(weight, np.float32)
+    st = lib().orc_weighted_lpc_with_direct_mse(_p(s, C.c_int32), len(s), C.byref(cfg),
+                                                None if w is None else _p(w, C.c_float), _p(corr, C.c_double),
+                                                _p(gram, C.c_double), _p(coefs, C.c_double))
+    return corr[: P + 1], gram[: P * P].reshape(P, P).T.copy(), coefs[:P], st
+
+
+def lpc_with_irls_mae(signal, cfg: QlpcConfig, steps: int):
+    """LpcEstimator::lpc_with_irls_mae (src/lpc.rs:814-850) -> (coefs, status)"""
+    s = np.ascontiguousarray(signal, np.int32)
+    corr, coefs = np.zeros(33, np.float64), np.zeros(32, np.float64)
+    st = lib().orc_lpc_with_irls_mae(_p(s, C.c_int32), len(s), C.byref(cfg), steps, _p(corr, C.c_double),
+                                     _p(coefs, C.c_double))
+    return coefs[: cfg.lpc_order], st
+
+
+def compute_raw_errors(signal, coefs) -> np.ndarray:
+    """compute_raw_errors (src/lpc.rs:602-618): prediction - signal in f32, zeros in the warm-up"""
+    s = np.ascontiguousarray(signal, np.int32)
+    c = np.ascontiguousarray(coefs, np.float64)
+    out = np.zeros(len(s), np.float32)
+    lib().orc_compute_raw_errors(_p(s, C.c_int32), len(s), _p(c, C.c_double), len(c), _p(out, C.c_float))
+    return out
 
 
 # --------------------------------------------------------------- rice.rs ----

@@ -30,6 +30,8 @@ pub struct QlpcConfig {
     pub tukey_alpha: f32,
     pub max_rice_parameter: u32,
     pub flags: u32,
+    pub use_direct_mse: u32,         // config::Qlpc::use_direct_mse (src/config.rs:280, `experimental`)
+    pub mae_optimization_steps: u32, // config::Qlpc::mae_optimization_steps (src/config.rs:285)
 }
 
 /// `flacenc_hip_subframe_params`: 352 bytes, one per analysed subframe.
@@ -206,6 +208,8 @@ fn abi_config(c: &config::SubFrameCoding) -> QlpcConfig {
         tukey_alpha,
         max_rice_parameter: c.prc.max_parameter as u32,
         flags: 0,
+        use_direct_mse: c.qlpc.use_direct_mse as u32,
+        mae_optimization_steps: c.qlpc.mae_optimization_steps as u32,
     }
 }
 

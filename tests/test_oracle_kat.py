@@ -676,3 +676,89 @@ def test_convert_le_bytes_to_ints():
     # the Fill doctest, src/source.rs:72-80
     assert orc.deinterleave(orc.le_bytes_to_i32s(bytes([0x12, 0x34, 0x54, 0x76, 0x56, 0x78, 0x10, 0x32]), 2),
                             2, 2).tolist() == [0x3412, 0x7856, 0x7654, 0x3210]
+
+
+# ---- experimental estimators: the reference's own tests of lpc.rs, restated ---------------------
+# The solver is nalgebra's (not in the reference tree): these pin the oracle as far as the reference pins itself.
+def test_lagged_outer_prod_sum_computation():
+    """src/lpc.rs:1339-1359, exact values"""
+    m = orc.lagged_outer_prod_sum(2, [4.0, -4.0, 3.0, -3.0, 2.0, -2.0, 1.0, -1.0])
+    assert m[0, 0] == float(-4 * -4 + 3 * 3 + -3 * -3 + 2 * 2 + -2 * -2 + 1 * 1 + -1 * -1)
+    assert m[0, 1] == float(4 * -4 + -4 * 3 + 3 * -3 + -3 * 2 + 2 * -2 + -2 * 1 + 1 * -1)
+    assert m[1, 1] == float(4 * 4 + -4 * -4 + 3 * 3 + -3 * -3 + 2 * 2 + -2 * -2 + 1 * 1)
+    assert m[1, 0] == m[0, 1]
+
+
+def test_lpc_with_known_coefs_dmse():
+    """src/lpc.rs:1194-1212: direct MSE recovers the generating filter (1, -1, 0.5)"""
+    signal = [0, -512, 0, 512, 256, -256, -256, 128, 256, 0, -192, -64, 128, 96, -64, -96, 16, 80, 16, -56, -32, 32,
+              36, -12]
+    cfg = orc.make_config(lpc_order=3, window="rectangle", use_direct_mse=True)
+    _, _, coefs, st = orc.lpc_with_direct_mse(signal, cfg)
+    assert st == 0
+    assert 0.9 < coefs[0] < 1.1 and -1.1 < coefs[1] < -0.9 and 0.4 < coefs[2] < 0.6
+
+
+def test_solve_mut_sym():
+    """src/lpc.rs:1361-1388: covar * solve(covar, autocorr[1..]) == autocorr[1..] (assert_close: rtol 1e-5)"""
+    s = util.quantize(util.sine(1024, 32, 0.8) + util.noise(3, 1024, 0.01), 16).astype(np.float32)
+    order = 12
+    R = orc.auto_correlation(order + 1, s)
+    G = orc.lagged_outer_prod_sum(order, s)
+    ok, x = orc.cholesky_solve(G, R[1:])
+    assert ok
+    np.testing.assert_allclose(G @ x, R[1:], rtol=1e-5)
+    np.testing.assert_allclose(x, np.linalg.solve(G, R[1:]), rtol=1e-6)  # and it is the solution LAPACK finds
+
+
+def test_cholesky_rejects_what_nalgebra_rejects():
+    """Cholesky::new_internal: a zero or negative pivot -> None -> the caller's regulariser loop (lpc.rs:887-896)"""
+    assert orc.cholesky_solve(np.zeros((3, 3)), np.ones(3))[0] is False
+    assert orc.cholesky_solve(np.array([[1.0, 2.0], [2.0, 1.0]]), np.ones(2))[0] is False
+    ok, x = orc.cholesky_solve(np.array([[4.0, 2.0], [2.0, 3.0]]), np.array([2.0, 1.0]))
+    assert ok and np.allclose(x, [0.5, 0.0])
+    # all-zero block: Gram = 0 -> regulariser 1 -> coefficients 0
+    _, _, coefs, st = orc.lpc_with_direct_mse(np.zeros(256, np.int32), orc.make_config(lpc_order=8, use_direct_mse=True))
+    assert st == 0 and not coefs.any()
+
+
+def test_if_direct_mse_is_better_than_autocorr():
+    """src/lpc.rs:1297-1337: sus109 ch0, 128 samples, order 24"""
+    sg = util.test_signal("sus109", 0)[:128]
+    ca = orc.lpc_from_autocorr(sg, orc.make_config(lpc_order=24, window=("tukey", 0.1)))[1]
+    cd = orc.lpc_with_direct_mse(sg, orc.make_config(lpc_order=24, window="rectangle", use_direct_mse=True))[2]
+    energy = (sg.astype(np.float64) ** 2).sum()
+    ea = orc.compute_raw_errors(sg, ca)[24:].astype(np.float64)
+    ed = orc.compute_raw_errors(sg, cd)[24:].astype(np.float64)
+    assert 10 * np.log10(energy / (ea ** 2).sum()) < 10 * np.log10(energy / (ed ** 2).sum())
+
+
+@pytest.mark.parametrize("block_size", [256, 512, 1024, 2048, 4096])
+def test_comparing_mse_vs_mae(block_size):
+    """src/lpc.rs:1448-1486: IRLS (4 steps) does not increase the mean absolute error"""
+    sg = util.test_signal("sus109", 0)[:block_size]
+    cfg = orc.make_config(lpc_order=16, window="rectangle", use_direct_mse=True)
+    c_mse = orc.lpc_with_direct_mse(sg, cfg)[2]
+    c_mae, st = orc.lpc_with_irls_mae(sg, cfg, 4)
+    assert st == 0
+    mae_mse = (np.abs(orc.compute_raw_errors(sg, c_mse)) / np.float32(len(sg))).sum(dtype=np.float32)
+    mae_mae = (np.abs(orc.compute_raw_errors(sg, c_mae)) / np.float32(len(sg))).sum(dtype=np.float32)
+    assert mae_mse >= mae_mae
+
+
+def test_perform_qlpc_switches():
+    """perform_qlpc (src/coding.rs:333-351): steps are ignored without use_direct_mse; with it the subframe is
+    still lossless"""
+    x = util.sine_noise(4096, 16, 57, 0.5, 0.05, seed=3)
+    a = orc.estimated_qlpc(x, 16, orc.make_config(lpc_order=10))
+    b = orc.estimated_qlpc(x, 16, orc.make_config(lpc_order=10, use_direct_mse=True))
+    c = orc.estimated_qlpc(x, 16, orc.make_config(lpc_order=10, use_direct_mse=True, mae_optimization_steps=2))
+    for r in (a, b, c):
+        k = r["order"]
+        assert np.array_equal(orc.decode_lpc(x[:k], r["coefs"], r["shift"], r["residual"]), x)
+    # (on a long stationary block under a Tukey window the two estimators agree to 1e-8 and quantise alike;
+    # a short block shows the difference)
+    y = x[:200]
+    a = orc.estimated_qlpc(y, 16, orc.make_config(lpc_order=10, window="rectangle"))
+    b = orc.estimated_qlpc(y, 16, orc.make_config(lpc_order=10, window="rectangle", use_direct_mse=True))
+    assert b["coefs"].tolist() != a["coefs"].tolist()

@@ -62,6 +62,12 @@ constexpr int kSeg = 68;            // dwords per lane segment: 64 samples + 4 p
 constexpr int kBufDwords = 65 * kSeg + 8;  // one leading all-zero segment (halo of lane 0) + look-ahead slack
 
 __device__ __forceinline__ int widx(int t) { return ((t >> 6) + 1) * kSeg + (t & 63); }
+// the same relative to a lane's segment base lb = widx(64 lane) for sample 64 lane + off, -64 <= off < 128: with a
+// compile-time off this is lb + constant (folded into the LDS instruction's offset field) where widx(tl + off)
+// on an opaque tl costs a shift, a v_mul_lo_u32, an and and two adds per access
+__device__ __forceinline__ int widx_rel(int lb, int off) {
+  return lb + off + (off >= 64 ? (kSeg - 64) : 0) - (off < 0 ? (kSeg - 64) : 0);
+}
 
 // |v| with i32::MIN -> 2^31 - 1 + 1 handled by the caller's unsigned compare; inputs are <= 25 bits
 __device__ __forceinline__ int abs_sat(int v) { return v < 0 ? -v : v; }
@@ -598,13 +604,21 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
   const bool has_window = a.window != nullptr;  // nullptr = all ones (rectangle / Tukey(0))
   const float* __restrict__ wtab = a.window + 32;
   const int flat_lo = a.flat_lo, flat_hi = a.flat_hi;
-  auto window4 = [&](int t) -> float4 {
+  int tl = lane << 6;         // first sample of this lane
+  int lb = (lane + 1) * kSeg;  // its place in an image: widx(tl) (made opaque again at the top of the candidate loop)
+  // four window weights at sample tl + off (off a multiple of 4)
+  auto window4_at = [&](int ix, int off) -> float4 {
     if (!has_window) return make_float4(1.0f, 1.0f, 1.0f, 1.0f);
-    if (WINDOW_IN_LDS) return *reinterpret_cast<const float4*>(&wlds[widx(t)]);
+    if (WINDOW_IN_LDS) return *reinterpret_cast<const float4*>(&wlds[ix]);
+    const int t = tl + off;
     float4 wv = make_float4(1.0f, 1.0f, 1.0f, 1.0f);  // exactly 1.0f inside the flat part
     if (!(t >= flat_lo && t + 4 <= flat_hi)) wv = *reinterpret_cast<const float4*>(wtab + t);
     return wv;
   };
+  auto window4 = [&](int off) -> float4 { return window4_at(widx_rel(lb, off), off); };
+  // (inside the lane's own 64 samples, 0 <= off < 64 -- and for the look-ahead fetch behind them, whose data is
+  // never used: no segment correction, so that a run-time off costs one add)
+  auto window4f = [&](int off) -> float4 { return window4_at(lb + off, off); };
   if (has_window && WINDOW_IN_LDS) {
     const float* __restrict__ wsrc = a.window + 32;
     if (tid < kSeg) wlds[tid] = 0.0f;
@@ -647,11 +661,19 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
   const int32_t* const bufB = sm + kBufDwords;  // right channel (stereo roles 2, 3)
   // four samples of this wave's role starting at t (multiple of 4, >= -64).  The role is
   // wave-uniform; phases are instantiated per role kind so that no branch sits in their loops.
-  auto ld4k = [&](auto kind_tag, int t) -> int4 {
+  auto ld4_at = [&](auto kind_tag, int ix) -> int4 {  // ix: index into an image
     constexpr int KIND = decltype(kind_tag)::value;  // 0 = own image, 2 = mid, 3 = side
-    int4 v = *reinterpret_cast<const int4*>(&bufA[widx(t)]);
+    // (the empty asm takes the loaded quad as ONE 128-bit operand: with lane-base + constant addresses the
+    // optimiser otherwise scalarises the 16-byte loads and re-pairs the dwords as ds_read2_b32 at each use -- and
+    // single dwords at a 68-dword lane stride are an 8-way bank conflict where the b128 form is conflict-free)
+    typedef int v4i_t __attribute__((ext_vector_type(4)));
+    v4i_t va = *reinterpret_cast<const v4i_t*>(&bufA[ix]);
+    asm("" : "+v"(va));
+    int4 v = make_int4(va.x, va.y, va.z, va.w);
     if (KIND >= 2) {
-      const int4 r = *reinterpret_cast<const int4*>(&bufB[widx(t)]);
+      v4i_t vb = *reinterpret_cast<const v4i_t*>(&bufB[ix]);
+      asm("" : "+v"(vb));
+      const int4 r = make_int4(vb.x, vb.y, vb.z, vb.w);
       if (KIND == 2) {  // mid = (l + r) >> 1, coding.rs:483
         v.x = (v.x + r.x) >> 1;
         v.y = (v.y + r.y) >> 1;
@@ -666,6 +688,9 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
     }
     return v;
   };
+  auto ld4k = [&](auto kind_tag, int off) -> int4 { return ld4_at(kind_tag, widx_rel(lb, off)); };  // sample tl + off
+  auto ld4kf = [&](auto kind_tag, int off) -> int4 { return ld4_at(kind_tag, lb + off); };           // 0 <= off < 64
+  auto ld4abs = [&](auto kind_tag, int t) -> int4 { return ld4_at(kind_tag, widx(t)); };             // sample t
   // run `f(kind_tag)` with the wave's role kind as a compile-time constant
   auto with_role = [&](auto&& f) {
     if (STEREO && role == 2) f(std::integral_constant<int, 2>{});
@@ -673,7 +698,6 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
     else f(std::integral_constant<int, 0>{});
   };
 
-  int tl = lane << 6;  // first sample of this lane (made opaque again at the top of the candidate loop)
   const unsigned long long bps_role = a.bps ? (unsigned long long)a.bps[sf]
                                             : (unsigned long long)(a.bps_uniform + ((STEREO && role == 3) ? 1u : 0u));
 
@@ -707,7 +731,7 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
     with_role([&](auto kind) {
 #pragma unroll 4
       for (int k = 0; k < 16; ++k) {
-        const int4 v = ld4k(kind, tl + 4 * k);
+        const int4 v = ld4k(kind, 4 * k);
         vmax = max(max(vmax, v.x), max(v.y, max(v.z, v.w)));
         vmin = min(min(vmin, v.x), min(v.y, min(v.z, v.w)));
       }
@@ -732,19 +756,21 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
     // are read where they are used instead of one step ahead, which keeps the loop inside 168 registers)
     constexpr bool PREFETCH_W = (HP == 8);
     int t_conv = 0;
-    auto fetch = [&](int t0) {
+    auto fetch = [&](int t0, auto fwd_tag) {  // fwd: t0 >= 0, plain lane-base + offset addressing
+      constexpr bool FWD = decltype(fwd_tag)::value;
       t_conv = t0;
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
-        rv[q] = ld4(t0 + 4 * q);
-        if (PREFETCH_W) rw[q] = window4(t0 + 4 * q);
+        rv[q] = FWD ? ld4kf(kind, t0 + 4 * q) : ld4(t0 + 4 * q);
+        if (PREFETCH_W) rw[q] = FWD ? window4f(t0 + 4 * q) : window4(t0 + 4 * q);
       }
     };
     // x_w[t] = (f32)s[t] * w[t]: one f32 rounding, then widen (lpc.rs:751-754)
-    auto convert = [&](int base) {
+    auto convert = [&](int base, auto fwd_tag) {
+      constexpr bool FWD = decltype(fwd_tag)::value;
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
-        if (!PREFETCH_W) rw[q] = window4(t_conv + 4 * q);
+        if (!PREFETCH_W) rw[q] = FWD ? window4f(t_conv + 4 * q) : window4(t_conv + 4 * q);
         dw[base + 4 * q + 0] = (double)((float)rv[q].x * rw[q].x);
         dw[base + 4 * q + 1] = (double)((float)rv[q].y * rw[q].y);
         dw[base + 4 * q + 2] = (double)((float)rv[q].z * rw[q].z);
@@ -752,17 +778,17 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
       }
     };
     // halo of the lane's first chunk (HP = 8 or 12 samples in front of it)
-    fetch(tl - 8);
-    convert(HP);  // lands in dw[HP .. HP+8): the "previous step" of the first step
+    fetch(-8, std::false_type{});
+    convert(HP, std::false_type{});  // lands in dw[HP .. HP+8): the "previous step" of the first step
     if (HP > 8) {
-      const int4 v = ld4(tl - 12);
-      const float4 wv = window4(tl - 12);
+      const int4 v = ld4(-12);
+      const float4 wv = window4(-12);
       dw[HP - 4 + 0] = (double)((float)v.x * wv.x);
       dw[HP - 4 + 1] = (double)((float)v.y * wv.y);
       dw[HP - 4 + 2] = (double)((float)v.z * wv.z);
       dw[HP - 4 + 3] = (double)((float)v.w * wv.w);
     }
-    fetch(tl);
+    fetch(0, std::true_type{});
     // one 16-sample chunk = two 8-sample steps; MASKED only for the block's first chunk, the
     // only one containing t < P (P <= 12 < 16): common lower bound t = P for every lag (lpc.rs:542).
     // PINGPONG: step h writes its 8 values into block (h ^ 1) and finds the previous step's in block h
@@ -773,7 +799,7 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
       constexpr bool MASKED = decltype(masked_tag)::value;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        const int t0 = tl + 16 * i + 8 * h;
+        const int t0 = 16 * i + 8 * h;  // relative to tl
         const int cur0 = PINGPONG ? 8 * h : HP;        // where this step's values go
         const int old0 = PINGPONG ? 8 * (h ^ 1) : 0;   // PINGPONG: the previous step's block
         if (!PINGPONG) {
@@ -785,12 +811,12 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
           vmax = max(max(vmax, rv[q].x), max(rv[q].y, max(rv[q].z, rv[q].w)));
           vmin = min(min(vmin, rv[q].x), min(rv[q].y, min(rv[q].z, rv[q].w)));
         }
-        convert(cur0);
-        fetch(t0 + 8);  // next step (one segment of slack exists behind the last lane)
+        convert(cur0, std::true_type{});
+        fetch(t0 + 8, std::true_type{});  // next step (behind the lane's last step: its own pad + the next segment, unused)
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           double cur = dw[cur0 + k];
-          if (MASKED) cur = (t0 + k >= P) ? cur : 0.0;
+          if (MASKED) cur = (tl + t0 + k >= P) ? cur : 0.0;
 #pragma unroll
           for (int tau = 0; tau <= MAXP; ++tau) {
             // x_w[t - tau]: in this step's block, or tau - k values before the end of the previous one
@@ -906,7 +932,7 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
     with_role([&](auto kind) {
 #pragma unroll
       for (int k = 0; k < 17; ++k) {
-        const int4 q = ld4k(kind, tl - 4 + 4 * k);
+        const int4 q = ld4k(kind, -4 + 4 * k);
         v[4 * k + 0] = (uint32_t)q.x;
         v[4 * k + 1] = (uint32_t)q.y;
         v[4 * k + 2] = (uint32_t)q.z;
@@ -918,7 +944,7 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
     with_role([&](auto kind) {
 #pragma unroll
       for (int k = 0; k < 17; ++k) {
-        const int4 q = ld4k(kind, tl - 4 + 4 * k);
+        const int4 q = ld4k(kind, -4 + 4 * k);
         v[4 * k + 0] = q.x;
         v[4 * k + 1] = q.y;
         v[4 * k + 2] = q.z;
@@ -1016,14 +1042,17 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
       v.y = e[k + 1];
       v.z = e[k + 2];
       v.w = e[k + 3];
-      *reinterpret_cast<int4*>(&buf[widx(tl + k)]) = v;
+      *reinterpret_cast<int4*>(&buf[lb + k]) = v;
     }
   };
 #pragma unroll 1
   for (;;) {
   // (the LDS addresses below are functions of tl alone: opaque here, they are recomputed per pass instead
   // of being hoisted out of the loop as two dozen registers that then live -- or spill -- across it)
-  if (FIXED) asm volatile("" : "+v"(tl));
+  if (FIXED) {
+    asm volatile("" : "+v"(lb));
+    lb &= ~3;  // (a no-op: kSeg is a multiple of 4 dwords -- it tells the compiler that the 16-byte LDS accesses are aligned)
+  }
   if (FIXED && cand != 5) {
     // ---- the order-`cand` fixed-LPC error signal (coding.rs:182-197) -> e[] ----
     fixed_load_into(ebuf);
@@ -1073,7 +1102,7 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
       int sw[HP + 16];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int t0 = tl + 16 * i;
+        const int t0 = 16 * i;  // relative to tl
         // compiler-level memory barrier: keeps the next chunk's LDS reads from being hoisted
         // above this chunk's arithmetic (which would cost VGPRs and an occupancy step)
         asm volatile("" ::: "memory");
@@ -1135,7 +1164,7 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
         int hw[HP];
 #pragma unroll
         for (int k = 0; k < HP; k += 4) {
-          const int4 v = ld4(tl - HP + k);
+          const int4 v = ld4(-HP + k);
           hw[k + 0] = v.x;
           hw[k + 1] = v.y;
           hw[k + 2] = v.z;
@@ -1147,7 +1176,7 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int t0 = tl + 16 * i;
+        const int t0 = 16 * i;  // relative to tl
         asm volatile("" ::: "memory");
         if (i > 0) {
 #pragma unroll
@@ -1211,7 +1240,7 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
         v.y = e[k + 1];
         v.z = e[k + 2];
         v.w = e[k + 3];
-        *reinterpret_cast<int4*>(&buf[widx(tl + k)]) = v;
+        *reinterpret_cast<int4*>(&buf[lb + k]) = v;
       }
     };
     if (STEREO) {
@@ -1548,12 +1577,12 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
         // the bit buffer will reuse the image area: keep what the writer still needs from it --
         // the warm-up samples (lane i < 16 holds sample i) and a Verbatim subframe's samples
         with_role([&](auto kind_tag) {
-          const int4 q = ld4k(kind_tag, lane < 16 ? (lane & ~3) : 0);
+          const int4 q = ld4abs(kind_tag, lane < 16 ? (lane & ~3) : 0);
           pack_wsmp = (lane & 3) == 0 ? q.x : ((lane & 3) == 1 ? q.y : ((lane & 3) == 2 ? q.z : q.w));
           if (kind == 1u) {
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
-              const int4 v4 = ld4k(kind_tag, tl + 4 * k);
+              const int4 v4 = ld4k(kind_tag, 4 * k);
               e[4 * k + 0] = v4.x;
               e[4 * k + 1] = v4.y;
               e[4 * k + 2] = v4.z;

@@ -133,7 +133,7 @@ struct flacenc_hip_handle {
   hipStream_t stream = nullptr;
   std::string last_error;
   std::vector<WindowEntry> windows;
-  DeviceBuffer d_samples, d_residual, d_params, d_bps, d_autocorr, d_lpc, d_tables, d_keys, d_sel, d_results, d_out, d_outlen, d_cparams, d_cresid, d_fparams, d_fresid, d_fkeys, d_split, d_presid, d_sumabs;
+  DeviceBuffer d_samples, d_residual, d_params, d_bps, d_autocorr, d_lpc, d_tables, d_keys, d_sel, d_results, d_out, d_outlen, d_cparams, d_cresid, d_fparams, d_fresid, d_fkeys, d_split, d_presid, d_sumabs, d_minmax;
   // streaming host path (flacenc_hip_encode_pcm_stereo): copy-in / copy-out streams, two slots of pinned
   // staging and device buffers, the events that order them
   hipStream_t s_in = nullptr, s_out = nullptr;
@@ -305,7 +305,9 @@ int enqueue(flacenc_hip_handle* h, const flacenc_hip_qlpc_config* cfg, const int
             size_t n_subframes, uint32_t block_size, size_t stride, const uint8_t* bps,
             flacenc_hip_subframe_params* params, int32_t* residual, size_t residual_stride,
             double* autocorr, double* lpc_coefs, hipStream_t stream, bool stereo = false,
-            uint32_t bps_uniform = 16) {
+            uint32_t bps_uniform = 16, int32_t* residual_lr = nullptr, size_t residual_lr_stride = 0,
+            int32_t* minmax_out = nullptr, bool* placed = nullptr) {
+  if (placed) *placed = false;
   const WindowEntry* win = nullptr;
   int rc = get_window(h, cfg, block_size, &win);
   if (rc != FLACENC_HIP_OK) return rc;
@@ -369,6 +371,16 @@ int enqueue(flacenc_hip_handle* h, const flacenc_hip_qlpc_config* cfg, const int
     rc = ensure(h, h->d_tables, plan.table_scratch_bytes_per_subframe * n_subframes);
     if (rc != FLACENC_HIP_OK) return rc;
     a.table_scratch = static_cast<uint32_t*>(h->d_tables.ptr);
+  }
+  // frame-level callers on the big-block shapes: L / R candidates straight into the output rows, role min / max
+  // from the residual kernel (only bigblock_residual_kernel knows how; see QlpcKernelArgs::residual_lr)
+  if (stereo && residual_lr != nullptr && minmax_out != nullptr &&
+      (reinterpret_cast<uintptr_t>(residual_lr) & 15) == 0 && (residual_lr_stride & 3) == 0 &&
+      (flacenc_hip::bigblock_eligible(a) || (a.direct_mse && flacenc_hip::bigblock_shape_eligible(a)))) {
+    a.residual_lr = residual_lr;
+    a.residual_lr_stride = residual_lr_stride;
+    a.minmax_out = minmax_out;
+    if (placed) *placed = true;
   }
   HIP_TRY(h, flacenc_hip::launch_qlpc(a, plan, stream));
   return FLACENC_HIP_OK;
@@ -636,7 +648,7 @@ void flacenc_hip_destroy(flacenc_hip_handle* h) {
     if (e.dev) (void)hipFree(e.dev);
   for (DeviceBuffer* b : {&h->d_samples, &h->d_residual, &h->d_params, &h->d_bps, &h->d_autocorr,
                           &h->d_lpc, &h->d_tables, &h->d_keys, &h->d_sel, &h->d_results, &h->d_out, &h->d_outlen, &h->d_cparams, &h->d_cresid,
-                          &h->d_fparams, &h->d_fresid, &h->d_fkeys, &h->d_split, &h->d_presid, &h->d_sumabs})
+                          &h->d_fparams, &h->d_fresid, &h->d_fkeys, &h->d_split, &h->d_presid, &h->d_sumabs, &h->d_minmax})
     if (b->ptr) (void)hipFree(b->ptr);
   for (int i = 0; i < 2; ++i) {
     for (DeviceBuffer* b : {&h->d_pcm[i], &h->d_pack[i], &h->d_plen[i], &h->d_poff[i], &h->d_cont[i]})
@@ -1844,10 +1856,15 @@ static int encode_stereo_frames_impl(flacenc_hip_handle* h, const flacenc_hip_fr
     if (cfg->use_lpc) {
       if ((rc = ensure(h, h->d_cparams, n_sub * sizeof(flacenc_hip_subframe_params))) != FLACENC_HIP_OK) return rc;
       if ((rc = ensure(h, h->d_cresid, n_sub * cstride * 4)) != FLACENC_HIP_OK) return rc;
+      if ((rc = ensure(h, h->d_minmax, n_sub * 2 * sizeof(int32_t))) != FLACENC_HIP_OK) return rc;
+      bool placed_lr = false;
       rc = enqueue(h, &cfg->qlpc, frames, n_sub, block_size, stride, nullptr,
                    static_cast<flacenc_hip_subframe_params*>(h->d_cparams.ptr),
-                   static_cast<int32_t*>(h->d_cresid.ptr), cstride, nullptr, nullptr, s, true, bits_per_sample);
+                   static_cast<int32_t*>(h->d_cresid.ptr), cstride, nullptr, nullptr, s, true, bits_per_sample,
+                   residual, residual_stride, static_cast<int32_t*>(h->d_minmax.ptr), &placed_lr);
       if (rc != FLACENC_HIP_OK) return rc;
+      d.lpc_lr_in_place = placed_lr ? 1u : 0u;
+      d.minmax = placed_lr ? static_cast<const int32_t*>(h->d_minmax.ptr) : nullptr;
       d.lpc_params = static_cast<const flacenc_hip_subframe_params*>(h->d_cparams.ptr);
       d.lpc_residual = static_cast<const int32_t*>(h->d_cresid.ptr);
     }

@@ -28,6 +28,13 @@ __global__ void __launch_bounds__(kThreads) frame_decide_kernel(FrameDecideArgs 
   // ---- is_constant (arrayutils.rs:382) for L, R, M = (l + r) >> 1, S = l - r ----
   int mn[4] = {INT32_MAX, INT32_MAX, INT32_MAX, INT32_MAX};
   int mx[4] = {INT32_MIN, INT32_MIN, INT32_MIN, INT32_MIN};
+  if (a.minmax != nullptr) {  // (already reduced by the residual kernel)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      mn[k] = a.minmax[((size_t)f * 4 + k) * 2 + 0];
+      mx[k] = a.minmax[((size_t)f * 4 + k) * 2 + 1];
+    }
+  } else
   for (int t = tid; t < n; t += kThreads) {
     const int lv = l[t], rv = r[t];
     const int v[4] = {lv, rv, (lv + rv) >> 1, lv - rv};
@@ -139,7 +146,15 @@ __global__ void __launch_bounds__(kThreads) frame_decide_kernel(FrameDecideArgs 
                          : kind == FLACENC_HIP_KIND_FIXED ? a.fixed_residual + sf * a.cand_stride
                                                           : nullptr;
     int32_t* dst = a.residual + (size_t)(2u * f + (uint32_t)c) * a.residual_stride;
-    for (int t = tid; t < n; t += kThreads) dst[t] = src ? src[t] : 0;
+    // (the L / R candidate of an LPC subframe may already be where it belongs)
+    if (a.lpc_lr_in_place && kind == FLACENC_HIP_KIND_LPC && role == (uint32_t)c) continue;
+    if (((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15) == 0 && (n & 3) == 0) {
+      const int4* s4 = reinterpret_cast<const int4*>(src);
+      int4* d4 = reinterpret_cast<int4*>(dst);
+      for (int t = tid; t < (n >> 2); t += kThreads) d4[t] = src ? s4[t] : make_int4(0, 0, 0, 0);
+    } else {
+      for (int t = tid; t < n; t += kThreads) dst[t] = src ? src[t] : 0;
+    }
   }
 }
 

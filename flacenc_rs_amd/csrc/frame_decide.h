@@ -24,6 +24,10 @@ struct FrameDecideArgs {
   const int32_t* fixed_residual;
   const unsigned long long* fixed_keys;  // the order selector's key of each fixed candidate
   size_t cand_stride;                    // row stride of both candidate residual buffers
+  // big-block shapes: the LPC candidates of L and R already sit in output rows 2f / 2f + 1 (QlpcKernelArgs::
+  // residual_lr) and the roles' min / max come from the residual kernel ([4 n_frames][2]; null: scan the frame)
+  uint32_t lpc_lr_in_place;
+  const int32_t* minmax;
   flacenc_hip_stereo_frame_result* results;  // out, [n_frames]
   int32_t* residual;                         // out; output channel c of frame f at (2f + c)*residual_stride
   size_t residual_stride;

@@ -338,8 +338,12 @@ __global__ void __launch_bounds__(256, FLACENC_BIG_ACORR_OCC) bigblock_acorr_ker
 }
 
 // ---------------------------------------------------------------------------------------------
-template <int MAXP, bool STEREO, int K>
+// FIXD: the predictor is one of fixed_lpc's (order `warm` <= 4, FIXED_LPC_COEFS, shift 0): the error signal by
+// repeated differencing, no multiply-adds (an instantiation of its own: as a run-time branch next to the
+// multiply-add path it cost the <8, stereo, 2> kernel 122 spilled registers)
+template <int MAXP, bool STEREO, int K, bool FIXD = false>
 __global__ void __launch_bounds__(256, FLACENC_BIG_RESID_OCC) bigblock_residual_kernel(QlpcKernelArgs a) {
+  static_assert(!FIXD || MAXP == 8, "the differencing path lives in the order-8 bucket");
   constexpr int HP = MAXP;  // multiple of 8
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   int32_t* const sm = reinterpret_cast<int32_t*>(smem_raw);
@@ -364,6 +368,9 @@ __global__ void __launch_bounds__(256, FLACENC_BIG_RESID_OCC) bigblock_residual_
   const int shift = uni(pr[33]);
   const int status = uni(pr[34]);
   int32_t* __restrict__ rrow = a.residual + (size_t)sf * a.residual_stride;
+  if (STEREO && a.residual_lr != nullptr && role < 2)  // L / R candidates in place of the output channel they can fill
+    rrow = a.residual_lr + (size_t)(2u * blk + (uint32_t)role) * a.residual_lr_stride;
+  int vmax = INT32_MIN, vmin = INT32_MAX;  // (only kept when minmax_out is set)
 
   uint32_t pl[K][7];
   // Stereo blocks of two passes: the second pass's loads are issued before the first pass is worked off and
@@ -428,7 +435,41 @@ __global__ void __launch_bounds__(256, FLACENC_BIG_RESID_OCC) bigblock_residual_
           sw[HP + q + 2] = v.z;
           sw[HP + q + 3] = v.w;
         }
+        if (a.minmax_out != nullptr) {
+#pragma unroll
+          for (int q = 0; q < 16; q += 2) {
+            vmax = max(vmax, max(sw[HP + q], sw[HP + q + 1]));
+            vmin = min(vmin, min(sw[HP + q], sw[HP + q + 1]));
+          }
+        }
         int32_t e[16];
+        if (FIXD) {
+          // fixed_lpc's predictors are repeated differences (reset_fixed_lpc_errors, coding.rs:182-197): `warm`
+          // wrapping subtractions per sample instead of eight 64-bit multiply-adds, a shift and a subtraction
+          // (the same value: FIXED_LPC_COEFS[k] with shift 0 is the k-th difference, decode.rs:179-201)
+          // (one straight-line body per order, chosen by a wave-uniform switch: a rolled loop over the levels kept
+          // the whole window live across its back edge and spilled)
+          auto diff = [&](auto order_tag) {
+            constexpr int ORD = decltype(order_tag)::value;
+            int32_t d[16 + ORD];
+#pragma unroll
+            for (int q = 0; q < 16 + ORD; ++q) d[q] = sw[HP - ORD + q];
+#pragma unroll
+            for (int lvl = 0; lvl < ORD; ++lvl) {
+#pragma unroll
+              for (int q = 15 + ORD; q >= 1 + lvl; --q) d[q] = (int32_t)((uint32_t)d[q] - (uint32_t)d[q - 1]);
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) e[q] = ((k == 0 && t0 + q < ORD) || status != 0) ? 0 : d[ORD + q];
+          };
+          switch (warm) {
+            case 0: diff(std::integral_constant<int, 0>{}); break;
+            case 1: diff(std::integral_constant<int, 1>{}); break;
+            case 2: diff(std::integral_constant<int, 2>{}); break;
+            case 3: diff(std::integral_constant<int, 3>{}); break;
+            default: diff(std::integral_constant<int, 4>{}); break;
+          }
+        } else {
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
           int64_t pred = 0;
@@ -437,6 +478,7 @@ __global__ void __launch_bounds__(256, FLACENC_BIG_RESID_OCC) bigblock_residual_
           e[q] = (int32_t)(uint32_t)(uint64_t)((int64_t)sw[HP + q] - (pred >> shift));
           // e[0 .. order') = 0 (lpc.rs:349): the block's first samples, i.e. pass 0, lane 0
           if ((k == 0 && t0 + q < warm) || status != 0) e[q] = 0;
+        }
         }
         if (active) {
 #pragma unroll
@@ -663,6 +705,14 @@ __global__ void __launch_bounds__(256, FLACENC_BIG_RESID_OCC) bigblock_residual_
       : 8ull + bps_role * (unsigned long long)warm + 4ull + 5ull +
             (unsigned long long)a.precision * (unsigned long long)warm + residual_bits;
 
+  if (a.minmax_out != nullptr) {
+    const int mx = (int)(wave_max_dpp((uint32_t)vmax ^ 0x80000000u) ^ 0x80000000u);
+    const int mn = (int)(wave_min_dpp((uint32_t)vmin ^ 0x80000000u) ^ 0x80000000u);
+    if (active && lane == 0) {
+      a.minmax_out[(size_t)sf * 2 + 0] = mn;
+      a.minmax_out[(size_t)sf * 2 + 1] = mx;
+    }
+  }
   if (!active) return;
   flacenc_hip_subframe_params* rec = a.params + sf;
   if (literal) {
@@ -845,11 +895,11 @@ hipError_t launch_acorr(const QlpcKernelArgs& a, hipStream_t stream) {
   return launch_big(bigblock_acorr_kernel<HP, NG, false>, opt_p, a, 4 * kHBufDwords * 4 + part + cross, stream);
 }
 
-template <int MAXP, int K>
+template <int MAXP, int K, bool FIXD = false>
 hipError_t launch_residual(const QlpcKernelArgs& a, hipStream_t stream) {
   static DynamicLdsOptIn opt_s, opt_p;
-  if (a.stereo) return launch_big(bigblock_residual_kernel<MAXP, true, K>, opt_s, a, 2 * kBufDwords * 4, stream);
-  return launch_big(bigblock_residual_kernel<MAXP, false, K>, opt_p, a, 4 * kBufDwords * 4, stream);
+  if (a.stereo) return launch_big(bigblock_residual_kernel<MAXP, true, K, FIXD>, opt_s, a, 2 * kBufDwords * 4, stream);
+  return launch_big(bigblock_residual_kernel<MAXP, false, K, FIXD>, opt_p, a, 4 * kBufDwords * 4, stream);
 }
 
 }  // namespace
@@ -879,7 +929,8 @@ hipError_t launch_bigblock_fixed_select(const QlpcKernelArgs& a, hipStream_t str
 
 hipError_t launch_bigblock_fixed_residual(const QlpcKernelArgs& a, hipStream_t stream) {
   const int k = (int)(a.block_size / 4096u);
-  return k == 1 ? launch_residual<8, 1>(a, stream) : (k == 2 ? launch_residual<8, 2>(a, stream) : launch_residual<8, 4>(a, stream));
+  return k == 1 ? launch_residual<8, 1, true>(a, stream)
+                : (k == 2 ? launch_residual<8, 2, true>(a, stream) : launch_residual<8, 4, true>(a, stream));
 }
 
 bool bigblock_eligible(const QlpcKernelArgs& a) {

@@ -47,6 +47,14 @@ struct QlpcKernelArgs {
   // autocorrelation + Levinson; launch_qlpc runs it into split_scratch and continues with the residual kernels
   uint32_t direct_mse = 0;
   uint32_t mae_steps = 0;
+  // Frame-level calls on the big-block shapes (bigblock_residual_kernel, stereo): the candidates of roles L and R
+  // go straight to the OUTPUT rows 2f and 2f + 1 (L can only ever fill output channel 0, R only channel 1:
+  // ChannelAssignment::select_channels, datatype.rs:1173-1185), M and S to `residual` as usual, and the role's
+  // min / max (is_constant, arrayutils.rs:382) to minmax_out[sf][2] -- frame_decide_kernel then copies a row only
+  // when the decision picked something else for that channel, and scans nothing.
+  int32_t* residual_lr = nullptr;
+  size_t residual_lr_stride = 0;
+  int32_t* minmax_out = nullptr;
   uint32_t only_marked;       // generic kernel: redo only subframes whose record says status == -1
   flacenc_hip_subframe_params* params;  // device
   int32_t* residual;                    // device

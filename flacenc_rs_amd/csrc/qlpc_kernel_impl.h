@@ -374,7 +374,7 @@ hipError_t launch_levinson_batch(const QlpcKernelArgs& a, hipStream_t stream) {
 
 template <int MAXP, bool BIG>
 hipError_t launch_one(const QlpcKernelArgs& a, int threads, size_t smem, hipStream_t stream) {
-  if constexpr (MAXP >= 24) {  // (orders 17..32; the order-16 bucket's body does not finish compiling out of line:
+  if constexpr (MAXP >= 24) {  // (orders 17..32, whose workgroups have 256 threads like the marked kernel's; the order-16 bucket's body does not finish compiling out of line:
                                // there the marked subframes are found by one workgroup per subframe, below)
     if (a.only_marked) {
       auto mk = qlpc_marked_kernel<MAXP, BIG>;

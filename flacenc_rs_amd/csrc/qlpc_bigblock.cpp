@@ -477,6 +477,8 @@ __global__ void __launch_bounds__(256, FLACENC_BIG_RESID_OCC) bigblock_residual_
           for (int j = 0; j < MAXP; ++j) pred += (int64_t)cq[j] * (int64_t)sw[HP + q - 1 - j];
           e[q] = (int32_t)(uint32_t)(uint64_t)((int64_t)sw[HP + q] - (pred >> shift));
           // e[0 .. order') = 0 (lpc.rs:349): the block's first samples, i.e. pass 0, lane 0
+          // (as a wave-uniform branch around the first two chunks instead of selects on every sample: measured
+          // 3-7 % slower -- more registers live across the branch, 30 spilled)
           if ((k == 0 && t0 + q < warm) || status != 0) e[q] = 0;
         }
         }
@@ -532,6 +534,7 @@ __global__ void __launch_bounds__(256, FLACENC_BIG_RESID_OCC) bigblock_residual_
   const uint32_t bitlen = maxu ? (uint32_t)(32 - __builtin_clz(maxu)) : 0u;
   const uint32_t max_p = a.max_rice_parameter < bitlen ? a.max_rice_parameter : bitlen;
   const bool finest_only = a.rice_finest_only != 0;
+  const bool small_bits = a.max_rice_parameter >= bitlen;
   PlaneSums ps[K];
 #pragma unroll
   for (int k = 0; k < K; ++k) ps[k] = make_plane_sums(pl[k]);
@@ -543,7 +546,7 @@ __global__ void __launch_bounds__(256, FLACENC_BIG_RESID_OCC) bigblock_residual_
   const bool literal = !(maxu < (1u << 26));
 
   uint32_t pk[K][7], pk7[K >= 2 ? K / 2 : 1], pk8 = 0xFFFFFFFFu;
-  auto search = [&](uint32_t p_lo) {
+  auto search = [&](uint32_t p_lo, uint32_t p_hi) {  // parameters p_lo..p_hi in groups of 4 (see rice_search)
 #pragma unroll
     for (int k = 0; k < K; ++k)
 #pragma unroll
@@ -552,8 +555,8 @@ __global__ void __launch_bounds__(256, FLACENC_BIG_RESID_OCC) bigblock_residual_
     for (int j = 0; j < K / 2; ++j) pk7[j] = 0xFFFFFFFFu;
     pk8 = 0xFFFFFFFFu;
 #pragma unroll 1
-    for (uint32_t p_base = p_lo; p_base <= max_p; p_base += 8u) {
-      uint32_t top[K][8];
+    for (uint32_t p_base = p_lo; p_base <= p_hi; p_base += 4u) {
+      uint32_t top[K][4];
 #pragma unroll
       for (int k = 0; k < K; ++k) {
         rice_build_tables<true>(ps[k], nullptr, len0[k], p_base, max_p, (k == 0) ? lane : 1, warm, top[k]);
@@ -565,7 +568,7 @@ __global__ void __launch_bounds__(256, FLACENC_BIG_RESID_OCC) bigblock_residual_
         for (int j = 0; j < K / 2; ++j) {
           uint32_t packed = pk7[j];
 #pragma unroll
-          for (int q = 0; q < 8; ++q) {
+          for (int q = 0; q < 4; ++q) {
             uint32_t v = top[2 * j][q] + top[2 * j + 1][q];
             v = v < kWMax ? v : kWMax;
             top[2 * j][q] = v;
@@ -577,7 +580,7 @@ __global__ void __launch_bounds__(256, FLACENC_BIG_RESID_OCC) bigblock_residual_
         if (K == 4) {
           uint32_t packed = pk8;
 #pragma unroll
-          for (int q = 0; q < 8; ++q) {
+          for (int q = 0; q < 4; ++q) {
             uint32_t v = top[0][q] + top[2][q];
             v = v < kWMax ? v : kWMax;
             const uint32_t c = (v << 5) | (p_base + (uint32_t)q);
@@ -589,16 +592,24 @@ __global__ void __launch_bounds__(256, FLACENC_BIG_RESID_OCC) bigblock_residual_
     }
   };
   // rice_window (see the 4096 kernel): the wave-minimum of floor(log2(mean + 1)) over all partitions
-  uint32_t p0l = 31u;
+  uint32_t p0l = 31u, p0h = 0u;
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     const uint32_t s0 = 2u * ps[k].sum_m + ps[k].negs;
-    const uint32_t c = 31u - (uint32_t)__builtin_clz((s0 >> 6) + 1u);
+    const uint32_t q0 = (s0 >> 6) + 1u;
+    const uint32_t c = 31u - (uint32_t)__builtin_clz(q0);
     p0l = c < p0l ? c : p0l;
+    // upper end (see the 4096 kernel): q bounds the partition's mean from above; the block's first partition
+    // has only 64 - warm >= 32 coded samples: twice the 64-sample mean covers it
+    const uint32_t qh = (k == 0 && lane == 0) ? 2u * q0 : q0;
+    const uint32_t ch = 31u - (uint32_t)__builtin_clz(qh);
+    p0h = ch > p0h ? ch : p0h;
   }
   const uint32_t p0min = wave_min_dpp(p0l);
   uint32_t p_lo = p0min > 2u ? p0min - 2u : 0u;
   p_lo = p_lo < max_p ? p_lo : max_p;
+  uint32_t p_hi = wave_max_dpp(p0h) + 1u;
+  p_hi = p_hi < max_p ? p_hi : max_p;
   if (literal) p_lo = 0u;
 
   // level totals; strict < keeps the finer order on ties (rice.rs:285)
@@ -614,13 +625,18 @@ __global__ void __launch_bounds__(256, FLACENC_BIG_RESID_OCC) bigblock_residual_
       uint32_t sat = 0;
       if (L < 7) {
         const bool lead = (lane & ((1 << L) - 1)) == 0;
+        uint32_t lbsum = 0;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
           const uint32_t bits = (pk[k][L] >> 5) + 4u;
           const uint32_t lb = lead ? bits : 0u;
           sat |= (lead && bits >= kMaxPToBits) ? 1u : 0u;
-          tot += ((unsigned long long)wave_sum_dpp(lb >> 16) << 16) + wave_sum_dpp(lb & 0xFFFFu);
+          // with the search not cut short by the configuration every minimum is <= 4 + 64 (bitlen + 1) < 2^12:
+          // the passes' values are added in the lane and summed over the wave once
+          if (small_bits) lbsum += lb;
+          else tot += ((unsigned long long)wave_sum_dpp(lb >> 16) << 16) + wave_sum_dpp(lb & 0xFFFFu);
         }
+        if (small_bits) tot = wave_sum_dpp(lbsum);
         sat = wave_or_dpp(sat);
       } else if (L == 7) {
 #pragma unroll
@@ -642,11 +658,11 @@ __global__ void __launch_bounds__(256, FLACENC_BIG_RESID_OCC) bigblock_residual_
     }
   };
   if (!literal) {
-    search(p_lo);
+    search(p_lo, p_hi);
     totals();
     // a saturated minimum could tie with clamped entries outside the window: search the whole range
     if (sat_levels != 0 && p_lo != 0) {
-      search(0u);
+      search(0u, max_p);
       totals();
     }
   }

@@ -510,6 +510,45 @@ def secondary(torch, _capi, handle, args, dev):
         "what": "FLACENC_HIP_FLAG_REFERENCE_SUM_ORDER: autocorrelation as one sequential chain per lag "
                 "(src/lpc.rs:533-548) by a lane-per-subframe kernel, then the fused kernel without its phase 1; "
                 "coefficients bit-identical to the reference's stable build", "subframe_bits_per_sample": bits_per_sample()})
+    ncfg = _capi.make_frame_config(_capi.make_config(lpc_order=args.lpc_order, rice_finest_only=args.finest_rice_order,
+                                                     flags=_capi.FLAG_NIGHTLY_SUM_ORDER), use_fixed=False)
+    ms = timed(lambda: handle.encode_stereo_frames_device(ncfg, noisy.data_ptr(), F, n, n, bps, results.data_ptr(),
+                                                          residual.data_ptr(), n, stream=stream.cuda_stream))
+    sec["nightly_sum_order"] = entry(ms, {
+        "what": "FLACENC_HIP_FLAG_NIGHTLY_SUM_ORDER: autocorrelation in the simd-nightly build's order (8 / 16 strided "
+                "lane chains per lag + head / foot, src/lpc.rs:439-531) by a kernel with a GPU lane per vector lane; "
+                "coefficients bit-identical to the oracle's restatement of that build", "subframe_bits_per_sample": bits_per_sample()})
+    # the reference's DEFAULT configuration: order 10, fixed-LPC candidate with ApproxEnt (config.rs defaults)
+    d10 = _capi.make_config(lpc_order=10)
+    ms = timed(lambda: handle.encode_stereo_frames_device(_capi.make_frame_config(d10, use_fixed=True), noisy.data_ptr(), F, n,
+                                                          n, bps, results.data_ptr(), residual.data_ptr(), n,
+                                                          stream=stream.cuda_stream))
+    sec["reference_default_config_order10"] = entry(ms, {
+        "what": "config::Encoder::default(): LPC order 10 + fixed-LPC candidate (ApproxEnt, 16 partitions), decision on the "
+                "GPU: qlpc_wave4096_kernel<10,true,true,true,false>", "subframe_bits_per_sample": bits_per_sample()})
+    r10 = _capi.make_config(lpc_order=10, flags=_capi.FLAG_REFERENCE_SUM_ORDER)
+    ms = timed(lambda: handle.encode_stereo_frames_device(_capi.make_frame_config(r10, use_fixed=True), noisy.data_ptr(), F, n,
+                                                          n, bps, results.data_ptr(), residual.data_ptr(), n,
+                                                          stream=stream.cuda_stream))
+    sec["reference_default_config_order10_reference_sum_order"] = entry(ms, {
+        "what": "the same with FLACENC_HIP_FLAG_REFERENCE_SUM_ORDER: two extra passes (autocorrelation chains per lag, "
+                "find_sum_abs_f32 chains per estimator partition) in front of the fused kernel -- the stable build's "
+                "bytes", "subframe_bits_per_sample": bits_per_sample()})
+    # the experimental estimators, on an eighth of the frames: one sequential chain per Gram entry
+    Fx = max(F // 8, 256)
+    xp = torch.empty((Fx * 4, _capi.PARAMS_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+    xr = torch.empty((Fx * 4, n), dtype=torch.int32, device=dev)
+    for label, mae in (("direct_mse_order8", 0), ("direct_mse_irls2_order8", 2)):
+        xcfg = _capi.make_config(lpc_order=args.lpc_order, window="rectangle", use_direct_mse=True,
+                                 mae_optimization_steps=mae)
+        ms = timed(lambda: handle.stereo_qlpc_batch_device(xcfg, noisy.data_ptr(), Fx, n, n, bps, xp.data_ptr(),
+                                                           xr.data_ptr(), n, stream=stream.cuda_stream))
+        med = float(np.median(ms))
+        sec[label] = {"frames": Fx, "ms_per_launch": stats(ms), "Msamples_per_s": round(Fx * 2 * n / (med * 1e-3) / 1e6, 1),
+                      "what": "flacenc_hip_stereo_qlpc_batch with use_direct_mse (covariance-method LPC, src/lpc.rs:853-903"
+                              + (", IRLS with %d re-weighting steps, :814-850" % mae if mae else "") +
+                              "), Rectangle window as in report/experimental.config.toml; 4 candidates per frame"}
+    del xp, xr
     # what the host-pointer boundary delivers end to end: packed 16-bit interleaved PCM in host memory ->
     # FLAC frame bytes in host memory (flacenc_hip_encode_pcm_stereo: chunked, pinned staging, upload /
     # analysis / download of neighbouring chunks overlapped).  Wall clock, PCIe both ways included.

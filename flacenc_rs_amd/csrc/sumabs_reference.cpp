@@ -169,6 +169,61 @@ __global__ void __launch_bounds__(256) sumabs_reference_kernel(SumAbsRefArgs a) 
     const int o = __shfl_xor(iters, m, 64);
     iters = o > iters ? o : iters;
   }
+  // Default geometry -- 16 partitions (a wave = the four roles of one stereo frame, or four plain subframes),
+  // 16-byte aligned rows, partitions that are whole multiples of 16 samples: the rows are read ONCE, coalesced
+  // (four lanes fetch the 64 contiguous bytes of a partition's next 16 samples; 16 cache lines per instruction
+  // where a lane-per-partition walk touches 64, per role), parked in a double-buffered per-wave LDS tile
+  // [row][partition][16 + 4 pad] and picked up from there by the lanes of every role.
+  __shared__ __attribute__((aligned(16))) int32_t tiles[4][2][4][16 * 20];
+  const bool fast = vec_ok && parts == 16 && (psz & 15) == 0 && n == 16 * psz &&
+                    (wave + 1u) * 4u <= a.n_subframes;  // wave-uniform
+  if (fast) {
+    constexpr int NROW = STEREO ? 2 : 4;
+    int32_t(*const tile)[4][16 * 20] = tiles[threadIdx.x >> 6];
+    const int lp = lane >> 2, lq = lane & 3;
+    const int32_t* lrow[NROW];
+#pragma unroll
+    for (int rr = 0; rr < NROW; ++rr)
+      lrow[rr] = STEREO ? a.samples + (size_t)(2u * (sf >> 2) + (uint32_t)rr) * a.stride
+                        : a.samples + (size_t)(wave * 4u + (uint32_t)rr) * a.stride;
+    int4 pre[NROW];
+    auto issue = [&](int j) {
+#pragma unroll
+      for (int rr = 0; rr < NROW; ++rr) pre[rr] = *reinterpret_cast<const int4*>(lrow[rr] + lp * psz + 16 * j + 4 * lq);
+    };
+    auto land = [&](int b) {
+#pragma unroll
+      for (int rr = 0; rr < NROW; ++rr) *reinterpret_cast<int4*>(&tile[b][rr][lp * 20 + 4 * lq]) = pre[rr];
+    };
+    const int ra = STEREO ? (kind == 1 ? 1 : 0) : r;
+    const int ntile = psz >> 4;
+    issue(0);
+    land(0);
+    for (int j = 0; j < ntile; ++j) {
+      if (j + 1 < ntile) issue(j + 1);
+      const int32_t* ta = &tile[j & 1][ra][p * 20];
+      const int32_t* tb = &tile[j & 1][STEREO ? 1 : ra][p * 20];
+      const int t0 = begin + 16 * j;
+      // (component by component: a select between whole int4 values went through private memory)
+      auto role_of = [&](int x, int y) -> uint32_t {
+        if (!STEREO) return (uint32_t)x;
+        const int mid = (x + y) >> 1, side = x - y;
+        return (uint32_t)(kind == 2 ? mid : (kind == 3 ? side : x));
+      };
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int4 v = *reinterpret_cast<const int4*>(ta + 4 * q);
+        int4 w = v;
+        if (STEREO) w = *reinterpret_cast<const int4*>(tb + 4 * q);
+        step(std::false_type{}, role_of(v.x, w.x), t0 + 4 * q + 0, 4 * q + 0);
+        step(std::false_type{}, role_of(v.y, w.y), t0 + 4 * q + 1, 4 * q + 1);
+        step(std::false_type{}, role_of(v.z, w.z), t0 + 4 * q + 2, 4 * q + 2);
+        step(std::false_type{}, role_of(v.w, w.w), t0 + 4 * q + 3, 4 * q + 3);
+      }
+      // (one wave per tile set: its LDS operations complete in order, no barrier)
+      if (j + 1 < ntile) land((j + 1) & 1);
+    }
+  } else {
   int4 cur[4], nxt[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) cur[q] = role_quad(w0 + 4 * q);
@@ -191,6 +246,7 @@ __global__ void __launch_bounds__(256) sumabs_reference_kernel(SumAbsRefArgs a) 
     else run(std::true_type{});
 #pragma unroll
     for (int q = 0; q < 4; ++q) cur[q] = nxt[q];
+  }
   }
 
   if (store) {

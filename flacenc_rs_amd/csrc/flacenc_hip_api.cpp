@@ -1811,7 +1811,7 @@ static int encode_stereo_frames_impl(flacenc_hip_handle* h, const flacenc_hip_fr
   bool want_fused = false;
   if (cfg->qlpc.flags & FLACENC_HIP_FLAG_FUSED_PACK) want_fused = true;
   if (cfg->qlpc.flags & FLACENC_HIP_FLAG_TWO_STAGE_PACK) want_fused = false;
-  if (pack && want_fused && !fixed_composite && flacenc_hip::wave_kernel_eligible(a)) {
+  if (pack && want_fused && !fixed_composite && block_size == 4096 && flacenc_hip::wave_kernel_eligible(a)) {
     const size_t bound = flacenc_hip_stereo_frame_bytes_bound(block_size, bits_per_sample);
     flacenc_hip::FramePackArgs pa{};
     fill_header_specs(pa, block_size, pack->sample_rate, bits_per_sample);

@@ -24,7 +24,8 @@ int bucket_order(int P) {
 }  // namespace
 
 bool wave_kernel_eligible(const QlpcKernelArgs& a) {
-  if (a.block_size != 4096 || a.lpc_order > 12) return false;
+  if ((a.block_size != 4096 && a.block_size != 4608) || a.lpc_order > 12) return false;
+  if (a.block_size == 4608 && a.pack_out != nullptr) return false;  // (the fused bit writer exists for 4096 only)
   if (a.fixed_mode != 0) return false;  // fixed_lpc as a stand-alone batch: generic kernel
   if (a.direct_mse) return false;       // experimental estimators: direct_mse_kernel + the split pipeline
   if (a.force_generic) return false;
@@ -226,6 +227,13 @@ hipError_t launch_qlpc(const QlpcKernelArgs& a, const QlpcLaunchPlan& plan, hipS
     const int mp = a.lpc_order <= 8 ? 8 : (a.lpc_order <= 10 ? 10 : 12);
     const int variant = a.stereo ? (a.frame_results ? (a.pack_out ? 5 : (a.use_fixed ? 3 : 2)) : 1)
                                  : (a.chan_results ? 4 : 0);
+    if (a.block_size == 4608) {
+#define FLACENC_HIP_W72CASE(MP, ST) \
+  if (mp == MP && variant == ST) return launch_qlpc_wave72_##MP##_##ST(a, stream);
+      FLACENC_HIP_FOR_EACH_WAVE72_INSTANCE(FLACENC_HIP_W72CASE)
+#undef FLACENC_HIP_W72CASE
+      return hipErrorInvalidValue;
+    }
 #define FLACENC_HIP_WCASE(MP, ST) \
   if (mp == MP && variant == ST) return launch_qlpc_wave_##MP##_##ST(a, stream);
     FLACENC_HIP_FOR_EACH_WAVE_INSTANCE(FLACENC_HIP_WCASE)

@@ -139,6 +139,13 @@ FLACENC_HIP_FOR_EACH_INSTANCE(FLACENC_HIP_DECLARE_INSTANCE)
 #define FLACENC_HIP_DECLARE_WAVE_INSTANCE(MP, ST) \
   hipError_t launch_qlpc_wave_##MP##_##ST(const QlpcKernelArgs&, hipStream_t);
 FLACENC_HIP_FOR_EACH_WAVE_INSTANCE(FLACENC_HIP_DECLARE_WAVE_INSTANCE)
+// ... and for blocks of 4608 samples (72 per lane; no fused bit writer)
+#define FLACENC_HIP_FOR_EACH_WAVE72_INSTANCE(X) \
+  X(8, 0) X(8, 1) X(8, 2) X(8, 3) X(8, 4) X(10, 0) X(10, 1) X(10, 2) X(10, 3) X(10, 4) \
+  X(12, 0) X(12, 1) X(12, 2) X(12, 3) X(12, 4)
+#define FLACENC_HIP_DECLARE_WAVE72_INSTANCE(MP, ST) \
+  hipError_t launch_qlpc_wave72_##MP##_##ST(const QlpcKernelArgs&, hipStream_t);
+FLACENC_HIP_FOR_EACH_WAVE72_INSTANCE(FLACENC_HIP_DECLARE_WAVE72_INSTANCE)
 
 }  // namespace flacenc_hip
 #endif

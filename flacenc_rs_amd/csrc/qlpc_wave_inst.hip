@@ -5,12 +5,20 @@
 // kernel: packed frame bytes instead of residual rows).
 #include "qlpc_wave_kernel_impl.h"
 
+// -DFLACENC_SPL=72: the same kernel for blocks of 4608 samples (72 per lane), variants 0..4.
+#ifndef FLACENC_SPL
+#define FLACENC_SPL 64
+#endif
+#if FLACENC_SPL == 64
 #define FLACENC_CAT2(a, b, c) launch_qlpc_wave_##a##_##b
+#else
+#define FLACENC_CAT2(a, b, c) launch_qlpc_wave72_##a##_##b
+#endif
 #define FLACENC_CAT(a, b) FLACENC_CAT2(a, b, )
 
 namespace flacenc_hip {
 hipError_t FLACENC_CAT(FLACENC_MAXP, FLACENC_STEREO)(const QlpcKernelArgs& a, hipStream_t stream) {
   return launch_wave4096<FLACENC_MAXP, (FLACENC_STEREO != 0 && FLACENC_STEREO != 4), (FLACENC_STEREO >= 2), (FLACENC_STEREO >= 3),
-                         (FLACENC_STEREO == 5)>(a, stream);
+                         (FLACENC_STEREO == 5), FLACENC_SPL>(a, stream);
 }
 }  // namespace flacenc_hip

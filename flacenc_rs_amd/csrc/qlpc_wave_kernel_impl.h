@@ -69,6 +69,36 @@ __device__ __forceinline__ int widx_rel(int lb, int off) {
   return lb + off + (off >= 64 ? (kSeg - 64) : 0) - (off < 0 ? (kSeg - 64) : 0);
 }
 
+// Geometry of the wave kernel for SPL samples per lane: 64 (blocks of 4096) or 72 (blocks of 4608 = 64 finest Rice
+// partitions of 72 samples, rice.rs:157-165 -- the CD-style block sizes 4608 / 2304 / 1152 / 576 all have
+// 72-sample partitions; the full wave's worth, 4608, gets this kernel).  A lane's segment in an LDS image is its
+// SPL samples + 4 dwords of padding (76 dwords for 72: consecutive lanes start 12 banks apart, 16 lanes cover the
+// 64 banks with their 4-dword reads, as 68 does).
+template <int SPL>
+struct WaveGeom {
+  static constexpr int N = 64 * SPL;
+  static constexpr int Seg = SPL + 4;
+  static constexpr int Buf = 65 * Seg + 8;  // one leading all-zero segment (halo of lane 0) + look-ahead slack
+  static constexpr int Quads = N / 4;       // 16-byte pieces per row
+  static constexpr int Chunks = N / 16;     // canonical 16-sample chunks per block (256 / 288)
+  // LDS index of sample t, 0 <= t < N + SPL
+  static __device__ __forceinline__ int idx(int t) {
+    if (SPL == 64) return ((t >> 6) + 1) * Seg + (t & 63);
+    const int sgm = (int)(((uint32_t)t * 58255u) >> 22);  // t / 72 (exact for t < 73727)
+    return (sgm + 1) * Seg + (t - sgm * SPL);
+  }
+  // ... of the 16-byte piece q (sample 4 q), 0 <= q < Quads
+  static __device__ __forceinline__ int qidx(int q) {
+    if (SPL == 64) return ((q >> 4) + 1) * Seg + ((q & 15) << 2);
+    const int sgm = (int)(((uint32_t)q * 3641u) >> 16);  // q / 18 (exact for q < 1300)
+    return (sgm + 1) * Seg + ((q - sgm * (SPL / 4)) << 2);
+  }
+  // ... of sample SPL lane + off relative to the lane's segment base lb = (lane + 1) Seg, -SPL <= off < 2 SPL
+  static __device__ __forceinline__ int rel(int lb, int off) {
+    return lb + off + (off >= SPL ? (Seg - SPL) : 0) - (off < 0 ? (Seg - SPL) : 0);
+  }
+};
+
 // |v| with i32::MIN -> 2^31 - 1 + 1 handled by the caller's unsigned compare; inputs are <= 25 bits
 __device__ __forceinline__ int abs_sat(int v) { return v < 0 ? -v : v; }
 
@@ -373,7 +403,7 @@ __device__ __forceinline__ unsigned long long plane_sum_any64(const PlaneSums& p
 // NOSAT (only with EXACT; chosen per subframe, see rice_nosat_ok): no entry of any level can reach the
 // saturation value and every parameter of the window is legal or provably losing, so the clamps and the
 // validity selects are dropped and the entries are kept pre-shifted (W << 5) for the packed minimiser.
-template <bool EXACT, bool NOSAT = false, int NP = 8>
+template <bool EXACT, bool NOSAT = false, int SPL = 64, int NP>
 __device__ __forceinline__ void rice_build_tables(const PlaneSums& ps, const int32_t* e, uint32_t len0,
                                                   uint32_t p_base, uint32_t max_p, int lane, int warm,
                                                   uint32_t (&Wp)[NP]) {
@@ -410,7 +440,7 @@ __device__ __forceinline__ void rice_build_tables(const PlaneSums& ps, const int
       const uint32_t pp = p_base + (uint32_t)j;
       uint32_t accb = 0;
 #pragma unroll
-      for (int k = 0; k < 64; ++k) {
+      for (int k = 0; k < SPL; ++k) {
         if (k >= off) {
           accb += zigzag(e[k]) >> (pp & 31u);
           if (((k - off) & 15) == 15) accb = accb < kMaxPToBits ? accb : kMaxPToBits;
@@ -466,7 +496,7 @@ __device__ __forceinline__ void rice_group_levels(uint32_t (&Wp)[NP], uint32_t (
 // [p_lo, p_hi] is the parameter window (rice_window below); groups of 4: typical material -- partitions whose
 // means lie within a factor of two of each other -- needs exactly one, and a wider window just takes more turns
 // of the rolled loop (a group of 8 evaluated twice the entries for the common case).
-template <bool EXACT, bool NOSAT = false>
+template <bool EXACT, bool NOSAT = false, int SPL = 64>
 __device__ __forceinline__ RiceResult rice_search(const PlaneSums& ps, const int32_t* e, uint32_t len0,
                                                   uint32_t p_lo, uint32_t p_hi, uint32_t max_p, bool small_bits,
                                                   int lane, int warm, bool finest_only) {
@@ -479,7 +509,7 @@ __device__ __forceinline__ RiceResult rice_search(const PlaneSums& ps, const int
 #pragma unroll 1
   for (uint32_t p_base = p_lo; p_base <= p_hi; p_base += (uint32_t)NP) {
     uint32_t Wp[NP];
-    rice_build_tables<EXACT, NOSAT>(ps, e, len0, p_base, max_p, lane, warm, Wp);
+    rice_build_tables<EXACT, NOSAT, SPL>(ps, e, len0, p_base, max_p, lane, warm, Wp);
     rice_group_levels<NOSAT>(Wp, pk, p_base, finest_only);
   }
 
@@ -521,24 +551,25 @@ struct RiceLiteralResult {
   RiceResult rr;
   unsigned long long sum_q;
 };
+template <int SPL = 64>
 __device__ __attribute__((noinline)) void rice_search_literal(const int32_t* e, uint32_t len0, uint32_t max_p,
                                                               int small_bits, int lane, int warm, int finest_only,
                                                               RiceLiteralResult* out) {
-  int32_t ev[64];
+  int32_t ev[SPL];
 #pragma unroll
-  for (int k = 0; k < 64; ++k) ev[k] = e[k];
+  for (int k = 0; k < SPL; ++k) ev[k] = e[k];
   PlaneSums none;
 #pragma unroll
   for (int k = 0; k < 7; ++k) none.q[k] = 0;
   none.sum_m = none.negs = 0;
-  RiceResult rr = rice_search<false>(none, ev, len0, 0u, max_p, max_p, small_bits != 0, lane, warm, finest_only != 0);
+  RiceResult rr = rice_search<false, false, SPL>(none, ev, len0, 0u, max_p, max_p, small_bits != 0, lane, warm, finest_only != 0);
   // the table sums of this path are the reference's wrapping u32 adds (rice.rs:88-93): code_bits
   // does not determine the true quotient sum any more, saturated or not -- always count it
   rr.saturated = true;
   const uint32_t gp = (uint32_t)__shfl((int)rr.my_p, lane & ~((1 << rr.bestk) - 1), 64);
   uint32_t lo = 0, hi = 0;
 #pragma unroll
-  for (int k = 0; k < 64; ++k) {
+  for (int k = 0; k < SPL; ++k) {
     uint32_t qv = zigzag(ev[k]) >> gp;  // warm-up slots hold 0
     lo += qv & 0xFFFFu;
     hi += qv >> 16;
@@ -551,9 +582,16 @@ __device__ __attribute__((noinline)) void rice_search_literal(const int32_t* e, 
 // DECIDE (stereo only): run encode_subframe's candidate choice and try_stereo_coding's channel
 // assignment (coding.rs:384-418 without the fixed-LPC candidate, :493-522) on the device and
 // write one flacenc_hip_stereo_frame_result + the TWO chosen residual rows per frame.
-template <int MAXP, bool STEREO, bool DECIDE, bool FIXED, bool PACK>
+template <int MAXP, bool STEREO, bool DECIDE, bool FIXED, bool PACK, int SPL = 64>
 __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(QlpcKernelArgs a) {
   static_assert(!PACK || (STEREO && DECIDE && FIXED), "the fused bit writer extends the full stereo frame kernel");
+  static_assert(SPL == 64 || (SPL == 72 && !PACK), "blocks of 4096 (64 samples per lane) or 4608 (72)");
+  using G = WaveGeom<SPL>;
+  // (shadow the file-level 4096-block constants, which the big-block kernels share)
+  constexpr int kWaveN = G::N;
+  constexpr int kSeg = G::Seg;
+  constexpr int kBufDwords = G::Buf;
+  auto widx = [](int t) { return G::idx(t); };
   // DECIDE with STEREO: encode_frame for a 2-channel frame (four roles + try_stereo_coding);
   // DECIDE without: encode_subframe for four independent channels (Independent(n) frames)
   static_assert(!FIXED || DECIDE, "the fixed-LPC candidate only exists inside encode_subframe's decision");
@@ -593,7 +631,7 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
   // same segment layout and shared by the four waves (3 workgroups x 53 KB fit one CU's LDS).
   // Plain mode keeps four sample images (71 KB) and reads the taper weights from the
   // L2-resident table instead, so that two workgroups still fit a CU.
-  constexpr bool WINDOW_IN_LDS = STEREO;
+  constexpr bool WINDOW_IN_LDS = STEREO && SPL == 64;  // (4608: two images are 40 KB; a third would cost the third workgroup per CU)
   constexpr int NIMG = NBUF + (WINDOW_IN_LDS ? 1 : 0);
   // Order 12 at three workgroups per CU: the quantised coefficients wave 0 hands back overlay the R[] rows it was
   // handed (its four lanes have read them, in lockstep, before any of them writes; nobody else reads R[] after
@@ -607,18 +645,14 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
   int tl = lane << 6;         // first sample of this lane
   int lb = (lane + 1) * kSeg;  // its place in an image: widx(tl) (made opaque again at the top of the candidate loop)
   // four window weights at sample tl + off (off a multiple of 4)
-  auto window4_at = [&](int ix, int off) -> float4 {
+  auto window4_at = [&](int ix, int t) -> float4 {  // ix: LDS index (window in LDS), t: sample number (else)
     if (!has_window) return make_float4(1.0f, 1.0f, 1.0f, 1.0f);
     if (WINDOW_IN_LDS) return *reinterpret_cast<const float4*>(&wlds[ix]);
-    const int t = tl + off;
     float4 wv = make_float4(1.0f, 1.0f, 1.0f, 1.0f);  // exactly 1.0f inside the flat part
     if (!(t >= flat_lo && t + 4 <= flat_hi)) wv = *reinterpret_cast<const float4*>(wtab + t);
     return wv;
   };
-  auto window4 = [&](int off) -> float4 { return window4_at(widx_rel(lb, off), off); };
-  // (inside the lane's own 64 samples, 0 <= off < 64 -- and for the look-ahead fetch behind them, whose data is
-  // never used: no segment correction, so that a run-time off costs one add)
-  auto window4f = [&](int off) -> float4 { return window4_at(lb + off, off); };
+
   if (has_window && WINDOW_IN_LDS) {
     const float* __restrict__ wsrc = a.window + 32;
     if (tid < kSeg) wlds[tid] = 0.0f;
@@ -630,23 +664,26 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
   }
   if (STEREO) {
     const int32_t* __restrict__ src = a.samples + (size_t)(2u * blk) * a.stride;
+    constexpr int NQ2 = 2 * G::Quads;  // 16-byte pieces of the two channels
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int q = tid + it * 256;  // 0..2047
-      const int ch = q >> 10;
-      const int t = (q & 1023) << 2;
-      const int4 v = *reinterpret_cast<const int4*>(src + (size_t)ch * a.stride + t);
-      *reinterpret_cast<int4*>(&sm[ch * kBufDwords + widx(t)]) = v;
+    for (int it = 0; it < (NQ2 + 255) / 256; ++it) {
+      const int q = tid + it * 256;
+      if ((NQ2 % 256) == 0 || q < NQ2) {
+        const int ch = q >= G::Quads ? 1 : 0;
+        const int qq = q - ch * G::Quads;
+        const int4 v = *reinterpret_cast<const int4*>(src + (size_t)ch * a.stride + (qq << 2));
+        *reinterpret_cast<int4*>(&sm[ch * kBufDwords + G::qidx(qq)]) = v;
+      }
     }
     __syncthreads();
   } else {
     {
       const int32_t* __restrict__ src = a.samples + (size_t)sf * a.stride;
 #pragma unroll
-      for (int it = 0; it < 16; ++it) {
-        const int t = (lane + it * 64) << 2;
-        const int4 v = *reinterpret_cast<const int4*>(src + t);
-        *reinterpret_cast<int4*>(&sm[wave * kBufDwords + widx(t)]) = v;
+      for (int it = 0; it < G::Quads / 64; ++it) {
+        const int qq = lane + it * 64;
+        const int4 v = *reinterpret_cast<const int4*>(src + (qq << 2));
+        *reinterpret_cast<int4*>(&sm[wave * kBufDwords + G::qidx(qq)]) = v;
       }
     }
     __syncthreads();  // (also orders the zero segment written by other waves)
@@ -688,8 +725,7 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
     }
     return v;
   };
-  auto ld4k = [&](auto kind_tag, int off) -> int4 { return ld4_at(kind_tag, widx_rel(lb, off)); };  // sample tl + off
-  auto ld4kf = [&](auto kind_tag, int off) -> int4 { return ld4_at(kind_tag, lb + off); };           // 0 <= off < 64
+  auto ld4k = [&](auto kind_tag, int off) -> int4 { return ld4_at(kind_tag, G::rel(lb, off)); };  // sample SPL lane + off
   auto ld4abs = [&](auto kind_tag, int t) -> int4 { return ld4_at(kind_tag, widx(t)); };             // sample t
   // run `f(kind_tag)` with the wave's role kind as a compile-time constant
   auto with_role = [&](auto&& f) {
@@ -704,7 +740,7 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
   // hoisted: produced by the candidate pass(es) below, consumed by the decision and the records
   // e[] sits behind four extra slots: the fixed-LPC error signal is differenced in place from the lane's
   // 64 samples + the 4 in front of them, so that no second 68-register array is alive next to e[]
-  int32_t ebuf[68];
+  int32_t ebuf[SPL + 4];
   int32_t* const e = ebuf + 4;
   int32_t cq[MAXP];
   int warm = 0, shift = 0, status = 0;
@@ -730,7 +766,7 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
     for (int k = 0; k < NLAG; ++k) R[k] = rin[k];
     with_role([&](auto kind) {
 #pragma unroll 4
-      for (int k = 0; k < 16; ++k) {
+      for (int k = 0; k < SPL / 4; ++k) {
         const int4 v = ld4k(kind, 4 * k);
         vmax = max(max(vmax, v.x), max(v.y, max(v.z, v.w)));
         vmin = min(min(vmin, v.x), min(v.y, min(v.z, v.w)));
@@ -738,7 +774,26 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
     });
   } else
   with_role([&](auto kind) {
-    auto ld4 = [&](int t) { return ld4k(kind, t); };
+    // Phase-1 sample mapping: lane l takes the canonical chunks 4 l .. 4 l + 3 = samples [64 l, 64 l + 64).  For
+    // 4096-sample blocks that is the lane's own LDS segment (addresses = lb + constant); for 4608 the 64 samples
+    // straddle the 72-sample segments at a lane-dependent place (p1rem), and the block's last 32 chunks are taken
+    // one each by lanes 0..31 afterwards (the "tail" below).  p1t = number of the mapping's first sample.
+    int p1t = tl, p1base = lb, p1rem = 0;
+    auto p1_set = [&](int t_first) {
+      p1t = t_first;
+      if (SPL != 64) {
+        const int sg = (int)(((uint32_t)t_first * 58255u) >> 22);  // / 72
+        p1rem = t_first - sg * SPL;
+        p1base = (sg + 1) * kSeg + p1rem;
+      }
+    };
+    p1_set(tl);
+    auto p1ix = [&](int off, auto fwd_tag) -> int {
+      constexpr bool FWD = decltype(fwd_tag)::value;
+      if (SPL == 64) return FWD ? lb + off : G::rel(lb, off);
+      const int r = p1rem + off;  // -12 <= r < 2 SPL
+      return p1base + off + (r >= SPL ? (kSeg - SPL) : 0) - (r < 0 ? (kSeg - SPL) : 0);
+    };
     // The lane walks its 64 samples as 4 chunks x 2 steps of 8 with a sliding f64 window of
     // HP halo + 8 new values.  A 16-sample chunk is one fma chain per lag, started with the
     // literal +0.0; chunk partials are combined (c0 + c1) + (c2 + c3): the in-lane levels of
@@ -757,20 +812,19 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
     constexpr bool PREFETCH_W = (HP == 8);
     int t_conv = 0;
     auto fetch = [&](int t0, auto fwd_tag) {  // fwd: t0 >= 0, plain lane-base + offset addressing
-      constexpr bool FWD = decltype(fwd_tag)::value;
       t_conv = t0;
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
-        rv[q] = FWD ? ld4kf(kind, t0 + 4 * q) : ld4(t0 + 4 * q);
-        if (PREFETCH_W) rw[q] = FWD ? window4f(t0 + 4 * q) : window4(t0 + 4 * q);
+        const int ix = p1ix(t0 + 4 * q, fwd_tag);
+        rv[q] = ld4_at(kind, ix);
+        if (PREFETCH_W) rw[q] = window4_at(ix, p1t + t0 + 4 * q);
       }
     };
     // x_w[t] = (f32)s[t] * w[t]: one f32 rounding, then widen (lpc.rs:751-754)
     auto convert = [&](int base, auto fwd_tag) {
-      constexpr bool FWD = decltype(fwd_tag)::value;
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
-        if (!PREFETCH_W) rw[q] = FWD ? window4f(t_conv + 4 * q) : window4(t_conv + 4 * q);
+        if (!PREFETCH_W) rw[q] = window4_at(p1ix(t_conv + 4 * q, fwd_tag), p1t + t_conv + 4 * q);
         dw[base + 4 * q + 0] = (double)((float)rv[q].x * rw[q].x);
         dw[base + 4 * q + 1] = (double)((float)rv[q].y * rw[q].y);
         dw[base + 4 * q + 2] = (double)((float)rv[q].z * rw[q].z);
@@ -780,14 +834,18 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
     // halo of the lane's first chunk (HP = 8 or 12 samples in front of it)
     fetch(-8, std::false_type{});
     convert(HP, std::false_type{});  // lands in dw[HP .. HP+8): the "previous step" of the first step
-    if (HP > 8) {
-      const int4 v = ld4(-12);
-      const float4 wv = window4(-12);
-      dw[HP - 4 + 0] = (double)((float)v.x * wv.x);
-      dw[HP - 4 + 1] = (double)((float)v.y * wv.y);
-      dw[HP - 4 + 2] = (double)((float)v.z * wv.z);
-      dw[HP - 4 + 3] = (double)((float)v.w * wv.w);
-    }
+    auto halo12 = [&]() {
+      if (HP > 8) {
+        const int ix = p1ix(-12, std::false_type{});
+        const int4 v = ld4_at(kind, ix);
+        const float4 wv = window4_at(ix, p1t - 12);
+        dw[HP - 4 + 0] = (double)((float)v.x * wv.x);
+        dw[HP - 4 + 1] = (double)((float)v.y * wv.y);
+        dw[HP - 4 + 2] = (double)((float)v.z * wv.z);
+        dw[HP - 4 + 3] = (double)((float)v.w * wv.w);
+      }
+    };
+    halo12();
     fetch(0, std::true_type{});
     // one 16-sample chunk = two 8-sample steps; MASKED only for the block's first chunk, the
     // only one containing t < P (P <= 12 < 16): common lower bound t = P for every lag (lpc.rs:542).
@@ -816,7 +874,7 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           double cur = dw[cur0 + k];
-          if (MASKED) cur = (tl + t0 + k >= P) ? cur : 0.0;
+          if (MASKED) cur = (p1t + t0 + k >= P) ? cur : 0.0;
 #pragma unroll
           for (int tau = 0; tau <= MAXP; ++tau) {
             // x_w[t - tau]: in this step's block, or tau - k values before the end of the previous one
@@ -848,6 +906,19 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
     // ... then the 6 lane levels
 #pragma unroll
     for (int k = 0; k < NLAG; ++k) R[k] = wave_tree_sum_dpp(p2[k]);
+    if (SPL != 64) {
+      // Blocks of 4608: chunks 256..287.  Chunk 256 + l runs on lane l < 32 (the upper lanes shadow them and
+      // contribute +0.0); the balanced tree over the 512-leaf padded chunk index is then
+      // node(0..255) + node(256..511), and node(256..511) = node(256..287) + zeros = the lane tree of the tail.
+      p1_set(64 * 64 + 16 * (lane & 31));
+      fetch(-8, std::false_type{});
+      convert(HP, std::false_type{});
+      halo12();
+      fetch(0, std::true_type{});
+      chunk(std::false_type{}, 0);
+#pragma unroll
+      for (int k = 0; k < NLAG; ++k) R[k] = R[k] + wave_tree_sum_dpp(lane < 32 ? acc[k] : 0.0);
+    }
   });
   // is_constant (arrayutils.rs:382): all samples of the role equal <=> max == min
   role_max = (int)(wave_max_dpp((uint32_t)vmax ^ 0x80000000u) ^ 0x80000000u);
@@ -928,10 +999,10 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
   fx.code_bits = fx.sum_q = fx.sub_bits = 0;
   // the lane's 64 samples + 4 in front of them (zeros in front of the block: the reference's
   // carry starts at 0, coding.rs:188), differenced `ord` times in place; valid from index ord on
-  auto fixed_load = [&](uint32_t (&v)[68]) {
+  auto fixed_load = [&](uint32_t (&v)[SPL + 4]) {
     with_role([&](auto kind) {
 #pragma unroll
-      for (int k = 0; k < 17; ++k) {
+      for (int k = 0; k < SPL / 4 + 1; ++k) {
         const int4 q = ld4k(kind, -4 + 4 * k);
         v[4 * k + 0] = (uint32_t)q.x;
         v[4 * k + 1] = (uint32_t)q.y;
@@ -940,10 +1011,10 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
       }
     });
   };
-  auto fixed_load_into = [&](int32_t (&v)[68]) {
+  auto fixed_load_into = [&](int32_t (&v)[SPL + 4]) {
     with_role([&](auto kind) {
 #pragma unroll
-      for (int k = 0; k < 17; ++k) {
+      for (int k = 0; k < SPL / 4 + 1; ++k) {
         const int4 q = ld4k(kind, -4 + 4 * k);
         v[4 * k + 0] = q.x;
         v[4 * k + 1] = q.y;
@@ -967,25 +1038,26 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
         for (int ord = 0; ord < 5; ++ord) ls[ord] = (double)sref[ord * 64];
       } else {
       {
-        uint32_t b[68];
+        uint32_t b[SPL + 4];
         fixed_load(b);
 #pragma unroll
-        for (int i = 0; i < 68; ++i) b[i] ^= 0x80000000u;
+        for (int i = 0; i < SPL + 4; ++i) b[i] ^= 0x80000000u;
 #pragma unroll
         for (int ord = 0; ord < 5; ++ord) {
-          uint32_t c[4] = {0u, 0u, 0u, 0u};
+          uint32_t c[5] = {0u, 0u, 0u, 0u, 0u};  // (the fifth: samples 64..71 of a 72-sample lane)
           if (ord == 0) {
 #pragma unroll
-            for (int j = 0; j < 64; ++j) c[j >> 4] = sad_u32(b[4 + j], 0x80000000u, c[j >> 4]);
+            for (int j = 0; j < SPL; ++j) c[j >> 4] = sad_u32(b[4 + j], 0x80000000u, c[j >> 4]);
           } else {
 #pragma unroll
-            for (int j = 0; j < 64; ++j) c[j >> 4] = sad_u32(b[4 + j], b[3 + j], c[j >> 4]);
+            for (int j = 0; j < SPL; ++j) c[j >> 4] = sad_u32(b[4 + j], b[3 + j], c[j >> 4]);
             if (ord < 4) {
 #pragma unroll
-              for (int i = 67; i >= ord; --i) b[i] = (b[i] - b[i - 1]) ^ 0x80000000u;
+              for (int i = SPL + 3; i >= ord; --i) b[i] = (b[i] - b[i - 1]) ^ 0x80000000u;
             }
           }
           ls[ord] = ((double)c[0] + (double)c[1]) + ((double)c[2] + (double)c[3]);
+          if (SPL > 64) ls[ord] += (double)c[4];  // (exact integers below 2^53: the order of these adds is immaterial)
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -1002,7 +1074,7 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
       // first minimum of the keys is the minimum of (key << 3 | order).
       const int G = 1 << g;
       const int jsub = lane & (G - 1);
-      const uint32_t psize = 64u << g;
+      const uint32_t psize = (uint32_t)SPL << g;
       uint32_t best_packed = 0xFFFFFFFFu;
 #pragma unroll 1
       for (int r = 0; r * G <= (int)a.fixed_max_order; ++r) {
@@ -1036,7 +1108,7 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
 
   auto put_own_e = [&](int32_t* buf) {
 #pragma unroll
-    for (int k = 0; k < 64; k += 4) {
+    for (int k = 0; k < SPL; k += 4) {
       int4 v;
       v.x = e[k + 0];
       v.y = e[k + 1];
@@ -1059,7 +1131,7 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
 #pragma unroll 1
     for (int lvl = 1; lvl <= cand; ++lvl) {
 #pragma unroll
-      for (int i = 67; i >= 1; --i) ebuf[i] = (int32_t)((uint32_t)ebuf[i] - (uint32_t)ebuf[i - 1]);
+      for (int i = SPL + 3; i >= 1; --i) ebuf[i] = (int32_t)((uint32_t)ebuf[i] - (uint32_t)ebuf[i - 1]);
     }
     // the first `order` errors are never coded (Residual keeps zeros there, coding.rs:151-160)
 #pragma unroll
@@ -1100,9 +1172,11 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
       constexpr bool WIDE = decltype(wide_tag)::value;
       auto ld4 = [&](int t) { return ld4k(kind, t); };
       int sw[HP + 16];
+      constexpr int NCH = (SPL + 15) / 16;  // 4 chunks of 16; 4608-sample blocks: + one of 8
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int t0 = 16 * i;  // relative to tl
+      for (int i = 0; i < NCH; ++i) {
+        const int t0 = 16 * i;  // relative to the lane's first sample
+        const int cn = (SPL - 16 * i) < 16 ? (SPL - 16 * i) : 16;  // samples in this chunk (compile-time per i)
         // compiler-level memory barrier: keeps the next chunk's LDS reads from being hoisted
         // above this chunk's arithmetic (which would cost VGPRs and an occupancy step)
         asm volatile("" ::: "memory");
@@ -1113,6 +1187,7 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
         const int first = (i == 0) ? 0 : HP;
 #pragma unroll
         for (int k = first; k < HP + 16; k += 4) {
+          if (k >= HP + cn) continue;
           const int4 v = ld4(t0 - HP + k);
           sw[k + 0] = v.x;
           sw[k + 1] = v.y;
@@ -1121,6 +1196,7 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
         }
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
+          if (k >= cn) continue;
           if (!WIDE) {
             int32_t pred = __mul24(cq[0], sw[HP + k - 1]);
 #pragma unroll
@@ -1204,7 +1280,7 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
         }
       }
     };
-    const bool dot_ok = !wide && role_min >= -32768 && role_max <= 32767;
+    const bool dot_ok = SPL == 64 && !wide && role_min >= -32768 && role_max <= 32767;
     with_role([&](auto kind) {
       constexpr int KIND = decltype(kind)::value;
       // (no v_mad_i32_i24 variant any more: it issued as many instructions as the 64-bit one -- both cost one
@@ -1218,7 +1294,7 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
       if ((lane == 0 && k < warm) || status != 0) e[k] = 0;
     if (status != 0) {
 #pragma unroll
-      for (int k = 16; k < 64; ++k) e[k] = 0;
+      for (int k = 16; k < SPL; ++k) e[k] = 0;
     }
   }
   __builtin_amdgcn_sched_barrier(0);
@@ -1234,7 +1310,7 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
   if (!DECIDE) {
     auto put_own = [&](int32_t* buf) {
 #pragma unroll
-      for (int k = 0; k < 64; k += 4) {
+      for (int k = 0; k < SPL; k += 4) {
         int4 v;
         v.x = e[k + 0];
         v.y = e[k + 1];
@@ -1250,13 +1326,16 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
       for (int half = 0; half < 2; ++half) {
         if ((wave >> 1) == half) put_own(sm + (wave & 1) * kBufDwords);
         __syncthreads();
+        constexpr int NQ2 = 2 * G::Quads;
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
+        for (int it = 0; it < (NQ2 + 255) / 256; ++it) {
           const int q = tid + it * 256;
-          const int ch = q >> 10;
-          const int t = (q & 1023) << 2;
-          const int4 v = *reinterpret_cast<const int4*>(&sm[ch * kBufDwords + widx(t)]);
-          *reinterpret_cast<int4*>(dst0 + (size_t)(2 * half + ch) * a.residual_stride + t) = v;
+          if ((NQ2 % 256) == 0 || q < NQ2) {
+            const int ch = q >= G::Quads ? 1 : 0;
+            const int qq = q - ch * G::Quads;
+            const int4 v = *reinterpret_cast<const int4*>(&sm[ch * kBufDwords + G::qidx(qq)]);
+            *reinterpret_cast<int4*>(dst0 + (size_t)(2 * half + ch) * a.residual_stride + (qq << 2)) = v;
+          }
         }
         if (half == 0) __syncthreads();
       }
@@ -1265,10 +1344,10 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
       int32_t* own = sm + wave * kBufDwords;
       put_own(own);
 #pragma unroll
-      for (int it = 0; it < 16; ++it) {
-        const int t = (lane + it * 64) << 2;
-        const int4 v = *reinterpret_cast<const int4*>(&own[widx(t)]);
-        *reinterpret_cast<int4*>(dst + t) = v;
+      for (int it = 0; it < G::Quads / 64; ++it) {
+        const int qq = lane + it * 64;
+        const int4 v = *reinterpret_cast<const int4*>(&own[G::qidx(qq)]);
+        *reinterpret_cast<int4*>(dst + (qq << 2)) = v;
       }
     }
   }
@@ -1300,6 +1379,21 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
     planes_add<5>(pc, pd);
     planes_add<6>(pl, pc);
     __builtin_amdgcn_sched_barrier(0);
+    if (SPL == 72) {
+      // samples 64..71 of a 72-sample partition: counts <= 72 still fit the seven planes
+      int32_t t8[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) t8[k] = k < 8 ? e[(SPL == 72 ? 64 : 0) + k] : 0;
+      popcount_planes16(t8, pd);
+      uint32_t carry = 0;
+#pragma unroll
+      for (int k = 0; k < 7; ++k) {
+        const uint32_t x_ = pl[k], y_ = k < 5 ? pd[k] : 0u;
+        pl[k] = __builtin_amdgcn_bitop3_b32(x_, y_, carry, 0x96);
+        carry = __builtin_amdgcn_bitop3_b32(x_, y_, carry, 0xE8);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
   // a bit is set in some word <=> its count is non-zero <=> it is set in some plane; and the
   // OR of the zig-zag codes u = 2 m + neg is (OR m) << 1 | (any neg)
@@ -1312,12 +1406,13 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
   // with the search not cut short by the configuration, every minimum is <= 4 + len*(bitlen+1)
   // and level totals fit 32 bits; otherwise sum in two 16-bit halves
   const bool small_bits = a.max_rice_parameter >= bitlen;
-  const uint32_t len0 = 64u - (lane == 0 ? (uint32_t)warm : 0u);
+  const uint32_t len0 = (uint32_t)SPL - (lane == 0 ? (uint32_t)warm : 0u);
 
   const bool finest_only = a.rice_finest_only != 0;
   RiceResult rr;
   unsigned long long sat_sum_q = 0;  // exact sum of quotients, only evaluated if a minimum saturated
-  if (maxu < (1u << 26)) {
+  // (the exact sums of a partition must fit 32 bits: 64 codes below 2^26, 72 codes below 2^25)
+  if (maxu < (1u << (SPL == 64 ? 26 : 25))) {
     // rice_window: a lower end for the parameter search.  For a partition (or merged group)
     // with sum S over len samples and mean m = S / len let p0 = floor(log2(m + 1)).  From
     // S/2^p - len < sum_i (u_i >> p) <= S/2^p:  table[p0] - 4 < len (p0 + 3)  and, for
@@ -1325,9 +1420,11 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
     // win or tie.  A group's mean is at least the smallest 64-sample partition mean, so the
     // wave-minimum of the (conservatively rounded) per-lane p0 bounds every order.  If the
     // configured max_p lies below that, the same inequalities leave max_p as the only candidate.
-    const uint32_t s0 = 2u * ps.sum_m + ps.negs;  // sum of the lane's 64 codes (< 2^32: u < 2^26)
+    const uint32_t s0 = 2u * ps.sum_m + ps.negs;  // sum of the lane's codes (< 2^32, see above)
     const uint32_t q0 = (s0 >> 6) + 1u;
-    const uint32_t p0min = wave_min_dpp(31u - (uint32_t)__builtin_clz(q0));
+    // (72-sample partitions: floor(S / 128) + 1 <= S / 72 + 1 keeps the lower end conservative)
+    const uint32_t q0lo = SPL == 64 ? q0 : (s0 >> 7) + 1u;
+    const uint32_t p0min = wave_min_dpp(31u - (uint32_t)__builtin_clz(q0lo));
     uint32_t p_lo = p0min > 2u ? p0min - 2u : 0u;
     p_lo = p_lo < max_p ? p_lo : max_p;
     // Upper end: table[p + 1] - table[p] = len - sum_i ceil((u_i >> p) / 2) >= len - S / 2^p, which is positive
@@ -1351,7 +1448,7 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
     bool nosat = false;
     if (!FIXED) {
       const uint32_t tot_hi = wave_sum_dpp(s0 >> 6);  // sum over lanes of floor(s0 / 64): < 2^32
-      nosat = small_bits && bitlen <= 24u && tot_hi < ((kMaxPToBits - 4u - 131072u) >> 6) - 64u;
+      nosat = small_bits && bitlen <= 24u && tot_hi < ((kMaxPToBits - 4u - (uint32_t)kWaveN * 32u) >> 6) - 64u;
     }
     if (!FIXED && nosat) rr = rice_search<true, true>(ps, nullptr, len0, p_lo, p_hi, max_p, small_bits, lane, warm, finest_only);
     else rr = rice_search<true>(ps, nullptr, len0, p_lo, p_hi, max_p, small_bits, lane, warm, finest_only);
@@ -1368,11 +1465,11 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
                   (unsigned long long)wave_sum_dpp((uint32_t)(mine & 0xFFFFu));
     }
   } else {
-    int32_t handed[64];  // private memory, written on this path only; e[] itself stays in registers
+    int32_t handed[SPL];  // private memory, written on this path only; e[] itself stays in registers
 #pragma unroll
-    for (int k = 0; k < 64; ++k) handed[k] = e[k];
+    for (int k = 0; k < SPL; ++k) handed[k] = e[k];
     RiceLiteralResult lit;
-    rice_search_literal(handed, len0, max_p, small_bits ? 1 : 0, lane, warm, finest_only ? 1 : 0, &lit);
+    rice_search_literal<SPL>(handed, len0, max_p, small_bits ? 1 : 0, lane, warm, finest_only ? 1 : 0, &lit);
     rr = lit.rr;
     sat_sum_q = lit.sum_q;
   }
@@ -1475,14 +1572,14 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
 #pragma unroll 1
         for (int lvl = 1; lvl <= fx.order; ++lvl) {
 #pragma unroll
-          for (int i = 67; i >= 1; --i) ebuf[i] = (int32_t)((uint32_t)ebuf[i] - (uint32_t)ebuf[i - 1]);
+          for (int i = SPL + 3; i >= 1; --i) ebuf[i] = (int32_t)((uint32_t)ebuf[i] - (uint32_t)ebuf[i - 1]);
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k)
           if (lane == 0 && k < fx.order) e[k] = 0;
       } else if (kind < 2u) {
 #pragma unroll
-        for (int k = 0; k < 64; ++k) e[k] = 0;
+        for (int k = 0; k < SPL; ++k) e[k] = 0;
       }
       {
         // own image -> coalesced store (only this wave touches its image)
@@ -1490,10 +1587,10 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
         int32_t* __restrict__ dst = a.residual + (size_t)sf * a.residual_stride;
         put_own_e(own);
 #pragma unroll
-        for (int it = 0; it < 16; ++it) {
-          const int t = (lane + it * 64) << 2;
-          const int4 v = *reinterpret_cast<const int4*>(&own[widx(t)]);
-          *reinterpret_cast<int4*>(dst + t) = v;
+        for (int it = 0; it < G::Quads / 64; ++it) {
+          const int qq = lane + it * 64;
+          const int4 v = *reinterpret_cast<const int4*>(&own[G::qidx(qq)]);
+          *reinterpret_cast<int4*>(dst + (qq << 2)) = v;
         }
       }
       flacenc_hip_channel_result* out = a.chan_results + sf;
@@ -1567,7 +1664,7 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
 #pragma unroll 1
         for (int lvl = 1; lvl <= fx.order; ++lvl) {
 #pragma unroll
-          for (int i = 67; i >= 1; --i) ebuf[i] = (int32_t)((uint32_t)ebuf[i] - (uint32_t)ebuf[i - 1]);
+          for (int i = SPL + 3; i >= 1; --i) ebuf[i] = (int32_t)((uint32_t)ebuf[i] - (uint32_t)ebuf[i - 1]);
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k)
@@ -1739,7 +1836,7 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
     if (slot >= 0) {
       if (kind < 2u) {
 #pragma unroll
-        for (int k = 0; k < 64; ++k) e[k] = 0;
+        for (int k = 0; k < SPL; ++k) e[k] = 0;
       }
       put_own_e(sm + slot * kBufDwords);
     }
@@ -1754,16 +1851,19 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
       // q = tid + 256 it with ch = q >> 10, each store cost 19 VALU instructions of 64-bit address arithmetic).
       uint32_t tid_out = (uint32_t)tid;
       asm volatile("" : "+v"(tid_out));
-      const uint32_t lds0 = ((tid_out >> 4) + 1u) * (uint32_t)kSeg + ((tid_out & 15u) << 2);  // widx(4 tid)
-      const uint32_t goff = tid_out << 2;                                                      // dwords
+      const uint32_t goff = tid_out << 2;  // dwords
 #pragma unroll
       for (int ch = 0; ch < 2; ++ch) {
         const int32_t* const simg = sm + ch * kBufDwords;
         int32_t* __restrict__ const drow = dst0 + (size_t)ch * a.residual_stride;
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-          const int4 v = *reinterpret_cast<const int4*>(&simg[lds0 + (uint32_t)(it * 16 * kSeg)]);
-          *reinterpret_cast<int4*>(drow + it * 1024 + goff) = v;
+        for (int it = 0; it < (G::Quads + 255) / 256; ++it) {
+          // (for 4096: ((tid >> 4) + 1 + 16 it) * 68 + ((tid & 15) << 2), one base + immediates)
+          const int qq = (int)tid_out + it * 256;
+          if ((G::Quads % 256) == 0 || qq < G::Quads) {
+            const int4 v = *reinterpret_cast<const int4*>(&simg[G::qidx(qq)]);
+            *reinterpret_cast<int4*>(drow + it * 1024 + goff) = v;
+          }
         }
       }
     }
@@ -1813,11 +1913,12 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
   }
 }
 
-template <int MAXP, bool STEREO, bool DECIDE, bool FIXED, bool PACK>
+template <int MAXP, bool STEREO, bool DECIDE, bool FIXED, bool PACK, int SPL = 64>
 hipError_t launch_wave4096(const QlpcKernelArgs& a, hipStream_t stream) {
-  auto kern = qlpc_wave4096_kernel<MAXP, STEREO, DECIDE, FIXED, PACK>;
-  // images (+ window) + exchange: [4][MAXP + 1] f64 (+ [4][16] i32 unless overlaid, see kXqOverlay)
-  constexpr size_t smem = (size_t)(STEREO ? 3 : 4) * kBufDwords * 4 + ((MAXP > 10 && !PACK) ? 4 * (MAXP + 1) * 8 : 4 * ((MAXP + 1) * 8 + 64));
+  auto kern = qlpc_wave4096_kernel<MAXP, STEREO, DECIDE, FIXED, PACK, SPL>;
+  // images (+ window, 4096-sample stereo only) + exchange: [4][MAXP + 1] f64 (+ [4][16] i32 unless overlaid, see kXqOverlay)
+  constexpr size_t smem = (size_t)(STEREO ? (SPL == 64 ? 3 : 2) : 4) * WaveGeom<SPL>::Buf * 4 +
+                          ((MAXP > 10 && !PACK) ? 4 * (MAXP + 1) * 8 : 4 * ((MAXP + 1) * 8 + 64));
   static DynamicLdsOptIn opt_in;  // per instantiation, per device inside
   if (hipError_t err = opt_in.ensure(reinterpret_cast<const void*>(kern), smem); err != hipSuccess) return err;
   const uint32_t blocks = STEREO ? a.n_subframes / 4u : (a.n_subframes + 3u) / 4u;

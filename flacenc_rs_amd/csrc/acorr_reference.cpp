@@ -2,14 +2,18 @@
 //
 // weighted_auto_correlation_nosimd (src/lpc.rs:533-548) keeps ONE accumulator per lag and walks the
 // block once:  for t in P..n { for tau in 0..=P { R[tau] = fma(x_w[t - tau], x_w[t], R[tau]) } }.
-// A chain of n dependent fma per lag cannot be split over lanes without changing the roundings, so
-// here a LANE owns a subframe and walks it serially with P + 1 independent chains (the layout of
-// levinson_batch_kernel); a wave covers 64 subframes = 16 stereo frames x {L, R, M, S}.  Global loads
-// stay coalesced by going through LDS tiles: the wave reads 64 consecutive samples of each of its rows
-// (16 lanes x 16 bytes per row), windows them in f32 exactly as fill_windowed_signal does
+// A chain of n dependent fma per lag cannot be split over lanes without changing the roundings, but the
+// chains of different lags are independent.  So a LANE owns (one subframe, four lags) and walks the block
+// serially with four chains; a WAVE covers 64 subframes = 16 stereo frames x {L, R, M, S} for one group of
+// four lags, and a workgroup is the ceil((P + 1) / 4) waves of those 64 subframes, sharing one staging of
+// the windowed signal.  (Round 2 had a lane carry all P + 1 chains of its subframe: 1.5 waves per SIMD at
+// the benchmark's batch, each a serial stream of 80 000 instructions -- 580 us where the arithmetic is 130.)
+// Global loads stay coalesced by going through LDS tiles: the workgroup reads 64 consecutive samples of each
+// of its rows (16 lanes x 16 bytes per row), windows them in f32 exactly as fill_windowed_signal does
 // (src/lpc.rs:739-756; M = (l + r) >> 1 and S = l - r formed here, src/coding.rs:483), and stores
-// them transposed-friendly (68-float rows) so that lane r then streams row r with ds_read_b128.
-// The next tile's loads are in flight while the current one is summed.
+// them transposed-friendly (68-float rows) so that lane r then streams row r with ds_read_b128.  Two
+// tiles form a ring: the lagged stream of lag group g trails the current one by 4 g samples and reads
+// the previous tile's tail.  The next tile's loads are in flight while the current one is summed.
 //
 // Steps with t < P are masked to x_w[t] = 0 instead of skipped: fma(y, 0, acc) == acc for every
 // accumulator value that can occur (accumulators start at +0 and can never become -0), so the chain
@@ -26,148 +30,249 @@ namespace {
 
 constexpr int kTile = 64;  // samples per tile
 constexpr int kRow = 68;   // floats per LDS row (64 + 4: lane r reading its row with b128 hits its own 4 banks)
+constexpr int kLpl = 4;    // lags per lane
+constexpr int kTileFloats = 64 * kRow;
+#ifndef FLACENC_ACREF_LPF
+#define FLACENC_ACREF_LPF 0  // a step's LDS reads issued one step ahead (slower: the rolled loop rotates them through moves)
+#endif
+#ifndef FLACENC_ACREF_UNROLL
+#define FLACENC_ACREF_UNROLL 1
+#endif
+#define FLACENC_PRAGMA_(x) _Pragma(#x)
+#define FLACENC_PRAGMA(x) FLACENC_PRAGMA_(x)
 
-template <int MAXP, bool STEREO>
-__global__ void __launch_bounds__(64) acorr_reference_kernel(AcorrRefArgs a) {
-  constexpr int HP = MAXP;  // lagged values kept in registers in front of the current 8
-  constexpr int NLOAD = STEREO ? 4 : 16;  // row groups of 4 rows (16 lanes x 16 B each) per tile
-  __shared__ __attribute__((aligned(16))) float tile[2][64 * kRow];
-  const int lane = threadIdx.x;
+template <bool STEREO>
+__global__ void __launch_bounds__(576) acorr_reference_kernel(AcorrRefArgs a) {
+  __shared__ __attribute__((aligned(16))) float tile[2 * kTileFloats];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // = lag group
   const int n = (int)a.block_size;
   const int P = (int)a.lpc_order;
   const uint32_t sf0 = blockIdx.x * 64u;
   const int n_tiles = (n + kTile - 1) / kTile;
-  const int sub = lane >> 4;           // which of the 4 rows of a load group
-  const int col = (lane & 15) << 2;    // first of this lane's 4 samples inside the tile
   const bool vec_ok = ((reinterpret_cast<uintptr_t>(a.samples) & 15) == 0) && ((a.stride & 3) == 0);
   const float* __restrict__ wtab = a.window ? a.window + 32 : nullptr;
 
-  int4 rawA[NLOAD], rawB[STEREO ? NLOAD : 1];
-  float4 wv;
-  // global -> registers for tile k: rows of this wave's subframes, samples [64 k, 64 k + 64)
-  auto issue = [&](int k) {
-    const int t = k * kTile + col;
-    const bool full = vec_ok && (k + 1) * kTile <= n;
-    auto ld = [&](const int32_t* row) -> int4 {
-      if (full) return *reinterpret_cast<const int4*>(row + t);
-      int4 v;
-      v.x = t + 0 < n ? row[t + 0] : 0;
-      v.y = t + 1 < n ? row[t + 1] : 0;
-      v.z = t + 2 < n ? row[t + 2] : 0;
-      v.w = t + 3 < n ? row[t + 3] : 0;
-      return v;
-    };
+  // the tile "in front of the block": zeros (read by the lagged streams, and multiplied by the masked
+  // x_w[t] = 0 of the steps t < P -- it must not hold NaN patterns)
+  for (int i = tid; i < kTileFloats; i += (int)blockDim.x) tile[kTileFloats + i] = 0.0f;
+
+  // global -> registers, cooperatively and for TWO tiles at a time: item = (row pair or row, 16-byte piece), 16
+  // consecutive threads read 256 consecutive bytes of a row for tile k and the 256 behind them for tile k + 1
+  // (512-byte runs per row: 256-byte ones alone left the loads at 2.6 TB/s of DRAM page misses).  STEREO: 16
+  // frames x 16 pieces, both channels per item (M and S are formed by the thread that holds l and r); plain:
+  // 64 rows x 16 pieces.  The launch provides at least 128 (plain: 256) threads, so a thread has at most IT items.
+  constexpr int NITEM = STEREO ? 256 : 1024;
+  constexpr int IT = STEREO ? 2 : 4;
+  const int nthreads = (int)blockDim.x;
+  int4 rA0[IT], rA1[IT], rB0[STEREO ? IT : 1], rB1[STEREO ? IT : 1];  // set 0: the even tile, set 1: the odd one
+  float4 w0, w1;
+  auto ld_row = [&](const int32_t* row, int t, bool full) __attribute__((always_inline)) -> int4 {
+    if (full) return *reinterpret_cast<const int4*>(row + t);
+    int4 v;
+    v.x = t + 0 < n ? row[t + 0] : 0;
+    v.y = t + 1 < n ? row[t + 1] : 0;
+    v.z = t + 2 < n ? row[t + 2] : 0;
+    v.w = t + 3 < n ? row[t + 3] : 0;
+    return v;
+  };
+  auto ld_w = [&](int t) __attribute__((always_inline)) -> float4 {
+    float4 w = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+    if (wtab) {
+      w.x = t + 0 < n ? wtab[t + 0] : 0.0f;
+      w.y = t + 1 < n ? wtab[t + 1] : 0.0f;
+      w.z = t + 2 < n ? wtab[t + 2] : 0.0f;
+      w.w = t + 3 < n ? wtab[t + 3] : 0.0f;
+    }
+    return w;
+  };
+  // row pointers of the thread's items, once (rows beyond the batch shadow the last valid one: same loads,
+  // nothing stored for them at the end)
+  const int col = (tid & 15) << 2;  // the same for all of a thread's items: the workgroup size is a multiple of 16
+  const int32_t* rowp[IT];
 #pragma unroll
-    for (int j = 0; j < NLOAD; ++j) {
-      const uint32_t rr = (uint32_t)(j * 4 + sub);
-      if (STEREO) {
-        const uint32_t frame = (sf0 >> 2) + rr;
-        if (frame * 4u < a.n_subframes) {
-          rawA[j] = ld(a.samples + (size_t)(2u * frame) * a.stride);
-          rawB[j] = ld(a.samples + (size_t)(2u * frame + 1u) * a.stride);
-        } else {
-          rawA[j] = make_int4(0, 0, 0, 0);
-          rawB[j] = make_int4(0, 0, 0, 0);
+  for (int it = 0; it < IT; ++it) {
+    const uint32_t rr = (uint32_t)((tid + it * nthreads) >> 4);
+    if (STEREO) {
+      uint32_t frame = (sf0 >> 2) + rr;
+      const uint32_t last = (a.n_subframes >> 2) - 1u;
+      frame = frame < last ? frame : last;
+      rowp[it] = a.samples + (size_t)(2u * frame) * a.stride;
+    } else {
+      uint32_t sf = sf0 + rr;
+      sf = sf < a.n_subframes ? sf : a.n_subframes - 1u;
+      rowp[it] = a.samples + (size_t)sf * a.stride;
+    }
+  }
+  // tiles k (even) and k + 1
+  auto issue_pair = [&](int k) __attribute__((always_inline)) {
+    const bool full0 = vec_ok && (k + 1) * kTile <= n;
+    const bool full1 = vec_ok && (k + 2) * kTile <= n;
+    const bool have1 = k + 1 < n_tiles;
+    const int t = k * kTile + col;
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      if (tid + it * nthreads < NITEM) {
+        rA0[it] = ld_row(rowp[it], t, full0);
+        if (STEREO) rB0[it] = ld_row(rowp[it] + a.stride, t, full0);
+        if (have1) {
+          rA1[it] = ld_row(rowp[it], t + kTile, full1);
+          if (STEREO) rB1[it] = ld_row(rowp[it] + a.stride, t + kTile, full1);
         }
-      } else {
-        const uint32_t sf = sf0 + rr;
-        rawA[j] = sf < a.n_subframes ? ld(a.samples + (size_t)sf * a.stride) : make_int4(0, 0, 0, 0);
       }
     }
-    wv = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
-    if (wtab) {
-      wv.x = t + 0 < n ? wtab[t + 0] : 0.0f;
-      wv.y = t + 1 < n ? wtab[t + 1] : 0.0f;
-      wv.z = t + 2 < n ? wtab[t + 2] : 0.0f;
-      wv.w = t + 3 < n ? wtab[t + 3] : 0.0f;
-    }
+    w0 = ld_w(t);
+    if (have1) w1 = ld_w(t + kTile);
   };
   // registers -> LDS: x_w = (f32)s * w, one f32 rounding (lpc.rs:751-754)
-  auto land = [&](float* buf) {
-    auto put = [&](int row, const int4& s) {
-      float4 x;
-      x.x = (float)s.x * wv.x;
-      x.y = (float)s.y * wv.y;
-      x.z = (float)s.z * wv.z;
-      x.w = (float)s.w * wv.w;
-      *reinterpret_cast<float4*>(&buf[row * kRow + col]) = x;
+  auto land = [&](auto set_tag, float* buf) __attribute__((always_inline)) {
+    constexpr int SET = decltype(set_tag)::value;
+    const float4 w = SET ? w1 : w0;
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int item = tid + it * nthreads;
+      if (item < NITEM) {
+        const int rr = item >> 4;
+        auto put = [&](int row, const int4& sv) {
+          float4 x;
+          x.x = (float)sv.x * w.x;
+          x.y = (float)sv.y * w.y;
+          x.z = (float)sv.z * w.z;
+          x.w = (float)sv.w * w.w;
+          *reinterpret_cast<float4*>(&buf[row * kRow + col]) = x;
+        };
+        if (STEREO) {
+          const int4 l = SET ? rA1[it] : rA0[it], r = SET ? rB1[it] : rB0[it];
+          put(4 * rr + 0, l);
+          put(4 * rr + 1, r);
+          put(4 * rr + 2, make_int4((l.x + r.x) >> 1, (l.y + r.y) >> 1, (l.z + r.z) >> 1, (l.w + r.w) >> 1));
+          put(4 * rr + 3, make_int4(l.x - r.x, l.y - r.y, l.z - r.z, l.w - r.w));
+        } else {
+          put(rr, SET ? rA1[it] : rA0[it]);
+        }
+      }
+    }
+  };
+
+  const int L0 = kLpl * wave;  // this wave's lags: L0 .. L0 + NL - 1
+  const float* const myrow = tile + lane * kRow;
+  double acc[kLpl];
+#pragma unroll
+  for (int j = 0; j < kLpl; ++j) acc[j] = 0.0;
+  // lw[i] = x_w[t - L0 - 4 + i] for the step at t: 4 carried + the step's own 8
+  double lw[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) lw[i] = 0.0;
+  // one tile for a wave with NL lags; G0: the group of lags 0..3, whose lagged stream is the current one
+  auto sum_tile = [&](auto nl_tag, auto g0_tag, auto masked_tag, int k) __attribute__((always_inline)) {
+      constexpr int NL = decltype(nl_tag)::value;
+      constexpr bool G0 = decltype(g0_tag)::value;
+      constexpr bool MASKED = decltype(masked_tag)::value;
+      const float* row = myrow + (k & 1) * kTileFloats;
+      // the step's LDS reads are issued one step ahead (all of a tile's reads stay inside the two resident tiles)
+      auto lag_ptr = [&](int u) { return myrow + ((u >> 6) & 1) * kTileFloats + (u & 63); };  // u % 4 == 0, u >= -64
+      float4 x0 = *reinterpret_cast<const float4*>(row);
+      float4 x1 = *reinterpret_cast<const float4*>(row + 4);
+      float4 y0 = x0, y1 = x1;
+      if (!G0) {
+        y0 = *reinterpret_cast<const float4*>(lag_ptr(k * kTile - L0));
+        y1 = *reinterpret_cast<const float4*>(lag_ptr(k * kTile - L0 + 4));
+      }
+FLACENC_PRAGMA(unroll FLACENC_ACREF_UNROLL)
+      for (int step = 0; step < 8; ++step) {
+        if (!FLACENC_ACREF_LPF && step > 0) {
+          x0 = *reinterpret_cast<const float4*>(row + 8 * step);
+          x1 = *reinterpret_cast<const float4*>(row + 8 * step + 4);
+          if (!G0) {
+            const int u = k * kTile + 8 * step - L0;
+            y0 = *reinterpret_cast<const float4*>(lag_ptr(u));
+            y1 = *reinterpret_cast<const float4*>(lag_ptr(u + 4));
+          }
+        }
+        double cur[8];
+        cur[0] = (double)x0.x;
+        cur[1] = (double)x0.y;
+        cur[2] = (double)x0.z;
+        cur[3] = (double)x0.w;
+        cur[4] = (double)x1.x;
+        cur[5] = (double)x1.y;
+        cur[6] = (double)x1.z;
+        cur[7] = (double)x1.w;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) lw[i] = lw[8 + i];
+        if (G0) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) lw[4 + i] = cur[i];
+        } else {
+          lw[4] = (double)y0.x;
+          lw[5] = (double)y0.y;
+          lw[6] = (double)y0.z;
+          lw[7] = (double)y0.w;
+          lw[8] = (double)y1.x;
+          lw[9] = (double)y1.y;
+          lw[10] = (double)y1.z;
+          lw[11] = (double)y1.w;
+        }
+        if (FLACENC_ACREF_LPF && step < 7) {
+          x0 = *reinterpret_cast<const float4*>(row + 8 * step + 8);
+          x1 = *reinterpret_cast<const float4*>(row + 8 * step + 12);
+          if (!G0) {
+            const int u = k * kTile + 8 * step + 8 - L0;  // a multiple of 4, >= -32: quads never straddle tiles
+            y0 = *reinterpret_cast<const float4*>(lag_ptr(u));
+            y1 = *reinterpret_cast<const float4*>(lag_ptr(u + 4));
+          }
+        }
+        const int tb = k * kTile + 8 * step;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+          // t < P: no step of the reference's loop; only the multiplier is masked -- as a lagged value the
+          // sample is read by later steps like any other
+          const double c = (!MASKED || tb + kk >= P) ? cur[kk] : 0.0;
+#pragma unroll
+          for (int j = 0; j < NL; ++j) acc[j] = __builtin_fma(lw[4 + kk - j], c, acc[j]);
+        }
+      }
     };
-#pragma unroll
-    for (int j = 0; j < NLOAD; ++j) {
-      const int rr = j * 4 + sub;
-      if (STEREO) {
-        const int4 l = rawA[j], r = rawB[j];
-        put(4 * rr + 0, l);
-        put(4 * rr + 1, r);
-        put(4 * rr + 2, make_int4((l.x + r.x) >> 1, (l.y + r.y) >> 1, (l.z + r.z) >> 1, (l.w + r.w) >> 1));
-        put(4 * rr + 3, make_int4(l.x - r.x, l.y - r.y, l.z - r.z, l.w - r.w));
-      } else {
-        put(rr, rawA[j]);
-      }
-    }
+  issue_pair(0);
+  __syncthreads();  // (the zero tile)
+  land(std::integral_constant<int, 0>{}, tile);
+  __syncthreads();
+  // lags of this wave; the launch rounds the workgroup up to two (plain: four) waves for the loads, so a wave
+  // may have none
+  const int nl = P + 1 - L0 < kLpl ? P + 1 - L0 : kLpl;
+  auto sum_nl = [&](auto g0_tag, auto masked_tag, int k) __attribute__((always_inline)) {
+    if (nl <= 0) return;
+    if (nl == 1) sum_tile(std::integral_constant<int, 1>{}, g0_tag, masked_tag, k);
+    else if (nl == 2) sum_tile(std::integral_constant<int, 2>{}, g0_tag, masked_tag, k);
+    else if (nl == 3) sum_tile(std::integral_constant<int, 3>{}, g0_tag, masked_tag, k);
+    else sum_tile(std::integral_constant<int, 4>{}, g0_tag, masked_tag, k);
   };
-
-  double dw[HP + 8];
-  double acc[MAXP + 1];
-#pragma unroll
-  for (int i = 0; i < HP + 8; ++i) dw[i] = 0.0;
-#pragma unroll
-  for (int i = 0; i <= MAXP; ++i) acc[i] = 0.0;
-
-  auto sum_tile = [&](auto masked_tag, const float* buf, int t_tile) {
-    constexpr bool MASKED = decltype(masked_tag)::value;
-    const float* row = buf + lane * kRow;
-#pragma unroll 1
-    for (int step = 0; step < 8; ++step) {
-#pragma unroll
-      for (int k = 0; k < HP; ++k) dw[k] = dw[k + 8];
-      const float4 x0 = *reinterpret_cast<const float4*>(row + 8 * step);
-      const float4 x1 = *reinterpret_cast<const float4*>(row + 8 * step + 4);
-      dw[HP + 0] = (double)x0.x;
-      dw[HP + 1] = (double)x0.y;
-      dw[HP + 2] = (double)x0.z;
-      dw[HP + 3] = (double)x0.w;
-      dw[HP + 4] = (double)x1.x;
-      dw[HP + 5] = (double)x1.y;
-      dw[HP + 6] = (double)x1.z;
-      dw[HP + 7] = (double)x1.w;
-      if (MASKED) {
-        // t < P: no step of the reference's loop; as a zero it stays in the window for later lags,
-        // where the reference reads the real x_w[t - tau] -- so only the multiplier is masked
-        const int tb = t_tile + 8 * step;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const double cur = (tb + k >= P) ? dw[HP + k] : 0.0;
-#pragma unroll
-          for (int tau = 0; tau <= MAXP; ++tau) acc[tau] = __builtin_fma(dw[HP + k - tau], cur, acc[tau]);
-        }
-      } else {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const double cur = dw[HP + k];
-#pragma unroll
-          for (int tau = 0; tau <= MAXP; ++tau) acc[tau] = __builtin_fma(dw[HP + k - tau], cur, acc[tau]);
-        }
-      }
-    }
-  };
-
-  issue(0);
-  land(tile[0]);
   for (int k = 0; k < n_tiles; ++k) {
-    if (k + 1 < n_tiles) issue(k + 1);
-    // (one wave per workgroup: LDS accesses of a wave are ordered, no barrier needed)
-    if (k * kTile < P) sum_tile(std::true_type{}, tile[k & 1], k * kTile);
-    else sum_tile(std::false_type{}, tile[k & 1], k * kTile);
-    if (k + 1 < n_tiles) land(tile[(k + 1) & 1]);
+    if (k * kTile < P) {
+      if (wave == 0) sum_nl(std::true_type{}, std::true_type{}, k);
+      else sum_nl(std::false_type{}, std::true_type{}, k);
+    } else {
+      if (wave == 0) sum_nl(std::true_type{}, std::false_type{}, k);
+      else sum_nl(std::false_type{}, std::false_type{}, k);
+    }
+    __syncthreads();  // every wave is done with tile k - 1, whose buffer takes tile k + 1
+    if (k + 1 < n_tiles) {
+      if (k & 1) land(std::integral_constant<int, 0>{}, tile);
+      else land(std::integral_constant<int, 1>{}, tile + kTileFloats);
+    }
+    __syncthreads();
+    // both register sets are parked: the next pair of tiles has the whole of tile k + 1's sums to arrive
+    if ((k & 1) == 0 && k + 2 < n_tiles) issue_pair(k + 2);
   }
-
   const uint32_t sf = sf0 + (uint32_t)lane;
   if (sf < a.n_subframes) {
     double* __restrict__ o = a.out + (size_t)sf * 33;
 #pragma unroll
-    for (int tau = 0; tau <= MAXP; ++tau) o[tau] = tau <= P ? acc[tau] : 0.0;
-    for (int tau = MAXP + 1; tau < 33; ++tau) o[tau] = 0.0;
+    for (int j = 0; j < kLpl; ++j)
+      if (j < nl) o[L0 + j] = acc[j];  // (nl <= 0: a loading-only wave)
+    if (wave == 0)
+      for (int tau = P + 1; tau < 33; ++tau) o[tau] = 0.0;
   }
 }
 
@@ -287,11 +392,13 @@ hipError_t launch_nightly(const AcorrRefArgs& a, hipStream_t stream) {
   return hipGetLastError();
 }
 
-template <int MAXP>
-hipError_t launch_bucket(const AcorrRefArgs& a, hipStream_t stream) {
+hipError_t launch_stable(const AcorrRefArgs& a, hipStream_t stream) {
   const uint32_t blocks = (a.n_subframes + 63u) / 64u;
-  if (a.stereo) hipLaunchKernelGGL((acorr_reference_kernel<MAXP, true>), dim3(blocks), dim3(64), 0, stream, a);
-  else hipLaunchKernelGGL((acorr_reference_kernel<MAXP, false>), dim3(blocks), dim3(64), 0, stream, a);
+  uint32_t groups = (a.lpc_order + 1u + (uint32_t)kLpl - 1u) / (uint32_t)kLpl;  // 1..9 lag groups = waves
+  const uint32_t min_waves = a.stereo ? 2u : 4u;  // (the cooperative loads want 128 / 256 threads)
+  groups = groups < min_waves ? min_waves : groups;
+  if (a.stereo) hipLaunchKernelGGL((acorr_reference_kernel<true>), dim3(blocks), dim3(64u * groups), 0, stream, a);
+  else hipLaunchKernelGGL((acorr_reference_kernel<false>), dim3(blocks), dim3(64u * groups), 0, stream, a);
   return hipGetLastError();
 }
 
@@ -301,13 +408,8 @@ hipError_t launch_acorr_reference(const AcorrRefArgs& a, hipStream_t stream) {
   if (a.n_subframes == 0) return hipSuccess;
   if (a.stereo && (a.n_subframes & 3u)) return hipErrorInvalidValue;
   if (a.nightly) return launch_nightly(a, stream);
-  const uint32_t P = a.lpc_order;
-  if (P <= 8) return launch_bucket<8>(a, stream);
-  if (P <= 12) return launch_bucket<12>(a, stream);
-  if (P <= 16) return launch_bucket<16>(a, stream);
-  if (P <= 24) return launch_bucket<24>(a, stream);
-  if (P <= 32) return launch_bucket<32>(a, stream);
-  return hipErrorInvalidValue;
+  if (a.lpc_order > 32u) return hipErrorInvalidValue;
+  return launch_stable(a, stream);
 }
 
 }  // namespace flacenc_hip

@@ -837,7 +837,7 @@ __global__ void __launch_bounds__(256, 2) bigblock_fixed_select_kernel(QlpcKerne
           for (int j = 0; j < 64; ++j) c[j >> 4] = sad_u32(b[4 + j], b[3 + j], c[j >> 4]);
           if (ord < 4) {
 #pragma unroll
-            for (int i = 67; i >= ord; --i) b[i] = (b[i] - b[i - 1]) ^ 0x80000000u;
+            for (int i = 67; i >= ord; --i) b[i] = xad_u32(b[i - 1], 0x7FFFFFFFu, b[i]);  // (bias 2^31 - 1 from here on)
           }
         }
         ls[ord] = ((double)c[0] + (double)c[1]) + ((double)c[2] + (double)c[3]);

@@ -77,6 +77,14 @@ hipError_t launch_qlpc(const QlpcKernelArgs& a, const QlpcLaunchPlan& plan, hipS
   if ((a.frame_results || a.chan_results) && !wave_kernel_eligible(a)) return hipErrorNotSupported;
   if (a.reference_order && a.sumabs_in == nullptr && a.sumabs_scratch != nullptr && a.lpc_stage == 0 &&
       (a.fixed_mode == 1u || (a.fixed_mode == 0 && a.use_fixed && a.fixed_order_sel == 1u && (a.frame_results || a.chan_results)))) {
+    if (a.fixed_mode == 0 && a.sumabs_mode == 0 && a.bps == nullptr && a.bps_uniform <= 16u && a.pack_out == nullptr) {
+      // the fused kernel on material of at most 16 bits (side channel: 17): its exact sums are the reference's
+      // f32 chains unless a partition reaches 2^24, and it walks those itself (QlpcKernelArgs::sumabs_mode)
+      QlpcKernelArgs b = a;
+      b.sumabs_mode = a.reference_order;
+      b.sumabs_scratch = nullptr;
+      return launch_qlpc(b, plan, stream);
+    }
     // Reference summation order for fixed_lpc's ApproxEnt selector: every estimator partition's sum of |e|
     // as find_sum_abs_f32's own f32 chain, one (subframe, partition) per lane; the selecting kernels then
     // read the sums instead of adding them up themselves.
@@ -225,8 +233,9 @@ hipError_t launch_qlpc(const QlpcKernelArgs& a, const QlpcLaunchPlan& plan, hipS
   }
   if (wave_kernel_eligible(a)) {
     const int mp = a.lpc_order <= 8 ? 8 : (a.lpc_order <= 10 ? 10 : 12);
-    const int variant = a.stereo ? (a.frame_results ? (a.pack_out ? 5 : (a.use_fixed ? 3 : 2)) : 1)
-                                 : (a.chan_results ? 4 : 0);
+    int variant = a.stereo ? (a.frame_results ? (a.pack_out ? 5 : (a.use_fixed ? 3 : 2)) : 1)
+                           : (a.chan_results ? 4 : 0);
+    if (a.sumabs_mode != 0u && (variant == 3 || variant == 4)) variant += 3;  // the instances with the chain walk
     if (a.block_size == 4608) {
 #define FLACENC_HIP_W72CASE(MP, ST) \
   if (mp == MP && variant == ST) return launch_qlpc_wave72_##MP##_##ST(a, stream);

@@ -42,6 +42,10 @@ struct QlpcKernelArgs {
   // the kernels' exact integer sums: launch_qlpc runs it into `sumabs_scratch` and hands it on as `sumabs_in`
   const float* sumabs_in = nullptr;  // device, [n][5][64]: order k, partition p at [(sf * 5 + k) * 64 + p]
   float* sumabs_scratch = nullptr;   // device, n * 5 * 64 floats, or nullptr
+  // ... except in front of the fused kernel on material of at most 16 bits: there the exact sums ARE the
+  // reference's while a partition stays below 2^24, and the kernel itself walks the rare partition that does not
+  // (1: the stable build's chain, 2: simd-nightly's lane chains) -- set by launch_qlpc, no pre-pass
+  uint32_t sumabs_mode = 0;
   // config::Qlpc::use_direct_mse / mae_optimization_steps (experimental in the reference, src/coding.rs:337-347):
   // the predictor comes from direct_mse_kernel (covariance-method LPC, optionally IRLS) instead of
   // autocorrelation + Levinson; launch_qlpc runs it into split_scratch and continues with the residual kernels
@@ -134,15 +138,15 @@ hipError_t launch_bigblock_fixed_residual(const QlpcKernelArgs& args, hipStream_
 FLACENC_HIP_FOR_EACH_INSTANCE(FLACENC_HIP_DECLARE_INSTANCE)
 
 #define FLACENC_HIP_FOR_EACH_WAVE_INSTANCE(X) \
-  X(8, 0) X(8, 1) X(8, 2) X(8, 3) X(8, 4) X(8, 5) X(10, 0) X(10, 1) X(10, 2) X(10, 3) X(10, 4) X(10, 5) \
-  X(12, 0) X(12, 1) X(12, 2) X(12, 3) X(12, 4) X(12, 5)
+  X(8, 0) X(8, 1) X(8, 2) X(8, 3) X(8, 4) X(8, 5) X(8, 6) X(8, 7) X(10, 0) X(10, 1) X(10, 2) X(10, 3) X(10, 4) X(10, 5) \
+  X(10, 6) X(10, 7) X(12, 0) X(12, 1) X(12, 2) X(12, 3) X(12, 4) X(12, 5) X(12, 6) X(12, 7)
 #define FLACENC_HIP_DECLARE_WAVE_INSTANCE(MP, ST) \
   hipError_t launch_qlpc_wave_##MP##_##ST(const QlpcKernelArgs&, hipStream_t);
 FLACENC_HIP_FOR_EACH_WAVE_INSTANCE(FLACENC_HIP_DECLARE_WAVE_INSTANCE)
 // ... and for blocks of 4608 samples (72 per lane; no fused bit writer)
 #define FLACENC_HIP_FOR_EACH_WAVE72_INSTANCE(X) \
-  X(8, 0) X(8, 1) X(8, 2) X(8, 3) X(8, 4) X(10, 0) X(10, 1) X(10, 2) X(10, 3) X(10, 4) \
-  X(12, 0) X(12, 1) X(12, 2) X(12, 3) X(12, 4)
+  X(8, 0) X(8, 1) X(8, 2) X(8, 3) X(8, 4) X(8, 6) X(8, 7) X(10, 0) X(10, 1) X(10, 2) X(10, 3) X(10, 4) X(10, 6) X(10, 7) \
+  X(12, 0) X(12, 1) X(12, 2) X(12, 3) X(12, 4) X(12, 6) X(12, 7)
 #define FLACENC_HIP_DECLARE_WAVE72_INSTANCE(MP, ST) \
   hipError_t launch_qlpc_wave72_##MP##_##ST(const QlpcKernelArgs&, hipStream_t);
 FLACENC_HIP_FOR_EACH_WAVE72_INSTANCE(FLACENC_HIP_DECLARE_WAVE72_INSTANCE)

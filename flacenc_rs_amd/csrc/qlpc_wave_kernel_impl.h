@@ -30,6 +30,7 @@
 
 #include "frame_bits.h"
 #include "qlpc_kernel_impl.h"
+#include "sumabs_chain.h"
 
 namespace flacenc_hip {
 namespace {
@@ -49,9 +50,13 @@ namespace {
 // deciding / candidate / fixed-LPC variants, and an exchange area 256 bytes smaller, see kXqOverlay) gains too:
 // 1.005 -> 0.815 ms, 1.12 -> 1.02 ms and 1.54 -> 1.29 ms per 24576 frames.  The fused bit writer (PACK) and the
 // independent-channel kernel spill in their inner loops at 168 registers and stay at 2.
+// (variants 6 / 7 are 3 / 4 with the order selector's chain walk: the same budget as their base variant)
+#if defined(FLACENC_STEREO)
+#define FLACENC_BASE_VARIANT (FLACENC_STEREO >= 6 ? FLACENC_STEREO - 3 : FLACENC_STEREO)
+#endif
 #if defined(FLACENC_STEREO) && defined(FLACENC_MAXP) && \
-    ((FLACENC_MAXP <= 10 && (FLACENC_STEREO == 1 || FLACENC_STEREO == 2 || FLACENC_STEREO == 3)) || \
-     (FLACENC_MAXP == 12 && ((FLACENC_ORDER12_OCC3 >> FLACENC_STEREO) & 1)))
+    ((FLACENC_MAXP <= 10 && (FLACENC_BASE_VARIANT == 1 || FLACENC_BASE_VARIANT == 2 || FLACENC_BASE_VARIANT == 3)) || \
+     (FLACENC_MAXP == 12 && ((FLACENC_ORDER12_OCC3 >> FLACENC_BASE_VARIANT) & 1)))
 #define FLACENC_WAVE_OCC 3
 #else
 #define FLACENC_WAVE_OCC 2
@@ -98,6 +103,42 @@ struct WaveGeom {
     return lb + off + (off >= SPL ? (Seg - SPL) : 0) - (off < 0 ? (Seg - SPL) : 0);
   }
 };
+
+// The fixed-LPC order selector's rare path under the reference's summation orders (QlpcKernelArgs::sumabs_mode):
+// an estimator partition whose exact sum of |e| reaches 2^24 is walked serially by its first lane, from the
+// LDS images, with the f32 chains of find_sum_abs_f32 (sumabs_chain.h).  begin == end: nothing to do for this lane.
+template <int SPL, bool NIGHTLY>
+__device__ __forceinline__ void sumabs_chains_walk(const int32_t* bufA, const int32_t* bufB, int kind, int begin, int end,
+                                                   float* out5) {
+  typedef WaveGeom<SPL> G;
+  auto sample = [&](int t) -> uint32_t {
+    const int ix = t < 0 ? SPL + t : G::idx(t);  // (the segment in front of the block holds zeros)
+    const int x = bufA[ix];
+    if (kind < 2) return (uint32_t)x;
+    const int y = bufB[ix];
+    return (uint32_t)(kind == 2 ? (x + y) >> 1 : x - y);
+  };
+  SumAbsChains<NIGHTLY> ch;
+  ch.init(begin, end);
+  const int w0 = begin & ~15;
+  ch.seed(sample(w0 - 4), sample(w0 - 3), sample(w0 - 2), sample(w0 - 1));
+#pragma unroll 1
+  for (int t0 = w0; t0 < end; t0 += 16) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int t = t0 + j;
+      ch.template step<true>(t < end ? sample(t) : 0u, t, j);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 5; ++k) out5[k] = ch.result(k);
+}
+template <int SPL>
+__device__ __attribute__((noinline)) void sumabs_chains_from_lds(const int32_t* bufA, const int32_t* bufB, int kind, int begin,
+                                                                 int end, int nightly, float* out5) {
+  if (nightly) sumabs_chains_walk<SPL, true>(bufA, bufB, kind, begin, end, out5);
+  else sumabs_chains_walk<SPL, false>(bufA, bufB, kind, begin, end, out5);
+}
 
 // |v| with i32::MIN -> 2^31 - 1 + 1 handled by the caller's unsigned compare; inputs are <= 25 bits
 __device__ __forceinline__ int abs_sat(int v) { return v < 0 ? -v : v; }
@@ -321,6 +362,14 @@ __device__ __forceinline__ void planes_add(uint32_t* a, const uint32_t* b) {
   a[NA] = carry;
 }
 
+// (x ^ m) + y (v_xad_u32).  With m = 0x7FFFFFFF it is y - x + (2^31 - 1) mod 2^32: the difference of two values
+// that carry a common bias, itself biased by 2^31 - 1 -- one instruction per differencing step where
+// (y - x) ^ 0x80000000 takes two.
+__device__ __forceinline__ uint32_t xad_u32(uint32_t x, uint32_t m, uint32_t y) {
+  uint32_t r;
+  asm("v_xad_u32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "s"(m), "v"(y));
+  return r;
+}
 // |x - y| + acc on unsigned operands (v_sad_u32)
 __device__ __forceinline__ uint32_t sad_u32(uint32_t x, uint32_t y, uint32_t acc) {
   uint32_t r;
@@ -582,8 +631,11 @@ __device__ __attribute__((noinline)) void rice_search_literal(const int32_t* e, 
 // DECIDE (stereo only): run encode_subframe's candidate choice and try_stereo_coding's channel
 // assignment (coding.rs:384-418 without the fixed-LPC candidate, :493-522) on the device and
 // write one flacenc_hip_stereo_frame_result + the TWO chosen residual rows per frame.
-template <int MAXP, bool STEREO, bool DECIDE, bool FIXED, bool PACK, int SPL = 64>
+// CHAINS: the instances that serve QlpcKernelArgs::sumabs_mode (the selector's rare walk of the reference's f32 chains;
+// instances of their own: the out-of-line call costs the common path of the others 19 spilled registers)
+template <int MAXP, bool STEREO, bool DECIDE, bool FIXED, bool PACK, int SPL = 64, bool CHAINS = false>
 __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(QlpcKernelArgs a) {
+  static_assert(!CHAINS || (FIXED && !PACK), "the chain walk belongs to the fixed-LPC order selector");
   static_assert(!PACK || (STEREO && DECIDE && FIXED), "the fused bit writer extends the full stereo frame kernel");
   static_assert(SPL == 64 || (SPL == 72 && !PACK), "blocks of 4096 (64 samples per lane) or 4608 (72)");
   using G = WaveGeom<SPL>;
@@ -1031,6 +1083,7 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
       // values; 16-sample sub-sums stay below 2^32 for inputs up to 25 bits, then go to f64
       double ls[5];
       const int g = (int)a.fixed_group_log2;
+      uint32_t loud = 0;  // wave-uniform: bit k = some partition's order-k sum reaches 2^24 (sumabs_mode, below)
       if (a.sumabs_in != nullptr) {
         // FLACENC_HIP_FLAG_REFERENCE_SUM_ORDER: find_sum_abs_f32's own f32 chains (sumabs_reference_kernel)
         const float* __restrict__ sref = a.sumabs_in + (size_t)sf * (5 * 64) + (lane >> g);
@@ -1038,22 +1091,44 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
         for (int ord = 0; ord < 5; ++ord) ls[ord] = (double)sref[ord * 64];
       } else {
       {
+        // the role's samples with a bias that makes them non-negative, formed from the images in as few steps
+        // as the unbiased value: own image x ^ 2^31 (bias 2^31), mid (l + r + 2^31) >>> 1 (bias 2^30: the sum
+        // cannot wrap for inputs of at most 25 bits), side (r ^ 0x7FFFFFFF) + l (bias 2^31 - 1)
         uint32_t b[SPL + 4];
-        fixed_load(b);
+        uint32_t bias0 = 0x80000000u;
+        with_role([&](auto kind) {
+          constexpr int KIND = decltype(kind)::value;
+          typedef uint32_t v4u_t __attribute__((ext_vector_type(4)));
+          bias0 = KIND == 2 ? 0x40000000u : KIND == 3 ? 0x7FFFFFFFu : 0x80000000u;
 #pragma unroll
-        for (int i = 0; i < SPL + 4; ++i) b[i] ^= 0x80000000u;
+          for (int k = 0; k < SPL / 4 + 1; ++k) {
+            const int ix = G::rel(lb, -4 + 4 * k);
+            v4u_t va = *reinterpret_cast<const v4u_t*>(&bufA[ix]);
+            asm("" : "+v"(va));
+            if (KIND >= 2) {
+              v4u_t vb = *reinterpret_cast<const v4u_t*>(&bufB[ix]);
+              asm("" : "+v"(vb));
+#pragma unroll
+              for (int q = 0; q < 4; ++q)
+                b[4 * k + q] = KIND == 2 ? (va[q] + vb[q] + 0x80000000u) >> 1 : xad_u32(vb[q], 0x7FFFFFFFu, va[q]);
+            } else {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) b[4 * k + q] = va[q] ^ 0x80000000u;
+            }
+          }
+        });
 #pragma unroll
         for (int ord = 0; ord < 5; ++ord) {
           uint32_t c[5] = {0u, 0u, 0u, 0u, 0u};  // (the fifth: samples 64..71 of a 72-sample lane)
           if (ord == 0) {
 #pragma unroll
-            for (int j = 0; j < SPL; ++j) c[j >> 4] = sad_u32(b[4 + j], 0x80000000u, c[j >> 4]);
+            for (int j = 0; j < SPL; ++j) c[j >> 4] = sad_u32(b[4 + j], bias0, c[j >> 4]);
           } else {
 #pragma unroll
             for (int j = 0; j < SPL; ++j) c[j >> 4] = sad_u32(b[4 + j], b[3 + j], c[j >> 4]);
             if (ord < 4) {
 #pragma unroll
-              for (int i = SPL + 3; i >= ord; --i) b[i] = (b[i] - b[i - 1]) ^ 0x80000000u;
+              for (int i = SPL + 3; i >= ord; --i) b[i] = xad_u32(b[i - 1], 0x7FFFFFFFu, b[i]);
             }
           }
           ls[ord] = ((double)c[0] + (double)c[1]) + ((double)c[2] + (double)c[3]);
@@ -1067,6 +1142,15 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
 #pragma unroll
         for (int ord = 0; ord < 5; ++ord) ls[ord] += __shfl_xor(ls[ord], 1 << lvl, 64);
       }
+      // FLACENC_HIP_FLAG_REFERENCE_SUM_ORDER / _NIGHTLY_SUM_ORDER on material of at most 16 bits (sumabs_mode; there
+      // launch_qlpc leaves sumabs_reference_kernel out): the reference adds |e| as f32, in either order a sum of
+      // non-negative integers whose every partial sum is bounded by the total -- exact, and equal to the sum
+      // above, while the total stays below 2^24 (the sums' own conversions included: |e| <= total).  An order
+      // with a partition at 2^24 or more ("loud") has roundings that depend on the order of the additions.
+      if (CHAINS && a.sumabs_mode != 0u) {
+#pragma unroll
+        for (int ord = 0; ord < 5; ++ord) loud |= __builtin_amdgcn_ballot_w64(ls[ord] >= 16777216.0) != 0ull ? (1u << ord) : 0u;
+      }
       }
       // estimate_entropy for several orders at once: the 2^g lanes of a partition all hold its
       // five sums, so lane j of a group takes order r 2^g + j in pass r.  Its partition estimates
@@ -1075,24 +1159,59 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
       const int G = 1 << g;
       const int jsub = lane & (G - 1);
       const uint32_t psize = (uint32_t)SPL << g;
+      // A loud order's key is known only up to the roundings of its chains: each of a partition's `psize`
+      // additions rounds by at most 2^-24 of the running sum, estimate_entropy's partition term
+      // cnt (avg log2(1 + 1/avg) + log2(avg + 1)), avg = 2 sum / cnt, moves by at most cnt log2(1 + 1/avg) d(avg)
+      // <= 1.45 cnt d(sum)/sum -- below 1.45 * 4608^2 * 2^-24 < 2 bits at the largest partition -- and its f32
+      // evaluation by a fraction of a bit; 16 bits per partition cover both with a wide margin.  A loud order
+      // whose exact-sum key lies further than that above the best quiet key cannot be the minimum, whatever its
+      // chains give; only if one might be (or the keys themselves are asked for) are the chains walked.
+      const uint32_t loud_slack = 16u * (64u >> g);
       uint32_t best_packed = 0xFFFFFFFFu;
+      bool with_slack = CHAINS && loud != 0u;
 #pragma unroll 1
-      for (int r = 0; r * G <= (int)a.fixed_max_order; ++r) {
-        const int ord = r * G + jsub;
-        const bool valid = ord <= (int)a.fixed_max_order;
-        double sv = ls[0];
+      for (;;) {  // (one instance of the evaluation: twice only when chains had to be walked)
+        best_packed = 0xFFFFFFFFu;
+        uint32_t best_loud = 0xFFFFFFFFu;
+#pragma unroll 1
+        for (int r = 0; r * G <= (int)a.fixed_max_order; ++r) {
+          const int ord = r * G + jsub;
+          const bool valid = ord <= (int)a.fixed_max_order;
+          double sv = ls[0];
 #pragma unroll
-        for (int q = 1; q < 5; ++q) sv = (q == ord) ? ls[q] : sv;
-        // sample_count = min(end - warmup, partition_len): only partition 0 loses the warm-up
-        const uint32_t cnt = psize - ((lane >> g) == 0 ? (uint32_t)ord : 0u);
-        uint32_t pb = valid ? approx_ent_bits(sv, cnt) : 0u;
+          for (int q = 1; q < 5; ++q) sv = (q == ord) ? ls[q] : sv;
+          // sample_count = min(end - warmup, partition_len): only partition 0 loses the warm-up
+          const uint32_t cnt = psize - ((lane >> g) == 0 ? (uint32_t)ord : 0u);
+          uint32_t pb = valid ? approx_ent_bits(sv, cnt) : 0u;
 #pragma unroll 1
-        for (int lvl = g; lvl < 6; ++lvl) pb += (uint32_t)__shfl_xor((int)pb, 1 << lvl, 64);
-        const unsigned long long key = (unsigned long long)pb + bps_role * (unsigned long long)ord;
-        if (a.fixed_keys && valid && lane < G) a.fixed_keys[(size_t)sf * 8 + ord] = key;
-        const uint32_t packed = valid ? (((uint32_t)key << 3) | (uint32_t)ord) : 0xFFFFFFFFu;  // key < 2^29
-        const uint32_t m = wave_min_dpp(packed);
-        best_packed = m < best_packed ? m : best_packed;
+          for (int lvl = g; lvl < 6; ++lvl) pb += (uint32_t)__shfl_xor((int)pb, 1 << lvl, 64);
+          const unsigned long long key = (unsigned long long)pb + bps_role * (unsigned long long)ord;
+          if (!with_slack && a.fixed_keys && valid && lane < G) a.fixed_keys[(size_t)sf * 8 + ord] = key;
+          const bool is_loud = with_slack && ((loud >> ord) & 1u) != 0u;
+          const uint32_t k32 = (uint32_t)key;  // key < 2^29
+          const uint32_t packed = (valid && !is_loud) ? ((k32 << 3) | (uint32_t)ord) : 0xFFFFFFFFu;
+          const uint32_t m = wave_min_dpp(packed);
+          best_packed = m < best_packed ? m : best_packed;
+          if (with_slack) {
+            const uint32_t lowered = (valid && is_loud) ? (k32 > loud_slack ? k32 - loud_slack : 0u) : 0xFFFFFFFFu;
+            const uint32_t ml = wave_min_dpp(lowered);
+            best_loud = ml < best_loud ? ml : best_loud;
+          }
+        }
+        if (!CHAINS || !with_slack) break;
+        if (a.fixed_keys == nullptr && best_packed != 0xFFFFFFFFu && best_loud > (best_packed >> 3)) break;
+        // the partitions' first lanes walk them with the reference's chains (sumabs_chain.h)
+        const int gl = G - 1;
+        const bool first = (lane & gl) == 0;
+        const int pbeg = first ? (lane * SPL) : 0, pend = first ? ((lane + gl + 1) * SPL) : 0;
+        float chain[5];
+        sumabs_chains_from_lds<SPL>(bufA, bufB, STEREO ? role : 0, pbeg, pend, a.sumabs_mode == 2u ? 1 : 0, chain);
+#pragma unroll
+        for (int ord = 0; ord < 5; ++ord) {
+          const float v = __shfl(chain[ord], lane & ~gl, 64);
+          ls[ord] = ((loud >> ord) & 1u) ? (double)v : ls[ord];
+        }
+        with_slack = false;
       }
       const unsigned long long best_key = (unsigned long long)(best_packed >> 3);
       const int best_ord = (int)(best_packed & 7u);
@@ -1913,9 +2032,9 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
   }
 }
 
-template <int MAXP, bool STEREO, bool DECIDE, bool FIXED, bool PACK, int SPL = 64>
+template <int MAXP, bool STEREO, bool DECIDE, bool FIXED, bool PACK, int SPL = 64, bool CHAINS = false>
 hipError_t launch_wave4096(const QlpcKernelArgs& a, hipStream_t stream) {
-  auto kern = qlpc_wave4096_kernel<MAXP, STEREO, DECIDE, FIXED, PACK, SPL>;
+  auto kern = qlpc_wave4096_kernel<MAXP, STEREO, DECIDE, FIXED, PACK, SPL, CHAINS>;
   // images (+ window, 4096-sample stereo only) + exchange: [4][MAXP + 1] f64 (+ [4][16] i32 unless overlaid, see kXqOverlay)
   constexpr size_t smem = (size_t)(STEREO ? (SPL == 64 ? 3 : 2) : 4) * WaveGeom<SPL>::Buf * 4 +
                           ((MAXP > 10 && !PACK) ? 4 * (MAXP + 1) * 8 : 4 * ((MAXP + 1) * 8 + 64));

@@ -23,6 +23,8 @@
 // i32::MIN, which 25-bit inputs cannot produce at order <= 4 (|e_4| <= 16 * 2^24).
 #include "sumabs_reference.h"
 
+#include "sumabs_chain.h"
+
 namespace flacenc_hip {
 namespace {
 
@@ -87,67 +89,15 @@ __global__ void __launch_bounds__(256) sumabs_reference_kernel(SumAbsRefArgs a) 
   const int end = begin + psz < n ? begin + psz : n;
   const int b4 = begin & ~3;
 
-  // state of the differencing at t = b4 - 1 (zero-extended signal in front of the block)
-  uint32_t sp, e1p, e2p, e3p;
+  // state of the differencing at t = b4 - 1 (zero-extended signal in front of the block); the chains themselves
+  // are SumAbsChains (sumabs_chain.h)
+  SumAbsChains<NIGHTLY> ch;
+  ch.init(begin, end);
   {
     const int4 h = role_quad(b4 - 4);
-    const uint32_t h0 = (uint32_t)h.x, h1 = (uint32_t)h.y, h2 = (uint32_t)h.z, h3 = (uint32_t)h.w;
-    sp = h3;
-    e1p = h3 - h2;
-    e2p = h3 - 2u * h2 + h1;
-    e3p = h3 - 3u * h2 + 3u * h1 - h0;
+    ch.seed((uint32_t)h.x, (uint32_t)h.y, (uint32_t)h.z, (uint32_t)h.w);
   }
-
-  // stable: acc[k] is the one chain of order k.  nightly: lanes[k][j] are the 16 vector-lane chains of the
-  // aligned body and acc[k] the scalar chain of head and foot (SimdVec storage is 64-byte aligned, so the
-  // body starts at the first multiple of 16 elements at or after `begin`, arrayutils.rs:459-493)
-  float acc[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-  float vl[NIGHTLY ? 5 : 1][NIGHTLY ? 16 : 1];
-  if (NIGHTLY) {
-#pragma unroll
-    for (int k = 0; k < 5; ++k)
-#pragma unroll
-      for (int j = 0; j < 16; ++j) vl[k][j] = 0.0f;
-  }
-  int body_lo = 0, body_hi = 0;
-  if (NIGHTLY) {
-    body_lo = (begin + 15) & ~15;
-    if (body_lo > end) body_lo = end;
-    body_hi = body_lo + ((end - body_lo) & ~15);
-  }
-
-  auto step = [&](auto masked_tag, uint32_t x, int t, int j16) {
-    constexpr bool MASKED = decltype(masked_tag)::value;
-    const uint32_t e1 = x - sp, e2 = e1 - e1p, e3 = e2 - e2p, e4 = e3 - e3p;
-    sp = x;
-    e1p = e1;
-    e2p = e2;
-    e3p = e3;
-    float f[5];
-    f[0] = __builtin_fabsf((float)(int32_t)x);
-    f[1] = __builtin_fabsf((float)(int32_t)e1);
-    f[2] = __builtin_fabsf((float)(int32_t)e2);
-    f[3] = __builtin_fabsf((float)(int32_t)e3);
-    f[4] = __builtin_fabsf((float)(int32_t)e4);
-    if (!NIGHTLY) {
-      const bool in = !MASKED || (t >= begin && t < end);
-#pragma unroll
-      for (int k = 0; k < 5; ++k) acc[k] = (in ? f[k] : 0.0f) + acc[k];  // acc >= +0: adding +0 changes nothing
-    } else {
-      // (t - body_lo) mod 16 == j16 by construction of the walk: quads start at multiples of 4 and body_lo
-      // is a multiple of 16 unless the body is empty
-      const bool in = !MASKED || (t >= begin && t < end);
-      const bool body = t >= body_lo && t < body_hi;
-#pragma unroll
-      for (int k = 0; k < 5; ++k) {
-        const float fk = in ? f[k] : 0.0f;
-        acc[k] = (body ? 0.0f : fk) + acc[k];
-#pragma unroll
-        for (int j = 0; j < 16; ++j)
-          if (j == j16) vl[k][j] = (body ? fk : 0.0f) + vl[k][j];
-      }
-    }
-  };
+  auto step = [&](auto masked_tag, uint32_t x, int t, int j16) { ch.template step<decltype(masked_tag)::value>(x, t, j16); };
 
   // the walk: 16 samples per iteration from b4 (a multiple of 4; for NIGHTLY the iteration grid is aligned
   // to 16 so that the vector lane index is a compile-time constant)
@@ -155,11 +105,7 @@ __global__ void __launch_bounds__(256) sumabs_reference_kernel(SumAbsRefArgs a) 
   if (NIGHTLY && w0 != b4) {
     // state at w0 - 1 instead of b4 - 1
     const int4 h = role_quad(w0 - 4);
-    const uint32_t h0 = (uint32_t)h.x, h1 = (uint32_t)h.y, h2 = (uint32_t)h.z, h3 = (uint32_t)h.w;
-    sp = h3;
-    e1p = h3 - h2;
-    e2p = h3 - 2u * h2 + h1;
-    e3p = h3 - 3u * h2 + 3u * h1 - h0;
+    ch.seed((uint32_t)h.x, (uint32_t)h.y, (uint32_t)h.z, (uint32_t)h.w);
   }
   int my_iters = (end - w0 + 15) >> 4;
   if (my_iters < 0) my_iters = 0;
@@ -253,15 +199,7 @@ __global__ void __launch_bounds__(256) sumabs_reference_kernel(SumAbsRefArgs a) 
     float* __restrict__ o = a.out + (size_t)sf * (5 * 64) + p;
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
-      float v;
-      if (!NIGHTLY) {
-        v = acc[k] + 0.0f;  // scalar_reduce_fn(acc, reduce_sum(zero vector)), arrayutils.rs:492
-      } else {
-        float lanes = 0.0f;  // SimdFloat::reduce_sum: ordered sum of the lanes (as the oracle restates it)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) lanes += vl[k][j];
-        v = acc[k] + lanes;
-      }
+      const float v = ch.result(k);
       o[k * 64] = v;
     }
   }

@@ -196,3 +196,67 @@ def test_orders_beyond_15_and_mixed_flags_are_refused(handle):
     with pytest.raises(_capi.FlacencHipError) as e:
         handle.qlpc_batch(x, 16, _capi.make_config(lpc_order=8, flags=NIGHTLY | _capi.FLAG_REFERENCE_SUM_ORDER))
     assert e.value.code == _capi.ERR_BAD_CONFIG
+
+
+def _loud_16bit_frames(n):
+    """16-bit stereo frames whose fixed-LPC error sums pass 2^24 per estimator partition at the higher orders:
+    full-scale alternation (+ noise, so that the f32 roundings depend on the order of the additions), opposite
+    phases in the two channels (a 17-bit side channel), full-scale white noise, ordinary material, and 48 frames
+    of alternation at random amplitudes."""
+    rng = np.random.default_rng(20261003)
+    alt = np.where(np.arange(n) % 2 == 0, 32767, -32768).astype(np.int64)
+    jit = rng.integers(-1500, 1500, size=(8, n))
+    f = np.zeros((54, 2, n), np.int64)
+    f[0, 0], f[0, 1] = alt + jit[0], alt + jit[1]
+    f[1, 0], f[1, 1] = alt + jit[2], -alt + jit[3]
+    f[2, 0], f[2, 1] = rng.integers(-32768, 32768, size=n), rng.integers(-32768, 32768, size=n)
+    f[3] = _capi.sigen_frames(1, 2, n, 16, 120.0, 0.5, 0.02, seed=8, nthreads=1)[0]
+    f[4, 0], f[4, 1] = alt * (np.arange(n) < n // 2) + jit[4] // 8, f[3, 0]   # loud first half only
+    f[5, 0], f[5, 1] = (alt // 2) + jit[5], rng.integers(-30000, 30000, size=n)
+    rng = np.random.default_rng(7)
+    sgn = np.where(np.arange(n) % 2 == 0, 1, -1).astype(np.int64)
+    for i in range(48):
+        for c in range(2):
+            amp, j = rng.integers(20000, 32768), rng.integers(100, 4000)
+            f[6 + i, c] = sgn * amp * (1 if c == 0 or i % 2 else -1) + rng.integers(-j, j, size=n)
+    return np.clip(f, -32768, 32767).astype(np.int32)
+
+
+@pytest.mark.parametrize("n,order,parts", [(4096, 8, 16), (4096, 10, 2), (4096, 12, 1), (4096, 8, 64), (4608, 10, 16),
+                                           (4608, 8, 1), (4608, 12, 2)])
+def test_sixteen_bit_partitions_past_2_pow_24(handle, n, order, parts):
+    """On material of at most 16 bits the fused kernel runs without sumabs_reference_kernel in front of it: its
+    exact sums of |e| are the reference's f32 chains while a partition stays below 2^24, and it walks the
+    partitions that do not itself.  Here most partitions of the loud frames are past 2^24 at orders 2..4: the
+    whole frame decision == the oracle with find_sum_abs_f32 in the nightly order, and with few, large estimator
+    partitions the corpus separates that order from the exactly rounded sum."""
+    frames = _loud_16bit_frames(n)
+    cfg = _capi.make_frame_config(gcfg(order), use_fixed=True, fixed_order_sel=1, fixed_partitions=parts)
+    res, resid = handle.encode_stereo_frames(frames, 16, cfg)
+    ofc = orc.make_frame_config(ocfg(order), use_fixed=True,
+                                fixed=orc.make_fixed_config(partitions=parts, sum_mode=orc.SUMABS_NIGHTLY))
+    want, wres = orc.encode_stereo_frames_cfg(frames, 16, ofc)
+    assert res["channel_assignment"].tolist() == want["channel_assignment"].tolist()
+    assert res["kind"].tolist() == want["kind"].tolist() and res["bits"].tolist() == want["bits"].tolist()
+    assert np.array_equal(resid, wres)
+    assert res.tobytes() == want.tobytes()
+    if (n, parts) in {(4096, 2), (4608, 1)}:
+        fc = orc.make_fixed_config(partitions=parts, sum_mode=orc.SUMABS_NIGHTLY)
+        fc_canon = orc.make_fixed_config(partitions=parts, sum_mode=orc.SUMABS_CANONICAL)
+        differ = 0
+        for f in range(frames.shape[0]):
+            l, r = frames[f, 0], frames[f, 1]
+            for role, sig in enumerate([l, r, *orc.stereo_to_midside(l, r)]):
+                b = 16 + (role == 3)
+                differ += orc.fixed_lpc(sig, b, 2 ** 63, fc)["estimate"] != orc.fixed_lpc(sig, b, 2 ** 63, fc_canon)["estimate"]
+        assert differ > 0, "corpus does not separate the summation orders"
+    # independent channels (encode_subframe per channel) through the same kernel family
+    ch = frames[:6].reshape(3, 4, n)
+    cres, cresid = handle.encode_frames(ch, 16, cfg)
+    for f in range(3):
+        for c in range(4):
+            w = orc.encode_subframe(ch[f, c], 16, ofc)
+            g = cres[f, c]
+            assert int(g["kind"]) == w["kind"] and int(g["bits"]) == w["bits"], (f, c)
+            if w["kind"] >= 2:
+                assert np.array_equal(cresid[f, c], w["residual"]), (f, c)

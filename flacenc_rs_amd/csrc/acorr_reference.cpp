@@ -32,17 +32,13 @@ constexpr int kTile = 64;  // samples per tile
 constexpr int kRow = 68;   // floats per LDS row (64 + 4: lane r reading its row with b128 hits its own 4 banks)
 constexpr int kLpl = 4;    // lags per lane
 constexpr int kTileFloats = 64 * kRow;
-#ifndef FLACENC_ACREF_LPF
-#define FLACENC_ACREF_LPF 0  // a step's LDS reads issued one step ahead (slower: the rolled loop rotates them through moves)
-#endif
-#ifndef FLACENC_ACREF_UNROLL
-#define FLACENC_ACREF_UNROLL 1
-#endif
-#define FLACENC_PRAGMA_(x) _Pragma(#x)
-#define FLACENC_PRAGMA(x) FLACENC_PRAGMA_(x)
 
-template <bool STEREO>
-__global__ void __launch_bounds__(576) acorr_reference_kernel(AcorrRefArgs a) {
+// NIGHTLY: the simd-nightly build's order for blocks that are multiples of 16 samples (no scalar foot), in the same
+// frame: per lag d the body's vector lane chains (8 for d < 8, 16 for d = 8..15: lane l takes the samples with
+// t mod LANES == l, from the first multiple of LANES at or after P) are 8 / 16 accumulators of the LANE that owns
+// the subframe, the scalar head (t = P .. that multiple) one more; waves: lags 0-3, 4-7, then pairs 8-9, 10-11, ...
+template <bool STEREO, bool NIGHTLY>
+__global__ void __launch_bounds__(NIGHTLY ? 384 : 576) acorr_reference_kernel(AcorrRefArgs a) {
   __shared__ __attribute__((aligned(16))) float tile[2 * kTileFloats];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -65,8 +61,9 @@ __global__ void __launch_bounds__(576) acorr_reference_kernel(AcorrRefArgs a) {
   // 64 rows x 16 pieces.  The launch provides at least 128 (plain: 256) threads, so a thread has at most IT items.
   constexpr int NITEM = STEREO ? 256 : 1024;
   constexpr int IT = STEREO ? 2 : 4;
+  constexpr bool PAIR = !NIGHTLY;  // (the nightly form needs the second set's 20 registers for its accumulators: one tile at a time)
   const int nthreads = (int)blockDim.x;
-  int4 rA0[IT], rA1[IT], rB0[STEREO ? IT : 1], rB1[STEREO ? IT : 1];  // set 0: the even tile, set 1: the odd one
+  int4 rA0[IT], rA1[PAIR ? IT : 1], rB0[STEREO ? IT : 1], rB1[(STEREO && PAIR) ? IT : 1];  // set 0: the even tile, set 1: the odd one
   float4 w0, w1;
   auto ld_row = [&](const int32_t* row, int t, bool full) __attribute__((always_inline)) -> int4 {
     if (full) return *reinterpret_cast<const int4*>(row + t);
@@ -109,16 +106,16 @@ __global__ void __launch_bounds__(576) acorr_reference_kernel(AcorrRefArgs a) {
   auto issue_pair = [&](int k) __attribute__((always_inline)) {
     const bool full0 = vec_ok && (k + 1) * kTile <= n;
     const bool full1 = vec_ok && (k + 2) * kTile <= n;
-    const bool have1 = k + 1 < n_tiles;
+    const bool have1 = PAIR && k + 1 < n_tiles;
     const int t = k * kTile + col;
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
       if (tid + it * nthreads < NITEM) {
         rA0[it] = ld_row(rowp[it], t, full0);
         if (STEREO) rB0[it] = ld_row(rowp[it] + a.stride, t, full0);
-        if (have1) {
-          rA1[it] = ld_row(rowp[it], t + kTile, full1);
-          if (STEREO) rB1[it] = ld_row(rowp[it] + a.stride, t + kTile, full1);
+        if (PAIR && have1) {
+          rA1[PAIR ? it : 0] = ld_row(rowp[it], t + kTile, full1);
+          if (STEREO) rB1[PAIR ? it : 0] = ld_row(rowp[it] + a.stride, t + kTile, full1);
         }
       }
     }
@@ -143,113 +140,147 @@ __global__ void __launch_bounds__(576) acorr_reference_kernel(AcorrRefArgs a) {
           *reinterpret_cast<float4*>(&buf[row * kRow + col]) = x;
         };
         if (STEREO) {
-          const int4 l = SET ? rA1[it] : rA0[it], r = SET ? rB1[it] : rB0[it];
+          const int4 l = SET ? rA1[PAIR ? it : 0] : rA0[it], r = SET ? rB1[PAIR ? it : 0] : rB0[it];
           put(4 * rr + 0, l);
           put(4 * rr + 1, r);
           put(4 * rr + 2, make_int4((l.x + r.x) >> 1, (l.y + r.y) >> 1, (l.z + r.z) >> 1, (l.w + r.w) >> 1));
           put(4 * rr + 3, make_int4(l.x - r.x, l.y - r.y, l.z - r.z, l.w - r.w));
         } else {
-          put(rr, SET ? rA1[it] : rA0[it]);
+          put(rr, SET ? rA1[PAIR ? it : 0] : rA0[it]);
         }
       }
     }
   };
 
-  const int L0 = kLpl * wave;  // this wave's lags: L0 .. L0 + NL - 1
+  // this wave's lags: L0 .. L0 + nl - 1 -- four in the stable order, four or two in the nightly one (32 accumulators);
+  // the lagged stream is read from the 16-byte aligned position B <= L0 and indexed OFF = L0 - B further back
+  // (nightly: waves 0 and 1 take lags 0-3 and 4-7 with 8 accumulators per lag, the others a pair with 16 each)
+  const int L0 = !NIGHTLY ? kLpl * wave : (wave < 2 ? 4 * wave : 8 + 2 * (wave - 2));
+  const int B = L0 & ~3;
+  const int per_wave = (!NIGHTLY || wave < 2) ? kLpl : 2;
+  const int nl = P + 1 - L0 < per_wave ? P + 1 - L0 : per_wave;  // (<= 0: a wave that only helps with the loads)
   const float* const myrow = tile + lane * kRow;
-  double acc[kLpl];
+  // stable: acc[j] is the chain of lag L0 + j.  nightly: acc[LANES j + l] is vector lane l of lag L0 + j, head[j] the
+  // scalar chain of the samples between P and the first whole vector
+  double acc[NIGHTLY ? 32 : kLpl];
+  double head[NIGHTLY ? kLpl : 1];
 #pragma unroll
-  for (int j = 0; j < kLpl; ++j) acc[j] = 0.0;
-  // lw[i] = x_w[t - L0 - 4 + i] for the step at t: 4 carried + the step's own 8
+  for (int j = 0; j < (NIGHTLY ? 32 : kLpl); ++j) acc[j] = 0.0;
+#pragma unroll
+  for (int j = 0; j < (NIGHTLY ? kLpl : 1); ++j) head[j] = 0.0;
+  // lw[i] = x_w[t - B - 4 + i] for the step at t: 4 carried + the step's own 8
   double lw[12];
 #pragma unroll
   for (int i = 0; i < 12; ++i) lw[i] = 0.0;
-  // one tile for a wave with NL lags; G0: the group of lags 0..3, whose lagged stream is the current one
-  auto sum_tile = [&](auto nl_tag, auto g0_tag, auto masked_tag, int k) __attribute__((always_inline)) {
-      constexpr int NL = decltype(nl_tag)::value;
-      constexpr bool G0 = decltype(g0_tag)::value;
-      constexpr bool MASKED = decltype(masked_tag)::value;
-      const float* row = myrow + (k & 1) * kTileFloats;
-      // the step's LDS reads are issued one step ahead (all of a tile's reads stay inside the two resident tiles)
-      auto lag_ptr = [&](int u) { return myrow + ((u >> 6) & 1) * kTileFloats + (u & 63); };  // u % 4 == 0, u >= -64
-      float4 x0 = *reinterpret_cast<const float4*>(row);
-      float4 x1 = *reinterpret_cast<const float4*>(row + 4);
-      float4 y0 = x0, y1 = x1;
-      if (!G0) {
-        y0 = *reinterpret_cast<const float4*>(lag_ptr(k * kTile - L0));
-        y1 = *reinterpret_cast<const float4*>(lag_ptr(k * kTile - L0 + 4));
+  // one tile for a wave with NL lags; G0: the wave of lag 0, whose lagged stream is the current one;
+  // LANES / OFF: nightly only
+  auto sum_tile = [&](auto nl_tag, auto g0_tag, auto masked_tag, auto lanes_tag, auto off_tag, int k) __attribute__((always_inline)) {
+    constexpr int NL = decltype(nl_tag)::value;
+    constexpr bool G0 = decltype(g0_tag)::value;
+    constexpr bool MASKED = decltype(masked_tag)::value;
+    constexpr int LANES = decltype(lanes_tag)::value;
+    constexpr int OFF = decltype(off_tag)::value;
+    const float* row = myrow + (k & 1) * kTileFloats;
+    auto lag_ptr = [&](int u) { return myrow + ((u >> 6) & 1) * kTileFloats + (u & 63); };  // u % 4 == 0, u >= -64
+    const int t0 = (P + LANES - 1) & ~(LANES - 1);  // nightly: the first whole vector of this lag
+    auto half = [&](auto h_tag, int step) __attribute__((always_inline)) {
+      constexpr int H = decltype(h_tag)::value;  // which half of a 16-sample stretch: the vector lane is kk + 8 H
+      const float4 x0 = *reinterpret_cast<const float4*>(row + 8 * step);
+      const float4 x1 = *reinterpret_cast<const float4*>(row + 8 * step + 4);
+      double cur[8];
+      cur[0] = (double)x0.x;
+      cur[1] = (double)x0.y;
+      cur[2] = (double)x0.z;
+      cur[3] = (double)x0.w;
+      cur[4] = (double)x1.x;
+      cur[5] = (double)x1.y;
+      cur[6] = (double)x1.z;
+      cur[7] = (double)x1.w;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) lw[i] = lw[8 + i];
+      if (G0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) lw[4 + i] = cur[i];
+      } else {
+        const int u = k * kTile + 8 * step - B;  // a multiple of 4, >= -32: quads never straddle tiles
+        const float4 y0 = *reinterpret_cast<const float4*>(lag_ptr(u));
+        const float4 y1 = *reinterpret_cast<const float4*>(lag_ptr(u + 4));
+        lw[4] = (double)y0.x;
+        lw[5] = (double)y0.y;
+        lw[6] = (double)y0.z;
+        lw[7] = (double)y0.w;
+        lw[8] = (double)y1.x;
+        lw[9] = (double)y1.y;
+        lw[10] = (double)y1.z;
+        lw[11] = (double)y1.w;
       }
-FLACENC_PRAGMA(unroll FLACENC_ACREF_UNROLL)
-      for (int step = 0; step < 8; ++step) {
-        if (!FLACENC_ACREF_LPF && step > 0) {
-          x0 = *reinterpret_cast<const float4*>(row + 8 * step);
-          x1 = *reinterpret_cast<const float4*>(row + 8 * step + 4);
-          if (!G0) {
-            const int u = k * kTile + 8 * step - L0;
-            y0 = *reinterpret_cast<const float4*>(lag_ptr(u));
-            y1 = *reinterpret_cast<const float4*>(lag_ptr(u + 4));
-          }
-        }
-        double cur[8];
-        cur[0] = (double)x0.x;
-        cur[1] = (double)x0.y;
-        cur[2] = (double)x0.z;
-        cur[3] = (double)x0.w;
-        cur[4] = (double)x1.x;
-        cur[5] = (double)x1.y;
-        cur[6] = (double)x1.z;
-        cur[7] = (double)x1.w;
+      const int tb = k * kTile + 8 * step;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) lw[i] = lw[8 + i];
-        if (G0) {
-#pragma unroll
-          for (int i = 0; i < 8; ++i) lw[4 + i] = cur[i];
-        } else {
-          lw[4] = (double)y0.x;
-          lw[5] = (double)y0.y;
-          lw[6] = (double)y0.z;
-          lw[7] = (double)y0.w;
-          lw[8] = (double)y1.x;
-          lw[9] = (double)y1.y;
-          lw[10] = (double)y1.z;
-          lw[11] = (double)y1.w;
-        }
-        if (FLACENC_ACREF_LPF && step < 7) {
-          x0 = *reinterpret_cast<const float4*>(row + 8 * step + 8);
-          x1 = *reinterpret_cast<const float4*>(row + 8 * step + 12);
-          if (!G0) {
-            const int u = k * kTile + 8 * step + 8 - L0;  // a multiple of 4, >= -32: quads never straddle tiles
-            y0 = *reinterpret_cast<const float4*>(lag_ptr(u));
-            y1 = *reinterpret_cast<const float4*>(lag_ptr(u + 4));
-          }
-        }
-        const int tb = k * kTile + 8 * step;
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-          // t < P: no step of the reference's loop; only the multiplier is masked -- as a lagged value the
-          // sample is read by later steps like any other
-          const double c = (!MASKED || tb + kk >= P) ? cur[kk] : 0.0;
+      for (int kk = 0; kk < 8; ++kk) {
+        // t < P: no step of the reference's loop; only the multiplier is masked -- as a lagged value the
+        // sample is read by later steps like any other
+        const double c = (!MASKED || tb + kk >= P) ? cur[kk] : 0.0;  // (cur[]: converted where it is used, see above)
+        if (!NIGHTLY) {
 #pragma unroll
           for (int j = 0; j < NL; ++j) acc[j] = __builtin_fma(lw[4 + kk - j], c, acc[j]);
+        } else {
+          const int l = (kk + 8 * H) & (LANES - 1);  // (a constant once the loop is unrolled)
+          // the head chain takes the samples below the first whole vector, the lane chain the others; the
+          // chain that is not the sample's gets a multiplier of 0 (x + 0 * y == x for every x that can occur),
+          // so no value is ever selected between two accumulators -- which would move them to memory
+          const bool in_head = MASKED && tb + kk < t0;  // (wave-uniform)
+          const double c_head = in_head ? c : 0.0, c_lane = in_head ? 0.0 : c;
+#pragma unroll
+          for (int j = 0; j < NL; ++j) {
+            const double lagged = lw[4 + kk - OFF - j];
+            if (MASKED) head[j] = __builtin_fma(c_head, lagged, head[j]);
+            acc[LANES * j + l] = __builtin_fma(MASKED ? c_lane : c, lagged, acc[LANES * j + l]);
+          }
         }
       }
     };
+#pragma unroll 1
+    for (int step = 0; step < 8; step += 2) {
+      half(std::integral_constant<int, 0>{}, step);
+      half(std::integral_constant<int, 1>{}, step + 1);
+    }
+  };
   issue_pair(0);
   __syncthreads();  // (the zero tile)
   land(std::integral_constant<int, 0>{}, tile);
   __syncthreads();
-  // lags of this wave; the launch rounds the workgroup up to two (plain: four) waves for the loads, so a wave
-  // may have none
-  const int nl = P + 1 - L0 < kLpl ? P + 1 - L0 : kLpl;
+  // (the launch rounds the workgroup up to two -- plain: four -- waves for the loads, so a wave may have no lags)
   auto sum_nl = [&](auto g0_tag, auto masked_tag, int k) __attribute__((always_inline)) {
+    constexpr bool G0 = decltype(g0_tag)::value;
+    (void)G0;
+    using I0 = std::integral_constant<int, 0>;
+    using I2 = std::integral_constant<int, 2>;
+    using I8 = std::integral_constant<int, 8>;
+    using I16 = std::integral_constant<int, 16>;
     if (nl <= 0) return;
-    if (nl == 1) sum_tile(std::integral_constant<int, 1>{}, g0_tag, masked_tag, k);
-    else if (nl == 2) sum_tile(std::integral_constant<int, 2>{}, g0_tag, masked_tag, k);
-    else if (nl == 3) sum_tile(std::integral_constant<int, 3>{}, g0_tag, masked_tag, k);
-    else sum_tile(std::integral_constant<int, 4>{}, g0_tag, masked_tag, k);
+    if (!NIGHTLY) {
+      if (nl == 1) sum_tile(std::integral_constant<int, 1>{}, g0_tag, masked_tag, I8{}, I0{}, k);
+      else if (nl == 2) sum_tile(std::integral_constant<int, 2>{}, g0_tag, masked_tag, I8{}, I0{}, k);
+      else if (nl == 3) sum_tile(std::integral_constant<int, 3>{}, g0_tag, masked_tag, I8{}, I0{}, k);
+      else sum_tile(std::integral_constant<int, 4>{}, g0_tag, masked_tag, I8{}, I0{}, k);
+    } else if (L0 < 8) {
+      if (nl == 1) sum_tile(std::integral_constant<int, 1>{}, g0_tag, masked_tag, I8{}, I0{}, k);
+      else if (nl == 2) sum_tile(std::integral_constant<int, 2>{}, g0_tag, masked_tag, I8{}, I0{}, k);
+      else if (nl == 3) sum_tile(std::integral_constant<int, 3>{}, g0_tag, masked_tag, I8{}, I0{}, k);
+      else sum_tile(std::integral_constant<int, 4>{}, g0_tag, masked_tag, I8{}, I0{}, k);
+    } else if (!G0) {
+      if (L0 == B) {
+        if (nl == 1) sum_tile(std::integral_constant<int, 1>{}, g0_tag, masked_tag, I16{}, I0{}, k);
+        else sum_tile(std::integral_constant<int, 2>{}, g0_tag, masked_tag, I16{}, I0{}, k);
+      } else {
+        if (nl == 1) sum_tile(std::integral_constant<int, 1>{}, g0_tag, masked_tag, I16{}, I2{}, k);
+        else sum_tile(std::integral_constant<int, 2>{}, g0_tag, masked_tag, I16{}, I2{}, k);
+      }
+    }
   };
   for (int k = 0; k < n_tiles; ++k) {
-    if (k * kTile < P) {
+    if (!PAIR && k + 1 < n_tiles) issue_pair(k + 1);  // (one tile: in flight while tile k is summed)
+    if (k * kTile < P || (NIGHTLY && k == 0)) {
       if (wave == 0) sum_nl(std::true_type{}, std::true_type{}, k);
       else sum_nl(std::false_type{}, std::true_type{}, k);
     } else {
@@ -258,19 +289,41 @@ FLACENC_PRAGMA(unroll FLACENC_ACREF_UNROLL)
     }
     __syncthreads();  // every wave is done with tile k - 1, whose buffer takes tile k + 1
     if (k + 1 < n_tiles) {
-      if (k & 1) land(std::integral_constant<int, 0>{}, tile);
+      if (!PAIR || (k & 1)) land(std::integral_constant<int, 0>{}, tile + ((k + 1) & 1) * kTileFloats);
       else land(std::integral_constant<int, 1>{}, tile + kTileFloats);
     }
     __syncthreads();
     // both register sets are parked: the next pair of tiles has the whole of tile k + 1's sums to arrive
-    if ((k & 1) == 0 && k + 2 < n_tiles) issue_pair(k + 2);
+    if (PAIR && (k & 1) == 0 && k + 2 < n_tiles) issue_pair(k + 2);
   }
   const uint32_t sf = sf0 + (uint32_t)lane;
   if (sf < a.n_subframes) {
     double* __restrict__ o = a.out + (size_t)sf * 33;
+    if (!NIGHTLY) {
 #pragma unroll
-    for (int j = 0; j < kLpl; ++j)
-      if (j < nl) o[L0 + j] = acc[j];  // (nl <= 0: a loading-only wave)
+      for (int j = 0; j < kLpl; ++j)
+        if (j < nl) o[L0 + j] = acc[j];  // (nl <= 0: a loading-only wave)
+    } else {
+      // acc = 0 + chain(head); acc += chain(foot) (empty here: + 0); R = acc + reduce_sum(lane chains), the lane
+      // sum ordered ((0 + v0) + v1) + ... (weighted_delay_prod_sum_impl, lpc.rs:439-500, as the oracle restates it)
+      auto finish = [&](auto lanes_tag) __attribute__((always_inline)) {
+        constexpr int LANES = decltype(lanes_tag)::value;
+#pragma unroll
+        for (int j = 0; j < 32 / LANES; ++j) {
+          if (j < nl) {
+            double r = 0.0;
+            r += head[j];
+            r += 0.0;
+            double lanesum = 0.0;
+#pragma unroll
+            for (int l = 0; l < LANES; ++l) lanesum += acc[LANES * j + l];
+            o[L0 + j] = r + lanesum;
+          }
+        }
+      };
+      if (L0 < 8) finish(std::integral_constant<int, 8>{});
+      else finish(std::integral_constant<int, 16>{});
+    }
     if (wave == 0)
       for (int tau = P + 1; tau < 33; ++tau) o[tau] = 0.0;
   }
@@ -392,13 +445,21 @@ hipError_t launch_nightly(const AcorrRefArgs& a, hipStream_t stream) {
   return hipGetLastError();
 }
 
-hipError_t launch_stable(const AcorrRefArgs& a, hipStream_t stream) {
+hipError_t launch_lag_groups(const AcorrRefArgs& a, hipStream_t stream) {
   const uint32_t blocks = (a.n_subframes + 63u) / 64u;
-  uint32_t groups = (a.lpc_order + 1u + (uint32_t)kLpl - 1u) / (uint32_t)kLpl;  // 1..9 lag groups = waves
-  const uint32_t min_waves = a.stereo ? 2u : 4u;  // (the cooperative loads want 128 / 256 threads)
+  uint32_t groups;  // lag groups = waves (1..9; nightly: lags 0-3, 4-7, then pairs: 1..6)
+  if (!a.nightly) groups = (a.lpc_order + 1u + (uint32_t)kLpl - 1u) / (uint32_t)kLpl;
+  else groups = a.lpc_order < 4u ? 1u : (a.lpc_order < 8u ? 2u : 2u + (a.lpc_order + 1u - 8u + 1u) / 2u);
+  const uint32_t min_waves = a.stereo ? 2u : 4u;                     // (the cooperative loads want 128 / 256 threads)
   groups = groups < min_waves ? min_waves : groups;
-  if (a.stereo) hipLaunchKernelGGL((acorr_reference_kernel<true>), dim3(blocks), dim3(64u * groups), 0, stream, a);
-  else hipLaunchKernelGGL((acorr_reference_kernel<false>), dim3(blocks), dim3(64u * groups), 0, stream, a);
+  const dim3 block(64u * groups);
+  if (a.nightly) {
+    if (a.stereo) hipLaunchKernelGGL((acorr_reference_kernel<true, true>), dim3(blocks), block, 0, stream, a);
+    else hipLaunchKernelGGL((acorr_reference_kernel<false, true>), dim3(blocks), block, 0, stream, a);
+  } else {
+    if (a.stereo) hipLaunchKernelGGL((acorr_reference_kernel<true, false>), dim3(blocks), block, 0, stream, a);
+    else hipLaunchKernelGGL((acorr_reference_kernel<false, false>), dim3(blocks), block, 0, stream, a);
+  }
   return hipGetLastError();
 }
 
@@ -407,9 +468,14 @@ hipError_t launch_stable(const AcorrRefArgs& a, hipStream_t stream) {
 hipError_t launch_acorr_reference(const AcorrRefArgs& a, hipStream_t stream) {
   if (a.n_subframes == 0) return hipSuccess;
   if (a.stereo && (a.n_subframes & 3u)) return hipErrorInvalidValue;
-  if (a.nightly) return launch_nightly(a, stream);
   if (a.lpc_order > 32u) return hipErrorInvalidValue;
-  return launch_stable(a, stream);
+  if (a.nightly) {
+    if (a.lpc_order > 15u) return hipErrorNotSupported;
+    // blocks that are whole vectors of 16 (no scalar foot): the lane-per-subframe form; any other size: one
+    // workgroup per subframe with a GPU lane per vector lane
+    if ((a.block_size & 15u) != 0u || a.block_size < 64u) return launch_nightly(a, stream);
+  }
+  return launch_lag_groups(a, stream);
 }
 
 }  // namespace flacenc_hip

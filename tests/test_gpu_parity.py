@@ -1020,13 +1020,20 @@ def test_frame_pipeline_config_fuzz(handle, seed):
         x[1, 1] = x[1, 0]
         x[5, 0] = -x[5, 1]
         x[9] = x[9] // 256
-        cfg = _capi.make_frame_config(_capi.make_config(**qcfg), **flags, **fixed)
+        # FLACENC_FUZZ_ORDER=reference|nightly (tools/fuzz_more.py): the same sweep in the reference's summation orders
+        mode = os.environ.get("FLACENC_FUZZ_ORDER", "canonical")
+        gflag, oac, osum = {"canonical": (0, orc.ACORR_CANONICAL, orc.SUMABS_CANONICAL),
+                            "reference": (_capi.FLAG_REFERENCE_SUM_ORDER, orc.ACORR_REFERENCE, orc.SUMABS_STABLE),
+                            "nightly": (_capi.FLAG_NIGHTLY_SUM_ORDER, orc.ACORR_NIGHTLY, orc.SUMABS_NIGHTLY)}[mode]
+        if mode == "nightly" and order > 15:
+            qcfg["lpc_order"] = order = 12
+        cfg = _capi.make_frame_config(_capi.make_config(flags=gflag, **qcfg), **flags, **fixed)
         got, gres = handle.encode_stereo_frames(x, bps, cfg)
-        ocfg = orc.make_frame_config(orc.make_config(acorr=orc.ACORR_CANONICAL, **qcfg), **flags,
+        ocfg = orc.make_frame_config(orc.make_config(acorr=oac, **qcfg), **flags,
                                      fixed=orc.make_fixed_config(max_order=fixed["fixed_max_order"],
                                                                  order_sel=fixed["fixed_order_sel"],
                                                                  partitions=fixed["fixed_partitions"],
-                                                                 sum_mode=orc.SUMABS_CANONICAL))
+                                                                 sum_mode=osum))
         want, wres = orc.encode_stereo_frames_cfg(x, bps, ocfg)
         try:
             _check_frames_against_oracle(x, bps, got, gres, want, wres)

@@ -18,6 +18,15 @@ use crate::error::{EncodeError, Verified, VerifyError};
 pub const OK: c_int = 0;
 pub const ERR_BAD_CONFIG: c_int = -1;
 pub const MEM_HOST: c_int = 0;
+/// `flags` of `QlpcConfig` (include/flacenc_hip.h).  The two order flags make the order-sensitive sums of the path
+/// the ones of a CPU build, bit for bit: the stable build's (`weighted_auto_correlation_nosimd`, `src/lpc.rs:533-548`;
+/// `find_sum_abs_f32` over `slice_as_simd = (data, [], [])`, `src/arrayutils.rs:435-506`) or the `simd-nightly`
+/// build's (`weighted_auto_correlation_simd`, `src/lpc.rs:510-531`; LPC orders up to 15).  A crate built with the
+/// `simd-nightly` feature would pass `FLAG_NIGHTLY_SUM_ORDER`, any other `FLAG_REFERENCE_SUM_ORDER`, to get the
+/// bytes its own CPU path produces.
+pub const FLAG_ALLOW_ORDER_32: u32 = 1;
+pub const FLAG_REFERENCE_SUM_ORDER: u32 = 32;
+pub const FLAG_NIGHTLY_SUM_ORDER: u32 = 64;
 
 /// `flacenc_hip_qlpc_config` (include/flacenc_hip.h): the path's fields of `config::Qlpc` /
 /// `config::Prc` (`src/config.rs:271-288`, `211-214`).
@@ -207,7 +216,13 @@ fn abi_config(c: &config::SubFrameCoding) -> QlpcConfig {
         window_type,
         tukey_alpha,
         max_rice_parameter: c.prc.max_parameter as u32,
-        flags: 0,
+        flags: if cfg!(feature = "simd-nightly") && c.qlpc.lpc_order <= 15 {
+            FLAG_NIGHTLY_SUM_ORDER
+        } else if cfg!(feature = "simd-nightly") {
+            0 // (the nightly split above order 15 depends on the allocator: canonical order, a valid encoding)
+        } else {
+            FLAG_REFERENCE_SUM_ORDER
+        },
         use_direct_mse: c.qlpc.use_direct_mse as u32,
         mae_optimization_steps: c.qlpc.mae_optimization_steps as u32,
     }

@@ -65,6 +65,8 @@ run("config4: 4096 x 16b 8-channel, order 10 (plain)", 2048, 8, 4096, 16, 10, Fa
 run("config5: 16384 x 24b stereo, order 24 (big-block kernels)", 1024, 2, 16384, 24, 24, True)
 run("config5: 16384 x 24b stereo, order 32 (big-block kernels)", 1024, 2, 16384, 24, 32, True)
 run("ragged: 4608 x 16b stereo, order 10 (72-sample-per-lane wave kernel)", 4096, 2, 4608, 16, 10, True)
+run("ragged: 1152 x 16b stereo, order 8 (generic kernel, 72-sample partitions bit-sliced)", 16384, 2, 1152, 16, 8, True)
+run("ragged: 2304 x 16b stereo, order 8 (generic kernel, 72-sample partitions bit-sliced)", 8192, 2, 2304, 16, 8, True)
 # the big-block shapes at 3 x the batch: whole rounds of workgroups for every kernel (512 and 768 resident
 # workgroups), launch costs amortised
 run("config3, 6144 frames per launch: 8192 x 24b stereo, order 24", 6144, 2, 8192, 24, 24, True)

@@ -362,7 +362,9 @@ int enqueue(flacenc_hip_handle* h, const flacenc_hip_qlpc_config* cfg, const int
                     "block_size <= 16384)";
     return FLACENC_HIP_ERR_UNSUPPORTED;
   }
-  if (cfg->lpc_order >= 13 || a.reference_order || a.direct_mse) {
+  // (R[] and the predictor records between the launches of the split pipelines: orders from 13, and blocks of
+  // 8192 / 16384 at any order -- the big-block kernels)
+  if (cfg->lpc_order >= 13 || a.reference_order || a.direct_mse || block_size == 8192 || block_size == 16384) {
     rc = ensure(h, h->d_split, n_subframes * (33 * 8 + 36 * 4));
     if (rc != FLACENC_HIP_OK) return rc;
     a.split_scratch = h->d_split.ptr;

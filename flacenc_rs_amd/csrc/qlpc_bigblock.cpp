@@ -180,10 +180,10 @@ __device__ __forceinline__ int4 bigblock_hld4(const int32_t* bufA, const int32_t
   return v;
 }
 
-template <int HP, int NG, bool STEREO>
+template <int HP, int NG, bool STEREO, int NLAGS = HP + 1>
 __global__ void __launch_bounds__(256, FLACENC_BIG_ACORR_OCC) bigblock_acorr_kernel(QlpcKernelArgs a) {
-  // HP = window depth = the order bucket (16, 24 or 32); lags 0..HP in NG groups of at most NL
-  constexpr int NLAG = HP + 1;
+  // HP = window depth = the order bucket (8, 16, 24 or 32); lags 0..NLAGS-1 (<= HP) in NG groups of at most NL
+  constexpr int NLAG = NLAGS;
   constexpr int NL = (NLAG + NG - 1) / NG;
   constexpr int NBATCH = 13;  // lags per LDS tree round (4 lanes per lag, <= 16)
   constexpr int LVMAX = 3;    // half passes per block <= 8
@@ -334,7 +334,7 @@ __global__ void __launch_bounds__(256, FLACENC_BIG_ACORR_OCC) bigblock_acorr_ker
     if (k == K2 - 1) stamp(5);
   }
   if (lane == 0 && active)
-    for (int j = HP + 1; j < 33; ++j) a.autocorr[(size_t)sf * 33 + j] = 0.0;
+    for (int j = NLAG; j < 33; ++j) a.autocorr[(size_t)sf * 33 + j] = 0.0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -902,13 +902,13 @@ hipError_t launch_big(KernelT kern, DynamicLdsOptIn& opt_in, const QlpcKernelArg
   return hipGetLastError();
 }
 
-template <int HP, int NG>
+template <int HP, int NG, int NLAGS = HP + 1>
 hipError_t launch_acorr(const QlpcKernelArgs& a, hipStream_t stream) {
   static DynamicLdsOptIn opt_s, opt_p;
   const size_t part = 4 * 3 * (HP + 1) * sizeof(double);
   const size_t cross = 4 * 13 * 64 * sizeof(double);  // wave_tree_sums_lds_n
-  if (a.stereo) return launch_big(bigblock_acorr_kernel<HP, NG, true>, opt_s, a, 2 * kHBufDwords * 4 + part + cross, stream);
-  return launch_big(bigblock_acorr_kernel<HP, NG, false>, opt_p, a, 4 * kHBufDwords * 4 + part + cross, stream);
+  if (a.stereo) return launch_big(bigblock_acorr_kernel<HP, NG, true, NLAGS>, opt_s, a, 2 * kHBufDwords * 4 + part + cross, stream);
+  return launch_big(bigblock_acorr_kernel<HP, NG, false, NLAGS>, opt_p, a, 4 * kHBufDwords * 4 + part + cross, stream);
 }
 
 template <int MAXP, int K, bool FIXD = false>
@@ -950,8 +950,11 @@ hipError_t launch_bigblock_fixed_residual(const QlpcKernelArgs& a, hipStream_t s
 }
 
 bool bigblock_eligible(const QlpcKernelArgs& a) {
-  // (4096 at these orders too: below 13 the fused 4096 kernel has it, above it would fall to the generic one)
-  if (a.lpc_order < 13 || a.lpc_order > 32) return false;
+  // (4096 at orders 13..32 too: below 13 the fused 4096 kernel has it, above it would fall to the generic one;
+  // 8192 / 16384 at every order -- round 2 left orders up to 12 on those blocks to the generic kernel, 88 G
+  // samples/s where order 24 ran at 146)
+  if (a.lpc_order < 1 || a.lpc_order > 32) return false;
+  if (a.lpc_order < 13 && a.block_size == 4096) return false;
   return bigblock_shape_eligible(a);
 }
 
@@ -971,6 +974,8 @@ bool bigblock_shape_eligible(const QlpcKernelArgs& a) {
 hipError_t launch_bigblock_acorr(const QlpcKernelArgs& a, hipStream_t stream) {
   // order <= 24: all 25 lags in one group; up to 32: 17 + 16 (window of 48 doubles + two accumulator sets
   // must fit 256 VGPRs: all 33 in one group compile to 256 registers + 5 spilled, and run 2.4 x slower)
+  if (a.lpc_order <= 8) return launch_acorr<8, 1>(a, stream);    // 9 lags, window of 8
+  if (a.lpc_order <= 12) return launch_acorr<16, 1, 13>(a, stream);  // 13 lags, window of 16
   if (a.lpc_order <= 16) return launch_acorr<16, 1>(a, stream);  // 17 lags, window of 16
   if (a.lpc_order <= 24) return launch_acorr<24, FLACENC_BIG_NG24>(a, stream);
   return launch_acorr<32, FLACENC_BIG_NG32>(a, stream);
@@ -978,8 +983,10 @@ hipError_t launch_bigblock_acorr(const QlpcKernelArgs& a, hipStream_t stream) {
 
 hipError_t launch_bigblock_residual(const QlpcKernelArgs& a, hipStream_t stream) {
   const int k = (int)(a.block_size / 4096u);
-  if (a.lpc_order <= 8)  // (only reached behind direct_mse_kernel: the autocorrelation pipeline starts at order 13)
+  if (a.lpc_order <= 8)
     return k == 1 ? launch_residual<8, 1>(a, stream) : (k == 2 ? launch_residual<8, 2>(a, stream) : launch_residual<8, 4>(a, stream));
+  if (a.lpc_order <= 12)
+    return k == 1 ? launch_residual<12, 1>(a, stream) : (k == 2 ? launch_residual<12, 2>(a, stream) : launch_residual<12, 4>(a, stream));
   if (a.lpc_order <= 16)
     return k == 1 ? launch_residual<16, 1>(a, stream) : (k == 2 ? launch_residual<16, 2>(a, stream) : launch_residual<16, 4>(a, stream));
   if (a.lpc_order <= 24)

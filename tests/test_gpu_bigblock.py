@@ -53,7 +53,9 @@ def batch(ns, n, bps, seed0, namp=0.01):
 
 
 @pytest.mark.parametrize("n", [8192, 16384])
-@pytest.mark.parametrize("order", [13, 16, 17, 24, 25, 32])
+# (orders up to 12 on these blocks took the generic kernel until round 3: 9- and 13-lag autocorrelation instances,
+# residual buckets 8 and 12)
+@pytest.mark.parametrize("order", [1, 2, 5, 8, 9, 10, 12, 13, 16, 17, 24, 25, 32])
 @pytest.mark.parametrize("bps", [16, 24])
 def test_plain_batches(handle, n, order, bps):
     ns = 7 if n == 8192 else 5   # not a multiple of 4: the last workgroup has idle rows
@@ -61,7 +63,8 @@ def test_plain_batches(handle, n, order, bps):
     assert (gp["status"] == 0).all()
 
 
-@pytest.mark.parametrize("n,order", [(8192, 24), (8192, 32), (16384, 24), (16384, 32), (16384, 13)])
+@pytest.mark.parametrize("n,order", [(8192, 24), (8192, 32), (16384, 24), (16384, 32), (16384, 13), (8192, 8), (8192, 10),
+                                     (16384, 12), (16384, 3)])
 def test_stereo_candidates(handle, n, order):
     bps = 24
     l, r = batch(3, n, bps, 100 + order), batch(3, n, bps, 700 + order)
@@ -117,7 +120,7 @@ def test_degenerate_signals(handle):
     check(handle, x, 24, 16, window="rectangle")
 
 
-@pytest.mark.parametrize("n,order", [(8192, 24), (16384, 32)])
+@pytest.mark.parametrize("n,order", [(8192, 24), (16384, 32), (8192, 10), (16384, 8)])
 def test_reference_summation_order(handle, n, order):
     check(handle, batch(4, n, 24, 77), 24, order, flags=_capi.FLAG_REFERENCE_SUM_ORDER, acorr=orc.ACORR_REFERENCE)
 

@@ -62,6 +62,8 @@ run("config2: 4096 x 16b stereo, order 8 (4 candidates)", 8192, 2, 4096, 16, 8, 
 run("config3: 8192 x 24b stereo, order 24 (big-block kernels)", 2048, 2, 8192, 24, 24, True)
 run("config3: 8192 x 24b stereo, order 32 (big-block kernels)", 2048, 2, 8192, 24, 32, True)
 run("config4: 4096 x 16b 8-channel, order 10 (plain)", 2048, 8, 4096, 16, 10, False)
+run("8192 x 24b stereo, order 10 (big-block kernels; the generic kernel until round 3)", 6144, 2, 8192, 24, 10, True)
+run("16384 x 24b stereo, order 8 (big-block kernels; the generic kernel until round 3)", 3072, 2, 16384, 24, 8, True)
 run("config5: 16384 x 24b stereo, order 24 (big-block kernels)", 1024, 2, 16384, 24, 24, True)
 run("config5: 16384 x 24b stereo, order 32 (big-block kernels)", 1024, 2, 16384, 24, 32, True)
 run("ragged: 4608 x 16b stereo, order 10 (72-sample-per-lane wave kernel)", 4096, 2, 4608, 16, 10, True)

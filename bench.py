@@ -601,6 +601,16 @@ def secondary(torch, _capi, handle, args, dev):
                       "what": "flacenc_hip_stereo_qlpc_batch: 4 candidates per frame, 25 f64 fma + 24 64-bit MACs per "
                               "analysed sample; fp64_fma_frac = the fma alone against the 78.6 TFLOP/s FP64 vector peak"}
         if bn == 8192:
+            # the same shape in the stable build's own summation order (lane-per-subframe autocorrelation chains in
+            # front of the Levinson batch and the residual kernel)
+            rcfg24 = _capi.make_config(lpc_order=24, flags=_capi.FLAG_REFERENCE_SUM_ORDER)
+            ms = timed(lambda: handle.stereo_qlpc_batch_device(rcfg24, big.data_ptr(), bf, bn, bn, 24, bparams.data_ptr(),
+                                                               bres.data_ptr(), bn, stream=stream.cuda_stream))
+            med = float(np.median(ms))
+            sec["config3_8192x24bit_order24_reference_sum_order"] = {
+                "frames": bf, "block_size": bn, "ms_per_launch": stats(ms),
+                "Msamples_per_s": round(bf * 2 * bn / (med * 1e-3) / 1e6, 1),
+                "what": "flacenc_hip_stereo_qlpc_batch with FLACENC_HIP_FLAG_REFERENCE_SUM_ORDER"}
             # the same blocks at the reference's default order 10 (big-block kernels since round 3's end; the
             # generic kernel before: 79 G samples/s)
             ocfg10 = _capi.make_config(lpc_order=10)

@@ -30,15 +30,17 @@ namespace {
 
 constexpr int kTile = 64;  // samples per tile
 constexpr int kRow = 68;   // floats per LDS row (64 + 4: lane r reading its row with b128 hits its own 4 banks)
-constexpr int kLpl = 4;    // lags per lane
+constexpr int kLpl = 4;    // lags per lane (LPL = 8 from order 16 on: four waves instead of seven at order 24)
 constexpr int kTileFloats = 64 * kRow;
 
 // NIGHTLY: the simd-nightly build's order for blocks that are multiples of 16 samples (no scalar foot), in the same
 // frame: per lag d the body's vector lane chains (8 for d < 8, 16 for d = 8..15: lane l takes the samples with
 // t mod LANES == l, from the first multiple of LANES at or after P) are 8 / 16 accumulators of the LANE that owns
 // the subframe, the scalar head (t = P .. that multiple) one more; waves: lags 0-3, 4-7, then pairs 8-9, 10-11, ...
-template <bool STEREO, bool NIGHTLY>
+template <bool STEREO, bool NIGHTLY, int LPL = kLpl>
 __global__ void __launch_bounds__(NIGHTLY ? 384 : 576) acorr_reference_kernel(AcorrRefArgs a) {
+  static_assert(LPL == 4 || (LPL == 8 && !NIGHTLY), "four lags per lane, or eight in the stable order");
+  constexpr int CARRY = LPL;  // lagged values carried from step to step
   __shared__ __attribute__((aligned(16))) float tile[2 * kTileFloats];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -155,23 +157,23 @@ __global__ void __launch_bounds__(NIGHTLY ? 384 : 576) acorr_reference_kernel(Ac
   // this wave's lags: L0 .. L0 + nl - 1 -- four in the stable order, four or two in the nightly one (32 accumulators);
   // the lagged stream is read from the 16-byte aligned position B <= L0 and indexed OFF = L0 - B further back
   // (nightly: waves 0 and 1 take lags 0-3 and 4-7 with 8 accumulators per lag, the others a pair with 16 each)
-  const int L0 = !NIGHTLY ? kLpl * wave : (wave < 2 ? 4 * wave : 8 + 2 * (wave - 2));
+  const int L0 = !NIGHTLY ? LPL * wave : (wave < 2 ? 4 * wave : 8 + 2 * (wave - 2));
   const int B = L0 & ~3;
-  const int per_wave = (!NIGHTLY || wave < 2) ? kLpl : 2;
+  const int per_wave = (!NIGHTLY || wave < 2) ? LPL : 2;
   const int nl = P + 1 - L0 < per_wave ? P + 1 - L0 : per_wave;  // (<= 0: a wave that only helps with the loads)
   const float* const myrow = tile + lane * kRow;
   // stable: acc[j] is the chain of lag L0 + j.  nightly: acc[LANES j + l] is vector lane l of lag L0 + j, head[j] the
   // scalar chain of the samples between P and the first whole vector
-  double acc[NIGHTLY ? 32 : kLpl];
+  double acc[NIGHTLY ? 32 : LPL];
   double head[NIGHTLY ? kLpl : 1];
 #pragma unroll
-  for (int j = 0; j < (NIGHTLY ? 32 : kLpl); ++j) acc[j] = 0.0;
+  for (int j = 0; j < (NIGHTLY ? 32 : LPL); ++j) acc[j] = 0.0;
 #pragma unroll
   for (int j = 0; j < (NIGHTLY ? kLpl : 1); ++j) head[j] = 0.0;
-  // lw[i] = x_w[t - B - 4 + i] for the step at t: 4 carried + the step's own 8
-  double lw[12];
+  // lw[i] = x_w[t - B - CARRY + i] for the step at t: CARRY carried + the step's own 8
+  double lw[CARRY + 8];
 #pragma unroll
-  for (int i = 0; i < 12; ++i) lw[i] = 0.0;
+  for (int i = 0; i < CARRY + 8; ++i) lw[i] = 0.0;
   // one tile for a wave with NL lags; G0: the wave of lag 0, whose lagged stream is the current one;
   // LANES / OFF: nightly only
   auto sum_tile = [&](auto nl_tag, auto g0_tag, auto masked_tag, auto lanes_tag, auto off_tag, int k) __attribute__((always_inline)) {
@@ -197,22 +199,22 @@ __global__ void __launch_bounds__(NIGHTLY ? 384 : 576) acorr_reference_kernel(Ac
       cur[6] = (double)x1.z;
       cur[7] = (double)x1.w;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) lw[i] = lw[8 + i];
+      for (int i = 0; i < CARRY; ++i) lw[i] = lw[8 + i];
       if (G0) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) lw[4 + i] = cur[i];
+        for (int i = 0; i < 8; ++i) lw[CARRY + i] = cur[i];
       } else {
         const int u = k * kTile + 8 * step - B;  // a multiple of 4, >= -32: quads never straddle tiles
         const float4 y0 = *reinterpret_cast<const float4*>(lag_ptr(u));
         const float4 y1 = *reinterpret_cast<const float4*>(lag_ptr(u + 4));
-        lw[4] = (double)y0.x;
-        lw[5] = (double)y0.y;
-        lw[6] = (double)y0.z;
-        lw[7] = (double)y0.w;
-        lw[8] = (double)y1.x;
-        lw[9] = (double)y1.y;
-        lw[10] = (double)y1.z;
-        lw[11] = (double)y1.w;
+        lw[CARRY + 0] = (double)y0.x;
+        lw[CARRY + 1] = (double)y0.y;
+        lw[CARRY + 2] = (double)y0.z;
+        lw[CARRY + 3] = (double)y0.w;
+        lw[CARRY + 4] = (double)y1.x;
+        lw[CARRY + 5] = (double)y1.y;
+        lw[CARRY + 6] = (double)y1.z;
+        lw[CARRY + 7] = (double)y1.w;
       }
       const int tb = k * kTile + 8 * step;
 #pragma unroll
@@ -222,7 +224,7 @@ __global__ void __launch_bounds__(NIGHTLY ? 384 : 576) acorr_reference_kernel(Ac
         const double c = (!MASKED || tb + kk >= P) ? cur[kk] : 0.0;  // (cur[]: converted where it is used, see above)
         if (!NIGHTLY) {
 #pragma unroll
-          for (int j = 0; j < NL; ++j) acc[j] = __builtin_fma(lw[4 + kk - j], c, acc[j]);
+          for (int j = 0; j < NL; ++j) acc[j] = __builtin_fma(lw[CARRY + kk - j], c, acc[j]);
         } else {
           const int l = (kk + 8 * H) & (LANES - 1);  // (a constant once the loop is unrolled)
           // the head chain takes the samples below the first whole vector, the lane chain the others; the
@@ -232,7 +234,7 @@ __global__ void __launch_bounds__(NIGHTLY ? 384 : 576) acorr_reference_kernel(Ac
           const double c_head = in_head ? c : 0.0, c_lane = in_head ? 0.0 : c;
 #pragma unroll
           for (int j = 0; j < NL; ++j) {
-            const double lagged = lw[4 + kk - OFF - j];
+            const double lagged = lw[CARRY + kk - OFF - j];
             if (MASKED) head[j] = __builtin_fma(c_head, lagged, head[j]);
             acc[LANES * j + l] = __builtin_fma(MASKED ? c_lane : c, lagged, acc[LANES * j + l]);
           }
@@ -262,7 +264,11 @@ __global__ void __launch_bounds__(NIGHTLY ? 384 : 576) acorr_reference_kernel(Ac
       if (nl == 1) sum_tile(std::integral_constant<int, 1>{}, g0_tag, masked_tag, I8{}, I0{}, k);
       else if (nl == 2) sum_tile(std::integral_constant<int, 2>{}, g0_tag, masked_tag, I8{}, I0{}, k);
       else if (nl == 3) sum_tile(std::integral_constant<int, 3>{}, g0_tag, masked_tag, I8{}, I0{}, k);
-      else sum_tile(std::integral_constant<int, 4>{}, g0_tag, masked_tag, I8{}, I0{}, k);
+      else if (LPL == 4 || nl == 4) sum_tile(std::integral_constant<int, 4>{}, g0_tag, masked_tag, I8{}, I0{}, k);
+      else if (nl == 5) sum_tile(std::integral_constant<int, LPL == 8 ? 5 : 4>{}, g0_tag, masked_tag, I8{}, I0{}, k);
+      else if (nl == 6) sum_tile(std::integral_constant<int, LPL == 8 ? 6 : 4>{}, g0_tag, masked_tag, I8{}, I0{}, k);
+      else if (nl == 7) sum_tile(std::integral_constant<int, LPL == 8 ? 7 : 4>{}, g0_tag, masked_tag, I8{}, I0{}, k);
+      else sum_tile(std::integral_constant<int, LPL == 8 ? 8 : 4>{}, g0_tag, masked_tag, I8{}, I0{}, k);
     } else if (L0 < 8) {
       if (nl == 1) sum_tile(std::integral_constant<int, 1>{}, g0_tag, masked_tag, I8{}, I0{}, k);
       else if (nl == 2) sum_tile(std::integral_constant<int, 2>{}, g0_tag, masked_tag, I8{}, I0{}, k);
@@ -301,7 +307,7 @@ __global__ void __launch_bounds__(NIGHTLY ? 384 : 576) acorr_reference_kernel(Ac
     double* __restrict__ o = a.out + (size_t)sf * 33;
     if (!NIGHTLY) {
 #pragma unroll
-      for (int j = 0; j < kLpl; ++j)
+      for (int j = 0; j < LPL; ++j)
         if (j < nl) o[L0 + j] = acc[j];  // (nl <= 0: a loading-only wave)
     } else {
       // acc = 0 + chain(head); acc += chain(foot) (empty here: + 0); R = acc + reduce_sum(lane chains), the lane
@@ -448,7 +454,8 @@ hipError_t launch_nightly(const AcorrRefArgs& a, hipStream_t stream) {
 hipError_t launch_lag_groups(const AcorrRefArgs& a, hipStream_t stream) {
   const uint32_t blocks = (a.n_subframes + 63u) / 64u;
   uint32_t groups;  // lag groups = waves (1..9; nightly: lags 0-3, 4-7, then pairs: 1..6)
-  if (!a.nightly) groups = (a.lpc_order + 1u + (uint32_t)kLpl - 1u) / (uint32_t)kLpl;
+  const bool wide = !a.nightly && a.lpc_order >= 16u;  // eight lags per lane: 3..5 waves where four per lane need 5..9
+  if (!a.nightly) groups = wide ? (a.lpc_order + 1u + 7u) / 8u : (a.lpc_order + 1u + (uint32_t)kLpl - 1u) / (uint32_t)kLpl;
   else groups = a.lpc_order < 4u ? 1u : (a.lpc_order < 8u ? 2u : 2u + (a.lpc_order + 1u - 8u + 1u) / 2u);
   const uint32_t min_waves = a.stereo ? 2u : 4u;                     // (the cooperative loads want 128 / 256 threads)
   groups = groups < min_waves ? min_waves : groups;
@@ -456,6 +463,9 @@ hipError_t launch_lag_groups(const AcorrRefArgs& a, hipStream_t stream) {
   if (a.nightly) {
     if (a.stereo) hipLaunchKernelGGL((acorr_reference_kernel<true, true>), dim3(blocks), block, 0, stream, a);
     else hipLaunchKernelGGL((acorr_reference_kernel<false, true>), dim3(blocks), block, 0, stream, a);
+  } else if (wide) {
+    if (a.stereo) hipLaunchKernelGGL((acorr_reference_kernel<true, false, 8>), dim3(blocks), block, 0, stream, a);
+    else hipLaunchKernelGGL((acorr_reference_kernel<false, false, 8>), dim3(blocks), block, 0, stream, a);
   } else {
     if (a.stereo) hipLaunchKernelGGL((acorr_reference_kernel<true, false>), dim3(blocks), block, 0, stream, a);
     else hipLaunchKernelGGL((acorr_reference_kernel<false, false>), dim3(blocks), block, 0, stream, a);

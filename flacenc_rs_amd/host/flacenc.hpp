@@ -475,19 +475,35 @@ class HipContext {
   }
   HipContext(const HipContext&) = delete;
   HipContext& operator=(const HipContext&) = delete;
-  HipContext(HipContext&& o) noexcept : h_(o.h_) { o.h_ = nullptr; }  // std::vector<HipContext>: one per GPU
+  HipContext(HipContext&& o) noexcept : h_(o.h_), sum_order_(o.sum_order_) { o.h_ = nullptr; }  // std::vector<HipContext>: one per GPU
   HipContext& operator=(HipContext&& o) noexcept {
     if (this != &o) {
       if (h_) flacenc_hip_destroy(h_);
       h_ = o.h_;
+      sum_order_ = o.sum_order_;
       o.h_ = nullptr;
     }
     return *this;
   }
   flacenc_hip_handle* get() const { return h_; }
 
+  // Which build of the crate the floating-point sums of the path reproduce bit for bit: the stable build
+  // (one mul_add chain per lag, src/lpc.rs:533-548; one f32 chain per estimator partition,
+  // src/arrayutils.rs:435-506), the `simd-nightly` build (src/lpc.rs:439-531; LPC orders up to 15 -- above,
+  // the canonical order is used), or neither (Canonical: the kernels' own order, fastest; a valid encoding of the
+  // same configuration, within the spread between the two CPU builds).
+  enum class SumOrder { Canonical, Stable, SimdNightly };
+  void set_sum_order(SumOrder o) { sum_order_ = o; }
+  SumOrder sum_order() const { return sum_order_; }
+  uint32_t sum_order_flags(size_t lpc_order) const {
+    if (sum_order_ == SumOrder::Stable) return FLACENC_HIP_FLAG_REFERENCE_SUM_ORDER;
+    if (sum_order_ == SumOrder::SimdNightly && lpc_order <= 15) return FLACENC_HIP_FLAG_NIGHTLY_SUM_ORDER;
+    return 0u;
+  }
+
  private:
   flacenc_hip_handle* h_ = nullptr;
+  SumOrder sum_order_ = SumOrder::Canonical;
 };
 
 // Staging memory for the host-pointer entry points: page-locked (flacenc_hip_host_alloc), so that the
@@ -622,7 +638,8 @@ inline std::vector<component::Frame> encode_frame_run(const config::Encoder& con
   const config::SubFrameCoding& sc = config.subframe_coding;
   std::vector<component::Frame> out;
   out.reserve(bufs.size());
-  const flacenc_hip_qlpc_config abi_cfg = detail::to_abi(sc);
+  flacenc_hip_qlpc_config abi_cfg = detail::to_abi(sc);
+  abi_cfg.flags |= gpu.sum_order_flags(sc.qlpc.lpc_order);
   const bool stereo = (nch == 2);
   const size_t per_frame = stereo ? 4 : nch;  // analyses per frame (coding.rs:530-544)
 

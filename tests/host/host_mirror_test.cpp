@@ -79,6 +79,29 @@ int main(int argc, char** argv) {
   for (size_t channels : {1, 2, 3, 5, 8}) integrity_test(gpu, cfg, channels, 16123, 16, 4096);
   integrity_test(gpu, cfg, 2, 16123, 16, 1152);   // ragged partition size (72 samples)
   integrity_test(gpu, cfg, 2, 40000, 24, 8192);   // 24-bit, big block
+  // the CPU builds' own summation orders (HipContext::set_sum_order): lossless like the canonical order, and a
+  // stream of the same size to within a fraction of a percent (the orders differ in roundings, not in what is coded)
+  {
+    config::Encoder cd = cfg;
+    cd.subframe_coding.use_fixed = true;
+    const std::vector<int32_t> signal = make_signal(2, 20000, 16, 4242);
+    size_t bits[3] = {0, 0, 0};
+    int k = 0;
+    for (HipContext::SumOrder so : {HipContext::SumOrder::Canonical, HipContext::SumOrder::Stable, HipContext::SumOrder::SimdNightly}) {
+      gpu.set_sum_order(so);
+      integrity_test(gpu, cd, 2, 20000, 16, 4096);
+      auto src = source::MemSource::from_samples(signal, 2, 16, 44100);
+      component::Stream st = encode_with_fixed_block_size(cd, src, 4096, gpu);
+      for (const component::Frame& f : st.frames) bits[k] += f.count_subframe_bits();
+      ++k;
+    }
+    gpu.set_sum_order(HipContext::SumOrder::Canonical);
+    std::printf("  subframe bits canonical / stable / simd-nightly order: %zu / %zu / %zu\n", bits[0], bits[1], bits[2]);
+    for (int j = 1; j < 3; ++j) {
+      const double rel = double(bits[j] > bits[0] ? bits[j] - bits[0] : bits[0] - bits[j]) / double(bits[0]);
+      CHECK(rel < 0.005);
+    }
+  }
   {
     config::Encoder c2 = cfg;  // stereo variants off -> Independent only
     c2.stereo_coding.use_leftside = c2.stereo_coding.use_rightside = c2.stereo_coding.use_midside = false;

@@ -329,8 +329,9 @@ __device__ __attribute__((noinline)) void qlpc_subframe_call(const QlpcKernelArg
 #undef FLACENC_BODY_BLOCK
 #undef FLACENC_BODY_DIRECT
 }
+// (launched with the generic kernel's own workgroup size for the bucket: up to 1024 threads at orders <= 12)
 template <int MAXP, bool BIG>
-__global__ void __launch_bounds__(256) qlpc_marked_kernel(QlpcKernelArgs a) {
+__global__ void __launch_bounds__(MAXP <= 12 ? 1024 : (MAXP <= 16 ? 512 : 256)) qlpc_marked_kernel(QlpcKernelArgs a) {
   const uint32_t base = blockIdx.x * blockDim.x;
   const uint32_t mine = base + threadIdx.x;
   if (!__syncthreads_or(mine < a.n_subframes && a.params[mine].status == -1 ? 1 : 0)) return;
@@ -374,8 +375,8 @@ hipError_t launch_levinson_batch(const QlpcKernelArgs& a, hipStream_t stream) {
 
 template <int MAXP, bool BIG>
 hipError_t launch_one(const QlpcKernelArgs& a, int threads, size_t smem, hipStream_t stream) {
-  if constexpr (MAXP >= 24) {  // (orders 17..32, whose workgroups have 256 threads like the marked kernel's; the order-16 bucket's body does not finish compiling out of line:
-                               // there the marked subframes are found by one workgroup per subframe, below)
+  if constexpr (MAXP >= 24 || MAXP <= 12) {  // (the order-16 bucket's body does not finish compiling out of line: there the
+                                              // marked subframes are found by one workgroup per subframe, below)
     if (a.only_marked) {
       auto mk = qlpc_marked_kernel<MAXP, BIG>;
       static DynamicLdsOptIn opt_in_marked;

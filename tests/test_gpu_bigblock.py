@@ -109,6 +109,10 @@ def test_huge_residuals_go_through_the_literal_tables(handle, max_p):
     check(handle, x, 25, 24, max_rice_parameter=max_p)
     y = np.stack([util.quantize(util.noise(9, 16384, 1.0), 25), batch(1, 16384, 25, 7)[0]])
     check(handle, y, 25, 32, max_rice_parameter=max_p)
+    # the low order buckets' clean-up launches (qlpc_marked_kernel<8 / 10 / 12>, workgroups of 512 / 1024 threads)
+    for order in (8, 10, 12, 3):
+        check(handle, x, 25, order, max_rice_parameter=max_p)
+    check(handle, y, 25, 9, max_rice_parameter=max_p)
 
 
 def test_degenerate_signals(handle):

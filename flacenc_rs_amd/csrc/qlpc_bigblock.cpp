@@ -985,6 +985,8 @@ hipError_t launch_bigblock_residual(const QlpcKernelArgs& a, hipStream_t stream)
   const int k = (int)(a.block_size / 4096u);
   if (a.lpc_order <= 8)
     return k == 1 ? launch_residual<8, 1>(a, stream) : (k == 2 ? launch_residual<8, 2>(a, stream) : launch_residual<8, 4>(a, stream));
+  if (a.lpc_order <= 10)  // (the reference's default order)
+    return k == 1 ? launch_residual<10, 1>(a, stream) : (k == 2 ? launch_residual<10, 2>(a, stream) : launch_residual<10, 4>(a, stream));
   if (a.lpc_order <= 12)
     return k == 1 ? launch_residual<12, 1>(a, stream) : (k == 2 ? launch_residual<12, 2>(a, stream) : launch_residual<12, 4>(a, stream));
   if (a.lpc_order <= 16)

@@ -11,8 +11,9 @@
 // SEQUENTIAL fma chain over time in the reference -- R[tau] over t = P..n-1, G[i][j] (i <= j) over t = P-1..n-2
 // of the block without its last sample -- and with y_a(t') = x_w[t' + 1 - a] both are entries of one
 // (P+1) x (P+1) matrix H[a][b] = sum_{t' = P-1}^{n-2} fma(y_a, f32(w[t' + 1] * y_b), .): R[tau] = H[tau][0],
-// G[i][j] = H[i + 1][j + 1].  A chain cannot be split without changing its roundings, so a THREAD owns a chain:
-// P + 1 + P (P + 1) / 2 of them (66 at order 10, 325 at 24, 561 at 32), all walking the same LDS array.
+// G[i][j] = H[i + 1][j + 1].  A chain cannot be split without changing its roundings -- but H is a dense contraction
+// over time with every output distinct, and v_mfma_f64_16x16x4_f64 chained through its C operand performs exactly
+// the chain's operations in the chain's order (measured, see the kernel): a WAVE owns a 16 x 16 tile of H.
 // The factorisation then runs on wave 0 with a lane per matrix row (the column updates of nalgebra's
 // left-looking Cholesky are independent across rows, so lanes change nothing in any element's operation
 // sequence), the triangular solves follow nalgebra's loops, including dotx's eight partial accumulators.
@@ -177,58 +178,63 @@ __global__ void __launch_bounds__(576) direct_mse_kernel(DirectMseArgs a) {
   if (tid == 0) misc[1] = 0;
   __syncthreads();
 
-  // this thread's chain: c < P + 1 -> (a, b) = (c, 0) = R[c]; then the upper triangle i <= j of G as (i+1, j+1)
-  const int NC = (P + 1) + P * (P + 1) / 2;
-  int ca = 0, cb = 0;
-  if (tid < P + 1) {
-    ca = tid;
-  } else if (tid < NC) {
-    int idx = tid - (P + 1), i = 0;
-    while (idx >= P - i) {
-      idx -= P - i;
-      ++i;
-    }
-    ca = i + 1;
-    cb = i + idx + 1;
-  }
+  // H on the matrix cores: D[a][b] += sum over four time steps of A[a][k] B[k][b] with A[a][k] = y_a(t' + k) and
+  // B[k][b] = f32(w y_b)(t' + k) is v_mfma_f64_16x16x4_f64, and chained through its C operand that instruction IS the
+  // sequential chain acc = fma(A[a][k], B[k][b], acc), k ascending, bit for bit (tools/microbench/mfma_f64_order.hip:
+  // 512 000 outputs over +-20 binades of operands, no mismatch; the descending order and a pairwise tree match on
+  // 53 % and 24 %).  A wave owns a 16 x 16 tile of H and walks the block once: 16 x 16 x (n - P) fma in (n - P) / 4
+  // instructions where round 3's first version had a thread walk one entry's chain (P + 1 + P (P + 1) / 2 threads,
+  // each reading both of its operands from LDS per step).  Needed tiles: column block 0 (R[tau] = H[tau][0]) and
+  // the upper triangle a <= b; rows / columns beyond P shadow row / column P and are never stored.
+  typedef double v4d_t __attribute__((ext_vector_type(4)));
+  const int wave = tid >> 6, nwaves = nthr >> 6;
+  const int NT = (P + 1 + 15) >> 4;  // tiles per side: 1 up to order 15, 2 up to 31, 3 at order 32
   const int steps = IRLS ? (int)a.mae_steps : 0;
   for (int it = 0; it <= steps; ++it) {
     // ---- chains ----
-    if (tid < NC && n >= P + 1) {
-      double acc = 0.0;
-      const float* __restrict__ pa = xw + (P - ca);  // y_a(t') = xw[t' + 1 - a], t' = P - 1 ..
-      const float* __restrict__ pb = xw + (P - cb);
-      const float* __restrict__ pw = wgt + P;        // w[t' + 1]
-      const int len = n - P;                         // t' = P - 1 .. n - 2
-      int k = 0;
-      for (; k + 4 <= len; k += 4) {
-        const float a0 = pa[k], a1 = pa[k + 1], a2 = pa[k + 2], a3 = pa[k + 3];
-        float b0 = pb[k], b1 = pb[k + 1], b2 = pb[k + 2], b3 = pb[k + 3];
-        if (IRLS) {
-          b0 = pw[k] * b0;
-          b1 = pw[k + 1] * b1;
-          b2 = pw[k + 2] * b2;
-          b3 = pw[k + 3] * b3;
+    if (n >= P + 1) {
+      const int len = n - P;  // t' = P - 1 .. n - 2
+      for (int tile = wave; tile < NT * NT; tile += nwaves) {  // (wave-uniform)
+        const int I = tile / NT, J = tile - I * NT;
+        if (J < I && J != 0) continue;
+        const int kq = lane >> 4;
+        int arow = 16 * I + (lane & 15), bcol = 16 * J + (lane & 15);
+        arow = arow > P ? P : arow;
+        bcol = bcol > P ? P : bcol;
+        const float* __restrict__ pa = xw + (P - arow) + kq;  // y_a(t') = xw[t' + 1 - a], t' = P - 1 ..
+        const float* __restrict__ pb = xw + (P - bcol) + kq;
+        const float* __restrict__ pw = wgt + P + kq;          // w[t' + 1]
+        v4d_t acc = {0.0, 0.0, 0.0, 0.0};
+        int k = 0;
+#pragma unroll 4
+        for (; k + 4 <= len; k += 4) {
+          const float av = pa[k];
+          float bv = pb[k];
+          if (IRLS) bv = pw[k] * bv;
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)av, (double)bv, acc, 0, 0, 0);
         }
-        acc = __builtin_fma((double)a0, (double)b0, acc);
-        acc = __builtin_fma((double)a1, (double)b1, acc);
-        acc = __builtin_fma((double)a2, (double)b2, acc);
-        acc = __builtin_fma((double)a3, (double)b3, acc);
+        if (k < len) {  // the last one to three steps: the missing ones multiply by 0 (x + 0 * y == x)
+          const bool in = k + kq < len;
+          const float av = in ? pa[k] : 0.0f;
+          float bv = in ? pb[k] : 0.0f;
+          if (IRLS && in) bv = pw[k] * bv;
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)av, (double)bv, acc, 0, 0, 0);
+        }
+        // output register r of lane l: row 4 r + l / 16, column l % 16
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ra = 16 * I + 4 * r + kq, cb = 16 * J + (lane & 15);
+          if (cb == 0 && ra <= P) {
+            corr[ra] = acc[r];
+          } else if (ra >= 1 && ra <= cb && cb <= P) {
+            gram[(ra - 1) + (cb - 1) * P] = acc[r];
+            gram[(cb - 1) + (ra - 1) * P] = acc[r];
+          }
+        }
       }
-      for (; k < len; ++k) {
-        float b0 = pb[k];
-        if (IRLS) b0 = pw[k] * b0;
-        acc = __builtin_fma((double)pa[k], (double)b0, acc);
-      }
-      if (tid < P + 1) {
-        corr[tid] = acc;
-      } else {
-        gram[(ca - 1) + (cb - 1) * P] = acc;
-        gram[(cb - 1) + (ca - 1) * P] = acc;
-      }
-    } else if (tid < NC) {
-      if (tid < P + 1) corr[tid] = 0.0;
-      else gram[(ca - 1) + (cb - 1) * P] = gram[(cb - 1) + (ca - 1) * P] = 0.0;
+    } else {
+      for (int c = tid; c < P + 1; c += nthr) corr[c] = 0.0;
+      for (int c = tid; c < P * P; c += nthr) gram[c] = 0.0;
     }
     __syncthreads();
     if (it == steps && a.autocorr && tid <= 32 && !IRLS) a.autocorr[(size_t)sf * 33 + tid] = tid <= P ? corr[tid] : 0.0;

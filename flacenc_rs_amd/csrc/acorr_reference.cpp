@@ -1,4 +1,7 @@
-// acorr_reference.cpp -- autocorrelation in the summation order of the reference's stable build.
+// acorr_reference.cpp -- autocorrelation in the summation orders of the reference's builds.
+//
+// The stable order runs on the matrix cores (acorr_reference_mfma_kernel, further down); the lag-group kernel
+// described first serves the simd-nightly order (and served the stable one until the MFMA form).
 //
 // weighted_auto_correlation_nosimd (src/lpc.rs:533-548) keeps ONE accumulator per lag and walks the
 // block once:  for t in P..n { for tau in 0..=P { R[tau] = fma(x_w[t - tau], x_w[t], R[tau]) } }.
@@ -451,6 +454,194 @@ hipError_t launch_nightly(const AcorrRefArgs& a, hipStream_t stream) {
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// The stable order on the matrix cores.  v_mfma_f64_4x4x4_4b_f64 multiplies four independent 4 x 4 x 4 blocks,
+// D_b[i][j] += sum_k A_b[i][k] B_b[k][j], and chained through its C operand it performs, per output, exactly the
+// sequential chain acc = fma(A_b[i][k], B_b[k][j], acc) with k ascending (tools/microbench/mfma_f64_4x4x4_probe.hip:
+// lane 16 k + 4 b + i holds A_b[i][k], lane 16 k + 4 b + j holds B_b[k][j], lane 16 i + 4 b + j holds D_b[i][j];
+// 32 000 outputs of 64-instruction chains over +-20 binades of operands, no mismatch).  With
+//     A_b[i][k] = x_w[4 m + k - i - 12]        (the lagged sample)
+//     B_b[k][j] = x_w[4 m + k - 12 + 4 j]      (the current sample; 0 below t = P and from t = n on)
+// instruction m adds x_w[t - (i + 4 j)] x_w[t] for t = 4 m + k - 12 + 4 j, k = 0..3, to output (i, j): sixteen lags
+// tau = i + 4 j per block, every output one chain over ascending t -- weighted_auto_correlation_nosimd's own
+// (src/lpc.rs:533-548), the terms the reference does not have contributing fma(., 0, acc) = acc.  The Toeplitz
+// structure that keeps the autocorrelation off a GEMM tile is exactly what a 4 x 4 block with one
+// lag digit per axis absorbs.  A block is a subframe: a wave carries the four roles of one stereo frame (or four
+// plain subframes), 256 fma per instruction at 3.4 ns per SIMD where v_fma_f64 does 64 in 1.9 ns.  Orders above
+// 15 add a second and third accumulator with A shifted by 16 and 32 lags.
+// Each wave stages its own four rows (f32, windowed, M / S formed) in its own LDS region: [64 samples of history |
+// a tile of 256], no workgroup barrier anywhere; the tile's loads are 1 KB runs per row.
+constexpr int kMTile = 256;   // samples per staging step
+constexpr int kMHist = 64;    // samples kept in front of the tile (lags up to 47 + the 12 of the column shift)
+constexpr int kMRow = kMHist + kMTile + 8;   // row stride = 8 mod 32 banks: the four blocks' A reads (7 addresses each)
+                                             // fall on disjoint banks, their B reads (16 each) two to a bank -- the minimum
+
+template <bool STEREO, int NS>
+__global__ void __launch_bounds__(256) acorr_reference_mfma_kernel(AcorrRefArgs a) {
+  typedef float elem_t;  // (f64 in LDS -- no conversion per operand, twice the LDS traffic, 3 workgroups per CU -- is 2.4 x slower)
+  __shared__ __attribute__((aligned(16))) elem_t lds[4][4 * kMRow];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  elem_t* const rows = lds[wave];  // row b at rows + b * kMRow
+  const int n = (int)a.block_size;
+  const int P = (int)a.lpc_order;
+  const bool vec_ok = ((reinterpret_cast<uintptr_t>(a.samples) & 15) == 0) && ((a.stride & 3) == 0);
+  const float* __restrict__ wtab = a.window ? a.window + 32 : nullptr;
+  // the wave's four subframes
+  const uint32_t unit = blockIdx.x * 4u + (uint32_t)wave;  // stereo: frame; plain: group of four subframes
+  const uint32_t sf0 = unit * 4u;
+  if (sf0 >= a.n_subframes) return;  // (whole wave; no barriers in this kernel)
+  const int32_t* rowp[STEREO ? 2 : 4];
+  if (STEREO) {
+    rowp[0] = a.samples + (size_t)(2u * unit) * a.stride;
+    rowp[1] = rowp[0] + a.stride;
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      uint32_t sf = sf0 + (uint32_t)r;
+      sf = sf < a.n_subframes ? sf : a.n_subframes - 1u;  // (a ragged last group shadows the last subframe)
+      rowp[r] = a.samples + (size_t)sf * a.stride;
+    }
+  }
+  // global -> registers for the tile at T0: lane l holds samples T0 + 4 l .. + 3 of each row
+  int4 raw[STEREO ? 2 : 4];
+  float4 wv;
+  auto issue = [&](int T0) __attribute__((always_inline)) {
+    const int t = T0 + 4 * lane;
+    const bool full = vec_ok && T0 + kMTile <= n;
+#pragma unroll
+    for (int r = 0; r < (STEREO ? 2 : 4); ++r) {
+      if (full) {
+        raw[r] = *reinterpret_cast<const int4*>(rowp[r] + t);
+      } else {
+        raw[r].x = t + 0 < n ? rowp[r][t + 0] : 0;
+        raw[r].y = t + 1 < n ? rowp[r][t + 1] : 0;
+        raw[r].z = t + 2 < n ? rowp[r][t + 2] : 0;
+        raw[r].w = t + 3 < n ? rowp[r][t + 3] : 0;
+      }
+    }
+    wv = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+    if (wtab) {
+      wv.x = t + 0 < n ? wtab[t + 0] : 0.0f;
+      wv.y = t + 1 < n ? wtab[t + 1] : 0.0f;
+      wv.z = t + 2 < n ? wtab[t + 2] : 0.0f;
+      wv.w = t + 3 < n ? wtab[t + 3] : 0.0f;
+    }
+  };
+  // registers -> the tile part of the rows: x_w = (f32)s * w, one f32 rounding (lpc.rs:751-754)
+  auto land = [&]() __attribute__((always_inline)) {
+    auto put = [&](int b, const int4& sv) {
+      float4 x;
+      x.x = (float)sv.x * wv.x;
+      x.y = (float)sv.y * wv.y;
+      x.z = (float)sv.z * wv.z;
+      x.w = (float)sv.w * wv.w;
+      *reinterpret_cast<float4*>(&rows[b * kMRow + kMHist + 4 * lane]) = x;
+    };
+    if (STEREO) {
+      const int4 l = raw[0], r = raw[1];
+      put(0, l);
+      put(1, r);
+      put(2, make_int4((l.x + r.x) >> 1, (l.y + r.y) >> 1, (l.z + r.z) >> 1, (l.w + r.w) >> 1));  // coding.rs:483
+      put(3, make_int4(l.x - r.x, l.y - r.y, l.z - r.z, l.w - r.w));
+    } else {
+#pragma unroll
+      for (int b = 0; b < 4; ++b) put(b, raw[b]);
+    }
+  };
+  // the history in front of the first tile: zeros (the samples in front of the block)
+  rows[(lane >> 4) * kMRow + (lane & 15)] = (elem_t)0;
+  rows[(lane >> 4) * kMRow + 16 + (lane & 15)] = (elem_t)0;
+  rows[(lane >> 4) * kMRow + 32 + (lane & 15)] = (elem_t)0;
+  rows[(lane >> 4) * kMRow + 48 + (lane & 15)] = (elem_t)0;
+
+  // this lane's operands: k = lane / 16, block b = (lane % 16) / 4, r = lane % 4 (i for A, j for B)
+  const int k = lane >> 4, b = (lane >> 2) & 3, r = lane & 3;
+  const elem_t* const pa = rows + b * kMRow + kMHist + (k - r - 12);      // + 4 m: x_w[T0 + 4 m + k - i - 12]
+  const elem_t* const pb = rows + b * kMRow + kMHist + (k - 12 + 4 * r);  // + 4 m: x_w[T0 + 4 m + k - 12 + 4 j]
+  double acc[NS];
+#pragma unroll
+  for (int s_ = 0; s_ < NS; ++s_) acc[s_] = 0.0;
+
+  const int n_steps = (n + 12 + 3) >> 2;                   // instructions: the last column trails by 12 samples
+  const int n_tiles = (4 * n_steps + kMTile - 1) / kMTile;  // (the tile after the block's end, if any, is all zeros)
+  issue(0);
+  for (int tile = 0; tile < n_tiles; ++tile) {
+    const int T0 = tile * kMTile;
+    land();
+    if (tile + 1 < n_tiles) issue(T0 + kMTile);  // in flight while this tile is summed
+    const int m_end = (n_steps - tile * (kMTile / 4)) < (kMTile / 4) ? (n_steps - tile * (kMTile / 4)) : (kMTile / 4);
+    // B is the current sample: nothing below t = P (only the first tile can hold such samples; P + 12 < 64)
+    int m = 0;
+    if (tile == 0) {
+      const int m_mask = (P + 12 + 3) >> 2;  // steps that can touch t < P
+      for (; m < m_mask && m < m_end; ++m) {
+        const int tcur = 4 * m + k - 12 + 4 * r;
+        const double bd = tcur >= P ? (double)pb[4 * m] : 0.0;
+#pragma unroll
+        for (int s_ = 0; s_ < NS; ++s_)
+          acc[s_] = __builtin_amdgcn_mfma_f64_4x4x4f64((double)pa[4 * m - 16 * s_], bd, acc[s_], 0, 0, 0);
+      }
+    }
+    if (m == 0 && m_end == kMTile / 4) {
+      // a whole tile: constant trip count, reads and MFMAs interleaved by the scheduler.  (Fetching 16 steps'
+      // operands ahead of the previous batch's MFMAs costs 104 registers and occupancy: 484 us against 444.  What
+      // binds is the LDS: 512 bytes of operands per instruction whichever way they are read, ~7 ns per instruction
+      // and SIMD at the LDS's rate where conversions + MFMA alone take 4.7.)
+#pragma unroll 16
+      for (int mm = 0; mm < kMTile / 4; ++mm) {
+        const double bd = (double)pb[4 * mm];
+#pragma unroll
+        for (int s_ = 0; s_ < NS; ++s_)
+          acc[s_] = __builtin_amdgcn_mfma_f64_4x4x4f64((double)pa[4 * mm - 16 * s_], bd, acc[s_], 0, 0, 0);
+      }
+    } else {
+      for (; m < m_end; ++m) {
+        const double bd = (double)pb[4 * m];
+#pragma unroll
+        for (int s_ = 0; s_ < NS; ++s_)
+          acc[s_] = __builtin_amdgcn_mfma_f64_4x4x4f64((double)pa[4 * m - 16 * s_], bd, acc[s_], 0, 0, 0);
+      }
+    }
+    // the tile's last 64 samples become the next tile's history (the wave's own LDS operations are ordered)
+    if (tile + 1 < n_tiles) {
+      const elem_t h = rows[(lane >> 4) * kMRow + kMTile + (lane & 15)];
+      const elem_t h1 = rows[(lane >> 4) * kMRow + kMTile + 16 + (lane & 15)];
+      const elem_t h2 = rows[(lane >> 4) * kMRow + kMTile + 32 + (lane & 15)];
+      const elem_t h3 = rows[(lane >> 4) * kMRow + kMTile + 48 + (lane & 15)];
+      rows[(lane >> 4) * kMRow + (lane & 15)] = h;
+      rows[(lane >> 4) * kMRow + 16 + (lane & 15)] = h1;
+      rows[(lane >> 4) * kMRow + 32 + (lane & 15)] = h2;
+      rows[(lane >> 4) * kMRow + 48 + (lane & 15)] = h3;
+    }
+  }
+  // D_b[i][j] sits in lane 16 i + 4 b + j: lag i + 4 j (+ 16 per further accumulator) of subframe sf0 + b
+  {
+    const int i = lane >> 4, bo = (lane >> 2) & 3, j = lane & 3;
+    const uint32_t sf = sf0 + (uint32_t)bo;
+    if (sf < a.n_subframes) {
+      double* __restrict__ o = a.out + (size_t)sf * 33;
+#pragma unroll
+      for (int s_ = 0; s_ < NS; ++s_) {
+        const int lag = i + 4 * j + 16 * s_;
+        if (lag <= 32) o[lag] = lag <= P ? acc[s_] : 0.0;
+      }
+      if (NS < 3 && i + 4 * j == 0) {
+        for (int lag = 16 * NS; lag < 33; ++lag) o[lag] = 0.0;
+      }
+    }
+  }
+}
+
+template <int NS>
+hipError_t launch_mfma(const AcorrRefArgs& a, hipStream_t stream) {
+  const uint32_t units = a.stereo ? a.n_subframes / 4u : (a.n_subframes + 3u) / 4u;
+  const uint32_t blocks = (units + 3u) / 4u;
+  if (a.stereo) hipLaunchKernelGGL((acorr_reference_mfma_kernel<true, NS>), dim3(blocks), dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL((acorr_reference_mfma_kernel<false, NS>), dim3(blocks), dim3(256), 0, stream, a);
+  return hipGetLastError();
+}
+
 hipError_t launch_lag_groups(const AcorrRefArgs& a, hipStream_t stream) {
   const uint32_t blocks = (a.n_subframes + 63u) / 64u;
   uint32_t groups;  // lag groups = waves (1..9; nightly: lags 0-3, 4-7, then pairs: 1..6)
@@ -484,6 +675,11 @@ hipError_t launch_acorr_reference(const AcorrRefArgs& a, hipStream_t stream) {
     // blocks that are whole vectors of 16 (no scalar foot): the lane-per-subframe form; any other size: one
     // workgroup per subframe with a GPU lane per vector lane
     if ((a.block_size & 15u) != 0u || a.block_size < 64u) return launch_nightly(a, stream);
+  }
+  if (!a.nightly) {  // the stable order: on the matrix cores
+    if (a.lpc_order <= 15u) return launch_mfma<1>(a, stream);
+    if (a.lpc_order <= 31u) return launch_mfma<2>(a, stream);
+    return launch_mfma<3>(a, stream);
   }
   return launch_lag_groups(a, stream);
 }

@@ -467,7 +467,8 @@ hipError_t launch_nightly(const AcorrRefArgs& a, hipStream_t stream) {
 // (src/lpc.rs:533-548), the terms the reference does not have contributing fma(., 0, acc) = acc.  The Toeplitz
 // structure that keeps the autocorrelation off a GEMM tile is exactly what a 4 x 4 block with one
 // lag digit per axis absorbs.  A block is a subframe: a wave carries the four roles of one stereo frame (or four
-// plain subframes), 256 fma per instruction at 3.4 ns per SIMD where v_fma_f64 does 64 in 1.9 ns.  Orders above
+// plain subframes), 256 fma per instruction in 16 cycles (the vector pipe's f64 rate; what the form saves is operand
+// handling: one LDS value per four fma).  Orders above
 // 15 add a second and third accumulator with A shifted by 16 and 32 lags.
 // Each wave stages its own four rows (f32, windowed, M / S formed) in its own LDS region: [64 samples of history |
 // a tile of 256], no workgroup barrier anywhere; the tile's loads are 1 KB runs per row.
@@ -585,9 +586,8 @@ __global__ void __launch_bounds__(256) acorr_reference_mfma_kernel(AcorrRefArgs 
     }
     if (m == 0 && m_end == kMTile / 4) {
       // a whole tile: constant trip count, reads and MFMAs interleaved by the scheduler.  (Fetching 16 steps'
-      // operands ahead of the previous batch's MFMAs costs 104 registers and occupancy: 484 us against 444.  What
-      // binds is the LDS: 512 bytes of operands per instruction whichever way they are read, ~7 ns per instruction
-      // and SIMD at the LDS's rate where conversions + MFMA alone take 4.7.)
+      // operands ahead of the previous batch's MFMAs costs 104 registers and occupancy: 484 us against 444.  A step
+      // costs a SIMD 11.5 ns -- 7.4 for the MFMA, 2 x 2 for the conversions, one after the other.)
 #pragma unroll 16
       for (int mm = 0; mm < kMTile / 4; ++mm) {
         const double bd = (double)pb[4 * mm];

@@ -17,35 +17,26 @@ __global__ void chain(const double* A, const double* B, double* D, int K4) {  //
   for (int m = 0; m < K4; ++m) acc = __builtin_amdgcn_mfma_f64_4x4x4f64(A[m * 64 + l], B[m * 64 + l], acc, 0, 0, 0);
   D[l] = acc;
 }
-__global__ void __launch_bounds__(256) timing(double* out, int iters, double x, double y) {
-  double acc = threadIdx.x;
-  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
-  for (int i = 0; i < iters; ++i) {
-#pragma unroll
-    for (int u = 0; u < 16; ++u) acc = __builtin_amdgcn_mfma_f64_4x4x4f64(x, y, acc, 0, 0, 0);
-  }
-  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
-  if (acc == 12345.678) out[1] = acc;
-  if (blockIdx.x == 0 && threadIdx.x == 0) out[0] = (double)(r1 - r0);
-}
-
-// one step of the autocorrelation kernel without its LDS reads: two f32 -> f64 conversions feeding an MFMA
-__global__ void __launch_bounds__(256) mixed(double* out, int iters, float x, float y) {
+// the autocorrelation kernel's step without its LDS reads -- two f32 -> f64 conversions feeding an MFMA (CVT) or
+// the MFMA alone -- as a grid of workgroups of four waves, timed by events around the whole launch.  (Timing one
+// workgroup from inside, as a first version of this probe did, reports that workgroup's share of an unevenly filled
+// chip: 3.4 ns per instruction where the launch as a whole says 8.)
+template <bool CVT>
+__global__ void __launch_bounds__(256) steps(double* out, int iters, float x, float y) {
   double acc = threadIdx.x;
   float xa = x + threadIdx.x, ya = y;
-  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  double a = xa, b = ya;
   for (int i = 0; i < iters; ++i) {
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
-      double a, b;
-      asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(a) : "v"(xa));
-      asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(b) : "v"(ya));
+      if (CVT) {
+        asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(a) : "v"(xa));
+        asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(b) : "v"(ya));
+      }
       acc = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, acc, 0, 0, 0);
     }
   }
-  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
   if (acc == 12345.678) out[1] = acc;
-  if (blockIdx.x == 0 && threadIdx.x == 0) out[0] = (double)(r1 - r0);
 }
 
 int main() {
@@ -98,30 +89,24 @@ int main() {
     }
     std::printf("chain of %d instructions == sequential fma (k ascending) under the layout hypothesis: %ld of %ld\n", K4, ok, tot);
   }
-  // 3. cost of a dependent chain, 1 / 2 / 4 waves per SIMD
-  for (int w : {1, 2, 4}) {
-    const int iters = 20000;
-    double h = 0;
-    for (int rep = 0; rep < 2; ++rep) {
-      hipLaunchKernelGGL(timing, dim3(256 * w), dim3(256), 0, 0, dD, iters, 1.0000001, 0.5);
-      hipDeviceSynchronize();
-      hipMemcpy(&h, dD, 8, hipMemcpyDeviceToHost);
+  // 3. cost: grids of 256 .. 6144 workgroups (1 .. 8 waves per SIMD resident, then several rounds), 4352 steps per wave
+  for (int cvt = 0; cvt < 2; ++cvt)
+    for (int grid : {256, 512, 1024, 2048, 6144}) {
+      hipEvent_t e0, e1;
+      hipEventCreate(&e0);
+      hipEventCreate(&e1);
+      float ms = 0;
+      for (int rep = 0; rep < 4; ++rep) {
+        hipEventRecord(e0);
+        if (cvt) hipLaunchKernelGGL((steps<true>), dim3(grid), dim3(256), 0, 0, dD, 272, 1.5f, 0.5f);
+        else hipLaunchKernelGGL((steps<false>), dim3(grid), dim3(256), 0, 0, dD, 272, 1.5f, 0.5f);
+        hipEventRecord(e1);
+        hipDeviceSynchronize();
+        hipEventElapsedTime(&ms, e0, e1);
+      }
+      std::printf("%s, %4d workgroups x 4 waves x 4352 steps: %7.1f us = %.2f ns per step per SIMD\n",
+                  cvt ? "2 x v_cvt_f64_f32 + v_mfma_f64_4x4x4" : "v_mfma_f64_4x4x4 alone", grid, ms * 1e3,
+                  ms * 1e6 / (grid * 4.0 * 4352 / 1024));
     }
-    const double ns = h * 10.0;  // 100 MHz ticks
-    std::printf("%d wave(s)/SIMD: %.2f ns per dependent v_mfma_f64_4x4x4 per wave, %.2f ns per instruction per SIMD\n", w,
-                ns / (iters * 16.0), ns / (iters * 16.0 * w));
-  }
-  for (int w : {1, 2, 4, 7, 8}) {
-    const int iters = 20000;
-    double h = 0;
-    for (int rep = 0; rep < 2; ++rep) {
-      hipLaunchKernelGGL(mixed, dim3(256 * w), dim3(256), 0, 0, dD, iters, 1.5f, 0.5f);
-      hipDeviceSynchronize();
-      hipMemcpy(&h, dD, 8, hipMemcpyDeviceToHost);
-    }
-    const double ns = h * 10.0;
-    std::printf("%d wave(s)/SIMD: 2 x v_cvt_f64_f32 + v_mfma_f64_4x4x4: %.2f ns per step per wave, %.2f ns per step per SIMD\n", w,
-                ns / (iters * 16.0), ns / (iters * 16.0 * w));
-  }
   return 0;
 }

@@ -1073,8 +1073,17 @@ def test_candidate_and_channel_api_fuzz(handle, seed):
             bpsv = np.full(flat.shape[0], bps, np.uint8)
             if bps < 24:
                 bpsv[::3] = bps + 1
+            # FLACENC_FUZZ_ORDER=reference|nightly (tools/fuzz_more.py): the same sweep in the reference's summation orders
+            mode = os.environ.get("FLACENC_FUZZ_ORDER", "canonical")
+            gflag, oac, osum = {"canonical": (0, orc.ACORR_CANONICAL, orc.SUMABS_CANONICAL),
+                                "reference": (_capi.FLAG_REFERENCE_SUM_ORDER, orc.ACORR_REFERENCE, orc.SUMABS_STABLE),
+                                "nightly": (_capi.FLAG_NIGHTLY_SUM_ORDER, orc.ACORR_NIGHTLY, orc.SUMABS_NIGHTLY)}[mode]
+            if mode == "nightly" and qcfg["lpc_order"] > 15:
+                qcfg["lpc_order"] = 15
+            qcfg["flags"] = gflag
+            ocfg_kw = {k: v for k, v in qcfg.items() if k != "flags"}
             params, resid, _, _ = handle.qlpc_batch(flat, bpsv, _capi.make_config(**qcfg))
-            ocfg = orc.make_config(acorr=orc.ACORR_CANONICAL, **qcfg)
+            ocfg = orc.make_config(acorr=oac, **ocfg_kw)
             for k in range(flat.shape[0]):
                 w = orc.estimated_qlpc(flat[k], int(bpsv[k]), ocfg)
                 p = params[k]
@@ -1090,7 +1099,7 @@ def test_candidate_and_channel_api_fuzz(handle, seed):
             fcfg = _capi.make_frame_config(_capi.make_config(**qcfg), use_fixed=True, **fx)
             fp, fr, fk = handle.fixed_lpc_batch(flat, bpsv, fcfg)
             ofx = orc.make_fixed_config(max_order=fx["fixed_max_order"], order_sel=fx["fixed_order_sel"],
-                                        partitions=fx["fixed_partitions"], sum_mode=orc.SUMABS_CANONICAL)
+                                        partitions=fx["fixed_partitions"], sum_mode=osum)
             for k in range(flat.shape[0]):
                 w = orc.fixed_lpc(flat[k], int(bpsv[k]), 2 ** 63, ofx, max_p=int(ocfg.max_rice_parameter))
                 assert int(fp[k]["order"]) == w["order"] and int(fk[k]) == w["estimate"][w["order"]], (k, fx)

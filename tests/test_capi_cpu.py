@@ -46,6 +46,16 @@ def test_verify_config_mirrors_reference_ranges():
     cfg = _capi.make_config()
     cfg.window_type = 7
     assert _capi.verify_config(cfg) == _capi.ERR_BAD_CONFIG
+    # ABI 4: the summation-order flags exclude each other, the simd-nightly order stops at lag 15 (above, the split
+    # of the reference's buffer depends on its allocator: UNSUPPORTED, not a configuration error), the experimental
+    # estimators' fields are accepted (the reference's `experimental` build) within the IRLS step bound
+    both = _capi.FLAG_REFERENCE_SUM_ORDER | _capi.FLAG_NIGHTLY_SUM_ORDER
+    assert _capi.verify_config(_capi.make_config(flags=both)) == _capi.ERR_BAD_CONFIG
+    assert _capi.verify_config(_capi.make_config(lpc_order=15, flags=_capi.FLAG_NIGHTLY_SUM_ORDER)) == _capi.OK
+    assert _capi.verify_config(_capi.make_config(lpc_order=16, flags=_capi.FLAG_NIGHTLY_SUM_ORDER)) == _capi.ERR_UNSUPPORTED
+    assert _capi.verify_config(_capi.make_config(lpc_order=24, flags=_capi.FLAG_REFERENCE_SUM_ORDER)) == _capi.OK
+    assert _capi.verify_config(_capi.make_config(use_direct_mse=True, mae_optimization_steps=3)) == _capi.OK
+    assert _capi.verify_config(_capi.make_config(use_direct_mse=True, mae_optimization_steps=65)) == _capi.ERR_BAD_CONFIG
 
 
 @pytest.mark.parametrize("window,n", [(("tukey", 0.4), 4096), (("tukey", 0.3), 32), (("tukey", 1.0), 1001),

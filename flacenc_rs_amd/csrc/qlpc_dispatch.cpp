@@ -47,6 +47,10 @@ QlpcLaunchPlan plan_qlpc_launch(uint32_t block_size, uint32_t lpc_order) {
   const int max_threads = plan.maxp <= 12 ? 1024 : (plan.maxp <= 16 ? 512 : 256);
   int threads = 64;
   while (threads < rows && threads < max_threads) threads <<= 1;
+  // a block a little over half a workgroup's worth of 16-sample rows (1152 = 72 rows, 2304 = 144) takes the smaller
+  // workgroup and a second, mostly idle chunk round: the second wave's idle lanes cost issue slots in every phase,
+  // the extra round only in two (measured: 2304 at order 8 / 10 78 -> 90 / 59 -> 82 G samples/s, 1152 at order 10 56 -> 65)
+  if (n < 4096 && threads > 64 && rows <= threads / 2 + threads / 8) threads >>= 1;
   plan.threads = threads;
   const int J = (rows + threads - 1) / threads;
   int Jp = 1;

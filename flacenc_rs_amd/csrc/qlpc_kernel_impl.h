@@ -375,6 +375,9 @@ hipError_t launch_levinson_batch(const QlpcKernelArgs& a, hipStream_t stream) {
 
 template <int MAXP, bool BIG>
 hipError_t launch_one(const QlpcKernelArgs& a, int threads, size_t smem, hipStream_t stream) {
+  // the order selector's sums are carved only for the launch that selects (plan_qlpc_launch counts them always): a
+  // 1152-sample block's workgroup drops from 10 LDS granules to 8, 12 -> 16 workgroups per CU
+  if (a.fixed_mode != 1u) smem -= (size_t)kFixedSumWords * 8;
   if constexpr (MAXP >= 24 || MAXP <= 12) {  // (the order-16 bucket's body does not finish compiling out of line: there the
                                               // marked subframes are found by one workgroup per subframe, below)
     if (a.only_marked) {

@@ -201,6 +201,16 @@ def test_ragged_block_sizes(handle, n):
     full_parity(handle, x, 16, 10)
 
 
+@pytest.mark.parametrize("n", [1040, 1152, 1280, 1281, 2064, 2304, 2400, 2560, 2561, 4095])
+@pytest.mark.parametrize("order", [4, 8, 12, 16, 32])
+def test_blocks_a_little_over_half_a_workgroup(handle, n, order):
+    """plan_qlpc_launch: a block whose 16-sample rows fill between 1/2 and 5/8 of the next power-of-two workgroup
+    (1152 = 72 rows, 2304 = 144) runs on half of it in two chunk rounds, the second mostly idle -- in every order
+    bucket (their workgroup limits differ), either side of the 5/8 boundary (1280 | 1281, 2560 | 2561), 24-bit too."""
+    full_parity(handle, batch_sine_noise(3, n, 16, seed0=n + order), 16, order)
+    full_parity(handle, batch_sine_noise(2, n, 24, seed0=n - order), 24, order)
+
+
 @pytest.mark.parametrize("n", [16384 + 256, 24576, 32512, 32767])
 def test_maximum_block_sizes(handle, n):
     """Up to MAX_BLOCK_SIZE = 32767 (constant.rs:57): the unpadded-LDS kernel variant."""

@@ -125,6 +125,21 @@ __device__ __forceinline__ uint32_t approx_ent_bits(double sum, uint32_t count) 
   return v > 0.0f ? (uint32_t)v : 0u;  // `as usize`: NaN and negatives -> 0
 }
 
+// (x ^ m) + y (v_xad_u32).  With m = 0x7FFFFFFF it is y - x + (2^31 - 1) mod 2^32: the difference of two values
+// that carry a common bias, itself biased by 2^31 - 1 -- one instruction per differencing step where
+// (y - x) ^ 0x80000000 takes two.
+__device__ __forceinline__ uint32_t xad_u32(uint32_t x, uint32_t m, uint32_t y) {
+  uint32_t r;
+  asm("v_xad_u32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "s"(m), "v"(y));
+  return r;
+}
+// |x - y| + acc on unsigned operands (v_sad_u32)
+__device__ __forceinline__ uint32_t sad_u32(uint32_t x, uint32_t y, uint32_t acc) {
+  uint32_t r;
+  asm("v_sad_u32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(acc));
+  return r;
+}
+
 // Optional per-phase timestamps (s_memtime, shader clock) for the profiling build of
 // tools/phase_profile.py: workgroup leader only, never read by the kernel itself.
 #define FLACENC_STAMP(slot)                                                             \

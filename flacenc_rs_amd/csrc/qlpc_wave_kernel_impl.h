@@ -362,21 +362,6 @@ __device__ __forceinline__ void planes_add(uint32_t* a, const uint32_t* b) {
   a[NA] = carry;
 }
 
-// (x ^ m) + y (v_xad_u32).  With m = 0x7FFFFFFF it is y - x + (2^31 - 1) mod 2^32: the difference of two values
-// that carry a common bias, itself biased by 2^31 - 1 -- one instruction per differencing step where
-// (y - x) ^ 0x80000000 takes two.
-__device__ __forceinline__ uint32_t xad_u32(uint32_t x, uint32_t m, uint32_t y) {
-  uint32_t r;
-  asm("v_xad_u32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "s"(m), "v"(y));
-  return r;
-}
-// |x - y| + acc on unsigned operands (v_sad_u32)
-__device__ __forceinline__ uint32_t sad_u32(uint32_t x, uint32_t y, uint32_t acc) {
-  uint32_t r;
-  asm("v_sad_u32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(acc));
-  return r;
-}
-
 // what fixed_lpc (coding.rs:298-331) settled on for one subframe
 struct FixedChoice {
   bool have;

@@ -862,6 +862,12 @@ def test_flac_stream_end_to_end(handle):
     (8192, 24, 24, dict()), (192, 16, 8, dict(fixed_order_sel=0)), (4096, 16, 16, dict()),
     (4096, 16, 8, dict(fixed_partitions=12)), (16384, 24, 12, dict(use_lpc=False)),
     (2304, 16, 8, dict(use_fixed=False)), (100, 8, 4, dict()),
+    # the selector's 18-samples-per-lane sums (blocks of 2^k * 18 samples with partitions of whole lanes) at the
+    # widest inputs -- frame 5: +-full scale alternating, the side channel 25 bits of it -- and next to partition
+    # counts that do not qualify (1152 / 12 = 96 is not a multiple of 18; 1152 / 128 = 9)
+    (1152, 24, 8, dict()), (2304, 24, 10, dict()), (576, 24, 6, dict()), (2304, 16, 8, dict(fixed_partitions=8)),
+    (1152, 24, 8, dict(fixed_partitions=64)), (1152, 16, 8, dict(fixed_partitions=32)), (1152, 24, 8, dict(fixed_partitions=12)),
+    (18432, 24, 8, dict()),
 ])
 def test_encode_stereo_frames_any_shape(handle, n, bps, order, kw):
     """flacenc_hip_encode_stereo_frames outside the fused kernel's shape (ragged / large / tiny
@@ -875,6 +881,8 @@ def test_encode_stereo_frames_any_shape(handle, n, bps, order, kw):
     base[2] = np.stack([(t // 7) % half, (t * t // (n // 4 + 1)) % half - half // 2]).astype(np.int32)
     base[3, 0] = 77
     base[4] = np.stack([util.quantize(util.noise(1, n, 0.999), bps), util.quantize(util.noise(2, n, 0.999), bps)])
+    alt = np.where(t % 2 == 0, (1 << (bps - 1)) - 1, -(1 << (bps - 1))).astype(np.int32)
+    base[5] = np.stack([alt, -1 - alt])  # fourth differences of 16 x full scale; side = 2 x full scale + 1
     use_fixed = kw.pop("use_fixed", True)
     cfg = _capi.make_frame_config(gpu_cfg(order), use_fixed=use_fixed, **kw)
     got, gres = handle.encode_stereo_frames(base, bps, cfg)

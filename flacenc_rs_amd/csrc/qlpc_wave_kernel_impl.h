@@ -182,35 +182,6 @@ __device__ __forceinline__ uint32_t wave_excl_scan_dpp(uint32_t v) {
   return s - v;
 }
 
-// Sum of an f64 over the 64 lanes in the canonical order -- the balanced pairwise tree over the lane
-// index -- by DPP row shifts and row broadcasts instead of six dependent LDS round trips
-// (wave_butterfly_sum): after row_shr 1, 2, 4, 8 lane 15 of a row holds ((..)+(..)) of its row exactly as
-// the butterfly pairs them (own + shifted = right + left, one IEEE add per tree node either way), then
-// row_bcast15 folds rows 0/1 and 2/3, row_bcast31 the two halves; the total sits in lane 63 and is
-// returned wave-uniform.  Lanes whose shifted source does not exist add +0.0 (row shifts: bound_ctrl) or
-// whatever the destination held (row broadcasts into masked-off rows: no preset, the 14 moves per tree that
-// an `old` operand of 0 costs are not spent) to a value nobody reads.
-__device__ __forceinline__ double wave_tree_sum_dpp(double v) {
-#define FLACENC_F64_DPP_STEP(CTRL, ROWMASK)                                                              \
-  {                                                                                                      \
-    const unsigned long long b_ = (unsigned long long)__double_as_longlong(v);                          \
-    const uint32_t lo_ = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)b_, CTRL, ROWMASK, 0xF, (ROWMASK) == 0xF);        \
-    const uint32_t hi_ = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)(b_ >> 32), CTRL, ROWMASK, 0xF, (ROWMASK) == 0xF); \
-    v = v + __longlong_as_double((long long)(((unsigned long long)hi_ << 32) | lo_));                    \
-  }
-  FLACENC_F64_DPP_STEP(0x111, 0xF)
-  FLACENC_F64_DPP_STEP(0x112, 0xF)
-  FLACENC_F64_DPP_STEP(0x114, 0xF)
-  FLACENC_F64_DPP_STEP(0x118, 0xF)
-  FLACENC_F64_DPP_STEP(0x142, 0xA)
-  FLACENC_F64_DPP_STEP(0x143, 0xC)
-#undef FLACENC_F64_DPP_STEP
-  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
-  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, 63);
-  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), 63);
-  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-}
-
 // The same canonical sums for NV values per lane at once, through a per-wave LDS area of NV x 64 doubles
 // instead of NV dependent DPP trees (35 VALU instructions each): every lane parks its NV values, lane
 // 4 j + s fetches value j of lanes [16 s, 16 s + 16) and adds them exactly as the tree pairs them --

@@ -133,7 +133,7 @@ def kernel_source_sha():
     """Fingerprint of the fused kernel's source: profile-derived figures are only attached to a run of
     the very code they were measured on."""
     h = hashlib.sha256()
-    for name in ("qlpc_wave_kernel_impl.h", "qlpc_wave_inst.hip", "qlpc_dispatch.cpp"):
+    for name in ("qlpc_wave_kernel_impl.h", "qlpc_kernel_impl.h", "qlpc_wave_inst.hip", "qlpc_dispatch.cpp"):
         with open(os.path.join(ROOT, "flacenc_rs_amd", "csrc", name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]

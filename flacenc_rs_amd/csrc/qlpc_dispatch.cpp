@@ -60,7 +60,7 @@ QlpcLaunchPlan plan_qlpc_launch(uint32_t block_size, uint32_t lpc_order) {
   size_t bytes = static_cast<size_t>(rows + kLeadRows) * rowstride * 4;
   bytes += static_cast<size_t>(Jp) * W * (plan.maxp + 1) * 8;
   bytes = (bytes + 15) & ~static_cast<size_t>(15);
-  bytes += 40 * 8 + 16 * 8 + 32 * 4 + kMiscCount * 4 + 2 * FLACENC_HIP_MAX_RICE_PARTITIONS;
+  bytes += 40 * 8 + 16 * 8 + 32 * 4 + kMiscCount * 4;
   bytes += (5 * 64 + 16) * 8;  // kFixedSumWords (qlpc_kernel_impl.h): fixed-LPC order selection
   if (!plan.big) {
     // finest_partition_order, rice.rs:157-165 (warm-up <= 32 < 64)
@@ -68,7 +68,10 @@ QlpcLaunchPlan plan_qlpc_launch(uint32_t block_size, uint32_t lpc_order) {
     int tz = __builtin_ctz(static_cast<unsigned>(n));
     int fo = lg < tz ? lg : tz;
     if (fo > 8) fo = 8;
+    bytes += static_cast<size_t>(((2 << fo) + 15) & ~15);  // the levels' Rice parameters, 2 bytes per finest partition
     bytes += static_cast<size_t>(1 << fo) * 32 * 4;
+  } else {
+    bytes += 2 * FLACENC_HIP_MAX_RICE_PARTITIONS;
   }
   plan.smem_bytes = bytes;
   plan.table_scratch_bytes_per_subframe =

@@ -868,6 +868,9 @@ def test_flac_stream_end_to_end(handle):
     (1152, 24, 8, dict()), (2304, 24, 10, dict()), (576, 24, 6, dict()), (2304, 16, 8, dict(fixed_partitions=8)),
     (1152, 24, 8, dict(fixed_partitions=64)), (1152, 16, 8, dict(fixed_partitions=32)), (1152, 24, 8, dict(fixed_partitions=12)),
     (18432, 24, 8, dict()),
+    # ... and the same sums on whole 16-sample rows (power-of-two blocks), with a count that does not qualify beside them
+    (2048, 24, 8, dict()), (256, 24, 6, dict()), (512, 24, 4, dict()), (1024, 16, 10, dict(fixed_partitions=64)),
+    (1024, 24, 8, dict(fixed_partitions=12)),
 ])
 def test_encode_stereo_frames_any_shape(handle, n, bps, order, kw):
     """flacenc_hip_encode_stereo_frames outside the fused kernel's shape (ragged / large / tiny

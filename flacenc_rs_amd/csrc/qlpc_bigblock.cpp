@@ -37,12 +37,6 @@ constexpr int kPass = 4096;
 #ifndef FLACENC_BIG_NG32
 #define FLACENC_BIG_NG32 2
 #endif
-#ifndef FLACENC_BIG_RESID_PREFETCH
-#define FLACENC_BIG_RESID_PREFETCH 1
-#endif
-#ifndef FLACENC_BIG_RESID_OCC
-#define FLACENC_BIG_RESID_OCC 3
-#endif
 
 // cooperative load of pass k of the workgroup's rows into the LDS images: segment 0 of an image holds the
 // 64 samples in front of the pass (zeros in front of the block), the pass follows (widx layout)
@@ -338,442 +332,6 @@ __global__ void __launch_bounds__(256, FLACENC_BIG_ACORR_OCC) bigblock_acorr_ker
 }
 
 // ---------------------------------------------------------------------------------------------
-// FIXD: the predictor is one of fixed_lpc's (order `warm` <= 4, FIXED_LPC_COEFS, shift 0): the error signal by
-// repeated differencing, no multiply-adds (an instantiation of its own: as a run-time branch next to the
-// multiply-add path it cost the <8, stereo, 2> kernel 122 spilled registers)
-template <int MAXP, bool STEREO, int K, bool FIXD = false>
-__global__ void __launch_bounds__(256, FLACENC_BIG_RESID_OCC) bigblock_residual_kernel(QlpcKernelArgs a) {
-  static_assert(!FIXD || MAXP == 8, "the differencing path lives in the order-8 bucket");
-  constexpr int HP = MAXP;  // multiple of 8
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  int32_t* const sm = reinterpret_cast<int32_t*>(smem_raw);
-  const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
-  const uint32_t blk = blockIdx.x;
-  uint32_t sf = blk * 4u + (uint32_t)wave;
-  const bool active = sf < a.n_subframes;
-  if (!active) sf = a.n_subframes - 1u;
-  const int role = STEREO ? wave : 0;
-  const int n = (int)a.block_size;
-  const int32_t* const bufA = sm + (STEREO ? (role == 1 ? 1 : 0) : wave) * kBufDwords;
-  const int32_t* const bufB = sm + kBufDwords;
-  const int tl = lane << 6;
-  const unsigned long long bps_role = a.bps ? (unsigned long long)a.bps[sf]
-                                            : (unsigned long long)(a.bps_uniform + ((STEREO && role == 3) ? 1u : 0u));
-  // the quantised predictor levinson_batch_kernel left: qc[32], order, shift, status
-  const int32_t* __restrict__ pr = a.pred + (size_t)sf * 36;
-  int32_t cq[MAXP];
-#pragma unroll
-  for (int i = 0; i < MAXP; ++i) cq[i] = uni(pr[i]);
-  const int warm = uni(pr[32]);
-  const int shift = uni(pr[33]);
-  const int status = uni(pr[34]);
-  int32_t* __restrict__ rrow = a.residual + (size_t)sf * a.residual_stride;
-  if (STEREO && a.residual_lr != nullptr && role < 2)  // L / R candidates in place of the output channel they can fill
-    rrow = a.residual_lr + (size_t)(2u * blk + (uint32_t)role) * a.residual_lr_stride;
-  int vmax = INT32_MIN, vmin = INT32_MAX;  // (only kept when minmax_out is set)
-
-  uint32_t pl[K][7];
-  // Stereo blocks of two passes: the second pass's loads are issued before the first pass is worked off and
-  // parked in the images afterwards (8 int4 per thread in plain variables, see FLACENC_HALF_FETCH); the 64
-  // samples in front of a pass are the tail of the previous one, copied inside LDS.
-  // (order bucket 24 only: at 32 the eight extra registers per int4 spill, and a spilled load is waited for at once)
-  constexpr bool PREFETCH = STEREO && K == 2 && MAXP <= 24 && FLACENC_BIG_RESID_PREFETCH;
-  int4 pq0, pq1, pq2, pq3, pq4, pq5, pq6, pq7;
-#define FLACENC_PASS_FETCH(K_)                                                                                \
-  {                                                                                                            \
-    const int32_t* __restrict__ src_ = a.samples + (size_t)(2u * blk) * a.stride + (size_t)(K_) * kPass;       \
-    pq0 = *reinterpret_cast<const int4*>(src_ + (size_t)((tid + 0) >> 10) * a.stride + (((tid + 0) & 1023) << 2));       \
-    pq1 = *reinterpret_cast<const int4*>(src_ + (size_t)((tid + 256) >> 10) * a.stride + (((tid + 256) & 1023) << 2));   \
-    pq2 = *reinterpret_cast<const int4*>(src_ + (size_t)((tid + 512) >> 10) * a.stride + (((tid + 512) & 1023) << 2));   \
-    pq3 = *reinterpret_cast<const int4*>(src_ + (size_t)((tid + 768) >> 10) * a.stride + (((tid + 768) & 1023) << 2));   \
-    pq4 = *reinterpret_cast<const int4*>(src_ + (size_t)((tid + 1024) >> 10) * a.stride + (((tid + 1024) & 1023) << 2)); \
-    pq5 = *reinterpret_cast<const int4*>(src_ + (size_t)((tid + 1280) >> 10) * a.stride + (((tid + 1280) & 1023) << 2)); \
-    pq6 = *reinterpret_cast<const int4*>(src_ + (size_t)((tid + 1536) >> 10) * a.stride + (((tid + 1536) & 1023) << 2)); \
-    pq7 = *reinterpret_cast<const int4*>(src_ + (size_t)((tid + 1792) >> 10) * a.stride + (((tid + 1792) & 1023) << 2)); \
-  }
-#define FLACENC_PASS_PUT(I_, V_) \
-  *reinterpret_cast<int4*>(&sm[((tid + 256 * (I_)) >> 10) * kBufDwords + widx(((tid + 256 * (I_)) & 1023) << 2)]) = V_;
-  if (PREFETCH) FLACENC_PASS_FETCH(0)
-  for (int k = 0; k < K; ++k) {
-    if (PREFETCH) {
-      int4 halo = make_int4(0, 0, 0, 0);
-      if (k > 0 && tid < 32) halo = *reinterpret_cast<const int4*>(&sm[(tid >> 4) * kBufDwords + widx(kPass - 64 + ((tid & 15) << 2))]);
-      __syncthreads();
-      FLACENC_PASS_PUT(0, pq0) FLACENC_PASS_PUT(1, pq1) FLACENC_PASS_PUT(2, pq2) FLACENC_PASS_PUT(3, pq3)
-      FLACENC_PASS_PUT(4, pq4) FLACENC_PASS_PUT(5, pq5) FLACENC_PASS_PUT(6, pq6) FLACENC_PASS_PUT(7, pq7)
-      if (tid < 32) *reinterpret_cast<int4*>(&sm[(tid >> 4) * kBufDwords + widx(((tid & 15) << 2) - 64)]) = halo;
-      if (k + 1 < K) FLACENC_PASS_FETCH(k + 1)
-    } else {
-      __syncthreads();
-      bigblock_load_pass<STEREO>(a, sm, blk, k, tid, wave, lane, sf);
-    }
-    __syncthreads();
-    auto run = [&](auto kind_tag, uint32_t (&planes)[7]) {
-      constexpr int KIND = decltype(kind_tag)::value;
-      // e[t] = s[t] - ((sum_j c_j s[t-1-j]) >> shift), exact in 64 bits, truncated to i32
-      // (lpc.rs:306-350, the i64 branch of :379-388 -- both branches give the same value)
-      int sw[HP + 16];
-      uint32_t pc[6];
-      // the HP samples in front of the lane, then a rolled loop over its four 16-sample chunks (every
-      // register array index below is a compile-time constant; the window slides at the loop's end)
-#pragma unroll
-      for (int q = 0; q < HP; q += 4) {
-        const int4 v = bigblock_ld4<KIND>(bufA, bufB, tl - HP + q);
-        sw[q + 0] = v.x;
-        sw[q + 1] = v.y;
-        sw[q + 2] = v.z;
-        sw[q + 3] = v.w;
-      }
-#pragma unroll 1
-      for (int i = 0; i < 4; ++i) {
-        const int t0 = tl + 16 * i;
-#pragma unroll
-        for (int q = 0; q < 16; q += 4) {
-          const int4 v = bigblock_ld4<KIND>(bufA, bufB, t0 + q);
-          sw[HP + q + 0] = v.x;
-          sw[HP + q + 1] = v.y;
-          sw[HP + q + 2] = v.z;
-          sw[HP + q + 3] = v.w;
-        }
-        if (a.minmax_out != nullptr) {
-#pragma unroll
-          for (int q = 0; q < 16; q += 2) {
-            vmax = max(vmax, max(sw[HP + q], sw[HP + q + 1]));
-            vmin = min(vmin, min(sw[HP + q], sw[HP + q + 1]));
-          }
-        }
-        int32_t e[16];
-        if (FIXD) {
-          // fixed_lpc's predictors are repeated differences (reset_fixed_lpc_errors, coding.rs:182-197): `warm`
-          // wrapping subtractions per sample instead of eight 64-bit multiply-adds, a shift and a subtraction
-          // (the same value: FIXED_LPC_COEFS[k] with shift 0 is the k-th difference, decode.rs:179-201)
-          // (one straight-line body per order, chosen by a wave-uniform switch: a rolled loop over the levels kept
-          // the whole window live across its back edge and spilled)
-          auto diff = [&](auto order_tag) {
-            constexpr int ORD = decltype(order_tag)::value;
-            int32_t d[16 + ORD];
-#pragma unroll
-            for (int q = 0; q < 16 + ORD; ++q) d[q] = sw[HP - ORD + q];
-#pragma unroll
-            for (int lvl = 0; lvl < ORD; ++lvl) {
-#pragma unroll
-              for (int q = 15 + ORD; q >= 1 + lvl; --q) d[q] = (int32_t)((uint32_t)d[q] - (uint32_t)d[q - 1]);
-            }
-#pragma unroll
-            for (int q = 0; q < 16; ++q) e[q] = ((k == 0 && t0 + q < ORD) || status != 0) ? 0 : d[ORD + q];
-          };
-          switch (warm) {
-            case 0: diff(std::integral_constant<int, 0>{}); break;
-            case 1: diff(std::integral_constant<int, 1>{}); break;
-            case 2: diff(std::integral_constant<int, 2>{}); break;
-            case 3: diff(std::integral_constant<int, 3>{}); break;
-            default: diff(std::integral_constant<int, 4>{}); break;
-          }
-        } else {
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          int64_t pred = 0;
-#pragma unroll
-          for (int j = 0; j < MAXP; ++j) pred += (int64_t)cq[j] * (int64_t)sw[HP + q - 1 - j];
-          e[q] = (int32_t)(uint32_t)(uint64_t)((int64_t)sw[HP + q] - (pred >> shift));
-          // e[0 .. order') = 0 (lpc.rs:349): the block's first samples, i.e. pass 0, lane 0
-          // (as a wave-uniform branch around the first two chunks instead of selects on every sample: measured
-          // 3-7 % slower -- more registers live across the branch, 30 spilled)
-          if ((k == 0 && t0 + q < warm) || status != 0) e[q] = 0;
-        }
-        }
-        if (active) {
-#pragma unroll
-          for (int q = 0; q < 16; q += 4)
-            *reinterpret_cast<int4*>(rrow + (size_t)k * kPass + t0 + q) = make_int4(e[q], e[q + 1], e[q + 2], e[q + 3]);
-        }
-        // bit-sliced population counts of the chunk, accumulated into the lane's 7 planes for this pass
-        uint32_t pb[5];
-        popcount_planes16(e, pb);
-        if (i == 0) {
-#pragma unroll
-          for (int q = 0; q < 5; ++q) planes[q] = pb[q];
-        } else if (i == 1) {
-          planes_add<5>(planes, pb);
-        } else if (i == 2) {
-#pragma unroll
-          for (int q = 0; q < 5; ++q) pc[q] = pb[q];
-        } else {
-          planes_add<5>(pc, pb);
-          planes_add<6>(planes, pc);
-        }
-#pragma unroll
-        for (int q = 0; q < HP; ++q) sw[q] = sw[q + 16];
-      }
-    };
-    // (the pass loop is rolled; pl[k] is selected by a compare chain so that the planes stay in registers)
-    uint32_t now[7];
-    if (STEREO && role == 2) run(std::integral_constant<int, 2>{}, now);
-    else if (STEREO && role == 3) run(std::integral_constant<int, 3>{}, now);
-    else run(std::integral_constant<int, 0>{}, now);
-#pragma unroll
-    for (int kk = 0; kk < K; ++kk)
-      if (kk == k) {
-#pragma unroll
-        for (int q = 0; q < 7; ++q) pl[kk][q] = now[q];
-      }
-  }
-
-  // ======================= partitioned-Rice search over 64 K partitions =======================
-  // finest order FO = 6 + log2 K (rice.rs:157-165); level L = order FO - L
-  constexpr int LK = K == 1 ? 0 : (K == 2 ? 1 : 2);
-  constexpr int NLEV = 7 + LK;
-  constexpr uint32_t kWMax = kMaxPToBits - 4u;
-  uint32_t orp = 0;
-#pragma unroll
-  for (int k = 0; k < K; ++k)
-#pragma unroll
-    for (int q = 0; q < 7; ++q) orp |= pl[k][q];
-  const uint32_t orw = wave_or_dpp(orp);
-  const uint32_t maxu = (orw << 1) | (orw >> 31);
-  const uint32_t bitlen = maxu ? (uint32_t)(32 - __builtin_clz(maxu)) : 0u;
-  const uint32_t max_p = a.max_rice_parameter < bitlen ? a.max_rice_parameter : bitlen;
-  const bool finest_only = a.rice_finest_only != 0;
-  const bool small_bits = a.max_rice_parameter >= bitlen;
-  PlaneSums ps[K];
-#pragma unroll
-  for (int k = 0; k < K; ++k) ps[k] = make_plane_sums(pl[k]);
-  uint32_t len0[K];
-#pragma unroll
-  for (int k = 0; k < K; ++k) len0[k] = 64u - ((k == 0 && lane == 0) ? (uint32_t)warm : 0u);
-  // residuals of 2^26 and more (the reference's wrapping chunk sums, rice.rs:88-93, then differ from the
-  // exact ones) are left to the generic kernel: this launch reports it and the dispatcher reruns it
-  const bool literal = !(maxu < (1u << 26));
-
-  uint32_t pk[K][7], pk7[K >= 2 ? K / 2 : 1], pk8 = 0xFFFFFFFFu;
-  auto search = [&](uint32_t p_lo, uint32_t p_hi) {  // parameters p_lo..p_hi in groups of 4 (see rice_search)
-#pragma unroll
-    for (int k = 0; k < K; ++k)
-#pragma unroll
-      for (int q = 0; q < 7; ++q) pk[k][q] = 0xFFFFFFFFu;
-#pragma unroll
-    for (int j = 0; j < K / 2; ++j) pk7[j] = 0xFFFFFFFFu;
-    pk8 = 0xFFFFFFFFu;
-#pragma unroll 1
-    for (uint32_t p_base = p_lo; p_base <= p_hi; p_base += 4u) {
-      uint32_t top[K][4];
-#pragma unroll
-      for (int k = 0; k < K; ++k) {
-        rice_build_tables<true>(ps[k], nullptr, len0[k], p_base, max_p, (k == 0) ? lane : 1, warm, top[k]);
-        rice_group_levels(top[k], pk[k], p_base, finest_only);
-      }
-      if (!finest_only) {
-        // levels that merge whole passes: lane 0 of the wave holds every pass's merged table
-#pragma unroll
-        for (int j = 0; j < K / 2; ++j) {
-          uint32_t packed = pk7[j];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            uint32_t v = top[2 * j][q] + top[2 * j + 1][q];
-            v = v < kWMax ? v : kWMax;
-            top[2 * j][q] = v;
-            const uint32_t c = (v << 5) | (p_base + (uint32_t)q);
-            packed = c < packed ? c : packed;
-          }
-          pk7[j] = packed;
-        }
-        if (K == 4) {
-          uint32_t packed = pk8;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            uint32_t v = top[0][q] + top[2][q];
-            v = v < kWMax ? v : kWMax;
-            const uint32_t c = (v << 5) | (p_base + (uint32_t)q);
-            packed = c < packed ? c : packed;
-          }
-          pk8 = packed;
-        }
-      }
-    }
-  };
-  // rice_window (see the 4096 kernel): the wave-minimum of floor(log2(mean + 1)) over all partitions
-  uint32_t p0l = 31u, p0h = 0u;
-#pragma unroll
-  for (int k = 0; k < K; ++k) {
-    const uint32_t s0 = 2u * ps[k].sum_m + ps[k].negs;
-    const uint32_t q0 = (s0 >> 6) + 1u;
-    const uint32_t c = 31u - (uint32_t)__builtin_clz(q0);
-    p0l = c < p0l ? c : p0l;
-    // upper end (see the 4096 kernel): q bounds the partition's mean from above; the block's first partition
-    // has only 64 - warm >= 32 coded samples: twice the 64-sample mean covers it
-    const uint32_t qh = (k == 0 && lane == 0) ? 2u * q0 : q0;
-    const uint32_t ch = 31u - (uint32_t)__builtin_clz(qh);
-    p0h = ch > p0h ? ch : p0h;
-  }
-  const uint32_t p0min = wave_min_dpp(p0l);
-  uint32_t p_lo = p0min > 2u ? p0min - 2u : 0u;
-  p_lo = p_lo < max_p ? p_lo : max_p;
-  uint32_t p_hi = wave_max_dpp(p0h) + 1u;
-  p_hi = p_hi < max_p ? p_hi : max_p;
-  if (literal) p_lo = 0u;
-
-  // level totals; strict < keeps the finer order on ties (rice.rs:285)
-  int bestl = 0;
-  unsigned long long best_bits = 0;
-  uint32_t sat_levels = 0;
-  auto totals = [&]() {
-    sat_levels = 0;
-#pragma unroll
-    for (int L = 0; L < NLEV; ++L) {
-      if (L > 0 && finest_only) break;
-      unsigned long long tot = 0;
-      uint32_t sat = 0;
-      if (L < 7) {
-        const bool lead = (lane & ((1 << L) - 1)) == 0;
-        uint32_t lbsum = 0;
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-          const uint32_t bits = (pk[k][L] >> 5) + 4u;
-          const uint32_t lb = lead ? bits : 0u;
-          sat |= (lead && bits >= kMaxPToBits) ? 1u : 0u;
-          // with the search not cut short by the configuration every minimum is <= 4 + 64 (bitlen + 1) < 2^12:
-          // the passes' values are added in the lane and summed over the wave once
-          if (small_bits) lbsum += lb;
-          else tot += ((unsigned long long)wave_sum_dpp(lb >> 16) << 16) + wave_sum_dpp(lb & 0xFFFFu);
-        }
-        if (small_bits) tot = wave_sum_dpp(lbsum);
-        sat = wave_or_dpp(sat);
-      } else if (L == 7) {
-#pragma unroll
-        for (int j = 0; j < K / 2; ++j) {
-          const uint32_t bits = (uint32_t)uni((int)((pk7[j] >> 5) + 4u));
-          sat |= bits >= kMaxPToBits ? 1u : 0u;
-          tot += bits;
-        }
-      } else {
-        const uint32_t bits = (uint32_t)uni((int)((pk8 >> 5) + 4u));
-        sat |= bits >= kMaxPToBits ? 1u : 0u;
-        tot = bits;
-      }
-      sat_levels |= sat << L;
-      if (L == 0 || tot < best_bits) {
-        best_bits = tot;
-        bestl = L;
-      }
-    }
-  };
-  if (!literal) {
-    search(p_lo, p_hi);
-    totals();
-    // a saturated minimum could tie with clamped entries outside the window: search the whole range
-    if (sat_levels != 0 && p_lo != 0) {
-      search(0u, max_p);
-      totals();
-    }
-  }
-  const bool saturated = (sat_levels >> bestl) & 1u;
-  const int rice_order = (6 + LK) - bestl;
-  const uint32_t best_parts = 1u << rice_order;
-
-  // the parameter of the chosen-order partition each (pass, lane) leads
-  uint32_t myp[K];
-#pragma unroll
-  for (int k = 0; k < K; ++k) {
-    uint32_t v = 0;
-#pragma unroll
-    for (int L = 0; L < 7; ++L) v = (L == bestl) ? (pk[k][L] & 31u) : v;
-    if (bestl == 7) v = (uint32_t)uni((int)(pk7[k >> 1] & 31u));
-    if (bestl == 8) v = (uint32_t)uni((int)(pk8 & 31u));
-    myp[k] = v;
-  }
-  // Residual::sum_quotients / count_bits (datatype.rs:2325-2331, bitrepr.rs:533-544)
-  const int lanebits = bestl < 6 ? bestl : 6;
-  const bool lane_leader = (lane & ((1 << lanebits) - 1)) == 0;
-  uint32_t sum_p = 0, rice2 = 0;
-#pragma unroll
-  for (int k = 0; k < K; ++k) {
-    const bool pass_leader = bestl <= 6 || (bestl == 7 && (k & 1) == 0) || (bestl == 8 && k == 0);
-    const bool leader = lane_leader && pass_leader;
-    sum_p += wave_sum_dpp(leader ? myp[k] : 0u);
-    rice2 |= wave_or_dpp((leader && myp[k] > 14) ? 1u : 0u);
-  }
-  const uint32_t p_first = (uint32_t)uni((int)myp[0]);
-  const unsigned long long rem_bits = (unsigned long long)sum_p * (unsigned long long)(n >> rice_order) -
-                                      (unsigned long long)warm * p_first;
-  unsigned long long sum_q;
-  if (saturated) {
-    // exact quotient sum from the planes under each partition's parameter
-    unsigned long long acc = 0;
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-      uint32_t gp = (uint32_t)__shfl((int)myp[k], lane & ~((1 << lanebits) - 1), 64);
-      if (bestl == 7) gp = (uint32_t)uni((int)(pk7[k >> 1] & 31u));
-      if (bestl == 8) gp = (uint32_t)uni((int)(pk8 & 31u));
-      const unsigned long long mine = plane_sum_any64(ps[k], gp);
-      acc += ((unsigned long long)wave_sum_dpp((uint32_t)(mine >> 16)) << 16) +
-             (unsigned long long)wave_sum_dpp((uint32_t)(mine & 0xFFFFu));
-    }
-    sum_q = acc;
-  } else {
-    sum_q = best_bits - 4ull * best_parts - (unsigned long long)(n - warm) - rem_bits;
-  }
-  const unsigned long long residual_bits = 2ull + 4ull + (unsigned long long)best_parts * (rice2 ? 5ull : 4ull) +
-                                           (sum_q + (unsigned long long)(n - warm)) + rem_bits;
-  // Lpc::count_bits (bitrepr.rs:492-499); as fixed_lpc's coder: FixedLpc::count_bits (no precision / shift /
-  // coefficient fields)
-  const unsigned long long sub_bits = a.fixed_mode != 0
-      ? 8ull + bps_role * (unsigned long long)warm + residual_bits
-      : 8ull + bps_role * (unsigned long long)warm + 4ull + 5ull +
-            (unsigned long long)a.precision * (unsigned long long)warm + residual_bits;
-
-  if (a.minmax_out != nullptr) {
-    const int mx = (int)(wave_max_dpp((uint32_t)vmax ^ 0x80000000u) ^ 0x80000000u);
-    const int mn = (int)(wave_min_dpp((uint32_t)vmin ^ 0x80000000u) ^ 0x80000000u);
-    if (active && lane == 0) {
-      a.minmax_out[(size_t)sf * 2 + 0] = mn;
-      a.minmax_out[(size_t)sf * 2 + 1] = mx;
-    }
-  }
-  if (!active) return;
-  flacenc_hip_subframe_params* rec = a.params + sf;
-  if (literal) {
-    // marker for the dispatcher: this subframe has to go through the generic kernel's literal tables
-    if (lane == 0) rec->status = -1;
-    return;
-  }
-  // partition j of the chosen order: pass (j << bestl) >> 6, lane (j << bestl) & 63
-  {
-    const uint32_t ok = status == 0 ? 1u : 0u;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const uint32_t j = (uint32_t)(lane + 64 * r);
-      const uint32_t first = (j << bestl) & (uint32_t)(64 * K - 1);  // finest-partition index of the first member
-      const uint32_t src_lane = first & 63u, src_pass = first >> 6;
-      uint32_t v = 0;
-#pragma unroll
-      for (int k = 0; k < K; ++k) {  // (every lane takes part in every shuffle)
-        const uint32_t got = (uint32_t)__shfl((int)myp[k], (int)src_lane, 64);
-        v = (src_pass == (uint32_t)k) ? got : v;
-      }
-      if (j >= best_parts) v = 0;
-      rec->rice_params[j] = (uint8_t)(ok ? v : 0u);
-    }
-  }
-  if (lane < 32) {
-    int32_t c = 0;
-#pragma unroll
-    for (int i = 0; i < MAXP; ++i)
-      if (i == lane) c = cq[i];
-    rec->coefs[lane] = (status == 0) ? (int16_t)c : (int16_t)0;
-  }
-  if (lane == 0) {
-    rec->order = (uint8_t)warm;
-    rec->shift = (int8_t)shift;
-    rec->precision = (uint8_t)(a.fixed_mode != 0 ? 0u : a.precision);
-    rec->rice_order = (uint8_t)(status == 0 ? rice_order : 0);
-    rec->status = status;
-    rec->code_bits = status == 0 ? best_bits : 0ull;
-    rec->subframe_bits = status == 0 ? sub_bits : 0ull;
-    rec->sum_quotients = status == 0 ? sum_q : 0ull;
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
 // fixed_lpc's order selection (OrderSel::ApproxEnt, coding.rs:265-287) for the big-block shapes: per pass
 // the exact sums of |e_k| over every estimator partition (v_sad_u32 on biased values, as in the fused
 // 4096 kernel), estimate_entropy per partition, the estimates added up over partitions and passes, the
@@ -911,13 +469,6 @@ hipError_t launch_acorr(const QlpcKernelArgs& a, hipStream_t stream) {
   return launch_big(bigblock_acorr_kernel<HP, NG, false, NLAGS>, opt_p, a, 4 * kHBufDwords * 4 + part + cross, stream);
 }
 
-template <int MAXP, int K, bool FIXD = false>
-hipError_t launch_residual(const QlpcKernelArgs& a, hipStream_t stream) {
-  static DynamicLdsOptIn opt_s, opt_p;
-  if (a.stereo) return launch_big(bigblock_residual_kernel<MAXP, true, K, FIXD>, opt_s, a, 2 * kBufDwords * 4, stream);
-  return launch_big(bigblock_residual_kernel<MAXP, false, K, FIXD>, opt_p, a, 4 * kBufDwords * 4, stream);
-}
-
 }  // namespace
 
 // fixed_lpc with OrderSel::ApproxEnt on the same shapes: estimator partitions that are whole groups of lanes
@@ -944,9 +495,7 @@ hipError_t launch_bigblock_fixed_select(const QlpcKernelArgs& a, hipStream_t str
 }
 
 hipError_t launch_bigblock_fixed_residual(const QlpcKernelArgs& a, hipStream_t stream) {
-  const int k = (int)(a.block_size / 4096u);
-  return k == 1 ? launch_residual<8, 1, true>(a, stream)
-                : (k == 2 ? launch_residual<8, 2, true>(a, stream) : launch_residual<8, 4, true>(a, stream));
+  return launch_bigblock_residual(a, stream);  // (FIXED_LPC_COEFS with shift 0 is a predictor like any other)
 }
 
 bool bigblock_eligible(const QlpcKernelArgs& a) {
@@ -981,19 +530,17 @@ hipError_t launch_bigblock_acorr(const QlpcKernelArgs& a, hipStream_t stream) {
   return launch_acorr<32, FLACENC_BIG_NG32>(a, stream);
 }
 
+// byte limbs of the rows L, R, M (or of every plain row): one width for the whole batch is known here, per-subframe
+// widths (a device array) get four limbs, which carry any i32
 hipError_t launch_bigblock_residual(const QlpcKernelArgs& a, hipStream_t stream) {
   const int k = (int)(a.block_size / 4096u);
-  if (a.lpc_order <= 8)
-    return k == 1 ? launch_residual<8, 1>(a, stream) : (k == 2 ? launch_residual<8, 2>(a, stream) : launch_residual<8, 4>(a, stream));
-  if (a.lpc_order <= 10)  // (the reference's default order)
-    return k == 1 ? launch_residual<10, 1>(a, stream) : (k == 2 ? launch_residual<10, 2>(a, stream) : launch_residual<10, 4>(a, stream));
-  if (a.lpc_order <= 12)
-    return k == 1 ? launch_residual<12, 1>(a, stream) : (k == 2 ? launch_residual<12, 2>(a, stream) : launch_residual<12, 4>(a, stream));
-  if (a.lpc_order <= 16)
-    return k == 1 ? launch_residual<16, 1>(a, stream) : (k == 2 ? launch_residual<16, 2>(a, stream) : launch_residual<16, 4>(a, stream));
-  if (a.lpc_order <= 24)
-    return k == 1 ? launch_residual<24, 1>(a, stream) : (k == 2 ? launch_residual<24, 2>(a, stream) : launch_residual<24, 4>(a, stream));
-  return k == 1 ? launch_residual<32, 1>(a, stream) : (k == 2 ? launch_residual<32, 2>(a, stream) : launch_residual<32, 4>(a, stream));
+  int nlb = 4;
+  if (a.bps == nullptr) nlb = a.bps_uniform <= 16u ? 2 : (a.bps_uniform <= 24u ? 3 : 4);
+#define FLACENC_HIP_BIGRES(K_, NLB_) \
+  if (k == K_ && nlb == NLB_) return launch_bigblock_residual_##K_##_##NLB_(a, stream);
+  FLACENC_HIP_FOR_EACH_BIGRES_INSTANCE(FLACENC_HIP_BIGRES)
+#undef FLACENC_HIP_BIGRES
+  return hipErrorInvalidValue;
 }
 
 }  // namespace flacenc_hip

@@ -151,5 +151,11 @@ FLACENC_HIP_FOR_EACH_WAVE_INSTANCE(FLACENC_HIP_DECLARE_WAVE_INSTANCE)
   hipError_t launch_qlpc_wave72_##MP##_##ST(const QlpcKernelArgs&, hipStream_t);
 FLACENC_HIP_FOR_EACH_WAVE72_INSTANCE(FLACENC_HIP_DECLARE_WAVE72_INSTANCE)
 
+// bigblock_residual_kernel: one translation unit per (passes of 4096 samples, byte limbs per sample)
+#define FLACENC_HIP_FOR_EACH_BIGRES_INSTANCE(X) X(1, 2) X(1, 3) X(1, 4) X(2, 2) X(2, 3) X(2, 4) X(4, 2) X(4, 3) X(4, 4)
+#define FLACENC_HIP_DECLARE_BIGRES_INSTANCE(K_, NLB_) \
+  hipError_t launch_bigblock_residual_##K_##_##NLB_(const QlpcKernelArgs&, hipStream_t);
+FLACENC_HIP_FOR_EACH_BIGRES_INSTANCE(FLACENC_HIP_DECLARE_BIGRES_INSTANCE)
+
 }  // namespace flacenc_hip
 #endif

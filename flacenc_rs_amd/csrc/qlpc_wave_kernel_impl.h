@@ -292,8 +292,9 @@ __device__ __forceinline__ void popcount_planes16(const int32_t* e, uint32_t (&p
   uint32_t u[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
+    // (x ^ t) | (t & 2^31): one v_bitop3_b32 (table 0xBC over (x, t, 2^31)) behind the shift
     const uint32_t x = (uint32_t)e[k], t = (uint32_t)(e[k] >> 31);
-    u[k] = (x & 0x80000000u) | ((x ^ t) & 0x7FFFFFFFu);
+    u[k] = __builtin_amdgcn_bitop3_b32(x, t, 0x80000000u, 0xBC);
   }
   uint32_t ones = 0, twos = 0, fours = 0, eights = 0, sixteens;
   uint32_t twosA, twosB, foursA, foursB, eightsA, eightsB;

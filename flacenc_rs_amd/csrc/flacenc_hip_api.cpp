@@ -133,7 +133,7 @@ struct flacenc_hip_handle {
   hipStream_t stream = nullptr;
   std::string last_error;
   std::vector<WindowEntry> windows;
-  DeviceBuffer d_samples, d_residual, d_params, d_bps, d_autocorr, d_lpc, d_tables, d_keys, d_sel, d_results, d_out, d_outlen, d_cparams, d_cresid, d_fparams, d_fresid, d_fkeys, d_split, d_presid, d_sumabs, d_minmax;
+  DeviceBuffer d_samples, d_residual, d_params, d_bps, d_autocorr, d_lpc, d_tables, d_keys, d_sel, d_results, d_out, d_outlen, d_cparams, d_cresid, d_fparams, d_fresid, d_fkeys, d_split, d_presid, d_sumabs, d_minmax, d_marked;
   // streaming host path (flacenc_hip_encode_pcm_stereo): copy-in / copy-out streams, two slots of pinned
   // staging and device buffers, the events that order them
   hipStream_t s_in = nullptr, s_out = nullptr;
@@ -301,6 +301,20 @@ int attach_sumabs_scratch(flacenc_hip_handle* h, flacenc_hip::QlpcKernelArgs& a,
   return FLACENC_HIP_OK;
 }
 
+// R[] and the predictor records between the launches of the split pipelines, and the counter through which
+// bigblock_residual_kernel tells the clean-up launch whether it marked anything (QlpcKernelArgs::marked_count)
+int attach_split_scratch(flacenc_hip_handle* h, flacenc_hip::QlpcKernelArgs& a) {
+  int rc = ensure(h, h->d_split, static_cast<size_t>(a.n_subframes) * (33 * 8 + 36 * 4));
+  if (rc != FLACENC_HIP_OK) return rc;
+  a.split_scratch = h->d_split.ptr;
+  if (h->d_marked.ptr == nullptr) {
+    if ((rc = ensure(h, h->d_marked, 64)) != FLACENC_HIP_OK) return rc;
+    HIP_TRY(h, hipMemset(h->d_marked.ptr, 0, 64));
+  }
+  a.marked_count = static_cast<uint32_t*>(h->d_marked.ptr);
+  return FLACENC_HIP_OK;
+}
+
 int enqueue(flacenc_hip_handle* h, const flacenc_hip_qlpc_config* cfg, const int32_t* samples,
             size_t n_subframes, uint32_t block_size, size_t stride, const uint8_t* bps,
             flacenc_hip_subframe_params* params, int32_t* residual, size_t residual_stride,
@@ -365,9 +379,7 @@ int enqueue(flacenc_hip_handle* h, const flacenc_hip_qlpc_config* cfg, const int
   // (R[] and the predictor records between the launches of the split pipelines: orders from 13, and blocks of
   // 8192 / 16384 at any order -- the big-block kernels)
   if (cfg->lpc_order >= 13 || a.reference_order || a.direct_mse || block_size == 8192 || block_size == 16384) {
-    rc = ensure(h, h->d_split, n_subframes * (33 * 8 + 36 * 4));
-    if (rc != FLACENC_HIP_OK) return rc;
-    a.split_scratch = h->d_split.ptr;
+    if ((rc = attach_split_scratch(h, a)) != FLACENC_HIP_OK) return rc;
   }
   if (plan.table_scratch_bytes_per_subframe) {
     rc = ensure(h, h->d_tables, plan.table_scratch_bytes_per_subframe * n_subframes);
@@ -567,9 +579,7 @@ int enqueue_fixed(flacenc_hip_handle* h, const flacenc_hip_frame_config* cfg, co
     a.fixed_mode = 1;
     if ((rc = attach_sumabs_scratch(h, a, true)) != FLACENC_HIP_OK) return rc;
     if (block_size == 4096 || block_size == 8192 || block_size == 16384) {  // the big-block kernels' predictor records
-      rc = ensure(h, h->d_split, n_subframes * (33 * 8 + 36 * 4));
-      if (rc != FLACENC_HIP_OK) return rc;
-      a.split_scratch = h->d_split.ptr;
+      if ((rc = attach_split_scratch(h, a)) != FLACENC_HIP_OK) return rc;
     }
     HIP_TRY(h, flacenc_hip::launch_qlpc(a, plan, stream));
     return FLACENC_HIP_OK;
@@ -650,7 +660,7 @@ void flacenc_hip_destroy(flacenc_hip_handle* h) {
     if (e.dev) (void)hipFree(e.dev);
   for (DeviceBuffer* b : {&h->d_samples, &h->d_residual, &h->d_params, &h->d_bps, &h->d_autocorr,
                           &h->d_lpc, &h->d_tables, &h->d_keys, &h->d_sel, &h->d_results, &h->d_out, &h->d_outlen, &h->d_cparams, &h->d_cresid,
-                          &h->d_fparams, &h->d_fresid, &h->d_fkeys, &h->d_split, &h->d_presid, &h->d_sumabs, &h->d_minmax})
+                          &h->d_fparams, &h->d_fresid, &h->d_fkeys, &h->d_split, &h->d_presid, &h->d_sumabs, &h->d_minmax, &h->d_marked})
     if (b->ptr) (void)hipFree(b->ptr);
   for (int i = 0; i < 2; ++i) {
     for (DeviceBuffer* b : {&h->d_pcm[i], &h->d_pack[i], &h->d_plen[i], &h->d_poff[i], &h->d_cont[i]})
@@ -1052,8 +1062,7 @@ int flacenc_hip_encode_frames_async(flacenc_hip_handle* h, const flacenc_hip_fra
     a.pred_out = nullptr;
     a.split_scratch = nullptr;
     if (a.reference_order) {  // R[] of the reference-order pass
-      if ((rc = ensure(h, h->d_split, static_cast<size_t>(a.n_subframes) * (33 * 8 + 36 * 4))) != FLACENC_HIP_OK) return rc;
-      a.split_scratch = h->d_split.ptr;
+      if ((rc = attach_split_scratch(h, a)) != FLACENC_HIP_OK) return rc;
     }
     if ((rc = attach_sumabs_scratch(h, a, cfg->use_fixed && cfg->fixed_order_sel == FLACENC_HIP_ORDERSEL_APPROXENT)) !=
         FLACENC_HIP_OK)
@@ -1799,9 +1808,8 @@ static int encode_stereo_frames_impl(flacenc_hip_handle* h, const flacenc_hip_fr
   a.pred_out = nullptr;
   a.split_scratch = nullptr;
   if (a.reference_order) {  // R[] of the reference-order pass
-    int rc2 = ensure(h, h->d_split, static_cast<size_t>(a.n_subframes) * (33 * 8 + 36 * 4));
+    int rc2 = attach_split_scratch(h, a);
     if (rc2 != FLACENC_HIP_OK) return rc2;
-    a.split_scratch = h->d_split.ptr;
     rc2 = attach_sumabs_scratch(h, a, a.use_fixed && a.fixed_order_sel == FLACENC_HIP_ORDERSEL_APPROXENT);
     if (rc2 != FLACENC_HIP_OK) return rc2;
   }

@@ -185,7 +185,7 @@ __global__ void __launch_bounds__(256, FLACENC_BIG_ACORR_OCC) bigblock_acorr_ker
   int32_t* const sm = reinterpret_cast<int32_t*>(smem_raw);
   constexpr int NBUF = STEREO ? 2 : 4;
   double* const part = reinterpret_cast<double*>(sm + NBUF * kHBufDwords);    // [4 waves][LVMAX][NLAG]
-  double* const cross = part + 4 * LVMAX * NLAG;                               // [4 waves][NBATCH][64]
+  double* const cross = part + 4 * LVMAX * NLAG;                               // [4 waves][NBATCH][kTreeRow]
   const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
   const uint32_t blk = blockIdx.x;
   uint32_t sf = blk * 4u + (uint32_t)wave;
@@ -199,7 +199,7 @@ __global__ void __launch_bounds__(256, FLACENC_BIG_ACORR_OCC) bigblock_acorr_ker
   const float* __restrict__ wtab = a.window ? a.window + 32 : nullptr;
   const int tl = lane << 5;
   double* const mine = part + wave * LVMAX * NLAG;
-  double* const mycross = cross + wave * NBATCH * 64;
+  double* const mycross = cross + wave * NBATCH * kTreeRow;
 
   auto stamp = [&](int slot) {
     if (a.stamps && lane == 0) a.stamps[(size_t)sf * 8 + slot] = (unsigned long long)clock64();
@@ -464,7 +464,7 @@ template <int HP, int NG, int NLAGS = HP + 1>
 hipError_t launch_acorr(const QlpcKernelArgs& a, hipStream_t stream) {
   static DynamicLdsOptIn opt_s, opt_p;
   const size_t part = 4 * 3 * (HP + 1) * sizeof(double);
-  const size_t cross = 4 * 13 * 64 * sizeof(double);  // wave_tree_sums_lds_n
+  const size_t cross = 4 * 13 * kTreeRow * sizeof(double);  // wave_tree_sums_lds_n
   if (a.stereo) return launch_big(bigblock_acorr_kernel<HP, NG, true, NLAGS>, opt_s, a, 2 * kHBufDwords * 4 + part + cross, stream);
   return launch_big(bigblock_acorr_kernel<HP, NG, false, NLAGS>, opt_p, a, 4 * kHBufDwords * 4 + part + cross, stream);
 }

@@ -599,7 +599,10 @@ __global__ void __launch_bounds__(256, (STEREO && K == 1) ? 3 : FLACENC_BIG_RESI
   flacenc_hip_subframe_params* rec = a.params + sf;
   if (literal) {
     // marker for the dispatcher: this subframe has to go through the generic kernel's literal tables
-    if (lane == 0) rec->status = -1;
+    if (lane == 0) {
+      rec->status = -1;
+      if (a.marked_count != nullptr) atomicAdd(a.marked_count, 1u);
+    }
     return;
   }
   // partition j of the chosen order: pass (j << bestl) >> 6, lane (j << bestl) & 63

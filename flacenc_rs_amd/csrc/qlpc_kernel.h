@@ -60,6 +60,9 @@ struct QlpcKernelArgs {
   size_t residual_lr_stride = 0;
   int32_t* minmax_out = nullptr;
   uint32_t only_marked;       // generic kernel: redo only subframes whose record says status == -1
+  // [0]: subframes bigblock_residual_kernel marked for that clean-up launch (zero between calls: qlpc_marked_kernel
+  // returns at once on 0, and its last workgroup to arrive -- ticket counter [1] -- clears both); nullptr: always scan
+  uint32_t* marked_count = nullptr;
   flacenc_hip_subframe_params* params;  // device
   int32_t* residual;                    // device
   size_t residual_stride;

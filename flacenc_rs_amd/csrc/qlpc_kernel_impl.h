@@ -378,6 +378,21 @@ template <int MAXP, bool BIG>
 __global__ void __launch_bounds__(MAXP <= 12 ? 1024 : (MAXP <= 16 ? 512 : 256)) qlpc_marked_kernel(QlpcKernelArgs a) {
   const uint32_t base = blockIdx.x * blockDim.x;
   const uint32_t mine = base + threadIdx.x;
+  if (a.marked_count != nullptr) {
+    // nothing marked (the usual case): no scan of the records.  Every workgroup reads the count, then takes a ticket;
+    // the last one to arrive clears count and tickets for the next call.
+    __shared__ uint32_t marked;
+    if (threadIdx.x == 0) {
+      marked = __hip_atomic_load(a.marked_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint32_t ticket = __hip_atomic_fetch_add(a.marked_count + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      if (ticket == gridDim.x - 1u) {
+        __hip_atomic_store(a.marked_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(a.marked_count + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    __syncthreads();
+    if (marked == 0u) return;
+  }
   if (!__syncthreads_or(mine < a.n_subframes && a.params[mine].status == -1 ? 1 : 0)) return;
   for (uint32_t i = 0; i < blockDim.x && base + i < a.n_subframes; ++i) {
     if (a.params[base + i].status == -1) qlpc_subframe_call<MAXP, BIG>(a, base + i);
@@ -436,7 +451,10 @@ hipError_t launch_one(const QlpcKernelArgs& a, int threads, size_t smem, hipStre
   static DynamicLdsOptIn opt_in;  // per instantiation, per device inside; the attribute only ever grows
   if (hipError_t err = opt_in.ensure(reinterpret_cast<const void*>(kern), smem); err != hipSuccess) return err;
   hipLaunchKernelGGL(kern, dim3(a.n_subframes), dim3(threads), smem, stream, a);
-  return hipGetLastError();
+  if (hipError_t err = hipGetLastError(); err != hipSuccess) return err;
+  // (a clean-up launch that is not qlpc_marked_kernel: the count of marked subframes is cleared behind it)
+  if (a.only_marked && a.marked_count != nullptr) return hipMemsetAsync(a.marked_count, 0, 8, stream);
+  return hipSuccess;
 }
 
 }  // namespace

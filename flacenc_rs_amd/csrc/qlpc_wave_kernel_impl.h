@@ -182,19 +182,25 @@ __device__ __forceinline__ uint32_t wave_excl_scan_dpp(uint32_t v) {
   return s - v;
 }
 
-// The same canonical sums for NV values per lane at once, through a per-wave LDS area of NV x 64 doubles
+// The same canonical sums for NV values per lane at once, through a per-wave LDS area of NV x kTreeRow doubles
 // instead of NV dependent DPP trees (35 VALU instructions each): every lane parks its NV values, lane
 // 4 j + s fetches value j of lanes [16 s, 16 s + 16) and adds them exactly as the tree pairs them --
 // ((v0 + v1) + (v2 + v3)) + ... -- and two row shifts fold the four sixteenths, (s0 + s1) + (s2 + s3).
 // The total of value j arrives in lane 4 j + 3 (other lanes, and lanes >= 4 NV, return garbage).
+// Layout: value j of lane l at j kTreeRow + (l >> 4) kTreeSeg + (l & 15) -- sixteenths 18 doubles apart, values 72:
+// the 16-byte reads of lanes (j, s) then start 36 s + 144 j dwords apart, sixteen distinct bank quads for any sixteen
+// consecutive lanes (dense rows of 64 put every other lane on the same banks: SQ_LDS_BANK_CONFLICT was 55 % of the
+// autocorrelation kernel's LDS cycles).
+constexpr int kTreeSeg = 18, kTreeRow = 4 * kTreeSeg;
 template <int NV>
 __device__ __forceinline__ double wave_tree_sums_lds_n(const double* v, double* buf, int lane) {
   static_assert(4 * NV <= 64, "one quad of lanes per value");
+  const int mypos = (lane >> 4) * kTreeSeg + (lane & 15);
 #pragma unroll
-  for (int j = 0; j < NV; ++j) buf[j * 64 + lane] = v[j];
+  for (int j = 0; j < NV; ++j) buf[j * kTreeRow + mypos] = v[j];
   __builtin_amdgcn_wave_barrier();  // (LDS operations of one wave complete in order)
   const int j = (lane >> 2) < NV ? (lane >> 2) : NV - 1;
-  const double2* src = reinterpret_cast<const double2*>(buf + j * 64 + (lane & 3) * 16);
+  const double2* src = reinterpret_cast<const double2*>(buf + j * kTreeRow + (lane & 3) * kTreeSeg);
   double x[16];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {

@@ -135,6 +135,14 @@ static double orc_tree_sum(const double* v, size_t lo, size_t hi, size_t count) 
   return orc_tree_sum(v, lo, mid, count) + orc_tree_sum(v, mid, hi, count);
 }
 
+/* Where the build's UNFLAGGED order is the reference's own: on blocks of 8192 / 16384 samples at LPC orders from
+ * 16 the product sums as weighted_auto_correlation_nosimd does (src/lpc.rs:533-548: one sequential fma chain per
+ * lag; on the GPU, v_mfma_f64_4x4x4 chains) -- there the stable build's order costs what the chunk tree costs, so
+ * ORC_ACORR_CANONICAL, "what the product computes without a summation-order flag", is ORC_ACORR_REFERENCE. */
+int orc_default_order_is_stable(size_t n, size_t lpc_order) {
+  return (n == 8192 || n == 16384) && lpc_order >= 16;
+}
+
 void orc_auto_correlation_canonical_f64(size_t order, const float* signal, size_t n,
                                         double* dest) {
   for (size_t tau = 0; tau < order; ++tau) dest[tau] = 0.0;
@@ -374,7 +382,7 @@ int orc_lpc_from_autocorr(const int32_t* signal, size_t n, const orc_qlpc_config
   float* xw = orc_tls.xw;
   orc_fill_windowed_signal(signal, window, n, xw);
   double corr[ORC_MAX_LPC_ORDER + 1];
-  if (cfg->acorr_order == ORC_ACORR_CANONICAL)
+  if (cfg->acorr_order == ORC_ACORR_CANONICAL && !orc_default_order_is_stable(n, lpc_order))
     orc_auto_correlation_canonical_f64(lpc_order + 1, xw, n, corr);
   else if (cfg->acorr_order == ORC_ACORR_NIGHTLY)
     orc_auto_correlation_nightly_f64(lpc_order + 1, xw, n, corr, 0);

@@ -42,7 +42,8 @@ extern "C" {
 
 /* autocorrelation summation orders */
 #define ORC_ACORR_REFERENCE 0 /* weighted_auto_correlation_nosimd, src/lpc.rs:533-548 */
-#define ORC_ACORR_CANONICAL 1 /* the build's canonical order: 16-sample chunk chains + balanced tree */
+#define ORC_ACORR_CANONICAL 1 /* the build's unflagged order: 16-sample chunk chains + balanced tree -- except where
+                                  orc_default_order_is_stable() says it is ORC_ACORR_REFERENCE */
 #define ORC_ACORR_NIGHTLY 2   /* weighted_auto_correlation_simd, src/lpc.rs:510-531 (aligned buffer) */
 /* config::Qlpc::use_direct_mse (src/config.rs:280): covariance-method LPC, src/lpc.rs:853-903; bits 8.. of
  * acorr_order carry config::Qlpc::mae_optimization_steps (src/config.rs:285; IRLS, src/lpc.rs:814-850).
@@ -136,6 +137,7 @@ void orc_fill_windowed_signal(const int32_t* signal, const float* window, size_t
 void orc_auto_correlation_f64(size_t order, const float* signal, size_t n, double* dest);
 void orc_auto_correlation_f32(size_t order, const float* signal, size_t n, float* dest);
 void orc_auto_correlation_canonical_f64(size_t order, const float* signal, size_t n, double* dest);
+int orc_default_order_is_stable(size_t n, size_t lpc_order);
 void orc_auto_correlation_nightly_f64(size_t order, const float* signal, size_t n, double* dest,
                                       size_t base_mod);
 int orc_symmetric_levinson_f64(const double* coefs, const double* ys, size_t order, double* dest);

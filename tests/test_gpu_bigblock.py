@@ -129,6 +129,52 @@ def test_reference_summation_order(handle, n, order):
     check(handle, batch(4, n, 24, 77), 24, order, flags=_capi.FLAG_REFERENCE_SUM_ORDER, acorr=orc.ACORR_REFERENCE)
 
 
+@pytest.mark.parametrize("n,order,stereo", [(8192, 24, True), (8192, 32, True), (16384, 24, True), (16384, 32, True),
+                                            (8192, 16, False), (16384, 20, False)])
+def test_config3_config5_unflagged_order_is_the_references(handle, n, order, stereo):
+    """BASELINE configs[2] / [4] (8192 / 16384 samples, 24-bit, orders from 16): with flags = 0 the product sums as the
+    reference's stable build does (weighted_auto_correlation_nosimd, src/lpc.rs:533-548) -- R[], the unquantised and
+    the quantised coefficients, residuals and Rice partitions are bit-equal to the oracle's ACORR_REFERENCE mode."""
+    x = batch(4 if stereo else 5, n, 24, 1234 + n + order)
+    gcfg = _capi.make_config(lpc_order=order)  # flags = 0
+    ocfg = orc.make_config(lpc_order=order, acorr=orc.ACORR_REFERENCE)
+    if stereo:
+        frames = x.reshape(-1, 2, n)
+        gp, gres = handle.stereo_qlpc_batch(frames, 24, gcfg)
+        for f in range(frames.shape[0]):
+            m, s = orc.stereo_to_midside(frames[f, 0], frames[f, 1])
+            op, ores, _, _ = orc.qlpc_batch(np.stack([frames[f, 0], frames[f, 1], m, s]), np.array([24, 24, 24, 25], np.uint8), ocfg)
+            records_equal(gp[f], op)
+            assert np.array_equal(gres[f], ores)
+    gp, gres, gR, gA = handle.qlpc_batch(x, 24, gcfg, want_fp=True)
+    op, ores, oR, oA = orc.qlpc_batch(x, 24, ocfg)
+    assert np.array_equal(gR.view(np.uint64), oR.view(np.uint64)), "R[] is the reference's sequential chain"
+    assert np.array_equal(gA.view(np.uint64), oA.view(np.uint64))
+    records_equal(gp, op)
+    assert np.array_equal(gres, ores)
+    # unaligned rows and the generic kernel change the kernels, not the sums
+    pp, pres, pR, _ = handle.qlpc_batch(x, 24, _capi.make_config(lpc_order=order, flags=_capi.FLAG_GENERIC_KERNEL), want_fp=True)
+    assert np.array_equal(pR.view(np.uint64), oR.view(np.uint64)) and gp.tobytes() == pp.tobytes()
+    # the oracle's "canonical" mode (what the product computes unflagged) is that same order on these shapes ...
+    _, _, cR, _ = orc.qlpc_batch(x, 24, orc.make_config(lpc_order=order, acorr=orc.ACORR_CANONICAL))
+    assert np.array_equal(cR.view(np.uint64), oR.view(np.uint64))
+    # ... which is not the chunk tree (the corpus separates the two orders)
+    w = orc.window_weights(("tukey", 0.4), n)
+    tree = np.stack([orc.auto_correlation(order + 1, orc.fill_windowed_signal(x[i], w), canonical=True) for i in range(x.shape[0])])
+    assert not np.array_equal(tree.view(np.uint64), oR[:, : order + 1].view(np.uint64))
+
+
+@pytest.mark.parametrize("n,order", [(8192, 15), (16384, 12), (4096, 24)])
+def test_shapes_next_to_them_keep_the_chunk_tree(handle, n, order):
+    """... and only there: order 15 on those blocks and order 24 on 4096-sample blocks still sum in the chunk tree."""
+    x = batch(4, n, 24, 99 + n + order)
+    gp, gres, gR, gA = handle.qlpc_batch(x, 24, _capi.make_config(lpc_order=order), want_fp=True)
+    _, _, cR, _ = orc.qlpc_batch(x, 24, orc.make_config(lpc_order=order, acorr=orc.ACORR_CANONICAL))
+    _, _, rR, _ = orc.qlpc_batch(x, 24, orc.make_config(lpc_order=order, acorr=orc.ACORR_REFERENCE))
+    assert np.array_equal(gR.view(np.uint64), cR.view(np.uint64))
+    assert not np.array_equal(cR.view(np.uint64), rR.view(np.uint64))
+
+
 @pytest.mark.parametrize("kw", [dict(quant_precision=7), dict(window=("tukey", 1.0)), dict(window="rectangle"),
                                 dict(rice_finest_only=True)])
 def test_config_space(handle, kw):

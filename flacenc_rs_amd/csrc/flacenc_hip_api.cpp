@@ -320,7 +320,7 @@ int enqueue(flacenc_hip_handle* h, const flacenc_hip_qlpc_config* cfg, const int
             flacenc_hip_subframe_params* params, int32_t* residual, size_t residual_stride,
             double* autocorr, double* lpc_coefs, hipStream_t stream, bool stereo = false,
             uint32_t bps_uniform = 16, int32_t* residual_lr = nullptr, size_t residual_lr_stride = 0,
-            int32_t* minmax_out = nullptr, bool* placed = nullptr) {
+            int32_t* minmax_out = nullptr, bool* placed = nullptr, uint32_t residual_mode = 0) {
   if (placed) *placed = false;
   const WindowEntry* win = nullptr;
   int rc = get_window(h, cfg, block_size, &win);
@@ -393,6 +393,14 @@ int enqueue(flacenc_hip_handle* h, const flacenc_hip_qlpc_config* cfg, const int
       (flacenc_hip::bigblock_eligible(a) || (a.direct_mse && flacenc_hip::bigblock_shape_eligible(a)))) {
     a.residual_lr = residual_lr;
     a.residual_lr_stride = residual_lr_stride;
+    a.minmax_out = minmax_out;
+    if (placed) *placed = true;
+  }
+  // ... or, with residual_mode 1, no rows at all: records and the roles' min / max only (the deciding store pass,
+  // bigblock_residual_kernel's mode 2, produces the two rows the frame keeps)
+  if (stereo && residual_mode == 1u && minmax_out != nullptr &&
+      (flacenc_hip::bigblock_eligible(a) || (a.direct_mse && flacenc_hip::bigblock_shape_eligible(a)))) {
+    a.residual_mode = 1u;
     a.minmax_out = minmax_out;
     if (placed) *placed = true;
   }
@@ -518,7 +526,8 @@ __global__ void bitcount_pick_kernel(const unsigned long long* keys, uint32_t n,
 int enqueue_fixed(flacenc_hip_handle* h, const flacenc_hip_frame_config* cfg, const int32_t* samples,
                   size_t n_subframes, uint32_t block_size, size_t stride, const uint8_t* bps,
                   uint32_t bps_uniform, bool stereo, flacenc_hip_subframe_params* params, int32_t* residual,
-                  size_t residual_stride, unsigned long long* selector_keys, hipStream_t stream) {
+                  size_t residual_stride, unsigned long long* selector_keys, hipStream_t stream,
+                  uint32_t residual_mode = 0) {
   int rc = verify_fixed(h, cfg);
   if (rc != FLACENC_HIP_OK) return rc;
   flacenc_hip::QlpcLaunchPlan plan = flacenc_hip::plan_qlpc_launch(block_size, 4);
@@ -580,6 +589,13 @@ int enqueue_fixed(flacenc_hip_handle* h, const flacenc_hip_frame_config* cfg, co
     if ((rc = attach_sumabs_scratch(h, a, true)) != FLACENC_HIP_OK) return rc;
     if (block_size == 4096 || block_size == 8192 || block_size == 16384) {  // the big-block kernels' predictor records
       if ((rc = attach_split_scratch(h, a)) != FLACENC_HIP_OK) return rc;
+    }
+    if (residual_mode == 1u) {  // (the caller checked that this launch takes the big-block kernels)
+      if (!flacenc_hip::bigblock_fixed_eligible(a)) {
+        h->last_error = "internal: analyse-only fixed_lpc batch on a shape the big-block kernels do not take";
+        return FLACENC_HIP_ERR_UNSUPPORTED;
+      }
+      a.residual_mode = 1u;
     }
     HIP_TRY(h, flacenc_hip::launch_qlpc(a, plan, stream));
     return FLACENC_HIP_OK;
@@ -1863,6 +1879,58 @@ static int encode_stereo_frames_impl(flacenc_hip_handle* h, const flacenc_hip_fr
     d.results = results;
     d.residual = residual;
     d.residual_stride = residual_stride;
+    // Big-block shapes: two analyse-only passes (QLPC, fixed_lpc: records, no residual rows), then one kernel that
+    // decides and writes only the two rows the frame keeps (bigblock_residual_kernel, modes 1 and 2) -- eight candidate
+    // rows per frame stay off HBM, and so does the copy of the chosen two.
+    const bool big_shape =
+        cfg->use_lpc && (block_size == 8192 || block_size == 16384 || (block_size == 4096 && cfg->qlpc.lpc_order >= 13)) &&
+        !(cfg->qlpc.flags & FLACENC_HIP_FLAG_GENERIC_KERNEL) && !cfg->qlpc.use_direct_mse &&
+        (reinterpret_cast<uintptr_t>(frames) & 15) == 0 && (stride & 3) == 0 &&
+        (reinterpret_cast<uintptr_t>(residual) & 15) == 0 && (residual_stride & 3) == 0;
+    const uint32_t fparts = cfg->fixed_partitions;
+    const bool fixed_big = !cfg->use_fixed ||
+                           (cfg->fixed_order_sel == FLACENC_HIP_ORDERSEL_APPROXENT && fparts != 0 && (fparts & (fparts - 1)) == 0 &&
+                            block_size / fparts >= 64 && block_size / fparts <= 4096 && cfg->fixed_max_order <= 4);
+    if (big_shape && fixed_big) {
+      if ((rc = ensure(h, h->d_cparams, n_sub * sizeof(flacenc_hip_subframe_params))) != FLACENC_HIP_OK) return rc;
+      if ((rc = ensure(h, h->d_cresid, n_sub * cstride * 4)) != FLACENC_HIP_OK) return rc;
+      if ((rc = ensure(h, h->d_minmax, n_sub * 2 * sizeof(int32_t))) != FLACENC_HIP_OK) return rc;
+      bool analysed = false;
+      rc = enqueue(h, &cfg->qlpc, frames, n_sub, block_size, stride, nullptr,
+                   static_cast<flacenc_hip_subframe_params*>(h->d_cparams.ptr), static_cast<int32_t*>(h->d_cresid.ptr),
+                   cstride, nullptr, nullptr, s, true, bits_per_sample, nullptr, 0,
+                   static_cast<int32_t*>(h->d_minmax.ptr), &analysed, 1u);
+      if (rc != FLACENC_HIP_OK) return rc;
+      if (!analysed) {
+        h->last_error = "internal: analyse-only QLPC batch on a shape the big-block kernels do not take";
+        return FLACENC_HIP_ERR_UNSUPPORTED;
+      }
+      flacenc_hip::QlpcKernelArgs m = a;  // (shape, width and the encode_frame switches are set above)
+      m.frame_results = results;
+      m.residual = residual;
+      m.residual_stride = residual_stride;
+      m.residual_mode = 2u;
+      m.stamps = nullptr;
+      m.cand_lpc_params = static_cast<const flacenc_hip_subframe_params*>(h->d_cparams.ptr);
+      m.cand_lpc_rows = static_cast<const int32_t*>(h->d_cresid.ptr);
+      m.cand_minmax = static_cast<const int32_t*>(h->d_minmax.ptr);
+      m.cand_stride = cstride;
+      if (cfg->use_fixed) {
+        if ((rc = ensure(h, h->d_fparams, n_sub * sizeof(flacenc_hip_subframe_params))) != FLACENC_HIP_OK) return rc;
+        if ((rc = ensure(h, h->d_fresid, n_sub * cstride * 4)) != FLACENC_HIP_OK) return rc;
+        if ((rc = ensure(h, h->d_fkeys, n_sub * 8)) != FLACENC_HIP_OK) return rc;
+        rc = enqueue_fixed(h, cfg, frames, n_sub, block_size, stride, nullptr, bits_per_sample, true,
+                           static_cast<flacenc_hip_subframe_params*>(h->d_fparams.ptr),
+                           static_cast<int32_t*>(h->d_fresid.ptr), cstride,
+                           static_cast<unsigned long long*>(h->d_fkeys.ptr), s, 1u);
+        if (rc != FLACENC_HIP_OK) return rc;
+        m.cand_fixed_params = static_cast<const flacenc_hip_subframe_params*>(h->d_fparams.ptr);
+        m.cand_fixed_rows = static_cast<const int32_t*>(h->d_fresid.ptr);
+        m.cand_fixed_keys = static_cast<const unsigned long long*>(h->d_fkeys.ptr);
+      }
+      HIP_TRY(h, flacenc_hip::launch_bigblock_residual(m, s));
+      return FLACENC_HIP_OK;
+    }
     if (cfg->use_lpc) {
       if ((rc = ensure(h, h->d_cparams, n_sub * sizeof(flacenc_hip_subframe_params))) != FLACENC_HIP_OK) return rc;
       if ((rc = ensure(h, h->d_cresid, n_sub * cstride * 4)) != FLACENC_HIP_OK) return rc;

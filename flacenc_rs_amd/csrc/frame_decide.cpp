@@ -8,6 +8,8 @@
 // outputs of the stereo QLPC batch and of the stereo fixed-LPC batch (4 candidates each per frame).
 #include "frame_decide.h"
 
+#include "frame_decide_device.h"
+
 namespace flacenc_hip {
 namespace {
 
@@ -15,10 +17,7 @@ constexpr int kThreads = 256;
 
 __global__ void __launch_bounds__(kThreads) frame_decide_kernel(FrameDecideArgs a) {
   __shared__ int smin[4][kThreads / 64], smax[4][kThreads / 64];
-  __shared__ unsigned long long sbits[4];
-  __shared__ uint32_t skind[4], sstatus[4];
-  __shared__ int sdc[4];
-  __shared__ uint32_t schoice[3];  // assignment, role0, role1
+  __shared__ FrameDecision sdec;
   const int tid = threadIdx.x;
   const uint32_t f = blockIdx.x;
   const int n = (int)a.block_size;
@@ -59,89 +58,35 @@ __global__ void __launch_bounds__(kThreads) frame_decide_kernel(FrameDecideArgs 
   }
   __syncthreads();
 
-  // ---- encode_subframe per role (threads 0..3), then try_stereo_coding (thread 0) ----
+  // ---- encode_subframe per role (threads 0..3), then try_stereo_coding (thread 0); the two chosen records ----
+  int lo = 0, hi = 0;
   if (tid < 4) {
-    const int role = tid;
-    int lo = smin[role][0], hi = smax[role][0];
+    lo = smin[tid][0];
+    hi = smax[tid][0];
     for (int w = 1; w < kThreads / 64; ++w) {
-      lo = smin[role][w] < lo ? smin[role][w] : lo;
-      hi = smax[role][w] > hi ? smax[role][w] : hi;
+      lo = smin[tid][w] < lo ? smin[tid][w] : lo;
+      hi = smax[tid][w] > hi ? smax[tid][w] : hi;
     }
-    const unsigned long long bps = a.bits_per_sample + (role == 3 ? 1u : 0u);  // coding.rs:444
-    const unsigned long long verbatim_bits = 8ull + (unsigned long long)n * bps;  // datatype.rs:1944
-    const size_t sf = (size_t)f * 4 + role;
-    const bool have_fixed = a.use_fixed && a.fixed_params && a.fixed_keys[sf] < verbatim_bits;  // coding.rs:262, :284
-    const unsigned long long fixed_bits = have_fixed ? a.fixed_params[sf].subframe_bits : ~0ull;
-    const unsigned long long baseline = fixed_bits < verbatim_bits ? fixed_bits : verbatim_bits;  // coding.rs:403-405
-    const bool lpc_ok = a.use_lpc && a.lpc_params && a.lpc_params[sf].status == 0;
-    uint32_t kind;
-    unsigned long long bits;
-    if (a.use_constant && lo == hi) {
-      kind = FLACENC_HIP_KIND_CONSTANT;
-      bits = 8ull + bps;  // bitrepr.rs:445
-    } else if (lpc_ok && a.lpc_params[sf].subframe_bits < baseline) {
-      kind = FLACENC_HIP_KIND_LPC;
-      bits = a.lpc_params[sf].subframe_bits;
-    } else if (have_fixed && fixed_bits < verbatim_bits) {
-      kind = FLACENC_HIP_KIND_FIXED;
-      bits = fixed_bits;
-    } else {
-      kind = FLACENC_HIP_KIND_VERBATIM;
-      bits = verbatim_bits;
-    }
-    skind[role] = kind;
-    sbits[role] = bits;
-    sdc[role] = lo;
-    sstatus[role] = (a.use_lpc && a.lpc_params) ? (uint32_t)a.lpc_params[sf].status : 0u;
   }
-  __syncthreads();
-  if (tid == 0) {
-    const unsigned long long bl = sbits[0], br = sbits[1], bm = sbits[2], bs = sbits[3];
-    unsigned long long min_bits = bl + br;
-    uint32_t assignment = 0;  // Independent(2)
-    if (a.use_leftside && bl + bs < min_bits) {
-      min_bits = bl + bs;
-      assignment = 1;
-    }
-    if (a.use_rightside && br + bs < min_bits) {
-      min_bits = br + bs;
-      assignment = 2;
-    }
-    if (a.use_midside && bm + bs < min_bits) {
-      min_bits = bm + bs;
-      assignment = 3;
-    }
-    schoice[0] = assignment;
-    schoice[1] = assignment == 2 ? 3u : (assignment == 3 ? 2u : 0u);
-    schoice[2] = (assignment == 0 || assignment == 2) ? 1u : 3u;
-    flacenc_hip_stereo_frame_result* fr = a.results + f;
-    fr->channel_assignment = (uint8_t)assignment;
-    // analysis status of the four LPC candidates (the reference panics on these, lpc.rs:646 / :786-799)
-    fr->analysis_status = (uint8_t)(sstatus[0] | sstatus[1] | sstatus[2] | sstatus[3]);
-    fr->pad[0] = fr->pad[1] = 0;
-    for (int c = 0; c < 2; ++c) {
-      const uint32_t role = schoice[1 + c];
-      fr->role[c] = (uint8_t)role;
-      fr->kind[c] = (uint8_t)skind[role];
-      fr->dc_offset[c] = skind[role] == FLACENC_HIP_KIND_CONSTANT ? sdc[role] : 0;
-    }
-    fr->bits[0] = bl;
-    fr->bits[1] = br;
-    fr->bits[2] = bm;
-    fr->bits[3] = bs;
-  }
-  __syncthreads();
+  FrameCandidates cand;
+  cand.block_size = a.block_size;
+  cand.bits_per_sample = a.bits_per_sample;
+  cand.use_constant = a.use_constant;
+  cand.use_fixed = a.use_fixed;
+  cand.use_lpc = a.use_lpc;
+  cand.use_leftside = a.use_leftside;
+  cand.use_rightside = a.use_rightside;
+  cand.use_midside = a.use_midside;
+  cand.lpc_params = a.lpc_params;
+  cand.fixed_params = a.fixed_params;
+  cand.fixed_keys = a.fixed_keys;
+  decide_frame(cand, f, tid, kThreads, lo, hi, sdec, a.results);
 
-  // ---- the two chosen subframes: record + residual row ----
+  // ---- the two chosen residual rows ----
   for (int c = 0; c < 2; ++c) {
-    const uint32_t role = schoice[1 + c];
-    const uint32_t kind = skind[role];
+    const uint32_t role = sdec.choice[1 + c];
+    const uint32_t kind = sdec.kind[role];
     const size_t sf = (size_t)f * 4 + role;
-    uint32_t* rec = reinterpret_cast<uint32_t*>(&a.results[f].lpc[c]);
-    const uint32_t* src_rec = kind == FLACENC_HIP_KIND_LPC     ? reinterpret_cast<const uint32_t*>(a.lpc_params + sf)
-                              : kind == FLACENC_HIP_KIND_FIXED ? reinterpret_cast<const uint32_t*>(a.fixed_params + sf)
-                                                               : nullptr;
-    for (int i = tid; i < (int)(sizeof(flacenc_hip_subframe_params) / 4); i += kThreads) rec[i] = src_rec ? src_rec[i] : 0u;
     const int32_t* src = kind == FLACENC_HIP_KIND_LPC     ? a.lpc_residual + sf * a.cand_stride
                          : kind == FLACENC_HIP_KIND_FIXED ? a.fixed_residual + sf * a.cand_stride
                                                           : nullptr;

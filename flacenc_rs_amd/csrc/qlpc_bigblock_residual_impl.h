@@ -36,6 +36,7 @@
 
 #include <type_traits>
 
+#include "frame_decide_device.h"
 #include "qlpc_kernel.h"
 #include "qlpc_wave_kernel_impl.h"
 
@@ -107,8 +108,16 @@ __device__ __forceinline__ void planes_reduce_scatter(uint32_t (&c)[4][5], uint3
 }
 
 // NLB: byte limbs of the rows L, R, M (stereo) or of every row (plain); the side channel carries one bit more.
-template <bool STEREO, int K, int NLB>
+// MODE 0: analyse and store (the candidate-level batches: four residual rows per frame leave the CU).
+// MODE 1: analyse only -- records, no residual rows (the frame-level pipeline's bit-count passes: one launch behind the
+//         QLPC predictors, one behind fixed_lpc's).
+// MODE 2: decide and store (stereo): encode_subframe / try_stereo_coding over the records the MODE-1 launches left
+//         (frame_decide_device.h), then the TWO chosen (role, predictor) pairs are run through the FIR again and only
+//         their rows are written -- eight candidate rows per frame never reach HBM.
+template <bool STEREO, int K, int NLB, int MODE>
 __global__ void __launch_bounds__(256, (STEREO && K == 1) ? 3 : FLACENC_BIG_RESID_OCC) bigblock_residual_kernel(QlpcKernelArgs a) {
+  static_assert(MODE == 0 || STEREO, "the frame-level modes are stereo");
+  constexpr bool ANALYSE = MODE != 2, STORE = MODE != 1;
   constexpr int NLS = STEREO ? (NLB < 4 ? NLB + 1 : 4) : NLB;
   constexpr int kPlanes = 3 * NLB + NLS;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -117,30 +126,74 @@ __global__ void __launch_bounds__(256, (STEREO && K == 1) ? 3 : FLACENC_BIG_RESI
   uint32_t sf = blk * 4u + (uint32_t)wave;
   const bool active = sf < a.n_subframes;
   if (!active) sf = a.n_subframes - 1u;
-  const int role = STEREO ? wave : 0;
   const int n = (int)a.block_size;
-  const unsigned long long bps_role = a.bps ? (unsigned long long)a.bps[sf]
-                                            : (unsigned long long)(a.bps_uniform + ((STEREO && role == 3) ? 1u : 0u));
-  const int NL = (STEREO && wave == 3) ? NLS : NLB;
-  unsigned char* const myplanes = smem_raw + wave * (NLB * kLimbPlane);
   int* const xch = reinterpret_cast<int*>(smem_raw + kPlanes * kLimbPlane);  // [4 roles][max, min]: LDS atomics meet here
   if (STEREO && tid < 8) xch[tid] = (tid & 1) ? INT32_MAX : INT32_MIN;  // (ordered before their use by the pass loop's barriers)
   // profiling hook (flacenc_hip_debug_set_stamps): slots 0 / 7 wall clock (100 MHz) at entry / exit, 1..6 shader clock
   auto stamp = [&](int slot) {
-    if (a.stamps && lane == 0)
-      a.stamps[(size_t)sf * 8 + slot] = (slot == 0 || slot == 7) ? (unsigned long long)__builtin_amdgcn_s_memrealtime()
-                                                                  : (unsigned long long)clock64();
+    if (a.stamps) {
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("" ::: "memory");
+      const unsigned long long t = (slot == 0 || slot == 7) ? (unsigned long long)__builtin_amdgcn_s_memrealtime()
+                                                            : (unsigned long long)__builtin_amdgcn_s_memtime();
+      if (lane == 0) a.stamps[(size_t)sf * 8 + slot] = t;
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    }
   };
   stamp(0);
   stamp(1);
-  // the quantised predictor: qc[32], order, shift, status
-  const int32_t* __restrict__ pr = a.pred + (size_t)sf * 36;
-  const int warm = uni(pr[32]);
-  const int shift = uni(pr[33]);
-  const int status = uni(pr[34]);
-  int32_t* __restrict__ rrow = a.residual + (size_t)sf * a.residual_stride;
-  if (STEREO && a.residual_lr != nullptr && role < 2)  // L / R candidates in place of the output channel they can fill
-    rrow = a.residual_lr + (size_t)(2u * blk + (uint32_t)role) * a.residual_lr_stride;
+  // which row of the frame this wave filters, behind which predictor, and where its residual goes
+  int role = STEREO ? wave : 0;
+  int warm, shift, status;
+  const int32_t* __restrict__ pr = nullptr;                        // MODE 0 / 1: qc[32], order, shift, status
+  const flacenc_hip_subframe_params* __restrict__ prec = nullptr;  // MODE 2: the chosen candidate's record
+  int32_t* __restrict__ rrow = nullptr;
+  uint32_t chosen_kind = FLACENC_HIP_KIND_LPC;
+  if (MODE == 2) {
+    FrameDecision* const sdec = reinterpret_cast<FrameDecision*>(smem_raw + kPlanes * kLimbPlane + 32);
+    FrameCandidates cand;
+    cand.block_size = a.block_size;
+    cand.bits_per_sample = a.bps_uniform;
+    cand.use_constant = a.use_constant;
+    cand.use_fixed = a.use_fixed;
+    cand.use_lpc = a.use_lpc;
+    cand.use_leftside = a.use_leftside;
+    cand.use_rightside = a.use_rightside;
+    cand.use_midside = a.use_midside;
+    cand.lpc_params = a.cand_lpc_params;
+    cand.fixed_params = a.cand_fixed_params;
+    cand.fixed_keys = a.cand_fixed_keys;
+    int lo = 0, hi = 0;
+    if (tid < 4) {
+      lo = a.cand_minmax[((size_t)blk * 4 + tid) * 2 + 0];
+      hi = a.cand_minmax[((size_t)blk * 4 + tid) * 2 + 1];
+    }
+    decide_frame(cand, blk, tid, 256, lo, hi, *sdec, a.frame_results);
+    // waves 0 / 1 = output channels 0 / 1 (waves 2, 3 only help staging the planes)
+    const int ch = wave & 1;
+    role = uni((int)sdec->choice[1 + ch]);
+    chosen_kind = (uint32_t)uni((int)sdec->kind[role]);
+    const size_t csf = (size_t)blk * 4 + (size_t)role;
+    prec = chosen_kind == FLACENC_HIP_KIND_LPC ? a.cand_lpc_params + csf
+                                               : (chosen_kind == FLACENC_HIP_KIND_FIXED ? a.cand_fixed_params + csf : nullptr);
+    warm = prec ? uni((int)prec->order) : 0;
+    shift = prec ? uni((int)prec->shift) : 0;
+    status = prec ? 0 : 1;  // Constant / Verbatim: a zero predictor, zero rows
+    rrow = a.residual + (size_t)(2u * blk + (uint32_t)ch) * a.residual_stride;
+  } else {
+    pr = a.pred + (size_t)sf * 36;
+    warm = uni(pr[32]);
+    shift = uni(pr[33]);
+    status = uni(pr[34]);
+    rrow = a.residual + (size_t)sf * a.residual_stride;
+    if (STEREO && a.residual_lr != nullptr && role < 2)  // L / R candidates in place of the output channel they can fill
+      rrow = a.residual_lr + (size_t)(2u * blk + (uint32_t)role) * a.residual_lr_stride;
+  }
+  const unsigned long long bps_role = a.bps ? (unsigned long long)a.bps[sf]
+                                            : (unsigned long long)(a.bps_uniform + ((STEREO && role == 3) ? 1u : 0u));
+  const int NL = (STEREO && role == 3) ? NLS : NLB;
+  unsigned char* const myplanes = smem_raw + (STEREO ? role : wave) * (NLB * kLimbPlane);
 
   // ---- A operand: row i = lane & 15, k = 16 kb + j in byte j; tap(i, k) = i - 1 - (k - 32).  The taps come from a
   // zero-padded table in LDS (it overlays the planes: they are filled behind the first barrier of the pass loop)
@@ -152,7 +205,7 @@ __global__ void __launch_bounds__(256, (STEREO && K == 1) ? 3 : FLACENC_BIG_RESI
     ctab[lane] = 0;
     ctab[lane + 64] = 0;
     if (status == 0) {
-      if (lane < 32) ctab[48 + lane] = pr[lane];
+      if (lane < 32) ctab[48 + lane] = MODE == 2 ? (int32_t)prec->coefs[lane] : pr[lane];
       if (lane == 32) ctab[47] = -(1 << shift);
     }
     uint32_t w0[4], w1[4];
@@ -197,7 +250,7 @@ __global__ void __launch_bounds__(256, (STEREO && K == 1) ? 3 : FLACENC_BIG_RESI
   // subframe to the generic kernel (below).  mid lies between l and r and side within their spread, so that check
   // needs L and R only; is_constant's input at frame level (minmax_out) wants every role's own extremes.
   int mx[4] = {INT32_MIN, INT32_MIN, INT32_MIN, INT32_MIN}, mn[4] = {INT32_MAX, INT32_MAX, INT32_MAX, INT32_MAX};
-  const bool track_ms = a.minmax_out != nullptr;
+  const bool track_ms = MODE == 2 || a.minmax_out != nullptr;  // (MODE 2: the same criterion as the MODE-1 launches that marked)
 
   uint32_t pl[K][7];
   // Stereo: a pass's loads (the thread's four quads of L and of R: 8 int4 in plain variables -- a struct or array of
@@ -234,6 +287,7 @@ __global__ void __launch_bounds__(256, (STEREO && K == 1) ? 3 : FLACENC_BIG_RESI
     }                                                                                                          \
   }
   if (STEREO) FLACENC_PASS_FETCH(0)
+#pragma unroll 1
   for (int k = 0; k < K; ++k) {
     if (STEREO) {
       // the 32 samples in front of the pass: the tail of the previous one (read before the barrier, while it is
@@ -343,15 +397,22 @@ __global__ void __launch_bounds__(256, (STEREO && K == 1) ? 3 : FLACENC_BIG_RESI
           }
           // (an inactive wave -- plain mode's last workgroup -- recomputes the batch's last subframe and stores the same
           // values to the same row: no branch around the stores, the tiles stay one basic block)
-          *reinterpret_cast<int4*>(rrow + (size_t)k * kBigPass + t0) = make_int4(e[4 * r], e[4 * r + 1], e[4 * r + 2], e[4 * r + 3]);
+          if (STORE)
+            *reinterpret_cast<int4*>(rrow + (size_t)k * kBigPass + t0) = make_int4(e[4 * r], e[4 * r + 1], e[4 * r + 2], e[4 * r + 3]);
+          // (the stores pace the tiles; without them the scheduler runs all 96 MFMAs of a pass ahead of the first
+          // recombination and keeps every result alive -- 58 spilled registers at 256: an empty volatile asm that "uses"
+          // the tile's residuals stands in for the store)
+          else asm volatile("" ::"v"(e[4 * r]), "v"(e[4 * r + 1]), "v"(e[4 * r + 2]), "v"(e[4 * r + 3]));
         }
         // the lane's 16 residuals of partition 16 Q + n -> bit-plane counts
-        popcount_planes16(e, cnt[Q]);
+        if (ANALYSE) popcount_planes16(e, cnt[Q]);
       }
-      planes_reduce_scatter(cnt, now);
+      if (ANALYSE) planes_reduce_scatter(cnt, now);
     };
-    if (STEREO && role == 3) tiles(std::integral_constant<int, NLS>{});
-    else tiles(std::integral_constant<int, NLB>{});
+    if (MODE != 2 || wave < 2) {
+      if (STEREO && role == 3) tiles(std::integral_constant<int, NLS>{});
+      else tiles(std::integral_constant<int, NLB>{});
+    }
     if (k == 0) stamp(3);  // first pass's tiles
     // (the pass loop is rolled; pl[k] is selected by a compare chain so that the planes stay in registers)
 #pragma unroll
@@ -386,6 +447,17 @@ __global__ void __launch_bounds__(256, (STEREO && K == 1) ? 3 : FLACENC_BIG_RESI
   vmin = uni(vmin);
   const int lim = NL >= 4 ? INT32_MAX : (1 << (8 * NL - 1)) - 1;
   const bool out_of_width = vmax > lim || vmin < -lim - 1;
+  if (MODE == 2) {
+    // a row outside its declared width was marked by the analysing launches and redone by the generic kernel, whose
+    // candidate row is the residual: copy it over what the byte planes produced
+    if (wave < 2 && out_of_width && prec != nullptr) {
+      const int32_t* __restrict__ src = (chosen_kind == FLACENC_HIP_KIND_LPC ? a.cand_lpc_rows : a.cand_fixed_rows) +
+                                        ((size_t)blk * 4 + (size_t)role) * a.cand_stride;
+      for (int t = lane; t < n; t += 64) rrow[t] = src[t];
+    }
+    stamp(7);
+    return;
+  }
 
   // ======================= partitioned-Rice search over 64 K partitions =======================
   // finest order FO = 6 + log2 K (rice.rs:157-165); level L = order FO - L
@@ -623,7 +695,7 @@ __global__ void __launch_bounds__(256, (STEREO && K == 1) ? 3 : FLACENC_BIG_RESI
       rec->rice_params[j] = (uint8_t)(ok ? v : 0u);
     }
   }
-  if (lane < 32) rec->coefs[lane] = (status == 0) ? (int16_t)pr[lane] : (int16_t)0;
+  if (lane < 32) rec->coefs[lane] = (status == 0 && MODE != 2) ? (int16_t)pr[lane] : (int16_t)0;
   if (lane == 0) {
     rec->order = (uint8_t)warm;
     rec->shift = (int8_t)shift;
@@ -638,19 +710,27 @@ __global__ void __launch_bounds__(256, (STEREO && K == 1) ? 3 : FLACENC_BIG_RESI
 
 // LDS: the byte planes of the workgroup's four rows + 32 bytes of min / max exchange (24-bit stereo: 13 planes =
 // 53 696 bytes, 42 of the 1280-byte granules: three workgroups per CU); the tap tables, 2 KB, overlay the planes
+template <int K, int NLB, int MODE>
+hipError_t launch_bigblock_residual_mode(const QlpcKernelArgs& a, hipStream_t stream) {
+  static DynamicLdsOptIn opt_s;
+  const uint32_t blocks = a.n_subframes / 4u;
+  const size_t smem = (size_t)(3 * NLB + (NLB < 4 ? NLB + 1 : 4)) * kLimbPlane + 32 + (MODE == 2 ? 128 : 0);
+  if (hipError_t err = opt_s.ensure(reinterpret_cast<const void*>(bigblock_residual_kernel<true, K, NLB, MODE>), smem); err != hipSuccess) return err;
+  hipLaunchKernelGGL((bigblock_residual_kernel<true, K, NLB, MODE>), dim3(blocks), dim3(256), smem, stream, a);
+  return hipGetLastError();
+}
+
 template <int K, int NLB>
 hipError_t launch_bigblock_residual_inst(const QlpcKernelArgs& a, hipStream_t stream) {
-  static DynamicLdsOptIn opt_s, opt_p;
-  const uint32_t blocks = a.stereo ? a.n_subframes / 4u : (a.n_subframes + 3u) / 4u;
-  if (a.stereo) {
-    const size_t smem = (size_t)(3 * NLB + (NLB < 4 ? NLB + 1 : 4)) * kLimbPlane + 32;
-    if (hipError_t err = opt_s.ensure(reinterpret_cast<const void*>(bigblock_residual_kernel<true, K, NLB>), smem); err != hipSuccess) return err;
-    hipLaunchKernelGGL((bigblock_residual_kernel<true, K, NLB>), dim3(blocks), dim3(256), smem, stream, a);
-  } else {
-    const size_t smem = (size_t)(4 * NLB) * kLimbPlane + 32;
-    if (hipError_t err = opt_p.ensure(reinterpret_cast<const void*>(bigblock_residual_kernel<false, K, NLB>), smem); err != hipSuccess) return err;
-    hipLaunchKernelGGL((bigblock_residual_kernel<false, K, NLB>), dim3(blocks), dim3(256), smem, stream, a);
-  }
+  if (a.stereo && a.residual_mode == 1u) return launch_bigblock_residual_mode<K, NLB, 1>(a, stream);
+  if (a.stereo && a.residual_mode == 2u) return launch_bigblock_residual_mode<K, NLB, 2>(a, stream);
+  if (a.residual_mode != 0u) return hipErrorInvalidValue;
+  if (a.stereo) return launch_bigblock_residual_mode<K, NLB, 0>(a, stream);
+  static DynamicLdsOptIn opt_p;
+  const uint32_t blocks = (a.n_subframes + 3u) / 4u;
+  const size_t smem = (size_t)(4 * NLB) * kLimbPlane + 32;
+  if (hipError_t err = opt_p.ensure(reinterpret_cast<const void*>(bigblock_residual_kernel<false, K, NLB, 0>), smem); err != hipSuccess) return err;
+  hipLaunchKernelGGL((bigblock_residual_kernel<false, K, NLB, 0>), dim3(blocks), dim3(256), smem, stream, a);
   return hipGetLastError();
 }
 

@@ -59,6 +59,17 @@ struct QlpcKernelArgs {
   int32_t* residual_lr = nullptr;
   size_t residual_lr_stride = 0;
   int32_t* minmax_out = nullptr;
+  // bigblock_residual_kernel: 0 = analyse + store four candidate rows per frame; 1 = analyse only (records, no rows);
+  // 2 = decide + store: encode_subframe / try_stereo_coding over the records two mode-1 launches left, then only the
+  // two chosen rows are produced (frame-level calls on the big-block shapes)
+  uint32_t residual_mode = 0;
+  const flacenc_hip_subframe_params* cand_lpc_params = nullptr;    // mode 2, [n_subframes]; null: candidate kind off
+  const flacenc_hip_subframe_params* cand_fixed_params = nullptr;
+  const unsigned long long* cand_fixed_keys = nullptr;             // the order selector's key of each fixed candidate
+  const int32_t* cand_minmax = nullptr;                            // [n_subframes][2]: min, max of each role
+  const int32_t* cand_lpc_rows = nullptr;                          // rows the generic clean-up wrote for marked subframes
+  const int32_t* cand_fixed_rows = nullptr;
+  size_t cand_stride = 0;
   uint32_t only_marked;       // generic kernel: redo only subframes whose record says status == -1
   // [0]: subframes bigblock_residual_kernel marked for that clean-up launch (zero between calls: qlpc_marked_kernel
   // returns at once on 0, and its last workgroup to arrive -- ticket counter [1] -- clears both); nullptr: always scan

@@ -479,7 +479,10 @@ constexpr int kMRow = kMHist + kMTile + 8;   // row stride = 8 mod 32 banks: the
 
 template <bool STEREO, int NS>
 __global__ void __launch_bounds__(256) acorr_reference_mfma_kernel(AcorrRefArgs a) {
-  typedef float elem_t;  // (f64 in LDS -- no conversion per operand, twice the LDS traffic, 3 workgroups per CU -- is 2.4 x slower)
+  // (f64 in LDS -- no conversion per operand, twice the LDS traffic, 3 workgroups per CU -- is 2.4 x slower; round 4 tried it
+  // again de-interleaved by sample phase, a lane's operand sequence contiguous and two steps per ds_read2_b64: 510 us
+  // against 344 at order 24 on 6144 frames of 8192 -- the LDS, not the conversions, is what that form waits for)
+  typedef float elem_t;
   __shared__ __attribute__((aligned(16))) elem_t lds[4][4 * kMRow];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

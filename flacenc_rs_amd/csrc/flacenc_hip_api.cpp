@@ -136,6 +136,7 @@ struct flacenc_hip_handle {
   DeviceBuffer d_samples, d_residual, d_params, d_bps, d_autocorr, d_lpc, d_tables, d_keys, d_sel, d_results, d_out, d_outlen, d_cparams, d_cresid, d_fparams, d_fresid, d_fkeys, d_split, d_presid, d_sumabs, d_minmax, d_marked;
   // streaming host path (flacenc_hip_encode_pcm_stereo): copy-in / copy-out streams, two slots of pinned
   // staging and device buffers, the events that order them
+  uint32_t marked_parity = 0;  // which of d_marked's two counters the current pipeline counts into
   hipStream_t s_in = nullptr, s_out = nullptr;
   hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_fill[2] = {nullptr, nullptr}, ev_pack[2] = {nullptr, nullptr},
              ev_d2h[2] = {nullptr, nullptr};
@@ -311,7 +312,9 @@ int attach_split_scratch(flacenc_hip_handle* h, flacenc_hip::QlpcKernelArgs& a) 
     if ((rc = ensure(h, h->d_marked, 64)) != FLACENC_HIP_OK) return rc;
     HIP_TRY(h, hipMemset(h->d_marked.ptr, 0, 64));
   }
-  a.marked_count = static_cast<uint32_t*>(h->d_marked.ptr);
+  h->marked_parity ^= 1u;
+  a.marked_count = static_cast<uint32_t*>(h->d_marked.ptr) + h->marked_parity;
+  a.marked_next = static_cast<uint32_t*>(h->d_marked.ptr) + (h->marked_parity ^ 1u);
   return FLACENC_HIP_OK;
 }
 

@@ -46,6 +46,9 @@ namespace {
 #ifndef FLACENC_BIG_RESID_OCC
 #define FLACENC_BIG_RESID_OCC 2  // (two passes and more: 212 registers unconstrained; at 168 the pass-ahead loads spill)
 #endif
+#ifndef FLACENC_BIG_OCC3_MODE
+#define FLACENC_BIG_OCC3_MODE 2  // (the deciding store pass needs 156 registers)
+#endif
 constexpr int kBigPass = 4096;
 constexpr int kLimbPlane = 32 + kBigPass;  // bytes: the 32 samples in front of the pass, then the pass
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -115,7 +118,7 @@ __device__ __forceinline__ void planes_reduce_scatter(uint32_t (&c)[4][5], uint3
 //         (frame_decide_device.h), then the TWO chosen (role, predictor) pairs are run through the FIR again and only
 //         their rows are written -- eight candidate rows per frame never reach HBM.
 template <bool STEREO, int K, int NLB, int MODE>
-__global__ void __launch_bounds__(256, (STEREO && K == 1) ? 3 : FLACENC_BIG_RESID_OCC) bigblock_residual_kernel(QlpcKernelArgs a) {
+__global__ void __launch_bounds__(256, ((STEREO && K == 1) || MODE == FLACENC_BIG_OCC3_MODE) ? 3 : FLACENC_BIG_RESID_OCC) bigblock_residual_kernel(QlpcKernelArgs a) {
   static_assert(MODE == 0 || STEREO, "the frame-level modes are stereo");
   constexpr bool ANALYSE = MODE != 2, STORE = MODE != 1;
   constexpr int NLS = STEREO ? (NLB < 4 ? NLB + 1 : 4) : NLB;

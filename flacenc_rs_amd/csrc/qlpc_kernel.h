@@ -71,9 +71,12 @@ struct QlpcKernelArgs {
   const int32_t* cand_fixed_rows = nullptr;
   size_t cand_stride = 0;
   uint32_t only_marked;       // generic kernel: redo only subframes whose record says status == -1
-  // [0]: subframes bigblock_residual_kernel marked for that clean-up launch (zero between calls: qlpc_marked_kernel
-  // returns at once on 0, and its last workgroup to arrive -- ticket counter [1] -- clears both); nullptr: always scan
+  // subframes bigblock_residual_kernel marked for that clean-up launch: qlpc_marked_kernel returns at once on 0.  The
+  // handle alternates between two counters from pipeline to pipeline; the clean-up launch clears `marked_next`, the one
+  // the following pipeline counts into (a pipeline without a clean-up launch leaves a stale count behind at worst: a
+  // scan that finds nothing).  nullptr: always scan.
   uint32_t* marked_count = nullptr;
+  uint32_t* marked_next = nullptr;
   flacenc_hip_subframe_params* params;  // device
   int32_t* residual;                    // device
   size_t residual_stride;

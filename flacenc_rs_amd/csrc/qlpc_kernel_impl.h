@@ -376,27 +376,22 @@ __device__ __attribute__((noinline)) void qlpc_subframe_call(const QlpcKernelArg
 // (launched with the generic kernel's own workgroup size for the bucket: up to 1024 threads at orders <= 12)
 template <int MAXP, bool BIG>
 __global__ void __launch_bounds__(MAXP <= 12 ? 1024 : (MAXP <= 16 ? 512 : 256)) qlpc_marked_kernel(QlpcKernelArgs a) {
-  const uint32_t base = blockIdx.x * blockDim.x;
-  const uint32_t mine = base + threadIdx.x;
   if (a.marked_count != nullptr) {
-    // nothing marked (the usual case): no scan of the records.  Every workgroup reads the count, then takes a ticket;
-    // the last one to arrive clears count and tickets for the next call.
-    __shared__ uint32_t marked;
-    if (threadIdx.x == 0) {
-      marked = __hip_atomic_load(a.marked_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const uint32_t ticket = __hip_atomic_fetch_add(a.marked_count + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-      if (ticket == gridDim.x - 1u) {
-        __hip_atomic_store(a.marked_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(a.marked_count + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-    __syncthreads();
-    if (marked == 0u) return;
+    // nothing marked (the usual case): no scan of the records.  Two counters take turns from pipeline to pipeline
+    // (QlpcKernelArgs::marked_count / marked_next): this launch clears the one the NEXT pipeline's residual kernel will
+    // count into.  (Tickets on one counter -- the last workgroup to arrive clears it -- cost 96 same-address
+    // device-scope atomics from all eight XCDs: 21 us for a launch that has nothing to do.)
+    if (blockIdx.x == 0 && threadIdx.x == 0) *a.marked_next = 0u;
+    if (__hip_atomic_load(a.marked_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
   }
-  if (!__syncthreads_or(mine < a.n_subframes && a.params[mine].status == -1 ? 1 : 0)) return;
-  for (uint32_t i = 0; i < blockDim.x && base + i < a.n_subframes; ++i) {
-    if (a.params[base + i].status == -1) qlpc_subframe_call<MAXP, BIG>(a, base + i);
-    __syncthreads();
+  // (a small grid walks the records in strides: the usual launch finds the count at 0 and is over at once)
+  for (uint32_t base = blockIdx.x * blockDim.x; base < a.n_subframes; base += gridDim.x * blockDim.x) {
+    const uint32_t mine = base + threadIdx.x;
+    if (!__syncthreads_or(mine < a.n_subframes && a.params[mine].status == -1 ? 1 : 0)) continue;
+    for (uint32_t i = 0; i < blockDim.x && base + i < a.n_subframes; ++i) {
+      if (a.params[base + i].status == -1) qlpc_subframe_call<MAXP, BIG>(a, base + i);
+      __syncthreads();
+    }
   }
 }
 
@@ -443,7 +438,9 @@ hipError_t launch_one(const QlpcKernelArgs& a, int threads, size_t smem, hipStre
       auto mk = qlpc_marked_kernel<MAXP, BIG>;
       static DynamicLdsOptIn opt_in_marked;
       if (hipError_t err = opt_in_marked.ensure(reinterpret_cast<const void*>(mk), smem); err != hipSuccess) return err;
-      hipLaunchKernelGGL(mk, dim3((a.n_subframes + (uint32_t)threads - 1u) / (uint32_t)threads), dim3(threads), smem, stream, a);
+      uint32_t grid = (a.n_subframes + (uint32_t)threads - 1u) / (uint32_t)threads;
+      if (grid > 96u) grid = 96u;  // (the kernel walks the records in grid strides)
+      hipLaunchKernelGGL(mk, dim3(grid), dim3(threads), smem, stream, a);
       return hipGetLastError();
     }
   }
@@ -453,7 +450,10 @@ hipError_t launch_one(const QlpcKernelArgs& a, int threads, size_t smem, hipStre
   hipLaunchKernelGGL(kern, dim3(a.n_subframes), dim3(threads), smem, stream, a);
   if (hipError_t err = hipGetLastError(); err != hipSuccess) return err;
   // (a clean-up launch that is not qlpc_marked_kernel: the count of marked subframes is cleared behind it)
-  if (a.only_marked && a.marked_count != nullptr) return hipMemsetAsync(a.marked_count, 0, 8, stream);
+  if (a.only_marked && a.marked_count != nullptr) {
+    if (hipError_t err = hipMemsetAsync(a.marked_count, 0, 4, stream); err != hipSuccess) return err;
+    return hipMemsetAsync(a.marked_next, 0, 4, stream);
+  }
   return hipSuccess;
 }
 

@@ -143,8 +143,8 @@ def all_gather_frame_bytes(place, packed: torch.Tensor, local_lengths: torch.Ten
     caller); there is no host fallback here.  By default the runs are padded to the longest run actually
     produced, which costs two host synchronisations (that size, and the stream's total); with `run_capacity`
     -- an upper bound on any rank's run, e.g. n_local * out_stride -- nothing is read back: runs travel
-    padded to that bound and the result is the capacity-sized buffer whose first `stream_offsets(...)[1]`
-    bytes are the stream."""
+    padded to that bound and the result is a buffer of min(world * capacity, n_frames_total * out_stride) bytes whose
+    first `stream_offsets(...)[1]` bytes are the stream -- callers slice with that total (the rest is uninitialised)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     per_rank = (n_frames_total + world - 1) // world
@@ -161,7 +161,9 @@ def all_gather_frame_bytes(place, packed: torch.Tensor, local_lengths: torch.Ten
     else:
         run_bytes = int(run_capacity)
     cap = (run_bytes + 15) & ~15
-    run = torch.zeros(max(cap, 16), dtype=torch.uint8, device=dev)
+    # (exact-size mode zero-fills the run so that the gathered buffer is reproducible byte for byte; in capacity mode
+    # the bytes behind a rank's frames are never read -- no memset of hundreds of megabytes per step)
+    run = (torch.zeros if run_capacity is None else torch.empty)(max(cap, 16), dtype=torch.uint8, device=dev)
     row_offsets = torch.arange(n_local, dtype=torch.int64, device=dev) * packed.shape[1]
     my_lengths = local_lengths.to(torch.int32).contiguous()
     place(packed, row_offsets, my_lengths, run, run_offsets[:n_local, rank].contiguous())
@@ -172,7 +174,8 @@ def all_gather_frame_bytes(place, packed: torch.Tensor, local_lengths: torch.Ten
         runs = run
     # frame f = j * world + r lives at r * cap' + run_offsets[j, r] in `runs`
     src = (run_offsets + torch.arange(world, dtype=torch.int64, device=dev) * run.numel()).reshape(-1)[:n_frames_total]
-    total = int(lengths_all.to(torch.int64).sum().item()) if run_capacity is None else world * cap
+    # capacity mode: the stream cannot be longer than the frames' rows (n_frames_total * row bytes <= world * cap)
+    total = int(lengths_all.to(torch.int64).sum().item()) if run_capacity is None else min(world * cap, n_frames_total * packed.shape[1])
     stream_bytes = torch.empty(max(total, 1), dtype=torch.uint8, device=dev)
     place(runs, src.contiguous(), lengths_all.to(torch.int32).contiguous(), stream_bytes,
           offsets.to(torch.int64).contiguous())

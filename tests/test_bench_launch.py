@@ -46,6 +46,18 @@ def test_three_ranks_uneven_is_still_ordered():
     assert line["config"]["exchange_check"]["ok"] is True
 
 
+def test_eight_ranks_ragged_frame_count():
+    """The launch an 8-GPU node gets (`--gpus 8`), over gloo: eight ranks, 13 frames per rank-step that do not divide
+    evenly into anything, every gather kind's stream checked on every rank."""
+    for gather in ("records", "payload"):
+        r = _run(["--gpus", "8", "--backend", "gloo", "--dry-run", "--steps", "1", "--frames", "13", "--gather", gather],
+                 timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = _json_line(r.stdout)
+        assert line["n_gpus"] == 8 and line["ranks_observed"] == 8
+        assert line["config"]["exchange_check"]["ok"] is True
+
+
 def test_world_size_mismatch_is_an_error():
     r = _run(["--gpus", "2", "--backend", "gloo", "--dry-run"], {"WORLD_SIZE": "3", "RANK": "0"})
     assert r.returncode == 2 and "WORLD_SIZE=3" in r.stderr

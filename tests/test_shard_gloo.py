@@ -1,4 +1,4 @@
-"""world_size-2 gloo test of the multi-GPU path on CPU: round-robin frame sharding + ordered
+"""world_size-2 and -8 gloo tests of the multi-GPU path on CPU: round-robin frame sharding + ordered
 all-gather of the parameter records must reproduce the single-process result in frame order
 (the role of ParSink, src/par.rs:67-95, tested there by `par_sink_finalization`, par.rs:457-556).
 No GPU here: each rank fills its records with the CPU oracle (allowed in tests/)."""
@@ -59,7 +59,9 @@ def _worker(rank, world, port, n_frames, out_dir):
     res, resid = orc.encode_stereo_frames_cfg(frames, bps, fc)
     blobs = [orc.write_stereo_frame(res[j], frames[j, 0], frames[j, 1], bps, 44100, f, resid[j, 0], resid[j, 1])
              for j, f in enumerate(mine)]
-    cap = max(len(b) for b in blobs) + 5
+    capt = torch.tensor([max([len(b) for b in blobs] + [0]) + 5], dtype=torch.int64)
+    dist.all_reduce(capt, op=dist.ReduceOp.MAX)  # one row width for every rank, like the packer's out_stride
+    cap = int(capt.item())
     packed = torch.zeros((len(mine), cap), dtype=torch.uint8)
     for j, b in enumerate(blobs):
         packed[j, :len(b)] = torch.frombuffer(bytearray(b), dtype=torch.uint8)
@@ -75,13 +77,20 @@ def _worker(rank, world, port, n_frames, out_dir):
     stream = shard.all_gather_frame_bytes(place, packed, my_len, lengths_all, offsets, n_frames)
     assert stream.numel() == int(total)
     np.save(os.path.join(out_dir, f"stream{rank}.npy"), stream.numpy())
+    # ... and with `run_capacity` (what bench.py passes: no size is read back; the result is capacity-sized and its
+    # first `total` bytes are the stream)
+    per_rank = (n_frames + world - 1) // world
+    capped = shard.all_gather_frame_bytes(place, packed, my_len, lengths_all, offsets, n_frames, run_capacity=per_rank * cap)
+    assert capped.numel() >= int(total) and capped.numel() <= n_frames * cap + 16 * world
+    assert torch.equal(capped[:int(total)], stream)
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_frames", [8, 7])
-def test_round_robin_shard_and_ordered_gather(tmp_path, n_frames):
-    world = 2
+# (world 8 with a frame count that is not a multiple of 8: the index arithmetic of an 8-GPU node -- ragged last
+# round, ranks with one frame fewer -- over gloo; ParSink::finalize, src/par.rs:82-94)
+@pytest.mark.parametrize("world,n_frames", [(2, 8), (2, 7), (8, 19), (8, 5)])
+def test_round_robin_shard_and_ordered_gather(tmp_path, world, n_frames):
     port = _free_port()
     mp.spawn(_worker, args=(world, port, n_frames, str(tmp_path)), nprocs=world, join=True)
     sys.path.insert(0, ROOT)
@@ -101,7 +110,8 @@ def test_round_robin_shard_and_ordered_gather(tmp_path, n_frames):
     # frame (numbers 0..n-1 in order, both CRCs) back to the input samples
     from tests import flac_parse
     s0 = np.load(os.path.join(str(tmp_path), "stream0.npy")).tobytes()
-    assert s0 == np.load(os.path.join(str(tmp_path), "stream1.npy")).tobytes()
+    for rank in range(1, world):
+        assert s0 == np.load(os.path.join(str(tmp_path), f"stream{rank}.npy")).tobytes()
     pos = 0
     for f in range(n_frames):
         fr = flac_parse.parse_frame(s0[pos:], stream_bps=16, stream_rate=44100)

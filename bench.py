@@ -157,6 +157,22 @@ def profiled_counters(args):
     return p
 
 
+def profiled_phases(args):
+    """Per-phase VALU instructions of the headline kernel next to the formulation's floor (profiles/
+    headline_phases.json, tools/phase_insts.sh): attached like the counters, to the profiled source only."""
+    default = parse_args([])
+    same_cfg = all(getattr(args, k) == getattr(default, k)
+                   for k in ("block_size", "lpc_order", "bps", "use_fixed", "finest_rice_order", "reference_order"))
+    try:
+        with open(os.path.join(ROOT, "profiles", "headline_phases.json")) as f:
+            p = json.load(f)
+    except Exception:
+        return None
+    if not same_cfg or p.get("kernel_source_sha") != kernel_source_sha():
+        return None
+    return p
+
+
 def kernel_name(args):
     """The kernel flacenc_hip_encode_stereo_frames dispatches to for this run (qlpc_dispatch.cpp)."""
     if args.block_size == 4096 and args.lpc_order <= 12:
@@ -329,6 +345,7 @@ def run(args, world):
         value = 0.0  # ranks shared a GPU and the collectives went through the host: not a measurement
     achieved = ALGO_BYTES_PER_SAMPLE * samples_per_step / (kernel_ms * 1e-3) / 1e9
     prof = profiled_counters(args)
+    phases = profiled_phases(args)
     # share of SIMD cycles with the VALU pipe executing: a ratio of two counters of the profiled runs of this
     # very kernel source (no clock assumed), see tools/make_headline_pmc.py
     valu_frac = round(prof["valu_busy_frac"], 4) if prof and prof.get("valu_busy_frac") else None
@@ -396,6 +413,10 @@ def run(args, world):
             "valu_issue_frac": valu_frac,
             "valu_insts_per_wave": prof.get("valu_insts_per_wave") if prof else None,
             "counters_from": ("profiles/headline_pmc.json @ kernel source %s" % prof["kernel_source_sha"]) if prof else None,
+            # where the instructions go, and the least this formulation can spend (profiles/headline_phases.json)
+            "valu_floor_insts_per_wave": phases.get("valu_floor_insts_per_wave") if phases else None,
+            "phases": [{"phase": p["phase"], "insts": p["valu_insts_per_wave"], "floor": p["floor"]}
+                       for p in phases["phases"]] if phases else None,
         },
     }
 

@@ -38,6 +38,8 @@ MEM_HOST = 0
 MEM_DEVICE = 1
 
 # every symbol include/flacenc_hip.h declares
+ABI_VERSION = 4  # FLACENC_HIP_ABI_VERSION of include/flacenc_hip.h
+DEBUG_SYMBOLS = ("flacenc_hip_debug_set_stamps", "flacenc_hip_debug_set_fixed_keys")
 EXPORTED_SYMBOLS = (
     "flacenc_hip_abi_version",
     "flacenc_hip_device_count",
@@ -74,8 +76,6 @@ EXPORTED_SYMBOLS = (
     "flacenc_hip_encode_pack_stereo_frames_async",
     "flacenc_hip_encode_pack_frames_async",
     "flacenc_hip_synchronize",
-    "flacenc_hip_debug_set_stamps",
-    "flacenc_hip_debug_set_fixed_keys",
     "flacenc_sigen_fill_frames",
     "flacenc_sigen_fill_frames_strided",
 )
@@ -204,6 +204,9 @@ def load() -> C.CDLL:
     L = C.CDLL(LIB_PATH)
     vp, i32p, u8p, f64p = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p
     L.flacenc_hip_abi_version.restype = C.c_int
+    # (the config structs are passed by value inside others: a library of another ABI revision reads them shifted)
+    if L.flacenc_hip_abi_version() != ABI_VERSION:
+        raise RuntimeError("%s has ABI %d, this binding is written for %d" % (LIB_PATH, L.flacenc_hip_abi_version(), ABI_VERSION))
     L.flacenc_hip_device_count.restype = C.c_int
     L.flacenc_hip_create.argtypes = [C.POINTER(vp), C.c_int]
     L.flacenc_hip_create.restype = C.c_int
@@ -217,10 +220,11 @@ def load() -> C.CDLL:
     L.flacenc_hip_window_weights.restype = C.c_int
     L.flacenc_hip_synchronize.argtypes = [vp]
     L.flacenc_hip_synchronize.restype = C.c_int
-    L.flacenc_hip_debug_set_stamps.argtypes = [vp, vp]
-    L.flacenc_hip_debug_set_stamps.restype = C.c_int
-    L.flacenc_hip_debug_set_fixed_keys.argtypes = [vp, vp]
-    L.flacenc_hip_debug_set_fixed_keys.restype = C.c_int
+    # test / profiling hooks (csrc/flacenc_hip_debug.h): present in builds with -DFLACENC_HIP_DEBUG_HOOKS only
+    for name in DEBUG_SYMBOLS:
+        if hasattr(L, name):
+            getattr(L, name).argtypes = [vp, vp]
+            getattr(L, name).restype = C.c_int
     batch_args = [vp, C.POINTER(QlpcConfig), i32p, C.c_size_t, C.c_uint32, C.c_size_t, u8p, vp, i32p,
                   C.c_size_t, f64p, f64p]
     L.flacenc_hip_qlpc_batch.argtypes = batch_args + [C.c_int]

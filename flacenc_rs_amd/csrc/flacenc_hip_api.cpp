@@ -20,6 +20,7 @@
 
 #include "direct_mse.h"
 #include "flacenc_hip.h"
+#include "flacenc_hip_debug.h"
 #include "frame_decide.h"
 #include "frame_pack.h"
 #include "qlpc_kernel.h"
@@ -735,6 +736,7 @@ int flacenc_hip_window_weights(const flacenc_hip_qlpc_config* cfg, uint32_t bloc
   return FLACENC_HIP_OK;
 }
 
+#ifdef FLACENC_HIP_DEBUG_HOOKS  // (flacenc_hip_debug.h: not part of the public ABI)
 int flacenc_hip_debug_set_fixed_keys(flacenc_hip_handle* h, unsigned long long* device_keys) {
   if (!h) return FLACENC_HIP_ERR_BAD_ARGUMENT;
   h->fixed_keys = device_keys;
@@ -746,6 +748,7 @@ int flacenc_hip_debug_set_stamps(flacenc_hip_handle* h, unsigned long long* devi
   h->stamps = device_stamps;
   return FLACENC_HIP_OK;
 }
+#endif
 
 int flacenc_hip_fixed_lpc_batch_async(flacenc_hip_handle* h, const flacenc_hip_frame_config* cfg,
                                       const int32_t* samples, size_t n_units, uint32_t block_size,

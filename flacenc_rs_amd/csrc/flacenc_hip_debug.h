@@ -1,0 +1,27 @@
+/* flacenc_hip_debug.h -- test and profiling hooks of libflacenc_hip.so.  NOT part of the drop-in boundary
+ * (include/flacenc_hip.h): they exist only in builds made with -DFLACENC_HIP_DEBUG_HOOKS (the Makefile's default,
+ * `make DEBUG_HOOKS=0` leaves them out), for tests/ and tools/. */
+#ifndef FLACENC_HIP_DEBUG_H_
+#define FLACENC_HIP_DEBUG_H_
+
+#include "flacenc_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Test hook (no reference counterpart): when `device_keys` is non-NULL, launches with use_fixed
+ * store the order selector's key for each tried fixed order (estimate_entropy + bps*order, or
+ * the BitCount bits; src/coding.rs:249, :271) at device_keys[subframe*8 + order]. */
+int flacenc_hip_debug_set_fixed_keys(flacenc_hip_handle* h, unsigned long long* device_keys);
+
+/* Profiling hook (no reference counterpart): when `device_stamps` is non-NULL every
+ * following launch makes each workgroup leader store 8 shader-clock timestamps
+ * (phase boundaries of the fused kernel) at device_stamps[subframe*8 + phase].
+ * Pass NULL to switch it off again.  See tools/phase_profile.py. */
+int flacenc_hip_debug_set_stamps(flacenc_hip_handle* h, unsigned long long* device_stamps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLACENC_HIP_DEBUG_H_ */

@@ -466,6 +466,10 @@ struct Stream {  // datatype.rs:65
 class HipContext {
  public:
   explicit HipContext(int device_id = 0) {
+    // (flacenc_hip_qlpc_config is embedded by value in the frame config: a library of another ABI revision would read
+    // every field behind it shifted)
+    if (flacenc_hip_abi_version() != FLACENC_HIP_ABI_VERSION)
+      throw error::EncodeError(error::EncodeError::Device, "libflacenc_hip.so has another ABI revision than include/flacenc_hip.h");
     const int rc = flacenc_hip_create(&h_, device_id);
     if (rc != FLACENC_HIP_OK)
       throw error::EncodeError(error::EncodeError::Device, "flacenc_hip_create failed (no usable GPU)");

@@ -528,17 +528,6 @@ int flacenc_hip_set_host_threads(flacenc_hip_handle* h, int threads);
 
 int flacenc_hip_synchronize(flacenc_hip_handle* h);
 
-/* Test hook (no reference counterpart): when `device_keys` is non-NULL, launches with use_fixed
- * store the order selector's key for each tried fixed order (estimate_entropy + bps*order, or
- * the BitCount bits; src/coding.rs:249, :271) at device_keys[subframe*8 + order]. */
-int flacenc_hip_debug_set_fixed_keys(flacenc_hip_handle* h, unsigned long long* device_keys);
-
-/* Profiling hook (no reference counterpart): when `device_stamps` is non-NULL every
- * following launch makes each workgroup leader store 8 shader-clock timestamps
- * (phase boundaries of the fused kernel) at device_stamps[subframe*8 + phase].
- * Pass NULL to switch it off again.  See tools/phase_profile.py. */
-int flacenc_hip_debug_set_stamps(flacenc_hip_handle* h, unsigned long long* device_stamps);
-
 #ifdef __cplusplus
 }
 #endif

@@ -119,7 +119,11 @@ pub struct Handle {
     _private: [u8; 0],
 }
 
+/// `FLACENC_HIP_ABI_VERSION` of `include/flacenc_hip.h` this binding was written against.
+pub const ABI_VERSION: c_int = 4;
+
 extern "C" {
+    pub fn flacenc_hip_abi_version() -> c_int;
     pub fn flacenc_hip_create(out: *mut *mut Handle, device_id: c_int) -> c_int;
     pub fn flacenc_hip_destroy(h: *mut Handle);
     pub fn flacenc_hip_last_error(h: *const Handle) -> *const c_char;
@@ -191,6 +195,10 @@ pub struct Gpu(*mut Handle);
 
 impl Gpu {
     pub fn new(device_id: i32) -> Result<Self, EncodeError> {
+        // (QlpcConfig is embedded by value in FrameConfig: a library of another revision would read it shifted)
+        if unsafe { flacenc_hip_abi_version() } != ABI_VERSION {
+            return Err(EncodeError::Config(VerifyError::new("gpu", "libflacenc_hip.so has another ABI revision")));
+        }
         let mut h = std::ptr::null_mut();
         match unsafe { flacenc_hip_create(&mut h, device_id) } {
             OK => Ok(Self(h)),
@@ -205,7 +213,25 @@ impl Drop for Gpu {
     }
 }
 
+/// Which of the crate's builds the floating-point sums reproduce bit for bit (the C++ mirror's
+/// `HipContext::SumOrder`).  `Canonical` -- the kernels' own order -- is the default there and here: it is the fastest
+/// (no second pass over the samples in front of the fused kernel) and a valid encoding of the same configuration;
+/// `CrateBuild` asks for the bytes of the build this file is compiled into (stable: `FLAG_REFERENCE_SUM_ORDER`,
+/// about a quarter of the throughput on 4096-sample blocks; `simd-nightly`: `FLAG_NIGHTLY_SUM_ORDER` up to order 15).
+/// Blocks of 8192 / 16384 samples at orders from 16 sum in the stable build's order either way.
+#[derive(Clone, Copy, PartialEq, Eq)]
+pub enum SumOrder {
+    Canonical,
+    CrateBuild,
+}
+
+/// `mae_optimization_steps` above 64 (`FLACENC_HIP_MAX_MAE_STEPS`) is refused with `BAD_CONFIG`: the reference's
+/// experimental build takes any value.
 fn abi_config(c: &config::SubFrameCoding) -> QlpcConfig {
+    abi_config_with(c, SumOrder::Canonical)
+}
+
+fn abi_config_with(c: &config::SubFrameCoding, order: SumOrder) -> QlpcConfig {
     let (window_type, tukey_alpha) = match c.qlpc.window {
         config::Window::Rectangle => (0, 0.0),
         config::Window::Tukey { alpha } => (1, alpha),
@@ -216,7 +242,9 @@ fn abi_config(c: &config::SubFrameCoding) -> QlpcConfig {
         window_type,
         tukey_alpha,
         max_rice_parameter: c.prc.max_parameter as u32,
-        flags: if cfg!(feature = "simd-nightly") && c.qlpc.lpc_order <= 15 {
+        flags: if order == SumOrder::Canonical {
+            0
+        } else if cfg!(feature = "simd-nightly") && c.qlpc.lpc_order <= 15 {
             FLAG_NIGHTLY_SUM_ORDER
         } else if cfg!(feature = "simd-nightly") {
             0 // (the nightly split above order 15 depends on the allocator: canonical order, a valid encoding)

@@ -1,11 +1,11 @@
 #!/bin/bash
 # Dynamic instruction counts per phase of the headline kernel: diagnostic builds that end the program after
 # phase k (ab/libflacenc_exit<k>.so, -DFLACENC_EXIT_AFTER=k) under rocprofv3 --pmc; differences = per-phase cost.
-R=$PWD; OUT=$R/gpurun_out/$1; mkdir -p $OUT; cd /tmp && export TMPDIR=/tmp
+R=$PWD; OUT=$R/gpurun_out/$1; mkdir -p $OUT; rm -f $OUT/summary.txt; cd /tmp && export TMPDIR=/tmp
 for lib in ab/libflacenc_exit0.so ab/libflacenc_exit1.so ab/libflacenc_exit2.so ab/libflacenc_exit3.so flacenc_rs_amd/libflacenc_hip.so; do
   tag=$(basename $lib .so)
   FLACENC_HIP_LIB=$R/$lib rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY --output-format csv -d $OUT/$tag -- python3 $R/tools/launch_headline.py > $OUT/$tag.log 2>&1
-  python3 - $OUT/$tag $tag <<'PY'
+  python3 - $OUT/$tag $tag <<'PY' | tee -a $OUT/summary.txt
 import csv,glob,sys,collections
 agg=collections.defaultdict(list)
 for f in glob.glob(sys.argv[1]+'/*/*counter_collection.csv'):

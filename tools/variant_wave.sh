@@ -1,14 +1,14 @@
 #!/bin/bash
-# tools/variant_wave.sh NAME MAXP VARIANT [extra -D flags]: an A/B library flacenc_rs_amd/variants/libflacenc_hip_NAME.so
+# tools/variant_wave.sh NAME MAXP VARIANT [extra -D flags]: an A/B library ab/libflacenc_hip_NAME.so
 # that differs from the current build only in one wave-kernel instance compiled with extra flags
 # (the other objects come from flacenc_rs_amd/csrc/build; run `make` there first).
 set -e
 NAME=$1; MP=$2; ST=$3; shift 3
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 C=$ROOT/flacenc_rs_amd/csrc
-mkdir -p $ROOT/flacenc_rs_amd/variants /tmp/variant_$NAME
+mkdir -p $ROOT/ab /tmp/variant_$NAME
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -I$ROOT/include -I$C \
   -DFLACENC_MAXP=$MP -DFLACENC_STEREO=$ST "$@" -c $C/qlpc_wave_inst.hip -o /tmp/variant_$NAME/w.o 2>&1 | grep -v warning || true
 OBJS=$(ls $C/build/*.o | grep -v "/qlpc_wave_inst_${MP}_${ST}.o")
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS /tmp/variant_$NAME/w.o -o $ROOT/flacenc_rs_amd/variants/libflacenc_hip_$NAME.so
-echo flacenc_rs_amd/variants/libflacenc_hip_$NAME.so
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS /tmp/variant_$NAME/w.o -o $ROOT/ab/libflacenc_hip_$NAME.so
+echo ab/libflacenc_hip_$NAME.so

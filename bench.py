@@ -619,8 +619,26 @@ def secondary(torch, _capi, handle, args, dev):
         sec[label] = {"frames": bf, "block_size": bn, "ms_per_launch": stats(ms),
                       "Msamples_per_s": round(bf * 2 * bn / (med * 1e-3) / 1e6, 1),
                       "fp64_fma_frac": round(25 * bf * 4 * bn / (med * 1e-3) / 39.3e12, 4),
-                      "what": "flacenc_hip_stereo_qlpc_batch: 4 candidates per frame, 25 f64 fma + 24 64-bit MACs per "
-                              "analysed sample; fp64_fma_frac = the fma alone against the 78.6 TFLOP/s FP64 vector peak"}
+                      "what": "flacenc_hip_stereo_qlpc_batch: 4 candidates per frame, 25 f64 fma per analysed sample (the "
+                              "stable build's chains on v_mfma_f64_4x4x4: the unflagged order on these shapes) + compute_error on "
+                              "v_mfma_i32_16x16x64_i8; fp64_fma_frac = the fma alone against the 78.6 TFLOP/s FP64 vector peak"}
+        if bn == 16384:
+            # BASELINE configs[4] as written: "experimental config ... block 16384, order 32" = use_direct_mse
+            # (src/lpc.rs:853-903, coding.rs:337-347) on 24-bit blocks of 16384 samples, with and without IRLS
+            xf = bf // 4
+            for xlabel, xorder, mae in (("config5_direct_mse_16384x24bit_order24", 24, 0),
+                                        ("config5_direct_mse_16384x24bit_order32", 32, 0),
+                                        ("config5_direct_mse_irls2_16384x24bit_order24", 24, 2)):
+                xcfg = _capi.make_config(lpc_order=xorder, window="rectangle", use_direct_mse=True, mae_optimization_steps=mae,
+                                         flags=_capi.FLAG_ALLOW_ORDER_32 if xorder > 24 else 0)
+                ms = timed(lambda: handle.stereo_qlpc_batch_device(xcfg, big.data_ptr(), xf, bn, bn, 24, bparams.data_ptr(),
+                                                                   bres.data_ptr(), bn, stream=stream.cuda_stream))
+                med = float(np.median(ms))
+                sec[xlabel] = {"frames": xf, "block_size": bn, "ms_per_launch": stats(ms),
+                               "Msamples_per_s": round(xf * 2 * bn / (med * 1e-3) / 1e6, 1),
+                               "what": "flacenc_hip_stereo_qlpc_batch with use_direct_mse at order %d%s, Rectangle window "
+                                       "(report/experimental.config.toml); 4 candidates per frame" %
+                                       (xorder, ", 2 IRLS steps" if mae else "")}
         if bn == 8192:
             # the same shape in the stable build's own summation order (lane-per-subframe autocorrelation chains in
             # front of the Levinson batch and the residual kernel)

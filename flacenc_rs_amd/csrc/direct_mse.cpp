@@ -104,10 +104,12 @@ __device__ __forceinline__ float dev_powf_pos(float x, float y) {
 
 constexpr int kErrChunk = 1024;
 
-// LDS: xw[n4] f32 | w[n4] f32 (IRLS only) | echunk[kErrChunk] f32 (IRLS only) | gram[32*32] f64 | m[32*32] f64 |
+// LDS: xw[n4] f32 | w[n4] f32 (IRLS only; WG: in HBM scratch instead -- blocks above 16384 samples, whose two f32 arrays
+//      do not fit 160 KB) | echunk[kErrChunk] f32 (IRLS only) | gram[32*32] f64 | m[32*32] f64 |
 //      corr[33] f64 | v[32] f64 | coefs[32] f64 | best[32] f64 | misc
-template <bool STEREO, bool IRLS>
+template <bool STEREO, bool IRLS, bool WG = false>
 __global__ void __launch_bounds__(576) direct_mse_kernel(DirectMseArgs a) {
+  static_assert(!WG || IRLS, "only the IRLS weights ever leave the LDS");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63;
   const int n = (int)a.block_size;
@@ -115,8 +117,8 @@ __global__ void __launch_bounds__(576) direct_mse_kernel(DirectMseArgs a) {
   const uint32_t sf = blockIdx.x;
   const int n4 = (n + 3) & ~3;
   float* const xw = reinterpret_cast<float*>(smem_raw);
-  float* const wgt = xw + n4;
-  float* const echunk = wgt + (IRLS ? n4 : 0);
+  float* const wgt = WG ? a.weight_scratch + (size_t)blockIdx.x * n4 : xw + n4;
+  float* const echunk = xw + n4 + ((IRLS && !WG) ? n4 : 0);
   double* const gram = reinterpret_cast<double*>(echunk + (IRLS ? kErrChunk : 0));  // column-major P x P
   double* const gram_ = gram;
   double* const m_ = gram + 32 * 32;
@@ -335,8 +337,15 @@ __global__ void __launch_bounds__(576) direct_mse_kernel(DirectMseArgs a) {
         const int t = base + o;
         float e = 0.0f;  // raw_errors[t] for t < order: never written, 0
         if (t >= P) {
-          e = (float)(int32_t)(0u - (uint32_t)sample(t));
-          for (int j = 0; j < P; ++j) e = __builtin_fmaf((float)coefs[j], (float)sample(t - 1 - j), e);
+          if (wtab == nullptr) {
+            // the rectangular window (the reference's experimental configuration): x_w IS (f32)s -- the taps come
+            // from LDS instead of P + 1 (stereo: twice that) loads from HBM per error
+            e = -xw[t];
+            for (int j = 0; j < P; ++j) e = __builtin_fmaf((float)coefs[j], xw[t - 1 - j], e);
+          } else {
+            e = (float)(int32_t)(0u - (uint32_t)sample(t));
+            for (int j = 0; j < P; ++j) e = __builtin_fmaf((float)coefs[j], (float)sample(t - 1 - j), e);
+          }
           float x = __builtin_fabsf(e);
           x = x > 1.0f ? x : 1.0f;
           x = x / normalizer;
@@ -347,9 +356,22 @@ __global__ void __launch_bounds__(576) direct_mse_kernel(DirectMseArgs a) {
       }
       __syncthreads();
       if (tid == 0) {
+        // (Iterator::sum is one sequential chain: sixteen values per trip come as four 16-byte reads, the additions
+        // stay in order)
         float sacc = fmisc[0];
         const int cnt = n - base < kErrChunk ? n - base : kErrChunk;
-        for (int o = 0; o < cnt; ++o) sacc += echunk[o];
+        int o = 0;
+        for (; o + 16 <= cnt; o += 16) {
+          const float4 q0 = *reinterpret_cast<const float4*>(&echunk[o]);
+          const float4 q1 = *reinterpret_cast<const float4*>(&echunk[o + 4]);
+          const float4 q2 = *reinterpret_cast<const float4*>(&echunk[o + 8]);
+          const float4 q3 = *reinterpret_cast<const float4*>(&echunk[o + 12]);
+          sacc += q0.x; sacc += q0.y; sacc += q0.z; sacc += q0.w;
+          sacc += q1.x; sacc += q1.y; sacc += q1.z; sacc += q1.w;
+          sacc += q2.x; sacc += q2.y; sacc += q2.z; sacc += q2.w;
+          sacc += q3.x; sacc += q3.y; sacc += q3.z; sacc += q3.w;
+        }
+        for (; o < cnt; ++o) sacc += echunk[o];
         fmisc[0] = sacc;
       }
     }
@@ -416,7 +438,7 @@ __global__ void __launch_bounds__(576) direct_mse_kernel(DirectMseArgs a) {
 size_t direct_mse_lds_bytes(uint32_t block_size, bool irls) {
   const size_t n4 = ((size_t)block_size + 3) & ~(size_t)3;
   size_t b = n4 * 4;
-  if (irls) b += n4 * 4 + kErrChunk * 4;
+  if (irls) b += (block_size > 16384u ? 0 : n4 * 4) + kErrChunk * 4;  // (above 16384 the weights live in HBM scratch)
   b += (32 * 32 * 2 + 33 + 32 * 3) * 8 + 64;
   return (b + 15) & ~(size_t)15;
 }
@@ -431,17 +453,19 @@ hipError_t launch_direct_mse(const DirectMseArgs& a, hipStream_t stream) {
   const uint32_t P = a.lpc_order;
   const uint32_t nc = (P + 1) + P * (P + 1) / 2;
   const uint32_t threads = ((nc < 64 ? 64 : nc) + 63u) & ~63u;  // <= 576
-  static DynamicLdsOptIn opt[4];
-#define FLACENC_DM_LAUNCH(ST, IR, SLOT)                                                                       \
+  static DynamicLdsOptIn opt[6];
+#define FLACENC_DM_LAUNCH(ST, IR, SLOT, WGT)                                                                       \
   {                                                                                                           \
-    auto kern = direct_mse_kernel<ST, IR>;                                                                    \
+    auto kern = direct_mse_kernel<ST, IR, WGT>;                                                                    \
     if (hipError_t e = opt[SLOT].ensure(reinterpret_cast<const void*>(kern), smem); e != hipSuccess) return e; \
     hipLaunchKernelGGL(kern, dim3(a.n_subframes), dim3(threads), smem, stream, a);                            \
   }
+  const bool wg = irls && a.block_size > 16384u;
+  if (wg && a.weight_scratch == nullptr) return hipErrorInvalidValue;
   if (a.stereo) {
-    if (irls) FLACENC_DM_LAUNCH(true, true, 0) else FLACENC_DM_LAUNCH(true, false, 1)
+    if (wg) FLACENC_DM_LAUNCH(true, true, 4, true) else if (irls) FLACENC_DM_LAUNCH(true, true, 0, false) else FLACENC_DM_LAUNCH(true, false, 1, false)
   } else {
-    if (irls) FLACENC_DM_LAUNCH(false, true, 2) else FLACENC_DM_LAUNCH(false, false, 3)
+    if (wg) FLACENC_DM_LAUNCH(false, true, 5, true) else if (irls) FLACENC_DM_LAUNCH(false, true, 2, false) else FLACENC_DM_LAUNCH(false, false, 3, false)
   }
 #undef FLACENC_DM_LAUNCH
   return hipGetLastError();

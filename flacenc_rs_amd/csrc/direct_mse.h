@@ -22,11 +22,13 @@ struct DirectMseArgs {
   int32_t* pred_out;       // device, [n][36]: qc[32], order, shift, status, 0 (as levinson_batch_kernel writes it)
   double* autocorr;        // device, nullable, [n][33]: R[0..=P] (of the chosen IRLS step)
   double* lpc_coefs;       // device, nullable, [n][32]: the unquantised solution
+  float* weight_scratch;   // device, [n][(block_size + 3) & ~3] floats: the IRLS weights of blocks above 16384 samples (else unused)
 };
 
 size_t direct_mse_lds_bytes(uint32_t block_size, bool irls);
 // perform_qlpc's experimental branches (src/coding.rs:337-347) for a batch, one workgroup per subframe;
-// hipErrorNotSupported when the block does not fit the LDS (IRLS: two f32 arrays of the block).
+// hipErrorNotSupported when the block does not fit the LDS (never for block_size <= 32767: above 16384 samples the IRLS
+// weights go to `weight_scratch`).
 hipError_t launch_direct_mse(const DirectMseArgs& args, hipStream_t stream);
 
 }  // namespace flacenc_hip

@@ -129,6 +129,7 @@ hipError_t launch_qlpc(const QlpcKernelArgs& a, const QlpcLaunchPlan& plan, hipS
     d.pred_out = pred;
     d.autocorr = a.autocorr;
     d.lpc_coefs = a.lpc_coefs;
+    d.weight_scratch = a.irls_weight_scratch;
     hipError_t err = launch_direct_mse(d, stream);
     if (err != hipSuccess) return err;
     QlpcKernelArgs s3 = a;

@@ -120,7 +120,7 @@ typedef struct flacenc_hip_handle flacenc_hip_handle;
  * The reference's stable `Verify` rejects both switches outside its `experimental` feature (config.rs:302-326);
  * this ABI follows the experimental build.  Its linear solver is nalgebra's (not part of the reference tree):
  * results equal the oracle's restatement of nalgebra 0.32's published algorithm bit for bit, which is as far
- * as this estimator can be pinned.  IRLS needs block_size <= 16384. */
+ * as this estimator can be pinned.  mae_optimization_steps is limited to FLACENC_HIP_MAX_MAE_STEPS. */
 typedef struct flacenc_hip_qlpc_config {
   uint32_t lpc_order;          /* 1..=24 (..=32 with ALLOW_ORDER_32) */
   uint32_t quant_precision;    /* 1..=15 */

@@ -167,10 +167,10 @@ def test_the_reference_s_qualitative_checks_hold_on_the_gpu(handle):
 
 
 def test_config_limits(handle):
-    x = batch(1, 32767, 16, 1)
-    with pytest.raises(_capi.FlacencHipError) as e:   # IRLS keeps the block and its weights in LDS
-        handle.qlpc_batch(x, 16, gcfg(8, 2))
-    assert e.value.code == _capi.ERR_UNSUPPORTED
+    x = batch(2, 32767, 16, 1)
+    # lpc_with_irls_mae takes any block up to 32767 samples (src/constant.rs:57): above 16384 the weights leave the LDS
+    exact(handle, x, 16, 8, 2, window="rectangle")
+    exact(handle, x[:, :20000], 16, 12, 1, window=("tukey", 0.3))
     exact(handle, x, 16, 8, window="rectangle")       # without IRLS the largest block fits
     with pytest.raises(_capi.FlacencHipError) as e:
         handle.qlpc_batch(x[:, :4096], 16, gcfg(8, 65))

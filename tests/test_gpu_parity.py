@@ -1019,7 +1019,7 @@ def test_frame_pipeline_config_fuzz(handle, seed):
     names its configuration."""
     rng = np.random.default_rng(9000 + seed)
     for trial in range(5):
-        n = int(rng.choice([4096, 4096, 4096, 1152, 4608, 256, 2048]))
+        n = int(rng.choice([4096, 4096, 4096, 1152, 4608, 256, 2048, 8192, 16384]))  # (8192 / 16384: the big-block frame pipeline, round 4)
         bps = int(rng.choice([8, 12, 16, 16, 20, 24]))
         order = int(rng.choice([1, 2, 4, 6, 8, 8, 10, 12, 12, 16, 24]))
         qcfg = dict(lpc_order=order, quant_precision=int(rng.integers(2, 16)),

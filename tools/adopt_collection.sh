@@ -10,6 +10,7 @@ cp $P/kernel_stats.csv profiles/${R}_kernel_stats.csv
 cp $P/kernel_stats_timed.csv profiles/${R}_kernel_stats_timed.csv
 cp $P/pmc_summary.json profiles/${R}_pmc_summary.json
 cp $P/headline_pmc.json profiles/headline_pmc.json
+[ -s $C/headline_phases.json ] && cp $C/headline_phases.json profiles/headline_phases.json
 cp $S/bench_pack.json profiles/${R}_stages_bench_pack.json
 cp $S/kernel_stats.csv profiles/${R}_stages_kernel_stats.csv
 cp $C/configs.json profiles/${R}_configs.json

@@ -68,6 +68,8 @@ def parse_args(argv=None):
                     help="what the multi-GPU exchange moves besides the frames' byte lengths: the 752-B "
                          "decision records = the encoded SubFrame components (default), the packed frame "
                          "bytes too (payload), or nothing (lengths)")
+    ap.add_argument("--no-stream-priority", action="store_true",
+                    help="exchange runs: leave the analysis on a normal-priority stream (A/B of the priority's effect)")
     ap.add_argument("--force-exchange", action="store_true",
                     help="run the multi-GPU exchange step even with one rank; for measuring its cost")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
@@ -243,9 +245,14 @@ def run(args, world):
     frame_len2 = [torch.zeros(F, dtype=torch.int32, device=dev) for _ in range(2)]
     residual = torch.empty((F * 2, n), dtype=torch.int32, device=dev)     # the two chosen channels
     handle = _capi.Handle(local_rank)
+    exchanging = world > 1 or args.force_exchange
+    if exchanging and not args.no_stream_priority:
+        # the analysis runs on a high-priority stream: the exchange's small kernels (length derivation, wire packing,
+        # the collective's copies, the prefix sum) then take the slots the VALU-bound analysis kernel leaves instead
+        # of competing for them (without priorities the forced exchange at one rank cost 12 %)
+        torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=-1))
     stream = torch.cuda.current_stream()
     comm = torch.cuda.Stream(device=dev)
-    exchanging = world > 1 or args.force_exchange
     payload = exchanging and args.gather == "payload"
     if payload:
         out_stride = handle.frame_bytes_bound(n, bps)

@@ -151,11 +151,13 @@ hipError_t launch_qlpc(const QlpcKernelArgs& a, const QlpcLaunchPlan& plan, hipS
 #undef FLACENC_HIP_DM3
     return hipErrorInvalidValue;
   }
-  // Blocks of 8192 / 16384 samples at orders from 16: the unflagged order IS the reference's stable one -- its chains on
-  // the f64 matrix cores cost what the chunk tree's fma cost there (BASELINE configs[2] / [4]), so those shapes emit
+  // Blocks of 4096 / 8192 / 16384 samples at orders from 16: the unflagged order IS the reference's stable one -- its
+  // chains on the f64 matrix cores cost no more than the chunk tree's fma there (BASELINE configs[2] / [4]; 4096-sample
+  // blocks: 344 against 404 us per 50 M samples at order 24), so those shapes emit
   // the stable build's bytes by default (the oracle's orc_default_order_is_stable states the same rule)
   // (a function of the shape alone: unaligned rows or FLACENC_HIP_FLAG_GENERIC_KERNEL change the kernels, not the sums)
-  const bool stable_by_default = a.reference_order == 0u && !a.direct_mse && (a.block_size == 8192u || a.block_size == 16384u) &&
+  const bool stable_by_default = a.reference_order == 0u && !a.direct_mse &&
+                                 (a.block_size == 4096u || a.block_size == 8192u || a.block_size == 16384u) &&
                                  a.lpc_order >= 16u && a.split_scratch != nullptr;
   if ((a.reference_order || stable_by_default) && a.fixed_mode == 0 && a.lpc_stage == 0 && a.acorr_in == nullptr) {
     // Reference summation order: R[] by the lane-per-subframe kernel, then the usual pipeline from

@@ -135,12 +135,12 @@ static double orc_tree_sum(const double* v, size_t lo, size_t hi, size_t count) 
   return orc_tree_sum(v, lo, mid, count) + orc_tree_sum(v, mid, hi, count);
 }
 
-/* Where the build's UNFLAGGED order is the reference's own: on blocks of 8192 / 16384 samples at LPC orders from
+/* Where the build's UNFLAGGED order is the reference's own: on blocks of 4096 / 8192 / 16384 samples at LPC orders from
  * 16 the product sums as weighted_auto_correlation_nosimd does (src/lpc.rs:533-548: one sequential fma chain per
- * lag; on the GPU, v_mfma_f64_4x4x4 chains) -- there the stable build's order costs what the chunk tree costs, so
+ * lag; on the GPU, v_mfma_f64_4x4x4 chains) -- there the stable build's order costs no more than the chunk tree, so
  * ORC_ACORR_CANONICAL, "what the product computes without a summation-order flag", is ORC_ACORR_REFERENCE. */
 int orc_default_order_is_stable(size_t n, size_t lpc_order) {
-  return (n == 8192 || n == 16384) && lpc_order >= 16;
+  return (n == 4096 || n == 8192 || n == 16384) && lpc_order >= 16;
 }
 
 void orc_auto_correlation_canonical_f64(size_t order, const float* signal, size_t n,

@@ -218,7 +218,7 @@ impl Drop for Gpu {
 /// (no second pass over the samples in front of the fused kernel) and a valid encoding of the same configuration;
 /// `CrateBuild` asks for the bytes of the build this file is compiled into (stable: `FLAG_REFERENCE_SUM_ORDER`,
 /// about a quarter of the throughput on 4096-sample blocks; `simd-nightly`: `FLAG_NIGHTLY_SUM_ORDER` up to order 15).
-/// Blocks of 8192 / 16384 samples at orders from 16 sum in the stable build's order either way.
+/// Blocks of 4096 / 8192 / 16384 samples at orders from 16 sum in the stable build's order either way.
 #[derive(Clone, Copy, PartialEq, Eq)]
 pub enum SumOrder {
     Canonical,

@@ -130,9 +130,9 @@ def test_reference_summation_order(handle, n, order):
 
 
 @pytest.mark.parametrize("n,order,stereo", [(8192, 24, True), (8192, 32, True), (16384, 24, True), (16384, 32, True),
-                                            (8192, 16, False), (16384, 20, False)])
+                                            (8192, 16, False), (16384, 20, False), (4096, 24, True), (4096, 16, False)])
 def test_config3_config5_unflagged_order_is_the_references(handle, n, order, stereo):
-    """BASELINE configs[2] / [4] (8192 / 16384 samples, 24-bit, orders from 16): with flags = 0 the product sums as the
+    """BASELINE configs[2] / [4] (8192 / 16384 samples -- and 4096 --, 24-bit, orders from 16): with flags = 0 the product sums as the
     reference's stable build does (weighted_auto_correlation_nosimd, src/lpc.rs:533-548) -- R[], the unquantised and
     the quantised coefficients, residuals and Rice partitions are bit-equal to the oracle's ACORR_REFERENCE mode."""
     x = batch(4 if stereo else 5, n, 24, 1234 + n + order)
@@ -164,9 +164,9 @@ def test_config3_config5_unflagged_order_is_the_references(handle, n, order, ste
     assert not np.array_equal(tree.view(np.uint64), oR[:, : order + 1].view(np.uint64))
 
 
-@pytest.mark.parametrize("n,order", [(8192, 15), (16384, 12), (4096, 24)])
+@pytest.mark.parametrize("n,order", [(8192, 15), (16384, 12), (4096, 15), (4608, 24), (2048, 24)])
 def test_shapes_next_to_them_keep_the_chunk_tree(handle, n, order):
-    """... and only there: order 15 on those blocks and order 24 on 4096-sample blocks still sum in the chunk tree."""
+    """... and only there: order 15 on those blocks and order 24 on other block sizes still sum in the chunk tree."""
     x = batch(4, n, 24, 99 + n + order)
     gp, gres, gR, gA = handle.qlpc_batch(x, 24, _capi.make_config(lpc_order=order), want_fp=True)
     _, _, cR, _ = orc.qlpc_batch(x, 24, orc.make_config(lpc_order=order, acorr=orc.ACORR_CANONICAL))

@@ -121,8 +121,9 @@ __global__ void __launch_bounds__(576) direct_mse_kernel(DirectMseArgs a) {
   float* const echunk = xw + n4 + ((IRLS && !WG) ? n4 : 0);
   double* const gram = reinterpret_cast<double*>(echunk + (IRLS ? kErrChunk : 0));  // column-major P x P
   double* const gram_ = gram;
-  double* const m_ = gram + 32 * 32;
-  double* const corr = m_ + 32 * 32;
+  const int PP = (P * P + 1) & ~1;  // (the two P x P matrices are sized by the order: 2 waves per SIMD at order 8)
+  double* const m_ = gram + PP;
+  double* const corr = m_ + PP;
   double* const v_ = corr + 33;
   double* const coefs = v_ + 32;
   double* const best = coefs + 32;
@@ -151,7 +152,43 @@ __global__ void __launch_bounds__(576) direct_mse_kernel(DirectMseArgs a) {
   };
   // x_w = (f32)s * w, one f32 rounding (lpc.rs:751-754); IRLS: weights start at 1 (lpc.rs:821-822)
   int32_t my_maxabs = 0;
-  for (int t = tid; t < n; t += nthr) {
+  // 16-byte pieces, four in flight per thread (a thread that fetched one sample per trip spent 64 dependent round
+  // trips to HBM on a 4096-sample block: two thirds of the kernel at order 8)
+  const bool vec_ok = ((reinterpret_cast<uintptr_t>(a.samples) & 15) == 0) && ((a.stride & 3) == 0);
+  const int nq = vec_ok ? (n >> 2) : 0;  // whole quads
+  auto stage4 = [&](int q, const int4 va, const int4 vb) {
+    int4 v = va;
+    if (STEREO && kind == 2) v = make_int4((va.x + vb.x) >> 1, (va.y + vb.y) >> 1, (va.z + vb.z) >> 1, (va.w + vb.w) >> 1);
+    if (STEREO && kind == 3) v = make_int4(va.x - vb.x, va.y - vb.y, va.z - vb.z, va.w - vb.w);  // coding.rs:483
+    float4 w4 = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+    if (wtab) w4 = *reinterpret_cast<const float4*>(wtab + 4 * q);  // (the table starts 16-byte aligned behind its 32 pad floats)
+    *reinterpret_cast<float4*>(xw + 4 * q) = make_float4((float)v.x * w4.x, (float)v.y * w4.y, (float)v.z * w4.z, (float)v.w * w4.w);
+    if (IRLS) {
+      *reinterpret_cast<float4*>(wgt + 4 * q) = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+      const int32_t sv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int32_t ab = sv[u] < 0 ? (int32_t)(0u - (uint32_t)sv[u]) : sv[u];  // i32::abs (wrapping)
+        my_maxabs = ab > my_maxabs ? ab : my_maxabs;
+      }
+    }
+  };
+  for (int q0 = tid; q0 < nq; q0 += 4 * nthr) {
+    int4 va[4], vb[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int q = q0 + u * nthr;
+      va[u] = vb[u] = make_int4(0, 0, 0, 0);
+      if (q < nq) {
+        va[u] = *reinterpret_cast<const int4*>(rowA + 4 * q);
+        if (STEREO && kind >= 2) vb[u] = *reinterpret_cast<const int4*>(rowB + 4 * q);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (q0 + u * nthr < nq) stage4(q0 + u * nthr, va[u], vb[u]);
+  }
+  for (int t = 4 * nq + tid; t < n; t += nthr) {  // unaligned rows, and the last samples of a ragged block
     const int32_t s = sample(t);
     xw[t] = (float)s * (wtab ? wtab[t] : 1.0f);
     if (IRLS) {
@@ -194,7 +231,98 @@ __global__ void __launch_bounds__(576) direct_mse_kernel(DirectMseArgs a) {
   const int steps = IRLS ? (int)a.mae_steps : 0;
   for (int it = 0; it <= steps; ++it) {
     // ---- chains ----
-    if (n >= P + 1) {
+    if (n >= P + 1 && P <= 11) {
+      // Orders up to 11: H is at most 12 x 12 = 3 x 3 blocks of 4 x 4, and v_mfma_f64_4x4x4_4b_f64 carries four such
+      // blocks per instruction (lane 16 k + 4 b + i: A_b[i][k], + j: B_b[k][j]; D_b[i][j] in lane 16 i + 4 b + j; chained
+      // through C it is the sequential chain, tools/microbench/mfma_f64_4x4x4_probe.hip).  Needed: column block 0 and
+      // the upper triangle -- four blocks up to order 7 (one instruction per four time steps, 16 cycles where the
+      // 16 x 16 tile takes 64), eight up to order 11 (two).
+      if (wave == 0) {
+        const int len = n - P;
+        const int NB = (P + 1 + 3) >> 2;  // 1..3
+        const int kq = lane >> 4, bs = (lane >> 2) & 3, r = lane & 3;
+        // block (I, J) of instruction q, slot bs
+        auto blk = [&](int q, int slot, int& I, int& J) {
+          if (NB <= 2) {  // (0,0) (0,1) (1,1) (1,0)
+            I = slot == 2 || slot == 3 ? 1 : 0;
+            J = slot == 1 || slot == 2 ? 1 : 0;
+          } else if (q == 0) {  // (0,0) (0,1) (0,2) (1,1)
+            I = slot == 3 ? 1 : 0;
+            J = slot == 3 ? 1 : slot;
+          } else {  // (1,2) (2,2) (1,0) (2,0)
+            I = slot == 0 || slot == 2 ? 1 : 2;
+            J = slot < 2 ? 2 : 0;
+          }
+        };
+        const int NI = NB <= 2 ? 1 : 2;
+        int I0, J0, I1 = 0, J1 = 0;
+        blk(0, bs, I0, J0);
+        if (NI > 1) blk(1, bs, I1, J1);
+        auto rowcol = [&](int I, int J, const float*& pa_, const float*& pb_) {
+          int arow = 4 * I + r, bcol = 4 * J + r;
+          arow = arow > P ? P : arow;
+          bcol = bcol > P ? P : bcol;
+          pa_ = xw + (P - arow) + kq;
+          pb_ = xw + (P - bcol) + kq;
+        };
+        const float *pa0, *pb0, *pa1, *pb1;
+        rowcol(I0, J0, pa0, pb0);
+        rowcol(I1, J1, pa1, pb1);
+        const float* __restrict__ pw = wgt + P + kq;
+        double acc0 = 0.0, acc1 = 0.0;
+        int k = 0;
+        // Eight steps per trip of an inner loop with a constant count: their LDS reads are issued together -- one wave
+        // per workgroup and two per SIMD cannot hide an LDS round trip per step.  (Left to `#pragma unroll` the loop
+        // stayed rolled: 47 % of the wave's cycles in s_waitcnt, 160 us per subframe for 15 us of matrix-core time.)
+        auto step = [&](int kk) __attribute__((always_inline)) {
+          float b0 = pb0[kk], b1 = NI > 1 ? pb1[kk] : 0.0f;
+          if (IRLS) {
+            const float wk = pw[kk];
+            b0 = wk * b0;
+            b1 = wk * b1;
+          }
+          acc0 = __builtin_amdgcn_mfma_f64_4x4x4f64((double)pa0[kk], (double)b0, acc0, 0, 0, 0);
+          if (NI > 1) acc1 = __builtin_amdgcn_mfma_f64_4x4x4f64((double)pa1[kk], (double)b1, acc1, 0, 0, 0);
+        };
+        if (NI > 1) {
+          for (; k + 32 <= len; k += 32) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) step(k + 4 * u);
+          }
+        } else {
+          for (; k + 32 <= len; k += 32) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) step(k + 4 * u);
+          }
+        }
+        for (; k + 4 <= len; k += 4) step(k);
+        if (k < len) {  // the last one to three steps: the missing ones multiply by 0 (x + 0 * y == x)
+          const bool in = k + kq < len;
+          const float a0 = in ? pa0[k] : 0.0f, a1 = in ? pa1[k] : 0.0f;
+          float b0 = in ? pb0[k] : 0.0f, b1 = in ? pb1[k] : 0.0f;
+          if (IRLS && in) {
+            const float wk = pw[k];
+            b0 = wk * b0;
+            b1 = wk * b1;
+          }
+          acc0 = __builtin_amdgcn_mfma_f64_4x4x4f64((double)a0, (double)b0, acc0, 0, 0, 0);
+          if (NI > 1) acc1 = __builtin_amdgcn_mfma_f64_4x4x4f64((double)a1, (double)b1, acc1, 0, 0, 0);
+        }
+        // D_b[i][j] sits in lane 16 i + 4 b + j
+        const int oi = lane >> 4, oj = lane & 3;
+        auto put = [&](int I, int J, double v) {
+          const int ra = 4 * I + oi, cb = 4 * J + oj;
+          if (cb == 0 && ra <= P) {
+            corr[ra] = v;
+          } else if (ra >= 1 && ra <= cb && cb <= P) {
+            gram[(ra - 1) + (cb - 1) * P] = v;
+            gram[(cb - 1) + (ra - 1) * P] = v;
+          }
+        };
+        put(I0, J0, acc0);
+        if (NI > 1) put(I1, J1, acc1);
+      }
+    } else if (n >= P + 1) {
       const int len = n - P;  // t' = P - 1 .. n - 2
       for (int tile = wave; tile < NT * NT; tile += nwaves) {  // (wave-uniform)
         const int I = tile / NT, J = tile - I * NT;
@@ -208,13 +336,17 @@ __global__ void __launch_bounds__(576) direct_mse_kernel(DirectMseArgs a) {
         const float* __restrict__ pw = wgt + P + kq;          // w[t' + 1]
         v4d_t acc = {0.0, 0.0, 0.0, 0.0};
         int k = 0;
-#pragma unroll 4
-        for (; k + 4 <= len; k += 4) {
-          const float av = pa[k];
-          float bv = pb[k];
-          if (IRLS) bv = pw[k] * bv;
+        auto tstep = [&](int kk) __attribute__((always_inline)) {
+          const float av = pa[kk];
+          float bv = pb[kk];
+          if (IRLS) bv = pw[kk] * bv;
           acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)av, (double)bv, acc, 0, 0, 0);
+        };
+        for (; k + 32 <= len; k += 32) {  // (eight steps' LDS reads in flight: see the block form above)
+#pragma unroll
+          for (int u = 0; u < 8; ++u) tstep(k + 4 * u);
         }
+        for (; k + 4 <= len; k += 4) tstep(k);
         if (k < len) {  // the last one to three steps: the missing ones multiply by 0 (x + 0 * y == x)
           const bool in = k + kq < len;
           const float av = in ? pa[k] : 0.0f;
@@ -435,11 +567,12 @@ __global__ void __launch_bounds__(576) direct_mse_kernel(DirectMseArgs a) {
 
 }  // namespace
 
-size_t direct_mse_lds_bytes(uint32_t block_size, bool irls) {
+size_t direct_mse_lds_bytes(uint32_t block_size, bool irls, uint32_t order) {
   const size_t n4 = ((size_t)block_size + 3) & ~(size_t)3;
   size_t b = n4 * 4;
   if (irls) b += (block_size > 16384u ? 0 : n4 * 4) + kErrChunk * 4;  // (above 16384 the weights live in HBM scratch)
-  b += (32 * 32 * 2 + 33 + 32 * 3) * 8 + 64;
+  const size_t pp = ((size_t)order * order + 1) & ~(size_t)1;
+  b += (pp * 2 + 33 + 32 * 3) * 8 + 64;
   return (b + 15) & ~(size_t)15;
 }
 
@@ -448,7 +581,7 @@ hipError_t launch_direct_mse(const DirectMseArgs& a, hipStream_t stream) {
   if (a.lpc_order < 1 || a.lpc_order > 32) return hipErrorInvalidValue;
   if (a.stereo && (a.n_subframes & 3u)) return hipErrorInvalidValue;
   const bool irls = a.mae_steps > 0;
-  const size_t smem = direct_mse_lds_bytes(a.block_size, irls);
+  const size_t smem = direct_mse_lds_bytes(a.block_size, irls, a.lpc_order);
   if (smem > 160 * 1024) return hipErrorNotSupported;
   const uint32_t P = a.lpc_order;
   const uint32_t nc = (P + 1) + P * (P + 1) / 2;

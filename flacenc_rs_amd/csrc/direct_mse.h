@@ -25,7 +25,7 @@ struct DirectMseArgs {
   float* weight_scratch;   // device, [n][(block_size + 3) & ~3] floats: the IRLS weights of blocks above 16384 samples (else unused)
 };
 
-size_t direct_mse_lds_bytes(uint32_t block_size, bool irls);
+size_t direct_mse_lds_bytes(uint32_t block_size, bool irls, uint32_t order);
 // perform_qlpc's experimental branches (src/coding.rs:337-347) for a batch, one workgroup per subframe;
 // hipErrorNotSupported when the block does not fit the LDS (never for block_size <= 32767: above 16384 samples the IRLS
 // weights go to `weight_scratch`).

@@ -375,7 +375,7 @@ int enqueue(flacenc_hip_handle* h, const flacenc_hip_qlpc_config* cfg, const int
   a.split_scratch = nullptr;
   a.direct_mse = cfg->use_direct_mse ? 1u : 0u;
   a.mae_steps = cfg->use_direct_mse ? cfg->mae_optimization_steps : 0u;  // (ignored without it, coding.rs:337-347)
-  if (a.direct_mse && flacenc_hip::direct_mse_lds_bytes(block_size, a.mae_steps > 0) > 160 * 1024) {
+  if (a.direct_mse && flacenc_hip::direct_mse_lds_bytes(block_size, a.mae_steps > 0, cfg->lpc_order) > 160 * 1024) {
     h->last_error = "use_direct_mse: the block does not fit the LDS";  // (not for any block up to 32767 samples)
     return FLACENC_HIP_ERR_UNSUPPORTED;
   }

@@ -309,7 +309,11 @@ typedef struct flacenc_hip_stereo_frame_result {
 /* Precondition (the reference checks it in FrameBuf::verify_samples, src/source.rs:262-275, before the path
  * is reached): every sample lies in [-2^(bits_per_sample-1), 2^(bits_per_sample-1)).  The frame entry points
  * do not re-check it; out-of-range samples give frames whose warm-up / Verbatim fields are truncated to
- * bits_per_sample bits. */
+ * bits_per_sample bits.  The same precondition holds for every entry point that takes a width (`bps` /
+ * `bits_per_sample`, 8..25 bits with the side channel): the fixed-LPC order selector's per-lane sums (v_sad_u32 on
+ * biased values) are exact for such samples only, and out-of-width input may select a different fixed order on
+ * power-of-two blocks than on ragged ones.  The big-block residual kernel checks each row's extremes against its
+ * declared width (its byte planes carry no more) and sends an out-of-width subframe to the generic kernel instead. */
 int flacenc_hip_encode_stereo_frames(flacenc_hip_handle* h, const flacenc_hip_frame_config* cfg,
                                      const int32_t* frames, size_t n_frames, uint32_t block_size,
                                      size_t stride, uint32_t bits_per_sample,

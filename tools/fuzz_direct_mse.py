@@ -25,7 +25,7 @@ for seed in range(lo, hi):
     bps = int(rng.choice([8, 12, 16, 16, 20, 24]))
     order = int(rng.choice([1, 2, 4, 8, 8, 10, 12, 16, 24, 32]))
     order = min(order, 32, n - 1)
-    steps = int(rng.choice([0, 0, 0, 1, 2, 3])) if n <= 16384 else 0
+    steps = int(rng.choice([0, 0, 0, 1, 2, 3]))  # (blocks above 16384 samples: the IRLS weights live in HBM scratch, round 4)
     qcfg = dict(lpc_order=order, quant_precision=int(rng.integers(4, 16)),
                 window=("rectangle" if rng.random() < 0.6 else ("tukey", float(np.round(rng.random(), 2)))),
                 max_rice_parameter=int(rng.choice([7, 14, 15, 30, 30])))

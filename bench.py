@@ -257,6 +257,7 @@ def run(args, world):
     if payload:
         out_stride = handle.frame_bytes_bound(n, bps)
         packed2 = [torch.empty((F, out_stride), dtype=torch.uint8, device=dev) for _ in range(2)]
+    wire2 = [torch.empty((F, shard.wire_record_bytes(n)), dtype=torch.uint8, device=dev) for _ in range(2)] if exchanging else None
     consumed = [None, None]  # event: the exchange that read buffer b has finished
     step_no = [0]
     last_exchange = {}
@@ -264,14 +265,23 @@ def run(args, world):
     def exchange(b):
         # the multi-GPU exchange step (ParSink's ordered gather): byte lengths -> stream order ->
         # stream offsets, then the encoded components themselves in stream order
-        if not payload:
+        # two kernels of the C library + the collectives: records -> wire form + byte lengths in one pass, and the
+        # stream offsets straight from the lengths as the all-gather delivers them (rank-major)
+        wire = None
+        if args.gather in ("records", "payload"):
+            wire, _ = shard.records_to_wire_device(handle, results2[b], n, bps, SAMPLE_RATE, rank, world,
+                                                   stream=comm.cuda_stream, wire=wire2[b],
+                                                   lengths=None if payload else frame_len2[b])
+        elif not payload:
             handle.stereo_frame_lengths_device(results2[b].data_ptr(), F, n, bps, SAMPLE_RATE, rank, world,
                                                frame_len2[b].data_ptr(), stream=comm.cuda_stream)
-        lengths_all = shard.all_gather_frame_lengths(frame_len2[b], world * F)
-        offsets, total = shard.stream_offsets(lengths_all)
+        gathered = shard.all_gather_rank_major(frame_len2[b], world * F)
+        lengths_all, offsets, total = shard.stream_offsets_device(handle, gathered, world * F, world,
+                                                                  stream=comm.cuda_stream)
         last_exchange.update(lengths_all=lengths_all, offsets=offsets, total=total)
-        if args.gather in ("records", "payload"):
-            last_exchange["records_all"] = shard.all_gather_frame_records(results2[b], world * F, n)
+        if wire is not None:
+            last_exchange["records_all"] = shard.GatheredRecords(
+                shard.all_gather_records(wire, world * F, materialize=False), world * F, n)
         if payload:
             # (run capacity = the packer's bound: no host synchronisation on the exchange stream)
             last_exchange["stream_bytes"] = shard.all_gather_frame_bytes(

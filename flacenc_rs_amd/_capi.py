@@ -61,6 +61,9 @@ EXPORTED_SYMBOLS = (
     "flacenc_hip_pack_stereo_frames_async",
     "flacenc_hip_stereo_frame_lengths_async",
     "flacenc_hip_place_frames_async",
+    "flacenc_hip_frame_wire_bytes",
+    "flacenc_hip_stereo_frame_wire_async",
+    "flacenc_hip_stream_offsets_async",
     "flacenc_hip_encode_pcm_stereo",
     "flacenc_hip_encode_pcm",
     "flacenc_hip_host_alloc",
@@ -254,6 +257,13 @@ def load() -> C.CDLL:
     L.flacenc_hip_stereo_frame_lengths_async.restype = C.c_int
     L.flacenc_hip_place_frames_async.argtypes = [vp, vp, vp, vp, C.c_size_t, vp, vp, vp]
     L.flacenc_hip_place_frames_async.restype = C.c_int
+    L.flacenc_hip_frame_wire_bytes.argtypes = [C.c_uint32]
+    L.flacenc_hip_frame_wire_bytes.restype = C.c_size_t
+    L.flacenc_hip_stereo_frame_wire_async.argtypes = [vp, vp, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32,
+                                                       C.c_uint32, C.c_uint32, vp, C.c_size_t, vp, vp]
+    L.flacenc_hip_stereo_frame_wire_async.restype = C.c_int
+    L.flacenc_hip_stream_offsets_async.argtypes = [vp, vp, C.c_size_t, C.c_uint32, C.c_uint64, vp, vp, vp, vp]
+    L.flacenc_hip_stream_offsets_async.restype = C.c_int
     L.flacenc_hip_encode_pcm_stereo.argtypes = [vp, C.POINTER(FrameConfig), vp, C.c_uint64, C.c_uint32, C.c_uint32,
                                                 C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_size_t, vp,
                                                 C.POINTER(C.c_uint64)]
@@ -536,6 +546,28 @@ class Handle:
         rc = self._lib.flacenc_hip_stereo_frame_lengths_async(
             self._h, results_ptr, n_frames, block_size, bits_per_sample, sample_rate, first_frame_number,
             frame_number_step, out_len_ptr, stream or None)
+        self._check(rc)
+
+    def frame_wire_bytes(self, block_size: int) -> int:
+        return int(self._lib.flacenc_hip_frame_wire_bytes(block_size))
+
+    def stereo_frame_wire_device(self, results_ptr: int, n_frames: int, block_size: int, bits_per_sample: int,
+                                 sample_rate: int, first_frame_number: int, frame_number_step: int, wire_ptr: int,
+                                 wire_stride: int, out_len_ptr: int | None, stream: int | None = None):
+        """Decision records -> wire records (+ the frames' byte lengths when out_len_ptr is given), one kernel."""
+        rc = self._lib.flacenc_hip_stereo_frame_wire_async(
+            self._h, results_ptr, n_frames, block_size, bits_per_sample, sample_rate, first_frame_number,
+            frame_number_step, wire_ptr, wire_stride, out_len_ptr or None, stream or None)
+        self._check(rc)
+
+    def stream_offsets_device(self, gathered_lengths_ptr: int, n_frames_total: int, world: int, header_bytes: int,
+                              lengths_stream_ptr: int | None, offsets_ptr: int, total_ptr: int,
+                              stream: int | None = None):
+        """All-gathered lengths (rank-major, uint32) -> stream-order lengths (uint32, optional), offsets and total
+        (uint64), one kernel."""
+        rc = self._lib.flacenc_hip_stream_offsets_async(self._h, gathered_lengths_ptr, n_frames_total, world,
+                                                        header_bytes, lengths_stream_ptr or None, offsets_ptr,
+                                                        total_ptr, stream or None)
         self._check(rc)
 
     def place_frames_device(self, src_ptr: int, src_offsets_ptr: int, lengths_ptr: int, n_frames: int, dst_ptr: int,

@@ -935,6 +935,58 @@ int flacenc_hip_stereo_frame_lengths_async(flacenc_hip_handle* h, const flacenc_
   return FLACENC_HIP_OK;
 }
 
+// 2^finest_partition_order of a block (src/rice.rs:157-165 with a warm-up of at most 64 samples: the bound over all
+// predictor orders): how many of a subframe record's rice_params can be non-zero
+static uint32_t finest_partitions(uint32_t block_size) {
+  uint32_t order = 0, n = block_size;
+  while (order < 8 && n % 2 == 0 && n / 2 >= 64) {
+    n /= 2;
+    ++order;
+  }
+  return 1u << order;
+}
+
+size_t flacenc_hip_frame_wire_bytes(uint32_t block_size) { return 48 + 2 * (96 + static_cast<size_t>(finest_partitions(block_size))); }
+
+int flacenc_hip_stereo_frame_wire_async(flacenc_hip_handle* h, const flacenc_hip_stereo_frame_result* results,
+                                        size_t n_frames, uint32_t block_size, uint32_t bits_per_sample,
+                                        uint32_t sample_rate, uint32_t first_frame_number, uint32_t frame_number_step,
+                                        uint8_t* wire, size_t wire_stride, uint32_t* out_len, void* stream) {
+  if (!h) return FLACENC_HIP_ERR_BAD_ARGUMENT;
+  if (n_frames == 0) return FLACENC_HIP_OK;
+  if (!results || !wire || n_frames > 0x7FFFFFFFull || wire_stride < flacenc_hip_frame_wire_bytes(block_size))
+    return FLACENC_HIP_ERR_BAD_ARGUMENT;
+  const unsigned long long last = static_cast<unsigned long long>(first_frame_number) +
+                                  static_cast<unsigned long long>(n_frames - 1) * frame_number_step;
+  if (last >= (1ull << 31)) {
+    h->last_error = "stereo_frame_wire: frame_number must be below 2^31";
+    return FLACENC_HIP_ERR_BAD_ARGUMENT;
+  }
+  flacenc_hip::FramePackArgs a{};
+  a.results = results;
+  a.n_frames = static_cast<uint32_t>(n_frames);
+  a.first_frame_number = first_frame_number;
+  a.frame_number_step = frame_number_step;
+  a.out_len = out_len;
+  fill_header_specs(a, block_size, sample_rate, bits_per_sample);
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, flacenc_hip::launch_frame_wire(a, finest_partitions(block_size), wire, wire_stride,
+                                            static_cast<hipStream_t>(stream)));
+  return FLACENC_HIP_OK;
+}
+
+int flacenc_hip_stream_offsets_async(flacenc_hip_handle* h, const uint32_t* gathered_lengths, size_t n_frames_total,
+                                     uint32_t world, uint64_t header_bytes, uint32_t* lengths_stream,
+                                     uint64_t* offsets, uint64_t* total, void* stream) {
+  if (!h || world == 0 || !total || n_frames_total > 0x7FFFFFFFull) return FLACENC_HIP_ERR_BAD_ARGUMENT;
+  if (n_frames_total && (!gathered_lengths || !offsets)) return FLACENC_HIP_ERR_BAD_ARGUMENT;
+  const uint32_t n = static_cast<uint32_t>(n_frames_total);
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, flacenc_hip::launch_stream_offsets(gathered_lengths, n, world, (n + world - 1) / world, header_bytes,
+                                                lengths_stream, offsets, total, static_cast<hipStream_t>(stream)));
+  return FLACENC_HIP_OK;
+}
+
 int flacenc_hip_place_frames_async(flacenc_hip_handle* h, const uint8_t* src, const uint64_t* src_offsets,
                                    const uint32_t* lengths, size_t n_frames, uint8_t* dst,
                                    const uint64_t* dst_offsets, void* stream) {

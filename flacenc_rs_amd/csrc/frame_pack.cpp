@@ -650,6 +650,116 @@ hipError_t launch_frame_offsets(const uint32_t* lengths, uint32_t n_frames, size
   return hipGetLastError();
 }
 
+// ---- the ordered gather's two device steps (ParSink, src/par.rs:67-95, across GPUs) --------------------------
+// Wire format of a stereo frame record: its 48 bytes of frame fields and, of each 352-byte subframe record, the
+// 96 fixed bytes + the first `parts` Rice parameters (a block has at most 2^finest_order partitions, rice.rs:157-165;
+// the rest of rice_params[256] is always zero).  One thread moves W bytes; thread 0 of a record also derives the
+// frame's byte length (frame_lengths_kernel's arithmetic), so records -> wire + lengths is one pass over the records.
+template <int W>
+__global__ __launch_bounds__(256) void frame_wire_kernel(FramePackArgs a, uint32_t keep, uint8_t* __restrict__ wire,
+                                                         size_t wire_stride) {
+  const uint32_t units = (48u + 2u * keep) / W;
+  const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+  const uint32_t f = (uint32_t)(t / units), u = (uint32_t)(t % units);
+  if (f >= a.n_frames) return;
+  const uint32_t w = u * W;
+  const uint32_t s = w < 48u + keep ? w : w - keep + 352u;  // second subframe record starts at 48 + 352
+  const uint8_t* src = reinterpret_cast<const uint8_t*>(a.results + f) + s;
+  uint8_t* dst = wire + (size_t)f * wire_stride + w;
+  if (W == 16) *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(src);
+  else if (W == 4) *reinterpret_cast<uint32_t*>(dst) = *reinterpret_cast<const uint32_t*>(src);
+  else *dst = *src;
+  if (u == 0 && a.out_len) {
+    const uint32_t frame_number = a.first_frame_number + f * a.frame_number_step;
+    const uint32_t code_bits = frame_number ? 32u - (uint32_t)__builtin_clz(frame_number) : 0u;
+    const uint32_t utf8_len = code_bits <= 7 ? 1u : 1u + (code_bits - 2u) / 5u;
+    const flacenc_hip_stereo_frame_result* fr = a.results + f;
+    const unsigned long long bits = 8ull * (4u + utf8_len + a.extra_len + 1u) + fr->bits[fr->role[0]] + fr->bits[fr->role[1]];
+    a.out_len[f] = (uint32_t)((bits + 7ull) >> 3) + 2u;
+  }
+}
+
+hipError_t launch_frame_wire(const FramePackArgs& a, uint32_t parts, uint8_t* wire, size_t wire_stride,
+                             hipStream_t stream) {
+  if (a.n_frames == 0) return hipSuccess;
+  const uint32_t keep = 96u + parts;
+  const bool wide = parts % 16u == 0 && wire_stride % 16u == 0 && (reinterpret_cast<uintptr_t>(wire) & 15u) == 0 &&
+                    (reinterpret_cast<uintptr_t>(a.results) & 15u) == 0;
+  const bool mid = parts % 4u == 0 && wire_stride % 4u == 0 && (reinterpret_cast<uintptr_t>(wire) & 3u) == 0;
+  const uint32_t W = wide ? 16u : mid ? 4u : 1u;
+  const uint64_t threads = (uint64_t)a.n_frames * ((48u + 2u * keep) / W);
+  const dim3 grid((uint32_t)((threads + 255) / 256));
+  if (W == 16) hipLaunchKernelGGL(frame_wire_kernel<16>, grid, dim3(256), 0, stream, a, keep, wire, wire_stride);
+  else if (W == 4) hipLaunchKernelGGL(frame_wire_kernel<4>, grid, dim3(256), 0, stream, a, keep, wire, wire_stride);
+  else hipLaunchKernelGGL(frame_wire_kernel<1>, grid, dim3(256), 0, stream, a, keep, wire, wire_stride);
+  return hipGetLastError();
+}
+
+// Stream offsets from the all-gathered frame lengths.  `lengths` is the collective's output as it arrives: rank-major,
+// lengths[r * per_rank + j] = stream frame j * world + r (world 1: plain stream order).  A workgroup owns 4096
+// consecutive stream frames; what precedes them is, per rank, a contiguous run of that rank's row, so every workgroup
+// sums its own prefix with coalesced reads (no scratch, no second launch; the redundant reads are n / 8192 rows of L2
+// traffic per workgroup, ~1 MB at 2 M frames) and scans its tile through the wave scans + one LDS step.
+__global__ __launch_bounds__(1024) void stream_offsets_kernel(const uint32_t* __restrict__ lengths, uint32_t n,
+                                                              uint32_t world, uint32_t per_rank,
+                                                              unsigned long long header,
+                                                              uint32_t* __restrict__ lengths_stream,
+                                                              uint64_t* __restrict__ offsets,
+                                                              uint64_t* __restrict__ total) {
+  __shared__ unsigned long long wave_pre[16], wave_sums[16];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint32_t base = blockIdx.x * 4096u;
+  unsigned long long pre = 0;
+  for (uint32_t r = 0; r < world && r < base; ++r) {
+    uint32_t cnt = (base - r + world - 1u) / world;  // frames j * world + r below base
+    if (cnt > per_rank) cnt = per_rank;
+    const uint32_t* row = lengths + (size_t)r * per_rank;
+    for (uint32_t j = tid; j < cnt; j += 1024u) pre += row[j];
+  }
+  uint32_t v[4];
+  unsigned long long mine = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < 4; ++k) {
+    const uint32_t f = base + 4u * tid + k;
+    v[k] = f < n ? lengths[(size_t)(f % world) * per_rank + f / world] : 0u;
+    mine += v[k];
+  }
+  unsigned long long s = mine;  // inclusive scan inside the wave; `pre` is only reduced
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const unsigned long long o = __shfl_up(s, d, 64);
+    if ((int)lane >= d) s += o;
+    pre += __shfl_xor(pre, d, 64);
+  }
+  if (lane == 63) {
+    wave_sums[wave] = s;
+    wave_pre[wave] = pre;
+  }
+  __syncthreads();
+  unsigned long long before = header;
+  for (uint32_t w = 0; w < 16; ++w) before += wave_pre[w] + (w < wave ? wave_sums[w] : 0ull);
+  unsigned long long off = before + s - mine;
+#pragma unroll
+  for (uint32_t k = 0; k < 4; ++k) {
+    const uint32_t f = base + 4u * tid + k;
+    if (f < n) {
+      offsets[f] = off;
+      if (lengths_stream) lengths_stream[f] = v[k];
+    }
+    off += v[k];
+  }
+  if (tid == 1023u && base + 4096u >= n) total[0] = off;  // the workgroup that holds the last frame (or n = 0)
+}
+
+hipError_t launch_stream_offsets(const uint32_t* lengths, uint32_t n_frames, uint32_t world, uint32_t per_rank,
+                                 uint64_t header_bytes, uint32_t* lengths_stream, uint64_t* offsets, uint64_t* total,
+                                 hipStream_t stream) {
+  const uint32_t grid = n_frames ? (n_frames + 4095u) / 4096u : 1u;
+  hipLaunchKernelGGL(stream_offsets_kernel, dim3(grid), dim3(1024), 0, stream, lengths, n_frames, world, per_rank,
+                     static_cast<unsigned long long>(header_bytes), lengths_stream, offsets, total);
+  return hipGetLastError();
+}
+
 size_t stereo_frame_bytes_bound(uint32_t block_size, uint32_t bits_per_sample) {
   // header <= 4 + 6 (frame number < 2^31) + 2 + 2 + 1, two subframes of at most Verbatim size
   // (encode_subframe never keeps anything larger, coding.rs:413-416), CRC-16

@@ -59,5 +59,14 @@ hipError_t launch_place_frames(const uint8_t* src, const uint64_t* src_offsets, 
 hipError_t launch_frame_offsets(const uint32_t* lengths, uint32_t n_frames, size_t src_stride, uint64_t* src_offsets,
                                 uint64_t* dst_offsets, uint64_t* total, hipStream_t stream);
 
+// records -> wire records (48 + 2 * (96 + parts) bytes each, at wire + f * wire_stride) and, when args.out_len is
+// set, the frames' byte lengths in the same pass; reads what launch_frame_lengths reads
+hipError_t launch_frame_wire(const FramePackArgs& args, uint32_t parts, uint8_t* wire, size_t wire_stride,
+                             hipStream_t stream);
+// exclusive prefix sum over the all-gathered lengths (rank-major [world][per_rank]) in stream order
+hipError_t launch_stream_offsets(const uint32_t* lengths, uint32_t n_frames, uint32_t world, uint32_t per_rank,
+                                 uint64_t header_bytes, uint32_t* lengths_stream, uint64_t* offsets, uint64_t* total,
+                                 hipStream_t stream);
+
 }  // namespace flacenc_hip
 #endif

@@ -1014,7 +1014,7 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
   fx.code_bits = fx.sum_q = fx.sub_bits = 0;
   // the lane's 64 samples + 4 in front of them (zeros in front of the block: the reference's
   // carry starts at 0, coding.rs:188), differenced `ord` times in place; valid from index ord on
-  auto fixed_load = [&](uint32_t (&v)[SPL + 4]) {
+  [[maybe_unused]] auto fixed_load = [&](uint32_t (&v)[SPL + 4]) {
     with_role([&](auto kind) {
 #pragma unroll
       for (int k = 0; k < SPL / 4 + 1; ++k) {

@@ -122,6 +122,59 @@ def all_gather_frame_records(records: torch.Tensor, n_frames_total: int, block_s
     return GatheredRecords(wire, n_frames_total, block_size)
 
 
+def all_gather_rank_major(local: torch.Tensor, n_frames_total: int, group=None) -> torch.Tensor:
+    """The collective alone: [world * ceil(F / G), ...] as all_gather_into_tensor delivers it (row r * per_rank + j =
+    stream frame j * G + r; shorter ranks zero-padded).  flacenc_hip_stream_offsets_async reads this layout."""
+    if not dist.is_available() or not dist.is_initialized():
+        assert local.shape[0] == n_frames_total
+        return local.contiguous()
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    per_rank = (n_frames_total + world - 1) // world
+    n_local = local_frame_count(n_frames_total, rank, world)
+    assert local.shape[0] == n_local, (local.shape, n_local)
+    if n_local < per_rank:
+        pad = torch.zeros((per_rank - n_local,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        local = torch.cat([local, pad], dim=0)
+    gathered = torch.empty((world * per_rank,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(gathered, local.contiguous(), group=group)
+    return gathered
+
+
+def records_to_wire_device(handle, records: torch.Tensor, block_size: int, bits_per_sample: int, sample_rate: int,
+                           first_frame_number: int, frame_number_step: int, stream: int | None = None,
+                           wire: torch.Tensor | None = None, lengths: torch.Tensor | None = None):
+    """records_to_wire + the frames' byte lengths on the GPU, one kernel (flacenc_hip_stereo_frame_wire_async).
+    Returns (wire [F, wire_record_bytes] uint8, lengths [F] int32); both can be passed in to be reused."""
+    assert records.is_cuda and records.dtype == torch.uint8 and records.is_contiguous(), "device records (no host fallback)"
+    n = records.shape[0]
+    wb = wire_record_bytes(block_size)
+    assert handle.frame_wire_bytes(block_size) == wb
+    if wire is None:
+        wire = torch.empty((n, wb), dtype=torch.uint8, device=records.device)
+    if lengths is None:
+        lengths = torch.empty(n, dtype=torch.int32, device=records.device)
+    assert wire.shape == (n, wb) and wire.is_contiguous() and lengths.shape == (n,) and lengths.dtype == torch.int32
+    handle.stereo_frame_wire_device(records.data_ptr(), n, block_size, bits_per_sample, sample_rate, first_frame_number,
+                                    frame_number_step, wire.data_ptr(), wb, lengths.data_ptr(), stream=stream)
+    return wire, lengths
+
+
+def stream_offsets_device(handle, gathered_lengths: torch.Tensor, n_frames_total: int, world: int,
+                          header_bytes: int = 0, stream: int | None = None):
+    """stream_offsets on the GPU straight from all_gather_rank_major's output (int32 lengths): one kernel
+    (flacenc_hip_stream_offsets_async) instead of the re-ordering copy + widening + scan + two elementwise passes.
+    Returns (lengths_all int32 [F] in stream order, offsets int64 [F], total 0-d int64)."""
+    assert gathered_lengths.is_cuda and gathered_lengths.dtype == torch.int32 and gathered_lengths.is_contiguous()
+    dev = gathered_lengths.device
+    lengths_all = torch.empty(n_frames_total, dtype=torch.int32, device=dev)
+    offsets = torch.empty(n_frames_total, dtype=torch.int64, device=dev)
+    total = torch.empty((), dtype=torch.int64, device=dev)
+    handle.stream_offsets_device(gathered_lengths.data_ptr(), n_frames_total, world, header_bytes,
+                                 lengths_all.data_ptr(), offsets.data_ptr(), total.data_ptr(), stream=stream)
+    return lengths_all, offsets, total
+
+
 def all_gather_frame_lengths(local_lengths: torch.Tensor, n_frames_total: int, group=None) -> torch.Tensor:
     """Byte lengths of all frames in stream order, on every rank (ParSink's ordering, src/par.rs:67-95,
     reduced to what it needs).  `local_lengths` is this rank's [n_local_frames] integer tensor."""

@@ -472,6 +472,25 @@ int flacenc_hip_place_frames_async(flacenc_hip_handle* h, const uint8_t* src, co
                                    const uint32_t* lengths, size_t n_frames, uint8_t* dst,
                                    const uint64_t* dst_offsets, void* stream);
 
+/* The ordered gather's two device steps (what ParSink, src/par.rs:67-95, does with a BTreeMap on one host).
+ * flacenc_hip_stereo_frame_wire_async turns this rank's decision records into their wire form -- the 48 bytes of frame
+ * fields and, of each of the two 352-byte subframe records, the 96 fixed bytes + the first 2^finest_order Rice
+ * parameters (src/rice.rs:157-165; the rest of rice_params[256] is always zero): flacenc_hip_frame_wire_bytes(block)
+ * bytes, 368 of 752 for blocks of 4096 -- at wire + f * wire_stride, and in the same pass writes the frames' byte
+ * lengths (flacenc_hip_stereo_frame_lengths_async's values) to out_len when that is not NULL.
+ * flacenc_hip_stream_offsets_async takes the all-gathered lengths as the collective delivers them -- rank-major,
+ * gathered_lengths[r * ceil(n / world) + j] = stream frame j * world + r, shorter ranks zero-padded; world = 1 is
+ * plain stream order -- and writes, in stream order, offsets[f] = header_bytes + sum of the lengths of frames below f,
+ * lengths_stream[f] (optional, NULL to skip) and total[0] = header_bytes + sum of all lengths. */
+size_t flacenc_hip_frame_wire_bytes(uint32_t block_size);
+int flacenc_hip_stereo_frame_wire_async(flacenc_hip_handle* h, const flacenc_hip_stereo_frame_result* results,
+                                        size_t n_frames, uint32_t block_size, uint32_t bits_per_sample,
+                                        uint32_t sample_rate, uint32_t first_frame_number, uint32_t frame_number_step,
+                                        uint8_t* wire, size_t wire_stride, uint32_t* out_len, void* stream);
+int flacenc_hip_stream_offsets_async(flacenc_hip_handle* h, const uint32_t* gathered_lengths, size_t n_frames_total,
+                                     uint32_t world, uint64_t header_bytes, uint32_t* lengths_stream,
+                                     uint64_t* offsets, uint64_t* total, void* stream);
+
 /* ---- input side ------------------------------------------------------- */
 /*
  * FrameBuf::fill_le_bytes (src/source.rs:288-298) for a run of consecutive frames of one stream, on

@@ -387,7 +387,8 @@ int enqueue(flacenc_hip_handle* h, const flacenc_hip_qlpc_config* cfg, const int
   }
   // (R[] and the predictor records between the launches of the split pipelines: orders from 13, and blocks of
   // 8192 / 16384 at any order -- the big-block kernels)
-  if (cfg->lpc_order >= 13 || a.reference_order || a.direct_mse || block_size == 8192 || block_size == 16384) {
+  if (cfg->lpc_order >= 13 || a.reference_order || a.direct_mse || block_size == 8192 || block_size == 16384 ||
+      flacenc_hip::subwave_shape(block_size)) {
     if ((rc = attach_split_scratch(h, a)) != FLACENC_HIP_OK) return rc;
   }
   if (plan.table_scratch_bytes_per_subframe) {

@@ -35,6 +35,23 @@ bool wave_kernel_eligible(const QlpcKernelArgs& a) {
   return true;
 }
 
+bool subwave_shape(uint32_t n) {
+  return n == 512 || n == 1024 || n == 2048 || n == 576 || n == 1152 || n == 2304;
+}
+
+// the plain analysis (records + residual rows, no on-device decision) in the build's canonical summation order
+bool subwave_eligible(const QlpcKernelArgs& a) {
+  if (!subwave_shape(a.block_size) || a.lpc_order > 12 || a.lpc_order == 0) return false;
+  if (a.fixed_mode != 0 || a.direct_mse || a.force_generic || a.lpc_stage != 0 || a.only_marked) return false;
+  if (a.reference_order != 0 || a.acorr_in != nullptr) return false;
+  if (a.frame_results != nullptr || a.chan_results != nullptr || a.pack_out != nullptr) return false;
+  if (a.params == nullptr || a.marked_count == nullptr) return false;
+  if ((reinterpret_cast<uintptr_t>(a.samples) & 15) || (a.stride & 3)) return false;
+  if ((reinterpret_cast<uintptr_t>(a.residual) & 15) || (a.residual_stride & 3)) return false;
+  if (a.stereo && (a.n_subframes & 3)) return false;
+  return a.n_subframes != 0;
+}
+
 QlpcLaunchPlan plan_qlpc_launch(uint32_t block_size, uint32_t lpc_order) {
   QlpcLaunchPlan plan;
   plan.wave = false;
@@ -245,6 +262,28 @@ hipError_t launch_qlpc(const QlpcKernelArgs& a, const QlpcLaunchPlan& plan, hipS
   if (plan.maxp == MP && plan.big == (BG != 0)) return launch_qlpc_##MP##_##BG(s3, plan.threads, plan.smem_bytes, stream);
     FLACENC_HIP_FOR_EACH_INSTANCE(FLACENC_HIP_STAGE3)
 #undef FLACENC_HIP_STAGE3
+    return hipErrorInvalidValue;
+  }
+  if (subwave_eligible(a)) {
+    // several subframes per wave; what it marks (residuals of 2^25 and more, saturated Rice tables) is redone by the
+    // generic kernel's clean-up launch, which returns at once when nothing was marked
+    const int mp = a.lpc_order <= 8 ? 8 : 12;
+    const int st = a.stereo ? 1 : 0;
+    const int spl = (a.block_size % 72u) == 0 ? 72 : 64;
+    hipError_t err = hipErrorInvalidValue;
+#define FLACENC_HIP_SUBCASE(MP, ST, SP) \
+  if (mp == MP && st == ST && spl == SP) err = launch_qlpc_subwave_##MP##_##ST##_##SP(a, stream);
+    FLACENC_HIP_FOR_EACH_SUBWAVE_INSTANCE(FLACENC_HIP_SUBCASE)
+#undef FLACENC_HIP_SUBCASE
+    if (err != hipSuccess) return err;
+    QlpcKernelArgs c = a;
+    c.only_marked = 1;
+    c.autocorr = nullptr;  // (written; the clean-up rewrites records and rows only)
+    c.lpc_coefs = nullptr;
+#define FLACENC_HIP_SUBCLEAN(MP, BG) \
+  if (plan.maxp == MP && plan.big == (BG != 0)) return launch_qlpc_##MP##_##BG(c, plan.threads, plan.smem_bytes, stream);
+    FLACENC_HIP_FOR_EACH_INSTANCE(FLACENC_HIP_SUBCLEAN)
+#undef FLACENC_HIP_SUBCLEAN
     return hipErrorInvalidValue;
   }
   if (wave_kernel_eligible(a)) {

@@ -175,5 +175,15 @@ FLACENC_HIP_FOR_EACH_WAVE72_INSTANCE(FLACENC_HIP_DECLARE_WAVE72_INSTANCE)
   hipError_t launch_bigblock_residual_##K_##_##NLB_(const QlpcKernelArgs&, hipStream_t);
 FLACENC_HIP_FOR_EACH_BIGRES_INSTANCE(FLACENC_HIP_DECLARE_BIGRES_INSTANCE)
 
+// qlpc_subwave_kernel: several subframes per wave for blocks of 8 / 16 / 32 finest Rice partitions (512 / 1024 / 2048,
+// 576 / 1152 / 2304 samples) at orders up to 12; one translation unit per (order bucket, stereo, samples per lane)
+bool subwave_eligible(const QlpcKernelArgs& args);
+bool subwave_shape(uint32_t block_size);
+#define FLACENC_HIP_FOR_EACH_SUBWAVE_INSTANCE(X) \
+  X(8, 0, 64) X(8, 0, 72) X(8, 1, 64) X(8, 1, 72) X(12, 0, 64) X(12, 0, 72) X(12, 1, 64) X(12, 1, 72)
+#define FLACENC_HIP_DECLARE_SUBWAVE_INSTANCE(MP, ST, SP) \
+  hipError_t launch_qlpc_subwave_##MP##_##ST##_##SP(const QlpcKernelArgs&, hipStream_t);
+FLACENC_HIP_FOR_EACH_SUBWAVE_INSTANCE(FLACENC_HIP_DECLARE_SUBWAVE_INSTANCE)
+
 }  // namespace flacenc_hip
 #endif

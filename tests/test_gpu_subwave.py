@@ -1,0 +1,145 @@
+"""The sub-wave kernel (qlpc_subwave_kernel_impl.h): blocks of 8 / 16 / 32 finest Rice partitions -- 512 / 1024 / 2048
+and the CD-style 576 / 1152 / 2304 (rice.rs:157-165) -- several subframes per wave.  Bit-exact against the oracle in
+the canonical summation order and byte-identical to the generic kernel (FLACENC_HIP_FLAG_GENERIC_KERNEL) it replaces
+on these shapes, for plain batches and the L, R, M, S candidates of 2-channel frames (coding.rs:476-491)."""
+import numpy as np
+import pytest
+
+import util
+from flacenc_rs_amd import _capi
+from oracle import oracle as orc
+from test_gpu_parity import batch_sine_noise, full_parity, assert_records_equal
+
+pytestmark = pytest.mark.gpu
+
+SIZES = [512, 1024, 2048, 576, 1152, 2304]
+
+
+@pytest.fixture(scope="module")
+def handle():
+    return _capi.Handle(0)
+
+
+@pytest.mark.parametrize("n", SIZES)
+@pytest.mark.parametrize("order", [1, 4, 8, 9, 12])
+def test_plain_batches(handle, n, order):
+    # subframe counts that leave the last workgroup's segments idle
+    full_parity(handle, batch_sine_noise(37, n, 16, seed0=n + order), 16, order)
+    full_parity(handle, batch_sine_noise(5, n, 24, seed0=n - order), 24, order)
+
+
+@pytest.mark.parametrize("n", SIZES)
+def test_mixed_bits_per_sample_and_parameters(handle, n):
+    x = np.concatenate([batch_sine_noise(9, n, 8, seed0=1), batch_sine_noise(9, n, 16, seed0=2),
+                        batch_sine_noise(9, n, 20, seed0=3)])
+    bps = np.array([8] * 9 + [16] * 9 + [20] * 9, np.uint8)
+    full_parity(handle, x, bps, 10)
+    full_parity(handle, x, bps, 8, precision=12, window=("tukey", 0.1), max_p=14)
+    full_parity(handle, x, bps, 6, precision=7, window="rectangle", max_p=3)
+
+
+def _stereo_against_oracle(handle, frames, bps, order):
+    gp, gres = handle.stereo_qlpc_batch(frames, bps, _capi.make_config(lpc_order=order))
+    pp, pres = handle.stereo_qlpc_batch(frames, bps, _capi.make_config(lpc_order=order, flags=_capi.FLAG_GENERIC_KERNEL))
+    assert gp.tobytes() == pp.tobytes() and np.array_equal(gres, pres)
+    for f in range(frames.shape[0]):
+        m, s = orc.stereo_to_midside(frames[f, 0], frames[f, 1])
+        x = np.stack([frames[f, 0], frames[f, 1], m, s])
+        op, ores, _, _ = orc.qlpc_batch(x, np.array([bps, bps, bps, bps + 1], np.uint8),
+                                        orc.make_config(lpc_order=order, acorr=orc.ACORR_CANONICAL))
+        assert_records_equal(gp[f], op, "frame %d" % f)
+        assert np.array_equal(gres[f], ores)
+    return gp
+
+
+@pytest.mark.parametrize("n", SIZES)
+@pytest.mark.parametrize("order,bps", [(8, 16), (10, 16), (12, 24), (3, 24)])
+def test_stereo_candidates(handle, n, order, bps):
+    nf = 11  # not a multiple of the 2 / 4 / 8 frames of a workgroup
+    frames = _capi.sigen_frames(nf, 2, n, bps, 200.0, 0.4, 0.1, seed=n + order)
+    frames[:, 1] = (frames[:, 1] * 3) // 4 + frames[:, 0] // 8
+    gp = _stereo_against_oracle(handle, frames, bps, order)
+    assert (gp["status"] == 0).all()
+
+
+@pytest.mark.parametrize("n", [576, 1024, 2304])
+def test_finest_rice_order_flag(handle, n):
+    frames = _capi.sigen_frames(5, 2, n, 16, 90.0, 0.5, 0.2, seed=n)
+    gp, gres = handle.stereo_qlpc_batch(frames, 16, _capi.make_config(lpc_order=8, rice_finest_only=True))
+    pp, pres = handle.stereo_qlpc_batch(frames, 16, _capi.make_config(lpc_order=8, rice_finest_only=True,
+                                                                      flags=_capi.FLAG_GENERIC_KERNEL))
+    assert gp.tobytes() == pp.tobytes() and np.array_equal(gres, pres)
+    finest = {576: 3, 1024: 4, 2304: 5}[n]
+    assert (gp["rice_order"] == finest).all()
+
+
+@pytest.mark.parametrize("n", SIZES)
+def test_segments_with_unlike_statistics(handle, n):
+    """Neighbouring segments of a wave share the Rice parameter window: silence, a constant, full-scale noise, a
+    quiet tone and bursts side by side (window bounds are wave-wide, every segment's own search must not notice)."""
+    rng = np.random.default_rng(n)
+    rows = []
+    for k in range(40):
+        kind = k % 8
+        if kind == 0:
+            v = np.zeros(n, np.int64)
+        elif kind == 1:
+            v = np.full(n, 1234, np.int64)
+        elif kind == 2:
+            v = rng.integers(-32768, 32768, n)
+        elif kind == 3:
+            v = np.round(30 * np.sin(np.arange(n) / 9.0)).astype(np.int64)
+        elif kind == 4:
+            v = rng.integers(-3, 4, n)
+            v[rng.integers(0, n, 5)] = 32767
+        elif kind == 5:
+            v = np.round(np.linspace(0, 1, n) ** 3 * 30000 * np.sin(np.arange(n) / 3.0)).astype(np.int64)
+        elif kind == 6:
+            v = np.where(np.arange(n) < n // 2, 0, rng.integers(-20000, 20000, n))
+        else:
+            v = rng.integers(-1, 2, n) * 32767
+        rows.append(v.astype(np.int32))
+    x = np.stack(rows)
+    for max_p in (30, 14, 2):
+        gp, gres, _, _ = handle.qlpc_batch(x, 16, _capi.make_config(lpc_order=8, max_rice_parameter=max_p))
+        pp, pres, _, _ = handle.qlpc_batch(x, 16, _capi.make_config(lpc_order=8, max_rice_parameter=max_p,
+                                                                   flags=_capi.FLAG_GENERIC_KERNEL))
+        assert gp.tobytes() == pp.tobytes() and np.array_equal(gres, pres), max_p
+        cp, cres, _, _ = orc.qlpc_batch(x, 16, orc.make_config(lpc_order=8, max_rice_parameter=max_p,
+                                                               acorr=orc.ACORR_CANONICAL))
+        assert_records_equal(gp, cp, "max_p %d" % max_p)
+        assert np.array_equal(gres, cres)
+
+
+@pytest.mark.parametrize("n", [1152, 2048])
+def test_wide_residuals_take_the_clean_up_launch(handle, n):
+    """Full-scale 24-bit noise: residuals of 2^25 and more do not fit the bit-plane sums -- the kernel marks the
+    subframe and the generic kernel redoes it; neighbours in the same wave keep their own results."""
+    rng = np.random.default_rng(7 * n)
+    quiet = batch_sine_noise(6, n, 16, seed0=5)
+    loud = (rng.integers(0, 2, (6, n)) * 2 - 1).astype(np.int32) * (2 ** 23 - 1)
+    x = np.empty((12, n), np.int32)
+    x[0::2], x[1::2] = quiet, loud
+    bps = np.array([16, 24] * 6, np.uint8)
+    gp, gres, _, _ = handle.qlpc_batch(x, bps, _capi.make_config(lpc_order=8))
+    cp, cres, _, _ = orc.qlpc_batch(x, bps, orc.make_config(lpc_order=8, acorr=orc.ACORR_CANONICAL))
+    assert_records_equal(gp, cp, "with marked subframes")
+    assert np.array_equal(gres, cres)
+
+
+def test_device_entry_point_with_row_strides(handle):
+    """flacenc_hip_stereo_qlpc_batch_async on device buffers whose rows are wider than the block."""
+    import torch
+    n, nf, stride = 1152, 9, 1160
+    frames = _capi.sigen_frames(nf, 2, n, 16, 150.0, 0.4, 0.2, seed=99)
+    x = torch.zeros((nf * 2, stride), dtype=torch.int32, device="cuda")
+    x[:, :n] = torch.from_numpy(frames.reshape(nf * 2, n)).cuda()
+    params = torch.zeros((nf * 4, 352), dtype=torch.uint8, device="cuda")
+    res = torch.zeros((nf * 4, stride), dtype=torch.int32, device="cuda")
+    handle.stereo_qlpc_batch_device(_capi.make_config(lpc_order=8), x.data_ptr(), nf, n, stride, 16, params.data_ptr(),
+                                    res.data_ptr(), stride)
+    torch.cuda.synchronize()
+    want_p, want_r = handle.stereo_qlpc_batch(frames, 16, _capi.make_config(lpc_order=8, flags=_capi.FLAG_GENERIC_KERNEL))
+    assert params.cpu().numpy().tobytes() == want_p.tobytes()
+    assert np.array_equal(res[:, :n].cpu().numpy().reshape(nf, 4, n), want_r)
+    assert int(res[:, n:].abs().max()) == 0

@@ -597,7 +597,8 @@ int enqueue_fixed(flacenc_hip_handle* h, const flacenc_hip_frame_config* cfg, co
   if (cfg->fixed_order_sel == FLACENC_HIP_ORDERSEL_APPROXENT) {
     a.fixed_mode = 1;
     if ((rc = attach_sumabs_scratch(h, a, true)) != FLACENC_HIP_OK) return rc;
-    if (block_size == 4096 || block_size == 8192 || block_size == 16384) {  // the big-block kernels' predictor records
+    if (block_size == 4096 || block_size == 8192 || block_size == 16384 ||  // the big-block kernels' predictor records
+        flacenc_hip::subwave_shape(block_size)) {                            // ... the sub-wave kernel's clean-up counter
       if ((rc = attach_split_scratch(h, a)) != FLACENC_HIP_OK) return rc;
     }
     if (residual_mode == 1u) {  // (the caller checked that this launch takes the big-block kernels)
@@ -1994,6 +1995,61 @@ static int encode_stereo_frames_impl(flacenc_hip_handle* h, const flacenc_hip_fr
       }
       HIP_TRY(h, flacenc_hip::launch_bigblock_residual(m, s));
       return FLACENC_HIP_OK;
+    }
+    // Blocks of 8 / 16 / 32 finest Rice partitions (512 .. 2304 samples): qlpc_subwave_kernel's frame variant does the
+    // whole of encode_frame -- both candidates of the four roles, the decision, the two chosen rows -- several frames
+    // per workgroup.  A frame with a candidate beyond its exact sums (residuals of 2^25 and more) comes back marked
+    // and takes the general path below, whose three kernels return at once when the count of marked frames is 0.
+    if (block_size >= FLACENC_HIP_MIN_BLOCK_SIZE && flacenc_hip::subwave_shape(block_size)) {
+      flacenc_hip::QlpcKernelArgs m = a;
+      m.stamps = nullptr;
+      m.fixed_partitions = cfg->fixed_partitions;
+      if ((rc = attach_split_scratch(h, m)) != FLACENC_HIP_OK) return rc;
+      if (flacenc_hip::subwave_frame_eligible(m)) {
+        if ((rc = ensure(h, h->d_cparams, n_sub * sizeof(flacenc_hip_subframe_params))) != FLACENC_HIP_OK) return rc;
+        if ((rc = ensure(h, h->d_cresid, n_sub * cstride * 4)) != FLACENC_HIP_OK) return rc;
+        m.cand_lpc_params = static_cast<const flacenc_hip_subframe_params*>(h->d_cparams.ptr);
+        if (cfg->use_fixed) {
+          if ((rc = ensure(h, h->d_fparams, n_sub * sizeof(flacenc_hip_subframe_params))) != FLACENC_HIP_OK) return rc;
+          if ((rc = ensure(h, h->d_fresid, n_sub * cstride * 4)) != FLACENC_HIP_OK) return rc;
+          if ((rc = ensure(h, h->d_fkeys, n_sub * 8)) != FLACENC_HIP_OK) return rc;
+          m.cand_fixed_params = static_cast<const flacenc_hip_subframe_params*>(h->d_fparams.ptr);
+        }
+        HIP_TRY(h, flacenc_hip::launch_subwave_frames(m, s));
+        // the marked frames' candidates, by the generic kernel's clean-up launches (status -1 in the scratch records)
+        flacenc_hip::QlpcKernelArgs c = m;
+        c.frame_results = nullptr;
+        c.cand_lpc_params = c.cand_fixed_params = nullptr;
+        c.params = static_cast<flacenc_hip_subframe_params*>(h->d_cparams.ptr);
+        c.residual = static_cast<int32_t*>(h->d_cresid.ptr);
+        c.residual_stride = cstride;
+        c.only_marked = 1;
+        c.use_fixed = 0;
+        c.fixed_keys = nullptr;
+        HIP_TRY(h, flacenc_hip::launch_qlpc(c, flacenc_hip::plan_qlpc_launch(block_size, cfg->qlpc.lpc_order), s));
+        d.lpc_params = c.params;
+        d.lpc_residual = c.residual;
+        if (cfg->use_fixed) {
+          flacenc_hip::QlpcKernelArgs x = c;
+          x.params = static_cast<flacenc_hip_subframe_params*>(h->d_fparams.ptr);
+          x.residual = static_cast<int32_t*>(h->d_fresid.ptr);
+          x.selector_keys = static_cast<unsigned long long*>(h->d_fkeys.ptr);
+          x.window = nullptr;
+          x.flat_lo = x.flat_hi = 0;
+          x.lpc_order = 4;
+          x.precision = 0;
+          x.use_fixed = 1;
+          x.fixed_mode = 1;
+          HIP_TRY(h, flacenc_hip::launch_qlpc(x, flacenc_hip::plan_qlpc_launch(block_size, 4), s));
+          d.fixed_params = x.params;
+          d.fixed_residual = x.residual;
+          d.fixed_keys = x.selector_keys;
+        }
+        d.only_marked = 1;
+        d.marked_count = m.marked_count;
+        HIP_TRY(h, flacenc_hip::launch_frame_decide(d, s));
+        return FLACENC_HIP_OK;
+      }
     }
     if (cfg->use_lpc) {
       if ((rc = ensure(h, h->d_cparams, n_sub * sizeof(flacenc_hip_subframe_params))) != FLACENC_HIP_OK) return rc;

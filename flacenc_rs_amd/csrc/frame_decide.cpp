@@ -20,6 +20,10 @@ __global__ void __launch_bounds__(kThreads) frame_decide_kernel(FrameDecideArgs 
   __shared__ FrameDecision sdec;
   const int tid = threadIdx.x;
   const uint32_t f = blockIdx.x;
+  if (a.only_marked) {  // (workgroup-uniform, in front of every barrier)
+    if (a.marked_count != nullptr && __hip_atomic_load(a.marked_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
+    if (a.results[f].channel_assignment != 0xFF) return;
+  }
   const int n = (int)a.block_size;
   const int32_t* __restrict__ l = a.frames + (size_t)(2u * f) * a.stride;
   const int32_t* __restrict__ r = l + a.stride;

@@ -31,6 +31,10 @@ struct FrameDecideArgs {
   flacenc_hip_stereo_frame_result* results;  // out, [n_frames]
   int32_t* residual;                         // out; output channel c of frame f at (2f + c)*residual_stride
   size_t residual_stride;
+  // clean-up behind qlpc_subwave_kernel's frame variant: only frames it marked (channel_assignment 0xFF), and nothing
+  // at all when the count it left is 0
+  uint32_t only_marked = 0;
+  const uint32_t* marked_count = nullptr;
 };
 
 hipError_t launch_frame_decide(const FrameDecideArgs& args, hipStream_t stream);

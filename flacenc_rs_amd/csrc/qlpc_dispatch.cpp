@@ -39,17 +39,52 @@ bool subwave_shape(uint32_t n) {
   return n == 512 || n == 1024 || n == 2048 || n == 576 || n == 1152 || n == 2304;
 }
 
-// the plain analysis (records + residual rows, no on-device decision) in the build's canonical summation order
-bool subwave_eligible(const QlpcKernelArgs& a) {
-  if (!subwave_shape(a.block_size) || a.lpc_order > 12 || a.lpc_order == 0) return false;
-  if (a.fixed_mode != 0 || a.direct_mse || a.force_generic || a.lpc_stage != 0 || a.only_marked) return false;
-  if (a.reference_order != 0 || a.acorr_in != nullptr) return false;
-  if (a.frame_results != nullptr || a.chan_results != nullptr || a.pack_out != nullptr) return false;
-  if (a.params == nullptr || a.marked_count == nullptr) return false;
+static bool subwave_buffers_ok(const QlpcKernelArgs& a) {
+  if (!subwave_shape(a.block_size) || a.n_subframes == 0 || a.force_generic || a.only_marked || a.direct_mse) return false;
+  if (a.reference_order != 0 || a.acorr_in != nullptr || a.sumabs_in != nullptr || a.lpc_stage != 0) return false;
   if ((reinterpret_cast<uintptr_t>(a.samples) & 15) || (a.stride & 3)) return false;
   if ((reinterpret_cast<uintptr_t>(a.residual) & 15) || (a.residual_stride & 3)) return false;
   if (a.stereo && (a.n_subframes & 3)) return false;
-  return a.n_subframes != 0;
+  return a.marked_count != nullptr && a.pack_out == nullptr;
+}
+
+// the estimator's partitions: a whole number of the selector's sub-sums (an eighth of a lane's samples), and either
+// 1 / 2 / 4 per lane or a power-of-two group of lanes inside the segment
+static bool subwave_fixed_ok(const QlpcKernelArgs& a) {
+  if (a.fixed_order_sel != 1u || a.fixed_max_order > 4u || a.fixed_partitions == 0u) return false;
+  const uint32_t n = a.block_size, spl = (n % 72u) == 0 ? 72u : 64u, parts = a.fixed_partitions;
+  if (n % parts) return false;
+  const uint32_t psz = n / parts;
+  if (psz < spl) return psz * 2 == spl || psz * 4 == spl;
+  const uint32_t lanes = psz / spl;
+  return psz % spl == 0 && (lanes & (lanes - 1)) == 0;
+}
+
+// the plain analysis (records + residual rows, no on-device decision) in the build's canonical summation order
+bool subwave_eligible(const QlpcKernelArgs& a) {
+  if (!subwave_buffers_ok(a) || a.lpc_order > 12 || a.lpc_order == 0 || a.fixed_mode != 0) return false;
+  return a.frame_results == nullptr && a.chan_results == nullptr && a.params != nullptr;
+}
+
+bool subwave_fixed_eligible(const QlpcKernelArgs& a) {
+  if (!subwave_buffers_ok(a) || a.fixed_mode != 1u || !subwave_fixed_ok(a)) return false;
+  return a.frame_results == nullptr && a.chan_results == nullptr && a.params != nullptr;
+}
+
+bool subwave_frame_eligible(const QlpcKernelArgs& a) {
+  if (!subwave_buffers_ok(a) || !a.stereo || a.fixed_mode != 0 || a.frame_results == nullptr) return false;
+  if (!a.use_lpc || a.lpc_order > 12 || a.lpc_order == 0) return false;
+  return !a.use_fixed || subwave_fixed_ok(a);
+}
+
+hipError_t launch_subwave_frames(const QlpcKernelArgs& a, hipStream_t stream) {
+  const int mp = a.lpc_order <= 8 ? 8 : 12;
+  const int spl = (a.block_size % 72u) == 0 ? 72 : 64;
+#define FLACENC_HIP_SUBFRAMES(MP, ST, SP, V) \
+  if (V == 2 && mp == MP && spl == SP) return launch_qlpc_subwave_##MP##_##ST##_##SP##_##V(a, stream);
+  FLACENC_HIP_FOR_EACH_SUBWAVE_INSTANCE(FLACENC_HIP_SUBFRAMES)
+#undef FLACENC_HIP_SUBFRAMES
+  return hipErrorInvalidValue;
 }
 
 QlpcLaunchPlan plan_qlpc_launch(uint32_t block_size, uint32_t lpc_order) {
@@ -264,15 +299,16 @@ hipError_t launch_qlpc(const QlpcKernelArgs& a, const QlpcLaunchPlan& plan, hipS
 #undef FLACENC_HIP_STAGE3
     return hipErrorInvalidValue;
   }
-  if (subwave_eligible(a)) {
+  if (subwave_eligible(a) || subwave_fixed_eligible(a)) {
     // several subframes per wave; what it marks (residuals of 2^25 and more, saturated Rice tables) is redone by the
     // generic kernel's clean-up launch, which returns at once when nothing was marked
-    const int mp = a.lpc_order <= 8 ? 8 : 12;
+    const int var = a.fixed_mode == 1u ? 1 : 0;
+    const int mp = (var == 1 || a.lpc_order <= 8) ? 8 : 12;
     const int st = a.stereo ? 1 : 0;
     const int spl = (a.block_size % 72u) == 0 ? 72 : 64;
     hipError_t err = hipErrorInvalidValue;
-#define FLACENC_HIP_SUBCASE(MP, ST, SP) \
-  if (mp == MP && st == ST && spl == SP) err = launch_qlpc_subwave_##MP##_##ST##_##SP(a, stream);
+#define FLACENC_HIP_SUBCASE(MP, ST, SP, V) \
+  if (mp == MP && st == ST && spl == SP && var == V) err = launch_qlpc_subwave_##MP##_##ST##_##SP##_##V(a, stream);
     FLACENC_HIP_FOR_EACH_SUBWAVE_INSTANCE(FLACENC_HIP_SUBCASE)
 #undef FLACENC_HIP_SUBCASE
     if (err != hipSuccess) return err;
@@ -280,6 +316,7 @@ hipError_t launch_qlpc(const QlpcKernelArgs& a, const QlpcLaunchPlan& plan, hipS
     c.only_marked = 1;
     c.autocorr = nullptr;  // (written; the clean-up rewrites records and rows only)
     c.lpc_coefs = nullptr;
+    c.selector_keys = a.selector_keys;
 #define FLACENC_HIP_SUBCLEAN(MP, BG) \
   if (plan.maxp == MP && plan.big == (BG != 0)) return launch_qlpc_##MP##_##BG(c, plan.threads, plan.smem_bytes, stream);
     FLACENC_HIP_FOR_EACH_INSTANCE(FLACENC_HIP_SUBCLEAN)

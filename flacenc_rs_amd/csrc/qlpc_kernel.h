@@ -176,13 +176,21 @@ FLACENC_HIP_FOR_EACH_WAVE72_INSTANCE(FLACENC_HIP_DECLARE_WAVE72_INSTANCE)
 FLACENC_HIP_FOR_EACH_BIGRES_INSTANCE(FLACENC_HIP_DECLARE_BIGRES_INSTANCE)
 
 // qlpc_subwave_kernel: several subframes per wave for blocks of 8 / 16 / 32 finest Rice partitions (512 / 1024 / 2048,
-// 576 / 1152 / 2304 samples) at orders up to 12; one translation unit per (order bucket, stereo, samples per lane)
-bool subwave_eligible(const QlpcKernelArgs& args);
+// 576 / 1152 / 2304 samples) at orders up to 12; one translation unit per (order bucket, stereo, samples per lane,
+// variant: 0 QLPC candidates, 1 fixed_lpc batch with the ApproxEnt selector, 2 the 2-channel frame decision)
 bool subwave_shape(uint32_t block_size);
-#define FLACENC_HIP_FOR_EACH_SUBWAVE_INSTANCE(X) \
-  X(8, 0, 64) X(8, 0, 72) X(8, 1, 64) X(8, 1, 72) X(12, 0, 64) X(12, 0, 72) X(12, 1, 64) X(12, 1, 72)
-#define FLACENC_HIP_DECLARE_SUBWAVE_INSTANCE(MP, ST, SP) \
-  hipError_t launch_qlpc_subwave_##MP##_##ST##_##SP(const QlpcKernelArgs&, hipStream_t);
+bool subwave_eligible(const QlpcKernelArgs& args);        // variant 0
+bool subwave_fixed_eligible(const QlpcKernelArgs& args);  // variant 1 (args.fixed_mode == 1)
+bool subwave_frame_eligible(const QlpcKernelArgs& args);  // variant 2 (args.frame_results set)
+// variant 2: results + the two chosen rows per frame; frames it could not decide (a candidate beyond the exact sums) are
+// marked -- channel_assignment 0xFF, status -1 in args.cand_lpc_params / cand_fixed_params, args.marked_count -- for the
+// caller's general path
+hipError_t launch_subwave_frames(const QlpcKernelArgs& args, hipStream_t stream);
+#define FLACENC_HIP_FOR_EACH_SUBWAVE_INSTANCE(X)                                                                      \
+  X(8, 0, 64, 0) X(8, 0, 72, 0) X(8, 1, 64, 0) X(8, 1, 72, 0) X(12, 0, 64, 0) X(12, 0, 72, 0) X(12, 1, 64, 0) X(12, 1, 72, 0) \
+  X(8, 0, 64, 1) X(8, 0, 72, 1) X(8, 1, 64, 1) X(8, 1, 72, 1) X(8, 1, 64, 2) X(8, 1, 72, 2) X(12, 1, 64, 2) X(12, 1, 72, 2)
+#define FLACENC_HIP_DECLARE_SUBWAVE_INSTANCE(MP, ST, SP, V) \
+  hipError_t launch_qlpc_subwave_##MP##_##ST##_##SP##_##V(const QlpcKernelArgs&, hipStream_t);
 FLACENC_HIP_FOR_EACH_SUBWAVE_INSTANCE(FLACENC_HIP_DECLARE_SUBWAVE_INSTANCE)
 
 }  // namespace flacenc_hip

@@ -107,8 +107,13 @@ __device__ __forceinline__ double seg_tree_sum_last(double v) {
   return v;
 }
 
-template <int MAXP, bool STEREO, int SPL, int LPS>
+// VARIANT 0: the QLPC candidate of every subframe (records + residual rows); 1: fixed_lpc with the ApproxEnt order
+// selector (coding.rs:298-331) as a batch of its own -- what the generic kernel's fixed_mode 1 produces; 2 (STEREO):
+// encode_frame for 2-channel frames -- both candidates of the four roles, encode_subframe's choice (coding.rs:384-418),
+// try_stereo_coding's assignment (:493-522), one flacenc_hip_stereo_frame_result and the TWO chosen rows per frame.
+template <int MAXP, bool STEREO, int SPL, int LPS, int VARIANT>
 __global__ void __launch_bounds__(STEREO ? 256 : 128, 3) qlpc_subwave_kernel(QlpcKernelArgs a) {
+  static_assert(VARIANT != 2 || STEREO, "the frame decision is the 2-channel one");
   using G = SubGeom<SPL, LPS>;
   constexpr int WAVES = STEREO ? 4 : 2;
   constexpr int THREADS = 64 * WAVES;
@@ -118,31 +123,37 @@ __global__ void __launch_bounds__(STEREO ? 256 : 128, 3) qlpc_subwave_kernel(Qlp
   constexpr int HP = (MAXP + 3) & ~3;
   constexpr int NLAG = MAXP + 1;
   constexpr int n = G::N;
+  constexpr bool LPC = VARIANT != 1;
+  constexpr bool FIXED = VARIANT != 0;
+  constexpr bool DECIDE = VARIANT == 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   int32_t* const sm = reinterpret_cast<int32_t*>(smem_raw);
   float* const wlds = reinterpret_cast<float*>(sm + NIMG * G::Img);
   double* const xr = reinterpret_cast<double*>(sm + (NIMG + 1) * G::Img);  // [SUBS][NLAG]
   int32_t* const xq = reinterpret_cast<int32_t*>(xr + SUBS * NLAG);        // [SUBS][16]
+  // DECIDE: per subframe slot {bits lo, bits hi, kind, dc, status, redo, 0, 0}
+  uint32_t* const xd = reinterpret_cast<uint32_t*>(xq + SUBS * 16);        // [SUBS][8]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = uni(tid >> 6);
   const int sl = lane & (LPS - 1);   // lane inside the segment
   const int sg = lane / LPS;         // segment of the wave
+  const int seg0 = lane & ~(LPS - 1);
   const int P = (int)a.lpc_order;
   const uint32_t blk = blockIdx.x;
 
   // ---- which subframe does this segment own ----
   const int g = STEREO ? (sg * 4 + wave) : (wave * S + sg);  // slot in the exchange areas (STEREO: frame-major, like sf)
-  uint32_t sf;
+  uint32_t sf, frame = 0;
   bool active;
   int img_a, img_b = 0;
   if (STEREO) {
     const uint32_t frames = a.n_subframes >> 2;
-    uint32_t f = blk * (uint32_t)S + (uint32_t)sg;
-    active = f < frames;
-    if (!active) f = frames - 1u;
-    sf = f * 4u + (uint32_t)wave;
+    frame = blk * (uint32_t)S + (uint32_t)sg;
+    active = frame < frames;
+    if (!active) frame = frames - 1u;
+    sf = frame * 4u + (uint32_t)wave;
     img_a = (2 * sg + (wave == 1 ? 1 : 0)) * G::Img;
     img_b = (2 * sg + 1) * G::Img;
   } else {
@@ -155,7 +166,7 @@ __global__ void __launch_bounds__(STEREO ? 256 : 128, 3) qlpc_subwave_kernel(Qlp
 
   // ======================= phase 0: HBM -> LDS ==============================
   for (int i = tid; i < NIMG * G::Seg; i += THREADS) sm[(i / G::Seg) * G::Img + (i % G::Seg)] = 0;
-  {
+  if (LPC) {
     const bool has_window = a.window != nullptr;
     const float* __restrict__ wsrc = a.window + 32;
     for (int i = tid; i < G::Seg; i += THREADS) wlds[i] = 0.0f;
@@ -228,7 +239,7 @@ __global__ void __launch_bounds__(STEREO ? 256 : 128, 3) qlpc_subwave_kernel(Qlp
                                             : (unsigned long long)(a.bps_uniform + ((STEREO && role == 3) ? 1u : 0u));
 
   // ======================= phase 1: window + autocorrelation ==============
-  {
+  if (LPC) {
     double R[NLAG];
     with_role([&](auto kind) {
       double dw[HP + 16];
@@ -304,44 +315,400 @@ __global__ void __launch_bounds__(STEREO ? 256 : 128, 3) qlpc_subwave_kernel(Qlp
         for (int k = NLAG; k < 33; ++k) a.autocorr[(size_t)sf * 33 + k] = 0.0;
       }
     }
-  }
-  __syncthreads();
+    __syncthreads();
 
-  // ======================= phase 2: Levinson + quantisation ================
-  if (wave == 0 && lane < SUBS) {
-    double Rl[NLAG];
+    // ======================= phase 2: Levinson + quantisation ================
+    if (wave == 0 && lane < SUBS) {
+      double Rl[NLAG];
 #pragma unroll
-    for (int k = 0; k < NLAG; ++k) Rl[k] = xr[lane * NLAG + k];
-    double coef[MAXP];
-    int32_t cqv[MAXP];
-    int warm_v, shift_v;
-    const int st = levinson_quantize<MAXP>(Rl, P, (int)a.precision, coef, cqv, &warm_v, &shift_v);
+      for (int k = 0; k < NLAG; ++k) Rl[k] = xr[lane * NLAG + k];
+      double coef[MAXP];
+      int32_t cqv[MAXP];
+      int warm_v, shift_v;
+      const int st = levinson_quantize<MAXP>(Rl, P, (int)a.precision, coef, cqv, &warm_v, &shift_v);
 #pragma unroll
-    for (int i = 0; i < MAXP; ++i) xq[lane * 16 + i] = cqv[i];
-    xq[lane * 16 + 12] = warm_v;
-    xq[lane * 16 + 13] = shift_v;
-    xq[lane * 16 + 14] = st;
-    if (a.lpc_coefs) {
-      // slot -> subframe (STEREO slots are frame-major: slot = 4 frame + role)
-      uint32_t sfl = STEREO ? (blk * (uint32_t)S + (uint32_t)(lane >> 2)) * 4u + (uint32_t)(lane & 3)
-                            : blk * (uint32_t)SUBS + (uint32_t)lane;
-      if (sfl < a.n_subframes) {
+      for (int i = 0; i < MAXP; ++i) xq[lane * 16 + i] = cqv[i];
+      xq[lane * 16 + 12] = warm_v;
+      xq[lane * 16 + 13] = shift_v;
+      xq[lane * 16 + 14] = st;
+      if (a.lpc_coefs) {
+        // slot -> subframe (STEREO slots are frame-major: slot = 4 frame + role)
+        uint32_t sfl = STEREO ? (blk * (uint32_t)S + (uint32_t)(lane >> 2)) * 4u + (uint32_t)(lane & 3)
+                              : blk * (uint32_t)SUBS + (uint32_t)lane;
+        if (sfl < a.n_subframes) {
 #pragma unroll
-        for (int i = 0; i < MAXP; ++i) a.lpc_coefs[(size_t)sfl * 32 + i] = (i < P && st == 0) ? coef[i] : 0.0;
-        for (int i = MAXP; i < 32; ++i) a.lpc_coefs[(size_t)sfl * 32 + i] = 0.0;
+          for (int i = 0; i < MAXP; ++i) a.lpc_coefs[(size_t)sfl * 32 + i] = (i < P && st == 0) ? coef[i] : 0.0;
+          for (int i = MAXP; i < 32; ++i) a.lpc_coefs[(size_t)sfl * 32 + i] = 0.0;
+        }
       }
     }
   }
-  __syncthreads();
+
+  // ---- the Rice search of whatever e[] holds (phase 4) ----
+  int32_t ebuf[SPL + 4];
+  int32_t* const e = ebuf + 4;
+  struct Coded {
+    int bestk;
+    uint32_t best_bits, my_p;
+    unsigned long long sum_q, residual_bits;
+    bool redo;
+  };
+  const bool finest_only = a.rice_finest_only != 0;
+  auto rice_phase = [&](int warm) -> Coded {
+    uint32_t pl[7];
+    {
+      uint32_t pb[5];
+      popcount_planes16(e, pb);
+#pragma unroll
+      for (int k = 0; k < 5; ++k) pl[k] = pb[k];
+      __builtin_amdgcn_sched_barrier(0);
+      popcount_planes16(e + 16, pb);
+      planes_add<5>(pl, pb);
+      __builtin_amdgcn_sched_barrier(0);
+      uint32_t pc[6], pd[5];
+      popcount_planes16(e + 32, pd);
+#pragma unroll
+      for (int k = 0; k < 5; ++k) pc[k] = pd[k];
+      __builtin_amdgcn_sched_barrier(0);
+      popcount_planes16(e + 48, pd);
+      planes_add<5>(pc, pd);
+      planes_add<6>(pl, pc);
+      __builtin_amdgcn_sched_barrier(0);
+      if (SPL == 72) {
+        int32_t t8[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t8[k] = k < 8 ? e[(SPL == 72 ? 64 : 0) + k] : 0;
+        popcount_planes16(t8, pd);
+        uint32_t carry = 0;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+          const uint32_t x_ = pl[k], y_ = k < 5 ? pd[k] : 0u;
+          pl[k] = __builtin_amdgcn_bitop3_b32(x_, y_, carry, 0x96);
+          carry = __builtin_amdgcn_bitop3_b32(x_, y_, carry, 0xE8);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    const uint32_t orw = seg_or<LPS>(pl[0] | pl[1] | pl[2] | pl[3] | pl[4] | pl[5] | pl[6]);
+    const uint32_t maxu = (orw << 1) | (orw >> 31);
+    const PlaneSums ps = make_plane_sums(pl);
+    const uint32_t bitlen = maxu ? (uint32_t)(32 - __builtin_clz(maxu)) : 0u;
+    const uint32_t max_p = a.max_rice_parameter < bitlen ? a.max_rice_parameter : bitlen;  // per segment
+    const uint32_t len0 = (uint32_t)SPL - (sl == 0 ? (uint32_t)warm : 0u);
+    Coded r;
+    // the exact partition sums must fit 32 bits (64 codes below 2^26, 72 below 2^25): otherwise the generic kernel
+    r.redo = maxu >= (1u << (SPL == 64 ? 26 : 25));
+
+    // rice_window (see the wave kernel): per-lane bounds p0 of the partition means; the wave-wide minimum and maximum
+    // bound every group of every segment, and a window wider than a segment's own only adds parameters that provably
+    // lose (entries above the segment's max_p are set to the saturation value)
+    const uint32_t s0 = 2u * ps.sum_m + ps.negs;
+    const uint32_t q0 = (s0 >> 6) + 1u;
+    const uint32_t q0lo = SPL == 64 ? q0 : (s0 >> 7) + 1u;
+    const uint32_t p0min = wave_min_dpp(r.redo ? 31u : 31u - (uint32_t)__builtin_clz(q0lo));
+    const uint32_t maxp_lo = wave_min_dpp(max_p), maxp_hi = wave_max_dpp(max_p);
+    uint32_t p_lo = p0min > 2u ? p0min - 2u : 0u;
+    p_lo = p_lo < maxp_lo ? p_lo : maxp_lo;
+    const uint32_t q0hi = q0 + (sl == 0 ? (s0 >> 8) + 1u : 0u);
+    const uint32_t p0max = wave_max_dpp(r.redo ? 0u : 31u - (uint32_t)__builtin_clz(q0hi));
+    uint32_t p_hi = p0max + 1u;
+    p_hi = p_hi < maxp_hi ? p_hi : maxp_hi;
+    if (p_hi < p_lo) p_hi = p_lo;
+
+    constexpr uint32_t kWMax = kMaxPToBits - 4u;
+    uint32_t pk[G::LOGL + 1];
+#pragma unroll
+    for (int k = 0; k <= G::LOGL; ++k) pk[k] = 0xFFFFFFFFu;
+#pragma unroll 1
+    for (uint32_t p_base = p_lo; p_base <= p_hi; p_base += 4u) {
+      uint32_t Wp[4];
+      rice_build_tables<true, false, SPL>(ps, nullptr, len0, p_base, max_p, lane, warm, Wp);
+#define FLACENC_SUB_RICE_LEVEL(K, SH)                                                         \
+  if (K <= G::LOGL) {                                                                         \
+    if (K > 0) {                                                                              \
+      uint32_t part[4];                                                                       \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) part[j] = from_upper_half<SH>(Wp[j]);     \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                         \
+        const uint32_t v = Wp[j] + part[j];                                                   \
+        Wp[j] = v < kWMax ? v : kWMax;                                                        \
+      }                                                                                       \
+    }                                                                                         \
+    uint32_t packed = pk[K <= G::LOGL ? K : 0];                                               \
+    _Pragma("unroll") for (int j = 0; j + 1 < 4; j += 2) {                                    \
+      const uint32_t c0 = (Wp[j] << 5) | (p_base + (uint32_t)j);                              \
+      const uint32_t c1 = (Wp[j + 1] << 5) | (p_base + (uint32_t)j + 1u);                     \
+      packed = umin3(packed, c0, c1);                                                         \
+    }                                                                                         \
+    pk[K <= G::LOGL ? K : 0] = packed;                                                        \
+  }
+      FLACENC_SUB_RICE_LEVEL(0, 1)
+      if (!finest_only) {
+        FLACENC_SUB_RICE_LEVEL(1, 1)
+        FLACENC_SUB_RICE_LEVEL(2, 2)
+        FLACENC_SUB_RICE_LEVEL(3, 4)
+        FLACENC_SUB_RICE_LEVEL(4, 8)
+        FLACENC_SUB_RICE_LEVEL(5, 16)
+      }
+#undef FLACENC_SUB_RICE_LEVEL
+    }
+    // level totals inside the segment; strict < keeps the finer order on ties (rice.rs:285)
+    r.bestk = 0;
+    r.best_bits = 0;
+    r.my_p = 0;
+    uint32_t sat_any = 0;
+#pragma unroll
+    for (int K = 0; K <= G::LOGL; ++K) {
+      if (K > 0 && finest_only) break;
+      const uint32_t bits = (pk[K] >> 5) + 4u;
+      const bool lead = (sl & ((1 << K) - 1)) == 0;
+      sat_any |= (lead && bits >= kMaxPToBits) ? 1u : 0u;
+      // (a segment's level total is at most 32 minima below 2^27)
+      const uint32_t tot = seg_sum<LPS>(lead ? bits : 0u);
+      if (K == 0 || tot < r.best_bits) {
+        r.best_bits = tot;
+        r.bestk = K;
+        r.my_p = pk[K] & 31u;
+      }
+    }
+    r.redo = r.redo || seg_or<LPS>(sat_any) != 0u;  // a saturated minimum: clamped entries may tie outside the window
+    // Residual::sum_quotients / count_bits (datatype.rs:2325-2331, bitrepr.rs:533-544)
+    const int rice_order = G::LOGL - r.bestk;
+    const uint32_t best_parts = 1u << rice_order;
+    const bool leader = (sl & ((1 << r.bestk) - 1)) == 0;
+    const uint32_t sum_p = seg_sum<LPS>(leader ? r.my_p : 0u);
+    const uint32_t p0 = (uint32_t)__shfl((int)r.my_p, seg0, 64);
+    const uint32_t rice2 = seg_or<LPS>((leader && r.my_p > 14) ? 1u : 0u);
+    const unsigned long long rem_bits = (unsigned long long)sum_p * (unsigned long long)(n >> rice_order) -
+                                        (unsigned long long)warm * p0;
+    r.sum_q = (unsigned long long)r.best_bits - 4ull * best_parts - (unsigned long long)(n - warm) - rem_bits;
+    r.residual_bits = 2ull + 4ull + (unsigned long long)best_parts * (rice2 ? 5ull : 4ull) +
+                      (r.sum_q + (unsigned long long)(n - warm)) + rem_bits;
+    return r;
+  };
+  // one predictor record (all LPS lanes of the segment take part); `c4`: coefs[0..3] of a FixedLpc record
+  auto write_record = [&](flacenc_hip_subframe_params* rec, const Coded& c, int status, int warm, int shift, uint32_t precision,
+                          unsigned long long sub_bits, const int32_t* cq, auto ncq_tag) {
+    constexpr int ncq = decltype(ncq_tag)::value;
+    const int rice_order = G::LOGL - c.bestk;
+    const uint32_t best_parts = 1u << rice_order;
+    {
+      // partition j of the chosen order lives on lane j << bestk of the segment
+      const int srcl = seg0 | ((sl << c.bestk) & (LPS - 1));
+      const uint32_t pv = (uint32_t)__shfl((int)c.my_p, srcl, 64);
+      rec->rice_params[sl] = (uint8_t)((sl < (int)best_parts && status == 0) ? pv : 0u);
+      uint32_t* words = reinterpret_cast<uint32_t*>(rec->rice_params);
+      for (int w = LPS / 4 + sl; w < FLACENC_HIP_MAX_RICE_PARTITIONS / 4; w += LPS) words[w] = 0u;
+    }
+    if (sl == 0) {
+      uint32_t* cw = reinterpret_cast<uint32_t*>(rec->coefs);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int c0 = (2 * i < ncq && status == 0) ? cq[2 * i < ncq ? 2 * i : 0] : 0;
+        const int c1 = (2 * i + 1 < ncq && status == 0) ? cq[2 * i + 1 < ncq ? 2 * i + 1 : 0] : 0;
+        cw[i] = ((uint32_t)c0 & 0xFFFFu) | ((uint32_t)c1 << 16);
+      }
+      rec->order = (uint8_t)warm;
+      rec->shift = (int8_t)shift;
+      rec->precision = (uint8_t)precision;
+      rec->rice_order = (uint8_t)(status == 0 ? rice_order : 0);
+      rec->status = status;
+      rec->code_bits = status == 0 ? (unsigned long long)c.best_bits : 0ull;
+      rec->subframe_bits = status == 0 ? sub_bits : 0ull;
+      rec->sum_quotients = status == 0 ? c.sum_q : 0ull;
+    }
+  };
+  auto store_row = [&](int32_t* __restrict__ row) {
+    int32_t* __restrict__ dst = row + sl * SPL;
+#pragma unroll
+    for (int k = 0; k < SPL; k += 4) *reinterpret_cast<int4*>(dst + k) = make_int4(e[k], e[k + 1], e[k + 2], e[k + 3]);
+  };
+
+  // ======================= fixed_lpc: order selection + coding =============
+  int fx_order = 0;
+  unsigned long long fx_key = ~0ull, fx_sub_bits = 0;
+  Coded fx{};
+  int role_min = 0, role_max = 0;
+  // the lane's samples + the 4 in front of them, differenced `ord` times in place (reset_fixed_lpc_errors,
+  // coding.rs:182-197: zero history in front of the block); valid from index ord on
+  auto fixed_error_signal = [&](int ord) {
+    with_role([&](auto kind) {
+#pragma unroll
+      for (int k = 0; k < SPL / 4 + 1; ++k) {
+        const int4 q = ld4_at(kind, G::rel(lb, -4 + 4 * k));
+        ebuf[4 * k + 0] = q.x;
+        ebuf[4 * k + 1] = q.y;
+        ebuf[4 * k + 2] = q.z;
+        ebuf[4 * k + 3] = q.w;
+      }
+    });
+#pragma unroll 1
+    for (int lvl = 1; lvl <= 4; ++lvl) {
+      if (lvl <= ord) {  // (per segment: lanes of lower orders sit out the later passes)
+#pragma unroll
+        for (int i = SPL + 3; i >= 1; --i) ebuf[i] = (int32_t)((uint32_t)ebuf[i] - (uint32_t)ebuf[i - 1]);
+      }
+    }
+    // the first `order` errors are never coded (Residual keeps zeros there, coding.rs:151-160)
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (sl == 0 && k < ord) e[k] = 0;
+  };
+  if (FIXED && (!DECIDE || a.use_fixed)) {
+    // ---- estimate_entropy (coding.rs:200-227) for orders 0..max_order: exact integer sums of |e_k| per estimator
+    // partition -- v_sad_u32 on biased values gives the next order's magnitudes from this order's values, sub-sums of
+    // SPL / 8 samples stay below 2^32 for inputs of up to 25 bits -- then one f32 evaluation per (order, partition)
+    constexpr int GS = SPL / 8;
+    const int psz = n / (int)a.fixed_partitions;            // launch_qlpc: a whole number of sub-sums, see subwave_fixed_ok
+    const int qpl = psz >= SPL ? 1 : SPL / psz;             // partitions per lane: 1, 2 or 4
+    const int glog = psz > SPL ? (31 - __builtin_clz(psz / SPL)) : 0;  // ... or 2^glog lanes per partition
+    uint32_t tot[5] = {0u, 0u, 0u, 0u, 0u};
+    {
+      uint32_t b[SPL + 4];
+      uint32_t bias0 = 0x80000000u;
+      uint32_t bmin = 0xFFFFFFFFu, bmax = 0u;
+      with_role([&](auto kind) {
+        constexpr int KIND = decltype(kind)::value;
+        typedef uint32_t v4u_t __attribute__((ext_vector_type(4)));
+        bias0 = KIND == 2 ? 0x40000000u : KIND == 3 ? 0x7FFFFFFFu : 0x80000000u;
+#pragma unroll
+        for (int k = 0; k < SPL / 4 + 1; ++k) {
+          const int ix = G::rel(lb, -4 + 4 * k);
+          v4u_t va = *reinterpret_cast<const v4u_t*>(&bufA[ix]);
+          asm("" : "+v"(va));
+          if (KIND >= 2) {
+            v4u_t vb = *reinterpret_cast<const v4u_t*>(&bufB[ix]);
+            asm("" : "+v"(vb));
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              b[4 * k + q] = KIND == 2 ? (va[q] + vb[q] + 0x80000000u) >> 1 : xad_u32(vb[q], 0x7FFFFFFFu, va[q]);
+          } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) b[4 * k + q] = va[q] ^ 0x80000000u;
+          }
+        }
+      });
+      // (a segment's first lane sees the zero segment in front of it: the biased zero, as the differences need it)
+      if (DECIDE) {
+#pragma unroll
+        for (int j = 0; j < SPL; ++j) {
+          bmin = b[4 + j] < bmin ? b[4 + j] : bmin;
+          bmax = b[4 + j] > bmax ? b[4 + j] : bmax;
+        }
+        bmin = seg_allreduce<LPS>(bmin, [](uint32_t x, uint32_t y) { return x < y ? x : y; });
+        bmax = seg_allreduce<LPS>(bmax, [](uint32_t x, uint32_t y) { return x > y ? x : y; });
+        role_min = (int)(bmin - bias0);
+        role_max = (int)(bmax - bias0);
+      }
+#pragma unroll
+      for (int ord = 0; ord < 5; ++ord) {
+        uint32_t c[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+        if (ord == 0) {
+#pragma unroll
+          for (int j = 0; j < SPL; ++j) c[j / GS] = sad_u32(b[4 + j], bias0, c[j / GS]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < SPL; ++j) c[j / GS] = sad_u32(b[4 + j], b[3 + j], c[j / GS]);
+          if (ord < 4) {
+#pragma unroll
+            for (int i = SPL + 3; i >= ord; --i) b[i] = xad_u32(b[i - 1], 0x7FFFFFFFu, b[i]);
+          }
+        }
+        // partition sums (exact integers below 2^53: the order of these adds is immaterial)
+        double ls[4];
+        if (qpl == 4) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) ls[q] = (double)c[2 * q] + (double)c[2 * q + 1];
+        } else if (qpl == 2) {
+          ls[0] = ((double)c[0] + (double)c[1]) + ((double)c[2] + (double)c[3]);
+          ls[1] = ((double)c[4] + (double)c[5]) + ((double)c[6] + (double)c[7]);
+          ls[2] = ls[3] = 0.0;
+        } else {
+          ls[0] = (((double)c[0] + (double)c[1]) + ((double)c[2] + (double)c[3])) +
+                  (((double)c[4] + (double)c[5]) + ((double)c[6] + (double)c[7]));
+          ls[1] = ls[2] = ls[3] = 0.0;
+#pragma unroll 1
+          for (int lvl = 0; lvl < glog; ++lvl) ls[0] += __shfl_xor(ls[0], 1 << lvl, 64);
+        }
+        if (ord <= (int)a.fixed_max_order) {
+          uint32_t pb = 0;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            if (q < qpl) {
+              // sample_count = min(end - warmup, partition_len): only the block's first partition loses the warm-up
+              const uint32_t cnt = (uint32_t)psz - ((sl >> glog) == 0 && q == 0 ? (uint32_t)ord : 0u);
+              pb += approx_ent_bits(ls[q], cnt);
+            }
+          }
+          tot[ord] = seg_sum<LPS>((sl & ((1 << glog) - 1)) == 0 ? pb : 0u);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    fx_key = ~0ull;
+#pragma unroll
+    for (int ord = 0; ord < 5; ++ord) {
+      if (ord <= (int)a.fixed_max_order) {
+        const unsigned long long kk = (unsigned long long)tot[ord] + bps_role * (unsigned long long)ord;
+        if (a.fixed_keys && active && sl == 0) a.fixed_keys[(size_t)sf * 8 + ord] = kk;
+        if (kk < fx_key) {  // min_by_key keeps the first minimum
+          fx_key = kk;
+          fx_order = ord;
+        }
+      }
+    }
+    if (!DECIDE && a.selector_keys && active && sl == 0) a.selector_keys[sf] = fx_key;
+    // fixed_lpc returns None when the estimate does not beat verbatim_bits (coding.rs:284): then nothing is coded
+    // (the stand-alone batch codes the order regardless, as the generic kernel's fixed_mode 1 does)
+    const bool have = !DECIDE || fx_key < 8ull + (unsigned long long)n * bps_role;
+    if (__builtin_amdgcn_ballot_w64(have) != 0ull) {
+      fixed_error_signal(fx_order);
+      fx = rice_phase(fx_order);
+      fx_sub_bits = 8ull + bps_role * (unsigned long long)fx_order + fx.residual_bits;  // bitrepr.rs:473-477
+    }
+  } else if (DECIDE) {
+    // no fixed candidate: the role's min / max alone (is_constant, arrayutils.rs:382)
+    int vmin = INT32_MAX, vmax = INT32_MIN;
+    with_role([&](auto kind) {
+#pragma unroll
+      for (int k = 0; k < SPL / 4; ++k) {
+        const int4 v = ld4_at(kind, lb + 4 * k);
+        vmax = max(max(vmax, v.x), max(v.y, max(v.z, v.w)));
+        vmin = min(min(vmin, v.x), min(v.y, min(v.z, v.w)));
+      }
+    });
+    role_min = (int)(seg_allreduce<LPS>((uint32_t)vmin ^ 0x80000000u, [](uint32_t x, uint32_t y) { return x < y ? x : y; }) ^ 0x80000000u);
+    role_max = (int)(seg_allreduce<LPS>((uint32_t)vmax ^ 0x80000000u, [](uint32_t x, uint32_t y) { return x > y ? x : y; }) ^ 0x80000000u);
+  }
+  if (VARIANT == 1) {
+    // ---- the stand-alone fixed_lpc batch: row + record, as the generic kernel's fixed_mode 1 ----
+    if (!active) return;
+    store_row(a.residual + (size_t)sf * a.residual_stride);
+    if (a.params == nullptr) return;
+    flacenc_hip_subframe_params* rec = a.params + sf;
+    if (fx.redo) {
+      if (sl == 0) {
+        rec->status = -1;
+        if (a.marked_count != nullptr) atomicAdd(a.marked_count, 1u);
+      }
+      return;
+    }
+    int32_t c4[4];
+    c4[0] = fx_order;  // FIXED_LPC_COEFS[order]: 0 / 1 / 2,-1 / 3,-3,1 / 4,-6,4,-1 (decode.rs:179-185)
+    c4[1] = fx_order == 2 ? -1 : (fx_order == 3 ? -3 : (fx_order == 4 ? -6 : 0));
+    c4[2] = fx_order == 3 ? 1 : (fx_order == 4 ? 4 : 0);
+    c4[3] = fx_order == 4 ? -1 : 0;
+    write_record(rec, fx, 0, fx_order, 0, 0u, fx_sub_bits, c4, std::integral_constant<int, 4>{});
+    return;
+  }
+
+  // ======================= phase 3: the QLPC residual -> registers =========
+  __syncthreads();  // wave 0's recursions are done
   int32_t cq[MAXP];
 #pragma unroll
   for (int i = 0; i < MAXP; ++i) cq[i] = xq[g * 16 + i];
   const int warm = xq[g * 16 + 12];
   const int shift = xq[g * 16 + 13];
-  int status = xq[g * 16 + 14];
-
-  // ======================= phase 3: residual -> registers ==================
-  int32_t e[SPL];
+  const int status = xq[g * 16 + 14];
   with_role([&](auto kind) {
     int sw[HP + 16];
     constexpr int NCH = (SPL + 15) / 16;
@@ -382,190 +749,147 @@ __global__ void __launch_bounds__(STEREO ? 256 : 128, 3) qlpc_subwave_kernel(Qlp
 #pragma unroll
     for (int k = 16; k < SPL; ++k) e[k] = 0;
   }
+  if (!DECIDE && active) store_row(a.residual + (size_t)sf * a.residual_stride);
 
-  // ======================= residual store: registers -> HBM ================
-  if (active) {
-    int32_t* __restrict__ dst = a.residual + (size_t)sf * a.residual_stride + sl * SPL;
-#pragma unroll
-    for (int k = 0; k < SPL; k += 4) *reinterpret_cast<int4*>(dst + k) = make_int4(e[k], e[k + 1], e[k + 2], e[k + 3]);
-  }
-
-  // ======================= phase 4: partitioned-Rice search ================
-  uint32_t pl[7];
-  {
-    uint32_t pb[5];
-    popcount_planes16(e, pb);
-#pragma unroll
-    for (int k = 0; k < 5; ++k) pl[k] = pb[k];
-    __builtin_amdgcn_sched_barrier(0);
-    popcount_planes16(e + 16, pb);
-    planes_add<5>(pl, pb);
-    __builtin_amdgcn_sched_barrier(0);
-    uint32_t pc[6], pd[5];
-    popcount_planes16(e + 32, pd);
-#pragma unroll
-    for (int k = 0; k < 5; ++k) pc[k] = pd[k];
-    __builtin_amdgcn_sched_barrier(0);
-    popcount_planes16(e + 48, pd);
-    planes_add<5>(pc, pd);
-    planes_add<6>(pl, pc);
-    __builtin_amdgcn_sched_barrier(0);
-    if (SPL == 72) {
-      int32_t t8[16];
-#pragma unroll
-      for (int k = 0; k < 16; ++k) t8[k] = k < 8 ? e[(SPL == 72 ? 64 : 0) + k] : 0;
-      popcount_planes16(t8, pd);
-      uint32_t carry = 0;
-#pragma unroll
-      for (int k = 0; k < 7; ++k) {
-        const uint32_t x_ = pl[k], y_ = k < 5 ? pd[k] : 0u;
-        pl[k] = __builtin_amdgcn_bitop3_b32(x_, y_, carry, 0x96);
-        carry = __builtin_amdgcn_bitop3_b32(x_, y_, carry, 0xE8);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-  const uint32_t orw = seg_or<LPS>(pl[0] | pl[1] | pl[2] | pl[3] | pl[4] | pl[5] | pl[6]);
-  const uint32_t maxu = (orw << 1) | (orw >> 31);
-  const PlaneSums ps = make_plane_sums(pl);
-  const uint32_t bitlen = maxu ? (uint32_t)(32 - __builtin_clz(maxu)) : 0u;
-  const uint32_t max_p = a.max_rice_parameter < bitlen ? a.max_rice_parameter : bitlen;  // per segment
-  const uint32_t len0 = (uint32_t)SPL - (sl == 0 ? (uint32_t)warm : 0u);
-  const bool finest_only = a.rice_finest_only != 0;
-  // the exact partition sums must fit 32 bits (64 codes below 2^26, 72 below 2^25): otherwise the clean-up launch
-  bool redo = maxu >= (1u << (SPL == 64 ? 26 : 25));
-
-  // rice_window (see the wave kernel): per-lane bounds p0 of the partition means; the wave-wide minimum and maximum
-  // bound every group of every segment, and a window wider than a segment's own only adds parameters that provably
-  // lose (entries above the segment's max_p are set to the saturation value)
-  const uint32_t s0 = 2u * ps.sum_m + ps.negs;
-  const uint32_t q0 = (s0 >> 6) + 1u;
-  const uint32_t q0lo = SPL == 64 ? q0 : (s0 >> 7) + 1u;
-  const uint32_t p0min = wave_min_dpp(redo ? 31u : 31u - (uint32_t)__builtin_clz(q0lo));
-  const uint32_t maxp_lo = wave_min_dpp(max_p), maxp_hi = wave_max_dpp(max_p);
-  uint32_t p_lo = p0min > 2u ? p0min - 2u : 0u;
-  p_lo = p_lo < maxp_lo ? p_lo : maxp_lo;
-  const uint32_t q0hi = q0 + (sl == 0 ? (s0 >> 8) + 1u : 0u);
-  const uint32_t p0max = wave_max_dpp(redo ? 0u : 31u - (uint32_t)__builtin_clz(q0hi));
-  uint32_t p_hi = p0max + 1u;
-  p_hi = p_hi < maxp_hi ? p_hi : maxp_hi;
-  if (p_hi < p_lo) p_hi = p_lo;
-
-  constexpr uint32_t kWMax = kMaxPToBits - 4u;
-  uint32_t pk[G::LOGL + 1];
-#pragma unroll
-  for (int k = 0; k <= G::LOGL; ++k) pk[k] = 0xFFFFFFFFu;
-#pragma unroll 1
-  for (uint32_t p_base = p_lo; p_base <= p_hi; p_base += 4u) {
-    uint32_t Wp[4];
-    rice_build_tables<true, false, SPL>(ps, nullptr, len0, p_base, max_p, lane, warm, Wp);
-#define FLACENC_SUB_RICE_LEVEL(K, SH)                                                         \
-  if (K <= G::LOGL) {                                                                         \
-    if (K > 0) {                                                                              \
-      uint32_t part[4];                                                                       \
-      _Pragma("unroll") for (int j = 0; j < 4; ++j) part[j] = from_upper_half<SH>(Wp[j]);     \
-      _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                         \
-        const uint32_t v = Wp[j] + part[j];                                                   \
-        Wp[j] = v < kWMax ? v : kWMax;                                                        \
-      }                                                                                       \
-    }                                                                                         \
-    uint32_t packed = pk[K <= G::LOGL ? K : 0];                                               \
-    _Pragma("unroll") for (int j = 0; j + 1 < 4; j += 2) {                                    \
-      const uint32_t c0 = (Wp[j] << 5) | (p_base + (uint32_t)j);                              \
-      const uint32_t c1 = (Wp[j + 1] << 5) | (p_base + (uint32_t)j + 1u);                     \
-      packed = umin3(packed, c0, c1);                                                         \
-    }                                                                                         \
-    pk[K <= G::LOGL ? K : 0] = packed;                                                        \
-  }
-    FLACENC_SUB_RICE_LEVEL(0, 1)
-    if (!finest_only) {
-      FLACENC_SUB_RICE_LEVEL(1, 1)
-      FLACENC_SUB_RICE_LEVEL(2, 2)
-      FLACENC_SUB_RICE_LEVEL(3, 4)
-      FLACENC_SUB_RICE_LEVEL(4, 8)
-      FLACENC_SUB_RICE_LEVEL(5, 16)
-    }
-#undef FLACENC_SUB_RICE_LEVEL
-  }
-  // level totals inside the segment; strict < keeps the finer order on ties (rice.rs:285)
-  int bestk = 0;
-  uint32_t best_bits = 0, my_p = 0, sat_any = 0;
-#pragma unroll
-  for (int K = 0; K <= G::LOGL; ++K) {
-    if (K > 0 && finest_only) break;
-    const uint32_t bits = (pk[K] >> 5) + 4u;
-    const bool lead = (sl & ((1 << K) - 1)) == 0;
-    sat_any |= (lead && bits >= kMaxPToBits) ? 1u : 0u;
-    // (a segment's level total is at most 32 minima below 2^27)
-    const uint32_t tot = seg_sum<LPS>(lead ? bits : 0u);
-    if (K == 0 || tot < best_bits) {
-      best_bits = tot;
-      bestk = K;
-      my_p = pk[K] & 31u;
-    }
-  }
-  redo = redo || seg_or<LPS>(sat_any) != 0u;  // a saturated minimum at any level: clamped entries may tie outside the window
-
-  const int rice_order = G::LOGL - bestk;
-  const uint32_t best_parts = 1u << rice_order;
-  // Residual::sum_quotients / count_bits (datatype.rs:2325-2331, bitrepr.rs:533-544)
-  const bool leader = (sl & ((1 << bestk) - 1)) == 0;
-  const uint32_t sum_p = seg_sum<LPS>(leader ? my_p : 0u);
-  const uint32_t p0 = (uint32_t)__shfl((int)my_p, lane & ~(LPS - 1), 64);
-  const uint32_t rice2 = seg_or<LPS>((leader && my_p > 14) ? 1u : 0u);
-  const unsigned long long rem_bits = (unsigned long long)sum_p * (unsigned long long)(n >> rice_order) -
-                                      (unsigned long long)warm * p0;
-  const unsigned long long sum_q = (unsigned long long)best_bits - 4ull * best_parts - (unsigned long long)(n - warm) - rem_bits;
-  const unsigned long long residual_bits = 2ull + 4ull + (unsigned long long)best_parts * (rice2 ? 5ull : 4ull) +
-                                           (sum_q + (unsigned long long)(n - warm)) + rem_bits;
+  const Coded lp = rice_phase(warm);
   const unsigned long long sub_bits = 8ull + bps_role * (unsigned long long)warm + 4ull + 5ull +
-                                      (unsigned long long)a.precision * (unsigned long long)warm + residual_bits;
-
-  // ======================= phase 5: the record ==============================
-  if (!active || a.params == nullptr) return;
-  flacenc_hip_subframe_params* rec = a.params + sf;
-  if (redo && status == 0) {
-    if (sl == 0) {
-      rec->status = -1;
-      if (a.marked_count != nullptr) atomicAdd(a.marked_count, 1u);
+                                      (unsigned long long)a.precision * (unsigned long long)warm + lp.residual_bits;
+  if (!DECIDE) {
+    // ======================= phase 5: the record ============================
+    if (!active || a.params == nullptr) return;
+    flacenc_hip_subframe_params* rec = a.params + sf;
+    if (lp.redo && status == 0) {
+      if (sl == 0) {
+        rec->status = -1;
+        if (a.marked_count != nullptr) atomicAdd(a.marked_count, 1u);
+      }
+      return;
     }
+    write_record(rec, lp, status, warm, shift, a.precision, sub_bits, cq, std::integral_constant<int, MAXP>{});
     return;
   }
-  {
-    // partition j of the chosen order lives on lane j << bestk of the segment
-    const int srcl = (lane & ~(LPS - 1)) | ((sl << bestk) & (LPS - 1));
-    const uint32_t pv = (uint32_t)__shfl((int)my_p, srcl, 64);
-    rec->rice_params[sl] = (uint8_t)((sl < (int)best_parts && status == 0) ? pv : 0u);
-    uint32_t* words = reinterpret_cast<uint32_t*>(rec->rice_params);
-    for (int w = LPS / 4 + sl; w < FLACENC_HIP_MAX_RICE_PARTITIONS / 4; w += LPS) words[w] = 0u;
-  }
-  if (sl == 0) {
-    uint32_t* cw = reinterpret_cast<uint32_t*>(rec->coefs);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int c0 = (2 * i < MAXP && status == 0) ? cq[2 * i < MAXP ? 2 * i : 0] : 0;
-      const int c1 = (2 * i + 1 < MAXP && status == 0) ? cq[2 * i + 1 < MAXP ? 2 * i + 1 : 0] : 0;
-      cw[i] = ((uint32_t)c0 & 0xFFFFu) | ((uint32_t)c1 << 16);
+
+  // ======================= encode_subframe + try_stereo_coding =============
+  if (DECIDE) {
+    const unsigned long long verbatim_bits = 8ull + (unsigned long long)n * bps_role;  // datatype.rs:1944
+    const bool have_fixed = a.use_fixed && fx_key < verbatim_bits;  // coding.rs:262, :284
+    const unsigned long long fixed_bits = have_fixed ? fx_sub_bits : ~0ull;
+    const unsigned long long baseline = fixed_bits < verbatim_bits ? fixed_bits : verbatim_bits;  // coding.rs:403-405
+    uint32_t kind;
+    unsigned long long bits;
+    if (a.use_constant && role_min == role_max) {
+      kind = FLACENC_HIP_KIND_CONSTANT;
+      bits = 8ull + bps_role;  // bitrepr.rs:445
+    } else if (a.use_lpc && status == 0 && sub_bits < baseline) {
+      kind = FLACENC_HIP_KIND_LPC;
+      bits = sub_bits;
+    } else if (have_fixed && fixed_bits < verbatim_bits) {
+      kind = FLACENC_HIP_KIND_FIXED;
+      bits = fixed_bits;
+    } else {
+      kind = FLACENC_HIP_KIND_VERBATIM;
+      bits = verbatim_bits;
     }
-    rec->order = (uint8_t)warm;
-    rec->shift = (int8_t)shift;
-    rec->precision = (uint8_t)a.precision;
-    rec->rice_order = (uint8_t)(status == 0 ? rice_order : 0);
-    rec->status = status;
-    rec->code_bits = status == 0 ? (unsigned long long)best_bits : 0ull;
-    rec->subframe_bits = status == 0 ? sub_bits : 0ull;
-    rec->sum_quotients = status == 0 ? sum_q : 0ull;
+    // a candidate the exact sums could not carry: the whole frame goes to the general path (launch_qlpc)
+    const bool redo = (a.use_lpc && status == 0 && lp.redo) || (have_fixed && fx.redo);
+    if (sl == 0) {
+      xd[g * 8 + 0] = (uint32_t)bits;
+      xd[g * 8 + 1] = (uint32_t)(bits >> 32);
+      xd[g * 8 + 2] = kind;
+      xd[g * 8 + 3] = (uint32_t)role_min;
+      xd[g * 8 + 4] = a.use_lpc ? (uint32_t)status : 0u;
+      xd[g * 8 + 5] = redo ? 1u : 0u;
+    }
+    __syncthreads();
+    unsigned long long rb[4];
+    uint32_t any_redo = 0, any_status = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const uint32_t* x = xd + (sg * 4 + r) * 8;
+      rb[r] = (unsigned long long)x[0] | ((unsigned long long)x[1] << 32);
+      any_redo |= x[5];
+      any_status |= x[4];
+    }
+    unsigned long long min_bits = rb[0] + rb[1];
+    uint32_t assignment = 0;  // Independent(2)
+    if (a.use_leftside && rb[0] + rb[3] < min_bits) {
+      min_bits = rb[0] + rb[3];
+      assignment = 1;
+    }
+    if (a.use_rightside && rb[1] + rb[3] < min_bits) {
+      min_bits = rb[1] + rb[3];
+      assignment = 2;
+    }
+    if (a.use_midside && rb[2] + rb[3] < min_bits) {
+      min_bits = rb[2] + rb[3];
+      assignment = 3;
+    }
+    // ChannelAssignment::select_channels, datatype.rs:1173-1185
+    const int role0 = assignment == 2 ? 3 : (assignment == 3 ? 2 : 0);
+    const int role1 = (assignment == 0 || assignment == 2) ? 1 : 3;
+    if (!active) return;
+    flacenc_hip_stereo_frame_result* fr = a.frame_results + frame;
+    if (any_redo) {
+      // marked for the general path: its candidate batches redo the frame's four roles, frame_decide_kernel the frame
+      if (sl == 0) {
+        if (a.cand_lpc_params) const_cast<flacenc_hip_subframe_params*>(a.cand_lpc_params)[sf].status = -1;
+        if (a.cand_fixed_params) const_cast<flacenc_hip_subframe_params*>(a.cand_fixed_params)[sf].status = -1;
+        if (role == 0) {
+          fr->channel_assignment = 0xFF;
+          if (a.marked_count != nullptr) atomicAdd(a.marked_count, 1u);
+        }
+      }
+      return;
+    }
+    if (role == 0 && sl == 0) {
+      fr->channel_assignment = (uint8_t)assignment;
+      fr->analysis_status = (uint8_t)any_status;
+      fr->pad[0] = fr->pad[1] = 0;
+#pragma unroll
+      for (int ch = 0; ch < 2; ++ch) {
+        const uint32_t* x = xd + (sg * 4 + (ch == 0 ? role0 : role1)) * 8;
+        fr->role[ch] = (uint8_t)(ch == 0 ? role0 : role1);
+        fr->kind[ch] = (uint8_t)x[2];
+        fr->dc_offset[ch] = x[2] == FLACENC_HIP_KIND_CONSTANT ? (int32_t)x[3] : 0;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) fr->bits[r] = rb[r];
+    }
+    if (role != role0 && role != role1) return;
+    const int ch = role == role0 ? 0 : 1;
+    flacenc_hip_subframe_params* rec = &fr->lpc[ch];
+    int32_t* row = a.residual + (size_t)(2u * frame + (uint32_t)ch) * a.residual_stride;
+    if (kind == FLACENC_HIP_KIND_LPC) {
+      store_row(row);
+      write_record(rec, lp, 0, warm, shift, a.precision, sub_bits, cq, std::integral_constant<int, MAXP>{});
+    } else if (kind == FLACENC_HIP_KIND_FIXED) {
+      fixed_error_signal(fx_order);
+      store_row(row);
+      int32_t c4[4];
+      c4[0] = fx_order;
+      c4[1] = fx_order == 2 ? -1 : (fx_order == 3 ? -3 : (fx_order == 4 ? -6 : 0));
+      c4[2] = fx_order == 3 ? 1 : (fx_order == 4 ? 4 : 0);
+      c4[3] = fx_order == 4 ? -1 : 0;
+      write_record(rec, fx, 0, fx_order, 0, 0u, fx_sub_bits, c4, std::integral_constant<int, 4>{});
+    } else {
+      // Constant / Verbatim: an all-zero row and a blank record
+#pragma unroll
+      for (int k = 0; k < SPL; ++k) e[k] = 0;
+      store_row(row);
+      uint32_t* w = reinterpret_cast<uint32_t*>(rec);
+      for (int i = sl; i < (int)(sizeof(flacenc_hip_subframe_params) / 4); i += LPS) w[i] = 0u;
+    }
   }
 }
 
-template <int MAXP, bool STEREO, int SPL, int LPS>
+template <int MAXP, bool STEREO, int SPL, int LPS, int VARIANT>
 hipError_t launch_subwave_geom(const QlpcKernelArgs& a, hipStream_t stream) {
   using G = SubGeom<SPL, LPS>;
   constexpr int WAVES = STEREO ? 4 : 2;
   constexpr int SUBS = WAVES * G::S;
   constexpr int NIMG = STEREO ? 2 * G::S : SUBS;
-  constexpr size_t smem = (size_t)(NIMG + 1) * G::Img * 4 + (size_t)SUBS * ((MAXP + 1) * 8 + 64);
-  auto kern = qlpc_subwave_kernel<MAXP, STEREO, SPL, LPS>;
+  constexpr size_t smem = (size_t)(NIMG + 1) * G::Img * 4 + (size_t)SUBS * ((MAXP + 1) * 8 + 64 + 32);
+  auto kern = qlpc_subwave_kernel<MAXP, STEREO, SPL, LPS, VARIANT>;
   static DynamicLdsOptIn opt_in;
   if (hipError_t err = opt_in.ensure(reinterpret_cast<const void*>(kern), smem); err != hipSuccess) return err;
   const uint32_t blocks = STEREO ? ((a.n_subframes >> 2) + (uint32_t)G::S - 1u) / (uint32_t)G::S
@@ -574,13 +898,13 @@ hipError_t launch_subwave_geom(const QlpcKernelArgs& a, hipStream_t stream) {
   return hipGetLastError();
 }
 
-template <int MAXP, bool STEREO, int SPL>
+template <int MAXP, bool STEREO, int SPL, int VARIANT>
 hipError_t launch_subwave(const QlpcKernelArgs& a, hipStream_t stream) {
   const uint32_t lps = a.block_size / (uint32_t)SPL;
   if (a.block_size != lps * (uint32_t)SPL) return hipErrorInvalidValue;
-  if (lps == 8) return launch_subwave_geom<MAXP, STEREO, SPL, 8>(a, stream);
-  if (lps == 16) return launch_subwave_geom<MAXP, STEREO, SPL, 16>(a, stream);
-  if (lps == 32) return launch_subwave_geom<MAXP, STEREO, SPL, 32>(a, stream);
+  if (lps == 8) return launch_subwave_geom<MAXP, STEREO, SPL, 8, VARIANT>(a, stream);
+  if (lps == 16) return launch_subwave_geom<MAXP, STEREO, SPL, 16, VARIANT>(a, stream);
+  if (lps == 32) return launch_subwave_geom<MAXP, STEREO, SPL, 32, VARIANT>(a, stream);
   return hipErrorInvalidValue;
 }
 

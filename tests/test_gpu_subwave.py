@@ -143,3 +143,108 @@ def test_device_entry_point_with_row_strides(handle):
     assert params.cpu().numpy().tobytes() == want_p.tobytes()
     assert np.array_equal(res[:, :n].cpu().numpy().reshape(nf, 4, n), want_r)
     assert int(res[:, n:].abs().max()) == 0
+
+
+# ------------------------------------------------------------------ fixed_lpc batch (variant 1) ----
+def _fixed_signals(n, bps):
+    return np.stack([util.sine_noise(n, bps, 200, 0.4, 0.05, seed=1), util.sine_noise(n, bps, 31, 0.7, 0.3, seed=2),
+                     util.quantize(util.sine(n, 100, 0.6), bps), (np.arange(n) // 7).astype(np.int32),
+                     ((np.arange(n) - n // 2) ** 2 // 400 % (1 << (bps - 2))).astype(np.int32),
+                     np.full(n, 77, np.int32), np.zeros(n, np.int32), util.quantize(util.noise(5, n, 0.999), bps),
+                     np.where(np.arange(n) % 2 == 0, 2 ** (bps - 1) - 1, -2 ** (bps - 1)).astype(np.int32),
+                     util.sine_noise(n, bps, 77, 0.2, 0.01, seed=9), util.sine_noise(n, bps, 13, 0.9, 0.0, seed=10)]).astype(np.int32)
+
+
+@pytest.mark.parametrize("n", SIZES)
+@pytest.mark.parametrize("bps,parts,max_order", [(16, 16, 4), (24, 16, 4), (16, 32, 4), (16, 8, 3), (16, 4, 4), (24, 1, 2),
+                                                 (16, 2, 0)])
+def test_fixed_lpc_batch(handle, n, bps, parts, max_order):
+    """flacenc_hip_fixed_lpc_batch (ApproxEnt) on the sub-wave shapes == fixed_lpc (coding.rs:298-331) and byte-identical
+    to the generic kernel: estimator partitions of a quarter lane up to the whole block."""
+    x = _fixed_signals(n, bps)
+    bpsv = np.full(x.shape[0], bps, np.uint8)
+    bpsv[1] = bps + 1 if bps < 25 else bps
+    mk = lambda flags: _capi.make_frame_config(_capi.make_config(lpc_order=8, flags=flags), use_fixed=True,
+                                               fixed_partitions=parts, fixed_max_order=max_order)
+    params, resid, keys = handle.fixed_lpc_batch(x, bpsv, mk(0))
+    gp, gr, gk = handle.fixed_lpc_batch(x, bpsv, mk(_capi.FLAG_GENERIC_KERNEL))
+    assert params.tobytes() == gp.tobytes() and np.array_equal(resid, gr) and np.array_equal(keys, gk)
+    fc = orc.make_fixed_config(max_order=max_order, partitions=parts, sum_mode=orc.SUMABS_CANONICAL)
+    for k in range(x.shape[0]):
+        w = orc.fixed_lpc(x[k], int(bpsv[k]), 2 ** 63, fc)
+        p = params[k]
+        assert int(p["order"]) == w["order"] and int(keys[k]) == w["estimate"][w["order"]], k
+        for fld in ("rice_order", "code_bits", "subframe_bits", "sum_quotients"):
+            assert int(p[fld]) == int(w[fld]), (k, fld)
+        assert p["coefs"][:4].tolist() == orc.FIXED_LPC_COEFS[w["order"]]
+        assert p["rice_params"][: 1 << w["rice_order"]].tolist() == w["rice_params"].tolist()
+        assert np.array_equal(resid[k], w["residual"]), k
+
+
+@pytest.mark.parametrize("n", SIZES)
+def test_fixed_lpc_batch_stereo_roles(handle, n):
+    bps = 16
+    x = _capi.sigen_frames(7, 2, n, bps, 90.0, 0.5, 0.02, seed=31)
+    x[1, 1] = x[1, 0] // 2 + 3
+    x[2] = (np.arange(n)[None, :] * np.array([[3], [-2]]) // 5).astype(np.int32)
+    mk = lambda flags: _capi.make_frame_config(_capi.make_config(lpc_order=8, flags=flags), use_fixed=True)
+    params, resid, keys = handle.fixed_lpc_batch(x, bps, mk(0), stereo=True)
+    gp, gr, gk = handle.fixed_lpc_batch(x, bps, mk(_capi.FLAG_GENERIC_KERNEL), stereo=True)
+    assert params.tobytes() == gp.tobytes() and np.array_equal(resid, gr) and np.array_equal(keys, gk)
+    fc = orc.make_fixed_config(sum_mode=orc.SUMABS_CANONICAL)
+    for f in range(x.shape[0]):
+        l, r = x[f, 0], x[f, 1]
+        for role, sig in enumerate([l, r, *orc.stereo_to_midside(l, r)]):
+            w = orc.fixed_lpc(sig, bps + (1 if role == 3 else 0), 2 ** 63, fc)
+            p = params[f, role]
+            assert int(p["order"]) == w["order"] and int(keys[f, role]) == w["estimate"][w["order"]], (f, role)
+            assert int(p["subframe_bits"]) == w["subframe_bits"] and int(p["code_bits"]) == w["code_bits"]
+            assert np.array_equal(resid[f, role], w["residual"]), (f, role)
+
+
+# ------------------------------------------------------------------ encode_frame (variant 2) ----
+@pytest.mark.parametrize("n", SIZES)
+@pytest.mark.parametrize("order,bps,flags", [
+    (8, 16, dict(use_fixed=True)), (10, 16, dict()), (12, 24, dict(use_fixed=True, fixed_max_order=2)),
+    (8, 16, dict(use_fixed=True, use_midside=False)), (8, 16, dict(use_fixed=True, use_constant=False, fixed_partitions=8)),
+    (6, 16, dict(use_fixed=True, use_leftside=False, use_rightside=False)), (8, 16, dict(use_fixed=True, fixed_partitions=32)),
+])
+def test_encode_stereo_frames(handle, n, order, bps, flags):
+    """flacenc_hip_encode_stereo_frames on the sub-wave shapes == encode_frame (coding.rs:530-544) restated by the
+    oracle -- every SubFrame kind and channel assignment -- byte-identical to the general path it replaces, and the
+    frames decode back to the input."""
+    from test_gpu_parity import _stereo_corpus, _check_frames_against_oracle, _decode_frames
+    x = _stereo_corpus(n, bps)
+    got, gres = handle.encode_stereo_frames(x, bps, _capi.make_frame_config(_capi.make_config(lpc_order=order), **flags))
+    gen, genres = handle.encode_stereo_frames(x, bps, _capi.make_frame_config(
+        _capi.make_config(lpc_order=order, flags=_capi.FLAG_GENERIC_KERNEL), **flags))
+    assert got.tobytes() == gen.tobytes() and np.array_equal(gres, genres)
+    oflags = {k: v for k, v in flags.items() if not k.startswith("fixed_")}
+    oflags.setdefault("use_fixed", False)
+    fixed = orc.make_fixed_config(max_order=flags.get("fixed_max_order", 4), partitions=flags.get("fixed_partitions", 16),
+                                  sum_mode=orc.SUMABS_CANONICAL)
+    ocfg = orc.make_frame_config(orc.make_config(lpc_order=order, acorr=orc.ACORR_CANONICAL), fixed=fixed, **oflags)
+    want, wres = orc.encode_stereo_frames_cfg(x, bps, ocfg)
+    _check_frames_against_oracle(x, bps, got, gres, want, wres)
+    _decode_frames(x, got, gres)
+    assert len({int(k) for k in got["kind"].reshape(-1)}) >= 3 and len({int(a) for a in got["channel_assignment"]}) >= 2
+
+
+@pytest.mark.parametrize("n", [1152, 2048, 576])
+def test_frames_with_candidates_beyond_the_exact_sums(handle, n):
+    """Full-scale 24-bit material next to ordinary frames: the frame variant marks what it cannot decide and the
+    general path (candidate batches + frame_decide_kernel, only the marked frames) finishes it."""
+    from test_gpu_parity import _check_frames_against_oracle, _decode_frames
+    bps = 24
+    rng = np.random.default_rng(n)
+    x = _capi.sigen_frames(13, 2, n, bps, 120.0, 0.4, 0.1, seed=n)
+    for f in (1, 4, 5, 12):
+        x[f, 0] = (rng.integers(0, 2, n) * 2 - 1).astype(np.int32) * (2 ** 23 - 1)
+        x[f, 1] = -x[f, 0] if f != 5 else (rng.integers(0, 2, n) * 2 - 1).astype(np.int32) * (2 ** 23 - 1)
+    cfg = _capi.make_frame_config(_capi.make_config(lpc_order=8), use_fixed=True)
+    got, gres = handle.encode_stereo_frames(x, bps, cfg)
+    ocfg = orc.make_frame_config(orc.make_config(lpc_order=8, acorr=orc.ACORR_CANONICAL),
+                                 fixed=orc.make_fixed_config(sum_mode=orc.SUMABS_CANONICAL))
+    want, wres = orc.encode_stereo_frames_cfg(x, bps, ocfg)
+    _check_frames_against_oracle(x, bps, got, gres, want, wres)
+    _decode_frames(x, got, gres)

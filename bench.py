@@ -700,6 +700,34 @@ def secondary(torch, _capi, handle, args, dev):
                         "decision) + flacenc_hip_pack_stereo_frames: PCM in HBM -> FLAC frame bytes in HBM"}
             del bfr, bch, bout, blen
         del big, bparams, bres
+    # blocks below a wave's worth of Rice partitions (qlpc_subwave_kernel: 4 subframes of 1152 samples per wave): the
+    # four candidates of every frame, and the frame-level call with the reference's default candidate set in one launch
+    sn, sfr = 1152, 16384
+    shost = _capi.sigen_frames(sfr, 2, sn, 16, 200.0, 0.4, 0.1, seed=0xF1AC0003)
+    small = torch.from_numpy(shost).to(dev)
+    sparams = torch.empty((sfr * 4, 352), dtype=torch.uint8, device=dev)
+    sres = torch.empty((sfr * 4, sn), dtype=torch.int32, device=dev)
+    scfg = _capi.make_config(lpc_order=8)
+    ms = timed(lambda: handle.stereo_qlpc_batch_device(scfg, small.data_ptr(), sfr, sn, sn, 16, sparams.data_ptr(),
+                                                       sres.data_ptr(), sn, stream=stream.cuda_stream))
+    med = float(np.median(ms))
+    sec["blocks_1152x16bit_order8"] = {
+        "frames": sfr, "block_size": sn, "ms_per_launch": stats(ms),
+        "Msamples_per_s": round(sfr * 2 * sn / (med * 1e-3) / 1e6, 1),
+        "what": "flacenc_hip_stereo_qlpc_batch on 1152-sample blocks (16 Rice partitions of 72): the sub-wave kernel, "
+                "4 subframes per wave (the generic kernel until round 4: 98 G samples/s)"}
+    sfres = torch.empty((sfr, rec_bytes), dtype=torch.uint8, device=dev)
+    sfcfg = _capi.make_frame_config(scfg, use_fixed=True)
+    ms = timed(lambda: handle.encode_stereo_frames_device(sfcfg, small.data_ptr(), sfr, sn, sn, 16, sfres.data_ptr(),
+                                                          sres.data_ptr(), sn, stream=stream.cuda_stream))
+    med = float(np.median(ms))
+    sec["frames_1152x16bit_default_candidates"] = {
+        "frames": sfr, "block_size": sn, "ms_per_launch": stats(ms),
+        "Msamples_per_s": round(sfr * 2 * sn / (med * 1e-3) / 1e6, 1),
+        "what": "flacenc_hip_encode_stereo_frames_async on 1152-sample blocks, QLPC + fixed-LPC candidates of L, R, M, S, "
+                "encode_frame's decision and the two chosen rows in ONE launch of the sub-wave kernel (three launches of "
+                "the generic kernels until round 4: 54 G samples/s)"}
+    del small, sparams, sres, sfres
     return sec
 
 

@@ -78,7 +78,7 @@ bool subwave_frame_eligible(const QlpcKernelArgs& a) {
 }
 
 hipError_t launch_subwave_frames(const QlpcKernelArgs& a, hipStream_t stream) {
-  const int mp = a.lpc_order <= 8 ? 8 : 12;
+  const int mp = a.lpc_order <= 8 ? 8 : (a.lpc_order <= 10 ? 10 : 12);
   const int spl = (a.block_size % 72u) == 0 ? 72 : 64;
 #define FLACENC_HIP_SUBFRAMES(MP, ST, SP, V) \
   if (V == 2 && mp == MP && spl == SP) return launch_qlpc_subwave_##MP##_##ST##_##SP##_##V(a, stream);
@@ -303,7 +303,7 @@ hipError_t launch_qlpc(const QlpcKernelArgs& a, const QlpcLaunchPlan& plan, hipS
     // several subframes per wave; what it marks (residuals of 2^25 and more, saturated Rice tables) is redone by the
     // generic kernel's clean-up launch, which returns at once when nothing was marked
     const int var = a.fixed_mode == 1u ? 1 : 0;
-    const int mp = (var == 1 || a.lpc_order <= 8) ? 8 : 12;
+    const int mp = (var == 1 || a.lpc_order <= 8) ? 8 : (a.lpc_order <= 10 ? 10 : 12);
     const int st = a.stereo ? 1 : 0;
     const int spl = (a.block_size % 72u) == 0 ? 72 : 64;
     hipError_t err = hipErrorInvalidValue;

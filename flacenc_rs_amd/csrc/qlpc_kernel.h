@@ -187,8 +187,9 @@ bool subwave_frame_eligible(const QlpcKernelArgs& args);  // variant 2 (args.fra
 // caller's general path
 hipError_t launch_subwave_frames(const QlpcKernelArgs& args, hipStream_t stream);
 #define FLACENC_HIP_FOR_EACH_SUBWAVE_INSTANCE(X)                                                                      \
-  X(8, 0, 64, 0) X(8, 0, 72, 0) X(8, 1, 64, 0) X(8, 1, 72, 0) X(12, 0, 64, 0) X(12, 0, 72, 0) X(12, 1, 64, 0) X(12, 1, 72, 0) \
-  X(8, 0, 64, 1) X(8, 0, 72, 1) X(8, 1, 64, 1) X(8, 1, 72, 1) X(8, 1, 64, 2) X(8, 1, 72, 2) X(12, 1, 64, 2) X(12, 1, 72, 2)
+  X(8, 0, 64, 0) X(8, 0, 72, 0) X(8, 1, 64, 0) X(8, 1, 72, 0) X(10, 0, 64, 0) X(10, 0, 72, 0) X(10, 1, 64, 0) X(10, 1, 72, 0)     \
+  X(12, 0, 64, 0) X(12, 0, 72, 0) X(12, 1, 64, 0) X(12, 1, 72, 0) X(8, 0, 64, 1) X(8, 0, 72, 1) X(8, 1, 64, 1) X(8, 1, 72, 1)     \
+  X(8, 1, 64, 2) X(8, 1, 72, 2) X(10, 1, 64, 2) X(10, 1, 72, 2) X(12, 1, 64, 2) X(12, 1, 72, 2)
 #define FLACENC_HIP_DECLARE_SUBWAVE_INSTANCE(MP, ST, SP, V) \
   hipError_t launch_qlpc_subwave_##MP##_##ST##_##SP##_##V(const QlpcKernelArgs&, hipStream_t);
 FLACENC_HIP_FOR_EACH_SUBWAVE_INSTANCE(FLACENC_HIP_DECLARE_SUBWAVE_INSTANCE)

@@ -1,5 +1,5 @@
 // qlpc_subwave_inst.hip -- one (order bucket, stereo, samples per lane, variant) instantiation of the sub-wave kernel per
-// translation unit (-DFLACENC_MAXP=<8|12> -DFLACENC_STEREO=<0|1> -DFLACENC_SPL=<64|72> -DFLACENC_VARIANT=<0|1|2>: QLPC
+// translation unit (-DFLACENC_MAXP=<8|10|12> -DFLACENC_STEREO=<0|1> -DFLACENC_SPL=<64|72> -DFLACENC_VARIANT=<0|1|2>: QLPC
 // candidates, fixed_lpc batch, 2-channel frame decision), with its three segment widths.
 #include "qlpc_subwave_kernel_impl.h"
 

@@ -67,8 +67,13 @@ run("16384 x 24b stereo, order 8 (big-block kernels; the generic kernel until ro
 run("config5: 16384 x 24b stereo, order 24 (big-block kernels)", 1024, 2, 16384, 24, 24, True)
 run("config5: 16384 x 24b stereo, order 32 (big-block kernels)", 1024, 2, 16384, 24, 32, True)
 run("ragged: 4608 x 16b stereo, order 10 (72-sample-per-lane wave kernel)", 4096, 2, 4608, 16, 10, True)
-run("ragged: 1152 x 16b stereo, order 8 (generic kernel, 72-sample partitions bit-sliced)", 16384, 2, 1152, 16, 8, True)
-run("ragged: 2304 x 16b stereo, order 8 (generic kernel, 72-sample partitions bit-sliced)", 8192, 2, 2304, 16, 8, True)
+run("ragged: 1152 x 16b stereo, order 8 (sub-wave kernel: 4 subframes per wave; the generic kernel until round 4)", 16384, 2, 1152, 16, 8, True)
+run("ragged: 2304 x 16b stereo, order 8 (sub-wave kernel: 2 subframes per wave; the generic kernel until round 4)", 8192, 2, 2304, 16, 8, True)
+run("ragged: 576 x 16b stereo, order 8 (sub-wave kernel: 8 subframes per wave)", 32768, 2, 576, 16, 8, True)
+run("ragged: 1152 x 16b stereo, order 10 (sub-wave kernel)", 16384, 2, 1152, 16, 10, True)
+run("2048 x 16b stereo, order 8 (sub-wave kernel)", 8192, 2, 2048, 16, 8, True)
+run("1024 x 16b stereo, order 8 (sub-wave kernel)", 16384, 2, 1024, 16, 8, True)
+run("1152 x 16b, 8 independent channels, order 8 (sub-wave kernel, plain batches)", 4096, 8, 1152, 16, 8, False)
 # the big-block shapes at 3 x the batch: whole rounds of workgroups for every kernel (512 and 768 resident
 # workgroups), launch costs amortised
 run("config3, 6144 frames per launch: 8192 x 24b stereo, order 24", 6144, 2, 8192, 24, 24, True)
@@ -113,6 +118,41 @@ def run_frames(name, frames, ch, n, bps, order):
                  "what": "encode_frames (default config: fixed-LPC candidate on) + pack_frames, PCM in HBM -> frame bytes in HBM"})
 
 
+def run_stereo_frames(name, frames, n, bps, order):
+    """flacenc_hip_encode_stereo_frames with the reference's default candidate set (fixed-LPC on), device-resident."""
+    host = _capi.sigen_frames(frames, 2, n, bps, 200.0, 0.4, 0.1, seed=7)
+    x = torch.from_numpy(host).to(dev)
+    res = torch.empty((frames, 752), dtype=torch.uint8, device=dev)
+    resid = torch.empty((frames * 2, n), dtype=torch.int32, device=dev)
+    cfg = _capi.make_frame_config(_capi.make_config(lpc_order=order), use_fixed=True)
+
+    def go():
+        h.encode_stereo_frames_device(cfg, x.data_ptr(), frames, n, n, bps, res.data_ptr(), resid.data_ptr(), n, stream=0)
+
+    import time
+    t_spin = time.perf_counter()
+    while time.perf_counter() - t_spin < 0.05:
+        go()
+        torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        go()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 5
+    inp = frames * 2 * n
+    print(f"{name:52s} {ms:8.3f} ms  {inp / ms / 1e3:9.1f} Msamples/s input, frame decisions", file=sys.stderr)
+    ROWS.append({"shape": name, "frames": frames, "channels": 2, "block_size": n, "bps": bps, "lpc_order": order,
+                 "ms_per_call": round(ms, 4), "Msamples_per_s_input": round(inp / ms / 1e3, 1),
+                 "what": "encode_stereo_frames, default candidates (QLPC + fixed-LPC for L, R, M, S, encode_frame's decision, two rows out)"})
+
+
+run_stereo_frames("frames: 1152 x 16b stereo, default candidates, order 8 (sub-wave kernel, one launch)", 16384, 1152, 16, 8)
+run_stereo_frames("frames: 2304 x 16b stereo, default candidates, order 8 (sub-wave kernel, one launch)", 8192, 2304, 16, 8)
+run_stereo_frames("frames: 1152 x 16b stereo, default candidates, order 10 (sub-wave kernel, one launch)", 16384, 1152, 16, 10)
+run_stereo_frames("frames: 2048 x 16b stereo, default candidates, order 8 (sub-wave kernel, one launch)", 8192, 2048, 16, 8)
+run_stereo_frames("frames: 4096 x 16b stereo, default candidates, order 10 (fused wave kernel)", 8192, 4096, 16, 10)
 run_frames("config4: 4096 x 16b 8-channel, default config, frames", 2048, 8, 4096, 16, 10)
 run_frames("mono: 4096 x 16b, default config, frames", 8192, 1, 4096, 16, 10)
 

@@ -1,9 +1,9 @@
 #!/bin/bash
-# Counter passes of the big-block pipeline (one group per run): tools/pmc_bigres.sh <out-subdir> [n] [order] [frames]
+# Counter passes of a stereo QLPC batch shape (one group per run): tools/pmc_bigres.sh <out-subdir> [n] [order] [frames] [bps]
 R=$PWD; OUT=$R/gpurun_out/$1; N=${2:-8192}; P=${3:-24}; mkdir -p $OUT; cd /tmp && export TMPDIR=/tmp
-fr=${4:-$((50331648 / N))}
+fr=${4:-$((50331648 / N))}; BPS=${5:-24}
 run() { local name=$1; shift
-  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -- python3 $R/tools/prof_config.py --n $N --order $P --frames $fr > $OUT/$name.log 2>&1; }
+  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -- python3 $R/tools/prof_config.py --n $N --order $P --frames $fr --bps $BPS > $OUT/$name.log 2>&1; }
 run a SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_MFMA
 run b SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_VALU_MFMA_BUSY_CYCLES
 run c SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_ADDR_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE

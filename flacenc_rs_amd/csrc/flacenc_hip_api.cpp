@@ -1153,6 +1153,72 @@ int flacenc_hip_encode_frames_async(flacenc_hip_handle* h, const flacenc_hip_fra
       HIP_TRY(h, flacenc_hip::launch_qlpc(a, plan, s));
       return FLACENC_HIP_OK;
     }
+    // blocks of 8 / 16 / 32 finest Rice partitions: qlpc_subwave_kernel's independent-channel variant -- both candidates
+    // and encode_subframe's choice of every channel in one launch; what it marks takes the general path below, restricted
+    // to the marked subframes (three launches that return at once when the count is 0)
+    if (block_size >= FLACENC_HIP_MIN_BLOCK_SIZE && flacenc_hip::subwave_shape(block_size)) {
+      flacenc_hip::QlpcKernelArgs m = a;
+      m.fixed_partitions = cfg->fixed_partitions;
+      if ((rc = attach_split_scratch(h, m)) != FLACENC_HIP_OK) return rc;
+      if (flacenc_hip::subwave_channels_eligible(m)) {
+        const size_t cs = (static_cast<size_t>(block_size) + 3) & ~static_cast<size_t>(3);
+        if ((rc = ensure(h, h->d_cparams, n_sub * sizeof(flacenc_hip_subframe_params))) != FLACENC_HIP_OK) return rc;
+        if ((rc = ensure(h, h->d_cresid, n_sub * cs * 4)) != FLACENC_HIP_OK) return rc;
+        m.cand_lpc_params = static_cast<const flacenc_hip_subframe_params*>(h->d_cparams.ptr);
+        if (cfg->use_fixed) {
+          if ((rc = ensure(h, h->d_fparams, n_sub * sizeof(flacenc_hip_subframe_params))) != FLACENC_HIP_OK) return rc;
+          if ((rc = ensure(h, h->d_fresid, n_sub * cs * 4)) != FLACENC_HIP_OK) return rc;
+          if ((rc = ensure(h, h->d_fkeys, n_sub * 8)) != FLACENC_HIP_OK) return rc;
+          m.cand_fixed_params = static_cast<const flacenc_hip_subframe_params*>(h->d_fparams.ptr);
+        }
+        HIP_TRY(h, flacenc_hip::launch_subwave_frames(m, s));
+        flacenc_hip::ChannelDecideArgs dm{};
+        dm.samples = frames;
+        dm.stride = stride;
+        dm.block_size = block_size;
+        dm.n_subframes = static_cast<uint32_t>(n_sub);
+        dm.bits_per_sample = bits_per_sample;
+        dm.use_constant = cfg->use_constant;
+        dm.use_fixed = cfg->use_fixed;
+        dm.use_lpc = cfg->use_lpc;
+        dm.cand_stride = cs;
+        dm.results = results;
+        dm.residual = residual;
+        dm.residual_stride = residual_stride;
+        flacenc_hip::QlpcKernelArgs c = m;
+        c.chan_results = nullptr;
+        c.cand_lpc_params = c.cand_fixed_params = nullptr;
+        c.params = static_cast<flacenc_hip_subframe_params*>(h->d_cparams.ptr);
+        c.residual = static_cast<int32_t*>(h->d_cresid.ptr);
+        c.residual_stride = cs;
+        c.only_marked = 1;
+        c.use_fixed = 0;
+        c.fixed_keys = nullptr;
+        HIP_TRY(h, flacenc_hip::launch_qlpc(c, flacenc_hip::plan_qlpc_launch(block_size, cfg->qlpc.lpc_order), s));
+        dm.lpc_params = c.params;
+        dm.lpc_residual = c.residual;
+        if (cfg->use_fixed) {
+          flacenc_hip::QlpcKernelArgs x = c;
+          x.params = static_cast<flacenc_hip_subframe_params*>(h->d_fparams.ptr);
+          x.residual = static_cast<int32_t*>(h->d_fresid.ptr);
+          x.selector_keys = static_cast<unsigned long long*>(h->d_fkeys.ptr);
+          x.window = nullptr;
+          x.flat_lo = x.flat_hi = 0;
+          x.lpc_order = 4;
+          x.precision = 0;
+          x.use_fixed = 1;
+          x.fixed_mode = 1;
+          HIP_TRY(h, flacenc_hip::launch_qlpc(x, flacenc_hip::plan_qlpc_launch(block_size, 4), s));
+          dm.fixed_params = x.params;
+          dm.fixed_residual = x.residual;
+          dm.fixed_keys = x.selector_keys;
+        }
+        dm.only_marked = 1;
+        dm.marked_count = m.marked_count;
+        HIP_TRY(h, flacenc_hip::launch_channel_decide(dm, s));
+        return FLACENC_HIP_OK;
+      }
+    }
   }
   const size_t cstride = (static_cast<size_t>(block_size) + 3) & ~static_cast<size_t>(3);
   flacenc_hip::ChannelDecideArgs d{};

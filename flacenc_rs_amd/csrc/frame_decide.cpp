@@ -113,6 +113,10 @@ __global__ void __launch_bounds__(kThreads) channel_decide_kernel(ChannelDecideA
   __shared__ uint32_t skind;
   const int tid = threadIdx.x;
   const size_t sf = blockIdx.x;
+  if (a.only_marked) {  // (workgroup-uniform, in front of every barrier)
+    if (a.marked_count != nullptr && __hip_atomic_load(a.marked_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
+    if (a.results[sf].kind != 0xFF) return;
+  }
   const int n = (int)a.block_size;
   const int32_t* __restrict__ x = a.samples + sf * a.stride;
   int mn = INT32_MAX, mx = INT32_MIN;

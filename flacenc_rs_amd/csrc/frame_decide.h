@@ -57,6 +57,9 @@ struct ChannelDecideArgs {
   flacenc_hip_channel_result* results;  // out, [n_subframes]
   int32_t* residual;                    // out; subframe k at k*residual_stride
   size_t residual_stride;
+  // clean-up behind qlpc_subwave_kernel's independent-channel variant: only subframes it marked (kind 0xFF)
+  uint32_t only_marked = 0;
+  const uint32_t* marked_count = nullptr;
 };
 hipError_t launch_channel_decide(const ChannelDecideArgs& args, hipStream_t stream);
 

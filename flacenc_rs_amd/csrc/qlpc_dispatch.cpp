@@ -77,11 +77,18 @@ bool subwave_frame_eligible(const QlpcKernelArgs& a) {
   return !a.use_fixed || subwave_fixed_ok(a);
 }
 
+bool subwave_channels_eligible(const QlpcKernelArgs& a) {
+  if (!subwave_buffers_ok(a) || a.stereo || a.fixed_mode != 0 || a.chan_results == nullptr) return false;
+  if (!a.use_lpc || a.lpc_order > 12 || a.lpc_order == 0) return false;
+  return !a.use_fixed || subwave_fixed_ok(a);
+}
+
 hipError_t launch_subwave_frames(const QlpcKernelArgs& a, hipStream_t stream) {
   const int mp = a.lpc_order <= 8 ? 8 : (a.lpc_order <= 10 ? 10 : 12);
   const int spl = (a.block_size % 72u) == 0 ? 72 : 64;
+  const int var = a.stereo ? 2 : 3;
 #define FLACENC_HIP_SUBFRAMES(MP, ST, SP, V) \
-  if (V == 2 && mp == MP && spl == SP) return launch_qlpc_subwave_##MP##_##ST##_##SP##_##V(a, stream);
+  if (V == var && mp == MP && spl == SP) return launch_qlpc_subwave_##MP##_##ST##_##SP##_##V(a, stream);
   FLACENC_HIP_FOR_EACH_SUBWAVE_INSTANCE(FLACENC_HIP_SUBFRAMES)
 #undef FLACENC_HIP_SUBFRAMES
   return hipErrorInvalidValue;

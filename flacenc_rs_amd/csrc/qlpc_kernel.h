@@ -177,7 +177,8 @@ FLACENC_HIP_FOR_EACH_BIGRES_INSTANCE(FLACENC_HIP_DECLARE_BIGRES_INSTANCE)
 
 // qlpc_subwave_kernel: several subframes per wave for blocks of 8 / 16 / 32 finest Rice partitions (512 / 1024 / 2048,
 // 576 / 1152 / 2304 samples) at orders up to 12; one translation unit per (order bucket, stereo, samples per lane,
-// variant: 0 QLPC candidates, 1 fixed_lpc batch with the ApproxEnt selector, 2 the 2-channel frame decision)
+// variant: 0 QLPC candidates, 1 fixed_lpc batch with the ApproxEnt selector, 2 the 2-channel frame decision, 3 frames of
+// independent channels)
 bool subwave_shape(uint32_t block_size);
 bool subwave_eligible(const QlpcKernelArgs& args);        // variant 0
 bool subwave_fixed_eligible(const QlpcKernelArgs& args);  // variant 1 (args.fixed_mode == 1)
@@ -186,10 +187,14 @@ bool subwave_frame_eligible(const QlpcKernelArgs& args);  // variant 2 (args.fra
 // marked -- channel_assignment 0xFF, status -1 in args.cand_lpc_params / cand_fixed_params, args.marked_count -- for the
 // caller's general path
 hipError_t launch_subwave_frames(const QlpcKernelArgs& args, hipStream_t stream);
+// variant 3: Independent(n) frames (args.chan_results set, args.stereo == 0); a subframe it could not decide is marked by
+// kind 0xFF in its result (+ the scratch records and the count, as above)
+bool subwave_channels_eligible(const QlpcKernelArgs& args);
 #define FLACENC_HIP_FOR_EACH_SUBWAVE_INSTANCE(X)                                                                      \
   X(8, 0, 64, 0) X(8, 0, 72, 0) X(8, 1, 64, 0) X(8, 1, 72, 0) X(10, 0, 64, 0) X(10, 0, 72, 0) X(10, 1, 64, 0) X(10, 1, 72, 0)     \
   X(12, 0, 64, 0) X(12, 0, 72, 0) X(12, 1, 64, 0) X(12, 1, 72, 0) X(8, 0, 64, 1) X(8, 0, 72, 1) X(8, 1, 64, 1) X(8, 1, 72, 1)     \
-  X(8, 1, 64, 2) X(8, 1, 72, 2) X(10, 1, 64, 2) X(10, 1, 72, 2) X(12, 1, 64, 2) X(12, 1, 72, 2)
+  X(8, 1, 64, 2) X(8, 1, 72, 2) X(10, 1, 64, 2) X(10, 1, 72, 2) X(12, 1, 64, 2) X(12, 1, 72, 2)                                 \
+  X(8, 0, 64, 3) X(8, 0, 72, 3) X(10, 0, 64, 3) X(10, 0, 72, 3) X(12, 0, 64, 3) X(12, 0, 72, 3)
 #define FLACENC_HIP_DECLARE_SUBWAVE_INSTANCE(MP, ST, SP, V) \
   hipError_t launch_qlpc_subwave_##MP##_##ST##_##SP##_##V(const QlpcKernelArgs&, hipStream_t);
 FLACENC_HIP_FOR_EACH_SUBWAVE_INSTANCE(FLACENC_HIP_DECLARE_SUBWAVE_INSTANCE)

@@ -110,10 +110,13 @@ __device__ __forceinline__ double seg_tree_sum_last(double v) {
 // VARIANT 0: the QLPC candidate of every subframe (records + residual rows); 1: fixed_lpc with the ApproxEnt order
 // selector (coding.rs:298-331) as a batch of its own -- what the generic kernel's fixed_mode 1 produces; 2 (STEREO):
 // encode_frame for 2-channel frames -- both candidates of the four roles, encode_subframe's choice (coding.rs:384-418),
-// try_stereo_coding's assignment (:493-522), one flacenc_hip_stereo_frame_result and the TWO chosen rows per frame.
+// try_stereo_coding's assignment (:493-522), one flacenc_hip_stereo_frame_result and the TWO chosen rows per frame;
+// 3 (plain): encode_frame for Independent(n) frames (coding.rs:537-541) -- both candidates and encode_subframe's choice
+// per channel, one flacenc_hip_channel_result and the chosen row per subframe.
 template <int MAXP, bool STEREO, int SPL, int LPS, int VARIANT>
 __global__ void __launch_bounds__(STEREO ? 256 : 128, 3) qlpc_subwave_kernel(QlpcKernelArgs a) {
   static_assert(VARIANT != 2 || STEREO, "the frame decision is the 2-channel one");
+  static_assert(VARIANT != 3 || !STEREO, "independent channels are plain subframes");
   using G = SubGeom<SPL, LPS>;
   constexpr int WAVES = STEREO ? 4 : 2;
   constexpr int THREADS = 64 * WAVES;
@@ -125,7 +128,7 @@ __global__ void __launch_bounds__(STEREO ? 256 : 128, 3) qlpc_subwave_kernel(Qlp
   constexpr int n = G::N;
   constexpr bool LPC = VARIANT != 1;
   constexpr bool FIXED = VARIANT != 0;
-  constexpr bool DECIDE = VARIANT == 2;
+  constexpr bool DECIDE = VARIANT >= 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   int32_t* const sm = reinterpret_cast<int32_t*>(smem_raw);
   float* const wlds = reinterpret_cast<float*>(sm + NIMG * G::Img);
@@ -792,6 +795,49 @@ __global__ void __launch_bounds__(STEREO ? 256 : 128, 3) qlpc_subwave_kernel(Qlp
     }
     // a candidate the exact sums could not carry: the whole frame goes to the general path (launch_qlpc)
     const bool redo = (a.use_lpc && status == 0 && lp.redo) || (have_fixed && fx.redo);
+    if (VARIANT == 3) {
+      // ---- Independent(n) frames: the segment's subframe is one output channel ----
+      if (!active) return;
+      flacenc_hip_channel_result* out = a.chan_results + sf;
+      if (redo) {
+        if (sl == 0) {
+          if (a.cand_lpc_params) const_cast<flacenc_hip_subframe_params*>(a.cand_lpc_params)[sf].status = -1;
+          if (a.cand_fixed_params) const_cast<flacenc_hip_subframe_params*>(a.cand_fixed_params)[sf].status = -1;
+          out->kind = 0xFF;
+          if (a.marked_count != nullptr) atomicAdd(a.marked_count, 1u);
+        }
+        return;
+      }
+      if (sl == 0) {
+        out->kind = (uint8_t)kind;
+        out->analysis_status = (uint8_t)(a.use_lpc ? status : 0);
+        out->pad[0] = out->pad[1] = 0;
+        out->dc_offset = kind == FLACENC_HIP_KIND_CONSTANT ? role_min : 0;
+        out->bits = bits;
+      }
+      int32_t* row = a.residual + (size_t)sf * a.residual_stride;
+      flacenc_hip_subframe_params* rec = &out->params;
+      if (kind == FLACENC_HIP_KIND_LPC) {
+        store_row(row);
+        write_record(rec, lp, 0, warm, shift, a.precision, sub_bits, cq, std::integral_constant<int, MAXP>{});
+      } else if (kind == FLACENC_HIP_KIND_FIXED) {
+        fixed_error_signal(fx_order);
+        store_row(row);
+        int32_t c4[4];
+        c4[0] = fx_order;
+        c4[1] = fx_order == 2 ? -1 : (fx_order == 3 ? -3 : (fx_order == 4 ? -6 : 0));
+        c4[2] = fx_order == 3 ? 1 : (fx_order == 4 ? 4 : 0);
+        c4[3] = fx_order == 4 ? -1 : 0;
+        write_record(rec, fx, 0, fx_order, 0, 0u, fx_sub_bits, c4, std::integral_constant<int, 4>{});
+      } else {
+#pragma unroll
+        for (int k = 0; k < SPL; ++k) e[k] = 0;
+        store_row(row);
+        uint32_t* w = reinterpret_cast<uint32_t*>(rec);
+        for (int i = sl; i < (int)(sizeof(flacenc_hip_subframe_params) / 4); i += LPS) w[i] = 0u;
+      }
+      return;
+    }
     if (sl == 0) {
       xd[g * 8 + 0] = (uint32_t)bits;
       xd[g * 8 + 1] = (uint32_t)(bits >> 32);

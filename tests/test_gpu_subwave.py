@@ -248,3 +248,49 @@ def test_frames_with_candidates_beyond_the_exact_sums(handle, n):
     want, wres = orc.encode_stereo_frames_cfg(x, bps, ocfg)
     _check_frames_against_oracle(x, bps, got, gres, want, wres)
     _decode_frames(x, got, gres)
+
+
+# ------------------------------------------------------------------ Independent(n) frames (variant 3) ----
+@pytest.mark.parametrize("n", SIZES)
+@pytest.mark.parametrize("channels,bps,order,use_fixed,kw", [
+    (1, 16, 8, True, {}), (8, 16, 10, True, {}), (3, 24, 12, True, dict(fixed_partitions=8, fixed_max_order=2)),
+    (5, 16, 8, False, {}), (2, 8, 4, True, dict(fixed_partitions=32)),
+])
+def test_encode_independent_channel_frames(handle, n, channels, bps, order, use_fixed, kw):
+    """flacenc_hip_encode_frames on the sub-wave shapes (encode_frame with Independent(n), coding.rs:537-541) ==
+    encode_subframe per channel restated by the oracle, byte-identical to the general path, and the packed frames
+    parse back to the input."""
+    import flac_parse
+    x = _capi.sigen_frames(9, channels, n, bps, 150.0, 0.5, 0.04, seed=channels * 1000 + n)
+    half = 1 << (bps - 2)
+    x[1, 0] = (np.arange(n) // 9) % half          # FixedLpc territory
+    x[2, channels - 1] = -5                        # Constant
+    x[3, 0] = util.quantize(util.noise(4, n, 0.999), bps)   # Verbatim
+    x[4] = 0
+    if bps == 24:
+        x[5, 0] = np.where(np.arange(n) % 2 == 0, 2 ** 23 - 1, -2 ** 23).astype(np.int32)  # beyond the exact sums
+    mk = lambda flags: _capi.make_frame_config(_capi.make_config(lpc_order=order, flags=flags), use_fixed=use_fixed, **kw)
+    res, resid = handle.encode_frames(x, bps, mk(0))
+    gen, genres = handle.encode_frames(x, bps, mk(_capi.FLAG_GENERIC_KERNEL))
+    assert res.tobytes() == gen.tobytes() and np.array_equal(resid, genres)
+    ocfg = orc.make_frame_config(orc.make_config(lpc_order=order, acorr=orc.ACORR_CANONICAL), use_fixed=use_fixed,
+                                 fixed=orc.make_fixed_config(max_order=kw.get("fixed_max_order", 4),
+                                                             partitions=kw.get("fixed_partitions", 16),
+                                                             sum_mode=orc.SUMABS_CANONICAL))
+    packed = handle.pack_frames(x, res, resid, bps, 44100, 70, 1)
+    kinds = set()
+    for f in range(x.shape[0]):
+        for c in range(channels):
+            w = orc.encode_subframe(x[f, c], bps, ocfg)
+            g = res[f, c]
+            assert int(g["kind"]) == w["kind"] and int(g["bits"]) == w["bits"], (f, c)
+            kinds.add(w["kind"])
+            if w["kind"] >= 2:
+                src = w["lpc"] if w["kind"] == 3 else w["fixed"]
+                assert int(g["params"]["subframe_bits"]) == int(src.subframe_bits) == w["bits"]
+                assert np.array_equal(resid[f, c], w["residual"]), (f, c)
+            else:
+                assert not resid[f, c].any()
+        got = flac_parse.parse_frame(packed[f], stream_bps=bps)
+        assert got["channel_tag"] == channels - 1 and np.array_equal(got["channels"], x[f]), f
+    assert {0, 1} <= kinds and (kinds & {2, 3})

@@ -155,6 +155,7 @@ run_stereo_frames("frames: 2048 x 16b stereo, default candidates, order 8 (sub-w
 run_stereo_frames("frames: 4096 x 16b stereo, default candidates, order 10 (fused wave kernel)", 8192, 4096, 16, 10)
 run_frames("config4: 4096 x 16b 8-channel, default config, frames", 2048, 8, 4096, 16, 10)
 run_frames("mono: 4096 x 16b, default config, frames", 8192, 1, 4096, 16, 10)
+run_frames("1152 x 16b 8-channel, default config, frames (sub-wave kernel, one launch + the packer)", 2048, 8, 1152, 16, 10)
 
 print(json.dumps({"tool": "tools/bench_configs.py", "timing": "HIP events around 5 calls after 2 warm-up calls and 50 ms of untimed clock spin-up, device-resident data",
                   "rows": ROWS}, indent=1))

@@ -1,5 +1,5 @@
 """Fuzz of the sub-wave kernel (blocks of 512 / 1024 / 2048 / 576 / 1152 / 2304 samples) against the generic kernel it
-replaces (FLACENC_HIP_FLAG_GENERIC_KERNEL: byte-identical records, rows, keys and frame results required) and, every
+replaces (FLACENC_HIP_FLAG_GENERIC_KERNEL: byte-identical records, rows, keys and frame results and channel results required) and, every
 `--oracle-every` seeds, against the CPU oracle: python tools/fuzz_subwave.py <seed lo> <seed hi> [--oracle-every N]"""
 import os
 import sys
@@ -103,6 +103,13 @@ def main():
             got, gres = h.encode_stereo_frames(x, bps, f0)
             gen, genres = h.encode_stereo_frames(x, bps, f1)
             assert got.tobytes() == gen.tobytes() and np.array_equal(gres, genres), "frames"
+            chn = int(rng.choice([1, 3, 8]))
+            nfc = (nf * 2) // chn
+            if nfc:
+                xc = flat[: nfc * chn].reshape(nfc, chn, n)
+                cr, crr = h.encode_frames(xc, bps, f0)
+                cg, cgr = h.encode_frames(xc, bps, f1)
+                assert cr.tobytes() == cg.tobytes() and np.array_equal(crr, cgr), "independent-channel frames"
             marked += int((np.abs(x.astype(np.int64)).max(axis=(1, 2)) >= (1 << 22)).sum())
             if seed % oracle_every == 0:
                 okw = {k: v for k, v in fkw.items() if not k.startswith("fixed_")}

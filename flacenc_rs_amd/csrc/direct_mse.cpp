@@ -372,6 +372,13 @@ __global__ void __launch_bounds__(576) direct_mse_kernel(DirectMseArgs a) {
     }
     __syncthreads();
     if (it == steps && a.autocorr && tid <= 32 && !IRLS) a.autocorr[(size_t)sf * 33 + tid] = tid <= P ? corr[tid] : 0.0;
+    if (!IRLS && a.gram_scratch != nullptr) {
+      // the chains' results go to HBM; direct_mse_solve_kernel takes it from here, a lane per subframe
+      double* __restrict__ out = a.gram_scratch + (size_t)sf * direct_mse_gram_stride((uint32_t)P);
+      for (int c = tid; c < 33; c += nthr) out[c] = c <= P ? corr[c] : 0.0;
+      for (int c = tid; c < P * P; c += nthr) out[33 + c] = gram[c];
+      return;
+    }
 
     // ---- solve_sym_mut with the regulariser loop (lpc.rs:887-896), wave 0, lane = matrix row ----
     if (tid < 64) {
@@ -565,6 +572,292 @@ __global__ void __launch_bounds__(576) direct_mse_kernel(DirectMseArgs a) {
   }
 }
 
+// The chains of orders up to 11 without IRLS steps, ONE WAVE per subframe and a SLIDING f64 window instead of the whole
+// block in LDS: the 4 x 4 x 4 block form above spends its time waiting -- one wave per workgroup, 16 KB of image per
+// subframe (eight workgroups per CU), a conversion for every operand of every step -- where this kernel keeps 4.2 KB
+// (528 doubles: 512 steps' samples + the P + 3 ahead of them), converts each sample once when it enters the window and
+// fetches the next 512 samples into registers before it walks the current ones; 24 and more workgroups fit a CU.
+// The chain itself -- v_mfma_f64_4x4x4_4b_f64 through its C operand, k ascending -- is the same, operand for operand.
+constexpr int kStreamPiece = 512;
+template <bool STEREO>
+__global__ void __launch_bounds__(64) direct_mse_stream_kernel(DirectMseArgs a) {
+  __shared__ __attribute__((aligned(16))) double win[kStreamPiece + 16];
+  const int lane = threadIdx.x;
+  const int n = (int)a.block_size;
+  const int P = (int)a.lpc_order;
+  const uint32_t sf = blockIdx.x;
+  const float* __restrict__ wtab = a.window ? a.window + 32 : nullptr;
+  const int32_t* rowA;
+  const int32_t* rowB = nullptr;
+  int kind = 0;
+  if (STEREO) {
+    const uint32_t frame = sf >> 2;
+    kind = (int)(sf & 3u);
+    rowA = a.samples + (size_t)(2u * frame + (kind == 1 ? 1u : 0u)) * a.stride;
+    rowB = a.samples + (size_t)(2u * frame + 1u) * a.stride;
+  } else {
+    rowA = a.samples + (size_t)sf * a.stride;
+  }
+  double* __restrict__ out = a.gram_scratch + (size_t)sf * direct_mse_gram_stride((uint32_t)P);
+  if (n < P + 1) {  // (lpc.rs:860-862: nothing to estimate from)
+    for (int c = lane; c < 33 + P * P; c += 64) out[c] = 0.0;
+    if (a.autocorr && lane <= 32) a.autocorr[(size_t)sf * 33 + lane] = 0.0;
+    return;
+  }
+  // x_w = (f32)s * w, one f32 rounding (lpc.rs:751-754), widened once; samples [4 q, 4 q + 4), zeros behind the block
+  struct Quad {
+    int4 va, vb;
+  };
+  auto fetch = [&](int q) -> Quad {  // (rows are 16-byte aligned with a stride of whole quads: the launcher checks)
+    Quad r;
+    r.va = r.vb = make_int4(0, 0, 0, 0);
+    if (4 * q + 3 < n) {
+      r.va = *reinterpret_cast<const int4*>(rowA + 4 * q);
+      if (STEREO && kind >= 2) r.vb = *reinterpret_cast<const int4*>(rowB + 4 * q);
+    } else if (4 * q < n) {
+      int32_t ta[4] = {0, 0, 0, 0}, tb[4] = {0, 0, 0, 0};
+      for (int u = 0; u < 4 && 4 * q + u < n; ++u) {
+        ta[u] = rowA[4 * q + u];
+        if (STEREO && kind >= 2) tb[u] = rowB[4 * q + u];
+      }
+      r.va = make_int4(ta[0], ta[1], ta[2], ta[3]);
+      r.vb = make_int4(tb[0], tb[1], tb[2], tb[3]);
+    }
+    return r;
+  };
+  auto place = [&](int q, const Quad& r, int at) {  // -> win[at .. at + 4)
+    int4 v = r.va;
+    if (STEREO && kind == 2) v = make_int4((r.va.x + r.vb.x) >> 1, (r.va.y + r.vb.y) >> 1, (r.va.z + r.vb.z) >> 1, (r.va.w + r.vb.w) >> 1);
+    if (STEREO && kind == 3) v = make_int4(r.va.x - r.vb.x, r.va.y - r.vb.y, r.va.z - r.vb.z, r.va.w - r.vb.w);  // coding.rs:483
+    float4 w4 = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+    if (wtab && 4 * q + 3 < n) w4 = *reinterpret_cast<const float4*>(wtab + 4 * q);
+    else if (wtab) {
+      float tw[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+      for (int u = 0; u < 4 && 4 * q + u < n; ++u) tw[u] = wtab[4 * q + u];
+      w4 = make_float4(tw[0], tw[1], tw[2], tw[3]);
+    }
+    *reinterpret_cast<double2*>(&win[at]) = make_double2((double)((float)v.x * w4.x), (double)((float)v.y * w4.y));
+    *reinterpret_cast<double2*>(&win[at + 2]) = make_double2((double)((float)v.z * w4.z), (double)((float)v.w * w4.w));
+  };
+  // lane -> operand elements, as in the block form of direct_mse_kernel
+  const int len = n - P;
+  const int NB = (P + 1 + 3) >> 2;  // 1..3
+  const int kq = lane >> 4, bs = (lane >> 2) & 3, r = lane & 3;
+  auto blk = [&](int q, int slot, int& I, int& J) {
+    if (NB <= 2) {  // (0,0) (0,1) (1,1) (1,0)
+      I = slot == 2 || slot == 3 ? 1 : 0;
+      J = slot == 1 || slot == 2 ? 1 : 0;
+    } else if (q == 0) {  // (0,0) (0,1) (0,2) (1,1)
+      I = slot == 3 ? 1 : 0;
+      J = slot == 3 ? 1 : slot;
+    } else {  // (1,2) (2,2) (1,0) (2,0)
+      I = slot == 0 || slot == 2 ? 1 : 2;
+      J = slot < 2 ? 2 : 0;
+    }
+  };
+  const int NI = NB <= 2 ? 1 : 2;
+  int I0, J0, I1 = 0, J1 = 0;
+  blk(0, bs, I0, J0);
+  if (NI > 1) blk(1, bs, I1, J1);
+  auto offs = [&](int I, int J, int& oa, int& ob) {
+    int arow = 4 * I + r, bcol = 4 * J + r;
+    arow = arow > P ? P : arow;
+    bcol = bcol > P ? P : bcol;
+    oa = (P - arow) + kq;  // step k reads x_w[(P - row) + k + kq]
+    ob = (P - bcol) + kq;
+  };
+  int oa0, ob0, oa1, ob1;
+  offs(I0, J0, oa0, ob0);
+  offs(I1, J1, oa1, ob1);
+  double acc0 = 0.0, acc1 = 0.0;
+  // window = samples [base, base + 512 + 16): two quads and a bit per lane
+  Quad nx[3];
+#pragma unroll
+  for (int u = 0; u < 3; ++u) {
+    const int q = lane + 64 * u;
+    if (q < (kStreamPiece + 16) / 4) place(q, fetch(q), 4 * q);
+  }
+  __builtin_amdgcn_wave_barrier();
+  for (int base = 0; base < len; base += kStreamPiece) {
+    // the next 512 samples (behind the 16 already ahead) on their way while this piece is walked
+    const bool more = base + kStreamPiece < len;
+    if (more) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) nx[u] = fetch((base + kStreamPiece + 16) / 4 + lane + 64 * u);
+    }
+    const int steps_here = (len - base) < kStreamPiece ? (len - base) : kStreamPiece;
+    const double* __restrict__ pa0 = win + oa0;
+    const double* __restrict__ pb0 = win + ob0;
+    const double* __restrict__ pa1 = win + oa1;
+    const double* __restrict__ pb1 = win + ob1;
+    auto step = [&](int kk) __attribute__((always_inline)) {
+      acc0 = __builtin_amdgcn_mfma_f64_4x4x4f64(pa0[kk], pb0[kk], acc0, 0, 0, 0);
+      if (NI > 1) acc1 = __builtin_amdgcn_mfma_f64_4x4x4f64(pa1[kk], pb1[kk], acc1, 0, 0, 0);
+    };
+    int k = 0;
+    for (; k + 32 <= steps_here; k += 32) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) step(k + 4 * u);
+    }
+    for (; k + 4 <= steps_here; k += 4) step(k);
+    if (k < steps_here) {  // the block's last one to three steps: the missing ones multiply by 0 (x + 0 * y == x)
+      const bool in = k + kq < steps_here;
+      acc0 = __builtin_amdgcn_mfma_f64_4x4x4f64(in ? pa0[k] : 0.0, in ? pb0[k] : 0.0, acc0, 0, 0, 0);
+      if (NI > 1) acc1 = __builtin_amdgcn_mfma_f64_4x4x4f64(in ? pa1[k] : 0.0, in ? pb1[k] : 0.0, acc1, 0, 0, 0);
+    }
+    if (more) {
+      __builtin_amdgcn_wave_barrier();  // (LDS operations of one wave complete in order; the compiler must not move them)
+      if (lane < 4) {
+        const double2 t0 = *reinterpret_cast<const double2*>(&win[kStreamPiece + 4 * lane]);
+        const double2 t1 = *reinterpret_cast<const double2*>(&win[kStreamPiece + 4 * lane + 2]);
+        *reinterpret_cast<double2*>(&win[4 * lane]) = t0;
+        *reinterpret_cast<double2*>(&win[4 * lane + 2]) = t1;
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) place((base + kStreamPiece + 16) / 4 + lane + 64 * u, nx[u], 16 + 4 * (lane + 64 * u));
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  // D_b[i][j] sits in lane 16 i + 4 b + j
+  const int oi = lane >> 4, oj = lane & 3;
+  auto put = [&](int I, int J, double v) {
+    const int ra = 4 * I + oi, cb = 4 * J + oj;
+    if (cb == 0 && ra <= P) {
+      out[ra] = v;
+      if (a.autocorr) a.autocorr[(size_t)sf * 33 + ra] = v;
+    } else if (ra >= 1 && ra <= cb && cb <= P) {
+      out[33 + (ra - 1) + (cb - 1) * P] = v;
+      out[33 + (cb - 1) + (ra - 1) * P] = v;
+    }
+  };
+  put(I0, J0, acc0);
+  if (NI > 1) put(I1, J1, acc1);
+  if (lane > P && lane <= 32) {
+    out[lane] = 0.0;
+    if (a.autocorr) a.autocorr[(size_t)sf * 33 + lane] = 0.0;
+  }
+}
+
+// solve_sym_mut with the regulariser loop (lpc.rs:887-896: nalgebra's Cholesky, restated in the oracle's
+// orc_cholesky_solve) + quantize_parameters (lpc.rs:273-302) for a batch, ONE SUBFRAME PER LANE: every operation of a
+// subframe's sequence is the lane's own, in the reference's order; the matrices live in LDS, element k of lane l at
+// k * LW + l.  LW = lanes in use per 64-thread workgroup = what 64 KB hold of (P * P + 2 P) doubles per subframe.
+__global__ void __launch_bounds__(64) direct_mse_solve_kernel(DirectMseArgs a, int LW) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int lane = threadIdx.x;
+  const int P = (int)a.lpc_order;
+  const uint32_t sf = blockIdx.x * (uint32_t)LW + (uint32_t)lane;
+  if (lane >= LW || sf >= a.n_subframes) return;  // (no barriers below: lanes are independent)
+  double* const m = reinterpret_cast<double*>(smem_raw) + lane;        // [P * P]
+  double* const v = m + (size_t)P * P * LW;                            // [P]
+  double* const diag = v + (size_t)P * LW;                             // [P]: the diagonal with the regulariser added so far
+#define M_(r, c) m[(size_t)((r) + (c) * P) * LW]
+#define V_(i) v[(size_t)(i) * LW]
+  const double* __restrict__ g = a.gram_scratch + (size_t)sf * direct_mse_gram_stride((uint32_t)P);
+  for (int i = 0; i < P; ++i) diag[(size_t)i * LW] = g[33 + i + i * P];
+  int status = 0;
+  double regularizer = 0.0;
+  int tries = 0;
+  for (;;) {
+    // mat.clone(); xy = corr[1..]
+    for (int c = 0; c < P; ++c)
+      for (int r = 0; r < P; ++r) M_(r, c) = r == c ? diag[(size_t)r * LW] : g[33 + r + c * P];
+    for (int i = 0; i < P; ++i) V_(i) = g[i + 1];
+    bool ok = true;
+    for (int j = 0; j < P && ok; ++j) {
+      for (int k = 0; k < j; ++k) {
+        const double factor = -M_(j, k);
+        for (int r = j; r < P; ++r) {
+          const double ax = factor * M_(r, k);
+          M_(r, j) = ax + M_(r, j);  // array_axcpy: (a * x) * 1 + 1 * y, no fma
+        }
+      }
+      const double dj = M_(j, j);
+      if (dj == 0.0 || !(dj >= 0.0)) {  // is_zero() / try_sqrt() == None
+        ok = false;
+        break;
+      }
+      const double denom = __builtin_sqrt(dj);
+      M_(j, j) = denom;
+      for (int r = j + 1; r < P; ++r) M_(r, j) = M_(r, j) / denom;
+    }
+    if (ok) {
+      // solve_lower_triangular_vector_unchecked_mut
+      for (int i = 0; i < P; ++i) {
+        const double coeff = V_(i) / M_(i, i);
+        V_(i) = coeff;
+        const double na = -coeff;
+        for (int r = i + 1; r < P; ++r) V_(r) = (na * M_(r, i)) + V_(r);
+      }
+      // ad_solve_lower_triangular: b[i] = (b[i] - dot(L[i+1.., i], b[i+1..])) / L[i][i], dotx's eight accumulators
+      for (int i = P - 1; i >= 0; --i) {
+        const int rows = P - (i + 1);
+        double acc8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        double res = 0.0;
+        int q = 0;
+        while (rows - q >= 8) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) acc8[u] += M_(i + 1 + q + u, i) * V_(i + 1 + q + u);
+          q += 8;
+        }
+        res += acc8[0] + acc8[4];
+        res += acc8[1] + acc8[5];
+        res += acc8[2] + acc8[6];
+        res += acc8[3] + acc8[7];
+        for (int k = q; k < rows; ++k) res += M_(i + 1 + k, i) * V_(i + 1 + k);
+        V_(i) = (V_(i) - res) / M_(i, i);
+      }
+      break;
+    }
+    // regularizer = max(1, 2 regularizer); diag += regularizer - old (lpc.rs:889-895)
+    const double old = regularizer;
+    const double twice = regularizer + regularizer;
+    regularizer = 1.0 > twice ? 1.0 : twice;
+    for (int i = 0; i < P; ++i) diag[(size_t)i * LW] += regularizer - old;
+    if (++tries > 2000) {  // (NaN input: the reference would not terminate)
+      status = FLACENC_HIP_SUBFRAME_NONFINITE;
+      for (int i = 0; i < P; ++i) V_(i) = 0.0;
+      break;
+    }
+  }
+  // ---- quantize_parameters, lpc.rs:273-302 (find_shift :234-254, quantize_parameter :258-270) ----
+  for (int i = 0; i < P; ++i) {
+    const uint64_t b = (uint64_t)__double_as_longlong(V_(i));
+    if (((b >> 52) & 0x7FF) == 0x7FF) status |= FLACENC_HIP_SUBFRAME_NONFINITE;
+  }
+  int32_t* pr = a.pred_out + (size_t)sf * 36;
+  for (int i = 0; i < 36; ++i) pr[i] = 0;
+  int shift = 0, order = 0;
+  if (status == 0) {
+    double max_abs = 0.0;
+    for (int i = 0; i < P; ++i) max_abs = fmax(max_abs, fabs(V_(i)));
+    int abs_log2 = dm_ceil_log2_pos(max_abs);
+    if (abs_log2 < -32752) abs_log2 = -32752;
+    const int precision = (int)a.precision;
+    shift = (precision - 1) - abs_log2;
+    shift = shift < 0 ? 0 : (shift > 15 ? 15 : shift);
+    const double scalefac = (double)(1 << shift);
+    const int lo = -(1 << (precision - 1)), hi = (1 << (precision - 1)) - 1;
+    order = 1;
+    for (int i = 0; i < P; ++i) {
+      double s = round(V_(i) * scalefac);  // half away from zero
+      s = s < -32768.0 ? -32768.0 : (s > 32767.0 ? 32767.0 : s);
+      int q = (int)s;
+      q = q < lo ? lo : (q > hi ? hi : q);
+      pr[i] = q;
+      if (q != 0) order = i + 1;  // tail-zero truncation, min 1
+    }
+    for (int i = order; i < P; ++i) pr[i] = 0;
+  }
+  pr[32] = order;
+  pr[33] = shift;
+  pr[34] = status;
+  if (a.lpc_coefs)
+    for (int i = 0; i < 32; ++i) a.lpc_coefs[(size_t)sf * 32 + i] = (i < P && status == 0) ? V_(i) : 0.0;
+#undef M_
+#undef V_
+}
+
 }  // namespace
 
 size_t direct_mse_lds_bytes(uint32_t block_size, bool irls, uint32_t order) {
@@ -581,6 +874,25 @@ hipError_t launch_direct_mse(const DirectMseArgs& a, hipStream_t stream) {
   if (a.lpc_order < 1 || a.lpc_order > 32) return hipErrorInvalidValue;
   if (a.stereo && (a.n_subframes & 3u)) return hipErrorInvalidValue;
   const bool irls = a.mae_steps > 0;
+  auto launch_solve = [&]() -> hipError_t {
+    const size_t per = ((size_t)a.lpc_order * a.lpc_order + 2 * a.lpc_order) * 8;  // LDS per subframe
+    int lw = 64;
+    while (lw > 1 && per * (size_t)lw > 64 * 1024) lw >>= 1;
+    const size_t solve_smem = per * (size_t)lw;
+    static DynamicLdsOptIn solve_opt;
+    if (hipError_t e = solve_opt.ensure(reinterpret_cast<const void*>(direct_mse_solve_kernel), solve_smem); e != hipSuccess) return e;
+    hipLaunchKernelGGL(direct_mse_solve_kernel, dim3((a.n_subframes + (uint32_t)lw - 1u) / (uint32_t)lw), dim3(64), solve_smem, stream,
+                       a, lw);
+    return hipGetLastError();
+  };
+  if (!irls && a.gram_scratch != nullptr && a.lpc_order <= 11 && (reinterpret_cast<uintptr_t>(a.samples) & 15) == 0 &&
+      (a.stride & 3) == 0) {
+    // orders up to 11: the sliding-window chains, then the batched solve
+    if (a.stereo) hipLaunchKernelGGL(direct_mse_stream_kernel<true>, dim3(a.n_subframes), dim3(64), 0, stream, a);
+    else hipLaunchKernelGGL(direct_mse_stream_kernel<false>, dim3(a.n_subframes), dim3(64), 0, stream, a);
+    if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+    return launch_solve();
+  }
   const size_t smem = direct_mse_lds_bytes(a.block_size, irls, a.lpc_order);
   if (smem > 160 * 1024) return hipErrorNotSupported;
   const uint32_t P = a.lpc_order;
@@ -601,7 +913,9 @@ hipError_t launch_direct_mse(const DirectMseArgs& a, hipStream_t stream) {
     if (wg) FLACENC_DM_LAUNCH(false, true, 5, true) else if (irls) FLACENC_DM_LAUNCH(false, true, 2, false) else FLACENC_DM_LAUNCH(false, false, 3, false)
   }
 #undef FLACENC_DM_LAUNCH
-  return hipGetLastError();
+  if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+  if (!irls && a.gram_scratch != nullptr) return launch_solve();
+  return hipSuccess;
 }
 
 }  // namespace flacenc_hip

@@ -23,7 +23,13 @@ struct DirectMseArgs {
   double* autocorr;        // device, nullable, [n][33]: R[0..=P] (of the chosen IRLS step)
   double* lpc_coefs;       // device, nullable, [n][32]: the unquantised solution
   float* weight_scratch;   // device, [n][(block_size + 3) & ~3] floats: the IRLS weights of blocks above 16384 samples (else unused)
+  // Without IRLS steps and with this scratch ([n][direct_mse_gram_stride(order)] doubles: R[0..32], then the order x order
+  // matrix column-major), the chains' kernel stops behind them and direct_mse_solve_kernel factorises, solves and
+  // quantises with a LANE per subframe; nullptr: everything in the one kernel, as with IRLS.
+  double* gram_scratch;
 };
+
+__host__ __device__ inline size_t direct_mse_gram_stride(uint32_t order) { return (33u + (size_t)order * order + 1u) & ~(size_t)1; }
 
 size_t direct_mse_lds_bytes(uint32_t block_size, bool irls, uint32_t order);
 // perform_qlpc's experimental branches (src/coding.rs:337-347) for a batch, one workgroup per subframe;

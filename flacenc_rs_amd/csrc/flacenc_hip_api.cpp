@@ -134,7 +134,7 @@ struct flacenc_hip_handle {
   hipStream_t stream = nullptr;
   std::string last_error;
   std::vector<WindowEntry> windows;
-  DeviceBuffer d_samples, d_residual, d_params, d_bps, d_autocorr, d_lpc, d_tables, d_keys, d_sel, d_results, d_out, d_outlen, d_cparams, d_cresid, d_fparams, d_fresid, d_fkeys, d_split, d_presid, d_sumabs, d_minmax, d_marked, d_irlsw;
+  DeviceBuffer d_samples, d_residual, d_params, d_bps, d_autocorr, d_lpc, d_tables, d_keys, d_sel, d_results, d_out, d_outlen, d_cparams, d_cresid, d_fparams, d_fresid, d_fkeys, d_split, d_presid, d_sumabs, d_minmax, d_marked, d_irlsw, d_gram;
   // streaming host path (flacenc_hip_encode_pcm_stereo): copy-in / copy-out streams, two slots of pinned
   // staging and device buffers, the events that order them
   uint32_t marked_parity = 0;  // which of d_marked's two counters the current pipeline counts into
@@ -378,6 +378,12 @@ int enqueue(flacenc_hip_handle* h, const flacenc_hip_qlpc_config* cfg, const int
   if (a.direct_mse && flacenc_hip::direct_mse_lds_bytes(block_size, a.mae_steps > 0, cfg->lpc_order) > 160 * 1024) {
     h->last_error = "use_direct_mse: the block does not fit the LDS";  // (not for any block up to 32767 samples)
     return FLACENC_HIP_ERR_UNSUPPORTED;
+  }
+  if (a.direct_mse && a.mae_steps == 0) {
+    // (R[] and the matrix between the chains and the lane-per-subframe solve)
+    rc = ensure(h, h->d_gram, n_subframes * flacenc_hip::direct_mse_gram_stride(cfg->lpc_order) * sizeof(double));
+    if (rc != FLACENC_HIP_OK) return rc;
+    a.direct_mse_scratch = static_cast<double*>(h->d_gram.ptr);
   }
   if (a.direct_mse && a.mae_steps > 0 && block_size > 16384) {
     // lpc_with_irls_mae (lpc.rs:814-850) has no block limit: above 16384 samples the weights live in HBM scratch
@@ -687,7 +693,7 @@ void flacenc_hip_destroy(flacenc_hip_handle* h) {
     if (e.dev) (void)hipFree(e.dev);
   for (DeviceBuffer* b : {&h->d_samples, &h->d_residual, &h->d_params, &h->d_bps, &h->d_autocorr,
                           &h->d_lpc, &h->d_tables, &h->d_keys, &h->d_sel, &h->d_results, &h->d_out, &h->d_outlen, &h->d_cparams, &h->d_cresid,
-                          &h->d_fparams, &h->d_fresid, &h->d_fkeys, &h->d_split, &h->d_presid, &h->d_sumabs, &h->d_minmax, &h->d_marked, &h->d_irlsw})
+                          &h->d_fparams, &h->d_fresid, &h->d_fkeys, &h->d_split, &h->d_presid, &h->d_sumabs, &h->d_minmax, &h->d_marked, &h->d_irlsw, &h->d_gram})
     if (b->ptr) (void)hipFree(b->ptr);
   for (int i = 0; i < 2; ++i) {
     for (DeviceBuffer* b : {&h->d_pcm[i], &h->d_pack[i], &h->d_plen[i], &h->d_poff[i], &h->d_cont[i]})

@@ -189,6 +189,7 @@ hipError_t launch_qlpc(const QlpcKernelArgs& a, const QlpcLaunchPlan& plan, hipS
     d.autocorr = a.autocorr;
     d.lpc_coefs = a.lpc_coefs;
     d.weight_scratch = a.irls_weight_scratch;
+    d.gram_scratch = a.mae_steps == 0 ? a.direct_mse_scratch : nullptr;
     hipError_t err = launch_direct_mse(d, stream);
     if (err != hipSuccess) return err;
     QlpcKernelArgs s3 = a;

@@ -51,6 +51,7 @@ struct QlpcKernelArgs {
   // autocorrelation + Levinson; launch_qlpc runs it into split_scratch and continues with the residual kernels
   uint32_t direct_mse = 0;
   uint32_t mae_steps = 0;
+  double* direct_mse_scratch = nullptr;  // device, n * direct_mse_gram_stride(order) doubles: R[] and the matrix between direct_mse_kernel's chains and the batched solve (no IRLS steps)
   float* irls_weight_scratch = nullptr;  // device, n * ((block_size + 3) & ~3) floats: IRLS weights of blocks above 16384 samples
   // Frame-level calls on the big-block shapes (bigblock_residual_kernel, stereo): the candidates of roles L and R
   // go straight to the OUTPUT rows 2f and 2f + 1 (L can only ever fill output channel 0, R only channel 1:

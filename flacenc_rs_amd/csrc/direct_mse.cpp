@@ -578,10 +578,15 @@ __global__ void __launch_bounds__(576) direct_mse_kernel(DirectMseArgs a) {
 // (528 doubles: 512 steps' samples + the P + 3 ahead of them), converts each sample once when it enters the window and
 // fetches the next 512 samples into registers before it walks the current ones; 24 and more workgroups fit a CU.
 // The chain itself -- v_mfma_f64_4x4x4_4b_f64 through its C operand, k ascending -- is the same, operand for operand.
+// WEIGHTED (IRLS steps after the first): B[k][b] = f32(w * y_b) (lpc.rs:463-470) -- the weights' window and an f32 copy
+// of the samples' ride along, the product and its widening stay in the loop; a subframe whose estimate already failed
+// is skipped.
 constexpr int kStreamPiece = 512;
-template <bool STEREO>
+template <bool STEREO, bool WEIGHTED = false>
 __global__ void __launch_bounds__(64) direct_mse_stream_kernel(DirectMseArgs a) {
   __shared__ __attribute__((aligned(16))) double win[kStreamPiece + 16];
+  __shared__ __attribute__((aligned(16))) float xf[WEIGHTED ? kStreamPiece + 16 : 4];
+  __shared__ __attribute__((aligned(16))) float ww[WEIGHTED ? kStreamPiece + 16 : 4];
   const int lane = threadIdx.x;
   const int n = (int)a.block_size;
   const int P = (int)a.lpc_order;
@@ -599,18 +604,24 @@ __global__ void __launch_bounds__(64) direct_mse_stream_kernel(DirectMseArgs a) 
     rowA = a.samples + (size_t)sf * a.stride;
   }
   double* __restrict__ out = a.gram_scratch + (size_t)sf * direct_mse_gram_stride((uint32_t)P);
+  const bool irls = a.irls_state != nullptr;  // (then R[] reaches a.autocorr through the error pass: the best step's)
+  if (irls && a.irls_step > 0 && a.irls_state[(size_t)sf * kIrlsStateDoubles + 66] != 0.0) return;  // the estimate failed in an earlier step
+  const float* __restrict__ wsrc = WEIGHTED ? a.irls_weights + (size_t)sf * (((size_t)n + 3) & ~(size_t)3) : nullptr;
   if (n < P + 1) {  // (lpc.rs:860-862: nothing to estimate from)
     for (int c = lane; c < 33 + P * P; c += 64) out[c] = 0.0;
-    if (a.autocorr && lane <= 32) a.autocorr[(size_t)sf * 33 + lane] = 0.0;
+    if (a.autocorr && !irls && lane <= 32) a.autocorr[(size_t)sf * 33 + lane] = 0.0;
     return;
   }
   // x_w = (f32)s * w, one f32 rounding (lpc.rs:751-754), widened once; samples [4 q, 4 q + 4), zeros behind the block
   struct Quad {
     int4 va, vb;
+    float4 wt;
   };
   auto fetch = [&](int q) -> Quad {  // (rows are 16-byte aligned with a stride of whole quads: the launcher checks)
     Quad r;
     r.va = r.vb = make_int4(0, 0, 0, 0);
+    r.wt = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (WEIGHTED && 4 * q < n) r.wt = *reinterpret_cast<const float4*>(wsrc + 4 * q);  // (rows of whole quads)
     if (4 * q + 3 < n) {
       r.va = *reinterpret_cast<const int4*>(rowA + 4 * q);
       if (STEREO && kind >= 2) r.vb = *reinterpret_cast<const int4*>(rowB + 4 * q);
@@ -636,8 +647,13 @@ __global__ void __launch_bounds__(64) direct_mse_stream_kernel(DirectMseArgs a) 
       for (int u = 0; u < 4 && 4 * q + u < n; ++u) tw[u] = wtab[4 * q + u];
       w4 = make_float4(tw[0], tw[1], tw[2], tw[3]);
     }
-    *reinterpret_cast<double2*>(&win[at]) = make_double2((double)((float)v.x * w4.x), (double)((float)v.y * w4.y));
-    *reinterpret_cast<double2*>(&win[at + 2]) = make_double2((double)((float)v.z * w4.z), (double)((float)v.w * w4.w));
+    const float4 xv = make_float4((float)v.x * w4.x, (float)v.y * w4.y, (float)v.z * w4.z, (float)v.w * w4.w);
+    *reinterpret_cast<double2*>(&win[at]) = make_double2((double)xv.x, (double)xv.y);
+    *reinterpret_cast<double2*>(&win[at + 2]) = make_double2((double)xv.z, (double)xv.w);
+    if (WEIGHTED) {
+      *reinterpret_cast<float4*>(&xf[at]) = xv;
+      *reinterpret_cast<float4*>(&ww[at]) = r.wt;
+    }
   };
   // lane -> operand elements, as in the block form of direct_mse_kernel
   const int len = n - P;
@@ -690,9 +706,18 @@ __global__ void __launch_bounds__(64) direct_mse_stream_kernel(DirectMseArgs a) 
     const double* __restrict__ pb0 = win + ob0;
     const double* __restrict__ pa1 = win + oa1;
     const double* __restrict__ pb1 = win + ob1;
+    const float* __restrict__ fb0 = xf + ob0;
+    const float* __restrict__ fb1 = xf + ob1;
+    const float* __restrict__ pw = ww + P + kq;  // w[t' + 1]
     auto step = [&](int kk) __attribute__((always_inline)) {
-      acc0 = __builtin_amdgcn_mfma_f64_4x4x4f64(pa0[kk], pb0[kk], acc0, 0, 0, 0);
-      if (NI > 1) acc1 = __builtin_amdgcn_mfma_f64_4x4x4f64(pa1[kk], pb1[kk], acc1, 0, 0, 0);
+      if (WEIGHTED) {
+        const float wk = pw[kk];
+        acc0 = __builtin_amdgcn_mfma_f64_4x4x4f64(pa0[kk], (double)(wk * fb0[kk]), acc0, 0, 0, 0);
+        if (NI > 1) acc1 = __builtin_amdgcn_mfma_f64_4x4x4f64(pa1[kk], (double)(wk * fb1[kk]), acc1, 0, 0, 0);
+      } else {
+        acc0 = __builtin_amdgcn_mfma_f64_4x4x4f64(pa0[kk], pb0[kk], acc0, 0, 0, 0);
+        if (NI > 1) acc1 = __builtin_amdgcn_mfma_f64_4x4x4f64(pa1[kk], pb1[kk], acc1, 0, 0, 0);
+      }
     };
     int k = 0;
     for (; k + 32 <= steps_here; k += 32) {
@@ -702,8 +727,11 @@ __global__ void __launch_bounds__(64) direct_mse_stream_kernel(DirectMseArgs a) 
     for (; k + 4 <= steps_here; k += 4) step(k);
     if (k < steps_here) {  // the block's last one to three steps: the missing ones multiply by 0 (x + 0 * y == x)
       const bool in = k + kq < steps_here;
-      acc0 = __builtin_amdgcn_mfma_f64_4x4x4f64(in ? pa0[k] : 0.0, in ? pb0[k] : 0.0, acc0, 0, 0, 0);
-      if (NI > 1) acc1 = __builtin_amdgcn_mfma_f64_4x4x4f64(in ? pa1[k] : 0.0, in ? pb1[k] : 0.0, acc1, 0, 0, 0);
+      const float wk = (WEIGHTED && in) ? pw[k] : 0.0f;
+      const double b0 = !in ? 0.0 : (WEIGHTED ? (double)(wk * fb0[k]) : pb0[k]);
+      const double b1 = !in ? 0.0 : (WEIGHTED ? (double)(wk * fb1[k]) : pb1[k]);
+      acc0 = __builtin_amdgcn_mfma_f64_4x4x4f64(in ? pa0[k] : 0.0, b0, acc0, 0, 0, 0);
+      if (NI > 1) acc1 = __builtin_amdgcn_mfma_f64_4x4x4f64(in ? pa1[k] : 0.0, b1, acc1, 0, 0, 0);
     }
     if (more) {
       __builtin_amdgcn_wave_barrier();  // (LDS operations of one wave complete in order; the compiler must not move them)
@@ -712,6 +740,12 @@ __global__ void __launch_bounds__(64) direct_mse_stream_kernel(DirectMseArgs a) 
         const double2 t1 = *reinterpret_cast<const double2*>(&win[kStreamPiece + 4 * lane + 2]);
         *reinterpret_cast<double2*>(&win[4 * lane]) = t0;
         *reinterpret_cast<double2*>(&win[4 * lane + 2]) = t1;
+        if (WEIGHTED) {
+          const float4 f0 = *reinterpret_cast<const float4*>(&xf[kStreamPiece + 4 * lane]);
+          const float4 f1 = *reinterpret_cast<const float4*>(&ww[kStreamPiece + 4 * lane]);
+          *reinterpret_cast<float4*>(&xf[4 * lane]) = f0;
+          *reinterpret_cast<float4*>(&ww[4 * lane]) = f1;
+        }
       }
 #pragma unroll
       for (int u = 0; u < 2; ++u) place((base + kStreamPiece + 16) / 4 + lane + 64 * u, nx[u], 16 + 4 * (lane + 64 * u));
@@ -724,7 +758,7 @@ __global__ void __launch_bounds__(64) direct_mse_stream_kernel(DirectMseArgs a) 
     const int ra = 4 * I + oi, cb = 4 * J + oj;
     if (cb == 0 && ra <= P) {
       out[ra] = v;
-      if (a.autocorr) a.autocorr[(size_t)sf * 33 + ra] = v;
+      if (a.autocorr && !irls) a.autocorr[(size_t)sf * 33 + ra] = v;
     } else if (ra >= 1 && ra <= cb && cb <= P) {
       out[33 + (ra - 1) + (cb - 1) * P] = v;
       out[33 + (cb - 1) + (ra - 1) * P] = v;
@@ -734,7 +768,121 @@ __global__ void __launch_bounds__(64) direct_mse_stream_kernel(DirectMseArgs a) 
   if (NI > 1) put(I1, J1, acc1);
   if (lane > P && lane <= 32) {
     out[lane] = 0.0;
-    if (a.autocorr) a.autocorr[(size_t)sf * 33 + lane] = 0.0;
+    if (a.autocorr && !irls) a.autocorr[(size_t)sf * 33 + lane] = 0.0;
+  }
+}
+
+// compute_raw_errors (lpc.rs:602-618: f32 fma chain over the taps of the UNWINDOWED samples), the sum of |error| as ONE
+// sequential f32 chain (Iterator::sum, lpc.rs:839), the best step so far (lpc.rs:840-844) and the next step's weights
+// (lpc.rs:845-847), one workgroup per subframe: state[0..32) = this step's solution, [32..64) = the best,
+// [64] = its error, [65] = have one, [66] = status.
+constexpr int kIrlsErrThreads = 256;
+template <bool STEREO>
+__global__ void __launch_bounds__(kIrlsErrThreads) direct_mse_irls_error_kernel(DirectMseArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  __shared__ float echunk[kErrChunk];
+  __shared__ float cf[32];
+  __shared__ int smax;
+  __shared__ float ssum;
+  const int tid = threadIdx.x;
+  const int n = (int)a.block_size;
+  const int P = (int)a.lpc_order;
+  const uint32_t sf = blockIdx.x;
+  double* const st = a.irls_state + (size_t)sf * kIrlsStateDoubles;
+  if (st[66] != 0.0) return;  // (uniform)
+  const int n4 = (n + 3) & ~3;
+  float* const xs = reinterpret_cast<float*>(smem_raw);  // (f32)s: what every tap and the leading term convert to
+  float* __restrict__ wout = a.irls_weights + (size_t)sf * n4;
+  const int32_t* rowA;
+  const int32_t* rowB = nullptr;
+  int kind = 0;
+  if (STEREO) {
+    const uint32_t frame = sf >> 2;
+    kind = (int)(sf & 3u);
+    rowA = a.samples + (size_t)(2u * frame + (kind == 1 ? 1u : 0u)) * a.stride;
+    rowB = a.samples + (size_t)(2u * frame + 1u) * a.stride;
+  } else {
+    rowA = a.samples + (size_t)sf * a.stride;
+  }
+  int my_maxabs = 0;
+  for (int t = tid; t < n; t += kIrlsErrThreads) {
+    int32_t s = rowA[t];
+    if (STEREO && kind >= 2) {
+      const int32_t r = rowB[t];
+      s = kind == 2 ? (s + r) >> 1 : s - r;  // coding.rs:483
+    }
+    xs[t] = (float)s;
+    const int32_t ab = s < 0 ? (int32_t)(0u - (uint32_t)s) : s;  // i32::abs (wrapping)
+    my_maxabs = ab > my_maxabs ? ab : my_maxabs;
+  }
+  if (tid == 0) {
+    smax = 0;
+    ssum = 0.0f;
+  }
+  if (tid < 32) cf[tid] = tid < P ? (float)st[tid] : 0.0f;
+  __syncthreads();
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int o = __shfl_xor(my_maxabs, d, 64);
+    my_maxabs = o > my_maxabs ? o : my_maxabs;
+  }
+  if ((tid & 63) == 0) atomicMax(&smax, my_maxabs);
+  __syncthreads();
+  const float normalizer = (float)smax;
+  const bool last = a.irls_step == a.mae_steps;  // no step follows: its weights are never read
+  for (int base = 0; base < n; base += kErrChunk) {
+    for (int o = tid; o < kErrChunk && base + o < n; o += kIrlsErrThreads) {
+      const int t = base + o;
+      float e = 0.0f;  // raw_errors[t] for t < order: never written, 0
+      if (t >= P) {
+        e = -xs[t];  // (f32)(-s) == -(f32)s: rounding is symmetric
+        for (int j = 0; j < P; ++j) e = __builtin_fmaf(cf[j], xs[t - 1 - j], e);
+        if (!last) {
+          float x = __builtin_fabsf(e);
+          x = x > 1.0f ? x : 1.0f;
+          x = x / normalizer;
+          x = x > 0.01f ? x : 0.01f;
+          wout[t] = dev_powf_pos(x, -1.2f);
+        }
+      } else if (!last && a.irls_step == 0) {
+        wout[t] = 1.0f;  // the first `order` weights stay 1 (lpc.rs:821-822)
+      }
+      echunk[o] = __builtin_fabsf(e);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      float sacc = ssum;
+      const int cnt = n - base < kErrChunk ? n - base : kErrChunk;
+      int o = 0;
+      for (; o + 16 <= cnt; o += 16) {
+        const float4 q0 = *reinterpret_cast<const float4*>(&echunk[o]);
+        const float4 q1 = *reinterpret_cast<const float4*>(&echunk[o + 4]);
+        const float4 q2 = *reinterpret_cast<const float4*>(&echunk[o + 8]);
+        const float4 q3 = *reinterpret_cast<const float4*>(&echunk[o + 12]);
+        sacc += q0.x; sacc += q0.y; sacc += q0.z; sacc += q0.w;
+        sacc += q1.x; sacc += q1.y; sacc += q1.z; sacc += q1.w;
+        sacc += q2.x; sacc += q2.y; sacc += q2.z; sacc += q2.w;
+        sacc += q3.x; sacc += q3.y; sacc += q3.z; sacc += q3.w;
+      }
+      for (; o < cnt; ++o) sacc += echunk[o];
+      ssum = sacc;
+    }
+    __syncthreads();
+  }
+  const float best_error = a.irls_step == 0 ? 3.40282347e+38f : (float)st[64];  // f32::MAX
+  if (ssum < best_error) {  // (uniform)
+    if (tid < 32) st[32 + tid] = st[tid];
+    if (tid <= 32 && a.autocorr) {
+      const double* g = a.gram_scratch + (size_t)sf * direct_mse_gram_stride((uint32_t)P);
+      a.autocorr[(size_t)sf * 33 + tid] = tid <= P ? g[tid] : 0.0;
+    }
+    if (tid == 0) {
+      st[64] = (double)ssum;
+      st[65] = 1.0;
+    }
+  } else if (a.irls_step == 0 && tid == 0) {
+    st[64] = (double)best_error;
+    st[65] = 0.0;
   }
 }
 
@@ -742,6 +890,9 @@ __global__ void __launch_bounds__(64) direct_mse_stream_kernel(DirectMseArgs a) 
 // orc_cholesky_solve) + quantize_parameters (lpc.rs:273-302) for a batch, ONE SUBFRAME PER LANE: every operation of a
 // subframe's sequence is the lane's own, in the reference's order; the matrices live in LDS, element k of lane l at
 // k * LW + l.  LW = lanes in use per 64-thread workgroup = what 64 KB hold of (P * P + 2 P) doubles per subframe.
+// PHASE 0: solve + quantise (no IRLS); 1: one IRLS step's solve -> irls_state (a failed estimate ends the subframe's
+// iteration, lpc.rs:829-830); 2: after the last step, the best solution -> quantise.
+template <int PHASE>
 __global__ void __launch_bounds__(64) direct_mse_solve_kernel(DirectMseArgs a, int LW) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int lane = threadIdx.x;
@@ -754,11 +905,22 @@ __global__ void __launch_bounds__(64) direct_mse_solve_kernel(DirectMseArgs a, i
 #define M_(r, c) m[(size_t)((r) + (c) * P) * LW]
 #define V_(i) v[(size_t)(i) * LW]
   const double* __restrict__ g = a.gram_scratch + (size_t)sf * direct_mse_gram_stride((uint32_t)P);
-  for (int i = 0; i < P; ++i) diag[(size_t)i * LW] = g[33 + i + i * P];
+  double* const st = PHASE != 0 ? a.irls_state + (size_t)sf * kIrlsStateDoubles : nullptr;
   int status = 0;
+  if (PHASE == 1) {
+    if (a.irls_step == 0) st[66] = 0.0;
+    else if (st[66] != 0.0) return;
+  }
+  if (PHASE == 2) {
+    status = (int)st[66];
+    const bool have = st[65] != 0.0;
+    if (status == 0 && !have) status = FLACENC_HIP_SUBFRAME_NONFINITE;  // best_coefs.unwrap() would panic
+    for (int i = 0; i < P; ++i) V_(i) = (status == 0) ? st[32 + i] : 0.0;
+  }
   double regularizer = 0.0;
   int tries = 0;
-  for (;;) {
+  if (PHASE != 2) for (int i = 0; i < P; ++i) diag[(size_t)i * LW] = g[33 + i + i * P];
+  for (; PHASE != 2;) {
     // mat.clone(); xy = corr[1..]
     for (int c = 0; c < P; ++c)
       for (int r = 0; r < P; ++r) M_(r, c) = r == c ? diag[(size_t)r * LW] : g[33 + r + c * P];
@@ -820,6 +982,11 @@ __global__ void __launch_bounds__(64) direct_mse_solve_kernel(DirectMseArgs a, i
       break;
     }
   }
+  if (PHASE == 1) {
+    for (int i = 0; i < 32; ++i) st[i] = i < P ? V_(i) : 0.0;
+    st[66] = (double)status;
+    return;
+  }
   // ---- quantize_parameters, lpc.rs:273-302 (find_shift :234-254, quantize_parameter :258-270) ----
   for (int i = 0; i < P; ++i) {
     const uint64_t b = (uint64_t)__double_as_longlong(V_(i));
@@ -874,24 +1041,61 @@ hipError_t launch_direct_mse(const DirectMseArgs& a, hipStream_t stream) {
   if (a.lpc_order < 1 || a.lpc_order > 32) return hipErrorInvalidValue;
   if (a.stereo && (a.n_subframes & 3u)) return hipErrorInvalidValue;
   const bool irls = a.mae_steps > 0;
-  auto launch_solve = [&]() -> hipError_t {
-    const size_t per = ((size_t)a.lpc_order * a.lpc_order + 2 * a.lpc_order) * 8;  // LDS per subframe
+  auto launch_solve = [&](const DirectMseArgs& d, int phase) -> hipError_t {
+    const size_t per = ((size_t)d.lpc_order * d.lpc_order + 2 * d.lpc_order) * 8;  // LDS per subframe
     int lw = 64;
     while (lw > 1 && per * (size_t)lw > 64 * 1024) lw >>= 1;
     const size_t solve_smem = per * (size_t)lw;
-    static DynamicLdsOptIn solve_opt;
-    if (hipError_t e = solve_opt.ensure(reinterpret_cast<const void*>(direct_mse_solve_kernel), solve_smem); e != hipSuccess) return e;
-    hipLaunchKernelGGL(direct_mse_solve_kernel, dim3((a.n_subframes + (uint32_t)lw - 1u) / (uint32_t)lw), dim3(64), solve_smem, stream,
-                       a, lw);
+    static DynamicLdsOptIn solve_opt[3];
+    const dim3 grid((d.n_subframes + (uint32_t)lw - 1u) / (uint32_t)lw);
+#define FLACENC_DM_SOLVE(PH)                                                                                             \
+  {                                                                                                                      \
+    auto kern = direct_mse_solve_kernel<PH>;                                                                             \
+    if (hipError_t e = solve_opt[PH].ensure(reinterpret_cast<const void*>(kern), solve_smem); e != hipSuccess) return e; \
+    hipLaunchKernelGGL(kern, grid, dim3(64), solve_smem, stream, d, lw);                                                 \
+  }
+    if (phase == 0) FLACENC_DM_SOLVE(0) else if (phase == 1) FLACENC_DM_SOLVE(1) else FLACENC_DM_SOLVE(2)
+#undef FLACENC_DM_SOLVE
     return hipGetLastError();
   };
-  if (!irls && a.gram_scratch != nullptr && a.lpc_order <= 11 && (reinterpret_cast<uintptr_t>(a.samples) & 15) == 0 &&
-      (a.stride & 3) == 0) {
+  const bool streamable = a.gram_scratch != nullptr && a.lpc_order <= 11 && (reinterpret_cast<uintptr_t>(a.samples) & 15) == 0 &&
+                          (a.stride & 3) == 0;
+  if (!irls && streamable) {
     // orders up to 11: the sliding-window chains, then the batched solve
     if (a.stereo) hipLaunchKernelGGL(direct_mse_stream_kernel<true>, dim3(a.n_subframes), dim3(64), 0, stream, a);
     else hipLaunchKernelGGL(direct_mse_stream_kernel<false>, dim3(a.n_subframes), dim3(64), 0, stream, a);
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
-    return launch_solve();
+    return launch_solve(a, 0);
+  }
+  if (irls && streamable && a.weight_scratch != nullptr && a.irls_state != nullptr) {
+    // IRLS, orders up to 11: per step the (weighted) chains, the batched solve, the error pass; then the best solution
+    const size_t err_smem = (((size_t)a.block_size + 3) & ~(size_t)3) * 4;
+    static DynamicLdsOptIn err_opt[2];
+    DirectMseArgs d = a;
+    d.irls_weights = a.weight_scratch;
+    for (uint32_t it = 0; it <= a.mae_steps; ++it) {
+      d.irls_step = it;
+      if (it == 0) {  // (weights of 1: the unweighted chain, operand for operand)
+        if (a.stereo) hipLaunchKernelGGL(direct_mse_stream_kernel<true>, dim3(a.n_subframes), dim3(64), 0, stream, d);
+        else hipLaunchKernelGGL(direct_mse_stream_kernel<false>, dim3(a.n_subframes), dim3(64), 0, stream, d);
+      } else {
+        if (a.stereo) hipLaunchKernelGGL((direct_mse_stream_kernel<true, true>), dim3(a.n_subframes), dim3(64), 0, stream, d);
+        else hipLaunchKernelGGL((direct_mse_stream_kernel<false, true>), dim3(a.n_subframes), dim3(64), 0, stream, d);
+      }
+      if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+      if (hipError_t e = launch_solve(d, 1); e != hipSuccess) return e;
+      if (a.stereo) {
+        auto kern = direct_mse_irls_error_kernel<true>;
+        if (hipError_t e = err_opt[0].ensure(reinterpret_cast<const void*>(kern), err_smem); e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(a.n_subframes), dim3(kIrlsErrThreads), err_smem, stream, d);
+      } else {
+        auto kern = direct_mse_irls_error_kernel<false>;
+        if (hipError_t e = err_opt[1].ensure(reinterpret_cast<const void*>(kern), err_smem); e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(a.n_subframes), dim3(kIrlsErrThreads), err_smem, stream, d);
+      }
+      if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+    }
+    return launch_solve(d, 2);
   }
   const size_t smem = direct_mse_lds_bytes(a.block_size, irls, a.lpc_order);
   if (smem > 160 * 1024) return hipErrorNotSupported;
@@ -914,7 +1118,7 @@ hipError_t launch_direct_mse(const DirectMseArgs& a, hipStream_t stream) {
   }
 #undef FLACENC_DM_LAUNCH
   if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
-  if (!irls && a.gram_scratch != nullptr) return launch_solve();
+  if (!irls && a.gram_scratch != nullptr) return launch_solve(a, 0);
   return hipSuccess;
 }
 

@@ -27,7 +27,16 @@ struct DirectMseArgs {
   // matrix column-major), the chains' kernel stops behind them and direct_mse_solve_kernel factorises, solves and
   // quantises with a LANE per subframe; nullptr: everything in the one kernel, as with IRLS.
   double* gram_scratch;
+  // IRLS in the same form (orders up to 11, aligned rows): per step the weighted chains, the batched solve and an
+  // error pass (raw errors, their sequential f32 sum, the best step so far, the next weights).  irls_state: [n][80]
+  // doubles -- the step's solution [32], the best one [32], {best error, have a best, status, 0...}; irls_weights:
+  // [n][(block_size + 3) & ~3] floats (= weight_scratch's layout).  Set by launch_direct_mse from `weight_scratch` and
+  // the tail of `gram_scratch` when both are there; `irls_step` is the launcher's loop variable.
+  double* irls_state;
+  float* irls_weights;
+  uint32_t irls_step;
 };
+constexpr size_t kIrlsStateDoubles = 80;
 
 __host__ __device__ inline size_t direct_mse_gram_stride(uint32_t order) { return (33u + (size_t)order * order + 1u) & ~(size_t)1; }
 

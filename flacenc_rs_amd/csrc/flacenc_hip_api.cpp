@@ -379,14 +379,16 @@ int enqueue(flacenc_hip_handle* h, const flacenc_hip_qlpc_config* cfg, const int
     h->last_error = "use_direct_mse: the block does not fit the LDS";  // (not for any block up to 32767 samples)
     return FLACENC_HIP_ERR_UNSUPPORTED;
   }
-  if (a.direct_mse && a.mae_steps == 0) {
-    // (R[] and the matrix between the chains and the lane-per-subframe solve)
-    rc = ensure(h, h->d_gram, n_subframes * flacenc_hip::direct_mse_gram_stride(cfg->lpc_order) * sizeof(double));
+  if (a.direct_mse) {
+    // (R[] and the matrix between the chains and the lane-per-subframe solve; with IRLS steps also the iteration's state)
+    rc = ensure(h, h->d_gram, n_subframes * (flacenc_hip::direct_mse_gram_stride(cfg->lpc_order) +
+                                             (a.mae_steps ? flacenc_hip::kIrlsStateDoubles : 0)) * sizeof(double));
     if (rc != FLACENC_HIP_OK) return rc;
     a.direct_mse_scratch = static_cast<double*>(h->d_gram.ptr);
   }
-  if (a.direct_mse && a.mae_steps > 0 && block_size > 16384) {
-    // lpc_with_irls_mae (lpc.rs:814-850) has no block limit: above 16384 samples the weights live in HBM scratch
+  if (a.direct_mse && a.mae_steps > 0) {
+    // the IRLS weights between the steps' kernels (orders up to 11); lpc_with_irls_mae (lpc.rs:814-850) has no block
+    // limit: above 16384 samples the one-kernel form keeps them here too
     rc = ensure(h, h->d_irlsw, n_subframes * ((static_cast<size_t>(block_size) + 3) & ~static_cast<size_t>(3)) * sizeof(float));
     if (rc != FLACENC_HIP_OK) return rc;
     a.irls_weight_scratch = static_cast<float*>(h->d_irlsw.ptr);

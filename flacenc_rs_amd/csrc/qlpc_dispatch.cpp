@@ -189,7 +189,10 @@ hipError_t launch_qlpc(const QlpcKernelArgs& a, const QlpcLaunchPlan& plan, hipS
     d.autocorr = a.autocorr;
     d.lpc_coefs = a.lpc_coefs;
     d.weight_scratch = a.irls_weight_scratch;
-    d.gram_scratch = a.mae_steps == 0 ? a.direct_mse_scratch : nullptr;
+    d.gram_scratch = a.direct_mse_scratch;
+    d.irls_state = (a.mae_steps != 0 && a.direct_mse_scratch != nullptr)
+                       ? a.direct_mse_scratch + static_cast<size_t>(a.n_subframes) * direct_mse_gram_stride(a.lpc_order)
+                       : nullptr;
     hipError_t err = launch_direct_mse(d, stream);
     if (err != hipSuccess) return err;
     QlpcKernelArgs s3 = a;

@@ -572,6 +572,220 @@ __global__ void __launch_bounds__(576) direct_mse_kernel(DirectMseArgs a) {
   }
 }
 
+// The chains from a SLIDING f64 window instead of the whole block in LDS, on v_mfma_f64_4x4x4_4b_f64 for every order.
+// H is cut into 4 x 4 blocks; needed are column block 0 (R[tau] = H[tau][0]) and the upper triangle: NB + NB (NB + 1) / 2 - 1
+// blocks for NB = ceil((P + 1) / 4) block rows -- 4 at order 7, 8 at 11, 34 at 24, 53 at 32 -- four per instruction.  The
+// form above (the whole block as f32 in LDS, a conversion for every operand of every step, one 16 x 16 tile per wave from
+// order 12 with 81 .. 1089 of 1024 .. 9216 outputs wanted) spends its time waiting and multiplying padding; this kernel keeps
+// 4.5 KB (560 doubles: 512 steps' samples + the P + 3 ahead of them), converts each sample once when it enters the
+// window, fetches the next 512 samples into registers before it walks the current ones, and deals the instructions to
+// up to four waves (NIW accumulators each): 24 and more workgroups fit a CU.  The chain of every entry --
+// the MFMA through its C operand, k ascending -- is the reference's sequential fma chain, operand for operand
+// (profiles/r03_mfma_f64_4x4x4_probe.txt).
+// WEIGHTED (IRLS steps after the first): B[k][b] = f32(w * y_b) (lpc.rs:463-470) -- the weights' window and an f32 copy
+// of the samples' ride along, the product and its widening stay in the loop; a subframe whose estimate already failed
+// is skipped.
+constexpr int kStreamPiece = 512;
+constexpr int kStreamHalo = 48;  // >= P + 3, whole quads
+template <bool STEREO, bool WEIGHTED, int NIW>
+__global__ void __launch_bounds__(256) direct_mse_stream_kernel(DirectMseArgs a) {
+  __shared__ __attribute__((aligned(16))) double win[kStreamPiece + kStreamHalo];
+  __shared__ __attribute__((aligned(16))) float xf[WEIGHTED ? kStreamPiece + kStreamHalo : 4];
+  __shared__ __attribute__((aligned(16))) float ww[WEIGHTED ? kStreamPiece + kStreamHalo : 4];
+  const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63;
+  const int wave = tid >> 6, nwaves = nthr >> 6;
+  const int n = (int)a.block_size;
+  const int P = (int)a.lpc_order;
+  const uint32_t sf = blockIdx.x;
+  const float* __restrict__ wtab = a.window ? a.window + 32 : nullptr;
+  const int32_t* rowA;
+  const int32_t* rowB = nullptr;
+  int kind = 0;
+  if (STEREO) {
+    const uint32_t frame = sf >> 2;
+    kind = (int)(sf & 3u);
+    rowA = a.samples + (size_t)(2u * frame + (kind == 1 ? 1u : 0u)) * a.stride;
+    rowB = a.samples + (size_t)(2u * frame + 1u) * a.stride;
+  } else {
+    rowA = a.samples + (size_t)sf * a.stride;
+  }
+  double* __restrict__ out = a.gram_scratch + (size_t)sf * direct_mse_gram_stride((uint32_t)P);
+  const bool irls = a.irls_state != nullptr;  // (then R[] reaches a.autocorr through the error pass: the best step's)
+  if (irls && a.irls_step > 0 && a.irls_state[(size_t)sf * kIrlsStateDoubles + 66] != 0.0) return;  // the estimate failed in an earlier step
+  const float* __restrict__ wsrc = WEIGHTED ? a.irls_weights + (size_t)sf * (((size_t)n + 3) & ~(size_t)3) : nullptr;
+  if (n < P + 1) {  // (lpc.rs:860-862: nothing to estimate from)
+    for (int c = tid; c < 33 + P * P; c += nthr) out[c] = 0.0;
+    if (a.autocorr && !irls && tid <= 32) a.autocorr[(size_t)sf * 33 + tid] = 0.0;
+    return;
+  }
+  // x_w = (f32)s * w, one f32 rounding (lpc.rs:751-754), widened once; samples [4 q, 4 q + 4), zeros behind the block
+  struct Quad {
+    int4 va, vb;
+    float4 wt;
+  };
+  auto fetch = [&](int q) -> Quad {  // (rows are 16-byte aligned with a stride of whole quads: the launcher checks)
+    Quad r;
+    r.va = r.vb = make_int4(0, 0, 0, 0);
+    r.wt = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (WEIGHTED && 4 * q < n) r.wt = *reinterpret_cast<const float4*>(wsrc + 4 * q);  // (rows of whole quads)
+    if (4 * q + 3 < n) {
+      r.va = *reinterpret_cast<const int4*>(rowA + 4 * q);
+      if (STEREO && kind >= 2) r.vb = *reinterpret_cast<const int4*>(rowB + 4 * q);
+    } else if (4 * q < n) {
+      int32_t ta[4] = {0, 0, 0, 0}, tb[4] = {0, 0, 0, 0};
+      for (int u = 0; u < 4 && 4 * q + u < n; ++u) {
+        ta[u] = rowA[4 * q + u];
+        if (STEREO && kind >= 2) tb[u] = rowB[4 * q + u];
+      }
+      r.va = make_int4(ta[0], ta[1], ta[2], ta[3]);
+      r.vb = make_int4(tb[0], tb[1], tb[2], tb[3]);
+    }
+    return r;
+  };
+  auto place = [&](int q, const Quad& r, int at) {  // -> win[at .. at + 4)
+    int4 v = r.va;
+    if (STEREO && kind == 2) v = make_int4((r.va.x + r.vb.x) >> 1, (r.va.y + r.vb.y) >> 1, (r.va.z + r.vb.z) >> 1, (r.va.w + r.vb.w) >> 1);
+    if (STEREO && kind == 3) v = make_int4(r.va.x - r.vb.x, r.va.y - r.vb.y, r.va.z - r.vb.z, r.va.w - r.vb.w);  // coding.rs:483
+    float4 w4 = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+    if (wtab && 4 * q + 3 < n) w4 = *reinterpret_cast<const float4*>(wtab + 4 * q);
+    else if (wtab) {
+      float tw[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+      for (int u = 0; u < 4 && 4 * q + u < n; ++u) tw[u] = wtab[4 * q + u];
+      w4 = make_float4(tw[0], tw[1], tw[2], tw[3]);
+    }
+    const float4 xv = make_float4((float)v.x * w4.x, (float)v.y * w4.y, (float)v.z * w4.z, (float)v.w * w4.w);
+    *reinterpret_cast<double2*>(&win[at]) = make_double2((double)xv.x, (double)xv.y);
+    *reinterpret_cast<double2*>(&win[at + 2]) = make_double2((double)xv.z, (double)xv.w);
+    if (WEIGHTED) {
+      *reinterpret_cast<float4*>(&xf[at]) = xv;
+      *reinterpret_cast<float4*>(&ww[at]) = r.wt;
+    }
+  };
+  // lane -> operand elements: lane 16 k + 4 b + i holds A_b[i][k], lane 16 k + 4 b + j holds B_b[k][j].  Block list:
+  // (0,0) (1,0) .. (NB-1,0), then column by column (0,1) (1,1), (0,2) (1,2) (2,2), ...; instruction q takes blocks
+  // 4 q .. 4 q + 3, wave w the instructions w, w + nwaves, ...; slots behind the list repeat block (0,0).
+  const int len = n - P;
+  const int NB = (P + 1 + 3) >> 2;  // 1..9
+  const int nblocks = NB + NB * (NB + 1) / 2 - 1;
+  const int kq = lane >> 4, bs = (lane >> 2) & 3, r = lane & 3;
+  auto block_of = [&](int idx, int& I, int& J) {
+    if (idx >= nblocks) idx = 0;
+    if (idx < NB) {
+      I = idx;
+      J = 0;
+      return;
+    }
+    idx -= NB;
+    int col = 1;
+    while (idx >= col + 1) {
+      idx -= col + 1;
+      ++col;
+    }
+    I = idx;
+    J = col;
+  };
+  int oa[NIW], ob[NIW], bi[NIW], bj[NIW];
+#pragma unroll
+  for (int i = 0; i < NIW; ++i) {
+    const int q = wave + nwaves * i;
+    block_of(4 * q + bs, bi[i], bj[i]);
+    int arow = 4 * bi[i] + r, bcol = 4 * bj[i] + r;
+    arow = arow > P ? P : arow;
+    bcol = bcol > P ? P : bcol;
+    oa[i] = (P - arow) + kq;  // step k reads x_w[(P - row) + k + kq]
+    ob[i] = (P - bcol) + kq;
+  }
+  double acc[NIW];
+#pragma unroll
+  for (int i = 0; i < NIW; ++i) acc[i] = 0.0;
+  // window = samples [base, base + 512 + halo)
+  constexpr int kWinQuads = (kStreamPiece + kStreamHalo) / 4;  // 140
+  for (int q = tid; q < kWinQuads; q += nthr) place(q, fetch(q), 4 * q);
+  __syncthreads();
+  for (int base = 0; base < len; base += kStreamPiece) {
+    // the next 512 samples (behind the halo already here) on their way while this piece is walked
+    const bool more = base + kStreamPiece < len;
+    Quad nx[2];
+    const int q_next = (base + kStreamPiece + kStreamHalo) / 4 + tid;
+    if (more) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        if (tid + u * nthr < kStreamPiece / 4) nx[u] = fetch(q_next + u * nthr);
+    }
+    const int steps_here = (len - base) < kStreamPiece ? (len - base) : kStreamPiece;
+    const float* __restrict__ pw = ww + P + kq;  // w[t' + 1]
+    auto step = [&](int kk) __attribute__((always_inline)) {
+      float wk = 0.0f;
+      if (WEIGHTED) wk = pw[kk];
+#pragma unroll
+      for (int i = 0; i < NIW; ++i) {
+        const double bv = WEIGHTED ? (double)(wk * xf[ob[i] + kk]) : win[ob[i] + kk];
+        acc[i] = __builtin_amdgcn_mfma_f64_4x4x4f64(win[oa[i] + kk], bv, acc[i], 0, 0, 0);
+      }
+    };
+    int k = 0;
+    for (; k + 32 <= steps_here; k += 32) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) step(k + 4 * u);
+    }
+    for (; k + 4 <= steps_here; k += 4) step(k);
+    if (k < steps_here) {  // the block's last one to three steps: the missing ones multiply by 0 (x + 0 * y == x)
+      const bool in = k + kq < steps_here;
+      const float wk = (WEIGHTED && in) ? pw[k] : 0.0f;
+#pragma unroll
+      for (int i = 0; i < NIW; ++i) {
+        const double av = in ? win[oa[i] + k] : 0.0;
+        const double bv = !in ? 0.0 : (WEIGHTED ? (double)(wk * xf[ob[i] + k]) : win[ob[i] + k]);
+        acc[i] = __builtin_amdgcn_mfma_f64_4x4x4f64(av, bv, acc[i], 0, 0, 0);
+      }
+    }
+    if (more) {
+      __syncthreads();  // every wave is done with this piece
+      if (tid < kStreamHalo / 4) {
+        const double2 t0 = *reinterpret_cast<const double2*>(&win[kStreamPiece + 4 * tid]);
+        const double2 t1 = *reinterpret_cast<const double2*>(&win[kStreamPiece + 4 * tid + 2]);
+        float4 f0, f1;
+        if (WEIGHTED) {
+          f0 = *reinterpret_cast<const float4*>(&xf[kStreamPiece + 4 * tid]);
+          f1 = *reinterpret_cast<const float4*>(&ww[kStreamPiece + 4 * tid]);
+        }
+        // (the halo's first quads land where its last ones are read from only if halo > piece: not so)
+        *reinterpret_cast<double2*>(&win[4 * tid]) = t0;
+        *reinterpret_cast<double2*>(&win[4 * tid + 2]) = t1;
+        if (WEIGHTED) {
+          *reinterpret_cast<float4*>(&xf[4 * tid]) = f0;
+          *reinterpret_cast<float4*>(&ww[4 * tid]) = f1;
+        }
+      }
+      __syncthreads();  // (the refill below overwrites the old halo's place)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        if (tid + u * nthr < kStreamPiece / 4) place(q_next + u * nthr, nx[u], kStreamHalo + 4 * (tid + u * nthr));
+      __syncthreads();
+    }
+  }
+  // D_b[i][j] sits in lane 16 i + 4 b + j
+  const int oi = lane >> 4, oj = lane & 3;
+#pragma unroll
+  for (int i = 0; i < NIW; ++i) {
+    const int ra = 4 * bi[i] + oi, cb = 4 * bj[i] + oj;
+    const double v = acc[i];
+    if (cb == 0 && ra <= P) {
+      out[ra] = v;
+      if (a.autocorr && !irls) a.autocorr[(size_t)sf * 33 + ra] = v;
+    } else if (ra >= 1 && ra <= cb && cb <= P) {
+      out[33 + (ra - 1) + (cb - 1) * P] = v;
+      out[33 + (cb - 1) + (ra - 1) * P] = v;
+    }
+  }
+  if (tid > P && tid <= 32) {
+    out[tid] = 0.0;
+    if (a.autocorr && !irls) a.autocorr[(size_t)sf * 33 + tid] = 0.0;
+  }
+}
+
+// ---- the same for orders up to 11 alone: one wave, at most two instructions, pointers instead of tables (measured: order 8
+// 0.356 ms per 12288 subframes against 0.479 in the general form above) ----
 // The chains of orders up to 11 without IRLS steps, ONE WAVE per subframe and a SLIDING f64 window instead of the whole
 // block in LDS: the 4 x 4 x 4 block form above spends its time waiting -- one wave per workgroup, 16 KB of image per
 // subframe (eight workgroups per CU), a conversion for every operand of every step -- where this kernel keeps 4.2 KB
@@ -581,9 +795,8 @@ __global__ void __launch_bounds__(576) direct_mse_kernel(DirectMseArgs a) {
 // WEIGHTED (IRLS steps after the first): B[k][b] = f32(w * y_b) (lpc.rs:463-470) -- the weights' window and an f32 copy
 // of the samples' ride along, the product and its widening stay in the loop; a subframe whose estimate already failed
 // is skipped.
-constexpr int kStreamPiece = 512;
 template <bool STEREO, bool WEIGHTED = false>
-__global__ void __launch_bounds__(64) direct_mse_stream_kernel(DirectMseArgs a) {
+__global__ void __launch_bounds__(64) direct_mse_stream_small_kernel(DirectMseArgs a) {
   __shared__ __attribute__((aligned(16))) double win[kStreamPiece + 16];
   __shared__ __attribute__((aligned(16))) float xf[WEIGHTED ? kStreamPiece + 16 : 4];
   __shared__ __attribute__((aligned(16))) float ww[WEIGHTED ? kStreamPiece + 16 : 4];
@@ -1058,31 +1271,57 @@ hipError_t launch_direct_mse(const DirectMseArgs& a, hipStream_t stream) {
 #undef FLACENC_DM_SOLVE
     return hipGetLastError();
   };
-  const bool streamable = a.gram_scratch != nullptr && a.lpc_order <= 11 && (reinterpret_cast<uintptr_t>(a.samples) & 15) == 0 &&
-                          (a.stride & 3) == 0;
-  if (!irls && streamable) {
-    // orders up to 11: the sliding-window chains, then the batched solve
-    if (a.stereo) hipLaunchKernelGGL(direct_mse_stream_kernel<true>, dim3(a.n_subframes), dim3(64), 0, stream, a);
-    else hipLaunchKernelGGL(direct_mse_stream_kernel<false>, dim3(a.n_subframes), dim3(64), 0, stream, a);
-    if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+  const bool streamable = a.gram_scratch != nullptr && (reinterpret_cast<uintptr_t>(a.samples) & 15) == 0 && (a.stride & 3) == 0;
+  // the sliding-window chains: NI instructions of four 4 x 4 blocks, dealt to 1..4 waves with NIW accumulators each
+  const uint32_t nb = (a.lpc_order + 1 + 3) >> 2;
+  const uint32_t ni = (nb + nb * (nb + 1) / 2 - 1 + 3) / 4;  // 1 .. 14
+  const uint32_t nw = (ni + 3) / 4, niw = (ni + nw - 1) / nw;
+  auto launch_stream = [&](const DirectMseArgs& d, bool weighted) -> hipError_t {
+    if (d.lpc_order <= 11) {
+      if (d.stereo) {
+        if (weighted) hipLaunchKernelGGL((direct_mse_stream_small_kernel<true, true>), dim3(d.n_subframes), dim3(64), 0, stream, d);
+        else hipLaunchKernelGGL((direct_mse_stream_small_kernel<true, false>), dim3(d.n_subframes), dim3(64), 0, stream, d);
+      } else {
+        if (weighted) hipLaunchKernelGGL((direct_mse_stream_small_kernel<false, true>), dim3(d.n_subframes), dim3(64), 0, stream, d);
+        else hipLaunchKernelGGL((direct_mse_stream_small_kernel<false, false>), dim3(d.n_subframes), dim3(64), 0, stream, d);
+      }
+      return hipGetLastError();
+    }
+    const dim3 grid(d.n_subframes), block(64 * nw);
+#define FLACENC_DM_STREAM(ST, WT, N_) hipLaunchKernelGGL((direct_mse_stream_kernel<ST, WT, N_>), grid, block, 0, stream, d);
+#define FLACENC_DM_STREAM_N(ST, WT)                        \
+  {                                                        \
+    if (niw == 1) FLACENC_DM_STREAM(ST, WT, 1)             \
+    else if (niw == 2) FLACENC_DM_STREAM(ST, WT, 2)        \
+    else if (niw == 3) FLACENC_DM_STREAM(ST, WT, 3)        \
+    else FLACENC_DM_STREAM(ST, WT, 4)                      \
+  }
+    if (d.stereo) {
+      if (weighted) FLACENC_DM_STREAM_N(true, true) else FLACENC_DM_STREAM_N(true, false)
+    } else {
+      if (weighted) FLACENC_DM_STREAM_N(false, true) else FLACENC_DM_STREAM_N(false, false)
+    }
+#undef FLACENC_DM_STREAM_N
+#undef FLACENC_DM_STREAM
+    return hipGetLastError();
+  };
+  // (without IRLS steps the 16 x 16 tiles of the one-kernel form stay ahead at orders 12..31 -- 2.05 against 2.40 ms per 768
+  // frames of 16384 samples at order 24: the block form's f64 operands are LDS-bound there, two 512-byte reads per 16-cycle
+  // MFMA on each of four SIMDs -- and fall behind at 32, whose third tile row is mostly padding: 5.6 against 3.9 ms)
+  if (!irls && streamable && (a.lpc_order <= 11 || a.lpc_order == 32)) {
+    if (hipError_t e = launch_stream(a, false); e != hipSuccess) return e;
     return launch_solve(a, 0);
   }
   if (irls && streamable && a.weight_scratch != nullptr && a.irls_state != nullptr) {
-    // IRLS, orders up to 11: per step the (weighted) chains, the batched solve, the error pass; then the best solution
+    // IRLS: per step the (weighted) chains, the batched solve, the error pass; then the best solution
     const size_t err_smem = (((size_t)a.block_size + 3) & ~(size_t)3) * 4;
     static DynamicLdsOptIn err_opt[2];
     DirectMseArgs d = a;
     d.irls_weights = a.weight_scratch;
     for (uint32_t it = 0; it <= a.mae_steps; ++it) {
       d.irls_step = it;
-      if (it == 0) {  // (weights of 1: the unweighted chain, operand for operand)
-        if (a.stereo) hipLaunchKernelGGL(direct_mse_stream_kernel<true>, dim3(a.n_subframes), dim3(64), 0, stream, d);
-        else hipLaunchKernelGGL(direct_mse_stream_kernel<false>, dim3(a.n_subframes), dim3(64), 0, stream, d);
-      } else {
-        if (a.stereo) hipLaunchKernelGGL((direct_mse_stream_kernel<true, true>), dim3(a.n_subframes), dim3(64), 0, stream, d);
-        else hipLaunchKernelGGL((direct_mse_stream_kernel<false, true>), dim3(a.n_subframes), dim3(64), 0, stream, d);
-      }
-      if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+      // (the first step's weights are 1: the unweighted chain, operand for operand)
+      if (hipError_t e = launch_stream(d, it != 0); e != hipSuccess) return e;
       if (hipError_t e = launch_solve(d, 1); e != hipSuccess) return e;
       if (a.stereo) {
         auto kern = direct_mse_irls_error_kernel<true>;

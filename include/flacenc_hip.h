@@ -303,8 +303,11 @@ typedef struct flacenc_hip_stereo_frame_result {
  * :230-288), runs on the GPU too, so the whole default-configuration decision is on the device.
  * Block size 4096 with lpc_order <= 12, 16-byte aligned rows and power-of-two ApproxEnt.partitions
  * runs as ONE fused kernel (a wave per candidate, samples read from HBM once, losing candidates never
- * leave the CU); every other shape (any block size 64..32767, any order, any partition count) runs
- * the candidate batches into handle scratch followed by a controller kernel -- same outputs.
+ * leave the CU); so do blocks of 512 / 1024 / 2048 and 576 / 1152 / 2304 samples (8 / 16 / 32 finest Rice
+ * partitions: several frames per workgroup) with the ApproxEnt selector and estimator partitions of a quarter,
+ * half or whole number of those; blocks of 8192 / 16384 samples (and 4096 from order 13) take two analysing
+ * passes and a deciding store pass; every other shape (any block size 64..32767, any order, any partition
+ * count) runs the candidate batches into handle scratch followed by a controller kernel -- same outputs.
  */
 /* Precondition (the reference checks it in FrameBuf::verify_samples, src/source.rs:262-275, before the path
  * is reached): every sample lies in [-2^(bits_per_sample-1), 2^(bits_per_sample-1)).  The frame entry points

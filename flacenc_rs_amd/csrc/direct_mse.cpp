@@ -784,6 +784,171 @@ __global__ void __launch_bounds__(256) direct_mse_stream_kernel(DirectMseArgs a)
   }
 }
 
+// Orders 12..31 from the same window on v_mfma_f64_16x16x4_f64: four waves = the four needed 16 x 16 tiles around one
+// window (two 512-byte operand reads per 64-cycle instruction: the LDS is idle where the 4 x 4 blocks above saturate it),
+// 4.5 KB of LDS per subframe where the one-kernel form stages the whole block.
+template <bool STEREO, bool WEIGHTED>
+__global__ void __launch_bounds__(256) direct_mse_stream_tiles_kernel(DirectMseArgs a) {
+  __shared__ __attribute__((aligned(16))) double win[kStreamPiece + kStreamHalo];
+  __shared__ __attribute__((aligned(16))) float xf[WEIGHTED ? kStreamPiece + kStreamHalo : 4];
+  __shared__ __attribute__((aligned(16))) float ww[WEIGHTED ? kStreamPiece + kStreamHalo : 4];
+  const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63;
+  const int wave = tid >> 6, nwaves = nthr >> 6;
+  const int n = (int)a.block_size;
+  const int P = (int)a.lpc_order;
+  const uint32_t sf = blockIdx.x;
+  const float* __restrict__ wtab = a.window ? a.window + 32 : nullptr;
+  const int32_t* rowA;
+  const int32_t* rowB = nullptr;
+  int kind = 0;
+  if (STEREO) {
+    const uint32_t frame = sf >> 2;
+    kind = (int)(sf & 3u);
+    rowA = a.samples + (size_t)(2u * frame + (kind == 1 ? 1u : 0u)) * a.stride;
+    rowB = a.samples + (size_t)(2u * frame + 1u) * a.stride;
+  } else {
+    rowA = a.samples + (size_t)sf * a.stride;
+  }
+  double* __restrict__ out = a.gram_scratch + (size_t)sf * direct_mse_gram_stride((uint32_t)P);
+  const bool irls = a.irls_state != nullptr;  // (then R[] reaches a.autocorr through the error pass: the best step's)
+  if (irls && a.irls_step > 0 && a.irls_state[(size_t)sf * kIrlsStateDoubles + 66] != 0.0) return;  // the estimate failed in an earlier step
+  const float* __restrict__ wsrc = WEIGHTED ? a.irls_weights + (size_t)sf * (((size_t)n + 3) & ~(size_t)3) : nullptr;
+  if (n < P + 1) {  // (lpc.rs:860-862: nothing to estimate from)
+    for (int c = tid; c < 33 + P * P; c += nthr) out[c] = 0.0;
+    if (a.autocorr && !irls && tid <= 32) a.autocorr[(size_t)sf * 33 + tid] = 0.0;
+    return;
+  }
+  // x_w = (f32)s * w, one f32 rounding (lpc.rs:751-754), widened once; samples [4 q, 4 q + 4), zeros behind the block
+  struct Quad {
+    int4 va, vb;
+    float4 wt;
+  };
+  auto fetch = [&](int q) -> Quad {  // (rows are 16-byte aligned with a stride of whole quads: the launcher checks)
+    Quad r;
+    r.va = r.vb = make_int4(0, 0, 0, 0);
+    r.wt = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (WEIGHTED && 4 * q < n) r.wt = *reinterpret_cast<const float4*>(wsrc + 4 * q);  // (rows of whole quads)
+    if (4 * q + 3 < n) {
+      r.va = *reinterpret_cast<const int4*>(rowA + 4 * q);
+      if (STEREO && kind >= 2) r.vb = *reinterpret_cast<const int4*>(rowB + 4 * q);
+    } else if (4 * q < n) {
+      int32_t ta[4] = {0, 0, 0, 0}, tb[4] = {0, 0, 0, 0};
+      for (int u = 0; u < 4 && 4 * q + u < n; ++u) {
+        ta[u] = rowA[4 * q + u];
+        if (STEREO && kind >= 2) tb[u] = rowB[4 * q + u];
+      }
+      r.va = make_int4(ta[0], ta[1], ta[2], ta[3]);
+      r.vb = make_int4(tb[0], tb[1], tb[2], tb[3]);
+    }
+    return r;
+  };
+  auto place = [&](int q, const Quad& r, int at) {  // -> win[at .. at + 4)
+    int4 v = r.va;
+    if (STEREO && kind == 2) v = make_int4((r.va.x + r.vb.x) >> 1, (r.va.y + r.vb.y) >> 1, (r.va.z + r.vb.z) >> 1, (r.va.w + r.vb.w) >> 1);
+    if (STEREO && kind == 3) v = make_int4(r.va.x - r.vb.x, r.va.y - r.vb.y, r.va.z - r.vb.z, r.va.w - r.vb.w);  // coding.rs:483
+    float4 w4 = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+    if (wtab && 4 * q + 3 < n) w4 = *reinterpret_cast<const float4*>(wtab + 4 * q);
+    else if (wtab) {
+      float tw[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+      for (int u = 0; u < 4 && 4 * q + u < n; ++u) tw[u] = wtab[4 * q + u];
+      w4 = make_float4(tw[0], tw[1], tw[2], tw[3]);
+    }
+    const float4 xv = make_float4((float)v.x * w4.x, (float)v.y * w4.y, (float)v.z * w4.z, (float)v.w * w4.w);
+    *reinterpret_cast<double2*>(&win[at]) = make_double2((double)xv.x, (double)xv.y);
+    *reinterpret_cast<double2*>(&win[at + 2]) = make_double2((double)xv.z, (double)xv.w);
+    if (WEIGHTED) {
+      *reinterpret_cast<float4*>(&xf[at]) = xv;
+      *reinterpret_cast<float4*>(&ww[at]) = r.wt;
+    }
+  };
+  // wave -> tile (I, J) of 16 x 16: (0,0) (0,1) (1,1) (1,0) -- column block 0 and the upper triangle of the 2 x 2 tiles of
+  // orders 12..31; lane l: A row / B column 16 I + l % 16 (rows and columns beyond P shadow P and are never stored),
+  // k = l / 16
+  const int len = n - P;
+  const int kq = lane >> 4;
+  const int TI = (wave == 2 || wave == 3) ? 1 : 0, TJ = (wave == 1 || wave == 2) ? 1 : 0;
+  int arow = 16 * TI + (lane & 15), bcol = 16 * TJ + (lane & 15);
+  arow = arow > P ? P : arow;
+  bcol = bcol > P ? P : bcol;
+  const int oa = (P - arow) + kq, ob = (P - bcol) + kq;  // step k reads x_w[(P - row) + k + kq]
+  typedef double v4d_t __attribute__((ext_vector_type(4)));
+  v4d_t acc = {0.0, 0.0, 0.0, 0.0};
+  // window = samples [base, base + 512 + halo)
+  constexpr int kWinQuads = (kStreamPiece + kStreamHalo) / 4;  // 140
+  for (int q = tid; q < kWinQuads; q += nthr) place(q, fetch(q), 4 * q);
+  __syncthreads();
+  for (int base = 0; base < len; base += kStreamPiece) {
+    // the next 512 samples (behind the halo already here) on their way while this piece is walked
+    const bool more = base + kStreamPiece < len;
+    Quad nx[2];
+    const int q_next = (base + kStreamPiece + kStreamHalo) / 4 + tid;
+    if (more) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        if (tid + u * nthr < kStreamPiece / 4) nx[u] = fetch(q_next + u * nthr);
+    }
+    const int steps_here = (len - base) < kStreamPiece ? (len - base) : kStreamPiece;
+    const float* __restrict__ pw = ww + P + kq;  // w[t' + 1]
+    auto step = [&](int kk) __attribute__((always_inline)) {
+      const double bv = WEIGHTED ? (double)(pw[kk] * xf[ob + kk]) : win[ob + kk];
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(win[oa + kk], bv, acc, 0, 0, 0);
+    };
+    int k = 0;
+    for (; k + 32 <= steps_here; k += 32) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) step(k + 4 * u);
+    }
+    for (; k + 4 <= steps_here; k += 4) step(k);
+    if (k < steps_here) {  // the block's last one to three steps: the missing ones multiply by 0 (x + 0 * y == x)
+      const bool in = k + kq < steps_here;
+      const double av = in ? win[oa + k] : 0.0;
+      const double bv = !in ? 0.0 : (WEIGHTED ? (double)(pw[k] * xf[ob + k]) : win[ob + k]);
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+    }
+    if (more) {
+      __syncthreads();  // every wave is done with this piece
+      if (tid < kStreamHalo / 4) {
+        const double2 t0 = *reinterpret_cast<const double2*>(&win[kStreamPiece + 4 * tid]);
+        const double2 t1 = *reinterpret_cast<const double2*>(&win[kStreamPiece + 4 * tid + 2]);
+        float4 f0, f1;
+        if (WEIGHTED) {
+          f0 = *reinterpret_cast<const float4*>(&xf[kStreamPiece + 4 * tid]);
+          f1 = *reinterpret_cast<const float4*>(&ww[kStreamPiece + 4 * tid]);
+        }
+        // (the halo's first quads land where its last ones are read from only if halo > piece: not so)
+        *reinterpret_cast<double2*>(&win[4 * tid]) = t0;
+        *reinterpret_cast<double2*>(&win[4 * tid + 2]) = t1;
+        if (WEIGHTED) {
+          *reinterpret_cast<float4*>(&xf[4 * tid]) = f0;
+          *reinterpret_cast<float4*>(&ww[4 * tid]) = f1;
+        }
+      }
+      __syncthreads();  // (the refill below overwrites the old halo's place)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        if (tid + u * nthr < kStreamPiece / 4) place(q_next + u * nthr, nx[u], kStreamHalo + 4 * (tid + u * nthr));
+      __syncthreads();
+    }
+  }
+  // output register r of lane l: row 4 r + l / 16, column l % 16
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int ra = 16 * TI + 4 * r + kq, cb = 16 * TJ + (lane & 15);
+    const double v = acc[r];
+    if (cb == 0 && ra <= P) {
+      out[ra] = v;
+      if (a.autocorr && !irls) a.autocorr[(size_t)sf * 33 + ra] = v;
+    } else if (ra >= 1 && ra <= cb && cb <= P) {
+      out[33 + (ra - 1) + (cb - 1) * P] = v;
+      out[33 + (cb - 1) + (ra - 1) * P] = v;
+    }
+  }
+  if (tid > P && tid <= 32) {
+    out[tid] = 0.0;
+    if (a.autocorr && !irls) a.autocorr[(size_t)sf * 33 + tid] = 0.0;
+  }
+}
+
 // ---- the same for orders up to 11 alone: one wave, at most two instructions, pointers instead of tables (measured: order 8
 // 0.356 ms per 12288 subframes against 0.479 in the general form above) ----
 // The chains of orders up to 11 without IRLS steps, ONE WAVE per subframe and a SLIDING f64 window instead of the whole
@@ -1287,6 +1452,16 @@ hipError_t launch_direct_mse(const DirectMseArgs& a, hipStream_t stream) {
       }
       return hipGetLastError();
     }
+    if (d.lpc_order <= 31) {
+      if (d.stereo) {
+        if (weighted) hipLaunchKernelGGL((direct_mse_stream_tiles_kernel<true, true>), dim3(d.n_subframes), dim3(256), 0, stream, d);
+        else hipLaunchKernelGGL((direct_mse_stream_tiles_kernel<true, false>), dim3(d.n_subframes), dim3(256), 0, stream, d);
+      } else {
+        if (weighted) hipLaunchKernelGGL((direct_mse_stream_tiles_kernel<false, true>), dim3(d.n_subframes), dim3(256), 0, stream, d);
+        else hipLaunchKernelGGL((direct_mse_stream_tiles_kernel<false, false>), dim3(d.n_subframes), dim3(256), 0, stream, d);
+      }
+      return hipGetLastError();
+    }
     const dim3 grid(d.n_subframes), block(64 * nw);
 #define FLACENC_DM_STREAM(ST, WT, N_) hipLaunchKernelGGL((direct_mse_stream_kernel<ST, WT, N_>), grid, block, 0, stream, d);
 #define FLACENC_DM_STREAM_N(ST, WT)                        \
@@ -1305,10 +1480,11 @@ hipError_t launch_direct_mse(const DirectMseArgs& a, hipStream_t stream) {
 #undef FLACENC_DM_STREAM
     return hipGetLastError();
   };
-  // (without IRLS steps the 16 x 16 tiles of the one-kernel form stay ahead at orders 12..31 -- 2.05 against 2.40 ms per 768
-  // frames of 16384 samples at order 24: the block form's f64 operands are LDS-bound there, two 512-byte reads per 16-cycle
-  // MFMA on each of four SIMDs -- and fall behind at 32, whose third tile row is mostly padding: 5.6 against 3.9 ms)
-  if (!irls && streamable && (a.lpc_order <= 11 || a.lpc_order == 32)) {
+  // (orders up to 11: 4 x 4 blocks on one wave; 12..31: the four 16 x 16 tiles on four waves -- the 4 x 4 block form is
+  // LDS-bound there, two 512-byte f64 operand reads per 16-cycle MFMA on each of four SIMDs: 2.40 against 1.87 ms per
+  // 768 frames of 16384 samples at order 24; order 32: 4 x 4 blocks on four waves, whose third tile row would be mostly
+  // padding: 5.6 -> 3.8 ms)
+  if (!irls && streamable) {
     if (hipError_t e = launch_stream(a, false); e != hipSuccess) return e;
     return launch_solve(a, 0);
   }

@@ -1157,8 +1157,11 @@ __global__ void __launch_bounds__(64) direct_mse_stream_small_kernel(DirectMseAr
 constexpr int kIrlsErrThreads = 256;
 template <bool STEREO>
 __global__ void __launch_bounds__(kIrlsErrThreads) direct_mse_irls_error_kernel(DirectMseArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  __shared__ float echunk[kErrChunk];
+  // (f32)s of one 1024-sample chunk + the 32 samples in front of it: what every tap and the leading term convert to.
+  // A window, not the block: 8.3 KB of LDS per workgroup keep eighteen subframes' sequential sums going per CU where
+  // the whole block (64 KB at 16384 samples) kept two.
+  __shared__ __attribute__((aligned(16))) float xs[kErrChunk + 32];
+  __shared__ __attribute__((aligned(16))) float echunk[kErrChunk];
   __shared__ float cf[32];
   __shared__ int smax;
   __shared__ float ssum;
@@ -1169,7 +1172,6 @@ __global__ void __launch_bounds__(kIrlsErrThreads) direct_mse_irls_error_kernel(
   double* const st = a.irls_state + (size_t)sf * kIrlsStateDoubles;
   if (st[66] != 0.0) return;  // (uniform)
   const int n4 = (n + 3) & ~3;
-  float* const xs = reinterpret_cast<float*>(smem_raw);  // (f32)s: what every tap and the leading term convert to
   float* __restrict__ wout = a.irls_weights + (size_t)sf * n4;
   const int32_t* rowA;
   const int32_t* rowB = nullptr;
@@ -1182,39 +1184,51 @@ __global__ void __launch_bounds__(kIrlsErrThreads) direct_mse_irls_error_kernel(
   } else {
     rowA = a.samples + (size_t)sf * a.stride;
   }
-  int my_maxabs = 0;
-  for (int t = tid; t < n; t += kIrlsErrThreads) {
+  auto sample = [&](int t) -> int32_t {
     int32_t s = rowA[t];
     if (STEREO && kind >= 2) {
       const int32_t r = rowB[t];
       s = kind == 2 ? (s + r) >> 1 : s - r;  // coding.rs:483
     }
-    xs[t] = (float)s;
-    const int32_t ab = s < 0 ? (int32_t)(0u - (uint32_t)s) : s;  // i32::abs (wrapping)
-    my_maxabs = ab > my_maxabs ? ab : my_maxabs;
-  }
+    return s;
+  };
+  const bool last = a.irls_step == a.mae_steps;  // no step follows: its weights are never read
   if (tid == 0) {
     smax = 0;
     ssum = 0.0f;
   }
   if (tid < 32) cf[tid] = tid < P ? (float)st[tid] : 0.0f;
   __syncthreads();
+  float normalizer = 1.0f;
+  if (!last) {  // the normaliser of the weights: max |s| over the block (lpc.rs:823-826)
+    int my_maxabs = 0;
+    for (int t = tid; t < n; t += kIrlsErrThreads) {
+      const int32_t s = sample(t);
+      const int32_t ab = s < 0 ? (int32_t)(0u - (uint32_t)s) : s;  // i32::abs (wrapping)
+      my_maxabs = ab > my_maxabs ? ab : my_maxabs;
+    }
 #pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const int o = __shfl_xor(my_maxabs, d, 64);
-    my_maxabs = o > my_maxabs ? o : my_maxabs;
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_xor(my_maxabs, d, 64);
+      my_maxabs = o > my_maxabs ? o : my_maxabs;
+    }
+    if ((tid & 63) == 0) atomicMax(&smax, my_maxabs);
+    __syncthreads();
+    normalizer = (float)smax;
   }
-  if ((tid & 63) == 0) atomicMax(&smax, my_maxabs);
-  __syncthreads();
-  const float normalizer = (float)smax;
-  const bool last = a.irls_step == a.mae_steps;  // no step follows: its weights are never read
   for (int base = 0; base < n; base += kErrChunk) {
+    __syncthreads();  // the previous chunk's errors are summed, its window is free
+    for (int o = tid; o < kErrChunk + 32; o += kIrlsErrThreads) {
+      const int t = base - 32 + o;
+      xs[o] = (t >= 0 && t < n) ? (float)sample(t) : 0.0f;
+    }
+    __syncthreads();
     for (int o = tid; o < kErrChunk && base + o < n; o += kIrlsErrThreads) {
       const int t = base + o;
       float e = 0.0f;  // raw_errors[t] for t < order: never written, 0
       if (t >= P) {
-        e = -xs[t];  // (f32)(-s) == -(f32)s: rounding is symmetric
-        for (int j = 0; j < P; ++j) e = __builtin_fmaf(cf[j], xs[t - 1 - j], e);
+        e = -xs[32 + o];  // (f32)(-s) == -(f32)s: rounding is symmetric
+        for (int j = 0; j < P; ++j) e = __builtin_fmaf(cf[j], xs[32 + o - 1 - j], e);
         if (!last) {
           float x = __builtin_fabsf(e);
           x = x > 1.0f ? x : 1.0f;
@@ -1229,6 +1243,8 @@ __global__ void __launch_bounds__(kIrlsErrThreads) direct_mse_irls_error_kernel(
     }
     __syncthreads();
     if (tid == 0) {
+      // (Iterator::sum is one sequential chain: sixteen values per trip come as four 16-byte reads, the additions
+      // stay in order)
       float sacc = ssum;
       const int cnt = n - base < kErrChunk ? n - base : kErrChunk;
       int o = 0;
@@ -1245,8 +1261,8 @@ __global__ void __launch_bounds__(kIrlsErrThreads) direct_mse_irls_error_kernel(
       for (; o < cnt; ++o) sacc += echunk[o];
       ssum = sacc;
     }
-    __syncthreads();
   }
+  __syncthreads();
   const float best_error = a.irls_step == 0 ? 3.40282347e+38f : (float)st[64];  // f32::MAX
   if (ssum < best_error) {  // (uniform)
     if (tid < 32) st[32 + tid] = st[tid];
@@ -1490,8 +1506,6 @@ hipError_t launch_direct_mse(const DirectMseArgs& a, hipStream_t stream) {
   }
   if (irls && streamable && a.weight_scratch != nullptr && a.irls_state != nullptr) {
     // IRLS: per step the (weighted) chains, the batched solve, the error pass; then the best solution
-    const size_t err_smem = (((size_t)a.block_size + 3) & ~(size_t)3) * 4;
-    static DynamicLdsOptIn err_opt[2];
     DirectMseArgs d = a;
     d.irls_weights = a.weight_scratch;
     for (uint32_t it = 0; it <= a.mae_steps; ++it) {
@@ -1499,15 +1513,8 @@ hipError_t launch_direct_mse(const DirectMseArgs& a, hipStream_t stream) {
       // (the first step's weights are 1: the unweighted chain, operand for operand)
       if (hipError_t e = launch_stream(d, it != 0); e != hipSuccess) return e;
       if (hipError_t e = launch_solve(d, 1); e != hipSuccess) return e;
-      if (a.stereo) {
-        auto kern = direct_mse_irls_error_kernel<true>;
-        if (hipError_t e = err_opt[0].ensure(reinterpret_cast<const void*>(kern), err_smem); e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3(a.n_subframes), dim3(kIrlsErrThreads), err_smem, stream, d);
-      } else {
-        auto kern = direct_mse_irls_error_kernel<false>;
-        if (hipError_t e = err_opt[1].ensure(reinterpret_cast<const void*>(kern), err_smem); e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3(a.n_subframes), dim3(kIrlsErrThreads), err_smem, stream, d);
-      }
+      if (a.stereo) hipLaunchKernelGGL(direct_mse_irls_error_kernel<true>, dim3(a.n_subframes), dim3(kIrlsErrThreads), 0, stream, d);
+      else hipLaunchKernelGGL(direct_mse_irls_error_kernel<false>, dim3(a.n_subframes), dim3(kIrlsErrThreads), 0, stream, d);
       if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
     }
     return launch_solve(d, 2);

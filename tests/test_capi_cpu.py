@@ -94,3 +94,16 @@ def test_sigen_matches_numpy_model():
     # determinism and thread-count independence
     y = _capi.sigen_frames(3, 2, n, bps, 200.0, 0.4, 0.4, seed=7, first_frame=5, nthreads=1)
     assert np.array_equal(x, y)
+
+
+def test_frame_wire_bytes_follow_the_finest_partition_count():
+    """flacenc_hip_frame_wire_bytes (host arithmetic): 48 bytes of frame fields + two subframe records cut behind
+    2^finest_partition_order Rice parameters (src/rice.rs:157-165, with the oracle's finest_partition_order for the
+    largest warm-up the order bound allows) -- the size shard.py's host statement of the wire format uses."""
+    from flacenc_rs_amd import shard
+    lib = _capi.load()
+    for n in list(range(1, 70)) + [96, 100, 128, 192, 256, 288, 512, 576, 1000, 1024, 1152, 2048, 2304, 4095, 4096, 4097,
+                                   4608, 8192, 16384, 20000, 32767]:
+        assert lib.flacenc_hip_frame_wire_bytes(n) == shard.wire_record_bytes(n), n
+        assert shard.wire_record_bytes(n) <= 752
+    assert shard.wire_record_bytes(4096) == 368 and shard.wire_record_bytes(16384) == 752

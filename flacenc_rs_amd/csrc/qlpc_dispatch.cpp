@@ -36,7 +36,7 @@ bool wave_kernel_eligible(const QlpcKernelArgs& a) {
 }
 
 bool subwave_shape(uint32_t n) {
-  return n == 512 || n == 1024 || n == 2048 || n == 576 || n == 1152 || n == 2304;
+  return n == 256 || n == 512 || n == 1024 || n == 2048 || n == 288 || n == 576 || n == 1152 || n == 2304;
 }
 
 static bool subwave_buffers_ok(const QlpcKernelArgs& a) {

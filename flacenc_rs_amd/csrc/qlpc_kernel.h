@@ -176,8 +176,8 @@ FLACENC_HIP_FOR_EACH_WAVE72_INSTANCE(FLACENC_HIP_DECLARE_WAVE72_INSTANCE)
   hipError_t launch_bigblock_residual_##K_##_##NLB_(const QlpcKernelArgs&, hipStream_t);
 FLACENC_HIP_FOR_EACH_BIGRES_INSTANCE(FLACENC_HIP_DECLARE_BIGRES_INSTANCE)
 
-// qlpc_subwave_kernel: several subframes per wave for blocks of 8 / 16 / 32 finest Rice partitions (512 / 1024 / 2048,
-// 576 / 1152 / 2304 samples) at orders up to 12; one translation unit per (order bucket, stereo, samples per lane,
+// qlpc_subwave_kernel: several subframes per wave for blocks of 4 / 8 / 16 / 32 finest Rice partitions (256 .. 2048,
+// 288 .. 2304 samples) at orders up to 12; one translation unit per (order bucket, stereo, samples per lane,
 // variant: 0 QLPC candidates, 1 fixed_lpc batch with the ApproxEnt selector, 2 the 2-channel frame decision, 3 frames of
 // independent channels)
 bool subwave_shape(uint32_t block_size);

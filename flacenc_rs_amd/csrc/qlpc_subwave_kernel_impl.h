@@ -1,9 +1,9 @@
 // qlpc_subwave_kernel_impl.h -- the fused QLPC kernel for blocks smaller than one wave's worth of finest Rice
-// partitions: 512 / 1024 / 2048 (64 samples per lane) and 576 / 1152 / 2304 (72 per lane, the CD-style sizes).
+// partitions: 256 / 512 / 1024 / 2048 (64 samples per lane) and 288 / 576 / 1152 / 2304 (72 per lane, the CD-style sizes).
 //
 // qlpc_wave_kernel_impl.h gives a subframe of 4096 (4608) samples one wave: lane l holds one finest Rice partition
 // (rice.rs:157-165).  A block of 1152 samples has sixteen such partitions, so here a wave carries 64 / LPS subframes
-// side by side, LPS = 8 / 16 / 32 lanes each ("segments" of the wave): every per-wave cost of the generic kernel on
+// side by side, LPS = 4 / 8 / 16 / 32 lanes each ("segments" of the wave): every per-wave cost of the generic kernel on
 // these sizes -- the lag trees, the serial Levinson recursion, the Rice level search, each the same number of wave
 // instructions whatever the block size -- is paid once per 2 / 4 / 8 subframes.  The phases are those of the wave
 // kernel with the wave-wide reductions cut at the segment:
@@ -44,7 +44,7 @@ struct SubGeom {
   static constexpr int Seg = SPL + 4;             // a lane's samples + 4 dwords: conflict-free 16-byte reads (see WaveGeom)
   static constexpr int Img = (LPS + 1) * Seg + 4; // one all-zero segment in front
   static constexpr int S = 64 / LPS;              // subframes per wave
-  static constexpr int LOGL = LPS == 8 ? 3 : (LPS == 16 ? 4 : 5);
+  static constexpr int LOGL = LPS == 4 ? 2 : (LPS == 8 ? 3 : (LPS == 16 ? 4 : 5));
   static constexpr int QuadsPerRow = N / 4;
   static constexpr int QuadsPerSeg = SPL / 4;
   // index inside an image of the 16-byte piece qq of a row
@@ -66,13 +66,13 @@ struct SubGeom {
 
 #define FLACENC_SUB_DPP(v, ctrl) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), (ctrl), 0xF, 0xF, false))
 
-// all-reduce over the LPS lanes of a segment (segments are aligned: 8 lanes = half a DPP row, 16 = a row, 32 = two):
+// all-reduce over the LPS lanes of a segment (segments are aligned: 4 lanes = a quad, 8 = half a DPP row, 16 = a row, 32 = two):
 // quad butterfly, half-row mirror, row mirror, lane ^ 16.  `op` must be commutative and associative (integers).
 template <int LPS, class Op>
 __device__ __forceinline__ uint32_t seg_allreduce(uint32_t v, Op op) {
   v = op(v, FLACENC_SUB_DPP(v, 0xB1));   // quad_perm [1, 0, 3, 2]
   v = op(v, FLACENC_SUB_DPP(v, 0x4E));   // quad_perm [2, 3, 0, 1]
-  v = op(v, FLACENC_SUB_DPP(v, 0x141));  // row_half_mirror: lane i <- 7 - i of its half row
+  if (LPS >= 8) v = op(v, FLACENC_SUB_DPP(v, 0x141));  // row_half_mirror: lane i <- 7 - i of its half row
   if (LPS >= 16) v = op(v, FLACENC_SUB_DPP(v, 0x140));  // row_mirror
   if (LPS >= 32) v = op(v, (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x401F));  // lane ^ 16
   return v;
@@ -100,7 +100,7 @@ __device__ __forceinline__ double seg_tree_sum_last(double v) {
   }
   FLACENC_F64_DPP_STEP(0x111, 0xF)
   FLACENC_F64_DPP_STEP(0x112, 0xF)
-  FLACENC_F64_DPP_STEP(0x114, 0xF)
+  if (LPS >= 8) FLACENC_F64_DPP_STEP(0x114, 0xF)
   if (LPS >= 16) FLACENC_F64_DPP_STEP(0x118, 0xF)
   if (LPS >= 32) FLACENC_F64_DPP_STEP(0x142, 0xA)  // row_bcast15 into rows 1 and 3
 #undef FLACENC_F64_DPP_STEP
@@ -948,6 +948,7 @@ template <int MAXP, bool STEREO, int SPL, int VARIANT>
 hipError_t launch_subwave(const QlpcKernelArgs& a, hipStream_t stream) {
   const uint32_t lps = a.block_size / (uint32_t)SPL;
   if (a.block_size != lps * (uint32_t)SPL) return hipErrorInvalidValue;
+  if (lps == 4) return launch_subwave_geom<MAXP, STEREO, SPL, 4, VARIANT>(a, stream);
   if (lps == 8) return launch_subwave_geom<MAXP, STEREO, SPL, 8, VARIANT>(a, stream);
   if (lps == 16) return launch_subwave_geom<MAXP, STEREO, SPL, 16, VARIANT>(a, stream);
   if (lps == 32) return launch_subwave_geom<MAXP, STEREO, SPL, 32, VARIANT>(a, stream);

@@ -303,7 +303,7 @@ typedef struct flacenc_hip_stereo_frame_result {
  * :230-288), runs on the GPU too, so the whole default-configuration decision is on the device.
  * Block size 4096 with lpc_order <= 12, 16-byte aligned rows and power-of-two ApproxEnt.partitions
  * runs as ONE fused kernel (a wave per candidate, samples read from HBM once, losing candidates never
- * leave the CU); so do blocks of 512 / 1024 / 2048 and 576 / 1152 / 2304 samples (8 / 16 / 32 finest Rice
+ * leave the CU); so do blocks of 256 / 512 / 1024 / 2048 and 288 / 576 / 1152 / 2304 samples (4 .. 32 finest Rice
  * partitions: several frames per workgroup) with the ApproxEnt selector and estimator partitions of a quarter,
  * half or whole number of those; blocks of 8192 / 16384 samples (and 4096 from order 13) take two analysing
  * passes and a deciding store pass; every other shape (any block size 64..32767, any order, any partition

@@ -12,7 +12,7 @@ from test_gpu_parity import batch_sine_noise, full_parity, assert_records_equal
 
 pytestmark = pytest.mark.gpu
 
-SIZES = [512, 1024, 2048, 576, 1152, 2304]
+SIZES = [256, 512, 1024, 2048, 288, 576, 1152, 2304]
 
 
 @pytest.fixture(scope="module")
@@ -69,7 +69,7 @@ def test_finest_rice_order_flag(handle, n):
     pp, pres = handle.stereo_qlpc_batch(frames, 16, _capi.make_config(lpc_order=8, rice_finest_only=True,
                                                                       flags=_capi.FLAG_GENERIC_KERNEL))
     assert gp.tobytes() == pp.tobytes() and np.array_equal(gres, pres)
-    finest = {576: 3, 1024: 4, 2304: 5}[n]
+    finest = {576: 3, 1024: 4, 2304: 5}[n]  # (256 / 288: 2)
     assert (gp["rice_order"] == finest).all()
 
 
@@ -227,7 +227,8 @@ def test_encode_stereo_frames(handle, n, order, bps, flags):
     want, wres = orc.encode_stereo_frames_cfg(x, bps, ocfg)
     _check_frames_against_oracle(x, bps, got, gres, want, wres)
     _decode_frames(x, got, gres)
-    assert len({int(k) for k in got["kind"].reshape(-1)}) >= 3 and len({int(a) for a in got["channel_assignment"]}) >= 2
+    if n >= 512:  # (the corpus shows every kind and several assignments; the shortest blocks settle on fewer)
+        assert len({int(k) for k in got["kind"].reshape(-1)}) >= 3 and len({int(a) for a in got["channel_assignment"]}) >= 2
 
 
 @pytest.mark.parametrize("n", [1152, 2048, 576])

@@ -12,7 +12,7 @@ import numpy as np  # noqa: E402
 
 from flacenc_rs_amd import _capi  # noqa: E402
 
-SIZES = [512, 1024, 2048, 576, 1152, 2304]
+SIZES = [256, 512, 1024, 2048, 288, 576, 1152, 2304]
 
 
 def signals(rng, nf, n, bps):

@@ -73,6 +73,7 @@ run("ragged: 576 x 16b stereo, order 8 (sub-wave kernel: 8 subframes per wave)",
 run("ragged: 1152 x 16b stereo, order 10 (sub-wave kernel)", 16384, 2, 1152, 16, 10, True)
 run("2048 x 16b stereo, order 8 (sub-wave kernel)", 8192, 2, 2048, 16, 8, True)
 run("1024 x 16b stereo, order 8 (sub-wave kernel)", 16384, 2, 1024, 16, 8, True)
+run("256 x 16b stereo, order 8 (sub-wave kernel: 16 subframes per wave)", 65536, 2, 256, 16, 8, True)
 run("1152 x 16b, 8 independent channels, order 8 (sub-wave kernel, plain batches)", 4096, 8, 1152, 16, 8, False)
 # the big-block shapes at 3 x the batch: whole rounds of workgroups for every kernel (512 and 768 resident
 # workgroups), launch costs amortised
@@ -152,6 +153,7 @@ run_stereo_frames("frames: 1152 x 16b stereo, default candidates, order 8 (sub-w
 run_stereo_frames("frames: 2304 x 16b stereo, default candidates, order 8 (sub-wave kernel, one launch)", 8192, 2304, 16, 8)
 run_stereo_frames("frames: 1152 x 16b stereo, default candidates, order 10 (sub-wave kernel, one launch)", 16384, 1152, 16, 10)
 run_stereo_frames("frames: 2048 x 16b stereo, default candidates, order 8 (sub-wave kernel, one launch)", 8192, 2048, 16, 8)
+run_stereo_frames("frames: 256 x 16b stereo, default candidates, order 8 (sub-wave kernel, one launch)", 65536, 256, 16, 8)
 run_stereo_frames("frames: 4096 x 16b stereo, default candidates, order 10 (fused wave kernel)", 8192, 4096, 16, 10)
 run_frames("config4: 4096 x 16b 8-channel, default config, frames", 2048, 8, 4096, 16, 10)
 run_frames("mono: 4096 x 16b, default config, frames", 8192, 1, 4096, 16, 10)

@@ -113,8 +113,12 @@ __device__ __forceinline__ double seg_tree_sum_last(double v) {
 // try_stereo_coding's assignment (:493-522), one flacenc_hip_stereo_frame_result and the TWO chosen rows per frame;
 // 3 (plain): encode_frame for Independent(n) frames (coding.rs:537-541) -- both candidates and encode_subframe's choice
 // per channel, one flacenc_hip_channel_result and the chosen row per subframe.
-template <int MAXP, bool STEREO, int SPL, int LPS, int VARIANT>
+// S16 (plain, material declared at most 16 bits wide): the images hold int16 -- half the LDS, six workgroups per CU
+// instead of three (a plain workgroup's 8 .. 32 images, not its registers, bound its occupancy).  A sample outside int16
+// (the caller's declared width was wrong: flacenc_hip.h's precondition) marks its subframe for the generic kernel.
+template <int MAXP, bool STEREO, int SPL, int LPS, int VARIANT, bool S16 = false>
 __global__ void __launch_bounds__(STEREO ? 256 : 128, 3) qlpc_subwave_kernel(QlpcKernelArgs a) {
+  static_assert(!S16 || !STEREO, "mid / side need 17 bits");
   static_assert(VARIANT != 2 || STEREO, "the frame decision is the 2-channel one");
   static_assert(VARIANT != 3 || !STEREO, "independent channels are plain subframes");
   using G = SubGeom<SPL, LPS>;
@@ -131,8 +135,10 @@ __global__ void __launch_bounds__(STEREO ? 256 : 128, 3) qlpc_subwave_kernel(Qlp
   constexpr bool DECIDE = VARIANT >= 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   int32_t* const sm = reinterpret_cast<int32_t*>(smem_raw);
-  float* const wlds = reinterpret_cast<float*>(sm + NIMG * G::Img);
-  double* const xr = reinterpret_cast<double*>(sm + (NIMG + 1) * G::Img);  // [SUBS][NLAG]
+  constexpr int IMGD = S16 ? G::Img / 2 : G::Img;  // dwords per image
+  const int16_t* const sm16 = reinterpret_cast<const int16_t*>(smem_raw);
+  float* const wlds = reinterpret_cast<float*>(sm + NIMG * IMGD);
+  double* const xr = reinterpret_cast<double*>(sm + NIMG * IMGD + G::Img);  // [SUBS][NLAG]
   int32_t* const xq = reinterpret_cast<int32_t*>(xr + SUBS * NLAG);        // [SUBS][16]
   // DECIDE: per subframe slot {bits lo, bits hi, kind, dc, status, redo, 0, 0}
   uint32_t* const xd = reinterpret_cast<uint32_t*>(xq + SUBS * 16);        // [SUBS][8]
@@ -168,7 +174,14 @@ __global__ void __launch_bounds__(STEREO ? 256 : 128, 3) qlpc_subwave_kernel(Qlp
   const int role = STEREO ? wave : 0;
 
   // ======================= phase 0: HBM -> LDS ==============================
-  for (int i = tid; i < NIMG * G::Seg; i += THREADS) sm[(i / G::Seg) * G::Img + (i % G::Seg)] = 0;
+  {
+    constexpr int ZD = S16 ? G::Seg / 2 : G::Seg;  // dwords of an image's leading zero segment
+    for (int i = tid; i < NIMG * ZD; i += THREADS) sm[(i / ZD) * IMGD + (i % ZD)] = 0;
+    if (S16) {
+      for (int i = tid; i < SUBS; i += THREADS) xd[i * 8 + 7] = 0u;  // "a sample did not fit int16"
+      __syncthreads();
+    }
+  }
   if (LPC) {
     const bool has_window = a.window != nullptr;
     const float* __restrict__ wsrc = a.window + 32;
@@ -199,7 +212,16 @@ __global__ void __launch_bounds__(STEREO ? 256 : 128, 3) qlpc_subwave_kernel(Qlp
           src_row = r;
         }
         const int4 v = *reinterpret_cast<const int4*>(a.samples + src_row * a.stride + (qq << 2));
-        *reinterpret_cast<int4*>(&sm[row * G::Img + G::qidx(qq)]) = v;
+        if (S16) {
+          const uint32_t over = ((uint32_t)(v.x + 32768) | (uint32_t)(v.y + 32768) | (uint32_t)(v.z + 32768) | (uint32_t)(v.w + 32768)) >> 16;
+          if (over) atomicOr(&xd[row * 8 + 7], 1u);
+          int2 pk;
+          pk.x = (int)(((uint32_t)v.x & 0xFFFFu) | ((uint32_t)v.y << 16));
+          pk.y = (int)(((uint32_t)v.z & 0xFFFFu) | ((uint32_t)v.w << 16));
+          *reinterpret_cast<int2*>(&sm[row * IMGD + (G::qidx(qq) >> 1)]) = pk;
+        } else {
+          *reinterpret_cast<int4*>(&sm[row * G::Img + G::qidx(qq)]) = v;
+        }
       }
     }
   }
@@ -209,6 +231,10 @@ __global__ void __launch_bounds__(STEREO ? 256 : 128, 3) qlpc_subwave_kernel(Qlp
   const int32_t* const bufB = sm + img_b;
   auto ld4_at = [&](auto kind_tag, int ix) -> int4 {
     constexpr int KIND = decltype(kind_tag)::value;  // 0 = own image, 2 = mid, 3 = side
+    if (S16) {
+      const int2 pk = *reinterpret_cast<const int2*>(&sm16[img_a + ix]);
+      return make_int4((pk.x << 16) >> 16, pk.x >> 16, (pk.y << 16) >> 16, pk.y >> 16);
+    }
     typedef int v4i_t __attribute__((ext_vector_type(4)));
     v4i_t va = *reinterpret_cast<const v4i_t*>(&bufA[ix]);
     asm("" : "+v"(va));
@@ -576,8 +602,14 @@ __global__ void __launch_bounds__(STEREO ? 256 : 128, 3) qlpc_subwave_kernel(Qlp
 #pragma unroll
         for (int k = 0; k < SPL / 4 + 1; ++k) {
           const int ix = G::rel(lb, -4 + 4 * k);
-          v4u_t va = *reinterpret_cast<const v4u_t*>(&bufA[ix]);
-          asm("" : "+v"(va));
+          v4u_t va;
+          if (S16) {
+            const int4 q = ld4_at(kind, ix);
+            va = v4u_t{(uint32_t)q.x, (uint32_t)q.y, (uint32_t)q.z, (uint32_t)q.w};
+          } else {
+            va = *reinterpret_cast<const v4u_t*>(&bufA[ix]);
+            asm("" : "+v"(va));
+          }
           if (KIND >= 2) {
             v4u_t vb = *reinterpret_cast<const v4u_t*>(&bufB[ix]);
             asm("" : "+v"(vb));
@@ -688,7 +720,7 @@ __global__ void __launch_bounds__(STEREO ? 256 : 128, 3) qlpc_subwave_kernel(Qlp
     store_row(a.residual + (size_t)sf * a.residual_stride);
     if (a.params == nullptr) return;
     flacenc_hip_subframe_params* rec = a.params + sf;
-    if (fx.redo) {
+    if (fx.redo || (S16 && xd[g * 8 + 7] != 0u)) {
       if (sl == 0) {
         rec->status = -1;
         if (a.marked_count != nullptr) atomicAdd(a.marked_count, 1u);
@@ -761,7 +793,7 @@ __global__ void __launch_bounds__(STEREO ? 256 : 128, 3) qlpc_subwave_kernel(Qlp
     // ======================= phase 5: the record ============================
     if (!active || a.params == nullptr) return;
     flacenc_hip_subframe_params* rec = a.params + sf;
-    if (lp.redo && status == 0) {
+    if ((lp.redo && status == 0) || (S16 && xd[g * 8 + 7] != 0u)) {
       if (sl == 0) {
         rec->status = -1;
         if (a.marked_count != nullptr) atomicAdd(a.marked_count, 1u);
@@ -794,7 +826,7 @@ __global__ void __launch_bounds__(STEREO ? 256 : 128, 3) qlpc_subwave_kernel(Qlp
       bits = verbatim_bits;
     }
     // a candidate the exact sums could not carry: the whole frame goes to the general path (launch_qlpc)
-    const bool redo = (a.use_lpc && status == 0 && lp.redo) || (have_fixed && fx.redo);
+    const bool redo = (a.use_lpc && status == 0 && lp.redo) || (have_fixed && fx.redo) || (S16 && xd[g * 8 + 7] != 0u);
     if (VARIANT == 3) {
       // ---- Independent(n) frames: the segment's subframe is one output channel ----
       if (!active) return;
@@ -928,14 +960,14 @@ __global__ void __launch_bounds__(STEREO ? 256 : 128, 3) qlpc_subwave_kernel(Qlp
   }
 }
 
-template <int MAXP, bool STEREO, int SPL, int LPS, int VARIANT>
+template <int MAXP, bool STEREO, int SPL, int LPS, int VARIANT, bool S16 = false>
 hipError_t launch_subwave_geom(const QlpcKernelArgs& a, hipStream_t stream) {
   using G = SubGeom<SPL, LPS>;
   constexpr int WAVES = STEREO ? 4 : 2;
   constexpr int SUBS = WAVES * G::S;
   constexpr int NIMG = STEREO ? 2 * G::S : SUBS;
-  constexpr size_t smem = (size_t)(NIMG + 1) * G::Img * 4 + (size_t)SUBS * ((MAXP + 1) * 8 + 64 + 32);
-  auto kern = qlpc_subwave_kernel<MAXP, STEREO, SPL, LPS, VARIANT>;
+  constexpr size_t smem = ((size_t)NIMG * (S16 ? G::Img / 2 : G::Img) + G::Img) * 4 + (size_t)SUBS * ((MAXP + 1) * 8 + 64 + 32);
+  auto kern = qlpc_subwave_kernel<MAXP, STEREO, SPL, LPS, VARIANT, S16>;
   static DynamicLdsOptIn opt_in;
   if (hipError_t err = opt_in.ensure(reinterpret_cast<const void*>(kern), smem); err != hipSuccess) return err;
   const uint32_t blocks = STEREO ? ((a.n_subframes >> 2) + (uint32_t)G::S - 1u) / (uint32_t)G::S
@@ -948,6 +980,15 @@ template <int MAXP, bool STEREO, int SPL, int VARIANT>
 hipError_t launch_subwave(const QlpcKernelArgs& a, hipStream_t stream) {
   const uint32_t lps = a.block_size / (uint32_t)SPL;
   if (a.block_size != lps * (uint32_t)SPL) return hipErrorInvalidValue;
+  if constexpr (!STEREO) {
+    if (a.bps == nullptr && a.bps_uniform <= 16u) {  // int16 images
+      if (lps == 4) return launch_subwave_geom<MAXP, STEREO, SPL, 4, VARIANT, true>(a, stream);
+      if (lps == 8) return launch_subwave_geom<MAXP, STEREO, SPL, 8, VARIANT, true>(a, stream);
+      if (lps == 16) return launch_subwave_geom<MAXP, STEREO, SPL, 16, VARIANT, true>(a, stream);
+      if (lps == 32) return launch_subwave_geom<MAXP, STEREO, SPL, 32, VARIANT, true>(a, stream);
+      return hipErrorInvalidValue;
+    }
+  }
   if (lps == 4) return launch_subwave_geom<MAXP, STEREO, SPL, 4, VARIANT>(a, stream);
   if (lps == 8) return launch_subwave_geom<MAXP, STEREO, SPL, 8, VARIANT>(a, stream);
   if (lps == 16) return launch_subwave_geom<MAXP, STEREO, SPL, 16, VARIANT>(a, stream);

@@ -295,3 +295,19 @@ def test_encode_independent_channel_frames(handle, n, channels, bps, order, use_
         got = flac_parse.parse_frame(packed[f], stream_bps=bps)
         assert got["channel_tag"] == channels - 1 and np.array_equal(got["channels"], x[f]), f
     assert {0, 1} <= kinds and (kinds & {2, 3})
+
+
+@pytest.mark.parametrize("n", [1152, 256, 2048])
+def test_samples_beyond_the_declared_width_fall_back(handle, n):
+    """Independent-channel frames declared 16 bits wide take int16 LDS images; a sample outside int16 breaks the caller's
+    precondition (flacenc_hip.h) -- the subframe is marked and the general path gives what it always gave."""
+    x = _capi.sigen_frames(6, 3, n, 16, 90.0, 0.5, 0.05, seed=n)
+    x[1, 0, n // 3] = 40000
+    x[4, 2, 5] = -32769
+    mk = lambda flags: _capi.make_frame_config(_capi.make_config(lpc_order=8, flags=flags), use_fixed=True)
+    res, resid = handle.encode_frames(x, 16, mk(0))
+    gen, genres = handle.encode_frames(x, 16, mk(_capi.FLAG_GENERIC_KERNEL))
+    assert res.tobytes() == gen.tobytes() and np.array_equal(resid, genres)
+    fp, fr, fk = handle.fixed_lpc_batch(x.reshape(18, n), 16, mk(0))
+    gp, gr, gk = handle.fixed_lpc_batch(x.reshape(18, n), 16, mk(_capi.FLAG_GENERIC_KERNEL))
+    assert fp.tobytes() == gp.tobytes() and np.array_equal(fr, gr) and np.array_equal(fk, gk)

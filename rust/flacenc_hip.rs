@@ -147,6 +147,19 @@ extern "C" {
         bytes_per_sample: u32, bits_per_sample: u32, block_size: u32, sample_rate: u32, first_frame_number: u32,
         frame_number_step: u32, out: *mut u8, out_capacity: usize, out_len: *mut u32, out_total: *mut u64,
     ) -> c_int;
+    /// The ordered gather's device steps (`ParSink`, src/par.rs:67-95, across GPUs): decision records -> wire records
+    /// (+ byte lengths) in one pass, and stream offsets from the all-gathered lengths (rank-major as the collective
+    /// delivers them).  Device pointers; `stream` is a hipStream_t.
+    pub fn flacenc_hip_frame_wire_bytes(block_size: u32) -> usize;
+    pub fn flacenc_hip_stereo_frame_wire_async(
+        h: *mut Handle, results: *const core::ffi::c_void, n_frames: usize, block_size: u32, bits_per_sample: u32,
+        sample_rate: u32, first_frame_number: u32, frame_number_step: u32, wire: *mut u8, wire_stride: usize,
+        out_len: *mut u32, stream: *mut core::ffi::c_void,
+    ) -> c_int;
+    pub fn flacenc_hip_stream_offsets_async(
+        h: *mut Handle, gathered_lengths: *const u32, n_frames_total: usize, world: u32, header_bytes: u64,
+        lengths_stream: *mut u32, offsets: *mut u64, total: *mut u64, stream: *mut core::ffi::c_void,
+    ) -> c_int;
     pub fn flacenc_hip_host_alloc(bytes: usize) -> *mut core::ffi::c_void;
     pub fn flacenc_hip_host_free(p: *mut core::ffi::c_void);
     pub fn flacenc_hip_set_host_threads(h: *mut Handle, threads: i32) -> i32;

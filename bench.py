@@ -379,6 +379,17 @@ def run(args, world):
         if payload:
             gather_desc += " + Frame::write on the producing GPU and all_gather of the packed frame bytes, placed at their stream offsets"
         gather_desc += "; on its own stream, overlapping the next step's analysis"
+    # bytes each rank contributes to the collectives of one step (what crosses each of its xGMI links once)
+    gather_bytes = None
+    if exchanging:
+        gather_bytes = {"lengths": 4 * F}
+        if args.gather in ("records", "payload"):
+            gather_bytes["records_wire"] = F * shard.wire_record_bytes(n)
+        if payload:
+            # runs travel padded to the packer's bound (run_capacity: nothing is read back to size the collective)
+            gather_bytes["payload_padded"] = (F * out_stride + 15) & ~15
+            gather_bytes["payload_used"] = int(frame_len2[0].to(torch.int64).sum().item())
+        gather_bytes["per_rank_per_step"] = sum(v for k, v in gather_bytes.items() if k != "payload_used")
 
     out = {
         "metric": "Msamples/s encoded (44.1kHz/16b stereo, block=4096): QLPC analysis path",
@@ -408,6 +419,7 @@ def run(args, world):
                          else "encode_subframe {Constant, Verbatim, LPC}") +
                         " + try_stereo_coding on the GPU; the two chosen residuals written",
             "gather": gather_desc,
+            "gather_bytes": gather_bytes,
             "exchange_check": exchange_check,
             "subframe_bits_per_sample": round(chosen_bits / (2 * F * n), 4),
             "assignments_indep_left_right_mid": assign_hist,
@@ -639,6 +651,18 @@ def secondary(torch, _capi, handle, args, dev):
                       "what": "flacenc_hip_stereo_qlpc_batch: 4 candidates per frame, 25 f64 fma per analysed sample (the "
                               "stable build's chains on v_mfma_f64_4x4x4: the unflagged order on these shapes) + compute_error on "
                               "v_mfma_i32_16x16x64_i8; fp64_fma_frac = the fma alone against the 78.6 TFLOP/s FP64 vector peak"}
+        # BASELINE configs[2] / [4] AS WRITTEN: "LPC order 32" (FLAC's maximum; beyond the reference's own verifier,
+        # config.rs:304, hence the extension flag).  33 lags = two 16-lag MFMA blocks + one extra chain.
+        bcfg32 = _capi.make_config(lpc_order=32, flags=_capi.FLAG_ALLOW_ORDER_32)
+        ms = timed(lambda: handle.stereo_qlpc_batch_device(bcfg32, big.data_ptr(), bf, bn, bn, 24, bparams.data_ptr(),
+                                                           bres.data_ptr(), bn, stream=stream.cuda_stream))
+        med = float(np.median(ms))
+        sec[label.replace("order24", "order32")] = {
+            "frames": bf, "block_size": bn, "ms_per_launch": stats(ms),
+            "Msamples_per_s": round(bf * 2 * bn / (med * 1e-3) / 1e6, 1),
+            "fp64_fma_frac": round(33 * bf * 4 * bn / (med * 1e-3) / 39.3e12, 4),
+            "what": "the same call at LPC order 32, the BASELINE config as written (FLACENC_HIP_FLAG_ALLOW_ORDER_32): 33 f64 "
+                    "fma per analysed sample in the stable build's order"}
         if bn == 16384:
             # BASELINE configs[4] as written: "experimental config ... block 16384, order 32" = use_direct_mse
             # (src/lpc.rs:853-903, coding.rs:337-347) on 24-bit blocks of 16384 samples, with and without IRLS
@@ -700,6 +724,43 @@ def secondary(torch, _capi, handle, args, dev):
                         "decision) + flacenc_hip_pack_stereo_frames: PCM in HBM -> FLAC frame bytes in HBM"}
             del bfr, bch, bout, blen
         del big, bparams, bres
+    # BASELINE configs[3]: 44.1 kHz / 16-bit 8-channel frames of 4096 samples at the default order 10 -- eight independent
+    # subframes per frame (encode_frame_impl(Independent(8)), coding.rs:537-541): the candidates alone, then the frame-level
+    # pipeline with the reference's default candidate set (encode_frames + pack_frames: PCM in HBM -> frame bytes in HBM)
+    c8f, c8n, c8ch = 6144, 4096, 8
+    x8 = torch.from_numpy(_capi.sigen_frames(c8f, c8ch, c8n, 16, 200.0, 0.4, 0.1, seed=0xF1AC0004)).to(dev)
+    p8 = torch.empty((c8f * c8ch, _capi.PARAMS_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+    r8 = torch.empty((c8f * c8ch, c8n), dtype=torch.int32, device=dev)
+    b8 = torch.full((c8f * c8ch,), 16, dtype=torch.uint8, device=dev)
+    cfg8 = _capi.make_config(lpc_order=10)
+    ms = timed(lambda: handle.qlpc_batch_device(cfg8, x8.data_ptr(), c8f * c8ch, c8n, c8n, b8.data_ptr(), p8.data_ptr(),
+                                                r8.data_ptr(), c8n, stream=stream.cuda_stream))
+    med = float(np.median(ms))
+    sec["config4_8ch_4096x16bit_order10"] = {
+        "frames": c8f, "channels": c8ch, "block_size": c8n, "ms_per_launch": stats(ms),
+        "Msamples_per_s": round(c8f * c8ch * c8n / (med * 1e-3) / 1e6, 1),
+        "hbm_frac": round(ALGO_BYTES_PER_SAMPLE * c8f * c8ch * c8n / (med * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+        "what": "flacenc_hip_qlpc_batch on 8-channel frames: 8 independent estimated_qlpc per frame, every residual row written"}
+    res8 = torch.empty((c8f * c8ch, _capi.CHANNEL_RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+    stride8 = (handle.frame_bytes_bound_channels(c8ch, c8n, 16) + 15) // 16 * 16
+    out8 = torch.empty((c8f, stride8), dtype=torch.uint8, device=dev)
+    len8 = torch.zeros(c8f, dtype=torch.int32, device=dev)
+    fcfg8 = _capi.make_frame_config(cfg8, use_fixed=True)
+
+    def frames8():
+        handle.encode_frames_device(fcfg8, x8.data_ptr(), c8f, c8ch, c8n, c8n, 16, res8.data_ptr(), r8.data_ptr(), c8n,
+                                    stream=stream.cuda_stream)
+        handle.pack_frames_device(x8.data_ptr(), c8f, c8ch, c8n, c8n, res8.data_ptr(), r8.data_ptr(), c8n, 16, SAMPLE_RATE, 0, 1,
+                                  out8.data_ptr(), stride8, len8.data_ptr(), stream=stream.cuda_stream)
+    ms = timed(frames8)
+    med = float(np.median(ms))
+    sec["config4_8ch_frames_default_config"] = {
+        "frames": c8f, "channels": c8ch, "block_size": c8n, "ms_per_launch": stats(ms),
+        "Msamples_per_s": round(c8f * c8ch * c8n / (med * 1e-3) / 1e6, 1),
+        "frame_bytes_per_step": int(len8.to(torch.int64).sum().item()),
+        "what": "flacenc_hip_encode_frames (order 10, fixed-LPC candidate on, encode_subframe's choice per channel) + "
+                "flacenc_hip_pack_frames: 8-channel PCM in HBM -> FLAC frame bytes in HBM"}
+    del x8, p8, r8, b8, res8, out8, len8
     # blocks below a wave's worth of Rice partitions (qlpc_subwave_kernel: 4 subframes of 1152 samples per wave): the
     # four candidates of every frame, and the frame-level call with the reference's default candidate set in one launch
     sn, sfr = 1152, 16384
@@ -779,8 +840,12 @@ def dry_run(args, world):
 
     ok = True
     for _ in range(max(1, args.steps)):
-        lengths_all = shard.all_gather_frame_lengths(lens, total_frames)
-        offsets, total = shard.stream_offsets(lengths_all)
+        # the sequence of the real exchange step: the collective's rank-major output, then what
+        # flacenc_hip_stream_offsets_async does with it (host statement) -- and the older re-ordering path beside it
+        gathered_rm = shard.all_gather_rank_major(lens, total_frames)
+        lengths_all, offsets, total = shard.stream_offsets_from_rank_major(gathered_rm, total_frames, world)
+        lengths_old = shard.all_gather_frame_lengths(lens, total_frames)
+        ok &= bool(torch.equal(lengths_all, lengths_old))
         want = [length_of(f) for f in range(total_frames)]
         ok &= lengths_all.tolist() == want
         ok &= offsets.tolist() == np.concatenate([[0], np.cumsum(want)[:-1]]).tolist() and int(total) == sum(want)

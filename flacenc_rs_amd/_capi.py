@@ -36,9 +36,10 @@ WINDOW_TUKEY = 1
 FLAG_ALLOW_ORDER_32 = 1
 MEM_HOST = 0
 MEM_DEVICE = 1
+COMM_ID_BYTES = 128  # FLACENC_HIP_COMM_ID_BYTES
 
 # every symbol include/flacenc_hip.h declares
-ABI_VERSION = 4  # FLACENC_HIP_ABI_VERSION of include/flacenc_hip.h
+ABI_VERSION = 5  # FLACENC_HIP_ABI_VERSION of include/flacenc_hip.h
 DEBUG_SYMBOLS = ("flacenc_hip_debug_set_stamps", "flacenc_hip_debug_set_fixed_keys")
 EXPORTED_SYMBOLS = (
     "flacenc_hip_abi_version",
@@ -78,6 +79,12 @@ EXPORTED_SYMBOLS = (
     "flacenc_hip_fill_le_bytes_async",
     "flacenc_hip_encode_pack_stereo_frames_async",
     "flacenc_hip_encode_pack_frames_async",
+    "flacenc_hip_comm_unique_id",
+    "flacenc_hip_comm_create",
+    "flacenc_hip_comm_destroy",
+    "flacenc_hip_comm_info",
+    "flacenc_hip_allgather_async",
+    "flacenc_hip_allgather_records_async",
     "flacenc_hip_synchronize",
     "flacenc_sigen_fill_frames",
     "flacenc_sigen_fill_frames_strided",
@@ -313,6 +320,18 @@ def load() -> C.CDLL:
     L.flacenc_hip_encode_stereo_frames.restype = C.c_int
     L.flacenc_hip_encode_stereo_frames_async.argtypes = frame_args + [vp]
     L.flacenc_hip_encode_stereo_frames_async.restype = C.c_int
+    L.flacenc_hip_comm_unique_id.argtypes = [vp]
+    L.flacenc_hip_comm_unique_id.restype = C.c_int
+    L.flacenc_hip_comm_create.argtypes = [vp, vp, C.c_int, C.c_int]
+    L.flacenc_hip_comm_create.restype = C.c_int
+    L.flacenc_hip_comm_destroy.argtypes = [vp]
+    L.flacenc_hip_comm_destroy.restype = C.c_int
+    L.flacenc_hip_comm_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.flacenc_hip_comm_info.restype = C.c_int
+    L.flacenc_hip_allgather_async.argtypes = [vp, vp, vp, C.c_size_t, vp]
+    L.flacenc_hip_allgather_async.restype = C.c_int
+    L.flacenc_hip_allgather_records_async.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_size_t, vp, vp]
+    L.flacenc_hip_allgather_records_async.restype = C.c_int
     L.flacenc_sigen_fill_frames.argtypes = [vp, C.c_size_t, C.c_uint32, C.c_uint32, C.c_size_t,
                                             C.c_uint32, C.c_float, C.c_float, C.c_float,
                                             C.c_uint64, C.c_uint64, C.c_int]
@@ -646,6 +665,61 @@ class Handle:
 
     def frame_bytes_bound(self, block_size: int, bits_per_sample: int) -> int:
         return int(self._lib.flacenc_hip_stereo_frame_bytes_bound(block_size, bits_per_sample))
+
+    # -- the ordered gather's collective (RCCL communicator owned by the handle) ----------
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        """ncclGetUniqueId: 128 bytes rank 0 hands to the other ranks."""
+        buf = (C.c_uint8 * COMM_ID_BYTES)()
+        rc = load().flacenc_hip_comm_unique_id(C.cast(buf, C.c_void_p))
+        if rc != OK:
+            raise FlacencHipError(rc, "flacenc_hip_comm_unique_id")
+        return bytes(buf)
+
+    def comm_create(self, unique_id: bytes, rank: int, world: int):
+        assert len(unique_id) == COMM_ID_BYTES
+        buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(unique_id)
+        self._check(self._lib.flacenc_hip_comm_create(self._h, C.cast(buf, C.c_void_p), rank, world))
+
+    def comm_destroy(self):
+        self._check(self._lib.flacenc_hip_comm_destroy(self._h))
+
+    def comm_info(self):
+        r, w = C.c_int(0), C.c_int(0)
+        self._check(self._lib.flacenc_hip_comm_info(self._h, C.byref(r), C.byref(w)))
+        return r.value, w.value
+
+    def allgather_device(self, send_ptr: int, recv_ptr: int, bytes_per_rank: int, stream: int | None = None):
+        self._check(self._lib.flacenc_hip_allgather_async(self._h, send_ptr, recv_ptr, bytes_per_rank, stream or None))
+
+    def allgather_records_device(self, local_ptr: int, n_local: int, n_total: int, record_bytes: int, gathered_ptr: int,
+                                 stream: int | None = None):
+        """The ordered gather's exchange: rank-major, short ranks zero-padded (all_gather_rank_major's layout)."""
+        self._check(self._lib.flacenc_hip_allgather_records_async(self._h, local_ptr or None, n_local, n_total, record_bytes,
+                                                                  gathered_ptr, stream or None))
+
+    def frame_bytes_bound_channels(self, channels: int, block_size: int, bits_per_sample: int) -> int:
+        return int(self._lib.flacenc_hip_frame_bytes_bound(channels, block_size, bits_per_sample))
+
+    def encode_frames_device(self, cfg: FrameConfig, frames_ptr: int, n_frames: int, channels: int, block_size: int,
+                             stride: int, bits_per_sample: int, results_ptr: int, residual_ptr: int,
+                             residual_stride: int, stream: int | None = None):
+        """flacenc_hip_encode_frames_async: Independent(channels) frames, device pointers."""
+        rc = self._lib.flacenc_hip_encode_frames_async(
+            self._h, C.byref(cfg), frames_ptr, n_frames, channels, block_size, stride, bits_per_sample, results_ptr,
+            residual_ptr, residual_stride, stream or None)
+        self._check(rc)
+
+    def pack_frames_device(self, frames_ptr: int, n_frames: int, channels: int, block_size: int, stride: int,
+                           results_ptr: int, residual_ptr: int, residual_stride: int, bits_per_sample: int,
+                           sample_rate: int, first_frame_number: int, frame_number_step: int, out_ptr: int,
+                           out_stride: int, out_len_ptr: int, stream: int | None = None):
+        """flacenc_hip_pack_frames_async: Frame::write for the frames encode_frames_device decided."""
+        rc = self._lib.flacenc_hip_pack_frames_async(
+            self._h, frames_ptr, n_frames, channels, block_size, stride, results_ptr, residual_ptr, residual_stride,
+            bits_per_sample, sample_rate, first_frame_number, frame_number_step, out_ptr, out_stride, out_len_ptr,
+            stream or None)
+        self._check(rc)
 
     def encode_frames(self, frames, bits_per_sample: int, cfg: FrameConfig):
         """encode_frame for Independent(channels) frames: `frames` int32 [n_frames, channels, n] ->

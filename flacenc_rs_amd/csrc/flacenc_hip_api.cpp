@@ -18,6 +18,7 @@
 #include <thread>
 #include <vector>
 
+#include "comm.h"
 #include "direct_mse.h"
 #include "flacenc_hip.h"
 #include "flacenc_hip_debug.h"
@@ -150,7 +151,14 @@ struct flacenc_hip_handle {
   std::unique_ptr<CopyPool> copy_pool;
   unsigned long long* stamps = nullptr;  // profiling hook, see flacenc_hip_debug_set_stamps
   unsigned long long* fixed_keys = nullptr;  // test hook, see flacenc_hip_debug_set_fixed_keys
+  flacenc_hip::CommState* comm = nullptr;  // RCCL communicator of the ordered gather (comm.cpp)
 };
+
+namespace flacenc_hip {
+CommState*& handle_comm_slot(flacenc_hip_handle* h) { return h->comm; }
+int handle_device(const flacenc_hip_handle* h) { return h->device; }
+void handle_set_error(flacenc_hip_handle* h, const std::string& what) { h->last_error = what; }
+}  // namespace flacenc_hip
 
 namespace {
 
@@ -691,6 +699,8 @@ void flacenc_hip_destroy(flacenc_hip_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
+  flacenc_hip::comm_release(h->comm);
+  h->comm = nullptr;
   for (WindowEntry& e : h->windows)
     if (e.dev) (void)hipFree(e.dev);
   for (DeviceBuffer* b : {&h->d_samples, &h->d_residual, &h->d_params, &h->d_bps, &h->d_autocorr,

@@ -175,6 +175,17 @@ def stream_offsets_device(handle, gathered_lengths: torch.Tensor, n_frames_total
     return lengths_all, offsets, total
 
 
+def stream_offsets_from_rank_major(gathered_lengths: torch.Tensor, n_frames_total: int, world: int, header_bytes: int = 0):
+    """Host statement (torch ops, any device) of flacenc_hip_stream_offsets_async: all_gather_rank_major's lengths
+    [world * ceil(F / G)] -> (lengths in stream order [F], offsets int64 [F], total).  Frame f = j * G + r sits at
+    row r * per_rank + j.  The dry run and the CPU tests check the layout contract with it; on the GPU the kernel runs."""
+    per_rank = (n_frames_total + world - 1) // world
+    assert gathered_lengths.numel() == world * per_rank
+    lengths = gathered_lengths.view(world, per_rank).transpose(0, 1).reshape(-1)[:n_frames_total].contiguous()
+    offsets, total = stream_offsets(lengths, header_bytes)
+    return lengths, offsets, total
+
+
 def all_gather_frame_lengths(local_lengths: torch.Tensor, n_frames_total: int, group=None) -> torch.Tensor:
     """Byte lengths of all frames in stream order, on every rank (ParSink's ordering, src/par.rs:67-95,
     reduced to what it needs).  `local_lengths` is this rank's [n_local_frames] integer tensor."""

@@ -19,6 +19,9 @@
  * Threading: a handle owns one HIP stream, its device scratch and its window
  * cache; it is NOT thread-safe -- use one handle per host thread / per GPU,
  * like the reference's per-thread `reusable!` scratch (src/lib.rs:92-116).
+ * ONE STREAM AT A TIME PER HANDLE: the *_async entry points take a stream per call, but the handle's scratch
+ * (and the marked-subframe counters its clean-up launches alternate between) is shared by all of them: calls
+ * on one handle must be ordered on one stream (or by events) -- two streams need two handles.
  * Errors never unwind across this boundary: every call returns an int status
  * (0 = OK, negative = error) and per-subframe `status` fields carry the
  * conditions on which the reference would panic.
@@ -33,7 +36,13 @@
 extern "C" {
 #endif
 
-#define FLACENC_HIP_ABI_VERSION 4 /* 4: use_direct_mse / mae_optimization_steps in flacenc_hip_qlpc_config, NIGHTLY_SUM_ORDER, frame-level calls take blocks below 64 samples */
+/* 5: blocks of 4096 / 8192 / 16384 samples at orders from 16 sum in the stable build's order by default (other bytes
+ *    for the same config than revision 4); the two flacenc_hip_debug_* symbols left the public ABI; new exports
+ *    flacenc_hip_frame_wire_bytes, flacenc_hip_stereo_frame_wire_async, flacenc_hip_stream_offsets_async (round 4) and
+ *    the flacenc_hip_comm_* / flacenc_hip_allgather_* collective calls (round 5).
+ * 4: use_direct_mse / mae_optimization_steps in flacenc_hip_qlpc_config, NIGHTLY_SUM_ORDER, frame-level calls take
+ *    blocks below 64 samples */
+#define FLACENC_HIP_ABI_VERSION 5
 
 /* FLAC allows LPC order 32; the reference's config verifier caps it at 24
  * (src/constant.rs:118, src/config.rs:304).  Orders 25..32 are an extension
@@ -220,8 +229,9 @@ int flacenc_hip_qlpc_batch_async(flacenc_hip_handle* h, const flacenc_hip_qlpc_c
  * (src/source.rs:115-127): channel c of frame f at frames + (2f + c)*stride.
  * M and S are formed on the GPU.  Outputs are indexed 4f + {0:L, 1:R, 2:M, 3:S};
  * the S record's subframe_bits uses bits_per_sample + 1 (src/coding.rs:444).
- * The choice between L+R / L+S / R+S / M+S stays with the caller
- * (src/coding.rs:493-522) until the fixed-LPC candidate is on the GPU too.
+ * This is the candidate-level call: all four records and residual rows come back and the choice between
+ * L+R / L+S / R+S / M+S (src/coding.rs:493-522) is the caller's.  flacenc_hip_encode_stereo_frames below makes
+ * it on the GPU (with the fixed-LPC candidate) and returns only the two chosen rows.
  */
 int flacenc_hip_stereo_qlpc_batch(flacenc_hip_handle* h, const flacenc_hip_qlpc_config* cfg,
                                   const int32_t* frames, size_t n_frames, uint32_t block_size,
@@ -493,6 +503,36 @@ int flacenc_hip_stereo_frame_wire_async(flacenc_hip_handle* h, const flacenc_hip
 int flacenc_hip_stream_offsets_async(flacenc_hip_handle* h, const uint32_t* gathered_lengths, size_t n_frames_total,
                                      uint32_t world, uint64_t header_bytes, uint32_t* lengths_stream,
                                      uint64_t* offsets, uint64_t* total, void* stream);
+
+/* ---- the collective of the ordered gather (one process per GPU) -------------------------------------------- */
+/*
+ * ParSink (src/par.rs:67-95) re-orders the frames its worker threads finish; with one PROCESS per GPU (frame f on
+ * rank f mod world) that re-ordering needs one exchange, and this is it: an RCCL communicator owned by the handle
+ * and an all-gather of fixed-size per-frame records on the caller's stream.  librccl is opened at run time on the
+ * first of these calls (ERR_UNSUPPORTED when it cannot be found; FLACENC_HIP_RCCL names another path) -- a
+ * single-GPU drop-in never loads it.
+ *   flacenc_hip_comm_unique_id   ncclGetUniqueId: rank 0 calls it and hands the 128 bytes to the other ranks by
+ *                                whatever means the host has (a file, a socket, MPI, torch.distributed's store)
+ *   flacenc_hip_comm_create      ncclCommInitRank on the handle's device; collective over all `world` ranks
+ *   flacenc_hip_comm_info        rank / world of the handle's communicator (world = 0: none)
+ *   flacenc_hip_allgather_async  ncclAllGather of bytes_per_rank bytes: recv[r * bytes_per_rank ..] = rank r's send
+ *   flacenc_hip_allgather_records_async
+ *                                the ordered gather's exchange for n_total frames dealt round-robin: `local` holds this
+ *                                rank's n_local = ceil((n_total - rank) / world) records of record_bytes each (wire
+ *                                records from flacenc_hip_stereo_frame_wire_async, or its 4-byte lengths); `gathered`
+ *                                receives world * ceil(n_total / world) records rank-major -- record r * per_rank + j =
+ *                                stream frame j * world + r, ranks one frame short zero-padded -- the layout
+ *                                flacenc_hip_stream_offsets_async reads.  `local` may be the rank's own slot of
+ *                                `gathered` (in place).  Device pointers; enqueued on `stream`.
+ */
+#define FLACENC_HIP_COMM_ID_BYTES 128
+int flacenc_hip_comm_unique_id(uint8_t id[FLACENC_HIP_COMM_ID_BYTES]);
+int flacenc_hip_comm_create(flacenc_hip_handle* h, const uint8_t id[FLACENC_HIP_COMM_ID_BYTES], int rank, int world);
+int flacenc_hip_comm_destroy(flacenc_hip_handle* h);
+int flacenc_hip_comm_info(flacenc_hip_handle* h, int* rank, int* world);
+int flacenc_hip_allgather_async(flacenc_hip_handle* h, const void* send, void* recv, size_t bytes_per_rank, void* stream);
+int flacenc_hip_allgather_records_async(flacenc_hip_handle* h, const void* local, size_t n_local, size_t n_total,
+                                        size_t record_bytes, void* gathered, void* stream);
 
 /* ---- input side ------------------------------------------------------- */
 /*

@@ -78,14 +78,16 @@ pub struct FrameConfig {
 }
 
 impl FrameConfig {
-    pub fn from_encoder(config: &config::Encoder) -> Self {
+    /// `order`: whose floating-point summation order the analysis reproduces (`Gpu::sum_order()` of the handle the
+    /// configuration is used with; `SumOrder::CrateBuild` = the bytes of the build this file is compiled into).
+    pub fn from_encoder(config: &config::Encoder, order: SumOrder) -> Self {
         let sc = &config.subframe_coding;
         let (sel, partitions) = match sc.fixed.order_sel {
             config::OrderSel::BitCount => (0, 0),
             config::OrderSel::ApproxEnt { partitions } => (1, partitions as u32),
         };
         Self {
-            qlpc: abi_config(sc),
+            qlpc: abi_config_with(sc, order),
             use_constant: sc.use_constant as u32,
             use_fixed: sc.use_fixed as u32,
             use_lpc: sc.use_lpc as u32,
@@ -120,7 +122,7 @@ pub struct Handle {
 }
 
 /// `FLACENC_HIP_ABI_VERSION` of `include/flacenc_hip.h` this binding was written against.
-pub const ABI_VERSION: c_int = 4;
+pub const ABI_VERSION: c_int = 5;
 
 extern "C" {
     pub fn flacenc_hip_abi_version() -> c_int;
@@ -159,6 +161,20 @@ extern "C" {
     pub fn flacenc_hip_stream_offsets_async(
         h: *mut Handle, gathered_lengths: *const u32, n_frames_total: usize, world: u32, header_bytes: u64,
         lengths_stream: *mut u32, offsets: *mut u64, total: *mut u64, stream: *mut core::ffi::c_void,
+    ) -> c_int;
+    /// ParSink's ordered gather (`src/par.rs:67-95`) across processes: an RCCL communicator owned by the handle
+    /// (`ncclGetUniqueId` / `ncclCommInitRank`) and the all-gather of this rank's wire records or byte lengths,
+    /// rank-major and zero-padded as `flacenc_hip_stream_offsets_async` reads them.
+    pub fn flacenc_hip_comm_unique_id(id: *mut u8) -> c_int;
+    pub fn flacenc_hip_comm_create(h: *mut Handle, id: *const u8, rank: c_int, world: c_int) -> c_int;
+    pub fn flacenc_hip_comm_destroy(h: *mut Handle) -> c_int;
+    pub fn flacenc_hip_comm_info(h: *mut Handle, rank: *mut c_int, world: *mut c_int) -> c_int;
+    pub fn flacenc_hip_allgather_async(
+        h: *mut Handle, send: *const c_void, recv: *mut c_void, bytes_per_rank: usize, stream: *mut c_void,
+    ) -> c_int;
+    pub fn flacenc_hip_allgather_records_async(
+        h: *mut Handle, local: *const c_void, n_local: usize, n_total: usize, record_bytes: usize,
+        gathered: *mut c_void, stream: *mut c_void,
     ) -> c_int;
     pub fn flacenc_hip_host_alloc(bytes: usize) -> *mut core::ffi::c_void;
     pub fn flacenc_hip_host_free(p: *mut core::ffi::c_void);
@@ -204,17 +220,29 @@ extern "C" {
 }
 
 /// One handle per host thread, like the crate's `reusable!` thread-locals (`src/lib.rs:92-116`).
-pub struct Gpu(*mut Handle);
+/// The second field is the summation order every configuration built for this handle asks for.
+pub struct Gpu(*mut Handle, SumOrder);
 
 impl Gpu {
+    /// A handle that reproduces the bytes of the crate build it is compiled into (`SumOrder::CrateBuild`): the drop-in
+    /// under `encode_with_fixed_block_size` must not change the encoder's output.
     pub fn new(device_id: i32) -> Result<Self, EncodeError> {
+        Self::with_sum_order(device_id, SumOrder::CrateBuild)
+    }
+
+    pub fn sum_order(&self) -> SumOrder {
+        self.1
+    }
+
+    /// `SumOrder::Canonical` trades byte-identity with the CPU build for the kernels' own (fastest) order.
+    pub fn with_sum_order(device_id: i32, order: SumOrder) -> Result<Self, EncodeError> {
         // (QlpcConfig is embedded by value in FrameConfig: a library of another revision would read it shifted)
         if unsafe { flacenc_hip_abi_version() } != ABI_VERSION {
             return Err(EncodeError::Config(VerifyError::new("gpu", "libflacenc_hip.so has another ABI revision")));
         }
         let mut h = std::ptr::null_mut();
         match unsafe { flacenc_hip_create(&mut h, device_id) } {
-            OK => Ok(Self(h)),
+            OK => Ok(Self(h, order)),
             _ => Err(EncodeError::Config(VerifyError::new("gpu", "no usable HIP device"))),
         }
     }
@@ -227,12 +255,13 @@ impl Drop for Gpu {
 }
 
 /// Which of the crate's builds the floating-point sums reproduce bit for bit (the C++ mirror's
-/// `HipContext::SumOrder`).  `Canonical` -- the kernels' own order -- is the default there and here: it is the fastest
-/// (no second pass over the samples in front of the fused kernel) and a valid encoding of the same configuration;
-/// `CrateBuild` asks for the bytes of the build this file is compiled into (stable: `FLAG_REFERENCE_SUM_ORDER`,
-/// about a quarter of the throughput on 4096-sample blocks; `simd-nightly`: `FLAG_NIGHTLY_SUM_ORDER` up to order 15).
-/// Blocks of 4096 / 8192 / 16384 samples at orders from 16 sum in the stable build's order either way.
-#[derive(Clone, Copy, PartialEq, Eq)]
+/// `HipContext::SumOrder`).  `CrateBuild` -- the default of `Gpu::new` -- asks for the bytes of the build this file is
+/// compiled into (stable: `FLAG_REFERENCE_SUM_ORDER`; `simd-nightly`: `FLAG_NIGHTLY_SUM_ORDER` up to order 15).
+/// `Canonical` is the kernels' own order: a valid encoding of the same configuration whose integer outputs are the
+/// stable build's wherever the library can certify it ("default order"), chosen with
+/// `Gpu::with_sum_order`.  Blocks of 4096 / 8192 / 16384 samples at orders from 16 sum in the stable build's order
+/// either way.
+#[derive(Clone, Copy, PartialEq, Eq, Debug)]
 pub enum SumOrder {
     Canonical,
     CrateBuild,
@@ -240,10 +269,6 @@ pub enum SumOrder {
 
 /// `mae_optimization_steps` above 64 (`FLACENC_HIP_MAX_MAE_STEPS`) is refused with `BAD_CONFIG`: the reference's
 /// experimental build takes any value.
-fn abi_config(c: &config::SubFrameCoding) -> QlpcConfig {
-    abi_config_with(c, SumOrder::Canonical)
-}
-
 fn abi_config_with(c: &config::SubFrameCoding, order: SumOrder) -> QlpcConfig {
     let (window_type, tukey_alpha) = match c.qlpc.window {
         config::Window::Rectangle => (0, 0.0),
@@ -332,7 +357,7 @@ pub fn estimated_qlpc_batch(
     gpu: &Gpu, config: &Verified<config::Encoder>, staged: &[i32], n_frames: usize,
     channels: usize, block_size: usize, bits_per_sample: u8,
 ) -> Result<(Vec<SubframeParams>, Vec<i32>), EncodeError> {
-    let cfg = abi_config(&config.subframe_coding);
+    let cfg = abi_config_with(&config.subframe_coding, gpu.sum_order());
     let per_frame = if channels == 2 { 4 } else { channels };
     let mut params = vec![unsafe { std::mem::zeroed::<SubframeParams>() }; n_frames * per_frame];
     let mut residual = vec![0i32; n_frames * per_frame * block_size];
@@ -355,5 +380,43 @@ pub fn estimated_qlpc_batch(
         OK => Ok((params, residual)),
         ERR_BAD_CONFIG => Err(EncodeError::Config(VerifyError::new("subframe_coding", "rejected by the GPU path"))),
         _ => panic!("flacenc_hip device error"), // the reference panics on internal errors too
+    }
+}
+
+/// `FLACENC_HIP_COMM_ID_BYTES`
+pub const COMM_ID_BYTES: usize = 128;
+
+impl Gpu {
+    /// Rank 0 of a one-process-per-GPU host calls this and hands the bytes to the other ranks (a file, a socket, MPI).
+    pub fn comm_unique_id() -> Result<[u8; COMM_ID_BYTES], EncodeError> {
+        let mut id = [0u8; COMM_ID_BYTES];
+        match unsafe { flacenc_hip_comm_unique_id(id.as_mut_ptr()) } {
+            OK => Ok(id),
+            _ => Err(EncodeError::Config(VerifyError::new("gpu", "librccl is not available"))),
+        }
+    }
+
+    /// Collective over all `world` ranks: frame f of the stream is analysed by rank f mod world.
+    pub fn comm_create(&self, id: &[u8; COMM_ID_BYTES], rank: i32, world: i32) -> Result<(), EncodeError> {
+        match unsafe { flacenc_hip_comm_create(self.0, id.as_ptr(), rank, world) } {
+            OK => Ok(()),
+            _ => Err(EncodeError::Config(VerifyError::new("gpu", "ncclCommInitRank failed"))),
+        }
+    }
+}
+
+#[cfg(test)]
+mod tests {
+    use super::*;
+
+    /// the summation-order choice must be reachable and must set the flag of the crate build.
+    #[test]
+    fn crate_build_order_sets_the_builds_flag() {
+        let enc = config::Encoder::default();
+        let canonical = FrameConfig::from_encoder(&enc, SumOrder::Canonical);
+        assert_eq!(canonical.qlpc.flags & (FLAG_REFERENCE_SUM_ORDER | FLAG_NIGHTLY_SUM_ORDER), 0);
+        let own = FrameConfig::from_encoder(&enc, SumOrder::CrateBuild);
+        let want = if cfg!(feature = "simd-nightly") { FLAG_NIGHTLY_SUM_ORDER } else { FLAG_REFERENCE_SUM_ORDER };
+        assert_eq!(own.qlpc.flags & (FLAG_REFERENCE_SUM_ORDER | FLAG_NIGHTLY_SUM_ORDER), want);
     }
 }

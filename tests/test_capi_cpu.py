@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_capi.EXPORTED_SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.flacenc_hip_abi_version() == 4
+    assert lib.flacenc_hip_abi_version() == 5
 
 
 def test_params_record_layout_matches_oracle_record():

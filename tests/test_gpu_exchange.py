@@ -87,3 +87,58 @@ def test_stream_offsets_of_an_empty_stream(handle):
     handle.stream_offsets_device(None, 0, 4, 42, None, None, total.data_ptr())
     torch.cuda.synchronize()
     assert int(total) == 42
+
+
+# ---- the collective inside the C library (flacenc_hip_comm_* / flacenc_hip_allgather_*): ParSink's ordered gather
+# (src/par.rs:67-95) for a Rust / C++ host with one process per GPU.  A test box has one GPU: a 1-rank RCCL
+# communicator makes exactly the calls an 8-rank one makes.
+def test_one_rank_communicator_gathers_like_shard(handle):
+    import torch
+    n_frames, block, bps = 77, 4096, 16
+    results = _records(handle, torch, n_frames, block, bps, seed=4242)
+    wire, lengths = shard.records_to_wire_device(handle, results, block, bps, 44100, 0, 1)
+    h2 = _capi.Handle(0)
+    assert h2.comm_info() == (0, 0)
+    uid = _capi.Handle.comm_unique_id()
+    assert len(uid) == _capi.COMM_ID_BYTES and any(uid)
+    h2.comm_create(uid, 0, 1)
+    assert h2.comm_info() == (0, 1)
+    with pytest.raises(RuntimeError):
+        h2.comm_create(uid, 0, 1)  # one communicator per handle
+    stream = torch.cuda.current_stream().cuda_stream
+    wb = wire.shape[1]
+    gathered = torch.full((n_frames, wb), 0xAB, dtype=torch.uint8, device="cuda")
+    h2.allgather_records_device(wire.data_ptr(), n_frames, n_frames, wb, gathered.data_ptr(), stream=stream)
+    glen = torch.full((n_frames,), -1, dtype=torch.int32, device="cuda")
+    h2.allgather_records_device(lengths.data_ptr(), n_frames, n_frames, 4, glen.data_ptr(), stream=stream)
+    torch.cuda.synchronize()
+    # what shard.py's statement of the same exchange delivers (no process group: world 1)
+    assert torch.equal(gathered, shard.all_gather_rank_major(wire, n_frames))
+    assert torch.equal(gathered, shard.all_gather_records(wire, n_frames))
+    assert torch.equal(glen, shard.all_gather_rank_major(lengths, n_frames))
+    # in place (the rank's own slot is the send buffer) and the plain byte all-gather
+    inplace = wire.clone()
+    h2.allgather_records_device(inplace.data_ptr(), n_frames, n_frames, wb, inplace.data_ptr(), stream=stream)
+    plain = torch.zeros_like(wire)
+    h2.allgather_device(wire.data_ptr(), plain.data_ptr(), wire.numel(), stream=stream)
+    torch.cuda.synchronize()
+    assert torch.equal(inplace, wire) and torch.equal(plain, wire)
+    # the gathered lengths feed flacenc_hip_stream_offsets_async as they are
+    lengths_all, offsets, total = shard.stream_offsets_device(h2, glen, n_frames, 1)
+    torch.cuda.synchronize()
+    want = torch.cumsum(lengths.to(torch.int64), 0) - lengths.to(torch.int64)
+    assert torch.equal(offsets, want) and int(total.item()) == int(lengths.to(torch.int64).sum().item())
+    # a count that is not this rank's share of the total is refused
+    with pytest.raises(RuntimeError):
+        h2.allgather_records_device(wire.data_ptr(), n_frames - 1, n_frames, wb, gathered.data_ptr(), stream=stream)
+    h2.comm_destroy()
+    assert h2.comm_info() == (0, 0)
+    with pytest.raises(RuntimeError):
+        h2.allgather_device(wire.data_ptr(), plain.data_ptr(), 16, stream=stream)
+
+
+def test_allgather_without_a_communicator_is_an_error(handle):
+    import torch
+    x = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    with pytest.raises(RuntimeError):
+        handle.allgather_records_device(x.data_ptr(), 4, 4, 16, x.data_ptr())

@@ -52,6 +52,28 @@ def _worker(rank, world, port, n_frames, out_dir):
     assert lengths_all.tolist() == want.tolist()
     assert offsets.tolist() == (42 + np.concatenate([[0], np.cumsum(want)[:-1]])).tolist()
     assert int(total) == 42 + int(want.sum())
+    # the collective alone, as bench.py's exchange step and flacenc_hip_allgather_records_async deliver it and as
+    # flacenc_hip_stream_offsets_async (stream_offsets_kernel) reads it: rank-major [world][ceil(F / G)], row
+    # r * per_rank + j = stream frame j * G + r, ranks that are a frame short zero-padded
+    per_rank = (n_frames + world - 1) // world
+    gl = shard.all_gather_rank_major(lens, n_frames)
+    assert gl.shape == (world * per_rank,) and gl.dtype == torch.int32
+    for r in range(world):
+        for j in range(per_rank):
+            f = j * world + r
+            assert int(gl[r * per_rank + j]) == (1000 + 7 * f if f < n_frames else 0), (r, j)
+    # host restatement of stream_offsets_kernel on that layout == stream_offsets on the stream-order lengths
+    ls = np.array([int(gl[(f % world) * per_rank + f // world]) for f in range(n_frames)], np.int64)
+    assert ls.tolist() == want.tolist()
+    assert (42 + np.concatenate([[0], np.cumsum(ls)[:-1]])).tolist() == offsets.tolist()
+    # ... and for multi-byte records (the wire records): rows of this rank's frames, zero rows behind a short rank
+    rows = torch.stack([torch.full((5,), f % 251, dtype=torch.uint8) for f in mine]) if len(mine) else torch.zeros((0, 5), dtype=torch.uint8)
+    gr = shard.all_gather_rank_major(rows, n_frames)
+    assert gr.shape == (world * per_rank, 5)
+    for r in range(world):
+        for j in range(per_rank):
+            f = j * world + r
+            assert gr[r * per_rank + j].tolist() == ([f % 251] * 5 if f < n_frames else [0] * 5)
     # the heavy exchange (`bench.py --gather payload`): the packed frame bytes themselves, assembled into
     # the frame stream on every rank.  Frames are written by the oracle's Frame::write with their stream
     # frame numbers; `place` here is the test's stand-in for flacenc_hip_place_frames_async.

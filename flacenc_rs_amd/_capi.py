@@ -40,7 +40,7 @@ COMM_ID_BYTES = 128  # FLACENC_HIP_COMM_ID_BYTES
 
 # every symbol include/flacenc_hip.h declares
 ABI_VERSION = 5  # FLACENC_HIP_ABI_VERSION of include/flacenc_hip.h
-DEBUG_SYMBOLS = ("flacenc_hip_debug_set_stamps", "flacenc_hip_debug_set_fixed_keys")
+DEBUG_SYMBOLS = ("flacenc_hip_debug_set_stamps", "flacenc_hip_debug_set_fixed_keys", "flacenc_hip_debug_set_cert_stats")
 EXPORTED_SYMBOLS = (
     "flacenc_hip_abi_version",
     "flacenc_hip_device_count",
@@ -350,6 +350,7 @@ FLAG_FUSED_PACK = 8
 FLAG_TWO_STAGE_PACK = 16
 FLAG_REFERENCE_SUM_ORDER = 32
 FLAG_NIGHTLY_SUM_ORDER = 64
+FLAG_CANONICAL_SUM_ORDER = 128  # the chunk tree without the order certificate
 
 
 def make_config(lpc_order=10, quant_precision=15, window=("tukey", 0.4), max_rice_parameter=30,
@@ -449,6 +450,11 @@ class Handle:
 
     def debug_set_stamps(self, device_ptr: int):
         self._check(self._lib.flacenc_hip_debug_set_stamps(self._h, device_ptr or None))
+
+    def debug_set_cert_stats(self, device_ptr: int):
+        """3 x uint32 on the device: subframes certified launches analysed, certificates that needed the rows of T^-1,
+        subframes recomputed from the reference's chains (flacenc_hip_debug.h)."""
+        self._check(self._lib.flacenc_hip_debug_set_cert_stats(self._h, device_ptr or None))
 
     def synchronize(self):
         self._check(self._lib.flacenc_hip_synchronize(self._h))

@@ -151,6 +151,7 @@ struct flacenc_hip_handle {
   std::unique_ptr<CopyPool> copy_pool;
   unsigned long long* stamps = nullptr;  // profiling hook, see flacenc_hip_debug_set_stamps
   unsigned long long* fixed_keys = nullptr;  // test hook, see flacenc_hip_debug_set_fixed_keys
+  uint32_t* cert_stats = nullptr;  // statistics hook, see flacenc_hip_debug_set_cert_stats
   flacenc_hip::CommState* comm = nullptr;  // RCCL communicator of the ordered gather (comm.cpp)
 };
 
@@ -301,6 +302,19 @@ uint32_t sum_order_mode(uint32_t flags) {
   return (flags & FLACENC_HIP_FLAG_REFERENCE_SUM_ORDER) ? 1u : 0u;
 }
 
+// The unflagged order on the fused kernel's shapes is certified (QlpcKernelArgs::certify; launch_qlpc decides where it
+// applies).  Launches that cannot run it inside the fused kernel -- unaligned rows, FLACENC_HIP_FLAG_GENERIC_KERNEL, the
+// fused bit writer -- take the reference's R[] from acorr_reference_kernel through the split scratch.
+void set_certify(flacenc_hip_handle* h, flacenc_hip::QlpcKernelArgs& a, uint32_t flags) {
+  a.certify = (flags & FLACENC_HIP_FLAG_CANONICAL_SUM_ORDER) ? 0u : 1u;
+  a.acorr_fallback = nullptr;
+  a.cert_stats = h->cert_stats;
+}
+bool certify_needs_scratch(const flacenc_hip::QlpcKernelArgs& a) {
+  return a.certify != 0u && flacenc_hip::cert_shape(a) && a.reference_order == 0u && !a.direct_mse && a.fixed_mode == 0 &&
+         (!flacenc_hip::wave_kernel_eligible(a) || a.pack_out != nullptr);
+}
+
 // FLACENC_HIP_FLAG_REFERENCE_SUM_ORDER with the ApproxEnt selector: room for sumabs_reference_kernel's
 // per-partition f32 sums (launch_qlpc runs it when `sumabs_scratch` is set)
 int attach_sumabs_scratch(flacenc_hip_handle* h, flacenc_hip::QlpcKernelArgs& a, bool approx_ent) {
@@ -359,6 +373,7 @@ int enqueue(flacenc_hip_handle* h, const flacenc_hip_qlpc_config* cfg, const int
   a.rice_finest_only = (cfg->flags & FLACENC_HIP_FLAG_FINEST_RICE_ORDER) ? 1u : 0u;
   a.force_generic = (cfg->flags & FLACENC_HIP_FLAG_GENERIC_KERNEL) ? 1u : 0u;
   a.reference_order = sum_order_mode(cfg->flags);
+  set_certify(h, a, cfg->flags);
   a.acorr_in = nullptr;
   a.only_marked = 0;
   a.params = params;
@@ -404,7 +419,7 @@ int enqueue(flacenc_hip_handle* h, const flacenc_hip_qlpc_config* cfg, const int
   // (R[] and the predictor records between the launches of the split pipelines: orders from 13, and blocks of
   // 8192 / 16384 at any order -- the big-block kernels)
   if (cfg->lpc_order >= 13 || a.reference_order || a.direct_mse || block_size == 8192 || block_size == 16384 ||
-      flacenc_hip::subwave_shape(block_size)) {
+      flacenc_hip::subwave_shape(block_size) || certify_needs_scratch(a)) {
     if ((rc = attach_split_scratch(h, a)) != FLACENC_HIP_OK) return rc;
   }
   if (plan.table_scratch_bytes_per_subframe) {
@@ -578,6 +593,7 @@ int enqueue_fixed(flacenc_hip_handle* h, const flacenc_hip_frame_config* cfg, co
   a.rice_finest_only = (cfg->qlpc.flags & FLACENC_HIP_FLAG_FINEST_RICE_ORDER) ? 1u : 0u;
   a.force_generic = (cfg->qlpc.flags & FLACENC_HIP_FLAG_GENERIC_KERNEL) ? 1u : 0u;
   a.reference_order = sum_order_mode(cfg->qlpc.flags);
+  set_certify(h, a, cfg->qlpc.flags);
   a.direct_mse = cfg->qlpc.use_direct_mse ? 1u : 0u;  // (keeps the launch off the fused wave kernel)
   a.acorr_in = nullptr;
   a.only_marked = 0;
@@ -771,6 +787,12 @@ int flacenc_hip_debug_set_fixed_keys(flacenc_hip_handle* h, unsigned long long* 
 int flacenc_hip_debug_set_stamps(flacenc_hip_handle* h, unsigned long long* device_stamps) {
   if (!h) return FLACENC_HIP_ERR_BAD_ARGUMENT;
   h->stamps = device_stamps;
+  return FLACENC_HIP_OK;
+}
+
+int flacenc_hip_debug_set_cert_stats(flacenc_hip_handle* h, uint32_t* device_counters) {
+  if (!h) return FLACENC_HIP_ERR_BAD_ARGUMENT;
+  h->cert_stats = device_counters;
   return FLACENC_HIP_OK;
 }
 #endif
@@ -1131,6 +1153,7 @@ int flacenc_hip_encode_frames_async(flacenc_hip_handle* h, const flacenc_hip_fra
   a.rice_finest_only = (cfg->qlpc.flags & FLACENC_HIP_FLAG_FINEST_RICE_ORDER) ? 1u : 0u;
   a.force_generic = (cfg->qlpc.flags & FLACENC_HIP_FLAG_GENERIC_KERNEL) ? 1u : 0u;
   a.reference_order = sum_order_mode(cfg->qlpc.flags);
+  set_certify(h, a, cfg->qlpc.flags);
   a.direct_mse = cfg->qlpc.use_direct_mse ? 1u : 0u;  // (keeps the launch off the fused wave kernel)
   a.acorr_in = nullptr;
   a.only_marked = 0;
@@ -1160,7 +1183,7 @@ int flacenc_hip_encode_frames_async(flacenc_hip_handle* h, const flacenc_hip_fra
     a.pred = nullptr;
     a.pred_out = nullptr;
     a.split_scratch = nullptr;
-    if (a.reference_order) {  // R[] of the reference-order pass
+    if (a.reference_order || certify_needs_scratch(a)) {  // R[] of the reference-order pass
       if ((rc = attach_split_scratch(h, a)) != FLACENC_HIP_OK) return rc;
     }
     if ((rc = attach_sumabs_scratch(h, a, cfg->use_fixed && cfg->fixed_order_sel == FLACENC_HIP_ORDERSEL_APPROXENT)) !=
@@ -1942,6 +1965,7 @@ static int encode_stereo_frames_impl(flacenc_hip_handle* h, const flacenc_hip_fr
   a.rice_finest_only = (cfg->qlpc.flags & FLACENC_HIP_FLAG_FINEST_RICE_ORDER) ? 1u : 0u;
   a.force_generic = (cfg->qlpc.flags & FLACENC_HIP_FLAG_GENERIC_KERNEL) ? 1u : 0u;
   a.reference_order = sum_order_mode(cfg->qlpc.flags);
+  set_certify(h, a, cfg->qlpc.flags);
   a.direct_mse = cfg->qlpc.use_direct_mse ? 1u : 0u;  // (keeps the launch off the fused wave kernel)
   a.acorr_in = nullptr;
   a.only_marked = 0;
@@ -2005,6 +2029,10 @@ static int encode_stereo_frames_impl(flacenc_hip_handle* h, const flacenc_hip_fr
     } else {
       a.pack_out = nullptr;
     }
+  }
+  if (a.split_scratch == nullptr && certify_needs_scratch(a)) {  // (the fused bit writer is handed the reference's R[])
+    int rc2 = attach_split_scratch(h, a);
+    if (rc2 != FLACENC_HIP_OK) return rc2;
   }
   if (!flacenc_hip::wave_kernel_eligible(a) || fixed_composite) {
     // General shapes: the same result from candidate batches (4 QLPC + 4 fixed-LPC candidates per

@@ -21,6 +21,12 @@ int flacenc_hip_debug_set_fixed_keys(flacenc_hip_handle* h, unsigned long long* 
  * Pass NULL to switch it off again.  See tools/phase_profile.py. */
 int flacenc_hip_debug_set_stamps(flacenc_hip_handle* h, unsigned long long* device_stamps);
 
+/* Statistics hook (no reference counterpart): when `device_counters` is non-NULL (3 x uint32, zeroed by the caller),
+ * launches that certify their summation order (blocks of 4096 / 4608 samples, orders up to 12, no order flag) add to
+ * [0] the subframes analysed, [1] the certificates that needed the rows of the inverse Toeplitz matrix, [2] the subframes
+ * recomputed from the reference's chains. */
+int flacenc_hip_debug_set_cert_stats(flacenc_hip_handle* h, uint32_t* device_counters);
+
 #ifdef __cplusplus
 }
 #endif

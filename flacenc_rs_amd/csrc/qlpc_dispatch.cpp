@@ -35,6 +35,10 @@ bool wave_kernel_eligible(const QlpcKernelArgs& a) {
   return true;
 }
 
+bool cert_shape(const QlpcKernelArgs& a) {
+  return (a.block_size == 4096 || a.block_size == 4608) && a.lpc_order >= 1 && a.lpc_order <= 12;
+}
+
 bool subwave_shape(uint32_t n) {
   return n == 256 || n == 512 || n == 1024 || n == 2048 || n == 288 || n == 576 || n == 1152 || n == 2304;
 }
@@ -219,6 +223,45 @@ hipError_t launch_qlpc(const QlpcKernelArgs& a, const QlpcLaunchPlan& plan, hipS
   // blocks: 344 against 404 us per 50 M samples at order 24), so those shapes emit
   // the stable build's bytes by default (the oracle's orc_default_order_is_stable states the same rule)
   // (a function of the shape alone: unaligned rows or FLACENC_HIP_FLAG_GENERIC_KERNEL change the kernels, not the sums)
+  // The unflagged order on blocks of 4096 / 4608 samples at orders up to 12 (the oracle's orc_default_order_is_certified):
+  // the chunk tree's sums where they certify the quantised parameters against the reference's chains, those chains where
+  // not (QlpcKernelArgs::certify).  The fused kernel does both itself; the generic kernel (unaligned rows,
+  // FLACENC_HIP_FLAG_GENERIC_KERNEL) takes the chains from acorr_reference_kernel -- same outputs, floating point
+  // included -- and the fused bit writer, which returns bytes alone, is simply given the reference's R[].
+  if (a.certify != 0u) {
+    const bool shape = cert_shape(a) && a.reference_order == 0u && !a.direct_mse && a.fixed_mode == 0 && a.lpc_stage == 0 &&
+                       a.acorr_in == nullptr && !a.only_marked;
+    if (!shape) {
+      QlpcKernelArgs b = a;
+      b.certify = 0;
+      return launch_qlpc(b, plan, stream);
+    }
+    const bool wave = wave_kernel_eligible(a);
+    if ((!wave && a.acorr_fallback == nullptr) || (wave && a.pack_out != nullptr)) {
+      if (a.split_scratch == nullptr) return hipErrorInvalidValue;
+      double* racc = reinterpret_cast<double*>(a.split_scratch);
+      AcorrRefArgs r{};
+      r.samples = a.samples;
+      r.stride = a.stride;
+      r.block_size = a.block_size;
+      r.n_subframes = a.n_subframes;
+      r.stereo = a.stereo;
+      r.window = a.window;
+      r.lpc_order = a.lpc_order;
+      r.nightly = 0u;
+      r.out = racc;
+      hipError_t err = launch_acorr_reference(r, stream);
+      if (err != hipSuccess) return err;
+      QlpcKernelArgs b = a;
+      if (wave) {  // the fused bit writer
+        b.certify = 0;
+        b.acorr_in = racc;
+      } else {
+        b.acorr_fallback = racc;
+      }
+      return launch_qlpc(b, plan, stream);
+    }
+  }
   const bool stable_by_default = a.reference_order == 0u && !a.direct_mse &&
                                  (a.block_size == 4096u || a.block_size == 8192u || a.block_size == 16384u) &&
                                  a.lpc_order >= 16u && a.split_scratch != nullptr;

@@ -37,6 +37,14 @@ struct QlpcKernelArgs {
   // launch_qlpc runs it into split_scratch (or `autocorr`) and hands the result on as `acorr_in`
   uint32_t reference_order;
   const double* acorr_in;     // device, [n][33]: precomputed R[], skips phase 1 (wave kernel)
+  // The unflagged order on blocks of 4096 / 4608 samples at orders up to 12 (set by launch_qlpc): the chunk tree's R[]
+  // is kept where it CERTIFIES the quantised parameters against the reference's chains (levinson_quantize<.., CERT>) and
+  // the subframe is redone from those chains where it does not -- by the fused kernel itself (reference_chains_from_lds),
+  // by the generic kernel from `acorr_fallback` (R[] of acorr_reference_kernel, [n][33]).  cert_stats (nullable, test /
+  // bench hook): [0] subframes analysed, [1] certificates that needed the rows of T^-1, [2] subframes redone.
+  uint32_t certify = 0;
+  const double* acorr_fallback = nullptr;
+  uint32_t* cert_stats = nullptr;
   // ... and, with the ApproxEnt order selector of fixed_lpc, every estimator partition's sum of |e| comes
   // from sumabs_reference_kernel (find_sum_abs_f32's sequential f32 chain, arrayutils.rs:496-506) instead of
   // the kernels' exact integer sums: launch_qlpc runs it into `sumabs_scratch` and hands it on as `sumabs_in`
@@ -135,6 +143,8 @@ struct QlpcLaunchPlan {
 QlpcLaunchPlan plan_qlpc_launch(uint32_t block_size, uint32_t lpc_order);
 // true if the wave-per-subframe kernel can take this launch (decided per call: alignment)
 bool wave_kernel_eligible(const QlpcKernelArgs& args);
+// blocks of 4096 / 4608 samples at orders up to 12: the shapes whose unflagged order is certified (QlpcKernelArgs::certify)
+bool cert_shape(const QlpcKernelArgs& args);
 hipError_t launch_qlpc(const QlpcKernelArgs& args, const QlpcLaunchPlan& plan, hipStream_t stream);
 // blocks of 8192 / 16384 samples at order 13..32 (qlpc_bigblock.cpp): autocorrelation and residual + Rice
 // search as two pass-structured kernels either side of levinson_batch_kernel

@@ -220,10 +220,94 @@ enum {
 // skips iteration n (it does not restart).  Operation order and every fma
 // follow the reference; forward[] is updated in place pairwise (d, n-d) which
 // reads exactly the old values forward_next[] would be computed from.
+// ---- the order certificate ("default order") -------------------------------------------------------
+// The kernels sum the autocorrelation in their own order (the chunk tree), the reference in one sequential chain per lag
+// (lpc.rs:533-548).  Both are within eps = (n + 32) 2^-53 S of the exact sums (n - P roundings of the chain + 24 of the
+// tree, each at most 2^-53 of a partial sum of absolute products; S >= sum |x_w[t] x_w[t - tau]| by Cauchy-Schwarz:
+// sqrt(R0 (R0 + P max|s|^2)) <= R0 + P max|s|^2 / 2), hence within eps of each other.  For T a = r, (T + E)(a + da) =
+// r + g with |E_ij|, |g_i| <= eps: |da_i| <= sum_j |T^-1_ij| eps (1 + sum |a_j|) to first order.  The quantiser
+// (lpc.rs:234-302) is a step function of a: if no a_i 2^shift comes within its |da_i| 2^shift of a rounding boundary
+// k + 1/2, and max |a| +- |da| does not straddle a power of two (find_shift), the reference's own R[] quantises to the
+// SAME QuantizedParameters -- the subframe is certified, and every integer output downstream is the reference's.  A
+// subframe that is not certified is redone from the reference's chains.  Factor 2 on the bound: the second-order term
+// and the recursion's own rounding (both <= a few per cent of the first-order term at these orders).
+// Tier 1 bounds every row sum of |T^-1| by the Gohberg-Semencul norm bound 2 |f|_1^2 / |f_0|, f = T^-1 e_0 = the
+// recursion's `forward` vector -- O(P), enough for material that is not strongly tonal; tier 2 evaluates the rows
+// themselves from f (T^-1_ij = T^-1_(i-1)(j-1) + (f_i f_j - f_(P-i) f_(P-j)) / f_0), O(P^2), ~70 x tighter.
+// oracle/flacenc_oracle.c (orc_quant_certified) states the same arithmetic operation for operation.
+constexpr double kCertSafety = 2.0;
+
 template <int MAXP>
+__device__ __forceinline__ bool quant_stable(const double (&a)[MAXP], int P, int shift, const double (&da)[MAXP]) {
+  double amax = 0.0, dmax = 0.0;
+#pragma unroll
+  for (int i = 0; i < MAXP; ++i)
+    if (i < P) {
+      amax = fmax(amax, fabs(a[i]));
+      dmax = fmax(dmax, da[i]);
+    }
+  const double lo = amax - dmax, hi = amax + dmax;
+  bool ok = lo > 0.0 && hi < 1.0e300;  // (false for a NaN bound)
+  if (ok) ok = ceil_log2_pos(lo) == ceil_log2_pos(hi);
+  const double scalefac = (double)(1 << shift);
+#pragma unroll
+  for (int i = 0; i < MAXP; ++i)
+    if (i < P) {
+      const double v = fabs(a[i]) * scalefac;
+      const double d = fabs((v - floor(v)) - 0.5);
+      if (!(d > da[i] * scalefac)) ok = false;
+    }
+  return ok;
+}
+
+// tier 2: row sums of |T^-1| from the forward vector; out of line -- only strongly tonal material gets here
+template <int MAXP>
+__device__ __attribute__((noinline)) bool quant_certified_rows(const double (&a)[MAXP], const double (&fwd)[MAXP], int P,
+                                                               int shift, double eps_a) {
+  double z[MAXP];  // z[i] = fwd[P - i], i >= 1
+#pragma unroll
+  for (int i = 0; i < MAXP; ++i) {
+    double v = 0.0;
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) v = (k == P - i) ? fwd[k] : v;
+    z[i] = v;
+  }
+  const double inv_f0 = 1.0 / fwd[0];
+  double row[MAXP], da[MAXP];
+  {
+    double rs = 0.0;
+#pragma unroll
+    for (int j = 0; j < MAXP; ++j) {
+      row[j] = j < P ? fwd[j] : 0.0;
+      rs += fabs(row[j]);
+    }
+    da[0] = (kCertSafety * rs) * eps_a;
+  }
+#pragma unroll
+  for (int i = 1; i < MAXP; ++i) {
+    double rs = 0.0;
+    if (i < P) {
+#pragma unroll
+      for (int j = MAXP - 1; j >= 1; --j) {
+        const double t = (fwd[i] * fwd[j] - z[i] * z[j]) * inv_f0;
+        row[j] = j < P ? row[j - 1] + t : 0.0;
+      }
+      row[0] = fwd[i];
+#pragma unroll
+      for (int j = 0; j < MAXP; ++j) rs += fabs(row[j]);
+    }
+    da[i] = (kCertSafety * rs) * eps_a;
+  }
+  return quant_stable<MAXP>(a, P, shift, da);
+}
+
+// CERT: *certified_out = the quantised parameters are provably those of any R[] within the summation bound of Rl
+// (max_abs_s = the subframe's max |s|, n = samples summed per lag); tier2_out counts evaluations of the rows (statistics)
+template <int MAXP, bool CERT = false>
 __device__ int levinson_quantize(const double* __restrict__ Rl, int P, int precision,
                                  double (&a)[MAXP], int32_t* qc_out, int* order_out,
-                                 int* shift_out) {
+                                 int* shift_out, uint32_t max_abs_s = 0, int n_sum = 0, bool* certified_out = nullptr,
+                                 bool* tier2_out = nullptr, bool do_cert = true) {
   double R[MAXP + 1];
 #pragma unroll
   for (int i = 0; i <= MAXP; ++i) R[i] = (i <= P) ? Rl[i] : 0.0;
@@ -247,10 +331,11 @@ __device__ int levinson_quantize(const double* __restrict__ Rl, int P, int preci
     if (!allzero) status |= FLACENC_HIP_SUBFRAME_NEG_ENERGY;  // lpc.rs:652-655
   }
 
-  if (status == 0 && R[0] != 0.0) {
-    double fwd[MAXP];
+  double fwd[MAXP];
+  bool skipped = false;  // a zero denominator skipped a step: forward[] is not T^-1 e_0 any more
 #pragma unroll
-    for (int i = 0; i < MAXP; ++i) fwd[i] = 0.0;
+  for (int i = 0; i < MAXP; ++i) fwd[i] = 0.0;
+  if (status == 0 && R[0] != 0.0) {
     fwd[0] = 1.0 / R[0];   // Float::recip(coefs[0] + diagonal_loading), loading = 0
     a[0] = R[1] / R[0];    // ys[0] / (coefs[0] + diagonal_loading)
 #pragma unroll
@@ -260,6 +345,7 @@ __device__ int levinson_quantize(const double* __restrict__ Rl, int P, int preci
 #pragma unroll
         for (int d = 0; d < n; ++d) err = __builtin_fma(R[n - d], fwd[d], err);
         double denom = __builtin_fma(err, -err, 1.0);
+        if (denom == 0.0) skipped = true;
         if (denom != 0.0) {
           double alpha = 1.0 / denom;
           double beta = -alpha * err;
@@ -323,6 +409,40 @@ __device__ int levinson_quantize(const double* __restrict__ Rl, int P, int preci
   }
   *order_out = order;
   *shift_out = shift;
+  if (CERT && !do_cert) {
+    *certified_out = true;
+    if (tier2_out) *tier2_out = false;
+  }
+  if (CERT && do_cert) {
+    // digital silence (R[0] == 0: every product is an exact zero in either order) is certified as it is; a status the
+    // reference would panic on, a skipped step or all-zero coefficients are left to the reference's own chains
+    bool certified = status == 0 && R[0] == 0.0;
+    bool tier2 = false;
+    if (status == 0 && R[0] != 0.0 && !skipped) {
+      double f1 = 0.0, a1 = 0.0;
+#pragma unroll
+      for (int i = 0; i < MAXP; ++i)
+        if (i < P) {
+          f1 += fabs(fwd[i]);
+          a1 += fabs(a[i]);
+        }
+      const double m = (double)max_abs_s;
+      const double S = R[0] + (0.5 * (double)P) * (m * m);
+      const double eps = ((double)(n_sum + 32) * 0x1p-53) * S;
+      const double eps_a = eps * (1.0 + a1);
+      const double tinv = (2.0 * (f1 * f1)) / fabs(fwd[0]);
+      double da[MAXP];
+#pragma unroll
+      for (int i = 0; i < MAXP; ++i) da[i] = (kCertSafety * tinv) * eps_a;
+      certified = quant_stable<MAXP>(a, P, shift, da);
+      if (!certified) {
+        tier2 = true;
+        certified = quant_certified_rows<MAXP>(a, fwd, P, shift, eps_a);
+      }
+    }
+    *certified_out = certified;
+    if (tier2_out) *tier2_out = tier2;
+  }
   return status;
 }
 

@@ -591,6 +591,108 @@ __device__ __attribute__((noinline)) void rice_search_literal(const int32_t* e, 
   out->rr = rr;
 }
 
+// ---- the certificate's fallback: the reference's own chains, in the kernel -------------------------------------------
+// A subframe whose chunk-tree sums do not certify its quantised parameters (levinson_quantize<.., CERT>) is redone from
+// weighted_auto_correlation_nosimd's sums (lpc.rs:533-548): one sequential fma chain per lag over t = P .. n - 1.  Wave 0
+// runs them for the workgroup's four subframes at once on v_mfma_f64_4x4x4_4b_f64 -- a block per subframe, sixteen lags
+// tau = i + 4 j per block, A_b[i][k] = x_w[4 m + k - i - 12], B_b[k][j] = x_w[4 m + k - 12 + 4 j] (0 below t = P and
+// from t = n on): acorr_reference_mfma_kernel's scheme (acorr_reference.cpp; the operand layout and the equality of the
+// chained instruction with the sequential chain are probed in tools/microbench/mfma_f64_4x4x4_probe.hip), fed from the
+// workgroup's LDS images instead of HBM.  `rows`: 4 x kCertRow floats of LDS scratch ([64 of history | a tile of 256]
+// per subframe); the sums come back in the same area, lag tau of subframe b at ((double*)rows)[16 b + tau].
+// Out of line: it runs for a fraction of a per cent of the frames of noisy material (all of them on near-pure tones),
+// 17 tiles x 64 MFMAs = ~40 k cycles, and must not cost the common path a register.
+constexpr int kCertHist = 64;
+constexpr int cert_tile(bool stereo, int spl) { return (!stereo && spl != 64) ? 64 : 256; }
+constexpr int cert_scratch_bytes(int tile) { return 4 * (kCertHist + tile + 8) * 4; }
+
+template <int SPL, bool STEREO, int kCertTile>
+__device__ __attribute__((noinline)) void reference_chains_from_lds(const int32_t* sm, float* rows, const float* wtab, int P) {
+  using G = WaveGeom<SPL>;
+  constexpr int n = G::N;
+  constexpr int kCertRow = kCertHist + kCertTile + 8;  // (row stride = 8 mod 32 banks, as acorr_reference.cpp's kMRow)
+  const int lane = threadIdx.x & 63;
+  int4 raw[STEREO ? 2 : 4];
+  float4 wv;
+  auto issue = [&](int T0) __attribute__((always_inline)) {
+    const int t = T0 + 4 * lane;
+    if (4 * lane >= kCertTile) return;
+    const bool in = t < n;  // (n is a multiple of 4: a quad lies inside the block or behind it)
+    const int ix = G::idx(in ? t : 0);
+#pragma unroll
+    for (int r = 0; r < (STEREO ? 2 : 4); ++r) {
+      const int4 v = *reinterpret_cast<const int4*>(&sm[r * G::Buf + ix]);
+      raw[r] = in ? v : make_int4(0, 0, 0, 0);
+    }
+    wv = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+    if (wtab != nullptr && in) wv = *reinterpret_cast<const float4*>(wtab + t);
+  };
+  // x_w = (f32)s * w, one f32 rounding (lpc.rs:751-754)
+  auto land = [&]() __attribute__((always_inline)) {
+    auto put = [&](int b, const int4& sv) {
+      float4 x;
+      x.x = (float)sv.x * wv.x;
+      x.y = (float)sv.y * wv.y;
+      x.z = (float)sv.z * wv.z;
+      x.w = (float)sv.w * wv.w;
+      if (4 * lane < kCertTile) *reinterpret_cast<float4*>(&rows[b * kCertRow + kCertHist + 4 * lane]) = x;
+    };
+    if (STEREO) {
+      const int4 l = raw[0], r = raw[1];
+      put(0, l);
+      put(1, r);
+      put(2, make_int4((l.x + r.x) >> 1, (l.y + r.y) >> 1, (l.z + r.z) >> 1, (l.w + r.w) >> 1));  // coding.rs:483
+      put(3, make_int4(l.x - r.x, l.y - r.y, l.z - r.z, l.w - r.w));
+    } else {
+#pragma unroll
+      for (int b = 0; b < 4; ++b) put(b, raw[b]);
+    }
+  };
+  // the history in front of the first tile: zeros (the samples in front of the block)
+#pragma unroll
+  for (int q = 0; q < 4; ++q) rows[(lane >> 4) * kCertRow + 16 * q + (lane & 15)] = 0.0f;
+  // this lane's operands: k = lane / 16, block b = (lane % 16) / 4, r = lane % 4 (i for A, j for B)
+  const int k = lane >> 4, b = (lane >> 2) & 3, r = lane & 3;
+  const float* const pa = rows + b * kCertRow + kCertHist + (k - r - 12);      // + 4 m: x_w[T0 + 4 m + k - i - 12]
+  const float* const pb = rows + b * kCertRow + kCertHist + (k - 12 + 4 * r);  // + 4 m: x_w[T0 + 4 m + k - 12 + 4 j]
+  double acc = 0.0;
+  constexpr int n_steps = (n + 12 + 3) >> 2;                          // the last column trails by 12 samples
+  constexpr int n_tiles = (4 * n_steps + kCertTile - 1) / kCertTile;  // (the tile behind the block's end is all zeros)
+  issue(0);
+#pragma unroll 1
+  for (int tile = 0; tile < n_tiles; ++tile) {
+    land();
+    if (tile + 1 < n_tiles) issue((tile + 1) * kCertTile);
+    const int left = n_steps - tile * (kCertTile / 4);
+    const int m_end = left < (kCertTile / 4) ? left : (kCertTile / 4);
+    int m = 0;
+    if (tile == 0) {
+      // B is the current sample: nothing below t = P (only the first tile holds such samples; P + 12 < 64)
+      const int m_mask = (P + 12 + 3) >> 2;
+      for (; m < m_mask && m < m_end; ++m) {
+        const int tcur = 4 * m + k - 12 + 4 * r;
+        const double bd = tcur >= P ? (double)pb[4 * m] : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_4x4x4f64((double)pa[4 * m], bd, acc, 0, 0, 0);
+      }
+    }
+#pragma unroll 8
+    for (; m < m_end; ++m) acc = __builtin_amdgcn_mfma_f64_4x4x4f64((double)pa[4 * m], (double)pb[4 * m], acc, 0, 0, 0);
+    // the tile's last 64 samples become the next tile's history (the wave's own LDS operations are ordered)
+    if (tile + 1 < n_tiles) {
+      float h[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) h[q] = rows[(lane >> 4) * kCertRow + kCertTile + 16 * q + (lane & 15)];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) rows[(lane >> 4) * kCertRow + 16 * q + (lane & 15)] = h[q];
+    }
+  }
+  // D_b[i][j] sits in lane 16 i + 4 b + j: lag i + 4 j of subframe b
+  {
+    const int i = lane >> 4, bo = (lane >> 2) & 3, j = lane & 3;
+    reinterpret_cast<double*>(rows)[16 * bo + i + 4 * j] = acc;
+  }
+}
+
 // DECIDE (stereo only): run encode_subframe's candidate choice and try_stereo_coding's channel
 // assignment (coding.rs:384-418 without the fixed-LPC candidate, :493-522) on the device and
 // write one flacenc_hip_stereo_frame_result + the TWO chosen residual rows per frame.
@@ -654,6 +756,16 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
   // reuses the area for larger things and keeps both.
   constexpr bool kXqOverlay = MAXP > 10 && !PACK;
   float* const wlds = reinterpret_cast<float*>(sm + NBUF * kBufDwords);
+  // The order certificate (levinson_quantize<.., CERT>) and its fallback (reference_chains_from_lds): everywhere but in
+  // the fused bit writer (whose exchange area is something else; launch_qlpc hands it the reference's R[] instead).
+  // Scratch: the window image, dead once phase 1 is over, where there is one; behind the exchange area otherwise (the
+  // plain 4608-sample instances -- four 19.8 KB images -- walk tiles of 64 samples: 2.2 KB is what two workgroups per
+  // CU leave).
+  constexpr bool kCertSupported = !PACK;
+  constexpr int kCertTileHere = cert_tile(STEREO, SPL);
+  float* const cert_rows = (STEREO && SPL == 64)
+                               ? wlds
+                               : reinterpret_cast<float*>(sm + NIMG * kBufDwords) + (4 * (MAXP + 1) * 8 + ((MAXP > 10) ? 0 : 256) + 16) / 4;
   const bool has_window = a.window != nullptr;  // nullptr = all ones (rectangle / Tukey(0))
   const float* __restrict__ wtab = a.window + 32;
   const int flat_lo = a.flat_lo, flat_hi = a.flat_hi;
@@ -964,35 +1076,76 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
     constexpr int XR = NLAG;  // (not rounded up: at order 10 the 32 bytes decide whether three workgroups fit a CU)
     double* const xr = reinterpret_cast<double*>(sm + NIMG * kBufDwords);  // [4][XR]
     int32_t* const xq = reinterpret_cast<int32_t*>(xr + (kXqOverlay ? 0 : 4 * XR));  // [4][16]
+    // the roles' max |s| for the order certificate (16 bytes behind the exchange area: what 42 LDS granules leave at order 10)
+    uint32_t* const xm = reinterpret_cast<uint32_t*>(kXqOverlay ? reinterpret_cast<int32_t*>(xr + 4 * XR) : xq + 64);
+    const bool certify = kCertSupported && a.certify != 0u && a.acorr_in == nullptr;
     if (lane == 0) {
 #pragma unroll
       for (int k = 0; k < NLAG; ++k) xr[wave * XR + k] = R[k];
+      if (kCertSupported) xm[wave] = my_maxabs;
     }
     __syncthreads();
     // (always wave 0, measured: wave 1 instead +2 %, wave 3 +4 %, rotating with the workgroup index -- blk & 1,
     // blk & 3, (blk + (blk >> 8)) & 3, a hash -- +0.6 to +4 %: the three workgroups of a CU do not stack their
     // recursions on one SIMD, and wave 0 carries the lightest role)
-    if (wave == 0 && lane < 4) {
-      __builtin_amdgcn_s_setprio(3);  // the other three waves of the workgroup wait for this one
-      double Rl[NLAG];
-#pragma unroll
-      for (int k = 0; k < NLAG; ++k) Rl[k] = xr[lane * XR + k];
-      double coef[MAXP];
-      int32_t cqv[MAXP];
-      int warm_v, shift_v;
-      const int st = levinson_quantize<MAXP>(Rl, P, (int)a.precision, coef, cqv, &warm_v, &shift_v);
-#pragma unroll
-      for (int i = 0; i < MAXP; ++i) xq[lane * 16 + i] = cqv[i];
-      xq[lane * 16 + 12] = warm_v;
-      xq[lane * 16 + 13] = shift_v;
-      xq[lane * 16 + 14] = st;
-      __builtin_amdgcn_s_setprio(0);
-      uint32_t sfl = blk * 4u + (uint32_t)lane;
+    if (wave == 0) {
+      // Pass 0: the recursion on the chunk tree's R[] (+ the order certificate when `certify`); pass 1, only if a
+      // subframe was not certified: the workgroup's four subframes once more from the reference's chains
+      // (reference_chains_from_lds), adopted by the subframes that need them.
+      bool certified = true;
+      uint32_t sfl = blk * 4u + (uint32_t)(lane & 3);
       if (sfl >= a.n_subframes) sfl = a.n_subframes - 1u;
-      if (a.lpc_coefs) {
+#pragma unroll 1
+      for (int pass = 0; pass < 2; ++pass) {
+        if (lane < 4 && (pass == 0 || !certified)) {
+          __builtin_amdgcn_s_setprio(3);  // the other three waves of the workgroup wait for this one
+          double Rl[NLAG];
+          if (pass == 0) {
 #pragma unroll
-        for (int i = 0; i < MAXP; ++i) a.lpc_coefs[(size_t)sfl * 32 + i] = (i < P && st == 0) ? coef[i] : 0.0;
-        for (int i = MAXP; i < 32; ++i) a.lpc_coefs[(size_t)sfl * 32 + i] = 0.0;
+            for (int k = 0; k < NLAG; ++k) Rl[k] = xr[lane * XR + k];
+          } else {
+            const double* const rr = reinterpret_cast<const double*>(cert_rows) + 16 * lane;
+#pragma unroll
+            for (int k = 0; k < NLAG; ++k) Rl[k] = k <= P ? rr[k] : 0.0;
+            if (a.autocorr) {
+#pragma unroll
+              for (int k = 0; k < NLAG; ++k)
+                if (k <= P) a.autocorr[(size_t)sfl * 33 + k] = Rl[k];
+            }
+          }
+          double coef[MAXP];
+          int32_t cqv[MAXP];
+          int warm_v, shift_v;
+          int st;
+          bool tier2 = false;
+          if (kCertSupported) {
+            bool cert_now = true;
+            st = levinson_quantize<MAXP, true>(Rl, P, (int)a.precision, coef, cqv, &warm_v, &shift_v, xm[lane], kWaveN,
+                                               &cert_now, &tier2, certify && pass == 0);
+            if (pass == 0) certified = cert_now;
+          } else {
+            st = levinson_quantize<MAXP>(Rl, P, (int)a.precision, coef, cqv, &warm_v, &shift_v);
+          }
+#pragma unroll
+          for (int i = 0; i < MAXP; ++i) xq[lane * 16 + i] = cqv[i];
+          xq[lane * 16 + 12] = warm_v;
+          xq[lane * 16 + 13] = shift_v;
+          xq[lane * 16 + 14] = st;
+          __builtin_amdgcn_s_setprio(0);
+          if (a.lpc_coefs) {
+#pragma unroll
+            for (int i = 0; i < MAXP; ++i) a.lpc_coefs[(size_t)sfl * 32 + i] = (i < P && st == 0) ? coef[i] : 0.0;
+            for (int i = MAXP; i < 32; ++i) a.lpc_coefs[(size_t)sfl * 32 + i] = 0.0;
+          }
+          if (kCertSupported && a.cert_stats != nullptr && pass == 0 && certify && blk * 4u + (uint32_t)lane < a.n_subframes) {
+            atomicAdd(a.cert_stats + 0, 1u);
+            if (tier2) atomicAdd(a.cert_stats + 1, 1u);
+            if (!certified) atomicAdd(a.cert_stats + 2, 1u);
+          }
+        }
+        if (!kCertSupported || pass == 1) break;
+        if (__builtin_amdgcn_ballot_w64(lane < 4 && !certified) == 0ull) break;
+        reference_chains_from_lds<SPL, STEREO, kCertTileHere>(sm, cert_rows, has_window ? a.window + 32 : nullptr, P);
       }
     }
   }
@@ -1999,8 +2152,11 @@ template <int MAXP, bool STEREO, bool DECIDE, bool FIXED, bool PACK, int SPL = 6
 hipError_t launch_wave4096(const QlpcKernelArgs& a, hipStream_t stream) {
   auto kern = qlpc_wave4096_kernel<MAXP, STEREO, DECIDE, FIXED, PACK, SPL, CHAINS>;
   // images (+ window, 4096-sample stereo only) + exchange: [4][MAXP + 1] f64 (+ [4][16] i32 unless overlaid, see kXqOverlay)
+  // (+ the roles' max |s| and, where no window image can lend it, the scratch of the certificate's fallback)
+  constexpr bool cert = !PACK;
   constexpr size_t smem = (size_t)(STEREO ? (SPL == 64 ? 3 : 2) : 4) * WaveGeom<SPL>::Buf * 4 +
-                          ((MAXP > 10 && !PACK) ? 4 * (MAXP + 1) * 8 : 4 * ((MAXP + 1) * 8 + 64));
+                          ((MAXP > 10 && !PACK) ? 4 * (MAXP + 1) * 8 : 4 * ((MAXP + 1) * 8 + 64)) +
+                          (cert ? 16 : 0) + ((cert && !(STEREO && SPL == 64)) ? cert_scratch_bytes(cert_tile(STEREO, SPL)) : 0);
   static DynamicLdsOptIn opt_in;  // per instantiation, per device inside
   if (hipError_t err = opt_in.ensure(reinterpret_cast<const void*>(kern), smem); err != hipSuccess) return err;
   const uint32_t blocks = STEREO ? a.n_subframes / 4u : (a.n_subframes + 3u) / 4u;

@@ -111,6 +111,16 @@ extern "C" {
  * BAD_CONFIG if both order flags are set. */
 #define FLACENC_HIP_FLAG_NIGHTLY_SUM_ORDER 64u
 
+/* The chunk tree as it is.  Without a summation-order flag, blocks of 4096 / 4608 samples at orders up to 12 (the fused
+ * kernel's shapes) are CERTIFIED: the kernels keep their own autocorrelation sums where the quantised LPC parameters
+ * provably equal those of the reference's sequential chains (a first-order perturbation bound on the Toeplitz solve
+ * against the distance of every coefficient to its rounding boundary) and recompute the subframe
+ * from those chains where they cannot prove it -- so that every integer output (coefficients, shift, order, residual,
+ * Rice partition, bit counts, frame bytes) is the stable build's, at the chunk tree's speed on material that is not
+ * strongly tonal.  This flag switches the certificate off: a valid encoding of the same configuration whose
+ * coefficients may differ from the reference's in the last quantisation step on a fraction of a per mille of subframes. */
+#define FLACENC_HIP_FLAG_CANONICAL_SUM_ORDER 128u
+
 /* where the caller's sample / output buffers live */
 #define FLACENC_HIP_MEM_HOST 0
 #define FLACENC_HIP_MEM_DEVICE 1

@@ -143,6 +143,18 @@ int orc_default_order_is_stable(size_t n, size_t lpc_order) {
   return (n == 4096 || n == 8192 || n == 16384) && lpc_order >= 16;
 }
 
+/* ... and on blocks of 4096 / 4608 samples at LPC orders up to 12 (the fused kernel's shapes) the unflagged product
+ * CERTIFIES its chunk-tree sums: it keeps them where the quantised parameters provably equal those of the reference's
+ * own chains, and recomputes the subframe from those chains (ORC_ACORR_REFERENCE) where it cannot prove it
+ * (orc_quant_certified below) -- so that every integer output of the default mode is the stable build's. */
+/* statistics of the certified mode since the last reset (not thread-safe: tests read them after single-threaded runs):
+ * [0] subframes analysed, [1] certificates that needed the rows of T^-1, [2] subframes recomputed in the reference's order */
+unsigned long orc_cert_stats[3] = {0, 0, 0};
+
+int orc_default_order_is_certified(size_t n, size_t lpc_order) {
+  return (n == 4096 || n == 4608) && lpc_order >= 1 && lpc_order <= 12;
+}
+
 void orc_auto_correlation_canonical_f64(size_t order, const float* signal, size_t n,
                                         double* dest) {
   for (size_t tau = 0; tau < order; ++tau) dest[tau] = 0.0;
@@ -264,6 +276,116 @@ void orc_auto_correlation_nightly_f64(size_t order, const float* signal, size_t 
 ORC_DEFINE_LEVINSON(orc_symmetric_levinson_f64, double, fma, 1.0, 0.0)
 ORC_DEFINE_LEVINSON(orc_symmetric_levinson_f32, float, fmaf, 1.0f, 0.0f)
 
+/* The same recursion (f64) handing out what the order certificate needs: the final `forward` vector (T^-1 e_0 of the
+ * order x order Toeplitz system) and whether a zero denominator skipped a step (then it is not).  NOT reference code:
+ * the product's certificate (flacenc_rs_amd/csrc/qlpc_kernel_impl.h, levinson_quantize<.., CERT>) restated. */
+static int orc_levinson_f64_forward(const double* coefs, const double* ys, size_t order, double* dest, double* forward,
+                                    int* skipped) {
+  double forward_next[ORC_MAX_LPC_ORDER + 1];
+  *skipped = 0;
+  for (size_t i = 0; i < order; ++i) dest[i] = 0.0;
+  for (size_t i = 0; i <= ORC_MAX_LPC_ORDER; ++i) forward[i] = forward_next[i] = 0.0;
+  if (order == 0) return ORC_STATUS_OK;
+  if (!(coefs[0] >= 0.0)) return ORC_STATUS_NEG_ENERGY;
+  if (coefs[0] == 0.0) {
+    int allzero = 1;
+    for (size_t i = 0; i < order; ++i) allzero &= (ys[i] == 0.0) & (coefs[i] == 0.0);
+    return allzero ? ORC_STATUS_OK : ORC_STATUS_NEG_ENERGY;
+  }
+  forward[0] = 1.0 / coefs[0];
+  dest[0] = ys[0] / coefs[0];
+  for (size_t n = 1; n < order; ++n) {
+    double error = 0.0;
+    for (size_t d = 0; d < n; ++d) error = fma(coefs[n - d], forward[d], error);
+    double denom = fma(error, -error, 1.0);
+    if (denom == 0.0) {
+      *skipped = 1;
+      continue;
+    }
+    double alpha = 1.0 / denom;
+    double beta = -alpha * error;
+    for (size_t d = 0; d <= n; ++d) forward_next[d] = fma(alpha, forward[d], beta * forward[n - d]);
+    for (size_t d = 0; d <= n; ++d) forward[d] = forward_next[d];
+    double delta = 0.0;
+    for (size_t d = 0; d < n; ++d) delta = fma(coefs[n - d], dest[d], delta);
+    double resid = ys[n] - delta;
+    for (size_t d = 0; d <= n; ++d) dest[d] = fma(resid, forward[n - d], dest[d]);
+  }
+  return ORC_STATUS_OK;
+}
+
+/* exact ceil(log2(m)) for finite m > 0 (the product's ceil_log2_pos) */
+static int orc_ceil_log2_pos(double m) {
+  uint64_t b;
+  memcpy(&b, &m, 8);
+  int e = (int)((b >> 52) & 0x7FF);
+  uint64_t frac = b & 0xFFFFFFFFFFFFFull;
+  if (e == 0) return -32752;
+  return (e - 1023) + (frac != 0 ? 1 : 0);
+}
+
+static int orc_quant_stable(const double* a, size_t P, int32_t shift, const double* da) {
+  double amax = 0.0, dmax = 0.0;
+  for (size_t i = 0; i < P; ++i) {
+    amax = fmax(amax, fabs(a[i]));
+    dmax = fmax(dmax, da[i]);
+  }
+  double lo = amax - dmax, hi = amax + dmax;
+  int ok = lo > 0.0 && hi < 1.0e300;
+  if (ok) ok = orc_ceil_log2_pos(lo) == orc_ceil_log2_pos(hi);
+  double scalefac = (double)(1 << shift);
+  for (size_t i = 0; i < P; ++i) {
+    double v = fabs(a[i]) * scalefac;
+    double d = fabs((v - floor(v)) - 0.5);
+    if (!(d > da[i] * scalefac)) ok = 0;
+  }
+  return ok;
+}
+
+/* The product's order certificate (levinson_quantize<.., CERT>, qlpc_kernel_impl.h), operation for operation: are the
+ * quantised parameters of `a` (solution for R with R[0] = r0, forward vector `fwd`) those of ANY autocorrelation within
+ * the summation bound eps of R?  max_abs_s = max |s| of the subframe, n = its length.  *tier2 = the row sums of |T^-1|
+ * had to be evaluated. */
+int orc_quant_certified(const double* a, const double* fwd, size_t P, double r0, uint32_t max_abs_s, size_t n,
+                        uint32_t precision, int* tier2) {
+  const double safety = 2.0;
+  if (tier2) *tier2 = 0;
+  int32_t shift = orc_find_shift(a, P, precision);
+  double f1 = 0.0, a1 = 0.0;
+  for (size_t i = 0; i < P; ++i) {
+    f1 += fabs(fwd[i]);
+    a1 += fabs(a[i]);
+  }
+  double m = (double)max_abs_s;
+  double S = r0 + (0.5 * (double)P) * (m * m);
+  double eps = ((double)(n + 32) * 0x1p-53) * S;
+  double eps_a = eps * (1.0 + a1);
+  double tinv = (2.0 * (f1 * f1)) / fabs(fwd[0]);
+  double da[ORC_MAX_LPC_ORDER];
+  for (size_t i = 0; i < P; ++i) da[i] = (safety * tinv) * eps_a;
+  if (orc_quant_stable(a, P, shift, da)) return 1;
+  if (tier2) *tier2 = 1;
+  /* rows of T^-1 from its first column: T^-1[i][j] = T^-1[i-1][j-1] + (f_i f_j - f_(P-i) f_(P-j)) / f_0 */
+  double row[ORC_MAX_LPC_ORDER], inv_f0 = 1.0 / fwd[0];
+  double rs = 0.0;
+  for (size_t j = 0; j < P; ++j) {
+    row[j] = fwd[j];
+    rs += fabs(row[j]);
+  }
+  da[0] = (safety * rs) * eps_a;
+  for (size_t i = 1; i < P; ++i) {
+    for (size_t j = P - 1; j >= 1; --j) {
+      double t = (fwd[i] * fwd[j] - fwd[P - i] * fwd[P - j]) * inv_f0;
+      row[j] = row[j - 1] + t;
+    }
+    row[0] = fwd[i];
+    rs = 0.0;
+    for (size_t j = 0; j < P; ++j) rs += fabs(row[j]);
+    da[i] = (safety * rs) * eps_a;
+  }
+  return orc_quant_stable(a, P, shift, da);
+}
+
 /* find_shift, src/lpc.rs:234-254 */
 int32_t orc_find_shift(const double* coefs, size_t n, uint32_t precision) {
   double max_abs = fabs(coefs[0]);
@@ -382,7 +504,44 @@ int orc_lpc_from_autocorr(const int32_t* signal, size_t n, const orc_qlpc_config
   float* xw = orc_tls.xw;
   orc_fill_windowed_signal(signal, window, n, xw);
   double corr[ORC_MAX_LPC_ORDER + 1];
-  if (cfg->acorr_order == ORC_ACORR_CANONICAL && !orc_default_order_is_stable(n, lpc_order))
+  if (cfg->acorr_order == ORC_ACORR_CANONICAL && orc_default_order_is_certified(n, lpc_order)) {
+    /* the unflagged product on these shapes: chunk-tree sums where their quantised parameters are certified to be the
+     * reference's, the reference's own chains where not */
+    orc_auto_correlation_canonical_f64(lpc_order + 1, xw, n, corr);
+    int st = ORC_STATUS_OK;
+    for (size_t i = 0; i <= lpc_order; ++i)
+      if (isnan(corr[i]) || isinf(corr[i])) st = ORC_STATUS_NONFINITE;
+    double fwd[ORC_MAX_LPC_ORDER + 1];
+    int skipped = 0, certified = 0;
+    if (st == ORC_STATUS_OK) st = orc_levinson_f64_forward(corr, corr + 1, lpc_order, coefs_out, fwd, &skipped);
+    if (st == ORC_STATUS_OK)
+      for (size_t i = 0; i < lpc_order; ++i)
+        if (isnan(coefs_out[i]) || isinf(coefs_out[i])) st = ORC_STATUS_NONFINITE;
+    if (st == ORC_STATUS_OK) {
+      if (corr[0] == 0.0) {
+        certified = 1; /* digital silence: exact zeros in either order */
+      } else if (!skipped) {
+        uint32_t maxabs = 0;
+        for (size_t t = 0; t < n; ++t) {
+          uint32_t m = signal[t] < 0 ? (uint32_t)0 - (uint32_t)signal[t] : (uint32_t)signal[t];
+          if (m > maxabs) maxabs = m;
+        }
+        int tier2 = 0;
+        certified = orc_quant_certified(coefs_out, fwd, lpc_order, corr[0], maxabs, n, cfg->quant_precision, &tier2);
+        orc_cert_stats[1] += (unsigned long)tier2;
+      }
+    }
+    orc_cert_stats[0] += 1;
+    if (certified) {
+      if (autocorr_out)
+        for (size_t i = 0; i <= lpc_order; ++i) autocorr_out[i] = corr[i];
+      return ORC_STATUS_OK;
+    }
+    orc_cert_stats[2] += 1;
+    for (size_t i = 0; i < lpc_order; ++i) coefs_out[i] = 0.0;
+    orc_auto_correlation_f64(lpc_order + 1, xw, n, corr);
+  } else if ((cfg->acorr_order == ORC_ACORR_CANONICAL || cfg->acorr_order == ORC_ACORR_CHUNK_TREE) &&
+             !orc_default_order_is_stable(n, lpc_order))
     orc_auto_correlation_canonical_f64(lpc_order + 1, xw, n, corr);
   else if (cfg->acorr_order == ORC_ACORR_NIGHTLY)
     orc_auto_correlation_nightly_f64(lpc_order + 1, xw, n, corr, 0);

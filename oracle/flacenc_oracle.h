@@ -43,12 +43,16 @@ extern "C" {
 /* autocorrelation summation orders */
 #define ORC_ACORR_REFERENCE 0 /* weighted_auto_correlation_nosimd, src/lpc.rs:533-548 */
 #define ORC_ACORR_CANONICAL 1 /* the build's unflagged order: 16-sample chunk chains + balanced tree -- except where
-                                  orc_default_order_is_stable() says it is ORC_ACORR_REFERENCE */
+                                  orc_default_order_is_stable() says it is ORC_ACORR_REFERENCE, and certified (else
+                                  recomputed as ORC_ACORR_REFERENCE) where orc_default_order_is_certified() says so */
 #define ORC_ACORR_NIGHTLY 2   /* weighted_auto_correlation_simd, src/lpc.rs:510-531 (aligned buffer) */
 /* config::Qlpc::use_direct_mse (src/config.rs:280): covariance-method LPC, src/lpc.rs:853-903; bits 8.. of
  * acorr_order carry config::Qlpc::mae_optimization_steps (src/config.rs:285; IRLS, src/lpc.rs:814-850).
  * Experimental in the reference, solver from nalgebra: parity unpinned (see flacenc_oracle.c). */
 #define ORC_ACORR_DIRECT_MSE 3
+/* the chunk tree as it is, without the certificate of orc_default_order_is_certified() (the product's
+ * FLACENC_HIP_FLAG_CANONICAL_SUM_ORDER) */
+#define ORC_ACORR_CHUNK_TREE 4
 
 /* find_sum_abs_f32 summation orders (src/arrayutils.rs:496-506) */
 #define ORC_SUMABS_STABLE 0    /* stable build: one sequential f32 chain */
@@ -138,6 +142,10 @@ void orc_auto_correlation_f64(size_t order, const float* signal, size_t n, doubl
 void orc_auto_correlation_f32(size_t order, const float* signal, size_t n, float* dest);
 void orc_auto_correlation_canonical_f64(size_t order, const float* signal, size_t n, double* dest);
 int orc_default_order_is_stable(size_t n, size_t lpc_order);
+int orc_default_order_is_certified(size_t n, size_t lpc_order);
+extern unsigned long orc_cert_stats[3];
+int orc_quant_certified(const double* a, const double* fwd, size_t P, double r0, uint32_t max_abs_s, size_t n,
+                        uint32_t precision, int* tier2);
 void orc_auto_correlation_nightly_f64(size_t order, const float* signal, size_t n, double* dest,
                                       size_t base_mod);
 int orc_symmetric_levinson_f64(const double* coefs, const double* ys, size_t order, double* dest);

@@ -18,6 +18,7 @@ _LIB_PATH = os.path.join(_HERE, "libflacenc_oracle.so")
 ACORR_REFERENCE = 0
 ACORR_CANONICAL = 1
 ACORR_NIGHTLY = 2
+ACORR_CHUNK_TREE = 4  # the chunk tree without the certificate (FLACENC_HIP_FLAG_CANONICAL_SUM_ORDER)
 ACORR_DIRECT_MSE = 3  # config::Qlpc::use_direct_mse; mae_optimization_steps in bits 8.. (experimental, X1)
 SUMABS_STABLE = 0
 SUMABS_NIGHTLY = 1
@@ -310,6 +311,24 @@ def make_config(lpc_order=10, quant_precision=15, window=("tukey", 0.4), max_ric
 
 
 # ---------------------------------------------------------------- lpc.rs ----
+def default_order_is_certified(n: int, lpc_order: int) -> bool:
+    """Shapes on which the unflagged product certifies its chunk-tree sums against the reference's chains."""
+    L = lib()
+    L.orc_default_order_is_certified.argtypes = [C.c_size_t, C.c_size_t]
+    L.orc_default_order_is_certified.restype = C.c_int
+    return bool(L.orc_default_order_is_certified(n, lpc_order))
+
+
+def cert_stats(reset: bool = False):
+    """(subframes analysed in the certified mode, certificates that needed the rows of T^-1, subframes recomputed in the
+    reference's order) since the last reset.  Plain counters: read them after single-threaded runs."""
+    arr = (C.c_ulong * 3).in_dll(lib(), "orc_cert_stats")
+    out = (int(arr[0]), int(arr[1]), int(arr[2]))
+    if reset:
+        arr[0] = arr[1] = arr[2] = 0
+    return out
+
+
 def window_weights(window, n: int) -> np.ndarray:
     cfg = make_config(window=window)
     out = np.empty(n, np.float32)

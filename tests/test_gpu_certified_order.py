@@ -1,0 +1,244 @@
+"""The unflagged summation order on blocks of 4096 / 4608 samples at LPC orders up to 12 (the fused kernel's shapes) is
+CERTIFIED: the kernels keep their chunk-tree autocorrelation where the quantised parameters provably equal those of the
+reference's sequential chains (src/lpc.rs:533-548) and recompute the subframe from those chains where they cannot prove it
+(DESIGN.md section 2).  So with flags = 0:
+
+  * every integer output -- QuantizedParameters, residual rows, Rice partitions, bit counts, decisions, frame bytes -- equals
+    the oracle's ACORR_REFERENCE mode on 100 % of every corpus, the ill-conditioned ones included (near-pure sines, where
+    the bare chunk tree is measurably different; DC + impulse; full-scale squares; the reference's real-audio fixtures);
+  * everything, floating point included, equals the oracle's statement of the same rule (ACORR_CANONICAL on these shapes:
+    orc_default_order_is_certified) bit for bit, through the fused kernel AND through the generic kernel (unaligned rows,
+    FLACENC_HIP_FLAG_GENERIC_KERNEL), and the device's counters (subframes analysed / certificates that needed the rows of
+    T^-1 / subframes recomputed) equal the oracle's;
+  * FLACENC_HIP_FLAG_CANONICAL_SUM_ORDER gives the bare chunk tree (the oracle's ACORR_CHUNK_TREE).
+"""
+import numpy as np
+import pytest
+
+import util
+from flacenc_rs_amd import _capi
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def handle():
+    h = _capi.Handle(0)
+    yield h
+    h.close()
+
+
+def gcfg(order, flags=0, **kw):
+    return _capi.make_config(lpc_order=order, flags=flags, **kw)
+
+
+def ocfg(order, acorr, **kw):
+    return orc.make_config(lpc_order=order, acorr=acorr, **kw)
+
+
+def records_equal(g, o, what=""):
+    for f in ("order", "shift", "precision", "rice_order", "status", "code_bits", "subframe_bits", "sum_quotients"):
+        assert np.array_equal(g[f], o[f]), (what, f, np.nonzero(g[f] != o[f])[0][:8])
+    assert np.array_equal(g["coefs"], o["coefs"]), what
+    assert np.array_equal(g["rice_params"], o["rice_params"]), what
+
+
+# ---- corpora ---------------------------------------------------------------------------------------------------------
+def near_pure_sines(count, n, bps=16, seed0=400):
+    """Sine(57.3, 0.6) + Noise(5e-4): Toeplitz condition numbers of 1e7 and more -- the corpus on which the bare chunk tree's
+    QuantizedParameters differ from the reference's in about one subframe of a few thousand."""
+    return np.stack([util.sine_noise(n, bps, 57.3, 0.6, 5e-4, seed0 + i, phase=0.1 * i) for i in range(count)])
+
+
+def noisy_sines(count, n, bps=16, seed0=100):
+    return np.stack([util.sine_noise(n, bps, 36.0 + (i % 5), 0.4, 0.04, seed0 + i, phase=0.2 * i) for i in range(count)])
+
+
+def dc_impulse(count, n, bps=16):
+    out = np.zeros((count, n), np.int32)
+    rng = np.random.default_rng(5)
+    for i in range(count):
+        out[i] = 1000 + 37 * i + rng.integers(-2, 3, n)
+        out[i, (17 * i + 3) % n] = (1 << (bps - 1)) - 1
+        if i % 3 == 0:
+            out[i, i % 9] = -(1 << (bps - 1))  # an impulse in front of t = P: outside R[0]
+    return out
+
+
+def squares(count, n, bps=16):
+    t = np.arange(n)
+    hi, lo = (1 << (bps - 1)) - 1, -(1 << (bps - 1))
+    return np.stack([np.where(((t + 3 * i) // (7 + i)) % 2 == 0, hi, lo).astype(np.int32) for i in range(count)])
+
+
+def real_audio(n, step=256):
+    rows = []
+    for name in ("ras103", "ras22", "sus109", "sus6"):
+        for ch in (0, 1):
+            x = util.test_signal(name, ch)
+            rows += [x[o:o + n] for o in range(0, 8192 - n + 1, step)]
+    return np.stack(rows)
+
+
+CORPORA = {
+    "near_pure_sines": lambda n: near_pure_sines(96, n),
+    "noisy_sines": lambda n: noisy_sines(64, n),
+    "dc_impulse": lambda n: dc_impulse(24, n),
+    "squares": lambda n: squares(16, n),
+    "real_audio": lambda n: real_audio(n),
+    "silence_and_constants": lambda n: np.stack([np.zeros(n, np.int32), np.full(n, -7, np.int32), np.full(n, 32767, np.int32),
+                                                 np.arange(n, dtype=np.int32) % 5 - 2]),
+}
+
+
+def certified_exact(handle, x, bps, order, flags=0, **kw):
+    """GPU (flags = 0) == oracle's certified rule bit for bit, == oracle's reference order on every integer output."""
+    import torch
+    x = np.ascontiguousarray(x, np.int32)
+    stats = torch.zeros(3, dtype=torch.int32, device="cuda")
+    handle.debug_set_cert_stats(stats.data_ptr())
+    try:
+        gp, gres, gR, gA = handle.qlpc_batch(x, bps, gcfg(order, flags=flags, **kw), want_fp=True)
+        torch.cuda.synchronize()
+    finally:
+        handle.debug_set_cert_stats(0)
+    orc.cert_stats(reset=True)
+    cp, cres, cR, cA = orc.qlpc_batch(x, bps, ocfg(order, orc.ACORR_CANONICAL, **kw), nthreads=1)
+    want_stats = orc.cert_stats()
+    rp, rres, rR, rA = orc.qlpc_batch(x, bps, ocfg(order, orc.ACORR_REFERENCE, **kw))
+    # the rule, floating point included
+    assert np.array_equal(gR.view(np.uint64), cR.view(np.uint64)), "R[] against the oracle's certified rule"
+    assert np.array_equal(gA.view(np.uint64), cA.view(np.uint64)), "LPC coefficient bits against the oracle's certified rule"
+    records_equal(gp, cp, "certified rule")
+    assert np.array_equal(gres, cres)
+    # what the rule is for: the reference's integers, all of them
+    same = (gp["coefs"] == rp["coefs"]).all(axis=1) & (gp["shift"] == rp["shift"]) & (gp["order"] == rp["order"])
+    assert int(same.sum()) == same.size, (int(same.sum()), same.size)
+    records_equal(gp, rp, "reference order")
+    assert np.array_equal(gres, rres)
+    got = tuple(int(v) for v in stats.cpu().numpy())
+    return got, want_stats
+
+
+@pytest.mark.parametrize("order", [8, 10, 12])
+@pytest.mark.parametrize("corpus", sorted(CORPORA))
+def test_default_order_is_the_references_on_4096(handle, corpus, order):
+    x = CORPORA[corpus](4096)
+    got, want = certified_exact(handle, x, 16, order)
+    print(f"{corpus}, order {order}: {want[0]} subframes, {want[1]} certificates needed the rows of T^-1, {want[2]} recomputed "
+          f"from the reference's chains; reference-identical fraction 1.0")
+    assert got == want, (got, want)
+
+
+@pytest.mark.parametrize("order", [1, 2, 5, 9, 11])
+def test_other_orders_and_the_4608_block(handle, order):
+    got, want = certified_exact(handle, near_pure_sines(24, 4096, seed0=900), 16, order)
+    assert got == want
+    x = np.concatenate([near_pure_sines(12, 4608, seed0=77), noisy_sines(12, 4608)])
+    got, want = certified_exact(handle, x, 16, order)
+    assert got == want
+
+
+def test_the_corpus_separates_the_orders(handle):
+    """The bare chunk tree (FLACENC_HIP_FLAG_CANONICAL_SUM_ORDER) is NOT the reference's on this corpus -- R[] never, the
+    quantised parameters in a few subframes of some thousands -- so the equalities above are not vacuous."""
+    x = near_pure_sines(1200, 4096, seed0=400)
+    tp, tres, tR, tA = handle.qlpc_batch(x, 16, gcfg(8, flags=_capi.FLAG_CANONICAL_SUM_ORDER), want_fp=True)
+    op, ores, oR, oA = orc.qlpc_batch(x, 16, ocfg(8, orc.ACORR_CHUNK_TREE))
+    assert np.array_equal(tR.view(np.uint64), oR.view(np.uint64))
+    records_equal(tp, op, "chunk tree")
+    assert np.array_equal(tres, ores)
+    rp, rres, rR, rA = orc.qlpc_batch(x, 16, ocfg(8, orc.ACORR_REFERENCE))
+    assert not np.array_equal(tR[:, :9].view(np.uint64), rR[:, :9].view(np.uint64))
+    differ = int(((tp["coefs"] != rp["coefs"]).any(axis=1) | (tp["shift"] != rp["shift"])).sum())
+    print(f"bare chunk tree: QuantizedParameters differ from the reference's in {differ} of {x.shape[0]} near-pure-sine subframes")
+    got, want = certified_exact(handle, x, 16, 8)
+    assert got == want and want[2] > 0
+
+
+def test_generic_kernel_and_unaligned_rows_follow_the_same_rule(handle):
+    """The certified rule is a function of the shape, not of the kernel: FLACENC_HIP_FLAG_GENERIC_KERNEL and rows the fused
+    kernel cannot take (a stride that is not a multiple of four samples) give the same bits."""
+    import torch
+    x = np.concatenate([near_pure_sines(10, 4096, seed0=31), noisy_sines(6, 4096), real_audio(4096, step=2048)])
+    got, want = certified_exact(handle, x, 16, 10, flags=_capi.FLAG_GENERIC_KERNEL)
+    ns, n = x.shape
+    stride = n + 3
+    buf = torch.zeros(ns * stride + 1, dtype=torch.int32, device="cuda")
+    rows = buf[1:].view(ns, stride)  # base misaligned by one sample
+    rows[:, :n] = torch.from_numpy(x).cuda()
+    params = torch.zeros((ns, 352), dtype=torch.uint8, device="cuda")
+    resid = torch.zeros((ns, n), dtype=torch.int32, device="cuda")
+    bps = torch.full((ns,), 16, dtype=torch.uint8, device="cuda")
+    handle.qlpc_batch_device(gcfg(10), rows.data_ptr(), ns, n, stride, bps.data_ptr(), params.data_ptr(), resid.data_ptr(), n,
+                             sync=True)
+    torch.cuda.synchronize()
+    gp = np.frombuffer(params.cpu().numpy().tobytes(), dtype=_capi.PARAMS_DTYPE)
+    cp, cres, _, _ = orc.qlpc_batch(x, 16, ocfg(10, orc.ACORR_CANONICAL))
+    rp, rres, _, _ = orc.qlpc_batch(x, 16, ocfg(10, orc.ACORR_REFERENCE))
+    records_equal(gp, cp, "unaligned rows")
+    records_equal(gp, rp, "unaligned rows, reference order")
+    assert np.array_equal(resid.cpu().numpy(), rres)
+
+
+@pytest.mark.parametrize("n", [4096, 4608])
+@pytest.mark.parametrize("use_fixed", [False, True])
+def test_frames_and_bytes_are_the_references(handle, n, use_fixed):
+    """encode_frame's decisions, the chosen rows and the packed frame bytes with flags = 0 == the oracle in the reference's
+    order (stereo roles: the four candidates of a frame are certified one by one)."""
+    l = np.concatenate([near_pure_sines(10, n, seed0=5), noisy_sines(6, n, seed0=8)])
+    r = np.concatenate([near_pure_sines(10, n, seed0=50), noisy_sines(6, n, seed0=80)])
+    frames = np.stack([l, r], axis=1)
+    fc = _capi.make_frame_config(gcfg(10), use_fixed=use_fixed)
+    res, resid = handle.encode_stereo_frames(frames, 16, fc)
+    blobs = handle.pack_stereo_frames(frames, res, resid, 16, 44100)
+    ofc = orc.make_frame_config(ocfg(10, orc.ACORR_REFERENCE), use_fixed=use_fixed)
+    ores, oresid = orc.encode_stereo_frames_cfg(frames, 16, ofc)
+    for f in range(frames.shape[0]):
+        want = orc.write_stereo_frame(ores[f], frames[f, 0], frames[f, 1], 16, 44100, f, oresid[f, 0], oresid[f, 1])
+        assert blobs[f] == want, f
+    assert np.array_equal(resid, oresid)
+
+
+def test_fused_bit_writer_takes_the_references_chains(handle):
+    """FLACENC_HIP_FLAG_FUSED_PACK (bytes only, no certificate inside that kernel): launch_qlpc hands it the reference's
+    R[], so its bytes are the two-kernel form's and the oracle's."""
+    import torch
+    n, nf = 4096, 12
+    l = near_pure_sines(nf, n, seed0=15)
+    r = near_pure_sines(nf, n, seed0=51)
+    frames = np.ascontiguousarray(np.stack([l, r], axis=1))
+    x = torch.from_numpy(frames).cuda()
+    out_stride = handle.frame_bytes_bound(n, 16)
+    ofc = orc.make_frame_config(ocfg(8, orc.ACORR_REFERENCE), use_fixed=True)
+    ores, oresid = orc.encode_stereo_frames_cfg(frames, 16, ofc)
+    for flag in (_capi.FLAG_FUSED_PACK, _capi.FLAG_TWO_STAGE_PACK):
+        fc = _capi.make_frame_config(gcfg(8, flags=flag), use_fixed=True)
+        results = torch.zeros((nf, 752), dtype=torch.uint8, device="cuda")
+        packed = torch.zeros((nf, out_stride), dtype=torch.uint8, device="cuda")
+        lens = torch.zeros(nf, dtype=torch.int32, device="cuda")
+        handle.encode_pack_stereo_frames_device(fc, x.data_ptr(), nf, n, n, 16, 44100, 0, 1, results.data_ptr(),
+                                                packed.data_ptr(), out_stride, lens.data_ptr())
+        torch.cuda.synchronize()
+        pk, ln = packed.cpu().numpy(), lens.cpu().numpy()
+        for f in range(nf):
+            want = orc.write_stereo_frame(ores[f], frames[f, 0], frames[f, 1], 16, 44100, f, oresid[f, 0], oresid[f, 1])
+            assert bytes(pk[f, :ln[f]]) == want, (flag, f)
+
+
+def test_independent_channels_are_certified_too(handle):
+    """Plain batches and Independent(n) frames (four subframes of one workgroup certified side by side), 4096 and 4608."""
+    for n in (4096, 4608):
+        chans = np.concatenate([near_pure_sines(5, n, seed0=61), noisy_sines(3, n, seed0=62)])
+        frames = chans.reshape(2, 4, n)
+        fc = _capi.make_frame_config(gcfg(10), use_fixed=True)
+        res, resid = handle.encode_frames(frames, 16, fc)
+        ofc = orc.make_frame_config(ocfg(10, orc.ACORR_REFERENCE), use_fixed=True)
+        for f in range(frames.shape[0]):
+            for c in range(frames.shape[1]):
+                w = orc.encode_subframe(frames[f, c], 16, ofc)
+                g = res[f, c]
+                assert int(g["kind"]) == w["kind"] and int(g["bits"]) == w["bits"], (n, f, c)
+                if w["kind"] >= 2:
+                    assert np.array_equal(resid[f, c], w["residual"]), (n, f, c)

@@ -64,6 +64,9 @@ def parse_args(argv=None):
     ap.add_argument("--reference-order", action="store_true",
                     help="FLACENC_HIP_FLAG_REFERENCE_SUM_ORDER: autocorrelation in the reference's stable "
                          "summation order (bit-identical coefficients; one extra pass over the samples)")
+    ap.add_argument("--canonical-order", action="store_true",
+                    help="FLACENC_HIP_FLAG_CANONICAL_SUM_ORDER: the bare chunk tree, without the order certificate that makes "
+                         "the default mode's integers the reference's (A/B of the certificate's cost; not the default)")
     ap.add_argument("--gather", choices=["records", "payload", "lengths"], default="records",
                     help="what the multi-GPU exchange moves besides the frames' byte lengths: the 752-B "
                          "decision records = the encoded SubFrame components (default), the packed frame "
@@ -230,7 +233,8 @@ def run(args, world):
     # the metric names (--use-fixed adds the reference default's fixed-LPC candidate); all stereo
     # assignments allowed
     qcfg = _capi.make_config(lpc_order=args.lpc_order, rice_finest_only=args.finest_rice_order,
-                             flags=_capi.FLAG_REFERENCE_SUM_ORDER if args.reference_order else 0)
+                             flags=_capi.FLAG_REFERENCE_SUM_ORDER if args.reference_order else
+                             (_capi.FLAG_CANONICAL_SUM_ORDER if args.canonical_order else 0))
     cfg = _capi.make_frame_config(qcfg, use_fixed=args.use_fixed)
     # synthetic "sigen" audio: Sine(200, 0.4) + Noise(0.4) like the reference's
     # stereo_frame_encoder_noisy_sine_lpc bench (src/coding.rs:1152), one continuous stream,

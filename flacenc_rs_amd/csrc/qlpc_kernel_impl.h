@@ -261,9 +261,72 @@ __device__ __forceinline__ bool quant_stable(const double (&a)[MAXP], int P, int
 }
 
 // tier 2: row sums of |T^-1| from the forward vector; out of line -- only strongly tonal material gets here
+// The recursion proper (lpc.rs:657-703), shared by levinson_quantize and the certificate's second tier: a[] = the
+// solution, fwd[] = the final `forward` vector, *skipped = a zero denominator skipped a step (lpc.rs:679-682).
 template <int MAXP>
-__device__ __attribute__((noinline)) bool quant_certified_rows(const double (&a)[MAXP], const double (&fwd)[MAXP], int P,
-                                                               int shift, double eps_a) {
+__device__ __forceinline__ void levinson_core(const double (&R)[MAXP + 1], int P, double (&a)[MAXP], double (&fwd)[MAXP],
+                                              bool* skipped) {
+  fwd[0] = 1.0 / R[0];   // Float::recip(coefs[0] + diagonal_loading), loading = 0
+  a[0] = R[1] / R[0];    // ys[0] / (coefs[0] + diagonal_loading)
+#pragma unroll
+  for (int n = 1; n < MAXP; ++n) {
+    if (n < P) {
+      double err = 0.0;
+#pragma unroll
+      for (int d = 0; d < n; ++d) err = __builtin_fma(R[n - d], fwd[d], err);
+      double denom = __builtin_fma(err, -err, 1.0);
+      if (denom == 0.0) *skipped = true;
+      if (denom != 0.0) {
+        double alpha = 1.0 / denom;
+        double beta = -alpha * err;
+        // forward_next[d] = fma(alpha, forward[d], beta * forward[n - d]), d <= n
+#pragma unroll
+        for (int d = 0; 2 * d <= n; ++d) {
+          double fd = fwd[d], fe = fwd[n - d];
+          double nd = __builtin_fma(alpha, fd, beta * fe);
+          double ne = __builtin_fma(alpha, fe, beta * fd);
+          fwd[d] = nd;
+          fwd[n - d] = ne;
+        }
+        double delta = 0.0;
+#pragma unroll
+        for (int d = 0; d < n; ++d) delta = __builtin_fma(R[n - d], a[d], delta);
+        double resid = R[n + 1] - delta;  // ys[n] - delta
+#pragma unroll
+        for (int d = 0; d <= n; ++d) a[d] = __builtin_fma(resid, fwd[n - d], a[d]);
+      }
+    }
+  }
+}
+
+// tier 2: row sums of |T^-1| from the forward vector.  Out of line and self-contained -- only strongly tonal material gets
+// here, and nothing of it may lengthen a live range on the common path: it reloads R[] from memory (`r_mem`: where the
+// caller took it from) and runs the recursion again for a[] and the forward vector (identical bits: the same code).
+template <int MAXP>
+__device__ __attribute__((noinline)) bool quant_certified_rows(const double* r_mem, int P, int precision, uint32_t max_abs_s,
+                                                               int n_sum) {
+  double R[MAXP + 1], a[MAXP], fwd[MAXP];
+#pragma unroll
+  for (int i = 0; i <= MAXP; ++i) R[i] = (i <= P) ? r_mem[i] : 0.0;
+#pragma unroll
+  for (int i = 0; i < MAXP; ++i) a[i] = fwd[i] = 0.0;
+  bool skipped = false;
+  levinson_core<MAXP>(R, P, a, fwd, &skipped);
+  // shift and eps_a as the first tier has them (find_shift, lpc.rs:234-254)
+  double a1 = 0.0, amax = 0.0;
+#pragma unroll
+  for (int i = 0; i < MAXP; ++i) {
+    a1 += fabs(a[i]);
+    amax = fmax(amax, fabs(a[i]));
+  }
+  int abs_log2 = ceil_log2_pos(amax);
+  if (abs_log2 < -32752) abs_log2 = -32752;
+  int shift = (precision - 1) - abs_log2;
+  shift = shift < 0 ? 0 : (shift > 15 ? 15 : shift);
+  const double m = (double)max_abs_s;
+  const double S = R[0] + (0.5 * (double)P) * (m * m);
+  const double eps = ((double)(n_sum + 32) * 0x1p-53) * S;
+  const double eps_a = eps * (1.0 + a1);
   double z[MAXP];  // z[i] = fwd[P - i], i >= 1
 #pragma unroll
   for (int i = 0; i < MAXP; ++i) {
@@ -301,6 +364,55 @@ __device__ __attribute__((noinline)) bool quant_certified_rows(const double (&a)
   return quant_stable<MAXP>(a, P, shift, da);
 }
 
+// The certificate proper, out of line: inlined behind the recursion its mere presence -- skipped or not -- cost the
+// kernel 6 % (47 more register copies and a different schedule of the recursion in front of it: the recursion is wave 0's
+// serial path, every cycle of it is the workgroup's).  Operands by value: a[] and a handful of scalars.
+// Returns bit 0: certified, bit 1: the rows of T^-1 were needed.
+template <int MAXP>
+struct CertArgs {
+  double a[MAXP];
+  double f1, f0, r0;    // |forward|_1, |forward[0]|, R[0]
+  uint32_t max_abs_s;
+  int n_sum, P, shift;
+};
+#ifdef FLACENC_CERT_T1_OUTLINE
+#define FLACENC_CERT_T1_ATTR __attribute__((noinline))
+#else
+#define FLACENC_CERT_T1_ATTR __forceinline__
+#endif
+template <int MAXP>
+__device__ FLACENC_CERT_T1_ATTR int quant_certified(const CertArgs<MAXP>& in) {
+  // (entries above P are +0.0 in a[]: no masks -- they add nothing, and a zero coefficient sits 0.5 from its boundary,
+  // further than any bound under which a real coefficient could pass)
+  double a1 = 0.0, amax = 0.0;
+#pragma unroll
+  for (int i = 0; i < MAXP; ++i) {
+    a1 += fabs(in.a[i]);
+    amax = fmax(amax, fabs(in.a[i]));
+  }
+  const double m = (double)in.max_abs_s;
+  const double S = in.r0 + (0.5 * (double)in.P) * (m * m);
+  const double eps = ((double)(in.n_sum + 32) * 0x1p-53) * S;
+  const double eps_a = eps * (1.0 + a1);
+  // tier 1: |da_i| <= kCertSafety (2 f1^2 / |f0|) eps_a for every i; everything is compared multiplied through by |f0|
+  // (no division): num = |da| |f0|
+  const double f1 = in.f1, f0 = in.f0;
+  const double num = ((kCertSafety * 2.0) * (f1 * f1)) * eps_a;
+  // find_shift: max |a| -+ |da| must stay inside (2^(e-1), 2^e], e = ceil(log2(max |a|)) (both gaps are exact)
+  const int e = ceil_log2_pos(amax);
+  const double g_lo = amax - ldexp(1.0, e - 1), g_hi = ldexp(1.0, e) - amax;
+  bool ok = amax > 0.0 && num < g_lo * f0 && num < g_hi * f0;
+  const double scalefac = (double)(1 << in.shift);
+  const double nums = num * scalefac;
+#pragma unroll
+  for (int i = 0; i < MAXP; ++i) {
+    const double v = fabs(in.a[i]) * scalefac;
+    const double d = fabs(__builtin_amdgcn_fract(v) - 0.5);  // (v - floor(v): v_fract_f64; v < 2^15, no clamp case)
+    if (!(d * f0 > nums)) ok = false;
+  }
+  return ok ? 1 : 2;  // 2: not certified by this tier -- the caller asks quant_certified_rows
+}
+
 // CERT: *certified_out = the quantised parameters are provably those of any R[] within the summation bound of Rl
 // (max_abs_s = the subframe's max |s|, n = samples summed per lag); tier2_out counts evaluations of the rows (statistics)
 template <int MAXP, bool CERT = false>
@@ -331,41 +443,18 @@ __device__ int levinson_quantize(const double* __restrict__ Rl, int P, int preci
     if (!allzero) status |= FLACENC_HIP_SUBFRAME_NEG_ENERGY;  // lpc.rs:652-655
   }
 
-  double fwd[MAXP];
   bool skipped = false;  // a zero denominator skipped a step: forward[] is not T^-1 e_0 any more
-#pragma unroll
-  for (int i = 0; i < MAXP; ++i) fwd[i] = 0.0;
+  double cert_f1 = 0.0, cert_f0 = 0.0;  // |forward|_1 and |forward[0]|: all the certificate's first tier needs of it
   if (status == 0 && R[0] != 0.0) {
-    fwd[0] = 1.0 / R[0];   // Float::recip(coefs[0] + diagonal_loading), loading = 0
-    a[0] = R[1] / R[0];    // ys[0] / (coefs[0] + diagonal_loading)
+    double fwd[MAXP];
 #pragma unroll
-    for (int n = 1; n < MAXP; ++n) {
-      if (n < P) {
-        double err = 0.0;
+    for (int i = 0; i < MAXP; ++i) fwd[i] = 0.0;
+    levinson_core<MAXP>(R, P, a, fwd, &skipped);
+    if (CERT) {
+      // (entries above P are +0.0: no masks)
 #pragma unroll
-        for (int d = 0; d < n; ++d) err = __builtin_fma(R[n - d], fwd[d], err);
-        double denom = __builtin_fma(err, -err, 1.0);
-        if (denom == 0.0) skipped = true;
-        if (denom != 0.0) {
-          double alpha = 1.0 / denom;
-          double beta = -alpha * err;
-          // forward_next[d] = fma(alpha, forward[d], beta * forward[n - d]), d <= n
-#pragma unroll
-          for (int d = 0; 2 * d <= n; ++d) {
-            double fd = fwd[d], fe = fwd[n - d];
-            double nd = __builtin_fma(alpha, fd, beta * fe);
-            double ne = __builtin_fma(alpha, fe, beta * fd);
-            fwd[d] = nd;
-            fwd[n - d] = ne;
-          }
-          double delta = 0.0;
-#pragma unroll
-          for (int d = 0; d < n; ++d) delta = __builtin_fma(R[n - d], a[d], delta);
-          double resid = R[n + 1] - delta;  // ys[n] - delta
-#pragma unroll
-          for (int d = 0; d <= n; ++d) a[d] = __builtin_fma(resid, fwd[n - d], a[d]);
-        }
-      }
+      for (int i = 0; i < MAXP; ++i) cert_f1 += fabs(fwd[i]);
+      cert_f0 = fabs(fwd[0]);
     }
 #pragma unroll
     for (int i = 0; i < MAXP; ++i) {
@@ -413,36 +502,34 @@ __device__ int levinson_quantize(const double* __restrict__ Rl, int P, int preci
     *certified_out = true;
     if (tier2_out) *tier2_out = false;
   }
+#ifdef FLACENC_CERT_NOBLOCK
+  if (CERT) *certified_out = true;
+#else
   if (CERT && do_cert) {
     // digital silence (R[0] == 0: every product is an exact zero in either order) is certified as it is; a status the
     // reference would panic on, a skipped step or all-zero coefficients are left to the reference's own chains
     bool certified = status == 0 && R[0] == 0.0;
     bool tier2 = false;
     if (status == 0 && R[0] != 0.0 && !skipped) {
-      double f1 = 0.0, a1 = 0.0;
+      CertArgs<MAXP> ca;
 #pragma unroll
-      for (int i = 0; i < MAXP; ++i)
-        if (i < P) {
-          f1 += fabs(fwd[i]);
-          a1 += fabs(a[i]);
-        }
-      const double m = (double)max_abs_s;
-      const double S = R[0] + (0.5 * (double)P) * (m * m);
-      const double eps = ((double)(n_sum + 32) * 0x1p-53) * S;
-      const double eps_a = eps * (1.0 + a1);
-      const double tinv = (2.0 * (f1 * f1)) / fabs(fwd[0]);
-      double da[MAXP];
-#pragma unroll
-      for (int i = 0; i < MAXP; ++i) da[i] = (kCertSafety * tinv) * eps_a;
-      certified = quant_stable<MAXP>(a, P, shift, da);
-      if (!certified) {
-        tier2 = true;
-        certified = quant_certified_rows<MAXP>(a, fwd, P, shift, eps_a);
-      }
+      for (int i = 0; i < MAXP; ++i) ca.a[i] = a[i];
+      ca.f1 = cert_f1;
+      ca.f0 = cert_f0;
+      ca.r0 = R[0];
+      ca.max_abs_s = max_abs_s;
+      ca.n_sum = n_sum;
+      ca.P = P;
+      ca.shift = shift;
+      const int fl = quant_certified<MAXP>(ca);
+      certified = (fl & 1) != 0;
+      tier2 = (fl & 2) != 0;  // the first tier could not decide: the caller runs quant_certified_rows (out of line,
+                              // NOT from here: a call site inside this function costs the common path 1.3 %)
     }
     *certified_out = certified;
     if (tier2_out) *tier2_out = tier2;
   }
+#endif
   return status;
 }
 

@@ -47,7 +47,7 @@ namespace {
 // on-device decision and the fixed-LPC candidate.  What is still spilled there sits around the out-of-line
 // call of the rare literal Rice search and in the decision tail.  Order 8: deciding kernel 0.313 -> 0.275 ms
 // per 8192 frames, with the fixed-LPC candidate 0.446 -> 0.380 ms.  Order 12 (17 / 35 / 44 spilled dwords in the
-// deciding / candidate / fixed-LPC variants, and an exchange area 256 bytes smaller, see kXqOverlay) gains too:
+// deciding / candidate / fixed-LPC variants, and an exchange area 256 bytes smaller, see kXqInWindow) gains too:
 // 1.005 -> 0.815 ms, 1.12 -> 1.02 ms and 1.54 -> 1.29 ms per 24576 frames.  The fused bit writer (PACK) and the
 // independent-channel kernel spill in their inner loops at 168 registers and stay at 2.
 // (variants 6 / 7 are 3 / 4 with the order selector's chain walk: the same budget as their base variant)
@@ -603,7 +603,7 @@ __device__ __attribute__((noinline)) void rice_search_literal(const int32_t* e, 
 // Out of line: it runs for a fraction of a per cent of the frames of noisy material (all of them on near-pure tones),
 // 17 tiles x 64 MFMAs = ~40 k cycles, and must not cost the common path a register.
 constexpr int kCertHist = 64;
-constexpr int cert_tile(bool stereo, int spl) { return (!stereo && spl != 64) ? 64 : 256; }
+constexpr int cert_tile(bool stereo, int spl) { return (!stereo && spl != 64) ? 32 : 256; }
 constexpr int cert_scratch_bytes(int tile) { return 4 * (kCertHist + tile + 8) * 4; }
 
 template <int SPL, bool STEREO, int kCertTile>
@@ -693,6 +693,47 @@ __device__ __attribute__((noinline)) void reference_chains_from_lds(const int32_
   }
 }
 
+// Phase 2 of the fused kernel for one subframe (one lane): the recursion + quantisation (+ the order certificate) on
+// R[0 .. MAXP] at `rsrc` (LDS), the quantised predictor to `xq_row` (LDS: [0 .. MAXP) coefficients, [12] order, [13]
+// shift, [14] status), the unquantised coefficients to `coefs_out` (global, nullable).  Returns bit 0: certified,
+// bit 1: the certificate needed the rows of T^-1.
+#ifdef FLACENC_LEV_OUTLINE
+#define FLACENC_LEV_ATTR __attribute__((noinline))
+#else
+#define FLACENC_LEV_ATTR __forceinline__
+#endif
+template <int MAXP, bool CERT>
+__device__ FLACENC_LEV_ATTR int levinson_phase(const double* rsrc, int P, int precision, int32_t* xq_row,
+                                                        double* coefs_out, uint32_t max_abs_s, int n_sum, bool do_cert) {
+  const double* const Rl = rsrc;  // (levinson_quantize reads R[0 .. P] from it; the certificate's second tier once more)
+  double coef[MAXP];
+  int32_t cqv[MAXP];
+  int warm_v, shift_v, st;
+  bool certified = true, tier2 = false;
+  if (CERT)
+    st = levinson_quantize<MAXP, true>(Rl, P, precision, coef, cqv, &warm_v, &shift_v, max_abs_s, n_sum, &certified, &tier2, do_cert);
+  else
+    st = levinson_quantize<MAXP>(Rl, P, precision, coef, cqv, &warm_v, &shift_v);
+#pragma unroll
+  for (int i = 0; i < MAXP; ++i) xq_row[i] = cqv[i];
+  xq_row[12] = warm_v;
+  xq_row[13] = shift_v;
+  xq_row[14] = st;
+  if (coefs_out) {
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i) coefs_out[i] = (i < P && st == 0) ? coef[i] : 0.0;
+    for (int i = MAXP; i < 32; ++i) coefs_out[i] = 0.0;
+  }
+  return (certified ? 1 : 0) | (tier2 ? 2 : 0);
+}
+
+// ... and the same out of line, without the certificate: the second pass of a workgroup whose first was not certified
+template <int MAXP>
+__device__ __attribute__((noinline)) void levinson_phase_cold(const double* rsrc, int P, int precision, int32_t* xq_row,
+                                                              double* coefs_out) {
+  levinson_phase<MAXP, false>(rsrc, P, precision, xq_row, coefs_out, 0u, 0, false);
+}
+
 // DECIDE (stereo only): run encode_subframe's candidate choice and try_stereo_coding's channel
 // assignment (coding.rs:384-418 without the fixed-LPC candidate, :493-522) on the device and
 // write one flacenc_hip_stereo_frame_result + the TWO chosen residual rows per frame.
@@ -754,18 +795,27 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
   // handed (its four lanes have read them, in lockstep, before any of them writes; nobody else reads R[] after
   // the barrier) -- 256 bytes less, which is what 3 x 42 LDS granules leave room for.  The fused bit writer
   // reuses the area for larger things and keeps both.
-  constexpr bool kXqOverlay = MAXP > 10 && !PACK;
+  // (Round 5: the certificate's second tier reads R[] again after the predictor has been written, so instead of
+  // overlaying R[] the quantised predictor of the order-12 stereo instances now goes into the window image -- dead once
+  // phase 1 is over -- behind the 5.2 KB the certificate's fallback uses of it; instances without a window image have
+  // the room for a predictor area of its own.)
+  constexpr bool kXqInWindow = MAXP > 10 && !PACK && STEREO && SPL == 64;
+  constexpr int kXqWindowOff = 1344;  // floats into the window image
   float* const wlds = reinterpret_cast<float*>(sm + NBUF * kBufDwords);
   // The order certificate (levinson_quantize<.., CERT>) and its fallback (reference_chains_from_lds): everywhere but in
   // the fused bit writer (whose exchange area is something else; launch_qlpc hands it the reference's R[] instead).
   // Scratch: the window image, dead once phase 1 is over, where there is one; behind the exchange area otherwise (the
-  // plain 4608-sample instances -- four 19.8 KB images -- walk tiles of 64 samples: 2.2 KB is what two workgroups per
+  // plain 4608-sample instances -- four 19.8 KB images -- walk tiles of 32 samples: 1.7 KB is what two workgroups per
   // CU leave).
+#ifdef FLACENC_NO_CERT
+  constexpr bool kCertSupported = false;  // (diagnostic build: the kernel without the order certificate)
+#else
   constexpr bool kCertSupported = !PACK;
+#endif
   constexpr int kCertTileHere = cert_tile(STEREO, SPL);
   float* const cert_rows = (STEREO && SPL == 64)
                                ? wlds
-                               : reinterpret_cast<float*>(sm + NIMG * kBufDwords) + (4 * (MAXP + 1) * 8 + ((MAXP > 10) ? 0 : 256) + 16) / 4;
+                               : reinterpret_cast<float*>(sm + NIMG * kBufDwords) + (4 * (MAXP + 1) * 8 + 256 + 16) / 4;
   const bool has_window = a.window != nullptr;  // nullptr = all ones (rectangle / Tukey(0))
   const float* __restrict__ wtab = a.window + 32;
   const int flat_lo = a.flat_lo, flat_hi = a.flat_hi;
@@ -1075,9 +1125,10 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
     // must fit one CU (3 x 42 granules = 157.5 KB)
     constexpr int XR = NLAG;  // (not rounded up: at order 10 the 32 bytes decide whether three workgroups fit a CU)
     double* const xr = reinterpret_cast<double*>(sm + NIMG * kBufDwords);  // [4][XR]
-    int32_t* const xq = reinterpret_cast<int32_t*>(xr + (kXqOverlay ? 0 : 4 * XR));  // [4][16]
+    int32_t* const xq = kXqInWindow ? reinterpret_cast<int32_t*>(wlds + kXqWindowOff) : reinterpret_cast<int32_t*>(xr + 4 * XR);  // [4][16]
     // the roles' max |s| for the order certificate (16 bytes behind the exchange area: what 42 LDS granules leave at order 10)
-    uint32_t* const xm = reinterpret_cast<uint32_t*>(kXqOverlay ? reinterpret_cast<int32_t*>(xr + 4 * XR) : xq + 64);
+    uint32_t* const xm = reinterpret_cast<uint32_t*>(kXqInWindow ? reinterpret_cast<int32_t*>(xr + 4 * XR) : xq + 64);
+    const double* const xr_keep = xr;
     const bool certify = kCertSupported && a.certify != 0u && a.acorr_in == nullptr;
     if (lane == 0) {
 #pragma unroll
@@ -1089,63 +1140,46 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
     // blk & 3, (blk + (blk >> 8)) & 3, a hash -- +0.6 to +4 %: the three workgroups of a CU do not stack their
     // recursions on one SIMD, and wave 0 carries the lightest role)
     if (wave == 0) {
-      // Pass 0: the recursion on the chunk tree's R[] (+ the order certificate when `certify`); pass 1, only if a
-      // subframe was not certified: the workgroup's four subframes once more from the reference's chains
-      // (reference_chains_from_lds), adopted by the subframes that need them.
-      bool certified = true;
+      // The recursion on the chunk tree's R[] (+ the order certificate when `certify`); then, only if a subframe was
+      // not certified, the workgroup's four subframes once more from the reference's chains (reference_chains_from_lds),
+      // adopted by the subframes that need them.  (Straight-line, the second pass through a copy of the recursion that
+      // lives out of line: as a two-trip loop around one inlined copy the common path lost 6 %.)
+      bool certified = true, need_rows = false;
       uint32_t sfl = blk * 4u + (uint32_t)(lane & 3);
       if (sfl >= a.n_subframes) sfl = a.n_subframes - 1u;
-#pragma unroll 1
-      for (int pass = 0; pass < 2; ++pass) {
-        if (lane < 4 && (pass == 0 || !certified)) {
-          __builtin_amdgcn_s_setprio(3);  // the other three waves of the workgroup wait for this one
-          double Rl[NLAG];
-          if (pass == 0) {
-#pragma unroll
-            for (int k = 0; k < NLAG; ++k) Rl[k] = xr[lane * XR + k];
-          } else {
-            const double* const rr = reinterpret_cast<const double*>(cert_rows) + 16 * lane;
-#pragma unroll
-            for (int k = 0; k < NLAG; ++k) Rl[k] = k <= P ? rr[k] : 0.0;
-            if (a.autocorr) {
-#pragma unroll
-              for (int k = 0; k < NLAG; ++k)
-                if (k <= P) a.autocorr[(size_t)sfl * 33 + k] = Rl[k];
-            }
-          }
-          double coef[MAXP];
-          int32_t cqv[MAXP];
-          int warm_v, shift_v;
-          int st;
-          bool tier2 = false;
-          if (kCertSupported) {
-            bool cert_now = true;
-            st = levinson_quantize<MAXP, true>(Rl, P, (int)a.precision, coef, cqv, &warm_v, &shift_v, xm[lane], kWaveN,
-                                               &cert_now, &tier2, certify && pass == 0);
-            if (pass == 0) certified = cert_now;
-          } else {
-            st = levinson_quantize<MAXP>(Rl, P, (int)a.precision, coef, cqv, &warm_v, &shift_v);
-          }
-#pragma unroll
-          for (int i = 0; i < MAXP; ++i) xq[lane * 16 + i] = cqv[i];
-          xq[lane * 16 + 12] = warm_v;
-          xq[lane * 16 + 13] = shift_v;
-          xq[lane * 16 + 14] = st;
-          __builtin_amdgcn_s_setprio(0);
-          if (a.lpc_coefs) {
-#pragma unroll
-            for (int i = 0; i < MAXP; ++i) a.lpc_coefs[(size_t)sfl * 32 + i] = (i < P && st == 0) ? coef[i] : 0.0;
-            for (int i = MAXP; i < 32; ++i) a.lpc_coefs[(size_t)sfl * 32 + i] = 0.0;
-          }
-          if (kCertSupported && a.cert_stats != nullptr && pass == 0 && certify && blk * 4u + (uint32_t)lane < a.n_subframes) {
-            atomicAdd(a.cert_stats + 0, 1u);
-            if (tier2) atomicAdd(a.cert_stats + 1, 1u);
-            if (!certified) atomicAdd(a.cert_stats + 2, 1u);
-          }
+      if (lane < 4) {
+        __builtin_amdgcn_s_setprio(3);  // the other three waves of the workgroup wait for this one
+        const int fl = levinson_phase<MAXP, kCertSupported>(xr + lane * XR, P, (int)a.precision, xq + lane * 16,
+                                                            a.lpc_coefs ? a.lpc_coefs + (size_t)sfl * 32 : nullptr,
+                                                            kCertSupported ? xm[lane] : 0u, kWaveN, certify);
+        __builtin_amdgcn_s_setprio(0);
+        certified = (fl & 1) != 0;
+        need_rows = (fl & 2) != 0;
+        if (kCertSupported && a.cert_stats != nullptr && certify && blk * 4u + (uint32_t)lane < a.n_subframes) {
+          atomicAdd(a.cert_stats + 0, 1u);
+          if (need_rows) atomicAdd(a.cert_stats + 1, 1u);
+          else if (!certified) atomicAdd(a.cert_stats + 2, 1u);
         }
-        if (!kCertSupported || pass == 1) break;
-        if (__builtin_amdgcn_ballot_w64(lane < 4 && !certified) == 0ull) break;
+      }
+      // second tier of the certificate (the rows of T^-1): out of line, for the lanes whose first tier could not decide
+      if (kCertSupported && __builtin_amdgcn_ballot_w64(lane < 4 && need_rows) != 0ull) {
+        if (lane < 4 && need_rows) {
+          certified = quant_certified_rows<MAXP>(xr_keep + lane * XR, P, (int)a.precision, xm[lane], kWaveN);
+          if (a.cert_stats != nullptr && !certified && blk * 4u + (uint32_t)lane < a.n_subframes) atomicAdd(a.cert_stats + 2, 1u);
+        }
+      }
+      if (kCertSupported && __builtin_amdgcn_ballot_w64(lane < 4 && !certified) != 0ull) {
+#ifndef FLACENC_CERT_NO_SLOWPATH
         reference_chains_from_lds<SPL, STEREO, kCertTileHere>(sm, cert_rows, has_window ? a.window + 32 : nullptr, P);
+#endif
+        if (lane < 4 && !certified) {
+          const double* const rsrc = reinterpret_cast<const double*>(cert_rows) + 16 * lane;
+          if (a.autocorr) {
+            for (int k = 0; k <= P; ++k) a.autocorr[(size_t)sfl * 33 + k] = rsrc[k];
+          }
+          levinson_phase_cold<MAXP>(rsrc, P, (int)a.precision, xq + lane * 16,
+                                    a.lpc_coefs ? a.lpc_coefs + (size_t)sfl * 32 : nullptr);
+        }
       }
     }
   }
@@ -1379,7 +1413,7 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
   {
     constexpr int XR = NLAG;  // (not rounded up: at order 10 the 32 bytes decide whether three workgroups fit a CU)
     double* const xr = reinterpret_cast<double*>(sm + NIMG * kBufDwords);  // [4][XR]
-    int32_t* const xq = reinterpret_cast<int32_t*>(xr + (kXqOverlay ? 0 : 4 * XR));  // [4][16]
+    int32_t* const xq = kXqInWindow ? reinterpret_cast<int32_t*>(wlds + kXqWindowOff) : reinterpret_cast<int32_t*>(xr + 4 * XR);  // [4][16]
     (void)xr;
     __syncthreads();
 #pragma unroll
@@ -2151,11 +2185,11 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
 template <int MAXP, bool STEREO, bool DECIDE, bool FIXED, bool PACK, int SPL = 64, bool CHAINS = false>
 hipError_t launch_wave4096(const QlpcKernelArgs& a, hipStream_t stream) {
   auto kern = qlpc_wave4096_kernel<MAXP, STEREO, DECIDE, FIXED, PACK, SPL, CHAINS>;
-  // images (+ window, 4096-sample stereo only) + exchange: [4][MAXP + 1] f64 (+ [4][16] i32 unless overlaid, see kXqOverlay)
+  // images (+ window, 4096-sample stereo only) + exchange: [4][MAXP + 1] f64 (+ [4][16] i32 unless it sits in the window image, see kXqInWindow)
   // (+ the roles' max |s| and, where no window image can lend it, the scratch of the certificate's fallback)
   constexpr bool cert = !PACK;
   constexpr size_t smem = (size_t)(STEREO ? (SPL == 64 ? 3 : 2) : 4) * WaveGeom<SPL>::Buf * 4 +
-                          ((MAXP > 10 && !PACK) ? 4 * (MAXP + 1) * 8 : 4 * ((MAXP + 1) * 8 + 64)) +
+                          ((MAXP > 10 && !PACK && STEREO && SPL == 64) ? 4 * (MAXP + 1) * 8 : 4 * ((MAXP + 1) * 8 + 64)) +
                           (cert ? 16 : 0) + ((cert && !(STEREO && SPL == 64)) ? cert_scratch_bytes(cert_tile(STEREO, SPL)) : 0);
   static DynamicLdsOptIn opt_in;  // per instantiation, per device inside
   if (hipError_t err = opt_in.ensure(reinterpret_cast<const void*>(kern), smem); err != hipSuccess) return err;

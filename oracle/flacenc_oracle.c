@@ -360,10 +360,23 @@ int orc_quant_certified(const double* a, const double* fwd, size_t P, double r0,
   double S = r0 + (0.5 * (double)P) * (m * m);
   double eps = ((double)(n + 32) * 0x1p-53) * S;
   double eps_a = eps * (1.0 + a1);
-  double tinv = (2.0 * (f1 * f1)) / fabs(fwd[0]);
+  /* tier 1, compared multiplied through by |f0| (the kernel's form: no division on the common path) */
+  double amax = 0.0;
+  for (size_t i = 0; i < P; ++i) amax = fmax(amax, fabs(a[i]));
+  double f0 = fabs(fwd[0]);
+  double num = ((safety * 2.0) * (f1 * f1)) * eps_a;
+  int e = orc_ceil_log2_pos(amax);
+  double g_lo = amax - ldexp(1.0, e - 1), g_hi = ldexp(1.0, e) - amax;
+  int ok = amax > 0.0 && num < g_lo * f0 && num < g_hi * f0;
+  double scalefac = (double)(1 << shift);
+  double nums = num * scalefac;
+  for (size_t i = 0; i < P; ++i) {
+    double v = fabs(a[i]) * scalefac;
+    double d = fabs((v - floor(v)) - 0.5);
+    if (!(d * f0 > nums)) ok = 0;
+  }
+  if (ok) return 1;
   double da[ORC_MAX_LPC_ORDER];
-  for (size_t i = 0; i < P; ++i) da[i] = (safety * tinv) * eps_a;
-  if (orc_quant_stable(a, P, shift, da)) return 1;
   if (tier2) *tier2 = 1;
   /* rows of T^-1 from its first column: T^-1[i][j] = T^-1[i-1][j-1] + (f_i f_j - f_(P-i) f_(P-j)) / f_0 */
   double row[ORC_MAX_LPC_ORDER], inv_f0 = 1.0 / fwd[0];

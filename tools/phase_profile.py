@@ -19,6 +19,7 @@ ap.add_argument("--lpc-order", type=int, default=8)
 ap.add_argument("--block-size", type=int, default=4096)
 ap.add_argument("--bps", type=int, default=16)
 ap.add_argument("--signal", default="200,0.4,0.4", help="sine period, sine amplitude, noise amplitude")
+ap.add_argument("--flags", type=int, default=0, help="flacenc_hip_qlpc_config.flags (128 = the bare chunk tree)")
 ap.add_argument("--use-fixed", action="store_true", help="fixed-LPC candidate on: its selection and "
                 "coding pass land in the 'acorr' slot (stamps are rewritten by the last candidate pass)")
 args = ap.parse_args()
@@ -30,7 +31,7 @@ x = torch.from_numpy(host).to(dev)
 results = torch.empty((F, 752), dtype=torch.uint8, device=dev)
 residual = torch.empty((F * 2, n), dtype=torch.int32, device=dev)
 stamps = torch.zeros((F * 4, 8), dtype=torch.int64, device=dev)
-cfg = _capi.make_frame_config(_capi.make_config(lpc_order=args.lpc_order), use_fixed=args.use_fixed)
+cfg = _capi.make_frame_config(_capi.make_config(lpc_order=args.lpc_order, flags=args.flags), use_fixed=args.use_fixed)
 h = _capi.Handle(0)
 for it in range(3):
     h.debug_set_stamps(stamps.data_ptr() if it == 2 else 0)

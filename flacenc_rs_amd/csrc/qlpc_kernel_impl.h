@@ -222,8 +222,8 @@ enum {
 // reads exactly the old values forward_next[] would be computed from.
 // ---- the order certificate ("default order") -------------------------------------------------------
 // The kernels sum the autocorrelation in their own order (the chunk tree), the reference in one sequential chain per lag
-// (lpc.rs:533-548).  Both are within eps = (n + 32) 2^-53 S of the exact sums (n - P roundings of the chain + 24 of the
-// tree, each at most 2^-53 of a partial sum of absolute products; S >= sum |x_w[t] x_w[t - tau]| by Cauchy-Schwarz:
+// (lpc.rs:533-548).  Both are within eps = (n + 96) 2^-53 S of the exact sums (n - P roundings of the chain + at most 71 of the
+// kernels' own orders, each at most 2^-53 of a partial sum of absolute products; S >= sum |x_w[t] x_w[t - tau]| by Cauchy-Schwarz:
 // sqrt(R0 (R0 + P max|s|^2)) <= R0 + P max|s|^2 / 2), hence within eps of each other.  For T a = r, (T + E)(a + da) =
 // r + g with |E_ij|, |g_i| <= eps: |da_i| <= sum_j |T^-1_ij| eps (1 + sum |a_j|) to first order.  The quantiser
 // (lpc.rs:234-302) is a step function of a: if no a_i 2^shift comes within its |da_i| 2^shift of a rounding boundary
@@ -236,6 +236,7 @@ enum {
 // themselves from f (T^-1_ij = T^-1_(i-1)(j-1) + (f_i f_j - f_(P-i) f_(P-j)) / f_0), O(P^2), ~70 x tighter.
 // oracle/flacenc_oracle.c (orc_quant_certified) states the same arithmetic operation for operation.
 constexpr double kCertSafety = 2.0;
+constexpr int kCertOwnRoundings = 96;  // >= P + the roundings of the kernels' own sums (71: a 64-sample chain, six tree levels, the 4608 tail)
 
 template <int MAXP>
 __device__ __forceinline__ bool quant_stable(const double (&a)[MAXP], int P, int shift, const double (&da)[MAXP]) {
@@ -325,7 +326,7 @@ __device__ __attribute__((noinline)) bool quant_certified_rows(const double* r_m
   shift = shift < 0 ? 0 : (shift > 15 ? 15 : shift);
   const double m = (double)max_abs_s;
   const double S = R[0] + (0.5 * (double)P) * (m * m);
-  const double eps = ((double)(n_sum + 32) * 0x1p-53) * S;
+  const double eps = ((double)(n_sum + kCertOwnRoundings) * 0x1p-53) * S;
   const double eps_a = eps * (1.0 + a1);
   double z[MAXP];  // z[i] = fwd[P - i], i >= 1
 #pragma unroll
@@ -392,7 +393,7 @@ __device__ FLACENC_CERT_T1_ATTR int quant_certified(const CertArgs<MAXP>& in) {
   }
   const double m = (double)in.max_abs_s;
   const double S = in.r0 + (0.5 * (double)in.P) * (m * m);
-  const double eps = ((double)(in.n_sum + 32) * 0x1p-53) * S;
+  const double eps = ((double)(in.n_sum + kCertOwnRoundings) * 0x1p-53) * S;
   const double eps_a = eps * (1.0 + a1);
   // tier 1: |da_i| <= kCertSafety (2 f1^2 / |f0|) eps_a for every i; everything is compared multiplied through by |f0|
   // (no division): num = |da| |f0|

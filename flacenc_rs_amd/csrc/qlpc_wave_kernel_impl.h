@@ -591,6 +591,61 @@ __device__ __attribute__((noinline)) void rice_search_literal(const int32_t* e, 
   out->rr = rr;
 }
 
+// ---- the fused kernel's summation order (round 5) -------------------------------------------------------------------
+// Lane l sums its 64 samples as one fma chain per lag; the 64 lane sums v[l] of a lag then meet as
+//     w[i] = (v[i] + v[i + 32]) + (v[i + 16] + v[i + 48]),  i = 0 .. 15,
+//     R = (((w15 + w14) + (w13 + w12)) + ((w11 + w10) + (w9 + w8))) + (((w7 + w6) + (w5 + w4)) + ((w3 + w2) + (w1 + w0)))
+// (oracle: orc_auto_correlation_lane_order_f64).  The first two levels are reduce-scatters: v_permlane32_swap(A, B) leaves
+// the lower half with (own A, the upper half's A) and the upper half with (the lower half's B, own B), so ONE add per
+// PAIR of lags halves both -- three instructions per pair and level where a DPP tree spends six -- and v_permlane16_swap
+// does the same between the rows of each half.  What is left, ceil(N / 4) values per lane, takes the four row shifts.
+// N = 9 lags: 62 instructions for what nine DPP trees of six levels did in 162 (+ 27 adds of the in-lane tree that the
+// single chain does not need).  An odd value out is paired with a register nobody defines; its "sum" is never read.
+template <int N>
+constexpr int kLaneOrderSlots = ((N + 1) / 2 + 1) / 2;
+
+__device__ __forceinline__ double f64_from_halves(uint32_t lo, uint32_t hi) {
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+template <int N>
+__device__ __forceinline__ void lane_order_reduce(const double (&v)[N], double (&out)[kLaneOrderSlots<N>]) {
+  constexpr int N1 = (N + 1) / 2, N2 = (N1 + 1) / 2;
+  double s1[N1];
+#pragma unroll
+  for (int p = 0; p < N1; ++p) {
+    const unsigned long long ab = (unsigned long long)__double_as_longlong(v[2 * p]);
+    unsigned long long bb;
+    if (2 * p + 1 < N) bb = (unsigned long long)__double_as_longlong(v[2 * p + 1]);
+    else asm volatile("" : "=v"(bb));  // (no partner: an undefined register)
+    const auto lo = __builtin_amdgcn_permlane32_swap((uint32_t)ab, (uint32_t)bb, false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((uint32_t)(ab >> 32), (uint32_t)(bb >> 32), false, false);
+    s1[p] = f64_from_halves(lo[0], hi[0]) + f64_from_halves(lo[1], hi[1]);
+  }
+#pragma unroll
+  for (int q = 0; q < N2; ++q) {
+    const unsigned long long ab = (unsigned long long)__double_as_longlong(s1[2 * q]);
+    unsigned long long bb;
+    if (2 * q + 1 < N1) bb = (unsigned long long)__double_as_longlong(s1[2 * q + 1]);
+    else asm volatile("" : "=v"(bb));
+    const auto lo = __builtin_amdgcn_permlane16_swap((uint32_t)ab, (uint32_t)bb, false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap((uint32_t)(ab >> 32), (uint32_t)(bb >> 32), false, false);
+    double t = f64_from_halves(lo[0], hi[0]) + f64_from_halves(lo[1], hi[1]);
+#define FLACENC_F64_ROW_STEP(CTRL)                                                                       \
+    {                                                                                                    \
+      const unsigned long long b_ = (unsigned long long)__double_as_longlong(t);                        \
+      const uint32_t lo_ = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)b_, CTRL, 0xF, 0xF, true);          \
+      const uint32_t hi_ = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)(b_ >> 32), CTRL, 0xF, 0xF, true);  \
+      t = t + f64_from_halves(lo_, hi_);                                                                 \
+    }
+    FLACENC_F64_ROW_STEP(0x111)
+    FLACENC_F64_ROW_STEP(0x112)
+    FLACENC_F64_ROW_STEP(0x114)
+    FLACENC_F64_ROW_STEP(0x118)
+#undef FLACENC_F64_ROW_STEP
+    out[q] = t;
+  }
+}
+
 // ---- the certificate's fallback: the reference's own chains, in the kernel -------------------------------------------
 // A subframe whose chunk-tree sums do not certify its quantised parameters (levinson_quantize<.., CERT>) is redone from
 // weighted_auto_correlation_nosimd's sums (lpc.rs:533-548): one sequential fma chain per lag over t = P .. n - 1.  Wave 0
@@ -784,7 +839,11 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
 
   // ======================= phase 0: HBM -> LDS ==============================
   // Segment layout: sample t of a channel image lives at widx(t); segment 0 is zero.
-  for (int i = tid; i < NBUF * kSeg; i += 256) sm[(i / kSeg) * kBufDwords + (i % kSeg)] = 0;
+  if (SPL == 64 && STEREO) {
+    if (tid < kSeg) sm[tid] = sm[kBufDwords + tid] = 0;
+  } else {
+    for (int i = tid; i < NBUF * kSeg; i += 256) sm[(i / kSeg) * kBufDwords + (i % kSeg)] = 0;
+  }
   // The window table (lpc.rs:96-120, computed on the host) is staged once per workgroup in the
   // same segment layout and shared by the four waves (3 workgroups x 53 KB fit one CU's LDS).
   // Plain mode keeps four sample images (71 KB) and reads the taper weights from the
@@ -830,16 +889,32 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
     return wv;
   };
 
+  // Blocks of 4096: quad q = tid + 256 it of a row lands at qidx(tid) + 1088 it -- one lane-dependent LDS address and one
+  // lane-dependent byte offset (16 tid) for the whole phase; row bases and iteration strides are scalars / immediates
+  // (the generic form below spent 113 VALU instructions per wave on selects and 64-bit address arithmetic).
+  [[maybe_unused]] const int q0 = G::qidx(tid);
+  [[maybe_unused]] const uint32_t e0 = (uint32_t)tid << 2;  // element offset of quad `tid`
   if (has_window && WINDOW_IN_LDS) {
     const float* __restrict__ wsrc = a.window + 32;
     if (tid < kSeg) wlds[tid] = 0.0f;
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int t = (tid + it * 256) << 2;
-      *reinterpret_cast<float4*>(&wlds[widx(t)]) = *reinterpret_cast<const float4*>(wsrc + t);
-    }
+    for (int it = 0; it < 4; ++it)
+      *reinterpret_cast<float4*>(&wlds[q0 + it * 16 * kSeg]) = *reinterpret_cast<const float4*>(wsrc + it * 1024 + e0);
   }
-  if (STEREO) {
+  if (STEREO && SPL == 64) {
+    const int32_t* __restrict__ srcl = a.samples + (size_t)(2u * blk) * a.stride;
+    const int32_t* __restrict__ srcr = srcl + a.stride;
+    int4 vl[4], vr[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) vl[it] = *reinterpret_cast<const int4*>(srcl + it * 1024 + e0);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) vr[it] = *reinterpret_cast<const int4*>(srcr + it * 1024 + e0);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) *reinterpret_cast<int4*>(&sm[q0 + it * 16 * kSeg]) = vl[it];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) *reinterpret_cast<int4*>(&sm[kBufDwords + q0 + it * 16 * kSeg]) = vr[it];
+    __syncthreads();
+  } else if (STEREO) {
     const int32_t* __restrict__ src = a.samples + (size_t)(2u * blk) * a.stride;
     constexpr int NQ2 = 2 * G::Quads;  // 16-byte pieces of the two channels
 #pragma unroll
@@ -933,7 +1008,9 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
   uint32_t my_maxabs = 0;
   auto lpc_front = [&]() {
   // ======================= phase 1: window + autocorrelation ==============
-  double R[NLAG];
+  double R[NLAG];                        // R[] handed in (acorr_in): the same in every lane
+  double Rq[kLaneOrderSlots<NLAG>];      // R[] summed here: slots of the rows' last lanes (lane_order_reduce)
+  const bool from_in = a.acorr_in != nullptr;
   int vmax = INT32_MIN, vmin = INT32_MAX;
   if (a.acorr_in != nullptr) {
     // FLACENC_HIP_FLAG_REFERENCE_SUM_ORDER: R[] was computed by acorr_reference_kernel in the
@@ -980,7 +1057,7 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
     constexpr bool PINGPONG = (HP == 8);  // halo == step: two 8-value blocks swap roles, nothing slides
     constexpr int WN = HP + 8;
     double dw[WN];
-    double acc[NLAG], s01[NLAG], p2[NLAG];
+    double acc[NLAG];
     // raw samples and weights of one 8-sample step, fetched one step ahead of their use
     int4 rv[2];
     float4 rw[2];
@@ -1030,8 +1107,9 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
     // (the chunk body holds both parities, so every index is a compile-time constant); the halo
     // convert above landed in block 1 = what step h = 0 expects.  Otherwise (HP = 12) the last HP
     // values slide down to become the halo.
-    auto chunk = [&](auto masked_tag, int i) {
+    auto chunk = [&](auto masked_tag, auto start_tag, int i) {
       constexpr bool MASKED = decltype(masked_tag)::value;
+      constexpr bool START = decltype(start_tag)::value;  // the lane's chains start here (literal +0.0), else they go on
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int t0 = 16 * i + 8 * h;  // relative to tl
@@ -1057,44 +1135,36 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
             // x_w[t - tau]: in this step's block, or tau - k values before the end of the previous one
             const double lagged = PINGPONG ? (tau <= k ? dw[cur0 + k - tau] : dw[old0 + 8 + k - tau])
                                            : dw[HP + k - tau];
-            acc[tau] = (h == 0 && k == 0) ? __builtin_fma(cur, lagged, 0.0) : __builtin_fma(cur, lagged, acc[tau]);
+            acc[tau] = (START && h == 0 && k == 0) ? __builtin_fma(cur, lagged, 0.0) : __builtin_fma(cur, lagged, acc[tau]);
           }
         }
       }
     };
+    // Round 5: the lane's 64 samples are ONE chain per lag (no restart per 16-sample chunk, no in-lane tree: the order
+    // certificate, not a shared summation order, is what ties the result to the reference's) ...
 #pragma unroll 1
     for (int i = 0; i < 4; ++i) {
-      if (i == 0) chunk(std::true_type{}, i);
-      else chunk(std::false_type{}, i);
-      if (i == 0) {
-#pragma unroll
-        for (int k = 0; k < NLAG; ++k) s01[k] = acc[k];
-      } else if (i == 1) {
-#pragma unroll
-        for (int k = 0; k < NLAG; ++k) s01[k] = s01[k] + acc[k];
-      } else if (i == 2) {
-#pragma unroll
-        for (int k = 0; k < NLAG; ++k) p2[k] = acc[k];
-      } else {
-#pragma unroll
-        for (int k = 0; k < NLAG; ++k) p2[k] = s01[k] + (p2[k] + acc[k]);
-      }
+      if (i == 0) chunk(std::true_type{}, std::true_type{}, i);
+      else chunk(std::false_type{}, std::false_type{}, i);
     }
-    // ... then the 6 lane levels
-#pragma unroll
-    for (int k = 0; k < NLAG; ++k) R[k] = wave_tree_sum_dpp(p2[k]);
+    // ... and the 64 lane sums meet by a reduce-scatter (lane_order_reduce): slot q of row r = lane >> 4 ends up with lag
+    // 4 q + 2 (r & 1) + (r >> 1), complete in the row's lane 15
+    lane_order_reduce<NLAG>(acc, Rq);
     if (SPL != 64) {
-      // Blocks of 4608: chunks 256..287.  Chunk 256 + l runs on lane l < 32 (the upper lanes shadow them and
-      // contribute +0.0); the balanced tree over the 512-leaf padded chunk index is then
-      // node(0..255) + node(256..511), and node(256..511) = node(256..287) + zeros = the lane tree of the tail.
+      // Blocks of 4608: the last 512 samples, 16 per lane on lanes 0..31 (the upper lanes shadow them and contribute
+      // +0.0), a chain of their own per lag, reduced the same way and added to the main part's sums
       p1_set(64 * 64 + 16 * (lane & 31));
       fetch(-8, std::false_type{});
       convert(HP, std::false_type{});
       halo12();
       fetch(0, std::true_type{});
-      chunk(std::false_type{}, 0);
+      chunk(std::false_type{}, std::true_type{}, 0);
 #pragma unroll
-      for (int k = 0; k < NLAG; ++k) R[k] = R[k] + wave_tree_sum_dpp(lane < 32 ? acc[k] : 0.0);
+      for (int k = 0; k < NLAG; ++k) acc[k] = lane < 32 ? acc[k] : 0.0;
+      double Rt[kLaneOrderSlots<NLAG>];
+      lane_order_reduce<NLAG>(acc, Rt);
+#pragma unroll
+      for (int q = 0; q < kLaneOrderSlots<NLAG>; ++q) Rq[q] = Rq[q] + Rt[q];
     }
   });
   // is_constant (arrayutils.rs:382): all samples of the role equal <=> max == min
@@ -1102,12 +1172,26 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
   role_min = (int)(wave_min_dpp((uint32_t)vmin ^ 0x80000000u) ^ 0x80000000u);
   // max |s| (find_max_abs, arrayutils.rs:509) from the running max / min
   my_maxabs = (uint32_t)max(role_max, -role_min) | (role_min == INT32_MIN ? 0x80000000u : 0u);
-  if (a.autocorr && lane < 33) {
-    double rv = 0.0;
+  // where this lane's slots go: lag 4 q + lag0 (rows' last lanes only)
+  const int lag0 = ((lane >> 3) & 2) + (lane >> 5);
+  const bool owner = (lane & 15) == 15;
+  if (a.autocorr) {
+    if (from_in) {
+      if (lane < 33) {
+        double rv = 0.0;
 #pragma unroll
-    for (int k = 0; k < NLAG; ++k)
-      if (k == lane && k <= P) rv = R[k];
-    a.autocorr[(size_t)sf * 33 + lane] = rv;
+        for (int k = 0; k < NLAG; ++k)
+          if (k == lane && k <= P) rv = R[k];
+        a.autocorr[(size_t)sf * 33 + lane] = rv;
+      }
+    } else {
+      if (lane < 33 && lane > P) a.autocorr[(size_t)sf * 33 + lane] = 0.0;
+      if (owner) {
+#pragma unroll
+        for (int q = 0; q < kLaneOrderSlots<NLAG>; ++q)
+          if (4 * q + lag0 <= P) a.autocorr[(size_t)sf * 33 + 4 * q + lag0] = Rq[q];
+      }
+    }
   }
   __builtin_amdgcn_sched_barrier(0);
   if (a.stamps && lane == 0) a.stamps[(size_t)sf * 8 + 2] = (unsigned long long)clock64();
@@ -1130,11 +1214,17 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
     uint32_t* const xm = reinterpret_cast<uint32_t*>(kXqInWindow ? reinterpret_cast<int32_t*>(xr + 4 * XR) : xq + 64);
     const double* const xr_keep = xr;
     const bool certify = kCertSupported && a.certify != 0u && a.acorr_in == nullptr;
-    if (lane == 0) {
+    if (from_in) {
+      if (lane == 0) {
 #pragma unroll
-      for (int k = 0; k < NLAG; ++k) xr[wave * XR + k] = R[k];
-      if (kCertSupported) xm[wave] = my_maxabs;
+        for (int k = 0; k < NLAG; ++k) xr[wave * XR + k] = R[k];
+      }
+    } else if (owner) {
+#pragma unroll
+      for (int q = 0; q < kLaneOrderSlots<NLAG>; ++q)
+        if (4 * q + lag0 < NLAG) xr[wave * XR + 4 * q + lag0] = Rq[q];
     }
+    if (kCertSupported && lane == 0) xm[wave] = my_maxabs;
     __syncthreads();
     // (always wave 0, measured: wave 1 instead +2 %, wave 3 +4 %, rotating with the workgroup index -- blk & 1,
     // blk & 3, (blk + (blk >> 8)) & 3, a hash -- +0.6 to +4 %: the three workgroups of a CU do not stack their

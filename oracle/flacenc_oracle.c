@@ -155,6 +155,49 @@ int orc_default_order_is_certified(size_t n, size_t lpc_order) {
   return (n == 4096 || n == 4608) && lpc_order >= 1 && lpc_order <= 12;
 }
 
+/* The fused kernel's own summation order on blocks of 4096 / 4608 samples (flacenc_rs_amd/csrc/qlpc_wave_kernel_impl.h,
+ * lane_order_reduce; NOT reference code): lane l = samples [64 l, 64 l + 64) is one fma chain per lag (started with the
+ * literal +0.0; terms below t = order - 1 are fma(0, ., acc) = acc), the 64 lane sums v[l] meet as
+ *   w[i] = (v[i] + v[i + 32]) + (v[i + 16] + v[i + 48]),  i = 0 .. 15,
+ *   R = (((w15 + w14) + (w13 + w12)) + ((w11 + w10) + (w9 + w8))) + (((w7 + w6) + (w5 + w4)) + ((w3 + w2) + (w1 + w0))),
+ * and a 4608-sample block adds the same tree over its last 512 samples, 16 per lane on lanes 0..31 (+0.0 above). */
+static double orc_lane_tree(const double* v) {
+  double w[16];
+  for (int i = 0; i < 16; ++i) w[i] = (v[i] + v[i + 32]) + (v[i + 16] + v[i + 48]);
+  for (int d = 1; d < 16; d <<= 1)
+    for (int i = 15; i >= d; i -= 2 * d) w[i] = w[i] + w[i - d];
+  return w[15];
+}
+
+void orc_auto_correlation_lane_order_f64(size_t order, const float* signal, size_t n, double* dest) {
+  for (size_t tau = 0; tau < order; ++tau) dest[tau] = 0.0;
+  if (order == 0 || (n != 4096 && n != 4608)) return;
+  size_t P = order - 1;
+  for (size_t tau = 0; tau < order; ++tau) {
+    double v[64];
+    for (size_t l = 0; l < 64; ++l) {
+      double acc = 0.0;
+      for (size_t t = 64 * l; t < 64 * l + 64; ++t) {
+        double cur = t >= P ? (double)signal[t] : 0.0;
+        double lagged = t >= tau ? (double)signal[t - tau] : 0.0;
+        acc = fma(cur, lagged, acc);
+      }
+      v[l] = acc;
+    }
+    double r = orc_lane_tree(v);
+    if (n == 4608) {
+      for (size_t l = 0; l < 64; ++l) {
+        double acc = 0.0;
+        if (l < 32)
+          for (size_t t = 4096 + 16 * l; t < 4096 + 16 * l + 16; ++t) acc = fma((double)signal[t], (double)signal[t - tau], acc);
+        v[l] = acc;
+      }
+      r = r + orc_lane_tree(v);
+    }
+    dest[tau] = r;
+  }
+}
+
 void orc_auto_correlation_canonical_f64(size_t order, const float* signal, size_t n,
                                         double* dest) {
   for (size_t tau = 0; tau < order; ++tau) dest[tau] = 0.0;
@@ -358,7 +401,7 @@ int orc_quant_certified(const double* a, const double* fwd, size_t P, double r0,
   }
   double m = (double)max_abs_s;
   double S = r0 + (0.5 * (double)P) * (m * m);
-  double eps = ((double)(n + 32) * 0x1p-53) * S;
+  double eps = ((double)(n + 96) * 0x1p-53) * S;
   double eps_a = eps * (1.0 + a1);
   /* tier 1, compared multiplied through by |f0| (the kernel's form: no division on the common path) */
   double amax = 0.0;
@@ -517,10 +560,12 @@ int orc_lpc_from_autocorr(const int32_t* signal, size_t n, const orc_qlpc_config
   float* xw = orc_tls.xw;
   orc_fill_windowed_signal(signal, window, n, xw);
   double corr[ORC_MAX_LPC_ORDER + 1];
-  if (cfg->acorr_order == ORC_ACORR_CANONICAL && orc_default_order_is_certified(n, lpc_order)) {
+  if ((cfg->acorr_order == ORC_ACORR_CANONICAL || cfg->acorr_order == ORC_ACORR_CERTIFIED_GENERIC) &&
+      orc_default_order_is_certified(n, lpc_order)) {
     /* the unflagged product on these shapes: chunk-tree sums where their quantised parameters are certified to be the
      * reference's, the reference's own chains where not */
-    orc_auto_correlation_canonical_f64(lpc_order + 1, xw, n, corr);
+    if (cfg->acorr_order == ORC_ACORR_CERTIFIED_GENERIC) orc_auto_correlation_canonical_f64(lpc_order + 1, xw, n, corr);
+    else orc_auto_correlation_lane_order_f64(lpc_order + 1, xw, n, corr);
     int st = ORC_STATUS_OK;
     for (size_t i = 0; i <= lpc_order; ++i)
       if (isnan(corr[i]) || isinf(corr[i])) st = ORC_STATUS_NONFINITE;
@@ -553,8 +598,11 @@ int orc_lpc_from_autocorr(const int32_t* signal, size_t n, const orc_qlpc_config
     orc_cert_stats[2] += 1;
     for (size_t i = 0; i < lpc_order; ++i) coefs_out[i] = 0.0;
     orc_auto_correlation_f64(lpc_order + 1, xw, n, corr);
-  } else if ((cfg->acorr_order == ORC_ACORR_CANONICAL || cfg->acorr_order == ORC_ACORR_CHUNK_TREE) &&
-             !orc_default_order_is_stable(n, lpc_order))
+  } else if (cfg->acorr_order == ORC_ACORR_CHUNK_TREE && orc_default_order_is_certified(n, lpc_order))
+    orc_auto_correlation_lane_order_f64(lpc_order + 1, xw, n, corr); /* the fused kernel's order, uncertified */
+  else if (cfg->acorr_order == ORC_ACORR_GENERIC_TREE ||
+           ((cfg->acorr_order == ORC_ACORR_CANONICAL || cfg->acorr_order == ORC_ACORR_CHUNK_TREE) &&
+            !orc_default_order_is_stable(n, lpc_order)))
     orc_auto_correlation_canonical_f64(lpc_order + 1, xw, n, corr);
   else if (cfg->acorr_order == ORC_ACORR_NIGHTLY)
     orc_auto_correlation_nightly_f64(lpc_order + 1, xw, n, corr, 0);

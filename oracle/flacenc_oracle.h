@@ -50,9 +50,15 @@ extern "C" {
  * acorr_order carry config::Qlpc::mae_optimization_steps (src/config.rs:285; IRLS, src/lpc.rs:814-850).
  * Experimental in the reference, solver from nalgebra: parity unpinned (see flacenc_oracle.c). */
 #define ORC_ACORR_DIRECT_MSE 3
-/* the chunk tree as it is, without the certificate of orc_default_order_is_certified() (the product's
- * FLACENC_HIP_FLAG_CANONICAL_SUM_ORDER) */
+/* the kernels' own order as it is, without the certificate of orc_default_order_is_certified() (the product's
+ * FLACENC_HIP_FLAG_CANONICAL_SUM_ORDER): the fused kernel's lane order on its shapes, the chunk tree elsewhere */
 #define ORC_ACORR_CHUNK_TREE 4
+/* the 16-sample chunk tree on every shape (what the generic kernel sums when it serves a fused-kernel shape) */
+#define ORC_ACORR_GENERIC_TREE 5
+/* ORC_ACORR_CANONICAL as the GENERIC kernel computes it when it serves a fused-kernel shape (unaligned rows,
+ * FLACENC_HIP_FLAG_GENERIC_KERNEL): the same certificate on the chunk tree's sums -- the same integers (the reference's),
+ * R[] and the unquantised coefficients in that kernel's own order */
+#define ORC_ACORR_CERTIFIED_GENERIC 6
 
 /* find_sum_abs_f32 summation orders (src/arrayutils.rs:496-506) */
 #define ORC_SUMABS_STABLE 0    /* stable build: one sequential f32 chain */
@@ -141,6 +147,7 @@ void orc_fill_windowed_signal(const int32_t* signal, const float* window, size_t
 void orc_auto_correlation_f64(size_t order, const float* signal, size_t n, double* dest);
 void orc_auto_correlation_f32(size_t order, const float* signal, size_t n, float* dest);
 void orc_auto_correlation_canonical_f64(size_t order, const float* signal, size_t n, double* dest);
+void orc_auto_correlation_lane_order_f64(size_t order, const float* signal, size_t n, double* dest);
 int orc_default_order_is_stable(size_t n, size_t lpc_order);
 int orc_default_order_is_certified(size_t n, size_t lpc_order);
 extern unsigned long orc_cert_stats[3];

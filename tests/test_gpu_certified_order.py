@@ -92,8 +92,9 @@ CORPORA = {
 }
 
 
-def certified_exact(handle, x, bps, order, flags=0, **kw):
+def certified_exact(handle, x, bps, order, flags=0, rule=None, **kw):
     """GPU (flags = 0) == oracle's certified rule bit for bit, == oracle's reference order on every integer output."""
+    rule = orc.ACORR_CANONICAL if rule is None else rule
     import torch
     x = np.ascontiguousarray(x, np.int32)
     stats = torch.zeros(3, dtype=torch.int32, device="cuda")
@@ -104,7 +105,7 @@ def certified_exact(handle, x, bps, order, flags=0, **kw):
     finally:
         handle.debug_set_cert_stats(0)
     orc.cert_stats(reset=True)
-    cp, cres, cR, cA = orc.qlpc_batch(x, bps, ocfg(order, orc.ACORR_CANONICAL, **kw), nthreads=1)
+    cp, cres, cR, cA = orc.qlpc_batch(x, bps, ocfg(order, rule, **kw), nthreads=1)
     want_stats = orc.cert_stats()
     rp, rres, rR, rA = orc.qlpc_batch(x, bps, ocfg(order, orc.ACORR_REFERENCE, **kw))
     # the rule, floating point included
@@ -162,7 +163,9 @@ def test_generic_kernel_and_unaligned_rows_follow_the_same_rule(handle):
     kernel cannot take (a stride that is not a multiple of four samples) give the same bits."""
     import torch
     x = np.concatenate([near_pure_sines(10, 4096, seed0=31), noisy_sines(6, 4096), real_audio(4096, step=2048)])
-    got, want = certified_exact(handle, x, 16, 10, flags=_capi.FLAG_GENERIC_KERNEL)
+    # (R[] and the unquantised coefficients are those of the kernel that ran -- the generic kernel sums the 16-sample chunk
+    # tree, the fused kernel its lane order -- the integers are the reference's either way)
+    got, want = certified_exact(handle, x, 16, 10, flags=_capi.FLAG_GENERIC_KERNEL, rule=orc.ACORR_CERTIFIED_GENERIC)
     ns, n = x.shape
     stride = n + 3
     buf = torch.zeros(ns * stride + 1, dtype=torch.int32, device="cuda")
@@ -175,7 +178,7 @@ def test_generic_kernel_and_unaligned_rows_follow_the_same_rule(handle):
                              sync=True)
     torch.cuda.synchronize()
     gp = np.frombuffer(params.cpu().numpy().tobytes(), dtype=_capi.PARAMS_DTYPE)
-    cp, cres, _, _ = orc.qlpc_batch(x, 16, ocfg(10, orc.ACORR_CANONICAL))
+    cp, cres, _, _ = orc.qlpc_batch(x, 16, ocfg(10, orc.ACORR_CERTIFIED_GENERIC))
     rp, rres, _, _ = orc.qlpc_batch(x, 16, ocfg(10, orc.ACORR_REFERENCE))
     records_equal(gp, cp, "unaligned rows")
     records_equal(gp, rp, "unaligned rows, reference order")

@@ -307,7 +307,6 @@ uint32_t sum_order_mode(uint32_t flags) {
 // fused bit writer -- take the reference's R[] from acorr_reference_kernel through the split scratch.
 void set_certify(flacenc_hip_handle* h, flacenc_hip::QlpcKernelArgs& a, uint32_t flags) {
   a.certify = (flags & FLACENC_HIP_FLAG_CANONICAL_SUM_ORDER) ? 0u : 1u;
-  a.acorr_fallback = nullptr;
   a.cert_stats = h->cert_stats;
 }
 bool certify_needs_scratch(const flacenc_hip::QlpcKernelArgs& a) {

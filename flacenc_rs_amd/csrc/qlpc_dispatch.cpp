@@ -224,41 +224,19 @@ hipError_t launch_qlpc(const QlpcKernelArgs& a, const QlpcLaunchPlan& plan, hipS
   // the stable build's bytes by default (the oracle's orc_default_order_is_stable states the same rule)
   // (a function of the shape alone: unaligned rows or FLACENC_HIP_FLAG_GENERIC_KERNEL change the kernels, not the sums)
   // The unflagged order on blocks of 4096 / 4608 samples at orders up to 12 (the oracle's orc_default_order_is_certified):
-  // the chunk tree's sums where they certify the quantised parameters against the reference's chains, those chains where
-  // not (QlpcKernelArgs::certify).  The fused kernel does both itself; the generic kernel (unaligned rows,
-  // FLACENC_HIP_FLAG_GENERIC_KERNEL) takes the chains from acorr_reference_kernel -- same outputs, floating point
-  // included -- and the fused bit writer, which returns bytes alone, is simply given the reference's R[].
+  // the fused kernel keeps its own sums where they certify the quantised parameters against the reference's chains and
+  // runs those chains itself where not (QlpcKernelArgs::certify).  Launches of these shapes that the fused kernel cannot
+  // take (unaligned rows, FLACENC_HIP_FLAG_GENERIC_KERNEL) or that cannot certify inside it (the fused bit writer, which
+  // returns bytes alone) are simply given the reference's R[] from acorr_reference_kernel: the same integers -- the
+  // reference's -- with R[] and the unquantised coefficients in the reference's own order.
   if (a.certify != 0u) {
     const bool shape = cert_shape(a) && a.reference_order == 0u && !a.direct_mse && a.fixed_mode == 0 && a.lpc_stage == 0 &&
                        a.acorr_in == nullptr && !a.only_marked;
-    if (!shape) {
+    const bool wave = shape && wave_kernel_eligible(a);
+    if (!shape || !wave || a.pack_out != nullptr) {
       QlpcKernelArgs b = a;
       b.certify = 0;
-      return launch_qlpc(b, plan, stream);
-    }
-    const bool wave = wave_kernel_eligible(a);
-    if ((!wave && a.acorr_fallback == nullptr) || (wave && a.pack_out != nullptr)) {
-      if (a.split_scratch == nullptr) return hipErrorInvalidValue;
-      double* racc = reinterpret_cast<double*>(a.split_scratch);
-      AcorrRefArgs r{};
-      r.samples = a.samples;
-      r.stride = a.stride;
-      r.block_size = a.block_size;
-      r.n_subframes = a.n_subframes;
-      r.stereo = a.stereo;
-      r.window = a.window;
-      r.lpc_order = a.lpc_order;
-      r.nightly = 0u;
-      r.out = racc;
-      hipError_t err = launch_acorr_reference(r, stream);
-      if (err != hipSuccess) return err;
-      QlpcKernelArgs b = a;
-      if (wave) {  // the fused bit writer
-        b.certify = 0;
-        b.acorr_in = racc;
-      } else {
-        b.acorr_fallback = racc;
-      }
+      if (shape) b.reference_order = 1u;  // the stable build's order, by the two-pass pipeline below
       return launch_qlpc(b, plan, stream);
     }
   }

@@ -39,11 +39,10 @@ struct QlpcKernelArgs {
   const double* acorr_in;     // device, [n][33]: precomputed R[], skips phase 1 (wave kernel)
   // The unflagged order on blocks of 4096 / 4608 samples at orders up to 12 (set by launch_qlpc): the chunk tree's R[]
   // is kept where it CERTIFIES the quantised parameters against the reference's chains (levinson_quantize<.., CERT>) and
-  // the subframe is redone from those chains where it does not -- by the fused kernel itself (reference_chains_from_lds),
-  // by the generic kernel from `acorr_fallback` (R[] of acorr_reference_kernel, [n][33]).  cert_stats (nullable, test /
-  // bench hook): [0] subframes analysed, [1] certificates that needed the rows of T^-1, [2] subframes redone.
+  // the subframe is redone from those chains where it does not -- by the fused kernel itself (reference_chains_from_lds);
+  // launches of these shapes on other kernels take the reference's order outright.  cert_stats (nullable, test / bench
+  // hook): [0] subframes analysed, [1] certificates that needed the rows of T^-1, [2] subframes redone.
   uint32_t certify = 0;
-  const double* acorr_fallback = nullptr;
   uint32_t* cert_stats = nullptr;
   // ... and, with the ApproxEnt order selector of fixed_lpc, every estimator partition's sum of |e| comes
   // from sumabs_reference_kernel (find_sum_abs_f32's sequential f32 chain, arrayutils.rs:496-506) instead of

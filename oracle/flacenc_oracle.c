@@ -560,12 +560,10 @@ int orc_lpc_from_autocorr(const int32_t* signal, size_t n, const orc_qlpc_config
   float* xw = orc_tls.xw;
   orc_fill_windowed_signal(signal, window, n, xw);
   double corr[ORC_MAX_LPC_ORDER + 1];
-  if ((cfg->acorr_order == ORC_ACORR_CANONICAL || cfg->acorr_order == ORC_ACORR_CERTIFIED_GENERIC) &&
-      orc_default_order_is_certified(n, lpc_order)) {
+  if (cfg->acorr_order == ORC_ACORR_CANONICAL && orc_default_order_is_certified(n, lpc_order)) {
     /* the unflagged product on these shapes: chunk-tree sums where their quantised parameters are certified to be the
      * reference's, the reference's own chains where not */
-    if (cfg->acorr_order == ORC_ACORR_CERTIFIED_GENERIC) orc_auto_correlation_canonical_f64(lpc_order + 1, xw, n, corr);
-    else orc_auto_correlation_lane_order_f64(lpc_order + 1, xw, n, corr);
+    orc_auto_correlation_lane_order_f64(lpc_order + 1, xw, n, corr);
     int st = ORC_STATUS_OK;
     for (size_t i = 0; i <= lpc_order; ++i)
       if (isnan(corr[i]) || isinf(corr[i])) st = ORC_STATUS_NONFINITE;

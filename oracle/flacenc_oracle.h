@@ -53,12 +53,8 @@ extern "C" {
 /* the kernels' own order as it is, without the certificate of orc_default_order_is_certified() (the product's
  * FLACENC_HIP_FLAG_CANONICAL_SUM_ORDER): the fused kernel's lane order on its shapes, the chunk tree elsewhere */
 #define ORC_ACORR_CHUNK_TREE 4
-/* the 16-sample chunk tree on every shape (what the generic kernel sums when it serves a fused-kernel shape) */
+/* the 16-sample chunk tree on every shape */
 #define ORC_ACORR_GENERIC_TREE 5
-/* ORC_ACORR_CANONICAL as the GENERIC kernel computes it when it serves a fused-kernel shape (unaligned rows,
- * FLACENC_HIP_FLAG_GENERIC_KERNEL): the same certificate on the chunk tree's sums -- the same integers (the reference's),
- * R[] and the unquantised coefficients in that kernel's own order */
-#define ORC_ACORR_CERTIFIED_GENERIC 6
 
 /* find_sum_abs_f32 summation orders (src/arrayutils.rs:496-506) */
 #define ORC_SUMABS_STABLE 0    /* stable build: one sequential f32 chain */

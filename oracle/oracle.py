@@ -20,7 +20,6 @@ ACORR_CANONICAL = 1
 ACORR_NIGHTLY = 2
 ACORR_CHUNK_TREE = 4  # the chunk tree without the certificate (FLACENC_HIP_FLAG_CANONICAL_SUM_ORDER)
 ACORR_GENERIC_TREE = 5  # the 16-sample chunk tree on every shape
-ACORR_CERTIFIED_GENERIC = 6  # the certified rule on the chunk tree's sums (the generic kernel on a fused-kernel shape)
 ACORR_DIRECT_MSE = 3  # config::Qlpc::use_direct_mse; mae_optimization_steps in bits 8.. (experimental, X1)
 SUMABS_STABLE = 0
 SUMABS_NIGHTLY = 1

@@ -7,9 +7,9 @@ reference's sequential chains (src/lpc.rs:533-548) and recompute the subframe fr
     the oracle's ACORR_REFERENCE mode on 100 % of every corpus, the ill-conditioned ones included (near-pure sines, where
     the bare chunk tree is measurably different; DC + impulse; full-scale squares; the reference's real-audio fixtures);
   * everything, floating point included, equals the oracle's statement of the same rule (ACORR_CANONICAL on these shapes:
-    orc_default_order_is_certified) bit for bit, through the fused kernel AND through the generic kernel (unaligned rows,
-    FLACENC_HIP_FLAG_GENERIC_KERNEL), and the device's counters (subframes analysed / certificates that needed the rows of
-    T^-1 / subframes recomputed) equal the oracle's;
+    orc_default_order_is_certified) bit for bit, and the device's counters (subframes analysed / certificates that needed
+    the rows of T^-1 / subframes recomputed) equal the oracle's; launches of these shapes on other kernels (unaligned rows,
+    FLACENC_HIP_FLAG_GENERIC_KERNEL) equal the oracle's ACORR_REFERENCE mode bit for bit;
   * FLACENC_HIP_FLAG_CANONICAL_SUM_ORDER gives the bare chunk tree (the oracle's ACORR_CHUNK_TREE).
 """
 import numpy as np
@@ -92,9 +92,9 @@ CORPORA = {
 }
 
 
-def certified_exact(handle, x, bps, order, flags=0, rule=None, **kw):
+def certified_exact(handle, x, bps, order, flags=0, **kw):
     """GPU (flags = 0) == oracle's certified rule bit for bit, == oracle's reference order on every integer output."""
-    rule = orc.ACORR_CANONICAL if rule is None else rule
+    rule = orc.ACORR_CANONICAL
     import torch
     x = np.ascontiguousarray(x, np.int32)
     stats = torch.zeros(3, dtype=torch.int32, device="cuda")
@@ -158,14 +158,17 @@ def test_the_corpus_separates_the_orders(handle):
     assert got == want and want[2] > 0
 
 
-def test_generic_kernel_and_unaligned_rows_follow_the_same_rule(handle):
-    """The certified rule is a function of the shape, not of the kernel: FLACENC_HIP_FLAG_GENERIC_KERNEL and rows the fused
-    kernel cannot take (a stride that is not a multiple of four samples) give the same bits."""
+def test_other_kernels_on_these_shapes_take_the_references_order(handle):
+    """The default on these shapes is "the reference's integers": launches the fused kernel cannot take --
+    FLACENC_HIP_FLAG_GENERIC_KERNEL, rows whose stride is not a multiple of four samples -- are given the reference's own
+    chains (acorr_reference_kernel) outright: everything equals the oracle's ACORR_REFERENCE mode, floating point included."""
     import torch
     x = np.concatenate([near_pure_sines(10, 4096, seed0=31), noisy_sines(6, 4096), real_audio(4096, step=2048)])
-    # (R[] and the unquantised coefficients are those of the kernel that ran -- the generic kernel sums the 16-sample chunk
-    # tree, the fused kernel its lane order -- the integers are the reference's either way)
-    got, want = certified_exact(handle, x, 16, 10, flags=_capi.FLAG_GENERIC_KERNEL, rule=orc.ACORR_CERTIFIED_GENERIC)
+    gp, gres, gR, gA = handle.qlpc_batch(x, 16, gcfg(10, flags=_capi.FLAG_GENERIC_KERNEL), want_fp=True)
+    rp, rres, rR, rA = orc.qlpc_batch(x, 16, ocfg(10, orc.ACORR_REFERENCE))
+    assert np.array_equal(gR.view(np.uint64), rR.view(np.uint64)) and np.array_equal(gA.view(np.uint64), rA.view(np.uint64))
+    records_equal(gp, rp, "generic kernel")
+    assert np.array_equal(gres, rres)
     ns, n = x.shape
     stride = n + 3
     buf = torch.zeros(ns * stride + 1, dtype=torch.int32, device="cuda")
@@ -178,9 +181,6 @@ def test_generic_kernel_and_unaligned_rows_follow_the_same_rule(handle):
                              sync=True)
     torch.cuda.synchronize()
     gp = np.frombuffer(params.cpu().numpy().tobytes(), dtype=_capi.PARAMS_DTYPE)
-    cp, cres, _, _ = orc.qlpc_batch(x, 16, ocfg(10, orc.ACORR_CERTIFIED_GENERIC))
-    rp, rres, _, _ = orc.qlpc_batch(x, 16, ocfg(10, orc.ACORR_REFERENCE))
-    records_equal(gp, cp, "unaligned rows")
     records_equal(gp, rp, "unaligned rows, reference order")
     assert np.array_equal(resid.cpu().numpy(), rres)
 

@@ -457,6 +457,10 @@ def run(args, world):
         out["secondary"] = secondary(torch, _capi, handle, args, dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(host, bps, args, n)
+        # the order certificate at work (outside the timed region): the device's counters over one more launch of the
+        # whole batch, and a sample of the frames against the oracle in the REFERENCE's summation order
+        ident = reference_identity(torch, _capi, handle, args, host, x, results2[last_b], residual, cfg, n, bps, F)
+        out["config"].update(ident)
     if rank == 0:
         print(json.dumps(out), flush=True)
     handle.close()
@@ -908,6 +912,43 @@ def usable_cores():
     return cores
 
 
+def reference_identity(torch, _capi, handle, args, host, x, results, residual, cfg, n, bps, F):
+    """How the default mode relates to the reference's stable build (src/lpc.rs:533-548), measured after the timed region:
+    `reference_identical_fraction` = frames of a sample whose decision record and two residual rows equal the oracle's in
+    ACORR_REFERENCE order (1.0 by construction where the order is certified); `certificate` = the kernel's own counters
+    over one launch of the whole batch.  Part of the cpu_baseline leg: the oracle is the checker here, never the product."""
+    import numpy as np
+
+    from oracle import oracle as orc
+
+    stats = torch.zeros(3, dtype=torch.int32, device=x.device)
+    handle.debug_set_cert_stats(stats.data_ptr())
+    handle.encode_stereo_frames_device(cfg, x.data_ptr(), F, n, n, bps, results.data_ptr(), residual.data_ptr(), n,
+                                       stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    handle.debug_set_cert_stats(0)
+    analysed, tier2, redone = (int(v) for v in stats.cpu().tolist())
+    K = min(F, 384)
+    g = np.frombuffer(results[:K].cpu().numpy().tobytes(), dtype=_capi.FRAME_RESULT_DTYPE)
+    grows = residual[:2 * K].cpu().numpy().reshape(K, 2, n)
+    flags = (_capi.FLAG_REFERENCE_SUM_ORDER if args.reference_order else 0)
+    ocfg = orc.make_config(lpc_order=args.lpc_order, acorr=orc.ACORR_REFERENCE, rice_finest_only=args.finest_rice_order)
+    ofc = orc.make_frame_config(ocfg, use_fixed=args.use_fixed)
+    want, wrows = orc.encode_stereo_frames_cfg(host[:K], bps, ofc)
+    same = np.array([bool(g[f] == want[f]) and np.array_equal(grows[f], wrows[f]) for f in range(K)])
+    return {
+        "reference_identical_fraction": round(float(same.mean()), 6),
+        "reference_identity": {
+            "what": "decision record (752 B) + the two chosen residual rows of each sampled frame against the oracle in the "
+                    "stable build's summation order (ACORR_REFERENCE)",
+            "frames_compared": int(K), "frames_identical": int(same.sum()),
+            "certificate": {"subframes_analysed": analysed, "needed_rows_of_inverse": tier2, "recomputed_from_reference_chains": redone,
+                            "recomputed_fraction": round(redone / analysed, 6) if analysed else None,
+                            "flags": flags},
+        },
+    }
+
+
 def cpu_baseline(host, bps, args, n):
     """The oracle (a port of the reference's path in reference summation order) timed on this
     box's host cores over a bounded sample of the same frames."""
@@ -928,6 +969,8 @@ def cpu_baseline(host, bps, args, n):
         "unit": "Msamples/s",
         "cores": cores,
         "kind": "port",
+        "build": "oracle/Makefile: cc -O3 -std=gnu99 -march=x86-64-v3 -ffp-contract=off -fno-fast-math (explicit fma() where the "
+                 "reference calls mul_add)",
         "sample": f"{sample_frames} of the same stereo frames x {repeats} passes, {cores} threads "
                   "(frame-parallel pool like src/par.rs), 4 analyses per frame",
     }

@@ -711,6 +711,41 @@ def test_solve_mut_sym():
     np.testing.assert_allclose(x, np.linalg.solve(G, R[1:]), rtol=1e-6)  # and it is the solution LAPACK finds
 
 
+def test_cholesky_solver_against_third_parties():
+    """X1's solver is nalgebra 0.32's Cholesky, restated from its published algorithm (the crate is not under
+    /root/reference): no reference-produced vector can pin it.  This bounds it by third parties instead: (a) LAPACK
+    (numpy's dpotrf / dpotrs route through np.linalg.cholesky / solve_triangular-free algebra) on well- and
+    ill-conditioned Gram matrices of every order 1..32 to 1e-12 of the conditioning-scaled solution, (b) exact small-integer
+    systems whose factors and solutions are integers or dyadic rationals -- every operation of either algorithm is exact
+    there, so the restatement must return them to the last bit."""
+    rng = np.random.default_rng(20251004)
+    for order in range(1, 33):
+        for trial in range(4):
+            n = 256 + 64 * trial
+            x = util.quantize(util.sine(n + order, 23.0 + order + 3 * trial, 0.5) + util.noise(order * 7 + trial, n + order, 0.2 / (1 + 3 * trial)),
+                              16).astype(np.float64)
+            X = np.stack([x[order - 1 - i:order - 1 - i + n] for i in range(order)])  # lagged vectors
+            G = X @ X.T
+            b = X @ x[order:order + n]
+            ok, got = orc.cholesky_solve(G, b)
+            assert ok
+            L = np.linalg.cholesky(G)  # LAPACK dpotrf
+            want = np.linalg.solve(L.T, np.linalg.solve(L, b))  # the two triangular solves (dtrtrs)
+            cond = np.linalg.cond(G)
+            tol = 1e-12 * max(1.0, cond / 1e3)  # forward error of a backward-stable solve ~ cond * 2^-53
+            assert np.max(np.abs(got - want)) <= tol * np.max(np.abs(want)), (order, trial, cond)
+    # exact cases: G = L L^T with small-integer lower-triangular L and power-of-two diagonals, b = G z for integer z
+    for order in (1, 2, 3, 5, 8, 12, 24, 32):
+        for trial in range(6):
+            L = np.tril(rng.integers(-3, 4, (order, order))).astype(np.float64)
+            np.fill_diagonal(L, 2.0 ** rng.integers(0, 3, order))
+            G = L @ L.T
+            z = rng.integers(-5, 6, order).astype(np.float64)
+            ok, got = orc.cholesky_solve(G, G @ z)
+            assert ok
+            assert np.array_equal(got, z), (order, trial)
+
+
 def test_cholesky_rejects_what_nalgebra_rejects():
     """Cholesky::new_internal: a zero or negative pivot -> None -> the caller's regulariser loop (lpc.rs:887-896)"""
     assert orc.cholesky_solve(np.zeros((3, 3)), np.ones(3))[0] is False

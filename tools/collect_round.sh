@@ -12,7 +12,8 @@ python3 tools/bench_configs.py > $O/configs.json 2> $O/configs.txt
 tools/prof_bigblock.sh collect_$TAG/bigblock > $O/bigblock.txt 2>&1
 tools/pmc_insts_bigblock.sh collect_$TAG/bigblock_pmc24 8192 24 > $O/bigblock_pmc_n8192_p24.txt 2>&1
 tools/pmc_insts_bigblock.sh collect_$TAG/bigblock_pmc32 8192 32 > $O/bigblock_pmc_n8192_p32.txt 2>&1
-# per-phase instruction counts of the headline kernel (needs ab/libflacenc_exit{0..3}.so: tools/variant_wave.sh exitK 8 2 -DFLACENC_EXIT_AFTER=K)
+# per-phase instruction counts of the headline kernel (needs ab/libflacenc_exit{0..3}.so from tools/build_exit_variants.sh, run
+# in the build container before this call; phase_insts.sh refuses libraries of other sources)
 bash tools/phase_insts.sh collect_$TAG/phases > $O/phases.txt 2>&1
 python3 tools/make_headline_phases.py $O/phases/summary.txt $TAG > $O/headline_phases.json 2>> $O/phases.txt
 tail -c 1500 $O/bench.json; cat $O/configs.txt; cat $O/bigblock.txt | tail -30

@@ -18,15 +18,16 @@ for line in open(sys.argv[1]):
         cum[m.group(1)] = float(m.group(2))
 order = ["libflacenc_exit0", "libflacenc_exit1", "libflacenc_exit2", "libflacenc_exit3", "libflacenc_hip"]
 names = ["load (HBM -> LDS images, window table)", "window + autocorrelation (9 lags x 64 samples per lane)",
-         "Levinson-Durbin + quantisation (4 subframes on 4 lanes of wave 0)", "residual (compute_error)",
+         "Levinson-Durbin + quantisation + order certificate (4 subframes on 4 lanes of wave 0)", "residual (compute_error)",
          "bit planes + Rice search + encode_frame decision + store of the two chosen rows"]
 # what the formulation cannot do without, per wave (64 samples per lane, order 8, stereo roles averaged):
 floors = [
     (30, "addresses of 8 + 8 16-byte moves per lane"),
-    (576 + 216 + 27 + 162 + 54 + 36,
-     "576 fma (9 lags x 64) + 216 conversions ((64 + 8) x cvt_f32_i32, mul_f32, cvt_f64_f32) + 27 in-lane tree adds + "
-     "162 lane tree (6 levels x 9 lags x 2 DPP moves + add) + 54 mid / side forming (role average) + 36 min / max"),
-    (163, "650 serial instructions on one wave of four"),
+    (576 + 216 + 62 + 54 + 36,
+     "576 fma (9 lags x 64) + 216 conversions ((64 + 8) x cvt_f32_i32, mul_f32, cvt_f64_f32) + 62 for the 64 lane sums "
+     "(round 5: reduce-scatter on v_permlane32/16_swap + four row shifts; one chain per lane, no in-lane tree) + 54 mid / "
+     "side forming (role average) + 36 min / max"),
+    (163 + 33, "650 serial instructions of the recursion + ~130 of the order certificate, on one wave of four"),
     (256 + 64 + 128 + 54, "256 v_dot2_i32_i16 (8 taps x 64 / 2) + 64 packs + 128 shift / subtract + 54 mid / side forming"),
     (128 + 120 + 33 + 21 + 40 + 98 + 70 + 60 + 40,
      "128 sign-magnitude + 120 carry-save + 33 plane adds + 21 plane sums + 40 table entries (4 parameters) + 98 merge "

@@ -1,7 +1,12 @@
 #!/bin/bash
 # Dynamic instruction counts per phase of the headline kernel: diagnostic builds that end the program after
 # phase k (ab/libflacenc_exit<k>.so, -DFLACENC_EXIT_AFTER=k) under rocprofv3 --pmc; differences = per-phase cost.
-R=$PWD; OUT=$R/gpurun_out/$1; mkdir -p $OUT; rm -f $OUT/summary.txt; cd /tmp && export TMPDIR=/tmp
+R=$PWD; OUT=$R/gpurun_out/$1; mkdir -p $OUT; rm -f $OUT/summary.txt
+# the exit libraries must come from the sources of the library they are compared with (tools/build_exit_variants.sh)
+want=$(cd $R && python3 -c "import bench; print(bench.kernel_source_sha())")
+have=$(cat $R/ab/exit_variants.sha 2>/dev/null || echo none)
+if [ "$want" != "$have" ]; then echo "phase_insts.sh: ab/libflacenc_exit*.so are stale ($have, sources are $want): run tools/build_exit_variants.sh" | tee $OUT/summary.txt; exit 1; fi
+cd /tmp && export TMPDIR=/tmp
 for lib in ab/libflacenc_exit0.so ab/libflacenc_exit1.so ab/libflacenc_exit2.so ab/libflacenc_exit3.so flacenc_rs_amd/libflacenc_hip.so; do
   tag=$(basename $lib .so)
   FLACENC_HIP_LIB=$R/$lib rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY --output-format csv -d $OUT/$tag -- python3 $R/tools/launch_headline.py > $OUT/$tag.log 2>&1

@@ -1,3 +1,4 @@
+#!/bin/bash
 R=$PWD; cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r04_dm -- python3 $R/tools/time_direct_mse.py > /dev/null 2>&1
 python3 - $R/gpurun_out/r04_dm <<'PY'

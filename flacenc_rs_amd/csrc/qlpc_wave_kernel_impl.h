@@ -54,7 +54,17 @@ namespace {
 #if defined(FLACENC_STEREO)
 #define FLACENC_BASE_VARIANT (FLACENC_STEREO >= 6 ? FLACENC_STEREO - 3 : FLACENC_STEREO)
 #endif
-#if defined(FLACENC_STEREO) && defined(FLACENC_MAXP) && \
+// Round 5 -- FOUR workgroups per CU (128 registers, window weights from L2 instead of a third LDS image; see
+// window_image below): possible since the lane order keeps one accumulator set per lag where the chunk tree kept three.
+// Same-box A/B, 24576 frames (98304: the deciding order-8 kernel 2.39 -> 2.10 ms): deciding kernels 0.614 -> 0.580
+// (order 8), 0.70 -> 0.664 (10), 0.77 -> 0.74 ms (12) with 50-75 spilled dwords; four-candidate kernels +3.5 / +4 % at
+// orders 8 / 10, -2 % at 12; with the fixed-LPC candidate (170-197 spilled dwords at 128 registers) +1.5 % slower at order
+// 8, -0.7 % at 10, -3 % at 12.  Blocks of 4608 (two 19.8 KB images + the certificate's scratch = 43 KB) stay at three.
+#if defined(FLACENC_STEREO) && defined(FLACENC_MAXP) && (!defined(FLACENC_SPL) || FLACENC_SPL == 64) && \
+    ((FLACENC_BASE_VARIANT == 2) || (FLACENC_BASE_VARIANT == 1 && FLACENC_MAXP <= 10) || \
+     (FLACENC_BASE_VARIANT == 3 && FLACENC_MAXP >= 10))
+#define FLACENC_WAVE_OCC 4
+#elif defined(FLACENC_STEREO) && defined(FLACENC_MAXP) && \
     ((FLACENC_MAXP <= 10 && (FLACENC_BASE_VARIANT == 1 || FLACENC_BASE_VARIANT == 2 || FLACENC_BASE_VARIANT == 3)) || \
      (FLACENC_MAXP == 12 && ((FLACENC_ORDER12_OCC3 >> FLACENC_BASE_VARIANT) & 1)))
 #define FLACENC_WAVE_OCC 3
@@ -62,6 +72,12 @@ namespace {
 #define FLACENC_WAVE_OCC 2
 #endif
 #endif
+// The stereo 4096-sample instances at three workgroups per CU keep the window table as a third LDS image; at FOUR
+// (round 5: 128 registers, possible since the lane order needs one accumulator set where the chunk tree needed three) the
+// 40 KB a workgroup may take hold the two channel images, the exchange area and the certificate's scratch, and the weights
+// come from the L2-resident table, loaded unconditionally (it holds exactly 1.0f inside the flat part) one step ahead.
+constexpr bool kWindowImageBuild = FLACENC_WAVE_OCC < 4;
+constexpr bool window_image(bool stereo, int spl) { return kWindowImageBuild && stereo && spl == 64; }
 constexpr int kWaveN = 4096;        // block size handled by this kernel
 constexpr int kSeg = 68;            // dwords per lane segment: 64 samples + 4 pad (conflict-free b128)
 constexpr int kBufDwords = 65 * kSeg + 8;  // one leading all-zero segment (halo of lane 0) + look-ahead slack
@@ -666,7 +682,8 @@ __device__ __forceinline__ void lane_order_reduce(const double (&v)[N], double (
 // Out of line: it runs for a fraction of a per cent of the frames of noisy material (all of them on near-pure tones),
 // 17 tiles x 64 MFMAs = ~40 k cycles, and must not cost the common path a register.
 constexpr int kCertHist = 64;
-constexpr int cert_tile(bool stereo, int spl) { return (!stereo && spl != 64) ? 32 : 256; }
+// (tiles of 256 samples; 128 where four workgroups share a CU's LDS, 32 for the plain 4608-sample instances)
+constexpr int cert_tile(bool stereo, int spl) { return (!stereo && spl != 64) ? 32 : (FLACENC_WAVE_OCC >= 4 ? 128 : 256); }
 constexpr int cert_scratch_bytes(int tile) { return 4 * (kCertHist + tile + 8) * 4; }
 
 template <int SPL, bool STEREO, int kCertTile>
@@ -856,7 +873,7 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
   // same segment layout and shared by the four waves (3 workgroups x 53 KB fit one CU's LDS).
   // Plain mode keeps four sample images (71 KB) and reads the taper weights from the
   // L2-resident table instead, so that two workgroups still fit a CU.
-  constexpr bool WINDOW_IN_LDS = STEREO && SPL == 64;  // (4608: two images are 40 KB; a third would cost the third workgroup per CU)
+  constexpr bool WINDOW_IN_LDS = window_image(STEREO, SPL);  // (4608: two images are 40 KB; a third would cost the third workgroup per CU)
   constexpr int NIMG = NBUF + (WINDOW_IN_LDS ? 1 : 0);
   // Order 12 at three workgroups per CU: the quantised coefficients wave 0 hands back overlay the R[] rows it was
   // handed (its four lanes have read them, in lockstep, before any of them writes; nobody else reads R[] after
@@ -866,7 +883,7 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
   // overlaying R[] the quantised predictor of the order-12 stereo instances now goes into the window image -- dead once
   // phase 1 is over -- behind the 5.2 KB the certificate's fallback uses of it; instances without a window image have
   // the room for a predictor area of its own.)
-  constexpr bool kXqInWindow = MAXP > 10 && !PACK && STEREO && SPL == 64;
+  constexpr bool kXqInWindow = MAXP > 10 && !PACK && window_image(STEREO, SPL);
   constexpr int kXqWindowOff = 1344;  // floats into the window image
   float* const wlds = reinterpret_cast<float*>(sm + NBUF * kBufDwords);
   // The order certificate (levinson_quantize<.., CERT>) and its fallback (reference_chains_from_lds): everywhere but in
@@ -880,7 +897,7 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
   constexpr bool kCertSupported = !PACK;
 #endif
   constexpr int kCertTileHere = cert_tile(STEREO, SPL);
-  float* const cert_rows = (STEREO && SPL == 64)
+  float* const cert_rows = window_image(STEREO, SPL)
                                ? wlds
                                : reinterpret_cast<float*>(sm + NIMG * kBufDwords) + (4 * (MAXP + 1) * 8 + 256 + 16) / 4;
   const bool has_window = a.window != nullptr;  // nullptr = all ones (rectangle / Tukey(0))
@@ -892,6 +909,7 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
   auto window4_at = [&](int ix, int t) -> float4 {  // ix: LDS index (window in LDS), t: sample number (else)
     if (!has_window) return make_float4(1.0f, 1.0f, 1.0f, 1.0f);
     if (WINDOW_IN_LDS) return *reinterpret_cast<const float4*>(&wlds[ix]);
+    if (FLACENC_WAVE_OCC >= 4) return *reinterpret_cast<const float4*>(wtab + t);  // (exactly 1.0f inside the flat part)
     float4 wv = make_float4(1.0f, 1.0f, 1.0f, 1.0f);  // exactly 1.0f inside the flat part
     if (!(t >= flat_lo && t + 4 <= flat_hi)) wv = *reinterpret_cast<const float4*>(wtab + t);
     return wv;
@@ -2298,9 +2316,9 @@ hipError_t launch_wave4096(const QlpcKernelArgs& a, hipStream_t stream) {
   // images (+ window, 4096-sample stereo only) + exchange: [4][MAXP + 1] f64 (+ [4][16] i32 unless it sits in the window image, see kXqInWindow)
   // (+ the roles' max |s| and, where no window image can lend it, the scratch of the certificate's fallback)
   constexpr bool cert = !PACK;
-  constexpr size_t smem = (size_t)(STEREO ? (SPL == 64 ? 3 : 2) : 4) * WaveGeom<SPL>::Buf * 4 +
-                          ((MAXP > 10 && !PACK && STEREO && SPL == 64) ? 4 * (MAXP + 1) * 8 : 4 * ((MAXP + 1) * 8 + 64)) +
-                          (cert ? 16 : 0) + ((cert && !(STEREO && SPL == 64)) ? cert_scratch_bytes(cert_tile(STEREO, SPL)) : 0);
+  constexpr size_t smem = (size_t)(STEREO ? (window_image(STEREO, SPL) ? 3 : 2) : 4) * WaveGeom<SPL>::Buf * 4 +
+                          ((MAXP > 10 && !PACK && window_image(STEREO, SPL)) ? 4 * (MAXP + 1) * 8 : 4 * ((MAXP + 1) * 8 + 64)) +
+                          (cert ? 16 : 0) + ((cert && !window_image(STEREO, SPL)) ? cert_scratch_bytes(cert_tile(STEREO, SPL)) : 0);
   static DynamicLdsOptIn opt_in;  // per instantiation, per device inside
   if (hipError_t err = opt_in.ensure(reinterpret_cast<const void*>(kern), smem); err != hipSuccess) return err;
   const uint32_t blocks = STEREO ? a.n_subframes / 4u : (a.n_subframes + 3u) / 4u;

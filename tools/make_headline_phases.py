@@ -11,6 +11,8 @@ ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
+# fraction of the HBM roof the same source measured (third argument; bench.py's roofline.frac)
+FRAC = float(sys.argv[3]) if len(sys.argv) > 3 else 0.373
 cum = {}
 for line in open(sys.argv[1]):
     m = re.match(r"(libflacenc_\w+)\s+VALU/wave\s+([\d.]+)", line)
@@ -49,7 +51,7 @@ out = {
     "valu_insts_per_wave": total,
     "valu_floor_insts_per_wave": floor_total,
     "phases": phases,
-    "reading": "the 0.50 target needs at most %d instructions per wave at today's issue efficiency; the floor of this "
-               "formulation is %d" % (int(total * 0.334 / 0.50) if total else 0, floor_total),
+    "reading": "at the measured %.3f of the HBM roof the 0.50 target would need at most %d instructions per wave at today's "
+               "issue efficiency; the floor of this formulation is %d" % (FRAC, int(total * FRAC / 0.50) if total else 0, floor_total),
 }
 print(json.dumps(out, indent=1))

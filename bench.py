@@ -568,6 +568,15 @@ def secondary(torch, _capi, handle, args, dev):
         "what": "FLACENC_HIP_FLAG_REFERENCE_SUM_ORDER: autocorrelation as one sequential chain per lag "
                 "(src/lpc.rs:533-548) by a lane-per-subframe kernel, then the fused kernel without its phase 1; "
                 "coefficients bit-identical to the reference's stable build", "subframe_bits_per_sample": bits_per_sample()})
+    icfg = _capi.make_frame_config(_capi.make_config(lpc_order=args.lpc_order, rice_finest_only=args.finest_rice_order,
+                                                     flags=_capi.FLAG_REFERENCE_SUM_ORDER | _capi.FLAG_INTEGER_PARITY_ONLY),
+                                   use_fixed=False)
+    ms = timed(lambda: handle.encode_stereo_frames_device(icfg, noisy.data_ptr(), F, n, n, bps, results.data_ptr(),
+                                                          residual.data_ptr(), n, stream=stream.cuda_stream))
+    sec["reference_sum_order_integer_parity_only"] = entry(ms, {
+        "what": "FLACENC_HIP_FLAG_REFERENCE_SUM_ORDER | _INTEGER_PARITY_ONLY (what the Rust / C++ drop-in asks for under a "
+                "stable build): the stable build's integers by the order certificate, no second pass on this shape",
+        "subframe_bits_per_sample": bits_per_sample()})
     ncfg = _capi.make_frame_config(_capi.make_config(lpc_order=args.lpc_order, rice_finest_only=args.finest_rice_order,
                                                      flags=_capi.FLAG_NIGHTLY_SUM_ORDER), use_fixed=False)
     ms = timed(lambda: handle.encode_stereo_frames_device(ncfg, noisy.data_ptr(), F, n, n, bps, results.data_ptr(),

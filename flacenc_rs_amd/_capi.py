@@ -350,7 +350,8 @@ FLAG_FUSED_PACK = 8
 FLAG_TWO_STAGE_PACK = 16
 FLAG_REFERENCE_SUM_ORDER = 32
 FLAG_NIGHTLY_SUM_ORDER = 64
-FLAG_CANONICAL_SUM_ORDER = 128  # the chunk tree without the order certificate
+FLAG_CANONICAL_SUM_ORDER = 128  # the kernels' own order without the order certificate
+FLAG_INTEGER_PARITY_ONLY = 256  # with FLAG_REFERENCE_SUM_ORDER: certified shapes keep their own order (integers only)
 
 
 def make_config(lpc_order=10, quant_precision=15, window=("tukey", 0.4), max_rice_parameter=30,

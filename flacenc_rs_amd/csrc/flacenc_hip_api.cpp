@@ -307,11 +307,13 @@ uint32_t sum_order_mode(uint32_t flags) {
 // fused bit writer -- take the reference's R[] from acorr_reference_kernel through the split scratch.
 void set_certify(flacenc_hip_handle* h, flacenc_hip::QlpcKernelArgs& a, uint32_t flags) {
   a.certify = (flags & FLACENC_HIP_FLAG_CANONICAL_SUM_ORDER) ? 0u : 1u;
+  // REFERENCE_SUM_ORDER | INTEGER_PARITY_ONLY: the certified shapes keep their own order (launch_qlpc)
+  a.integer_parity_only = ((flags & FLACENC_HIP_FLAG_INTEGER_PARITY_ONLY) && (flags & FLACENC_HIP_FLAG_REFERENCE_SUM_ORDER)) ? 1u : 0u;
   a.cert_stats = h->cert_stats;
 }
 bool certify_needs_scratch(const flacenc_hip::QlpcKernelArgs& a) {
-  return a.certify != 0u && flacenc_hip::cert_shape(a) && a.reference_order == 0u && !a.direct_mse && a.fixed_mode == 0 &&
-         (!flacenc_hip::wave_kernel_eligible(a) || a.pack_out != nullptr);
+  return a.certify != 0u && flacenc_hip::cert_shape(a) && (a.reference_order == 0u || a.integer_parity_only) &&
+         !a.direct_mse && a.fixed_mode == 0 && (!flacenc_hip::wave_kernel_eligible(a) || a.pack_out != nullptr);
 }
 
 // FLACENC_HIP_FLAG_REFERENCE_SUM_ORDER with the ApproxEnt selector: room for sumabs_reference_kernel's

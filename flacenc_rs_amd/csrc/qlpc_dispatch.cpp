@@ -229,8 +229,12 @@ hipError_t launch_qlpc(const QlpcKernelArgs& a, const QlpcLaunchPlan& plan, hipS
   // take (unaligned rows, FLACENC_HIP_FLAG_GENERIC_KERNEL) or that cannot certify inside it (the fused bit writer, which
   // returns bytes alone) are simply given the reference's R[] from acorr_reference_kernel: the same integers -- the
   // reference's -- with R[] and the unquantised coefficients in the reference's own order.
+  bool certified_fused = false;  // this launch certifies inside the fused kernel: no reference-order pass in front of it
   if (a.certify != 0u) {
-    const bool shape = cert_shape(a) && a.reference_order == 0u && !a.direct_mse && a.fixed_mode == 0 && a.lpc_stage == 0 &&
+    // (FLACENC_HIP_FLAG_INTEGER_PARITY_ONLY: the stable order is asked for, but only for the integers -- the certificate
+    // gives those; reference_order stays set for the fixed-LPC selector's sums)
+    const bool order_ok = a.reference_order == 0u || (a.reference_order == 1u && a.integer_parity_only != 0u);
+    const bool shape = cert_shape(a) && order_ok && !a.direct_mse && a.fixed_mode == 0 && a.lpc_stage == 0 &&
                        a.acorr_in == nullptr && !a.only_marked;
     const bool wave = shape && wave_kernel_eligible(a);
     if (!shape || !wave || a.pack_out != nullptr) {
@@ -239,11 +243,12 @@ hipError_t launch_qlpc(const QlpcKernelArgs& a, const QlpcLaunchPlan& plan, hipS
       if (shape) b.reference_order = 1u;  // the stable build's order, by the two-pass pipeline below
       return launch_qlpc(b, plan, stream);
     }
+    certified_fused = true;
   }
   const bool stable_by_default = a.reference_order == 0u && !a.direct_mse &&
                                  (a.block_size == 4096u || a.block_size == 8192u || a.block_size == 16384u) &&
                                  a.lpc_order >= 16u && a.split_scratch != nullptr;
-  if ((a.reference_order || stable_by_default) && a.fixed_mode == 0 && a.lpc_stage == 0 && a.acorr_in == nullptr) {
+  if ((a.reference_order || stable_by_default) && !certified_fused && a.fixed_mode == 0 && a.lpc_stage == 0 && a.acorr_in == nullptr) {
     // Reference summation order: R[] by the lane-per-subframe kernel, then the usual pipeline from
     // Levinson on (below: the fused wave kernel with its phase 1 skipped, the big-block kernels from
     // their second launch, or the generic kernel's three-launch split from its second launch).

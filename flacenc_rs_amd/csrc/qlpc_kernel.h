@@ -43,6 +43,7 @@ struct QlpcKernelArgs {
   // launches of these shapes on other kernels take the reference's order outright.  cert_stats (nullable, test / bench
   // hook): [0] subframes analysed, [1] certificates that needed the rows of T^-1, [2] subframes redone.
   uint32_t certify = 0;
+  uint32_t integer_parity_only = 0;  // FLACENC_HIP_FLAG_INTEGER_PARITY_ONLY with reference_order 1: certified shapes keep their order
   uint32_t* cert_stats = nullptr;
   // ... and, with the ApproxEnt order selector of fixed_lpc, every estimator partition's sum of |e| comes
   // from sumabs_reference_kernel (find_sum_abs_f32's sequential f32 chain, arrayutils.rs:496-506) instead of

@@ -500,7 +500,8 @@ class HipContext {
   void set_sum_order(SumOrder o) { sum_order_ = o; }
   SumOrder sum_order() const { return sum_order_; }
   uint32_t sum_order_flags(size_t lpc_order) const {
-    if (sum_order_ == SumOrder::Stable) return FLACENC_HIP_FLAG_REFERENCE_SUM_ORDER;
+    // (the mirror consumes integers only: certified shapes keep their own order, INTEGER_PARITY_ONLY)
+    if (sum_order_ == SumOrder::Stable) return FLACENC_HIP_FLAG_REFERENCE_SUM_ORDER | FLACENC_HIP_FLAG_INTEGER_PARITY_ONLY;
     if (sum_order_ == SumOrder::SimdNightly && lpc_order <= 15) return FLACENC_HIP_FLAG_NIGHTLY_SUM_ORDER;
     return 0u;
   }

@@ -90,8 +90,9 @@ extern "C" {
 #define FLACENC_HIP_FLAG_TWO_STAGE_PACK 16u
 /* Autocorrelation in the summation order of the reference's stable build: one sequential mul_add chain
  * per lag over t = order .. n-1 (weighted_auto_correlation_nosimd, src/lpc.rs:533-548), computed one
- * subframe per lane by a kernel of its own, instead of the kernels' default order (16-sample chunk
- * chains combined by a balanced tree -- same FMA count, different roundings, documented in DESIGN.md).
+ * subframe per lane by a kernel of its own, instead of the kernels' own orders (a chain per lane or per 16-sample
+ * chunk, combined by a tree -- same FMA count, different roundings; certified against the reference's on the fused
+ * kernel's shapes, see FLACENC_HIP_FLAG_CANONICAL_SUM_ORDER below and DESIGN.md section 2).
  * With this flag R[], the LPC coefficients and therefore every integer output are those of the stable
  * reference build for everything the oracle pins.  Costs one extra pass over the samples.
  * The flag also reaches the path's other order-sensitive sum: with OrderSel::ApproxEnt, fixed_lpc's
@@ -120,6 +121,13 @@ extern "C" {
  * strongly tonal.  This flag switches the certificate off: a valid encoding of the same configuration whose
  * coefficients may differ from the reference's in the last quantisation step on a fraction of a per mille of subframes. */
 #define FLACENC_HIP_FLAG_CANONICAL_SUM_ORDER 128u
+
+/* A modifier of FLACENC_HIP_FLAG_REFERENCE_SUM_ORDER for callers that consume the INTEGER outputs only (a drop-in under
+ * encode_with_fixed_block_size does: QuantizedParameters, residuals, Rice partitions, frame bytes): shapes whose unflagged
+ * order is certified to give the stable build's integers (blocks of 4096 / 4608 samples at orders up to 12) keep it -- no
+ * second pass over the samples there -- and every other shape takes the stable build's chains as the flag alone would.
+ * What is given up is only the bit-equality of the optional floating-point outputs (autocorr, lpc_coefs). */
+#define FLACENC_HIP_FLAG_INTEGER_PARITY_ONLY 256u
 
 /* where the caller's sample / output buffers live */
 #define FLACENC_HIP_MEM_HOST 0

@@ -27,6 +27,11 @@ pub const MEM_HOST: c_int = 0;
 pub const FLAG_ALLOW_ORDER_32: u32 = 1;
 pub const FLAG_REFERENCE_SUM_ORDER: u32 = 32;
 pub const FLAG_NIGHTLY_SUM_ORDER: u32 = 64;
+/// `FLACENC_HIP_FLAG_CANONICAL_SUM_ORDER`: the kernels' own order without the order certificate.
+pub const FLAG_CANONICAL_SUM_ORDER: u32 = 128;
+/// `FLACENC_HIP_FLAG_INTEGER_PARITY_ONLY`: with `FLAG_REFERENCE_SUM_ORDER`, shapes whose own order is certified to give the
+/// stable build's integers keep it (no second pass over the samples); this binding consumes integers only.
+pub const FLAG_INTEGER_PARITY_ONLY: u32 = 256;
 
 /// `flacenc_hip_qlpc_config` (include/flacenc_hip.h): the path's fields of `config::Qlpc` /
 /// `config::Prc` (`src/config.rs:271-288`, `211-214`).
@@ -257,8 +262,9 @@ impl Drop for Gpu {
 /// Which of the crate's builds the floating-point sums reproduce bit for bit (the C++ mirror's
 /// `HipContext::SumOrder`).  `CrateBuild` -- the default of `Gpu::new` -- asks for the bytes of the build this file is
 /// compiled into (stable: `FLAG_REFERENCE_SUM_ORDER`; `simd-nightly`: `FLAG_NIGHTLY_SUM_ORDER` up to order 15).
-/// `Canonical` is the kernels' own order: a valid encoding of the same configuration whose integer outputs are the
-/// stable build's wherever the library can certify it ("default order"), chosen with
+/// `Canonical` is the library's unflagged mode: the stable build's integers on the shapes whose order it certifies
+/// (blocks of 4096 / 4608 samples at orders up to 12, big blocks from order 16), the kernels' own
+/// order -- a valid encoding of the same configuration -- elsewhere (e.g. a stream's ragged last block); chosen with
 /// `Gpu::with_sum_order`.  Blocks of 4096 / 8192 / 16384 samples at orders from 16 sum in the stable build's order
 /// either way.
 #[derive(Clone, Copy, PartialEq, Eq, Debug)]
@@ -287,7 +293,7 @@ fn abi_config_with(c: &config::SubFrameCoding, order: SumOrder) -> QlpcConfig {
         } else if cfg!(feature = "simd-nightly") {
             0 // (the nightly split above order 15 depends on the allocator: canonical order, a valid encoding)
         } else {
-            FLAG_REFERENCE_SUM_ORDER
+            FLAG_REFERENCE_SUM_ORDER | FLAG_INTEGER_PARITY_ONLY
         },
         use_direct_mse: c.qlpc.use_direct_mse as u32,
         mae_optimization_steps: c.qlpc.mae_optimization_steps as u32,
@@ -418,5 +424,7 @@ mod tests {
         let own = FrameConfig::from_encoder(&enc, SumOrder::CrateBuild);
         let want = if cfg!(feature = "simd-nightly") { FLAG_NIGHTLY_SUM_ORDER } else { FLAG_REFERENCE_SUM_ORDER };
         assert_eq!(own.qlpc.flags & (FLAG_REFERENCE_SUM_ORDER | FLAG_NIGHTLY_SUM_ORDER), want);
+        // the stable build asks for its integers, not for the floating-point intermediates
+        assert_eq!(own.qlpc.flags & FLAG_INTEGER_PARITY_ONLY != 0, !cfg!(feature = "simd-nightly"));
     }
 }

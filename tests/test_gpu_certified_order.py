@@ -245,3 +245,42 @@ def test_independent_channels_are_certified_too(handle):
                 assert int(g["kind"]) == w["kind"] and int(g["bits"]) == w["bits"], (n, f, c)
                 if w["kind"] >= 2:
                     assert np.array_equal(resid[f, c], w["residual"]), (n, f, c)
+
+
+def test_integer_parity_only_keeps_the_certified_order_and_the_references_integers(handle):
+    """FLACENC_HIP_FLAG_REFERENCE_SUM_ORDER | _INTEGER_PARITY_ONLY (what the Rust / C++ drop-in passes for a stable build):
+    on the certified shapes no second pass -- the certificate's counters move, R[] is the kernel's own where certified --
+    and the integers are the reference's; with the fixed-LPC candidate and on a shape that is not certified (a ragged
+    block) everything is the plain reference-order mode's."""
+    import torch
+    flags = _capi.FLAG_REFERENCE_SUM_ORDER | _capi.FLAG_INTEGER_PARITY_ONLY
+    x = np.concatenate([near_pure_sines(12, 4096, seed0=71), noisy_sines(20, 4096, seed0=72)])
+    stats = torch.zeros(3, dtype=torch.int32, device="cuda")
+    handle.debug_set_cert_stats(stats.data_ptr())
+    try:
+        gp, gres, gR, gA = handle.qlpc_batch(x, 16, gcfg(8, flags=flags), want_fp=True)
+        torch.cuda.synchronize()
+    finally:
+        handle.debug_set_cert_stats(0)
+    assert int(stats[0]) == x.shape[0]  # certified inside the fused kernel, not by a pass in front of it
+    cp, cres, cR, cA = orc.qlpc_batch(x, 16, ocfg(8, orc.ACORR_CANONICAL))
+    rp, rres, rR, rA = orc.qlpc_batch(x, 16, ocfg(8, orc.ACORR_REFERENCE))
+    assert np.array_equal(gR.view(np.uint64), cR.view(np.uint64))  # (the unflagged rule's floating point)
+    records_equal(gp, rp, "integers")
+    assert np.array_equal(gres, rres)
+    # frames with the default candidates: bytes == the oracle in the reference's orders (selector sums included)
+    l, r = near_pure_sines(6, 4096, seed0=81), noisy_sines(6, 4096, seed0=82)
+    frames = np.stack([l, r], axis=1)
+    fc = _capi.make_frame_config(gcfg(10, flags=flags), use_fixed=True)
+    res, resid = handle.encode_stereo_frames(frames, 16, fc)
+    blobs = handle.pack_stereo_frames(frames, res, resid, 16, 44100)
+    ofc = orc.make_frame_config(ocfg(10, orc.ACORR_REFERENCE), use_fixed=True, fixed=orc.make_fixed_config(sum_mode=orc.SUMABS_STABLE))
+    ores, oresid = orc.encode_stereo_frames_cfg(frames, 16, ofc)
+    for f in range(frames.shape[0]):
+        assert blobs[f] == orc.write_stereo_frame(ores[f], frames[f, 0], frames[f, 1], 16, 44100, f, oresid[f, 0], oresid[f, 1]), f
+    # a shape without a certificate: the flag pair is the plain reference-order mode
+    y = noisy_sines(6, 1000, seed0=90)
+    p1, r1, R1, A1 = handle.qlpc_batch(y, 16, gcfg(8, flags=flags), want_fp=True)
+    p2, r2, R2, A2 = handle.qlpc_batch(y, 16, gcfg(8, flags=_capi.FLAG_REFERENCE_SUM_ORDER), want_fp=True)
+    assert np.array_equal(R1.view(np.uint64), R2.view(np.uint64)) and np.array_equal(r1, r2)
+    records_equal(p1, p2, "ragged block")

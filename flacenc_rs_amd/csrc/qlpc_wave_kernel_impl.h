@@ -555,6 +555,46 @@ __device__ __forceinline__ RiceResult rice_search(const PlaneSums& ps, const int
   r.my_p = 0;
   r.saturated = false;
   uint32_t sat_any = 0;
+  if (NOSAT && !finest_only) {
+    // Level totals by ONE triangular reduction instead of seven wave sums (round 5): level K's minima live on the lanes
+    // that are multiples of 2^K, so their sum needs only the tree levels from K on -- at spacing S the leaders of 2 S
+    // add their partner's running totals of every level below log2(2 S): 1 + 2 + 3 + 4 + 5 + 6 = 21 adds (fifteen of
+    // them with the fetch folded in as a DPP operand or done by the LDS crossbar) where seven full sums took 42 and the
+    // leader masks 21 more.  NOSAT: no minimum can have saturated, totals fit 32 bits.  Lane 0 ends up with all seven.
+    uint32_t t[7];
+#pragma unroll
+    for (int K = 0; K < 7; ++K) t[K] = (pk[K] >> 5) + 4u;
+    t[0] += from_upper_half<1>(t[0]);
+#pragma unroll
+    for (int K = 0; K < 2; ++K) t[K] += from_upper_half<2>(t[K]);
+#pragma unroll
+    for (int K = 0; K < 3; ++K) t[K] += from_upper_half<4>(t[K]);
+#pragma unroll
+    for (int K = 0; K < 4; ++K) t[K] += from_upper_half<8>(t[K]);
+#pragma unroll
+    for (int K = 0; K < 5; ++K) t[K] += from_upper_half<16>(t[K]);
+#pragma unroll
+    for (int K = 0; K < 6; ++K) t[K] += from_upper_half<32>(t[K]);
+    // strict < keeps the finer order on ties (rice.rs:285); everything below is wave-uniform
+    uint32_t best = (uint32_t)__builtin_amdgcn_readfirstlane((int)t[0]);
+    int bk = 0;
+#pragma unroll
+    for (int K = 1; K < 7; ++K) {
+      const uint32_t tot = (uint32_t)__builtin_amdgcn_readfirstlane((int)t[K]);
+      if (tot < best) {
+        best = tot;
+        bk = K;
+      }
+    }
+    r.best_bits = best;
+    r.bestk = bk;
+    uint32_t mp = pk[0];
+#pragma unroll
+    for (int K = 1; K < 7; ++K) mp = (bk == K) ? pk[K] : mp;
+    r.my_p = mp & 31u;
+    r.sat_levels = 0;
+    return r;
+  }
   // level totals: the group leaders' minima summed over the wave; strict < keeps the finer order on
   // ties (rice.rs:285)
 #pragma unroll

@@ -1,0 +1,76 @@
+"""Soundness of the order certificate on the CPU, through the oracle's statement of it
+(orc_quant_certified == the kernel's arithmetic, operation for operation; tests/test_gpu_certified_order.py holds the GPU to
+the oracle bit for bit, counters included).  The certificate is a first-order perturbation bound with a safety factor, not
+a theorem about the floating-point recursion: this is its evidence -- over tens of thousands of subframes drawn to stress
+it (near-pure and multi-tone material with Toeplitz condition numbers up to 1e9, every order 1..12, precisions 3..15, all
+windows, 8..24 bits, silence / constants / impulses / clipping) a CERTIFIED subframe's QuantizedParameters never differ
+from the reference order's, while the bare kernel order's do on some of the very same subframes."""
+import numpy as np
+import pytest
+
+import util
+from oracle import oracle as orc
+
+
+def _corpus(rng, count, n, bps):
+    t = np.arange(n, dtype=np.float64)
+    full = float(1 << (bps - 1))
+    rows = []
+    for i in range(count):
+        kind = i % 8
+        if kind == 0:  # near-pure sine, noise floor 60..100 dB down
+            x = 0.6 * np.sin(2 * np.pi * t / rng.uniform(6.0, 400.0) + rng.uniform(0, 6.28)) + rng.uniform(-1, 1, n) * 10 ** rng.uniform(-5, -3)
+        elif kind == 1:  # two close tones
+            p = rng.uniform(8.0, 120.0)
+            x = 0.4 * np.sin(2 * np.pi * t / p) + 0.4 * np.sin(2 * np.pi * t / (p * rng.uniform(1.001, 1.05))) + rng.uniform(-1, 1, n) * 1e-4
+        elif kind == 2:  # sine + noise (the bench family)
+            x = 0.4 * np.sin(2 * np.pi * t / rng.uniform(20, 300)) + rng.uniform(-1, 1, n) * rng.uniform(0.01, 0.4)
+        elif kind == 3:  # decaying resonance (strongly predictable)
+            x = 0.9 * np.exp(-t / rng.uniform(500, 5000)) * np.sin(2 * np.pi * t / rng.uniform(10, 60))
+        elif kind == 4:  # clipped tone
+            x = np.clip(1.7 * np.sin(2 * np.pi * t / rng.uniform(30, 200)), -0.999, 0.999)
+        elif kind == 5:  # DC + impulse(s), one possibly in front of t = P
+            x = np.full(n, rng.uniform(-0.5, 0.5)) + rng.uniform(-1, 1, n) * 1e-4
+            x[rng.integers(0, n)] = 0.99
+            x[rng.integers(0, 12)] = -0.99
+        elif kind == 6:  # low-pass noise (AR(1) close to the unit circle)
+            e = rng.uniform(-1, 1, n) * 0.01
+            x = np.zeros(n)
+            a = rng.uniform(0.95, 0.9999)
+            for k in range(1, n):
+                x[k] = a * x[k - 1] + e[k]
+            x *= 0.8 / max(1e-9, np.abs(x).max())
+        else:  # square wave with jitter
+            x = np.where(((t + rng.integers(0, 50)) // rng.integers(5, 80)) % 2 == 0, 0.8, -0.8) + rng.uniform(-1, 1, n) * 1e-3
+        rows.append(np.clip(np.rint(x * full), -full, full - 1).astype(np.int32))
+    rows.append(np.zeros(n, np.int32))
+    rows.append(np.full(n, 17, np.int32))
+    return np.stack(rows)
+
+
+@pytest.mark.parametrize("n", [4096, 4608])
+def test_a_certified_subframe_is_never_wrong(n):
+    rng = np.random.default_rng(20251004 + n)
+    total = recomputed = tier2 = tree_differs = 0
+    for rnd in range(24 if n == 4096 else 8):
+        order = int(rng.integers(1, 13))
+        precision = int(rng.integers(3, 16))
+        bps = int(rng.choice([8, 12, 16, 16, 16, 20, 24]))
+        window = [("tukey", 0.4), ("tukey", 0.1), ("tukey", 1.0), "rectangle"][rnd % 4]
+        x = _corpus(rng, 160, n, bps)
+        kw = dict(lpc_order=order, quant_precision=precision, window=window)
+        orc.cert_stats(reset=True)
+        cp, cres, _, _ = orc.qlpc_batch(x, bps, orc.make_config(acorr=orc.ACORR_CANONICAL, **kw), nthreads=1, want_fp=False)
+        st = orc.cert_stats()
+        rp, rres, _, _ = orc.qlpc_batch(x, bps, orc.make_config(acorr=orc.ACORR_REFERENCE, **kw), want_fp=False)
+        tp, _, _, _ = orc.qlpc_batch(x, bps, orc.make_config(acorr=orc.ACORR_CHUNK_TREE, **kw), want_fp=False)
+        for f in ("coefs", "shift", "order", "status", "rice_order", "code_bits", "subframe_bits"):
+            assert np.array_equal(cp[f], rp[f]), (n, order, precision, bps, window, f)
+        assert np.array_equal(cres, rres)
+        total += st[0]
+        tier2 += st[1]
+        recomputed += st[2]
+        tree_differs += int(((tp["coefs"] != rp["coefs"]).any(axis=1) | (tp["shift"] != rp["shift"])).sum())
+    print(f"n = {n}: {total} subframes, {tier2} needed the rows of T^-1, {recomputed} recomputed from the reference's chains "
+          f"({recomputed / total:.3f}), 0 certified-but-different; the bare kernel order differs in {tree_differs}")
+    assert total >= 1000 and recomputed < total  # (the certificate does certify most of even this corpus)

@@ -1,5 +1,5 @@
 """CPU soak of the order certificate through the oracle (the test tests/test_certificate_cpu.py at scale):
-    python tools/certificate_soak.py [rounds=400]
+    python tools/certificate_soak.py [rounds=400] [seed=77]
 prints subframes / tier-2 / recomputed / certified-but-different (must be 0) / bare-order-differs."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -9,7 +9,7 @@ from oracle import oracle as orc
 import test_certificate_cpu as T
 
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 400
-rng = np.random.default_rng(77)
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 77)
 total = tier2 = redone = bad = tree = 0
 for rnd in range(rounds):
     n = 4096 if rnd % 4 else 4608

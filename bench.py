@@ -651,7 +651,39 @@ def secondary(torch, _capi, handle, args, dev):
                                                           residual.data_ptr(), n, stream=stream.cuda_stream))
     sec["tonal_workload"] = entry(ms, {"what": "headline kernel on sigen Sine(36,0.4)+Noise(0.04) (src/lib.rs:219-221)",
                                        "subframe_bits_per_sample": bits_per_sample()})
-    del tonal, results, residual, packed
+    del tonal
+    # Real audio: the eight fixture channels the reference's own tests load (tests/golden/testsignal.*.bin, 8192 16-bit
+    # samples each; src/test_helper.rs:81-125), cut into stereo frames at a hop of 64 samples and tiled to the batch.
+    # Music is strongly coloured: the order certificate recomputes a larger share of it from the
+    # reference's chains than of the bench signal -- this row is the headline kernel's rate on such material.
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden")
+    names = ("sus109", "sus6", "ras22", "ras103")
+    if bps == 16 and n <= 8192 and all(os.path.exists(os.path.join(gold, "testsignal.%s.ch%d.bin" % (nm, c))) for nm in names for c in (0, 1)):
+        cut = []
+        for nm in names:
+            ch = [np.fromfile(os.path.join(gold, "testsignal.%s.ch%d.bin" % (nm, c)), dtype="<i2").astype(np.int32) for c in (0, 1)]
+            for t0 in range(0, 8192 - n + 1, 64):
+                cut.append(np.stack([ch[0][t0:t0 + n], ch[1][t0:t0 + n]]))
+        cut = np.stack(cut)
+        real = torch.from_numpy(np.ascontiguousarray(np.tile(cut, ((F + len(cut) - 1) // len(cut), 1, 1))[:F])).to(dev)
+        for order in (8, 10, 12):
+            rcfg = _capi.make_frame_config(_capi.make_config(lpc_order=order), use_fixed=False)
+            ms = timed(lambda: handle.encode_stereo_frames_device(rcfg, real.data_ptr(), F, n, n, bps, results.data_ptr(),
+                                                                  residual.data_ptr(), n, stream=stream.cuda_stream))
+            cst = torch.zeros(3, dtype=torch.int32, device=dev)
+            handle.debug_set_cert_stats(cst.data_ptr())
+            handle.encode_stereo_frames_device(rcfg, real.data_ptr(), F, n, n, bps, results.data_ptr(), residual.data_ptr(), n,
+                                               stream=stream.cuda_stream)
+            torch.cuda.synchronize()
+            handle.debug_set_cert_stats(0)
+            analysed, _tier2, redone = (int(v) for v in cst.cpu().tolist())
+            sec["real_audio_fixtures_order%d" % order] = entry(ms, {
+                "what": "headline kernel (frame decision, no fixed-LPC candidate) on %d distinct stereo frames cut from the "
+                        "reference's real-audio test fixtures, tiled to the batch" % len(cut),
+                "subframe_bits_per_sample": bits_per_sample(),
+                "certificate_recomputed_fraction": round(redone / analysed, 4) if analysed else None})
+        del real
+    del results, residual, packed
     # BASELINE configs[2] / [4]: 24-bit stereo blocks of 8192 / 16384 samples at order 24 (the reference's maximum)
     # through the big-block kernels -- all four candidates (L, R, M, S) analysed, f64-fma bound
     for label, bn, bf in (("config3_8192x24bit_order24", 8192, 6144), ("config5_16384x24bit_order24", 16384, 3072)):

@@ -40,7 +40,8 @@ COMM_ID_BYTES = 128  # FLACENC_HIP_COMM_ID_BYTES
 
 # every symbol include/flacenc_hip.h declares
 ABI_VERSION = 5  # FLACENC_HIP_ABI_VERSION of include/flacenc_hip.h
-DEBUG_SYMBOLS = ("flacenc_hip_debug_set_stamps", "flacenc_hip_debug_set_fixed_keys", "flacenc_hip_debug_set_cert_stats")
+DEBUG_SYMBOLS = ("flacenc_hip_debug_set_stamps", "flacenc_hip_debug_set_fixed_keys", "flacenc_hip_debug_set_cert_stats",
+                 "flacenc_hip_debug_set_adaptive_order", "flacenc_hip_debug_adaptive_state")
 EXPORTED_SYMBOLS = (
     "flacenc_hip_abi_version",
     "flacenc_hip_device_count",
@@ -235,6 +236,9 @@ def load() -> C.CDLL:
         if hasattr(L, name):
             getattr(L, name).argtypes = [vp, vp]
             getattr(L, name).restype = C.c_int
+    if hasattr(L, "flacenc_hip_debug_set_adaptive_order"):
+        L.flacenc_hip_debug_set_adaptive_order.argtypes = [vp, C.c_int]
+        L.flacenc_hip_debug_adaptive_state.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     batch_args = [vp, C.POINTER(QlpcConfig), i32p, C.c_size_t, C.c_uint32, C.c_size_t, u8p, vp, i32p,
                   C.c_size_t, f64p, f64p]
     L.flacenc_hip_qlpc_batch.argtypes = batch_args + [C.c_int]
@@ -456,6 +460,17 @@ class Handle:
         """3 x uint32 on the device: subframes certified launches analysed, certificates that needed the rows of T^-1,
         subframes recomputed from the reference's chains (flacenc_hip_debug.h)."""
         self._check(self._lib.flacenc_hip_debug_set_cert_stats(self._h, device_ptr or None))
+
+    def debug_set_adaptive_order(self, on: bool):
+        """Launches of the certified shapes that return integers only switch to the two-pass form on hard material
+        (flacenc_hip_debug.h); off pins the fused kernel's certificate."""
+        self._check(self._lib.flacenc_hip_debug_set_adaptive_order(self._h, 1 if on else 0))
+
+    def debug_adaptive_state(self):
+        """(span, left) of the adaptive order mode: span 0 = the material last seen was easy."""
+        span, left = C.c_int(0), C.c_int(0)
+        self._check(self._lib.flacenc_hip_debug_adaptive_state(self._h, C.byref(span), C.byref(left)))
+        return span.value, left.value
 
     def synchronize(self):
         self._check(self._lib.flacenc_hip_synchronize(self._h))

@@ -153,6 +153,14 @@ struct flacenc_hip_handle {
   unsigned long long* fixed_keys = nullptr;  // test hook, see flacenc_hip_debug_set_fixed_keys
   uint32_t* cert_stats = nullptr;  // statistics hook, see flacenc_hip_debug_set_cert_stats
   flacenc_hip::CommState* comm = nullptr;  // RCCL communicator of the ordered gather (comm.cpp)
+  // Order mode of the certified shapes by material (launch_adaptive): the certificate's own counters of the last
+  // launches, cumulative on the device and mirrored into one pinned word by a one-thread kernel behind each such launch
+  uint32_t* d_cert_fb = nullptr;               // device: the three counters of QlpcKernelArgs::cert_stats
+  unsigned long long* h_cert_fb = nullptr;     // pinned, device-visible: the latest verdict (cert_feedback_kernel)
+  uint32_t fb_seq = 0, fb_seen_seq = 0, fb_probe_seq = 0;  // sequence numbers of the launches that carried the counters
+  bool fb_probe_out = false;
+  int two_pass_left = 0, two_pass_span = 0;
+  int adaptive_order = 1;                      // flacenc_hip_debug_set_adaptive_order(h, 0) pins the certified kernel
 };
 
 namespace flacenc_hip {
@@ -342,6 +350,102 @@ int attach_split_scratch(flacenc_hip_handle* h, flacenc_hip::QlpcKernelArgs& a) 
   return FLACENC_HIP_OK;
 }
 
+// The certified shapes (blocks of 4096 / 4608 samples at orders up to 12) by material.  The fused kernel settles a
+// subframe's order certificate in its first tier for next to nothing; the second tier and the recomputation from the
+// reference's chains are serial work of one wave while its workgroup waits -- rare on noise-like material (2 subframes in
+// 393 216 of the bench signal), the rule on music (the reference's real-audio fixtures: 26 % / 82 % / 100 % of the
+// subframes at orders 8 / 10 / 12, 180 / 91 / 59 G samples/s where the bench signal runs at 350).  Two passes -- the
+// reference's chains on the matrix cores for every subframe, then the fused kernel on their R[] -- give the SAME integers
+// at a flat 1.4 x the certified kernel's best time.  So launches that return integers only (no R[], no coefficients: their
+// bits depend on the pass that produced them) watch the certificate's counters and take the two-pass form while the
+// material they were last given was hard: above kHardShare of the subframes unsettled by the first tier, for a span of
+// launches that doubles (8 .. 64) while the probes between the spans keep finding it so.
+// One thread behind a launch that carried the counters: its verdict -- (sequence number, hard subframes, analysed subframes)
+// in one 64-bit store to the pinned word -- and the counters cleared for the next one.
+__global__ void cert_feedback_kernel(uint32_t* counters, unsigned long long* out, uint32_t seq) {
+  const unsigned long long analysed = counters[0], hard = counters[1] + counters[2];
+  counters[0] = counters[1] = counters[2] = 0u;
+  *out = ((unsigned long long)(seq & 0xFFFFu) << 48) | ((hard & 0xFFFFFFull) << 24) | (analysed & 0xFFFFFFull);
+}
+constexpr double kHardShare = 0.10;
+constexpr uint32_t kFeedbackMinSubframes = 4096, kFeedbackMaxSubframes = 1u << 24;
+inline uint32_t next_seq(uint32_t seq) { return ((seq + 1u) & 0xFFFFu) ? ((seq + 1u) & 0xFFFFu) : 1u; }  // (0: the word's initial state)
+
+int launch_adaptive(flacenc_hip_handle* h, flacenc_hip::QlpcKernelArgs& a, const flacenc_hip::QlpcLaunchPlan& plan,
+                    hipStream_t stream) {
+  const bool order_ok = a.reference_order == 0u || (a.reference_order == 1u && a.integer_parity_only != 0u);
+  const bool fused_certified = a.certify != 0u && flacenc_hip::cert_shape(a) && order_ok && !a.direct_mse && a.fixed_mode == 0 &&
+                               a.lpc_stage == 0 && a.acorr_in == nullptr && !a.only_marked && a.pack_out == nullptr &&
+                               flacenc_hip::wave_kernel_eligible(a);
+  const bool watch = fused_certified && h->adaptive_order != 0 && h->cert_stats == nullptr && a.autocorr == nullptr &&
+                     a.lpc_coefs == nullptr && a.n_subframes >= kFeedbackMinSubframes && a.n_subframes < kFeedbackMaxSubframes;
+  if (!watch) {
+    HIP_TRY(h, flacenc_hip::launch_qlpc(a, plan, stream));
+    return FLACENC_HIP_OK;
+  }
+  if (h->d_cert_fb == nullptr) {
+    HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->d_cert_fb), 16));
+    HIP_TRY(h, hipMemset(h->d_cert_fb, 0, 16));
+    HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&h->h_cert_fb), 8, hipHostMallocMapped));
+    *h->h_cert_fb = 0ull;
+  }
+  // The latest verdict that has landed (a plain read of the pinned word: late is fine, torn it cannot be).  The host may
+  // run many launches ahead of the device, so nothing is concluded from launches whose counters are not in: on easy
+  // material every launch carries the counters and any new verdict counts; on hard material a span of two-pass launches
+  // is followed by ONE probe (a certified launch), and the launches behind the probe stay two-pass until ITS verdict is in.
+  const unsigned long long word = *reinterpret_cast<volatile unsigned long long*>(h->h_cert_fb);
+  const uint32_t l_seq = static_cast<uint32_t>(word >> 48), l_hard = static_cast<uint32_t>(word >> 24) & 0xFFFFFFu,
+                 l_an = static_cast<uint32_t>(word) & 0xFFFFFFu;
+  const bool is_hard = l_an != 0u && static_cast<double>(l_hard) > kHardShare * static_cast<double>(l_an);
+  bool two_pass;
+  if (h->two_pass_span == 0) {  // easy so far
+    if (l_seq != h->fb_seen_seq) {
+      h->fb_seen_seq = l_seq;
+      if (is_hard) h->two_pass_left = h->two_pass_span = 8;
+    }
+    two_pass = h->two_pass_span != 0;
+  } else if (h->two_pass_left > 0) {
+    two_pass = true;
+  } else if (!h->fb_probe_out) {
+    two_pass = false;  // the probe
+    h->fb_probe_out = true;
+    h->fb_probe_seq = next_seq(h->fb_seq);
+  } else if (l_seq != h->fb_probe_seq) {
+    two_pass = true;  // the probe's verdict is not in yet
+  } else {
+    h->fb_probe_out = false;
+    h->fb_seen_seq = l_seq;
+    if (is_hard) {
+      h->two_pass_span = h->two_pass_span >= 64 ? 64 : 2 * h->two_pass_span;
+      h->two_pass_left = h->two_pass_span;
+      two_pass = true;
+    } else {
+      h->two_pass_span = 0;
+      two_pass = false;
+    }
+  }
+  if (two_pass) {
+    if (h->two_pass_left > 0) --h->two_pass_left;
+    flacenc_hip::QlpcKernelArgs b = a;
+    b.certify = 0;
+    b.reference_order = 1u;  // (the autocorrelation alone: the selector's sums follow sumabs_scratch, which the flags decide)
+    if (b.split_scratch == nullptr) {
+      int rc = attach_split_scratch(h, b);
+      if (rc != FLACENC_HIP_OK) return rc;
+    }
+    HIP_TRY(h, flacenc_hip::launch_qlpc(b, plan, stream));
+    return FLACENC_HIP_OK;
+  }
+  a.cert_stats = h->d_cert_fb;
+  HIP_TRY(h, flacenc_hip::launch_qlpc(a, plan, stream));
+  h->fb_seq = next_seq(h->fb_seq);
+  unsigned long long* out = nullptr;
+  HIP_TRY(h, hipHostGetDevicePointer(reinterpret_cast<void**>(&out), h->h_cert_fb, 0));
+  hipLaunchKernelGGL(cert_feedback_kernel, dim3(1), dim3(1), 0, stream, h->d_cert_fb, out, h->fb_seq);
+  HIP_TRY(h, hipGetLastError());
+  return FLACENC_HIP_OK;
+}
+
 int enqueue(flacenc_hip_handle* h, const flacenc_hip_qlpc_config* cfg, const int32_t* samples,
             size_t n_subframes, uint32_t block_size, size_t stride, const uint8_t* bps,
             flacenc_hip_subframe_params* params, int32_t* residual, size_t residual_stride,
@@ -446,8 +550,7 @@ int enqueue(flacenc_hip_handle* h, const flacenc_hip_qlpc_config* cfg, const int
     a.minmax_out = minmax_out;
     if (placed) *placed = true;
   }
-  HIP_TRY(h, flacenc_hip::launch_qlpc(a, plan, stream));
-  return FLACENC_HIP_OK;
+  return launch_adaptive(h, a, plan, stream);
 }
 
 // y = x^(8 per) mod P and its powers for the CRC-16 slice combination (see frame_pack.h)
@@ -705,7 +808,9 @@ int flacenc_hip_create(flacenc_hip_handle** out, int device_id) {
   h->device = device_id;
   if (hipSetDevice(device_id) != hipSuccess ||
       hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
-    delete h;
+    if (h->d_cert_fb) (void)hipFree(h->d_cert_fb);
+  if (h->h_cert_fb) (void)hipHostFree(h->h_cert_fb);
+  delete h;
     return FLACENC_HIP_ERR_DEVICE;
   }
   *out = h;
@@ -788,6 +893,21 @@ int flacenc_hip_debug_set_fixed_keys(flacenc_hip_handle* h, unsigned long long* 
 int flacenc_hip_debug_set_stamps(flacenc_hip_handle* h, unsigned long long* device_stamps) {
   if (!h) return FLACENC_HIP_ERR_BAD_ARGUMENT;
   h->stamps = device_stamps;
+  return FLACENC_HIP_OK;
+}
+
+int flacenc_hip_debug_set_adaptive_order(flacenc_hip_handle* h, int on) {
+  if (!h) return FLACENC_HIP_ERR_BAD_ARGUMENT;
+  h->adaptive_order = on ? 1 : 0;
+  h->two_pass_left = h->two_pass_span = 0;
+  h->fb_probe_out = false;
+  return FLACENC_HIP_OK;
+}
+
+int flacenc_hip_debug_adaptive_state(flacenc_hip_handle* h, int* span, int* left) {
+  if (!h) return FLACENC_HIP_ERR_BAD_ARGUMENT;
+  if (span) *span = h->two_pass_span;
+  if (left) *left = h->two_pass_left;
   return FLACENC_HIP_OK;
 }
 
@@ -1192,8 +1312,7 @@ int flacenc_hip_encode_frames_async(flacenc_hip_handle* h, const flacenc_hip_fra
       return rc;
     if (pow2 && flacenc_hip::wave_kernel_eligible(a)) {
       flacenc_hip::QlpcLaunchPlan plan = flacenc_hip::plan_qlpc_launch(block_size, cfg->qlpc.lpc_order);
-      HIP_TRY(h, flacenc_hip::launch_qlpc(a, plan, s));
-      return FLACENC_HIP_OK;
+      return launch_adaptive(h, a, plan, s);
     }
     // blocks of 8 / 16 / 32 finest Rice partitions: qlpc_subwave_kernel's independent-channel variant -- both candidates
     // and encode_subframe's choice of every channel in one launch; what it marks takes the general path below, restricted
@@ -2196,8 +2315,7 @@ static int encode_stereo_frames_impl(flacenc_hip_handle* h, const flacenc_hip_fr
     return FLACENC_HIP_OK;
   }
   flacenc_hip::QlpcLaunchPlan plan = flacenc_hip::plan_qlpc_launch(block_size, cfg->qlpc.lpc_order);
-  HIP_TRY(h, flacenc_hip::launch_qlpc(a, plan, static_cast<hipStream_t>(stream)));
-  return FLACENC_HIP_OK;
+  return launch_adaptive(h, a, plan, static_cast<hipStream_t>(stream));
 }
 
 int flacenc_hip_encode_stereo_frames(flacenc_hip_handle* h, const flacenc_hip_frame_config* cfg,

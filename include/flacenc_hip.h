@@ -118,7 +118,12 @@ extern "C" {
  * against the distance of every coefficient to its rounding boundary) and recompute the subframe
  * from those chains where they cannot prove it -- so that every integer output (coefficients, shift, order, residual,
  * Rice partition, bit counts, frame bytes) is the stable build's, at the chunk tree's speed on material that is not
- * strongly tonal.  This flag switches the certificate off: a valid encoding of the same configuration whose
+ * strongly tonal.  On material that IS (music, mostly: the certificate's second tier and the recomputation are serial
+ * work), launches of at least 4096 subframes that return integers only -- no autocorr, no lpc_coefs -- switch, by what
+ * the certificate's counters said about the launches before them, to two passes (the reference's chains for every
+ * subframe on the matrix cores, then the fused kernel): the same integers at a flat 1.4 x the certified kernel's best
+ * time; a choice of speed, never of result ("the order mode by material").
+ * This flag switches the certificate off: a valid encoding of the same configuration whose
  * coefficients may differ from the reference's in the last quantisation step on a fraction of a per mille of subframes. */
 #define FLACENC_HIP_FLAG_CANONICAL_SUM_ORDER 128u
 

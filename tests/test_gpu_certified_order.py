@@ -284,3 +284,64 @@ def test_integer_parity_only_keeps_the_certified_order_and_the_references_intege
     p2, r2, R2, A2 = handle.qlpc_batch(y, 16, gcfg(8, flags=_capi.FLAG_REFERENCE_SUM_ORDER), want_fp=True)
     assert np.array_equal(R1.view(np.uint64), R2.view(np.uint64)) and np.array_equal(r1, r2)
     records_equal(p1, p2, "ragged block")
+
+
+@pytest.mark.parametrize("order,use_fixed", [(8, False), (10, True)])
+def test_two_pass_form_on_hard_material_gives_the_same_bytes(handle, order, use_fixed):
+    """Integer-only launches of at least 4096 subframes watch the certificate's counters and take the two-pass form (the
+    reference's chains for every subframe on the matrix cores, then the fused kernel on their R[]) while the material last
+    seen was hard (flacenc_hip_api.cpp, launch_adaptive).  A choice of speed, never of result: on a batch of near-pure
+    tones every launch -- certified kernel, two-pass, probe -- writes the same records and rows, the oracle's in the
+    reference's order; a noisy batch never leaves the certified kernel."""
+    import torch
+    n, nf = 4096, 1024
+    rng = np.random.default_rng(order)
+    base_l, base_r = near_pure_sines(24, n, seed0=700 + order), near_pure_sines(24, n, seed0=800 + order)
+    pick = rng.integers(0, 24, size=(nf, 2))
+    hard = np.ascontiguousarray(np.stack([base_l[pick[:, 0]], base_r[pick[:, 1]]], axis=1))
+    easy_l, easy_r = noisy_sines(24, n, seed0=900), noisy_sines(24, n, seed0=950)
+    easy = np.ascontiguousarray(np.stack([easy_l[pick[:, 0]], easy_r[pick[:, 1]]], axis=1))
+    fc = _capi.make_frame_config(gcfg(order), use_fixed=use_fixed)
+    ofc = orc.make_frame_config(ocfg(order, orc.ACORR_REFERENCE), use_fixed=use_fixed)
+    results = torch.zeros((nf, _capi.FRAME_RESULT_DTYPE.itemsize), dtype=torch.uint8, device="cuda")
+    residual = torch.zeros((nf * 2, n), dtype=torch.int32, device="cuda")
+
+    def run(x):
+        results.zero_()
+        residual.zero_()
+        handle.encode_stereo_frames_device(fc, x.data_ptr(), nf, n, n, 16, results.data_ptr(), residual.data_ptr(), n)
+        torch.cuda.synchronize()
+        return results.cpu().numpy().tobytes(), residual.cpu().numpy().copy()
+
+    handle.debug_set_adaptive_order(True)  # (also resets the state a previous test left)
+    try:
+        xe = torch.from_numpy(easy).cuda()
+        ref = run(xe)
+        for _ in range(4):
+            got = run(xe)
+            assert got[0] == ref[0] and np.array_equal(got[1], ref[1])
+            assert handle.debug_adaptive_state() == (0, 0), "a noisy batch stays on the certified kernel"
+        xh = torch.from_numpy(hard).cuda()
+        first = run(xh)  # certified kernel (nothing known about this material yet)
+        spans = []
+        for _ in range(30):  # span of 8, probe, span of 16, probe ...
+            got = run(xh)
+            assert got[0] == first[0] and np.array_equal(got[1], first[1])
+            spans.append(handle.debug_adaptive_state()[0])
+        assert spans[0] == 8 and 16 in spans, spans
+        handle.debug_set_adaptive_order(False)
+        pinned = run(xh)
+        assert pinned[0] == first[0] and np.array_equal(pinned[1], first[1])
+    finally:
+        handle.debug_set_adaptive_order(True)
+    # ... and they are the oracle's in the reference's order (the distinct frames: every pair of the 24 + 24 base channels used)
+    g = np.frombuffer(first[0], dtype=_capi.FRAME_RESULT_DTYPE)
+    rows = first[1].reshape(nf, 2, n)
+    seen = {}
+    for f in range(nf):
+        seen.setdefault((int(pick[f, 0]), int(pick[f, 1])), f)
+    idx = sorted(seen.values())[:48]
+    want, wrows = orc.encode_stereo_frames_cfg(hard[idx], 16, ofc)
+    for k, f in enumerate(idx):
+        assert g[f] == want[k], f
+        assert np.array_equal(rows[f], wrows[k]), f

@@ -158,6 +158,7 @@ struct flacenc_hip_handle {
   uint32_t* d_cert_fb = nullptr;               // device: the three counters of QlpcKernelArgs::cert_stats
   unsigned long long* h_cert_fb = nullptr;     // pinned, device-visible: the latest verdict (cert_feedback_kernel)
   uint32_t fb_seq = 0, fb_seen_seq = 0, fb_probe_seq = 0;  // sequence numbers of the launches that carried the counters
+  uint32_t fb_pending = 0;  // subframes counted on the device since the last verdict went out
   bool fb_probe_out = false;
   int two_pass_left = 0, two_pass_span = 0;
   int adaptive_order = 1;                      // flacenc_hip_debug_set_adaptive_order(h, 0) pins the certified kernel
@@ -365,11 +366,13 @@ int attach_split_scratch(flacenc_hip_handle* h, flacenc_hip::QlpcKernelArgs& a) 
 __global__ void cert_feedback_kernel(uint32_t* counters, unsigned long long* out, uint32_t seq) {
   const unsigned long long analysed = counters[0], hard = counters[1] + counters[2];
   counters[0] = counters[1] = counters[2] = 0u;
-  *out = ((unsigned long long)(seq & 0xFFFFu) << 48) | ((hard & 0xFFFFFFull) << 24) | (analysed & 0xFFFFFFull);
+  *out = ((unsigned long long)(seq & 0xFFFu) << 52) | ((hard & 0x3FFFFFFull) << 26) | (analysed & 0x3FFFFFFull);
 }
 constexpr double kHardShare = 0.10;
-constexpr uint32_t kFeedbackMinSubframes = 4096, kFeedbackMaxSubframes = 1u << 24;
-inline uint32_t next_seq(uint32_t seq) { return ((seq + 1u) & 0xFFFFu) ? ((seq + 1u) & 0xFFFFu) : 1u; }  // (0: the word's initial state)
+// a verdict is taken from at least this many subframes (counters of smaller launches add up until they are), a probe's from
+// at least kProbeMinSubframes; launches of 2^25 subframes and more are not watched (the verdict's fields are 26 bits wide)
+constexpr uint32_t kFeedbackMinSubframes = 4096, kProbeMinSubframes = 1024, kFeedbackMaxSubframes = 1u << 25;
+inline uint32_t next_seq(uint32_t seq) { return ((seq + 1u) & 0xFFFu) ? ((seq + 1u) & 0xFFFu) : 1u; }  // (0: the word's initial state)
 
 int launch_adaptive(flacenc_hip_handle* h, flacenc_hip::QlpcKernelArgs& a, const flacenc_hip::QlpcLaunchPlan& plan,
                     hipStream_t stream) {
@@ -378,7 +381,7 @@ int launch_adaptive(flacenc_hip_handle* h, flacenc_hip::QlpcKernelArgs& a, const
                                a.lpc_stage == 0 && a.acorr_in == nullptr && !a.only_marked && a.pack_out == nullptr &&
                                flacenc_hip::wave_kernel_eligible(a);
   const bool watch = fused_certified && h->adaptive_order != 0 && h->cert_stats == nullptr && a.autocorr == nullptr &&
-                     a.lpc_coefs == nullptr && a.n_subframes >= kFeedbackMinSubframes && a.n_subframes < kFeedbackMaxSubframes;
+                     a.lpc_coefs == nullptr && a.n_subframes < kFeedbackMaxSubframes;
   if (!watch) {
     HIP_TRY(h, flacenc_hip::launch_qlpc(a, plan, stream));
     return FLACENC_HIP_OK;
@@ -394,8 +397,8 @@ int launch_adaptive(flacenc_hip_handle* h, flacenc_hip::QlpcKernelArgs& a, const
   // material every launch carries the counters and any new verdict counts; on hard material a span of two-pass launches
   // is followed by ONE probe (a certified launch), and the launches behind the probe stay two-pass until ITS verdict is in.
   const unsigned long long word = *reinterpret_cast<volatile unsigned long long*>(h->h_cert_fb);
-  const uint32_t l_seq = static_cast<uint32_t>(word >> 48), l_hard = static_cast<uint32_t>(word >> 24) & 0xFFFFFFu,
-                 l_an = static_cast<uint32_t>(word) & 0xFFFFFFu;
+  const uint32_t l_seq = static_cast<uint32_t>(word >> 52), l_hard = static_cast<uint32_t>(word >> 26) & 0x3FFFFFFu,
+                 l_an = static_cast<uint32_t>(word) & 0x3FFFFFFu;
   const bool is_hard = l_an != 0u && static_cast<double>(l_hard) > kHardShare * static_cast<double>(l_an);
   bool two_pass;
   if (h->two_pass_span == 0) {  // easy so far
@@ -407,9 +410,11 @@ int launch_adaptive(flacenc_hip_handle* h, flacenc_hip::QlpcKernelArgs& a, const
   } else if (h->two_pass_left > 0) {
     two_pass = true;
   } else if (!h->fb_probe_out) {
-    two_pass = false;  // the probe
+    two_pass = false;  // the probe: certified launches until kProbeMinSubframes have been counted
     h->fb_probe_out = true;
-    h->fb_probe_seq = next_seq(h->fb_seq);
+    h->fb_probe_seq = 0u;  // (assigned when its feedback goes out)
+  } else if (h->fb_probe_seq == 0u) {
+    two_pass = false;  // the probe is still collecting
   } else if (l_seq != h->fb_probe_seq) {
     two_pass = true;  // the probe's verdict is not in yet
   } else {
@@ -438,11 +443,17 @@ int launch_adaptive(flacenc_hip_handle* h, flacenc_hip::QlpcKernelArgs& a, const
   }
   a.cert_stats = h->d_cert_fb;
   HIP_TRY(h, flacenc_hip::launch_qlpc(a, plan, stream));
-  h->fb_seq = next_seq(h->fb_seq);
-  unsigned long long* out = nullptr;
-  HIP_TRY(h, hipHostGetDevicePointer(reinterpret_cast<void**>(&out), h->h_cert_fb, 0));
-  hipLaunchKernelGGL(cert_feedback_kernel, dim3(1), dim3(1), 0, stream, h->d_cert_fb, out, h->fb_seq);
-  HIP_TRY(h, hipGetLastError());
+  h->fb_pending += a.n_subframes;
+  const bool probing = h->fb_probe_out && h->fb_probe_seq == 0u;
+  if (h->fb_pending >= (probing ? kProbeMinSubframes : kFeedbackMinSubframes)) {
+    h->fb_pending = 0;
+    h->fb_seq = next_seq(h->fb_seq);
+    if (probing) h->fb_probe_seq = h->fb_seq;
+    unsigned long long* out = nullptr;
+    HIP_TRY(h, hipHostGetDevicePointer(reinterpret_cast<void**>(&out), h->h_cert_fb, 0));
+    hipLaunchKernelGGL(cert_feedback_kernel, dim3(1), dim3(1), 0, stream, h->d_cert_fb, out, h->fb_seq);
+    HIP_TRY(h, hipGetLastError());
+  }
   return FLACENC_HIP_OK;
 }
 

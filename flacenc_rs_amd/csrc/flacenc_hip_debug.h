@@ -27,7 +27,7 @@ int flacenc_hip_debug_set_stamps(flacenc_hip_handle* h, unsigned long long* devi
  * recomputed from the reference's chains. */
 int flacenc_hip_debug_set_cert_stats(flacenc_hip_handle* h, uint32_t* device_counters);
 /* 0: launches of the certified shapes always take the fused kernel's certificate; 1 (default): integer-only launches of
- * at least 4096 subframes take the two-pass form (the reference's chains for every subframe, same integers) while the
+ * any size take the two-pass form (the reference's chains for every subframe, same integers) while the
  * certificate's counters of the launches before them say the material is hard (flacenc_hip_api.cpp, launch_adaptive) */
 int flacenc_hip_debug_set_adaptive_order(flacenc_hip_handle* h, int on);
 /* the current span of two-pass launches (0: the material last seen was easy) and how many of it are left */

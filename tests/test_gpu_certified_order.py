@@ -286,15 +286,16 @@ def test_integer_parity_only_keeps_the_certified_order_and_the_references_intege
     records_equal(p1, p2, "ragged block")
 
 
-@pytest.mark.parametrize("order,use_fixed", [(8, False), (10, True)])
-def test_two_pass_form_on_hard_material_gives_the_same_bytes(handle, order, use_fixed):
-    """Integer-only launches of at least 4096 subframes watch the certificate's counters and take the two-pass form (the
+@pytest.mark.parametrize("order,use_fixed,nf", [(8, False, 1024), (10, True, 1024), (12, False, 160)])
+def test_two_pass_form_on_hard_material_gives_the_same_bytes(handle, order, use_fixed, nf):
+    """Integer-only launches watch the certificate's counters (a verdict per 4096 subframes) and take the two-pass form (the
     reference's chains for every subframe on the matrix cores, then the fused kernel on their R[]) while the material last
     seen was hard (flacenc_hip_api.cpp, launch_adaptive).  A choice of speed, never of result: on a batch of near-pure
     tones every launch -- certified kernel, two-pass, probe -- writes the same records and rows, the oracle's in the
-    reference's order; a noisy batch never leaves the certified kernel."""
+    reference's order; a noisy batch never leaves the certified kernel.  Launches of 640 subframes: their counters add up to
+    a verdict, the probe takes two of them."""
     import torch
-    n, nf = 4096, 1024
+    n = 4096
     rng = np.random.default_rng(order)
     base_l, base_r = near_pure_sines(24, n, seed0=700 + order), near_pure_sines(24, n, seed0=800 + order)
     pick = rng.integers(0, 24, size=(nf, 2))
@@ -328,7 +329,9 @@ def test_two_pass_form_on_hard_material_gives_the_same_bytes(handle, order, use_
             got = run(xh)
             assert got[0] == first[0] and np.array_equal(got[1], first[1])
             spans.append(handle.debug_adaptive_state()[0])
-        assert spans[0] == 8 and 16 in spans, spans
+        assert 8 in spans and 16 in spans, spans
+        if nf * 4 >= 4096:
+            assert spans[0] == 8, spans  # (one launch is a verdict; smaller launches add up to one)
         handle.debug_set_adaptive_order(False)
         pinned = run(xh)
         assert pinned[0] == first[0] and np.array_equal(pinned[1], first[1])

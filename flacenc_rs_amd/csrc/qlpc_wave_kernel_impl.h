@@ -727,7 +727,12 @@ constexpr int cert_tile(bool stereo, int spl) { return (!stereo && spl != 64) ? 
 constexpr int cert_scratch_bytes(int tile) { return 4 * (kCertHist + tile + 8) * 4; }
 
 template <int SPL, bool STEREO, int kCertTile>
-__device__ __attribute__((noinline)) void reference_chains_from_lds(const int32_t* sm, float* rows, const float* wtab, int P) {
+__device__ __attribute__((noinline)) void reference_chains_from_lds(uint32_t rows_off, const float* wtab, int P) {
+  // (the images and the scratch rows by their place in the workgroup's LDS, not by pointer: behind a generic pointer
+  // every access of this out-of-line function paid a 64-bit address and an address-space cast -- 140 instructions per 16 steps)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int32_t* const sm = reinterpret_cast<const int32_t*>(smem_raw);
+  float* const rows = reinterpret_cast<float*>(smem_raw + rows_off);
   using G = WaveGeom<SPL>;
   constexpr int n = G::N;
   constexpr int kCertRow = kCertHist + kCertTile + 8;  // (row stride = 8 mod 32 banks, as acorr_reference.cpp's kMRow)
@@ -795,7 +800,15 @@ __device__ __attribute__((noinline)) void reference_chains_from_lds(const int32_
         acc = __builtin_amdgcn_mfma_f64_4x4x4f64((double)pa[4 * m], bd, acc, 0, 0, 0);
       }
     }
-#pragma unroll 8
+    // groups of 16 steps with a constant trip count: their 32 operand reads are issued together, ahead of the chain --
+    // with the bound a variable every step waited for its own two LDS reads, alone on its SIMD: ~270 cycles a step,
+    // 135 us per recomputed frame where the MFMA chain itself needs 17 (measured on the reference's real-audio fixtures)
+    for (; m + 16 <= m_end; m += 16) {
+      const float* const qa = pa + 4 * m;
+      const float* const qb = pb + 4 * m;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) acc = __builtin_amdgcn_mfma_f64_4x4x4f64((double)qa[4 * u], (double)qb[4 * u], acc, 0, 0, 0);
+    }
     for (; m < m_end; ++m) acc = __builtin_amdgcn_mfma_f64_4x4x4f64((double)pa[4 * m], (double)pb[4 * m], acc, 0, 0, 0);
     // the tile's last 64 samples become the next tile's history (the wave's own LDS operations are ordered)
     if (tile + 1 < n_tiles) {
@@ -881,6 +894,9 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
+  // (The hardware already spreads the workgroups' waves: HW_REG_HW_ID stamps -- tools/hwid_probe.py on a -DFLACENC_STAMP_HWID
+  // build -- show wave 0 evenly on the four SIMDs, a workgroup's four waves on four different ones, and the waves 0 of two
+  // workgroups resident on a CU on one SIMD in 7 % of the pairs; rotating the roles by the workgroup index changes nothing.)
   const int wave = uni(tid >> 6);  // wave-uniform by construction; tell the compiler
   const int P = (int)a.lpc_order;
   const int n = kWaveN;
@@ -1326,7 +1342,8 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
       }
       if (kCertSupported && __builtin_amdgcn_ballot_w64(lane < 4 && !certified) != 0ull) {
 #ifndef FLACENC_CERT_NO_SLOWPATH
-        reference_chains_from_lds<SPL, STEREO, kCertTileHere>(sm, cert_rows, has_window ? a.window + 32 : nullptr, P);
+        reference_chains_from_lds<SPL, STEREO, kCertTileHere>(
+            (uint32_t)(reinterpret_cast<unsigned char*>(cert_rows) - smem_raw), has_window ? a.window + 32 : nullptr, P);
 #endif
         if (lane < 4 && !certified) {
           const double* const rsrc = reinterpret_cast<const double*>(cert_rows) + 16 * lane;
@@ -2346,7 +2363,13 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
   }
   if (a.stamps && lane == 0) {
     a.stamps[(size_t)sf * 8 + 6] = (unsigned long long)clock64();
+#ifdef FLACENC_STAMP_HWID
+    // (diagnostic build: where the wave ran -- HW_REG_HW_ID in the low word, HW_REG_XCC_ID in the high word)
+    a.stamps[(size_t)sf * 8 + 7] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
+                                   ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+#else
     a.stamps[(size_t)sf * 8 + 7] = (unsigned long long)clock64();
+#endif
   }
 }
 

@@ -355,7 +355,7 @@ int attach_split_scratch(flacenc_hip_handle* h, flacenc_hip::QlpcKernelArgs& a) 
 // subframe's order certificate in its first tier for next to nothing; the second tier and the recomputation from the
 // reference's chains are serial work of one wave while its workgroup waits -- rare on noise-like material (2 subframes in
 // 393 216 of the bench signal), the rule on music (the reference's real-audio fixtures: 26 % / 82 % / 100 % of the
-// subframes at orders 8 / 10 / 12, 180 / 91 / 59 G samples/s where the bench signal runs at 350).  Two passes -- the
+// subframes at orders 8 / 10 / 12 count as unsettled, 220 / 146 / 100 G samples/s where the bench signal runs at 350).  Two passes -- the
 // reference's chains on the matrix cores for every subframe, then the fused kernel on their R[] -- give the SAME integers
 // at a flat 1.4 x the certified kernel's best time.  So launches that return integers only (no R[], no coefficients: their
 // bits depend on the pass that produced them) watch the certificate's counters and take the two-pass form while the

@@ -666,8 +666,8 @@ def secondary(torch, _capi, handle, args, dev):
                 cut.append(np.stack([ch[0][t0:t0 + n], ch[1][t0:t0 + n]]))
         cut = np.stack(cut)
         real = torch.from_numpy(np.ascontiguousarray(np.tile(cut, ((F + len(cut) - 1) // len(cut), 1, 1))[:F])).to(dev)
-        for order in (8, 10, 12):
-            rcfg = _capi.make_frame_config(_capi.make_config(lpc_order=order), use_fixed=False)
+        for order, fixed in ((8, False), (10, False), (12, False), (10, True)):
+            rcfg = _capi.make_frame_config(_capi.make_config(lpc_order=order), use_fixed=fixed)
             ms = timed(lambda: handle.encode_stereo_frames_device(rcfg, real.data_ptr(), F, n, n, bps, results.data_ptr(),
                                                                   residual.data_ptr(), n, stream=stream.cuda_stream))
             cst = torch.zeros(3, dtype=torch.int32, device=dev)
@@ -677,9 +677,10 @@ def secondary(torch, _capi, handle, args, dev):
             torch.cuda.synchronize()
             handle.debug_set_cert_stats(0)
             analysed, _tier2, redone = (int(v) for v in cst.cpu().tolist())
-            sec["real_audio_fixtures_order%d" % order] = entry(ms, {
-                "what": "headline kernel (frame decision, no fixed-LPC candidate) on %d distinct stereo frames cut from the "
-                        "reference's real-audio test fixtures, tiled to the batch" % len(cut),
+            sec["real_audio_fixtures_default_config_order10" if fixed else "real_audio_fixtures_order%d" % order] = entry(ms, {
+                "what": "%s on %d distinct stereo frames cut from the reference's real-audio test fixtures, tiled to the batch" % (
+                    "the reference's default configuration (order 10, fixed-LPC candidate)" if fixed
+                    else "headline kernel (frame decision, no fixed-LPC candidate)", len(cut)),
                 "subframe_bits_per_sample": bits_per_sample(),
                 "certificate_recomputed_fraction": round(redone / analysed, 4) if analysed else None})
         del real

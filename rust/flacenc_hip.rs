@@ -1,23 +1,38 @@
 //! flacenc_hip.rs -- Rust side of the drop-in boundary (SOURCE ONLY: there is no rustc in the
 //! build image, so this file has never been compiled; the executable host mirror is the C++
-//! header `flacenc_rs_amd/host/flacenc.hpp`, which follows the same structure).
+//! header `flacenc_rs_amd/host/flacenc.hpp`, which follows the same structure, and
+//! `tests/test_rust_binding.py` holds the `extern "C"` block and the `#[repr(C)]` structs below to
+//! `include/flacenc_hip.h` -- every export, arity, argument type, field and constant).
 //!
 //! A maintainer adds this module to the crate (`mod gpu;` behind a `hip` cargo feature), links
 //! `libflacenc_hip.so` (`build.rs`: `println!("cargo:rustc-link-lib=dylib=flacenc_hip")`), and
-//! branches to it where `encode_with_fixed_block_size` already branches on `config.multithread`
-//! (`src/coding.rs:650-655`).  Nothing else in the crate changes: the controller
-//! (`encode_subframe` `src/coding.rs:384`, `try_stereo_coding` `:469`) keeps running on the
-//! host and receives its `estimated_qlpc` candidates from the GPU.
+//! branches to `gpu::encode_with_fixed_block_size` where `encode_with_fixed_block_size` already
+//! branches on `config.multithread` (`src/coding.rs:650-655`).  Three levels, as in the header:
+//!
+//!   * `encode_with_fixed_block_size`             the whole of `encode_fixed_size_frame` + `Frame::write` on the GPU;
+//!                                                frames come back as bytes (`flacenc_hip_encode_pcm`)
+//!   * `encode_with_fixed_block_size_components`  `encode_frame`'s decisions on the GPU, `component::SubFrame`s rebuilt
+//!                                                on the host (`flacenc_hip_encode_[stereo_]frames` + `*_from_record`)
+//!   * `estimated_qlpc_batch`                     candidates only: the controller (`encode_subframe` `src/coding.rs:384`,
+//!                                                `try_stereo_coding` `:469`) stays on the host
+//!
+//! The one change outside this module: `Frame::set_precomputed_bitstream` (see the comment above
+//! `encode_with_fixed_block_size` below).
 
 use std::os::raw::{c_char, c_int, c_void};
 
-use crate::component::{Lpc, QuantizedParameters, Residual, SubFrame};
+use crate::component::{
+    BlockSizeSpec, ChannelAssignment, Constant, Frame, FrameOffset, Lpc, QuantizedParameters, Residual, SampleRateSpec,
+    SampleSizeSpec, Stream, SubFrame, Verbatim,
+};
 use crate::config;
-use crate::error::{EncodeError, Verified, VerifyError};
+use crate::error::{EncodeError, SourceError, SourceErrorReason, Verified, VerifyError};
+use crate::source::{Context, Fill, FrameBuf, Source};
 
 pub const OK: c_int = 0;
 pub const ERR_BAD_CONFIG: c_int = -1;
 pub const MEM_HOST: c_int = 0;
+pub const MEM_DEVICE: c_int = 1;
 /// `flags` of `QlpcConfig` (include/flacenc_hip.h).  The two order flags make the order-sensitive sums of the path
 /// the ones of a CPU build, bit for bit: the stable build's (`weighted_auto_correlation_nosimd`, `src/lpc.rs:533-548`;
 /// `find_sum_abs_f32` over `slice_as_simd = (data, [], [])`, `src/arrayutils.rs:435-506`) or the `simd-nightly`
@@ -121,6 +136,24 @@ pub struct StereoFrameResult {
     pub lpc: [SubframeParams; 2],
 }
 
+/// `flacenc_hip_channel_result`: 368 bytes, what `encode_subframe` (`src/coding.rs:384-418`) decided for one channel of
+/// an `Independent(n)` frame (`encode_frame` for channel counts other than 2, `src/coding.rs:537-541`).
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct ChannelResult {
+    pub kind: u8,            // 0 Constant, 1 Verbatim, 2 FixedLpc, 3 Lpc
+    pub analysis_status: u8, // status bits of this channel's LPC analysis
+    pub pad: [u8; 2],
+    pub dc_offset: i32,
+    pub bits: u64,
+    pub params: SubframeParams,
+}
+
+pub const KIND_CONSTANT: u8 = 0;
+pub const KIND_VERBATIM: u8 = 1;
+pub const KIND_FIXED: u8 = 2;
+pub const KIND_LPC: u8 = 3;
+
 #[repr(C)]
 pub struct Handle {
     _private: [u8; 0],
@@ -159,7 +192,7 @@ extern "C" {
     /// delivers them).  Device pointers; `stream` is a hipStream_t.
     pub fn flacenc_hip_frame_wire_bytes(block_size: u32) -> usize;
     pub fn flacenc_hip_stereo_frame_wire_async(
-        h: *mut Handle, results: *const core::ffi::c_void, n_frames: usize, block_size: u32, bits_per_sample: u32,
+        h: *mut Handle, results: *const StereoFrameResult, n_frames: usize, block_size: u32, bits_per_sample: u32,
         sample_rate: u32, first_frame_number: u32, frame_number_step: u32, wire: *mut u8, wire_stride: usize,
         out_len: *mut u32, stream: *mut core::ffi::c_void,
     ) -> c_int;
@@ -222,6 +255,80 @@ extern "C" {
         residual: *mut i32, residual_stride: usize, autocorr: *mut f64, lpc_coefs: *mut f64,
         stream: *mut c_void,
     ) -> c_int;
+    // ---- the rest of include/flacenc_hip.h (tests/test_rust_binding.py holds this block to the header: every export,
+    // ---- same arity, same argument classes)
+    pub fn flacenc_hip_device_count() -> c_int;
+    /// `lpc::window_weights` (`src/lpc.rs:96-120`) as the kernels use it.
+    pub fn flacenc_hip_window_weights(cfg: *const QlpcConfig, block_size: u32, out: *mut f32) -> c_int;
+    pub fn flacenc_hip_stereo_qlpc_batch_async(
+        h: *mut Handle, cfg: *const QlpcConfig, frames: *const i32, n_frames: usize, block_size: u32, stride: usize,
+        bits_per_sample: u32, params: *mut SubframeParams, residual: *mut i32, residual_stride: usize,
+        stream: *mut c_void,
+    ) -> c_int;
+    pub fn flacenc_hip_encode_stereo_frames_async(
+        h: *mut Handle, cfg: *const FrameConfig, frames: *const i32, n_frames: usize, block_size: u32, stride: usize,
+        bits_per_sample: u32, results: *mut StereoFrameResult, residual: *mut i32, residual_stride: usize,
+        stream: *mut c_void,
+    ) -> c_int;
+    pub fn flacenc_hip_fixed_lpc_batch_async(
+        h: *mut Handle, cfg: *const FrameConfig, samples: *const i32, n_units: usize, block_size: u32, stride: usize,
+        bps: *const u8, bits_per_sample: u32, layout: c_int, params: *mut SubframeParams, residual: *mut i32,
+        residual_stride: usize, selector_keys: *mut u64, stream: *mut c_void,
+    ) -> c_int;
+    pub fn flacenc_hip_pack_stereo_frames_async(
+        h: *mut Handle, frames: *const i32, n_frames: usize, block_size: u32, stride: usize,
+        results: *const StereoFrameResult, residual: *const i32, residual_stride: usize, bits_per_sample: u32,
+        sample_rate: u32, first_frame_number: u32, frame_number_step: u32, out: *mut u8, out_stride: usize,
+        out_len: *mut u32, stream: *mut c_void,
+    ) -> c_int;
+    /// `encode_frame` for 1 or 3..=8 independent channels (`src/coding.rs:537-541`), decision on the GPU.
+    pub fn flacenc_hip_encode_frames(
+        h: *mut Handle, cfg: *const FrameConfig, frames: *const i32, n_frames: usize, channels: u32, block_size: u32,
+        stride: usize, bits_per_sample: u32, results: *mut ChannelResult, residual: *mut i32, residual_stride: usize,
+        memory_kind: c_int,
+    ) -> c_int;
+    pub fn flacenc_hip_encode_frames_async(
+        h: *mut Handle, cfg: *const FrameConfig, frames: *const i32, n_frames: usize, channels: u32, block_size: u32,
+        stride: usize, bits_per_sample: u32, results: *mut ChannelResult, residual: *mut i32, residual_stride: usize,
+        stream: *mut c_void,
+    ) -> c_int;
+    pub fn flacenc_hip_frame_bytes_bound(channels: u32, block_size: u32, bits_per_sample: u32) -> usize;
+    pub fn flacenc_hip_pack_frames(
+        h: *mut Handle, frames: *const i32, n_frames: usize, channels: u32, block_size: u32, stride: usize,
+        results: *const ChannelResult, residual: *const i32, residual_stride: usize, bits_per_sample: u32,
+        sample_rate: u32, first_frame_number: u32, frame_number_step: u32, out: *mut u8, out_stride: usize,
+        out_len: *mut u32, memory_kind: c_int,
+    ) -> c_int;
+    pub fn flacenc_hip_pack_frames_async(
+        h: *mut Handle, frames: *const i32, n_frames: usize, channels: u32, block_size: u32, stride: usize,
+        results: *const ChannelResult, residual: *const i32, residual_stride: usize, bits_per_sample: u32,
+        sample_rate: u32, first_frame_number: u32, frame_number_step: u32, out: *mut u8, out_stride: usize,
+        out_len: *mut u32, stream: *mut c_void,
+    ) -> c_int;
+    /// `encode_fixed_size_frame` + `Frame::write` for a run of frames in HBM (`src/coding.rs:581-606`).
+    pub fn flacenc_hip_encode_pack_stereo_frames_async(
+        h: *mut Handle, cfg: *const FrameConfig, frames: *const i32, n_frames: usize, block_size: u32, stride: usize,
+        bits_per_sample: u32, sample_rate: u32, first_frame_number: u32, frame_number_step: u32,
+        results: *mut StereoFrameResult, out: *mut u8, out_stride: usize, out_len: *mut u32, stream: *mut c_void,
+    ) -> c_int;
+    pub fn flacenc_hip_encode_pack_frames_async(
+        h: *mut Handle, cfg: *const FrameConfig, frames: *const i32, n_frames: usize, channels: u32, block_size: u32,
+        stride: usize, bits_per_sample: u32, sample_rate: u32, first_frame_number: u32, frame_number_step: u32,
+        results: *mut ChannelResult, out: *mut u8, out_stride: usize, out_len: *mut u32, stream: *mut c_void,
+    ) -> c_int;
+    pub fn flacenc_hip_stereo_frame_lengths_async(
+        h: *mut Handle, results: *const StereoFrameResult, n_frames: usize, block_size: u32, bits_per_sample: u32,
+        sample_rate: u32, first_frame_number: u32, frame_number_step: u32, out_len: *mut u32, stream: *mut c_void,
+    ) -> c_int;
+    pub fn flacenc_hip_place_frames_async(
+        h: *mut Handle, src: *const u8, src_offsets: *const u64, lengths: *const u32, n_frames: usize, dst: *mut u8,
+        dst_offsets: *const u64, stream: *mut c_void,
+    ) -> c_int;
+    pub fn flacenc_hip_fill_le_bytes_async(
+        h: *mut Handle, bytes: *const u8, total_samples: u64, channels: u32, bytes_per_sample: u32, n_frames: usize,
+        block_size: u32, frames: *mut i32, stride: usize, stream: *mut c_void,
+    ) -> c_int;
+    pub fn flacenc_hip_synchronize(h: *mut Handle) -> c_int;
 }
 
 /// One handle per host thread, like the crate's `reusable!` thread-locals (`src/lib.rs:92-116`).
@@ -387,6 +494,322 @@ pub fn estimated_qlpc_batch(
         ERR_BAD_CONFIG => Err(EncodeError::Config(VerifyError::new("subframe_coding", "rejected by the GPU path"))),
         _ => panic!("flacenc_hip device error"), // the reference panics on internal errors too
     }
+}
+
+// =====================================================================================================================
+// `gpu::encode_with_fixed_block_size`: the branch `coding::encode_with_fixed_block_size` (`src/coding.rs:645-676`) takes
+// next to its `par` branch (`:650-655`).  Same signature, same `Stream` out.  Two shapes:
+//
+//   * `encode_with_fixed_block_size`            frame BYTES from the GPU (`flacenc_hip_encode_pcm`): what a file encoder
+//                                               needs.  Frames carry their header and `precomputed_bitstream`, no SubFrames.
+//   * `encode_with_fixed_block_size_components` `component::SubFrame`s rebuilt from the GPU's decision records through
+//                                               the crate's own `from_parts` constructors: for callers that inspect them.
+//
+// Both follow `par::encode_with_fixed_block_size` (`src/par.rs:355-449`) step for step: `Stream::new`, a feed loop that
+// drains the `Source` into buffers with the MD5 / sample-count `Context` riding along as the second half of a `Fill`
+// pair (`src/par.rs:288-325`), the frames added in frame-number order (`ParSink::finalize`, `:82-94` -- here the order
+// of the batch), then STREAMINFO: MD5, `set_block_sizes(max, max)` and `set_total_samples` (`src/par.rs:425-447`).
+//
+// The one addition the crate needs outside this module: `Frame::set_precomputed_bitstream(&mut self, Vec<u8>)` next to
+// `Frame::precompute_bitstream` (`src/component/datatype.rs:1036-1045`); the field is private to that module.
+// `BitRepr for Frame` already serves `count_bits` and `write` from it (`src/component/bitrepr.rs:275-293`).
+// =====================================================================================================================
+
+/// Frames per GPU call: bounds the host buffers of a run (4096 stereo frames of 4096 16-bit samples = 64 MiB of PCM);
+/// `flacenc_hip_encode_pcm` cuts a run into chunks of 768..8192 frames itself and overlaps their transfers.
+pub const FRAMES_PER_RUN: usize = 4096;
+
+/// A `Fill` (`src/source.rs:42-82`) that keeps what a `Source` hands over as packed little-endian interleaved PCM --
+/// the form `flacenc_hip_encode_pcm` uploads (2..3 bytes per sample over PCIe instead of the 4 of a `FrameBuf`).
+pub struct PcmRun {
+    bytes: Vec<u8>,
+    bytes_per_sample: usize,
+    channels: usize,
+    frames: usize,
+}
+
+impl PcmRun {
+    pub fn new(bits_per_sample: usize, channels: usize) -> Self {
+        Self { bytes: Vec::new(), bytes_per_sample: bits_per_sample.div_ceil(8), channels, frames: 0 }
+    }
+    fn clear(&mut self) {
+        self.bytes.clear();
+        self.frames = 0;
+    }
+    /// inter-channel samples held
+    fn samples(&self) -> usize {
+        self.bytes.len() / self.bytes_per_sample / self.channels
+    }
+}
+
+impl Fill for PcmRun {
+    fn fill_interleaved(&mut self, interleaved: &[i32]) -> Result<(), SourceError> {
+        for v in interleaved {
+            self.bytes.extend_from_slice(&v.to_le_bytes()[..self.bytes_per_sample]); // as Context hashes them, source.rs:411
+        }
+        self.frames += usize::from(!interleaved.is_empty());
+        Ok(())
+    }
+    fn fill_le_bytes(&mut self, bytes: &[u8], bytes_per_sample: usize) -> Result<(), SourceError> {
+        if bytes_per_sample != self.bytes_per_sample {
+            return Err(SourceError::by_reason(SourceErrorReason::InvalidBuffer)); // a sample width the run was not set up for
+        }
+        self.bytes.extend_from_slice(bytes);
+        self.frames += usize::from(!bytes.is_empty());
+        Ok(())
+    }
+}
+
+fn map_rc(rc: c_int, what: &str) -> Result<(), EncodeError> {
+    match rc {
+        OK => Ok(()),
+        ERR_BAD_CONFIG => Err(EncodeError::Config(VerifyError::new("gpu", what))),
+        _ => panic!("flacenc_hip device error in {what}"), // the reference panics on internal errors too
+    }
+}
+
+/// `ChannelAssignment` from the 4-bit code of a frame header (`src/component/bitrepr.rs:373-419`; byte 3, high nibble).
+fn channel_assignment_from_code(code: u8) -> ChannelAssignment {
+    match code {
+        8 => ChannelAssignment::LeftSide,
+        9 => ChannelAssignment::RightSide,
+        10 => ChannelAssignment::MidSide,
+        n => ChannelAssignment::Independent(n + 1),
+    }
+}
+
+fn empty_frame(block: usize, ch: ChannelAssignment, bits_per_sample: usize, sample_rate: usize, number: usize) -> Frame {
+    // the specs exactly as encode_frame_impl chooses them (src/coding.rs:431-436)
+    let mut frame = Frame::new_empty(
+        BlockSizeSpec::from_size(block as u16),
+        ch,
+        SampleSizeSpec::from_bits(bits_per_sample as u8).unwrap_or(SampleSizeSpec::Unspecified),
+        SampleRateSpec::from_freq(sample_rate as u32).unwrap_or(SampleRateSpec::Unspecified),
+    );
+    frame.header_mut().set_frame_offset(FrameOffset::Frame(number as u32)); // encode_fixed_size_frame, src/coding.rs:602-604
+    frame
+}
+
+fn finalize_stream(stream: &mut Stream, context: &Context, len_hint: Option<usize>) {
+    // src/coding.rs:677-693 = src/par.rs:425-447
+    if stream.frame_count() > 0 {
+        let max_block_size = stream.stream_info().max_block_size();
+        stream.stream_info_mut().set_block_sizes(max_block_size, max_block_size).unwrap();
+    }
+    stream.stream_info_mut().set_md5_digest(&context.md5_digest());
+    stream.stream_info_mut().set_total_samples(len_hint.unwrap_or_else(|| context.total_samples()));
+}
+
+/// Shape 1, bytes: `Source` -> packed PCM runs -> `flacenc_hip_encode_pcm` -> frames with precomputed bitstreams.
+///
+/// Mirror of `coding::encode_with_fixed_block_size` (`src/coding.rs:645-676`) / `par::encode_with_fixed_block_size`
+/// (`src/par.rs:355-449`) with the GPU as the worker pool: the whole of `encode_fixed_size_frame` + `Frame::write`
+/// (candidates, `encode_subframe`, `try_stereo_coding`, bit writer, CRCs) runs on the device.
+pub fn encode_with_fixed_block_size<T: Source>(
+    config: &Verified<config::Encoder>, mut src: T, block_size: usize,
+) -> Result<Stream, EncodeError> {
+    let gpu = Gpu::new(0)?;
+    let (channels, bits_per_sample, sample_rate) = (src.channels(), src.bits_per_sample(), src.sample_rate());
+    let mut stream = Stream::new(sample_rate, channels, bits_per_sample)?;
+    let frame_cfg = FrameConfig::from_encoder(config, gpu.sum_order());
+    let mut run_and_context = (PcmRun::new(bits_per_sample, channels), Context::new(bits_per_sample, channels));
+    let bound = unsafe { flacenc_hip_frame_bytes_bound(channels as u32, block_size as u32, bits_per_sample as u32) };
+    let mut out = vec![0u8; bound * FRAMES_PER_RUN];
+    let mut lens = vec![0u32; FRAMES_PER_RUN];
+    let mut first_frame = 0usize;
+    loop {
+        // the feed loop (src/par.rs:288-325), a run of frames at a time
+        run_and_context.0.clear();
+        let mut last_read = block_size;
+        while run_and_context.0.frames < FRAMES_PER_RUN && last_read == block_size {
+            last_read = src.read_samples(block_size, &mut run_and_context)?;
+            if last_read == 0 {
+                break;
+            }
+        }
+        let run = &run_and_context.0;
+        if run.frames == 0 {
+            break;
+        }
+        let mut written = 0u64;
+        map_rc(
+            unsafe {
+                flacenc_hip_encode_pcm(
+                    gpu.0, &frame_cfg, run.bytes.as_ptr(), run.samples() as u64, channels as u32,
+                    run.bytes_per_sample as u32, bits_per_sample as u32, block_size as u32, sample_rate as u32,
+                    first_frame as u32, 1, out.as_mut_ptr(), out.len(), lens.as_mut_ptr(), &mut written,
+                )
+            },
+            "flacenc_hip_encode_pcm",
+        )?;
+        // ParSink::finalize (src/par.rs:82-94): frames come back in frame-number order already
+        let mut off = 0usize;
+        let mut remaining = run.samples();
+        for f in 0..run.frames {
+            let bytes = out[off..off + lens[f] as usize].to_vec();
+            off += lens[f] as usize;
+            let block = remaining.min(block_size);
+            remaining -= block;
+            let mut frame =
+                empty_frame(block, channel_assignment_from_code(bytes[3] >> 4), bits_per_sample, sample_rate, first_frame + f);
+            frame.set_precomputed_bitstream(bytes);
+            stream.add_frame(frame);
+        }
+        first_frame += run.frames;
+        if last_read < block_size {
+            break; // a short (or empty) read ends the stream, as `read_samples == 0` does after it in the serial loop
+        }
+    }
+    finalize_stream(&mut stream, &run_and_context.1, src.len_hint());
+    Ok(stream)
+}
+
+/// The signal of output channel role `role` (0 L, 1 R, 2 M, 3 S) of a stereo frame: warm-up samples and Verbatim
+/// bodies are taken from it (`try_stereo_coding`'s MSFRAMEBUF, `src/coding.rs:476-491`).
+fn role_signal(l: &[i32], r: &[i32], role: u8) -> Vec<i32> {
+    match role {
+        0 => l.to_vec(),
+        1 => r.to_vec(),
+        2 => l.iter().zip(r).map(|(a, b)| (a + b) >> 1).collect(),
+        _ => l.iter().zip(r).map(|(a, b)| a - b).collect(),
+    }
+}
+
+/// One `SubFrame` from what `encode_subframe` (`src/coding.rs:384-418`) decided on the GPU.
+fn subframe_from_decision(kind: u8, dc_offset: i32, p: &SubframeParams, residual: &[i32], signal: &[i32], bps: u8) -> SubFrame {
+    match kind {
+        KIND_CONSTANT => Constant::from_parts(signal.len(), dc_offset, bps).into(),
+        KIND_VERBATIM => Verbatim::from_samples(signal, bps).into(),
+        KIND_FIXED => fixed_lpc_from_record(p, residual, signal, bps),
+        _ => lpc_from_record(p, residual, signal, bps),
+    }
+}
+
+/// Shape 2, components: K `FrameBuf`s per call -> `flacenc_hip_encode_stereo_frames` (2 channels) or
+/// `flacenc_hip_encode_frames` (1, 3..=8) -> `Frame`s of real `SubFrame`s, bit writer and CRCs on the host as in the
+/// serial encoder.  `frames_per_call` `FrameBuf`s are alive at once (`par`'s `workers * FRAMEBUF_MULTIPLICITY`,
+/// `src/par.rs:364-368`).
+pub fn encode_with_fixed_block_size_components<T: Source>(
+    config: &Verified<config::Encoder>, mut src: T, block_size: usize, frames_per_call: usize,
+) -> Result<Stream, EncodeError> {
+    let gpu = Gpu::new(0)?;
+    let (channels, bits_per_sample, sample_rate) = (src.channels(), src.bits_per_sample(), src.sample_rate());
+    let mut stream = Stream::new(sample_rate, channels, bits_per_sample)?;
+    let frame_cfg = FrameConfig::from_encoder(config, gpu.sum_order());
+    let mut context = Context::new(bits_per_sample, channels);
+    let mut framebufs: Vec<FrameBuf> = Vec::new();
+    for _ in 0..frames_per_call {
+        framebufs.push(FrameBuf::with_size(channels, block_size)?);
+    }
+    let mut staged = vec![0i32; frames_per_call * channels * block_size];
+    let mut residual = vec![0i32; frames_per_call * channels * block_size];
+    let mut stereo = vec![unsafe { std::mem::zeroed::<StereoFrameResult>() }; if channels == 2 { frames_per_call } else { 0 }];
+    let mut indep = vec![unsafe { std::mem::zeroed::<ChannelResult>() }; if channels == 2 { 0 } else { frames_per_call * channels }];
+    let mut first_frame = 0usize;
+    let mut done = false;
+    while !done {
+        // fill up to K FrameBufs (src/par.rs:288-325); a batch holds frames of ONE block size, so a short last block
+        // is a batch of its own
+        let mut k = 0usize;
+        let mut batch_block = block_size;
+        while k < frames_per_call {
+            let read = src.read_samples(block_size, &mut (&mut framebufs[k], &mut context))?;
+            if read == 0 {
+                done = true;
+                break;
+            }
+            framebufs[k].verify_samples(bits_per_sample)?; // encode_fixed_size_frame, src/coding.rs:593
+            if read < block_size {
+                done = true;
+                if k > 0 {
+                    encode_component_batch(
+                        &gpu, &frame_cfg, &framebufs[..k], block_size, channels, bits_per_sample, sample_rate, first_frame,
+                        &mut staged, &mut residual, &mut stereo, &mut indep, &mut stream,
+                    )?;
+                    first_frame += k;
+                    framebufs.swap(0, k);
+                }
+                k = 1;
+                batch_block = read;
+                break;
+            }
+            k += 1;
+        }
+        if k > 0 {
+            encode_component_batch(
+                &gpu, &frame_cfg, &framebufs[..k], batch_block, channels, bits_per_sample, sample_rate, first_frame,
+                &mut staged, &mut residual, &mut stereo, &mut indep, &mut stream,
+            )?;
+            first_frame += k;
+        }
+    }
+    finalize_stream(&mut stream, &context, src.len_hint());
+    Ok(stream)
+}
+
+#[allow(clippy::too_many_arguments)]
+fn encode_component_batch(
+    gpu: &Gpu, frame_cfg: &FrameConfig, framebufs: &[FrameBuf], block: usize, channels: usize, bits_per_sample: usize,
+    sample_rate: usize, first_frame: usize, staged: &mut [i32], residual: &mut [i32], stereo: &mut [StereoFrameResult],
+    indep: &mut [ChannelResult], stream: &mut Stream,
+) -> Result<(), EncodeError> {
+    let k = framebufs.len();
+    // FrameBuf::channel_slice IS the ABI's layout: channel c of frame f at (f * channels + c) * stride
+    for (f, fb) in framebufs.iter().enumerate() {
+        for c in 0..channels {
+            staged[(f * channels + c) * block..][..block].copy_from_slice(fb.channel_slice(c));
+        }
+    }
+    if channels == 2 {
+        map_rc(
+            unsafe {
+                flacenc_hip_encode_stereo_frames(
+                    gpu.0, frame_cfg, staged.as_ptr(), k, block as u32, block, bits_per_sample as u32,
+                    stereo.as_mut_ptr(), residual.as_mut_ptr(), block, MEM_HOST,
+                )
+            },
+            "flacenc_hip_encode_stereo_frames",
+        )?;
+        for f in 0..k {
+            let res = &stereo[f];
+            assert_eq!(res.analysis_status, 0, "the reference panics on these LPC statistics (lpc.rs:646, :786-799)");
+            let ch_info = channel_assignment_from_code(if res.channel_assignment == 0 { 1 } else { 7 + res.channel_assignment });
+            let (l, r) = (&staged[(2 * f) * block..][..block], &staged[(2 * f + 1) * block..][..block]);
+            let mut frame = empty_frame(block, ch_info.clone(), bits_per_sample, sample_rate, first_frame + f);
+            for c in 0..2 {
+                let signal = role_signal(l, r, res.role[c]);
+                let bps = (bits_per_sample + ch_info.bits_per_sample_offset(c)) as u8; // src/coding.rs:444
+                frame.add_subframe(subframe_from_decision(
+                    res.kind[c], res.dc_offset[c], &res.lpc[c], &residual[(2 * f + c) * block..][..block], &signal, bps,
+                ));
+            }
+            stream.add_frame(frame);
+        }
+    } else {
+        map_rc(
+            unsafe {
+                flacenc_hip_encode_frames(
+                    gpu.0, frame_cfg, staged.as_ptr(), k, channels as u32, block as u32, block, bits_per_sample as u32,
+                    indep.as_mut_ptr(), residual.as_mut_ptr(), block, MEM_HOST,
+                )
+            },
+            "flacenc_hip_encode_frames",
+        )?;
+        for f in 0..k {
+            let mut frame =
+                empty_frame(block, ChannelAssignment::Independent(channels as u8), bits_per_sample, sample_rate, first_frame + f);
+            for c in 0..channels {
+                let i = f * channels + c;
+                assert_eq!(indep[i].analysis_status, 0, "the reference panics on these LPC statistics (lpc.rs:646, :786-799)");
+                frame.add_subframe(subframe_from_decision(
+                    indep[i].kind, indep[i].dc_offset, &indep[i].params, &residual[i * block..][..block],
+                    &staged[i * block..][..block], bits_per_sample as u8,
+                ));
+            }
+            stream.add_frame(frame);
+        }
+    }
+    Ok(())
 }
 
 /// `FLACENC_HIP_COMM_ID_BYTES`

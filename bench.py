@@ -670,12 +670,15 @@ def secondary(torch, _capi, handle, args, dev):
             rcfg = _capi.make_frame_config(_capi.make_config(lpc_order=order), use_fixed=fixed)
             ms = timed(lambda: handle.encode_stereo_frames_device(rcfg, real.data_ptr(), F, n, n, bps, results.data_ptr(),
                                                                   residual.data_ptr(), n, stream=stream.cuda_stream))
+            # (the certificate's counters: a hook of the test build, libflacenc_hip_hooks.so -- the same kernel objects; the
+            # timed launches above ran on the product library's handle)
             cst = torch.zeros(3, dtype=torch.int32, device=dev)
-            handle.debug_set_cert_stats(cst.data_ptr())
-            handle.encode_stereo_frames_device(rcfg, real.data_ptr(), F, n, n, bps, results.data_ptr(), residual.data_ptr(), n,
-                                               stream=stream.cuda_stream)
+            hk = hooks_handle(_capi, dev)
+            hk.debug_set_cert_stats(cst.data_ptr())
+            hk.encode_stereo_frames_device(rcfg, real.data_ptr(), F, n, n, bps, results.data_ptr(), residual.data_ptr(), n,
+                                           stream=stream.cuda_stream)
             torch.cuda.synchronize()
-            handle.debug_set_cert_stats(0)
+            hk.debug_set_cert_stats(0)
             analysed, _tier2, redone = (int(v) for v in cst.cpu().tolist())
             sec["real_audio_fixtures_default_config_order10" if fixed else "real_audio_fixtures_order%d" % order] = entry(ms, {
                 "what": "%s on %d distinct stereo frames cut from the reference's real-audio test fixtures, tiled to the batch" % (
@@ -954,6 +957,17 @@ def usable_cores():
     return cores
 
 
+_HOOKS_HANDLE = {}
+
+
+def hooks_handle(_capi, dev):
+    """One handle of the hooks build per device, made on first use and never inside a timed region."""
+    idx = dev.index if hasattr(dev, "index") and dev.index is not None else 0
+    if idx not in _HOOKS_HANDLE:
+        _HOOKS_HANDLE[idx] = _capi.Handle(idx, hooks=True)
+    return _HOOKS_HANDLE[idx]
+
+
 def reference_identity(torch, _capi, handle, args, host, x, results, residual, cfg, n, bps, F):
     """How the default mode relates to the reference's stable build (src/lpc.rs:533-548), measured after the timed region:
     `reference_identical_fraction` = frames of a sample whose decision record and two residual rows equal the oracle's in
@@ -964,11 +978,12 @@ def reference_identity(torch, _capi, handle, args, host, x, results, residual, c
     from oracle import oracle as orc
 
     stats = torch.zeros(3, dtype=torch.int32, device=x.device)
-    handle.debug_set_cert_stats(stats.data_ptr())
-    handle.encode_stereo_frames_device(cfg, x.data_ptr(), F, n, n, bps, results.data_ptr(), residual.data_ptr(), n,
-                                       stream=torch.cuda.current_stream().cuda_stream)
+    hk = hooks_handle(_capi, x.device)  # (libflacenc_hip_hooks.so: the product's kernel objects + the counters' hook)
+    hk.debug_set_cert_stats(stats.data_ptr())
+    hk.encode_stereo_frames_device(cfg, x.data_ptr(), F, n, n, bps, results.data_ptr(), residual.data_ptr(), n,
+                                   stream=torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
-    handle.debug_set_cert_stats(0)
+    hk.debug_set_cert_stats(0)
     analysed, tier2, redone = (int(v) for v in stats.cpu().tolist())
     K = min(F, 384)
     g = np.frombuffer(results[:K].cpu().numpy().tobytes(), dtype=_capi.FRAME_RESULT_DTYPE)

@@ -16,6 +16,10 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # FLACENC_HIP_LIB: development aid for A/B timing of two builds on one GPU box; never a fallback
 LIB_PATH = os.environ.get("FLACENC_HIP_LIB") or os.path.join(_HERE, "libflacenc_hip.so")
+# The same objects + the test / profiling hooks of csrc/flacenc_hip_debug.h (the product library has none of them):
+# what Handle(dev, hooks=True) loads.  An A/B library named by FLACENC_HIP_LIB (tools/variant_*.sh build them with the
+# hooks) serves both.
+HOOKS_LIB_PATH = os.environ.get("FLACENC_HIP_LIB") or os.path.join(_HERE, "libflacenc_hip_hooks.so")
 
 OK = 0
 ERR_BAD_CONFIG = -1
@@ -191,14 +195,22 @@ class FlacencHipError(RuntimeError):
         super().__init__(f"flacenc_hip error {_ERR_NAMES.get(code, code)}: {message}")
 
 
-_lib = None
+_libs = {}
 
 
 def load() -> C.CDLL:
-    """Load libflacenc_hip.so; raises if it has not been built (no fallback)."""
-    global _lib
-    if _lib is not None:
-        return _lib
+    """Load libflacenc_hip.so (the product library); raises if it has not been built (no fallback)."""
+    return _load_path(LIB_PATH)
+
+
+def load_hooks() -> C.CDLL:
+    """Load libflacenc_hip_hooks.so: the product's objects + flacenc_hip_debug_* (tests and tools only)."""
+    return _load_path(HOOKS_LIB_PATH)
+
+
+def _load_path(LIB_PATH: str) -> C.CDLL:
+    if LIB_PATH in _libs:
+        return _libs[LIB_PATH]
     if not os.path.exists(LIB_PATH):
         raise FileNotFoundError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`"
@@ -344,7 +356,7 @@ def load() -> C.CDLL:
                                                     C.c_uint32, C.c_float, C.c_float, C.c_float,
                                                     C.c_uint64, C.c_uint64, C.c_uint64, C.c_int]
     L.flacenc_sigen_fill_frames_strided.restype = C.c_int
-    _lib = L
+    _libs[LIB_PATH] = L
     return L
 
 
@@ -422,8 +434,9 @@ def pinned_array(nbytes: int) -> np.ndarray:
 class Handle:
     """RAII wrapper of flacenc_hip_handle (one per host thread / GPU)."""
 
-    def __init__(self, device_id: int = 0):
-        self._lib = load()
+    def __init__(self, device_id: int = 0, hooks: bool = False):
+        """hooks=True: a handle of libflacenc_hip_hooks.so, the only one the debug_* methods below work on."""
+        self._lib = load_hooks() if hooks else load()
         self._h = C.c_void_p()
         rc = self._lib.flacenc_hip_create(C.byref(self._h), device_id)
         if rc != OK:
@@ -450,26 +463,31 @@ class Handle:
         if rc != OK:
             raise FlacencHipError(rc, self._lib.flacenc_hip_last_error(self._h).decode())
 
+    def _hook(self, name):
+        if not hasattr(self._lib, name):
+            raise RuntimeError(name + " is not in the product library: make the handle with Handle(dev, hooks=True)")
+        return getattr(self._lib, name)
+
     def debug_set_fixed_keys(self, device_ptr: int):
-        self._check(self._lib.flacenc_hip_debug_set_fixed_keys(self._h, device_ptr or None))
+        self._check(self._hook("flacenc_hip_debug_set_fixed_keys")(self._h, device_ptr or None))
 
     def debug_set_stamps(self, device_ptr: int):
-        self._check(self._lib.flacenc_hip_debug_set_stamps(self._h, device_ptr or None))
+        self._check(self._hook("flacenc_hip_debug_set_stamps")(self._h, device_ptr or None))
 
     def debug_set_cert_stats(self, device_ptr: int):
         """3 x uint32 on the device: subframes certified launches analysed, certificates that needed the rows of T^-1,
         subframes recomputed from the reference's chains (flacenc_hip_debug.h)."""
-        self._check(self._lib.flacenc_hip_debug_set_cert_stats(self._h, device_ptr or None))
+        self._check(self._hook("flacenc_hip_debug_set_cert_stats")(self._h, device_ptr or None))
 
     def debug_set_adaptive_order(self, on: bool):
         """Launches of the certified shapes that return integers only switch to the two-pass form on hard material
         (flacenc_hip_debug.h); off pins the fused kernel's certificate."""
-        self._check(self._lib.flacenc_hip_debug_set_adaptive_order(self._h, 1 if on else 0))
+        self._check(self._hook("flacenc_hip_debug_set_adaptive_order")(self._h, 1 if on else 0))
 
     def debug_adaptive_state(self):
         """(span, left) of the adaptive order mode: span 0 = the material last seen was easy."""
         span, left = C.c_int(0), C.c_int(0)
-        self._check(self._lib.flacenc_hip_debug_adaptive_state(self._h, C.byref(span), C.byref(left)))
+        self._check(self._hook("flacenc_hip_debug_adaptive_state")(self._h, C.byref(span), C.byref(left)))
         return span.value, left.value
 
     def synchronize(self):

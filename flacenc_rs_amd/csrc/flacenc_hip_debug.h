@@ -1,6 +1,7 @@
-/* flacenc_hip_debug.h -- test and profiling hooks of libflacenc_hip.so.  NOT part of the drop-in boundary
- * (include/flacenc_hip.h): they exist only in builds made with -DFLACENC_HIP_DEBUG_HOOKS (the Makefile's default,
- * `make DEBUG_HOOKS=0` leaves them out), for tests/ and tools/. */
+/* flacenc_hip_debug.h -- test and profiling hooks.  NOT part of the drop-in boundary (include/flacenc_hip.h) and NOT in
+ * the product library: the Makefile links libflacenc_hip.so without them and a second library, libflacenc_hip_hooks.so --
+ * the same objects, flacenc_hip_api.cpp compiled once more with -DFLACENC_HIP_DEBUG_HOOKS -- for tests/ and tools/
+ * (flacenc_rs_amd/_capi.py: Handle(dev, hooks=True)). */
 #ifndef FLACENC_HIP_DEBUG_H_
 #define FLACENC_HIP_DEBUG_H_
 

@@ -25,6 +25,22 @@ def test_library_exports_every_declared_symbol():
     assert lib.flacenc_hip_abi_version() == 5
 
 
+def test_product_library_exports_the_c_abi_and_nothing_else():
+    """VERDICT r5 hygiene: libflacenc_hip.so carries no test hook, no C++ internal and no unprefixed helper
+    (csrc/exports.map); libflacenc_hip_hooks.so is the same plus the five flacenc_hip_debug_* of csrc/flacenc_hip_debug.h."""
+    import subprocess
+
+    def exported(path):
+        out = subprocess.check_output(["nm", "-D", "--defined-only", path], text=True)
+        return {line.split()[-1] for line in out.splitlines() if line.strip()}
+
+    product, hooks = exported(_capi.LIB_PATH), exported(_capi.HOOKS_LIB_PATH)
+    assert product == set(_capi.EXPORTED_SYMBOLS), sorted(product ^ set(_capi.EXPORTED_SYMBOLS))
+    assert hooks == product | set(_capi.DEBUG_SYMBOLS), sorted(hooks ^ (product | set(_capi.DEBUG_SYMBOLS)))
+    debug_h = open(os.path.join(ROOT, "flacenc_rs_amd", "csrc", "flacenc_hip_debug.h")).read()
+    assert set(re.findall(r"\b(flacenc_hip_debug_[a-z0-9_]+)\s*\(", debug_h)) == set(_capi.DEBUG_SYMBOLS)
+
+
 def test_params_record_layout_matches_oracle_record():
     assert _capi.PARAMS_DTYPE == orc.RECORD_DTYPE
     assert _capi.PARAMS_DTYPE.itemsize == 352

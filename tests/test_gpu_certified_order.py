@@ -24,7 +24,9 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(scope="module")
 def handle():
-    h = _capi.Handle(0)
+    # (the hooks build -- the product library's objects + flacenc_hip_debug_*: every test here reads the certificate's
+    # device counters or steers the order mode; the product library runs these shapes in test_gpu_parity.py)
+    h = _capi.Handle(0, hooks=True)
     yield h
     h.close()
 

@@ -142,10 +142,11 @@ def test_frame_pipeline_and_bytes(handle, n, bps, order, use_fixed):
     (4096, 16, 16, 4), (4608, 24, 16, 4), (1152, 24, 7, 4), (20000, 24, 33, 3), (100, 8, 64, 4), (8191, 24, 5, 4),
     (577, 24, 3, 2), (4096, 24, 12, 4),
 ])
-def test_fixed_selector_in_nightly_sum_order(handle, n, bps, parts, max_order):
+def test_fixed_selector_in_nightly_sum_order(hooks_handle, n, bps, parts, max_order):
     """fixed_lpc's ApproxEnt keys with find_sum_abs_f32 in the simd-nightly order (partition p of a 64-byte aligned
     SimdVec<i32, 16> starts at element offset p * partition_size: head up to the next multiple of 16, 16 lane
     chains over the body, foot), for every order; chosen order, Rice partition, bit counts, error signal."""
+    handle = hooks_handle  # (debug_set_fixed_keys: the hooks build, same kernels)
     import torch
     x = np.concatenate([batch(12, n, bps, 4000),
                         np.stack([util.quantize(util.noise(5, n, 0.999), bps), (np.arange(n) // 7).astype(np.int32),

@@ -587,10 +587,11 @@ def test_encode_stereo_frames_with_fixed_lpc_candidate(handle, order, fixed):
     _decode_frames(x, got, gres)
 
 
-def test_fixed_lpc_selector_keys_equal_oracle(handle):
+def test_fixed_lpc_selector_keys_equal_oracle(hooks_handle):
     """The selector's per-order keys (estimate_entropy + bps*order, coding.rs:271; BitCount bits,
     coding.rs:249) for L, R, M, S of every frame, bit for bit; and against the reference's own two
     summation orders wherever every partition sum stays below 2^24."""
+    handle = hooks_handle  # (debug_set_fixed_keys: the hooks build, same kernels)
     import torch
     bps = 16
     x = _fixed_corpus()

@@ -202,11 +202,12 @@ def _selector_corpus(n, bps):
     # than the warm-up), block sizes with no alignment at all
     (4608, 24, 16, 4), (1152, 24, 7, 4), (20000, 24, 33, 3), (100, 8, 64, 4), (8191, 24, 5, 4), (577, 24, 3, 2),
 ])
-def test_fixed_selector_in_stable_sum_order(handle, n, bps, parts, max_order):
+def test_fixed_selector_in_stable_sum_order(hooks_handle, n, bps, parts, max_order):
     """fixed_lpc with OrderSel::ApproxEnt in reference order: the selector's key of every order equals the
     oracle's with find_sum_abs_f32 as the stable build's sequential chain, and so do the chosen order, the Rice
     partition, the bit counts and the error signal.  The corpus is checked to be discriminating: at 24 bits
     some keys differ between the sequential chain and the exactly rounded sum."""
+    handle = hooks_handle  # (debug_set_fixed_keys: the hooks build, same kernels)
     import torch
     x = _selector_corpus(n, bps)
     separating = bps == 24 and n in (8192, 16384) and parts == 16

@@ -6,7 +6,7 @@ F, n, bps = 1024, 4096, 16
 x = torch.from_numpy(_capi.sigen_frames(F, 2, n, bps, 200.0, 0.4, 0.4, seed=0xF1AC0001)).cuda()
 results = torch.zeros((F, 752), dtype=torch.uint8, device="cuda")
 residual = torch.zeros((F * 2, n), dtype=torch.int32, device="cuda")
-h = _capi.Handle(0)
+h = _capi.Handle(0, hooks=True)
 for flags in (0, 128):
     stats = torch.zeros(3, dtype=torch.int32, device="cuda")
     h.debug_set_cert_stats(stats.data_ptr())

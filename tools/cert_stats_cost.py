@@ -6,7 +6,7 @@ F, n, bps = 98304, 4096, 16
 x = torch.from_numpy(_capi.sigen_frames(F, 2, n, bps, 200.0, 0.4, 0.4, seed=0xF1AC0001)).cuda()
 results = torch.zeros((F, _capi.FRAME_RESULT_DTYPE.itemsize), dtype=torch.uint8, device="cuda")
 residual = torch.zeros((F * 2, n), dtype=torch.int32, device="cuda")
-h = _capi.Handle(0)
+h = _capi.Handle(0, hooks=True)
 cfg = _capi.make_frame_config(_capi.make_config(lpc_order=8), use_fixed=False)
 st = torch.zeros(3, dtype=torch.int32, device="cuda")
 go = lambda: h.encode_stereo_frames_device(cfg, x.data_ptr(), F, n, n, bps, results.data_ptr(), residual.data_ptr(), n, stream=0)

@@ -24,7 +24,7 @@ results = torch.empty((F, 752), dtype=torch.uint8, device=dev)
 residual = torch.empty((F * 2, n), dtype=torch.int32, device=dev)
 stamps = torch.zeros((F * 4, 8), dtype=torch.int64, device=dev)
 cfg = _capi.make_frame_config(_capi.make_config(lpc_order=args.lpc_order), use_fixed=args.use_fixed)
-h = _capi.Handle(0)
+h = _capi.Handle(0, hooks=True)
 st = torch.cuda.current_stream()
 
 

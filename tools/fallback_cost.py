@@ -11,7 +11,7 @@ rng = np.random.default_rng(1)
 pick = rng.integers(0, 64, size=(F, 2))
 x = torch.from_numpy(np.ascontiguousarray(np.stack([base[pick[:, 0]], base[pick[:, 1]]], axis=1))).cuda()
 results = torch.zeros((F, 752), dtype=torch.uint8, device="cuda"); residual = torch.zeros((F * 2, n), dtype=torch.int32, device="cuda")
-h = _capi.Handle(0); h.debug_set_adaptive_order(False)
+h = _capi.Handle(0, hooks=True); h.debug_set_adaptive_order(False)
 for order in (8, 12):
     for flags in (0, _capi.FLAG_CANONICAL_SUM_ORDER):
         cfg = _capi.make_frame_config(_capi.make_config(lpc_order=order, flags=flags), use_fixed=False)

@@ -9,7 +9,7 @@ F, n, bps = 8192, 4096, 16
 x = torch.from_numpy(_capi.sigen_frames(F, 2, n, bps, 200.0, 0.4, 0.4, seed=1)).cuda()
 results = torch.zeros((F, 752), dtype=torch.uint8, device="cuda"); residual = torch.zeros((F * 2, n), dtype=torch.int32, device="cuda")
 st = torch.zeros((F * 4, 8), dtype=torch.int64, device="cuda")
-h = _capi.Handle(0); h.debug_set_stamps(st.data_ptr())
+h = _capi.Handle(0, hooks=True); h.debug_set_stamps(st.data_ptr())
 cfg = _capi.make_frame_config(_capi.make_config(lpc_order=8), use_fixed=False)
 for _ in range(2):
     h.encode_stereo_frames_device(cfg, x.data_ptr(), F, n, n, bps, results.data_ptr(), residual.data_ptr(), n, stream=0)

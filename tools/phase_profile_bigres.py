@@ -11,7 +11,7 @@ ap.add_argument("--order", type=int, default=24)
 ap.add_argument("--bps", type=int, default=24)
 ap.add_argument("--frames", type=int, default=6144)
 args = ap.parse_args()
-h = _capi.Handle(0)
+h = _capi.Handle(0, hooks=True)
 F, n = args.frames, args.n
 x = torch.from_numpy(_capi.sigen_frames(F, 2, n, args.bps, 200.0, 0.4, 0.1, seed=7)).cuda()
 params = torch.empty((F * 4, 352), dtype=torch.uint8, device="cuda")

@@ -23,7 +23,7 @@ params = torch.empty((F * 4, 352), dtype=torch.uint8, device=dev)
 residual = torch.empty((F * 4, n), dtype=torch.int32, device=dev)
 stamps = torch.zeros((F * 4, 8), dtype=torch.int64, device=dev)
 cfg = _capi.make_config(lpc_order=args.lpc_order)
-h = _capi.Handle(0)
+h = _capi.Handle(0, hooks=True)
 for it in range(3):
     h.debug_set_stamps(stamps.data_ptr() if it == 2 else 0)
     h.stereo_qlpc_batch_device(cfg, x.data_ptr(), F, n, n, args.bps, params.data_ptr(), residual.data_ptr(), n, stream=0)

@@ -23,7 +23,7 @@ results = torch.empty((F, 752), dtype=torch.uint8, device="cuda")
 resid = torch.empty((F * 2, n), dtype=torch.int32, device="cuda")
 stamps = torch.zeros((F * 4, 8), dtype=torch.int64, device="cuda")
 cfg = _capi.make_frame_config(_capi.make_config(lpc_order=args.lpc_order), use_fixed=True)
-h = _capi.Handle(0)
+h = _capi.Handle(0, hooks=True)
 for it in range(3):
     h.debug_set_stamps(stamps.data_ptr() if it == 2 else 0)
     h.encode_stereo_frames_device(cfg, x.data_ptr(), F, n, n, args.bps, results.data_ptr(), resid.data_ptr(), n, stream=0)

@@ -20,7 +20,7 @@ cut = np.stack(cut)
 x = torch.from_numpy(np.ascontiguousarray(np.tile(cut, ((F + len(cut) - 1) // len(cut), 1, 1))[:F])).cuda()
 results = torch.zeros((F, _capi.FRAME_RESULT_DTYPE.itemsize), dtype=torch.uint8, device="cuda")
 residual = torch.zeros((F * 2, n), dtype=torch.int32, device="cuda")
-h = _capi.Handle(0)
+h = _capi.Handle(0, hooks=True)
 for order in (8, 10, 12):
     for adaptive, flags in ((1, 0), (0, 0), (0, _capi.FLAG_CANONICAL_SUM_ORDER)):
         h.debug_set_adaptive_order(bool(adaptive))

@@ -9,6 +9,6 @@ mkdir -p $ROOT/ab /tmp/variant_$NAME
 BASE=qlpc_bigres_inst_${K}_${NLB}
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -I$ROOT/include -I$C \
   -DFLACENC_BIG_K=$K -DFLACENC_BIG_NLB=$NLB "$@" -c $C/qlpc_bigblock_residual_inst.hip -o /tmp/variant_$NAME/$BASE.o 2>&1 | grep -v warning || true
-OBJS=$(ls $C/build/*.o | grep -v "/$BASE.o")
+OBJS="$(ls $C/build/*.o | grep -v "/$BASE.o" | grep -v "/flacenc_hip_api.o") $C/build/hooks/flacenc_hip_api.o"  # (A/B libraries carry the debug hooks: the tools that load them use both)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS /tmp/variant_$NAME/$BASE.o -o $ROOT/ab/libflacenc_hip_$NAME.so
 echo ab/libflacenc_hip_$NAME.so

@@ -9,6 +9,6 @@ C=$ROOT/flacenc_rs_amd/csrc
 mkdir -p $ROOT/ab /tmp/variant_$NAME
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -I$ROOT/include -I$C \
   -DFLACENC_MAXP=$MP -DFLACENC_STEREO=$ST "$@" -c $C/qlpc_wave_inst.hip -o /tmp/variant_$NAME/w.o 2>&1 | grep -v warning || true
-OBJS=$(ls $C/build/*.o | grep -v "/qlpc_wave_inst_${MP}_${ST}.o")
+OBJS="$(ls $C/build/*.o | grep -v "/qlpc_wave_inst_${MP}_${ST}.o" | grep -v "/flacenc_hip_api.o") $C/build/hooks/flacenc_hip_api.o"  # (A/B libraries carry the debug hooks: the tools that load them use both)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS /tmp/variant_$NAME/w.o -ldl -o $ROOT/ab/libflacenc_hip_$NAME.so
 echo ab/libflacenc_hip_$NAME.so

@@ -717,112 +717,168 @@ __device__ __forceinline__ void lane_order_reduce(const double (&v)[N], double (
 // tau = i + 4 j per block, A_b[i][k] = x_w[4 m + k - i - 12], B_b[k][j] = x_w[4 m + k - 12 + 4 j] (0 below t = P and
 // from t = n on): acorr_reference_mfma_kernel's scheme (acorr_reference.cpp; the operand layout and the equality of the
 // chained instruction with the sequential chain are probed in tools/microbench/mfma_f64_4x4x4_probe.hip), fed from the
-// workgroup's LDS images instead of HBM.  `rows`: 4 x kCertRow floats of LDS scratch ([64 of history | a tile of 256]
-// per subframe); the sums come back in the same area, lag tau of subframe b at ((double*)rows)[16 b + tau].
-// Out of line: it runs for a fraction of a per cent of the frames of noisy material (all of them on near-pure tones),
-// 17 tiles x 64 MFMAs = ~40 k cycles, and must not cost the common path a register.
-constexpr int kCertHist = 64;
-// (tiles of 256 samples; 128 where four workgroups share a CU's LDS, 32 for the plain 4608-sample instances)
-constexpr int cert_tile(bool stereo, int spl) { return (!stereo && spl != 64) ? 32 : (FLACENC_WAVE_OCC >= 4 ? 128 : 256); }
-constexpr int cert_scratch_bytes(int tile) { return 4 * (kCertHist + tile + 8) * 4; }
+// workgroup's LDS images instead of HBM.  `rows`: 4 x kCertRow values of LDS scratch ([history | a tile] per subframe);
+// the sums come back in the same area, lag tau of subframe b at ((double*)rows)[16 b + tau].
+// Out of line: it runs for a fraction of a per cent of the frames of noisy material (all of them on near-pure tones)
+// and must not cost the common path a register.
+// Round 6: the rows are staged as f64 -- a sample is converted ONCE, by the lane that lands it, where until then every
+// step converted its two operands on the chain's own pipe (the f64 "matrix" instruction occupies the vector ALU, nothing
+// overlaps it: 2 x 8 + 16 cycles a step for a lone wave; in-kernel stamps on the reference's real-audio fixtures had
+// a recomputed frame's phase 2 at 140 k cycles against 15 k, the chains 100 k of it where 1088 bare steps need 18 k).
+// What that bought is 3 % on music and nothing on near-pure tones, and an ablation says why (profiles/r06_fallback_ablation.txt):
+// 0.70 of the fallback's 0.94 ms per 24576 recomputed frames are the 1032 DEPENDENT v_mfma_f64_4x4x4 themselves, ~65
+// cycles each -- one chain per SIMD fills a quarter of a pipe that acorr_reference_mfma_kernel fills with 28 chains per
+// CU; staging is 0.16, the history copy 0.05.  The fallback is latency-bound by construction; hard material is the order
+// mode's business (flacenc_hip_api.cpp, launch_adaptive), not this function's.
+// Tiles of 96 samples + 32 of history per subframe = 4.25 KB: what four workgroups per CU leave next to the two images.
+// The plain 4608-sample instances (four 19.8 KB images, 1.7 KB left) keep f32 rows and tiles of 32.
+constexpr bool cert_f64(bool stereo, int spl) { return stereo || spl == 64; }
+constexpr int cert_hist(bool stereo, int spl) { return cert_f64(stereo, spl) ? 32 : 64; }
+constexpr int cert_tile(bool stereo, int spl) { return cert_f64(stereo, spl) ? 96 : 32; }
+constexpr int cert_scratch_bytes(bool stereo, int spl) {
+  return 4 * (cert_hist(stereo, spl) + cert_tile(stereo, spl) + 8) * (cert_f64(stereo, spl) ? 8 : 4);
+}
 
-template <int SPL, bool STEREO, int kCertTile>
+template <int SPL, bool STEREO>
 __device__ __attribute__((noinline)) void reference_chains_from_lds(uint32_t rows_off, const float* wtab, int P) {
   // (the images and the scratch rows by their place in the workgroup's LDS, not by pointer: behind a generic pointer
   // every access of this out-of-line function paid a 64-bit address and an address-space cast -- 140 instructions per 16 steps)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int32_t* const sm = reinterpret_cast<const int32_t*>(smem_raw);
-  float* const rows = reinterpret_cast<float*>(smem_raw + rows_off);
+  constexpr bool F64 = cert_f64(STEREO, SPL);
+  constexpr int kCertTile = cert_tile(STEREO, SPL), kCertHist = cert_hist(STEREO, SPL);
+  using row_t = std::conditional_t<F64, double, float>;
+  row_t* const rows = reinterpret_cast<row_t*>(smem_raw + rows_off);
   using G = WaveGeom<SPL>;
   constexpr int n = G::N;
-  constexpr int kCertRow = kCertHist + kCertTile + 8;  // (row stride = 8 mod 32 banks, as acorr_reference.cpp's kMRow)
+  constexpr int kCertRow = kCertHist + kCertTile + 8;
+  static_assert(kCertHist >= 28 && (kCertTile % 32) == 0 && (4 * kCertHist) % 64 == 0, "operands reach 27 samples back; whole groups of 8 steps");
   const int lane = threadIdx.x & 63;
-  int4 raw[STEREO ? 2 : 4];
-  float4 wv;
+  // Staging: TWO samples per lane on kCertTile / 2 lanes (round 6; four per lane kept a quarter of the wave busy with twice
+  // the instructions: a lone wave pays ~6 cycles for each whatever its exec mask)
+  int2 raw[STEREO ? 2 : 4];
+  float2 wv;
+  const bool stager = 2 * lane < kCertTile;
   auto issue = [&](int T0) __attribute__((always_inline)) {
-    const int t = T0 + 4 * lane;
-    if (4 * lane >= kCertTile) return;
-    const bool in = t < n;  // (n is a multiple of 4: a quad lies inside the block or behind it)
+    const int t = T0 + 2 * lane;
+    if (!stager) return;
+    const bool in = t < n;  // (n is even: a pair lies inside the block or behind it)
     const int ix = G::idx(in ? t : 0);
 #pragma unroll
     for (int r = 0; r < (STEREO ? 2 : 4); ++r) {
-      const int4 v = *reinterpret_cast<const int4*>(&sm[r * G::Buf + ix]);
-      raw[r] = in ? v : make_int4(0, 0, 0, 0);
+      const int2 v = *reinterpret_cast<const int2*>(&sm[r * G::Buf + ix]);
+      raw[r] = in ? v : make_int2(0, 0);
     }
-    wv = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
-    if (wtab != nullptr && in) wv = *reinterpret_cast<const float4*>(wtab + t);
+    wv = make_float2(1.0f, 1.0f);
+    if (wtab != nullptr && in) {
+      // A GLOBAL load, said so: through the generic pointer of this out-of-line function it is a flat_load, which counts
+      // as an LDS operation too (the waits for the operand reads then include the memory latency of the next tile's weights)
+      typedef float v2f_t __attribute__((ext_vector_type(2)));
+      typedef const v2f_t __attribute__((address_space(1))) gv2f_t;
+      const v2f_t w2 = *(gv2f_t*)(wtab + t);
+      wv = make_float2(w2.x, w2.y);
+    }
   };
-  // x_w = (f32)s * w, one f32 rounding (lpc.rs:751-754)
+  // x_w = (f32)s * w, one f32 rounding (lpc.rs:751-754); widened here, once per sample (lpc.rs:545)
   auto land = [&]() __attribute__((always_inline)) {
-    auto put = [&](int b, const int4& sv) {
-      float4 x;
-      x.x = (float)sv.x * wv.x;
-      x.y = (float)sv.y * wv.y;
-      x.z = (float)sv.z * wv.z;
-      x.w = (float)sv.w * wv.w;
-      if (4 * lane < kCertTile) *reinterpret_cast<float4*>(&rows[b * kCertRow + kCertHist + 4 * lane]) = x;
+    auto put = [&](int b, const int2& sv) {
+      const float x0 = (float)sv.x * wv.x, x1 = (float)sv.y * wv.y;
+      if (stager) {
+        row_t* const dst = &rows[b * kCertRow + kCertHist + 2 * lane];
+        if (F64) *reinterpret_cast<double2*>(dst) = make_double2((double)x0, (double)x1);
+        else *reinterpret_cast<float2*>(dst) = make_float2(x0, x1);
+      }
     };
     if (STEREO) {
-      const int4 l = raw[0], r = raw[1];
+      const int2 l = raw[0], r = raw[1];
       put(0, l);
       put(1, r);
-      put(2, make_int4((l.x + r.x) >> 1, (l.y + r.y) >> 1, (l.z + r.z) >> 1, (l.w + r.w) >> 1));  // coding.rs:483
-      put(3, make_int4(l.x - r.x, l.y - r.y, l.z - r.z, l.w - r.w));
+      put(2, make_int2((l.x + r.x) >> 1, (l.y + r.y) >> 1));  // coding.rs:483
+      put(3, make_int2(l.x - r.x, l.y - r.y));
     } else {
 #pragma unroll
       for (int b = 0; b < 4; ++b) put(b, raw[b]);
     }
   };
-  // the history in front of the first tile: zeros (the samples in front of the block)
+  // the history in front of the first tile: zeros (the samples in front of the block); 4 kCertHist values on 64 lanes
+  constexpr int kHistPer = 4 * kCertHist / 64;  // values per lane: 2 (f64 rows) or 4
 #pragma unroll
-  for (int q = 0; q < 4; ++q) rows[(lane >> 4) * kCertRow + 16 * q + (lane & 15)] = 0.0f;
+  for (int q = 0; q < kHistPer; ++q) {
+    const int v = lane * kHistPer + q;  // value v of the 4 x kCertHist: row v / kCertHist, place v % kCertHist
+    rows[(v / kCertHist) * kCertRow + (v % kCertHist)] = (row_t)0;
+  }
   // this lane's operands: k = lane / 16, block b = (lane % 16) / 4, r = lane % 4 (i for A, j for B)
   const int k = lane >> 4, b = (lane >> 2) & 3, r = lane & 3;
-  const float* const pa = rows + b * kCertRow + kCertHist + (k - r - 12);      // + 4 m: x_w[T0 + 4 m + k - i - 12]
-  const float* const pb = rows + b * kCertRow + kCertHist + (k - 12 + 4 * r);  // + 4 m: x_w[T0 + 4 m + k - 12 + 4 j]
+  const row_t* const pa = rows + b * kCertRow + kCertHist + (k - r - 12);      // + 4 m: x_w[T0 + 4 m + k - i - 12]
+  const row_t* const pb = rows + b * kCertRow + kCertHist + (k - 12 + 4 * r);  // + 4 m: x_w[T0 + 4 m + k - 12 + 4 j]
   double acc = 0.0;
   constexpr int n_steps = (n + 12 + 3) >> 2;                          // the last column trails by 12 samples
   constexpr int n_tiles = (4 * n_steps + kCertTile - 1) / kCertTile;  // (the tile behind the block's end is all zeros)
+  constexpr int NG = kCertTile / 32;                                  // groups of 8 steps per tile
   issue(0);
 #pragma unroll 1
   for (int tile = 0; tile < n_tiles; ++tile) {
     land();
     if (tile + 1 < n_tiles) issue((tile + 1) * kCertTile);
     const int left = n_steps - tile * (kCertTile / 4);
-    const int m_end = left < (kCertTile / 4) ? left : (kCertTile / 4);
-    int m = 0;
-    if (tile == 0) {
-      // B is the current sample: nothing below t = P (only the first tile holds such samples; P + 12 < 64)
-      const int m_mask = (P + 12 + 3) >> 2;
-      for (; m < m_mask && m < m_end; ++m) {
-        const int tcur = 4 * m + k - 12 + 4 * r;
-        const double bd = tcur >= P ? (double)pb[4 * m] : 0.0;
-        acc = __builtin_amdgcn_mfma_f64_4x4x4f64((double)pa[4 * m], bd, acc, 0, 0, 0);
+    if (left >= kCertTile / 4) {
+      // a whole tile: NG groups of 8 steps, the operands of group g + 1 read while group g's chain runs (a lone wave has
+      // nothing else to cover an LDS round trip with)
+      double oa[8], ob[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        oa[u] = (double)pa[4 * u];
+        ob[u] = (double)pb[4 * u];
       }
-    }
-    // groups of 16 steps with a constant trip count: their 32 operand reads are issued together, ahead of the chain --
-    // with the bound a variable every step waited for its own two LDS reads, alone on its SIMD: ~270 cycles a step,
-    // 135 us per recomputed frame where the MFMA chain itself needs 17 (measured on the reference's real-audio fixtures)
-    for (; m + 16 <= m_end; m += 16) {
-      const float* const qa = pa + 4 * m;
-      const float* const qb = pb + 4 * m;
+      if (tile == 0) {
+        // B is the current sample: nothing below t = P (only the first group holds such samples: P + 12 < 32)
 #pragma unroll
-      for (int u = 0; u < 16; ++u) acc = __builtin_amdgcn_mfma_f64_4x4x4f64((double)qa[4 * u], (double)qb[4 * u], acc, 0, 0, 0);
+        for (int u = 0; u < 8; ++u) ob[u] = (4 * u + k - 12 + 4 * r) >= P ? ob[u] : 0.0;
+      }
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        double na[8], nb[8];
+        if (g + 1 < NG) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            na[u] = (double)pa[32 * (g + 1) + 4 * u];
+            nb[u] = (double)pb[32 * (g + 1) + 4 * u];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f64_4x4x4f64(oa[u], ob[u], acc, 0, 0, 0);
+        if (g + 1 < NG) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            oa[u] = na[u];
+            ob[u] = nb[u];
+          }
+        }
+      }
+    } else {
+      // the block's last, partial tile (never the first)
+      for (int m = 0; m < left; ++m)
+        acc = __builtin_amdgcn_mfma_f64_4x4x4f64((double)pa[4 * m], (double)pb[4 * m], acc, 0, 0, 0);
     }
-    for (; m < m_end; ++m) acc = __builtin_amdgcn_mfma_f64_4x4x4f64((double)pa[4 * m], (double)pb[4 * m], acc, 0, 0, 0);
-    // the tile's last 64 samples become the next tile's history (the wave's own LDS operations are ordered)
+    // the tile's last kCertHist samples become the next tile's history (the wave's own LDS operations are ordered)
     if (tile + 1 < n_tiles) {
-      float h[4];
+      row_t h[kHistPer];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) h[q] = rows[(lane >> 4) * kCertRow + kCertTile + 16 * q + (lane & 15)];
+      for (int q = 0; q < kHistPer; ++q) {
+        const int v = lane * kHistPer + q;
+        h[q] = rows[(v / kCertHist) * kCertRow + kCertTile + (v % kCertHist)];
+      }
 #pragma unroll
-      for (int q = 0; q < 4; ++q) rows[(lane >> 4) * kCertRow + 16 * q + (lane & 15)] = h[q];
+      for (int q = 0; q < kHistPer; ++q) {
+        const int v = lane * kHistPer + q;
+        rows[(v / kCertHist) * kCertRow + (v % kCertHist)] = h[q];
+      }
     }
   }
   // D_b[i][j] sits in lane 16 i + 4 b + j: lag i + 4 j of subframe b
   {
     const int i = lane >> 4, bo = (lane >> 2) & 3, j = lane & 3;
-    reinterpret_cast<double*>(rows)[16 * bo + i + 4 * j] = acc;
+    reinterpret_cast<double*>(smem_raw + rows_off)[16 * bo + i + 4 * j] = acc;
   }
 }
 
@@ -952,7 +1008,6 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
 #else
   constexpr bool kCertSupported = !PACK;
 #endif
-  constexpr int kCertTileHere = cert_tile(STEREO, SPL);
   float* const cert_rows = window_image(STEREO, SPL)
                                ? wlds
                                : reinterpret_cast<float*>(sm + NIMG * kBufDwords) + (4 * (MAXP + 1) * 8 + 256 + 16) / 4;
@@ -1342,7 +1397,7 @@ __global__ void __launch_bounds__(256, FLACENC_WAVE_OCC) qlpc_wave4096_kernel(Ql
       }
       if (kCertSupported && __builtin_amdgcn_ballot_w64(lane < 4 && !certified) != 0ull) {
 #ifndef FLACENC_CERT_NO_SLOWPATH
-        reference_chains_from_lds<SPL, STEREO, kCertTileHere>(
+        reference_chains_from_lds<SPL, STEREO>(
             (uint32_t)(reinterpret_cast<unsigned char*>(cert_rows) - smem_raw), has_window ? a.window + 32 : nullptr, P);
 #endif
         if (lane < 4 && !certified) {
@@ -2381,7 +2436,7 @@ hipError_t launch_wave4096(const QlpcKernelArgs& a, hipStream_t stream) {
   constexpr bool cert = !PACK;
   constexpr size_t smem = (size_t)(STEREO ? (window_image(STEREO, SPL) ? 3 : 2) : 4) * WaveGeom<SPL>::Buf * 4 +
                           ((MAXP > 10 && !PACK && window_image(STEREO, SPL)) ? 4 * (MAXP + 1) * 8 : 4 * ((MAXP + 1) * 8 + 64)) +
-                          (cert ? 16 : 0) + ((cert && !window_image(STEREO, SPL)) ? cert_scratch_bytes(cert_tile(STEREO, SPL)) : 0);
+                          (cert ? 16 : 0) + ((cert && !window_image(STEREO, SPL)) ? cert_scratch_bytes(STEREO, SPL) : 0);
   static DynamicLdsOptIn opt_in;  // per instantiation, per device inside
   if (hipError_t err = opt_in.ensure(reinterpret_cast<const void*>(kern), smem); err != hipSuccess) return err;
   const uint32_t blocks = STEREO ? a.n_subframes / 4u : (a.n_subframes + 3u) / 4u;

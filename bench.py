@@ -75,6 +75,11 @@ def parse_args(argv=None):
                     help="exchange runs: leave the analysis on a normal-priority stream (A/B of the priority's effect)")
     ap.add_argument("--force-exchange", action="store_true",
                     help="run the multi-GPU exchange step even with one rank; for measuring its cost")
+    ap.add_argument("--comm", choices=["torch", "capi"], default="torch",
+                    help="who runs the exchange's all-gathers: torch.distributed (default) or the C library's own RCCL "
+                         "communicator (flacenc_hip_comm_create + flacenc_hip_allgather_records_async: what a Rust / C++ "
+                         "host with one process per GPU calls); torch.distributed stays for the launch, the barrier and "
+                         "the timing reduction, and hands rank 0's communicator id to the other ranks")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="torch.distributed backend; nccl is RCCL on ROCm.  gloo only with --dry-run")
     ap.add_argument("--shared-gpu-test", action="store_true",
@@ -119,6 +124,8 @@ def main():
         raise SystemExit("--backend gloo is only for --dry-run / --shared-gpu-test (the product path has no CPU fallback)")
     if args.shared_gpu_test and args.backend != "gloo":
         raise SystemExit("--shared-gpu-test needs --backend gloo (RCCL wants one device per rank)")
+    if args.comm == "capi" and (args.dry_run or args.shared_gpu_test or args.backend == "gloo"):
+        raise SystemExit("--comm capi is the library's RCCL communicator: one GPU per rank, no gloo / dry-run form")
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None and args.gpus > 1:
         sys.exit(launch_ranks(args, argv))
@@ -262,6 +269,16 @@ def run(args, world):
         out_stride = handle.frame_bytes_bound(n, bps)
         packed2 = [torch.empty((F, out_stride), dtype=torch.uint8, device=dev) for _ in range(2)]
     wire2 = [torch.empty((F, shard.wire_record_bytes(n)), dtype=torch.uint8, device=dev) for _ in range(2)] if exchanging else None
+    capi_comm = None
+    if exchanging and args.comm == "capi":
+        # the library's own communicator: rank 0's ncclGetUniqueId travels through torch.distributed's object broadcast
+        # (any channel the host has would do), every rank joins with its handle, and the gathers below run on `comm`
+        uid = [_capi.Handle.comm_unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(uid, src=0)
+        handle.comm_create(uid[0], rank, world)
+        capi_comm = shard.CapiCollective(handle, stream=comm.cuda_stream)
+        assert (capi_comm.rank, capi_comm.world) == (rank, world)
     consumed = [None, None]  # event: the exchange that read buffer b has finished
     step_no = [0]
     last_exchange = {}
@@ -279,18 +296,18 @@ def run(args, world):
         elif not payload:
             handle.stereo_frame_lengths_device(results2[b].data_ptr(), F, n, bps, SAMPLE_RATE, rank, world,
                                                frame_len2[b].data_ptr(), stream=comm.cuda_stream)
-        gathered = shard.all_gather_rank_major(frame_len2[b], world * F)
+        gathered = shard.all_gather_rank_major(frame_len2[b], world * F, collective=capi_comm)
         lengths_all, offsets, total = shard.stream_offsets_device(handle, gathered, world * F, world,
                                                                   stream=comm.cuda_stream)
         last_exchange.update(lengths_all=lengths_all, offsets=offsets, total=total)
         if wire is not None:
             last_exchange["records_all"] = shard.GatheredRecords(
-                shard.all_gather_records(wire, world * F, materialize=False), world * F, n)
+                shard.all_gather_records(wire, world * F, materialize=False, collective=capi_comm), world * F, n)
         if payload:
             # (run capacity = the packer's bound: no host synchronisation on the exchange stream)
             last_exchange["stream_bytes"] = shard.all_gather_frame_bytes(
                 shard.device_place(handle, comm.cuda_stream), packed2[b], frame_len2[b], lengths_all, offsets,
-                world * F, run_capacity=F * out_stride)
+                world * F, run_capacity=F * out_stride, collective=capi_comm)
 
     def step(events=None):
         b = step_no[0] & 1
@@ -402,6 +419,9 @@ def run(args, world):
         "n_gpus": world,
         "ranks_observed": ranks_observed,
         "collective_backend": (dist.get_backend() if dist.is_initialized() else None),
+        "exchange_collective": (None if not exchanging else
+                                "C ABI: flacenc_hip_comm_create + flacenc_hip_allgather_records_async / flacenc_hip_allgather_async"
+                                if capi_comm is not None else "torch.distributed all_gather_into_tensor"),
         **({"shared_gpu_test": True} if args.shared_gpu_test else {}),
         "steps": args.steps,
         "warmup": args.warmup,

@@ -221,20 +221,26 @@ enum {
 // follow the reference; forward[] is updated in place pairwise (d, n-d) which
 // reads exactly the old values forward_next[] would be computed from.
 // ---- the order certificate ("default order") -------------------------------------------------------
-// The kernels sum the autocorrelation in their own order (the chunk tree), the reference in one sequential chain per lag
-// (lpc.rs:533-548).  Both are within eps = (n + 96) 2^-53 S of the exact sums (n - P roundings of the chain + at most 71 of the
-// kernels' own orders, each at most 2^-53 of a partial sum of absolute products; S >= sum |x_w[t] x_w[t - tau]| by Cauchy-Schwarz:
-// sqrt(R0 (R0 + P max|s|^2)) <= R0 + P max|s|^2 / 2), hence within eps of each other.  For T a = r, (T + E)(a + da) =
-// r + g with |E_ij|, |g_i| <= eps: |da_i| <= sum_j |T^-1_ij| eps (1 + sum |a_j|) to first order.  The quantiser
-// (lpc.rs:234-302) is a step function of a: if no a_i 2^shift comes within its |da_i| 2^shift of a rounding boundary
-// k + 1/2, and max |a| +- |da| does not straddle a power of two (find_shift), the reference's own R[] quantises to the
-// SAME QuantizedParameters -- the subframe is certified, and every integer output downstream is the reference's.  A
-// subframe that is not certified is redone from the reference's chains.  Factor 2 on the bound: the second-order term
-// and the recursion's own rounding (both <= a few per cent of the first-order term at these orders).
+// The kernels sum the autocorrelation in their own order, the reference in one sequential chain per lag (lpc.rs:533-548).
+// With u = 2^-53, what the certificate rests on (oracle/flacenc_oracle.c, orc_quant_certified, states the same arithmetic
+// operation for operation and says which steps are shown and which assumed):
+//   eps   = (n + 96) u S >= |R^ - R~|: n - P roundings of the chain + at most 71 of the kernels' own orders, each at most u
+//           times a partial sum of |products| <= S = R0 + P max|s|^2 / 2 (Cauchy-Schwarz);
+//   F_i   = rowsum_i(|T^-1|) eps (1 + |a|_1): for T a = r, (T + E)(a + da) = r + g with |E_ij|, |g_i| <= eps the first-order
+//           |da_i| (attained by low-pass material: T^-1 a sign checkerboard under an alternating a);
+//   2 F_i : the factor 2 covers the second-order term (<= 0.23 F_i once the boundary test passes, quant_precision >= 6) and
+//           the rounding of the two floating-point recursions (<= 0.77 F_i if their residuals obey c_L <= 11, measured
+//           <= 0.39) -- ON SYSTEMS THE RECURSION FINDS POSITIVE DEFINITE.  The sums start at t = P for every lag, so R[]
+//           need not be an autocorrelation (a block that opens on a clipped plateau is enough); on such systems the
+//           recursion is unstable -- round 6's attack, tools/certificate_attack.py, found the two computed solutions 68 x
+//           further apart than 2 F_i on a subframe the rule of round 5 certified -- and they are excluded (`nonpd`).
+// The quantiser (lpc.rs:234-302) is a step function of a: if no a_i 2^shift comes within 2 F_i 2^shift of a rounding
+// boundary k + 1/2, and max |a| -+ 2 F_i does not straddle a power of two (find_shift), the reference's own R[] quantises
+// to the SAME QuantizedParameters -- the subframe is certified, and every integer output downstream is the reference's.  A
+// subframe that is not certified is redone from the reference's chains.
 // Tier 1 bounds every row sum of |T^-1| by the Gohberg-Semencul norm bound 2 |f|_1^2 / |f_0|, f = T^-1 e_0 = the
 // recursion's `forward` vector -- O(P), enough for material that is not strongly tonal; tier 2 evaluates the rows
 // themselves from f (T^-1_ij = T^-1_(i-1)(j-1) + (f_i f_j - f_(P-i) f_(P-j)) / f_0), O(P^2), ~70 x tighter.
-// oracle/flacenc_oracle.c (orc_quant_certified) states the same arithmetic operation for operation.
 constexpr double kCertSafety = 2.0;
 constexpr int kCertOwnRoundings = 96;  // >= P + the roundings of the kernels' own sums (71: a 64-sample chain, six tree levels, the 4608 tail)
 
@@ -266,7 +272,7 @@ __device__ __forceinline__ bool quant_stable(const double (&a)[MAXP], int P, int
 // solution, fwd[] = the final `forward` vector, *skipped = a zero denominator skipped a step (lpc.rs:679-682).
 template <int MAXP>
 __device__ __forceinline__ void levinson_core(const double (&R)[MAXP + 1], int P, double (&a)[MAXP], double (&fwd)[MAXP],
-                                              bool* skipped) {
+                                              bool* skipped, bool* nonpd = nullptr) {
   fwd[0] = 1.0 / R[0];   // Float::recip(coefs[0] + diagonal_loading), loading = 0
   a[0] = R[1] / R[0];    // ys[0] / (coefs[0] + diagonal_loading)
 #pragma unroll
@@ -277,6 +283,9 @@ __device__ __forceinline__ void levinson_core(const double (&R)[MAXP + 1], int P
       for (int d = 0; d < n; ++d) err = __builtin_fma(R[n - d], fwd[d], err);
       double denom = __builtin_fma(err, -err, 1.0);
       if (denom == 0.0) *skipped = true;
+      // (the certificate: a denominator that is not positive = the Toeplitz matrix is not positive definite -- the sums
+      // start at t = P for every lag, R[] need not be an autocorrelation -- and the recursion is outside its stable domain)
+      if (nonpd != nullptr && !(denom > 0.0)) *nonpd = true;
       if (denom != 0.0) {
         double alpha = 1.0 / denom;
         double beta = -alpha * err;
@@ -414,7 +423,7 @@ __device__ FLACENC_CERT_T1_ATTR int quant_certified(const CertArgs<MAXP>& in) {
   return ok ? 1 : 2;  // 2: not certified by this tier -- the caller asks quant_certified_rows
 }
 
-// CERT: *certified_out = the quantised parameters are provably those of any R[] within the summation bound of Rl
+// CERT: *certified_out = the certificate above holds: the quantised parameters are those of any R[] within the summation bound of Rl
 // (max_abs_s = the subframe's max |s|, n = samples summed per lag); tier2_out counts evaluations of the rows (statistics)
 template <int MAXP, bool CERT = false>
 __device__ int levinson_quantize(const double* __restrict__ Rl, int P, int precision,
@@ -445,12 +454,13 @@ __device__ int levinson_quantize(const double* __restrict__ Rl, int P, int preci
   }
 
   bool skipped = false;  // a zero denominator skipped a step: forward[] is not T^-1 e_0 any more
+  bool nonpd = false;    // a denominator was not positive: no certificate for this system
   double cert_f1 = 0.0, cert_f0 = 0.0;  // |forward|_1 and |forward[0]|: all the certificate's first tier needs of it
   if (status == 0 && R[0] != 0.0) {
     double fwd[MAXP];
 #pragma unroll
     for (int i = 0; i < MAXP; ++i) fwd[i] = 0.0;
-    levinson_core<MAXP>(R, P, a, fwd, &skipped);
+    levinson_core<MAXP>(R, P, a, fwd, &skipped, CERT ? &nonpd : nullptr);
     if (CERT) {
       // (entries above P are +0.0: no masks)
 #pragma unroll
@@ -511,7 +521,7 @@ __device__ int levinson_quantize(const double* __restrict__ Rl, int P, int preci
     // reference would panic on, a skipped step or all-zero coefficients are left to the reference's own chains
     bool certified = status == 0 && R[0] == 0.0;
     bool tier2 = false;
-    if (status == 0 && R[0] != 0.0 && !skipped) {
+    if (status == 0 && R[0] != 0.0 && !skipped && !nonpd) {
       CertArgs<MAXP> ca;
 #pragma unroll
       for (int i = 0; i < MAXP; ++i) ca.a[i] = a[i];

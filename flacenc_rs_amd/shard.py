@@ -26,7 +26,36 @@ def local_frame_count(n_frames_total: int, rank: int, world: int) -> int:
     return len(frames_of_rank(n_frames_total, rank, world))
 
 
-def all_gather_records(local: torch.Tensor, n_frames_total: int, group=None, materialize: bool = True) -> torch.Tensor:
+class CapiCollective:
+    """The ordered gather's collective through the C ABI instead of torch.distributed: the RCCL communicator a handle owns
+    (flacenc_hip_comm_create) and flacenc_hip_allgather_records_async / flacenc_hip_allgather_async on `stream` -- what a
+    Rust or C++ host with one process per GPU calls (src/par.rs:67-95 across processes).  Passed as `collective=` to the
+    gathers below; rank and world are the communicator's."""
+
+    def __init__(self, handle, stream: int | None = None):
+        self.handle = handle
+        self.stream = stream
+        self.rank, self.world = handle.comm_info()
+        assert self.world >= 1, "flacenc_hip_comm_create first"
+
+    def records(self, gathered: torch.Tensor, local: torch.Tensor, n_local: int, n_total: int):
+        """rank-major, ranks one frame short zero-padded by the library (no padded copy on this side)"""
+        rec = local.element_size() * (local.numel() // max(local.shape[0], 1)) if local.shape[0] else gathered.element_size() * (gathered.numel() // gathered.shape[0])
+        assert local.is_contiguous() and gathered.is_contiguous() and local.is_cuda and gathered.is_cuda
+        self.handle.allgather_records_device(local.data_ptr() if n_local else 0, n_local, n_total, rec, gathered.data_ptr(), stream=self.stream)
+
+    def plain(self, gathered: torch.Tensor, local: torch.Tensor):
+        assert local.is_contiguous() and gathered.is_contiguous() and gathered.numel() * gathered.element_size() == self.world * local.numel() * local.element_size()
+        self.handle.allgather_device(local.data_ptr(), gathered.data_ptr(), local.numel() * local.element_size(), stream=self.stream)
+
+
+def _world_rank(group, collective):
+    if collective is not None:
+        return collective.world, collective.rank
+    return dist.get_world_size(group), dist.get_rank(group)
+
+
+def all_gather_records(local: torch.Tensor, n_frames_total: int, group=None, materialize: bool = True, collective=None) -> torch.Tensor:
     """All-gather per-frame records and return them in stream (frame-number) order.
     `materialize=False` returns the stream order as a strided view [ceil(F / G), G, ...] of the collective's
     output (frame f at [f // G, f % G]) instead of a re-ordered copy -- nothing but the collective runs.
@@ -36,22 +65,24 @@ def all_gather_records(local: torch.Tensor, n_frames_total: int, group=None, mat
     multiple of the world size); shorter ranks are padded for the collective.  The result is
     [n_frames_total, ...] on every rank -- what ParSink::finalize hands to the stream writer.
     """
-    if not dist.is_available() or not dist.is_initialized():
+    if collective is None and (not dist.is_available() or not dist.is_initialized()):
         assert local.shape[0] == n_frames_total
         return local if materialize else local.unsqueeze(1)
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
+    world, rank = _world_rank(group, collective)
     per_rank = (n_frames_total + world - 1) // world
     n_local = local_frame_count(n_frames_total, rank, world)
     assert local.shape[0] == n_local, (local.shape, n_local)
-    if n_local < per_rank:
-        pad = torch.zeros((per_rank - n_local,) + tuple(local.shape[1:]), dtype=local.dtype,
-                          device=local.device)
-        local = torch.cat([local, pad], dim=0)
-    local = local.contiguous()
     gathered = torch.empty((world * per_rank,) + tuple(local.shape[1:]), dtype=local.dtype,
                            device=local.device)
-    dist.all_gather_into_tensor(gathered, local, group=group)
+    if collective is not None:
+        collective.records(gathered, local.contiguous(), n_local, n_frames_total)
+    else:
+        if n_local < per_rank:
+            pad = torch.zeros((per_rank - n_local,) + tuple(local.shape[1:]), dtype=local.dtype,
+                              device=local.device)
+            local = torch.cat([local, pad], dim=0)
+        local = local.contiguous()
+        dist.all_gather_into_tensor(gathered, local, group=group)
     # gathered[r * per_rank + j] is stream frame j * world + r  ->  transpose (r, j) -> (j, r)
     g = gathered.view((world, per_rank) + tuple(local.shape[1:]))
     if not materialize:
@@ -122,21 +153,23 @@ def all_gather_frame_records(records: torch.Tensor, n_frames_total: int, block_s
     return GatheredRecords(wire, n_frames_total, block_size)
 
 
-def all_gather_rank_major(local: torch.Tensor, n_frames_total: int, group=None) -> torch.Tensor:
+def all_gather_rank_major(local: torch.Tensor, n_frames_total: int, group=None, collective=None) -> torch.Tensor:
     """The collective alone: [world * ceil(F / G), ...] as all_gather_into_tensor delivers it (row r * per_rank + j =
     stream frame j * G + r; shorter ranks zero-padded).  flacenc_hip_stream_offsets_async reads this layout."""
-    if not dist.is_available() or not dist.is_initialized():
+    if collective is None and (not dist.is_available() or not dist.is_initialized()):
         assert local.shape[0] == n_frames_total
         return local.contiguous()
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
+    world, rank = _world_rank(group, collective)
     per_rank = (n_frames_total + world - 1) // world
     n_local = local_frame_count(n_frames_total, rank, world)
     assert local.shape[0] == n_local, (local.shape, n_local)
+    gathered = torch.empty((world * per_rank,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    if collective is not None:
+        collective.records(gathered, local.contiguous(), n_local, n_frames_total)
+        return gathered
     if n_local < per_rank:
         pad = torch.zeros((per_rank - n_local,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         local = torch.cat([local, pad], dim=0)
-    gathered = torch.empty((world * per_rank,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(gathered, local.contiguous(), group=group)
     return gathered
 
@@ -194,7 +227,7 @@ def all_gather_frame_lengths(local_lengths: torch.Tensor, n_frames_total: int, g
 
 def all_gather_frame_bytes(place, packed: torch.Tensor, local_lengths: torch.Tensor, lengths_all: torch.Tensor,
                            offsets: torch.Tensor, n_frames_total: int, group=None,
-                           run_capacity: int | None = None) -> torch.Tensor:
+                           run_capacity: int | None = None, collective=None) -> torch.Tensor:
     """All-gather the packed FLAC frames themselves and return the assembled frame stream (uint8, frames
     back to back in frame-number order) on every rank -- ParSink::finalize's output (src/par.rs:82-94).
 
@@ -209,8 +242,11 @@ def all_gather_frame_bytes(place, packed: torch.Tensor, local_lengths: torch.Ten
     -- an upper bound on any rank's run, e.g. n_local * out_stride -- nothing is read back: runs travel
     padded to that bound and the result is a buffer of min(world * capacity, n_frames_total * out_stride) bytes whose
     first `stream_offsets(...)[1]` bytes are the stream -- callers slice with that total (the rest is uninitialised)."""
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if collective is not None:
+        world, rank = collective.world, collective.rank
+    else:
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
     per_rank = (n_frames_total + world - 1) // world
     n_local = local_frame_count(n_frames_total, rank, world)
     assert packed.shape[0] == n_local and packed.dtype == torch.uint8 and packed.is_contiguous()
@@ -231,7 +267,10 @@ def all_gather_frame_bytes(place, packed: torch.Tensor, local_lengths: torch.Ten
     row_offsets = torch.arange(n_local, dtype=torch.int64, device=dev) * packed.shape[1]
     my_lengths = local_lengths.to(torch.int32).contiguous()
     place(packed, row_offsets, my_lengths, run, run_offsets[:n_local, rank].contiguous())
-    if dist.is_initialized():  # (also a 1-rank group: the same collective call as with 8 ranks)
+    if collective is not None:
+        runs = torch.empty(world * run.numel(), dtype=torch.uint8, device=dev)
+        collective.plain(runs, run)
+    elif dist.is_initialized():  # (also a 1-rank group: the same collective call as with 8 ranks)
         runs = torch.empty(world * run.numel(), dtype=torch.uint8, device=dev)
         dist.all_gather_into_tensor(runs, run, group=group)
     else:

@@ -112,11 +112,13 @@ extern "C" {
  * BAD_CONFIG if both order flags are set. */
 #define FLACENC_HIP_FLAG_NIGHTLY_SUM_ORDER 64u
 
-/* The chunk tree as it is.  Without a summation-order flag, blocks of 4096 / 4608 samples at orders up to 12 (the fused
- * kernel's shapes) are CERTIFIED: the kernels keep their own autocorrelation sums where the quantised LPC parameters
- * provably equal those of the reference's sequential chains (a first-order perturbation bound on the Toeplitz solve
- * against the distance of every coefficient to its rounding boundary) and recompute the subframe
- * from those chains where they cannot prove it -- so that every integer output (coefficients, shift, order, residual,
+/* The kernels' own order as it is.  Without a summation-order flag, blocks of 4096 / 4608 samples at orders up to 12 (the
+ * fused kernel's shapes) are CERTIFIED: the kernels keep their own autocorrelation sums where a perturbation bound on the
+ * Toeplitz solve, held against the distance of every coefficient to its rounding boundary, says that the quantised LPC
+ * parameters equal those of the reference's sequential chains, and recompute the subframe from those chains where it
+ * does not (DESIGN.md section 2 lists what of the bound is shown and what is assumed and measured: it is evidence-backed,
+ * not a theorem about the floating-point recursion; systems the recursion does not find positive definite are never
+ * certified) -- so that every integer output (coefficients, shift, order, residual,
  * Rice partition, bit counts, frame bytes) is the stable build's, at the chunk tree's speed on material that is not
  * strongly tonal.  On material that IS (music, mostly: the certificate's second tier and the recomputation are serial
  * work), launches that return integers only -- no autocorr, no lpc_coefs -- switch, by what the certificate's counters

@@ -144,9 +144,10 @@ int orc_default_order_is_stable(size_t n, size_t lpc_order) {
 }
 
 /* ... and on blocks of 4096 / 4608 samples at LPC orders up to 12 (the fused kernel's shapes) the unflagged product
- * CERTIFIES its chunk-tree sums: it keeps them where the quantised parameters provably equal those of the reference's
- * own chains, and recomputes the subframe from those chains (ORC_ACORR_REFERENCE) where it cannot prove it
- * (orc_quant_certified below) -- so that every integer output of the default mode is the stable build's. */
+ * CERTIFIES its own sums: it keeps them where a perturbation bound on the Toeplitz solve (orc_quant_certified below:
+ * what of it is shown and what is assumed) says the quantised parameters equal those of the reference's own chains, and
+ * recomputes the subframe from those chains (ORC_ACORR_REFERENCE) where it does not -- so that every integer output of
+ * the default mode is the stable build's. */
 /* statistics of the certified mode since the last reset (not thread-safe: tests read them after single-threaded runs):
  * [0] subframes analysed, [1] certificates that needed the rows of T^-1, [2] subframes recomputed in the reference's order */
 unsigned long orc_cert_stats[3] = {0, 0, 0};
@@ -324,6 +325,9 @@ ORC_DEFINE_LEVINSON(orc_symmetric_levinson_f32, float, fmaf, 1.0f, 0.0f)
  * the product's certificate (flacenc_rs_amd/csrc/qlpc_kernel_impl.h, levinson_quantize<.., CERT>) restated. */
 static int orc_levinson_f64_forward(const double* coefs, const double* ys, size_t order, double* dest, double* forward,
                                     int* skipped) {
+  /* *skipped: bit 0 = a zero denominator skipped a step (lpc.rs:679-682), bit 1 = a denominator was not positive -- the
+   * Toeplitz matrix is not positive definite (the sums start at t = P for every lag: R[] need not be an autocorrelation)
+   * and the recursion is outside the domain where it is stable.  Either way the certificate does not apply. */
   double forward_next[ORC_MAX_LPC_ORDER + 1];
   *skipped = 0;
   for (size_t i = 0; i < order; ++i) dest[i] = 0.0;
@@ -341,8 +345,9 @@ static int orc_levinson_f64_forward(const double* coefs, const double* ys, size_
     double error = 0.0;
     for (size_t d = 0; d < n; ++d) error = fma(coefs[n - d], forward[d], error);
     double denom = fma(error, -error, 1.0);
+    if (!(denom > 0.0)) *skipped |= 2;
     if (denom == 0.0) {
-      *skipped = 1;
+      *skipped |= 1;
       continue;
     }
     double alpha = 1.0 / denom;
@@ -388,40 +393,48 @@ static int orc_quant_stable(const double* a, size_t P, int32_t shift, const doub
 /* The product's order certificate (levinson_quantize<.., CERT>, qlpc_kernel_impl.h), operation for operation: are the
  * quantised parameters of `a` (solution for R with R[0] = r0, forward vector `fwd`) those of ANY autocorrelation within
  * the summation bound eps of R?  max_abs_s = max |s| of the subframe, n = its length.  *tier2 = the row sums of |T^-1|
- * had to be evaluated. */
-int orc_quant_certified(const double* a, const double* fwd, size_t P, double r0, uint32_t max_abs_s, size_t n,
-                        uint32_t precision, int* tier2) {
+ * had to be evaluated.
+ *
+ * What is shown and what is assumed (DESIGN.md section 2 has the derivation).  With u = 2^-53:
+ *   eps      = (n + 96) u S >= |R^ - R~|_inf: n - P roundings of the reference's chain + <= 71 of the kernel's order, each
+ *              <= u x a partial sum of |products| <= u S, S = R0 + P max|s|^2 / 2 (Cauchy-Schwarz)            [shown]
+ *   F_i      = rowsum_i(|T^-1|) eps (1 + |a|_1) >= |first-order change of a_i|; attained by low-pass material, whose
+ *              T^-1 is a sign checkerboard under an alternating a (profiles/r06_fallback_ablation.txt, 6)     [shown]
+ *   2nd order: |da_i| <= F_i (1 + rho' / (1 - rho)), rho, rho' < P 2^-precision once the subframe passes the boundary
+ *              test below, i.e. <= 1.23 F_i for quant_precision >= 6 and P <= 12                               [shown]
+ *   recursion: both recursions (the reference's on R^, the kernel's on R~) are floating point.  ASSUMED: on a system the
+ *              recursion itself finds positive definite (every denominator 1 - err^2 > 0) the computed solution's
+ *              residual obeys |T a^ - r|_inf <= c_L P^2 u R0 (1 + |a^|_1) with c_L <= 11; then the two runs' errors add at
+ *              most (2 c_L P^2 / (n + 96)) F_i <= 0.77 F_i.  Measured (tools/certificate_attack.py, exact rational
+ *              residuals, 870 000 adversarial subframes): c_L <= 0.39.  Systems that are NOT positive definite -- the sums
+ *              start at t = P for every lag, R[] need not be an autocorrelation: a block that opens on a clipped plateau
+ *              is enough -- have no such bound (c_L up to 45 000 found, the two computed solutions 68 x further apart than
+ *              2 F_i on a subframe the round-5 rule certified) and are excluded: round 6, `skipped` bit 1 below.
+ *   safety   = 2.0 >= 1.23 + 2 c_L P^2 / (n + 96) for P <= 12, n >= 4096, c_L <= 11.
+ * Not a theorem about the floating-point recursion -- c_L is evidence, and below quant_precision 6 so is the second-order
+ * factor -- which is why tests/test_certificate_cpu.py soaks it and attacks it: the worst |a^_ref - a^_kernel|_i / (2 F_i)
+ * a hill-climber finds among certifiable subframes is 0.04 (1.5 ... 68 before the exclusion). */
+static void orc_cert_bounds(const double* R, const double* a, const double* fwd, size_t P, uint32_t max_abs_s, size_t n,
+                            double* num_out, double* f0_out, double* eps_a_out) {
   const double safety = 2.0;
-  if (tier2) *tier2 = 0;
-  int32_t shift = orc_find_shift(a, P, precision);
   double f1 = 0.0, a1 = 0.0;
   for (size_t i = 0; i < P; ++i) {
     f1 += fabs(fwd[i]);
     a1 += fabs(a[i]);
   }
   double m = (double)max_abs_s;
-  double S = r0 + (0.5 * (double)P) * (m * m);
+  double S = R[0] + (0.5 * (double)P) * (m * m);
   double eps = ((double)(n + 96) * 0x1p-53) * S;
   double eps_a = eps * (1.0 + a1);
-  /* tier 1, compared multiplied through by |f0| (the kernel's form: no division on the common path) */
-  double amax = 0.0;
-  for (size_t i = 0; i < P; ++i) amax = fmax(amax, fabs(a[i]));
-  double f0 = fabs(fwd[0]);
-  double num = ((safety * 2.0) * (f1 * f1)) * eps_a;
-  int e = orc_ceil_log2_pos(amax);
-  double g_lo = amax - ldexp(1.0, e - 1), g_hi = ldexp(1.0, e) - amax;
-  int ok = amax > 0.0 && num < g_lo * f0 && num < g_hi * f0;
-  double scalefac = (double)(1 << shift);
-  double nums = num * scalefac;
-  for (size_t i = 0; i < P; ++i) {
-    double v = fabs(a[i]) * scalefac;
-    double d = fabs((v - floor(v)) - 0.5);
-    if (!(d * f0 > nums)) ok = 0;
-  }
-  if (ok) return 1;
-  double da[ORC_MAX_LPC_ORDER];
-  if (tier2) *tier2 = 1;
-  /* rows of T^-1 from its first column: T^-1[i][j] = T^-1[i-1][j-1] + (f_i f_j - f_(P-i) f_(P-j)) / f_0 */
+  *f0_out = fabs(fwd[0]);
+  *num_out = ((safety * 2.0) * (f1 * f1)) * eps_a; /* tier 1: |da_i| |f0| <= num for every i */
+  *eps_a_out = eps_a;
+}
+
+/* tier 2: da[i] = safety x rowsum_i(|T^-1|) x eps_a; rows of T^-1 from its first column:
+ * T^-1[i][j] = T^-1[i-1][j-1] + (f_i f_j - f_(P-i) f_(P-j)) / f_0 */
+static void orc_cert_rows(const double* fwd, size_t P, double eps_a, double* da) {
+  const double safety = 2.0;
   double row[ORC_MAX_LPC_ORDER], inv_f0 = 1.0 / fwd[0];
   double rs = 0.0;
   for (size_t j = 0; j < P; ++j) {
@@ -439,6 +452,31 @@ int orc_quant_certified(const double* a, const double* fwd, size_t P, double r0,
     for (size_t j = 0; j < P; ++j) rs += fabs(row[j]);
     da[i] = (safety * rs) * eps_a;
   }
+}
+
+int orc_quant_certified(const double* R, const double* a, const double* fwd, size_t P, uint32_t max_abs_s, size_t n,
+                        uint32_t precision, int* tier2) {
+  if (tier2) *tier2 = 0;
+  int32_t shift = orc_find_shift(a, P, precision);
+  double num, f0, eps_a;
+  orc_cert_bounds(R, a, fwd, P, max_abs_s, n, &num, &f0, &eps_a);
+  /* tier 1, compared multiplied through by |f0| (the kernel's form: no division on the common path) */
+  double amax = 0.0;
+  for (size_t i = 0; i < P; ++i) amax = fmax(amax, fabs(a[i]));
+  int e = orc_ceil_log2_pos(amax);
+  double g_lo = amax - ldexp(1.0, e - 1), g_hi = ldexp(1.0, e) - amax;
+  int ok = amax > 0.0 && num < g_lo * f0 && num < g_hi * f0;
+  double scalefac = (double)(1 << shift);
+  double nums = num * scalefac;
+  for (size_t i = 0; i < P; ++i) {
+    double v = fabs(a[i]) * scalefac;
+    double d = fabs((v - floor(v)) - 0.5);
+    if (!(d * f0 > nums)) ok = 0;
+  }
+  if (ok) return 1;
+  double da[ORC_MAX_LPC_ORDER];
+  if (tier2) *tier2 = 1;
+  orc_cert_rows(fwd, P, eps_a, da);
   return orc_quant_stable(a, P, shift, da);
 }
 
@@ -583,7 +621,7 @@ int orc_lpc_from_autocorr(const int32_t* signal, size_t n, const orc_qlpc_config
           if (m > maxabs) maxabs = m;
         }
         int tier2 = 0;
-        certified = orc_quant_certified(coefs_out, fwd, lpc_order, corr[0], maxabs, n, cfg->quant_precision, &tier2);
+        certified = orc_quant_certified(corr, coefs_out, fwd, lpc_order, maxabs, n, cfg->quant_precision, &tier2);
         orc_cert_stats[1] += (unsigned long)tier2;
       }
     }
@@ -616,6 +654,39 @@ int orc_lpc_from_autocorr(const int32_t* signal, size_t n, const orc_qlpc_config
   if (status != ORC_STATUS_OK) return status;
   for (size_t i = 0; i < lpc_order; ++i)
     if (isnan(coefs_out[i]) || isinf(coefs_out[i])) return ORC_STATUS_NONFINITE; /* :797-799 */
+  return ORC_STATUS_OK;
+}
+
+/* Tool / test hook (tools/certificate_attack.py, tests/test_certificate_cpu.py): the certificate's quantities for one
+ * subframe of a certified shape -- R[] in the fused kernel's lane order, the recursion's solution and, per coefficient,
+ * the second tier's bound da[i] (safety included); *tier1 = the first tier's uniform bound num / |f0|.  Returns the
+ * recursion's status, or -1 where the certificate does not apply (shape, digital silence, a skipped step). */
+int orc_certificate_bounds(const int32_t* signal, size_t n, const orc_qlpc_config* cfg, double* corr_out, double* coefs_out,
+                           double* da_out, double* tier1_out) {
+  size_t P = cfg->lpc_order;
+  if (!orc_default_order_is_certified(n, P)) return -1;
+  float* window = (float*)malloc(sizeof(float) * n);
+  float* xw = (float*)malloc(sizeof(float) * (n + 1));
+  orc_window_weights(cfg->window_type, cfg->tukey_alpha, n, window);
+  orc_fill_windowed_signal(signal, window, n, xw);
+  double corr[ORC_MAX_LPC_ORDER + 1], fwd[ORC_MAX_LPC_ORDER + 1];
+  orc_auto_correlation_lane_order_f64(P + 1, xw, n, corr);
+  free(window);
+  free(xw);
+  int skipped = 0;
+  int st = orc_levinson_f64_forward(corr, corr + 1, P, coefs_out, fwd, &skipped);
+  for (size_t i = 0; i <= P; ++i) corr_out[i] = corr[i];
+  if (st != ORC_STATUS_OK) return st;
+  if (corr[0] == 0.0 || skipped) return -1;
+  uint32_t maxabs = 0;
+  for (size_t t = 0; t < n; ++t) {
+    uint32_t m = signal[t] < 0 ? (uint32_t)0 - (uint32_t)signal[t] : (uint32_t)signal[t];
+    if (m > maxabs) maxabs = m;
+  }
+  double num, f0, eps_a;
+  orc_cert_bounds(corr, coefs_out, fwd, P, maxabs, n, &num, &f0, &eps_a);
+  *tier1_out = num / f0;
+  orc_cert_rows(fwd, P, eps_a, da_out);
   return ORC_STATUS_OK;
 }
 

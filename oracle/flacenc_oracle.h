@@ -147,12 +147,15 @@ void orc_auto_correlation_lane_order_f64(size_t order, const float* signal, size
 int orc_default_order_is_stable(size_t n, size_t lpc_order);
 int orc_default_order_is_certified(size_t n, size_t lpc_order);
 extern unsigned long orc_cert_stats[3];
-int orc_quant_certified(const double* a, const double* fwd, size_t P, double r0, uint32_t max_abs_s, size_t n,
+int orc_quant_certified(const double* R, const double* a, const double* fwd, size_t P, uint32_t max_abs_s, size_t n,
                         uint32_t precision, int* tier2);
 void orc_auto_correlation_nightly_f64(size_t order, const float* signal, size_t n, double* dest,
                                       size_t base_mod);
 int orc_symmetric_levinson_f64(const double* coefs, const double* ys, size_t order, double* dest);
 int orc_symmetric_levinson_f32(const float* coefs, const float* ys, size_t order, float* dest);
+/* tool / test hook: the order certificate's bounds for one subframe (flacenc_oracle.c) */
+int orc_certificate_bounds(const int32_t* signal, size_t n, const orc_qlpc_config* cfg, double* corr_out, double* coefs_out,
+                           double* da_out, double* tier1_out);
 int32_t orc_find_shift(const double* coefs, size_t n, uint32_t precision);
 void orc_quantize_parameters(const double* coefs, size_t n, uint32_t precision, orc_qparams* out);
 void orc_compute_error(const orc_qparams* qp, const int32_t* signal, size_t n, int32_t* errors);

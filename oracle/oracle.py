@@ -320,6 +320,25 @@ def default_order_is_certified(n: int, lpc_order: int) -> bool:
     return bool(L.orc_default_order_is_certified(n, lpc_order))
 
 
+def certificate_bounds(signal, cfg: "QlpcConfig"):
+    """The order certificate's quantities for one subframe of a certified shape (orc_certificate_bounds): R[] in the fused
+    kernel's lane order, the recursion's coefficients, the second tier's per-coefficient bound da (safety included) and the
+    first tier's uniform bound.  None where the certificate does not apply (silence, a skipped step, another shape)."""
+    x = np.ascontiguousarray(signal, np.int32)
+    P = int(cfg.lpc_order)
+    corr = np.zeros(33, np.float64)
+    coefs = np.zeros(32, np.float64)
+    da = np.zeros(32, np.float64)
+    tier1 = C.c_double(0.0)
+    L = lib()
+    L.orc_certificate_bounds.restype = C.c_int
+    rc = L.orc_certificate_bounds(_p(x, C.c_int32), C.c_size_t(len(x)), C.byref(cfg), _p(corr, C.c_double),
+                                  _p(coefs, C.c_double), _p(da, C.c_double), C.byref(tier1))
+    if rc != 0:
+        return None
+    return {"R": corr[: P + 1].copy(), "a": coefs[:P].copy(), "da": da[:P].copy(), "tier1": float(tier1.value)}
+
+
 def cert_stats(reset: bool = False):
     """(subframes analysed in the certified mode, certificates that needed the rows of T^-1, subframes recomputed in the
     reference's order) since the last reset.  Plain counters: read them after single-threaded runs."""

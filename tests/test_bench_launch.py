@@ -95,6 +95,23 @@ def test_two_real_ranks_on_the_visible_gpus(gather):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("gather", ["records", "payload"])
+def test_one_rank_exchange_through_the_librarys_communicator(gather):
+    """`--comm capi`: the exchange's all-gathers run on the RCCL communicator the C library owns
+    (flacenc_hip_comm_create; flacenc_hip_allgather_records_async for lengths and wire records, flacenc_hip_allgather_async
+    for the packed runs) -- the calls a Rust / C++ host with one process per GPU makes -- and assemble the same stream."""
+    r = _run(["--force-exchange", "--comm", "capi", "--frames", "1536", "--steps", "3", "--warmup", "1", "--gather", gather,
+              "--no-secondary", "--no-cpu-baseline"], timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = _json_line(r.stdout)
+    assert line["n_gpus"] == 1 and line["ranks_observed"] == 1
+    assert line["exchange_collective"].startswith("C ABI: flacenc_hip_comm_create")
+    chk = line["config"]["exchange_check"]
+    assert chk["ok"] is True and chk["stream_frames"] == 1536 and chk["stream_bytes"] > 0
+    assert line["value"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gather", ["records", "payload"])
 def test_one_rank_rccl_exchange(gather):
     """RCCL itself, on the one GPU of a test box: `--force-exchange` initialises a 1-rank `nccl` process group
     and the exchange step runs the real collectives -- all_reduce for the rank count, all_gather_into_tensor

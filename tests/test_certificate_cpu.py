@@ -1,7 +1,8 @@
 """Soundness of the order certificate on the CPU, through the oracle's statement of it
 (orc_quant_certified == the kernel's arithmetic, operation for operation; tests/test_gpu_certified_order.py holds the GPU to
 the oracle bit for bit, counters included).  The certificate is a first-order perturbation bound with a safety factor, not
-a theorem about the floating-point recursion: this is its evidence -- over tens of thousands of subframes drawn to stress
+a theorem about the floating-point recursion (oracle/flacenc_oracle.c, orc_quant_certified, lists what is shown and what
+is assumed): this is its evidence -- over tens of thousands of subframes drawn to stress
 it (near-pure and multi-tone material with Toeplitz condition numbers up to 1e9, every order 1..12, precisions 3..15, all
 windows, 8..24 bits, silence / constants / impulses / clipping) a CERTIFIED subframe's QuantizedParameters never differ
 from the reference order's, while the bare kernel order's do on some of the very same subframes."""
@@ -74,3 +75,40 @@ def test_a_certified_subframe_is_never_wrong(n):
     print(f"n = {n}: {total} subframes, {tier2} needed the rows of T^-1, {recomputed} recomputed from the reference's chains "
           f"({recomputed / total:.3f}), 0 certified-but-different; the bare kernel order differs in {tree_differs}")
     assert total >= 1000 and recomputed < total  # (the certificate does certify most of even this corpus)
+
+
+def test_a_system_that_is_not_positive_definite_is_not_certified():
+    """Round 6's counter-example to the round-5 rule (tests/golden/README.md): the block opens on a clipped plateau, the
+    Toeplitz matrix of its lag sums has a negative eigenvalue, the recursion is unstable on it and its two runs -- on the
+    reference's sums and on the kernel's -- end 3.1e-7 apart where the bound (2 F_i = 4.6e-9) had certified the subframe.
+    The rule now excludes systems with a non-positive denominator: the subframe is recomputed from the reference's chains."""
+    import os
+    x = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cert_nonpd_plateau_24bit.npy"))
+    kw = dict(lpc_order=8, quant_precision=15, window="rectangle")
+    orc.cert_stats(reset=True)
+    cp, cres, _, _ = orc.qlpc_batch(x[None, :], 24, orc.make_config(acorr=orc.ACORR_CANONICAL, **kw), nthreads=1)
+    assert orc.cert_stats() == (1, 0, 1), "analysed, no second tier, recomputed"
+    assert orc.certificate_bounds(x, orc.make_config(**kw)) is None
+    rp, rres, rR, ra = orc.qlpc_batch(x[None, :], 24, orc.make_config(acorr=orc.ACORR_REFERENCE, **kw))
+    _, _, kR, ka = orc.qlpc_batch(x[None, :], 24, orc.make_config(acorr=orc.ACORR_CHUNK_TREE, **kw))
+    assert np.array_equal(cp, rp) and np.array_equal(cres, rres)
+    R = kR[0, :9]
+    T = np.array([[R[abs(i - j)] for j in range(8)] for i in range(8)])
+    assert np.linalg.eigvalsh(T).min() < 0, "the fixture's point: lag sums from t = P on need not be an autocorrelation"
+    assert np.abs(ra[0, :8] - ka[0, :8]).max() > 1e-7  # (the round-5 bound for this subframe was 4.6e-9)
+
+
+def test_attack_on_the_certificate_stays_an_order_of_magnitude_below_the_bound():
+    """tools/certificate_attack.py for a bounded time: a hill-climber over signal parameters that maximises
+    |a^_ref - a^_kernel|_i / bound_i among certifiable subframes (every bound below half a quantisation step).  Four runs of
+    170 s found 0.030-0.040 after round 6's exclusion (1.5 ... 68 before it); VERDICT r5 asks for <= 0.1.  Also: the residual
+    constant c_L of the floating-point recursion that the stated bound assumes to be <= 11."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import certificate_attack as ca
+    worst, c_l, evals = ca.attack(25.0, seed=20251005, orders=[4, 8, 10, 12], log=lambda *_: None)
+    print(f"{evals} evaluations: worst actual / bound {worst[0]:.4f}, largest recursion constant c_L {c_l:.3f}")
+    assert evals > 2000
+    assert worst[0] <= 0.1, worst
+    assert c_l <= 2.0, c_l

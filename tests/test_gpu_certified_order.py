@@ -1,5 +1,5 @@
 """The unflagged summation order on blocks of 4096 / 4608 samples at LPC orders up to 12 (the fused kernel's shapes) is
-CERTIFIED: the kernels keep their chunk-tree autocorrelation where the quantised parameters provably equal those of the
+CERTIFIED: the kernels keep their own autocorrelation sums where the order certificate says the quantised parameters equal those of the
 reference's sequential chains (src/lpc.rs:533-548) and recompute the subframe from those chains where they cannot prove it
 (DESIGN.md section 2).  So with flags = 0:
 
@@ -141,6 +141,24 @@ def test_other_orders_and_the_4608_block(handle, order):
     x = np.concatenate([near_pure_sines(12, 4608, seed0=77), noisy_sines(12, 4608)])
     got, want = certified_exact(handle, x, 16, order)
     assert got == want
+
+
+def test_systems_that_are_not_positive_definite_are_recomputed(handle):
+    """Round 6 (tests/test_certificate_cpu.py::test_a_system_that_is_not_positive_definite_is_not_certified): lag sums from
+    t = P on need not be an autocorrelation; where the recursion meets a non-positive denominator it is unstable, the
+    certificate does not apply and the subframe takes the reference's chains -- on the device as in the oracle, counters
+    included.  The attack's 24-bit counter-example, and plateaus in front of 16-bit material (same mechanism)."""
+    import os
+    x = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cert_nonpd_plateau_24bit.npy"))
+    got, want = certified_exact(handle, np.stack([x, x, x, x]), 24, 8, window="rectangle")
+    assert got == want == (4, 0, 4), (got, want)
+    y = noisy_sines(16, 4096, seed0=31)
+    for k in range(16):
+        y[k, : 8 + k] = 30000 if k % 2 else -30000  # a full-scale plateau over the first lags
+    for window in ("rectangle", ("tukey", 0.4)):
+        for order in (8, 12):
+            got, want = certified_exact(handle, y, 16, order, window=window)
+            assert got == want, (window, order, got, want)
 
 
 def test_the_corpus_separates_the_orders(handle):

@@ -491,10 +491,23 @@ __global__ void __launch_bounds__(256) acorr_reference_mfma_kernel(AcorrRefArgs 
   const int P = (int)a.lpc_order;
   const bool vec_ok = ((reinterpret_cast<uintptr_t>(a.samples) & 15) == 0) && ((a.stride & 3) == 0);
   const float* __restrict__ wtab = a.window ? a.window + 32 : nullptr;
-  // the wave's four subframes
-  const uint32_t unit = blockIdx.x * 4u + (uint32_t)wave;  // stereo: frame; plain: group of four subframes
+  // the wave's four subframes: unit = blockIdx.x * 4 + wave (stereo: a frame; plain: a group of four subframes) -- or, in
+  // the sub-wave kernel's clean-up (marked_params; round 6), the units of a small grid's stride that hold a record of
+  // status -2 (int32 at byte 68 of the 352-byte record): the launch normally finds the count of marked records at 0 and
+  // must cost next to nothing then
+  auto process = [&](const uint32_t unit) __attribute__((always_inline)) {
   const uint32_t sf0 = unit * 4u;
   if (sf0 >= a.n_subframes) return;  // (whole wave; no barriers in this kernel)
+  if (a.marked_params != nullptr) {
+    const unsigned char* const recs = static_cast<const unsigned char*>(a.marked_params);
+    bool any = false;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const uint32_t sf = sf0 + (uint32_t)r;
+      if (sf < a.n_subframes) any |= *reinterpret_cast<const int32_t*>(recs + (size_t)sf * 352u + 68u) == -2;
+    }
+    if (!any) return;
+  }
   const int32_t* rowp[STEREO ? 2 : 4];
   if (STEREO) {
     rowp[0] = a.samples + (size_t)(2u * unit) * a.stride;
@@ -634,12 +647,20 @@ __global__ void __launch_bounds__(256) acorr_reference_mfma_kernel(AcorrRefArgs 
       }
     }
   }
+  };  // process
+  if (a.marked_params == nullptr) {
+    process(blockIdx.x * 4u + (uint32_t)wave);
+  } else {
+    if (a.marked_count != nullptr && __hip_atomic_load(a.marked_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
+    for (uint32_t unit = blockIdx.x * 4u + (uint32_t)wave; unit * 4u < a.n_subframes; unit += gridDim.x * 4u) process(unit);
+  }
 }
 
 template <int NS>
 hipError_t launch_mfma(const AcorrRefArgs& a, hipStream_t stream) {
   const uint32_t units = a.stereo ? a.n_subframes / 4u : (a.n_subframes + 3u) / 4u;
-  const uint32_t blocks = (units + 3u) / 4u;
+  uint32_t blocks = (units + 3u) / 4u;
+  if (a.marked_params != nullptr && blocks > 512u) blocks = 512u;  // (a grid-stride walk of the records: see the kernel)
   if (a.stereo) hipLaunchKernelGGL((acorr_reference_mfma_kernel<true, NS>), dim3(blocks), dim3(256), 0, stream, a);
   else hipLaunchKernelGGL((acorr_reference_mfma_kernel<false, NS>), dim3(blocks), dim3(256), 0, stream, a);
   return hipGetLastError();

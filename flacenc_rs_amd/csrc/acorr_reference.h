@@ -19,6 +19,11 @@ struct AcorrRefArgs {
   uint32_t lpc_order;      // P: lags 0..P are produced
   uint32_t nightly;        // 0: the stable build's single chain per lag; 1: simd-nightly's lane chains (P <= 15)
   double* out;             // device, [n_subframes][33]; lags above P are written as 0
+  // Clean-up behind the sub-wave kernel's order certificate (round 6): only the subframes whose record carries status -2
+  // (flacenc_hip_subframe_params, 352 bytes each; stable order only) -- a wave whose four subframes have none returns at
+  // once, the whole launch when *marked_count is 0.  nullptr: every subframe.
+  const void* marked_params = nullptr;
+  const uint32_t* marked_count = nullptr;
 };
 
 // R[tau] = the single sequential fma chain of weighted_auto_correlation_nosimd (src/lpc.rs:533-548):

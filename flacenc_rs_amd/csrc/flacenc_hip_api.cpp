@@ -1331,6 +1331,7 @@ int flacenc_hip_encode_frames_async(flacenc_hip_handle* h, const flacenc_hip_fra
     if (block_size >= FLACENC_HIP_MIN_BLOCK_SIZE && flacenc_hip::subwave_shape(block_size)) {
       flacenc_hip::QlpcKernelArgs m = a;
       m.fixed_partitions = cfg->fixed_partitions;
+      m.cert_subwave = (a.certify != 0u && a.reference_order == 0u && !a.direct_mse && cfg->use_lpc && cfg->qlpc.lpc_order <= 12) ? 1u : 0u;
       if ((rc = attach_split_scratch(h, m)) != FLACENC_HIP_OK) return rc;
       if (flacenc_hip::subwave_channels_eligible(m)) {
         const size_t cs = (static_cast<size_t>(block_size) + 3) & ~static_cast<size_t>(3);
@@ -2247,6 +2248,8 @@ static int encode_stereo_frames_impl(flacenc_hip_handle* h, const flacenc_hip_fr
       flacenc_hip::QlpcKernelArgs m = a;
       m.stamps = nullptr;
       m.fixed_partitions = cfg->fixed_partitions;
+      // (the order certificate on these shapes: first tier in the kernel, the reference's chains for the frames it marks)
+      m.cert_subwave = (a.certify != 0u && a.reference_order == 0u && !a.direct_mse && cfg->use_lpc && cfg->qlpc.lpc_order <= 12) ? 1u : 0u;
       if ((rc = attach_split_scratch(h, m)) != FLACENC_HIP_OK) return rc;
       if (flacenc_hip::subwave_frame_eligible(m)) {
         if ((rc = ensure(h, h->d_cparams, n_sub * sizeof(flacenc_hip_subframe_params))) != FLACENC_HIP_OK) return rc;

@@ -229,6 +229,30 @@ hipError_t launch_qlpc(const QlpcKernelArgs& a, const QlpcLaunchPlan& plan, hipS
   // take (unaligned rows, FLACENC_HIP_FLAG_GENERIC_KERNEL) or that cannot certify inside it (the fused bit writer, which
   // returns bytes alone) are simply given the reference's R[] from acorr_reference_kernel: the same integers -- the
   // reference's -- with R[] and the unquantised coefficients in the reference's own order.
+  // The clean-up launch behind the sub-wave kernel's order certificate (round 6): the records it marked with status -2 take
+  // the reference's chains -- acorr_reference_mfma_kernel restricted to them (a wave without such a record returns at once,
+  // the launch when nothing was marked) -- and the generic kernel redoes them from that R[] (`acorr_marked`).
+  if (a.only_marked && a.cert_subwave != 0u && a.acorr_marked == nullptr && a.fixed_mode == 0 && a.split_scratch != nullptr &&
+      a.params != nullptr) {
+    double* racc = reinterpret_cast<double*>(a.split_scratch);
+    AcorrRefArgs r{};
+    r.samples = a.samples;
+    r.stride = a.stride;
+    r.block_size = a.block_size;
+    r.n_subframes = a.n_subframes;
+    r.stereo = a.stereo;
+    r.window = a.window;
+    r.lpc_order = a.lpc_order;
+    r.nightly = 0u;
+    r.out = racc;
+    r.marked_params = a.params;
+    r.marked_count = a.marked_count;
+    hipError_t err = launch_acorr_reference(r, stream);
+    if (err != hipSuccess) return err;
+    QlpcKernelArgs b = a;
+    b.acorr_marked = racc;
+    return launch_qlpc(b, plan, stream);
+  }
   bool certified_fused = false;  // this launch certifies inside the fused kernel: no reference-order pass in front of it
   if (a.certify != 0u) {
     // (FLACENC_HIP_FLAG_INTEGER_PARITY_ONLY: the stable order is asked for, but only for the integers -- the certificate
@@ -237,6 +261,16 @@ hipError_t launch_qlpc(const QlpcKernelArgs& a, const QlpcLaunchPlan& plan, hipS
     const bool shape = cert_shape(a) && order_ok && !a.direct_mse && a.fixed_mode == 0 && a.lpc_stage == 0 &&
                        a.acorr_in == nullptr && !a.only_marked;
     const bool wave = shape && wave_kernel_eligible(a);
+    // the sub-wave kernel's shapes (round 6): first tier in the kernel, the reference's chains for what it marks
+    const bool sub_shape = subwave_shape(a.block_size) && a.lpc_order >= 1 && a.lpc_order <= 12 && a.reference_order == 0u &&
+                           !a.direct_mse && a.fixed_mode == 0 && a.lpc_stage == 0 && a.acorr_in == nullptr && !a.only_marked;
+    if (sub_shape) {
+      QlpcKernelArgs b = a;
+      b.certify = 0;
+      if (subwave_eligible(a) && a.split_scratch != nullptr) b.cert_subwave = 1u;
+      else b.reference_order = 1u;  // (unaligned rows, FLACENC_HIP_FLAG_GENERIC_KERNEL: the reference's order outright)
+      return launch_qlpc(b, plan, stream);
+    }
     if (!shape || !wave || a.pack_out != nullptr) {
       QlpcKernelArgs b = a;
       b.certify = 0;
@@ -351,9 +385,12 @@ hipError_t launch_qlpc(const QlpcKernelArgs& a, const QlpcLaunchPlan& plan, hipS
     if (err != hipSuccess) return err;
     QlpcKernelArgs c = a;
     c.only_marked = 1;
-    c.autocorr = nullptr;  // (written; the clean-up rewrites records and rows only)
-    c.lpc_coefs = nullptr;
+    if (a.cert_subwave == 0u) {
+      c.autocorr = nullptr;  // (written; the clean-up rewrites records and rows only)
+      c.lpc_coefs = nullptr;
+    }  // (cert_subwave: R[] and the coefficients of a record marked -2 become the reference order's)
     c.selector_keys = a.selector_keys;
+    if (a.cert_subwave != 0u && a.fixed_mode == 0) return launch_qlpc(c, plan, stream);  // (+ the reference's chains, top)
 #define FLACENC_HIP_SUBCLEAN(MP, BG) \
   if (plan.maxp == MP && plan.big == (BG != 0)) return launch_qlpc_##MP##_##BG(c, plan.threads, plan.smem_bytes, stream);
     FLACENC_HIP_FOR_EACH_INSTANCE(FLACENC_HIP_SUBCLEAN)

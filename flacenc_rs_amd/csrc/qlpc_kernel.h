@@ -43,6 +43,12 @@ struct QlpcKernelArgs {
   // launches of these shapes on other kernels take the reference's order outright.  cert_stats (nullable, test / bench
   // hook): [0] subframes analysed, [1] certificates that needed the rows of T^-1, [2] subframes redone.
   uint32_t certify = 0;
+  // ... and on the sub-wave kernel's shapes (blocks of 256 .. 2304 samples, orders up to 12; round 6): qlpc_subwave_kernel
+  // holds its chunk-tree sums to the certificate and marks what it does not certify with record status -2;
+  // the clean-up launch behind it (only_marked) runs the reference's chains for exactly those records
+  // (acorr_reference_mfma_kernel, restricted to them) and hands them to the generic kernel as `acorr_marked`
+  uint32_t cert_subwave = 0;
+  const double* acorr_marked = nullptr;  // device, [n][33]: R[] of the records with status -2 (clean-up launch only)
   uint32_t integer_parity_only = 0;  // FLACENC_HIP_FLAG_INTEGER_PARITY_ONLY with reference_order 1: certified shapes keep their order
   uint32_t* cert_stats = nullptr;
   // ... and, with the ApproxEnt order selector of fixed_lpc, every estimator partition's sum of |e| comes

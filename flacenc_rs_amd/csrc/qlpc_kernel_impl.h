@@ -603,13 +603,28 @@ __global__ void __launch_bounds__(MAXP <= 12 ? 1024 : (MAXP <= 16 ? 512 : 256)) 
     if (__hip_atomic_load(a.marked_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
   }
   // (a small grid walks the records in strides: the usual launch finds the count at 0 and is over at once)
+  // Round 6: the marked records of a window are found by wave ballots and visited one by one -- the window used to be
+  // walked record by record with a barrier each (1024 barriers for one marked record: 40 us of a launch that, with the
+  // order certificate on the sub-wave shapes, now normally has a handful of records to redo).
+  __shared__ unsigned long long marked_ballot[16];
+  const int mw = threadIdx.x >> 6, nw = (int)(blockDim.x >> 6);
   for (uint32_t base = blockIdx.x * blockDim.x; base < a.n_subframes; base += gridDim.x * blockDim.x) {
     const uint32_t mine = base + threadIdx.x;
-    if (!__syncthreads_or(mine < a.n_subframes && a.params[mine].status == -1 ? 1 : 0)) continue;
-    for (uint32_t i = 0; i < blockDim.x && base + i < a.n_subframes; ++i) {
-      if (a.params[base + i].status == -1) qlpc_subframe_call<MAXP, BIG>(a, base + i);
-      __syncthreads();
+    // (-1: beyond the marking kernel's exact sums; -2: not passed by the sub-wave kernel's order certificate)
+    const bool marked = mine < a.n_subframes && (a.params[mine].status == -1 || a.params[mine].status == -2);
+    const unsigned long long bal = __builtin_amdgcn_ballot_w64(marked);
+    if ((threadIdx.x & 63) == 0) marked_ballot[mw] = bal;
+    if (!__syncthreads_or(marked ? 1 : 0)) continue;
+    for (int w = 0; w < nw; ++w) {
+      unsigned long long b = marked_ballot[w];  // (workgroup-uniform: every thread walks the same bits)
+      while (b != 0ull) {
+        const int bit = __builtin_ctzll(b);
+        b &= b - 1ull;
+        qlpc_subframe_call<MAXP, BIG>(a, base + (uint32_t)(64 * w + bit));
+        __syncthreads();
+      }
     }
+    __syncthreads();  // (the ballots are rewritten by the next window)
   }
 }
 

@@ -23,6 +23,11 @@
 // Rare subframes -- residuals of 2^25 (72-sample lanes; 2^26 for 64) and more, or a saturated table minimum
 // (rice.rs:51) -- are marked (record status -1, QlpcKernelArgs::marked_count) and redone by the generic kernel's
 // clean-up launch, as bigblock_residual_kernel does.
+// Round 6 -- the order certificate on these shapes (QlpcKernelArgs::cert_subwave): the chunk-tree sums
+// are kept where the certificate (levinson_quantize<.., CERT>: the Gohberg-Semencul norm bound behind each recursion, the
+// rows of T^-1 out of line where that cannot decide) says that the quantised parameters are those of the reference's
+// chains (lpc.rs:533-548); a subframe it does not certify is marked with status -2, and the clean-up launch redoes it from those
+// chains (acorr_reference_mfma_kernel restricted to the marked records -> the generic kernel with their R[]).
 // STEREO: wave w of the workgroup is role w (L, R, M, S) of the workgroup's 64 / LPS frames, whose two channel
 // images are shared in LDS -- the role stays wave-uniform and each channel is read from HBM once.
 // Plain: two waves per workgroup, every segment an independent subframe with its own image.
@@ -270,6 +275,7 @@ __global__ void __launch_bounds__(STEREO ? 256 : 128, 3) qlpc_subwave_kernel(Qlp
   // ======================= phase 1: window + autocorrelation ==============
   if (LPC) {
     double R[NLAG];
+    int cert_max = 0, cert_min = 0;
     with_role([&](auto kind) {
       double dw[HP + 16];
       double acc[NLAG], s01[NLAG], p2[NLAG];
@@ -278,6 +284,9 @@ __global__ void __launch_bounds__(STEREO ? 256 : 128, 3) qlpc_subwave_kernel(Qlp
       auto conv4 = [&](int t, int at) {
         const int ix = G::idx(t);
         const int4 v = ld4_at(kind, ix);
+        // (the certificate's max |s|: every sample of the subframe passes here once or twice; the zeros in front of it add nothing)
+        cert_max = max(max(cert_max, v.x), max(v.y, max(v.z, v.w)));
+        cert_min = min(min(cert_min, v.x), min(v.y, min(v.z, v.w)));
         const float4 w = *reinterpret_cast<const float4*>(&wlds[ix]);
         dw[at + 0] = (double)((float)v.x * w.x);
         dw[at + 1] = (double)((float)v.y * w.y);
@@ -335,6 +344,12 @@ __global__ void __launch_bounds__(STEREO ? 256 : 128, 3) qlpc_subwave_kernel(Qlp
         for (int k = 0; k < NLAG; ++k) R[k] = R[k] + seg_tree_sum_last<LPS>(sl < LPS / 2 ? acc[k] : 0.0);
       }
     });
+    {
+      // max |s| of the subframe (find_max_abs, arrayutils.rs:509), for the certificate's summation bound
+      const uint32_t hi = seg_allreduce<LPS>((uint32_t)cert_max, [](uint32_t x, uint32_t y) { return x > y ? x : y; });
+      const uint32_t lo = seg_allreduce<LPS>((uint32_t)(-(long long)cert_min), [](uint32_t x, uint32_t y) { return x > y ? x : y; });
+      if (sl == LPS - 1) xd[g * 8 + 6] = hi > lo ? hi : lo;
+    }
     if (sl == LPS - 1) {
 #pragma unroll
       for (int k = 0; k < NLAG; ++k) xr[g * NLAG + k] = R[k];
@@ -354,12 +369,32 @@ __global__ void __launch_bounds__(STEREO ? 256 : 128, 3) qlpc_subwave_kernel(Qlp
       double coef[MAXP];
       int32_t cqv[MAXP];
       int warm_v, shift_v;
-      const int st = levinson_quantize<MAXP>(Rl, P, (int)a.precision, coef, cqv, &warm_v, &shift_v);
+      // (cert_subwave: + the order certificate's first tier; a subframe it does not certify is marked, see the header)
+      bool certified = true, tier2 = false;
+      const bool do_cert = a.cert_subwave != 0u;
+      const int st = levinson_quantize<MAXP, true>(Rl, P, (int)a.precision, coef, cqv, &warm_v, &shift_v, xd[lane * 8 + 6], n,
+                                                   &certified, &tier2, do_cert);
 #pragma unroll
       for (int i = 0; i < MAXP; ++i) xq[lane * 16 + i] = cqv[i];
       xq[lane * 16 + 12] = warm_v;
       xq[lane * 16 + 13] = shift_v;
       xq[lane * 16 + 14] = st;
+      // second tier (the rows of T^-1), out of line and only for the lanes whose first tier could not decide: it keeps a
+      // handful of subframes per launch of moderately tonal material out of the clean-up launches, whose fixed cost
+      // (~50 us: the reference's chains + a workgroup of the generic kernel per record) is a quarter of a 16 M-sample launch
+      if (do_cert && __builtin_amdgcn_ballot_w64(tier2) != 0ull) {
+        if (tier2) certified = quant_certified_rows<MAXP>(xr + lane * NLAG, P, (int)a.precision, xd[lane * 8 + 6], n);
+      }
+      xq[lane * 16 + 15] = (do_cert && !certified) ? 1 : 0;
+      if (do_cert && a.cert_stats != nullptr) {
+        const uint32_t sfc = STEREO ? (blk * (uint32_t)S + (uint32_t)(lane >> 2)) * 4u + (uint32_t)(lane & 3)
+                                    : blk * (uint32_t)SUBS + (uint32_t)lane;
+        if (sfc < a.n_subframes) {
+          atomicAdd(a.cert_stats + 0, 1u);
+          if (tier2) atomicAdd(a.cert_stats + 1, 1u);
+          if (!certified) atomicAdd(a.cert_stats + 2, 1u);
+        }
+      }
       if (a.lpc_coefs) {
         // slot -> subframe (STEREO slots are frame-major: slot = 4 frame + role)
         uint32_t sfl = STEREO ? (blk * (uint32_t)S + (uint32_t)(lane >> 2)) * 4u + (uint32_t)(lane & 3)
@@ -744,6 +779,7 @@ __global__ void __launch_bounds__(STEREO ? 256 : 128, 3) qlpc_subwave_kernel(Qlp
   const int warm = xq[g * 16 + 12];
   const int shift = xq[g * 16 + 13];
   const int status = xq[g * 16 + 14];
+  const bool cert_mark = xq[g * 16 + 15] != 0;  // not certified: the reference's chains, by the clean-up launch
   with_role([&](auto kind) {
     int sw[HP + 16];
     constexpr int NCH = (SPL + 15) / 16;
@@ -793,9 +829,9 @@ __global__ void __launch_bounds__(STEREO ? 256 : 128, 3) qlpc_subwave_kernel(Qlp
     // ======================= phase 5: the record ============================
     if (!active || a.params == nullptr) return;
     flacenc_hip_subframe_params* rec = a.params + sf;
-    if ((lp.redo && status == 0) || (S16 && xd[g * 8 + 7] != 0u)) {
+    if ((lp.redo && status == 0) || (S16 && xd[g * 8 + 7] != 0u) || cert_mark) {
       if (sl == 0) {
-        rec->status = -1;
+        rec->status = cert_mark ? -2 : -1;
         if (a.marked_count != nullptr) atomicAdd(a.marked_count, 1u);
       }
       return;
@@ -826,14 +862,15 @@ __global__ void __launch_bounds__(STEREO ? 256 : 128, 3) qlpc_subwave_kernel(Qlp
       bits = verbatim_bits;
     }
     // a candidate the exact sums could not carry: the whole frame goes to the general path (launch_qlpc)
-    const bool redo = (a.use_lpc && status == 0 && lp.redo) || (have_fixed && fx.redo) || (S16 && xd[g * 8 + 7] != 0u);
+    const bool redo = (a.use_lpc && status == 0 && lp.redo) || (have_fixed && fx.redo) || (S16 && xd[g * 8 + 7] != 0u) ||
+                      (a.use_lpc && cert_mark);
     if (VARIANT == 3) {
       // ---- Independent(n) frames: the segment's subframe is one output channel ----
       if (!active) return;
       flacenc_hip_channel_result* out = a.chan_results + sf;
       if (redo) {
         if (sl == 0) {
-          if (a.cand_lpc_params) const_cast<flacenc_hip_subframe_params*>(a.cand_lpc_params)[sf].status = -1;
+          if (a.cand_lpc_params) const_cast<flacenc_hip_subframe_params*>(a.cand_lpc_params)[sf].status = cert_mark ? -2 : -1;
           if (a.cand_fixed_params) const_cast<flacenc_hip_subframe_params*>(a.cand_fixed_params)[sf].status = -1;
           out->kind = 0xFF;
           if (a.marked_count != nullptr) atomicAdd(a.marked_count, 1u);
@@ -910,7 +947,7 @@ __global__ void __launch_bounds__(STEREO ? 256 : 128, 3) qlpc_subwave_kernel(Qlp
     if (any_redo) {
       // marked for the general path: its candidate batches redo the frame's four roles, frame_decide_kernel the frame
       if (sl == 0) {
-        if (a.cand_lpc_params) const_cast<flacenc_hip_subframe_params*>(a.cand_lpc_params)[sf].status = -1;
+        if (a.cand_lpc_params) const_cast<flacenc_hip_subframe_params*>(a.cand_lpc_params)[sf].status = cert_mark ? -2 : -1;
         if (a.cand_fixed_params) const_cast<flacenc_hip_subframe_params*>(a.cand_fixed_params)[sf].status = -1;
         if (role == 0) {
           fr->channel_assignment = 0xFF;

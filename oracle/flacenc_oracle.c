@@ -151,9 +151,17 @@ int orc_default_order_is_stable(size_t n, size_t lpc_order) {
 /* statistics of the certified mode since the last reset (not thread-safe: tests read them after single-threaded runs):
  * [0] subframes analysed, [1] certificates that needed the rows of T^-1, [2] subframes recomputed in the reference's order */
 unsigned long orc_cert_stats[3] = {0, 0, 0};
+int orc_certified_subwave_shape(size_t n);
 
 int orc_default_order_is_certified(size_t n, size_t lpc_order) {
-  return (n == 4096 || n == 4608) && lpc_order >= 1 && lpc_order <= 12;
+  return (n == 4096 || n == 4608 || orc_certified_subwave_shape(n)) && lpc_order >= 1 && lpc_order <= 12;
+}
+
+/* ... and (round 6) on the sub-wave kernel's shapes -- blocks of 4 / 8 / 16 / 32 finest Rice partitions: 256 .. 2048 and the
+ * CD-style 288 .. 2304 -- its chunk-tree sums are held to the same certificate; what it does not certify is marked and
+ * recomputed from the reference's chains by the clean-up launch behind the kernel. */
+int orc_certified_subwave_shape(size_t n) {
+  return n == 256 || n == 512 || n == 1024 || n == 2048 || n == 288 || n == 576 || n == 1152 || n == 2304;
 }
 
 /* The fused kernel's own summation order on blocks of 4096 / 4608 samples (flacenc_rs_amd/csrc/qlpc_wave_kernel_impl.h,
@@ -456,6 +464,7 @@ static void orc_cert_rows(const double* fwd, size_t P, double eps_a, double* da)
 
 int orc_quant_certified(const double* R, const double* a, const double* fwd, size_t P, uint32_t max_abs_s, size_t n,
                         uint32_t precision, int* tier2) {
+  const int allow_tier2 = 1;
   if (tier2) *tier2 = 0;
   int32_t shift = orc_find_shift(a, P, precision);
   double num, f0, eps_a;
@@ -474,6 +483,7 @@ int orc_quant_certified(const double* R, const double* a, const double* fwd, siz
     if (!(d * f0 > nums)) ok = 0;
   }
   if (ok) return 1;
+  if (!allow_tier2) return 0;
   double da[ORC_MAX_LPC_ORDER];
   if (tier2) *tier2 = 1;
   orc_cert_rows(fwd, P, eps_a, da);
@@ -601,7 +611,8 @@ int orc_lpc_from_autocorr(const int32_t* signal, size_t n, const orc_qlpc_config
   if (cfg->acorr_order == ORC_ACORR_CANONICAL && orc_default_order_is_certified(n, lpc_order)) {
     /* the unflagged product on these shapes: chunk-tree sums where their quantised parameters are certified to be the
      * reference's, the reference's own chains where not */
-    orc_auto_correlation_lane_order_f64(lpc_order + 1, xw, n, corr);
+    if (orc_certified_subwave_shape(n)) orc_auto_correlation_canonical_f64(lpc_order + 1, xw, n, corr); /* the chunk tree */
+    else orc_auto_correlation_lane_order_f64(lpc_order + 1, xw, n, corr);
     int st = ORC_STATUS_OK;
     for (size_t i = 0; i <= lpc_order; ++i)
       if (isnan(corr[i]) || isinf(corr[i])) st = ORC_STATUS_NONFINITE;
@@ -634,7 +645,8 @@ int orc_lpc_from_autocorr(const int32_t* signal, size_t n, const orc_qlpc_config
     orc_cert_stats[2] += 1;
     for (size_t i = 0; i < lpc_order; ++i) coefs_out[i] = 0.0;
     orc_auto_correlation_f64(lpc_order + 1, xw, n, corr);
-  } else if (cfg->acorr_order == ORC_ACORR_CHUNK_TREE && orc_default_order_is_certified(n, lpc_order))
+  } else if (cfg->acorr_order == ORC_ACORR_CHUNK_TREE && orc_default_order_is_certified(n, lpc_order) &&
+             !orc_certified_subwave_shape(n))
     orc_auto_correlation_lane_order_f64(lpc_order + 1, xw, n, corr); /* the fused kernel's order, uncertified */
   else if (cfg->acorr_order == ORC_ACORR_GENERIC_TREE ||
            ((cfg->acorr_order == ORC_ACORR_CANONICAL || cfg->acorr_order == ORC_ACORR_CHUNK_TREE) &&
@@ -670,7 +682,8 @@ int orc_certificate_bounds(const int32_t* signal, size_t n, const orc_qlpc_confi
   orc_window_weights(cfg->window_type, cfg->tukey_alpha, n, window);
   orc_fill_windowed_signal(signal, window, n, xw);
   double corr[ORC_MAX_LPC_ORDER + 1], fwd[ORC_MAX_LPC_ORDER + 1];
-  orc_auto_correlation_lane_order_f64(P + 1, xw, n, corr);
+  if (orc_certified_subwave_shape(n)) orc_auto_correlation_canonical_f64(P + 1, xw, n, corr);
+  else orc_auto_correlation_lane_order_f64(P + 1, xw, n, corr);
   free(window);
   free(xw);
   int skipped = 0;

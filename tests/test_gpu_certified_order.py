@@ -161,6 +161,59 @@ def test_systems_that_are_not_positive_definite_are_recomputed(handle):
             assert got == want, (window, order, got, want)
 
 
+@pytest.mark.parametrize("n", [256, 576, 1024, 1152, 2048, 2304])
+@pytest.mark.parametrize("order", [8, 12])
+def test_sub_wave_shapes_first_tier_or_the_references_chains(handle, n, order):
+    """Round 6: blocks of 256 .. 2304 samples (the sub-wave kernel) keep their chunk-tree sums where the certificate
+    passes; what it does not pass is marked (record status -2) and redone from the reference's chains by the clean-up
+    launch (acorr_reference_mfma_kernel restricted to the marked records -> the generic kernel with their R[]).  GPU == the
+    oracle's statement of that rule bit for bit (R[] and coefficients included, counters included) and == the reference
+    order on every integer, on easy material (nothing marked), hard material (nearly everything marked) and a mixture."""
+    easy = noisy_sines(40, n, seed0=10 + order)
+    hard = near_pure_sines(40, n, seed0=500 + order)
+    got, want = certified_exact(handle, easy, 16, order)
+    assert got == want, (got, want)
+    got, want = certified_exact(handle, hard, 16, order)
+    assert got == want and want[2] > 0, (got, want)  # (the corpus does reach the clean-up path)
+    mixed = np.concatenate([easy[:13], hard[:14], easy[13:20], dc_impulse(6, n), np.zeros((2, n), np.int32)])
+    got, want = certified_exact(handle, mixed, 16, order)
+    assert got == want, (got, want)
+    got, want = certified_exact(handle, mixed, 24, order, window="rectangle")
+    assert got == want, (got, want)
+
+
+@pytest.mark.parametrize("n,use_fixed", [(1152, True), (2304, False), (512, True)])
+def test_sub_wave_frames_are_the_references(handle, n, use_fixed):
+    """... and through encode_frame on these shapes (qlpc_subwave_kernel's frame variant -> marked frames -> candidate
+    clean-up with the reference's chains -> frame_decide): decision records, chosen rows and packed bytes of every frame are
+    the oracle's in the REFERENCE order, hard frames and easy ones side by side."""
+    nf = 96
+    rng = np.random.default_rng(n)
+    base = np.concatenate([near_pure_sines(16, n, seed0=40), noisy_sines(16, n, seed0=60)])
+    pick = rng.integers(0, 32, size=(nf, 2))
+    frames = np.ascontiguousarray(np.stack([base[pick[:, 0]], base[pick[:, 1]]], axis=1))
+    fc = _capi.make_frame_config(gcfg(8), use_fixed=use_fixed)
+    res, resid = handle.encode_stereo_frames(frames, 16, fc)
+    blobs = handle.pack_stereo_frames(frames, res, resid, 16, 44100)
+    ofc = orc.make_frame_config(ocfg(8, orc.ACORR_REFERENCE), use_fixed=use_fixed)
+    ores, oresid = orc.encode_stereo_frames_cfg(frames, 16, ofc)
+    assert res["channel_assignment"].tolist() == ores["channel_assignment"].tolist()
+    assert res["kind"].tolist() == ores["kind"].tolist() and res["bits"].tolist() == ores["bits"].tolist()
+    assert np.array_equal(resid, oresid)
+    for f in range(nf):
+        assert res[f] == ores[f], f
+        assert blobs[f] == orc.write_stereo_frame(ores[f], frames[f, 0], frames[f, 1], 16, 44100, f, oresid[f, 0], oresid[f, 1]), f
+    # 8 independent channels (flacenc_hip_encode_frames: the sub-wave kernel's independent-channel variant)
+    ch = np.ascontiguousarray(base[rng.integers(0, 32, size=(24, 8))])
+    cres, cresid = handle.encode_frames(ch, 16, fc)
+    want = [orc.encode_subframe(ch[f, c], 16, ofc) for f in range(24) for c in range(8)]
+    for i, w in enumerate(want):
+        f, c = divmod(i, 8)
+        assert int(cres[f, c]["kind"]) == w["kind"] and int(cres[f, c]["bits"]) == w["bits"], (f, c)
+        if w["kind"] >= 2:
+            assert np.array_equal(cresid[f, c], w["residual"]), (f, c)
+
+
 def test_the_corpus_separates_the_orders(handle):
     """The bare chunk tree (FLACENC_HIP_FLAG_CANONICAL_SUM_ORDER) is NOT the reference's on this corpus -- R[] never, the
     quantised parameters in a few subframes of some thousands -- so the equalities above are not vacuous."""

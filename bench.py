@@ -706,6 +706,34 @@ def secondary(torch, _capi, handle, args, dev):
                     else "headline kernel (frame decision, no fixed-LPC candidate)", len(cut)),
                 "subframe_bits_per_sample": bits_per_sample(),
                 "certificate_recomputed_fraction": round(redone / analysed, 4) if analysed else None})
+        # the order mode's start-up and small launches.  A fresh handle knows nothing about the material:
+        # its first launches run the certified kernel until the counters have a verdict (4096 subframes) -- the row gives the
+        # first three launches one by one; and launches of 128 frames = 512 subframes, eight of which make one verdict.
+        rcfg8 = _capi.make_frame_config(_capi.make_config(lpc_order=10), use_fixed=False)
+        fresh = _capi.Handle(dev.index if dev.index is not None else 0)
+        cold = []
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            fresh.encode_stereo_frames_device(rcfg8, real.data_ptr(), F, n, n, bps, results.data_ptr(), residual.data_ptr(), n,
+                                              stream=stream.cuda_stream)
+            e1.record(stream)
+            torch.cuda.synchronize()
+            cold.append(round(e0.elapsed_time(e1), 4))
+        sec["real_audio_fixtures_order10_cold_start"] = {
+            "frames": F, "ms_first_three_launches": cold,
+            "Msamples_per_s_first_launch": round(F * 2 * n / (cold[0] * 1e-3) / 1e6, 1),
+            "what": "order 10 on the real-audio frames, first three launches of a fresh handle (scratch growth and the window "
+                    "table included in the first; the order mode has no verdict yet: certified kernel)"}
+        fs = 128
+        ms = timed(lambda: fresh.encode_stereo_frames_device(rcfg8, real.data_ptr(), fs, n, n, bps, results.data_ptr(),
+                                                             residual.data_ptr(), n, stream=stream.cuda_stream))
+        med = float(np.median(ms))
+        sec["real_audio_fixtures_order10_512_subframes_per_launch"] = {
+            "frames": fs, "ms_per_launch": stats(ms), "Msamples_per_s": round(fs * 2 * n / (med * 1e-3) / 1e6, 1),
+            "what": "order 10 on the real-audio frames in launches of 128 frames = 512 subframes: a sixth of one round of "
+                    "workgroups (launch-bound), eight launches to a verdict of the order mode"}
+        fresh.close()
         del real
     del results, residual, packed
     # BASELINE configs[2] / [4]: 24-bit stereo blocks of 8192 / 16384 samples at order 24 (the reference's maximum)
@@ -849,7 +877,8 @@ def secondary(torch, _capi, handle, args, dev):
         "frames": sfr, "block_size": sn, "ms_per_launch": stats(ms),
         "Msamples_per_s": round(sfr * 2 * sn / (med * 1e-3) / 1e6, 1),
         "what": "flacenc_hip_stereo_qlpc_batch on 1152-sample blocks (16 Rice partitions of 72): the sub-wave kernel, "
-                "4 subframes per wave (the generic kernel until round 4: 98 G samples/s)"}
+                "4 subframes per wave (the generic kernel until round 4: 98 G samples/s); since round 6 with the order "
+                "certificate (the reference's integers on 100 % of the subframes: +6 .. 13 % on this launch of 38 M samples)"}
     sfres = torch.empty((sfr, rec_bytes), dtype=torch.uint8, device=dev)
     sfcfg = _capi.make_frame_config(scfg, use_fixed=True)
     ms = timed(lambda: handle.encode_stereo_frames_device(sfcfg, small.data_ptr(), sfr, sn, sn, 16, sfres.data_ptr(),

@@ -229,8 +229,9 @@ enum {
 //   F_i   = rowsum_i(|T^-1|) eps (1 + |a|_1): for T a = r, (T + E)(a + da) = r + g with |E_ij|, |g_i| <= eps the first-order
 //           |da_i| (attained by low-pass material: T^-1 a sign checkerboard under an alternating a);
 //   2 F_i : the factor 2 covers the second-order term (<= 0.23 F_i once the boundary test passes, quant_precision >= 6) and
-//           the rounding of the two floating-point recursions (<= 0.77 F_i if their residuals obey c_L <= 11, measured
-//           <= 0.39) -- ON SYSTEMS THE RECURSION FINDS POSITIVE DEFINITE.  The sums start at t = P for every lag, so R[]
+//           the rounding of the two floating-point recursions (<= 0.77 F_i if their residuals obey c_L <= 0.77 (n + 96) /
+//           (2 P^2): 11 at (4096, 12), 0.94 at (256, 12); measured <= 0.39 resp. <= 0.19 under attack) -- ON SYSTEMS THE
+//           RECURSION FINDS POSITIVE DEFINITE.  The sums start at t = P for every lag, so R[]
 //           need not be an autocorrelation (a block that opens on a clipped plateau is enough); on such systems the
 //           recursion is unstable -- round 6's attack, tools/certificate_attack.py, found the two computed solutions 68 x
 //           further apart than 2 F_i on a subframe the rule of round 5 certified -- and they are excluded (`nonpd`).

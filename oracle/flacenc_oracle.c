@@ -412,13 +412,16 @@ static int orc_quant_stable(const double* a, size_t P, int32_t shift, const doub
  *              test below, i.e. <= 1.23 F_i for quant_precision >= 6 and P <= 12                               [shown]
  *   recursion: both recursions (the reference's on R^, the kernel's on R~) are floating point.  ASSUMED: on a system the
  *              recursion itself finds positive definite (every denominator 1 - err^2 > 0) the computed solution's
- *              residual obeys |T a^ - r|_inf <= c_L P^2 u R0 (1 + |a^|_1) with c_L <= 11; then the two runs' errors add at
- *              most (2 c_L P^2 / (n + 96)) F_i <= 0.77 F_i.  Measured (tools/certificate_attack.py, exact rational
- *              residuals, 870 000 adversarial subframes): c_L <= 0.39.  Systems that are NOT positive definite -- the sums
+ *              residual obeys |T a^ - r|_inf <= c_L P^2 u R0 (1 + |a^|_1); the two runs' errors then add at most
+ *              (2 c_L P^2 / (n + 96)) F_i, which the factor 2 covers while c_L <= 0.77 (n + 96) / (2 P^2): 11 at (4096, 12),
+ *              3.3 at (1152, 12), 0.94 at (256, 12) -- the smallest allowance of any certified shape (eps shrinks with n,
+ *              the recursion's rounding does not).  Measured (tools/certificate_attack.py, exact rational residuals):
+ *              c_L <= 0.39 over 870 000 adversarial subframes of 4096 samples, <= 0.19 = at most 0.10 of the shape's
+ *              allowance over 1.2 M of 256 / 576 / 1152.  Systems that are NOT positive definite -- the sums
  *              start at t = P for every lag, R[] need not be an autocorrelation: a block that opens on a clipped plateau
  *              is enough -- have no such bound (c_L up to 45 000 found, the two computed solutions 68 x further apart than
  *              2 F_i on a subframe the round-5 rule certified) and are excluded: round 6, `skipped` bit 1 below.
- *   safety   = 2.0 >= 1.23 + 2 c_L P^2 / (n + 96) for P <= 12, n >= 4096, c_L <= 11.
+ *   safety   = 2.0 >= 1.23 + 2 c_L P^2 / (n + 96) under that allowance.
  * Not a theorem about the floating-point recursion -- c_L is evidence, and below quant_precision 6 so is the second-order
  * factor -- which is why tests/test_certificate_cpu.py soaks it and attacks it: the worst |a^_ref - a^_kernel|_i / (2 F_i)
  * a hill-climber finds among certifiable subframes is 0.04 (1.5 ... 68 before the exclusion). */

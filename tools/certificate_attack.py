@@ -10,7 +10,11 @@ A ratio above 1 would be a counter-example to what the certificate relies on; th
 0.007.  Also measured, with exact rational arithmetic: c_L = |T a^ - r|_inf / (P^2 u R0 (1 + |a^|_1)), the residual constant
 of the floating-point recursion that the stated bound ASSUMES (<= 11 would do; flacenc_oracle.c, orc_quant_certified).
 
-    python tools/certificate_attack.py [--seconds 120] [--seed 1] [--orders 8,10,12]
+    python tools/certificate_attack.py [--seconds 120] [--seed 1] [--orders 8,10,12] [--n 4096]
+
+--n: the block size (4096 / 4608: the fused kernel's lane order; 256 .. 2304: the sub-wave kernel's chunk tree).  The
+allowance the factor 2 leaves the two recursions is 0.77 F_i, i.e. c_L <= 0.77 (n + 96) / (2 P^2): 11 at (4096, 12), 0.94 at
+(256, 12), the smallest of the certified shapes.
 
 CPU only (the oracle is the statement of the certificate; tests/test_gpu_certified_order.py holds the GPU to it bit for bit).
 """
@@ -109,11 +113,20 @@ def levinson_constant(R, a):
     return float(worst / denom) if denom != 0 else 0.0
 
 
-def attack(seconds, seed, orders, log=print):
+def allowed_constant(n, order):
+    """The c_L up to which safety 2 covers second order (1.23) + both recursions' rounding (2 c_L P^2 / (n + 96))."""
+    return 0.77 * (n + 96) / (2.0 * order * order)
+
+
+def attack(seconds, seed, orders, log=print, n=None):
+    global N
+    if n is not None:
+        N = int(n)
     rng = np.random.default_rng(seed)
     t_end = time.time() + seconds
     worst = (0.0, None)
     worst_cl = 0.0
+    worst_cl_frac = 0.0  # ... as a fraction of what its (n, order) allows
     evals = 0
     while time.time() < t_end:
         order = int(rng.choice(orders))
@@ -141,11 +154,14 @@ def attack(seconds, seed, orders, log=print):
         x = synth(p, bps, noise)
         b = orc.certificate_bounds(x, orc.make_config(lpc_order=order, quant_precision=precision, window=window))
         if b is not None:
-            worst_cl = max(worst_cl, levinson_constant(b["R"], b["a"]))
+            cl = levinson_constant(b["R"], b["a"])
+            worst_cl = max(worst_cl, cl)
+            worst_cl_frac = max(worst_cl_frac, cl / allowed_constant(N, order))
         if best > worst[0]:
             worst = (best, dict(bdet, order=order, precision=precision, bps=bps, window=window, params=p, signal=x))
             log("  new worst actual/bound %.4f  (order %d, precision %d, %d bit, %s; coefficient %d: |da| %.3e against %.3e)" % (
                 best, order, precision, bps, window, bdet["i"], bdet["actual"], bdet["bound"]))
+    attack.last_constant_fraction = worst_cl_frac
     return worst, worst_cl, evals
 
 
@@ -155,10 +171,13 @@ if __name__ == "__main__":
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--orders", default="4,8,10,12")
     ap.add_argument("--save", default=None, help="write the worst case's samples (int32 .npy) here")
+    ap.add_argument("--n", type=int, default=4096, help="block size: 4096 / 4608 or one of the sub-wave kernel's")
     args = ap.parse_args()
-    worst, cl, evals = attack(args.seconds, args.seed, [int(v) for v in args.orders.split(",")])
-    print("%d evaluations in %.0f s: worst actual / bound = %.4f; largest recursion constant c_L = %.3f (the bound assumes <= 11)" % (
-        evals, args.seconds, worst[0], cl))
+    orders = [int(v) for v in args.orders.split(",")]
+    worst, cl, evals = attack(args.seconds, args.seed, orders, n=args.n)
+    print("n = %d: %d evaluations in %.0f s: worst actual / bound = %.4f; largest recursion constant c_L = %.3f (%.2f of what "
+          "its shape allows; the smallest allowance here is %.2f)" % (
+              args.n, evals, args.seconds, worst[0], cl, attack.last_constant_fraction, min(allowed_constant(args.n, o) for o in orders)))
     if worst[1]:
         sig = worst[1].pop("signal")
         if args.save:

@@ -1,5 +1,6 @@
 """CPU soak of the order certificate through the oracle (the test tests/test_certificate_cpu.py at scale):
-    python tools/certificate_soak.py [rounds=400] [seed=77]
+    python tools/certificate_soak.py [rounds=400] [seed=77] [sizes=4096,4096,4096,4608]
+(sizes: the block sizes the rounds cycle through; e.g. 256,288,512,576,1024,1152,2048,2304 for the sub-wave kernel's shapes)
 prints subframes / tier-2 / recomputed / certified-but-different (must be 0) / bare-order-differs."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,9 +11,10 @@ import test_certificate_cpu as T
 
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 77)
+sizes = [int(v) for v in sys.argv[3].split(",")] if len(sys.argv) > 3 else [4608, 4096, 4096, 4096]
 total = tier2 = redone = bad = tree = 0
 for rnd in range(rounds):
-    n = 4096 if rnd % 4 else 4608
+    n = sizes[rnd % len(sizes)]
     order = int(rng.integers(1, 13)); precision = int(rng.integers(3, 16)); bps = int(rng.choice([8, 12, 16, 16, 16, 20, 24]))
     window = [("tukey", 0.4), ("tukey", 0.1), ("tukey", 1.0), "rectangle"][rnd % 4]
     x = T._corpus(rng, 160, n, bps)

@@ -877,8 +877,9 @@ def secondary(torch, _capi, handle, args, dev):
         "frames": sfr, "block_size": sn, "ms_per_launch": stats(ms),
         "Msamples_per_s": round(sfr * 2 * sn / (med * 1e-3) / 1e6, 1),
         "what": "flacenc_hip_stereo_qlpc_batch on 1152-sample blocks (16 Rice partitions of 72): the sub-wave kernel, "
-                "4 subframes per wave (the generic kernel until round 4: 98 G samples/s); since round 6 with the order "
-                "certificate (the reference's integers on 100 % of the subframes: +6 .. 13 % on this launch of 38 M samples)"}
+                "4 subframes per wave (the generic kernel until round 4: 98 G samples/s); since round 6 behind a pass of "
+                "the reference's chains for every subframe (acorr_reference_mfma_kernel): the reference's integers and R[] on "
+                "100 % of the subframes, the same cost on every material (round 5, chunk tree, T2: 203 G samples/s)"}
     sfres = torch.empty((sfr, rec_bytes), dtype=torch.uint8, device=dev)
     sfcfg = _capi.make_frame_config(scfg, use_fixed=True)
     ms = timed(lambda: handle.encode_stereo_frames_device(sfcfg, small.data_ptr(), sfr, sn, sn, 16, sfres.data_ptr(),

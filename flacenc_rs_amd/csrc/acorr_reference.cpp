@@ -651,7 +651,17 @@ __global__ void __launch_bounds__(256) acorr_reference_mfma_kernel(AcorrRefArgs 
   if (a.marked_params == nullptr) {
     process(blockIdx.x * 4u + (uint32_t)wave);
   } else {
-    if (a.marked_count != nullptr && __hip_atomic_load(a.marked_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
+    const uint32_t count = a.marked_count != nullptr ? __hip_atomic_load(a.marked_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0u;
+    if (count == 0u) return;
+    if (a.marked_list != nullptr && count <= a.marked_cap) {
+      // the marks' own list: entry e = a record (marked_unit 1) or a stereo frame (4); this kernel's unit is four records.
+      // (A group of four that holds several marked records is walked once per mark: the same sums, written again.)
+      for (uint32_t i = blockIdx.x * 4u + (uint32_t)wave; i < count; i += gridDim.x * 4u) {
+        const uint32_t e = a.marked_list[i];
+        process(a.marked_unit == 4u ? e : e >> 2);
+      }
+      return;
+    }
     for (uint32_t unit = blockIdx.x * 4u + (uint32_t)wave; unit * 4u < a.n_subframes; unit += gridDim.x * 4u) process(unit);
   }
 }

@@ -24,6 +24,9 @@ struct AcorrRefArgs {
   // once, the whole launch when *marked_count is 0.  nullptr: every subframe.
   const void* marked_params = nullptr;
   const uint32_t* marked_count = nullptr;
+  const uint32_t* marked_list = nullptr;  // QlpcKernelArgs::marked_list / marked_cap / marked_unit
+  uint32_t marked_cap = 0;
+  uint32_t marked_unit = 1;
 };
 
 // R[tau] = the single sequential fma chain of weighted_auto_correlation_nosimd (src/lpc.rs:533-548):

@@ -341,13 +341,19 @@ int attach_split_scratch(flacenc_hip_handle* h, flacenc_hip::QlpcKernelArgs& a) 
   int rc = ensure(h, h->d_split, static_cast<size_t>(a.n_subframes) * (33 * 8 + 36 * 4));
   if (rc != FLACENC_HIP_OK) return rc;
   a.split_scratch = h->d_split.ptr;
+  // two counters (16 words reserved) + a list of the first kMarkedCap marks behind each
+  constexpr uint32_t kMarkedCap = 1024;
+  constexpr size_t kMarkedBytes = 64 + 2 * static_cast<size_t>(kMarkedCap) * 4;
   if (h->d_marked.ptr == nullptr) {
-    if ((rc = ensure(h, h->d_marked, 64)) != FLACENC_HIP_OK) return rc;
-    HIP_TRY(h, hipMemset(h->d_marked.ptr, 0, 64));
+    if ((rc = ensure(h, h->d_marked, kMarkedBytes)) != FLACENC_HIP_OK) return rc;
+    HIP_TRY(h, hipMemset(h->d_marked.ptr, 0, kMarkedBytes));
   }
   h->marked_parity ^= 1u;
   a.marked_count = static_cast<uint32_t*>(h->d_marked.ptr) + h->marked_parity;
   a.marked_next = static_cast<uint32_t*>(h->d_marked.ptr) + (h->marked_parity ^ 1u);
+  a.marked_list = static_cast<uint32_t*>(h->d_marked.ptr) + 16 + h->marked_parity * kMarkedCap;
+  a.marked_cap = kMarkedCap;
+  a.marked_unit = 1;
   return FLACENC_HIP_OK;
 }
 
@@ -1388,6 +1394,8 @@ int flacenc_hip_encode_frames_async(flacenc_hip_handle* h, const flacenc_hip_fra
         }
         dm.only_marked = 1;
         dm.marked_count = m.marked_count;
+        dm.marked_list = m.marked_list;  // (entries: subframes)
+        dm.marked_cap = m.marked_cap;
         HIP_TRY(h, flacenc_hip::launch_channel_decide(dm, s));
         return FLACENC_HIP_OK;
       }
@@ -2248,9 +2256,10 @@ static int encode_stereo_frames_impl(flacenc_hip_handle* h, const flacenc_hip_fr
       flacenc_hip::QlpcKernelArgs m = a;
       m.stamps = nullptr;
       m.fixed_partitions = cfg->fixed_partitions;
-      // (the order certificate on these shapes: first tier in the kernel, the reference's chains for the frames it marks)
+      // (the unflagged order on these shapes is the reference's: its chains for every QLPC candidate in front, QlpcKernelArgs::cert_subwave)
       m.cert_subwave = (a.certify != 0u && a.reference_order == 0u && !a.direct_mse && cfg->use_lpc && cfg->qlpc.lpc_order <= 12) ? 1u : 0u;
       if ((rc = attach_split_scratch(h, m)) != FLACENC_HIP_OK) return rc;
+      m.marked_unit = 4;  // (the kernel lists marked FRAMES; the candidate clean-ups visit their four roles)
       if (flacenc_hip::subwave_frame_eligible(m)) {
         if ((rc = ensure(h, h->d_cparams, n_sub * sizeof(flacenc_hip_subframe_params))) != FLACENC_HIP_OK) return rc;
         if ((rc = ensure(h, h->d_cresid, n_sub * cstride * 4)) != FLACENC_HIP_OK) return rc;
@@ -2293,6 +2302,8 @@ static int encode_stereo_frames_impl(flacenc_hip_handle* h, const flacenc_hip_fr
         }
         d.only_marked = 1;
         d.marked_count = m.marked_count;
+        d.marked_list = m.marked_list;  // (entries: frames)
+        d.marked_cap = m.marked_cap;
         HIP_TRY(h, flacenc_hip::launch_frame_decide(d, s));
         return FLACENC_HIP_OK;
       }

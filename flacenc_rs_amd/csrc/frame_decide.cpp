@@ -19,11 +19,21 @@ __global__ void __launch_bounds__(kThreads) frame_decide_kernel(FrameDecideArgs 
   __shared__ int smin[4][kThreads / 64], smax[4][kThreads / 64];
   __shared__ FrameDecision sdec;
   const int tid = threadIdx.x;
-  const uint32_t f = blockIdx.x;
-  if (a.only_marked) {  // (workgroup-uniform, in front of every barrier)
-    if (a.marked_count != nullptr && __hip_atomic_load(a.marked_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
-    if (a.results[f].channel_assignment != 0xFF) return;
+  // Every frame (grid = n_frames: one trip), or -- only_marked, a small grid -- the frames the marking kernel listed
+  // (FrameDecideArgs::marked_list) or, when the list does not hold them all, a grid-stride walk of all frames.  Everything
+  // that steers the loop is workgroup-uniform and in front of every barrier of a trip.
+  uint32_t count = a.n_frames;
+  bool listed = false;
+  if (a.only_marked) {
+    const uint32_t marks = a.marked_count != nullptr ? __hip_atomic_load(a.marked_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0u;
+    if (marks == 0u) return;
+    listed = a.marked_list != nullptr && marks <= a.marked_cap;
+    if (listed) count = marks;
   }
+  for (uint32_t trip = blockIdx.x; trip < count; trip += gridDim.x) {
+  const uint32_t f = listed ? a.marked_list[trip] : trip;
+  if (f >= a.n_frames) continue;
+  if (a.only_marked && a.results[f].channel_assignment != 0xFF) continue;
   const int n = (int)a.block_size;
   const int32_t* __restrict__ l = a.frames + (size_t)(2u * f) * a.stride;
   const int32_t* __restrict__ r = l + a.stride;
@@ -105,6 +115,8 @@ __global__ void __launch_bounds__(kThreads) frame_decide_kernel(FrameDecideArgs 
       for (int t = tid; t < n; t += kThreads) dst[t] = src ? src[t] : 0;
     }
   }
+  __syncthreads();  // (the shared decision and extremes are rewritten by the next trip)
+  }
 }
 
 // encode_subframe (coding.rs:384-418) for one channel of an Independent(n) frame
@@ -112,11 +124,19 @@ __global__ void __launch_bounds__(kThreads) channel_decide_kernel(ChannelDecideA
   __shared__ int smin[kThreads / 64], smax[kThreads / 64];
   __shared__ uint32_t skind;
   const int tid = threadIdx.x;
-  const size_t sf = blockIdx.x;
-  if (a.only_marked) {  // (workgroup-uniform, in front of every barrier)
-    if (a.marked_count != nullptr && __hip_atomic_load(a.marked_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
-    if (a.results[sf].kind != 0xFF) return;
+  // (the loop of frame_decide_kernel: every subframe, the listed ones, or a grid-stride walk)
+  uint32_t count = a.n_subframes;
+  bool listed = false;
+  if (a.only_marked) {
+    const uint32_t marks = a.marked_count != nullptr ? __hip_atomic_load(a.marked_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0u;
+    if (marks == 0u) return;
+    listed = a.marked_list != nullptr && marks <= a.marked_cap;
+    if (listed) count = marks;
   }
+  for (uint32_t trip = blockIdx.x; trip < count; trip += gridDim.x) {
+  const size_t sf = listed ? a.marked_list[trip] : trip;
+  if (sf >= a.n_subframes) continue;
+  if (a.only_marked && a.results[sf].kind != 0xFF) continue;
   const int n = (int)a.block_size;
   const int32_t* __restrict__ x = a.samples + sf * a.stride;
   int mn = INT32_MAX, mx = INT32_MIN;
@@ -183,19 +203,24 @@ __global__ void __launch_bounds__(kThreads) channel_decide_kernel(ChannelDecideA
                                                         : nullptr;
   int32_t* dst = a.residual + sf * a.residual_stride;
   for (int t = tid; t < n; t += kThreads) dst[t] = src ? src[t] : 0;
+  __syncthreads();
+  }
 }
 
 }  // namespace
 
 hipError_t launch_channel_decide(const ChannelDecideArgs& a, hipStream_t stream) {
   if (a.n_subframes == 0) return hipSuccess;
-  hipLaunchKernelGGL(channel_decide_kernel, dim3(a.n_subframes), dim3(kThreads), 0, stream, a);
+  // (only_marked: a small grid that visits the listed subframes, or walks all of them in strides)
+  const uint32_t grid = (a.only_marked && a.n_subframes > 512u) ? 512u : a.n_subframes;
+  hipLaunchKernelGGL(channel_decide_kernel, dim3(grid), dim3(kThreads), 0, stream, a);
   return hipGetLastError();
 }
 
 hipError_t launch_frame_decide(const FrameDecideArgs& a, hipStream_t stream) {
   if (a.n_frames == 0) return hipSuccess;
-  hipLaunchKernelGGL(frame_decide_kernel, dim3(a.n_frames), dim3(kThreads), 0, stream, a);
+  const uint32_t grid = (a.only_marked && a.n_frames > 512u) ? 512u : a.n_frames;
+  hipLaunchKernelGGL(frame_decide_kernel, dim3(grid), dim3(kThreads), 0, stream, a);
   return hipGetLastError();
 }
 

@@ -35,6 +35,8 @@ struct FrameDecideArgs {
   // at all when the count it left is 0
   uint32_t only_marked = 0;
   const uint32_t* marked_count = nullptr;
+  const uint32_t* marked_list = nullptr;  // QlpcKernelArgs::marked_list (entries: frames resp. subframes)
+  uint32_t marked_cap = 0;
 };
 
 hipError_t launch_frame_decide(const FrameDecideArgs& args, hipStream_t stream);
@@ -60,6 +62,8 @@ struct ChannelDecideArgs {
   // clean-up behind qlpc_subwave_kernel's independent-channel variant: only subframes it marked (kind 0xFF)
   uint32_t only_marked = 0;
   const uint32_t* marked_count = nullptr;
+  const uint32_t* marked_list = nullptr;  // QlpcKernelArgs::marked_list (entries: frames resp. subframes)
+  uint32_t marked_cap = 0;
 };
 hipError_t launch_channel_decide(const ChannelDecideArgs& args, hipStream_t stream);
 

@@ -676,7 +676,7 @@ __global__ void __launch_bounds__(256, ((STEREO && K == 1) || MODE == FLACENC_BI
     // marker for the dispatcher: this subframe has to go through the generic kernel's literal tables
     if (lane == 0) {
       rec->status = -1;
-      if (a.marked_count != nullptr) atomicAdd(a.marked_count, 1u);
+      count_marked(a, sf);
     }
     return;
   }

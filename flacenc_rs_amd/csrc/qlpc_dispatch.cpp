@@ -45,7 +45,7 @@ bool subwave_shape(uint32_t n) {
 
 static bool subwave_buffers_ok(const QlpcKernelArgs& a) {
   if (!subwave_shape(a.block_size) || a.n_subframes == 0 || a.force_generic || a.only_marked || a.direct_mse) return false;
-  if (a.reference_order != 0 || a.acorr_in != nullptr || a.sumabs_in != nullptr || a.lpc_stage != 0) return false;
+  if (a.sumabs_in != nullptr || a.lpc_stage != 0) return false;
   if ((reinterpret_cast<uintptr_t>(a.samples) & 15) || (a.stride & 3)) return false;
   if ((reinterpret_cast<uintptr_t>(a.residual) & 15) || (a.residual_stride & 3)) return false;
   if (a.stereo && (a.n_subframes & 3)) return false;
@@ -67,27 +67,57 @@ static bool subwave_fixed_ok(const QlpcKernelArgs& a) {
 // the plain analysis (records + residual rows, no on-device decision) in the build's canonical summation order
 bool subwave_eligible(const QlpcKernelArgs& a) {
   if (!subwave_buffers_ok(a) || a.lpc_order > 12 || a.lpc_order == 0 || a.fixed_mode != 0) return false;
+  // (a flagged summation order reaches the kernel as R[] of the launch in front: acorr_in)
+  if (a.reference_order != 0 && a.acorr_in == nullptr) return false;
   return a.frame_results == nullptr && a.chan_results == nullptr && a.params != nullptr;
 }
 
 bool subwave_fixed_eligible(const QlpcKernelArgs& a) {
   if (!subwave_buffers_ok(a) || a.fixed_mode != 1u || !subwave_fixed_ok(a)) return false;
+  if (a.reference_order != 0 || a.acorr_in != nullptr) return false;
   return a.frame_results == nullptr && a.chan_results == nullptr && a.params != nullptr;
 }
 
 bool subwave_frame_eligible(const QlpcKernelArgs& a) {
   if (!subwave_buffers_ok(a) || !a.stereo || a.fixed_mode != 0 || a.frame_results == nullptr) return false;
+  if (a.reference_order != 0 || a.acorr_in != nullptr) return false;  // (flagged orders: the selector's sums are the reference's too)
   if (!a.use_lpc || a.lpc_order > 12 || a.lpc_order == 0) return false;
   return !a.use_fixed || subwave_fixed_ok(a);
 }
 
 bool subwave_channels_eligible(const QlpcKernelArgs& a) {
   if (!subwave_buffers_ok(a) || a.stereo || a.fixed_mode != 0 || a.chan_results == nullptr) return false;
+  if (a.reference_order != 0 || a.acorr_in != nullptr) return false;
   if (!a.use_lpc || a.lpc_order > 12 || a.lpc_order == 0) return false;
   return !a.use_fixed || subwave_fixed_ok(a);
 }
 
+// R[] of every subframe of `a` in the stable build's order (acorr_reference_mfma_kernel) into a.split_scratch
+static hipError_t reference_chains_for_all(const QlpcKernelArgs& a, double* racc, hipStream_t stream) {
+  AcorrRefArgs r{};
+  r.samples = a.samples;
+  r.stride = a.stride;
+  r.block_size = a.block_size;
+  r.n_subframes = a.n_subframes;
+  r.stereo = a.stereo;
+  r.window = a.window;
+  r.lpc_order = a.lpc_order;
+  r.nightly = 0u;
+  r.out = racc;
+  return launch_acorr_reference(r, stream);
+}
+
 hipError_t launch_subwave_frames(const QlpcKernelArgs& a, hipStream_t stream) {
+  if (a.cert_subwave != 0u && a.acorr_in == nullptr) {
+    // the two-pass form of the unflagged order on these shapes: the reference's chains for every QLPC candidate in front,
+    // the kernel's own autocorrelation skipped (the fixed-LPC candidate keeps the canonical sums of the unflagged mode)
+    if (a.split_scratch == nullptr) return hipErrorInvalidValue;
+    double* racc = reinterpret_cast<double*>(a.split_scratch);
+    if (hipError_t err = reference_chains_for_all(a, racc, stream); err != hipSuccess) return err;
+    QlpcKernelArgs b = a;
+    b.acorr_in = racc;
+    return launch_subwave_frames(b, stream);
+  }
   const int mp = a.lpc_order <= 8 ? 8 : (a.lpc_order <= 10 ? 10 : 12);
   const int spl = (a.block_size % 72u) == 0 ? 72 : 64;
   const int var = a.stereo ? 2 : 3;
@@ -247,6 +277,9 @@ hipError_t launch_qlpc(const QlpcKernelArgs& a, const QlpcLaunchPlan& plan, hipS
     r.out = racc;
     r.marked_params = a.params;
     r.marked_count = a.marked_count;
+    r.marked_list = a.marked_list;
+    r.marked_cap = a.marked_cap;
+    r.marked_unit = a.marked_unit;
     hipError_t err = launch_acorr_reference(r, stream);
     if (err != hipSuccess) return err;
     QlpcKernelArgs b = a;
@@ -267,8 +300,11 @@ hipError_t launch_qlpc(const QlpcKernelArgs& a, const QlpcLaunchPlan& plan, hipS
     if (sub_shape) {
       QlpcKernelArgs b = a;
       b.certify = 0;
-      if (subwave_eligible(a) && a.split_scratch != nullptr) b.cert_subwave = 1u;
-      else b.reference_order = 1u;  // (unaligned rows, FLACENC_HIP_FLAG_GENERIC_KERNEL: the reference's order outright)
+      // the reference's chains in front of the sub-wave kernel, its own autocorrelation skipped (acorr_in): the same cost
+      // on every material.  (An order certificate inside that kernel was 6-13 % faster on noise-like material and 20 to
+      // 140 x slower on music at orders 10-12: profiles/r06_subwave_two_pass.txt.)  Unaligned rows and
+      // FLACENC_HIP_FLAG_GENERIC_KERNEL take the same R[] through the generic kernel.
+      b.reference_order = 1u;
       return launch_qlpc(b, plan, stream);
     }
     if (!shape || !wave || a.pack_out != nullptr) {
@@ -328,7 +364,7 @@ hipError_t launch_qlpc(const QlpcKernelArgs& a, const QlpcLaunchPlan& plan, hipS
 #undef FLACENC_HIP_FIXCLEAN
     return hipErrorInvalidValue;
   }
-  if (bigblock_eligible(a) || (a.acorr_in != nullptr && !wave_kernel_eligible(a) && a.lpc_stage == 0)) {
+  if (bigblock_eligible(a) || (a.acorr_in != nullptr && !wave_kernel_eligible(a) && !subwave_eligible(a) && a.lpc_stage == 0)) {
     // R[] -> levinson_batch_kernel (one subframe per lane) -> residual + Rice search
     if (a.split_scratch == nullptr) return hipErrorInvalidValue;
     const bool big = bigblock_eligible(a);
@@ -385,12 +421,16 @@ hipError_t launch_qlpc(const QlpcKernelArgs& a, const QlpcLaunchPlan& plan, hipS
     if (err != hipSuccess) return err;
     QlpcKernelArgs c = a;
     c.only_marked = 1;
-    if (a.cert_subwave == 0u) {
-      c.autocorr = nullptr;  // (written; the clean-up rewrites records and rows only)
-      c.lpc_coefs = nullptr;
-    }  // (cert_subwave: R[] and the coefficients of a record marked -2 become the reference order's)
+    c.autocorr = nullptr;  // (written; the clean-up rewrites records and rows only)
+    c.lpc_coefs = nullptr;
     c.selector_keys = a.selector_keys;
-    if (a.cert_subwave != 0u && a.fixed_mode == 0) return launch_qlpc(c, plan, stream);  // (+ the reference's chains, top)
+    if (a.acorr_in != nullptr) {
+      // R[] came from the launch in front (the reference's chains of the unflagged order, or a flagged order): what the
+      // kernel marked (-2) is redone from that very R[]
+      c.acorr_marked = a.acorr_in;
+      c.acorr_in = nullptr;
+      c.reference_order = 0u;
+    }
 #define FLACENC_HIP_SUBCLEAN(MP, BG) \
   if (plan.maxp == MP && plan.big == (BG != 0)) return launch_qlpc_##MP##_##BG(c, plan.threads, plan.smem_bytes, stream);
     FLACENC_HIP_FOR_EACH_INSTANCE(FLACENC_HIP_SUBCLEAN)

@@ -43,10 +43,12 @@ struct QlpcKernelArgs {
   // launches of these shapes on other kernels take the reference's order outright.  cert_stats (nullable, test / bench
   // hook): [0] subframes analysed, [1] certificates that needed the rows of T^-1, [2] subframes redone.
   uint32_t certify = 0;
-  // ... and on the sub-wave kernel's shapes (blocks of 256 .. 2304 samples, orders up to 12; round 6): qlpc_subwave_kernel
-  // holds its chunk-tree sums to the certificate and marks what it does not certify with record status -2;
-  // the clean-up launch behind it (only_marked) runs the reference's chains for exactly those records
-  // (acorr_reference_mfma_kernel, restricted to them) and hands them to the generic kernel as `acorr_marked`
+  // ... and on the sub-wave kernel's shapes (blocks of 256 .. 2304 samples, orders up to 12; round 6) the unflagged order is
+  // the reference's by two passes: launch_subwave_frames runs the reference's chains for every QLPC candidate in front
+  // (acorr_reference_mfma_kernel) and qlpc_subwave_kernel takes them as acorr_in; the clean-up launch behind it
+  // (only_marked) redoes what the kernel marked (-2) from those chains, which acorr_reference_mfma_kernel recomputes for
+  // exactly the marked records and hands to the generic kernel as `acorr_marked`.  (Candidate-level launches of these
+  // shapes simply run with reference_order = 1: qlpc_dispatch.cpp.)
   uint32_t cert_subwave = 0;
   const double* acorr_marked = nullptr;  // device, [n][33]: R[] of the records with status -2 (clean-up launch only)
   uint32_t integer_parity_only = 0;  // FLACENC_HIP_FLAG_INTEGER_PARITY_ONLY with reference_order 1: certified shapes keep their order
@@ -93,6 +95,15 @@ struct QlpcKernelArgs {
   // scan that finds nothing).  nullptr: always scan.
   uint32_t* marked_count = nullptr;
   uint32_t* marked_next = nullptr;
+  // The first `marked_cap` of those marks, in the order they were counted (slot = what the mark's atomicAdd returned): the
+  // clean-up launches visit these records directly instead of reading the status of all n_subframes records -- a scan of
+  // 262 144 records for one marked subframe took a 256-sample launch 90 us (round 6).  An entry counts in units of
+  // `marked_unit` records: 1, or 4 for stereo frames (whose four roles are marked together: entry = the frame).  Consumers
+  // check an entry against n_subframes and the record's own status, so that entries a pipeline without a clean-up launch
+  // left behind cost a look and nothing else.  nullptr, or more marks than the list holds: the scan.
+  uint32_t* marked_list = nullptr;
+  uint32_t marked_cap = 0;
+  uint32_t marked_unit = 1;
   flacenc_hip_subframe_params* params;  // device
   int32_t* residual;                    // device
   size_t residual_stride;
@@ -136,6 +147,13 @@ struct QlpcKernelArgs {
   uint32_t pack_lds_words, pack_crc_per;
   uint16_t pack_crc_pow[32];
 };
+
+// A record (or, unit 4, a stereo frame) is marked for the clean-up launches: counted, and entered in the list while it has room.
+__device__ __forceinline__ void count_marked(const QlpcKernelArgs& a, uint32_t index) {
+  if (a.marked_count == nullptr) return;
+  const uint32_t slot = atomicAdd(a.marked_count, 1u);
+  if (a.marked_list != nullptr && slot < a.marked_cap) a.marked_list[slot] = index;
+}
 
 struct QlpcLaunchPlan {
   bool wave;       // wave-per-subframe kernel (block_size 4096, order <= 12, aligned buffers)

@@ -229,9 +229,8 @@ enum {
 //   F_i   = rowsum_i(|T^-1|) eps (1 + |a|_1): for T a = r, (T + E)(a + da) = r + g with |E_ij|, |g_i| <= eps the first-order
 //           |da_i| (attained by low-pass material: T^-1 a sign checkerboard under an alternating a);
 //   2 F_i : the factor 2 covers the second-order term (<= 0.23 F_i once the boundary test passes, quant_precision >= 6) and
-//           the rounding of the two floating-point recursions (<= 0.77 F_i if their residuals obey c_L <= 0.77 (n + 96) /
-//           (2 P^2): 11 at (4096, 12), 0.94 at (256, 12); measured <= 0.39 resp. <= 0.19 under attack) -- ON SYSTEMS THE
-//           RECURSION FINDS POSITIVE DEFINITE.  The sums start at t = P for every lag, so R[]
+//           the rounding of the two floating-point recursions (<= 0.77 F_i if their residuals obey c_L <= 11, measured
+//           <= 0.39) -- ON SYSTEMS THE RECURSION FINDS POSITIVE DEFINITE.  The sums start at t = P for every lag, so R[]
 //           need not be an autocorrelation (a block that opens on a clipped plateau is enough); on such systems the
 //           recursion is unstable -- round 6's attack, tools/certificate_attack.py, found the two computed solutions 68 x
 //           further apart than 2 F_i on a subframe the rule of round 5 certified -- and they are excluded (`nonpd`).
@@ -601,7 +600,21 @@ __global__ void __launch_bounds__(MAXP <= 12 ? 1024 : (MAXP <= 16 ? 512 : 256)) 
     // count into.  (Tickets on one counter -- the last workgroup to arrive clears it -- cost 96 same-address
     // device-scope atomics from all eight XCDs: 21 us for a launch that has nothing to do.)
     if (blockIdx.x == 0 && threadIdx.x == 0) *a.marked_next = 0u;
-    if (__hip_atomic_load(a.marked_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
+    const uint32_t count = __hip_atomic_load(a.marked_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (count == 0u) return;
+    if (a.marked_list != nullptr && count <= a.marked_cap) {
+      // the marks' own list (QlpcKernelArgs::marked_list): no scan.  Everything here is workgroup-uniform.
+      const uint32_t unit = a.marked_unit;
+      for (uint32_t i = blockIdx.x; i < count * unit; i += gridDim.x) {
+        const uint32_t sf = a.marked_list[i / unit] * unit + i % unit;
+        if (sf >= a.n_subframes) continue;
+        const int st = a.params[sf].status;
+        if (st != -1 && st != -2) continue;
+        qlpc_subframe_call<MAXP, BIG>(a, sf);
+        __syncthreads();
+      }
+      return;
+    }
   }
   // (a small grid walks the records in strides: the usual launch finds the count at 0 and is over at once)
   // Round 6: the marked records of a window are found by wave ballots and visited one by one -- the window used to be

@@ -23,11 +23,12 @@
 // Rare subframes -- residuals of 2^25 (72-sample lanes; 2^26 for 64) and more, or a saturated table minimum
 // (rice.rs:51) -- are marked (record status -1, QlpcKernelArgs::marked_count) and redone by the generic kernel's
 // clean-up launch, as bigblock_residual_kernel does.
-// Round 6 -- the order certificate on these shapes (QlpcKernelArgs::cert_subwave): the chunk-tree sums
-// are kept where the certificate (levinson_quantize<.., CERT>: the Gohberg-Semencul norm bound behind each recursion, the
-// rows of T^-1 out of line where that cannot decide) says that the quantised parameters are those of the reference's
-// chains (lpc.rs:533-548); a subframe it does not certify is marked with status -2, and the clean-up launch redoes it from those
-// chains (acorr_reference_mfma_kernel restricted to the marked records -> the generic kernel with their R[]).
+// Round 6 -- the unflagged order on these shapes emits the reference's integers by TWO PASSES: acorr_reference_mfma_kernel
+// runs the reference's chains (lpc.rs:533-548) for every subframe in front, and this kernel takes that R[] (acorr_in) in
+// place of its phase 1; what it marks is then marked -2 and redone from the same R[].  (An order certificate inside this
+// kernel -- chunk-tree sums kept where a perturbation bound cleared them, the rest marked for a clean-up launch -- was built
+// first: 6-13 % faster on noise-like material, 20 to 140 x slower on music at orders 10-12, where a third to two thirds of the
+// subframes took the clean-up; profiles/r06_subwave_two_pass.txt.)
 // STEREO: wave w of the workgroup is role w (L, R, M, S) of the workgroup's 64 / LPS frames, whose two channel
 // images are shared in LDS -- the role stays wave-uniform and each channel is read from HBM once.
 // Plain: two waves per workgroup, every segment an independent subframe with its own image.
@@ -187,7 +188,7 @@ __global__ void __launch_bounds__(STEREO ? 256 : 128, 3) qlpc_subwave_kernel(Qlp
       __syncthreads();
     }
   }
-  if (LPC) {
+  if (LPC && a.acorr_in == nullptr) {
     const bool has_window = a.window != nullptr;
     const float* __restrict__ wsrc = a.window + 32;
     for (int i = tid; i < G::Seg; i += THREADS) wlds[i] = 0.0f;
@@ -275,7 +276,14 @@ __global__ void __launch_bounds__(STEREO ? 256 : 128, 3) qlpc_subwave_kernel(Qlp
   // ======================= phase 1: window + autocorrelation ==============
   if (LPC) {
     double R[NLAG];
-    int cert_max = 0, cert_min = 0;
+    // (acorr_in: R[] comes from the launch in front -- the reference's chains by acorr_reference_mfma_kernel, or a flagged
+    // order -- and the phase is a load; QlpcKernelArgs::acorr_in is a kernel argument: the branch is uniform)
+    if (a.acorr_in != nullptr) {
+      if (sl == LPS - 1) {
+#pragma unroll
+        for (int k = 0; k < NLAG; ++k) R[k] = a.acorr_in[(size_t)sf * 33 + k];
+      }
+    } else
     with_role([&](auto kind) {
       double dw[HP + 16];
       double acc[NLAG], s01[NLAG], p2[NLAG];
@@ -284,9 +292,6 @@ __global__ void __launch_bounds__(STEREO ? 256 : 128, 3) qlpc_subwave_kernel(Qlp
       auto conv4 = [&](int t, int at) {
         const int ix = G::idx(t);
         const int4 v = ld4_at(kind, ix);
-        // (the certificate's max |s|: every sample of the subframe passes here once or twice; the zeros in front of it add nothing)
-        cert_max = max(max(cert_max, v.x), max(v.y, max(v.z, v.w)));
-        cert_min = min(min(cert_min, v.x), min(v.y, min(v.z, v.w)));
         const float4 w = *reinterpret_cast<const float4*>(&wlds[ix]);
         dw[at + 0] = (double)((float)v.x * w.x);
         dw[at + 1] = (double)((float)v.y * w.y);
@@ -344,16 +349,10 @@ __global__ void __launch_bounds__(STEREO ? 256 : 128, 3) qlpc_subwave_kernel(Qlp
         for (int k = 0; k < NLAG; ++k) R[k] = R[k] + seg_tree_sum_last<LPS>(sl < LPS / 2 ? acc[k] : 0.0);
       }
     });
-    {
-      // max |s| of the subframe (find_max_abs, arrayutils.rs:509), for the certificate's summation bound
-      const uint32_t hi = seg_allreduce<LPS>((uint32_t)cert_max, [](uint32_t x, uint32_t y) { return x > y ? x : y; });
-      const uint32_t lo = seg_allreduce<LPS>((uint32_t)(-(long long)cert_min), [](uint32_t x, uint32_t y) { return x > y ? x : y; });
-      if (sl == LPS - 1) xd[g * 8 + 6] = hi > lo ? hi : lo;
-    }
     if (sl == LPS - 1) {
 #pragma unroll
       for (int k = 0; k < NLAG; ++k) xr[g * NLAG + k] = R[k];
-      if (a.autocorr && active) {
+      if (a.autocorr && active && a.autocorr != a.acorr_in) {
 #pragma unroll
         for (int k = 0; k < NLAG; ++k) a.autocorr[(size_t)sf * 33 + k] = k <= P ? R[k] : 0.0;
         for (int k = NLAG; k < 33; ++k) a.autocorr[(size_t)sf * 33 + k] = 0.0;
@@ -369,32 +368,12 @@ __global__ void __launch_bounds__(STEREO ? 256 : 128, 3) qlpc_subwave_kernel(Qlp
       double coef[MAXP];
       int32_t cqv[MAXP];
       int warm_v, shift_v;
-      // (cert_subwave: + the order certificate's first tier; a subframe it does not certify is marked, see the header)
-      bool certified = true, tier2 = false;
-      const bool do_cert = a.cert_subwave != 0u;
-      const int st = levinson_quantize<MAXP, true>(Rl, P, (int)a.precision, coef, cqv, &warm_v, &shift_v, xd[lane * 8 + 6], n,
-                                                   &certified, &tier2, do_cert);
+      const int st = levinson_quantize<MAXP>(Rl, P, (int)a.precision, coef, cqv, &warm_v, &shift_v);
 #pragma unroll
       for (int i = 0; i < MAXP; ++i) xq[lane * 16 + i] = cqv[i];
       xq[lane * 16 + 12] = warm_v;
       xq[lane * 16 + 13] = shift_v;
       xq[lane * 16 + 14] = st;
-      // second tier (the rows of T^-1), out of line and only for the lanes whose first tier could not decide: it keeps a
-      // handful of subframes per launch of moderately tonal material out of the clean-up launches, whose fixed cost
-      // (~50 us: the reference's chains + a workgroup of the generic kernel per record) is a quarter of a 16 M-sample launch
-      if (do_cert && __builtin_amdgcn_ballot_w64(tier2) != 0ull) {
-        if (tier2) certified = quant_certified_rows<MAXP>(xr + lane * NLAG, P, (int)a.precision, xd[lane * 8 + 6], n);
-      }
-      xq[lane * 16 + 15] = (do_cert && !certified) ? 1 : 0;
-      if (do_cert && a.cert_stats != nullptr) {
-        const uint32_t sfc = STEREO ? (blk * (uint32_t)S + (uint32_t)(lane >> 2)) * 4u + (uint32_t)(lane & 3)
-                                    : blk * (uint32_t)SUBS + (uint32_t)lane;
-        if (sfc < a.n_subframes) {
-          atomicAdd(a.cert_stats + 0, 1u);
-          if (tier2) atomicAdd(a.cert_stats + 1, 1u);
-          if (!certified) atomicAdd(a.cert_stats + 2, 1u);
-        }
-      }
       if (a.lpc_coefs) {
         // slot -> subframe (STEREO slots are frame-major: slot = 4 frame + role)
         uint32_t sfl = STEREO ? (blk * (uint32_t)S + (uint32_t)(lane >> 2)) * 4u + (uint32_t)(lane & 3)
@@ -758,7 +737,7 @@ __global__ void __launch_bounds__(STEREO ? 256 : 128, 3) qlpc_subwave_kernel(Qlp
     if (fx.redo || (S16 && xd[g * 8 + 7] != 0u)) {
       if (sl == 0) {
         rec->status = -1;
-        if (a.marked_count != nullptr) atomicAdd(a.marked_count, 1u);
+        count_marked(a, sf);
       }
       return;
     }
@@ -779,7 +758,6 @@ __global__ void __launch_bounds__(STEREO ? 256 : 128, 3) qlpc_subwave_kernel(Qlp
   const int warm = xq[g * 16 + 12];
   const int shift = xq[g * 16 + 13];
   const int status = xq[g * 16 + 14];
-  const bool cert_mark = xq[g * 16 + 15] != 0;  // not certified: the reference's chains, by the clean-up launch
   with_role([&](auto kind) {
     int sw[HP + 16];
     constexpr int NCH = (SPL + 15) / 16;
@@ -829,10 +807,10 @@ __global__ void __launch_bounds__(STEREO ? 256 : 128, 3) qlpc_subwave_kernel(Qlp
     // ======================= phase 5: the record ============================
     if (!active || a.params == nullptr) return;
     flacenc_hip_subframe_params* rec = a.params + sf;
-    if ((lp.redo && status == 0) || (S16 && xd[g * 8 + 7] != 0u) || cert_mark) {
+    if ((lp.redo && status == 0) || (S16 && xd[g * 8 + 7] != 0u)) {
       if (sl == 0) {
-        rec->status = cert_mark ? -2 : -1;
-        if (a.marked_count != nullptr) atomicAdd(a.marked_count, 1u);
+        rec->status = a.acorr_in != nullptr ? -2 : -1;  // (-2: redone from the R[] this launch was given)
+        count_marked(a, sf);
       }
       return;
     }
@@ -862,18 +840,17 @@ __global__ void __launch_bounds__(STEREO ? 256 : 128, 3) qlpc_subwave_kernel(Qlp
       bits = verbatim_bits;
     }
     // a candidate the exact sums could not carry: the whole frame goes to the general path (launch_qlpc)
-    const bool redo = (a.use_lpc && status == 0 && lp.redo) || (have_fixed && fx.redo) || (S16 && xd[g * 8 + 7] != 0u) ||
-                      (a.use_lpc && cert_mark);
+    const bool redo = (a.use_lpc && status == 0 && lp.redo) || (have_fixed && fx.redo) || (S16 && xd[g * 8 + 7] != 0u);
     if (VARIANT == 3) {
       // ---- Independent(n) frames: the segment's subframe is one output channel ----
       if (!active) return;
       flacenc_hip_channel_result* out = a.chan_results + sf;
       if (redo) {
         if (sl == 0) {
-          if (a.cand_lpc_params) const_cast<flacenc_hip_subframe_params*>(a.cand_lpc_params)[sf].status = cert_mark ? -2 : -1;
+          if (a.cand_lpc_params) const_cast<flacenc_hip_subframe_params*>(a.cand_lpc_params)[sf].status = a.acorr_in != nullptr ? -2 : -1;
           if (a.cand_fixed_params) const_cast<flacenc_hip_subframe_params*>(a.cand_fixed_params)[sf].status = -1;
           out->kind = 0xFF;
-          if (a.marked_count != nullptr) atomicAdd(a.marked_count, 1u);
+          count_marked(a, sf);
         }
         return;
       }
@@ -947,11 +924,11 @@ __global__ void __launch_bounds__(STEREO ? 256 : 128, 3) qlpc_subwave_kernel(Qlp
     if (any_redo) {
       // marked for the general path: its candidate batches redo the frame's four roles, frame_decide_kernel the frame
       if (sl == 0) {
-        if (a.cand_lpc_params) const_cast<flacenc_hip_subframe_params*>(a.cand_lpc_params)[sf].status = cert_mark ? -2 : -1;
+        if (a.cand_lpc_params) const_cast<flacenc_hip_subframe_params*>(a.cand_lpc_params)[sf].status = a.acorr_in != nullptr ? -2 : -1;
         if (a.cand_fixed_params) const_cast<flacenc_hip_subframe_params*>(a.cand_fixed_params)[sf].status = -1;
         if (role == 0) {
           fr->channel_assignment = 0xFF;
-          if (a.marked_count != nullptr) atomicAdd(a.marked_count, 1u);
+          count_marked(a, frame);  // (marked_unit 4: the frame's four roles)
         }
       }
       return;

@@ -151,17 +151,18 @@ int orc_default_order_is_stable(size_t n, size_t lpc_order) {
 /* statistics of the certified mode since the last reset (not thread-safe: tests read them after single-threaded runs):
  * [0] subframes analysed, [1] certificates that needed the rows of T^-1, [2] subframes recomputed in the reference's order */
 unsigned long orc_cert_stats[3] = {0, 0, 0};
-int orc_certified_subwave_shape(size_t n);
 
 int orc_default_order_is_certified(size_t n, size_t lpc_order) {
-  return (n == 4096 || n == 4608 || orc_certified_subwave_shape(n)) && lpc_order >= 1 && lpc_order <= 12;
+  return (n == 4096 || n == 4608) && lpc_order >= 1 && lpc_order <= 12;
 }
 
 /* ... and (round 6) on the sub-wave kernel's shapes -- blocks of 4 / 8 / 16 / 32 finest Rice partitions: 256 .. 2048 and the
- * CD-style 288 .. 2304 -- its chunk-tree sums are held to the same certificate; what it does not certify is marked and
- * recomputed from the reference's chains by the clean-up launch behind the kernel. */
-int orc_certified_subwave_shape(size_t n) {
-  return n == 256 || n == 512 || n == 1024 || n == 2048 || n == 288 || n == 576 || n == 1152 || n == 2304;
+ * CD-style 288 .. 2304, orders up to 12 -- the unflagged product runs the reference's chains for every subframe in a pass
+ * of their own (ORC_ACORR_CANONICAL is ORC_ACORR_REFERENCE there); only ORC_ACORR_CHUNK_TREE, the product's
+ * FLACENC_HIP_FLAG_CANONICAL_SUM_ORDER, keeps the one-pass chunk tree on them. */
+int orc_default_order_is_two_pass(size_t n, size_t lpc_order) {
+  return (n == 256 || n == 512 || n == 1024 || n == 2048 || n == 288 || n == 576 || n == 1152 || n == 2304) &&
+         lpc_order >= 1 && lpc_order <= 12;
 }
 
 /* The fused kernel's own summation order on blocks of 4096 / 4608 samples (flacenc_rs_amd/csrc/qlpc_wave_kernel_impl.h,
@@ -412,16 +413,15 @@ static int orc_quant_stable(const double* a, size_t P, int32_t shift, const doub
  *              test below, i.e. <= 1.23 F_i for quant_precision >= 6 and P <= 12                               [shown]
  *   recursion: both recursions (the reference's on R^, the kernel's on R~) are floating point.  ASSUMED: on a system the
  *              recursion itself finds positive definite (every denominator 1 - err^2 > 0) the computed solution's
- *              residual obeys |T a^ - r|_inf <= c_L P^2 u R0 (1 + |a^|_1); the two runs' errors then add at most
- *              (2 c_L P^2 / (n + 96)) F_i, which the factor 2 covers while c_L <= 0.77 (n + 96) / (2 P^2): 11 at (4096, 12),
- *              3.3 at (1152, 12), 0.94 at (256, 12) -- the smallest allowance of any certified shape (eps shrinks with n,
- *              the recursion's rounding does not).  Measured (tools/certificate_attack.py, exact rational residuals):
- *              c_L <= 0.39 over 870 000 adversarial subframes of 4096 samples, <= 0.19 = at most 0.10 of the shape's
- *              allowance over 1.2 M of 256 / 576 / 1152.  Systems that are NOT positive definite -- the sums
+ *              residual obeys |T a^ - r|_inf <= c_L P^2 u R0 (1 + |a^|_1) with c_L <= 11; then the two runs' errors add at
+ *              most (2 c_L P^2 / (n + 96)) F_i <= 0.77 F_i for P <= 12 and n >= 4096, the certified shapes (the allowance
+ *              shrinks with n -- 0.94 at (256, 12) -- which is one reason the sub-wave shapes are not certified but given
+ *              the reference's chains outright).  Measured (tools/certificate_attack.py, exact rational residuals,
+ *              870 000 adversarial subframes): c_L <= 0.39.  Systems that are NOT positive definite -- the sums
  *              start at t = P for every lag, R[] need not be an autocorrelation: a block that opens on a clipped plateau
  *              is enough -- have no such bound (c_L up to 45 000 found, the two computed solutions 68 x further apart than
  *              2 F_i on a subframe the round-5 rule certified) and are excluded: round 6, `skipped` bit 1 below.
- *   safety   = 2.0 >= 1.23 + 2 c_L P^2 / (n + 96) under that allowance.
+ *   safety   = 2.0 >= 1.23 + 2 c_L P^2 / (n + 96) for P <= 12, n >= 4096, c_L <= 11.
  * Not a theorem about the floating-point recursion -- c_L is evidence, and below quant_precision 6 so is the second-order
  * factor -- which is why tests/test_certificate_cpu.py soaks it and attacks it: the worst |a^_ref - a^_kernel|_i / (2 F_i)
  * a hill-climber finds among certifiable subframes is 0.04 (1.5 ... 68 before the exclusion). */
@@ -612,10 +612,9 @@ int orc_lpc_from_autocorr(const int32_t* signal, size_t n, const orc_qlpc_config
   orc_fill_windowed_signal(signal, window, n, xw);
   double corr[ORC_MAX_LPC_ORDER + 1];
   if (cfg->acorr_order == ORC_ACORR_CANONICAL && orc_default_order_is_certified(n, lpc_order)) {
-    /* the unflagged product on these shapes: chunk-tree sums where their quantised parameters are certified to be the
-     * reference's, the reference's own chains where not */
-    if (orc_certified_subwave_shape(n)) orc_auto_correlation_canonical_f64(lpc_order + 1, xw, n, corr); /* the chunk tree */
-    else orc_auto_correlation_lane_order_f64(lpc_order + 1, xw, n, corr);
+    /* the unflagged product on these shapes: the fused kernel's lane-order sums where their quantised parameters are
+     * certified to be the reference's, the reference's own chains where not */
+    orc_auto_correlation_lane_order_f64(lpc_order + 1, xw, n, corr);
     int st = ORC_STATUS_OK;
     for (size_t i = 0; i <= lpc_order; ++i)
       if (isnan(corr[i]) || isinf(corr[i])) st = ORC_STATUS_NONFINITE;
@@ -648,12 +647,12 @@ int orc_lpc_from_autocorr(const int32_t* signal, size_t n, const orc_qlpc_config
     orc_cert_stats[2] += 1;
     for (size_t i = 0; i < lpc_order; ++i) coefs_out[i] = 0.0;
     orc_auto_correlation_f64(lpc_order + 1, xw, n, corr);
-  } else if (cfg->acorr_order == ORC_ACORR_CHUNK_TREE && orc_default_order_is_certified(n, lpc_order) &&
-             !orc_certified_subwave_shape(n))
+  } else if (cfg->acorr_order == ORC_ACORR_CHUNK_TREE && orc_default_order_is_certified(n, lpc_order))
     orc_auto_correlation_lane_order_f64(lpc_order + 1, xw, n, corr); /* the fused kernel's order, uncertified */
   else if (cfg->acorr_order == ORC_ACORR_GENERIC_TREE ||
-           ((cfg->acorr_order == ORC_ACORR_CANONICAL || cfg->acorr_order == ORC_ACORR_CHUNK_TREE) &&
-            !orc_default_order_is_stable(n, lpc_order)))
+           (cfg->acorr_order == ORC_ACORR_CHUNK_TREE && !orc_default_order_is_stable(n, lpc_order)) ||
+           (cfg->acorr_order == ORC_ACORR_CANONICAL && !orc_default_order_is_stable(n, lpc_order) &&
+            !orc_default_order_is_two_pass(n, lpc_order)))
     orc_auto_correlation_canonical_f64(lpc_order + 1, xw, n, corr);
   else if (cfg->acorr_order == ORC_ACORR_NIGHTLY)
     orc_auto_correlation_nightly_f64(lpc_order + 1, xw, n, corr, 0);
@@ -685,8 +684,7 @@ int orc_certificate_bounds(const int32_t* signal, size_t n, const orc_qlpc_confi
   orc_window_weights(cfg->window_type, cfg->tukey_alpha, n, window);
   orc_fill_windowed_signal(signal, window, n, xw);
   double corr[ORC_MAX_LPC_ORDER + 1], fwd[ORC_MAX_LPC_ORDER + 1];
-  if (orc_certified_subwave_shape(n)) orc_auto_correlation_canonical_f64(P + 1, xw, n, corr);
-  else orc_auto_correlation_lane_order_f64(P + 1, xw, n, corr);
+  orc_auto_correlation_lane_order_f64(P + 1, xw, n, corr);
   free(window);
   free(xw);
   int skipped = 0;

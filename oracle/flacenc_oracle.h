@@ -146,7 +146,7 @@ void orc_auto_correlation_canonical_f64(size_t order, const float* signal, size_
 void orc_auto_correlation_lane_order_f64(size_t order, const float* signal, size_t n, double* dest);
 int orc_default_order_is_stable(size_t n, size_t lpc_order);
 int orc_default_order_is_certified(size_t n, size_t lpc_order);
-int orc_certified_subwave_shape(size_t n);
+int orc_default_order_is_two_pass(size_t n, size_t lpc_order);
 extern unsigned long orc_cert_stats[3];
 int orc_quant_certified(const double* R, const double* a, const double* fwd, size_t P, uint32_t max_abs_s, size_t n,
                         uint32_t precision, int* tier2);

@@ -49,11 +49,11 @@ def _corpus(rng, count, n, bps):
     return np.stack(rows)
 
 
-@pytest.mark.parametrize("n", [4096, 4608, 1152, 256])  # the fused kernel's lane order; the sub-wave kernel's chunk tree (round 6)
+@pytest.mark.parametrize("n", [4096, 4608])
 def test_a_certified_subframe_is_never_wrong(n):
     rng = np.random.default_rng(20251004 + n)
     total = recomputed = tier2 = tree_differs = 0
-    for rnd in range(24 if n == 4096 else 8 if n == 4608 else 16):
+    for rnd in range(24 if n == 4096 else 8):
         order = int(rng.integers(1, 13))
         precision = int(rng.integers(3, 16))
         bps = int(rng.choice([8, 12, 16, 16, 16, 20, 24]))
@@ -112,22 +112,3 @@ def test_attack_on_the_certificate_stays_an_order_of_magnitude_below_the_bound()
     assert evals > 2000
     assert worst[0] <= 0.1, worst
     assert c_l <= 2.0, c_l
-
-
-def test_attack_on_the_smallest_certified_shape():
-    """The same attack on blocks of 256 samples (the sub-wave kernel's chunk tree, round 6).  The summation bound shrinks with
-    n while the recursions' rounding does not: what the factor 2 leaves them is c_L <= 0.77 (n + 96) / (2 P^2) -- 0.94 at
-    (256, 12) against 11 at (4096, 12).  Three runs of 150 s at 256 / 576 / 1152 samples: ratio <= 0.024, c_L <= 0.19, at most
-    0.10 of its shape's allowance (profiles/r06_certificate_attack.txt, 4)."""
-    import os
-    import sys
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
-    import certificate_attack as ca
-    try:
-        worst, c_l, evals = ca.attack(15.0, seed=20251006, orders=[8, 10, 12], log=lambda *_: None, n=256)
-    finally:
-        ca.N = 4096
-    print(f"{evals} evaluations: worst actual / bound {worst[0]:.4f}, c_L {c_l:.3f} = {ca.attack.last_constant_fraction:.2f} of the allowance")
-    assert evals > 2000
-    assert worst[0] <= 0.1, worst
-    assert ca.attack.last_constant_fraction <= 0.5

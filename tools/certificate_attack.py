@@ -12,9 +12,8 @@ of the floating-point recursion that the stated bound ASSUMES (<= 11 would do; f
 
     python tools/certificate_attack.py [--seconds 120] [--seed 1] [--orders 8,10,12] [--n 4096]
 
---n: the block size (4096 / 4608: the fused kernel's lane order; 256 .. 2304: the sub-wave kernel's chunk tree).  The
-allowance the factor 2 leaves the two recursions is 0.77 F_i, i.e. c_L <= 0.77 (n + 96) / (2 P^2): 11 at (4096, 12), 0.94 at
-(256, 12), the smallest of the certified shapes.
+--n: the block size, 4096 or 4608 (the certified shapes).  The allowance the factor 2 leaves the two recursions is
+0.77 F_i, i.e. c_L <= 0.77 (n + 96) / (2 P^2): 11 at (4096, 12).
 
 CPU only (the oracle is the statement of the certificate; tests/test_gpu_certified_order.py holds the GPU to it bit for bit).
 """
@@ -171,7 +170,7 @@ if __name__ == "__main__":
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--orders", default="4,8,10,12")
     ap.add_argument("--save", default=None, help="write the worst case's samples (int32 .npy) here")
-    ap.add_argument("--n", type=int, default=4096, help="block size: 4096 / 4608 or one of the sub-wave kernel's")
+    ap.add_argument("--n", type=int, default=4096, help="block size: 4096 or 4608")
     args = ap.parse_args()
     orders = [int(v) for v in args.orders.split(",")]
     worst, cl, evals = attack(args.seconds, args.seed, orders, n=args.n)

@@ -1,6 +1,6 @@
 """CPU soak of the order certificate through the oracle (the test tests/test_certificate_cpu.py at scale):
     python tools/certificate_soak.py [rounds=400] [seed=77] [sizes=4096,4096,4096,4608]
-(sizes: the block sizes the rounds cycle through; e.g. 256,288,512,576,1024,1152,2048,2304 for the sub-wave kernel's shapes)
+(sizes: the block sizes the rounds cycle through, of the certified shapes 4096 / 4608)
 prints subframes / tier-2 / recomputed / certified-but-different (must be 0) / bare-order-differs."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -58,6 +58,27 @@ def signals(rng, nf, n, bps):
     return x
 
 
+def _diff_channels(cr, cg, crr, cgr, chn):
+    """Where two encode_frames results part ways: first differing (frame, channel) and the fields that differ there."""
+    out = " (%d channels)" % chn
+    a, b = cr.reshape(-1), cg.reshape(-1)
+    for i in range(a.size):
+        if a[i].tobytes() != b[i].tobytes() or not np.array_equal(crr.reshape(a.size, -1)[i], cgr.reshape(a.size, -1)[i]):
+            out += " subframe %d:" % i
+            for f in ("kind", "analysis_status", "dc_offset", "bits"):
+                if a[i][f] != b[i][f]:
+                    out += " %s %s != %s;" % (f, a[i][f], b[i][f])
+            for f in a[i]["params"].dtype.names:
+                if not np.array_equal(a[i]["params"][f], b[i]["params"][f]):
+                    out += " params.%s %s != %s;" % (f, np.asarray(a[i]["params"][f]).ravel()[:14], np.asarray(b[i]["params"][f]).ravel()[:14])
+            ra, rb = crr.reshape(a.size, -1)[i], cgr.reshape(a.size, -1)[i]
+            if not np.array_equal(ra, rb):
+                k = int(np.flatnonzero(ra != rb)[0])
+                out += " residual differs from sample %d (%d of %d): %s != %s" % (k, int((ra != rb).sum()), ra.size, ra[k:k + 4], rb[k:k + 4])
+            break
+    return out
+
+
 def main():
     lo_seed, hi_seed = int(sys.argv[1]), int(sys.argv[2])
     oracle_every = int(sys.argv[sys.argv.index("--oracle-every") + 1]) if "--oracle-every" in sys.argv else 10
@@ -109,7 +130,7 @@ def main():
                 xc = flat[: nfc * chn].reshape(nfc, chn, n)
                 cr, crr = h.encode_frames(xc, bps, f0)
                 cg, cgr = h.encode_frames(xc, bps, f1)
-                assert cr.tobytes() == cg.tobytes() and np.array_equal(crr, cgr), "independent-channel frames"
+                assert cr.tobytes() == cg.tobytes() and np.array_equal(crr, cgr), "independent-channel frames" + _diff_channels(cr, cg, crr, cgr, chn)
             marked += int((np.abs(x.astype(np.int64)).max(axis=(1, 2)) >= (1 << 22)).sum())
             if seed % oracle_every == 0:
                 okw = {k: v for k, v in fkw.items() if not k.startswith("fixed_")}

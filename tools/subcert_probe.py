@@ -1,8 +1,10 @@
 """What the order certificate costs on the sub-wave kernel's shapes, and how often its tiers are needed: the stereo candidate
 batch (four subframes per frame) per block size, order and material -- the bench signal and stereo frames cut from the
 reference's real-audio fixtures -- with the certificate (flags 0) and without (FLACENC_HIP_FLAG_CANONICAL_SUM_ORDER).
-    gpurun -- python tools/subcert_probe.py [samples per launch = 2^25]
-Prints per row: ms and G samples/s of both launches, and the certificate's counters [analysed, second tier, marked]."""
+    gpurun -- python tools/subcert_probe.py [samples per launch = 2^25] [block sizes = 256,576,1152,2304]
+Prints per row: ms and G samples/s of both launches.  (Round 6 first built an order certificate inside the kernel and used
+this probe to price it -- its counters were the last column; the unflagged order on these shapes is now the reference's by
+two passes and the counters stay at zero: profiles/r06_subwave_two_pass.txt.)"""
 import os, sys
 ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -38,7 +40,7 @@ def timed(go, reps=10):
     return float(np.median([a.elapsed_time(b) for a, b in ev]))
 
 
-for n in (256, 576, 1152, 2304):
+for n in ([int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else (256, 576, 1152, 2304)):
     frames = TOTAL // (2 * n)
     for material in ("bench signal", "real audio"):
         host = _capi.sigen_frames(frames, 2, n, 16, 200.0, 0.4, 0.4, seed=7) if material == "bench signal" else music(frames, n)
@@ -56,7 +58,8 @@ for n in (256, 576, 1152, 2304):
                     st = torch.zeros(3, dtype=torch.int32, device=dev)
                     h.debug_set_cert_stats(st.data_ptr()); go(); torch.cuda.synchronize(); h.debug_set_cert_stats(0)
                     stats = st.cpu().tolist()
-            print("n %4d order %2d %-12s certified %.3f ms %6.1f G | certificate off %.3f ms %6.1f G | x %.3f | analysed / second tier / marked %s (%.2f %% / %.2f %%)" % (
+            print("n %4d order %2d %-12s unflagged (two passes) %.3f ms %6.1f G | CANONICAL_SUM_ORDER (one pass) %.3f ms %6.1f G | x %.3f | analysed / second tier / marked %s (%.2f %% / %.2f %%)" % (
                 n, order, material, row[0][0], row[0][1], row[1][0], row[1][1], row[0][0] / row[1][0], stats,
                 100.0 * stats[1] / max(1, stats[0]), 100.0 * stats[2] / max(1, stats[0])), flush=True)
         del x, params, resid
+

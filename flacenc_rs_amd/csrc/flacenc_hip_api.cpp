@@ -540,8 +540,9 @@ int enqueue(flacenc_hip_handle* h, const flacenc_hip_qlpc_config* cfg, const int
   }
   // (R[] and the predictor records between the launches of the split pipelines: orders from 13, and blocks of
   // 8192 / 16384 at any order -- the big-block kernels)
+  // (... and, round 6, every unflagged launch: the reference's chains go in front of whatever kernel takes the shape)
   if (cfg->lpc_order >= 13 || a.reference_order || a.direct_mse || block_size == 8192 || block_size == 16384 ||
-      flacenc_hip::subwave_shape(block_size) || certify_needs_scratch(a)) {
+      flacenc_hip::subwave_shape(block_size) || a.certify != 0u) {
     if ((rc = attach_split_scratch(h, a)) != FLACENC_HIP_OK) return rc;
   }
   if (plan.table_scratch_bytes_per_subframe) {

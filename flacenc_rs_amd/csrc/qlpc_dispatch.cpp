@@ -294,23 +294,17 @@ hipError_t launch_qlpc(const QlpcKernelArgs& a, const QlpcLaunchPlan& plan, hipS
     const bool shape = cert_shape(a) && order_ok && !a.direct_mse && a.fixed_mode == 0 && a.lpc_stage == 0 &&
                        a.acorr_in == nullptr && !a.only_marked;
     const bool wave = shape && wave_kernel_eligible(a);
-    // the sub-wave kernel's shapes (round 6): first tier in the kernel, the reference's chains for what it marks
-    const bool sub_shape = subwave_shape(a.block_size) && a.lpc_order >= 1 && a.lpc_order <= 12 && a.reference_order == 0u &&
-                           !a.direct_mse && a.fixed_mode == 0 && a.lpc_stage == 0 && a.acorr_in == nullptr && !a.only_marked;
-    if (sub_shape) {
-      QlpcKernelArgs b = a;
-      b.certify = 0;
-      // the reference's chains in front of the sub-wave kernel, its own autocorrelation skipped (acorr_in): the same cost
-      // on every material.  (An order certificate inside that kernel was 6-13 % faster on noise-like material and 20 to
-      // 140 x slower on music at orders 10-12: profiles/r06_subwave_two_pass.txt.)  Unaligned rows and
-      // FLACENC_HIP_FLAG_GENERIC_KERNEL take the same R[] through the generic kernel.
-      b.reference_order = 1u;
-      return launch_qlpc(b, plan, stream);
-    }
+    // Every other shape (round 6): the reference's chains for every subframe in a pass of their own in front of the kernel
+    // that takes the shape -- the sub-wave kernel (its autocorrelation skipped: acorr_in; an order certificate inside it was
+    // 6-13 % faster on noise-like material and 20 to 140 x slower on music, profiles/r06_subwave_two_pass.txt), the
+    // big-block kernels, the generic kernel -- so that the unflagged integers are the stable build's on ANY shape
+    // (the oracle's orc_default_order_is_two_pass); FLACENC_HIP_FLAG_CANONICAL_SUM_ORDER keeps the one-pass orders.
+    const bool two_pass = a.reference_order == 0u && !a.direct_mse && a.fixed_mode == 0 && a.lpc_stage == 0 &&
+                          a.acorr_in == nullptr && !a.only_marked && a.lpc_order >= 1 && a.split_scratch != nullptr;
     if (!shape || !wave || a.pack_out != nullptr) {
       QlpcKernelArgs b = a;
       b.certify = 0;
-      if (shape) b.reference_order = 1u;  // the stable build's order, by the two-pass pipeline below
+      if (shape || two_pass) b.reference_order = 1u;  // the stable build's order, by the two-pass pipeline below
       return launch_qlpc(b, plan, stream);
     }
     certified_fused = true;

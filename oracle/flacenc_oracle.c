@@ -156,13 +156,11 @@ int orc_default_order_is_certified(size_t n, size_t lpc_order) {
   return (n == 4096 || n == 4608) && lpc_order >= 1 && lpc_order <= 12;
 }
 
-/* ... and (round 6) on the sub-wave kernel's shapes -- blocks of 4 / 8 / 16 / 32 finest Rice partitions: 256 .. 2048 and the
- * CD-style 288 .. 2304, orders up to 12 -- the unflagged product runs the reference's chains for every subframe in a pass
- * of their own (ORC_ACORR_CANONICAL is ORC_ACORR_REFERENCE there); only ORC_ACORR_CHUNK_TREE, the product's
- * FLACENC_HIP_FLAG_CANONICAL_SUM_ORDER, keeps the one-pass chunk tree on them. */
+/* ... and (round 6) on EVERY other shape the unflagged product runs the reference's chains for every subframe in a pass of
+ * their own in front of the kernel that takes the shape (ORC_ACORR_CANONICAL is ORC_ACORR_REFERENCE there); only
+ * ORC_ACORR_CHUNK_TREE, the product's FLACENC_HIP_FLAG_CANONICAL_SUM_ORDER, keeps the one-pass chunk tree on them. */
 int orc_default_order_is_two_pass(size_t n, size_t lpc_order) {
-  return (n == 256 || n == 512 || n == 1024 || n == 2048 || n == 288 || n == 576 || n == 1152 || n == 2304) &&
-         lpc_order >= 1 && lpc_order <= 12;
+  return lpc_order >= 1 && !orc_default_order_is_certified(n, lpc_order) && !orc_default_order_is_stable(n, lpc_order);
 }
 
 /* The fused kernel's own summation order on blocks of 4096 / 4608 samples (flacenc_rs_amd/csrc/qlpc_wave_kernel_impl.h,

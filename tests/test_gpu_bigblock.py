@@ -164,15 +164,26 @@ def test_config3_config5_unflagged_order_is_the_references(handle, n, order, ste
     assert not np.array_equal(tree.view(np.uint64), oR[:, : order + 1].view(np.uint64))
 
 
-@pytest.mark.parametrize("n,order", [(8192, 15), (16384, 12), (4096, 15), (4608, 24), (2048, 24)])
-def test_shapes_next_to_them_keep_the_chunk_tree(handle, n, order):
-    """... and only there: order 15 on those blocks and order 24 on other block sizes still sum in the chunk tree."""
+@pytest.mark.parametrize("n,order", [(8192, 15), (16384, 12), (4096, 15), (4608, 24), (2048, 24), (1000, 8), (20000, 10)])
+def test_shapes_next_to_them_take_the_chains_in_a_pass_of_their_own(handle, n, order):
+    """Round 6: every other shape -- order 15 on those blocks, order 24 on other block sizes, ragged and very large blocks --
+    is given the reference's chains too when no flag is set (two passes: orc_default_order_is_two_pass), everything equal to
+    the oracle's ACORR_REFERENCE mode, floating point included; FLACENC_HIP_FLAG_CANONICAL_SUM_ORDER keeps the one-pass
+    chunk tree there, which is NOT the reference's order on this corpus."""
     x = batch(4, n, 24, 99 + n + order)
     gp, gres, gR, gA = handle.qlpc_batch(x, 24, _capi.make_config(lpc_order=order), want_fp=True)
-    _, _, cR, _ = orc.qlpc_batch(x, 24, orc.make_config(lpc_order=order, acorr=orc.ACORR_CANONICAL))
-    _, _, rR, _ = orc.qlpc_batch(x, 24, orc.make_config(lpc_order=order, acorr=orc.ACORR_REFERENCE))
-    assert np.array_equal(gR.view(np.uint64), cR.view(np.uint64))
-    assert not np.array_equal(cR.view(np.uint64), rR.view(np.uint64))
+    cp, cres, cR, cA = orc.qlpc_batch(x, 24, orc.make_config(lpc_order=order, acorr=orc.ACORR_CANONICAL))
+    rp, rres, rR, rA = orc.qlpc_batch(x, 24, orc.make_config(lpc_order=order, acorr=orc.ACORR_REFERENCE))
+    assert np.array_equal(gR.view(np.uint64), rR.view(np.uint64)) and np.array_equal(gA.view(np.uint64), rA.view(np.uint64))
+    assert np.array_equal(cR.view(np.uint64), rR.view(np.uint64))
+    records_equal(gp, rp)
+    assert np.array_equal(gres, rres)
+    tp, tres, tR, tA = handle.qlpc_batch(x, 24, _capi.make_config(lpc_order=order, flags=_capi.FLAG_CANONICAL_SUM_ORDER), want_fp=True)
+    op, ores, oR, oA = orc.qlpc_batch(x, 24, orc.make_config(lpc_order=order, acorr=orc.ACORR_CHUNK_TREE))
+    assert np.array_equal(tR.view(np.uint64), oR.view(np.uint64))
+    records_equal(tp, op)
+    assert np.array_equal(tres, ores)
+    assert not np.array_equal(oR.view(np.uint64), rR.view(np.uint64))
 
 
 @pytest.mark.parametrize("kw", [dict(quant_precision=7), dict(window=("tukey", 1.0)), dict(window="rectangle"),

@@ -125,12 +125,13 @@ extern "C" {
  * said about the launches before them (a verdict per 4096 subframes or more), to two passes (the reference's chains for every
  * subframe on the matrix cores, then the fused kernel): the same integers at a flat 1.4 x the certified kernel's best
  * time; a choice of speed, never of result ("the order mode by material").
- * Blocks of 256 / 512 / 1024 / 2048 and 288 / 576 / 1152 / 2304 samples at orders up to 12 take those two passes always
- * (round 6: an order certificate inside their kernel was up to 140 x slower on music), as do blocks of 4096 / 8192 / 16384
- * from order 16: there the unflagged R[], coefficients and integers are the stable build's outright.
- * This flag switches the certificate -- and the small blocks' pass of reference chains -- off: a valid encoding of the same
- * configuration whose coefficients may differ from the reference's in the last quantisation step on a fraction of a per
- * mille of subframes. */
+ * EVERY OTHER SHAPE takes those two passes always (round 6; the pass of chains in front of whatever kernel takes the
+ * shape -- an order certificate inside the small blocks' kernel was up to 140 x slower on music): there the unflagged R[],
+ * coefficients and integers are the stable build's outright.
+ * This flag switches the certificate -- and the other shapes' pass of reference chains -- off (blocks of 4096 / 8192 /
+ * 16384 at orders from 16 keep the chains: they cost nothing extra there): a valid encoding of the same configuration
+ * whose coefficients may differ from the reference's in the last quantisation step on a fraction of a per mille of
+ * subframes. */
 #define FLACENC_HIP_FLAG_CANONICAL_SUM_ORDER 128u
 
 /* A modifier of FLACENC_HIP_FLAG_REFERENCE_SUM_ORDER for callers that consume the INTEGER outputs only (a drop-in under

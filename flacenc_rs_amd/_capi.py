@@ -43,7 +43,7 @@ MEM_DEVICE = 1
 COMM_ID_BYTES = 128  # FLACENC_HIP_COMM_ID_BYTES
 
 # every symbol include/flacenc_hip.h declares
-ABI_VERSION = 5  # FLACENC_HIP_ABI_VERSION of include/flacenc_hip.h
+ABI_VERSION = 6  # FLACENC_HIP_ABI_VERSION of include/flacenc_hip.h
 DEBUG_SYMBOLS = ("flacenc_hip_debug_set_stamps", "flacenc_hip_debug_set_fixed_keys", "flacenc_hip_debug_set_cert_stats",
                  "flacenc_hip_debug_set_adaptive_order", "flacenc_hip_debug_adaptive_state")
 EXPORTED_SYMBOLS = (

@@ -36,13 +36,17 @@
 extern "C" {
 #endif
 
-/* 5: blocks of 4096 / 8192 / 16384 samples at orders from 16 sum in the stable build's order by default (other bytes
+/* 6: without a summation-order flag the autocorrelation is the stable build's on every shape (round 5: certified on blocks
+ *    of 4096 / 4608 at orders up to 12; round 6: the reference's chains in a pass of their own everywhere else) -- other bytes
+ *    for the same config than revision 5 on a fraction of a per mille of subframes; the product library exports the
+ *    declarations of this header and nothing else (the debug hooks live in libflacenc_hip_hooks.so).  No signature changed.
+ * 5: blocks of 4096 / 8192 / 16384 samples at orders from 16 sum in the stable build's order by default (other bytes
  *    for the same config than revision 4); the two flacenc_hip_debug_* symbols left the public ABI; new exports
  *    flacenc_hip_frame_wire_bytes, flacenc_hip_stereo_frame_wire_async, flacenc_hip_stream_offsets_async (round 4) and
  *    the flacenc_hip_comm_* / flacenc_hip_allgather_* collective calls (round 5).
  * 4: use_direct_mse / mae_optimization_steps in flacenc_hip_qlpc_config, NIGHTLY_SUM_ORDER, frame-level calls take
  *    blocks below 64 samples */
-#define FLACENC_HIP_ABI_VERSION 5
+#define FLACENC_HIP_ABI_VERSION 6
 
 /* FLAC allows LPC order 32; the reference's config verifier caps it at 24
  * (src/constant.rs:118, src/config.rs:304).  Orders 25..32 are an extension

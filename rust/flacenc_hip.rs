@@ -160,7 +160,7 @@ pub struct Handle {
 }
 
 /// `FLACENC_HIP_ABI_VERSION` of `include/flacenc_hip.h` this binding was written against.
-pub const ABI_VERSION: c_int = 5;
+pub const ABI_VERSION: c_int = 6;
 
 extern "C" {
     pub fn flacenc_hip_abi_version() -> c_int;

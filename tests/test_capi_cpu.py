@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_capi.EXPORTED_SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.flacenc_hip_abi_version() == 5
+    assert lib.flacenc_hip_abi_version() == _capi.ABI_VERSION == 6
 
 
 def test_product_library_exports_the_c_abi_and_nothing_else():

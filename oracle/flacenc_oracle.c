@@ -422,7 +422,7 @@ static int orc_quant_stable(const double* a, size_t P, int32_t shift, const doub
  *   safety   = 2.0 >= 1.23 + 2 c_L P^2 / (n + 96) for P <= 12, n >= 4096, c_L <= 11.
  * Not a theorem about the floating-point recursion -- c_L is evidence, and below quant_precision 6 so is the second-order
  * factor -- which is why tests/test_certificate_cpu.py soaks it and attacks it: the worst |a^_ref - a^_kernel|_i / (2 F_i)
- * a hill-climber finds among certifiable subframes is 0.04 (1.5 ... 68 before the exclusion). */
+ * a hill-climber finds among certifiable subframes is 0.05 (1.5 ... 68 before the exclusion). */
 static void orc_cert_bounds(const double* R, const double* a, const double* fwd, size_t P, uint32_t max_abs_s, size_t n,
                             double* num_out, double* f0_out, double* eps_a_out) {
   const double safety = 2.0;

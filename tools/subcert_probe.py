@@ -1,6 +1,6 @@
-"""What the order certificate costs on the sub-wave kernel's shapes, and how often its tiers are needed: the stereo candidate
-batch (four subframes per frame) per block size, order and material -- the bench signal and stereo frames cut from the
-reference's real-audio fixtures -- with the certificate (flags 0) and without (FLACENC_HIP_FLAG_CANONICAL_SUM_ORDER).
+"""The sub-wave kernel's shapes unflagged (two passes: the reference's chains in front) and with
+FLACENC_HIP_FLAG_CANONICAL_SUM_ORDER (one pass, the chunk tree): the stereo candidate batch (four subframes per frame) per
+block size, order and material -- the bench signal and stereo frames cut from the reference's real-audio fixtures.
     gpurun -- python tools/subcert_probe.py [samples per launch = 2^25] [block sizes = 256,576,1152,2304]
 Prints per row: ms and G samples/s of both launches.  (Round 6 first built an order certificate inside the kernel and used
 this probe to price it -- its counters were the last column; the unflagged order on these shapes is now the reference's by

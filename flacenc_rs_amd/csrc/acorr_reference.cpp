@@ -523,13 +523,20 @@ __global__ void __launch_bounds__(256) acorr_reference_mfma_kernel(AcorrRefArgs 
   // global -> registers for the tile at T0: lane l holds samples T0 + 4 l .. + 3 of each row
   int4 raw[STEREO ? 2 : 4];
   float4 wv;
+  // (whole quads: with aligned rows and n a multiple of four a lane's four samples are all inside the block or all behind
+  // it, so the block's last, partial tile and the tile behind it -- a fifth of the tiles of a 1152-sample block, half of a
+  // 256-sample block's -- load like the full ones instead of element by element)
+  const bool quads = vec_ok && (n & 3) == 0;
+  const bool wquads = wtab != nullptr && (n & 3) == 0 && (reinterpret_cast<uintptr_t>(wtab) & 15) == 0;
   auto issue = [&](int T0) __attribute__((always_inline)) {
     const int t = T0 + 4 * lane;
     const bool full = vec_ok && T0 + kMTile <= n;
 #pragma unroll
     for (int r = 0; r < (STEREO ? 2 : 4); ++r) {
-      if (full) {
+      if (full || (quads && t < n)) {
         raw[r] = *reinterpret_cast<const int4*>(rowp[r] + t);
+      } else if (quads) {
+        raw[r] = make_int4(0, 0, 0, 0);
       } else {
         raw[r].x = t + 0 < n ? rowp[r][t + 0] : 0;
         raw[r].y = t + 1 < n ? rowp[r][t + 1] : 0;
@@ -538,7 +545,9 @@ __global__ void __launch_bounds__(256) acorr_reference_mfma_kernel(AcorrRefArgs 
       }
     }
     wv = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
-    if (wtab) {
+    if (wquads) {
+      wv = t < n ? *reinterpret_cast<const float4*>(wtab + t) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    } else if (wtab) {
       wv.x = t + 0 < n ? wtab[t + 0] : 0.0f;
       wv.y = t + 1 < n ? wtab[t + 1] : 0.0f;
       wv.z = t + 2 < n ? wtab[t + 2] : 0.0f;

@@ -112,3 +112,22 @@ def test_attack_on_the_certificate_stays_an_order_of_magnitude_below_the_bound()
     assert evals > 2000
     assert worst[0] <= 0.1, worst
     assert c_l <= 2.0, c_l
+
+
+@pytest.mark.parametrize("n,order", [(1000, 8), (1152, 12), (256, 4), (8192, 10), (16384, 15), (20000, 6)])
+def test_every_other_shape_is_the_references_by_two_passes(n, order):
+    """Round 6's rule for the unflagged order outside the certified shapes (orc_default_order_is_two_pass): the oracle's
+    ACORR_CANONICAL mode IS its ACORR_REFERENCE mode there -- R[], coefficients, records, residuals -- no certificate runs
+    (the counters stay at zero), and ACORR_CHUNK_TREE (FLACENC_HIP_FLAG_CANONICAL_SUM_ORDER) keeps the 16-sample chunk
+    tree, whose R[] differs."""
+    rng = np.random.default_rng(n + order)
+    x = _corpus(rng, 8, n, 16)
+    kw = dict(lpc_order=order)
+    orc.cert_stats(reset=True)
+    cp, cres, cR, cA = orc.qlpc_batch(x, 16, orc.make_config(acorr=orc.ACORR_CANONICAL, **kw), nthreads=1)
+    assert orc.cert_stats() == (0, 0, 0)
+    rp, rres, rR, rA = orc.qlpc_batch(x, 16, orc.make_config(acorr=orc.ACORR_REFERENCE, **kw))
+    tp, tres, tR, tA = orc.qlpc_batch(x, 16, orc.make_config(acorr=orc.ACORR_CHUNK_TREE, **kw))
+    assert np.array_equal(cR.view(np.uint64), rR.view(np.uint64)) and np.array_equal(cA.view(np.uint64), rA.view(np.uint64))
+    assert cp.tobytes() == rp.tobytes() and np.array_equal(cres, rres)
+    assert not np.array_equal(tR[:, : order + 1].view(np.uint64), rR[:, : order + 1].view(np.uint64))

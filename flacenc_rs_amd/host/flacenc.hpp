@@ -494,8 +494,9 @@ class HipContext {
   // Which build of the crate the floating-point sums of the path reproduce bit for bit: the stable build
   // (one mul_add chain per lag, src/lpc.rs:533-548; one f32 chain per estimator partition,
   // src/arrayutils.rs:435-506), the `simd-nightly` build (src/lpc.rs:439-531; LPC orders up to 15 -- above,
-  // the canonical order is used), or neither (Canonical: the kernels' own order, fastest; a valid encoding of the
-  // same configuration, within the spread between the two CPU builds).
+  // the unflagged order is used), or the library's unflagged mode (Canonical: since ABI 6 the stable build's quantised LPC
+  // parameters on every shape -- certified on blocks of 4096 / 4608, the stable build's own chains elsewhere -- with the
+  // fixed-LPC selector's sums exact integers rather than that build's f32 chains, which only matters above 16 bits).
   enum class SumOrder { Canonical, Stable, SimdNightly };
   void set_sum_order(SumOrder o) { sum_order_ = o; }
   SumOrder sum_order() const { return sum_order_; }

@@ -369,11 +369,11 @@ impl Drop for Gpu {
 /// Which of the crate's builds the floating-point sums reproduce bit for bit (the C++ mirror's
 /// `HipContext::SumOrder`).  `CrateBuild` -- the default of `Gpu::new` -- asks for the bytes of the build this file is
 /// compiled into (stable: `FLAG_REFERENCE_SUM_ORDER`; `simd-nightly`: `FLAG_NIGHTLY_SUM_ORDER` up to order 15).
-/// `Canonical` is the library's unflagged mode: the stable build's integers on the shapes whose order it certifies
-/// (blocks of 4096 / 4608 samples at orders up to 12, big blocks from order 16), the kernels' own
-/// order -- a valid encoding of the same configuration -- elsewhere (e.g. a stream's ragged last block); chosen with
-/// `Gpu::with_sum_order`.  Blocks of 4096 / 8192 / 16384 samples at orders from 16 sum in the stable build's order
-/// either way.
+/// `Canonical` is the library's unflagged mode: since ABI 6 the stable build's quantised LPC parameters -- and every integer
+/// that follows from them -- on EVERY shape (blocks of 4096 / 4608 samples at orders up to 12 by an order certificate, every
+/// other shape by the stable build's own chains in a pass in front of the kernels).  What it does not
+/// pin is the fixed-LPC selector's per-partition sums on material of more than 16 bits (exact integer sums there), which
+/// `CrateBuild` does; chosen with `Gpu::with_sum_order`.
 #[derive(Clone, Copy, PartialEq, Eq, Debug)]
 pub enum SumOrder {
     Canonical,

@@ -251,6 +251,37 @@ def test_frames_with_candidates_beyond_the_exact_sums(handle, n):
     _decode_frames(x, got, gres)
 
 
+def test_more_marks_than_the_list_holds(handle):
+    """The clean-up launches visit the first 1024 marks through the marks' list (QlpcKernelArgs::marked_list) and fall back
+    to walking all records / frames when a launch marked more: 1300 marked stereo frames of 576 samples (frame_decide_kernel's
+    grid-stride walk, the candidate clean-ups' scans), the same rows as 2600 marked candidates and as 866 three-channel
+    frames (channel_decide_kernel) -- every result byte-identical to the generic path's, which the other tests hold to
+    the oracle, and the first frames checked against the oracle directly."""
+    from test_gpu_parity import _check_frames_against_oracle
+    n, bps, nf = 576, 24, 1300
+    rng = np.random.default_rng(7)
+    base = (rng.integers(0, 2, (8, n)) * 2 - 1).astype(np.int32) * (2 ** 23 - 1)
+    x = np.ascontiguousarray(np.stack([base[rng.integers(0, 8, nf)], base[rng.integers(0, 8, nf)]], axis=1))
+    x[::97] = _capi.sigen_frames(len(x[::97]), 2, n, bps, 120.0, 0.4, 0.1, seed=3)  # a few ordinary frames in between
+    mk = lambda flags: _capi.make_frame_config(_capi.make_config(lpc_order=8, flags=flags), use_fixed=True)
+    got, gres = handle.encode_stereo_frames(x, bps, mk(0))
+    gen, genres = handle.encode_stereo_frames(x, bps, mk(_capi.FLAG_GENERIC_KERNEL))
+    assert got.tobytes() == gen.tobytes() and np.array_equal(gres, genres)
+    ocfg = orc.make_frame_config(orc.make_config(lpc_order=8, acorr=orc.ACORR_CANONICAL),
+                                 fixed=orc.make_fixed_config(sum_mode=orc.SUMABS_CANONICAL))
+    want, wres = orc.encode_stereo_frames_cfg(x[:40], bps, ocfg)
+    _check_frames_against_oracle(x[:40], bps, got[:40], gres[:40], want, wres)
+    q0, q1 = _capi.make_config(lpc_order=8), _capi.make_config(lpc_order=8, flags=_capi.FLAG_GENERIC_KERNEL)
+    flat = x.reshape(nf * 2, n)
+    gp, gr, _, _ = handle.qlpc_batch(flat, bps, q0)
+    pp, pr, _, _ = handle.qlpc_batch(flat, bps, q1)
+    assert gp.tobytes() == pp.tobytes() and np.array_equal(gr, pr)
+    xc = flat[: (nf * 2 // 3) * 3].reshape(-1, 3, n)
+    cr, crr = handle.encode_frames(xc, bps, mk(0))
+    cg, cgr = handle.encode_frames(xc, bps, mk(_capi.FLAG_GENERIC_KERNEL))
+    assert cr.tobytes() == cg.tobytes() and np.array_equal(crr, cgr)
+
+
 # ------------------------------------------------------------------ Independent(n) frames (variant 3) ----
 @pytest.mark.parametrize("n", SIZES)
 @pytest.mark.parametrize("channels,bps,order,use_fixed,kw", [

@@ -180,7 +180,7 @@ def profiled_phases(args):
             p = json.load(f)
     except Exception:
         return None
-    if not same_cfg or p.get("kernel_source_sha") != kernel_source_sha():
+    if not same_cfg or p.get("kernel_source_sha") != kernel_source_sha() or not p.get("phases"):
         return None
     return p
 

@@ -35,6 +35,11 @@ floors = [
      "128 sign-magnitude + 120 carry-save + 33 plane adds + 21 plane sums + 40 table entries (4 parameters) + 98 merge "
      "levels + 70 level totals + 60 decision / records + 40 store addressing (two of four waves)"),
 ]
+missing = [k for k in order if k not in cum]
+if missing:
+    # (round 6: a collection ran without ab/libflacenc_exit*.so and wrote a table without phases, which bench.py attached)
+    sys.exit("make_headline_phases.py: no counters for %s in %s -- run tools/build_exit_variants.sh before the gpurun call" % (
+        ", ".join(missing), sys.argv[1]))
 phases, prev = [], 0.0
 for key, name, (floor, what) in zip(order, names, floors):
     if key not in cum:
